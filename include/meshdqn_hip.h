@@ -1,0 +1,155 @@
+/*
+ * meshdqn_hip.h - C ABI of the MI355X (gfx950) hot path of MeshDQN.
+ *
+ * Drop-in boundary for the data-parallel hot path of BaratiLab/MeshDQN
+ * (Env2DAirfoil rollout = Taylor-Hood IPCS Navier-Stokes solve + graph
+ * Q-network forward).  The reference has no native code and no FFI: all of its
+ * arithmetic sits behind Python calls into DOLFIN / PyG.  Each entry point
+ * below names the reference call site (file:line in BaratiLab/MeshDQN) whose
+ * arithmetic it replaces; the Python classes in `meshdqn_amd/` that keep the
+ * reference's `FlowSolver` / `Env2DAirfoil` / `NodeRemovalNet` surfaces bind
+ * these symbols through ctypes.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only; no torch types.
+ *   - every call returns int: 0 = ok, <0 = error (text via mdq_last_error()).
+ *   - all array arguments marked "device" are DEVICE pointers borrowed from
+ *     the caller (torch tensors); the library never frees them and performs no
+ *     hidden allocation; work is enqueued on the given hipStream_t (passed as
+ *     void*; NULL = default stream) and the call returns without a device sync.
+ *   - "host" arguments are ordinary host pointers.
+ *   - not re-entrant per batch descriptor; independent descriptors may be used
+ *     from independent streams / processes.
+ *
+ * Batch layout: B environments, every per-environment array padded to common
+ * capacities (NV vertices, NT triangles, NE edges, N2 = NV+NE scalar P2 dofs,
+ * NNZ2 / NNZ1 non-zeros of the P2 / P1 CSR patterns); actual sizes in the
+ * per-environment count arrays.  Velocity vectors are component-interleaved:
+ * u[dof][c], dof in [0,N2), c in {x,y}.
+ */
+#ifndef MESHDQN_HIP_H
+#define MESHDQN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDQ_ABI_VERSION 1
+
+/* ---- error handling ----------------------------------------------------- */
+int mdq_abi_version(void);
+const char* mdq_last_error(void);
+
+/* ---- IPCS batch descriptor ---------------------------------------------- */
+typedef struct mdq_ipcs_desc {
+  /* sizes */
+  int32_t B;            /* environments in the batch                         */
+  int32_t NV, NT, NE;   /* per-environment capacities                        */
+  int32_t N2;           /* NV + NE (scalar P2 dof capacity)                  */
+  int32_t NNZ2, NNZ1;   /* CSR capacities of the P2 / P1 patterns            */
+  int32_t NAF;          /* capacity of the airfoil (tag 1) facet list        */
+  /* physics: flow_params / solver_params of FlowSolver (flow_solver.py:49-52,95) */
+  double mu, rho, dt;
+  /* Krylov controls (the reference uses MUMPS LU, flow_solver.py:150-151;
+     these bound the error of the iterative replacement) */
+  double rtol;          /* relative residual tolerance (preconditioned norm) */
+  int32_t maxit_u, maxit_p, maxit_m;
+  int32_t _pad0;
+  /* per-environment counts, device int32[B] */
+  const int32_t* nv;
+  const int32_t* nt;
+  const int32_t* ne;
+  const int32_t* naf;
+  /* mesh, device */
+  const double* coords;        /* [B][NV][2]  (smoothed) vertex coordinates   */
+  const int32_t* cell_dofs;    /* [B][6][NT]  P2 dofs per cell: 3 vertices (ascending), 3 edge dofs NVenv+edge */
+  const int8_t* cell_outflow;  /* [B][NT]     local edge (0..2) lying on the outflow boundary, or -1 */
+  /* CSR patterns + deterministic gather maps, device */
+  const int32_t* rowptr2;      /* [B][N2+1]   */
+  const int32_t* colidx2;      /* [B][NNZ2]   */
+  const int32_t* asm2_ptr;     /* [B][NNZ2+1] non-zero <- element slots       */
+  const int32_t* asm2_src;     /* [B][36*NT]  slot = cell*36 + i*6 + j        */
+  const int32_t* rowptr1;      /* [B][NV+1]   */
+  const int32_t* colidx1;      /* [B][NNZ1]   */
+  const int32_t* asm1_ptr;     /* [B][NNZ1+1] */
+  const int32_t* asm1_src;     /* [B][9*NT]   slot = cell*9 + i*3 + j         */
+  const int32_t* g2_ptr;       /* [B][N2+1]   P2 dof <- element slots         */
+  const int32_t* g2_src;       /* [B][6*NT]   slot = cell*6 + i               */
+  const int32_t* g1_ptr;       /* [B][NV+1]   */
+  const int32_t* g1_src;       /* [B][3*NT]   slot = cell*3 + i               */
+  /* Dirichlet data (flow_solver.py:123-132), device */
+  const uint8_t* bcu_flag;     /* [B][N2]  1 = velocity dof constrained (both components) */
+  const double* bcu_gx;        /* [B][N2]  x-velocity value (y value is 0)    */
+  const uint8_t* bcp_flag;     /* [B][NV]  1 = pressure dof constrained to 0  */
+  /* airfoil facets for the probes (probes.py:23-50), device */
+  const int32_t* af_facets;    /* [B][NAF][2] (cell, local edge)              */
+  /* assembled operators, device, written by mdq_ipcs_assemble */
+  double* geom;                /* [B][5][NT]  Jinv00,Jinv01,Jinv10,Jinv11,|det| */
+  double* A1;                  /* [B][NNZ2][4] row-scaled velocity blocks xx,xy,yx,yy */
+  double* Ms;                  /* [B][NNZ2]   symmetrically scaled P2 mass (with BCs) */
+  double* K1s;                 /* [B][NNZ1]   symmetrically scaled P1 stiffness (with BCs) */
+  double* lift1;               /* [B][N2][2]  A1_full[:,bc] g                 */
+  double* lift3;               /* [B][N2][2]  M_full[:,bc] g                  */
+  double* idiag1;              /* [B][N2][2]  1/diag(A1)                      */
+  double* sdiagM;              /* [B][N2]     sqrt(diag(M_bc))                */
+  double* sdiagK;              /* [B][NV]     sqrt(diag(K1_bc))               */
+  /* state, device */
+  double* u_n;                 /* [B][N2][2]  */
+  double* p_n;                 /* [B][NV]     */
+  /* workspace, device: at least mdq_ipcs_workspace_doubles() doubles */
+  double* work;
+  int64_t work_doubles;
+} mdq_ipcs_desc;
+
+/* doubles of workspace needed for a descriptor with the given capacities */
+int64_t mdq_ipcs_workspace_doubles(int32_t B, int32_t NV, int32_t NT, int32_t NE);
+
+/*
+ * Assemble the three IPCS operators for every environment of the batch.
+ * Replaces `SystemAssembler(a1,L1,bcu).assemble(A)` x3 and the UFL forms
+ * (flow_solver.py:98-144; same for remesh in DEPLOY mode, :268-316):
+ * per-triangle geometry + P2/P1 element matrices -> CSR values by a
+ * deterministic gather, symmetric Dirichlet elimination, Jacobi scaling.
+ */
+int mdq_ipcs_assemble(const mdq_ipcs_desc* d, void* stream);
+
+/*
+ * Advance every environment by `nsteps` IPCS time steps.
+ * Replaces `FlowSolver.evolve()` (flow_solver.py:362-396): per step three
+ * right-hand-side assemblies, three linear solves (BiCGStab / CG / CG in place
+ * of the MUMPS back-substitutions), u_n/p_n update and the drag / lift probes
+ * (probes.py:23-50).
+ *   drag, lift : device double[B][nsteps]   (accumulated_drag / accumulated_lift)
+ *   iters      : device int32[B][3] or NULL; Krylov iterations of the three
+ *                solves are ADDED to it (velocity, pressure, correction)
+ */
+int mdq_ipcs_evolve(const mdq_ipcs_desc* d, int32_t nsteps, double* drag, double* lift,
+                    int32_t* iters, void* stream);
+
+/*
+ * Drag and lift of given fields on every environment's current mesh.
+ * Replaces `DragProbe.sample(u,p)` / `LiftProbe.sample(u,p)` (probes.py:23-50)
+ * as used by `Env2DAirfoil.calculate_reward` (Env2DAirfoil.py:390-394).
+ *   u : device double[B][nfields][N2][2], p : device double[B][nfields][NV]
+ *   drag, lift : device double[B][nfields]
+ */
+int mdq_probe_forces(const mdq_ipcs_desc* d, int32_t nfields, const double* u, const double* p,
+                     double* drag, double* lift, void* stream);
+
+/* ---- host-side mesh smoothing (DOLFIN Mesh.smooth, flow_solver.py:65-67,236-237) ---- */
+/*
+ * Gauss-Seidel centroid smoothing of interior vertices in index order, step
+ * limited to half the smallest altitude of the vertex star.  Host arrays.
+ *   coords [nv][2] in/out; nbr_ptr[nv+1], nbr[]: vertex -> neighbour vertices;
+ *   vc_ptr[nv+1], vc[]: vertex -> cell*3+local; cells[nt][3]; on_boundary[nv].
+ */
+int mdq_smooth_host(double* coords, int32_t nv, const int32_t* cells, int32_t nt,
+                    const int64_t* nbr_ptr, const int64_t* nbr, const int64_t* vc_ptr,
+                    const int64_t* vc, const uint8_t* on_boundary, int32_t iterations);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MESHDQN_HIP_H */

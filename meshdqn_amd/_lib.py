@@ -1,0 +1,98 @@
+"""ctypes binding of `libmeshdqn_hip.so` (the C ABI declared in include/meshdqn_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or a call
+fails, a `MeshDQNHipError` is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmeshdqn_hip.so")
+
+ABI_VERSION = 1
+
+
+class MeshDQNHipError(RuntimeError):
+    pass
+
+
+class IpcsDesc(C.Structure):
+    """Mirror of `mdq_ipcs_desc` (include/meshdqn_hip.h) - keep field order in sync."""
+    _fields_ = [
+        ("B", C.c_int32), ("NV", C.c_int32), ("NT", C.c_int32), ("NE", C.c_int32),
+        ("N2", C.c_int32), ("NNZ2", C.c_int32), ("NNZ1", C.c_int32), ("NAF", C.c_int32),
+        ("mu", C.c_double), ("rho", C.c_double), ("dt", C.c_double),
+        ("rtol", C.c_double),
+        ("maxit_u", C.c_int32), ("maxit_p", C.c_int32), ("maxit_m", C.c_int32), ("_pad0", C.c_int32),
+        ("nv", C.c_void_p), ("nt", C.c_void_p), ("ne", C.c_void_p), ("naf", C.c_void_p),
+        ("coords", C.c_void_p), ("cell_dofs", C.c_void_p), ("cell_outflow", C.c_void_p),
+        ("rowptr2", C.c_void_p), ("colidx2", C.c_void_p), ("asm2_ptr", C.c_void_p), ("asm2_src", C.c_void_p),
+        ("rowptr1", C.c_void_p), ("colidx1", C.c_void_p), ("asm1_ptr", C.c_void_p), ("asm1_src", C.c_void_p),
+        ("g2_ptr", C.c_void_p), ("g2_src", C.c_void_p), ("g1_ptr", C.c_void_p), ("g1_src", C.c_void_p),
+        ("bcu_flag", C.c_void_p), ("bcu_gx", C.c_void_p), ("bcp_flag", C.c_void_p),
+        ("af_facets", C.c_void_p),
+        ("geom", C.c_void_p), ("A1", C.c_void_p), ("Ms", C.c_void_p), ("K1s", C.c_void_p),
+        ("lift1", C.c_void_p), ("lift3", C.c_void_p), ("idiag1", C.c_void_p),
+        ("sdiagM", C.c_void_p), ("sdiagK", C.c_void_p),
+        ("u_n", C.c_void_p), ("p_n", C.c_void_p),
+        ("work", C.c_void_p), ("work_doubles", C.c_int64),
+    ]
+
+
+# every symbol include/meshdqn_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "mdq_abi_version": (C.c_int, []),
+    "mdq_last_error": (C.c_char_p, []),
+    "mdq_ipcs_workspace_doubles": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "mdq_ipcs_assemble": (C.c_int, [C.POINTER(IpcsDesc), C.c_void_p]),
+    "mdq_ipcs_evolve": (C.c_int, [C.POINTER(IpcsDesc), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mdq_probe_forces": (C.c_int, [C.POINTER(IpcsDesc), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
+    "mdq_smooth_host": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (building nothing: see meshdqn_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MeshDQNHipError(
+            f"{LIB_PATH} is missing - build it with `python -m meshdqn_amd.build` "
+            "(the MI355X path has no CPU fallback)")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as exc:  # pragma: no cover
+        raise MeshDQNHipError(f"cannot load {LIB_PATH}: {exc}") from exc
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise MeshDQNHipError(f"{LIB_PATH} does not export {name}") from exc
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.mdq_abi_version()
+    if v != ABI_VERSION:
+        raise MeshDQNHipError(f"ABI version mismatch: library {v}, python {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().mdq_last_error()
+        raise MeshDQNHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def stream_ptr(stream=None):
+    """hipStream_t of a torch stream (or of torch's current stream)."""
+    import torch
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    return C.c_void_p(stream.cuda_stream)

@@ -1,0 +1,1157 @@
+// IPCS Navier-Stokes hot path for gfx950: assembly, time stepping, probes.
+//
+// One 1024-thread workgroup (16 wave64) owns one environment for the whole
+// launch: its operators, vectors and element scratch stay in that CU's L2 slice /
+// LDS, every synchronisation is a workgroup barrier, every reduction a fixed
+// tree (bitwise reproducible), and `nsteps` time steps run inside ONE launch.
+//
+// Reference semantics restated here (BaratiLab/MeshDQN):
+//   flow_solver.py:98-120   UFL forms F1 / a2,L2 / a3,L3
+//   flow_solver.py:123-144  Dirichlet BCs + SystemAssembler (symmetric elimination)
+//   flow_solver.py:362-396  evolve()
+//   probes.py:23-50         drag / lift surface integrals
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "../../include/meshdqn_hip.h"
+#include "mdq_device.h"
+
+namespace mdq {
+
+__constant__ RefTab c_tab;
+
+// ------------------------------------------------------------------ per-environment views
+
+__host__ __device__ inline int64_t work_per_env(int NV, int NT, int NE) {
+  const int64_t N2 = (int64_t)NV + NE;
+  // escr 12*NT | 6 velocity vectors (double2[N2]) | p_new[NV] | 8 spare
+  const int64_t n = 12 * (int64_t)NT + 12 * N2 + NV + 8;
+  return (n + 31) & ~(int64_t)31;  // keep every environment's slab 256-byte aligned
+}
+
+struct EnvView {
+  int nv, nt, ne, n2, nnz2, nnz1, naf;
+  int NT;  // capacity (SoA stride of cell_dofs / geom)
+  const double* coords;
+  const int32_t* cell_dofs;  // [6][NT]
+  const int8_t* cell_outflow;
+  const int32_t *rowptr2, *colidx2, *asm2_ptr, *asm2_src;
+  const int32_t *rowptr1, *colidx1, *asm1_ptr, *asm1_src;
+  const int32_t *g2_ptr, *g2_src, *g1_ptr, *g1_src;
+  const uint8_t* bcu_flag;
+  const double* bcu_gx;
+  const uint8_t* bcp_flag;
+  const int32_t* af_facets;
+  double* geom;  // [5][NT]
+  double* A1;    // [nnz2][4]
+  double* Ms;
+  double* K1s;
+  double2* lift1;
+  double2* lift3;
+  double2* idiag1;
+  double* sdiagM;
+  double* sdiagK;
+  double2* u_n;
+  double* p_n;
+  double* work;
+};
+
+__device__ __forceinline__ EnvView env_view(const mdq_ipcs_desc& d, int b) {
+  EnvView v;
+  v.nv = d.nv[b];
+  v.nt = d.nt[b];
+  v.ne = d.ne[b];
+  v.n2 = v.nv + v.ne;
+  v.naf = d.naf[b];
+  v.NT = d.NT;
+  const int64_t B = b;
+  v.coords = d.coords + B * d.NV * 2;
+  v.cell_dofs = d.cell_dofs + B * 6 * d.NT;
+  v.cell_outflow = d.cell_outflow + B * d.NT;
+  v.rowptr2 = d.rowptr2 + B * (d.N2 + 1);
+  v.colidx2 = d.colidx2 + B * d.NNZ2;
+  v.asm2_ptr = d.asm2_ptr + B * (d.NNZ2 + 1);
+  v.asm2_src = d.asm2_src + B * 36 * d.NT;
+  v.rowptr1 = d.rowptr1 + B * (d.NV + 1);
+  v.colidx1 = d.colidx1 + B * d.NNZ1;
+  v.asm1_ptr = d.asm1_ptr + B * (d.NNZ1 + 1);
+  v.asm1_src = d.asm1_src + B * 9 * d.NT;
+  v.g2_ptr = d.g2_ptr + B * (d.N2 + 1);
+  v.g2_src = d.g2_src + B * 6 * d.NT;
+  v.g1_ptr = d.g1_ptr + B * (d.NV + 1);
+  v.g1_src = d.g1_src + B * 3 * d.NT;
+  v.bcu_flag = d.bcu_flag + B * d.N2;
+  v.bcu_gx = d.bcu_gx + B * d.N2;
+  v.bcp_flag = d.bcp_flag + B * d.NV;
+  v.af_facets = d.af_facets + B * d.NAF * 2;
+  v.geom = d.geom + B * 5 * d.NT;
+  v.A1 = d.A1 + B * d.NNZ2 * 4;
+  v.Ms = d.Ms + B * d.NNZ2;
+  v.K1s = d.K1s + B * d.NNZ1;
+  v.lift1 = reinterpret_cast<double2*>(d.lift1) + B * d.N2;
+  v.lift3 = reinterpret_cast<double2*>(d.lift3) + B * d.N2;
+  v.idiag1 = reinterpret_cast<double2*>(d.idiag1) + B * d.N2;
+  v.sdiagM = d.sdiagM + B * d.N2;
+  v.sdiagK = d.sdiagK + B * d.NV;
+  v.u_n = reinterpret_cast<double2*>(d.u_n) + B * d.N2;
+  v.p_n = d.p_n + B * d.NV;
+  v.work = d.work + B * work_per_env(d.NV, d.NT, d.NE);
+  v.nnz2 = v.rowptr2[v.n2];
+  v.nnz1 = v.rowptr1[v.nv];
+  return v;
+}
+
+struct Geo {
+  double j00, j01, j10, j11, det;
+};
+
+__device__ __forceinline__ Geo load_geo(const EnvView& v, int e) {
+  Geo g;
+  g.j00 = v.geom[0 * v.NT + e];
+  g.j01 = v.geom[1 * v.NT + e];
+  g.j10 = v.geom[2 * v.NT + e];
+  g.j11 = v.geom[3 * v.NT + e];
+  g.det = v.geom[4 * v.NT + e];
+  return g;
+}
+
+__device__ __forceinline__ void load_cell_coords(const EnvView& v, int e, double (&X)[3][2]) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int vid = v.cell_dofs[k * v.NT + e];
+    X[k][0] = v.coords[2 * vid];
+    X[k][1] = v.coords[2 * vid + 1];
+  }
+}
+
+// single basis function / gradient at a reference point without register arrays
+__device__ __forceinline__ double p2_phi_one(int i, double l0, double l1, double l2) {
+  if (i < 3) {
+    const double l = sel3(i, l0, l1, l2);
+    return l * (2.0 * l - 1.0);
+  }
+  const int k = i - 3;
+  return 4.0 * sel3(k, l1, l0, l0) * sel3(k, l2, l2, l1);
+}
+
+__device__ __forceinline__ void p2_dphi_one(int j, double l0, double l1, double l2, double& dx, double& dy) {
+  // reference gradients of the barycentric coordinates
+  if (j < 3) {
+    const double f = 4.0 * sel3(j, l0, l1, l2) - 1.0;
+    dx = f * sel3(j, -1.0, 1.0, 0.0);
+    dy = f * sel3(j, -1.0, 0.0, 1.0);
+    return;
+  }
+  const int k = j - 3;
+  const double la = sel3(k, l1, l0, l0), lb = sel3(k, l2, l2, l1);
+  const double dax = sel3(k, 1.0, -1.0, -1.0), day = sel3(k, 0.0, -1.0, -1.0);
+  const double dbx = sel3(k, 0.0, 0.0, 1.0), dby = sel3(k, 1.0, 1.0, 0.0);
+  dx = 4.0 * (la * dbx + lb * dax);
+  dy = 4.0 * (la * dby + lb * day);
+}
+
+// ================================================================== assembly
+
+// B^{cd}_e[i][j] = int_{outflow facet k of cell e} phi_i (d_c phi_j) n_d ds
+// (`- dot(mu*nabla_grad(U)*n, v)*ds`, flow_solver.py:109), 2-point Gauss (degree 3 integrand).
+__device__ inline void outflow_entry(const EnvView& v, int e, int k, int i, int j, const Geo& g, double (&Bcd)[2][2]) {
+  double X[3][2];
+  load_cell_coords(v, e, X);
+  const Facet f = facet_geometry(X, k);
+  Bcd[0][0] = Bcd[0][1] = Bcd[1][0] = Bcd[1][1] = 0.0;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const double s = c_tab.gx[q], w = c_tab.gw[q] * f.len;
+    const double xi = f.ra[0] + s * (f.rb[0] - f.ra[0]);
+    const double eta = f.ra[1] + s * (f.rb[1] - f.ra[1]);
+    const double l0 = 1.0 - xi - eta;
+    const double phi = p2_phi_one(i, l0, xi, eta);
+    double dx, dy;
+    p2_dphi_one(j, l0, xi, eta, dx, dy);
+    const double gxp = g.j00 * dx + g.j10 * dy;  // physical d/dx phi_j
+    const double gyp = g.j01 * dx + g.j11 * dy;
+    Bcd[0][0] += w * phi * gxp * f.nx;
+    Bcd[0][1] += w * phi * gxp * f.ny;
+    Bcd[1][0] += w * phi * gyp * f.nx;
+    Bcd[1][1] += w * phi * gyp * f.ny;
+  }
+}
+
+__global__ __launch_bounds__(WG) void assemble_kernel(mdq_ipcs_desc d) {
+  const int b = blockIdx.x;
+  const EnvView v = env_view(d, b);
+  const int tid = threadIdx.x;
+  const double a = d.rho / d.dt, mu = d.mu;
+
+  // ---- phase 0: affine geometry per triangle
+  for (int e = tid; e < v.nt; e += WG) {
+    double X[3][2];
+    load_cell_coords(v, e, X);
+    const double J00 = X[1][0] - X[0][0], J01 = X[2][0] - X[0][0];
+    const double J10 = X[1][1] - X[0][1], J11 = X[2][1] - X[0][1];
+    const double det = J00 * J11 - J01 * J10;
+    v.geom[0 * v.NT + e] = J11 / det;
+    v.geom[1 * v.NT + e] = -J01 / det;
+    v.geom[2 * v.NT + e] = -J10 / det;
+    v.geom[3 * v.NT + e] = J00 / det;
+    v.geom[4 * v.NT + e] = fabs(det);
+  }
+  __syncthreads();
+
+  // ---- phase 1: full (pre-BC) operator values, one thread per non-zero
+  for (int k = tid; k < v.nnz2; k += WG) {
+    double m = 0.0, kxx = 0.0, kxy = 0.0, kyx = 0.0, kyy = 0.0;
+    double bxx = 0.0, bxy = 0.0, byx = 0.0, byy = 0.0;
+    const int s0 = v.asm2_ptr[k], s1 = v.asm2_ptr[k + 1];
+    for (int s = s0; s < s1; ++s) {
+      const int slot = v.asm2_src[s];
+      const int e = slot / 36, ij = slot - e * 36, i = ij / 6, j = ij - i * 6;
+      const Geo g = load_geo(v, e);
+      m += g.det * c_tab.Mhat[i][j];
+      // K^{ab}_ij = det * sum_{cd} Jinv[c][a] Jinv[d][b] Ghat[c][d][i][j]
+      const double g00 = c_tab.Ghat[0][0][i][j], g01 = c_tab.Ghat[0][1][i][j];
+      const double g10 = c_tab.Ghat[1][0][i][j], g11 = c_tab.Ghat[1][1][i][j];
+      // Jinv[c][a]: c = reference index (row), a = physical index (col)
+      const double Ja[2][2] = {{g.j00, g.j01}, {g.j10, g.j11}};
+      kxx += g.det * (Ja[0][0] * (Ja[0][0] * g00 + Ja[1][0] * g01) + Ja[1][0] * (Ja[0][0] * g10 + Ja[1][0] * g11));
+      kxy += g.det * (Ja[0][0] * (Ja[0][1] * g00 + Ja[1][1] * g01) + Ja[1][0] * (Ja[0][1] * g10 + Ja[1][1] * g11));
+      kyx += g.det * (Ja[0][1] * (Ja[0][0] * g00 + Ja[1][0] * g01) + Ja[1][1] * (Ja[0][0] * g10 + Ja[1][0] * g11));
+      kyy += g.det * (Ja[0][1] * (Ja[0][1] * g00 + Ja[1][1] * g01) + Ja[1][1] * (Ja[0][1] * g10 + Ja[1][1] * g11));
+      const int ko = v.cell_outflow[e];
+      if (ko >= 0) {
+        double Bcd[2][2];
+        outflow_entry(v, e, ko, i, j, g, Bcd);
+        bxx += Bcd[0][0];
+        bxy += Bcd[0][1];
+        byx += Bcd[1][0];
+        byy += Bcd[1][1];
+      }
+    }
+    const double L = kxx + kyy;
+    // block(c,d) = a M delta_cd + mu/2 (delta_cd L + K^{dc}) - mu/2 B^{cd}
+    double4 blk;
+    blk.x = a * m + 0.5 * mu * (L + kxx) - 0.5 * mu * bxx;
+    blk.y = 0.5 * mu * kyx - 0.5 * mu * bxy;
+    blk.z = 0.5 * mu * kxy - 0.5 * mu * byx;
+    blk.w = a * m + 0.5 * mu * (L + kyy) - 0.5 * mu * byy;
+    reinterpret_cast<double4*>(v.A1)[k] = blk;
+    v.Ms[k] = m;
+  }
+  for (int k = tid; k < v.nnz1; k += WG) {
+    double kk = 0.0;
+    const int s0 = v.asm1_ptr[k], s1 = v.asm1_ptr[k + 1];
+    for (int s = s0; s < s1; ++s) {
+      const int slot = v.asm1_src[s];
+      const int e = slot / 9, ij = slot - e * 9, i = ij / 3, j = ij - i * 3;
+      const Geo g = load_geo(v, e);
+      // grad lambda_i = Jinv^T dl_i, dl = (-1,-1),(1,0),(0,1)
+      const double dix = sel3(i, -g.j00 - g.j10, g.j00, g.j10), diy = sel3(i, -g.j01 - g.j11, g.j01, g.j11);
+      const double djx = sel3(j, -g.j00 - g.j10, g.j00, g.j10), djy = sel3(j, -g.j01 - g.j11, g.j01, g.j11);
+      kk += 0.5 * g.det * (dix * djx + diy * djy);
+    }
+    v.K1s[k] = kk;
+  }
+  __syncthreads();
+
+  // ---- phase 2: Dirichlet lifting vectors and diagonals, one thread per row
+  for (int r = tid; r < v.n2; r += WG) {
+    double l1x = 0.0, l1y = 0.0, l3x = 0.0, dx = 1.0, dy = 1.0, dm = 1.0;
+    const bool fr = v.bcu_flag[r] != 0;
+    for (int k = v.rowptr2[r]; k < v.rowptr2[r + 1]; ++k) {
+      const int c = v.colidx2[k];
+      const double4 blk = reinterpret_cast<const double4*>(v.A1)[k];
+      if (v.bcu_flag[c]) {
+        const double gx = v.bcu_gx[c];  // gy = 0 for every BC of the reference
+        l1x += blk.x * gx;
+        l1y += blk.z * gx;
+        l3x += v.Ms[k] * gx;
+      }
+      if (c == r && !fr) {
+        dx = blk.x;
+        dy = blk.w;
+        dm = v.Ms[k];
+      }
+    }
+    v.lift1[r] = make_double2(l1x, l1y);
+    v.lift3[r] = make_double2(l3x, 0.0);
+    v.idiag1[r] = make_double2(1.0 / dx, 1.0 / dy);
+    v.sdiagM[r] = sqrt(dm);
+  }
+  for (int r = tid; r < v.nv; r += WG) {
+    double dk = 1.0;
+    if (!v.bcp_flag[r]) {
+      for (int k = v.rowptr1[r]; k < v.rowptr1[r + 1]; ++k)
+        if (v.colidx1[k] == r) dk = v.K1s[k];
+    }
+    v.sdiagK[r] = sqrt(dk);
+  }
+  __syncthreads();
+
+  // ---- phase 3: symmetric elimination + Jacobi scaling
+  for (int r = tid; r < v.n2; r += WG) {
+    const bool fr = v.bcu_flag[r] != 0;
+    const double2 id = v.idiag1[r];
+    const double sr = v.sdiagM[r];
+    for (int k = v.rowptr2[r]; k < v.rowptr2[r + 1]; ++k) {
+      const int c = v.colidx2[k];
+      const bool fc = v.bcu_flag[c] != 0;
+      double4 blk = reinterpret_cast<const double4*>(v.A1)[k];
+      double m = v.Ms[k];
+      if (fr || fc) {
+        const double one = (c == r) ? 1.0 : 0.0;
+        blk = make_double4(one, 0.0, 0.0, one);
+        m = one;
+      } else {
+        blk.x *= id.x;
+        blk.y *= id.x;
+        blk.z *= id.y;
+        blk.w *= id.y;
+        m = m / (sr * v.sdiagM[c]);
+      }
+      reinterpret_cast<double4*>(v.A1)[k] = blk;
+      v.Ms[k] = m;
+    }
+  }
+  for (int r = tid; r < v.nv; r += WG) {
+    const bool fr = v.bcp_flag[r] != 0;
+    const double sr = v.sdiagK[r];
+    for (int k = v.rowptr1[r]; k < v.rowptr1[r + 1]; ++k) {
+      const int c = v.colidx1[k];
+      const bool fc = v.bcp_flag[c] != 0;
+      double kk = v.K1s[k];
+      if (fr || fc)
+        kk = (c == r) ? 1.0 : 0.0;
+      else
+        kk = kk / (sr * v.sdiagK[c]);
+      v.K1s[k] = kk;
+    }
+  }
+}
+
+// ================================================================== element right-hand sides
+
+struct ElemData {
+  int dof[6];
+  Geo g;
+};
+
+__device__ __forceinline__ ElemData load_elem(const EnvView& v, int e) {
+  ElemData E;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) E.dof[i] = v.cell_dofs[i * v.NT + e];
+  E.g = load_geo(v, e);
+  return E;
+}
+
+// physical gradient of P2 basis i at quadrature point q
+#define MDQ_PHYS_GRAD(q, i, gx_, gy_)                                          \
+  const double gx_ = E.g.j00 * c_tab.qdphi[q][i][0] + E.g.j10 * c_tab.qdphi[q][i][1]; \
+  const double gy_ = E.g.j01 * c_tab.qdphi[q][i][0] + E.g.j11 * c_tab.qdphi[q][i][1];
+
+// step 1 (flow_solver.py:106-112): local vector of L1 = rhs(F1)
+//   r^c_i = int [ (a u_c - rho (u.grad)u_c) phi_i + (-mu eps(u)_{ac} + p delta_ac) d_a phi_i ]
+//           + mu/2 int_{outflow} phi_i n_d d_c u_d ds
+__device__ inline void elem_rhs1(const EnvView& v, const mdq_ipcs_desc& d, const double2* __restrict__ u,
+                                 const double* __restrict__ p, double2* __restrict__ escr) {
+  const double a = d.rho / d.dt, mu = d.mu, rho = d.rho;
+  for (int e = threadIdx.x; e < v.nt; e += WG) {
+    const ElemData E = load_elem(v, e);
+    double2 ue[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ue[i] = u[E.dof[i]];
+    double pe[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pe[i] = p[E.dof[i]];
+    double2 r[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) r[i] = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      double ux = 0, uy = 0, uxx = 0, uxy = 0, uyx = 0, uyy = 0;  // u, d_x ux, d_y ux, d_x uy, d_y uy
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        MDQ_PHYS_GRAD(q, i, gx, gy)
+        const double ph = c_tab.qphi[q][i];
+        ux += ue[i].x * ph;
+        uy += ue[i].y * ph;
+        uxx += ue[i].x * gx;
+        uxy += ue[i].x * gy;
+        uyx += ue[i].y * gx;
+        uyy += ue[i].y * gy;
+      }
+      const double pq = pe[0] * c_tab.qpsi[q][0] + pe[1] * c_tab.qpsi[q][1] + pe[2] * c_tab.qpsi[q][2];
+      const double w = c_tab.qw[q] * E.g.det;
+      const double sx = w * (a * ux - rho * (ux * uxx + uy * uxy));
+      const double sy = w * (a * uy - rho * (ux * uyx + uy * uyy));
+      const double exy = 0.5 * (uxy + uyx);
+      // F_ac = -mu eps_ac + p delta_ac
+      const double Fxx = w * (-mu * uxx + pq), Fyx = w * (-mu * exy);  // c = x: F_xx, F_yx
+      const double Fxy = w * (-mu * exy), Fyy = w * (-mu * uyy + pq);  // c = y: F_xy, F_yy
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        MDQ_PHYS_GRAD(q, i, gx, gy)
+        const double ph = c_tab.qphi[q][i];
+        r[i].x += sx * ph + Fxx * gx + Fyx * gy;
+        r[i].y += sy * ph + Fxy * gx + Fyy * gy;
+      }
+    }
+    const int ko = v.cell_outflow[e];
+    if (ko >= 0) {
+      double X[3][2];
+      load_cell_coords(v, e, X);
+      const Facet f = facet_geometry(X, ko);
+      for (int q = 0; q < 2; ++q) {
+        const double s = c_tab.gx[q], w = 0.5 * mu * c_tab.gw[q] * f.len;
+        const double xi = f.ra[0] + s * (f.rb[0] - f.ra[0]);
+        const double eta = f.ra[1] + s * (f.rb[1] - f.ra[1]);
+        double phi[6], dphi[6][2];
+        p2_eval(xi, eta, phi, dphi);
+        // n_d d_c u_d  for c = x, y
+        double tx = 0.0, ty = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const double gx = E.g.j00 * dphi[j][0] + E.g.j10 * dphi[j][1];
+          const double gy = E.g.j01 * dphi[j][0] + E.g.j11 * dphi[j][1];
+          const double un = ue[j].x * f.nx + ue[j].y * f.ny;
+          tx += gx * un;
+          ty += gy * un;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          r[i].x += w * phi[i] * tx;
+          r[i].y += w * phi[i] * ty;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) escr[e * 6 + i] = r[i];
+  }
+}
+
+// step 2 (flow_solver.py:115-116): r_j = int grad p_n . grad psi_j - (1/dt) div(u*) psi_j
+__device__ inline void elem_rhs2(const EnvView& v, const mdq_ipcs_desc& d, const double2* __restrict__ u,
+                                 const double* __restrict__ p, double* __restrict__ escr) {
+  const double idt = 1.0 / d.dt;
+  for (int e = threadIdx.x; e < v.nt; e += WG) {
+    const ElemData E = load_elem(v, e);
+    double2 ue[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ue[i] = u[E.dof[i]];
+    double pe[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pe[i] = p[E.dof[i]];
+    // P1 gradients (constant per cell)
+    const double glx[3] = {-E.g.j00 - E.g.j10, E.g.j00, E.g.j10};
+    const double gly[3] = {-E.g.j01 - E.g.j11, E.g.j01, E.g.j11};
+    const double gpx = pe[0] * glx[0] + pe[1] * glx[1] + pe[2] * glx[2];
+    const double gpy = pe[0] * gly[0] + pe[1] * gly[1] + pe[2] * gly[2];
+    double r[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r[j] = 0.5 * E.g.det * (gpx * glx[j] + gpy * gly[j]);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      double div = 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        MDQ_PHYS_GRAD(q, i, gx, gy)
+        div += ue[i].x * gx + ue[i].y * gy;
+      }
+      const double w = c_tab.qw[q] * E.g.det * idt * div;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) r[j] -= w * c_tab.qpsi[q][j];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) escr[e * 3 + j] = r[j];
+  }
+}
+
+// step 3 (flow_solver.py:119-120): r^c_i = int (u*_c - dt d_c(p - p_n)) phi_i
+__device__ inline void elem_rhs3(const EnvView& v, const mdq_ipcs_desc& d, const double2* __restrict__ u,
+                                 const double* __restrict__ pnew, const double* __restrict__ pold,
+                                 double2* __restrict__ escr) {
+  for (int e = threadIdx.x; e < v.nt; e += WG) {
+    const ElemData E = load_elem(v, e);
+    double2 ue[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ue[i] = u[E.dof[i]];
+    double dp[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dp[i] = pnew[E.dof[i]] - pold[E.dof[i]];
+    const double glx[3] = {-E.g.j00 - E.g.j10, E.g.j00, E.g.j10};
+    const double gly[3] = {-E.g.j01 - E.g.j11, E.g.j01, E.g.j11};
+    const double gx = d.dt * (dp[0] * glx[0] + dp[1] * glx[1] + dp[2] * glx[2]);
+    const double gy = d.dt * (dp[0] * gly[0] + dp[1] * gly[1] + dp[2] * gly[2]);
+    double2 r[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) r[i] = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      double ux = 0.0, uy = 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        ux += ue[i].x * c_tab.qphi[q][i];
+        uy += ue[i].y * c_tab.qphi[q][i];
+      }
+      const double w = c_tab.qw[q] * E.g.det;
+      const double sx = w * (ux - gx), sy = w * (uy - gy);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        r[i].x += sx * c_tab.qphi[q][i];
+        r[i].y += sy * c_tab.qphi[q][i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) escr[e * 6 + i] = r[i];
+  }
+}
+
+// ================================================================== sparse kernels (workgroup-wide)
+
+// y = A x for the 2x2-block CSR velocity operator; G lanes cooperate on one block row.
+template <int G, class Epi>
+__device__ __forceinline__ void spmv_bcsr2(const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                                           const double* __restrict__ A, const double2* __restrict__ x, int n,
+                                           Epi epi) {
+  const int g = threadIdx.x / G, l = threadIdx.x % G;
+  const double4* __restrict__ A4 = reinterpret_cast<const double4*>(A);
+  for (int base = 0; base < n; base += WG / G) {
+    const int row = base + g;
+    double y0 = 0.0, y1 = 0.0;
+    if (row < n) {
+      const int s = rp[row], e = rp[row + 1];
+      for (int k = s + l; k < e; k += G) {
+        const double4 a = A4[k];
+        const double2 xv = x[ci[k]];
+        y0 += a.x * xv.x + a.y * xv.y;
+        y1 += a.z * xv.x + a.w * xv.y;
+      }
+    }
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) {
+      y0 += __shfl_down(y0, off, G);
+      y1 += __shfl_down(y1, off, G);
+    }
+    if (l == 0 && row < n) epi(row, y0, y1);
+  }
+}
+
+// y = A x, scalar CSR, two right-hand sides interleaved (P2 mass, both velocity components)
+template <int G, class Epi>
+__device__ __forceinline__ void spmv_csr_2rhs(const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                                              const double* __restrict__ A, const double2* __restrict__ x, int n,
+                                              Epi epi) {
+  const int g = threadIdx.x / G, l = threadIdx.x % G;
+  for (int base = 0; base < n; base += WG / G) {
+    const int row = base + g;
+    double y0 = 0.0, y1 = 0.0;
+    if (row < n) {
+      const int s = rp[row], e = rp[row + 1];
+      for (int k = s + l; k < e; k += G) {
+        const double a = A[k];
+        const double2 xv = x[ci[k]];
+        y0 += a * xv.x;
+        y1 += a * xv.y;
+      }
+    }
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) {
+      y0 += __shfl_down(y0, off, G);
+      y1 += __shfl_down(y1, off, G);
+    }
+    if (l == 0 && row < n) epi(row, y0, y1);
+  }
+}
+
+// y = A x, scalar CSR, one right-hand side (P1 pressure operator; arrays may live in LDS)
+template <int G, class Epi>
+__device__ __forceinline__ void spmv_csr(const int32_t* rp, const int32_t* ci, const double* A, const double* x,
+                                         int n, Epi epi) {
+  const int g = threadIdx.x / G, l = threadIdx.x % G;
+  for (int base = 0; base < n; base += WG / G) {
+    const int row = base + g;
+    double y0 = 0.0;
+    if (row < n) {
+      const int s = rp[row], e = rp[row + 1];
+      for (int k = s + l; k < e; k += G) y0 += A[k] * x[ci[k]];
+    }
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) y0 += __shfl_down(y0, off, G);
+    if (l == 0 && row < n) epi(row, y0);
+  }
+}
+
+// ================================================================== Krylov solvers
+
+// BiCGStab on the row-scaled velocity system  (D^-1 A1) x = D^-1 b.
+// On entry r holds D^-1 b and x the initial guess; on exit x holds the solution.
+__device__ inline int bicgstab_velocity(const EnvView& v, double rtol, int maxit, double2* __restrict__ x,
+                                        double2* __restrict__ r, double2* __restrict__ rh, double2* __restrict__ p,
+                                        double2* __restrict__ vv, double2* __restrict__ t, double* red) {
+  const int n = v.n2, tid = threadIdx.x;
+  // r = b - A x ; bb = (b,b) ; rr = (r,r)
+  double acc[2] = {0.0, 0.0};
+  __syncthreads();
+  spmv_bcsr2<16>(v.rowptr2, v.colidx2, v.A1, x, n, [&](int row, double y0, double y1) {
+    const double2 b = r[row];
+    const double2 rr = make_double2(b.x - y0, b.y - y1);
+    r[row] = rr;
+    rh[row] = rr;
+    p[row] = make_double2(0.0, 0.0);
+    vv[row] = make_double2(0.0, 0.0);
+    acc[0] += b.x * b.x + b.y * b.y;
+    acc[1] += rr.x * rr.x + rr.y * rr.y;
+  });
+  block_sum<2>(acc, red);
+  const double bb = acc[0];
+  double rr = acc[1];
+  const double tol2 = rtol * rtol * bb;
+  if (!(rr > tol2) || bb == 0.0) return 0;
+  double rho = rr, rho_old = 1.0, alpha = 1.0, omega = 1.0;  // (rh,r) = (r,r) at start
+  int it = 0;
+  while (it < maxit) {
+    ++it;
+    const double beta = (rho / rho_old) * (alpha / omega);
+    for (int i = tid; i < n; i += WG) {
+      const double2 ri = r[i], pi = p[i], vi = vv[i];
+      p[i] = make_double2(ri.x + beta * (pi.x - omega * vi.x), ri.y + beta * (pi.y - omega * vi.y));
+    }
+    __syncthreads();
+    double a1[1] = {0.0};
+    spmv_bcsr2<16>(v.rowptr2, v.colidx2, v.A1, p, n, [&](int row, double y0, double y1) {
+      vv[row] = make_double2(y0, y1);
+      const double2 h = rh[row];
+      a1[0] += h.x * y0 + h.y * y1;
+    });
+    block_sum<1>(a1, red);
+    if (a1[0] == 0.0) break;  // breakdown
+    alpha = rho / a1[0];
+    double a2[1] = {0.0};
+    for (int i = tid; i < n; i += WG) {
+      const double2 ri = r[i], vi = vv[i];
+      const double2 s = make_double2(ri.x - alpha * vi.x, ri.y - alpha * vi.y);
+      r[i] = s;
+      a2[0] += s.x * s.x + s.y * s.y;
+    }
+    block_sum<1>(a2, red);  // (barriers inside also publish s)
+    if (!(a2[0] > tol2)) {
+      for (int i = tid; i < n; i += WG) {
+        const double2 xi = x[i], pi = p[i];
+        x[i] = make_double2(xi.x + alpha * pi.x, xi.y + alpha * pi.y);
+      }
+      break;
+    }
+    double a3[2] = {0.0, 0.0};
+    spmv_bcsr2<16>(v.rowptr2, v.colidx2, v.A1, r, n, [&](int row, double y0, double y1) {
+      t[row] = make_double2(y0, y1);
+      const double2 s = r[row];
+      a3[0] += y0 * s.x + y1 * s.y;
+      a3[1] += y0 * y0 + y1 * y1;
+    });
+    block_sum<2>(a3, red);
+    if (a3[1] == 0.0) break;
+    omega = a3[0] / a3[1];
+    double a4[2] = {0.0, 0.0};
+    for (int i = tid; i < n; i += WG) {
+      const double2 xi = x[i], pi = p[i], si = r[i], ti = t[i], hi = rh[i];
+      x[i] = make_double2(xi.x + alpha * pi.x + omega * si.x, xi.y + alpha * pi.y + omega * si.y);
+      const double2 rn = make_double2(si.x - omega * ti.x, si.y - omega * ti.y);
+      r[i] = rn;
+      a4[0] += rn.x * rn.x + rn.y * rn.y;
+      a4[1] += hi.x * rn.x + hi.y * rn.y;
+    }
+    block_sum<2>(a4, red);
+    rr = a4[0];
+    if (!(rr > tol2)) break;
+    rho_old = rho;
+    rho = a4[1];
+    if (rho == 0.0 || omega == 0.0) break;
+  }
+  __syncthreads();
+  return it;
+}
+
+// CG on the symmetrically scaled mass system, two right-hand sides at once (x and y components).
+// On entry r holds S^-1 b, x the initial guess S x0; on exit x holds S x.
+__device__ inline int cg_mass(const EnvView& v, double rtol, int maxit, double2* __restrict__ x,
+                              double2* __restrict__ r, double2* __restrict__ p, double2* __restrict__ q, double* red) {
+  const int n = v.n2, tid = threadIdx.x;
+  double acc[2] = {0.0, 0.0};
+  __syncthreads();
+  spmv_csr_2rhs<16>(v.rowptr2, v.colidx2, v.Ms, x, n, [&](int row, double y0, double y1) {
+    const double2 b = r[row];
+    const double2 rr = make_double2(b.x - y0, b.y - y1);
+    r[row] = rr;
+    p[row] = rr;
+    acc[0] += b.x * b.x + b.y * b.y;
+    acc[1] += rr.x * rr.x + rr.y * rr.y;
+  });
+  block_sum<2>(acc, red);
+  const double bb = acc[0];
+  double rr = acc[1];
+  const double tol2 = rtol * rtol * bb;
+  if (!(rr > tol2) || bb == 0.0) return 0;
+  int it = 0;
+  // the two systems share one Krylov recurrence on the stacked vector (block-diagonal operator)
+  while (it < maxit) {
+    ++it;
+    double a1[1] = {0.0};
+    spmv_csr_2rhs<16>(v.rowptr2, v.colidx2, v.Ms, p, n, [&](int row, double y0, double y1) {
+      q[row] = make_double2(y0, y1);
+      const double2 pi = p[row];
+      a1[0] += pi.x * y0 + pi.y * y1;
+    });
+    block_sum<1>(a1, red);
+    if (!(a1[0] > 0.0)) break;
+    const double alpha = rr / a1[0];
+    double a2[1] = {0.0};
+    for (int i = tid; i < n; i += WG) {
+      const double2 xi = x[i], pi = p[i], ri = r[i], qi = q[i];
+      x[i] = make_double2(xi.x + alpha * pi.x, xi.y + alpha * pi.y);
+      const double2 rn = make_double2(ri.x - alpha * qi.x, ri.y - alpha * qi.y);
+      r[i] = rn;
+      a2[0] += rn.x * rn.x + rn.y * rn.y;
+    }
+    block_sum<1>(a2, red);
+    const double rr_new = a2[0];
+    if (!(rr_new > tol2)) break;
+    const double beta = rr_new / rr;
+    rr = rr_new;
+    for (int i = tid; i < n; i += WG) {
+      const double2 ri = r[i], pi = p[i];
+      p[i] = make_double2(ri.x + beta * pi.x, ri.y + beta * pi.y);
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  return it;
+}
+
+// CG on the symmetrically scaled pressure system; vectors (and, when it fits, the matrix) in LDS.
+__device__ inline int cg_pressure(int n, const int32_t* rp, const int32_t* ci, const double* A, double rtol,
+                                  int maxit, double* x, double* r, double* p, double* q, double* red) {
+  const int tid = threadIdx.x;
+  double acc[2] = {0.0, 0.0};
+  __syncthreads();
+  spmv_csr<8>(rp, ci, A, x, n, [&](int row, double y0) {
+    const double b = r[row];
+    const double rr = b - y0;
+    r[row] = rr;
+    p[row] = rr;
+    acc[0] += b * b;
+    acc[1] += rr * rr;
+  });
+  block_sum<2>(acc, red);
+  const double bb = acc[0];
+  double rr = acc[1];
+  const double tol2 = rtol * rtol * bb;
+  if (!(rr > tol2) || bb == 0.0) return 0;
+  int it = 0;
+  while (it < maxit) {
+    ++it;
+    double a1[1] = {0.0};
+    spmv_csr<8>(rp, ci, A, p, n, [&](int row, double y0) {
+      q[row] = y0;
+      a1[0] += p[row] * y0;
+    });
+    block_sum<1>(a1, red);
+    if (!(a1[0] > 0.0)) break;
+    const double alpha = rr / a1[0];
+    double a2[1] = {0.0};
+    for (int i = tid; i < n; i += WG) {
+      x[i] += alpha * p[i];
+      const double rn = r[i] - alpha * q[i];
+      r[i] = rn;
+      a2[0] += rn * rn;
+    }
+    block_sum<1>(a2, red);
+    const double rr_new = a2[0];
+    if (!(rr_new > tol2)) break;
+    const double beta = rr_new / rr;
+    rr = rr_new;
+    for (int i = tid; i < n; i += WG) p[i] = r[i] + beta * p[i];
+    __syncthreads();
+  }
+  __syncthreads();
+  return it;
+}
+
+// ================================================================== probes
+
+// (drag, lift) of one field pair on the airfoil facets; result valid in every thread.
+__device__ inline void forces(const EnvView& v, double mu, const double2* __restrict__ u,
+                              const double* __restrict__ p, double* red, double& drag, double& lift) {
+  double acc[2] = {0.0, 0.0};
+  for (int f = threadIdx.x; f < v.naf; f += WG) {
+    const int e = v.af_facets[2 * f], k = v.af_facets[2 * f + 1];
+    const ElemData E = load_elem(v, e);
+    double X[3][2];
+    load_cell_coords(v, e, X);
+    const Facet F = facet_geometry(X, k);
+    double2 ue[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ue[i] = u[E.dof[i]];
+    double pe[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pe[i] = p[E.dof[i]];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const double s = c_tab.gx[q], w = c_tab.gw[q] * F.len;
+      const double xi = F.ra[0] + s * (F.rb[0] - F.ra[0]);
+      const double eta = F.ra[1] + s * (F.rb[1] - F.ra[1]);
+      double phi[6], dphi[6][2];
+      p2_eval(xi, eta, phi, dphi);
+      double uxx = 0, uxy = 0, uyx = 0, uyy = 0;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const double gx = E.g.j00 * dphi[j][0] + E.g.j10 * dphi[j][1];
+        const double gy = E.g.j01 * dphi[j][0] + E.g.j11 * dphi[j][1];
+        uxx += ue[j].x * gx;
+        uxy += ue[j].x * gy;
+        uyx += ue[j].y * gx;
+        uyy += ue[j].y * gy;
+      }
+      const double pq = pe[0] * (1.0 - xi - eta) + pe[1] * xi + pe[2] * eta;
+      const double sxx = 2.0 * mu * uxx - pq, sxy = mu * (uxy + uyx), syy = 2.0 * mu * uyy - pq;
+      acc[0] += w * (sxx * F.nx + sxy * F.ny);
+      acc[1] += w * (sxy * F.nx + syy * F.ny);
+    }
+  }
+  block_sum<2>(acc, red);
+  drag = acc[0];
+  lift = acc[1];
+}
+
+__global__ __launch_bounds__(WG) void probe_kernel(mdq_ipcs_desc d, int nfields, const double* u, const double* p,
+                                                    double* drag, double* lift) {
+  __shared__ double red[NWAVE * 2];
+  const int b = blockIdx.x;
+  const EnvView v = env_view(d, b);
+  for (int f = 0; f < nfields; ++f) {
+    const double2* uf = reinterpret_cast<const double2*>(u) + ((int64_t)b * nfields + f) * d.N2;
+    const double* pf = p + ((int64_t)b * nfields + f) * d.NV;
+    double dr, li;
+    forces(v, d.mu, uf, pf, red, dr, li);
+    if (threadIdx.x == 0) {
+      drag[(int64_t)b * nfields + f] = dr;
+      lift[(int64_t)b * nfields + f] = li;
+    }
+    __syncthreads();
+  }
+}
+
+// ================================================================== time stepping
+
+// dynamic LDS: [red 64 doubles][pressure vectors 4*NVp][optional K1 matrix: values, colidx, rowptr]
+template <bool K1_IN_LDS>
+__global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps, double* drag, double* lift,
+                                                     int32_t* iters) {
+  extern __shared__ __align__(16) double smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const EnvView v = env_view(d, b);
+  const int n2 = v.n2, nv = v.nv;
+  const int NVp = (d.NV + 1) & ~1;
+
+  double* red = smem;  // 64
+  double* px = smem + 64;
+  double* pr = px + NVp;
+  double* pp = pr + NVp;
+  double* pq = pp + NVp;
+  double* lK = pq + NVp;                                          // [NNZ1]
+  int32_t* lci = reinterpret_cast<int32_t*>(lK + d.NNZ1);        // [NNZ1]
+  int32_t* lrp = lci + d.NNZ1 + (d.NNZ1 & 1);                     // [NV+1]
+
+  // workspace carve-up (global; stays in this CU's L2 slice)
+  double* w = v.work;
+  double2* escr2 = reinterpret_cast<double2*>(w);  // 6*NT double2 (aliased as 3*NT doubles for step 2)
+  double* escr1 = w;
+  double2* xs = reinterpret_cast<double2*>(w + 12 * (int64_t)d.NT);
+  double2* vr = xs + d.N2;
+  double2* vh = vr + d.N2;
+  double2* vp = vh + d.N2;
+  double2* vv = vp + d.N2;
+  double2* vt = vv + d.N2;
+  double* pnew = reinterpret_cast<double*>(vt + d.N2);
+
+  if (K1_IN_LDS) {
+    for (int k = tid; k < v.nnz1; k += WG) {
+      lK[k] = v.K1s[k];
+      lci[k] = v.colidx1[k];
+    }
+    for (int k = tid; k <= nv; k += WG) lrp[k] = v.rowptr1[k];
+  }
+  const int32_t* rp1 = K1_IN_LDS ? lrp : v.rowptr1;
+  const int32_t* ci1 = K1_IN_LDS ? lci : v.colidx1;
+  const double* K1 = K1_IN_LDS ? lK : v.K1s;
+
+  int it_u = 0, it_p = 0, it_m = 0;
+  __syncthreads();
+
+  for (int step = 0; step < nsteps; ++step) {
+    // ---------------- step 1: tentative velocity
+    elem_rhs1(v, d, v.u_n, v.p_n, escr2);
+    __syncthreads();
+    for (int i = tid; i < n2; i += WG) {
+      double2 bsum = make_double2(0.0, 0.0);
+      for (int s = v.g2_ptr[i]; s < v.g2_ptr[i + 1]; ++s) {
+        const double2 c = escr2[v.g2_src[s]];
+        bsum.x += c.x;
+        bsum.y += c.y;
+      }
+      const double2 l = v.lift1[i], id = v.idiag1[i];
+      double2 bi;
+      if (v.bcu_flag[i])
+        bi = make_double2(v.bcu_gx[i], 0.0);
+      else
+        bi = make_double2((bsum.x - l.x) * id.x, (bsum.y - l.y) * id.y);
+      vr[i] = bi;
+      xs[i] = v.u_n[i];
+    }
+    it_u += bicgstab_velocity(v, d.rtol, d.maxit_u, xs, vr, vh, vp, vv, vt, red);
+
+    // ---------------- step 2: pressure
+    elem_rhs2(v, d, xs, v.p_n, escr1);
+    __syncthreads();
+    for (int i = tid; i < nv; i += WG) {
+      double bsum = 0.0;
+      for (int s = v.g1_ptr[i]; s < v.g1_ptr[i + 1]; ++s) bsum += escr1[v.g1_src[s]];
+      const double sd = v.sdiagK[i];
+      pr[i] = v.bcp_flag[i] ? 0.0 : bsum / sd;
+      px[i] = v.p_n[i] * sd;
+    }
+    it_p += cg_pressure(nv, rp1, ci1, K1, d.rtol, d.maxit_p, px, pr, pp, pq, red);
+    for (int i = tid; i < nv; i += WG) pnew[i] = px[i] / v.sdiagK[i];
+    __syncthreads();
+
+    // ---------------- step 3: velocity correction
+    elem_rhs3(v, d, xs, pnew, v.p_n, escr2);
+    __syncthreads();
+    for (int i = tid; i < n2; i += WG) {
+      double2 bsum = make_double2(0.0, 0.0);
+      for (int s = v.g2_ptr[i]; s < v.g2_ptr[i + 1]; ++s) {
+        const double2 c = escr2[v.g2_src[s]];
+        bsum.x += c.x;
+        bsum.y += c.y;
+      }
+      const double2 l = v.lift3[i];
+      const double sd = v.sdiagM[i];
+      double2 bi;
+      if (v.bcu_flag[i])
+        bi = make_double2(v.bcu_gx[i], 0.0);
+      else
+        bi = make_double2((bsum.x - l.x) / sd, (bsum.y - l.y) / sd);
+      vr[i] = bi;
+      const double2 x0 = xs[i];
+      xs[i] = make_double2(x0.x * sd, x0.y * sd);
+    }
+    it_m += cg_mass(v, d.rtol, d.maxit_m, xs, vr, vp, vv, red);
+
+    // ---------------- update state + probes
+    for (int i = tid; i < n2; i += WG) {
+      const double sd = v.sdiagM[i];
+      const double2 x = xs[i];
+      v.u_n[i] = make_double2(x.x / sd, x.y / sd);
+    }
+    for (int i = tid; i < nv; i += WG) v.p_n[i] = pnew[i];
+    __syncthreads();
+    double dr, li;
+    forces(v, d.mu, v.u_n, v.p_n, red, dr, li);
+    if (tid == 0) {
+      drag[(int64_t)b * nsteps + step] = dr;
+      lift[(int64_t)b * nsteps + step] = li;
+    }
+  }
+  if (tid == 0 && iters) {
+    iters[3 * b + 0] += it_u;
+    iters[3 * b + 1] += it_p;
+    iters[3 * b + 2] += it_m;
+  }
+}
+
+// ================================================================== host side
+
+static thread_local std::string g_err;
+
+static int fail(const char* what, hipError_t e) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return -1;
+}
+static int fail_msg(const std::string& m) {
+  g_err = m;
+  return -2;
+}
+
+static void build_tables(RefTab& T) {
+  const double s15 = std::sqrt(15.0);
+  const double a1 = (6.0 - s15) / 21.0, a2 = (6.0 + s15) / 21.0;
+  const double w0 = 9.0 / 40.0, w1 = (155.0 - s15) / 1200.0, w2 = (155.0 + s15) / 1200.0;
+  const double pts[NQ][2] = {{1.0 / 3.0, 1.0 / 3.0}, {a1, a1}, {1.0 - 2.0 * a1, a1}, {a1, 1.0 - 2.0 * a1},
+                             {a2, a2},               {1.0 - 2.0 * a2, a2}, {a2, 1.0 - 2.0 * a2}};
+  const double wts[NQ] = {w0, w1, w1, w1, w2, w2, w2};
+  auto basis = [](double xi, double eta, double* phi, double (*dphi)[2], double* psi) {
+    const double lam[3] = {1.0 - xi - eta, xi, eta};
+    const double dl[3][2] = {{-1.0, -1.0}, {1.0, 0.0}, {0.0, 1.0}};
+    const int EA[3] = {1, 0, 0}, EB[3] = {2, 2, 1};
+    for (int k = 0; k < 3; ++k) {
+      psi[k] = lam[k];
+      phi[k] = lam[k] * (2.0 * lam[k] - 1.0);
+      dphi[k][0] = (4.0 * lam[k] - 1.0) * dl[k][0];
+      dphi[k][1] = (4.0 * lam[k] - 1.0) * dl[k][1];
+      phi[3 + k] = 4.0 * lam[EA[k]] * lam[EB[k]];
+      dphi[3 + k][0] = 4.0 * (lam[EA[k]] * dl[EB[k]][0] + lam[EB[k]] * dl[EA[k]][0]);
+      dphi[3 + k][1] = 4.0 * (lam[EA[k]] * dl[EB[k]][1] + lam[EB[k]] * dl[EA[k]][1]);
+    }
+  };
+  std::memset(&T, 0, sizeof(T));
+  for (int q = 0; q < NQ; ++q) {
+    T.qw[q] = 0.5 * wts[q];
+    basis(pts[q][0], pts[q][1], T.qphi[q], T.qdphi[q], T.qpsi[q]);
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) {
+        T.Mhat[i][j] += T.qw[q] * T.qphi[q][i] * T.qphi[q][j];
+        for (int c = 0; c < 2; ++c)
+          for (int dd = 0; dd < 2; ++dd) T.Ghat[c][dd][i][j] += T.qw[q] * T.qdphi[q][i][c] * T.qdphi[q][j][dd];
+      }
+  }
+  const double g = 0.5 / std::sqrt(3.0);
+  T.gx[0] = 0.5 - g;
+  T.gx[1] = 0.5 + g;
+  T.gw[0] = T.gw[1] = 0.5;
+}
+
+static int ensure_tables() {
+  static std::once_flag once;
+  static hipError_t err = hipSuccess;
+  std::call_once(once, [] {
+    RefTab T;
+    build_tables(T);
+    err = hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &T, sizeof(T));
+  });
+  if (err != hipSuccess) return fail("hipMemcpyToSymbol(c_tab)", err);
+  return 0;
+}
+
+static int check_desc(const mdq_ipcs_desc* d) {
+  if (!d) return fail_msg("null descriptor");
+  if (d->B <= 0 || d->NV <= 0 || d->NT <= 0 || d->NE <= 0) return fail_msg("bad batch sizes");
+  if (d->N2 != d->NV + d->NE) return fail_msg("N2 must equal NV+NE");
+  if (d->work_doubles < (int64_t)d->B * work_per_env(d->NV, d->NT, d->NE))
+    return fail_msg("workspace too small (see mdq_ipcs_workspace_doubles)");
+  if (!(d->dt > 0.0) || !(d->rho > 0.0)) return fail_msg("dt and rho must be positive");
+  return 0;
+}
+
+}  // namespace mdq
+
+using namespace mdq;
+
+extern "C" {
+
+int mdq_abi_version(void) { return MDQ_ABI_VERSION; }
+
+const char* mdq_last_error(void) { return g_err.c_str(); }
+
+int64_t mdq_ipcs_workspace_doubles(int32_t B, int32_t NV, int32_t NT, int32_t NE) {
+  return (int64_t)B * work_per_env(NV, NT, NE);
+}
+
+int mdq_ipcs_assemble(const mdq_ipcs_desc* d, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  if (int rc = ensure_tables()) return rc;
+  hipLaunchKernelGGL(assemble_kernel, dim3(d->B), dim3(WG), 0, (hipStream_t)stream, *d);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail("assemble_kernel launch", e);
+  return 0;
+}
+
+int mdq_ipcs_evolve(const mdq_ipcs_desc* d, int32_t nsteps, double* drag, double* lift, int32_t* iters,
+                    void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  if (nsteps <= 0) return fail_msg("nsteps must be positive");
+  if (!drag || !lift) return fail_msg("drag/lift output pointers are required");
+  if (int rc = ensure_tables()) return rc;
+  const int NVp = (d->NV + 1) & ~1;
+  size_t lds_small = sizeof(double) * (64 + 4 * (size_t)NVp);
+  size_t lds_full = lds_small + sizeof(double) * d->NNZ1 + sizeof(int32_t) * ((size_t)d->NNZ1 + (d->NNZ1 & 1)) +
+                    sizeof(int32_t) * ((size_t)d->NV + 2);
+  const size_t LDS_MAX = 160 * 1024;
+  if (lds_small > LDS_MAX) return fail_msg("mesh too large for the LDS-resident pressure vectors");
+  hipError_t e;
+  if (lds_full <= LDS_MAX) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&evolve_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
+    if (e != hipSuccess) return fail("hipFuncSetAttribute(evolve<true>)", e);
+    hipLaunchKernelGGL(evolve_kernel<true>, dim3(d->B), dim3(WG), lds_full, (hipStream_t)stream, *d, nsteps, drag,
+                       lift, iters);
+  } else {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&evolve_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small);
+    if (e != hipSuccess) return fail("hipFuncSetAttribute(evolve<false>)", e);
+    hipLaunchKernelGGL(evolve_kernel<false>, dim3(d->B), dim3(WG), lds_small, (hipStream_t)stream, *d, nsteps, drag,
+                       lift, iters);
+  }
+  e = hipGetLastError();
+  if (e != hipSuccess) return fail("evolve_kernel launch", e);
+  return 0;
+}
+
+int mdq_probe_forces(const mdq_ipcs_desc* d, int32_t nfields, const double* u, const double* p, double* drag,
+                     double* lift, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  if (nfields <= 0 || !u || !p || !drag || !lift) return fail_msg("bad probe arguments");
+  if (int rc = ensure_tables()) return rc;
+  hipLaunchKernelGGL(probe_kernel, dim3(d->B), dim3(WG), 0, (hipStream_t)stream, *d, nfields, u, p, drag, lift);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail("probe_kernel launch", e);
+  return 0;
+}
+
+// DOLFIN MeshSmoothing::smooth restated for the host (flow_solver.py:65-67, 236-237).
+int mdq_smooth_host(double* x, int32_t nv, const int32_t* cells, int32_t nt, const int64_t* nbr_ptr,
+                    const int64_t* nbr, const int64_t* vc_ptr, const int64_t* vc, const uint8_t* on_boundary,
+                    int32_t iterations) {
+  if (!x || !cells || !nbr_ptr || !nbr || !vc_ptr || !vc || !on_boundary) return fail_msg("null argument");
+  (void)nt;
+  const double DOLFIN_EPS = 3.0e-16;
+  for (int it = 0; it < iterations; ++it) {
+    for (int v = 0; v < nv; ++v) {
+      if (on_boundary[v]) continue;
+      const double px = x[2 * v], py = x[2 * v + 1];
+      double cx = 0.0, cy = 0.0;
+      const int64_t n0 = nbr_ptr[v], n1 = nbr_ptr[v + 1];
+      for (int64_t k = n0; k < n1; ++k) {
+        cx += x[2 * nbr[k]];
+        cy += x[2 * nbr[k] + 1];
+      }
+      const double cnt = (double)(n1 - n0);
+      cx /= cnt;
+      cy /= cnt;
+      double rmin = 0.0;
+      for (int64_t k = vc_ptr[v]; k < vc_ptr[v + 1]; ++k) {
+        const int64_t c = vc[k] / 3, loc = vc[k] % 3;
+        const int32_t o0 = cells[3 * c + (loc == 0 ? 1 : 0)], o1 = cells[3 * c + (loc == 2 ? 1 : 2)];
+        const double ax = x[2 * o0], ay = x[2 * o0 + 1];
+        const double tx = x[2 * o1] - ax, ty = x[2 * o1 + 1] - ay;
+        double nx = ty, ny = -tx;
+        const double nn = std::sqrt(nx * nx + ny * ny);
+        nx /= nn;
+        ny /= nn;
+        const double r = std::fabs(nx * (px - ax) + ny * (py - ay));
+        rmin = (rmin == 0.0) ? r : (r < rmin ? r : rmin);
+      }
+      const double dx = cx - px, dy = cy - py;
+      const double r = std::sqrt(dx * dx + dy * dy);
+      if (r < DOLFIN_EPS) continue;
+      const double step = (0.5 * rmin < r) ? 0.5 * rmin : r;
+      x[2 * v] = px + step * dx / r;
+      x[2 * v + 1] = py + step * dy / r;
+    }
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,3 @@
+// Single translation unit of libmeshdqn_hip.so (keeps __constant__ tables and
+// the thread-local error string in one place; no relocatable device code needed).
+#include "mdq_ipcs.hip"

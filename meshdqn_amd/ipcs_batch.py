@@ -1,0 +1,228 @@
+"""Batched IPCS solver: B environments (meshes) advanced together on one MI355X.
+
+Host side of `mdq_ipcs_assemble` / `mdq_ipcs_evolve` / `mdq_probe_forces`
+(include/meshdqn_hip.h).  Builds the padded index arrays from `MeshTopology`,
+owns the device tensors (torch = allocator + stream plumbing only) and hands
+raw device pointers to the C ABI.  No CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .topology import TAG_AIRFOIL, TAG_OUTFLOW, MeshTopology
+
+
+def smooth_coords(topo: MeshTopology, iterations: int = 50, coords: np.ndarray | None = None) -> np.ndarray:
+    """DOLFIN `Mesh.smooth(iterations)` (`flow_solver.py:65-67,236-237`) via the
+    library's host routine; returns the new coordinates (topology unchanged)."""
+    lib = _lib.load()
+    x = np.array(topo.coords if coords is None else coords, dtype=np.float64, order="C", copy=True)
+    nbr_ptr, nbr, vc_ptr, vc = topo.vertex_adjacency()
+    cells = np.ascontiguousarray(topo.cells, dtype=np.int32)
+    onb = np.ascontiguousarray(topo.on_boundary, dtype=np.uint8)
+    nbr_ptr = np.ascontiguousarray(nbr_ptr, np.int64)
+    nbr = np.ascontiguousarray(nbr, np.int64)
+    vc_ptr = np.ascontiguousarray(vc_ptr, np.int64)
+    vc = np.ascontiguousarray(vc, np.int64)
+    rc = lib.mdq_smooth_host(x.ctypes.data, topo.nv, cells.ctypes.data, topo.nt, nbr_ptr.ctypes.data,
+                             nbr.ctypes.data, vc_ptr.ctypes.data, vc.ctypes.data, onb.ctypes.data, int(iterations))
+    _lib.check(rc, "mdq_smooth_host")
+    return x
+
+
+class IpcsBatch:
+    """Device-resident batch of Taylor-Hood IPCS problems."""
+
+    def __init__(self, topos: Sequence[MeshTopology], coords: Sequence[np.ndarray] | None = None,
+                 mu: float = 1e-3, rho: float = 1.0, dt: float = 1e-3, rtol: float = 1e-10,
+                 maxit=(200, 4000, 200), device: str | torch.device = "cuda", capacities: dict | None = None):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.MeshDQNHipError("IpcsBatch needs a GPU device (no CPU fallback)")
+        self.topos = list(topos)
+        B = len(self.topos)
+        if B == 0:
+            raise ValueError("empty batch")
+        coords = [t.coords for t in self.topos] if coords is None else list(coords)
+        self.B = B
+        self.mu, self.rho, self.dt, self.rtol = float(mu), float(rho), float(dt), float(rtol)
+        self.maxit = tuple(int(m) for m in maxit)
+
+        per = [self._host_arrays(t, x) for t, x in zip(self.topos, coords)]
+        cap = dict(NV=max(p["nv"] for p in per), NT=max(p["nt"] for p in per), NE=max(p["ne"] for p in per),
+                   NNZ2=max(p["colidx2"].size for p in per), NNZ1=max(p["colidx1"].size for p in per),
+                   NAF=max(max(p["af"].shape[0] for p in per), 1))
+        if capacities:
+            for k, val in capacities.items():
+                if val < cap[k]:
+                    raise ValueError(f"capacity {k}={val} smaller than required {cap[k]}")
+                cap[k] = int(val)
+        self.cap = cap
+        NV, NT, NE, NNZ2, NNZ1, NAF = (cap[k] for k in ("NV", "NT", "NE", "NNZ2", "NNZ1", "NAF"))
+        N2 = NV + NE
+        self.N2 = N2
+
+        def stack(key, shape, dtype, fill=0):
+            out = np.full((B,) + shape, fill, dtype=dtype)
+            for b, p in enumerate(per):
+                a = p[key]
+                out[(b,) + tuple(slice(0, s) for s in a.shape)] = a
+            return out
+
+        h = {}
+        h["nv"] = np.array([p["nv"] for p in per], np.int32)
+        h["nt"] = np.array([p["nt"] for p in per], np.int32)
+        h["ne"] = np.array([p["ne"] for p in per], np.int32)
+        h["naf"] = np.array([p["af"].shape[0] for p in per], np.int32)
+        h["coords"] = stack("coords", (NV, 2), np.float64)
+        h["cell_dofs"] = stack("cell_dofs_soa", (6, NT), np.int32)
+        h["cell_outflow"] = stack("cell_outflow", (NT,), np.int8, fill=-1)
+        h["rowptr2"] = stack("rowptr2", (N2 + 1,), np.int32)
+        h["colidx2"] = stack("colidx2", (NNZ2,), np.int32)
+        h["asm2_ptr"] = stack("asm2_ptr", (NNZ2 + 1,), np.int32)
+        h["asm2_src"] = stack("asm2_src", (36 * NT,), np.int32)
+        h["rowptr1"] = stack("rowptr1", (NV + 1,), np.int32)
+        h["colidx1"] = stack("colidx1", (NNZ1,), np.int32)
+        h["asm1_ptr"] = stack("asm1_ptr", (NNZ1 + 1,), np.int32)
+        h["asm1_src"] = stack("asm1_src", (9 * NT,), np.int32)
+        h["g2_ptr"] = stack("g2_ptr", (N2 + 1,), np.int32)
+        h["g2_src"] = stack("g2_src", (6 * NT,), np.int32)
+        h["g1_ptr"] = stack("g1_ptr", (NV + 1,), np.int32)
+        h["g1_src"] = stack("g1_src", (3 * NT,), np.int32)
+        h["bcu_flag"] = stack("bcu_flag", (N2,), np.uint8)
+        h["bcu_gx"] = stack("bcu_gx", (N2,), np.float64)
+        h["bcp_flag"] = stack("bcp_flag", (NV,), np.uint8)
+        h["af_facets"] = stack("af", (NAF, 2), np.int32)
+        self.host = h
+        self.per = per
+        dev = self.device
+        self.t = {k: torch.from_numpy(v).to(dev) for k, v in h.items()}
+
+        def z(*shape):
+            return torch.zeros(shape, dtype=torch.float64, device=dev)
+
+        t = self.t
+        t["geom"] = z(B, 5, NT)
+        t["A1"] = z(B, NNZ2, 4)
+        t["Ms"] = z(B, NNZ2)
+        t["K1s"] = z(B, NNZ1)
+        t["lift1"] = z(B, N2, 2)
+        t["lift3"] = z(B, N2, 2)
+        t["idiag1"] = z(B, N2, 2)
+        t["sdiagM"] = z(B, N2)
+        t["sdiagK"] = z(B, NV)
+        t["u_n"] = z(B, N2, 2)
+        t["p_n"] = z(B, NV)
+        nwork = int(self.lib.mdq_ipcs_workspace_doubles(B, NV, NT, NE))
+        t["work"] = z(nwork)
+        self.iters = torch.zeros((B, 3), dtype=torch.int32, device=dev)
+        self.steps_done = 0
+
+        d = _lib.IpcsDesc()
+        d.B, d.NV, d.NT, d.NE, d.N2, d.NNZ2, d.NNZ1, d.NAF = B, NV, NT, NE, N2, NNZ2, NNZ1, NAF
+        d.mu, d.rho, d.dt, d.rtol = self.mu, self.rho, self.dt, self.rtol
+        d.maxit_u, d.maxit_p, d.maxit_m = self.maxit
+        for name, _typ in _lib.IpcsDesc._fields_:
+            if name in t:
+                setattr(d, name, t[name].data_ptr())
+        d.work_doubles = nwork
+        self.desc = d
+        self.assembled = False
+
+    # ------------------------------------------------------------------
+    @staticmethod
+    def _host_arrays(topo: MeshTopology, coords: np.ndarray) -> dict:
+        bc = topo.boundary_conditions(coords)
+        pat = topo.patterns()
+        gat = topo.dof_gathers()
+        rowptr2, colidx2, asm2_ptr, asm2_src = pat["p2"]
+        rowptr1, colidx1, asm1_ptr, asm1_src = pat["p1"]
+        out_f, _ = topo.facets(bc["tags"], TAG_OUTFLOW)
+        af, af_edges = topo.facets(bc["tags"], TAG_AIRFOIL)
+        cell_outflow = np.full(topo.nt, -1, dtype=np.int8)
+        cell_outflow[out_f[:, 0]] = out_f[:, 1]
+        return dict(nv=topo.nv, nt=topo.nt, ne=topo.ne, coords=np.asarray(coords, np.float64),
+                    cell_dofs_soa=np.ascontiguousarray(topo.cell_dofs.T, dtype=np.int32),
+                    cell_outflow=cell_outflow,
+                    rowptr2=rowptr2, colidx2=colidx2, asm2_ptr=asm2_ptr, asm2_src=asm2_src,
+                    rowptr1=rowptr1, colidx1=colidx1, asm1_ptr=asm1_ptr, asm1_src=asm1_src,
+                    g2_ptr=gat["p2"][0], g2_src=gat["p2"][1], g1_ptr=gat["p1"][0], g1_src=gat["p1"][1],
+                    bcu_flag=bc["bcu_flag"], bcu_gx=bc["bcu_gx"], bcp_flag=bc["bcp_flag"],
+                    af=af, af_edges=af_edges, tags=bc["tags"])
+
+    # ------------------------------------------------------------------
+    @property
+    def u_n(self) -> torch.Tensor:
+        """(B, N2, 2) velocity dofs [dof][component]."""
+        return self.t["u_n"]
+
+    @property
+    def p_n(self) -> torch.Tensor:
+        return self.t["p_n"]
+
+    def reset_state(self):
+        self.t["u_n"].zero_()
+        self.t["p_n"].zero_()
+        self.iters.zero_()
+        self.steps_done = 0
+
+    def assemble(self, stream=None):
+        rc = self.lib.mdq_ipcs_assemble(C.byref(self.desc), _lib.stream_ptr(stream))
+        _lib.check(rc, "mdq_ipcs_assemble")
+        self.assembled = True
+
+    def evolve(self, nsteps: int = 1, stream=None, out=None):
+        """Advance all environments `nsteps` IPCS steps; returns (drag, lift) (B,nsteps) device tensors."""
+        if not self.assembled:
+            self.assemble(stream)
+        if out is None:
+            drag = torch.empty((self.B, nsteps), dtype=torch.float64, device=self.device)
+            lift = torch.empty_like(drag)
+        else:
+            drag, lift = out
+        rc = self.lib.mdq_ipcs_evolve(C.byref(self.desc), int(nsteps), drag.data_ptr(), lift.data_ptr(),
+                                      self.iters.data_ptr(), _lib.stream_ptr(stream))
+        _lib.check(rc, "mdq_ipcs_evolve")
+        self.steps_done += nsteps
+        return drag, lift
+
+    def probe_forces(self, u: torch.Tensor, p: torch.Tensor, stream=None):
+        """u (B,F,N2,2), p (B,F,NV) -> drag, lift (B,F)."""
+        F = u.shape[1]
+        assert u.shape == (self.B, F, self.N2, 2) and p.shape == (self.B, F, self.cap["NV"])
+        u = u.contiguous()
+        p = p.contiguous()
+        drag = torch.empty((self.B, F), dtype=torch.float64, device=self.device)
+        lift = torch.empty_like(drag)
+        rc = self.lib.mdq_probe_forces(C.byref(self.desc), F, u.data_ptr(), p.data_ptr(), drag.data_ptr(),
+                                       lift.data_ptr(), _lib.stream_ptr(stream))
+        _lib.check(rc, "mdq_probe_forces")
+        return drag, lift
+
+    # ------------------------------------------------------------------
+    def algorithmic_bytes_per_step(self, iters_per_step=None) -> float:
+        """SURVEY.md 8(d) accounting: every SpMV streams its CSR matrix once
+        (fp64 values, int32 indices), vector passes 8 B per entry per vector."""
+        tot = 0.0
+        it = iters_per_step
+        for b, p in enumerate(self.per):
+            nv, nt, ne = p["nv"], p["nt"], p["ne"]
+            n2 = nv + ne
+            nnz2, nnz1 = p["colidx2"].size, p["colidx1"].size
+
+            def spmv(nnz, n):
+                return 12.0 * nnz + 4.0 * (n + 1) + 16.0 * n
+            a1 = spmv(4 * nnz2, 2 * n2)
+            mm = spmv(nnz2, n2) * 2
+            k1 = spmv(nnz1, nv)
+            elem = 268.0 * nt
+            iu, ip, im = (it[b] if it is not None else (6.0, 134.0, 3.0))
+            tot += (3 * elem + a1 + iu * (2 * a1 + 10 * 8 * 2 * n2) + k1 + ip * (k1 + 6 * 8 * nv)
+                    + mm + im * (mm + 6 * 8 * 2 * n2) + 200.0 * p["af"].shape[0])
+        return tot

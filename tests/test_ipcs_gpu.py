@@ -1,0 +1,135 @@
+"""GPU parity tests: HIP IPCS path (through the C ABI) against the CPU oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle_util import (device_sym_matrix, device_velocity_matrix, interleaved_to_oracle_vel)
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _make(meshes, names, **kw):
+    import torch
+    from meshdqn_amd.ipcs_batch import IpcsBatch, smooth_coords
+    from meshdqn_amd.topology import MeshTopology
+    topos, xs = [], []
+    for n in names:
+        coords, cells = meshes[n]
+        t = MeshTopology(coords, cells)
+        topos.append(t)
+        xs.append(smooth_coords(t, 50))
+    return IpcsBatch(topos, xs, device="cuda", **kw), topos, xs
+
+
+@pytest.fixture(scope="module")
+def oracle_solvers(meshes):
+    from oracle.ipcs import OracleFlowSolver
+    return {n: OracleFlowSolver(*meshes[n]) for n in ("ys930", "ah93w145")}
+
+
+def test_assembly_matches_oracle(meshes, oracle_solvers, lib_built):
+    import torch
+    batch, topos, xs = _make(meshes, ["ys930", "ah93w145"])
+    batch.assemble()
+    torch.cuda.synchronize()
+    t = {k: v.cpu().numpy() for k, v in batch.t.items()}
+    for b, name in enumerate(["ys930", "ah93w145"]):
+        o = oracle_solvers[name]
+        th = o.th
+        n2, nv = th.np2, th.nv
+        assert np.abs(xs[b] - o.mesh.coords).max() < 1e-13
+        A = device_velocity_matrix(t["rowptr2"][b][:n2 + 1], t["colidx2"][b], t["A1"][b], t["idiag1"][b])
+        ref = o.A1.tocsr()
+        scale = abs(ref).max()
+        assert abs(A - ref).max() / scale < 1e-13
+        M = device_sym_matrix(t["rowptr2"][b][:n2 + 1], t["colidx2"][b], t["Ms"][b], t["sdiagM"][b])
+        # oracle A3 = blockdiag(M_bc, M_bc)
+        refM = o.A3.tocsr()[:n2, :n2]
+        assert abs(M - refM).max() / abs(refM).max() < 1e-13
+        K = device_sym_matrix(t["rowptr1"][b][:nv + 1], t["colidx1"][b], t["K1s"][b], t["sdiagK"][b])
+        refK = o.A2.tocsr()
+        assert abs(K - refK).max() / abs(refK).max() < 1e-13
+        l1 = interleaved_to_oracle_vel(t["lift1"][b][:n2])
+        free = np.ones(2 * n2, bool)
+        free[th.bcu_dofs] = False
+        assert np.abs(l1 - o.lift1)[free].max() <= 1e-13 * max(1.0, np.abs(o.lift1).max())
+        l3 = interleaved_to_oracle_vel(t["lift3"][b][:n2])
+        assert np.abs(l3 - o.lift3)[free].max() <= 1e-13 * max(1.0, np.abs(o.lift3).max())
+
+
+def test_first_steps_match_oracle(meshes, lib_built):
+    """Per-step parity of u, p, drag, lift against the sparse-LU oracle."""
+    import torch
+    from oracle.ipcs import OracleFlowSolver
+    names = ["ys930", "ah93w145"]
+    batch, topos, xs = _make(meshes, names, rtol=1e-12)
+    oracles = [OracleFlowSolver(*meshes[n]) for n in names]
+    for step in range(3):
+        drag, lift = batch.evolve(1)
+        torch.cuda.synchronize()
+        u = batch.u_n.cpu().numpy()
+        p = batch.p_n.cpu().numpy()
+        for b, o in enumerate(oracles):
+            uo, po, do, lo = o.evolve()
+            n2, nv = o.th.np2, o.th.nv
+            ug = interleaved_to_oracle_vel(u[b][:n2])
+            assert np.abs(ug - uo).max() / np.abs(uo).max() < 1e-8, (step, b)
+            assert np.abs(p[b][:nv] - po).max() / np.abs(po).max() < 1e-8, (step, b)
+            assert abs(drag[b, 0].item() - do) / abs(do) < 1e-8
+            assert abs(lift[b, 0].item() - lo) / abs(lo) < 1e-8
+    it = batch.iters.cpu().numpy()
+    assert (it > 0).all()
+
+
+def test_multi_step_launch_equals_single_steps(meshes, lib_built):
+    import torch
+    b1, _, _ = _make(meshes, ["ys930"])
+    b2, _, _ = _make(meshes, ["ys930"])
+    d1, l1 = b1.evolve(6)
+    parts = [b2.evolve(1) for _ in range(6)]
+    torch.cuda.synchronize()
+    d2 = torch.cat([p[0] for p in parts], dim=1)
+    assert torch.equal(d1, d2)  # bitwise: deterministic reductions, no atomics
+    assert torch.equal(b1.u_n, b2.u_n)
+
+
+def test_probe_forces_matches_oracle(meshes, oracle_solvers, lib_built):
+    import torch
+    batch, topos, xs = _make(meshes, ["ys930"])
+    batch.assemble()
+    o = oracle_solvers["ys930"]
+    rng = np.random.default_rng(0)
+    n2, nv = o.th.np2, o.th.nv
+    F = 3
+    u = rng.standard_normal((1, F, batch.N2, 2))
+    p = rng.standard_normal((1, F, batch.cap["NV"]))
+    dr, li = batch.probe_forces(torch.from_numpy(u).cuda(), torch.from_numpy(p).cuda())
+    for f in range(F):
+        do, lo = o.th.forces(interleaved_to_oracle_vel(u[0, f, :n2]), p[0, f, :nv])
+        assert abs(dr[0, f].item() - do) < 1e-12 * max(1, abs(do))
+        assert abs(li[0, f].item() - lo) < 1e-12 * max(1, abs(lo))
+
+
+@pytest.mark.slow
+def test_kat_5000_steps_matches_reference_csv(meshes, lib_built):
+    """The reference's two known-answer rows (tests/golden/kat_rows.json):
+    drag / lift after 5000 IPCS steps within 1e-4 relative (north-star tolerance);
+    we additionally require 1e-6."""
+    import torch
+    kat = json.load(open(os.path.join(GOLDEN, "kat_rows.json")))
+    names = ["ys930", "ah93w145"]
+    batch, _, _ = _make(meshes, names)
+    for _ in range(50):
+        drag, lift = batch.evolve(100)
+    torch.cuda.synchronize()
+    for b, n in enumerate(names):
+        d, l = drag[b, -1].item(), lift[b, -1].item()
+        assert abs(d - kat[n]["drag"]) / abs(kat[n]["drag"]) < 1e-4
+        assert abs(l - kat[n]["lift"]) / abs(kat[n]["lift"]) < 1e-4
+        # 7 printed digits of the CSV
+        assert abs(d - kat[n]["drag"]) < 6e-8
+        assert abs(l - kat[n]["lift"]) < 6e-8
