@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X hot path: batched Env2DAirfoil IPCS steps on the ys930 mesh.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: every one of the `--envs`
+(default 128, BASELINE.json configs[1]) environments of a rank advances by ONE
+IPCS time step (`FlowSolver.evolve`, flow_solver.py:362-396: three right-hand
+sides, three Krylov solves, drag/lift probes) - unit-of-work definition S2 of
+SURVEY.md section 8(d).  Inputs (meshes, operators, flow state) are resident in
+HBM before the timed region; the flow state is a developed flow obtained by
+`--spinup` untimed IPCS steps from rest so that Krylov iteration counts are
+representative.  value = (ranks x envs x K) / max-over-ranks time.
+
+For N > 1 launch with torchrun (one rank per GPU); environments are independent
+so they are sharded across ranks with no data-path collective (weak scaling).
+
+Extra objects in the JSON line: `roofline` (dominant kernel = evolve_kernel,
+algorithmic bytes per launch / measured launch duration vs the 8 TB/s HBM peak)
+and `cpu_baseline` (the numpy/scipy sparse-LU oracle timed on one host core on
+a bounded sample of the same workload, rank 0 at N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(budget_s=15.0, spinup=20):
+    """Oracle (kind 'port') on one core: IPCS evolve() steps/s for ONE ys930 env."""
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    from oracle.ipcs import OracleFlowSolver
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ys930.npz"))
+    fs = OracleFlowSolver(z["coords"], z["cells"])
+    for _ in range(spinup):
+        fs.evolve()
+    n = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        fs.evolve()
+        n += 1
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit="env steps/s", cores=1, kind="port",
+                sample=f"{n} FlowSolver.evolve() steps of 1 ys930 env (numpy/scipy oracle, sparse LU "
+                       f"back-substitution like the reference's MUMPS path), {dt:.1f} s on 1 core; "
+                       f"mesh smoothing / assembly / factorisation excluded")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs", type=int, default=128, help="environments per GPU")
+    ap.add_argument("--spinup", type=int, default=300, help="untimed IPCS steps from rest before warmup")
+    ap.add_argument("--mesh", default="ys930")
+    ap.add_argument("--rtol", type=float, default=1e-10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    from meshdqn_amd import build as _b
+    if rank == 0:
+        _b.build()
+    if dist is not None:
+        dist.barrier()
+    from meshdqn_amd.ipcs_batch import IpcsBatch, smooth_coords
+    from meshdqn_amd.topology import MeshTopology
+
+    z = np.load(os.path.join(ROOT, "tests", "golden", f"{args.mesh}.npz"))
+    topo = MeshTopology(z["coords"], z["cells"])
+    x = smooth_coords(topo, 50)
+    B = args.envs
+    batch = IpcsBatch([topo] * B, [x] * B, device=dev, rtol=args.rtol)
+    batch.assemble()
+    out = (torch.empty((B, 1), dtype=torch.float64, device=dev), torch.empty((B, 1), dtype=torch.float64, device=dev))
+    # developed flow state (untimed); single-step launches like the timed region so that the
+    # rocprofv3 --stats average of evolve_kernel over the whole run is comparable with launch_ms
+    for _ in range(args.spinup):
+        batch.evolve(1, out=out)
+    for _ in range(args.warmup):
+        batch.evolve(1, out=out)
+    batch.iters.zero_()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        batch.evolve(1, out=out)  # one launch of evolve_kernel on torch's current stream
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern_ms = ev0.elapsed_time(ev1) / args.steps  # average launch duration (HIP events, same stream)
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+
+    iters = batch.iters.cpu().numpy().astype(np.float64) / args.steps  # (B,3) per step
+    alg_bytes = batch.algorithmic_bytes_per_step(iters)  # per launch (all envs of this rank)
+    drag = out[0][:, 0].cpu().numpy()
+    lift = out[1][:, 0].cpu().numpy()
+
+    if rank == 0:
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("evolve_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "env steps/sec (ys930 ~2k-tri)",
+            "value": world * B * args.steps / elapsed,
+            "unit": "env steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.mesh} (876 vertices / 1570 triangles, smoothed), {B} batched envs per GPU, "
+                            f"step = S2: one IPCS evolve() per env (3 RHS + BiCGStab/CG/CG + drag/lift), "
+                            f"developed flow after {args.spinup} untimed steps from rest",
+                "envs_per_gpu": B, "rtol": args.rtol, "dt": 1e-3, "mu": 1e-3, "rho": 1.0,
+                "krylov_iters_per_step": {"velocity_bicgstab": float(iters[:, 0].mean()),
+                                          "pressure_cg": float(iters[:, 1].mean()),
+                                          "correction_cg": float(iters[:, 2].mean())},
+                "drag_env0": float(drag[0]), "lift_env0": float(lift[0]),
+                "parallelism": f"dp{world} (independent envs sharded, no data-path collective)",
+                "reference_published": "45.8 IPCS steps/s for 1 env (FEniCS, unknown hardware; BASELINE.md) - context only",
+            },
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "evolve_kernel", "launch_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "algorithmic bytes follow SURVEY.md 8(d): every SpMV streams its CSR matrix once "
+                                 "(no credit for LDS/L2 residency), measured Krylov iteration counts"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.cpu_budget)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -23,7 +23,8 @@
  *
  * Batch layout: B environments, every per-environment array padded to common
  * capacities (NV vertices, NT triangles, NE edges, N2 = NV+NE scalar P2 dofs,
- * NNZ2 / NNZ1 non-zeros of the P2 / P1 CSR patterns); actual sizes in the
+ * NNZ2 / NNZ1 non-zeros of the P2 / P1 CSR patterns, NSE2 / NSE1 entries of
+ * their SELL-64 layouts); actual sizes in the
  * per-environment count arrays.  Velocity vectors are component-interleaved:
  * u[dof][c], dof in [0,N2), c in {x,y}.
  */
@@ -50,6 +51,7 @@ typedef struct mdq_ipcs_desc {
   int32_t N2;           /* NV + NE (scalar P2 dof capacity)                  */
   int32_t NNZ2, NNZ1;   /* CSR capacities of the P2 / P1 patterns            */
   int32_t NAF;          /* capacity of the airfoil (tag 1) facet list        */
+  int32_t NSE2, NSE1;   /* SELL-64 entry capacities of the P2 / P1 operators */
   /* physics: flow_params / solver_params of FlowSolver (flow_solver.py:49-52,95) */
   double mu, rho, dt;
   /* Krylov controls (the reference uses MUMPS LU, flow_solver.py:150-151;
@@ -75,6 +77,12 @@ typedef struct mdq_ipcs_desc {
   const int32_t* colidx1;      /* [B][NNZ1]   */
   const int32_t* asm1_ptr;     /* [B][NNZ1+1] */
   const int32_t* asm1_src;     /* [B][9*NT]   slot = cell*9 + i*3 + j         */
+  /* SELL-64 layout of the same patterns (slices of 64 consecutive rows, column-major
+     inside a slice, width = longest row of the slice, padding column = own row) */
+  const int32_t* sl2_off;      /* [B][N2/64+2]  slice offsets in entries      */
+  const int32_t* sl2_col;      /* [B][NSE2]   */
+  const int32_t* sl1_off;      /* [B][NV/64+2] */
+  const int32_t* sl1_col;      /* [B][NSE1]   */
   const int32_t* g2_ptr;       /* [B][N2+1]   P2 dof <- element slots         */
   const int32_t* g2_src;       /* [B][6*NT]   slot = cell*6 + i               */
   const int32_t* g1_ptr;       /* [B][NV+1]   */
@@ -87,9 +95,9 @@ typedef struct mdq_ipcs_desc {
   const int32_t* af_facets;    /* [B][NAF][2] (cell, local edge)              */
   /* assembled operators, device, written by mdq_ipcs_assemble */
   double* geom;                /* [B][5][NT]  Jinv00,Jinv01,Jinv10,Jinv11,|det| */
-  double* A1;                  /* [B][NNZ2][4] row-scaled velocity blocks xx,xy,yx,yy */
-  double* Ms;                  /* [B][NNZ2]   symmetrically scaled P2 mass (with BCs) */
-  double* K1s;                 /* [B][NNZ1]   symmetrically scaled P1 stiffness (with BCs) */
+  double* A1;                  /* [B][NSE2][4] SELL, row-scaled velocity blocks xx,xy,yx,yy */
+  double* Ms;                  /* [B][NSE2]   SELL, symmetrically scaled P2 mass (with BCs) */
+  double* K1s;                 /* [B][NSE1]   SELL, symmetrically scaled P1 stiffness (with BCs) */
   double* lift1;               /* [B][N2][2]  A1_full[:,bc] g                 */
   double* lift3;               /* [B][N2][2]  M_full[:,bc] g                  */
   double* idiag1;              /* [B][N2][2]  1/diag(A1)                      */

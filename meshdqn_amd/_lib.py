@@ -23,6 +23,7 @@ class IpcsDesc(C.Structure):
     _fields_ = [
         ("B", C.c_int32), ("NV", C.c_int32), ("NT", C.c_int32), ("NE", C.c_int32),
         ("N2", C.c_int32), ("NNZ2", C.c_int32), ("NNZ1", C.c_int32), ("NAF", C.c_int32),
+        ("NSE2", C.c_int32), ("NSE1", C.c_int32),
         ("mu", C.c_double), ("rho", C.c_double), ("dt", C.c_double),
         ("rtol", C.c_double),
         ("maxit_u", C.c_int32), ("maxit_p", C.c_int32), ("maxit_m", C.c_int32), ("_pad0", C.c_int32),
@@ -30,6 +31,7 @@ class IpcsDesc(C.Structure):
         ("coords", C.c_void_p), ("cell_dofs", C.c_void_p), ("cell_outflow", C.c_void_p),
         ("rowptr2", C.c_void_p), ("colidx2", C.c_void_p), ("asm2_ptr", C.c_void_p), ("asm2_src", C.c_void_p),
         ("rowptr1", C.c_void_p), ("colidx1", C.c_void_p), ("asm1_ptr", C.c_void_p), ("asm1_src", C.c_void_p),
+        ("sl2_off", C.c_void_p), ("sl2_col", C.c_void_p), ("sl1_off", C.c_void_p), ("sl1_col", C.c_void_p),
         ("g2_ptr", C.c_void_p), ("g2_src", C.c_void_p), ("g1_ptr", C.c_void_p), ("g1_src", C.c_void_p),
         ("bcu_flag", C.c_void_p), ("bcu_gx", C.c_void_p), ("bcp_flag", C.c_void_p),
         ("af_facets", C.c_void_p),
@@ -62,6 +64,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64; import it FIRST so that our library binds to the
+    # same HIP runtime instance (two runtimes in one process do not share devices/streams)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise MeshDQNHipError(
             f"{LIB_PATH} is missing - build it with `python -m meshdqn_amd.build` "

@@ -40,6 +40,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
            "-I", os.path.join(HERE, "..", "include"), "-I", CSRC]
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
+    cmd += os.environ.get("MDQ_CFLAGS", "").split()
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     cmd += ["-o", LIB + ".tmp"]
     res = subprocess.run(cmd, capture_output=True, text=True)

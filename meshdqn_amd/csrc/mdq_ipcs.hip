@@ -42,13 +42,14 @@ struct EnvView {
   const int8_t* cell_outflow;
   const int32_t *rowptr2, *colidx2, *asm2_ptr, *asm2_src;
   const int32_t *rowptr1, *colidx1, *asm1_ptr, *asm1_src;
+  const int32_t *sl2_off, *sl2_col, *sl1_off, *sl1_col;
   const int32_t *g2_ptr, *g2_src, *g1_ptr, *g1_src;
   const uint8_t* bcu_flag;
   const double* bcu_gx;
   const uint8_t* bcp_flag;
   const int32_t* af_facets;
   double* geom;  // [5][NT]
-  double* A1;    // [nnz2][4]
+  double* A1;    // SELL [entries][4]
   double* Ms;
   double* K1s;
   double2* lift1;
@@ -81,6 +82,10 @@ __device__ __forceinline__ EnvView env_view(const mdq_ipcs_desc& d, int b) {
   v.colidx1 = d.colidx1 + B * d.NNZ1;
   v.asm1_ptr = d.asm1_ptr + B * (d.NNZ1 + 1);
   v.asm1_src = d.asm1_src + B * 9 * d.NT;
+  v.sl2_off = d.sl2_off + B * (d.N2 / 64 + 2);
+  v.sl2_col = d.sl2_col + B * d.NSE2;
+  v.sl1_off = d.sl1_off + B * (d.NV / 64 + 2);
+  v.sl1_col = d.sl1_col + B * d.NSE1;
   v.g2_ptr = d.g2_ptr + B * (d.N2 + 1);
   v.g2_src = d.g2_src + B * 6 * d.NT;
   v.g1_ptr = d.g1_ptr + B * (d.NV + 1);
@@ -90,9 +95,9 @@ __device__ __forceinline__ EnvView env_view(const mdq_ipcs_desc& d, int b) {
   v.bcp_flag = d.bcp_flag + B * d.NV;
   v.af_facets = d.af_facets + B * d.NAF * 2;
   v.geom = d.geom + B * 5 * d.NT;
-  v.A1 = d.A1 + B * d.NNZ2 * 4;
-  v.Ms = d.Ms + B * d.NNZ2;
-  v.K1s = d.K1s + B * d.NNZ1;
+  v.A1 = d.A1 + B * d.NSE2 * 4;
+  v.Ms = d.Ms + B * d.NSE2;
+  v.K1s = d.K1s + B * d.NSE1;
   v.lift1 = reinterpret_cast<double2*>(d.lift1) + B * d.N2;
   v.lift3 = reinterpret_cast<double2*>(d.lift3) + B * d.N2;
   v.idiag1 = reinterpret_cast<double2*>(d.idiag1) + B * d.N2;
@@ -203,14 +208,20 @@ __global__ __launch_bounds__(WG) void assemble_kernel(mdq_ipcs_desc d) {
   }
   __syncthreads();
 
+  // position of entry j of row r inside the SELL-64 arrays
+  auto pos2 = [&](int r, int j) { return v.sl2_off[r >> 6] + j * 64 + (r & 63); };
+  auto pos1 = [&](int r, int j) { return v.sl1_off[r >> 6] + j * 64 + (r & 63); };
+
   // ---- phase 1: full (pre-BC) operator values, one thread per non-zero
   for (int k = tid; k < v.nnz2; k += WG) {
     double m = 0.0, kxx = 0.0, kxy = 0.0, kyx = 0.0, kyy = 0.0;
     double bxx = 0.0, bxy = 0.0, byx = 0.0, byy = 0.0;
     const int s0 = v.asm2_ptr[k], s1 = v.asm2_ptr[k + 1];
+    int row = 0;
     for (int s = s0; s < s1; ++s) {
       const int slot = v.asm2_src[s];
       const int e = slot / 36, ij = slot - e * 36, i = ij / 6, j = ij - i * 6;
+      if (s == s0) row = v.cell_dofs[i * v.NT + e];
       const Geo g = load_geo(v, e);
       m += g.det * c_tab.Mhat[i][j];
       // K^{ab}_ij = det * sum_{cd} Jinv[c][a] Jinv[d][b] Ghat[c][d][i][j]
@@ -239,22 +250,25 @@ __global__ __launch_bounds__(WG) void assemble_kernel(mdq_ipcs_desc d) {
     blk.y = 0.5 * mu * kyx - 0.5 * mu * bxy;
     blk.z = 0.5 * mu * kxy - 0.5 * mu * byx;
     blk.w = a * m + 0.5 * mu * (L + kyy) - 0.5 * mu * byy;
-    reinterpret_cast<double4*>(v.A1)[k] = blk;
-    v.Ms[k] = m;
+    const int ps = pos2(row, k - v.rowptr2[row]);
+    reinterpret_cast<double4*>(v.A1)[ps] = blk;
+    v.Ms[ps] = m;
   }
   for (int k = tid; k < v.nnz1; k += WG) {
     double kk = 0.0;
     const int s0 = v.asm1_ptr[k], s1 = v.asm1_ptr[k + 1];
+    int row = 0;
     for (int s = s0; s < s1; ++s) {
       const int slot = v.asm1_src[s];
       const int e = slot / 9, ij = slot - e * 9, i = ij / 3, j = ij - i * 3;
+      if (s == s0) row = v.cell_dofs[i * v.NT + e];
       const Geo g = load_geo(v, e);
       // grad lambda_i = Jinv^T dl_i, dl = (-1,-1),(1,0),(0,1)
       const double dix = sel3(i, -g.j00 - g.j10, g.j00, g.j10), diy = sel3(i, -g.j01 - g.j11, g.j01, g.j11);
       const double djx = sel3(j, -g.j00 - g.j10, g.j00, g.j10), djy = sel3(j, -g.j01 - g.j11, g.j01, g.j11);
       kk += 0.5 * g.det * (dix * djx + diy * djy);
     }
-    v.K1s[k] = kk;
+    v.K1s[pos1(row, k - v.rowptr1[row])] = kk;
   }
   __syncthreads();
 
@@ -262,19 +276,20 @@ __global__ __launch_bounds__(WG) void assemble_kernel(mdq_ipcs_desc d) {
   for (int r = tid; r < v.n2; r += WG) {
     double l1x = 0.0, l1y = 0.0, l3x = 0.0, dx = 1.0, dy = 1.0, dm = 1.0;
     const bool fr = v.bcu_flag[r] != 0;
-    for (int k = v.rowptr2[r]; k < v.rowptr2[r + 1]; ++k) {
-      const int c = v.colidx2[k];
-      const double4 blk = reinterpret_cast<const double4*>(v.A1)[k];
+    const int k0 = v.rowptr2[r], len = v.rowptr2[r + 1] - k0;
+    for (int j = 0; j < len; ++j) {
+      const int c = v.colidx2[k0 + j], ps = pos2(r, j);
+      const double4 blk = reinterpret_cast<const double4*>(v.A1)[ps];
       if (v.bcu_flag[c]) {
         const double gx = v.bcu_gx[c];  // gy = 0 for every BC of the reference
         l1x += blk.x * gx;
         l1y += blk.z * gx;
-        l3x += v.Ms[k] * gx;
+        l3x += v.Ms[ps] * gx;
       }
       if (c == r && !fr) {
         dx = blk.x;
         dy = blk.w;
-        dm = v.Ms[k];
+        dm = v.Ms[ps];
       }
     }
     v.lift1[r] = make_double2(l1x, l1y);
@@ -285,51 +300,72 @@ __global__ __launch_bounds__(WG) void assemble_kernel(mdq_ipcs_desc d) {
   for (int r = tid; r < v.nv; r += WG) {
     double dk = 1.0;
     if (!v.bcp_flag[r]) {
-      for (int k = v.rowptr1[r]; k < v.rowptr1[r + 1]; ++k)
-        if (v.colidx1[k] == r) dk = v.K1s[k];
+      const int k0 = v.rowptr1[r], len = v.rowptr1[r + 1] - k0;
+      for (int j = 0; j < len; ++j)
+        if (v.colidx1[k0 + j] == r) dk = v.K1s[pos1(r, j)];
     }
     v.sdiagK[r] = sqrt(dk);
   }
   __syncthreads();
 
-  // ---- phase 3: symmetric elimination + Jacobi scaling
-  for (int r = tid; r < v.n2; r += WG) {
-    const bool fr = v.bcu_flag[r] != 0;
-    const double2 id = v.idiag1[r];
-    const double sr = v.sdiagM[r];
-    for (int k = v.rowptr2[r]; k < v.rowptr2[r + 1]; ++k) {
-      const int c = v.colidx2[k];
-      const bool fc = v.bcu_flag[c] != 0;
-      double4 blk = reinterpret_cast<const double4*>(v.A1)[k];
-      double m = v.Ms[k];
-      if (fr || fc) {
-        const double one = (c == r) ? 1.0 : 0.0;
-        blk = make_double4(one, 0.0, 0.0, one);
-        m = one;
-      } else {
-        blk.x *= id.x;
-        blk.y *= id.x;
-        blk.z *= id.y;
-        blk.w *= id.y;
-        m = m / (sr * v.sdiagM[c]);
+  // ---- phase 3: symmetric elimination + Jacobi scaling (+ zero the SELL padding)
+  const int rows2 = ((v.n2 + 63) >> 6) << 6;
+  for (int r = tid; r < rows2; r += WG) {
+    const int width = (v.sl2_off[(r >> 6) + 1] - v.sl2_off[r >> 6]) >> 6;
+    int len = 0;
+    if (r < v.n2) {
+      const bool fr = v.bcu_flag[r] != 0;
+      const double2 id = v.idiag1[r];
+      const double sr = v.sdiagM[r];
+      const int k0 = v.rowptr2[r];
+      len = v.rowptr2[r + 1] - k0;
+      for (int j = 0; j < len; ++j) {
+        const int c = v.colidx2[k0 + j], ps = pos2(r, j);
+        const bool fc = v.bcu_flag[c] != 0;
+        double4 blk = reinterpret_cast<const double4*>(v.A1)[ps];
+        double m = v.Ms[ps];
+        if (fr || fc) {
+          const double one = (c == r) ? 1.0 : 0.0;
+          blk = make_double4(one, 0.0, 0.0, one);
+          m = one;
+        } else {
+          blk.x *= id.x;
+          blk.y *= id.x;
+          blk.z *= id.y;
+          blk.w *= id.y;
+          m = m / (sr * v.sdiagM[c]);
+        }
+        reinterpret_cast<double4*>(v.A1)[ps] = blk;
+        v.Ms[ps] = m;
       }
-      reinterpret_cast<double4*>(v.A1)[k] = blk;
-      v.Ms[k] = m;
+    }
+    for (int j = len; j < width; ++j) {
+      const int ps = pos2(r, j);
+      reinterpret_cast<double4*>(v.A1)[ps] = make_double4(0.0, 0.0, 0.0, 0.0);
+      v.Ms[ps] = 0.0;
     }
   }
-  for (int r = tid; r < v.nv; r += WG) {
-    const bool fr = v.bcp_flag[r] != 0;
-    const double sr = v.sdiagK[r];
-    for (int k = v.rowptr1[r]; k < v.rowptr1[r + 1]; ++k) {
-      const int c = v.colidx1[k];
-      const bool fc = v.bcp_flag[c] != 0;
-      double kk = v.K1s[k];
-      if (fr || fc)
-        kk = (c == r) ? 1.0 : 0.0;
-      else
-        kk = kk / (sr * v.sdiagK[c]);
-      v.K1s[k] = kk;
+  const int rows1 = ((v.nv + 63) >> 6) << 6;
+  for (int r = tid; r < rows1; r += WG) {
+    const int width = (v.sl1_off[(r >> 6) + 1] - v.sl1_off[r >> 6]) >> 6;
+    int len = 0;
+    if (r < v.nv) {
+      const bool fr = v.bcp_flag[r] != 0;
+      const double sr = v.sdiagK[r];
+      const int k0 = v.rowptr1[r];
+      len = v.rowptr1[r + 1] - k0;
+      for (int j = 0; j < len; ++j) {
+        const int c = v.colidx1[k0 + j], ps = pos1(r, j);
+        const bool fc = v.bcp_flag[c] != 0;
+        double kk = v.K1s[ps];
+        if (fr || fc)
+          kk = (c == r) ? 1.0 : 0.0;
+        else
+          kk = kk / (sr * v.sdiagK[c]);
+        v.K1s[ps] = kk;
+      }
     }
+    for (int j = len; j < width; ++j) v.K1s[pos1(r, j)] = 0.0;
   }
 }
 
@@ -511,77 +547,71 @@ __device__ inline void elem_rhs3(const EnvView& v, const mdq_ipcs_desc& d, const
 }
 
 // ================================================================== sparse kernels (workgroup-wide)
+//
+// SELL-64, one thread per row: wave w owns slices w, w+16, ... (rows tid, tid+1024, ...), the
+// same ownership as every `for (i = tid; i < n; i += WG)` vector pass, so a thread only ever
+// reads/writes its own entries of the Krylov vectors; only the SpMV input vector is gathered.
+// Matrix loads are perfectly coalesced (64 lanes x 32 B / 8 B contiguous per instruction).
 
-// y = A x for the 2x2-block CSR velocity operator; G lanes cooperate on one block row.
-template <int G, class Epi>
-__device__ __forceinline__ void spmv_bcsr2(const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
-                                           const double* __restrict__ A, const double2* __restrict__ x, int n,
-                                           Epi epi) {
-  const int g = threadIdx.x / G, l = threadIdx.x % G;
+template <class Epi>
+__device__ __forceinline__ void spmv_sell_b2(const int32_t* __restrict__ sl_off, const int32_t* __restrict__ sl_col,
+                                             const double* __restrict__ A, const double2* x, int n, Epi epi) {
+  const int lane = threadIdx.x & 63;
+  const int nsl = (n + 63) >> 6;
   const double4* __restrict__ A4 = reinterpret_cast<const double4*>(A);
-  for (int base = 0; base < n; base += WG / G) {
-    const int row = base + g;
+  for (int s = threadIdx.x >> 6; s < nsl; s += NWAVE) {
+    const int base = sl_off[s], w = (sl_off[s + 1] - base) >> 6;
+    const double4* a = A4 + base + lane;
+    const int32_t* c = sl_col + base + lane;
     double y0 = 0.0, y1 = 0.0;
-    if (row < n) {
-      const int s = rp[row], e = rp[row + 1];
-      for (int k = s + l; k < e; k += G) {
-        const double4 a = A4[k];
-        const double2 xv = x[ci[k]];
-        y0 += a.x * xv.x + a.y * xv.y;
-        y1 += a.z * xv.x + a.w * xv.y;
-      }
+#pragma unroll 4
+    for (int j = 0; j < w; ++j) {
+      const double4 av = a[j * 64];
+      const double2 xv = x[c[j * 64]];
+      y0 += av.x * xv.x + av.y * xv.y;
+      y1 += av.z * xv.x + av.w * xv.y;
     }
-#pragma unroll
-    for (int off = G / 2; off > 0; off >>= 1) {
-      y0 += __shfl_down(y0, off, G);
-      y1 += __shfl_down(y1, off, G);
-    }
-    if (l == 0 && row < n) epi(row, y0, y1);
+    const int row = (s << 6) + lane;
+    if (row < n) epi(row, y0, y1);
   }
 }
 
-// y = A x, scalar CSR, two right-hand sides interleaved (P2 mass, both velocity components)
-template <int G, class Epi>
-__device__ __forceinline__ void spmv_csr_2rhs(const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
-                                              const double* __restrict__ A, const double2* __restrict__ x, int n,
-                                              Epi epi) {
-  const int g = threadIdx.x / G, l = threadIdx.x % G;
-  for (int base = 0; base < n; base += WG / G) {
-    const int row = base + g;
+template <class Epi>
+__device__ __forceinline__ void spmv_sell_2rhs(const int32_t* __restrict__ sl_off, const int32_t* __restrict__ sl_col,
+                                               const double* __restrict__ A, const double2* x, int n, Epi epi) {
+  const int lane = threadIdx.x & 63;
+  const int nsl = (n + 63) >> 6;
+  for (int s = threadIdx.x >> 6; s < nsl; s += NWAVE) {
+    const int base = sl_off[s], w = (sl_off[s + 1] - base) >> 6;
+    const double* a = A + base + lane;
+    const int32_t* c = sl_col + base + lane;
     double y0 = 0.0, y1 = 0.0;
-    if (row < n) {
-      const int s = rp[row], e = rp[row + 1];
-      for (int k = s + l; k < e; k += G) {
-        const double a = A[k];
-        const double2 xv = x[ci[k]];
-        y0 += a * xv.x;
-        y1 += a * xv.y;
-      }
+#pragma unroll 4
+    for (int j = 0; j < w; ++j) {
+      const double av = a[j * 64];
+      const double2 xv = x[c[j * 64]];
+      y0 += av * xv.x;
+      y1 += av * xv.y;
     }
-#pragma unroll
-    for (int off = G / 2; off > 0; off >>= 1) {
-      y0 += __shfl_down(y0, off, G);
-      y1 += __shfl_down(y1, off, G);
-    }
-    if (l == 0 && row < n) epi(row, y0, y1);
+    const int row = (s << 6) + lane;
+    if (row < n) epi(row, y0, y1);
   }
 }
 
-// y = A x, scalar CSR, one right-hand side (P1 pressure operator; arrays may live in LDS)
-template <int G, class Epi>
-__device__ __forceinline__ void spmv_csr(const int32_t* rp, const int32_t* ci, const double* A, const double* x,
-                                         int n, Epi epi) {
-  const int g = threadIdx.x / G, l = threadIdx.x % G;
-  for (int base = 0; base < n; base += WG / G) {
-    const int row = base + g;
+template <class Epi>
+__device__ __forceinline__ void spmv_sell(const int32_t* sl_off, const int32_t* sl_col, const double* A,
+                                          const double* x, int n, Epi epi) {
+  const int lane = threadIdx.x & 63;
+  const int nsl = (n + 63) >> 6;
+  for (int s = threadIdx.x >> 6; s < nsl; s += NWAVE) {
+    const int base = sl_off[s], w = (sl_off[s + 1] - base) >> 6;
+    const double* a = A + base + lane;
+    const int32_t* c = sl_col + base + lane;
     double y0 = 0.0;
-    if (row < n) {
-      const int s = rp[row], e = rp[row + 1];
-      for (int k = s + l; k < e; k += G) y0 += A[k] * x[ci[k]];
-    }
-#pragma unroll
-    for (int off = G / 2; off > 0; off >>= 1) y0 += __shfl_down(y0, off, G);
-    if (l == 0 && row < n) epi(row, y0);
+#pragma unroll 3
+    for (int j = 0; j < w; ++j) y0 += a[j * 64] * x[c[j * 64]];
+    const int row = (s << 6) + lane;
+    if (row < n) epi(row, y0);
   }
 }
 
@@ -589,19 +619,20 @@ __device__ __forceinline__ void spmv_csr(const int32_t* rp, const int32_t* ci, c
 
 // BiCGStab on the row-scaled velocity system  (D^-1 A1) x = D^-1 b.
 // On entry r holds D^-1 b and x the initial guess; on exit x holds the solution.
+// gp / gr: the two vectors that SpMVs gather from (p and r=s); they live in LDS when they fit.
 __device__ inline int bicgstab_velocity(const EnvView& v, double rtol, int maxit, double2* __restrict__ x,
-                                        double2* __restrict__ r, double2* __restrict__ rh, double2* __restrict__ p,
+                                        double2* gr, double2* __restrict__ rh, double2* gp,
                                         double2* __restrict__ vv, double2* __restrict__ t, double* red) {
   const int n = v.n2, tid = threadIdx.x;
-  // r = b - A x ; bb = (b,b) ; rr = (r,r)
+  // r = b - A x (x gathered from global once); bb = (b,b); rr = (r,r)
   double acc[2] = {0.0, 0.0};
   __syncthreads();
-  spmv_bcsr2<16>(v.rowptr2, v.colidx2, v.A1, x, n, [&](int row, double y0, double y1) {
-    const double2 b = r[row];
+  spmv_sell_b2(v.sl2_off, v.sl2_col, v.A1, x, n, [&](int row, double y0, double y1) {
+    const double2 b = gr[row];
     const double2 rr = make_double2(b.x - y0, b.y - y1);
-    r[row] = rr;
+    gr[row] = rr;
     rh[row] = rr;
-    p[row] = make_double2(0.0, 0.0);
+    gp[row] = make_double2(0.0, 0.0);
     vv[row] = make_double2(0.0, 0.0);
     acc[0] += b.x * b.x + b.y * b.y;
     acc[1] += rr.x * rr.x + rr.y * rr.y;
@@ -617,12 +648,12 @@ __device__ inline int bicgstab_velocity(const EnvView& v, double rtol, int maxit
     ++it;
     const double beta = (rho / rho_old) * (alpha / omega);
     for (int i = tid; i < n; i += WG) {
-      const double2 ri = r[i], pi = p[i], vi = vv[i];
-      p[i] = make_double2(ri.x + beta * (pi.x - omega * vi.x), ri.y + beta * (pi.y - omega * vi.y));
+      const double2 ri = gr[i], pi = gp[i], vi = vv[i];
+      gp[i] = make_double2(ri.x + beta * (pi.x - omega * vi.x), ri.y + beta * (pi.y - omega * vi.y));
     }
     __syncthreads();
     double a1[1] = {0.0};
-    spmv_bcsr2<16>(v.rowptr2, v.colidx2, v.A1, p, n, [&](int row, double y0, double y1) {
+    spmv_sell_b2(v.sl2_off, v.sl2_col, v.A1, gp, n, [&](int row, double y0, double y1) {
       vv[row] = make_double2(y0, y1);
       const double2 h = rh[row];
       a1[0] += h.x * y0 + h.y * y1;
@@ -632,24 +663,24 @@ __device__ inline int bicgstab_velocity(const EnvView& v, double rtol, int maxit
     alpha = rho / a1[0];
     double a2[1] = {0.0};
     for (int i = tid; i < n; i += WG) {
-      const double2 ri = r[i], vi = vv[i];
+      const double2 ri = gr[i], vi = vv[i];
       const double2 s = make_double2(ri.x - alpha * vi.x, ri.y - alpha * vi.y);
-      r[i] = s;
+      gr[i] = s;
       a2[0] += s.x * s.x + s.y * s.y;
     }
-    block_sum<1>(a2, red);  // (barriers inside also publish s)
+    block_sum<1>(a2, red);  // (its barriers also publish s)
     if (!(a2[0] > tol2)) {
       for (int i = tid; i < n; i += WG) {
-        const double2 xi = x[i], pi = p[i];
+        const double2 xi = x[i], pi = gp[i];
         x[i] = make_double2(xi.x + alpha * pi.x, xi.y + alpha * pi.y);
       }
       break;
     }
     double a3[2] = {0.0, 0.0};
-    spmv_bcsr2<16>(v.rowptr2, v.colidx2, v.A1, r, n, [&](int row, double y0, double y1) {
+    spmv_sell_b2(v.sl2_off, v.sl2_col, v.A1, gr, n, [&](int row, double y0, double y1) {
       t[row] = make_double2(y0, y1);
-      const double2 s = r[row];
-      a3[0] += y0 * s.x + y1 * s.y;
+      const double2 sv = gr[row];
+      a3[0] += y0 * sv.x + y1 * sv.y;
       a3[1] += y0 * y0 + y1 * y1;
     });
     block_sum<2>(a3, red);
@@ -657,10 +688,10 @@ __device__ inline int bicgstab_velocity(const EnvView& v, double rtol, int maxit
     omega = a3[0] / a3[1];
     double a4[2] = {0.0, 0.0};
     for (int i = tid; i < n; i += WG) {
-      const double2 xi = x[i], pi = p[i], si = r[i], ti = t[i], hi = rh[i];
+      const double2 ti = t[i], xi = x[i], pi = gp[i], si = gr[i], hi = rh[i];
       x[i] = make_double2(xi.x + alpha * pi.x + omega * si.x, xi.y + alpha * pi.y + omega * si.y);
       const double2 rn = make_double2(si.x - omega * ti.x, si.y - omega * ti.y);
-      r[i] = rn;
+      gr[i] = rn;
       a4[0] += rn.x * rn.x + rn.y * rn.y;
       a4[1] += hi.x * rn.x + hi.y * rn.y;
     }
@@ -676,17 +707,17 @@ __device__ inline int bicgstab_velocity(const EnvView& v, double rtol, int maxit
 }
 
 // CG on the symmetrically scaled mass system, two right-hand sides at once (x and y components).
-// On entry r holds S^-1 b, x the initial guess S x0; on exit x holds S x.
+// On entry r holds S^-1 b, x the initial guess S x0; on exit x holds S x.  gp: gathered vector.
 __device__ inline int cg_mass(const EnvView& v, double rtol, int maxit, double2* __restrict__ x,
-                              double2* __restrict__ r, double2* __restrict__ p, double2* __restrict__ q, double* red) {
+                              double2* __restrict__ r, double2* gp, double2* __restrict__ q, double* red) {
   const int n = v.n2, tid = threadIdx.x;
   double acc[2] = {0.0, 0.0};
   __syncthreads();
-  spmv_csr_2rhs<16>(v.rowptr2, v.colidx2, v.Ms, x, n, [&](int row, double y0, double y1) {
+  spmv_sell_2rhs(v.sl2_off, v.sl2_col, v.Ms, x, n, [&](int row, double y0, double y1) {
     const double2 b = r[row];
     const double2 rr = make_double2(b.x - y0, b.y - y1);
     r[row] = rr;
-    p[row] = rr;
+    gp[row] = rr;
     acc[0] += b.x * b.x + b.y * b.y;
     acc[1] += rr.x * rr.x + rr.y * rr.y;
   });
@@ -700,9 +731,9 @@ __device__ inline int cg_mass(const EnvView& v, double rtol, int maxit, double2*
   while (it < maxit) {
     ++it;
     double a1[1] = {0.0};
-    spmv_csr_2rhs<16>(v.rowptr2, v.colidx2, v.Ms, p, n, [&](int row, double y0, double y1) {
+    spmv_sell_2rhs(v.sl2_off, v.sl2_col, v.Ms, gp, n, [&](int row, double y0, double y1) {
       q[row] = make_double2(y0, y1);
-      const double2 pi = p[row];
+      const double2 pi = gp[row];
       a1[0] += pi.x * y0 + pi.y * y1;
     });
     block_sum<1>(a1, red);
@@ -710,7 +741,7 @@ __device__ inline int cg_mass(const EnvView& v, double rtol, int maxit, double2*
     const double alpha = rr / a1[0];
     double a2[1] = {0.0};
     for (int i = tid; i < n; i += WG) {
-      const double2 xi = x[i], pi = p[i], ri = r[i], qi = q[i];
+      const double2 xi = x[i], pi = gp[i], ri = r[i], qi = q[i];
       x[i] = make_double2(xi.x + alpha * pi.x, xi.y + alpha * pi.y);
       const double2 rn = make_double2(ri.x - alpha * qi.x, ri.y - alpha * qi.y);
       r[i] = rn;
@@ -722,8 +753,8 @@ __device__ inline int cg_mass(const EnvView& v, double rtol, int maxit, double2*
     const double beta = rr_new / rr;
     rr = rr_new;
     for (int i = tid; i < n; i += WG) {
-      const double2 ri = r[i], pi = p[i];
-      p[i] = make_double2(ri.x + beta * pi.x, ri.y + beta * pi.y);
+      const double2 ri = r[i], pi = gp[i];
+      gp[i] = make_double2(ri.x + beta * pi.x, ri.y + beta * pi.y);
     }
     __syncthreads();
   }
@@ -732,12 +763,12 @@ __device__ inline int cg_mass(const EnvView& v, double rtol, int maxit, double2*
 }
 
 // CG on the symmetrically scaled pressure system; vectors (and, when it fits, the matrix) in LDS.
-__device__ inline int cg_pressure(int n, const int32_t* rp, const int32_t* ci, const double* A, double rtol,
+__device__ inline int cg_pressure(int n, const int32_t* sl_off, const int32_t* sl_col, const double* A, double rtol,
                                   int maxit, double* x, double* r, double* p, double* q, double* red) {
   const int tid = threadIdx.x;
   double acc[2] = {0.0, 0.0};
   __syncthreads();
-  spmv_csr<8>(rp, ci, A, x, n, [&](int row, double y0) {
+  spmv_sell(sl_off, sl_col, A, x, n, [&](int row, double y0) {
     const double b = r[row];
     const double rr = b - y0;
     r[row] = rr;
@@ -754,7 +785,7 @@ __device__ inline int cg_pressure(int n, const int32_t* rp, const int32_t* ci, c
   while (it < maxit) {
     ++it;
     double a1[1] = {0.0};
-    spmv_csr<8>(rp, ci, A, p, n, [&](int row, double y0) {
+    spmv_sell(sl_off, sl_col, A, p, n, [&](int row, double y0) {
       q[row] = y0;
       a1[0] += p[row] * y0;
     });
@@ -846,24 +877,42 @@ __global__ __launch_bounds__(WG) void probe_kernel(mdq_ipcs_desc d, int nfields,
 
 // ================================================================== time stepping
 
-// dynamic LDS: [red 64 doubles][pressure vectors 4*NVp][optional K1 matrix: values, colidx, rowptr]
-template <bool K1_IN_LDS>
+// dynamic LDS: [red 64 doubles][union: velocity gather vectors p,r (double2[N2p] each)
+//                                  | pressure: 4 vectors [NVp] + K1 in SELL form (values, columns, slice offsets)]
+struct LdsPlan {
+  int N2p, NVp;
+  size_t vel_bytes, prs_vec_bytes, prs_mat_bytes;
+};
+__host__ __device__ inline LdsPlan lds_plan(int N2, int NV, int NSE1) {
+  LdsPlan P;
+  P.N2p = (N2 + 1) & ~1;
+  P.NVp = (NV + 1) & ~1;
+  P.vel_bytes = 2 * sizeof(double2) * (size_t)P.N2p;
+  P.prs_vec_bytes = 4 * sizeof(double) * (size_t)P.NVp;
+  P.prs_mat_bytes = sizeof(double) * (size_t)NSE1 + sizeof(int32_t) * ((size_t)NSE1 + (NSE1 & 1)) +
+                    sizeof(int32_t) * (size_t)(((NV / 64 + 2) + 1) & ~1);
+  return P;
+}
+
+template <bool VEL_LDS, bool K1_LDS>
 __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps, double* drag, double* lift,
                                                      int32_t* iters) {
   extern __shared__ __align__(16) double smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const EnvView v = env_view(d, b);
   const int n2 = v.n2, nv = v.nv;
-  const int NVp = (d.NV + 1) & ~1;
+  const LdsPlan P = lds_plan(d.N2, d.NV, d.NSE1);
 
-  double* red = smem;  // 64
-  double* px = smem + 64;
-  double* pr = px + NVp;
-  double* pp = pr + NVp;
-  double* pq = pp + NVp;
-  double* lK = pq + NVp;                                          // [NNZ1]
-  int32_t* lci = reinterpret_cast<int32_t*>(lK + d.NNZ1);        // [NNZ1]
-  int32_t* lrp = lci + d.NNZ1 + (d.NNZ1 & 1);                     // [NV+1]
+  double* red = smem;  // 64 doubles
+  double* U = smem + 64;
+  // pressure view of the union
+  double* px = U;
+  double* pr = px + P.NVp;
+  double* pp = pr + P.NVp;
+  double* pq = pp + P.NVp;
+  double* lK = pq + P.NVp;                                            // [NSE1]
+  int32_t* lci = reinterpret_cast<int32_t*>(lK + d.NSE1);            // [NSE1]
+  int32_t* lso = lci + d.NSE1 + (d.NSE1 & 1);                         // [NV/64+2]
 
   // workspace carve-up (global; stays in this CU's L2 slice)
   double* w = v.work;
@@ -876,25 +925,31 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
   double2* vv = vp + d.N2;
   double2* vt = vv + d.N2;
   double* pnew = reinterpret_cast<double*>(vt + d.N2);
+  // velocity view of the union (or global fall-back)
+  double2* gp = VEL_LDS ? reinterpret_cast<double2*>(U) : vp;
+  double2* gr = VEL_LDS ? reinterpret_cast<double2*>(U) + P.N2p : vr;
 
-  if (K1_IN_LDS) {
-    for (int k = tid; k < v.nnz1; k += WG) {
-      lK[k] = v.K1s[k];
-      lci[k] = v.colidx1[k];
-    }
-    for (int k = tid; k <= nv; k += WG) lrp[k] = v.rowptr1[k];
-  }
-  const int32_t* rp1 = K1_IN_LDS ? lrp : v.rowptr1;
-  const int32_t* ci1 = K1_IN_LDS ? lci : v.colidx1;
-  const double* K1 = K1_IN_LDS ? lK : v.K1s;
+  const int nsl1 = (nv + 63) >> 6;
+  const int32_t* so1 = K1_LDS ? lso : v.sl1_off;
+  const int32_t* ci1 = K1_LDS ? lci : v.sl1_col;
+  const double* K1 = K1_LDS ? lK : v.K1s;
 
   int it_u = 0, it_p = 0, it_m = 0;
+#ifdef MDQ_PROFILE
+  long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tprev = __builtin_amdgcn_s_memtime();
+#define MDQ_STAMP(k) { __syncthreads(); long long tn = __builtin_amdgcn_s_memtime(); prof[k] += tn - tprev; tprev = tn; }
+#else
+#define MDQ_STAMP(k)
+#endif
   __syncthreads();
 
   for (int step = 0; step < nsteps; ++step) {
     // ---------------- step 1: tentative velocity
+    MDQ_STAMP(7)
     elem_rhs1(v, d, v.u_n, v.p_n, escr2);
     __syncthreads();
+    MDQ_STAMP(0)
     for (int i = tid; i < n2; i += WG) {
       double2 bsum = make_double2(0.0, 0.0);
       for (int s = v.g2_ptr[i]; s < v.g2_ptr[i + 1]; ++s) {
@@ -908,12 +963,22 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
         bi = make_double2(v.bcu_gx[i], 0.0);
       else
         bi = make_double2((bsum.x - l.x) * id.x, (bsum.y - l.y) * id.y);
-      vr[i] = bi;
+      gr[i] = bi;
       xs[i] = v.u_n[i];
     }
-    it_u += bicgstab_velocity(v, d.rtol, d.maxit_u, xs, vr, vh, vp, vv, vt, red);
+    MDQ_STAMP(1)
+    it_u += bicgstab_velocity(v, d.rtol, d.maxit_u, xs, gr, vh, gp, vv, vt, red);
+    MDQ_STAMP(2)
 
     // ---------------- step 2: pressure
+    if (K1_LDS) {
+      const int ne1 = v.sl1_off[nsl1];
+      for (int k = tid; k < ne1; k += WG) {
+        lK[k] = v.K1s[k];
+        lci[k] = v.sl1_col[k];
+      }
+      for (int k = tid; k <= nsl1; k += WG) lso[k] = v.sl1_off[k];
+    }
     elem_rhs2(v, d, xs, v.p_n, escr1);
     __syncthreads();
     for (int i = tid; i < nv; i += WG) {
@@ -923,7 +988,9 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
       pr[i] = v.bcp_flag[i] ? 0.0 : bsum / sd;
       px[i] = v.p_n[i] * sd;
     }
-    it_p += cg_pressure(nv, rp1, ci1, K1, d.rtol, d.maxit_p, px, pr, pp, pq, red);
+    MDQ_STAMP(3)
+    it_p += cg_pressure(nv, so1, ci1, K1, d.rtol, d.maxit_p, px, pr, pp, pq, red);
+    MDQ_STAMP(4)
     for (int i = tid; i < nv; i += WG) pnew[i] = px[i] / v.sdiagK[i];
     __syncthreads();
 
@@ -948,7 +1015,9 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
       const double2 x0 = xs[i];
       xs[i] = make_double2(x0.x * sd, x0.y * sd);
     }
-    it_m += cg_mass(v, d.rtol, d.maxit_m, xs, vr, vp, vv, red);
+    MDQ_STAMP(5)
+    it_m += cg_mass(v, d.rtol, d.maxit_m, xs, vr, gp, vv, red);
+    MDQ_STAMP(6)
 
     // ---------------- update state + probes
     for (int i = tid; i < n2; i += WG) {
@@ -965,11 +1034,28 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
       lift[(int64_t)b * nsteps + step] = li;
     }
   }
+#ifdef MDQ_PROFILE
+  if (tid == 0) {
+    double* pw = pnew + d.NV;
+    for (int k = 0; k < 8; ++k) pw[k] += (double)prof[k];
+  }
+#endif
   if (tid == 0 && iters) {
     iters[3 * b + 0] += it_u;
     iters[3 * b + 1] += it_p;
     iters[3 * b + 2] += it_m;
   }
+}
+
+template <bool VEL_LDS, bool K1_LDS>
+static hipError_t launch_evolve(const mdq_ipcs_desc* d, size_t lds, int nsteps, double* drag, double* lift,
+                                int32_t* iters, hipStream_t stream) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&evolve_kernel<VEL_LDS, K1_LDS>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((evolve_kernel<VEL_LDS, K1_LDS>), dim3(d->B), dim3(WG), lds, stream, *d, nsteps, drag, lift,
+                     iters);
+  return hipGetLastError();
 }
 
 // ================================================================== host side
@@ -1074,27 +1160,24 @@ int mdq_ipcs_evolve(const mdq_ipcs_desc* d, int32_t nsteps, double* drag, double
   if (nsteps <= 0) return fail_msg("nsteps must be positive");
   if (!drag || !lift) return fail_msg("drag/lift output pointers are required");
   if (int rc = ensure_tables()) return rc;
-  const int NVp = (d->NV + 1) & ~1;
-  size_t lds_small = sizeof(double) * (64 + 4 * (size_t)NVp);
-  size_t lds_full = lds_small + sizeof(double) * d->NNZ1 + sizeof(int32_t) * ((size_t)d->NNZ1 + (d->NNZ1 & 1)) +
-                    sizeof(int32_t) * ((size_t)d->NV + 2);
-  const size_t LDS_MAX = 160 * 1024;
-  if (lds_small > LDS_MAX) return fail_msg("mesh too large for the LDS-resident pressure vectors");
+  const LdsPlan P = lds_plan(d->N2, d->NV, d->NSE1);
+  const size_t LDS_MAX = 160 * 1024, red_bytes = 64 * sizeof(double);
+  if (red_bytes + P.prs_vec_bytes > LDS_MAX) return fail_msg("mesh too large for the LDS-resident pressure vectors");
+  const bool k1_lds = red_bytes + P.prs_vec_bytes + P.prs_mat_bytes <= LDS_MAX;
+  const bool vel_lds = red_bytes + P.vel_bytes <= LDS_MAX;
+  size_t u = P.prs_vec_bytes + (k1_lds ? P.prs_mat_bytes : 0);
+  if (vel_lds && P.vel_bytes > u) u = P.vel_bytes;
+  const size_t lds = red_bytes + u;
   hipError_t e;
-  if (lds_full <= LDS_MAX) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&evolve_kernel<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
-    if (e != hipSuccess) return fail("hipFuncSetAttribute(evolve<true>)", e);
-    hipLaunchKernelGGL(evolve_kernel<true>, dim3(d->B), dim3(WG), lds_full, (hipStream_t)stream, *d, nsteps, drag,
-                       lift, iters);
-  } else {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&evolve_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small);
-    if (e != hipSuccess) return fail("hipFuncSetAttribute(evolve<false>)", e);
-    hipLaunchKernelGGL(evolve_kernel<false>, dim3(d->B), dim3(WG), lds_small, (hipStream_t)stream, *d, nsteps, drag,
-                       lift, iters);
-  }
-  e = hipGetLastError();
+  hipStream_t st = (hipStream_t)stream;
+  if (vel_lds && k1_lds)
+    e = launch_evolve<true, true>(d, lds, nsteps, drag, lift, iters, st);
+  else if (vel_lds)
+    e = launch_evolve<true, false>(d, lds, nsteps, drag, lift, iters, st);
+  else if (k1_lds)
+    e = launch_evolve<false, true>(d, lds, nsteps, drag, lift, iters, st);
+  else
+    e = launch_evolve<false, false>(d, lds, nsteps, drag, lift, iters, st);
   if (e != hipSuccess) return fail("evolve_kernel launch", e);
   return 0;
 }

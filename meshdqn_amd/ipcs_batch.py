@@ -57,7 +57,8 @@ class IpcsBatch:
         per = [self._host_arrays(t, x) for t, x in zip(self.topos, coords)]
         cap = dict(NV=max(p["nv"] for p in per), NT=max(p["nt"] for p in per), NE=max(p["ne"] for p in per),
                    NNZ2=max(p["colidx2"].size for p in per), NNZ1=max(p["colidx1"].size for p in per),
-                   NAF=max(max(p["af"].shape[0] for p in per), 1))
+                   NAF=max(max(p["af"].shape[0] for p in per), 1),
+                   NSE2=max(p["sl2_col"].size for p in per), NSE1=max(p["sl1_col"].size for p in per))
         if capacities:
             for k, val in capacities.items():
                 if val < cap[k]:
@@ -65,6 +66,7 @@ class IpcsBatch:
                 cap[k] = int(val)
         self.cap = cap
         NV, NT, NE, NNZ2, NNZ1, NAF = (cap[k] for k in ("NV", "NT", "NE", "NNZ2", "NNZ1", "NAF"))
+        NSE2, NSE1 = cap["NSE2"], cap["NSE1"]
         N2 = NV + NE
         self.N2 = N2
 
@@ -91,6 +93,10 @@ class IpcsBatch:
         h["colidx1"] = stack("colidx1", (NNZ1,), np.int32)
         h["asm1_ptr"] = stack("asm1_ptr", (NNZ1 + 1,), np.int32)
         h["asm1_src"] = stack("asm1_src", (9 * NT,), np.int32)
+        h["sl2_off"] = stack("sl2_off", (N2 // 64 + 2,), np.int32)
+        h["sl2_col"] = stack("sl2_col", (NSE2,), np.int32)
+        h["sl1_off"] = stack("sl1_off", (NV // 64 + 2,), np.int32)
+        h["sl1_col"] = stack("sl1_col", (NSE1,), np.int32)
         h["g2_ptr"] = stack("g2_ptr", (N2 + 1,), np.int32)
         h["g2_src"] = stack("g2_src", (6 * NT,), np.int32)
         h["g1_ptr"] = stack("g1_ptr", (NV + 1,), np.int32)
@@ -109,9 +115,9 @@ class IpcsBatch:
 
         t = self.t
         t["geom"] = z(B, 5, NT)
-        t["A1"] = z(B, NNZ2, 4)
-        t["Ms"] = z(B, NNZ2)
-        t["K1s"] = z(B, NNZ1)
+        t["A1"] = z(B, NSE2, 4)
+        t["Ms"] = z(B, NSE2)
+        t["K1s"] = z(B, NSE1)
         t["lift1"] = z(B, N2, 2)
         t["lift3"] = z(B, N2, 2)
         t["idiag1"] = z(B, N2, 2)
@@ -126,6 +132,7 @@ class IpcsBatch:
 
         d = _lib.IpcsDesc()
         d.B, d.NV, d.NT, d.NE, d.N2, d.NNZ2, d.NNZ1, d.NAF = B, NV, NT, NE, N2, NNZ2, NNZ1, NAF
+        d.NSE2, d.NSE1 = NSE2, NSE1
         d.mu, d.rho, d.dt, d.rtol = self.mu, self.rho, self.dt, self.rtol
         d.maxit_u, d.maxit_p, d.maxit_m = self.maxit
         for name, _typ in _lib.IpcsDesc._fields_:
@@ -145,6 +152,8 @@ class IpcsBatch:
         rowptr1, colidx1, asm1_ptr, asm1_src = pat["p1"]
         out_f, _ = topo.facets(bc["tags"], TAG_OUTFLOW)
         af, af_edges = topo.facets(bc["tags"], TAG_AIRFOIL)
+        sl2_off, sl2_col, pos2 = topo.sell_layout(rowptr2, colidx2)
+        sl1_off, sl1_col, pos1 = topo.sell_layout(rowptr1, colidx1)
         cell_outflow = np.full(topo.nt, -1, dtype=np.int8)
         cell_outflow[out_f[:, 0]] = out_f[:, 1]
         return dict(nv=topo.nv, nt=topo.nt, ne=topo.ne, coords=np.asarray(coords, np.float64),
@@ -152,6 +161,7 @@ class IpcsBatch:
                     cell_outflow=cell_outflow,
                     rowptr2=rowptr2, colidx2=colidx2, asm2_ptr=asm2_ptr, asm2_src=asm2_src,
                     rowptr1=rowptr1, colidx1=colidx1, asm1_ptr=asm1_ptr, asm1_src=asm1_src,
+                    sl2_off=sl2_off, sl2_col=sl2_col, sl1_off=sl1_off, sl1_col=sl1_col, pos2=pos2, pos1=pos1,
                     g2_ptr=gat["p2"][0], g2_src=gat["p2"][1], g1_ptr=gat["p1"][0], g1_src=gat["p1"][1],
                     bcu_flag=bc["bcu_flag"], bcu_gx=bc["bcu_gx"], bcp_flag=bc["bcp_flag"],
                     af=af, af_edges=af_edges, tags=bc["tags"])

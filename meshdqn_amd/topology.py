@@ -202,6 +202,35 @@ class MeshTopology:
         return out
 
     @staticmethod
+    def sell_layout(rowptr, colidx, C=64):
+        """SELL-C layout (slices of C consecutive rows, column-major inside a
+        slice, slice width = longest row of the slice; no row permutation).
+
+        Returns sl_off (nslices+1, offsets in entries), sl_col (padded column
+        indices; padding points at the row itself) and pos (nnz,) = position of
+        every CSR non-zero inside the SELL arrays."""
+        n = rowptr.size - 1
+        lens = np.diff(rowptr).astype(np.int64)
+        ns = (n + C - 1) // C
+        padded = np.zeros(ns * C, dtype=np.int64)
+        padded[:n] = lens
+        width = padded.reshape(ns, C).max(axis=1)
+        sl_off = np.zeros(ns + 1, dtype=np.int64)
+        np.cumsum(width * C, out=sl_off[1:])
+        rows = np.repeat(np.arange(n), lens)
+        j = np.arange(rowptr[-1]) - np.repeat(rowptr[:-1].astype(np.int64), lens)
+        pos = sl_off[rows // C] + j * C + rows % C
+        total = int(sl_off[-1])
+        # padding entries reference their own row (always a valid index) with value 0
+        allrows = np.minimum(np.arange(ns * C), max(n - 1, 0))
+        sl_col = np.empty(total, dtype=np.int32)
+        for s_ in range(ns):
+            w = int(width[s_])
+            sl_col[sl_off[s_]:sl_off[s_ + 1]] = np.tile(allrows[s_ * C:(s_ + 1) * C], w)
+        sl_col[pos] = colidx[:rowptr[-1]]
+        return sl_off.astype(np.int32), sl_col, pos.astype(np.int32)
+
+    @staticmethod
     def _dof_gather(dofs_local, ndofs):
         """dof <- list of flat slots e*nl + i (ascending e)."""
         flat = dofs_local.ravel()

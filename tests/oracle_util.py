@@ -12,9 +12,10 @@ def interleaved_to_oracle_vel(u):
     return np.concatenate([u[:, 0], u[:, 1]])
 
 
-def device_velocity_matrix(rowptr, colidx, A1, idiag1):
+def device_velocity_matrix(rowptr, colidx, A1, idiag1, pos):
     """Rebuild the (unscaled) velocity operator in the oracle's [ux|uy] ordering
-    from the device BCSR arrays (A1 is row-scaled by idiag1)."""
+    from the device SELL block arrays (A1 is row-scaled by idiag1); `pos` maps
+    CSR non-zeros to SELL positions."""
     n2 = rowptr.size - 1
     nnz = rowptr[-1]
     rows = np.repeat(np.arange(n2), np.diff(rowptr))
@@ -23,16 +24,16 @@ def device_velocity_matrix(rowptr, colidx, A1, idiag1):
     for c in range(2):
         row_blocks = []
         for d in range(2):
-            vals = A1[:nnz, 2 * c + d] / idiag1[rows, c]
+            vals = A1[pos, 2 * c + d] / idiag1[rows, c]
             row_blocks.append(sp.coo_matrix((vals, (rows, cols)), shape=(n2, n2)))
         blocks.append(row_blocks)
     return sp.bmat(blocks).tocsr()
 
 
-def device_sym_matrix(rowptr, colidx, vals, sdiag):
+def device_sym_matrix(rowptr, colidx, vals, sdiag, pos):
     n = rowptr.size - 1
     nnz = rowptr[-1]
     rows = np.repeat(np.arange(n), np.diff(rowptr))
     cols = colidx[:nnz]
-    v = vals[:nnz] * sdiag[rows] * sdiag[cols]
+    v = vals[pos] * sdiag[rows] * sdiag[cols]
     return sp.coo_matrix((v, (rows, cols)), shape=(n, n)).tocsr()

@@ -1,0 +1,24 @@
+#!/bin/bash
+# HBM traffic of evolve_kernel from PMC counters (separate passes, no tracing domains), on the GPU box:
+#   tools/pmc_traffic.sh <outdir-under-gpurun_out> [bench args...]
+set -u
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --output-format csv -d $OUT/$C -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline "$@" > $OUT/$C.log 2>&1
+done
+python3 - "$OUT" <<'PY'
+import csv, glob, sys, json
+out = sys.argv[1]
+res = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    vals = []
+    for f in glob.glob(f"{out}/{c}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "evolve_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c:
+                vals.append(float(r["Counter_Value"]))
+    res[c] = dict(n=len(vals), mean=sum(vals) / max(len(vals), 1), last100_mean=sum(vals[-100:]) / max(len(vals[-100:]), 1))
+print(json.dumps(res))
+json.dump(res, open(f"{out}/pmc_summary.json", "w"), indent=1)
+PY

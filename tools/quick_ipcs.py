@@ -25,3 +25,16 @@ for rep in range(3):
     print(f"B={B} nsteps={nsteps}: {dt*1e3/nsteps:.3f} ms/step  {B*nsteps/dt:.0f} env-steps/s")
 it = batch.iters.cpu().numpy().astype(float) / (3 * nsteps)
 print("iters/step (u,p,m): mean", it.mean(0), "max", it.max(0))
+
+if os.environ.get("MDQ_CFLAGS", "").find("MDQ_PROFILE") >= 0:
+    c = batch.cap
+    NV, NT, NE = c["NV"], c["NT"], c["NE"]
+    N2 = NV + NE
+    per = (12 * NT + 12 * N2 + NV + 8 + 31) // 32 * 32
+    w = batch.t["work"].cpu().numpy().reshape(B, per)
+    prof = w[:, 12 * NT + 12 * N2 + NV: 12 * NT + 12 * N2 + NV + 8]
+    tot_steps = 5 + 3 * nsteps
+    names = ["elem_rhs1", "gather1", "bicgstab", "rhs2+gather", "cg_pressure", "rhs3+gather", "cg_mass", "update+probe"]
+    m = prof.mean(0) / tot_steps
+    for n_, v_ in zip(names, m):
+        print(f"  {n_:14s} {v_/100.0:9.1f} us/step (at 100MHz memtime)  {100*v_/m.sum():5.1f}%")
