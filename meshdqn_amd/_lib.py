@@ -26,12 +26,13 @@ class IpcsDesc(C.Structure):
         ("NSE2", C.c_int32), ("NSE1", C.c_int32),
         ("mu", C.c_double), ("rho", C.c_double), ("dt", C.c_double),
         ("rtol", C.c_double),
-        ("maxit_u", C.c_int32), ("maxit_p", C.c_int32), ("maxit_m", C.c_int32), ("_pad0", C.c_int32),
+        ("maxit_u", C.c_int32), ("maxit_p", C.c_int32), ("maxit_m", C.c_int32), ("mode", C.c_int32),
         ("nv", C.c_void_p), ("nt", C.c_void_p), ("ne", C.c_void_p), ("naf", C.c_void_p),
         ("coords", C.c_void_p), ("cell_dofs", C.c_void_p), ("cell_outflow", C.c_void_p),
         ("rowptr2", C.c_void_p), ("colidx2", C.c_void_p), ("asm2_ptr", C.c_void_p), ("asm2_src", C.c_void_p),
         ("rowptr1", C.c_void_p), ("colidx1", C.c_void_p), ("asm1_ptr", C.c_void_p), ("asm1_src", C.c_void_p),
         ("sl2_off", C.c_void_p), ("sl2_col", C.c_void_p), ("sl1_off", C.c_void_p), ("sl1_col", C.c_void_p),
+        ("mf_scat", C.c_void_p), ("mf_tptr", C.c_void_p),
         ("g2_ptr", C.c_void_p), ("g2_src", C.c_void_p), ("g1_ptr", C.c_void_p), ("g1_src", C.c_void_p),
         ("bcu_flag", C.c_void_p), ("bcu_gx", C.c_void_p), ("bcp_flag", C.c_void_p),
         ("af_facets", C.c_void_p),

@@ -5,7 +5,7 @@
 
 namespace mdq {
 
-constexpr int WG = 1024;       // threads per workgroup = 16 wave64 = one CU's worth of one environment
+constexpr int WG = 512;        // threads per workgroup = 8 wave64 (2 per SIMD, 256-VGPR budget); one workgroup per environment
 constexpr int NWAVE = WG / 64;
 constexpr int NQ = 7;          // Radon 7-point rule, exact to degree 5
 

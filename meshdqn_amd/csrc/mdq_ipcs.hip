@@ -20,6 +20,7 @@
 
 #include "../../include/meshdqn_hip.h"
 #include "mdq_device.h"
+#include "mdq_elem.h"
 
 namespace mdq {
 
@@ -43,6 +44,8 @@ struct EnvView {
   const int32_t *rowptr2, *colidx2, *asm2_ptr, *asm2_src;
   const int32_t *rowptr1, *colidx1, *asm1_ptr, *asm1_src;
   const int32_t *sl2_off, *sl2_col, *sl1_off, *sl1_col;
+  const int32_t *mf_scat, *mf_tptr;
+  int mf_tstride;  // N2+1
   const int32_t *g2_ptr, *g2_src, *g1_ptr, *g1_src;
   const uint8_t* bcu_flag;
   const double* bcu_gx;
@@ -86,6 +89,9 @@ __device__ __forceinline__ EnvView env_view(const mdq_ipcs_desc& d, int b) {
   v.sl2_col = d.sl2_col + B * d.NSE2;
   v.sl1_off = d.sl1_off + B * (d.NV / 64 + 2);
   v.sl1_col = d.sl1_col + B * d.NSE1;
+  v.mf_scat = d.mf_scat + B * 6 * d.NT;
+  v.mf_tstride = d.N2 + 1;
+  v.mf_tptr = d.mf_tptr + B * ((d.NT + 1023) / 1024) * (d.N2 + 1);
   v.g2_ptr = d.g2_ptr + B * (d.N2 + 1);
   v.g2_src = d.g2_src + B * 6 * d.NT;
   v.g1_ptr = d.g1_ptr + B * (d.NV + 1);
@@ -110,10 +116,6 @@ __device__ __forceinline__ EnvView env_view(const mdq_ipcs_desc& d, int b) {
   v.nnz1 = v.rowptr1[v.nv];
   return v;
 }
-
-struct Geo {
-  double j00, j01, j10, j11, det;
-};
 
 __device__ __forceinline__ Geo load_geo(const EnvView& v, int e) {
   Geo g;
@@ -371,32 +373,25 @@ __global__ __launch_bounds__(WG) void assemble_kernel(mdq_ipcs_desc d) {
 
 // ================================================================== element right-hand sides
 
-struct ElemData {
+struct ElemIdx {
   int dof[6];
-  Geo g;
 };
 
-__device__ __forceinline__ ElemData load_elem(const EnvView& v, int e) {
-  ElemData E;
+__device__ __forceinline__ ElemIdx load_dofs(const EnvView& v, int e) {
+  ElemIdx E;
 #pragma unroll
   for (int i = 0; i < 6; ++i) E.dof[i] = v.cell_dofs[i * v.NT + e];
-  E.g = load_geo(v, e);
   return E;
 }
 
-// physical gradient of P2 basis i at quadrature point q
-#define MDQ_PHYS_GRAD(q, i, gx_, gy_)                                          \
-  const double gx_ = E.g.j00 * c_tab.qdphi[q][i][0] + E.g.j10 * c_tab.qdphi[q][i][1]; \
-  const double gy_ = E.g.j01 * c_tab.qdphi[q][i][0] + E.g.j11 * c_tab.qdphi[q][i][1];
-
-// step 1 (flow_solver.py:106-112): local vector of L1 = rhs(F1)
-//   r^c_i = int [ (a u_c - rho (u.grad)u_c) phi_i + (-mu eps(u)_{ac} + p delta_ac) d_a phi_i ]
-//           + mu/2 int_{outflow} phi_i n_d d_c u_d ds
-__device__ inline void elem_rhs1(const EnvView& v, const mdq_ipcs_desc& d, const double2* __restrict__ u,
-                                 const double* __restrict__ p, double2* __restrict__ escr) {
-  const double a = d.rho / d.dt, mu = d.mu, rho = d.rho;
+// element loops of the three right-hand sides: one thread per triangle, results to the
+// per-environment scratch (slot = cell*6+i / cell*3+j) that the dof-gather passes read
+__device__ inline void rhs1_elements(const EnvView& v, const mdq_ipcs_desc& d, const double2* __restrict__ u,
+                                     const double* __restrict__ p, double2* __restrict__ escr) {
+  const double a = d.rho / d.dt;
   for (int e = threadIdx.x; e < v.nt; e += WG) {
-    const ElemData E = load_elem(v, e);
+    const ElemIdx E = load_dofs(v, e);
+    const Geo g = load_geo(v, e);
     double2 ue[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) ue[i] = u[E.dof[i]];
@@ -404,145 +399,127 @@ __device__ inline void elem_rhs1(const EnvView& v, const mdq_ipcs_desc& d, const
 #pragma unroll
     for (int i = 0; i < 3; ++i) pe[i] = p[E.dof[i]];
     double2 r[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) r[i] = make_double2(0.0, 0.0);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      double ux = 0, uy = 0, uxx = 0, uxy = 0, uyx = 0, uyy = 0;  // u, d_x ux, d_y ux, d_x uy, d_y uy
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        MDQ_PHYS_GRAD(q, i, gx, gy)
-        const double ph = c_tab.qphi[q][i];
-        ux += ue[i].x * ph;
-        uy += ue[i].y * ph;
-        uxx += ue[i].x * gx;
-        uxy += ue[i].x * gy;
-        uyx += ue[i].y * gx;
-        uyy += ue[i].y * gy;
-      }
-      const double pq = pe[0] * c_tab.qpsi[q][0] + pe[1] * c_tab.qpsi[q][1] + pe[2] * c_tab.qpsi[q][2];
-      const double w = c_tab.qw[q] * E.g.det;
-      const double sx = w * (a * ux - rho * (ux * uxx + uy * uxy));
-      const double sy = w * (a * uy - rho * (ux * uyx + uy * uyy));
-      const double exy = 0.5 * (uxy + uyx);
-      // F_ac = -mu eps_ac + p delta_ac
-      const double Fxx = w * (-mu * uxx + pq), Fyx = w * (-mu * exy);  // c = x: F_xx, F_yx
-      const double Fxy = w * (-mu * exy), Fyy = w * (-mu * uyy + pq);  // c = y: F_xy, F_yy
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        MDQ_PHYS_GRAD(q, i, gx, gy)
-        const double ph = c_tab.qphi[q][i];
-        r[i].x += sx * ph + Fxx * gx + Fyx * gy;
-        r[i].y += sy * ph + Fxy * gx + Fyy * gy;
-      }
-    }
+    elem_rhs1_vol(g, a, d.mu, d.rho, ue, pe, r);
     const int ko = v.cell_outflow[e];
     if (ko >= 0) {
       double X[3][2];
       load_cell_coords(v, e, X);
-      const Facet f = facet_geometry(X, ko);
-      for (int q = 0; q < 2; ++q) {
-        const double s = c_tab.gx[q], w = 0.5 * mu * c_tab.gw[q] * f.len;
-        const double xi = f.ra[0] + s * (f.rb[0] - f.ra[0]);
-        const double eta = f.ra[1] + s * (f.rb[1] - f.ra[1]);
-        double phi[6], dphi[6][2];
-        p2_eval(xi, eta, phi, dphi);
-        // n_d d_c u_d  for c = x, y
-        double tx = 0.0, ty = 0.0;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          const double gx = E.g.j00 * dphi[j][0] + E.g.j10 * dphi[j][1];
-          const double gy = E.g.j01 * dphi[j][0] + E.g.j11 * dphi[j][1];
-          const double un = ue[j].x * f.nx + ue[j].y * f.ny;
-          tx += gx * un;
-          ty += gy * un;
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          r[i].x += w * phi[i] * tx;
-          r[i].y += w * phi[i] * ty;
-        }
-      }
+      elem_outflow_add(g, X, ko, 0.5 * d.mu, ue, r);  // + mu/2 <nabla_grad(u_n) n, v>
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) escr[e * 6 + i] = r[i];
   }
 }
 
-// step 2 (flow_solver.py:115-116): r_j = int grad p_n . grad psi_j - (1/dt) div(u*) psi_j
-__device__ inline void elem_rhs2(const EnvView& v, const mdq_ipcs_desc& d, const double2* __restrict__ u,
-                                 const double* __restrict__ p, double* __restrict__ escr) {
+__device__ inline void rhs2_elements(const EnvView& v, const mdq_ipcs_desc& d, const double2* __restrict__ u,
+                                     const double* __restrict__ p, double* __restrict__ escr) {
   const double idt = 1.0 / d.dt;
   for (int e = threadIdx.x; e < v.nt; e += WG) {
-    const ElemData E = load_elem(v, e);
+    const ElemIdx E = load_dofs(v, e);
+    const Geo g = load_geo(v, e);
     double2 ue[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) ue[i] = u[E.dof[i]];
     double pe[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) pe[i] = p[E.dof[i]];
-    // P1 gradients (constant per cell)
-    const double glx[3] = {-E.g.j00 - E.g.j10, E.g.j00, E.g.j10};
-    const double gly[3] = {-E.g.j01 - E.g.j11, E.g.j01, E.g.j11};
-    const double gpx = pe[0] * glx[0] + pe[1] * glx[1] + pe[2] * glx[2];
-    const double gpy = pe[0] * gly[0] + pe[1] * gly[1] + pe[2] * gly[2];
     double r[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) r[j] = 0.5 * E.g.det * (gpx * glx[j] + gpy * gly[j]);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      double div = 0.0;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        MDQ_PHYS_GRAD(q, i, gx, gy)
-        div += ue[i].x * gx + ue[i].y * gy;
-      }
-      const double w = c_tab.qw[q] * E.g.det * idt * div;
-#pragma unroll
-      for (int j = 0; j < 3; ++j) r[j] -= w * c_tab.qpsi[q][j];
-    }
+    elem_rhs2(g, idt, ue, pe, r);
 #pragma unroll
     for (int j = 0; j < 3; ++j) escr[e * 3 + j] = r[j];
   }
 }
 
-// step 3 (flow_solver.py:119-120): r^c_i = int (u*_c - dt d_c(p - p_n)) phi_i
-__device__ inline void elem_rhs3(const EnvView& v, const mdq_ipcs_desc& d, const double2* __restrict__ u,
-                                 const double* __restrict__ pnew, const double* __restrict__ pold,
-                                 double2* __restrict__ escr) {
+__device__ inline void rhs3_elements(const EnvView& v, const mdq_ipcs_desc& d, const double2* __restrict__ u,
+                                     const double* __restrict__ pnew, const double* __restrict__ pold,
+                                     double2* __restrict__ escr) {
   for (int e = threadIdx.x; e < v.nt; e += WG) {
-    const ElemData E = load_elem(v, e);
+    const ElemIdx E = load_dofs(v, e);
+    const Geo g = load_geo(v, e);
     double2 ue[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) ue[i] = u[E.dof[i]];
     double dp[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) dp[i] = pnew[E.dof[i]] - pold[E.dof[i]];
-    const double glx[3] = {-E.g.j00 - E.g.j10, E.g.j00, E.g.j10};
-    const double gly[3] = {-E.g.j01 - E.g.j11, E.g.j01, E.g.j11};
-    const double gx = d.dt * (dp[0] * glx[0] + dp[1] * glx[1] + dp[2] * glx[2]);
-    const double gy = d.dt * (dp[0] * gly[0] + dp[1] * gly[1] + dp[2] * gly[2]);
     double2 r[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) r[i] = make_double2(0.0, 0.0);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      double ux = 0.0, uy = 0.0;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        ux += ue[i].x * c_tab.qphi[q][i];
-        uy += ue[i].y * c_tab.qphi[q][i];
-      }
-      const double w = c_tab.qw[q] * E.g.det;
-      const double sx = w * (ux - gx), sy = w * (uy - gy);
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        r[i].x += sx * c_tab.qphi[q][i];
-        r[i].y += sy * c_tab.qphi[q][i];
-      }
-    }
+    elem_rhs3(g, d.dt, ue, dp, r);
 #pragma unroll
     for (int i = 0; i < 6; ++i) escr[e * 6 + i] = r[i];
+  }
+}
+
+// ================================================================== matrix-free operator application
+//
+// y = Op x with the operator applied triangle by triangle (LDS-staged element tiles):
+//   x   : gather vector in LDS (double2[n2])
+//   es  : LDS tile of element results, SoA  es[i*CH + t]  (t = thread = triangle of the chunk)
+// Per chunk of CH = WG triangles: every thread applies its triangle's 12x12 operator, barrier,
+// then every thread sums the tile entries of its OWN rows (rows tid, tid+WG, ...) in ascending
+// triangle order (fixed order => bitwise reproducible, no atomics), barrier.
+// Requires n2 <= MF_ROWS*WG.
+constexpr int MF_CH = 1024;                    // triangles per LDS tile (host maps use the same chunking)
+constexpr int MF_ROWS = 4096 / WG;             // own rows per thread (n2 <= 4096)
+
+// acc[k] = sum of the element results that land on own row tid + k*WG (zero for rows >= n2).
+// op(e, geo, dofs, ye) fills the 6 double2 results of triangle e.
+template <class ElemOp>
+__device__ __forceinline__ void tile_accumulate(const EnvView& v, double2* es, ElemOp op, double2 (&acc)[MF_ROWS]) {
+  const int tid = threadIdx.x, n = v.n2;
+#pragma unroll
+  for (int k = 0; k < MF_ROWS; ++k) acc[k] = make_double2(0.0, 0.0);
+  int chunk = 0;
+  for (int c0 = 0; c0 < v.nt; c0 += MF_CH, ++chunk) {
+    // tile ranges of the own rows for this chunk: issued before the element work so that the
+    // L2 latency hides behind it
+    const int32_t* tp = v.mf_tptr + chunk * v.mf_tstride;
+    int lo[MF_ROWS], hi[MF_ROWS];
+#pragma unroll
+    for (int k = 0; k < MF_ROWS; ++k) {
+      const int row = tid + k * WG;
+      lo[k] = row < n ? tp[row] : 0;
+      hi[k] = row < n ? tp[row + 1] : 0;
+    }
+    for (int e = c0 + tid; e < min(c0 + MF_CH, v.nt); e += WG) {
+      const ElemIdx E = load_dofs(v, e);
+      int sc[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) sc[i] = v.mf_scat[i * v.NT + e];
+      const Geo g = load_geo(v, e);
+      double2 ye[6];
+      op(e, g, E, ye);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) es[sc[i]] = ye[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MF_ROWS; ++k) {
+      for (int j = lo[k]; j < hi[k]; ++j) {
+        const double2 c = es[j];
+        acc[k].x += c.x;
+        acc[k].y += c.y;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <class ElemOp, class Epi>
+__device__ __forceinline__ void matfree_apply(const EnvView& v, const double2* x, double2* es, ElemOp op, Epi epi) {
+  double2 acc[MF_ROWS];
+  tile_accumulate(
+      v, es,
+      [&](int e, const Geo& g, const ElemIdx& E, double2(&ye)[6]) {
+        double2 xe[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) xe[i] = x[E.dof[i]];
+        op(e, g, xe, ye);
+      },
+      acc);
+#pragma unroll
+  for (int k = 0; k < MF_ROWS; ++k) {
+    const int row = threadIdx.x + k * WG;
+    if (row < v.n2) epi(row, acc[k].x, acc[k].y);
   }
 }
 
@@ -616,46 +593,80 @@ __device__ __forceinline__ void spmv_sell(const int32_t* sl_off, const int32_t* 
 }
 
 // ================================================================== Krylov solvers
+//
+// MODE 0: assembled SELL operators, gather vectors in global memory (any mesh size)
+// MODE 1: assembled SELL operators, gather vectors p / r resident in LDS
+// MODE 2: matrix-free element-tile operators (x staged in LDS, tile of element results in LDS)
 
-// BiCGStab on the row-scaled velocity system  (D^-1 A1) x = D^-1 b.
-// On entry r holds D^-1 b and x the initial guess; on exit x holds the solution.
-// gp / gr: the two vectors that SpMVs gather from (p and r=s); they live in LDS when they fit.
-__device__ inline int bicgstab_velocity(const EnvView& v, double rtol, int maxit, double2* __restrict__ x,
-                                        double2* gr, double2* __restrict__ rh, double2* gp,
-                                        double2* __restrict__ vv, double2* __restrict__ t, double* red) {
+struct VelCtx {
+  double2* x;    // solution (own rows)
+  double2* r;    // residual / s (own rows)
+  double2* rh;   // shadow residual (own rows)
+  double2* p;    // search direction (own rows)
+  double2* vv;   // A p (own rows)
+  double2* t;    // A s (own rows)
+  double2* gp;   // where SpMV #1 gathers p from   (MODE 2: the LDS stage buffer)
+  double2* gr;   // where SpMV #2 gathers s from   (MODE 2: the same LDS stage buffer)
+  double2* es;   // MODE 2: LDS element tile
+  double a, mu;
+};
+
+// y = (D^-1 A1_bc) x on vectors that vanish on constrained dofs (see bicgstab_velocity)
+template <int MODE, class Epi>
+__device__ __forceinline__ void apply_velocity(const EnvView& v, const VelCtx& c, const double2* gx, Epi epi) {
+  if (MODE == 2) {
+    matfree_apply(
+        v, gx, c.es,
+        [&](int e, const Geo& g, const double2(&xe)[6], double2(&ye)[6]) {
+          elem_velocity(g, c.a, c.mu, xe, ye);
+          const int ko = v.cell_outflow[e];
+          if (ko >= 0) {
+            double X[3][2];
+            load_cell_coords(v, e, X);
+            elem_outflow_add(g, X, ko, -0.5 * c.mu, xe, ye);
+          }
+        },
+        [&](int row, double y0, double y1) {
+          if (v.bcu_flag[row]) {
+            epi(row, 0.0, 0.0);
+          } else {
+            const double2 id = v.idiag1[row];
+            epi(row, y0 * id.x, y1 * id.y);
+          }
+        });
+  } else {
+    spmv_sell_b2(v.sl2_off, v.sl2_col, v.A1, gx, v.n2, epi);
+  }
+}
+
+// BiCGStab on the row-scaled velocity system  (D^-1 A1_bc) x = D^-1 b.
+// Entry: c.r holds the initial residual r0 = D^-1 (b - A x0) (zero on constrained dofs because x0
+// already satisfies the Dirichlet values), bb = |D^-1 b|^2 and rr0 = |r0|^2 are workgroup-uniform.
+// Every Krylov vector therefore vanishes on constrained dofs and the eliminated operator equals the
+// plain element operator on them.  Exit: c.x holds the solution.
+template <int MODE>
+__device__ inline int bicgstab_velocity(const EnvView& v, const VelCtx& c, double rtol, int maxit, double bb,
+                                        double rr0, double* red) {
   const int n = v.n2, tid = threadIdx.x;
-  // r = b - A x (x gathered from global once); bb = (b,b); rr = (r,r)
-  double acc[2] = {0.0, 0.0};
-  __syncthreads();
-  spmv_sell_b2(v.sl2_off, v.sl2_col, v.A1, x, n, [&](int row, double y0, double y1) {
-    const double2 b = gr[row];
-    const double2 rr = make_double2(b.x - y0, b.y - y1);
-    gr[row] = rr;
-    rh[row] = rr;
-    gp[row] = make_double2(0.0, 0.0);
-    vv[row] = make_double2(0.0, 0.0);
-    acc[0] += b.x * b.x + b.y * b.y;
-    acc[1] += rr.x * rr.x + rr.y * rr.y;
-  });
-  block_sum<2>(acc, red);
-  const double bb = acc[0];
-  double rr = acc[1];
   const double tol2 = rtol * rtol * bb;
+  double rr = rr0;
   if (!(rr > tol2) || bb == 0.0) return 0;
-  double rho = rr, rho_old = 1.0, alpha = 1.0, omega = 1.0;  // (rh,r) = (r,r) at start
+  double rho = rr, rho_old = 1.0, alpha = 1.0, omega = 1.0;  // rh = r0, p = v = 0 on entry
   int it = 0;
   while (it < maxit) {
     ++it;
     const double beta = (rho / rho_old) * (alpha / omega);
     for (int i = tid; i < n; i += WG) {
-      const double2 ri = gr[i], pi = gp[i], vi = vv[i];
-      gp[i] = make_double2(ri.x + beta * (pi.x - omega * vi.x), ri.y + beta * (pi.y - omega * vi.y));
+      const double2 ri = c.r[i], pi = c.p[i], vi = c.vv[i];
+      const double2 pn = make_double2(ri.x + beta * (pi.x - omega * vi.x), ri.y + beta * (pi.y - omega * vi.y));
+      c.p[i] = pn;
+      if (MODE == 2) c.gp[i] = pn;
     }
     __syncthreads();
     double a1[1] = {0.0};
-    spmv_sell_b2(v.sl2_off, v.sl2_col, v.A1, gp, n, [&](int row, double y0, double y1) {
-      vv[row] = make_double2(y0, y1);
-      const double2 h = rh[row];
+    apply_velocity<MODE>(v, c, c.gp, [&](int row, double y0, double y1) {
+      c.vv[row] = make_double2(y0, y1);
+      const double2 h = c.rh[row];
       a1[0] += h.x * y0 + h.y * y1;
     });
     block_sum<1>(a1, red);
@@ -663,23 +674,24 @@ __device__ inline int bicgstab_velocity(const EnvView& v, double rtol, int maxit
     alpha = rho / a1[0];
     double a2[1] = {0.0};
     for (int i = tid; i < n; i += WG) {
-      const double2 ri = gr[i], vi = vv[i];
-      const double2 s = make_double2(ri.x - alpha * vi.x, ri.y - alpha * vi.y);
-      gr[i] = s;
-      a2[0] += s.x * s.x + s.y * s.y;
+      const double2 ri = c.r[i], vi = c.vv[i];
+      const double2 sv = make_double2(ri.x - alpha * vi.x, ri.y - alpha * vi.y);
+      c.r[i] = sv;
+      if (MODE == 2) c.gr[i] = sv;
+      a2[0] += sv.x * sv.x + sv.y * sv.y;
     }
     block_sum<1>(a2, red);  // (its barriers also publish s)
     if (!(a2[0] > tol2)) {
       for (int i = tid; i < n; i += WG) {
-        const double2 xi = x[i], pi = gp[i];
-        x[i] = make_double2(xi.x + alpha * pi.x, xi.y + alpha * pi.y);
+        const double2 xi = c.x[i], pi = c.p[i];
+        c.x[i] = make_double2(xi.x + alpha * pi.x, xi.y + alpha * pi.y);
       }
       break;
     }
     double a3[2] = {0.0, 0.0};
-    spmv_sell_b2(v.sl2_off, v.sl2_col, v.A1, gr, n, [&](int row, double y0, double y1) {
-      t[row] = make_double2(y0, y1);
-      const double2 sv = gr[row];
+    apply_velocity<MODE>(v, c, c.gr, [&](int row, double y0, double y1) {
+      c.t[row] = make_double2(y0, y1);
+      const double2 sv = c.r[row];
       a3[0] += y0 * sv.x + y1 * sv.y;
       a3[1] += y0 * y0 + y1 * y1;
     });
@@ -688,10 +700,10 @@ __device__ inline int bicgstab_velocity(const EnvView& v, double rtol, int maxit
     omega = a3[0] / a3[1];
     double a4[2] = {0.0, 0.0};
     for (int i = tid; i < n; i += WG) {
-      const double2 ti = t[i], xi = x[i], pi = gp[i], si = gr[i], hi = rh[i];
-      x[i] = make_double2(xi.x + alpha * pi.x + omega * si.x, xi.y + alpha * pi.y + omega * si.y);
+      const double2 ti = c.t[i], xi = c.x[i], pi = c.p[i], si = c.r[i], hi = c.rh[i];
+      c.x[i] = make_double2(xi.x + alpha * pi.x + omega * si.x, xi.y + alpha * pi.y + omega * si.y);
       const double2 rn = make_double2(si.x - omega * ti.x, si.y - omega * ti.y);
-      gr[i] = rn;
+      c.r[i] = rn;
       a4[0] += rn.x * rn.x + rn.y * rn.y;
       a4[1] += hi.x * rn.x + hi.y * rn.y;
     }
@@ -706,34 +718,51 @@ __device__ inline int bicgstab_velocity(const EnvView& v, double rtol, int maxit
   return it;
 }
 
-// CG on the symmetrically scaled mass system, two right-hand sides at once (x and y components).
-// On entry r holds S^-1 b, x the initial guess S x0; on exit x holds S x.  gp: gathered vector.
-__device__ inline int cg_mass(const EnvView& v, double rtol, int maxit, double2* __restrict__ x,
-                              double2* __restrict__ r, double2* gp, double2* __restrict__ q, double* red) {
+struct MassCtx {
+  double2* x;   // S x (own rows)
+  double2* r;   // residual (own rows)
+  double2* p;   // search direction (own rows)
+  double2* q;   // M p (own rows)
+  double2* gp;  // where the SpMV gathers p from
+  double2* es;  // MODE 2: LDS element tile
+};
+
+// y = (S^-1 M_bc S^-1) x on vectors that vanish on constrained dofs
+template <int MODE, class Epi>
+__device__ __forceinline__ void apply_mass(const EnvView& v, const MassCtx& c, const double2* gx, Epi epi) {
+  if (MODE == 2) {
+    // gx holds S^-1 x (pre-scaled when staged), the epilogue applies the left S^-1
+    matfree_apply(
+        v, gx, c.es, [&](int, const Geo& g, const double2(&xe)[6], double2(&ye)[6]) { elem_mass(g, xe, ye); },
+        [&](int row, double y0, double y1) {
+          if (v.bcu_flag[row]) {
+            epi(row, 0.0, 0.0);
+          } else {
+            const double is = 1.0 / v.sdiagM[row];
+            epi(row, y0 * is, y1 * is);
+          }
+        });
+  } else {
+    spmv_sell_2rhs(v.sl2_off, v.sl2_col, v.Ms, gx, v.n2, epi);
+  }
+}
+
+// CG on the symmetrically scaled mass system, both velocity components at once.
+// Entry: c.r = r0 = S^-1 (b - M S^-1 x0) with zeros on constrained dofs, c.p = r0 (and its staged copy).
+template <int MODE>
+__device__ inline int cg_mass(const EnvView& v, const MassCtx& c, double rtol, int maxit, double bb, double rr0,
+                              double* red) {
   const int n = v.n2, tid = threadIdx.x;
-  double acc[2] = {0.0, 0.0};
-  __syncthreads();
-  spmv_sell_2rhs(v.sl2_off, v.sl2_col, v.Ms, x, n, [&](int row, double y0, double y1) {
-    const double2 b = r[row];
-    const double2 rr = make_double2(b.x - y0, b.y - y1);
-    r[row] = rr;
-    gp[row] = rr;
-    acc[0] += b.x * b.x + b.y * b.y;
-    acc[1] += rr.x * rr.x + rr.y * rr.y;
-  });
-  block_sum<2>(acc, red);
-  const double bb = acc[0];
-  double rr = acc[1];
   const double tol2 = rtol * rtol * bb;
+  double rr = rr0;
   if (!(rr > tol2) || bb == 0.0) return 0;
   int it = 0;
-  // the two systems share one Krylov recurrence on the stacked vector (block-diagonal operator)
   while (it < maxit) {
     ++it;
     double a1[1] = {0.0};
-    spmv_sell_2rhs(v.sl2_off, v.sl2_col, v.Ms, gp, n, [&](int row, double y0, double y1) {
-      q[row] = make_double2(y0, y1);
-      const double2 pi = gp[row];
+    apply_mass<MODE>(v, c, c.gp, [&](int row, double y0, double y1) {
+      c.q[row] = make_double2(y0, y1);
+      const double2 pi = c.p[row];
       a1[0] += pi.x * y0 + pi.y * y1;
     });
     block_sum<1>(a1, red);
@@ -741,10 +770,10 @@ __device__ inline int cg_mass(const EnvView& v, double rtol, int maxit, double2*
     const double alpha = rr / a1[0];
     double a2[1] = {0.0};
     for (int i = tid; i < n; i += WG) {
-      const double2 xi = x[i], pi = gp[i], ri = r[i], qi = q[i];
-      x[i] = make_double2(xi.x + alpha * pi.x, xi.y + alpha * pi.y);
+      const double2 xi = c.x[i], pi = c.p[i], ri = c.r[i], qi = c.q[i];
+      c.x[i] = make_double2(xi.x + alpha * pi.x, xi.y + alpha * pi.y);
       const double2 rn = make_double2(ri.x - alpha * qi.x, ri.y - alpha * qi.y);
-      r[i] = rn;
+      c.r[i] = rn;
       a2[0] += rn.x * rn.x + rn.y * rn.y;
     }
     block_sum<1>(a2, red);
@@ -753,8 +782,13 @@ __device__ inline int cg_mass(const EnvView& v, double rtol, int maxit, double2*
     const double beta = rr_new / rr;
     rr = rr_new;
     for (int i = tid; i < n; i += WG) {
-      const double2 ri = r[i], pi = gp[i];
-      gp[i] = make_double2(ri.x + beta * pi.x, ri.y + beta * pi.y);
+      const double2 ri = c.r[i], pi = c.p[i];
+      const double2 pn = make_double2(ri.x + beta * pi.x, ri.y + beta * pi.y);
+      c.p[i] = pn;
+      if (MODE == 2) {
+        const double is = 1.0 / v.sdiagM[i];
+        c.gp[i] = make_double2(pn.x * is, pn.y * is);
+      }
     }
     __syncthreads();
   }
@@ -819,7 +853,8 @@ __device__ inline void forces(const EnvView& v, double mu, const double2* __rest
   double acc[2] = {0.0, 0.0};
   for (int f = threadIdx.x; f < v.naf; f += WG) {
     const int e = v.af_facets[2 * f], k = v.af_facets[2 * f + 1];
-    const ElemData E = load_elem(v, e);
+    const ElemIdx E = load_dofs(v, e);
+    const Geo g = load_geo(v, e);
     double X[3][2];
     load_cell_coords(v, e, X);
     const Facet F = facet_geometry(X, k);
@@ -831,7 +866,7 @@ __device__ inline void forces(const EnvView& v, double mu, const double2* __rest
     for (int i = 0; i < 3; ++i) pe[i] = p[E.dof[i]];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const double s = c_tab.gx[q], w = c_tab.gw[q] * F.len;
+      const double s = (q == 0 ? 0.5 - 0.28867513459481288225 : 0.5 + 0.28867513459481288225), w = 0.5 * F.len;
       const double xi = F.ra[0] + s * (F.rb[0] - F.ra[0]);
       const double eta = F.ra[1] + s * (F.rb[1] - F.ra[1]);
       double phi[6], dphi[6][2];
@@ -839,8 +874,8 @@ __device__ inline void forces(const EnvView& v, double mu, const double2* __rest
       double uxx = 0, uxy = 0, uyx = 0, uyy = 0;
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
-        const double gx = E.g.j00 * dphi[j][0] + E.g.j10 * dphi[j][1];
-        const double gy = E.g.j01 * dphi[j][0] + E.g.j11 * dphi[j][1];
+        const double gx = g.j00 * dphi[j][0] + g.j10 * dphi[j][1];
+        const double gy = g.j01 * dphi[j][0] + g.j11 * dphi[j][1];
         uxx += ue[j].x * gx;
         uxy += ue[j].x * gy;
         uyx += ue[j].y * gx;
@@ -877,24 +912,32 @@ __global__ __launch_bounds__(WG) void probe_kernel(mdq_ipcs_desc d, int nfields,
 
 // ================================================================== time stepping
 
-// dynamic LDS: [red 64 doubles][union: velocity gather vectors p,r (double2[N2p] each)
+#ifdef MDQ_PROFILE
+#define MDQ_STAMP(k) { __syncthreads(); long long tn = __builtin_amdgcn_s_memtime(); prof[k] += tn - tprev; tprev = tn; }
+#else
+#define MDQ_STAMP(k)
+#endif
+
+// dynamic LDS: [red 64 doubles][union: velocity stage (MODE 1: p,r  double2[N2p] each;
+//                                          MODE 2: x stage double2[N2p] + element tile double2[6*WG])
 //                                  | pressure: 4 vectors [NVp] + K1 in SELL form (values, columns, slice offsets)]
 struct LdsPlan {
   int N2p, NVp;
-  size_t vel_bytes, prs_vec_bytes, prs_mat_bytes;
+  size_t vel1_bytes, vel2_bytes, prs_vec_bytes, prs_mat_bytes;
 };
 __host__ __device__ inline LdsPlan lds_plan(int N2, int NV, int NSE1) {
   LdsPlan P;
   P.N2p = (N2 + 1) & ~1;
   P.NVp = (NV + 1) & ~1;
-  P.vel_bytes = 2 * sizeof(double2) * (size_t)P.N2p;
+  P.vel1_bytes = 2 * sizeof(double2) * (size_t)P.N2p;
+  P.vel2_bytes = sizeof(double2) * ((size_t)P.N2p + 6 * MF_CH);
   P.prs_vec_bytes = 4 * sizeof(double) * (size_t)P.NVp;
   P.prs_mat_bytes = sizeof(double) * (size_t)NSE1 + sizeof(int32_t) * ((size_t)NSE1 + (NSE1 & 1)) +
                     sizeof(int32_t) * (size_t)(((NV / 64 + 2) + 1) & ~1);
   return P;
 }
 
-template <bool VEL_LDS, bool K1_LDS>
+template <int MODE, bool K1_LDS>
 __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps, double* drag, double* lift,
                                                      int32_t* iters) {
   extern __shared__ __align__(16) double smem[];
@@ -925,9 +968,40 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
   double2* vv = vp + d.N2;
   double2* vt = vv + d.N2;
   double* pnew = reinterpret_cast<double*>(vt + d.N2);
-  // velocity view of the union (or global fall-back)
-  double2* gp = VEL_LDS ? reinterpret_cast<double2*>(U) : vp;
-  double2* gr = VEL_LDS ? reinterpret_cast<double2*>(U) + P.N2p : vr;
+  // velocity view of the union
+  double2* L0 = reinterpret_cast<double2*>(U);
+  double2* L1 = L0 + P.N2p;
+
+  VelCtx vc;
+  vc.x = xs;
+  vc.rh = vh;
+  vc.vv = vv;
+  vc.t = vt;
+  vc.a = d.rho / d.dt;
+  vc.mu = d.mu;
+  vc.es = L1;
+  if (MODE == 1) {
+    vc.p = vc.gp = L0;
+    vc.r = vc.gr = L1;
+  } else if (MODE == 2) {
+    vc.p = vp;
+    vc.r = vr;
+    vc.gp = vc.gr = L0;
+  } else {
+    vc.p = vc.gp = vp;
+    vc.r = vc.gr = vr;
+  }
+  MassCtx mc;
+  mc.x = xs;
+  mc.r = vr;
+  mc.q = vv;
+  mc.es = L1;
+  if (MODE == 2) {
+    mc.p = vp;
+    mc.gp = L0;
+  } else {
+    mc.p = mc.gp = (MODE == 1) ? L0 : vp;
+  }
 
   const int nsl1 = (nv + 63) >> 6;
   const int32_t* so1 = K1_LDS ? lso : v.sl1_off;
@@ -938,39 +1012,53 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
 #ifdef MDQ_PROFILE
   long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tprev = __builtin_amdgcn_s_memtime();
-#define MDQ_STAMP(k) { __syncthreads(); long long tn = __builtin_amdgcn_s_memtime(); prof[k] += tn - tprev; tprev = tn; }
-#else
-#define MDQ_STAMP(k)
 #endif
   __syncthreads();
 
   for (int step = 0; step < nsteps; ++step) {
-    // ---------------- step 1: tentative velocity
+    // ---------------- step 1: tentative velocity  (flow_solver.py:106-112, solve 1 of :378-380)
     MDQ_STAMP(7)
-    elem_rhs1(v, d, v.u_n, v.p_n, escr2);
+    rhs1_elements(v, d, v.u_n, v.p_n, escr2);
     __syncthreads();
     MDQ_STAMP(0)
+    double acc[2] = {0.0, 0.0};
     for (int i = tid; i < n2; i += WG) {
-      double2 bsum = make_double2(0.0, 0.0);
+      double2 f = make_double2(0.0, 0.0);
       for (int s = v.g2_ptr[i]; s < v.g2_ptr[i + 1]; ++s) {
         const double2 c = escr2[v.g2_src[s]];
-        bsum.x += c.x;
-        bsum.y += c.y;
+        f.x += c.x;
+        f.y += c.y;
       }
       const double2 l = v.lift1[i], id = v.idiag1[i];
-      double2 bi;
-      if (v.bcu_flag[i])
-        bi = make_double2(v.bcu_gx[i], 0.0);
-      else
-        bi = make_double2((bsum.x - l.x) * id.x, (bsum.y - l.y) * id.y);
-      gr[i] = bi;
-      xs[i] = v.u_n[i];
+      const bool fl = v.bcu_flag[i] != 0;
+      const double2 g = make_double2(v.bcu_gx[i], 0.0);
+      const double2 bi = fl ? g : make_double2((f.x - l.x) * id.x, (f.y - l.y) * id.y);
+      const double2 x0 = fl ? g : v.u_n[i];  // initial guess satisfies the Dirichlet values
+      xs[i] = x0;
+      if (MODE == 2) {
+        L0[i] = x0;
+        vc.r[i] = fl ? make_double2(0.0, 0.0) : make_double2(f.x * id.x, f.y * id.y);
+      } else {
+        vc.r[i] = bi;
+      }
+      acc[0] += bi.x * bi.x + bi.y * bi.y;
     }
+    __syncthreads();
+    apply_velocity<MODE>(v, vc, MODE == 2 ? L0 : xs, [&](int row, double y0, double y1) {
+      const double2 bi = vc.r[row];
+      const double2 r0 = make_double2(bi.x - y0, bi.y - y1);
+      vc.r[row] = r0;
+      vc.rh[row] = r0;
+      vc.p[row] = make_double2(0.0, 0.0);
+      vc.vv[row] = make_double2(0.0, 0.0);
+      acc[1] += r0.x * r0.x + r0.y * r0.y;
+    });
+    block_sum<2>(acc, red);
     MDQ_STAMP(1)
-    it_u += bicgstab_velocity(v, d.rtol, d.maxit_u, xs, gr, vh, gp, vv, vt, red);
+    it_u += bicgstab_velocity<MODE>(v, vc, d.rtol, d.maxit_u, acc[0], acc[1], red);
     MDQ_STAMP(2)
 
-    // ---------------- step 2: pressure
+    // ---------------- step 2: pressure  (flow_solver.py:115-116)
     if (K1_LDS) {
       const int ne1 = v.sl1_off[nsl1];
       for (int k = tid; k < ne1; k += WG) {
@@ -979,7 +1067,7 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
       }
       for (int k = tid; k <= nsl1; k += WG) lso[k] = v.sl1_off[k];
     }
-    elem_rhs2(v, d, xs, v.p_n, escr1);
+    rhs2_elements(v, d, xs, v.p_n, escr1);
     __syncthreads();
     for (int i = tid; i < nv; i += WG) {
       double bsum = 0.0;
@@ -994,32 +1082,55 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
     for (int i = tid; i < nv; i += WG) pnew[i] = px[i] / v.sdiagK[i];
     __syncthreads();
 
-    // ---------------- step 3: velocity correction
-    elem_rhs3(v, d, xs, pnew, v.p_n, escr2);
+    // ---------------- step 3: velocity correction  (flow_solver.py:119-120)
+    rhs3_elements(v, d, xs, pnew, v.p_n, escr2);
     __syncthreads();
+    double am[2] = {0.0, 0.0};
     for (int i = tid; i < n2; i += WG) {
-      double2 bsum = make_double2(0.0, 0.0);
+      double2 f = make_double2(0.0, 0.0);
       for (int s = v.g2_ptr[i]; s < v.g2_ptr[i + 1]; ++s) {
         const double2 c = escr2[v.g2_src[s]];
-        bsum.x += c.x;
-        bsum.y += c.y;
+        f.x += c.x;
+        f.y += c.y;
       }
       const double2 l = v.lift3[i];
       const double sd = v.sdiagM[i];
-      double2 bi;
-      if (v.bcu_flag[i])
-        bi = make_double2(v.bcu_gx[i], 0.0);
-      else
-        bi = make_double2((bsum.x - l.x) / sd, (bsum.y - l.y) / sd);
-      vr[i] = bi;
-      const double2 x0 = xs[i];
-      xs[i] = make_double2(x0.x * sd, x0.y * sd);
+      const bool fl = v.bcu_flag[i] != 0;
+      const double2 g = make_double2(v.bcu_gx[i], 0.0);
+      const double2 bi = fl ? g : make_double2((f.x - l.x) / sd, (f.y - l.y) / sd);
+      const double2 x0 = fl ? g : xs[i];
+      xs[i] = make_double2(x0.x * sd, x0.y * sd);  // scaled unknown S x
+      if (MODE == 2) {
+        L0[i] = x0;  // S^-1 (S x0)
+        mc.r[i] = fl ? make_double2(0.0, 0.0) : make_double2(f.x / sd, f.y / sd);
+      } else {
+        mc.r[i] = bi;
+      }
+      am[0] += bi.x * bi.x + bi.y * bi.y;
+    }
+    __syncthreads();
+    apply_mass<MODE>(v, mc, MODE == 2 ? L0 : xs, [&](int row, double y0, double y1) {
+      const double2 bi = mc.r[row];
+      const double2 r0 = make_double2(bi.x - y0, bi.y - y1);
+      mc.r[row] = r0;
+      mc.p[row] = r0;
+      am[1] += r0.x * r0.x + r0.y * r0.y;
+    });
+    block_sum<2>(am, red);
+    if (MODE == 2) {
+      // stage S^-1 p0 (own rows; the apply above is complete: block_sum barriers passed)
+      for (int i = tid; i < n2; i += WG) {
+        const double is = 1.0 / v.sdiagM[i];
+        const double2 p0 = mc.p[i];
+        L0[i] = make_double2(p0.x * is, p0.y * is);
+      }
+      __syncthreads();
     }
     MDQ_STAMP(5)
-    it_m += cg_mass(v, d.rtol, d.maxit_m, xs, vr, gp, vv, red);
+    it_m += cg_mass<MODE>(v, mc, d.rtol, d.maxit_m, am[0], am[1], red);
     MDQ_STAMP(6)
 
-    // ---------------- update state + probes
+    // ---------------- update state + probes  (flow_solver.py:382-389)
     for (int i = tid; i < n2; i += WG) {
       const double sd = v.sdiagM[i];
       const double2 x = xs[i];
@@ -1047,14 +1158,415 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
   }
 }
 
-template <bool VEL_LDS, bool K1_LDS>
+template <int MODE, bool K1_LDS>
 static hipError_t launch_evolve(const mdq_ipcs_desc* d, size_t lds, int nsteps, double* drag, double* lift,
                                 int32_t* iters, hipStream_t stream) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&evolve_kernel<VEL_LDS, K1_LDS>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&evolve_kernel<MODE, K1_LDS>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((evolve_kernel<VEL_LDS, K1_LDS>), dim3(d->B), dim3(WG), lds, stream, *d, nsteps, drag, lift,
+  hipLaunchKernelGGL((evolve_kernel<MODE, K1_LDS>), dim3(d->B), dim3(WG), lds, stream, *d, nsteps, drag, lift,
                      iters);
+  return hipGetLastError();
+}
+
+// ================================================================== matrix-free kernel, Krylov vectors in registers
+//
+// MODE 2 proper: every thread keeps its own rows (tid + k*WG, k < MF_ROWS) of ALL Krylov vectors
+// in registers for the whole solve; per operator application only the gather copy of the input
+// vector goes through LDS (stage) and the element results through the LDS tile.  Global memory is
+// touched only for the element metadata (dofs, tile maps, geometry) and once per time step for
+// the state vectors.
+
+#define MDQ_FOR_ROWS(k, row)                       \
+  _Pragma("unroll") for (int k = 0; k < MF_ROWS; ++k) \
+    if (const int row = threadIdx.x + k * WG; row < n2)
+
+__device__ __forceinline__ void velocity_op(const EnvView& v, double a, double mu, int e, const Geo& g,
+                                            const double2 (&xe)[6], double2 (&ye)[6]) {
+  elem_velocity(g, a, mu, xe, ye);
+  const int ko = v.cell_outflow[e];
+  if (ko >= 0) {
+    double X[3][2];
+    load_cell_coords(v, e, X);
+    elem_outflow_add(g, X, ko, -0.5 * mu, xe, ye);
+  }
+}
+
+template <bool K1_LDS>
+__global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nsteps, double* drag, double* lift,
+                                                        int32_t* iters) {
+  extern __shared__ __align__(16) double smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const EnvView v = env_view(d, b);
+  const int n2 = v.n2, nv = v.nv;
+  const LdsPlan P = lds_plan(d.N2, d.NV, d.NSE1);
+  const double a = d.rho / d.dt, mu = d.mu;
+
+  double* red = smem;  // 64 doubles
+  double* U = smem + 64;
+  double* px = U;
+  double* pr = px + P.NVp;
+  double* pp = pr + P.NVp;
+  double* pq = pp + P.NVp;
+  double* lK = pq + P.NVp;
+  int32_t* lci = reinterpret_cast<int32_t*>(lK + d.NSE1);
+  int32_t* lso = lci + d.NSE1 + (d.NSE1 & 1);
+  double2* stage = reinterpret_cast<double2*>(U);  // gather copy of the operator input
+  double2* tile = stage + P.N2p;                    // element results of one chunk
+
+  double* w = v.work;
+  double* escr1 = w;
+  double2* xs = reinterpret_cast<double2*>(w + 12 * (int64_t)d.NT);  // u* for the element loops of steps 2/3
+  double* pnew = reinterpret_cast<double*>(xs + 6 * (int64_t)d.N2);
+
+  const int nsl1 = (nv + 63) >> 6;
+  const int32_t* so1 = K1_LDS ? lso : v.sl1_off;
+  const int32_t* ci1 = K1_LDS ? lci : v.sl1_col;
+  const double* K1 = K1_LDS ? lK : v.K1s;
+
+  int it_u = 0, it_p = 0, it_m = 0;
+#ifdef MDQ_PROFILE
+  long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tprev = __builtin_amdgcn_s_memtime();
+#endif
+  __syncthreads();
+
+  for (int step = 0; step < nsteps; ++step) {
+    MDQ_STAMP(7)
+    // ================= step 1: tentative velocity
+    double2 x[MF_ROWS], r[MF_ROWS], rh[MF_ROWS], p[MF_ROWS], vv[MF_ROWS], y[MF_ROWS];
+    // Jacobi row scaling of the velocity system with the Dirichlet flag folded in (0 = constrained row)
+    double2 idg[MF_ROWS];
+#pragma unroll
+    for (int k = 0; k < MF_ROWS; ++k) {
+      const int row = tid + k * WG;
+      idg[k] = make_double2(0.0, 0.0);
+      if (row < n2 && !v.bcu_flag[row]) idg[k] = v.idiag1[row];
+    }
+    {
+      // f = rhs(F1) (volume + outflow facet term), element vectors through the tile
+      const double2* un = v.u_n;
+      const double* pn = v.p_n;
+      tile_accumulate(
+          v, tile,
+          [&](int e, const Geo& g, const ElemIdx& E, double2(&ye)[6]) {
+            double2 ue[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) ue[i] = un[E.dof[i]];
+            double pe[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) pe[i] = pn[E.dof[i]];
+            elem_rhs1_vol(g, a, mu, d.rho, ue, pe, ye);
+            const int ko = v.cell_outflow[e];
+            if (ko >= 0) {
+              double X[3][2];
+              load_cell_coords(v, e, X);
+              elem_outflow_add(g, X, ko, 0.5 * mu, ue, ye);
+            }
+          },
+          y);
+    }
+    MDQ_STAMP(0)
+    double acc[2] = {0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < MF_ROWS; ++k) {
+      const int row = tid + k * WG;
+      x[k] = make_double2(0.0, 0.0);
+      if (row < n2) {
+        const bool fl = v.bcu_flag[row] != 0;
+        const double2 g = make_double2(v.bcu_gx[row], 0.0);
+        x[k] = fl ? g : v.u_n[row];  // initial guess satisfies the Dirichlet values
+        stage[row] = x[k];
+        // |D^-1 b|^2 with b = f - lift (free) / g (constrained): same norm as the assembled path
+        const double2 l = v.lift1[row];
+        const double2 bi = fl ? g : make_double2((y[k].x - l.x) * idg[k].x, (y[k].y - l.y) * idg[k].y);
+        acc[0] += bi.x * bi.x + bi.y * bi.y;
+      }
+    }
+    __syncthreads();
+    {
+      double2 ax[MF_ROWS];
+      tile_accumulate(
+          v, tile,
+          [&](int e, const Geo& g, const ElemIdx& E, double2(&ye)[6]) {
+            double2 xe[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) xe[i] = stage[E.dof[i]];
+            velocity_op(v, a, mu, e, g, xe, ye);
+          },
+          ax);
+#pragma unroll
+      for (int k = 0; k < MF_ROWS; ++k) {
+        // r0 = D^-1 (f - A_full x0) on free rows, 0 on constrained rows (idg = 0 there)
+        r[k] = make_double2((y[k].x - ax[k].x) * idg[k].x, (y[k].y - ax[k].y) * idg[k].y);
+        rh[k] = r[k];
+        p[k] = make_double2(0.0, 0.0);
+        vv[k] = make_double2(0.0, 0.0);
+        acc[1] += r[k].x * r[k].x + r[k].y * r[k].y;
+      }
+    }
+    block_sum<2>(acc, red);
+    MDQ_STAMP(1)
+    {
+      const double bb = acc[0], tol2 = d.rtol * d.rtol * bb;
+      double rr = acc[1];
+      if (rr > tol2 && bb != 0.0) {
+        double rho = rr, rho_old = 1.0, alpha = 1.0, omega = 1.0;
+        int it = 0;
+        while (it < d.maxit_u) {
+          ++it;
+          const double beta = (rho / rho_old) * (alpha / omega);
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k) {
+            const int row = tid + k * WG;
+            p[k] = make_double2(r[k].x + beta * (p[k].x - omega * vv[k].x), r[k].y + beta * (p[k].y - omega * vv[k].y));
+            if (row < n2) stage[row] = p[k];
+          }
+          __syncthreads();
+          tile_accumulate(
+              v, tile,
+              [&](int e, const Geo& g, const ElemIdx& E, double2(&ye)[6]) {
+                double2 xe[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) xe[i] = stage[E.dof[i]];
+                velocity_op(v, a, mu, e, g, xe, ye);
+              },
+              vv);
+          double a1[1] = {0.0};
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k) {
+            vv[k] = make_double2(vv[k].x * idg[k].x, vv[k].y * idg[k].y);
+            a1[0] += rh[k].x * vv[k].x + rh[k].y * vv[k].y;
+          }
+          block_sum<1>(a1, red);
+          if (a1[0] == 0.0) break;
+          alpha = rho / a1[0];
+          double a2[1] = {0.0};
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k) {
+            const int row = tid + k * WG;
+            r[k] = make_double2(r[k].x - alpha * vv[k].x, r[k].y - alpha * vv[k].y);  // s
+            if (row < n2) stage[row] = r[k];
+            a2[0] += r[k].x * r[k].x + r[k].y * r[k].y;
+          }
+          block_sum<1>(a2, red);  // its barriers publish the staged s
+          if (!(a2[0] > tol2)) {
+#pragma unroll
+            for (int k = 0; k < MF_ROWS; ++k)
+              x[k] = make_double2(x[k].x + alpha * p[k].x, x[k].y + alpha * p[k].y);
+            break;
+          }
+          double2 t[MF_ROWS];
+          tile_accumulate(
+              v, tile,
+              [&](int e, const Geo& g, const ElemIdx& E, double2(&ye)[6]) {
+                double2 xe[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) xe[i] = stage[E.dof[i]];
+                velocity_op(v, a, mu, e, g, xe, ye);
+              },
+              t);
+          double a3[2] = {0.0, 0.0};
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k) {
+            t[k] = make_double2(t[k].x * idg[k].x, t[k].y * idg[k].y);
+            a3[0] += t[k].x * r[k].x + t[k].y * r[k].y;
+            a3[1] += t[k].x * t[k].x + t[k].y * t[k].y;
+          }
+          block_sum<2>(a3, red);
+          if (a3[1] == 0.0) break;
+          omega = a3[0] / a3[1];
+          double a4[2] = {0.0, 0.0};
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k) {
+            x[k] = make_double2(x[k].x + alpha * p[k].x + omega * r[k].x, x[k].y + alpha * p[k].y + omega * r[k].y);
+            r[k] = make_double2(r[k].x - omega * t[k].x, r[k].y - omega * t[k].y);
+            a4[0] += r[k].x * r[k].x + r[k].y * r[k].y;
+            a4[1] += rh[k].x * r[k].x + rh[k].y * r[k].y;
+          }
+          block_sum<2>(a4, red);
+          rr = a4[0];
+          if (!(rr > tol2)) break;
+          rho_old = rho;
+          rho = a4[1];
+          if (rho == 0.0 || omega == 0.0) break;
+        }
+        it_u += it;
+      }
+    }
+    // u* to global for the element loops of steps 2 and 3
+    MDQ_FOR_ROWS(k, row) xs[row] = x[k];
+    __syncthreads();
+    MDQ_STAMP(2)
+
+    // ================= step 2: pressure (assembled K1 in SELL form, LDS resident)
+    if (K1_LDS) {
+      const int ne1 = v.sl1_off[nsl1];
+      for (int kk = tid; kk < ne1; kk += WG) {
+        lK[kk] = v.K1s[kk];
+        lci[kk] = v.sl1_col[kk];
+      }
+      for (int kk = tid; kk <= nsl1; kk += WG) lso[kk] = v.sl1_off[kk];
+    }
+    rhs2_elements(v, d, xs, v.p_n, escr1);
+    __syncthreads();
+    for (int i = tid; i < nv; i += WG) {
+      double bsum = 0.0;
+      for (int s = v.g1_ptr[i]; s < v.g1_ptr[i + 1]; ++s) bsum += escr1[v.g1_src[s]];
+      const double sd = v.sdiagK[i];
+      pr[i] = v.bcp_flag[i] ? 0.0 : bsum / sd;
+      px[i] = v.p_n[i] * sd;
+    }
+    MDQ_STAMP(3)
+    it_p += cg_pressure(nv, so1, ci1, K1, d.rtol, d.maxit_p, px, pr, pp, pq, red);
+    MDQ_STAMP(4)
+    for (int i = tid; i < nv; i += WG) pnew[i] = px[i] / v.sdiagK[i];
+    __syncthreads();
+
+    // ================= step 3: velocity correction (mass solve, both components)
+    {
+      const double* pold = v.p_n;
+      tile_accumulate(
+          v, tile,
+          [&](int e, const Geo& g, const ElemIdx& E, double2(&ye)[6]) {
+            double2 ue[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) ue[i] = xs[E.dof[i]];
+            double dp[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) dp[i] = pnew[E.dof[i]] - pold[E.dof[i]];
+            elem_rhs3(g, d.dt, ue, dp, ye);
+          },
+          y);
+    }
+    double am[2] = {0.0, 0.0};
+    // symmetric Jacobi scaling S^-1 of the mass system, 0 on constrained rows
+    double ism[MF_ROWS];
+    // x still holds u* (satisfies the Dirichlet values): scaled unknown S x, stage S^-1 (S x0) = x0
+#pragma unroll
+    for (int k = 0; k < MF_ROWS; ++k) {
+      const int row = tid + k * WG;
+      ism[k] = 0.0;
+      if (row < n2) {
+        const bool fl = v.bcu_flag[row] != 0;
+        if (!fl) ism[k] = 1.0 / v.sdiagM[row];
+        stage[row] = x[k];
+        const double2 l = v.lift3[row];
+        const double2 bi = fl ? x[k] : make_double2((y[k].x - l.x) * ism[k], (y[k].y - l.y) * ism[k]);
+        am[0] += bi.x * bi.x + bi.y * bi.y;
+      }
+    }
+    __syncthreads();
+    {
+      double2 ax[MF_ROWS];
+      tile_accumulate(
+          v, tile,
+          [&](int, const Geo& g, const ElemIdx& E, double2(&ye)[6]) {
+            double2 xe[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) xe[i] = stage[E.dof[i]];
+            elem_mass(g, xe, ye);
+          },
+          ax);
+#pragma unroll
+      for (int k = 0; k < MF_ROWS; ++k) {
+        r[k] = make_double2((y[k].x - ax[k].x) * ism[k], (y[k].y - ax[k].y) * ism[k]);  // 0 on constrained rows
+        p[k] = r[k];
+        am[1] += r[k].x * r[k].x + r[k].y * r[k].y;
+        // scaled unknown: S x (S = 1/ism on free rows; constrained rows keep x = g with S = 1)
+        if (ism[k] != 0.0) x[k] = make_double2(x[k].x / ism[k], x[k].y / ism[k]);
+      }
+    }
+    block_sum<2>(am, red);
+    MDQ_STAMP(5)
+    {
+      const double bb = am[0], tol2 = d.rtol * d.rtol * bb;
+      double rr = am[1];
+      if (rr > tol2 && bb != 0.0) {
+        int it = 0;
+        while (it < d.maxit_m) {
+          ++it;
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k) {
+            const int row = tid + k * WG;
+            if (row < n2) stage[row] = make_double2(p[k].x * ism[k], p[k].y * ism[k]);
+          }
+          __syncthreads();
+          double2 q[MF_ROWS];
+          tile_accumulate(
+              v, tile,
+              [&](int, const Geo& g, const ElemIdx& E, double2(&ye)[6]) {
+                double2 xe[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) xe[i] = stage[E.dof[i]];
+                elem_mass(g, xe, ye);
+              },
+              q);
+          double a1[1] = {0.0};
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k) {
+            q[k] = make_double2(q[k].x * ism[k], q[k].y * ism[k]);
+            a1[0] += p[k].x * q[k].x + p[k].y * q[k].y;
+          }
+          block_sum<1>(a1, red);
+          if (!(a1[0] > 0.0)) break;
+          const double alpha = rr / a1[0];
+          double a2[1] = {0.0};
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k) {
+            x[k] = make_double2(x[k].x + alpha * p[k].x, x[k].y + alpha * p[k].y);
+            r[k] = make_double2(r[k].x - alpha * q[k].x, r[k].y - alpha * q[k].y);
+            a2[0] += r[k].x * r[k].x + r[k].y * r[k].y;
+          }
+          block_sum<1>(a2, red);
+          const double rr_new = a2[0];
+          if (!(rr_new > tol2)) break;
+          const double beta = rr_new / rr;
+          rr = rr_new;
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k)
+            p[k] = make_double2(r[k].x + beta * p[k].x, r[k].y + beta * p[k].y);
+        }
+        it_m += it;
+      }
+    }
+    MDQ_STAMP(6)
+
+    // ================= update state + probes
+#pragma unroll
+    for (int k = 0; k < MF_ROWS; ++k) {
+      const int row = tid + k * WG;
+      if (row < n2) v.u_n[row] = (ism[k] != 0.0) ? make_double2(x[k].x * ism[k], x[k].y * ism[k]) : x[k];
+    }
+    for (int i = tid; i < nv; i += WG) v.p_n[i] = pnew[i];
+    __syncthreads();
+    double dr, li;
+    forces(v, d.mu, v.u_n, v.p_n, red, dr, li);
+    if (tid == 0) {
+      drag[(int64_t)b * nsteps + step] = dr;
+      lift[(int64_t)b * nsteps + step] = li;
+    }
+  }
+#ifdef MDQ_PROFILE
+  if (tid == 0) {
+    double* pw = pnew + d.NV;
+    for (int k = 0; k < 8; ++k) pw[k] += (double)prof[k];
+  }
+#endif
+  if (tid == 0 && iters) {
+    iters[3 * b + 0] += it_u;
+    iters[3 * b + 1] += it_p;
+    iters[3 * b + 2] += it_m;
+  }
+}
+
+template <bool K1_LDS>
+static hipError_t launch_evolve_mf(const mdq_ipcs_desc* d, size_t lds, int nsteps, double* drag, double* lift,
+                                   int32_t* iters, hipStream_t stream) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&evolve_mf_kernel<K1_LDS>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((evolve_mf_kernel<K1_LDS>), dim3(d->B), dim3(WG), lds, stream, *d, nsteps, drag, lift, iters);
   return hipGetLastError();
 }
 
@@ -1164,20 +1676,30 @@ int mdq_ipcs_evolve(const mdq_ipcs_desc* d, int32_t nsteps, double* drag, double
   const size_t LDS_MAX = 160 * 1024, red_bytes = 64 * sizeof(double);
   if (red_bytes + P.prs_vec_bytes > LDS_MAX) return fail_msg("mesh too large for the LDS-resident pressure vectors");
   const bool k1_lds = red_bytes + P.prs_vec_bytes + P.prs_mat_bytes <= LDS_MAX;
-  const bool vel_lds = red_bytes + P.vel_bytes <= LDS_MAX;
+  int mode = d->mode;
+  if (mode < 0 || mode > 2) {  // auto: matrix-free tiles if they fit, else LDS gather vectors, else global
+    mode = 0;
+    if (red_bytes + P.vel1_bytes <= LDS_MAX) mode = 1;
+    if (red_bytes + P.vel2_bytes <= LDS_MAX && d->N2 <= MF_ROWS * WG) mode = 2;
+  }
+  if (mode == 2 && (red_bytes + P.vel2_bytes > LDS_MAX || d->N2 > MF_ROWS * WG))
+    return fail_msg("matrix-free mode needs N2 <= 4096 and the x stage + element tile in LDS");
+  if (mode == 1 && red_bytes + P.vel1_bytes > LDS_MAX) return fail_msg("LDS gather vectors do not fit");
   size_t u = P.prs_vec_bytes + (k1_lds ? P.prs_mat_bytes : 0);
-  if (vel_lds && P.vel_bytes > u) u = P.vel_bytes;
+  const size_t vel = mode == 2 ? P.vel2_bytes : (mode == 1 ? P.vel1_bytes : 0);
+  if (vel > u) u = vel;
   const size_t lds = red_bytes + u;
   hipError_t e;
   hipStream_t st = (hipStream_t)stream;
-  if (vel_lds && k1_lds)
-    e = launch_evolve<true, true>(d, lds, nsteps, drag, lift, iters, st);
-  else if (vel_lds)
-    e = launch_evolve<true, false>(d, lds, nsteps, drag, lift, iters, st);
-  else if (k1_lds)
-    e = launch_evolve<false, true>(d, lds, nsteps, drag, lift, iters, st);
+  if (mode == 2)
+    e = k1_lds ? launch_evolve_mf<true>(d, lds, nsteps, drag, lift, iters, st)
+               : launch_evolve_mf<false>(d, lds, nsteps, drag, lift, iters, st);
+  else if (mode == 1)
+    e = k1_lds ? launch_evolve<1, true>(d, lds, nsteps, drag, lift, iters, st)
+               : launch_evolve<1, false>(d, lds, nsteps, drag, lift, iters, st);
   else
-    e = launch_evolve<false, false>(d, lds, nsteps, drag, lift, iters, st);
+    e = k1_lds ? launch_evolve<0, true>(d, lds, nsteps, drag, lift, iters, st)
+               : launch_evolve<0, false>(d, lds, nsteps, drag, lift, iters, st);
   if (e != hipSuccess) return fail("evolve_kernel launch", e);
   return 0;
 }

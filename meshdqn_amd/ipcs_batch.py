@@ -40,7 +40,8 @@ class IpcsBatch:
 
     def __init__(self, topos: Sequence[MeshTopology], coords: Sequence[np.ndarray] | None = None,
                  mu: float = 1e-3, rho: float = 1.0, dt: float = 1e-3, rtol: float = 1e-10,
-                 maxit=(200, 4000, 200), device: str | torch.device = "cuda", capacities: dict | None = None):
+                 maxit=(200, 4000, 200), device: str | torch.device = "cuda", capacities: dict | None = None,
+                 mode: int = -1):
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -97,6 +98,9 @@ class IpcsBatch:
         h["sl2_col"] = stack("sl2_col", (NSE2,), np.int32)
         h["sl1_off"] = stack("sl1_off", (NV // 64 + 2,), np.int32)
         h["sl1_col"] = stack("sl1_col", (NSE1,), np.int32)
+        NCH = (NT + 1023) // 1024
+        h["mf_scat"] = stack("mf_scat", (6, NT), np.int32)
+        h["mf_tptr"] = stack("mf_tptr", (NCH, N2 + 1), np.int32)
         h["g2_ptr"] = stack("g2_ptr", (N2 + 1,), np.int32)
         h["g2_src"] = stack("g2_src", (6 * NT,), np.int32)
         h["g1_ptr"] = stack("g1_ptr", (NV + 1,), np.int32)
@@ -135,6 +139,7 @@ class IpcsBatch:
         d.NSE2, d.NSE1 = NSE2, NSE1
         d.mu, d.rho, d.dt, d.rtol = self.mu, self.rho, self.dt, self.rtol
         d.maxit_u, d.maxit_p, d.maxit_m = self.maxit
+        d.mode = int(mode)
         for name, _typ in _lib.IpcsDesc._fields_:
             if name in t:
                 setattr(d, name, t[name].data_ptr())
@@ -154,6 +159,7 @@ class IpcsBatch:
         af, af_edges = topo.facets(bc["tags"], TAG_AIRFOIL)
         sl2_off, sl2_col, pos2 = topo.sell_layout(rowptr2, colidx2)
         sl1_off, sl1_col, pos1 = topo.sell_layout(rowptr1, colidx1)
+        mf_scat, mf_tptr = topo.matfree_maps(1024)
         cell_outflow = np.full(topo.nt, -1, dtype=np.int8)
         cell_outflow[out_f[:, 0]] = out_f[:, 1]
         return dict(nv=topo.nv, nt=topo.nt, ne=topo.ne, coords=np.asarray(coords, np.float64),
@@ -162,6 +168,7 @@ class IpcsBatch:
                     rowptr2=rowptr2, colidx2=colidx2, asm2_ptr=asm2_ptr, asm2_src=asm2_src,
                     rowptr1=rowptr1, colidx1=colidx1, asm1_ptr=asm1_ptr, asm1_src=asm1_src,
                     sl2_off=sl2_off, sl2_col=sl2_col, sl1_off=sl1_off, sl1_col=sl1_col, pos2=pos2, pos1=pos1,
+                    mf_scat=mf_scat, mf_tptr=mf_tptr,
                     g2_ptr=gat["p2"][0], g2_src=gat["p2"][1], g1_ptr=gat["p1"][0], g1_src=gat["p1"][1],
                     bcu_flag=bc["bcu_flag"], bcu_gx=bc["bcu_gx"], bcp_flag=bc["bcp_flag"],
                     af=af, af_edges=af_edges, tags=bc["tags"])

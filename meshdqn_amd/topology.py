@@ -239,6 +239,30 @@ class MeshTopology:
         np.cumsum(np.bincount(flat, minlength=ndofs), out=ptr[1:])
         return ptr, order
 
+    def matfree_maps(self, chunk=1024):
+        """Tile maps of the matrix-free operator application (one chunk = `chunk`
+        consecutive triangles = one LDS tile of 6*chunk element results):
+          scat (6, nt): position of result i of triangle e inside its chunk's tile;
+                        tile entries are ordered by (destination row, triangle) so that
+          tptr (nchunks, np2+1): row r owns tile entries [tptr[c,r], tptr[c,r+1]) of chunk c,
+                        in ascending triangle order (deterministic summation)."""
+        nt, n2 = self.nt, self.np2
+        nch = max((nt + chunk - 1) // chunk, 1)
+        rows = self.cell_dofs  # (nt,6)
+        e_idx = np.repeat(np.arange(nt)[:, None], 6, axis=1)
+        scat = np.zeros((nt, 6), dtype=np.int32)
+        tptr = np.zeros((nch, n2 + 1), dtype=np.int32)
+        for c in range(nch):
+            lo, hi = c * chunk, min((c + 1) * chunk, nt)
+            r = rows[lo:hi].ravel()
+            e = e_idx[lo:hi].ravel()
+            order = np.lexsort((e, r))
+            pos = np.empty(order.size, dtype=np.int32)
+            pos[order] = np.arange(order.size, dtype=np.int32)
+            scat[lo:hi] = pos.reshape(hi - lo, 6)
+            np.cumsum(np.bincount(r, minlength=n2), out=tptr[c, 1:])
+        return np.ascontiguousarray(scat.T), tptr
+
     def dof_gathers(self):
         return dict(p2=self._dof_gather(self.cell_dofs, self.np2),
                     p1=self._dof_gather(self.cells, self.nv))
