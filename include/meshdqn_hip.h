@@ -95,6 +95,23 @@ typedef struct mdq_ipcs_desc {
   const uint8_t* bcu_flag;     /* [B][N2]  1 = velocity dof constrained (both components) */
   const double* bcu_gx;        /* [B][N2]  x-velocity value (y value is 0)    */
   const uint8_t* bcp_flag;     /* [B][NV]  1 = pressure dof constrained to 0  */
+  /* direct (substructured) pressure solver, written by the host after assembly
+     (meshdqn_amd/pressure_direct.py; replaces the reference's MUMPS factorisation of A2,
+     flow_solver.py:150-159).  pd_enabled = 0 -> Jacobi-CG on the SELL operator instead. */
+  int32_t pd_enabled;
+  int32_t NPART, NPW, NPF, NPGI, NPS, NPGK;   /* capacities of the arrays below */
+  int32_t _pad1;
+  const int32_t* pd_hdr;       /* [B][4]  nI, nG, nparts, 0                       */
+  const int32_t* pd_node;      /* [B][NV] node id of permuted position (interiors by subdomain, then separator) */
+  const int32_t* pd_meta;      /* [B][NPART][6] q0, m, W offset, F offset, g, gidx offset */
+  const int32_t* pd_rowblk;    /* [B][NV] subdomain of permuted interior row       */
+  const double* pd_W;          /* [B][NPW]  inv(K[I_s,I_s]) column-major blocks    */
+  const double* pd_F;          /* [B][NPF]  W_s K[I_s,G_s] column-major blocks     */
+  const int32_t* pd_gidx;      /* [B][NPGI] separator-local column ids of F blocks */
+  const double* pd_Sinv;       /* [B][NPS]  inverse Schur complement, column-major nG x nG */
+  const int32_t* pd_gk_ptr;    /* [B][NV+1] CSR of K[G,I] in permuted interior numbering */
+  const int32_t* pd_gk_col;    /* [B][NPGK] */
+  const double* pd_gk_val;     /* [B][NPGK] */
   /* airfoil facets for the probes (probes.py:23-50), device */
   const int32_t* af_facets;    /* [B][NAF][2] (cell, local edge)              */
   /* assembled operators, device, written by mdq_ipcs_assemble */

@@ -35,6 +35,11 @@ class IpcsDesc(C.Structure):
         ("mf_scat", C.c_void_p), ("mf_tptr", C.c_void_p),
         ("g2_ptr", C.c_void_p), ("g2_src", C.c_void_p), ("g1_ptr", C.c_void_p), ("g1_src", C.c_void_p),
         ("bcu_flag", C.c_void_p), ("bcu_gx", C.c_void_p), ("bcp_flag", C.c_void_p),
+        ("pd_enabled", C.c_int32), ("NPART", C.c_int32), ("NPW", C.c_int32), ("NPF", C.c_int32),
+        ("NPGI", C.c_int32), ("NPS", C.c_int32), ("NPGK", C.c_int32), ("_pad1", C.c_int32),
+        ("pd_hdr", C.c_void_p), ("pd_node", C.c_void_p), ("pd_meta", C.c_void_p), ("pd_rowblk", C.c_void_p),
+        ("pd_W", C.c_void_p), ("pd_F", C.c_void_p), ("pd_gidx", C.c_void_p), ("pd_Sinv", C.c_void_p),
+        ("pd_gk_ptr", C.c_void_p), ("pd_gk_col", C.c_void_p), ("pd_gk_val", C.c_void_p),
         ("af_facets", C.c_void_p),
         ("geom", C.c_void_p), ("A1", C.c_void_p), ("Ms", C.c_void_p), ("K1s", C.c_void_p),
         ("lift1", C.c_void_p), ("lift3", C.c_void_p), ("idiag1", C.c_void_p),

@@ -845,6 +845,101 @@ __device__ inline int cg_pressure(int n, const int32_t* sl_off, const int32_t* s
   return it;
 }
 
+// ================================================================== direct pressure solve
+//
+// Solve phase of the substructuring factorisation built by meshdqn_amd/pressure_direct.py
+// (the MI355X counterpart of the MUMPS back-substitution of flow_solver.py:380): dense
+// column-major blocks, one thread per row, coalesced streaming, three barriers per solve.
+struct PdView {
+  int nI, nG, nparts;
+  const int32_t *node, *meta, *rowblk, *gidx, *gk_ptr, *gk_col;
+  const double *W, *F, *Sinv, *gk_val;
+};
+
+__device__ __forceinline__ PdView pd_view(const mdq_ipcs_desc& d, int b) {
+  PdView p;
+  const int64_t B = b;
+  const int32_t* h = d.pd_hdr + B * 4;
+  p.nI = h[0];
+  p.nG = h[1];
+  p.nparts = h[2];
+  p.node = d.pd_node + B * d.NV;
+  p.meta = d.pd_meta + B * d.NPART * 6;
+  p.rowblk = d.pd_rowblk + B * d.NV;
+  p.W = d.pd_W + B * d.NPW;
+  p.F = d.pd_F + B * d.NPF;
+  p.gidx = d.pd_gidx + B * d.NPGI;
+  p.Sinv = d.pd_Sinv + B * d.NPS;
+  p.gk_ptr = d.pd_gk_ptr + B * (d.NV + 1);
+  p.gk_col = d.pd_gk_col + B * d.NPGK;
+  p.gk_val = d.pd_gk_val + B * d.NPGK;
+  return p;
+}
+
+// x = K^-1 b.  b, x: LDS vectors in natural node order (x may alias b); t0,t1,t2: LDS scratch
+// of at least max(n, WG) doubles each.
+__device__ inline void pressure_direct(const PdView& pd, int n, const double* b, double* x, double* t0, double* t1,
+                                       double* t2) {
+  const int tid = threadIdx.x, nI = pd.nI, nG = pd.nG;
+  double* bp = t0;  // permuted right-hand side
+  double* y = t1;   // W b_I  |  separator: g, then x_G
+  __syncthreads();
+  for (int q = tid; q < n; q += WG) bp[q] = b[pd.node[q]];
+  __syncthreads();
+  // y_I = W b_I
+  for (int q = tid; q < nI; q += WG) {
+    const int32_t* m6 = pd.meta + 6 * pd.rowblk[q];
+    const int q0 = m6[0], m = m6[1];
+    const double* Wc = pd.W + m6[2] + (q - q0);
+    double acc = 0.0;
+#pragma unroll 8
+    for (int j = 0; j < m; ++j) acc += Wc[(int64_t)j * m] * bp[q0 + j];
+    y[q] = acc;
+  }
+  __syncthreads();
+  // g = b_G - K[G,I] y_I
+  for (int g = tid; g < nG; g += WG) {
+    double acc = bp[nI + g];
+    for (int k = pd.gk_ptr[g]; k < pd.gk_ptr[g + 1]; ++k) acc -= pd.gk_val[k] * y[pd.gk_col[k]];
+    y[nI + g] = acc;
+  }
+  __syncthreads();
+  // x_G = Sinv g : rows split over column slices so that all waves stream Sinv
+  const int NGP = (nG + 63) & ~63;
+  const int nsl = NGP > 0 ? (WG / NGP > 0 ? WG / NGP : 1) : 1;
+  const int cw = (nG + nsl - 1) / nsl;
+  for (int idx = tid; idx < nsl * NGP; idx += WG) {
+    const int sl = idx / NGP, row = idx - sl * NGP;
+    double acc = 0.0;
+    if (row < nG) {
+      const int c1 = min(nG, (sl + 1) * cw);
+      const double* Sc = pd.Sinv + row;
+#pragma unroll 8
+      for (int c = sl * cw; c < c1; ++c) acc += Sc[(int64_t)c * nG] * y[nI + c];
+    }
+    t2[idx] = acc;
+  }
+  __syncthreads();
+  for (int g = tid; g < nG; g += WG) {
+    double acc = 0.0;
+    for (int sl = 0; sl < nsl; ++sl) acc += t2[sl * NGP + g];
+    bp[g] = acc;  // x_G (bp is free now)
+  }
+  __syncthreads();
+  // x_I = y_I - F x_G ; scatter back to natural order
+  for (int q = tid; q < nI; q += WG) {
+    const int32_t* m6 = pd.meta + 6 * pd.rowblk[q];
+    const int q0 = m6[0], m = m6[1], gs = m6[4];
+    const double* Fc = pd.F + m6[3] + (q - q0);
+    const int32_t* gi = pd.gidx + m6[5];
+    double acc = y[q];
+    for (int c = 0; c < gs; ++c) acc -= Fc[(int64_t)c * m] * bp[gi[c]];
+    x[pd.node[q]] = acc;
+  }
+  for (int g = tid; g < nG; g += WG) x[pd.node[nI + g]] = bp[g];
+  __syncthreads();
+}
+
 // ================================================================== probes
 
 // (drag, lift) of one field pair on the airfoil facets; result valid in every thread.
@@ -928,11 +1023,11 @@ struct LdsPlan {
 __host__ __device__ inline LdsPlan lds_plan(int N2, int NV, int NSE1) {
   LdsPlan P;
   P.N2p = (N2 + 1) & ~1;
-  P.NVp = (NV + 1) & ~1;
+  P.NVp = ((NV > WG ? NV : WG) + 63) & ~63;
   P.vel1_bytes = 2 * sizeof(double2) * (size_t)P.N2p;
   P.vel2_bytes = sizeof(double2) * ((size_t)P.N2p + 6 * MF_CH);
-  P.prs_vec_bytes = 4 * sizeof(double) * (size_t)P.NVp;
-  P.prs_mat_bytes = sizeof(double) * (size_t)NSE1 + sizeof(int32_t) * ((size_t)NSE1 + (NSE1 & 1)) +
+  P.prs_vec_bytes = 5 * sizeof(double) * (size_t)P.NVp;  // x, r, p, q + one scratch vector (direct solver)
+  P.prs_mat_bytes = sizeof(double) * (size_t)(NSE1 > WG ? NSE1 : WG) + sizeof(int32_t) * ((size_t)NSE1 + (NSE1 & 1)) +
                     sizeof(int32_t) * (size_t)(((NV / 64 + 2) + 1) & ~1);
   return P;
 }
@@ -1059,7 +1154,7 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
     MDQ_STAMP(2)
 
     // ---------------- step 2: pressure  (flow_solver.py:115-116)
-    if (K1_LDS) {
+    if (K1_LDS && !d.pd_enabled) {
       const int ne1 = v.sl1_off[nsl1];
       for (int k = tid; k < ne1; k += WG) {
         lK[k] = v.K1s[k];
@@ -1077,7 +1172,12 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
       px[i] = v.p_n[i] * sd;
     }
     MDQ_STAMP(3)
-    it_p += cg_pressure(nv, so1, ci1, K1, d.rtol, d.maxit_p, px, pr, pp, pq, red);
+    if (d.pd_enabled) {
+      const PdView pd = pd_view(d, b);
+      pressure_direct(pd, nv, pr, px, pp, pq, lK);
+    } else {
+      it_p += cg_pressure(nv, so1, ci1, K1, d.rtol, d.maxit_p, px, pr, pp, pq, red);
+    }
     MDQ_STAMP(4)
     for (int i = tid; i < nv; i += WG) pnew[i] = px[i] / v.sdiagK[i];
     __syncthreads();
@@ -1400,7 +1500,7 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
     MDQ_STAMP(2)
 
     // ================= step 2: pressure (assembled K1 in SELL form, LDS resident)
-    if (K1_LDS) {
+    if (K1_LDS && !d.pd_enabled) {
       const int ne1 = v.sl1_off[nsl1];
       for (int kk = tid; kk < ne1; kk += WG) {
         lK[kk] = v.K1s[kk];
@@ -1418,7 +1518,12 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
       px[i] = v.p_n[i] * sd;
     }
     MDQ_STAMP(3)
-    it_p += cg_pressure(nv, so1, ci1, K1, d.rtol, d.maxit_p, px, pr, pp, pq, red);
+    if (d.pd_enabled) {
+      const PdView pd = pd_view(d, b);
+      pressure_direct(pd, nv, pr, px, pp, pq, lK);
+    } else {
+      it_p += cg_pressure(nv, so1, ci1, K1, d.rtol, d.maxit_p, px, pr, pp, pq, red);
+    }
     MDQ_STAMP(4)
     for (int i = tid; i < nv; i += WG) pnew[i] = px[i] / v.sdiagK[i];
     __syncthreads();
@@ -1675,7 +1780,7 @@ int mdq_ipcs_evolve(const mdq_ipcs_desc* d, int32_t nsteps, double* drag, double
   const LdsPlan P = lds_plan(d->N2, d->NV, d->NSE1);
   const size_t LDS_MAX = 160 * 1024, red_bytes = 64 * sizeof(double);
   if (red_bytes + P.prs_vec_bytes > LDS_MAX) return fail_msg("mesh too large for the LDS-resident pressure vectors");
-  const bool k1_lds = red_bytes + P.prs_vec_bytes + P.prs_mat_bytes <= LDS_MAX;
+  const bool k1_lds = !d->pd_enabled && red_bytes + P.prs_vec_bytes + P.prs_mat_bytes <= LDS_MAX;
   int mode = d->mode;
   if (mode < 0 || mode > 2) {  // auto: matrix-free tiles if they fit, else LDS gather vectors, else global
     mode = 0;
@@ -1685,7 +1790,7 @@ int mdq_ipcs_evolve(const mdq_ipcs_desc* d, int32_t nsteps, double* drag, double
   if (mode == 2 && (red_bytes + P.vel2_bytes > LDS_MAX || d->N2 > MF_ROWS * WG))
     return fail_msg("matrix-free mode needs N2 <= 4096 and the x stage + element tile in LDS");
   if (mode == 1 && red_bytes + P.vel1_bytes > LDS_MAX) return fail_msg("LDS gather vectors do not fit");
-  size_t u = P.prs_vec_bytes + (k1_lds ? P.prs_mat_bytes : 0);
+  size_t u = P.prs_vec_bytes + (k1_lds ? P.prs_mat_bytes : 0);  // (K1 values alias the scratch vector: CG does not use it)
   const size_t vel = mode == 2 ? P.vel2_bytes : (mode == 1 ? P.vel1_bytes : 0);
   if (vel > u) u = vel;
   const size_t lds = red_bytes + u;

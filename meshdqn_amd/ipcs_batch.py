@@ -41,7 +41,7 @@ class IpcsBatch:
     def __init__(self, topos: Sequence[MeshTopology], coords: Sequence[np.ndarray] | None = None,
                  mu: float = 1e-3, rho: float = 1.0, dt: float = 1e-3, rtol: float = 1e-10,
                  maxit=(200, 4000, 200), device: str | torch.device = "cuda", capacities: dict | None = None,
-                 mode: int = -1):
+                 mode: int = -1, pressure_direct: bool = True, pressure_parts: int = 16):
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -144,8 +144,12 @@ class IpcsBatch:
             if name in t:
                 setattr(d, name, t[name].data_ptr())
         d.work_doubles = nwork
+        d.pd_enabled = 0
         self.desc = d
         self.assembled = False
+        self.pressure_direct = bool(pressure_direct)
+        self.pressure_parts = int(pressure_parts)
+        self._pd_cache = {}
 
     # ------------------------------------------------------------------
     @staticmethod
@@ -193,6 +197,52 @@ class IpcsBatch:
         rc = self.lib.mdq_ipcs_assemble(C.byref(self.desc), _lib.stream_ptr(stream))
         _lib.check(rc, "mdq_ipcs_assemble")
         self.assembled = True
+        if self.pressure_direct:
+            self._factorize_pressure()
+
+    def _factorize_pressure(self):
+        """Host factorisation of every environment's (scaled, BC-eliminated) pressure matrix
+        (`LUSolver('mumps')` of A2, flow_solver.py:150-159) -> substructuring factors on the device."""
+        from .pressure_direct import build_pressure_direct
+        torch.cuda.synchronize(self.device)
+        K1s = self.t["K1s"].cpu().numpy()
+        pds = []
+        for b, p in enumerate(self.per):
+            nv = p["nv"]
+            key = (id(self.topos[b]), p["coords"].tobytes())
+            if key not in self._pd_cache:
+                rp, ci, pos = p["rowptr1"], p["colidx1"], p["pos1"]
+                rows = np.repeat(np.arange(nv), np.diff(rp))
+                K = np.zeros((nv, nv))
+                K[rows, ci[:rp[-1]]] = K1s[b][pos]
+                self._pd_cache[key] = build_pressure_direct(p["coords"], K, self.pressure_parts)
+            pds.append(self._pd_cache[key])
+        B, NV = self.B, self.cap["NV"]
+        cap = dict(NPART=max(q["nparts"] for q in pds), NPW=max(max(q["W"].size for q in pds), 1),
+                   NPF=max(max(q["F"].size for q in pds), 1), NPGI=max(max(q["gidx"].size for q in pds), 1),
+                   NPS=max(max(q["Sinv"].size for q in pds), 1), NPGK=max(max(q["gk_col"].size for q in pds), 1))
+        self.pd_cap = cap
+
+        def stack(key, n, dtype):
+            out = np.zeros((B, n), dtype=dtype)
+            for b, q in enumerate(pds):
+                a = q[key]
+                out[b, :a.size] = a
+            return out
+
+        h = dict(pd_hdr=np.array([[q["nI"], q["nG"], q["nparts"], 0] for q in pds], np.int32),
+                 pd_node=stack("node", NV, np.int32), pd_meta=stack("meta", cap["NPART"] * 6, np.int32),
+                 pd_rowblk=stack("rowblk", NV, np.int32), pd_W=stack("W", cap["NPW"], np.float64),
+                 pd_F=stack("F", cap["NPF"], np.float64), pd_gidx=stack("gidx", cap["NPGI"], np.int32),
+                 pd_Sinv=stack("Sinv", cap["NPS"], np.float64), pd_gk_ptr=stack("gk_ptr", NV + 1, np.int32),
+                 pd_gk_col=stack("gk_col", cap["NPGK"], np.int32), pd_gk_val=stack("gk_val", cap["NPGK"], np.float64))
+        d = self.desc
+        for k, a in h.items():
+            self.t[k] = torch.from_numpy(a).to(self.device)
+            setattr(d, k, self.t[k].data_ptr())
+        d.NPART, d.NPW, d.NPF, d.NPGI, d.NPS, d.NPGK = (cap[k] for k in ("NPART", "NPW", "NPF", "NPGI", "NPS", "NPGK"))
+        d.pd_enabled = 1
+        self.pds = pds
 
     def evolve(self, nsteps: int = 1, stream=None, out=None):
         """Advance all environments `nsteps` IPCS steps; returns (drag, lift) (B,nsteps) device tensors."""

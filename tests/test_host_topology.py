@@ -87,3 +87,42 @@ def test_library_exports_every_declared_symbol(lib_built):
     for name in declared:
         assert hasattr(lib, name)
     assert lib.mdq_abi_version() == _lib.ABI_VERSION
+
+
+def test_pressure_direct_factors_reproduce_dense_solve(meshes):
+    """Substructuring factors (host setup of the direct pressure solver) against numpy's solve."""
+    from meshdqn_amd.pressure_direct import build_pressure_direct, solve_reference
+    from oracle.ipcs import OracleFlowSolver
+    coords, cells = meshes["ah93w145"]
+    fs = OracleFlowSolver(coords, cells, smooth=False, factorize=False)
+    K = fs.A2.toarray()
+    sd = np.sqrt(np.diag(K))
+    Kt = K / np.outer(sd, sd)
+    for parts in (1, 4, 16):
+        pd = build_pressure_direct(fs.mesh.coords, Kt, parts)
+        assert pd["nI"] + pd["nG"] == K.shape[0]
+        assert sorted(pd["node"].tolist()) == list(range(K.shape[0]))
+        rng = np.random.default_rng(parts)
+        b = rng.standard_normal(K.shape[0])
+        x = solve_reference(pd, b)
+        xr = np.linalg.solve(Kt, b)
+        assert np.abs(x - xr).max() / np.abs(xr).max() < 1e-11
+
+
+def test_descriptor_layout_matches_c_header(tmp_path):
+    """ctypes mirror of mdq_ipcs_desc has the same size / field offsets as the C header."""
+    import ctypes as C, os, subprocess
+    from meshdqn_amd import _lib
+    hdr = os.path.join(os.path.dirname(_lib.HERE), "include", "meshdqn_hip.h")
+    fields = [n for n, _ in _lib.IpcsDesc._fields_]
+    src = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{hdr}"', 'int main(){',
+           'printf("%zu\\n", sizeof(mdq_ipcs_desc));']
+    src += [f'printf("%zu\\n", offsetof(mdq_ipcs_desc, {f}));' for f in fields]
+    src.append('return 0;}')
+    cfile = tmp_path / "lay.c"
+    cfile.write_text("\n".join(src))
+    exe = tmp_path / "lay"
+    subprocess.check_call(["gcc", str(cfile), "-o", str(exe)])
+    vals = [int(x) for x in subprocess.check_output([str(exe)]).decode().split()]
+    assert vals[0] == C.sizeof(_lib.IpcsDesc)
+    assert vals[1:] == [getattr(_lib.IpcsDesc, f).offset for f in fields]

@@ -64,12 +64,14 @@ def test_assembly_matches_oracle(meshes, oracle_solvers, lib_built):
         assert np.abs(l3 - o.lift3)[free].max() <= 1e-13 * max(1.0, np.abs(o.lift3).max())
 
 
-def test_first_steps_match_oracle(meshes, lib_built):
-    """Per-step parity of u, p, drag, lift against the sparse-LU oracle."""
+@pytest.mark.parametrize("mode,direct", [(2, True), (2, False), (1, True), (1, False), (0, False)])
+def test_first_steps_match_oracle(meshes, lib_built, mode, direct):
+    """Per-step parity of u, p, drag, lift against the sparse-LU oracle, for every operator
+    mode (0/1 assembled SELL, 2 matrix-free tiles) and both pressure solvers (direct / CG)."""
     import torch
     from oracle.ipcs import OracleFlowSolver
     names = ["ys930", "ah93w145"]
-    batch, topos, xs = _make(meshes, names, rtol=1e-12)
+    batch, topos, xs = _make(meshes, names, rtol=1e-12, mode=mode, pressure_direct=direct)
     oracles = [OracleFlowSolver(*meshes[n]) for n in names]
     for step in range(3):
         drag, lift = batch.evolve(1)
@@ -85,7 +87,8 @@ def test_first_steps_match_oracle(meshes, lib_built):
             assert abs(drag[b, 0].item() - do) / abs(do) < 1e-8
             assert abs(lift[b, 0].item() - lo) / abs(lo) < 1e-8
     it = batch.iters.cpu().numpy()
-    assert (it > 0).all()
+    assert (it[:, 0] > 0).all() and (it[:, 2] > 0).all()
+    assert ((it[:, 1] == 0) if direct else (it[:, 1] > 0)).all()
 
 
 def test_multi_step_launch_equals_single_steps(meshes, lib_built):
