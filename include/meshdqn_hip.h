@@ -59,7 +59,8 @@ typedef struct mdq_ipcs_desc {
   double rtol;          /* relative residual tolerance (preconditioned norm) */
   int32_t maxit_u, maxit_p, maxit_m;
   int32_t mode;         /* operator application: -1 auto, 0 assembled SELL (global gather vectors),
-                           1 assembled SELL (LDS gather vectors), 2 matrix-free LDS element tiles */
+                           1 assembled SELL (LDS gather vectors), 2 matrix-free LDS element tiles (bitwise
+                           reproducible), 3 matrix-free with LDS fp64 atomics (fastest; round-off reproducible) */
   /* per-environment counts, device int32[B] */
   const int32_t* nv;
   const int32_t* nt;
@@ -85,7 +86,7 @@ typedef struct mdq_ipcs_desc {
   const int32_t* sl1_off;      /* [B][NV/64+2] */
   const int32_t* sl1_col;      /* [B][NSE1]   */
   /* matrix-free tile maps (mode 2): chunks of 1024 consecutive triangles          */
-  const int32_t* mf_scat;      /* [B][6][NT]  tile position of result i of a triangle (ordered by row, triangle) */
+  const int32_t* mf_scat;      /* [B][6][NT]  packed: dof | tile position << 12 | (outflow edge + 1) << 28 (word 0); tile entries ordered by (row, triangle) */
   const int32_t* mf_tptr;      /* [B][NCH][N2+1] row r owns tile entries [tptr[r], tptr[r+1]) of chunk c; NCH = (NT+1023)/1024 */
   const int32_t* g2_ptr;       /* [B][N2+1]   P2 dof <- element slots         */
   const int32_t* g2_src;       /* [B][6*NT]   slot = cell*6 + i               */

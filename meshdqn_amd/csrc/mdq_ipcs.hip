@@ -1,6 +1,6 @@
 // IPCS Navier-Stokes hot path for gfx950: assembly, time stepping, probes.
 //
-// One 1024-thread workgroup (16 wave64) owns one environment for the whole
+// One 512-thread workgroup (8 wave64) owns one environment for the whole
 // launch: its operators, vectors and element scratch stay in that CU's L2 slice /
 // LDS, every synchronisation is a workgroup barrier, every reduction a fixed
 // tree (bitwise reproducible), and `nsteps` time steps run inside ONE launch.
@@ -26,12 +26,14 @@ namespace mdq {
 
 __constant__ RefTab c_tab;
 
+constexpr int MF_CH = 1024;  // triangles per LDS tile: 2 per thread, interleaved for FP64 ILP (host maps use the same chunking)
+
 // ------------------------------------------------------------------ per-environment views
 
 __host__ __device__ inline int64_t work_per_env(int NV, int NT, int NE) {
   const int64_t N2 = (int64_t)NV + NE;
   // escr 12*NT | 6 velocity vectors (double2[N2]) | p_new[NV] | 8 spare
-  const int64_t n = 12 * (int64_t)NT + 12 * N2 + NV + 8;
+  const int64_t n = 12 * (int64_t)NT + 12 * N2 + NV + 24;
   return (n + 31) & ~(int64_t)31;  // keep every environment's slab 256-byte aligned
 }
 
@@ -63,6 +65,9 @@ struct EnvView {
   double2* u_n;
   double* p_n;
   double* work;
+#ifdef MDQ_PROFILE
+  long long* sprof;  // LDS [8]: tile_accumulate phase cycles (thread 0)
+#endif
 };
 
 __device__ __forceinline__ EnvView env_view(const mdq_ipcs_desc& d, int b) {
@@ -91,7 +96,7 @@ __device__ __forceinline__ EnvView env_view(const mdq_ipcs_desc& d, int b) {
   v.sl1_col = d.sl1_col + B * d.NSE1;
   v.mf_scat = d.mf_scat + B * 6 * d.NT;
   v.mf_tstride = d.N2 + 1;
-  v.mf_tptr = d.mf_tptr + B * ((d.NT + 1023) / 1024) * (d.N2 + 1);
+  v.mf_tptr = d.mf_tptr + B * ((d.NT + MF_CH - 1) / MF_CH) * (d.N2 + 1);
   v.g2_ptr = d.g2_ptr + B * (d.N2 + 1);
   v.g2_src = d.g2_src + B * 6 * d.NT;
   v.g1_ptr = d.g1_ptr + B * (d.NV + 1);
@@ -458,74 +463,91 @@ __device__ inline void rhs3_elements(const EnvView& v, const mdq_ipcs_desc& d, c
 // then every thread sums the tile entries of its OWN rows (rows tid, tid+WG, ...) in ascending
 // triangle order (fixed order => bitwise reproducible, no atomics), barrier.
 // Requires n2 <= MF_ROWS*WG.
-constexpr int MF_CH = 1024;                    // triangles per LDS tile (host maps use the same chunking)
-constexpr int MF_ROWS = 4096 / WG;             // own rows per thread (n2 <= 4096)
+constexpr int MF_ROWS = 7;                     // own rows per thread: n2 <= MF_ROWS*WG = 3584
+
+// Per-thread metadata of the triangles it applies in one chunk (MF_EPT = MF_CH / WG of them):
+// 6 packed words (dof | tile position << 12 | (outflow edge + 1) << 28) + affine geometry.
+// It is PREFETCHED one chunk ahead (rolling over to chunk 0 of the next application) so that the
+// L2 latency of these loads hides behind the barrier / row-gather phase.
+constexpr int MF_EPT = MF_CH / WG;
+struct TileMeta {
+  int w[MF_EPT][6];
+  Geo g[MF_EPT];
+};
+
+__device__ __forceinline__ void tile_prefetch(const EnvView& v, TileMeta& tm, int chunk) {
+#pragma unroll
+  for (int j = 0; j < MF_EPT; ++j) {
+    const int e = chunk * MF_CH + threadIdx.x + j * WG;
+    if (e < v.nt) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) tm.w[j][i] = v.mf_scat[i * v.NT + e];
+      tm.g[j] = load_geo(v, e);
+    }
+  }
+}
 
 // acc[k] = sum of the element results that land on own row tid + k*WG (zero for rows >= n2).
-// op(e, geo, dofs, ye) fills the 6 double2 results of triangle e.
+// op(e, geo, dofs, outflow_edge, ye) fills the 6 double2 results of triangle e.
+// On entry tm holds the metadata of chunk 0; on exit again (prefetched for the next application).
 template <class ElemOp>
-__device__ __forceinline__ void tile_accumulate(const EnvView& v, double2* es, ElemOp op, double2 (&acc)[MF_ROWS]) {
+__device__ __forceinline__ void tile_accumulate(const EnvView& v, double2* es, TileMeta& tm, ElemOp op,
+                                                double2 (&acc)[MF_ROWS]) {
   const int tid = threadIdx.x, n = v.n2;
 #pragma unroll
   for (int k = 0; k < MF_ROWS; ++k) acc[k] = make_double2(0.0, 0.0);
-  int chunk = 0;
-  for (int c0 = 0; c0 < v.nt; c0 += MF_CH, ++chunk) {
-    // tile ranges of the own rows for this chunk: issued before the element work so that the
-    // L2 latency hides behind it
+  const int nch = (v.nt + MF_CH - 1) / MF_CH;
+#ifdef MDQ_PROFILE
+  long long tq = __builtin_amdgcn_s_memtime();
+#define MDQ_TSTAMP(k) { long long tn = __builtin_amdgcn_s_memtime(); if (tid == 0) v.sprof[k] += tn - tq; tq = tn; }
+#else
+#define MDQ_TSTAMP(k)
+#endif
+  for (int chunk = 0; chunk < nch; ++chunk) {
+    double2* eb = es;
+    // tile ranges of the own rows for this chunk (latency hides behind the element work)
     const int32_t* tp = v.mf_tptr + chunk * v.mf_tstride;
-    int lo[MF_ROWS], hi[MF_ROWS];
+    int lohi[MF_ROWS];  // lo | hi << 16 (tile positions < 6*MF_CH < 65536)
 #pragma unroll
     for (int k = 0; k < MF_ROWS; ++k) {
       const int row = tid + k * WG;
-      lo[k] = row < n ? tp[row] : 0;
-      hi[k] = row < n ? tp[row + 1] : 0;
+      lohi[k] = row < n ? (tp[row] | (tp[row + 1] << 16)) : 0;
     }
-    for (int e = c0 + tid; e < min(c0 + MF_CH, v.nt); e += WG) {
-      const ElemIdx E = load_dofs(v, e);
-      int sc[6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) sc[i] = v.mf_scat[i * v.NT + e];
-      const Geo g = load_geo(v, e);
-      double2 ye[6];
-      op(e, g, E, ye);
+    for (int j = 0; j < MF_EPT; ++j) {
+      const int e = chunk * MF_CH + tid + j * WG;
+      if (e < v.nt) {
+        ElemIdx E;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) es[sc[i]] = ye[i];
+        for (int i = 0; i < 6; ++i) E.dof[i] = tm.w[j][i] & 0xFFF;
+        double2 ye[6];
+        op(e, tm.g[j], E, ((tm.w[j][0] >> 28) & 3) - 1, ye);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) eb[(tm.w[j][i] >> 12) & 0x1FFF] = ye[i];
+      }
     }
+    MDQ_TSTAMP(0)
+    tile_prefetch(v, tm, chunk + 1 < nch ? chunk + 1 : 0);
+    MDQ_TSTAMP(1)
     __syncthreads();
+    MDQ_TSTAMP(2)
 #pragma unroll
     for (int k = 0; k < MF_ROWS; ++k) {
-      for (int j = lo[k]; j < hi[k]; ++j) {
-        const double2 c = es[j];
+      for (int j = lohi[k] & 0xFFFF; j < (lohi[k] >> 16); ++j) {
+        const double2 c = eb[j];
         acc[k].x += c.x;
         acc[k].y += c.y;
       }
     }
+    MDQ_TSTAMP(3)
     __syncthreads();
-  }
-}
-
-template <class ElemOp, class Epi>
-__device__ __forceinline__ void matfree_apply(const EnvView& v, const double2* x, double2* es, ElemOp op, Epi epi) {
-  double2 acc[MF_ROWS];
-  tile_accumulate(
-      v, es,
-      [&](int e, const Geo& g, const ElemIdx& E, double2(&ye)[6]) {
-        double2 xe[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) xe[i] = x[E.dof[i]];
-        op(e, g, xe, ye);
-      },
-      acc);
-#pragma unroll
-  for (int k = 0; k < MF_ROWS; ++k) {
-    const int row = threadIdx.x + k * WG;
-    if (row < v.n2) epi(row, acc[k].x, acc[k].y);
+    MDQ_TSTAMP(4)
   }
 }
 
 // ================================================================== sparse kernels (workgroup-wide)
 //
-// SELL-64, one thread per row: wave w owns slices w, w+16, ... (rows tid, tid+1024, ...), the
+// SELL-64, one thread per row: wave w owns slices w, w+NWAVE, ... (rows tid, tid+WG, ...), the
 // same ownership as every `for (i = tid; i < n; i += WG)` vector pass, so a thread only ever
 // reads/writes its own entries of the Krylov vectors; only the SpMV input vector is gathered.
 // Matrix loads are perfectly coalesced (64 lanes x 32 B / 8 B contiguous per instruction).
@@ -614,29 +636,8 @@ struct VelCtx {
 // y = (D^-1 A1_bc) x on vectors that vanish on constrained dofs (see bicgstab_velocity)
 template <int MODE, class Epi>
 __device__ __forceinline__ void apply_velocity(const EnvView& v, const VelCtx& c, const double2* gx, Epi epi) {
-  if (MODE == 2) {
-    matfree_apply(
-        v, gx, c.es,
-        [&](int e, const Geo& g, const double2(&xe)[6], double2(&ye)[6]) {
-          elem_velocity(g, c.a, c.mu, xe, ye);
-          const int ko = v.cell_outflow[e];
-          if (ko >= 0) {
-            double X[3][2];
-            load_cell_coords(v, e, X);
-            elem_outflow_add(g, X, ko, -0.5 * c.mu, xe, ye);
-          }
-        },
-        [&](int row, double y0, double y1) {
-          if (v.bcu_flag[row]) {
-            epi(row, 0.0, 0.0);
-          } else {
-            const double2 id = v.idiag1[row];
-            epi(row, y0 * id.x, y1 * id.y);
-          }
-        });
-  } else {
-    spmv_sell_b2(v.sl2_off, v.sl2_col, v.A1, gx, v.n2, epi);
-  }
+  static_assert(MODE != 2, "the matrix-free mode has its own kernel (evolve_mf_kernel)");
+  spmv_sell_b2(v.sl2_off, v.sl2_col, v.A1, gx, v.n2, epi);
 }
 
 // BiCGStab on the row-scaled velocity system  (D^-1 A1_bc) x = D^-1 b.
@@ -730,21 +731,8 @@ struct MassCtx {
 // y = (S^-1 M_bc S^-1) x on vectors that vanish on constrained dofs
 template <int MODE, class Epi>
 __device__ __forceinline__ void apply_mass(const EnvView& v, const MassCtx& c, const double2* gx, Epi epi) {
-  if (MODE == 2) {
-    // gx holds S^-1 x (pre-scaled when staged), the epilogue applies the left S^-1
-    matfree_apply(
-        v, gx, c.es, [&](int, const Geo& g, const double2(&xe)[6], double2(&ye)[6]) { elem_mass(g, xe, ye); },
-        [&](int row, double y0, double y1) {
-          if (v.bcu_flag[row]) {
-            epi(row, 0.0, 0.0);
-          } else {
-            const double is = 1.0 / v.sdiagM[row];
-            epi(row, y0 * is, y1 * is);
-          }
-        });
-  } else {
-    spmv_sell_2rhs(v.sl2_off, v.sl2_col, v.Ms, gx, v.n2, epi);
-  }
+  static_assert(MODE != 2, "the matrix-free mode has its own kernel (evolve_mf_kernel)");
+  spmv_sell_2rhs(v.sl2_off, v.sl2_col, v.Ms, gx, v.n2, epi);
 }
 
 // CG on the symmetrically scaled mass system, both velocity components at once.
@@ -1018,14 +1006,15 @@ __global__ __launch_bounds__(WG) void probe_kernel(mdq_ipcs_desc d, int nfields,
 //                                  | pressure: 4 vectors [NVp] + K1 in SELL form (values, columns, slice offsets)]
 struct LdsPlan {
   int N2p, NVp;
-  size_t vel1_bytes, vel2_bytes, prs_vec_bytes, prs_mat_bytes;
+  size_t vel1_bytes, vel2_bytes, vel3_bytes, prs_vec_bytes, prs_mat_bytes;
 };
 __host__ __device__ inline LdsPlan lds_plan(int N2, int NV, int NSE1) {
   LdsPlan P;
   P.N2p = (N2 + 1) & ~1;
   P.NVp = ((NV > WG ? NV : WG) + 63) & ~63;
   P.vel1_bytes = 2 * sizeof(double2) * (size_t)P.N2p;
-  P.vel2_bytes = sizeof(double2) * ((size_t)P.N2p + 6 * MF_CH);
+  P.vel2_bytes = sizeof(double2) * ((size_t)P.N2p + 6 * MF_CH);  // stage + tile
+  P.vel3_bytes = 3 * sizeof(double2) * (size_t)P.N2p;  // p, r, result vector
   P.prs_vec_bytes = 5 * sizeof(double) * (size_t)P.NVp;  // x, r, p, q + one scratch vector (direct solver)
   P.prs_mat_bytes = sizeof(double) * (size_t)(NSE1 > WG ? NSE1 : WG) + sizeof(int32_t) * ((size_t)NSE1 + (NSE1 & 1)) +
                     sizeof(int32_t) * (size_t)(((NV / 64 + 2) + 1) & ~1);
@@ -1281,10 +1270,9 @@ static hipError_t launch_evolve(const mdq_ipcs_desc* d, size_t lds, int nsteps, 
   _Pragma("unroll") for (int k = 0; k < MF_ROWS; ++k) \
     if (const int row = threadIdx.x + k * WG; row < n2)
 
-__device__ __forceinline__ void velocity_op(const EnvView& v, double a, double mu, int e, const Geo& g,
+__device__ __forceinline__ void velocity_op(const EnvView& v, double a, double mu, int e, int ko, const Geo& g,
                                             const double2 (&xe)[6], double2 (&ye)[6]) {
   elem_velocity(g, a, mu, xe, ye);
-  const int ko = v.cell_outflow[e];
   if (ko >= 0) {
     double X[3][2];
     load_cell_coords(v, e, X);
@@ -1324,6 +1312,15 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
   const int32_t* ci1 = K1_LDS ? lci : v.sl1_col;
   const double* K1 = K1_LDS ? lK : v.K1s;
 
+#ifdef MDQ_PROFILE
+  __shared__ long long sprof_s[16];
+  if (tid < 16) sprof_s[tid] = 0;
+  const_cast<EnvView&>(v).sprof = sprof_s;
+  __syncthreads();
+#endif
+  TileMeta tm;
+  tile_prefetch(v, tm, 0);
+
   int it_u = 0, it_p = 0, it_m = 0;
 #ifdef MDQ_PROFILE
   long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1334,22 +1331,32 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
   for (int step = 0; step < nsteps; ++step) {
     MDQ_STAMP(7)
     // ================= step 1: tentative velocity
-    double2 x[MF_ROWS], r[MF_ROWS], rh[MF_ROWS], p[MF_ROWS], vv[MF_ROWS], y[MF_ROWS];
+    double2 r[MF_ROWS], p[MF_ROWS], vv[MF_ROWS], y[MF_ROWS];
+    // Register budget: the element phase interleaves two triangles per thread for FP64 ILP, so only
+    // r, p, v stay in registers across it; x (updated once per iteration) and the shadow residual
+    // rh (constant) live in global memory, touched by their row owner only (coalesced, L2 resident).
+    double2* xg = xs;
+    double2* rhg = reinterpret_cast<double2*>(w + 12 * (int64_t)d.NT) + d.N2;
     // Jacobi row scaling of the velocity system with the Dirichlet flag folded in (0 = constrained row)
-    double2 idg[MF_ROWS];
+    // (kept in fp32: any positive row scaling is a valid left preconditioner and the solution of
+    // D^-1 A x = D^-1 b does not depend on it; fp32 halves its register footprint)
+    float2 idg[MF_ROWS];
 #pragma unroll
     for (int k = 0; k < MF_ROWS; ++k) {
       const int row = tid + k * WG;
-      idg[k] = make_double2(0.0, 0.0);
-      if (row < n2 && !v.bcu_flag[row]) idg[k] = v.idiag1[row];
+      idg[k] = make_float2(0.f, 0.f);
+      if (row < n2 && !v.bcu_flag[row]) {
+        const double2 t_ = v.idiag1[row];
+        idg[k] = make_float2((float)t_.x, (float)t_.y);
+      }
     }
     {
       // f = rhs(F1) (volume + outflow facet term), element vectors through the tile
       const double2* un = v.u_n;
       const double* pn = v.p_n;
       tile_accumulate(
-          v, tile,
-          [&](int e, const Geo& g, const ElemIdx& E, double2(&ye)[6]) {
+          v, tile, tm,
+          [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
             double2 ue[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) ue[i] = un[E.dof[i]];
@@ -1357,7 +1364,6 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
 #pragma unroll
             for (int i = 0; i < 3; ++i) pe[i] = pn[E.dof[i]];
             elem_rhs1_vol(g, a, mu, d.rho, ue, pe, ye);
-            const int ko = v.cell_outflow[e];
             if (ko >= 0) {
               double X[3][2];
               load_cell_coords(v, e, X);
@@ -1371,12 +1377,12 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
 #pragma unroll
     for (int k = 0; k < MF_ROWS; ++k) {
       const int row = tid + k * WG;
-      x[k] = make_double2(0.0, 0.0);
       if (row < n2) {
         const bool fl = v.bcu_flag[row] != 0;
         const double2 g = make_double2(v.bcu_gx[row], 0.0);
-        x[k] = fl ? g : v.u_n[row];  // initial guess satisfies the Dirichlet values
-        stage[row] = x[k];
+        const double2 x0 = fl ? g : v.u_n[row];  // initial guess satisfies the Dirichlet values
+        xg[row] = x0;
+        stage[row] = x0;
         // |D^-1 b|^2 with b = f - lift (free) / g (constrained): same norm as the assembled path
         const double2 l = v.lift1[row];
         const double2 bi = fl ? g : make_double2((y[k].x - l.x) * idg[k].x, (y[k].y - l.y) * idg[k].y);
@@ -1387,19 +1393,20 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
     {
       double2 ax[MF_ROWS];
       tile_accumulate(
-          v, tile,
-          [&](int e, const Geo& g, const ElemIdx& E, double2(&ye)[6]) {
+          v, tile, tm,
+          [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
             double2 xe[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) xe[i] = stage[E.dof[i]];
-            velocity_op(v, a, mu, e, g, xe, ye);
+            velocity_op(v, a, mu, e, ko, g, xe, ye);
           },
           ax);
 #pragma unroll
       for (int k = 0; k < MF_ROWS; ++k) {
+        const int row = tid + k * WG;
         // r0 = D^-1 (f - A_full x0) on free rows, 0 on constrained rows (idg = 0 there)
         r[k] = make_double2((y[k].x - ax[k].x) * idg[k].x, (y[k].y - ax[k].y) * idg[k].y);
-        rh[k] = r[k];
+        if (row < n2) rhg[row] = r[k];
         p[k] = make_double2(0.0, 0.0);
         vv[k] = make_double2(0.0, 0.0);
         acc[1] += r[k].x * r[k].x + r[k].y * r[k].y;
@@ -1413,8 +1420,15 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
       if (rr > tol2 && bb != 0.0) {
         double rho = rr, rho_old = 1.0, alpha = 1.0, omega = 1.0;
         int it = 0;
+#ifdef MDQ_PROFILE
+        long long tb = __builtin_amdgcn_s_memtime();
+#define MDQ_BSTAMP(k) { long long tn = __builtin_amdgcn_s_memtime(); if (tid == 0) sprof_s[k] += tn - tb; tb = tn; }
+#else
+#define MDQ_BSTAMP(k)
+#endif
         while (it < d.maxit_u) {
           ++it;
+          MDQ_BSTAMP(15)
           const double beta = (rho / rho_old) * (alpha / omega);
 #pragma unroll
           for (int k = 0; k < MF_ROWS; ++k) {
@@ -1423,22 +1437,29 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
             if (row < n2) stage[row] = p[k];
           }
           __syncthreads();
+          MDQ_BSTAMP(8)
           tile_accumulate(
-              v, tile,
-              [&](int e, const Geo& g, const ElemIdx& E, double2(&ye)[6]) {
+              v, tile, tm,
+              [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
                 double2 xe[6];
 #pragma unroll
                 for (int i = 0; i < 6; ++i) xe[i] = stage[E.dof[i]];
-                velocity_op(v, a, mu, e, g, xe, ye);
+                velocity_op(v, a, mu, e, ko, g, xe, ye);
               },
               vv);
+          MDQ_BSTAMP(9)
           double a1[1] = {0.0};
 #pragma unroll
           for (int k = 0; k < MF_ROWS; ++k) {
+            const int row = tid + k * WG;
             vv[k] = make_double2(vv[k].x * idg[k].x, vv[k].y * idg[k].y);
-            a1[0] += rh[k].x * vv[k].x + rh[k].y * vv[k].y;
+            if (row < n2) {
+              const double2 h = rhg[row];
+              a1[0] += h.x * vv[k].x + h.y * vv[k].y;
+            }
           }
           block_sum<1>(a1, red);
+          MDQ_BSTAMP(10)
           if (a1[0] == 0.0) break;
           alpha = rho / a1[0];
           double a2[1] = {0.0};
@@ -1450,22 +1471,29 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
             a2[0] += r[k].x * r[k].x + r[k].y * r[k].y;
           }
           block_sum<1>(a2, red);  // its barriers publish the staged s
+          MDQ_BSTAMP(11)
           if (!(a2[0] > tol2)) {
 #pragma unroll
-            for (int k = 0; k < MF_ROWS; ++k)
-              x[k] = make_double2(x[k].x + alpha * p[k].x, x[k].y + alpha * p[k].y);
+            for (int k = 0; k < MF_ROWS; ++k) {
+              const int row = tid + k * WG;
+              if (row < n2) {
+                const double2 xo = xg[row];
+                xg[row] = make_double2(xo.x + alpha * p[k].x, xo.y + alpha * p[k].y);
+              }
+            }
             break;
           }
           double2 t[MF_ROWS];
           tile_accumulate(
-              v, tile,
-              [&](int e, const Geo& g, const ElemIdx& E, double2(&ye)[6]) {
+              v, tile, tm,
+              [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
                 double2 xe[6];
 #pragma unroll
                 for (int i = 0; i < 6; ++i) xe[i] = stage[E.dof[i]];
-                velocity_op(v, a, mu, e, g, xe, ye);
+                velocity_op(v, a, mu, e, ko, g, xe, ye);
               },
               t);
+          MDQ_BSTAMP(12)
           double a3[2] = {0.0, 0.0};
 #pragma unroll
           for (int k = 0; k < MF_ROWS; ++k) {
@@ -1474,17 +1502,23 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
             a3[1] += t[k].x * t[k].x + t[k].y * t[k].y;
           }
           block_sum<2>(a3, red);
+          MDQ_BSTAMP(13)
           if (a3[1] == 0.0) break;
           omega = a3[0] / a3[1];
           double a4[2] = {0.0, 0.0};
 #pragma unroll
           for (int k = 0; k < MF_ROWS; ++k) {
-            x[k] = make_double2(x[k].x + alpha * p[k].x + omega * r[k].x, x[k].y + alpha * p[k].y + omega * r[k].y);
-            r[k] = make_double2(r[k].x - omega * t[k].x, r[k].y - omega * t[k].y);
-            a4[0] += r[k].x * r[k].x + r[k].y * r[k].y;
-            a4[1] += rh[k].x * r[k].x + rh[k].y * r[k].y;
+            const int row = tid + k * WG;
+            if (row < n2) {
+              const double2 xo = xg[row], h = rhg[row];
+              xg[row] = make_double2(xo.x + alpha * p[k].x + omega * r[k].x, xo.y + alpha * p[k].y + omega * r[k].y);
+              r[k] = make_double2(r[k].x - omega * t[k].x, r[k].y - omega * t[k].y);
+              a4[0] += r[k].x * r[k].x + r[k].y * r[k].y;
+              a4[1] += h.x * r[k].x + h.y * r[k].y;
+            }
           }
           block_sum<2>(a4, red);
+          MDQ_BSTAMP(14)
           rr = a4[0];
           if (!(rr > tol2)) break;
           rho_old = rho;
@@ -1494,9 +1528,7 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
         it_u += it;
       }
     }
-    // u* to global for the element loops of steps 2 and 3
-    MDQ_FOR_ROWS(k, row) xs[row] = x[k];
-    __syncthreads();
+    __syncthreads();  // xg (= xs, u*) complete: the element loops of steps 2 and 3 gather it
     MDQ_STAMP(2)
 
     // ================= step 2: pressure (assembled K1 in SELL form, LDS resident)
@@ -1532,8 +1564,8 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
     {
       const double* pold = v.p_n;
       tile_accumulate(
-          v, tile,
-          [&](int e, const Geo& g, const ElemIdx& E, double2(&ye)[6]) {
+          v, tile, tm,
+          [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
             double2 ue[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) ue[i] = xs[E.dof[i]];
@@ -1545,6 +1577,12 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
           y);
     }
     double am[2] = {0.0, 0.0};
+    double2 x[MF_ROWS];
+#pragma unroll
+    for (int k = 0; k < MF_ROWS; ++k) {
+      const int row = tid + k * WG;
+      x[k] = row < n2 ? xs[row] : make_double2(0.0, 0.0);  // u* (own rows)
+    }
     // symmetric Jacobi scaling S^-1 of the mass system, 0 on constrained rows
     double ism[MF_ROWS];
     // x still holds u* (satisfies the Dirichlet values): scaled unknown S x, stage S^-1 (S x0) = x0
@@ -1565,8 +1603,8 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
     {
       double2 ax[MF_ROWS];
       tile_accumulate(
-          v, tile,
-          [&](int, const Geo& g, const ElemIdx& E, double2(&ye)[6]) {
+          v, tile, tm,
+          [&](int, const Geo& g, const ElemIdx& E, int, double2(&ye)[6]) {
             double2 xe[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) xe[i] = stage[E.dof[i]];
@@ -1599,8 +1637,8 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
           __syncthreads();
           double2 q[MF_ROWS];
           tile_accumulate(
-              v, tile,
-              [&](int, const Geo& g, const ElemIdx& E, double2(&ye)[6]) {
+              v, tile, tm,
+              [&](int, const Geo& g, const ElemIdx& E, int, double2(&ye)[6]) {
                 double2 xe[6];
 #pragma unroll
                 for (int i = 0; i < 6; ++i) xe[i] = stage[E.dof[i]];
@@ -1656,6 +1694,7 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
   if (tid == 0) {
     double* pw = pnew + d.NV;
     for (int k = 0; k < 8; ++k) pw[k] += (double)prof[k];
+    for (int k = 0; k < 16; ++k) pw[8 + k] += (double)sprof_s[k];
   }
 #endif
   if (tid == 0 && iters) {
@@ -1672,6 +1711,495 @@ static hipError_t launch_evolve_mf(const mdq_ipcs_desc* d, size_t lds, int nstep
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((evolve_mf_kernel<K1_LDS>), dim3(d->B), dim3(WG), lds, stream, *d, nsteps, drag, lift, iters);
+  return hipGetLastError();
+}
+
+// ================================================================== matrix-free kernel, LDS-atomic accumulation (mode 3)
+//
+// Same element operators as mode 2, but the element results are accumulated straight into an LDS
+// result vector with hardware LDS fp64 atomics (ds_add_f64) instead of going through a tile and an
+// ordered row gather.  That frees the 96 KB tile: the search direction p, the residual r (= s) AND
+// the result vector all live in LDS, only v stays in registers, so the element phase can interleave
+// several triangles per thread (FP64 ILP) without register spills, with two barriers per operator
+// application.  Price: the summation order of the <= 8 contributions per row depends on timing, so
+// results are reproducible to round-off only (modes 0-2 are bitwise reproducible).
+
+constexpr int AT_PAIR = 2;  // triangles interleaved per thread per round
+
+struct AtMeta {
+  int w[AT_PAIR][6];
+  Geo g[AT_PAIR];
+};
+
+__device__ __forceinline__ void at_prefetch(const EnvView& v, AtMeta& m, int round) {
+#pragma unroll
+  for (int j = 0; j < AT_PAIR; ++j) {
+    const int e = threadIdx.x + (round * AT_PAIR + j) * WG;
+    if (e < v.nt) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) m.w[j][i] = v.mf_scat[i * v.NT + e];
+      m.g[j] = load_geo(v, e);
+    }
+  }
+}
+
+// Y[dof] += element results for every triangle (Y zeroed and published by the caller).
+// op(e, geo, dofs, outflow_edge, ye).  On entry m holds round 0; on exit again (rolling prefetch).
+template <class ElemOp>
+__device__ __forceinline__ void atomic_accumulate(const EnvView& v, double* Yd, AtMeta& m, ElemOp op) {
+  const int nrounds = (v.nt + AT_PAIR * WG - 1) / (AT_PAIR * WG);
+  for (int round = 0; round < nrounds; ++round) {
+    double2 ye[AT_PAIR][6];
+    int dof[AT_PAIR][6];
+#pragma unroll
+    for (int j = 0; j < AT_PAIR; ++j) {
+      const int e = threadIdx.x + (round * AT_PAIR + j) * WG;
+      if (e < v.nt) {
+        ElemIdx E;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) E.dof[i] = dof[j][i] = m.w[j][i] & 0xFFF;
+        op(e, m.g[j], E, ((m.w[j][0] >> 28) & 3) - 1, ye[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < AT_PAIR; ++j) {
+      const int e = threadIdx.x + (round * AT_PAIR + j) * WG;
+      if (e < v.nt) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          unsafeAtomicAdd(Yd + 2 * dof[j][i], ye[j][i].x);
+          unsafeAtomicAdd(Yd + 2 * dof[j][i] + 1, ye[j][i].y);
+        }
+      }
+    }
+    at_prefetch(v, m, round + 1 < nrounds ? round + 1 : 0);
+  }
+}
+
+template <bool K1_LDS>
+__global__ __launch_bounds__(WG) void evolve_at_kernel(mdq_ipcs_desc d, int nsteps, double* drag, double* lift,
+                                                        int32_t* iters) {
+  extern __shared__ __align__(16) double smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const EnvView v = env_view(d, b);
+  const int n2 = v.n2, nv = v.nv;
+  const LdsPlan P = lds_plan(d.N2, d.NV, d.NSE1);
+  const double a = d.rho / d.dt, mu = d.mu;
+
+  double* red = smem;  // 64 doubles
+  double* U = smem + 64;
+  double* px = U;
+  double* pr = px + P.NVp;
+  double* pp = pr + P.NVp;
+  double* pq = pp + P.NVp;
+  double* lK = pq + P.NVp;
+  int32_t* lci = reinterpret_cast<int32_t*>(lK + d.NSE1);
+  int32_t* lso = lci + d.NSE1 + (d.NSE1 & 1);
+  double2* Pl = reinterpret_cast<double2*>(U);  // search direction p / staged operator input
+  double2* Rl = Pl + P.N2p;                      // residual r (= s)
+  double2* Yl = Rl + P.N2p;                      // operator result (atomic accumulation)
+  double* Yd = reinterpret_cast<double*>(Yl);
+
+  double* w = v.work;
+  double* escr1 = w;
+  double2* xs = reinterpret_cast<double2*>(w + 12 * (int64_t)d.NT);  // x of the velocity solve = u*
+  double2* rhg = xs + d.N2;                                          // shadow residual
+  double* pnew = reinterpret_cast<double*>(xs + 6 * (int64_t)d.N2);
+
+  const int nsl1 = (nv + 63) >> 6;
+  const int32_t* so1 = K1_LDS ? lso : v.sl1_off;
+  const int32_t* ci1 = K1_LDS ? lci : v.sl1_col;
+  const double* K1 = K1_LDS ? lK : v.K1s;
+
+  AtMeta tm;
+  at_prefetch(v, tm, 0);
+
+  int it_u = 0, it_p = 0, it_m = 0;
+#ifdef MDQ_PROFILE
+  long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tprev = __builtin_amdgcn_s_memtime();
+#endif
+  __syncthreads();
+
+  for (int step = 0; step < nsteps; ++step) {
+    MDQ_STAMP(7)
+    // ================= step 1: tentative velocity
+    float2 idg[MF_ROWS];
+#pragma unroll
+    for (int k = 0; k < MF_ROWS; ++k) {
+      const int row = tid + k * WG;
+      idg[k] = make_float2(0.f, 0.f);
+      if (row < n2) {
+        Yl[row] = make_double2(0.0, 0.0);
+        if (!v.bcu_flag[row]) {
+          const double2 t_ = v.idiag1[row];
+          idg[k] = make_float2((float)t_.x, (float)t_.y);
+        }
+      }
+    }
+    __syncthreads();
+    {
+      const double2* un = v.u_n;
+      const double* pn = v.p_n;
+      atomic_accumulate(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
+        double2 ue[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) ue[i] = un[E.dof[i]];
+        double pe[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pe[i] = pn[E.dof[i]];
+        elem_rhs1_vol(g, a, mu, d.rho, ue, pe, ye);
+        if (ko >= 0) {
+          double X[3][2];
+          load_cell_coords(v, e, X);
+          elem_outflow_add(g, X, ko, 0.5 * mu, ue, ye);
+        }
+      });
+    }
+    __syncthreads();
+    MDQ_STAMP(0)
+    double acc[2] = {0.0, 0.0};
+    double2 f[MF_ROWS];
+#pragma unroll
+    for (int k = 0; k < MF_ROWS; ++k) {
+      const int row = tid + k * WG;
+      f[k] = make_double2(0.0, 0.0);
+      if (row < n2) {
+        f[k] = Yl[row];
+        Yl[row] = make_double2(0.0, 0.0);
+        const bool fl = v.bcu_flag[row] != 0;
+        const double2 g = make_double2(v.bcu_gx[row], 0.0);
+        const double2 x0 = fl ? g : v.u_n[row];  // initial guess satisfies the Dirichlet values
+        xs[row] = x0;
+        Pl[row] = x0;
+        const double2 l = v.lift1[row];
+        const double2 bi = fl ? g : make_double2((f[k].x - l.x) * idg[k].x, (f[k].y - l.y) * idg[k].y);
+        acc[0] += bi.x * bi.x + bi.y * bi.y;
+      }
+    }
+    __syncthreads();
+    atomic_accumulate(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
+      double2 xe[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) xe[i] = Pl[E.dof[i]];
+      velocity_op(v, a, mu, e, ko, g, xe, ye);
+    });
+    __syncthreads();
+    double2 vv[MF_ROWS];
+#pragma unroll
+    for (int k = 0; k < MF_ROWS; ++k) {
+      const int row = tid + k * WG;
+      vv[k] = make_double2(0.0, 0.0);
+      if (row < n2) {
+        const double2 ax = Yl[row];
+        // r0 = D^-1 (f - A_full x0) on free rows, 0 on constrained rows (idg = 0 there)
+        const double2 r0 = make_double2((f[k].x - ax.x) * idg[k].x, (f[k].y - ax.y) * idg[k].y);
+        Rl[row] = r0;
+        rhg[row] = r0;
+        Pl[row] = make_double2(0.0, 0.0);
+        acc[1] += r0.x * r0.x + r0.y * r0.y;
+      }
+    }
+    block_sum<2>(acc, red);
+    MDQ_STAMP(1)
+    {
+      const double bb = acc[0], tol2 = d.rtol * d.rtol * bb;
+      double rr = acc[1];
+      if (rr > tol2 && bb != 0.0) {
+        double rho = rr, rho_old = 1.0, alpha = 1.0, omega = 1.0;
+        int it = 0;
+        while (it < d.maxit_u) {
+          ++it;
+          const double beta = (rho / rho_old) * (alpha / omega);
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k) {
+            const int row = tid + k * WG;
+            if (row < n2) {
+              const double2 ri = Rl[row], pi = Pl[row];
+              Pl[row] = make_double2(ri.x + beta * (pi.x - omega * vv[k].x), ri.y + beta * (pi.y - omega * vv[k].y));
+              Yl[row] = make_double2(0.0, 0.0);
+            }
+          }
+          __syncthreads();
+          atomic_accumulate(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
+            double2 xe[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) xe[i] = Pl[E.dof[i]];
+            velocity_op(v, a, mu, e, ko, g, xe, ye);
+          });
+          __syncthreads();
+          double a1[1] = {0.0};
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k) {
+            const int row = tid + k * WG;
+            if (row < n2) {
+              const double2 yv = Yl[row], h = rhg[row];
+              vv[k] = make_double2(yv.x * idg[k].x, yv.y * idg[k].y);
+              a1[0] += h.x * vv[k].x + h.y * vv[k].y;
+            }
+          }
+          block_sum<1>(a1, red);
+          if (a1[0] == 0.0) break;
+          alpha = rho / a1[0];
+          double a2[1] = {0.0};
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k) {
+            const int row = tid + k * WG;
+            if (row < n2) {
+              const double2 ri = Rl[row];
+              const double2 sv = make_double2(ri.x - alpha * vv[k].x, ri.y - alpha * vv[k].y);
+              Rl[row] = sv;
+              Yl[row] = make_double2(0.0, 0.0);
+              a2[0] += sv.x * sv.x + sv.y * sv.y;
+            }
+          }
+          block_sum<1>(a2, red);  // its barriers publish s and the zeroed result vector
+          if (!(a2[0] > tol2)) {
+#pragma unroll
+            for (int k = 0; k < MF_ROWS; ++k) {
+              const int row = tid + k * WG;
+              if (row < n2) {
+                const double2 xo = xs[row], pi = Pl[row];
+                xs[row] = make_double2(xo.x + alpha * pi.x, xo.y + alpha * pi.y);
+              }
+            }
+            break;
+          }
+          atomic_accumulate(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
+            double2 xe[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) xe[i] = Rl[E.dof[i]];
+            velocity_op(v, a, mu, e, ko, g, xe, ye);
+          });
+          __syncthreads();
+          double a3[2] = {0.0, 0.0};
+          double2 t[MF_ROWS];
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k) {
+            const int row = tid + k * WG;
+            t[k] = make_double2(0.0, 0.0);
+            if (row < n2) {
+              const double2 yv = Yl[row], sv = Rl[row];
+              t[k] = make_double2(yv.x * idg[k].x, yv.y * idg[k].y);
+              a3[0] += t[k].x * sv.x + t[k].y * sv.y;
+              a3[1] += t[k].x * t[k].x + t[k].y * t[k].y;
+            }
+          }
+          block_sum<2>(a3, red);
+          if (a3[1] == 0.0) break;
+          omega = a3[0] / a3[1];
+          double a4[2] = {0.0, 0.0};
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k) {
+            const int row = tid + k * WG;
+            if (row < n2) {
+              const double2 xo = xs[row], h = rhg[row], pi = Pl[row], sv = Rl[row];
+              xs[row] = make_double2(xo.x + alpha * pi.x + omega * sv.x, xo.y + alpha * pi.y + omega * sv.y);
+              const double2 rn = make_double2(sv.x - omega * t[k].x, sv.y - omega * t[k].y);
+              Rl[row] = rn;
+              a4[0] += rn.x * rn.x + rn.y * rn.y;
+              a4[1] += h.x * rn.x + h.y * rn.y;
+            }
+          }
+          block_sum<2>(a4, red);
+          rr = a4[0];
+          if (!(rr > tol2)) break;
+          rho_old = rho;
+          rho = a4[1];
+          if (rho == 0.0 || omega == 0.0) break;
+        }
+        it_u += it;
+      }
+    }
+    __syncthreads();  // xs (= u*) complete: the element loops of steps 2 and 3 gather it
+    MDQ_STAMP(2)
+
+    // ================= step 2: pressure
+    if (K1_LDS && !d.pd_enabled) {
+      const int ne1 = v.sl1_off[nsl1];
+      for (int kk = tid; kk < ne1; kk += WG) {
+        lK[kk] = v.K1s[kk];
+        lci[kk] = v.sl1_col[kk];
+      }
+      for (int kk = tid; kk <= nsl1; kk += WG) lso[kk] = v.sl1_off[kk];
+    }
+    rhs2_elements(v, d, xs, v.p_n, escr1);
+    __syncthreads();
+    for (int i = tid; i < nv; i += WG) {
+      double bsum = 0.0;
+      for (int s = v.g1_ptr[i]; s < v.g1_ptr[i + 1]; ++s) bsum += escr1[v.g1_src[s]];
+      const double sd = v.sdiagK[i];
+      pr[i] = v.bcp_flag[i] ? 0.0 : bsum / sd;
+      px[i] = v.p_n[i] * sd;
+    }
+    MDQ_STAMP(3)
+    if (d.pd_enabled) {
+      const PdView pd = pd_view(d, b);
+      pressure_direct(pd, nv, pr, px, pp, pq, lK);
+    } else {
+      it_p += cg_pressure(nv, so1, ci1, K1, d.rtol, d.maxit_p, px, pr, pp, pq, red);
+    }
+    MDQ_STAMP(4)
+    for (int i = tid; i < nv; i += WG) pnew[i] = px[i] / v.sdiagK[i];
+    __syncthreads();
+
+    // ================= step 3: velocity correction (mass solve, both components)
+    double2 x[MF_ROWS], r[MF_ROWS], p[MF_ROWS];
+    double ism[MF_ROWS];
+    double am[2] = {0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < MF_ROWS; ++k) {
+      const int row = tid + k * WG;
+      if (row < n2) Yl[row] = make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    {
+      const double* pold = v.p_n;
+      atomic_accumulate(v, Yd, tm, [&](int, const Geo& g, const ElemIdx& E, int, double2(&ye)[6]) {
+        double2 ue[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) ue[i] = xs[E.dof[i]];
+        double dp[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dp[i] = pnew[E.dof[i]] - pold[E.dof[i]];
+        elem_rhs3(g, d.dt, ue, dp, ye);
+      });
+    }
+    __syncthreads();
+    double2 f3[MF_ROWS];
+#pragma unroll
+    for (int k = 0; k < MF_ROWS; ++k) {
+      const int row = tid + k * WG;
+      ism[k] = 0.0;
+      x[k] = f3[k] = make_double2(0.0, 0.0);
+      if (row < n2) {
+        const bool fl = v.bcu_flag[row] != 0;
+        if (!fl) ism[k] = 1.0 / v.sdiagM[row];
+        f3[k] = Yl[row];
+        Yl[row] = make_double2(0.0, 0.0);
+        x[k] = xs[row];      // u* (satisfies the Dirichlet values)
+        Pl[row] = x[k];      // stage S^-1 (S x0) = x0
+        const double2 l = v.lift3[row];
+        const double2 bi = fl ? x[k] : make_double2((f3[k].x - l.x) * ism[k], (f3[k].y - l.y) * ism[k]);
+        am[0] += bi.x * bi.x + bi.y * bi.y;
+      }
+    }
+    __syncthreads();
+    atomic_accumulate(v, Yd, tm, [&](int, const Geo& g, const ElemIdx& E, int, double2(&ye)[6]) {
+      double2 xe[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) xe[i] = Pl[E.dof[i]];
+      elem_mass(g, xe, ye);
+    });
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MF_ROWS; ++k) {
+      const int row = tid + k * WG;
+      r[k] = p[k] = make_double2(0.0, 0.0);
+      if (row < n2) {
+        const double2 ax = Yl[row];
+        r[k] = make_double2((f3[k].x - ax.x) * ism[k], (f3[k].y - ax.y) * ism[k]);  // 0 on constrained rows
+        p[k] = r[k];
+        am[1] += r[k].x * r[k].x + r[k].y * r[k].y;
+        if (ism[k] != 0.0) x[k] = make_double2(x[k].x / ism[k], x[k].y / ism[k]);  // scaled unknown S x
+      }
+    }
+    block_sum<2>(am, red);
+    MDQ_STAMP(5)
+    {
+      const double bb = am[0], tol2 = d.rtol * d.rtol * bb;
+      double rr = am[1];
+      if (rr > tol2 && bb != 0.0) {
+        int it = 0;
+        while (it < d.maxit_m) {
+          ++it;
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k) {
+            const int row = tid + k * WG;
+            if (row < n2) {
+              Pl[row] = make_double2(p[k].x * ism[k], p[k].y * ism[k]);
+              Yl[row] = make_double2(0.0, 0.0);
+            }
+          }
+          __syncthreads();
+          atomic_accumulate(v, Yd, tm, [&](int, const Geo& g, const ElemIdx& E, int, double2(&ye)[6]) {
+            double2 xe[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) xe[i] = Pl[E.dof[i]];
+            elem_mass(g, xe, ye);
+          });
+          __syncthreads();
+          double a1[1] = {0.0};
+          double2 q[MF_ROWS];
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k) {
+            const int row = tid + k * WG;
+            q[k] = make_double2(0.0, 0.0);
+            if (row < n2) {
+              const double2 yv = Yl[row];
+              q[k] = make_double2(yv.x * ism[k], yv.y * ism[k]);
+              a1[0] += p[k].x * q[k].x + p[k].y * q[k].y;
+            }
+          }
+          block_sum<1>(a1, red);
+          if (!(a1[0] > 0.0)) break;
+          const double alpha = rr / a1[0];
+          double a2[1] = {0.0};
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k) {
+            x[k] = make_double2(x[k].x + alpha * p[k].x, x[k].y + alpha * p[k].y);
+            r[k] = make_double2(r[k].x - alpha * q[k].x, r[k].y - alpha * q[k].y);
+            a2[0] += r[k].x * r[k].x + r[k].y * r[k].y;
+          }
+          block_sum<1>(a2, red);
+          const double rr_new = a2[0];
+          if (!(rr_new > tol2)) break;
+          const double beta = rr_new / rr;
+          rr = rr_new;
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k)
+            p[k] = make_double2(r[k].x + beta * p[k].x, r[k].y + beta * p[k].y);
+        }
+        it_m += it;
+      }
+    }
+    MDQ_STAMP(6)
+
+    // ================= update state + probes
+#pragma unroll
+    for (int k = 0; k < MF_ROWS; ++k) {
+      const int row = tid + k * WG;
+      if (row < n2) v.u_n[row] = (ism[k] != 0.0) ? make_double2(x[k].x * ism[k], x[k].y * ism[k]) : x[k];
+    }
+    for (int i = tid; i < nv; i += WG) v.p_n[i] = pnew[i];
+    __syncthreads();
+    double dr, li;
+    forces(v, d.mu, v.u_n, v.p_n, red, dr, li);
+    if (tid == 0) {
+      drag[(int64_t)b * nsteps + step] = dr;
+      lift[(int64_t)b * nsteps + step] = li;
+    }
+  }
+#ifdef MDQ_PROFILE
+  if (tid == 0) {
+    double* pw = pnew + d.NV;
+    for (int k = 0; k < 8; ++k) pw[k] += (double)prof[k];
+  }
+#endif
+  if (tid == 0 && iters) {
+    iters[3 * b + 0] += it_u;
+    iters[3 * b + 1] += it_p;
+    iters[3 * b + 2] += it_m;
+  }
+}
+
+template <bool K1_LDS>
+static hipError_t launch_evolve_at(const mdq_ipcs_desc* d, size_t lds, int nsteps, double* drag, double* lift,
+                                   int32_t* iters, hipStream_t stream) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&evolve_at_kernel<K1_LDS>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((evolve_at_kernel<K1_LDS>), dim3(d->B), dim3(WG), lds, stream, *d, nsteps, drag, lift, iters);
   return hipGetLastError();
 }
 
@@ -1782,21 +2310,27 @@ int mdq_ipcs_evolve(const mdq_ipcs_desc* d, int32_t nsteps, double* drag, double
   if (red_bytes + P.prs_vec_bytes > LDS_MAX) return fail_msg("mesh too large for the LDS-resident pressure vectors");
   const bool k1_lds = !d->pd_enabled && red_bytes + P.prs_vec_bytes + P.prs_mat_bytes <= LDS_MAX;
   int mode = d->mode;
-  if (mode < 0 || mode > 2) {  // auto: matrix-free tiles if they fit, else LDS gather vectors, else global
+  if (mode < 0 || mode > 3) {  // auto: fastest variant that fits
     mode = 0;
     if (red_bytes + P.vel1_bytes <= LDS_MAX) mode = 1;
     if (red_bytes + P.vel2_bytes <= LDS_MAX && d->N2 <= MF_ROWS * WG) mode = 2;
+    if (red_bytes + P.vel3_bytes <= LDS_MAX && d->N2 <= MF_ROWS * WG) mode = 3;
   }
+  if (mode == 3 && (red_bytes + P.vel3_bytes > LDS_MAX || d->N2 > MF_ROWS * WG))
+    return fail_msg("mode 3 needs N2 <= 3584 and three velocity vectors in LDS");
   if (mode == 2 && (red_bytes + P.vel2_bytes > LDS_MAX || d->N2 > MF_ROWS * WG))
-    return fail_msg("matrix-free mode needs N2 <= 4096 and the x stage + element tile in LDS");
+    return fail_msg("matrix-free tile mode needs N2 <= 3584 and the x stage + element tile in LDS");
   if (mode == 1 && red_bytes + P.vel1_bytes > LDS_MAX) return fail_msg("LDS gather vectors do not fit");
   size_t u = P.prs_vec_bytes + (k1_lds ? P.prs_mat_bytes : 0);  // (K1 values alias the scratch vector: CG does not use it)
-  const size_t vel = mode == 2 ? P.vel2_bytes : (mode == 1 ? P.vel1_bytes : 0);
+  const size_t vel = mode == 3 ? P.vel3_bytes : (mode == 2 ? P.vel2_bytes : (mode == 1 ? P.vel1_bytes : 0));
   if (vel > u) u = vel;
   const size_t lds = red_bytes + u;
   hipError_t e;
   hipStream_t st = (hipStream_t)stream;
-  if (mode == 2)
+  if (mode == 3)
+    e = k1_lds ? launch_evolve_at<true>(d, lds, nsteps, drag, lift, iters, st)
+               : launch_evolve_at<false>(d, lds, nsteps, drag, lift, iters, st);
+  else if (mode == 2)
     e = k1_lds ? launch_evolve_mf<true>(d, lds, nsteps, drag, lift, iters, st)
                : launch_evolve_mf<false>(d, lds, nsteps, drag, lift, iters, st);
   else if (mode == 1)

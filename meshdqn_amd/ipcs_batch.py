@@ -163,9 +163,12 @@ class IpcsBatch:
         af, af_edges = topo.facets(bc["tags"], TAG_AIRFOIL)
         sl2_off, sl2_col, pos2 = topo.sell_layout(rowptr2, colidx2)
         sl1_off, sl1_col, pos1 = topo.sell_layout(rowptr1, colidx1)
-        mf_scat, mf_tptr = topo.matfree_maps(1024)
         cell_outflow = np.full(topo.nt, -1, dtype=np.int8)
         cell_outflow[out_f[:, 0]] = out_f[:, 1]
+        if topo.np2 <= 4096:
+            mf_scat, mf_tptr = topo.matfree_packed(cell_outflow, 1024)
+        else:  # matrix-free mode unavailable for this size (kernel falls back to the SELL operators)
+            mf_scat, mf_tptr = topo.matfree_maps(1024)
         return dict(nv=topo.nv, nt=topo.nt, ne=topo.ne, coords=np.asarray(coords, np.float64),
                     cell_dofs_soa=np.ascontiguousarray(topo.cell_dofs.T, dtype=np.int32),
                     cell_outflow=cell_outflow,

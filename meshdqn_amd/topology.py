@@ -263,6 +263,16 @@ class MeshTopology:
             np.cumsum(np.bincount(r, minlength=n2), out=tptr[c, 1:])
         return np.ascontiguousarray(scat.T), tptr
 
+    def matfree_packed(self, cell_outflow, chunk=1024):
+        """(6, nt) int32 words  dof | tile_pos << 12 | (outflow_edge + 1) << 28 (word 0 only):
+        everything a thread needs to apply one triangle's operator, in 6 coalesced loads."""
+        if self.np2 > 4096 or 6 * chunk > 65536:
+            raise ValueError("packed matrix-free metadata needs np2 <= 4096")
+        scat, tptr = self.matfree_maps(chunk)
+        w = self.cell_dofs.T.astype(np.int64) | (scat.astype(np.int64) << 12)
+        w[0] |= (np.asarray(cell_outflow, dtype=np.int64) + 1) << 28
+        return w.astype(np.int32), tptr
+
     def dof_gathers(self):
         return dict(p2=self._dof_gather(self.cell_dofs, self.np2),
                     p1=self._dof_gather(self.cells, self.nv))

@@ -64,7 +64,7 @@ def test_assembly_matches_oracle(meshes, oracle_solvers, lib_built):
         assert np.abs(l3 - o.lift3)[free].max() <= 1e-13 * max(1.0, np.abs(o.lift3).max())
 
 
-@pytest.mark.parametrize("mode,direct", [(2, True), (2, False), (1, True), (1, False), (0, False)])
+@pytest.mark.parametrize("mode,direct", [(3, True), (3, False), (2, True), (2, False), (1, True), (1, False), (0, False)])
 def test_first_steps_match_oracle(meshes, lib_built, mode, direct):
     """Per-step parity of u, p, drag, lift against the sparse-LU oracle, for every operator
     mode (0/1 assembled SELL, 2 matrix-free tiles) and both pressure solvers (direct / CG)."""
@@ -93,8 +93,9 @@ def test_first_steps_match_oracle(meshes, lib_built, mode, direct):
 
 def test_multi_step_launch_equals_single_steps(meshes, lib_built):
     import torch
-    b1, _, _ = _make(meshes, ["ys930"])
-    b2, _, _ = _make(meshes, ["ys930"])
+    # modes 0-2 sum in a fixed order (mode 3 uses LDS atomics: reproducible to round-off only)
+    b1, _, _ = _make(meshes, ["ys930"], mode=2)
+    b2, _, _ = _make(meshes, ["ys930"], mode=2)
     d1, l1 = b1.evolve(6)
     parts = [b2.evolve(1) for _ in range(6)]
     torch.cuda.synchronize()

@@ -30,7 +30,7 @@ if os.environ.get("MDQ_CFLAGS", "").find("MDQ_PROFILE") >= 0:
     c = batch.cap
     NV, NT, NE = c["NV"], c["NT"], c["NE"]
     N2 = NV + NE
-    per = (12 * NT + 12 * N2 + NV + 8 + 31) // 32 * 32
+    per = (12 * NT + 12 * N2 + NV + 24 + 31) // 32 * 32
     w = batch.t["work"].cpu().numpy().reshape(B, per)
     prof = w[:, 12 * NT + 12 * N2 + NV: 12 * NT + 12 * N2 + NV + 8]
     tot_steps = 5 + 3 * nsteps
@@ -38,3 +38,7 @@ if os.environ.get("MDQ_CFLAGS", "").find("MDQ_PROFILE") >= 0:
     m = prof.mean(0) / tot_steps
     for n_, v_ in zip(names, m):
         print(f"  {n_:14s} {v_/100.0:9.1f} us/step (at 100MHz memtime)  {100*v_/m.sum():5.1f}%")
+    tp = w[:, 12 * NT + 12 * N2 + NV + 8: 12 * NT + 12 * N2 + NV + 16].mean(0) / tot_steps
+    print("  tile_accumulate phases (thread 0, all call sites): elem %.0f  prefetch-issue %.0f  barrier1 %.0f  gather %.0f  barrier2 %.0f  | total %.0f of step %.0f" % (tp[0], tp[1], tp[2], tp[3], tp[4], tp[:5].sum(), m.sum()))
+    bp = w[:, 12 * NT + 12 * N2 + NV + 16: 12 * NT + 12 * N2 + NV + 24].mean(0) / tot_steps
+    print("  bicgstab per step (cycles): p-upd+stage+sync %.0f | apply1 %.0f | red a1 %.0f | s-upd+red a2 %.0f | apply2 %.0f | red a3 %.0f | x,r upd+red a4 %.0f | loop-top %.0f" % tuple(bp))
