@@ -20,8 +20,27 @@ struct RefTab {
   double gx[2], gw[2];         // 2-point Gauss rule on [0,1]
 };
 
-__device__ __forceinline__ double shfl_down_f64(double v, int off, int width) {
-  return __shfl_down(v, off, width);
+// ---- wave64 sum with DPP (VALU cross-lane moves; __shfl_* lowers to ds_bpermute round trips
+// through the LDS crossbar, ~10x slower for a 6-step fp64 butterfly) ---------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_get(double v) {
+  // lanes disabled by ROW_MASK and lanes shifted in from outside the row read 0
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+// sum over the 64 lanes, returned in every lane (fixed association order => deterministic)
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_get<0x111, 0xF>(v);  // row_shr:1
+  v += dpp_get<0x112, 0xF>(v);  // row_shr:2
+  v += dpp_get<0x114, 0xF>(v);  // row_shr:4
+  v += dpp_get<0x118, 0xF>(v);  // row_shr:8   -> lane 15 of each row of 16 holds the row sum
+  v += dpp_get<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_get<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
 }
 
 // Deterministic workgroup-wide sum of N values; every thread returns the same bits.
@@ -29,10 +48,7 @@ __device__ __forceinline__ double shfl_down_f64(double v, int off, int width) {
 template <int N>
 __device__ __forceinline__ void block_sum(double (&v)[N], double* lds) {
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-    for (int n = 0; n < N; ++n) v[n] += __shfl_down(v[n], off, 64);
-  }
+  for (int n = 0; n < N; ++n) v[n] = wave_sum(v[n]);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   __syncthreads();
   if (lane == 0) {
@@ -111,6 +127,30 @@ __device__ __forceinline__ Facet facet_geometry(const double (&X)[3][2], int k) 
   f.rb[0] = sel3(k, 0.0, 0.0, 1.0);
   f.rb[1] = sel3(k, 1.0, 1.0, 0.0);
   return f;
+}
+
+// One-barrier variant: `lds` holds two buffers of NWAVE*N doubles used alternately (`sel` flips on
+// every call, workgroup-uniformly).  A buffer is rewritten two calls later, i.e. after the barrier
+// of the call in between, which every thread passes only after it has finished reading.
+template <int N>
+__device__ __forceinline__ void block_sum1(double (&v)[N], double* lds, int& sel) {
+#pragma unroll
+  for (int n = 0; n < N; ++n) v[n] = wave_sum(v[n]);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double* buf = lds + sel * (NWAVE * 2);
+  sel ^= 1;
+  if (lane == 0) {
+#pragma unroll
+    for (int n = 0; n < N; ++n) buf[w * N + n] = v[n];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < NWAVE; ++i) s += buf[i * N + n];
+    v[n] = s;
+  }
 }
 
 }  // namespace mdq

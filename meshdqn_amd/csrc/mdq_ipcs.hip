@@ -1748,6 +1748,12 @@ __device__ __forceinline__ void at_prefetch(const EnvView& v, AtMeta& m, int rou
 template <class ElemOp>
 __device__ __forceinline__ void atomic_accumulate(const EnvView& v, double* Yd, AtMeta& m, ElemOp op) {
   const int nrounds = (v.nt + AT_PAIR * WG - 1) / (AT_PAIR * WG);
+#ifdef MDQ_PROFILE
+  long long tq = __builtin_amdgcn_s_memtime();
+#define MDQ_ASTAMP(k) { __builtin_amdgcn_s_waitcnt(0xC07F); long long tn = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) v.sprof[k] += tn - tq; tq = tn; }
+#else
+#define MDQ_ASTAMP(k)
+#endif
   for (int round = 0; round < nrounds; ++round) {
     double2 ye[AT_PAIR][6];
     int dof[AT_PAIR][6];
@@ -1761,6 +1767,7 @@ __device__ __forceinline__ void atomic_accumulate(const EnvView& v, double* Yd, 
         op(e, m.g[j], E, ((m.w[j][0] >> 28) & 3) - 1, ye[j]);
       }
     }
+    MDQ_ASTAMP(0)
 #pragma unroll
     for (int j = 0; j < AT_PAIR; ++j) {
       const int e = threadIdx.x + (round * AT_PAIR + j) * WG;
@@ -1772,7 +1779,9 @@ __device__ __forceinline__ void atomic_accumulate(const EnvView& v, double* Yd, 
         }
       }
     }
+    MDQ_ASTAMP(1)
     at_prefetch(v, m, round + 1 < nrounds ? round + 1 : 0);
+    MDQ_ASTAMP(2)
   }
 }
 
@@ -1803,7 +1812,6 @@ __global__ __launch_bounds__(WG) void evolve_at_kernel(mdq_ipcs_desc d, int nste
   double* w = v.work;
   double* escr1 = w;
   double2* xs = reinterpret_cast<double2*>(w + 12 * (int64_t)d.NT);  // x of the velocity solve = u*
-  double2* rhg = xs + d.N2;                                          // shadow residual
   double* pnew = reinterpret_cast<double*>(xs + 6 * (int64_t)d.N2);
 
   const int nsl1 = (nv + 63) >> 6;
@@ -1811,10 +1819,17 @@ __global__ __launch_bounds__(WG) void evolve_at_kernel(mdq_ipcs_desc d, int nste
   const int32_t* ci1 = K1_LDS ? lci : v.sl1_col;
   const double* K1 = K1_LDS ? lK : v.K1s;
 
+#ifdef MDQ_PROFILE
+  __shared__ long long sprof_s[16];
+  if (tid < 16) sprof_s[tid] = 0;
+  const_cast<EnvView&>(v).sprof = sprof_s;
+  __syncthreads();
+#endif
   AtMeta tm;
   at_prefetch(v, tm, 0);
 
   int it_u = 0, it_p = 0, it_m = 0;
+  int rsel = 0;  // parity of the one-barrier reductions
 #ifdef MDQ_PROFILE
   long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tprev = __builtin_amdgcn_s_memtime();
@@ -1895,7 +1910,6 @@ __global__ __launch_bounds__(WG) void evolve_at_kernel(mdq_ipcs_desc d, int nste
         // r0 = D^-1 (f - A_full x0) on free rows, 0 on constrained rows (idg = 0 there)
         const double2 r0 = make_double2((f[k].x - ax.x) * idg[k].x, (f[k].y - ax.y) * idg[k].y);
         Rl[row] = r0;
-        rhg[row] = r0;
         Pl[row] = make_double2(0.0, 0.0);
         acc[1] += r0.x * r0.x + r0.y * r0.y;
       }
@@ -1908,8 +1922,30 @@ __global__ __launch_bounds__(WG) void evolve_at_kernel(mdq_ipcs_desc d, int nste
       if (rr > tol2 && bb != 0.0) {
         double rho = rr, rho_old = 1.0, alpha = 1.0, omega = 1.0;
         int it = 0;
+        // shadow residual in registers (own rows).  BiCGStab accepts ANY fixed shadow vector with
+        // (rh, r0) != 0; we take r0 rounded to fp32, which halves its register footprint.
+        float2 rh[MF_ROWS];
+        {
+          double a0[1] = {0.0};
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k) {
+            const int row = tid + k * WG;
+            rh[k] = make_float2(0.f, 0.f);
+            if (row < n2) {
+              const double2 r0 = Rl[row];
+              rh[k] = make_float2((float)r0.x, (float)r0.y);
+              a0[0] += (double)rh[k].x * r0.x + (double)rh[k].y * r0.y;
+            }
+          }
+          block_sum1<1>(a0, red, rsel);
+          rho = a0[0];  // (rh, r0)
+        }
+#ifdef MDQ_PROFILE
+        long long tb = __builtin_amdgcn_s_memtime();
+#endif
         while (it < d.maxit_u) {
           ++it;
+          MDQ_BSTAMP(15)
           const double beta = (rho / rho_old) * (alpha / omega);
 #pragma unroll
           for (int k = 0; k < MF_ROWS; ++k) {
@@ -1921,56 +1957,55 @@ __global__ __launch_bounds__(WG) void evolve_at_kernel(mdq_ipcs_desc d, int nste
             }
           }
           __syncthreads();
+          MDQ_BSTAMP(8)
           atomic_accumulate(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
             double2 xe[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) xe[i] = Pl[E.dof[i]];
             velocity_op(v, a, mu, e, ko, g, xe, ye);
           });
+          MDQ_BSTAMP(9)
           __syncthreads();
+          MDQ_BSTAMP(10)
           double a1[1] = {0.0};
 #pragma unroll
           for (int k = 0; k < MF_ROWS; ++k) {
             const int row = tid + k * WG;
             if (row < n2) {
-              const double2 yv = Yl[row], h = rhg[row];
+              const double2 yv = Yl[row];
               vv[k] = make_double2(yv.x * idg[k].x, yv.y * idg[k].y);
-              a1[0] += h.x * vv[k].x + h.y * vv[k].y;
+              a1[0] += rh[k].x * vv[k].x + rh[k].y * vv[k].y;
             }
           }
-          block_sum<1>(a1, red);
+          block_sum1<1>(a1, red, rsel);
+          MDQ_BSTAMP(11)
           if (a1[0] == 0.0) break;
           alpha = rho / a1[0];
-          double a2[1] = {0.0};
+          // s = r - alpha v ; no early exit on |s| (saves a reduction; the check on |r| follows)
 #pragma unroll
           for (int k = 0; k < MF_ROWS; ++k) {
             const int row = tid + k * WG;
             if (row < n2) {
               const double2 ri = Rl[row];
-              const double2 sv = make_double2(ri.x - alpha * vv[k].x, ri.y - alpha * vv[k].y);
-              Rl[row] = sv;
+              Rl[row] = make_double2(ri.x - alpha * vv[k].x, ri.y - alpha * vv[k].y);
               Yl[row] = make_double2(0.0, 0.0);
-              a2[0] += sv.x * sv.x + sv.y * sv.y;
             }
           }
-          block_sum<1>(a2, red);  // its barriers publish s and the zeroed result vector
-          if (!(a2[0] > tol2)) {
-#pragma unroll
-            for (int k = 0; k < MF_ROWS; ++k) {
-              const int row = tid + k * WG;
-              if (row < n2) {
-                const double2 xo = xs[row], pi = Pl[row];
-                xs[row] = make_double2(xo.x + alpha * pi.x, xo.y + alpha * pi.y);
-              }
-            }
-            break;
-          }
+          __syncthreads();  // publish s and the zeroed result vector
+          MDQ_BSTAMP(12)
           atomic_accumulate(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
             double2 xe[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) xe[i] = Rl[E.dof[i]];
             velocity_op(v, a, mu, e, ko, g, xe, ye);
           });
+          // x of the own rows: issue the global reads now, they are consumed after the reduction
+          double2 xo[MF_ROWS];
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k) {
+            const int row = tid + k * WG;
+            xo[k] = row < n2 ? xs[row] : make_double2(0.0, 0.0);
+          }
           __syncthreads();
           double a3[2] = {0.0, 0.0};
           double2 t[MF_ROWS];
@@ -1985,7 +2020,8 @@ __global__ __launch_bounds__(WG) void evolve_at_kernel(mdq_ipcs_desc d, int nste
               a3[1] += t[k].x * t[k].x + t[k].y * t[k].y;
             }
           }
-          block_sum<2>(a3, red);
+          block_sum1<2>(a3, red, rsel);
+          MDQ_BSTAMP(13)
           if (a3[1] == 0.0) break;
           omega = a3[0] / a3[1];
           double a4[2] = {0.0, 0.0};
@@ -1993,15 +2029,16 @@ __global__ __launch_bounds__(WG) void evolve_at_kernel(mdq_ipcs_desc d, int nste
           for (int k = 0; k < MF_ROWS; ++k) {
             const int row = tid + k * WG;
             if (row < n2) {
-              const double2 xo = xs[row], h = rhg[row], pi = Pl[row], sv = Rl[row];
-              xs[row] = make_double2(xo.x + alpha * pi.x + omega * sv.x, xo.y + alpha * pi.y + omega * sv.y);
+              const double2 pi = Pl[row], sv = Rl[row];
+              xs[row] = make_double2(xo[k].x + alpha * pi.x + omega * sv.x, xo[k].y + alpha * pi.y + omega * sv.y);
               const double2 rn = make_double2(sv.x - omega * t[k].x, sv.y - omega * t[k].y);
               Rl[row] = rn;
               a4[0] += rn.x * rn.x + rn.y * rn.y;
-              a4[1] += h.x * rn.x + h.y * rn.y;
+              a4[1] += rh[k].x * rn.x + rh[k].y * rn.y;
             }
           }
-          block_sum<2>(a4, red);
+          block_sum1<2>(a4, red, rsel);
+          MDQ_BSTAMP(14)
           rr = a4[0];
           if (!(rr > tol2)) break;
           rho_old = rho;
@@ -2141,7 +2178,7 @@ __global__ __launch_bounds__(WG) void evolve_at_kernel(mdq_ipcs_desc d, int nste
               a1[0] += p[k].x * q[k].x + p[k].y * q[k].y;
             }
           }
-          block_sum<1>(a1, red);
+          block_sum1<1>(a1, red, rsel);
           if (!(a1[0] > 0.0)) break;
           const double alpha = rr / a1[0];
           double a2[1] = {0.0};
@@ -2151,7 +2188,7 @@ __global__ __launch_bounds__(WG) void evolve_at_kernel(mdq_ipcs_desc d, int nste
             r[k] = make_double2(r[k].x - alpha * q[k].x, r[k].y - alpha * q[k].y);
             a2[0] += r[k].x * r[k].x + r[k].y * r[k].y;
           }
-          block_sum<1>(a2, red);
+          block_sum1<1>(a2, red, rsel);
           const double rr_new = a2[0];
           if (!(rr_new > tol2)) break;
           const double beta = rr_new / rr;
@@ -2184,6 +2221,7 @@ __global__ __launch_bounds__(WG) void evolve_at_kernel(mdq_ipcs_desc d, int nste
   if (tid == 0) {
     double* pw = pnew + d.NV;
     for (int k = 0; k < 8; ++k) pw[k] += (double)prof[k];
+    for (int k = 0; k < 16; ++k) pw[8 + k] += (double)sprof_s[k];
   }
 #endif
   if (tid == 0 && iters) {

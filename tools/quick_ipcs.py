@@ -39,6 +39,7 @@ if os.environ.get("MDQ_CFLAGS", "").find("MDQ_PROFILE") >= 0:
     for n_, v_ in zip(names, m):
         print(f"  {n_:14s} {v_/100.0:9.1f} us/step (at 100MHz memtime)  {100*v_/m.sum():5.1f}%")
     tp = w[:, 12 * NT + 12 * N2 + NV + 8: 12 * NT + 12 * N2 + NV + 16].mean(0) / tot_steps
-    print("  tile_accumulate phases (thread 0, all call sites): elem %.0f  prefetch-issue %.0f  barrier1 %.0f  gather %.0f  barrier2 %.0f  | total %.0f of step %.0f" % (tp[0], tp[1], tp[2], tp[3], tp[4], tp[:5].sum(), m.sum()))
+    print("  (mode3: elem-compute, atomics, prefetch) tile_accumulate phases (thread 0, all call sites): elem %.0f  prefetch-issue %.0f  barrier1 %.0f  gather %.0f  barrier2 %.0f  | total %.0f of step %.0f" % (tp[0], tp[1], tp[2], tp[3], tp[4], tp[:5].sum(), m.sum()))
     bp = w[:, 12 * NT + 12 * N2 + NV + 16: 12 * NT + 12 * N2 + NV + 24].mean(0) / tot_steps
-    print("  bicgstab per step (cycles): p-upd+stage+sync %.0f | apply1 %.0f | red a1 %.0f | s-upd+red a2 %.0f | apply2 %.0f | red a3 %.0f | x,r upd+red a4 %.0f | loop-top %.0f" % tuple(bp))
+    print("  bicgstab per step (cycles): [8] %.0f | [9] %.0f | [10] %.0f | [11] %.0f | [12] %.0f | [13] %.0f | [14] %.0f | [15] %.0f" % tuple(bp))
+    print("   mode3 legend: 8 p-upd+sync, 9 apply1, 10 barrier after apply1, 11 readY+dot+red a1, 12 s-upd+sync, 13 apply2+xprefetch+sync+dots+red a3, 14 update+red a4, 15 loop top")
