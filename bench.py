@@ -125,7 +125,9 @@ def main():
         elapsed = tt.item()
 
     iters = batch.iters.cpu().numpy().astype(np.float64) / args.steps  # (B,3) per step
-    alg_bytes = batch.algorithmic_bytes_per_step(iters)  # per launch (all envs of this rank)
+    survey_bytes = batch.algorithmic_bytes_per_step(iters)  # SURVEY 8(d) assembled-CSR convention, per launch
+    alg_bytes = batch.implemented_bytes_per_step(iters)      # bytes the implemented (matrix-free) algorithm moves
+    flops = batch.flops_per_step(iters)
     drag = out[0][:, 0].cpu().numpy()
     lift = out[1][:, 0].cpu().numpy()
 
@@ -165,10 +167,17 @@ def main():
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "evolve_kernel", "launch_ms": kern_ms,
+                         "kernel": "evolve_at_kernel (mode 3: matrix-free, LDS fp64 atomics)", "launch_ms": kern_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "algorithmic bytes follow SURVEY.md 8(d): every SpMV streams its CSR matrix once "
-                                 "(no credit for LDS/L2 residency), measured Krylov iteration counts"},
+                         "survey_csr_convention": {"bytes_per_launch": survey_bytes,
+                                                   "equivalent_GBs": survey_bytes / (kern_ms * 1e-3) / 1e9},
+                         "fp64_valu": {"flops_per_launch": flops, "achieved_TFLOPs": flops / (kern_ms * 1e-3) / 1e12,
+                                       "peak_TFLOPs": 78.6 * B / 256.0,
+                                       "frac_of_used_CUs": flops / (kern_ms * 1e-3) / 1e12 / (78.6 * B / 256.0)},
+                         "note": "the kernel is matrix-free: operators are re-derived per triangle from 64 B of "
+                                 "metadata, Krylov vectors live in LDS/registers, so HBM traffic is ~100x below the "
+                                 "assembled-CSR figure of SURVEY 8(d) (reported under survey_csr_convention) and the "
+                                 "binding resource is FP64 VALU issue + LDS atomics on the B CUs in use (1 CU per env)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_budget)

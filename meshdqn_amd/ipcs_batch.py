@@ -277,8 +277,10 @@ class IpcsBatch:
 
     # ------------------------------------------------------------------
     def algorithmic_bytes_per_step(self, iters_per_step=None) -> float:
-        """SURVEY.md 8(d) accounting: every SpMV streams its CSR matrix once
-        (fp64 values, int32 indices), vector passes 8 B per entry per vector."""
+        """SURVEY.md 8(d) accounting (assembled-CSR convention): every SpMV streams its CSR matrix
+        once (fp64 values, int32 indices), vector passes 8 B per entry per vector.  This is the
+        figure of merit the survey defines; the matrix-free modes move far fewer bytes
+        (see `implemented_bytes_per_step`)."""
         tot = 0.0
         it = iters_per_step
         for b, p in enumerate(self.per):
@@ -295,4 +297,40 @@ class IpcsBatch:
             iu, ip, im = (it[b] if it is not None else (6.0, 134.0, 3.0))
             tot += (3 * elem + a1 + iu * (2 * a1 + 10 * 8 * 2 * n2) + k1 + ip * (k1 + 6 * 8 * nv)
                     + mm + im * (mm + 6 * 8 * 2 * n2) + 200.0 * p["af"].shape[0])
+        return tot
+
+    def implemented_bytes_per_step(self, iters_per_step, mode: int = 3) -> float:
+        """Global-memory bytes the IMPLEMENTED algorithm has to move per batch step (no credit for
+        L2 hits; LDS / register resident data not counted), modes 2/3 (matrix-free) with the direct
+        pressure solver:
+          per operator application: element metadata 6 packed words + 5 geometry doubles per triangle
+          per BiCGStab iteration (mode 3): x read + write (16 B per dof)
+          per step: u_n, p_n read by the element loops and rewritten, u*, right-hand-side scratch of
+          step 2, boundary data, direct-solver factors W, F, Sinv, K[G,I]."""
+        tot = 0.0
+        for b, p in enumerate(self.per):
+            nv, nt, ne = p["nv"], p["nt"], p["ne"]
+            n2 = nv + ne
+            iu, ip, im = iters_per_step[b]
+            apply_b = (24.0 + 40.0) * nt
+            napply = 2 + 2 * iu + 2 + im  # rhs1, A x0, 2 per BiCGStab it, rhs3, M x0, 1 per CG it
+            per_it_vec = 32.0 * n2 * iu
+            state = (16.0 * n2 * 6 + 8.0 * nv * 6) + 12.0 * nt * 3 * 2 + 25.0 * n2
+            if getattr(self, "pds", None) is not None and self.desc.pd_enabled:
+                q = self.pds[b]
+                prs = 8.0 * (q["W"].size + q["F"].size + q["Sinv"].size + q["gk_val"].size) + 4.0 * (
+                    q["gk_col"].size + 2 * nv + q["gidx"].size)
+            else:
+                prs = ip * (12.0 * p["colidx1"].size)
+            tot += napply * apply_b + per_it_vec + state + prs
+        return tot
+
+    def flops_per_step(self, iters_per_step) -> float:
+        """fp64 operations (FMA = 2) of the matrix-free path per batch step (element operators only)."""
+        tot = 0.0
+        for b, p in enumerate(self.per):
+            nt = p["nt"]
+            iu, ip, im = iters_per_step[b]
+            f_vel, f_mass, f_rhs1, f_rhs3 = 2 * 300.0, 2 * 60.0, 2 * 900.0, 2 * 80.0
+            tot += nt * ((1 + 2 * iu) * f_vel + (1 + im) * f_mass + f_rhs1 + f_rhs3)
         return tot

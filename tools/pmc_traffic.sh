@@ -16,7 +16,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     vals = []
     for f in glob.glob(f"{out}/{c}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "evolve_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c:
+            if "evolve_" in r["Kernel_Name"] and r["Counter_Name"] == c:
                 vals.append(float(r["Counter_Value"]))
     res[c] = dict(n=len(vals), mean=sum(vals) / max(len(vals), 1), last100_mean=sum(vals[-100:]) / max(len(vals[-100:]), 1))
 print(json.dumps(res))
