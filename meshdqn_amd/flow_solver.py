@@ -1,0 +1,174 @@
+"""`FlowSolver` - the reference's surface (flow_solver.py:47-396) on the MI355X IPCS kernels.
+
+Same constructor signature, attributes and methods as the reference class:
+
+    solver = FlowSolver(flow_params, geometry_params, solver_params)
+    u_, p_, drag, lift = solver.evolve()
+    solver.remesh(mesh); solver.deploy(); solver.mark_boundaries()
+    solver.mesh, .removable, .drag_probe, .lift_probe, .num_vertices,
+    .accumulated_drag, .accumulated_lift, .gtime, .dt
+
+DOLFIN objects are replaced by light device-backed stand-ins (`Mesh`, `Function`)
+that expose the handful of methods the reference's callers use
+(`coordinates()`, `cells()`, `vector().get_local()/set_local()`, `copy(deepcopy=True)`).
+All arithmetic runs in `libmeshdqn_hip.so` (no CPU fallback).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .io_xdmf import load_mesh
+from .ipcs_batch import IpcsBatch, smooth_coords
+from .probes import DragProbe, LiftProbe
+from .topology import MeshTopology
+
+
+class Mesh:
+    """Minimal stand-in for `dolfin.Mesh` (vertex coordinates + ordered triangle cells)."""
+
+    def __init__(self, coords, cells=None):
+        if isinstance(coords, Mesh):  # copy constructor: Mesh(other)
+            self.topology_ = MeshTopology(coords.coordinates().copy(), coords.cells().copy())
+        else:
+            self.topology_ = MeshTopology(coords, cells)
+
+    def coordinates(self) -> np.ndarray:
+        return self.topology_.coords
+
+    def cells(self) -> np.ndarray:
+        return self.topology_.cells
+
+    def num_vertices(self) -> int:
+        return self.topology_.nv
+
+    def num_cells(self) -> int:
+        return self.topology_.nt
+
+    def smooth(self, iterations: int = 50):
+        """DOLFIN `Mesh.smooth` (in place)."""
+        self.topology_.coords[:] = smooth_coords(self.topology_, iterations)
+
+
+class _Vector:
+    def __init__(self, fn):
+        self._fn = fn
+
+    def get_local(self) -> np.ndarray:
+        return self._fn.data.detach().cpu().numpy().reshape(-1).copy()
+
+    def set_local(self, values):
+        v = torch.as_tensor(np.asarray(values, dtype=np.float64).reshape(self._fn.data.shape))
+        self._fn.data.copy_(v.to(self._fn.data.device))
+
+
+class Function:
+    """Stand-in for a `dolfin.Function` on P2^2 (velocity, data (np2,2)) or P1 (pressure, data (nv,))."""
+
+    def __init__(self, topo: MeshTopology, data: torch.Tensor, kind: str):
+        self.topo, self.data, self.kind = topo, data, kind
+        self.name = kind
+
+    def vector(self) -> _Vector:
+        return _Vector(self)
+
+    def copy(self, deepcopy: bool = True) -> "Function":
+        return Function(self.topo, self.data.clone() if deepcopy else self.data, self.kind)
+
+    def rename(self, name, label):
+        self.name = name
+
+    def set_allow_extrapolation(self, flag: bool):
+        pass  # evaluation always extrapolates from the nearest cell (see mesh_ops.interpolate)
+
+    def vertex_values(self) -> np.ndarray:
+        """Values at the mesh vertices = the vertex dofs (P2 vertex dofs come first)."""
+        nv = self.topo.nv
+        return self.data[:nv].detach().cpu().numpy().copy()
+
+
+class FlowSolver(object):
+    """IPCS scheme with explicit treatment of nonlinearity (flow_solver.py:47-48)."""
+
+    def __init__(self, flow_params, geometry_params, solver_params, device="cuda"):
+        self.mu = float(flow_params["mu"])
+        self.rho = float(flow_params["rho"])
+        self.viscosity, self.density = self.mu, self.rho
+        self.DEPLOY = False
+        self.device = torch.device(device)
+        if flow_params.get("inflow", "constant") != "constant":
+            raise NotImplementedError("only the reference's 'constant' (time independent parabolic) inflow is supported")
+        coords, cells = load_mesh(geometry_params["mesh"])
+        self.mesh = Mesh(coords, cells)
+        self.smooth = solver_params.get("smooth", False)
+        if self.smooth:
+            self.mesh.smooth(50)
+        self.dt_value = float(solver_params["dt"])
+        # `solver_type` of the yaml is ignored by the reference (it reads 'la_solve', flow_solver.py:147)
+        self.solver_type = solver_params.get("la_solve", "lu")
+        assert self.solver_type in ("lu", "la_solve")
+        self.rtol = float(solver_params.get("rtol", 1e-10))
+        self._setup(reassemble=True)
+        self.gtime = 0.0
+
+    # `dt` is a dolfin Constant in the reference; callers use `self.dt(0)`
+    def dt(self, _=0):
+        return self.dt_value
+
+    # ------------------------------------------------------------------
+    def _setup(self, reassemble: bool):
+        topo = self.mesh.topology_
+        self.removable = list(topo.removable())
+        self.bnd_tags = topo.facet_tags()
+        if reassemble:
+            self.batch = IpcsBatch([topo], [topo.coords], mu=self.mu, rho=self.rho, dt=self.dt_value,
+                                   rtol=self.rtol, device=self.device,
+                                   pressure_direct=(self.solver_type == "lu"))
+            self.batch.assemble()
+        n2, nv = topo.np2, topo.nv
+        self.u_n = Function(topo, self.batch.u_n[0, :n2] if reassemble else torch.zeros((n2, 2), dtype=torch.float64, device=self.device), "velocity")
+        self.p_n = Function(topo, self.batch.p_n[0, :nv] if reassemble else torch.zeros((nv,), dtype=torch.float64, device=self.device), "pressure")
+        self.u_, self.p_ = self.u_n, self.p_n
+        self.drag_probe = DragProbe(self.viscosity, None, self, tags=[1])
+        self.lift_probe = LiftProbe(self.viscosity, None, self, tags=[1])
+        self.accumulated_drag, self.accumulated_lift = [], []
+        self.num_vertices = nv
+
+    def mark_boundaries(self):
+        """Tags of the exterior facets: 0 walls / 1 airfoil / 2 inflow / 3 outflow / 4 other
+        (flow_solver.py:194-226).  Returns (edge ids, tags)."""
+        topo = self.mesh.topology_
+        return topo.boundary_edges, topo.facet_tags()
+
+    def deploy(self):
+        self.DEPLOY = True
+
+    def remesh(self, mesh: Mesh):
+        """flow_solver.py:233-359: swap the mesh, smooth again, recompute `removable`, new spaces /
+        functions / probes; operators are re-assembled (and the clock reset) only in DEPLOY mode."""
+        self.mesh = mesh
+        if self.smooth:
+            self.mesh.smooth(50)
+        if self.DEPLOY:
+            self._setup(reassemble=True)
+            self.gtime = 0.0
+        else:
+            # probes / functions follow the new mesh; the (unused in training) solver state is dropped
+            topo = self.mesh.topology_
+            self.batch = IpcsBatch([topo], [topo.coords], mu=self.mu, rho=self.rho, dt=self.dt_value,
+                                   rtol=self.rtol, device=self.device, pressure_direct=False)
+            self._setup(reassemble=False)
+            self.u_n = Function(topo, self.batch.u_n[0, :topo.np2], "velocity")
+            self.p_n = Function(topo, self.batch.p_n[0, :topo.nv], "pressure")
+            self.u_, self.p_ = self.u_n, self.p_n
+
+    def evolve(self, nsteps: int = 1):
+        """One IPCS time step (flow_solver.py:362-396); returns (u_, p_, drag, lift).
+        `nsteps > 1` runs several steps in one kernel launch and returns the last values."""
+        drag, lift = self.batch.evolve(nsteps)
+        self.gtime += self.dt_value * nsteps
+        d = drag[0].tolist()
+        l = lift[0].tolist()
+        self.accumulated_drag.extend(d)
+        self.accumulated_lift.extend(l)
+        return self.u_, self.p_, d[-1], l[-1]

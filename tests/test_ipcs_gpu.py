@@ -140,3 +140,32 @@ def test_kat_5000_steps_matches_reference_csv(meshes, lib_built):
         # 1e-5 relative on top of the CSV's 7 printed digits (Krylov instead of LU)
         assert abs(d - kat[n]["drag"]) < 5e-8 + 1e-5 * abs(kat[n]["drag"])
         assert abs(l - kat[n]["lift"]) < 5e-8 + 1e-5 * abs(kat[n]["lift"])
+
+
+def test_flow_solver_surface_matches_oracle(lib_built, tmp_path):
+    """The reference's FlowSolver surface (constructor dicts, evolve() 4-tuple, probes, remesh)."""
+    import numpy as np
+    from meshdqn_amd.flow_solver import FlowSolver, Function
+    from oracle.ipcs import OracleFlowSolver
+    mesh = os.path.join(GOLDEN, "ah93w145.npz")
+    fs = FlowSolver(flow_params={"mu": 1e-3, "rho": 1.0, "inflow": "constant"},
+                    geometry_params={"mesh": mesh},
+                    solver_params={"dt": 0.001, "solver_type": "lu", "smooth": True})
+    z = np.load(mesh)
+    o = OracleFlowSolver(z["coords"], z["cells"])
+    assert fs.num_vertices == 797 and sum(fs.removable) == 634
+    for _ in range(3):
+        u, p, drag, lift = fs.evolve()
+        uo, po, do, lo = o.evolve()
+    # default Krylov tolerance 1e-10 (the first steps from rest are the stiffest): 1e-7 on the forces
+    assert abs(drag - do) / abs(do) < 1e-7 and abs(lift - lo) / abs(lo) < 1e-7
+    assert len(fs.accumulated_drag) == 3 and abs(fs.gtime - 0.003) < 1e-15
+    # probes on copies of the fields (what Env2DAirfoil.calculate_reward does)
+    d2 = fs.drag_probe.sample(u.copy(deepcopy=True), p.copy(deepcopy=True))
+    l2 = fs.lift_probe.sample(u, p)
+    assert abs(d2 - do) / abs(do) < 1e-7 and abs(l2 - lo) / abs(lo) < 1e-7
+    # vector().get_local()/set_local round trip
+    v = u.vector().get_local()
+    u2 = u.copy(deepcopy=True)
+    u2.vector().set_local(2.0 * v)
+    assert np.allclose(u2.vector().get_local(), 2.0 * v)
