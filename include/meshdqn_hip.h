@@ -168,6 +168,45 @@ int mdq_ipcs_evolve(const mdq_ipcs_desc* d, int32_t nsteps, double* drag, double
 int mdq_probe_forces(const mdq_ipcs_desc* d, int32_t nfields, const double* u, const double* p,
                      double* drag, double* lift, void* stream);
 
+/* ---- graph Q-network forward (airfoilgcnn.py:85-145 NodeRemovalNet, :170-209 AirfoilGCNN) ---- */
+typedef struct mdq_gcn_level {
+  int32_t type;          /* 0 = SAGEConv (mean aggr, root weight), 1 = GCNConv (self loops, sym. norm) */
+  int32_t fin;           /* input features of this level */
+  const float* w_l;      /* device [fin][C]: SAGE lin_l.weight^T / GCN lin.weight^T */
+  const float* b;        /* device [C]: SAGE lin_l.bias / GCN bias */
+  const float* w_r;      /* device [fin][C]: SAGE lin_r.weight^T (unused for GCN) */
+  const float* pool_w;   /* device [C]: TopKPooling.weight */
+} mdq_gcn_level;
+
+typedef struct mdq_gcn_net {
+  int32_t nlevels, C, fin0, out_dim;  /* conv/pool levels, conv width, input features, head outputs */
+  double ratio;                       /* TopKPooling ratio */
+  int32_t softmax;                    /* 1: softmax over the head outputs (NodeRemovalNet) */
+  int32_t _pad;
+  mdq_gcn_level levels[6];
+  const float* lin1_w;   /* device [2C][128]  lin1.weight^T */
+  const float* lin1_b;
+  const float* lin2_w;   /* device [128][64] */
+  const float* lin2_b;
+  const float* lin3_w;   /* device [64][out_dim] */
+  const float* lin3_b;
+} mdq_gcn_net;
+
+/*
+ * Batched forward of B graphs (one workgroup per graph, whole network out of LDS; dense head on MFMA).
+ * Replaces `NodeRemovalNet.forward(Batch)` / `AirfoilGCNN.forward(Batch)` and the PyG layers they call.
+ *   x        device float [sum_nodes][fin0]     node features, graphs concatenated
+ *   node_ptr device int32 [B+1]                 first node of every graph
+ *   esrc/edst device int32 [sum_edges]          edge end points, LOCAL node ids (0..n_g-1), j -> i
+ *   edge_ptr device int32 [B+1]
+ *   emb      device float [B][2C]  (out)        graph embeddings (x1+x2+...)
+ *   out      device float [B][out_dim] (out)    head outputs (softmax probabilities if net.softmax)
+ *   NMAX / EMAX: upper bounds of nodes / edges per graph (sizes the LDS carve-up)
+ */
+int mdq_gcn_forward(const mdq_gcn_net* net, int32_t B, int32_t NMAX, int32_t EMAX, const float* x,
+                    const int32_t* node_ptr, const int32_t* esrc, const int32_t* edst,
+                    const int32_t* edge_ptr, float* emb, float* out, void* stream);
+
 /* ---- host-side mesh smoothing (DOLFIN Mesh.smooth, flow_solver.py:65-67,236-237) ---- */
 /*
  * Gauss-Seidel centroid smoothing of interior vertices in index order, step

@@ -58,6 +58,8 @@ SYMBOLS = {
     "mdq_ipcs_evolve": (C.c_int, [C.POINTER(IpcsDesc), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdq_probe_forces": (C.c_int, [C.POINTER(IpcsDesc), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),
+    "mdq_gcn_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdq_smooth_host": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
 }

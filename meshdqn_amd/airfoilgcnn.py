@@ -232,10 +232,10 @@ class NodeRemovalNet(nn.Module, _WeightAccessors):
         x = F.softmax(x, dim=1)  # pick which vertex to remove
         return x
 
-    def forward_fused(self, x, edge_index, edge_ptr, nodes_per_graph):
-        """Inference on the fused HIP kernel; see meshdqn_amd.gcn_fused.node_removal_forward."""
+    def forward_fused(self, data):
+        """Inference (no autograd) on the fused HIP kernels: one workgroup per graph, MFMA head."""
         from .gcn_fused import node_removal_forward
-        return node_removal_forward(self, x, edge_index, edge_ptr, nodes_per_graph)
+        return node_removal_forward(self, data)
 
 
 class AirfoilGCNN(nn.Module, _WeightAccessors):
@@ -273,3 +273,8 @@ class AirfoilGCNN(nn.Module, _WeightAccessors):
         x = F.relu(self.lin2(x))
         x = self.lin3(x)
         return x
+
+    def forward_fused(self, data):
+        """Inference (no autograd) on the fused HIP kernels."""
+        from .gcn_fused import node_removal_forward
+        return node_removal_forward(self, data)

@@ -1,0 +1,402 @@
+// Fused batched forward of the reference's graph Q-networks on gfx950.
+//
+// Kernel 1 (gcn_embed_kernel): ONE 256-thread workgroup per graph runs every conv / pool level out
+// of LDS - CSR-by-target mean aggregation (SAGEConv), symmetric-normalised aggregation (GCNConv),
+// TopKPooling (tanh score, rank-by-counting top-k, edge filter + relabel), [max || mean] readouts -
+// and writes the 2C-wide graph embedding (sum of the per-level readouts).
+// Kernel 2 (mlp_head_kernel): the dense head lin1 -> relu -> lin2 -> relu -> lin3 (-> softmax),
+// batched over graphs on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains).
+//
+// Restated semantics: airfoilgcnn.py:85-145 (NodeRemovalNet.forward), :170-209 (AirfoilGCNN.forward)
+// and the PyG layers they call.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "../../include/meshdqn_hip.h"
+
+namespace mdq_gcn {
+
+constexpr int WGT = 256;
+constexpr int NACC = 24;  // accumulators per thread of the "feature-outer" small-graph convolution
+
+struct Lds {
+  float* x;      // level input features  [n][fin]      (row stride = fin)
+  float* h;      // conv output           [n][C+1]
+  float* agg;    // aggregated features   [n][fin]
+  float* score;  // [n]
+  float* deg;    // [n]  in-degree (+1 for GCN)
+  int* adj_ptr;  // [n+1] CSR by target
+  int* adj;      // [E]   source ids in edge order
+  int* esrc;     // [E]
+  int* edst;     // [E]
+  int* newid;    // [n]
+  int* misc;     // [8]
+};
+
+// CSR by target (sources kept in edge order => deterministic sums)
+__device__ inline void build_csr(const Lds& L, int n, int E) {
+  const int tid = threadIdx.x;
+  for (int i = tid; i < n; i += WGT) {
+    int c = 0;
+    for (int e = 0; e < E; ++e) c += (L.edst[e] == i);
+    L.adj_ptr[i + 1] = c;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    L.adj_ptr[0] = 0;
+    for (int i = 0; i < n; ++i) L.adj_ptr[i + 1] += L.adj_ptr[i];
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += WGT) {
+    int p = L.adj_ptr[i];
+    for (int e = 0; e < E; ++e)
+      if (L.edst[e] == i) L.adj[p++] = L.esrc[e];
+  }
+  __syncthreads();
+}
+
+// out[i][c] = relu( b[c] + sum_f wl[f][c] * A[i][f] (+ wr[f][c] * X[i][f]) ) ;  A, X in LDS with stride fin
+// Form (a): per node, weights of channel c in registers (fin <= 32).
+template <bool ROOT>
+__device__ inline void conv_dense_small_fin(const Lds& L, int n, int fin, int C, const float* __restrict__ wl,
+                                            const float* __restrict__ b, const float* __restrict__ wr,
+                                            const float* A, const float* X) {
+  const int tid = threadIdx.x, c = tid % C, g = tid / C, G = WGT / C;
+  float wlr[32], wrr[32];
+#pragma unroll
+  for (int f = 0; f < 32; ++f) {
+    wlr[f] = f < fin ? wl[f * C + c] : 0.f;
+    wrr[f] = (ROOT && f < fin) ? wr[f * C + c] : 0.f;
+  }
+  const float bc = b[c];
+  for (int i = g; i < n; i += G) {
+    float acc = 0.f;
+#pragma unroll
+    for (int f = 0; f < 32; ++f) {
+      if (f < fin) {
+        acc = fmaf(wlr[f], A[i * fin + f], acc);
+        if (ROOT) acc = fmaf(wrr[f], X[i * fin + f], acc);
+      }
+    }
+    L.h[i * (C + 1) + c] = acc + bc;
+  }
+}
+
+// Form (b): feature-outer loop, up to NACC nodes per thread (n <= NACC * WGT/C), any fin.
+template <bool ROOT>
+__device__ inline void conv_dense_small_n(const Lds& L, int n, int fin, int C, const float* __restrict__ wl,
+                                          const float* __restrict__ b, const float* __restrict__ wr, const float* A,
+                                          const float* X) {
+  const int tid = threadIdx.x, c = tid % C, g = tid / C, G = WGT / C;
+  float acc[NACC];
+#pragma unroll
+  for (int r = 0; r < NACC; ++r) acc[r] = 0.f;
+  for (int f = 0; f < fin; ++f) {
+    const float w1 = wl[f * C + c];
+    const float w2 = ROOT ? wr[f * C + c] : 0.f;
+#pragma unroll
+    for (int r = 0; r < NACC; ++r) {
+      const int i = g + r * G;
+      if (i < n) {
+        acc[r] = fmaf(w1, A[i * fin + f], acc[r]);
+        if (ROOT) acc[r] = fmaf(w2, X[i * fin + f], acc[r]);
+      }
+    }
+  }
+  const float bc = b[c];
+#pragma unroll
+  for (int r = 0; r < NACC; ++r) {
+    const int i = g + r * G;
+    if (i < n) L.h[i * (C + 1) + c] = acc[r] + bc;
+  }
+}
+
+// level input buffer: level 0 holds [NMAX][fin0], later levels [ceil(ratio*NMAX)][C]
+__host__ __device__ inline int mdq_gcn_xs(const mdq_gcn_net& net, int NMAX) {
+  const int k1 = (int)ceil(net.ratio * (double)NMAX);
+  const int a = NMAX * net.fin0, b = k1 * net.C;
+  return ((a > b ? a : b) + 3) & ~3;
+}
+
+struct Level {
+  int type, fin;
+  const float *wl, *b, *wr, *pw;
+};
+
+// one conv + relu + TopK pool + readout level; features in L.x ([n][fin]) are replaced by the pooled ones
+__device__ inline void run_level(const Lds& L, const Level& lv, int C, double ratio, int& n, int& E, float& rmax,
+                                 float& rmean) {
+  const int tid = threadIdx.x, fin = lv.fin;
+  build_csr(L, n, E);
+  // ---- aggregation into L.agg
+  if (lv.type == 0) {  // SAGE: mean over incoming edges (duplicates count), 0 for isolated nodes
+    for (int idx = tid; idx < n * fin; idx += WGT) {
+      const int i = idx / fin, f = idx - i * fin;
+      float s = 0.f;
+      const int p0 = L.adj_ptr[i], p1 = L.adj_ptr[i + 1];
+      for (int p = p0; p < p1; ++p) s += L.x[L.adj[p] * fin + f];
+      L.agg[idx] = p1 > p0 ? s / (float)(p1 - p0) : 0.f;
+    }
+  } else {  // GCN: (A + I) with D^-1/2 on both sides, applied to X before the (linear) weight
+    for (int i = tid; i < n; i += WGT) L.deg[i] = 1.0f / sqrtf((float)(L.adj_ptr[i + 1] - L.adj_ptr[i] + 1));
+    __syncthreads();
+    for (int idx = tid; idx < n * fin; idx += WGT) {
+      const int i = idx / fin, f = idx - i * fin;
+      const float di = L.deg[i];
+      float s = di * di * L.x[idx];
+      for (int p = L.adj_ptr[i]; p < L.adj_ptr[i + 1]; ++p) {
+        const int j = L.adj[p];
+        s += L.deg[j] * di * L.x[j * fin + f];
+      }
+      L.agg[idx] = s;
+    }
+  }
+  __syncthreads();
+  // ---- dense part
+  const int G = WGT / C;
+  if (fin <= 32) {
+    if (lv.type == 0)
+      conv_dense_small_fin<true>(L, n, fin, C, lv.wl, lv.b, lv.wr, L.agg, L.x);
+    else
+      conv_dense_small_fin<false>(L, n, fin, C, lv.wl, lv.b, nullptr, L.agg, L.x);
+  } else {
+    // (n <= NACC*G is guaranteed by the host-side check)
+    if (lv.type == 0)
+      conv_dense_small_n<true>(L, n, fin, C, lv.wl, lv.b, lv.wr, L.agg, L.x);
+    else
+      conv_dense_small_n<false>(L, n, fin, C, lv.wl, lv.b, nullptr, L.agg, L.x);
+  }
+  (void)G;
+  __syncthreads();
+  // ---- relu + score = tanh(h . w / |w|)
+  float wn = 0.f;
+  for (int c = 0; c < C; ++c) wn = fmaf(lv.pw[c], lv.pw[c], wn);
+  wn = sqrtf(wn);
+  for (int i = tid; i < n; i += WGT) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) {
+      float hv = L.h[i * (C + 1) + c];
+      hv = hv > 0.f ? hv : 0.f;
+      L.h[i * (C + 1) + c] = hv;
+      s = fmaf(hv, lv.pw[c], s);
+    }
+    L.score[i] = tanhf(s / wn);
+  }
+  __syncthreads();
+  // ---- top-k by rank counting (descending score, ties by lower index = stable sort)
+  const int k = (int)ceil(ratio * (double)n);
+  for (int i = tid; i < n; i += WGT) {
+    const float si = L.score[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const float sj = L.score[j];
+      rank += (sj > si) || (sj == si && j < i);
+    }
+    L.newid[i] = rank < k ? rank : -1;
+  }
+  __syncthreads();
+  // ---- pooled features x'[r][c] = h[perm r][c] * score[perm r]  -> L.x with stride C
+  for (int i = tid; i < n; i += WGT) {
+    const int r = L.newid[i];
+    if (r >= 0) {
+      const float s = L.score[i];
+      for (int c = 0; c < C; ++c) L.x[r * C + c] = L.h[i * (C + 1) + c] * s;
+    }
+  }
+  // ---- filter + relabel edges, preserving edge order (wave 0, ballot compaction)
+  if (tid < 64) {
+    int outp = 0;
+    for (int base = 0; base < E; base += 64) {
+      const int e = base + tid;
+      int s = -1, d = -1;
+      if (e < E) {
+        s = L.newid[L.esrc[e]];
+        d = L.newid[L.edst[e]];
+      }
+      const bool keep = (s >= 0) && (d >= 0);
+      const unsigned long long m = __ballot(keep);
+      const int pos = outp + __popcll(m & ((1ull << tid) - 1ull));
+      // (in-place is safe: pos <= e, and all reads of this chunk happened before the ballot)
+      if (keep) {
+        L.esrc[pos] = s;
+        L.edst[pos] = d;
+      }
+      outp += __popcll(m);
+    }
+    if (tid == 0) L.misc[0] = outp;
+  }
+  __syncthreads();
+  E = L.misc[0];
+  n = k;
+  // ---- readout over the pooled nodes: thread c < C
+  if (tid < C) {
+    float mx = -INFINITY, sm = 0.f;
+    for (int r = 0; r < n; ++r) {
+      const float v = L.x[r * C + tid];
+      mx = fmaxf(mx, v);
+      sm += v;
+    }
+    rmax += mx;
+    rmean += sm / (float)n;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(WGT) void gcn_embed_kernel(mdq_gcn_net net, int NMAX, int EMAX, const float* x,
+                                                         const int32_t* node_ptr, const int32_t* esrc,
+                                                         const int32_t* edst, const int32_t* edge_ptr, float* emb) {
+  extern __shared__ __align__(16) float sm[];
+  const int b = blockIdx.x, tid = threadIdx.x, C = net.C;
+  const int n0 = node_ptr[b], nn = node_ptr[b + 1] - n0;
+  const int e0 = edge_ptr[b], ne = edge_ptr[b + 1] - e0;
+  const int XS = mdq_gcn_xs(net, NMAX);  // floats of the level-input / aggregation buffers
+  Lds L;
+  float* p = sm;
+  L.x = p;      p += XS;
+  L.h = p;      p += (size_t)NMAX * (C + 1);
+  L.agg = p;    p += XS;
+  L.score = p;  p += NMAX;
+  L.deg = p;    p += NMAX;
+  int* q = reinterpret_cast<int*>(p);
+  L.adj_ptr = q; q += NMAX + 1;
+  L.adj = q;     q += EMAX;
+  L.esrc = q;    q += EMAX;
+  L.edst = q;    q += EMAX;
+  L.newid = q;   q += NMAX;
+  L.misc = q;
+  for (int idx = tid; idx < nn * net.fin0; idx += WGT) L.x[idx] = x[(size_t)n0 * net.fin0 + idx];
+  for (int e = tid; e < ne; e += WGT) {
+    L.esrc[e] = esrc[e0 + e];
+    L.edst[e] = edst[e0 + e];
+  }
+  __syncthreads();
+  int n = nn, E = ne;
+  float rmax = 0.f, rmean = 0.f;
+  for (int l = 0; l < net.nlevels; ++l) {
+    Level lv;
+    lv.type = net.levels[l].type;
+    lv.fin = net.levels[l].fin;
+    lv.wl = net.levels[l].w_l;
+    lv.b = net.levels[l].b;
+    lv.wr = net.levels[l].w_r;
+    lv.pw = net.levels[l].pool_w;
+    run_level(L, lv, C, net.ratio, n, E, rmax, rmean);
+  }
+  if (tid < C) {
+    emb[(size_t)b * 2 * C + tid] = rmax;
+    emb[(size_t)b * 2 * C + C + tid] = rmean;
+  }
+}
+
+// ------------------------------------------------------------------ MLP head on the matrix cores
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+// OUT[32][ncols] = act( IN[32][K] * W[K][ncols] + bias ), IN / OUT in LDS (row-major), W in global
+// (row-major [K][ncols] = transposed torch weight).  4 waves, one 32x32 block each per pass.
+__device__ inline void head_layer(const float* in, int in_stride, int K, const float* __restrict__ W,
+                                  const float* __restrict__ bias, int ncols, float* out, int out_stride, bool relu) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nblk = (ncols + 31) / 32;
+  for (int blk = wave; blk < nblk; blk += WGT / 64) {
+    const int col = blk * 32 + (lane & 31);
+    const bool cv = col < ncols;
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int kh = lane >> 5;
+    for (int k = 0; k < K; k += 2) {
+      const float a = in[(lane & 31) * in_stride + k + kh];
+      const float bv = cv ? W[(size_t)(k + kh) * ncols + col] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+    }
+    if (cv) {
+      const float bc = bias[col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float v = acc[r] + bc;
+        if (relu) v = v > 0.f ? v : 0.f;
+        out[row * out_stride + col] = v;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(WGT) void mlp_head_kernel(mdq_gcn_net net, int B, const float* emb, float* out) {
+  extern __shared__ __align__(16) float sm[];
+  const int tid = threadIdx.x, K1 = 2 * net.C, OUT = net.out_dim;
+  const int OUTP = (OUT + 31) & ~31;
+  // row strides padded by one float: the A-operand reads walk 32 rows at a fixed k (bank conflicts otherwise)
+  float* a0 = sm;                    // [32][K1+1]
+  float* a1 = a0 + 32 * (K1 + 1);    // [32][129]
+  float* a2 = a1 + 32 * 129;         // [32][65]
+  float* a3 = a2 + 32 * 65;          // [32][OUTP]
+  const int g0 = blockIdx.x * 32;
+  for (int idx = tid; idx < 32 * K1; idx += WGT) {
+    const int r = idx / K1, c = idx - r * K1;
+    a0[r * (K1 + 1) + c] = (g0 + r < B) ? emb[(size_t)(g0 + r) * K1 + c] : 0.f;
+  }
+  __syncthreads();
+  head_layer(a0, K1 + 1, K1, net.lin1_w, net.lin1_b, 128, a1, 129, true);
+  __syncthreads();
+  head_layer(a1, 129, 128, net.lin2_w, net.lin2_b, 64, a2, 65, true);
+  __syncthreads();
+  head_layer(a2, 65, 64, net.lin3_w, net.lin3_b, OUT, a3, OUTP, false);
+  __syncthreads();
+  // softmax (optional) + store: one wave per row, 8 rows per wave
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int r = wave; r < 32; r += WGT / 64) {
+    if (g0 + r >= B) continue;
+    const float* row = a3 + r * OUTP;
+    if (net.softmax) {
+      float mx = -INFINITY;
+      for (int c = lane; c < OUT; c += 64) mx = fmaxf(mx, row[c]);
+      for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+      float s = 0.f;
+      for (int c = lane; c < OUT; c += 64) s += expf(row[c] - mx);
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+      for (int c = lane; c < OUT; c += 64) out[(size_t)(g0 + r) * OUT + c] = expf(row[c] - mx) / s;
+    } else {
+      for (int c = lane; c < OUT; c += 64) out[(size_t)(g0 + r) * OUT + c] = row[c];
+    }
+  }
+}
+
+}  // namespace mdq_gcn
+
+extern "C" int mdq_gcn_forward(const mdq_gcn_net* net, int32_t B, int32_t NMAX, int32_t EMAX, const float* x,
+                               const int32_t* node_ptr, const int32_t* esrc, const int32_t* edst,
+                               const int32_t* edge_ptr, float* emb, float* out, void* stream) {
+  using namespace mdq_gcn;
+  if (!net || B <= 0 || !x || !node_ptr || !edge_ptr || !emb || !out) return mdq_set_error("mdq_gcn_forward: bad arguments");
+  const int C = net->C;
+  if (C != 64 && C != 128 && C != 256 && C != 32) return mdq_set_error("mdq_gcn_forward: conv width must divide 256");
+  if (net->fin0 > 32 && NMAX > NACC * (WGT / C)) return mdq_set_error("mdq_gcn_forward: graph too large for the input width");
+  for (int l = 0; l < net->nlevels; ++l) {
+    // node count entering level l
+    double n = NMAX;
+    for (int j = 0; j < l; ++j) n = std::ceil(net->ratio * n);
+    if (net->levels[l].fin > 32 && n > NACC * (WGT / C)) return mdq_set_error("mdq_gcn_forward: too many nodes at a wide level");
+  }
+  size_t lds = sizeof(float) * ((size_t)mdq_gcn_xs(*net, NMAX) * 2 + (size_t)NMAX * (C + 1) + 2 * (size_t)NMAX) +
+               sizeof(int) * ((size_t)NMAX + 1 + 3 * (size_t)EMAX + NMAX + 8);
+  if (lds > 160 * 1024) return mdq_set_error("mdq_gcn_forward: graph does not fit in LDS");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gcn_embed_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return mdq_set_error(hipGetErrorString(e));
+  hipLaunchKernelGGL(gcn_embed_kernel, dim3(B), dim3(WGT), lds, st, *net, NMAX, EMAX, x, node_ptr, esrc, edst,
+                     edge_ptr, emb);
+  e = hipGetLastError();
+  if (e != hipSuccess) return mdq_set_error(hipGetErrorString(e));
+  const int OUTP = (net->out_dim + 31) & ~31;
+  size_t lds2 = sizeof(float) * 32 * ((size_t)2 * C + 1 + 129 + 65 + OUTP);
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds2);
+  if (e != hipSuccess) return mdq_set_error(hipGetErrorString(e));
+  hipLaunchKernelGGL(mlp_head_kernel, dim3((B + 31) / 32), dim3(WGT), lds2, st, *net, B, emb, out);
+  e = hipGetLastError();
+  if (e != hipSuccess) return mdq_set_error(hipGetErrorString(e));
+  return 0;
+}

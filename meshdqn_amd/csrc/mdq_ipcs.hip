@@ -2316,6 +2316,12 @@ static int check_desc(const mdq_ipcs_desc* d) {
 
 }  // namespace mdq
 
+// shared by the other sources of this translation unit
+int mdq_set_error(const char* msg) {
+  mdq::g_err = msg;
+  return -2;
+}
+
 using namespace mdq;
 
 extern "C" {

@@ -1,3 +1,4 @@
 // Single translation unit of libmeshdqn_hip.so (keeps __constant__ tables and
 // the thread-local error string in one place; no relocatable device code needed).
 #include "mdq_ipcs.hip"
+#include "mdq_gcn.hip"
