@@ -207,6 +207,38 @@ int mdq_gcn_forward(const mdq_gcn_net* net, int32_t B, int32_t NMAX, int32_t EMA
                     const int32_t* node_ptr, const int32_t* esrc, const int32_t* edst,
                     const int32_t* edge_ptr, float* emb, float* out, void* stream);
 
+/* ---- snapshot interpolation onto coarsened meshes (Env2DAirfoil.py:556-593, :515-522) ---- */
+typedef struct mdq_interp_desc {
+  int32_t B, S;            /* target meshes (environments), snapshots                         */
+  int32_t NP, NP1;         /* capacities: target P2 points (vertices then edge midpoints), P1 points (vertices) */
+  int32_t src_nv, src_nt, src_n2;
+  int32_t gnx, gny;        /* uniform location grid over the source mesh                       */
+  int32_t _pad;
+  double x0, y0, inv_hx, inv_hy;
+  const int32_t* npts;     /* device [B]   P2 target points per environment                    */
+  const int32_t* np1;      /* device [B]   P1 target points (= vertices) per environment       */
+  const double* points;    /* device [B][NP][2]  target coordinates                            */
+  /* source (original, smoothed) mesh and its snapshots, device */
+  const double* src_coords;     /* [src_nv][2]                                                 */
+  const int32_t* src_cell_dofs; /* [6][src_nt]                                                 */
+  const double* src_geom;       /* [5][src_nt] as written by mdq_ipcs_assemble                 */
+  const int32_t* bin_ptr;       /* [gnx*gny+1] candidate cells per grid bin (ascending ids, never empty) */
+  const int32_t* bin_cells;
+  const double* src_u;          /* [S][src_n2][2]                                              */
+  const double* src_p;          /* [S][src_nv]                                                 */
+  /* outputs, device */
+  double* out_u;                /* [B][S][NP][2]                                               */
+  double* out_p;                /* [B][S][NP1]                                                 */
+  int32_t* out_cell;            /* [B][NP] located source cell (may be NULL)                   */
+} mdq_interp_desc;
+
+/*
+ * Interpolate S stored (u, p) snapshots of the ORIGINAL mesh onto the P2 / P1 dof points of B
+ * coarsened meshes: point location (containing cell, else nearest = extrapolation) + basis evaluation.
+ * Replaces `v_func.interpolate(original_u)` / `p_func.interpolate(original_p)` (Env2DAirfoil.py:556-568).
+ */
+int mdq_interpolate_snapshots(const mdq_interp_desc* d, void* stream);
+
 /* ---- host-side mesh smoothing (DOLFIN Mesh.smooth, flow_solver.py:65-67,236-237) ---- */
 /*
  * Gauss-Seidel centroid smoothing of interior vertices in index order, step

@@ -49,6 +49,20 @@ class IpcsDesc(C.Structure):
     ]
 
 
+class InterpDesc(C.Structure):
+    """Mirror of `mdq_interp_desc`."""
+    _fields_ = [
+        ("B", C.c_int32), ("S", C.c_int32), ("NP", C.c_int32), ("NP1", C.c_int32),
+        ("src_nv", C.c_int32), ("src_nt", C.c_int32), ("src_n2", C.c_int32),
+        ("gnx", C.c_int32), ("gny", C.c_int32), ("_pad", C.c_int32),
+        ("x0", C.c_double), ("y0", C.c_double), ("inv_hx", C.c_double), ("inv_hy", C.c_double),
+        ("npts", C.c_void_p), ("np1", C.c_void_p), ("points", C.c_void_p),
+        ("src_coords", C.c_void_p), ("src_cell_dofs", C.c_void_p), ("src_geom", C.c_void_p),
+        ("bin_ptr", C.c_void_p), ("bin_cells", C.c_void_p), ("src_u", C.c_void_p), ("src_p", C.c_void_p),
+        ("out_u", C.c_void_p), ("out_p", C.c_void_p), ("out_cell", C.c_void_p),
+    ]
+
+
 # every symbol include/meshdqn_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "mdq_abi_version": (C.c_int, []),
@@ -60,6 +74,7 @@ SYMBOLS = {
                                    C.c_void_p]),
     "mdq_gcn_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mdq_interpolate_snapshots": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mdq_smooth_host": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
 }

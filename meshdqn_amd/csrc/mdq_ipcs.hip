@@ -117,8 +117,7 @@ __device__ __forceinline__ EnvView env_view(const mdq_ipcs_desc& d, int b) {
   v.u_n = reinterpret_cast<double2*>(d.u_n) + B * d.N2;
   v.p_n = d.p_n + B * d.NV;
   v.work = d.work + B * work_per_env(d.NV, d.NT, d.NE);
-  v.nnz2 = v.rowptr2[v.n2];
-  v.nnz1 = v.rowptr1[v.nv];
+  v.nnz2 = v.nnz1 = 0;  // (filled by the assembly kernel: light descriptors carry no patterns)
   return v;
 }
 
@@ -196,7 +195,9 @@ __device__ inline void outflow_entry(const EnvView& v, int e, int k, int i, int 
 
 __global__ __launch_bounds__(WG) void assemble_kernel(mdq_ipcs_desc d) {
   const int b = blockIdx.x;
-  const EnvView v = env_view(d, b);
+  EnvView v = env_view(d, b);
+  v.nnz2 = v.rowptr2[v.n2];
+  v.nnz1 = v.rowptr1[v.nv];
   const int tid = threadIdx.x;
   const double a = d.rho / d.dt, mu = d.mu;
 
@@ -937,9 +938,21 @@ __device__ inline void forces(const EnvView& v, double mu, const double2* __rest
   for (int f = threadIdx.x; f < v.naf; f += WG) {
     const int e = v.af_facets[2 * f], k = v.af_facets[2 * f + 1];
     const ElemIdx E = load_dofs(v, e);
-    const Geo g = load_geo(v, e);
     double X[3][2];
     load_cell_coords(v, e, X);
+    // geometry straight from the coordinates: the probes then need no assembled operators
+    // (Env2DAirfoil.calculate_reward samples them on every freshly coarsened mesh)
+    Geo g;
+    {
+      const double J00 = X[1][0] - X[0][0], J01 = X[2][0] - X[0][0];
+      const double J10 = X[1][1] - X[0][1], J11 = X[2][1] - X[0][1];
+      const double det = J00 * J11 - J01 * J10;
+      g.j00 = J11 / det;
+      g.j01 = -J01 / det;
+      g.j10 = -J10 / det;
+      g.j11 = J00 / det;
+      g.det = fabs(det);
+    }
     const Facet F = facet_geometry(X, k);
     double2 ue[6];
 #pragma unroll
@@ -2389,7 +2402,9 @@ int mdq_ipcs_evolve(const mdq_ipcs_desc* d, int32_t nsteps, double* drag, double
 
 int mdq_probe_forces(const mdq_ipcs_desc* d, int32_t nfields, const double* u, const double* p, double* drag,
                      double* lift, void* stream) {
-  if (int rc = check_desc(d)) return rc;
+  // needs only: B, NV, NT, NE, N2, NAF, mu, nv, nt, ne, naf, coords, cell_dofs, af_facets
+  if (!d || d->B <= 0 || d->N2 != d->NV + d->NE || !d->coords || !d->cell_dofs || !d->af_facets)
+    return fail_msg("mdq_probe_forces: incomplete mesh descriptor");
   if (nfields <= 0 || !u || !p || !drag || !lift) return fail_msg("bad probe arguments");
   if (int rc = ensure_tables()) return rc;
   hipLaunchKernelGGL(probe_kernel, dim3(d->B), dim3(WG), 0, (hipStream_t)stream, *d, nfields, u, p, drag, lift);

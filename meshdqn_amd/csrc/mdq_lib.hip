@@ -2,3 +2,4 @@
 // the thread-local error string in one place; no relocatable device code needed).
 #include "mdq_ipcs.hip"
 #include "mdq_gcn.hip"
+#include "mdq_mesh.hip"

@@ -1,0 +1,87 @@
+// Mesh-side kernels of the environment step: point location + P2/P1 evaluation of the stored
+// snapshots on a coarsened mesh (Env2DAirfoil._check_mesh, Env2DAirfoil.py:556-593:
+// `v_func.interpolate(original_u)`, `p_func.interpolate(original_p)` and the vertex evaluations).
+#include <hip/hip_runtime.h>
+
+#include "../../include/meshdqn_hip.h"
+
+namespace mdq_mesh {
+
+// One thread per target point: walk the candidate cells of its grid bin (ascending cell id), take the
+// first cell whose barycentric coordinates are all >= 0, otherwise the candidate with the smallest
+// violation (extrapolation from the nearest cell, `allow_extrapolation=True`), then evaluate all
+// snapshots with the P2 / P1 bases of that cell.
+__global__ __launch_bounds__(256) void interpolate_kernel(mdq_interp_desc d) {
+  const int b = blockIdx.y;
+  const int npts = d.npts[b];
+  const int np1 = d.np1[b];
+  const int64_t B = b;
+  const double* pts = d.points + B * d.NP * 2;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < npts; k += gridDim.x * blockDim.x) {
+    const double px = pts[2 * k], py = pts[2 * k + 1];
+    int gx = (int)floor((px - d.x0) * d.inv_hx), gy = (int)floor((py - d.y0) * d.inv_hy);
+    gx = gx < 0 ? 0 : (gx >= d.gnx ? d.gnx - 1 : gx);
+    gy = gy < 0 ? 0 : (gy >= d.gny ? d.gny - 1 : gy);
+    const int bin = gy * d.gnx + gx;
+    int best = -1;
+    double bxi = 0.0, beta = 0.0, bviol = -1e300;
+    for (int s = d.bin_ptr[bin]; s < d.bin_ptr[bin + 1]; ++s) {
+      const int c = d.bin_cells[s];
+      const int v0 = d.src_cell_dofs[0 * d.src_nt + c];
+      const double dx = px - d.src_coords[2 * v0], dy = py - d.src_coords[2 * v0 + 1];
+      const double j00 = d.src_geom[0 * d.src_nt + c], j01 = d.src_geom[1 * d.src_nt + c];
+      const double j10 = d.src_geom[2 * d.src_nt + c], j11 = d.src_geom[3 * d.src_nt + c];
+      // reference coordinates: [xi, eta] = J^-1 (x - x0); geom stores Jinv[c][a] (reference row, physical col)
+      const double xi = j00 * dx + j01 * dy, eta = j10 * dx + j11 * dy;
+      const double l0 = 1.0 - xi - eta;
+      double viol = fmin(fmin(l0, xi), eta);
+      viol = viol < 0.0 ? viol : 0.0;
+      if (viol > bviol) {  // strict: the first (lowest id) best candidate wins
+        bviol = viol;
+        best = c;
+        bxi = xi;
+        beta = eta;
+        if (viol == 0.0) break;
+      }
+    }
+    const double l0 = 1.0 - bxi - beta, l1 = bxi, l2 = beta;
+    double phi[6];
+    phi[0] = l0 * (2.0 * l0 - 1.0);
+    phi[1] = l1 * (2.0 * l1 - 1.0);
+    phi[2] = l2 * (2.0 * l2 - 1.0);
+    phi[3] = 4.0 * l1 * l2;
+    phi[4] = 4.0 * l0 * l2;
+    phi[5] = 4.0 * l0 * l1;
+    int dof[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dof[i] = d.src_cell_dofs[i * d.src_nt + best];
+    for (int s = 0; s < d.S; ++s) {
+      const double* us = d.src_u + (int64_t)s * d.src_n2 * 2;
+      double ux = 0.0, uy = 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        ux += us[2 * dof[i]] * phi[i];
+        uy += us[2 * dof[i] + 1] * phi[i];
+      }
+      double* uo = d.out_u + ((B * d.S + s) * d.NP + k) * 2;
+      uo[0] = ux;
+      uo[1] = uy;
+      if (k < np1) {
+        const double* ps = d.src_p + (int64_t)s * d.src_nv;
+        d.out_p[(B * d.S + s) * d.NP1 + k] = ps[dof[0]] * l0 + ps[dof[1]] * l1 + ps[dof[2]] * l2;
+      }
+    }
+    if (d.out_cell) d.out_cell[B * d.NP + k] = best;
+  }
+}
+
+}  // namespace mdq_mesh
+
+extern "C" int mdq_interpolate_snapshots(const mdq_interp_desc* d, void* stream) {
+  if (!d || d->B <= 0 || d->S <= 0 || d->NP <= 0) return mdq_set_error("mdq_interpolate_snapshots: bad arguments");
+  const int bx = (d->NP + 255) / 256;
+  hipLaunchKernelGGL(mdq_mesh::interpolate_kernel, dim3(bx, d->B), dim3(256), 0, (hipStream_t)stream, *d);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return mdq_set_error(hipGetErrorString(e));
+  return 0;
+}

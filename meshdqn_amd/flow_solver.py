@@ -120,19 +120,36 @@ class FlowSolver(object):
         topo = self.mesh.topology_
         self.removable = list(topo.removable())
         self.bnd_tags = topo.facet_tags()
+        n2, nv = topo.np2, topo.nv
+        self._light = None
         if reassemble:
             self.batch = IpcsBatch([topo], [topo.coords], mu=self.mu, rho=self.rho, dt=self.dt_value,
                                    rtol=self.rtol, device=self.device,
                                    pressure_direct=(self.solver_type == "lu"))
             self.batch.assemble()
-        n2, nv = topo.np2, topo.nv
-        self.u_n = Function(topo, self.batch.u_n[0, :n2] if reassemble else torch.zeros((n2, 2), dtype=torch.float64, device=self.device), "velocity")
-        self.p_n = Function(topo, self.batch.p_n[0, :nv] if reassemble else torch.zeros((nv,), dtype=torch.float64, device=self.device), "pressure")
+            self.u_n = Function(topo, self.batch.u_n[0, :n2], "velocity")
+            self.p_n = Function(topo, self.batch.p_n[0, :nv], "pressure")
+        else:
+            # training mode (DEPLOY False): the reference builds new spaces / zero functions / probes but
+            # does NOT re-assemble or re-factorise (flow_solver.py:268 `if(self.DEPLOY)`)
+            self.batch = None
+            self.u_n = Function(topo, torch.zeros((n2, 2), dtype=torch.float64, device=self.device), "velocity")
+            self.p_n = Function(topo, torch.zeros((nv,), dtype=torch.float64, device=self.device), "pressure")
         self.u_, self.p_ = self.u_n, self.p_n
         self.drag_probe = DragProbe(self.viscosity, None, self, tags=[1])
         self.lift_probe = LiftProbe(self.viscosity, None, self, tags=[1])
         self.accumulated_drag, self.accumulated_lift = [], []
         self.num_vertices = nv
+
+    def probe_batch(self):
+        """Device mesh data for the force probes on the current mesh."""
+        if self.batch is not None:
+            return self.batch
+        if self._light is None:
+            from .mesh_ops import LightMeshBatch
+            topo = self.mesh.topology_
+            self._light = LightMeshBatch([topo], [topo.coords], self.mu, device=self.device)
+        return self._light
 
     def mark_boundaries(self):
         """Tags of the exterior facets: 0 walls / 1 airfoil / 2 inflow / 3 outflow / 4 other
@@ -149,22 +166,15 @@ class FlowSolver(object):
         self.mesh = mesh
         if self.smooth:
             self.mesh.smooth(50)
+        self._setup(reassemble=self.DEPLOY)
         if self.DEPLOY:
-            self._setup(reassemble=True)
             self.gtime = 0.0
-        else:
-            # probes / functions follow the new mesh; the (unused in training) solver state is dropped
-            topo = self.mesh.topology_
-            self.batch = IpcsBatch([topo], [topo.coords], mu=self.mu, rho=self.rho, dt=self.dt_value,
-                                   rtol=self.rtol, device=self.device, pressure_direct=False)
-            self._setup(reassemble=False)
-            self.u_n = Function(topo, self.batch.u_n[0, :topo.np2], "velocity")
-            self.p_n = Function(topo, self.batch.p_n[0, :topo.nv], "pressure")
-            self.u_, self.p_ = self.u_n, self.p_n
 
     def evolve(self, nsteps: int = 1):
         """One IPCS time step (flow_solver.py:362-396); returns (u_, p_, drag, lift).
         `nsteps > 1` runs several steps in one kernel launch and returns the last values."""
+        if self.batch is None:
+            raise RuntimeError("operators are only (re-)assembled in DEPLOY mode after remesh (flow_solver.py:268)")
         drag, lift = self.batch.evolve(nsteps)
         self.gtime += self.dt_value * nsteps
         d = drag[0].tolist()

@@ -1,0 +1,186 @@
+"""Mesh-side device operations of the environment step (host wrappers over the C ABI).
+
+  * `LightMeshBatch`   - just enough of a mesh batch on the device for the force probes
+                         (`mdq_probe_forces`) on freshly coarsened meshes.
+  * `SnapshotInterpolator` - `Function.interpolate` of the stored snapshots from the ORIGINAL mesh
+                         onto coarsened meshes (`mdq_interpolate_snapshots`): uniform location grid
+                         built once on the host, point location + P2/P1 evaluation on the GPU.
+  * `remove_vertex_delaunay` - vertex removal + global re-triangulation exactly as the reference does it
+                         (`scipy.spatial.Delaunay` on the host, Env2DAirfoil.py:480-496).
+  * `polygon_distance`  - vectorised `shapely.Polygon.distance(Point)` for the N-closest ranking.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import numpy as np
+import torch
+from scipy.spatial import Delaunay
+
+from . import _lib
+from .topology import TAG_AIRFOIL, MeshTopology
+
+
+class LightMeshBatch:
+    def __init__(self, topos: Sequence[MeshTopology], coords: Sequence[np.ndarray], mu: float, device="cuda",
+                 capacities: dict | None = None):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.topos = list(topos)
+        B = len(self.topos)
+        afs = []
+        for t, x in zip(self.topos, coords):
+            tags = t.facet_tags(x)
+            af, _ = t.facets(tags, TAG_AIRFOIL)
+            afs.append(af)
+        cap = dict(NV=max(t.nv for t in topos), NT=max(t.nt for t in topos), NE=max(t.ne for t in topos),
+                   NAF=max(max(a.shape[0] for a in afs), 1))
+        if capacities:
+            for k, v in capacities.items():
+                cap[k] = max(cap[k], int(v))
+        self.cap, self.B = cap, B
+        NV, NT, NE, NAF = cap["NV"], cap["NT"], cap["NE"], cap["NAF"]
+        self.N2 = NV + NE
+        h_coords = np.zeros((B, NV, 2))
+        h_cd = np.zeros((B, 6, NT), np.int32)
+        h_af = np.zeros((B, NAF, 2), np.int32)
+        for b, (t, x, af) in enumerate(zip(self.topos, coords, afs)):
+            h_coords[b, :t.nv] = x
+            h_cd[b, :, :t.nt] = t.cell_dofs.T
+            h_af[b, :af.shape[0]] = af
+        dev = self.device
+        self.t = dict(coords=torch.from_numpy(h_coords).to(dev), cell_dofs=torch.from_numpy(h_cd).to(dev),
+                      af_facets=torch.from_numpy(h_af).to(dev),
+                      nv=torch.tensor([t.nv for t in topos], dtype=torch.int32, device=dev),
+                      nt=torch.tensor([t.nt for t in topos], dtype=torch.int32, device=dev),
+                      ne=torch.tensor([t.ne for t in topos], dtype=torch.int32, device=dev),
+                      naf=torch.tensor([a.shape[0] for a in afs], dtype=torch.int32, device=dev))
+        d = _lib.IpcsDesc()
+        d.B, d.NV, d.NT, d.NE, d.N2, d.NAF = B, NV, NT, NE, NV + NE, NAF
+        d.mu = float(mu)
+        for k, v in self.t.items():
+            setattr(d, k, v.data_ptr())
+        self.desc = d
+
+    def probe_forces(self, u: torch.Tensor, p: torch.Tensor, stream=None):
+        """u (B,F,N2,2), p (B,F,NV) -> drag, lift (B,F)."""
+        F = u.shape[1]
+        assert u.shape == (self.B, F, self.N2, 2) and p.shape == (self.B, F, self.cap["NV"]), (u.shape, p.shape)
+        u, p = u.contiguous(), p.contiguous()
+        drag = torch.empty((self.B, F), dtype=torch.float64, device=self.device)
+        lift = torch.empty_like(drag)
+        rc = self.lib.mdq_probe_forces(C.byref(self.desc), F, u.data_ptr(), p.data_ptr(), drag.data_ptr(),
+                                       lift.data_ptr(), _lib.stream_ptr(stream))
+        _lib.check(rc, "mdq_probe_forces")
+        return drag, lift
+
+
+class SnapshotInterpolator:
+    """Source = the original (smoothed) mesh with S stored snapshots; targets = coarsened meshes."""
+
+    def __init__(self, topo: MeshTopology, coords: np.ndarray, u_snap: torch.Tensor, p_snap: torch.Tensor,
+                 device="cuda", grid=(224, 64)):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.topo = topo
+        self.S = int(u_snap.shape[0])
+        assert u_snap.shape == (self.S, topo.np2, 2) and p_snap.shape == (self.S, topo.nv)
+        x = np.asarray(coords, np.float64)
+        X = x[topo.cells]  # (nt,3,2)
+        J00, J01 = X[:, 1, 0] - X[:, 0, 0], X[:, 2, 0] - X[:, 0, 0]
+        J10, J11 = X[:, 1, 1] - X[:, 0, 1], X[:, 2, 1] - X[:, 0, 1]
+        det = J00 * J11 - J01 * J10
+        geom = np.stack([J11 / det, -J01 / det, -J10 / det, J00 / det, np.abs(det)])
+        # uniform location grid: every bin lists (ascending) the cells whose bounding box touches it
+        gnx, gny = grid
+        lo, hi = x.min(axis=0), x.max(axis=0)
+        hx, hy = (hi[0] - lo[0]) / gnx, (hi[1] - lo[1]) / gny
+        bmin = np.floor((X.min(axis=1) - lo) / (hx, hy) - 1e-9).astype(int)
+        bmax = np.floor((X.max(axis=1) - lo) / (hx, hy) + 1e-9).astype(int)
+        bmin = np.clip(bmin, 0, (gnx - 1, gny - 1))
+        bmax = np.clip(bmax, 0, (gnx - 1, gny - 1))
+        lists = [[] for _ in range(gnx * gny)]
+        for c in range(topo.nt):
+            for gy in range(bmin[c, 1], bmax[c, 1] + 1):
+                base = gy * gnx
+                for gx in range(bmin[c, 0], bmax[c, 0] + 1):
+                    lists[base + gx].append(c)
+        cent = X.mean(axis=1)
+        for bidx, l in enumerate(lists):
+            if not l:  # bin inside the airfoil hole: nearest cell (extrapolation never really happens there)
+                gy, gx = divmod(bidx, gnx)
+                pc = lo + ((gx + 0.5) * hx, (gy + 0.5) * hy)
+                l.append(int(np.argmin(((cent - pc) ** 2).sum(axis=1))))
+        bin_ptr = np.zeros(gnx * gny + 1, np.int32)
+        bin_ptr[1:] = np.cumsum([len(l) for l in lists])
+        bin_cells = np.concatenate([np.asarray(l, np.int32) for l in lists])
+        dev = self.device
+        self.t = dict(src_coords=torch.from_numpy(x).to(dev),
+                      src_cell_dofs=torch.from_numpy(np.ascontiguousarray(topo.cell_dofs.T, np.int32)).to(dev),
+                      src_geom=torch.from_numpy(geom).to(dev), bin_ptr=torch.from_numpy(bin_ptr).to(dev),
+                      bin_cells=torch.from_numpy(bin_cells).to(dev),
+                      src_u=u_snap.to(dev, torch.float64).contiguous(), src_p=p_snap.to(dev, torch.float64).contiguous())
+        self.grid = (gnx, gny, float(lo[0]), float(lo[1]), 1.0 / hx, 1.0 / hy)
+
+    def interpolate(self, topos: Sequence[MeshTopology], coords: Sequence[np.ndarray], NP=None, NP1=None, stream=None):
+        """-> u (B,S,NP,2), p (B,S,NP1): snapshot values at every target's P2 dof points (vertices, then edge
+        midpoints in the target's edge numbering) / P1 points (vertices)."""
+        B = len(topos)
+        NP = NP or max(t.np2 for t in topos)
+        NP1 = NP1 or max(t.nv for t in topos)
+        pts = np.zeros((B, NP, 2))
+        for b, (t, x) in enumerate(zip(topos, coords)):
+            pts[b, :t.np2] = t.dof_coords(x)
+        dev = self.device
+        t_pts = torch.from_numpy(pts).to(dev)
+        npts = torch.tensor([t.np2 for t in topos], dtype=torch.int32, device=dev)
+        np1 = torch.tensor([t.nv for t in topos], dtype=torch.int32, device=dev)
+        out_u = torch.zeros((B, self.S, NP, 2), dtype=torch.float64, device=dev)
+        out_p = torch.zeros((B, self.S, NP1), dtype=torch.float64, device=dev)
+        d = _lib.InterpDesc()
+        d.B, d.S, d.NP, d.NP1 = B, self.S, NP, NP1
+        d.src_nv, d.src_nt, d.src_n2 = self.topo.nv, self.topo.nt, self.topo.np2
+        d.gnx, d.gny, d.x0, d.y0, d.inv_hx, d.inv_hy = self.grid
+        d.npts, d.np1, d.points = npts.data_ptr(), np1.data_ptr(), t_pts.data_ptr()
+        for k, v in self.t.items():
+            setattr(d, k, v.data_ptr())
+        d.out_u, d.out_p, d.out_cell = out_u.data_ptr(), out_p.data_ptr(), None
+        rc = self.lib.mdq_interpolate_snapshots(C.byref(d), _lib.stream_ptr(stream))
+        _lib.check(rc, "mdq_interpolate_snapshots")
+        return out_u, out_p
+
+
+def remove_vertex_delaunay(coords: np.ndarray, boundary_vertices: np.ndarray, idx: int):
+    """Env2DAirfoil.py:477-496: drop vertex `idx`, Delaunay-triangulate ALL remaining points (Qhull via
+    scipy, exactly the reference's call), drop the simplices made of boundary vertices only.
+    Returns (new_coords, new_cells); raises ValueError when Qhull cannot triangulate."""
+    bv = np.array(boundary_vertices, copy=True)
+    bv[bv > idx] -= 1
+    keep = np.ones(coords.shape[0], dtype=bool)
+    keep[idx] = False
+    new_coords = coords[keep]
+    tri = Delaunay(new_coords)
+    cells = tri.simplices
+    cells = cells[np.sum(np.isin(cells, bv), axis=1) != 3]
+    return new_coords, cells
+
+
+def polygon_distance(poly: np.ndarray, pts: np.ndarray) -> np.ndarray:
+    """`Polygon(poly).distance(Point(p))` for many points: 0 inside / on the ring, else the distance to the
+    nearest ring segment (closing segment included)."""
+    a = poly
+    b = np.roll(poly, -1, axis=0)
+    ab = b - a  # (m,2)
+    ap = pts[:, None, :] - a[None, :, :]  # (n,m,2)
+    t = np.clip((ap * ab[None]).sum(-1) / (ab * ab).sum(-1)[None], 0.0, 1.0)
+    q = a[None] + t[..., None] * ab[None]
+    dist = np.sqrt(((pts[:, None, :] - q) ** 2).sum(-1)).min(axis=1)
+    x, y = pts[:, 0:1], pts[:, 1:2]
+    x1, y1, x2, y2 = a[None, :, 0], a[None, :, 1], b[None, :, 0], b[None, :, 1]
+    cond = (y1 > y) != (y2 > y)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        xin = x1 + (y - y1) * (x2 - x1) / (y2 - y1)
+    inside = (np.where(cond, x < xin, False).sum(axis=1) % 2) == 1
+    dist[inside] = 0.0
+    return dist

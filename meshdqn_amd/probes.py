@@ -25,9 +25,7 @@ class _ForceProbe(object):
         self.dim = 2
 
     def _forces(self, u, p):
-        batch = self.ds.batch
-        if not batch.assembled:
-            batch.assemble()  # geometry (Jinv, |det|) is produced by the assembly kernel
+        batch = self.ds.probe_batch()
         N2, NV = batch.N2, batch.cap["NV"]
         ub = torch.zeros((1, 1, N2, 2), dtype=torch.float64, device=batch.device)
         pb = torch.zeros((1, 1, NV), dtype=torch.float64, device=batch.device)

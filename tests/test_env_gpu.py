@@ -1,0 +1,75 @@
+"""GPU parity: the reference-surface Env2DAirfoil (HIP interpolation / probes / smoothing) vs the oracle env."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+AGENT = dict(solver_steps=20, episodes=10, timesteps=10000, threshold=0.001, N_closest=180, gt_drag=-1, gt_time=-1,
+             u=-1, p=-1, time_reward=0.005, save_steps=4, goal_vertices=0.95, plot_dir="")
+
+
+def _config(mesh):
+    return dict(flow_config=dict(flow_params=dict(mu=1e-3, rho=1.0, inflow="constant"),
+                                 geometry_params=dict(mesh=os.path.join(GOLDEN, f"{mesh}.npz")),
+                                 solver_params=dict(dt=0.001, solver_type="lu", smooth=True, rtol=1e-12)),
+                agent_params=dict(AGENT))
+
+
+def _p2_to_oracle(u, n2):
+    a = u.vector().get_local().reshape(n2, 2)
+    return np.concatenate([a[:, 0], a[:, 1]])
+
+
+@pytest.mark.parametrize("mesh", ["ys930", "ah93w145"])
+def test_episode_matches_oracle(lib_built, meshes, mesh):
+    from meshdqn_amd.env import Env2DAirfoil
+    from oracle.env import OracleEnv
+    env = Env2DAirfoil(_config(mesh))
+    coords, cells = meshes[mesh]
+    ora = OracleEnv(coords, cells, AGENT)
+    # ground truth / snapshots of reset()
+    assert np.allclose(env.gt_drag, ora.gt_drag, rtol=1e-8, atol=0)
+    assert np.allclose(env.gt_lift, ora.gt_lift, rtol=1e-8, atol=0)
+    n2 = ora.orig_th.np2
+    for i in range(5):
+        uo = ora.original_u[i]
+        assert np.abs(_p2_to_oracle(env.original_u[i], n2) - uo).max() / np.abs(uo).max() < 1e-8
+    s, so = env.get_state(), ora.get_state()
+    assert s.x.shape == (180, 17) and s.x.dtype == torch.float32
+    assert np.array_equal(s.edge_index.numpy(), so["edge_index"])
+    assert np.allclose(s.x.numpy(), so["x"], rtol=1e-5, atol=1e-6)
+    assert np.array_equal(env.n_closest, ora.n_closest)       # bit-exact vertex ranking
+    rng = np.random.default_rng(1370)
+    for k in range(6):
+        a = int(rng.integers(0, 181)) if k != 2 else 180       # include one "do nothing" action
+        st, r, done, _ = env.step(a)
+        sto, ro, doneo, _ = ora.step(a)
+        assert done == doneo
+        assert env.coord_map == ora.coord_map                   # removed-vertex indices bit-exact
+        assert np.array_equal(env.n_closest, ora.n_closest)
+        assert np.array_equal(env.flow_solver.mesh.cells(), ora.flow.mesh.cells)
+        assert np.abs(env.flow_solver.mesh.coordinates() - ora.flow.mesh.coords).max() < 1e-12
+        assert np.array_equal(st.edge_index.numpy(), sto["edge_index"])
+        assert np.allclose(st.x.numpy(), sto["x"], rtol=1e-5, atol=1e-6)
+        assert np.allclose(st.edge_attr, sto["edge_attr"], rtol=1e-12)
+        if a != 180 or k > 0:
+            assert np.allclose(env.new_drags, ora.new_drags, rtol=1e-8)
+            assert np.allclose(env.new_lifts, ora.new_lifts, rtol=1e-8)
+        assert abs(r - ro) < 1e-6 * max(1.0, abs(ro))
+    # interpolated snapshots on the coarsened mesh
+    n2c = ora.cur_th.np2
+    for i in range(5):
+        uo = ora.u[i]
+        assert np.abs(_p2_to_oracle(env.u[i], n2c) - uo).max() / np.abs(uo).max() < 1e-8
+
+
+def test_bad_actions_follow_reference_error_codes(lib_built):
+    from meshdqn_amd.env import Env2DAirfoil
+    env = Env2DAirfoil(_config("ah93w145"))
+    env.get_state()
+    st, r, done, _ = env.step(9999)  # KeyError in coord_map -> code 2: reward -1, terminal
+    assert r == -1.0 and done is True
