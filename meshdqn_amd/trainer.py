@@ -1,0 +1,312 @@
+"""Data-parallel DQN trainer: the counterpart of the reference's Ray rollout / parameter-server loop
+(airfoil_dqn.py:46-67 replay, :151-340 parameter server + gradient worker, :428-503 rollout).
+
+MI355X-first re-design: one process per GPU (torchrun), every rank owns its
+environments, a replica of both Q-networks and a replay shard; per optimiser step ONE flat fp32
+all-reduce of the 173 493 gradients over RCCL (`torch.distributed`, backend "nccl"; "gloo" on CPU for
+the tests) replaces the parameter server, and an optional all-gather of fixed-size transition records
+replaces the central replay actor.  No Ray.
+
+Kept from the reference: Transition tuple, ring replay of 10 000, epsilon schedule
+0.01 + 0.99 exp(-t/10000) per worker, double DQN with the selected net toggled every `target_update`
+gradient applications, Huber loss, gamma, Adam(lr 1e-5, wd 1e-6) + MultiStepLR[5e5,1e6,1.5e6] x0.1,
+softmax outputs used as Q-values.  Deliberately NOT kept (bugs of the published script):
+the Adam optimiser is persistent per network instead of being re-created on every call, and
+`optimizer.step()` runs after the new gradients are set, not before (airfoil_dqn.py:188-199).
+"""
+from __future__ import annotations
+
+import math
+import os
+import random
+from collections import namedtuple
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .airfoilgcnn import NodeRemovalNet
+from .data import Batch, Data
+
+Transition = namedtuple("Transition", ("state", "action", "next_state", "reward"))
+
+
+class ReplayMemory(object):
+    """airfoil_dqn.py:48-67 (without the Ray actor)."""
+
+    def __init__(self, capacity):
+        self.capacity = capacity
+        self.memory = []
+        self.position = 0
+
+    def push(self, *args):
+        if len(self.memory) < self.capacity:
+            self.memory.append(None)
+        self.memory[self.position] = Transition(*args)
+        self.position = (self.position + 1) % self.capacity
+
+    def sample(self, batch_size):
+        return random.sample(self.memory, batch_size)
+
+    def size(self):
+        return len(self.memory)
+
+    __len__ = size
+
+
+def epsilon_threshold(steps_done, start=1.0, end=0.01, decay=10000):
+    """airfoil_dqn.py:455."""
+    return end + (start - end) * math.exp(-steps_done / decay)
+
+
+# ---------------------------------------------------------------------------- distributed helpers
+
+class DistContext:
+    """Process-group plumbing: rank / world from the torchrun environment, RCCL on GPUs, gloo on CPU."""
+
+    def __init__(self, backend: Optional[str] = None, device: Optional[torch.device] = None):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if device is None:
+            device = torch.device("cuda", self.local_rank) if torch.cuda.is_available() else torch.device("cpu")
+        self.device = device
+        self.owns_group = False
+        if self.world > 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            backend = backend or ("nccl" if device.type == "cuda" else "gloo")
+            if device.type == "cuda":
+                torch.cuda.set_device(device)
+                dist.init_process_group(backend, device_id=device)
+            else:
+                dist.init_process_group(backend)
+            self.owns_group = True
+
+    def shard(self, n_total: int):
+        """Contiguous block of environment ids owned by this rank (env id -> rank = id // (n/world))."""
+        per = n_total // self.world
+        extra = n_total % self.world
+        lo = self.rank * per + min(self.rank, extra)
+        return range(lo, lo + per + (1 if self.rank < extra else 0))
+
+    def allreduce_mean_(self, flat: torch.Tensor) -> torch.Tensor:
+        if self.world > 1:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            flat /= self.world
+        return flat
+
+    def max_over_ranks(self, value: float) -> float:
+        if self.world == 1:
+            return value
+        t = torch.tensor([value], dtype=torch.float64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier()
+
+    def close(self):
+        if self.owns_group and dist.is_initialized():
+            dist.destroy_process_group()
+
+
+# fixed-size transition record for the replay all-gather: x (N,F) f32 twice,
+# edge_index padded to E_MAX int32 twice, edge counts, action, reward, done
+def pack_transitions(trs: List[Transition], n_nodes: int, n_feat: int, e_max: int) -> torch.Tensor:
+    rec = 2 * n_nodes * n_feat + 2 * 2 * e_max + 5
+    out = torch.zeros((len(trs), rec), dtype=torch.float32)
+    for i, t in enumerate(trs):
+        off = 0
+        for s in (t.state, t.next_state):
+            if s is not None:
+                out[i, off:off + n_nodes * n_feat] = s.x.reshape(-1).float().cpu()
+            off += n_nodes * n_feat
+        for s in (t.state, t.next_state):
+            if s is not None:
+                e = s.edge_index.shape[1]
+                if e > e_max:
+                    raise ValueError(f"edge count {e} exceeds e_max {e_max}")
+                out[i, off:off + e] = s.edge_index[0].float().cpu()
+                out[i, off + e_max:off + e_max + e] = s.edge_index[1].float().cpu()
+            off += 2 * e_max
+        out[i, off] = t.state.edge_index.shape[1]
+        out[i, off + 1] = t.next_state.edge_index.shape[1] if t.next_state is not None else 0
+        out[i, off + 2] = float(t.action.item() if torch.is_tensor(t.action) else t.action)
+        out[i, off + 3] = float(t.reward.item() if torch.is_tensor(t.reward) else t.reward)
+        out[i, off + 4] = 0.0 if t.next_state is not None else 1.0
+    return out
+
+
+def unpack_transitions(rec: torch.Tensor, n_nodes: int, n_feat: int, e_max: int) -> List[Transition]:
+    out = []
+    nf = n_nodes * n_feat
+    for r in rec.cpu():
+        off = 2 * nf + 4 * e_max
+        e0, e1 = int(r[off].item()), int(r[off + 1].item())
+        done = r[off + 4].item() > 0.5
+
+        def graph(k, e):
+            x = r[k * nf:(k + 1) * nf].reshape(n_nodes, n_feat).clone()
+            base = 2 * nf + k * 2 * e_max
+            ei = torch.stack([r[base:base + e], r[base + e_max:base + e_max + e]]).long()
+            return Data(x=x, edge_index=ei, edge_attr=[])
+        s = graph(0, e0)
+        ns = None if done else graph(1, e1)
+        out.append(Transition(s, torch.tensor([[int(r[off + 2].item())]]), ns, torch.tensor([r[off + 3].item()])))
+    return out
+
+
+def allgather_transitions(ctx: DistContext, trs: List[Transition], n_nodes: int, n_feat: int, e_max: int):
+    """All ranks contribute the same number of transitions per call (one per environment step)."""
+    rec = pack_transitions(trs, n_nodes, n_feat, e_max).to(ctx.device)
+    if ctx.world == 1:
+        return unpack_transitions(rec, n_nodes, n_feat, e_max)
+    bufs = [torch.empty_like(rec) for _ in range(ctx.world)]
+    dist.all_gather(bufs, rec)
+    return unpack_transitions(torch.cat(bufs), n_nodes, n_feat, e_max)
+
+
+# ---------------------------------------------------------------------------- trainer
+
+class DQNTrainer:
+    def __init__(self, n_actions: int, num_inputs: int, ctx: Optional[DistContext] = None, lr=1e-5, weight_decay=1e-6,
+                 batch_size=32, gamma=1.0, target_update=50, replay_capacity=10000, conv_width=128, topk=0.1,
+                 seed=1370):
+        self.ctx = ctx or DistContext()
+        dev = self.ctx.device
+        torch.manual_seed(seed)  # identical initial replicas on every rank (airfoil_dqn.py:28-32)
+        self.policy_net_1 = NodeRemovalNet(n_actions + 1, conv_width=conv_width, topk=topk).float()
+        self.policy_net_2 = NodeRemovalNet(n_actions + 1, conv_width=conv_width, topk=topk).float()
+        self.policy_net_1.set_num_nodes(num_inputs)
+        self.policy_net_2.set_num_nodes(num_inputs)
+        self.policy_net_1.to(dev)
+        self.policy_net_2.to(dev)
+        self.n_actions, self.batch_size, self.gamma, self.target_update = n_actions, batch_size, gamma, target_update
+        self.opts = [torch.optim.Adam(n.parameters(), lr=lr, weight_decay=weight_decay)
+                     for n in (self.policy_net_1, self.policy_net_2)]
+        self.scheds = [torch.optim.lr_scheduler.MultiStepLR(o, milestones=[500000, 1000000, 1500000], gamma=0.1)
+                       for o in self.opts]
+        self.memory = ReplayMemory(replay_capacity)
+        self.criterion = torch.nn.HuberLoss()
+        self.num_grads = 0
+        self.select = True
+        self.losses: List[float] = []
+        random.seed(seed + self.ctx.rank)
+        np.random.seed(seed + self.ctx.rank)
+
+    # --- acting -------------------------------------------------------------
+    @torch.no_grad()
+    def select_action(self, state: Data, fused: Optional[bool] = None) -> int:
+        """Greedy action of policy_net_1 (airfoil_dqn.py:208-209); fused HIP forward on a GPU."""
+        dev = self.ctx.device
+        if fused is None:
+            fused = dev.type == "cuda"
+        st = state.to(dev)
+        q = self.policy_net_1.forward_fused(st) if fused else self.policy_net_1(st)
+        return int(q.argmax().item())
+
+    # --- learning -----------------------------------------------------------
+    def _loss(self, transitions: List[Transition]):
+        dev = self.ctx.device
+        batch = Transition(*zip(*transitions))
+        non_final_mask = torch.tensor([s is not None for s in batch.next_state], dtype=torch.bool, device=dev)
+        non_final_next = [s for s in batch.next_state if s is not None]
+        action_batch = torch.cat([a.reshape(1, 1) for a in batch.action]).to(dev)
+        reward_batch = torch.cat([r.reshape(1) for r in batch.reward]).to(dev).float()
+        net_a, net_b = (self.policy_net_1, self.policy_net_2)
+        states = Batch.from_data_list([s.to(dev) for s in batch.state])
+        if self.select:
+            out = net_a(states)
+        else:
+            with torch.no_grad():
+                out = net_a(states)
+        q_sa = out.gather(1, action_batch).squeeze(1)
+        next_vals = torch.zeros(len(transitions), device=dev)
+        if non_final_next:
+            nb = Batch.from_data_list([s.to(dev) for s in non_final_next])
+            if self.select:
+                with torch.no_grad():
+                    nv = net_b(nb).max(1)[0].float()
+            else:
+                nv = net_b(nb).max(1)[0].float()
+            next_vals[non_final_mask] = nv
+        expected = next_vals * self.gamma + reward_batch
+        return self.criterion(q_sa.float(), expected.float())
+
+    def optimize(self, transitions: Optional[List[Transition]] = None):
+        """One optimiser step (airfoil_dqn.py:315-340 + :184-200 + :286-310): local loss/backward, ONE flat
+        all-reduce of the gradient over all ranks, identical Adam step on every rank."""
+        if transitions is None:
+            if self.memory.size() < self.batch_size:
+                return None
+            transitions = self.memory.sample(self.batch_size)
+        if (self.num_grads % self.target_update) == 0:
+            self.select = not self.select
+        k = 0 if self.select else 1
+        net = (self.policy_net_1, self.policy_net_2)[k]
+        net.zero_grad(set_to_none=True)
+        loss = self._loss(transitions)
+        loss.backward()
+        flat = net.flat_gradients()
+        self.ctx.allreduce_mean_(flat)
+        net.set_flat_gradients(flat)
+        self.opts[k].step()
+        self.scheds[k].step()
+        self.num_grads += 1
+        self.losses.append(float(loss.item()))
+        return self.losses[-1]
+
+    def state_dicts(self):
+        return self.policy_net_1.state_dict(), self.policy_net_2.state_dict()
+
+    def save(self, save_dir, prefix=""):
+        """`ParameterServer.write` (airfoil_dqn.py:214-218): PyG-keyed state dicts."""
+        os.makedirs(save_dir, exist_ok=True)
+        torch.save(self.policy_net_1.state_dict(), os.path.join(save_dir, f"{prefix}policy_net_1.pt"))
+        torch.save(self.policy_net_2.state_dict(), os.path.join(save_dir, f"{prefix}policy_net_2.pt"))
+
+
+def train_loop_per_worker(trainer: DQNTrainer, env_factory, num_episodes: int, max_steps: Optional[int] = None,
+                          eps_decay=10000, eps_start=1.0, eps_end=0.01, share_replay=False, e_max=1024):
+    """Rollout loop of one rank (airfoil_dqn.py:428-503): epsilon-greedy over N_closest+1 actions, push the
+    transition, optimise, rebuild the env every episode.  Returns per-episode reward lists."""
+    ctx = trainer.ctx
+    n_actions = trainer.n_actions
+    steps_done = 0
+    env = env_factory()
+    history = []
+    total = 0
+    for episode in range(num_episodes):
+        if episode != 0:
+            env = env_factory()
+        state = env.get_state()
+        ep_rewards, ep_actions = [], []
+        while True:
+            sample = np.random.random()
+            eps = epsilon_threshold(steps_done, eps_start, eps_end, eps_decay)
+            steps_done += 1
+            if sample > eps:
+                action = trainer.select_action(state)
+            else:
+                action = random.sample(range(n_actions + 1), 1)[0]
+            next_state, reward, done, _ = env.step(action)
+            ep_rewards.append(reward)
+            ep_actions.append(action)
+            tr = Transition(state, torch.tensor([[action]], dtype=torch.long), None if done else next_state,
+                            torch.tensor([reward], dtype=torch.float32))
+            if share_replay and ctx.world > 1:
+                for t in allgather_transitions(ctx, [tr], state.x.shape[0], state.x.shape[1], e_max):
+                    trainer.memory.push(*t)
+            else:
+                trainer.memory.push(*tr)
+            state = next_state
+            trainer.optimize()
+            total += 1
+            if done or (max_steps is not None and total >= max_steps):
+                break
+        history.append((ep_rewards, ep_actions))
+        if max_steps is not None and total >= max_steps:
+            break
+    return history

@@ -1,0 +1,131 @@
+"""CPU tests of the data-parallel trainer: world_size-2 gloo gradient all-reduce, replay all-gather,
+environment sharding, epsilon schedule, double-DQN bookkeeping."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from meshdqn_amd.data import Data
+from meshdqn_amd.trainer import (DQNTrainer, DistContext, ReplayMemory, Transition, allgather_transitions,
+                                 epsilon_threshold, pack_transitions, unpack_transitions)
+
+
+def _state(rng, n=180, f=17, e=372):
+    return Data(x=torch.from_numpy(rng.standard_normal((n, f))).float(),
+                edge_index=torch.from_numpy(rng.integers(0, n, size=(2, e))).long(), edge_attr=[])
+
+
+def _transitions(seed, count=8):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(count):
+        done = (i % 4 == 3)
+        out.append(Transition(_state(rng), torch.tensor([[int(rng.integers(0, 181))]]), None if done else _state(rng),
+                              torch.tensor([float(rng.standard_normal())])))
+    return out
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    ctx = DistContext(backend="gloo", device=torch.device("cpu"))
+    tr = DQNTrainer(180, 17, ctx=ctx, lr=1e-3, target_update=2)
+    p0 = tr.policy_net_2.flat_gradients().numel()
+    w0 = torch.cat([p.detach().reshape(-1) for p in tr.policy_net_1.parameters()]).clone()
+    losses = []
+    for step in range(3):
+        losses.append(tr.optimize(_transitions(100 * step + rank)))
+    w1 = torch.cat([p.detach().reshape(-1) for p in tr.policy_net_1.parameters()])
+    w2 = torch.cat([p.detach().reshape(-1) for p in tr.policy_net_2.parameters()])
+    # replay all-gather of one transition per rank
+    got = allgather_transitions(ctx, _transitions(7 + rank, 1), 180, 17, 512)
+    shard = list(ctx.shard(11))
+    tmax = ctx.max_over_ranks(1.0 + rank)
+    q.put((rank, p0, w0.numpy(), w1.numpy(), w2.numpy(), losses, len(got), float(got[1].state.x.sum()), shard, tmax,
+           tr.select, tr.num_grads))
+    ctx.barrier()
+    ctx.close()
+
+
+def test_two_rank_gloo_allreduce_and_gather():
+    world, port = 2, _free_port()
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    procs = [ctxm.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    r0, r1 = res
+    assert r0[1] == 173493
+    # replicas start identical, stay identical after 3 all-reduced steps, and did move
+    assert np.array_equal(r0[2], r1[2])
+    assert np.array_equal(r0[3], r1[3]) and np.array_equal(r0[4], r1[4])
+    assert not np.array_equal(r0[2], r0[3])
+    # the ranks saw different data (different local losses) - only the all-reduce keeps them in sync
+    assert r0[5] != r1[5]
+    assert r0[6] == r1[6] == 2
+    exp = float(_transitions(8, 1)[0].state.x.sum())
+    assert abs(r0[7] - exp) < 1e-3 and abs(r1[7] - exp) < 1e-3
+    assert r0[8] == [0, 1, 2, 3, 4, 5] and r1[8] == [6, 7, 8, 9, 10]
+    assert r0[9] == r1[9] == 2.0
+    assert r0[10] == r1[10] and r0[11] == r1[11] == 3
+
+
+def test_allreduced_gradient_is_the_rank_mean():
+    """Single process check of what the 2-rank run must produce: averaging the two local gradients."""
+    torch.manual_seed(0)
+    tr = DQNTrainer(180, 17, ctx=DistContext(device=torch.device("cpu")), lr=1e-3)
+    grads = []
+    for rank in range(2):
+        tr.select = True
+        tr.policy_net_1.zero_grad(set_to_none=True)
+        tr._loss(_transitions(rank)).backward()
+        grads.append(tr.policy_net_1.flat_gradients().clone())
+    mean = 0.5 * (grads[0] + grads[1])
+    tr.policy_net_1.set_flat_gradients(mean)
+    assert torch.allclose(tr.policy_net_1.flat_gradients(), mean)
+    assert mean.abs().sum() > 0
+
+
+def test_transition_pack_roundtrip_and_replay_ring():
+    trs = _transitions(3, 6)
+    rec = pack_transitions(trs, 180, 17, 512)
+    assert rec.shape == (6, 2 * 180 * 17 + 4 * 512 + 5)
+    back = unpack_transitions(rec, 180, 17, 512)
+    for a, b in zip(trs, back):
+        assert torch.equal(a.state.x, b.state.x) and torch.equal(a.state.edge_index, b.state.edge_index)
+        assert (a.next_state is None) == (b.next_state is None)
+        if a.next_state is not None:
+            assert torch.equal(a.next_state.edge_index, b.next_state.edge_index)
+        assert int(a.action) == int(b.action) and abs(float(a.reward) - float(b.reward)) < 1e-6
+    mem = ReplayMemory(4)
+    for i in range(6):
+        mem.push(i, i, i, i)
+    assert mem.size() == 4 and sorted(t.state for t in mem.memory) == [2, 3, 4, 5]
+    assert len(mem.sample(3)) == 3
+    assert abs(epsilon_threshold(0) - 1.0) < 1e-12 and abs(epsilon_threshold(10000) - (0.01 + 0.99 / np.e)) < 1e-12
+
+
+def test_double_dqn_select_toggles_every_target_update():
+    tr = DQNTrainer(180, 17, ctx=DistContext(device=torch.device("cpu")), target_update=2)
+    seen = []
+    for i in range(5):
+        tr.optimize(_transitions(i, 4))
+        seen.append(tr.select)
+    # toggled when num_grads % 2 == 0 BEFORE the step (airfoil_dqn.py:185-186), starting from True
+    assert seen == [False, False, True, True, False]
