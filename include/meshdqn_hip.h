@@ -96,6 +96,16 @@ typedef struct mdq_ipcs_desc {
   const uint8_t* bcu_flag;     /* [B][N2]  1 = velocity dof constrained (both components) */
   const double* bcu_gx;        /* [B][N2]  x-velocity value (y value is 0)    */
   const uint8_t* bcp_flag;     /* [B][NV]  1 = pressure dof constrained to 0  */
+  /* outflow-facet term of F1 (`- dot(mu*nabla_grad(U)*n, v)*ds`, flow_solver.py:109) as a tiny row list
+     for the matrix-free mode 3: row r owns entries [bo_ptr[t], bo_ptr[t+1]) with 2x2 blocks
+     B^{cd} = int_facet phi_r (d_c phi_col) n_d ds; values written by mdq_ipcs_assemble */
+  int32_t NBO, NBE;            /* capacities: outflow rows, entries                 */
+  const int32_t* nbo;          /* device [B]  number of outflow rows                */
+  const int32_t* bo_rows;      /* device [B][NBO]   P2 dof of the row               */
+  const int32_t* bo_ptr;       /* device [B][NBO+1]                                 */
+  const int32_t* bo_col;       /* device [B][NBE]   P2 dof of the column            */
+  const int32_t* bo_src;       /* device [B][NBE]   cell*36 + i*6 + j (local test / trial index) */
+  double* bo_val;              /* device [B][NBE][4] (out) xx, xy, yx, yy           */
   /* direct (substructured) pressure solver, written by the host after assembly
      (meshdqn_amd/pressure_direct.py; replaces the reference's MUMPS factorisation of A2,
      flow_solver.py:150-159).  pd_enabled = 0 -> Jacobi-CG on the SELL operator instead. */

@@ -35,6 +35,9 @@ class IpcsDesc(C.Structure):
         ("mf_scat", C.c_void_p), ("mf_tptr", C.c_void_p),
         ("g2_ptr", C.c_void_p), ("g2_src", C.c_void_p), ("g1_ptr", C.c_void_p), ("g1_src", C.c_void_p),
         ("bcu_flag", C.c_void_p), ("bcu_gx", C.c_void_p), ("bcp_flag", C.c_void_p),
+        ("NBO", C.c_int32), ("NBE", C.c_int32),
+        ("nbo", C.c_void_p), ("bo_rows", C.c_void_p), ("bo_ptr", C.c_void_p), ("bo_col", C.c_void_p),
+        ("bo_src", C.c_void_p), ("bo_val", C.c_void_p),
         ("pd_enabled", C.c_int32), ("NPART", C.c_int32), ("NPW", C.c_int32), ("NPF", C.c_int32),
         ("NPGI", C.c_int32), ("NPS", C.c_int32), ("NPGK", C.c_int32), ("_pad1", C.c_int32),
         ("pd_hdr", C.c_void_p), ("pd_node", C.c_void_p), ("pd_meta", C.c_void_p), ("pd_rowblk", C.c_void_p),

@@ -53,6 +53,9 @@ struct EnvView {
   const double* bcu_gx;
   const uint8_t* bcp_flag;
   const int32_t* af_facets;
+  int nbo;
+  const int32_t *bo_rows, *bo_ptr, *bo_col, *bo_src;
+  double* bo_val;
   double* geom;  // [5][NT]
   double* A1;    // SELL [entries][4]
   double* Ms;
@@ -105,6 +108,12 @@ __device__ __forceinline__ EnvView env_view(const mdq_ipcs_desc& d, int b) {
   v.bcu_gx = d.bcu_gx + B * d.N2;
   v.bcp_flag = d.bcp_flag + B * d.NV;
   v.af_facets = d.af_facets + B * d.NAF * 2;
+  v.nbo = d.nbo ? d.nbo[b] : 0;
+  v.bo_rows = d.bo_rows + B * d.NBO;
+  v.bo_ptr = d.bo_ptr + B * (d.NBO + 1);
+  v.bo_col = d.bo_col + B * d.NBE;
+  v.bo_src = d.bo_src + B * d.NBE;
+  v.bo_val = d.bo_val + B * d.NBE * 4;
   v.geom = d.geom + B * 5 * d.NT;
   v.A1 = d.A1 + B * d.NSE2 * 4;
   v.Ms = d.Ms + B * d.NSE2;
@@ -277,6 +286,18 @@ __global__ __launch_bounds__(WG) void assemble_kernel(mdq_ipcs_desc d) {
       kk += 0.5 * g.det * (dix * djx + diy * djy);
     }
     v.K1s[pos1(row, k - v.rowptr1[row])] = kk;
+  }
+  // outflow row list of the matrix-free mode 3 (same facet integrals as above, kept separate)
+  if (v.nbo > 0) {
+    const int nbe = v.bo_ptr[v.nbo];
+    for (int t = tid; t < nbe; t += WG) {
+      const int slot = v.bo_src[t];
+      const int e = slot / 36, ij = slot - e * 36, i = ij / 6, j = ij - i * 6;
+      const Geo g = load_geo(v, e);
+      double Bcd[2][2];
+      outflow_entry(v, e, v.cell_outflow[e], i, j, g, Bcd);
+      reinterpret_cast<double4*>(v.bo_val)[t] = make_double4(Bcd[0][0], Bcd[0][1], Bcd[1][0], Bcd[1][1]);
+    }
   }
   __syncthreads();
 
@@ -1758,43 +1779,98 @@ __device__ __forceinline__ void at_prefetch(const EnvView& v, AtMeta& m, int rou
 
 // Y[dof] += element results for every triangle (Y zeroed and published by the caller).
 // op(e, geo, dofs, outflow_edge, ye).  On entry m holds round 0; on exit again (rolling prefetch).
-template <class ElemOp>
+// INTERLEAVE = true computes the AT_PAIR triangles of a round side by side (FP64 ILP for the hot
+// operator applications); false runs them one after the other (register-hungry right-hand sides).
+template <bool INTERLEAVE, class ElemOp>
 __device__ __forceinline__ void atomic_accumulate(const EnvView& v, double* Yd, AtMeta& m, ElemOp op) {
   const int nrounds = (v.nt + AT_PAIR * WG - 1) / (AT_PAIR * WG);
-#ifdef MDQ_PROFILE
-  long long tq = __builtin_amdgcn_s_memtime();
-#define MDQ_ASTAMP(k) { __builtin_amdgcn_s_waitcnt(0xC07F); long long tn = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) v.sprof[k] += tn - tq; tq = tn; }
-#else
-#define MDQ_ASTAMP(k)
-#endif
   for (int round = 0; round < nrounds; ++round) {
-    double2 ye[AT_PAIR][6];
-    int dof[AT_PAIR][6];
+    if (INTERLEAVE) {
+      double2 ye[AT_PAIR][6];
+      int dof[AT_PAIR][6];
 #pragma unroll
-    for (int j = 0; j < AT_PAIR; ++j) {
-      const int e = threadIdx.x + (round * AT_PAIR + j) * WG;
-      if (e < v.nt) {
-        ElemIdx E;
+      for (int j = 0; j < AT_PAIR; ++j) {
+        const int e = threadIdx.x + (round * AT_PAIR + j) * WG;
+        if (e < v.nt) {
+          ElemIdx E;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) E.dof[i] = dof[j][i] = m.w[j][i] & 0xFFF;
-        op(e, m.g[j], E, ((m.w[j][0] >> 28) & 3) - 1, ye[j]);
+          for (int i = 0; i < 6; ++i) E.dof[i] = dof[j][i] = m.w[j][i] & 0xFFF;
+          op(e, m.g[j], E, ((m.w[j][0] >> 28) & 3) - 1, ye[j]);
+        }
       }
-    }
-    MDQ_ASTAMP(0)
 #pragma unroll
-    for (int j = 0; j < AT_PAIR; ++j) {
-      const int e = threadIdx.x + (round * AT_PAIR + j) * WG;
-      if (e < v.nt) {
+      for (int j = 0; j < AT_PAIR; ++j) {
+        const int e = threadIdx.x + (round * AT_PAIR + j) * WG;
+        if (e < v.nt) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          unsafeAtomicAdd(Yd + 2 * dof[j][i], ye[j][i].x);
-          unsafeAtomicAdd(Yd + 2 * dof[j][i] + 1, ye[j][i].y);
+          for (int i = 0; i < 6; ++i) {
+            unsafeAtomicAdd(Yd + 2 * dof[j][i], ye[j][i].x);
+            unsafeAtomicAdd(Yd + 2 * dof[j][i] + 1, ye[j][i].y);
+          }
+        }
+      }
+    } else {
+#pragma unroll 1
+      for (int j = 0; j < AT_PAIR; ++j) {
+        const int e = threadIdx.x + (round * AT_PAIR + j) * WG;
+        if (e < v.nt) {
+          ElemIdx E;
+          double2 ye[6];
+          const int* wj = j == 0 ? m.w[0] : m.w[1];
+          const Geo gj = j == 0 ? m.g[0] : m.g[1];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) E.dof[i] = wj[i] & 0xFFF;
+          op(e, gj, E, ((wj[0] >> 28) & 3) - 1, ye);
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            unsafeAtomicAdd(Yd + 2 * E.dof[i], ye[i].x);
+            unsafeAtomicAdd(Yd + 2 * E.dof[i] + 1, ye[i].y);
+          }
         }
       }
     }
-    MDQ_ASTAMP(1)
     at_prefetch(v, m, round + 1 < nrounds ? round + 1 : 0);
-    MDQ_ASTAMP(2)
+  }
+}
+
+// Outflow rows owned by this thread (row % WG == tid): at most BO_OWN of them, found once per launch.
+constexpr int BO_OWN = 2;
+struct BoOwn {
+  int t[BO_OWN];
+};
+__device__ __forceinline__ BoOwn outflow_rows_owned(const EnvView& v) {
+  BoOwn o;
+#pragma unroll
+  for (int q = 0; q < BO_OWN; ++q) o.t[q] = -1;
+  for (int t = 0; t < v.nbo; ++t) {
+    if ((v.bo_rows[t] % WG) == (int)threadIdx.x) {
+      if (o.t[0] < 0) o.t[0] = t;
+      else o.t[1] = t;  // (a third owned row cannot occur: outflow rows are < 2*WG apart in practice; checked on the host)
+    }
+  }
+  return o;
+}
+
+// Y[row] += coef * sum_entries B x[col] for the outflow rows owned by this thread.
+// Called between the barrier that completes the atomic accumulation and the owner's read of Y;
+// x must not be modified by other threads before the next barrier.
+__device__ __forceinline__ void outflow_rows_add(const EnvView& v, const BoOwn& own, double coef, const double2* x,
+                                                 double2* Y) {
+#pragma unroll
+  for (int q = 0; q < BO_OWN; ++q) {
+    const int t = own.t[q];
+    if (t >= 0) {
+      const int row = v.bo_rows[t];
+      double sx = 0.0, sy = 0.0;
+      for (int k = v.bo_ptr[t]; k < v.bo_ptr[t + 1]; ++k) {
+        const double4 bv = reinterpret_cast<const double4*>(v.bo_val)[k];
+        const double2 xc = x[v.bo_col[k]];
+        sx += bv.x * xc.x + bv.y * xc.y;
+        sy += bv.z * xc.x + bv.w * xc.y;
+      }
+      const double2 y = Y[row];
+      Y[row] = make_double2(y.x + coef * sx, y.y + coef * sy);
+    }
   }
 }
 
@@ -1840,6 +1916,7 @@ __global__ __launch_bounds__(WG) void evolve_at_kernel(mdq_ipcs_desc d, int nste
 #endif
   AtMeta tm;
   at_prefetch(v, tm, 0);
+  const BoOwn bo_own = outflow_rows_owned(v);
 
   int it_u = 0, it_p = 0, it_m = 0;
   int rsel = 0;  // parity of the one-barrier reductions
@@ -1869,7 +1946,7 @@ __global__ __launch_bounds__(WG) void evolve_at_kernel(mdq_ipcs_desc d, int nste
     {
       const double2* un = v.u_n;
       const double* pn = v.p_n;
-      atomic_accumulate(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
+      atomic_accumulate<false>(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
         double2 ue[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) ue[i] = un[E.dof[i]];
@@ -1877,14 +1954,10 @@ __global__ __launch_bounds__(WG) void evolve_at_kernel(mdq_ipcs_desc d, int nste
 #pragma unroll
         for (int i = 0; i < 3; ++i) pe[i] = pn[E.dof[i]];
         elem_rhs1_vol(g, a, mu, d.rho, ue, pe, ye);
-        if (ko >= 0) {
-          double X[3][2];
-          load_cell_coords(v, e, X);
-          elem_outflow_add(g, X, ko, 0.5 * mu, ue, ye);
-        }
       });
     }
     __syncthreads();
+    outflow_rows_add(v, bo_own, 0.5 * mu, v.u_n, Yl);  // + mu/2 <nabla_grad(u_n) n, v> on the outflow rows
     MDQ_STAMP(0)
     double acc[2] = {0.0, 0.0};
     double2 f[MF_ROWS];
@@ -1906,13 +1979,14 @@ __global__ __launch_bounds__(WG) void evolve_at_kernel(mdq_ipcs_desc d, int nste
       }
     }
     __syncthreads();
-    atomic_accumulate(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
+    atomic_accumulate<true>(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
       double2 xe[6];
 #pragma unroll
       for (int i = 0; i < 6; ++i) xe[i] = Pl[E.dof[i]];
-      velocity_op(v, a, mu, e, ko, g, xe, ye);
+      elem_velocity(g, a, mu, xe, ye);
     });
     __syncthreads();
+    outflow_rows_add(v, bo_own, -0.5 * mu, Pl, Yl);
     double2 vv[MF_ROWS];
 #pragma unroll
     for (int k = 0; k < MF_ROWS; ++k) {
@@ -1923,11 +1997,16 @@ __global__ __launch_bounds__(WG) void evolve_at_kernel(mdq_ipcs_desc d, int nste
         // r0 = D^-1 (f - A_full x0) on free rows, 0 on constrained rows (idg = 0 there)
         const double2 r0 = make_double2((f[k].x - ax.x) * idg[k].x, (f[k].y - ax.y) * idg[k].y);
         Rl[row] = r0;
-        Pl[row] = make_double2(0.0, 0.0);
         acc[1] += r0.x * r0.x + r0.y * r0.y;
       }
     }
     block_sum<2>(acc, red);
+    // p = 0 (only now: the outflow rows above still gathered x0 from Pl until the barriers of the reduction)
+#pragma unroll
+    for (int k = 0; k < MF_ROWS; ++k) {
+      const int row = tid + k * WG;
+      if (row < n2) Pl[row] = make_double2(0.0, 0.0);
+    }
     MDQ_STAMP(1)
     {
       const double bb = acc[0], tol2 = d.rtol * d.rtol * bb;
@@ -1971,15 +2050,16 @@ __global__ __launch_bounds__(WG) void evolve_at_kernel(mdq_ipcs_desc d, int nste
           }
           __syncthreads();
           MDQ_BSTAMP(8)
-          atomic_accumulate(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
+          atomic_accumulate<true>(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
             double2 xe[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) xe[i] = Pl[E.dof[i]];
-            velocity_op(v, a, mu, e, ko, g, xe, ye);
+            elem_velocity(g, a, mu, xe, ye);
           });
           MDQ_BSTAMP(9)
           __syncthreads();
           MDQ_BSTAMP(10)
+          outflow_rows_add(v, bo_own, -0.5 * mu, Pl, Yl);
           double a1[1] = {0.0};
 #pragma unroll
           for (int k = 0; k < MF_ROWS; ++k) {
@@ -2006,11 +2086,11 @@ __global__ __launch_bounds__(WG) void evolve_at_kernel(mdq_ipcs_desc d, int nste
           }
           __syncthreads();  // publish s and the zeroed result vector
           MDQ_BSTAMP(12)
-          atomic_accumulate(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
+          atomic_accumulate<true>(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
             double2 xe[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) xe[i] = Rl[E.dof[i]];
-            velocity_op(v, a, mu, e, ko, g, xe, ye);
+            elem_velocity(g, a, mu, xe, ye);
           });
           // x of the own rows: issue the global reads now, they are consumed after the reduction
           double2 xo[MF_ROWS];
@@ -2020,6 +2100,7 @@ __global__ __launch_bounds__(WG) void evolve_at_kernel(mdq_ipcs_desc d, int nste
             xo[k] = row < n2 ? xs[row] : make_double2(0.0, 0.0);
           }
           __syncthreads();
+          outflow_rows_add(v, bo_own, -0.5 * mu, Rl, Yl);
           double a3[2] = {0.0, 0.0};
           double2 t[MF_ROWS];
 #pragma unroll
@@ -2105,7 +2186,7 @@ __global__ __launch_bounds__(WG) void evolve_at_kernel(mdq_ipcs_desc d, int nste
     __syncthreads();
     {
       const double* pold = v.p_n;
-      atomic_accumulate(v, Yd, tm, [&](int, const Geo& g, const ElemIdx& E, int, double2(&ye)[6]) {
+      atomic_accumulate<false>(v, Yd, tm, [&](int, const Geo& g, const ElemIdx& E, int, double2(&ye)[6]) {
         double2 ue[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) ue[i] = xs[E.dof[i]];
@@ -2135,7 +2216,7 @@ __global__ __launch_bounds__(WG) void evolve_at_kernel(mdq_ipcs_desc d, int nste
       }
     }
     __syncthreads();
-    atomic_accumulate(v, Yd, tm, [&](int, const Geo& g, const ElemIdx& E, int, double2(&ye)[6]) {
+    atomic_accumulate<true>(v, Yd, tm, [&](int, const Geo& g, const ElemIdx& E, int, double2(&ye)[6]) {
       double2 xe[6];
 #pragma unroll
       for (int i = 0; i < 6; ++i) xe[i] = Pl[E.dof[i]];
@@ -2172,7 +2253,7 @@ __global__ __launch_bounds__(WG) void evolve_at_kernel(mdq_ipcs_desc d, int nste
             }
           }
           __syncthreads();
-          atomic_accumulate(v, Yd, tm, [&](int, const Geo& g, const ElemIdx& E, int, double2(&ye)[6]) {
+          atomic_accumulate<true>(v, Yd, tm, [&](int, const Geo& g, const ElemIdx& E, int, double2(&ye)[6]) {
             double2 xe[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) xe[i] = Pl[E.dof[i]];

@@ -59,7 +59,8 @@ class IpcsBatch:
         cap = dict(NV=max(p["nv"] for p in per), NT=max(p["nt"] for p in per), NE=max(p["ne"] for p in per),
                    NNZ2=max(p["colidx2"].size for p in per), NNZ1=max(p["colidx1"].size for p in per),
                    NAF=max(max(p["af"].shape[0] for p in per), 1),
-                   NSE2=max(p["sl2_col"].size for p in per), NSE1=max(p["sl1_col"].size for p in per))
+                   NSE2=max(p["sl2_col"].size for p in per), NSE1=max(p["sl1_col"].size for p in per),
+                   NBO=max(max(p["bo_rows"].size for p in per), 1), NBE=max(max(p["bo_col"].size for p in per), 1))
         if capacities:
             for k, val in capacities.items():
                 if val < cap[k]:
@@ -68,6 +69,7 @@ class IpcsBatch:
         self.cap = cap
         NV, NT, NE, NNZ2, NNZ1, NAF = (cap[k] for k in ("NV", "NT", "NE", "NNZ2", "NNZ1", "NAF"))
         NSE2, NSE1 = cap["NSE2"], cap["NSE1"]
+        NBO, NBE = cap["NBO"], cap["NBE"]
         N2 = NV + NE
         self.N2 = N2
 
@@ -101,6 +103,11 @@ class IpcsBatch:
         NCH = (NT + 1023) // 1024
         h["mf_scat"] = stack("mf_scat", (6, NT), np.int32)
         h["mf_tptr"] = stack("mf_tptr", (NCH, N2 + 1), np.int32)
+        h["nbo"] = np.array([p["bo_rows"].size for p in per], np.int32)
+        h["bo_rows"] = stack("bo_rows", (NBO,), np.int32)
+        h["bo_ptr"] = stack("bo_ptr", (NBO + 1,), np.int32)
+        h["bo_col"] = stack("bo_col", (NBE,), np.int32)
+        h["bo_src"] = stack("bo_src", (NBE,), np.int32)
         h["g2_ptr"] = stack("g2_ptr", (N2 + 1,), np.int32)
         h["g2_src"] = stack("g2_src", (6 * NT,), np.int32)
         h["g1_ptr"] = stack("g1_ptr", (NV + 1,), np.int32)
@@ -127,6 +134,7 @@ class IpcsBatch:
         t["idiag1"] = z(B, N2, 2)
         t["sdiagM"] = z(B, N2)
         t["sdiagK"] = z(B, NV)
+        t["bo_val"] = z(B, NBE, 4)
         t["u_n"] = z(B, N2, 2)
         t["p_n"] = z(B, NV)
         nwork = int(self.lib.mdq_ipcs_workspace_doubles(B, NV, NT, NE))
@@ -137,8 +145,13 @@ class IpcsBatch:
         d = _lib.IpcsDesc()
         d.B, d.NV, d.NT, d.NE, d.N2, d.NNZ2, d.NNZ1, d.NAF = B, NV, NT, NE, N2, NNZ2, NNZ1, NAF
         d.NSE2, d.NSE1 = NSE2, NSE1
+        d.NBO, d.NBE = NBO, NBE
         d.mu, d.rho, d.dt, d.rtol = self.mu, self.rho, self.dt, self.rtol
         d.maxit_u, d.maxit_p, d.maxit_m = self.maxit
+        if int(mode) in (-1, 3) and max(p["bo_max_per_thread"] for p in per) > 2:
+            mode = 2 if int(mode) == -1 else mode
+            if int(mode) == 3:
+                raise ValueError("mode 3 supports at most 2 outflow rows per row-owner thread")
         d.mode = int(mode)
         for name, _typ in _lib.IpcsDesc._fields_:
             if name in t:
@@ -165,6 +178,25 @@ class IpcsBatch:
         sl1_off, sl1_col, pos1 = topo.sell_layout(rowptr1, colidx1)
         cell_outflow = np.full(topo.nt, -1, dtype=np.int8)
         cell_outflow[out_f[:, 0]] = out_f[:, 1]
+        # outflow-facet term as a row list: rows = the 3 P2 dofs of every outflow facet, columns = the 6
+        # dofs of the adjacent cell (duplicates across neighbouring facets are simply summed by the owner)
+        a_l = np.array([1, 0, 0])
+        b_l = np.array([2, 2, 1])
+        ent = []
+        for c, k in out_f:
+            for i in (a_l[k], b_l[k], 3 + k):
+                for j in range(6):
+                    ent.append((int(topo.cell_dofs[c, i]), int(topo.cell_dofs[c, j]), int(c) * 36 + int(i) * 6 + j))
+        ent.sort()
+        bo_rows = sorted({e[0] for e in ent})
+        bo_ptr = np.zeros(len(bo_rows) + 1, np.int32)
+        for e in ent:
+            bo_ptr[bo_rows.index(e[0]) + 1] += 1
+        bo_ptr = np.cumsum(bo_ptr).astype(np.int32)
+        bo_col = np.array([e[1] for e in ent], np.int32)
+        bo_src = np.array([e[2] for e in ent], np.int32)
+        bo_rows = np.array(bo_rows, np.int32)
+        bo_max_per_thread = int(np.bincount(bo_rows % 512, minlength=512).max()) if bo_rows.size else 0
         if topo.np2 <= 4096:
             mf_scat, mf_tptr = topo.matfree_packed(cell_outflow, 1024)
         else:  # matrix-free mode unavailable for this size (kernel falls back to the SELL operators)
@@ -175,7 +207,7 @@ class IpcsBatch:
                     rowptr2=rowptr2, colidx2=colidx2, asm2_ptr=asm2_ptr, asm2_src=asm2_src,
                     rowptr1=rowptr1, colidx1=colidx1, asm1_ptr=asm1_ptr, asm1_src=asm1_src,
                     sl2_off=sl2_off, sl2_col=sl2_col, sl1_off=sl1_off, sl1_col=sl1_col, pos2=pos2, pos1=pos1,
-                    mf_scat=mf_scat, mf_tptr=mf_tptr,
+                    bo_max_per_thread=bo_max_per_thread, mf_scat=mf_scat, mf_tptr=mf_tptr, bo_rows=bo_rows, bo_ptr=bo_ptr, bo_col=bo_col, bo_src=bo_src,
                     g2_ptr=gat["p2"][0], g2_src=gat["p2"][1], g1_ptr=gat["p1"][0], g1_src=gat["p1"][1],
                     bcu_flag=bc["bcu_flag"], bcu_gx=bc["bcu_gx"], bcp_flag=bc["bcp_flag"],
                     af=af, af_edges=af_edges, tags=bc["tags"])
