@@ -2325,6 +2325,463 @@ __global__ __launch_bounds__(WG) void evolve_at_kernel(mdq_ipcs_desc d, int nste
   }
 }
 
+// ---- mode 3 as three kernels per time step (separate register allocation per phase: the BiCGStab
+// loop then runs without spill reloads; state is handed over through global memory as before) ----
+__global__ __launch_bounds__(WG) void at_velocity_kernel(mdq_ipcs_desc d, int32_t* iters) {
+  extern __shared__ __align__(16) double smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const EnvView v = env_view(d, b);
+  const int n2 = v.n2, nv = v.nv;
+  const LdsPlan P = lds_plan(d.N2, d.NV, d.NSE1);
+  const double a = d.rho / d.dt, mu = d.mu;
+  (void)a; (void)mu; (void)nv; (void)n2;
+  double* red = smem;  // 64 doubles
+  double* U = smem + 64;
+  double* w = v.work;
+  double2* xs = reinterpret_cast<double2*>(w + 12 * (int64_t)d.NT);  // x of the velocity solve = u*
+  double* pnew = reinterpret_cast<double*>(xs + 6 * (int64_t)d.N2);
+  int rsel = 0;  // parity of the one-barrier reductions
+  (void)rsel; (void)pnew; (void)red;
+  double2* Pl = reinterpret_cast<double2*>(U);  // search direction p / staged operator input
+  double2* Rl = Pl + P.N2p;                      // residual r (= s)
+  double2* Yl = Rl + P.N2p;                      // operator result (atomic accumulation)
+  double* Yd = reinterpret_cast<double*>(Yl);
+  AtMeta tm;
+  at_prefetch(v, tm, 0);
+  const BoOwn bo_own = outflow_rows_owned(v);
+  int it_u = 0;
+  __syncthreads();
+  {
+    // ================= step 1: tentative velocity
+    float2 idg[MF_ROWS];
+#pragma unroll
+    for (int k = 0; k < MF_ROWS; ++k) {
+      const int row = tid + k * WG;
+      idg[k] = make_float2(0.f, 0.f);
+      if (row < n2) {
+        Yl[row] = make_double2(0.0, 0.0);
+        if (!v.bcu_flag[row]) {
+          const double2 t_ = v.idiag1[row];
+          idg[k] = make_float2((float)t_.x, (float)t_.y);
+        }
+      }
+    }
+    __syncthreads();
+    {
+      const double2* un = v.u_n;
+      const double* pn = v.p_n;
+      atomic_accumulate<false>(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
+        double2 ue[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) ue[i] = un[E.dof[i]];
+        double pe[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pe[i] = pn[E.dof[i]];
+        elem_rhs1_vol(g, a, mu, d.rho, ue, pe, ye);
+      });
+    }
+    __syncthreads();
+    outflow_rows_add(v, bo_own, 0.5 * mu, v.u_n, Yl);  // + mu/2 <nabla_grad(u_n) n, v> on the outflow rows
+    double acc[2] = {0.0, 0.0};
+    double2 f[MF_ROWS];
+#pragma unroll
+    for (int k = 0; k < MF_ROWS; ++k) {
+      const int row = tid + k * WG;
+      f[k] = make_double2(0.0, 0.0);
+      if (row < n2) {
+        f[k] = Yl[row];
+        Yl[row] = make_double2(0.0, 0.0);
+        const bool fl = v.bcu_flag[row] != 0;
+        const double2 g = make_double2(v.bcu_gx[row], 0.0);
+        const double2 x0 = fl ? g : v.u_n[row];  // initial guess satisfies the Dirichlet values
+        xs[row] = x0;
+        Pl[row] = x0;
+        const double2 l = v.lift1[row];
+        const double2 bi = fl ? g : make_double2((f[k].x - l.x) * idg[k].x, (f[k].y - l.y) * idg[k].y);
+        acc[0] += bi.x * bi.x + bi.y * bi.y;
+      }
+    }
+    __syncthreads();
+    atomic_accumulate<true>(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
+      double2 xe[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) xe[i] = Pl[E.dof[i]];
+      elem_velocity(g, a, mu, xe, ye);
+    });
+    __syncthreads();
+    outflow_rows_add(v, bo_own, -0.5 * mu, Pl, Yl);
+    double2 vv[MF_ROWS];
+#pragma unroll
+    for (int k = 0; k < MF_ROWS; ++k) {
+      const int row = tid + k * WG;
+      vv[k] = make_double2(0.0, 0.0);
+      if (row < n2) {
+        const double2 ax = Yl[row];
+        // r0 = D^-1 (f - A_full x0) on free rows, 0 on constrained rows (idg = 0 there)
+        const double2 r0 = make_double2((f[k].x - ax.x) * idg[k].x, (f[k].y - ax.y) * idg[k].y);
+        Rl[row] = r0;
+        acc[1] += r0.x * r0.x + r0.y * r0.y;
+      }
+    }
+    block_sum<2>(acc, red);
+    // p = 0 (only now: the outflow rows above still gathered x0 from Pl until the barriers of the reduction)
+#pragma unroll
+    for (int k = 0; k < MF_ROWS; ++k) {
+      const int row = tid + k * WG;
+      if (row < n2) Pl[row] = make_double2(0.0, 0.0);
+    }
+    {
+      const double bb = acc[0], tol2 = d.rtol * d.rtol * bb;
+      double rr = acc[1];
+      if (rr > tol2 && bb != 0.0) {
+        double rho = rr, rho_old = 1.0, alpha = 1.0, omega = 1.0;
+        int it = 0;
+        // shadow residual in registers (own rows).  BiCGStab accepts ANY fixed shadow vector with
+        // (rh, r0) != 0; we take r0 rounded to fp32, which halves its register footprint.
+        float2 rh[MF_ROWS];
+        {
+          double a0[1] = {0.0};
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k) {
+            const int row = tid + k * WG;
+            rh[k] = make_float2(0.f, 0.f);
+            if (row < n2) {
+              const double2 r0 = Rl[row];
+              rh[k] = make_float2((float)r0.x, (float)r0.y);
+              a0[0] += (double)rh[k].x * r0.x + (double)rh[k].y * r0.y;
+            }
+          }
+          block_sum1<1>(a0, red, rsel);
+          rho = a0[0];  // (rh, r0)
+        }
+        while (it < d.maxit_u) {
+          ++it;
+          const double beta = (rho / rho_old) * (alpha / omega);
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k) {
+            const int row = tid + k * WG;
+            if (row < n2) {
+              const double2 ri = Rl[row], pi = Pl[row];
+              Pl[row] = make_double2(ri.x + beta * (pi.x - omega * vv[k].x), ri.y + beta * (pi.y - omega * vv[k].y));
+              Yl[row] = make_double2(0.0, 0.0);
+            }
+          }
+          __syncthreads();
+          atomic_accumulate<true>(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
+            double2 xe[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) xe[i] = Pl[E.dof[i]];
+            elem_velocity(g, a, mu, xe, ye);
+          });
+          __syncthreads();
+          outflow_rows_add(v, bo_own, -0.5 * mu, Pl, Yl);
+          double a1[1] = {0.0};
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k) {
+            const int row = tid + k * WG;
+            if (row < n2) {
+              const double2 yv = Yl[row];
+              vv[k] = make_double2(yv.x * idg[k].x, yv.y * idg[k].y);
+              a1[0] += rh[k].x * vv[k].x + rh[k].y * vv[k].y;
+            }
+          }
+          block_sum1<1>(a1, red, rsel);
+          if (a1[0] == 0.0) break;
+          alpha = rho / a1[0];
+          // s = r - alpha v ; no early exit on |s| (saves a reduction; the check on |r| follows)
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k) {
+            const int row = tid + k * WG;
+            if (row < n2) {
+              const double2 ri = Rl[row];
+              Rl[row] = make_double2(ri.x - alpha * vv[k].x, ri.y - alpha * vv[k].y);
+              Yl[row] = make_double2(0.0, 0.0);
+            }
+          }
+          __syncthreads();  // publish s and the zeroed result vector
+          atomic_accumulate<true>(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
+            double2 xe[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) xe[i] = Rl[E.dof[i]];
+            elem_velocity(g, a, mu, xe, ye);
+          });
+          // x of the own rows: issue the global reads now, they are consumed after the reduction
+          double2 xo[MF_ROWS];
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k) {
+            const int row = tid + k * WG;
+            xo[k] = row < n2 ? xs[row] : make_double2(0.0, 0.0);
+          }
+          __syncthreads();
+          outflow_rows_add(v, bo_own, -0.5 * mu, Rl, Yl);
+          double a3[2] = {0.0, 0.0};
+          double2 t[MF_ROWS];
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k) {
+            const int row = tid + k * WG;
+            t[k] = make_double2(0.0, 0.0);
+            if (row < n2) {
+              const double2 yv = Yl[row], sv = Rl[row];
+              t[k] = make_double2(yv.x * idg[k].x, yv.y * idg[k].y);
+              a3[0] += t[k].x * sv.x + t[k].y * sv.y;
+              a3[1] += t[k].x * t[k].x + t[k].y * t[k].y;
+            }
+          }
+          block_sum1<2>(a3, red, rsel);
+          if (a3[1] == 0.0) break;
+          omega = a3[0] / a3[1];
+          double a4[2] = {0.0, 0.0};
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k) {
+            const int row = tid + k * WG;
+            if (row < n2) {
+              const double2 pi = Pl[row], sv = Rl[row];
+              xs[row] = make_double2(xo[k].x + alpha * pi.x + omega * sv.x, xo[k].y + alpha * pi.y + omega * sv.y);
+              const double2 rn = make_double2(sv.x - omega * t[k].x, sv.y - omega * t[k].y);
+              Rl[row] = rn;
+              a4[0] += rn.x * rn.x + rn.y * rn.y;
+              a4[1] += rh[k].x * rn.x + rh[k].y * rn.y;
+            }
+          }
+          block_sum1<2>(a4, red, rsel);
+          rr = a4[0];
+          if (!(rr > tol2)) break;
+          rho_old = rho;
+          rho = a4[1];
+          if (rho == 0.0 || omega == 0.0) break;
+        }
+        it_u += it;
+      }
+    }
+    __syncthreads();  // xs (= u*) complete: the element loops of steps 2 and 3 gather it
+
+  }
+  if (tid == 0 && iters) iters[3 * b + 0] += it_u;
+}
+
+template <bool K1_LDS>
+__global__ __launch_bounds__(WG) void at_pressure_kernel(mdq_ipcs_desc d, int32_t* iters) {
+  extern __shared__ __align__(16) double smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const EnvView v = env_view(d, b);
+  const int n2 = v.n2, nv = v.nv;
+  const LdsPlan P = lds_plan(d.N2, d.NV, d.NSE1);
+  const double a = d.rho / d.dt, mu = d.mu;
+  (void)a; (void)mu; (void)nv; (void)n2;
+  double* red = smem;  // 64 doubles
+  double* U = smem + 64;
+  double* w = v.work;
+  double2* xs = reinterpret_cast<double2*>(w + 12 * (int64_t)d.NT);  // x of the velocity solve = u*
+  double* pnew = reinterpret_cast<double*>(xs + 6 * (int64_t)d.N2);
+  int rsel = 0;  // parity of the one-barrier reductions
+  (void)rsel; (void)pnew; (void)red;
+  double* px = U;
+  double* pr = px + P.NVp;
+  double* pp = pr + P.NVp;
+  double* pq = pp + P.NVp;
+  double* lK = pq + P.NVp;
+  int32_t* lci = reinterpret_cast<int32_t*>(lK + d.NSE1);
+  int32_t* lso = lci + d.NSE1 + (d.NSE1 & 1);
+  double* escr1 = w;
+  const int nsl1 = (nv + 63) >> 6;
+  const int32_t* so1 = K1_LDS ? lso : v.sl1_off;
+  const int32_t* ci1 = K1_LDS ? lci : v.sl1_col;
+  const double* K1 = K1_LDS ? lK : v.K1s;
+  int it_p = 0;
+  {
+    // ================= step 2: pressure
+    if (K1_LDS && !d.pd_enabled) {
+      const int ne1 = v.sl1_off[nsl1];
+      for (int kk = tid; kk < ne1; kk += WG) {
+        lK[kk] = v.K1s[kk];
+        lci[kk] = v.sl1_col[kk];
+      }
+      for (int kk = tid; kk <= nsl1; kk += WG) lso[kk] = v.sl1_off[kk];
+    }
+    rhs2_elements(v, d, xs, v.p_n, escr1);
+    __syncthreads();
+    for (int i = tid; i < nv; i += WG) {
+      double bsum = 0.0;
+      for (int s = v.g1_ptr[i]; s < v.g1_ptr[i + 1]; ++s) bsum += escr1[v.g1_src[s]];
+      const double sd = v.sdiagK[i];
+      pr[i] = v.bcp_flag[i] ? 0.0 : bsum / sd;
+      px[i] = v.p_n[i] * sd;
+    }
+    if (d.pd_enabled) {
+      const PdView pd = pd_view(d, b);
+      pressure_direct(pd, nv, pr, px, pp, pq, lK);
+    } else {
+      it_p += cg_pressure(nv, so1, ci1, K1, d.rtol, d.maxit_p, px, pr, pp, pq, red);
+    }
+    for (int i = tid; i < nv; i += WG) pnew[i] = px[i] / v.sdiagK[i];
+    __syncthreads();
+
+  }
+  if (tid == 0 && iters) iters[3 * b + 1] += it_p;
+}
+
+__global__ __launch_bounds__(WG) void at_correction_kernel(mdq_ipcs_desc d, int nsteps, int step, double* drag,
+                                                            double* lift, int32_t* iters) {
+  extern __shared__ __align__(16) double smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const EnvView v = env_view(d, b);
+  const int n2 = v.n2, nv = v.nv;
+  const LdsPlan P = lds_plan(d.N2, d.NV, d.NSE1);
+  const double a = d.rho / d.dt, mu = d.mu;
+  (void)a; (void)mu; (void)nv; (void)n2;
+  double* red = smem;  // 64 doubles
+  double* U = smem + 64;
+  double* w = v.work;
+  double2* xs = reinterpret_cast<double2*>(w + 12 * (int64_t)d.NT);  // x of the velocity solve = u*
+  double* pnew = reinterpret_cast<double*>(xs + 6 * (int64_t)d.N2);
+  int rsel = 0;  // parity of the one-barrier reductions
+  (void)rsel; (void)pnew; (void)red;
+  double2* Pl = reinterpret_cast<double2*>(U);
+  double2* Yl = Pl + P.N2p;
+  double* Yd = reinterpret_cast<double*>(Yl);
+  AtMeta tm;
+  at_prefetch(v, tm, 0);
+  int it_m = 0;
+  __syncthreads();
+  {
+    // ================= step 3: velocity correction (mass solve, both components)
+    double2 x[MF_ROWS], r[MF_ROWS], p[MF_ROWS];
+    double ism[MF_ROWS];
+    double am[2] = {0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < MF_ROWS; ++k) {
+      const int row = tid + k * WG;
+      if (row < n2) Yl[row] = make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    {
+      const double* pold = v.p_n;
+      atomic_accumulate<false>(v, Yd, tm, [&](int, const Geo& g, const ElemIdx& E, int, double2(&ye)[6]) {
+        double2 ue[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) ue[i] = xs[E.dof[i]];
+        double dp[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dp[i] = pnew[E.dof[i]] - pold[E.dof[i]];
+        elem_rhs3(g, d.dt, ue, dp, ye);
+      });
+    }
+    __syncthreads();
+    double2 f3[MF_ROWS];
+#pragma unroll
+    for (int k = 0; k < MF_ROWS; ++k) {
+      const int row = tid + k * WG;
+      ism[k] = 0.0;
+      x[k] = f3[k] = make_double2(0.0, 0.0);
+      if (row < n2) {
+        const bool fl = v.bcu_flag[row] != 0;
+        if (!fl) ism[k] = 1.0 / v.sdiagM[row];
+        f3[k] = Yl[row];
+        Yl[row] = make_double2(0.0, 0.0);
+        x[k] = xs[row];      // u* (satisfies the Dirichlet values)
+        Pl[row] = x[k];      // stage S^-1 (S x0) = x0
+        const double2 l = v.lift3[row];
+        const double2 bi = fl ? x[k] : make_double2((f3[k].x - l.x) * ism[k], (f3[k].y - l.y) * ism[k]);
+        am[0] += bi.x * bi.x + bi.y * bi.y;
+      }
+    }
+    __syncthreads();
+    atomic_accumulate<true>(v, Yd, tm, [&](int, const Geo& g, const ElemIdx& E, int, double2(&ye)[6]) {
+      double2 xe[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) xe[i] = Pl[E.dof[i]];
+      elem_mass(g, xe, ye);
+    });
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MF_ROWS; ++k) {
+      const int row = tid + k * WG;
+      r[k] = p[k] = make_double2(0.0, 0.0);
+      if (row < n2) {
+        const double2 ax = Yl[row];
+        r[k] = make_double2((f3[k].x - ax.x) * ism[k], (f3[k].y - ax.y) * ism[k]);  // 0 on constrained rows
+        p[k] = r[k];
+        am[1] += r[k].x * r[k].x + r[k].y * r[k].y;
+        if (ism[k] != 0.0) x[k] = make_double2(x[k].x / ism[k], x[k].y / ism[k]);  // scaled unknown S x
+      }
+    }
+    block_sum<2>(am, red);
+    {
+      const double bb = am[0], tol2 = d.rtol * d.rtol * bb;
+      double rr = am[1];
+      if (rr > tol2 && bb != 0.0) {
+        int it = 0;
+        while (it < d.maxit_m) {
+          ++it;
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k) {
+            const int row = tid + k * WG;
+            if (row < n2) {
+              Pl[row] = make_double2(p[k].x * ism[k], p[k].y * ism[k]);
+              Yl[row] = make_double2(0.0, 0.0);
+            }
+          }
+          __syncthreads();
+          atomic_accumulate<true>(v, Yd, tm, [&](int, const Geo& g, const ElemIdx& E, int, double2(&ye)[6]) {
+            double2 xe[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) xe[i] = Pl[E.dof[i]];
+            elem_mass(g, xe, ye);
+          });
+          __syncthreads();
+          double a1[1] = {0.0};
+          double2 q[MF_ROWS];
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k) {
+            const int row = tid + k * WG;
+            q[k] = make_double2(0.0, 0.0);
+            if (row < n2) {
+              const double2 yv = Yl[row];
+              q[k] = make_double2(yv.x * ism[k], yv.y * ism[k]);
+              a1[0] += p[k].x * q[k].x + p[k].y * q[k].y;
+            }
+          }
+          block_sum1<1>(a1, red, rsel);
+          if (!(a1[0] > 0.0)) break;
+          const double alpha = rr / a1[0];
+          double a2[1] = {0.0};
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k) {
+            x[k] = make_double2(x[k].x + alpha * p[k].x, x[k].y + alpha * p[k].y);
+            r[k] = make_double2(r[k].x - alpha * q[k].x, r[k].y - alpha * q[k].y);
+            a2[0] += r[k].x * r[k].x + r[k].y * r[k].y;
+          }
+          block_sum1<1>(a2, red, rsel);
+          const double rr_new = a2[0];
+          if (!(rr_new > tol2)) break;
+          const double beta = rr_new / rr;
+          rr = rr_new;
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k)
+            p[k] = make_double2(r[k].x + beta * p[k].x, r[k].y + beta * p[k].y);
+        }
+        it_m += it;
+      }
+    }
+
+    // ================= update state + probes
+#pragma unroll
+    for (int k = 0; k < MF_ROWS; ++k) {
+      const int row = tid + k * WG;
+      if (row < n2) v.u_n[row] = (ism[k] != 0.0) ? make_double2(x[k].x * ism[k], x[k].y * ism[k]) : x[k];
+    }
+    for (int i = tid; i < nv; i += WG) v.p_n[i] = pnew[i];
+    __syncthreads();
+    double dr, li;
+    forces(v, d.mu, v.u_n, v.p_n, red, dr, li);
+    if (tid == 0) {
+      drag[(int64_t)b * nsteps + step] = dr;
+      lift[(int64_t)b * nsteps + step] = li;
+    }
+  }
+  if (tid == 0 && iters) iters[3 * b + 2] += it_m;
+}
+
 template <bool K1_LDS>
 static hipError_t launch_evolve_at(const mdq_ipcs_desc* d, size_t lds, int nsteps, double* drag, double* lift,
                                    int32_t* iters, hipStream_t stream) {
@@ -2465,10 +2922,36 @@ int mdq_ipcs_evolve(const mdq_ipcs_desc* d, int32_t nsteps, double* drag, double
   const size_t lds = red_bytes + u;
   hipError_t e;
   hipStream_t st = (hipStream_t)stream;
-  if (mode == 3)
-    e = k1_lds ? launch_evolve_at<true>(d, lds, nsteps, drag, lift, iters, st)
-               : launch_evolve_at<false>(d, lds, nsteps, drag, lift, iters, st);
-  else if (mode == 2)
+  if (mode == 3) {
+    const size_t lds_v = red_bytes + P.vel3_bytes;
+    const size_t lds_p = red_bytes + P.prs_vec_bytes + (k1_lds ? P.prs_mat_bytes : 0);
+    const size_t lds_c = red_bytes + 2 * sizeof(double2) * (size_t)P.N2p;
+    static bool attr_set = false;
+    if (!attr_set) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&at_velocity_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&at_pressure_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&at_pressure_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&at_correction_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return fail("hipFuncSetAttribute(mode 3 kernels)", e);
+      attr_set = true;
+    }
+    for (int step = 0; step < nsteps; ++step) {
+      hipLaunchKernelGGL(at_velocity_kernel, dim3(d->B), dim3(WG), lds_v, st, *d, iters);
+      if (k1_lds)
+        hipLaunchKernelGGL(at_pressure_kernel<true>, dim3(d->B), dim3(WG), lds_p, st, *d, iters);
+      else
+        hipLaunchKernelGGL(at_pressure_kernel<false>, dim3(d->B), dim3(WG), lds_p, st, *d, iters);
+      hipLaunchKernelGGL(at_correction_kernel, dim3(d->B), dim3(WG), lds_c, st, *d, nsteps, step, drag, lift, iters);
+    }
+    e = hipGetLastError();
+  } else if (mode == 2)
     e = k1_lds ? launch_evolve_mf<true>(d, lds, nsteps, drag, lift, iters, st)
                : launch_evolve_mf<false>(d, lds, nsteps, drag, lift, iters, st);
   else if (mode == 1)
