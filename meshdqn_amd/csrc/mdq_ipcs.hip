@@ -2350,6 +2350,9 @@ __global__ __launch_bounds__(WG) void at_velocity_kernel(mdq_ipcs_desc d, int32_
   at_prefetch(v, tm, 0);
   const BoOwn bo_own = outflow_rows_owned(v);
   int it_u = 0;
+  double2* hist = xs + d.N2;                                          // u* of the step before the last
+  double* histc = reinterpret_cast<double*>(xs + 3 * (int64_t)d.N2);  // [0]: tentative velocities stored so far
+  const int nhist = (int)histc[0];
   __syncthreads();
   {
     // ================= step 1: tentative velocity
@@ -2393,7 +2396,16 @@ __global__ __launch_bounds__(WG) void at_velocity_kernel(mdq_ipcs_desc d, int32_
         Yl[row] = make_double2(0.0, 0.0);
         const bool fl = v.bcu_flag[row] != 0;
         const double2 g = make_double2(v.bcu_gx[row], 0.0);
-        const double2 x0 = fl ? g : v.u_n[row];  // initial guess satisfies the Dirichlet values
+        // initial guess: linear extrapolation of the two previous tentative velocities (xs still holds
+        // u*_n, hist u*_{n-1}); u_n while there is no history.  It satisfies the Dirichlet values.
+        const double2 us1 = xs[row];
+        double2 x0 = v.u_n[row];
+        if (nhist >= 2) {
+          const double2 us2 = hist[row];
+          x0 = make_double2(2.0 * us1.x - us2.x, 2.0 * us1.y - us2.y);
+        }
+        if (fl) x0 = g;
+        hist[row] = us1;
         xs[row] = x0;
         Pl[row] = x0;
         const double2 l = v.lift1[row];
@@ -2556,7 +2568,10 @@ __global__ __launch_bounds__(WG) void at_velocity_kernel(mdq_ipcs_desc d, int32_
     __syncthreads();  // xs (= u*) complete: the element loops of steps 2 and 3 gather it
 
   }
-  if (tid == 0 && iters) iters[3 * b + 0] += it_u;
+  if (tid == 0) {
+    histc[0] = (double)(nhist < 2 ? nhist + 1 : 2);
+    if (iters) iters[3 * b + 0] += it_u;
+  }
 }
 
 template <bool K1_LDS>
@@ -2642,6 +2657,8 @@ __global__ __launch_bounds__(WG) void at_correction_kernel(mdq_ipcs_desc d, int 
   AtMeta tm;
   at_prefetch(v, tm, 0);
   int it_m = 0;
+  const double2* hist = xs + d.N2;  // u* of the previous step (shifted by the velocity kernel of this step)
+  const int nhist = (int)reinterpret_cast<const double*>(xs + 3 * (int64_t)d.N2)[0];
   __syncthreads();
   {
     // ================= step 3: velocity correction (mass solve, both components)
@@ -2678,7 +2695,13 @@ __global__ __launch_bounds__(WG) void at_correction_kernel(mdq_ipcs_desc d, int 
         if (!fl) ism[k] = 1.0 / v.sdiagM[row];
         f3[k] = Yl[row];
         Yl[row] = make_double2(0.0, 0.0);
-        x[k] = xs[row];      // u* (satisfies the Dirichlet values)
+        // initial guess: u* plus the previous step's correction (u_n - u*_n), i.e. a guess for
+        // u* - dt grad(dp); plain u* while there is no history.  Dirichlet rows keep u* = g.
+        x[k] = xs[row];
+        if (!fl && nhist >= 2) {
+          const double2 un = v.u_n[row], up = hist[row];
+          x[k] = make_double2(x[k].x + (un.x - up.x), x[k].y + (un.y - up.y));
+        }
         Pl[row] = x[k];      // stage S^-1 (S x0) = x0
         const double2 l = v.lift3[row];
         const double2 bi = fl ? x[k] : make_double2((f3[k].x - l.x) * ism[k], (f3[k].y - l.y) * ism[k]);

@@ -225,6 +225,7 @@ class IpcsBatch:
     def reset_state(self):
         self.t["u_n"].zero_()
         self.t["p_n"].zero_()
+        self.t["work"].zero_()  # (also drops the initial-guess history of the velocity solve)
         self.iters.zero_()
         self.steps_done = 0
 
