@@ -125,21 +125,30 @@ def main():
         elapsed = tt.item()
 
     iters = batch.iters.cpu().numpy().astype(np.float64) / args.steps  # (B,3) per step
-    survey_bytes = batch.algorithmic_bytes_per_step(iters)  # SURVEY 8(d) assembled-CSR convention, per launch
-    alg_bytes = batch.implemented_bytes_per_step(iters)      # bytes the implemented (matrix-free) algorithm moves
-    flops = batch.flops_per_step(iters)
     drag = out[0][:, 0].cpu().numpy()
     lift = out[1][:, 0].cpu().numpy()
+    # second pass over the same number of steps with HIP events around every kernel launch (recorded by the
+    # library on the launch stream): average duration of each of the three kernels of a step
+    batch.iters.zero_()
+    _, _, kms = batch.evolve_timed(args.steps, out=(torch.empty((B, args.steps), dtype=torch.float64, device=dev),
+                                                   torch.empty((B, args.steps), dtype=torch.float64, device=dev)))
+    iters2 = batch.iters.cpu().numpy().astype(np.float64) / args.steps
+    k_vel, k_prs, k_cor = (m / args.steps for m in kms)
+    vel_bytes = batch.velocity_kernel_bytes(iters2)
+    vel_flops = batch.velocity_kernel_flops(iters2)
+    survey_bytes = batch.algorithmic_bytes_per_step(iters2)  # SURVEY 8(d) assembled-CSR convention, whole step
+    step_bytes = batch.implemented_bytes_per_step(iters2)     # bytes the implemented algorithm moves, whole step
 
     if rank == 0:
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        achieved = vel_bytes / (k_vel * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get("evolve_kernel_hbm_bytes_per_launch")
+                traffic = json.load(open(tp)).get("velocity_kernel_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        nt, nv, ne = topo.nt, topo.nv, topo.ne
         res = {
             "metric": "env steps/sec (ys930 ~2k-tri)",
             "value": world * B * args.steps / elapsed,
@@ -154,12 +163,12 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.mesh} (876 vertices / 1570 triangles, smoothed), {B} batched envs per GPU, "
-                            f"step = S2: one IPCS evolve() per env (3 RHS + BiCGStab/CG/CG + drag/lift), "
+                "workload": f"{args.mesh} ({nv} vertices / {nt} triangles, smoothed), {B} batched envs per GPU, "
+                            f"step = S2: one IPCS evolve() per env (3 RHS + BiCGStab / direct pressure / CG + drag/lift), "
                             f"developed flow after {args.spinup} untimed steps from rest",
                 "envs_per_gpu": B, "rtol": args.rtol, "dt": 1e-3, "mu": 1e-3, "rho": 1.0,
                 "krylov_iters_per_step": {"velocity_bicgstab": float(iters[:, 0].mean()),
-                                          "pressure_cg": float(iters[:, 1].mean()),
+                                          "pressure": float(iters[:, 1].mean()),
                                           "correction_cg": float(iters[:, 2].mean())},
                 "drag_env0": float(drag[0]), "lift_env0": float(lift[0]),
                 "parallelism": f"dp{world} (independent envs sharded, no data-path collective)",
@@ -167,17 +176,19 @@ def main():
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "evolve_at_kernel (mode 3: matrix-free, LDS fp64 atomics)", "launch_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "survey_csr_convention": {"bytes_per_launch": survey_bytes,
-                                                   "equivalent_GBs": survey_bytes / (kern_ms * 1e-3) / 1e9},
-                         "fp64_valu": {"flops_per_launch": flops, "achieved_TFLOPs": flops / (kern_ms * 1e-3) / 1e12,
-                                       "peak_TFLOPs": 78.6 * B / 256.0,
-                                       "frac_of_used_CUs": flops / (kern_ms * 1e-3) / 1e12 / (78.6 * B / 256.0)},
-                         "note": "the kernel is matrix-free: operators are re-derived per triangle from 64 B of "
-                                 "metadata, Krylov vectors live in LDS/registers, so HBM traffic is ~100x below the "
-                                 "assembled-CSR figure of SURVEY 8(d) (reported under survey_csr_convention) and the "
-                                 "binding resource is FP64 VALU issue + LDS atomics on the B CUs in use (1 CU per env)"},
+                         "kernel": "at_velocity_kernel (rhs1 + matrix-free Jacobi-BiCGStab, LDS fp64 atomics)",
+                         "launch_ms": k_vel, "algorithmic_bytes_per_launch": vel_bytes,
+                         "kernels_ms_per_step": {"at_velocity_kernel": k_vel, "at_pressure_kernel": k_prs,
+                                                 "at_correction_kernel": k_cor},
+                         "whole_step": {"implemented_bytes": step_bytes, "survey_csr_convention_bytes": survey_bytes,
+                                        "survey_equivalent_GBs": survey_bytes / (elapsed / args.steps) / 1e9},
+                         "fp64_valu": {"flops_per_launch": vel_flops,
+                                       "achieved_TFLOPs": vel_flops / (k_vel * 1e-3) / 1e12,
+                                       "peak_TFLOPs_on_used_CUs": 78.6 * min(B, 256) / 256.0,
+                                       "frac": vel_flops / (k_vel * 1e-3) / 1e12 / (78.6 * min(B, 256) / 256.0)},
+                         "note": "matrix-free: operators are re-derived per triangle from 64 B of metadata, Krylov vectors "
+                                 "live in LDS/registers; the binding resources are FP64 VALU issue, LDS atomics and "
+                                 "workgroup barriers on the B CUs in use (one CU per environment), not HBM"},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_budget)

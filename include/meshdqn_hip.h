@@ -169,6 +169,14 @@ int mdq_ipcs_evolve(const mdq_ipcs_desc* d, int32_t nsteps, double* drag, double
                     int32_t* iters, void* stream);
 
 /*
+ * Same as mdq_ipcs_evolve for the three-kernel mode 3, with HIP events recorded on `stream` around every
+ * kernel launch; the accumulated durations (milliseconds over all nsteps) of the velocity / pressure /
+ * correction kernels are returned in host array kernel_ms[3].  Synchronises the stream (measurement aid).
+ */
+int mdq_ipcs_evolve_timed(const mdq_ipcs_desc* d, int32_t nsteps, double* drag, double* lift,
+                          int32_t* iters, void* stream, double* kernel_ms);
+
+/*
  * Drag and lift of given fields on every environment's current mesh.
  * Replaces `DragProbe.sample(u,p)` / `LiftProbe.sample(u,p)` (probes.py:23-50)
  * as used by `Env2DAirfoil.calculate_reward` (Env2DAirfoil.py:390-394).

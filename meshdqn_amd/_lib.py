@@ -73,6 +73,8 @@ SYMBOLS = {
     "mdq_ipcs_workspace_doubles": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "mdq_ipcs_assemble": (C.c_int, [C.POINTER(IpcsDesc), C.c_void_p]),
     "mdq_ipcs_evolve": (C.c_int, [C.POINTER(IpcsDesc), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mdq_ipcs_evolve_timed": (C.c_int, [C.POINTER(IpcsDesc), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.POINTER(C.c_double)]),
     "mdq_probe_forces": (C.c_int, [C.POINTER(IpcsDesc), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),
     "mdq_gcn_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,

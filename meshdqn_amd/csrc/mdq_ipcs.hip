@@ -2917,8 +2917,23 @@ int mdq_ipcs_assemble(const mdq_ipcs_desc* d, void* stream) {
   return 0;
 }
 
+static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag, double* lift, int32_t* iters,
+                            void* stream, double* kernel_ms);
+
 int mdq_ipcs_evolve(const mdq_ipcs_desc* d, int32_t nsteps, double* drag, double* lift, int32_t* iters,
                     void* stream) {
+  return ipcs_evolve_impl(d, nsteps, drag, lift, iters, stream, nullptr);
+}
+
+int mdq_ipcs_evolve_timed(const mdq_ipcs_desc* d, int32_t nsteps, double* drag, double* lift, int32_t* iters,
+                          void* stream, double* kernel_ms) {
+  if (!kernel_ms) return fail_msg("kernel_ms is required");
+  if (d && d->mode != 3 && d->mode != -1) return fail_msg("per-kernel timing exists for the three-kernel mode 3 only");
+  return ipcs_evolve_impl(d, nsteps, drag, lift, iters, stream, kernel_ms);
+}
+
+static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag, double* lift, int32_t* iters,
+                            void* stream, double* kernel_ms) {
   if (int rc = check_desc(d)) return rc;
   if (nsteps <= 0) return fail_msg("nsteps must be positive");
   if (!drag || !lift) return fail_msg("drag/lift output pointers are required");
@@ -2934,6 +2949,7 @@ int mdq_ipcs_evolve(const mdq_ipcs_desc* d, int32_t nsteps, double* drag, double
     if (red_bytes + P.vel2_bytes <= LDS_MAX && d->N2 <= MF_ROWS * WG) mode = 2;
     if (red_bytes + P.vel3_bytes <= LDS_MAX && d->N2 <= MF_ROWS * WG) mode = 3;
   }
+  if (kernel_ms && mode != 3) return fail_msg("per-kernel timing exists for the three-kernel mode 3 only");
   if (mode == 3 && (red_bytes + P.vel3_bytes > LDS_MAX || d->N2 > MF_ROWS * WG))
     return fail_msg("mode 3 needs N2 <= 3584 and three velocity vectors in LDS");
   if (mode == 2 && (red_bytes + P.vel2_bytes > LDS_MAX || d->N2 > MF_ROWS * WG))
@@ -2965,14 +2981,34 @@ int mdq_ipcs_evolve(const mdq_ipcs_desc* d, int32_t nsteps, double* drag, double
       if (e != hipSuccess) return fail("hipFuncSetAttribute(mode 3 kernels)", e);
       attr_set = true;
     }
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (kernel_ms) {
+      for (int i = 0; i < 4; ++i)
+        if ((e = hipEventCreate(&ev[i])) != hipSuccess) return fail("hipEventCreate", e);
+      kernel_ms[0] = kernel_ms[1] = kernel_ms[2] = 0.0;
+    }
     for (int step = 0; step < nsteps; ++step) {
+      if (kernel_ms) hipEventRecord(ev[0], st);
       hipLaunchKernelGGL(at_velocity_kernel, dim3(d->B), dim3(WG), lds_v, st, *d, iters);
+      if (kernel_ms) hipEventRecord(ev[1], st);
       if (k1_lds)
         hipLaunchKernelGGL(at_pressure_kernel<true>, dim3(d->B), dim3(WG), lds_p, st, *d, iters);
       else
         hipLaunchKernelGGL(at_pressure_kernel<false>, dim3(d->B), dim3(WG), lds_p, st, *d, iters);
+      if (kernel_ms) hipEventRecord(ev[2], st);
       hipLaunchKernelGGL(at_correction_kernel, dim3(d->B), dim3(WG), lds_c, st, *d, nsteps, step, drag, lift, iters);
+      if (kernel_ms) {
+        hipEventRecord(ev[3], st);
+        if ((e = hipEventSynchronize(ev[3])) != hipSuccess) return fail("hipEventSynchronize", e);
+        for (int i = 0; i < 3; ++i) {
+          float ms = 0.f;
+          hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+          kernel_ms[i] += ms;
+        }
+      }
     }
+    if (kernel_ms)
+      for (int i = 0; i < 4; ++i) hipEventDestroy(ev[i]);
     e = hipGetLastError();
   } else if (mode == 2)
     e = k1_lds ? launch_evolve_mf<true>(d, lds, nsteps, drag, lift, iters, st)

@@ -295,6 +295,23 @@ class IpcsBatch:
         self.steps_done += nsteps
         return drag, lift
 
+    def evolve_timed(self, nsteps: int = 1, stream=None, out=None):
+        """`evolve` with HIP events around every kernel (mode 3): returns (drag, lift, ms) where ms[3] are the
+        accumulated durations of the velocity / pressure / correction kernels over the nsteps."""
+        if not self.assembled:
+            self.assemble(stream)
+        if out is None:
+            drag = torch.empty((self.B, nsteps), dtype=torch.float64, device=self.device)
+            lift = torch.empty_like(drag)
+        else:
+            drag, lift = out
+        ms = (C.c_double * 3)()
+        rc = self.lib.mdq_ipcs_evolve_timed(C.byref(self.desc), int(nsteps), drag.data_ptr(), lift.data_ptr(),
+                                            self.iters.data_ptr(), _lib.stream_ptr(stream), ms)
+        _lib.check(rc, "mdq_ipcs_evolve_timed")
+        self.steps_done += nsteps
+        return drag, lift, [ms[0], ms[1], ms[2]]
+
     def probe_forces(self, u: torch.Tensor, p: torch.Tensor, stream=None):
         """u (B,F,N2,2), p (B,F,NV) -> drag, lift (B,F)."""
         F = u.shape[1]
@@ -356,6 +373,27 @@ class IpcsBatch:
             else:
                 prs = ip * (12.0 * p["colidx1"].size)
             tot += napply * apply_b + per_it_vec + state + prs
+        return tot
+
+    def velocity_kernel_bytes(self, iters_per_step) -> float:
+        """Global-memory bytes of ONE launch of the dominant kernel (at_velocity_kernel, mode 3) for the whole
+        batch, no cache credit: per operator application 64 B of triangle metadata (6 packed words + 5 geometry
+        doubles), 2 + 2*it applications (rhs1, A x0, two per BiCGStab iteration); x read + written per iteration
+        (32 B per dof); per launch u_n, p_n gathered by the rhs1 element loop (6x16 + 3x8 B per triangle), u_n,
+        u* history, idiag, lift, Dirichlet data and the final u* (9 x 16 B + 2 B per dof)."""
+        tot = 0.0
+        for b, p in enumerate(self.per):
+            nv, nt, ne = p["nv"], p["nt"], p["ne"]
+            n2 = nv + ne
+            iu = iters_per_step[b][0]
+            tot += (2 + 2 * iu) * 64.0 * nt + 32.0 * n2 * iu + 120.0 * nt + 146.0 * n2
+        return tot
+
+    def velocity_kernel_flops(self, iters_per_step) -> float:
+        tot = 0.0
+        for b, p in enumerate(self.per):
+            iu = iters_per_step[b][0]
+            tot += p["nt"] * ((1 + 2 * iu) * 600.0 + 1800.0) + (p["nv"] + p["ne"]) * iu * 60.0
         return tot
 
     def flops_per_step(self, iters_per_step) -> float:

@@ -13,12 +13,14 @@ import csv, glob, sys, json
 out = sys.argv[1]
 res = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    vals = []
+    per = {}
     for f in glob.glob(f"{out}/{c}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "evolve_" in r["Kernel_Name"] and r["Counter_Name"] == c:
-                vals.append(float(r["Counter_Value"]))
-    res[c] = dict(n=len(vals), mean=sum(vals) / max(len(vals), 1), last100_mean=sum(vals[-100:]) / max(len(vals[-100:]), 1))
+            name = r["Kernel_Name"]
+            if ("evolve_" in name or "at_" in name) and r["Counter_Name"] == c:
+                key = name.split("(")[0].replace("void ", "")
+                per.setdefault(key, []).append(float(r["Counter_Value"]))
+    res[c] = {k: dict(n=len(v), mean=sum(v) / len(v), last100_mean=sum(v[-100:]) / len(v[-100:])) for k, v in per.items()}
 print(json.dumps(res))
 json.dump(res, open(f"{out}/pmc_summary.json", "w"), indent=1)
 PY
