@@ -184,3 +184,20 @@ def polygon_distance(poly: np.ndarray, pts: np.ndarray) -> np.ndarray:
     inside = (np.where(cond, x < xin, False).sum(axis=1) % 2) == 1
     dist[inside] = 0.0
     return dist
+
+
+def red_refine(coords: np.ndarray, cells: np.ndarray):
+    """Uniform (red) refinement: every triangle -> 4, new vertices at the edge midpoints (boundary
+    midpoints stay on the straight boundary segments).  Used for the refined ~6k-triangle stress
+    configuration of BASELINE.json."""
+    topo = MeshTopology(coords, cells)
+    nv = topo.nv
+    mid = 0.5 * (topo.coords[topo.edges[:, 0]] + topo.coords[topo.edges[:, 1]])
+    new_coords = np.concatenate([topo.coords, mid])
+    c, ce = topo.cells, topo.cell_edges + nv  # local edge k is opposite local vertex k
+    new_cells = np.concatenate([
+        np.stack([c[:, 0], ce[:, 2], ce[:, 1]], axis=1),
+        np.stack([c[:, 1], ce[:, 0], ce[:, 2]], axis=1),
+        np.stack([c[:, 2], ce[:, 1], ce[:, 0]], axis=1),
+        np.stack([ce[:, 0], ce[:, 1], ce[:, 2]], axis=1)])
+    return new_coords, new_cells.astype(np.int32)

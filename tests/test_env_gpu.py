@@ -73,3 +73,34 @@ def test_bad_actions_follow_reference_error_codes(lib_built):
     env.get_state()
     st, r, done, _ = env.step(9999)  # KeyError in coord_map -> code 2: reward -1, terminal
     assert r == -1.0 and done is True
+
+
+def test_deploy_resimulation_matches_oracle(lib_built, meshes, tmp_path):
+    """deploy_dqn.py semantics: after every removal the operators are re-assembled on the coarsened mesh
+    and the flow is re-simulated from rest; trajectories in the reference's row layouts."""
+    from meshdqn_amd.deploy import deploy
+    from meshdqn_amd.env import Env2DAirfoil
+    from oracle.env import OracleEnv
+    from oracle.ipcs import OracleFlowSolver
+    env = Env2DAirfoil(_config("ah93w145"))
+    coords, cells = meshes["ah93w145"]
+    ora = OracleEnv(coords, cells, AGENT)
+    acts = [17, 180, 42]
+    # (the 20-step toy ground truth terminates episodes immediately: keep going to exercise the loop)
+    out = deploy(env, actions=acts, complete_traj=True, save_dir=str(tmp_path), prefix="t_", stop_on_done=False)
+    assert out["actions"].tolist() == acts
+    assert out["drag_trajectory"].shape == (2, 1 + 5 + 5) and out["interpolate_drag_trajectory"].shape[1] == 11
+    assert os.path.exists(os.path.join(str(tmp_path), "t_drag_trajectory.npy"))
+    # oracle: same removals, then a fresh IPCS run from rest on the final coarsened (already smoothed) mesh
+    ora.get_state()
+    for a in acts:
+        ora.step(a)
+    m = ora.flow.mesh
+    fs = OracleFlowSolver(m.coords, m.cells, smooth=False)
+    dr = []
+    for i in range(AGENT["solver_steps"]):
+        _, _, d, l = fs.evolve()
+        if (i + 1) % AGENT["save_steps"] == 0:
+            dr.append(d)
+    assert out["traj_vertices"].tolist() == [796, 795]
+    assert np.allclose(out["traj_drag"][-1], dr, rtol=1e-7)

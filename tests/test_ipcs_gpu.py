@@ -169,3 +169,32 @@ def test_flow_solver_surface_matches_oracle(lib_built, tmp_path):
     u2 = u.copy(deepcopy=True)
     u2.vector().set_local(2.0 * v)
     assert np.allclose(u2.vector().get_local(), 2.0 * v)
+
+
+@pytest.mark.slow
+def test_refined_mesh_c5_assembled_path(meshes, lib_built):
+    """BASELINE config 5: ys930 red-refined once (3322 vertices / 6280 triangles, 25 848 velocity dofs).
+    Too large for the LDS-resident matrix-free modes -> assembled SELL operators (mode 0) + direct pressure
+    solve; parity against the oracle for the first steps."""
+    import torch
+    from meshdqn_amd.ipcs_batch import IpcsBatch, smooth_coords
+    from meshdqn_amd.mesh_ops import red_refine
+    from meshdqn_amd.topology import MeshTopology
+    from oracle.ipcs import OracleFlowSolver
+    coords, cells = meshes["ys930"]
+    t0 = MeshTopology(coords, cells)
+    rc, rcells = red_refine(smooth_coords(t0, 50), cells)
+    topo = MeshTopology(rc, rcells)
+    assert (topo.nv, topo.nt, topo.ne) == (3322, 6280, 9602)
+    batch = IpcsBatch([topo, topo], [rc, rc], rtol=1e-12)   # auto mode
+    ora = OracleFlowSolver(rc, rcells, smooth=False)
+    for step in range(2):
+        drag, lift = batch.evolve(1)
+        uo, po, do, lo = ora.evolve()
+    torch.cuda.synchronize()
+    n2, nv = ora.th.np2, ora.th.nv
+    u = batch.u_n[1, :n2].cpu().numpy()
+    ug = np.concatenate([u[:, 0], u[:, 1]])
+    assert np.abs(ug - uo).max() / np.abs(uo).max() < 1e-8
+    assert np.abs(batch.p_n[1, :nv].cpu().numpy() - po).max() / np.abs(po).max() < 1e-8
+    assert abs(drag[0, 0].item() - do) / abs(do) < 1e-8 and abs(lift[1, 0].item() - lo) / abs(lo) < 1e-8
