@@ -268,6 +268,52 @@ int mdq_smooth_host(double* coords, int32_t nv, const int32_t* cells, int32_t nt
                     const int64_t* nbr_ptr, const int64_t* nbr, const int64_t* vc_ptr,
                     const int64_t* vc, const uint8_t* on_boundary, int32_t iterations);
 
+/*
+ * Batched host mesh engine of the environment step (std::thread over environments):
+ * remove one interior vertex per environment (remove_idx[b] < 0: none), restore the Delaunay
+ * triangulation of the remaining points by star re-triangulation + Lawson flips (= the reference's
+ * global `scipy.spatial.Delaunay` + all-boundary-simplex filter, Env2DAirfoil.py:480-496), then
+ * DOLFIN-style smoothing (flow_solver.py:236-237).  Host arrays, in place:
+ *   coords [B][NV][2], cells [B][NT][3] (any orientation in; ascending vertex ids per cell out),
+ *   nv[B], nt[B] (updated), status[B] (0 ok, <0: star/ear-clipping/flip failure, mesh unusable).
+ */
+int mdq_remesh_host(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv,
+                    int32_t* nt, const int32_t* remove_idx, int32_t smooth_iters, int32_t nthreads,
+                    int32_t* status);
+
+/* ---- batched topology + N-closest selection + state graph (host arrays) ---- */
+typedef struct mdq_env_topo_desc {
+  int32_t B, NV, NT, NP, NAF, N, EMAX, npoly;   /* capacities; N = N_closest; npoly = airfoil polygon points */
+  /* inputs */
+  const double* coords;     /* [B][NV][2] */
+  const int32_t* cells;     /* [B][NT][3]  ascending vertex ids per cell */
+  const int32_t* nv;        /* [B] */
+  const int32_t* nt;        /* [B] */
+  const int32_t* offset;    /* [B]  do_nothing_offset (Env2DAirfoil.py:308) */
+  const double* polygon;    /* [npoly][2]  airfoil boundary points of the ORIGINAL mesh in vertex order (:223-233) */
+  /* outputs */
+  int32_t* ne;              /* [B] */
+  int32_t* cell_dofs;       /* [B][6][NT]  P2 dofs (edges numbered by first appearance) */
+  double* points;           /* [B][NP][2]  P2 dof coordinates: vertices, then edge midpoints */
+  int32_t* naf;             /* [B] */
+  int32_t* af_facets;       /* [B][NAF][2] (cell, local edge) of the airfoil facets */
+  int32_t* nremovable;      /* [B] */
+  int32_t* nsel;            /* [B]  min(N, removable - offset) */
+  int32_t* n_closest;       /* [B][N]  ranks inside the removable list (the reference indexes features with these) */
+  int32_t* coord_map;       /* [B][N]  vertex id of every action */
+  int32_t* nedges;          /* [B] */
+  int32_t* edge_src;        /* [B][EMAX] */
+  int32_t* edge_dst;        /* [B][EMAX] */
+  double* edge_len;         /* [B][EMAX] edge_attr */
+} mdq_env_topo_desc;
+
+/*
+ * Per environment: unique edges / P2 dof map / dof coordinates, boundary + airfoil facets, `removable`
+ * (flow_solver.py:75-78 quirk), polygon distances + argsort + N-closest window (Env2DAirfoil.py:220-241,
+ * 293-315) and the state graph edges (:258-280).  status[b] = 0 ok, <0 capacity exceeded.
+ */
+int mdq_env_topology_host(const mdq_env_topo_desc* d, int32_t nthreads, int32_t* status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,14 @@ class InterpDesc(C.Structure):
     ]
 
 
+class EnvTopoDesc(C.Structure):
+    """Mirror of `mdq_env_topo_desc`."""
+    _fields_ = [(n, C.c_int32) for n in ("B", "NV", "NT", "NP", "NAF", "N", "EMAX", "npoly")] + [
+        (n, C.c_void_p) for n in ("coords", "cells", "nv", "nt", "offset", "polygon", "ne", "cell_dofs", "points", "naf",
+                                  "af_facets", "nremovable", "nsel", "n_closest", "coord_map", "nedges", "edge_src",
+                                  "edge_dst", "edge_len")]
+
+
 # every symbol include/meshdqn_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "mdq_abi_version": (C.c_int, []),
@@ -80,6 +88,9 @@ SYMBOLS = {
     "mdq_gcn_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdq_interpolate_snapshots": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mdq_remesh_host": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "mdq_env_topology_host": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "mdq_smooth_host": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
 }

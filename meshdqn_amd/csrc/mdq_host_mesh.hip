@@ -1,0 +1,517 @@
+// Host-side (C++) mesh engine of the batched environment step: vertex removal + re-triangulation,
+// DOLFIN-style smoothing and Taylor-Hood topology for B environments at once (std::thread over envs).
+//
+// Reference semantics (Env2DAirfoil.py:452-512 `_remove_vertex`, flow_solver.py:233-250 `remesh`):
+//   drop the vertex, Delaunay-triangulate ALL remaining points (scipy/Qhull), drop the simplices made of
+//   boundary vertices only, rebuild the mesh, smooth(50), recompute boundary / removable flags.
+// Here the SAME triangulation is obtained without a global rebuild: the Delaunay triangulation of a point
+// set in general position is unique, so re-triangulating the removed vertex' star (ear clipping) and
+// applying Lawson flips to every interior edge until all are locally Delaunay yields it (the fluid
+// boundary edges are Delaunay edges of the full point set on these meshes - SURVEY.md 8(a7) - so the
+// constrained and the filtered unconstrained triangulations coincide).  Written with flat arrays and
+// no allocation in the inner loops: this is the algorithm the GPU port of the next round follows.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../include/meshdqn_hip.h"
+
+namespace mdq_host {
+
+struct EdgeMap {  // open addressing hash: key (a<b) -> value
+  std::vector<int64_t> key;
+  std::vector<int32_t> val;
+  uint32_t mask;
+  explicit EdgeMap(int n) {
+    uint32_t cap = 16;
+    while (cap < (uint32_t)(2 * n + 8)) cap <<= 1;
+    key.assign(cap, -1);
+    val.assign(cap, -1);
+    mask = cap - 1;
+  }
+  static int64_t mk(int a, int b) { return a < b ? ((int64_t)a << 32) | (uint32_t)b : ((int64_t)b << 32) | (uint32_t)a; }
+  int32_t* find_or_insert(int a, int b, bool& inserted) {
+    const int64_t k = mk(a, b);
+    uint32_t h = (uint32_t)((uint64_t)k * 0x9E3779B97F4A7C15ull >> 40) & mask;
+    while (key[h] != -1 && key[h] != k) h = (h + 1) & mask;
+    inserted = key[h] == -1;
+    key[h] = k;
+    return &val[h];
+  }
+  int32_t* find(int a, int b) {
+    const int64_t k = mk(a, b);
+    uint32_t h = (uint32_t)((uint64_t)k * 0x9E3779B97F4A7C15ull >> 40) & mask;
+    while (key[h] != -1 && key[h] != k) h = (h + 1) & mask;
+    return key[h] == -1 ? nullptr : &val[h];
+  }
+};
+
+static inline double orient2d(const double* a, const double* b, const double* c) {
+  return (b[0] - a[0]) * (c[1] - a[1]) - (b[1] - a[1]) * (c[0] - a[0]);
+}
+
+// > 0 when d lies inside the circumcircle of the CCW triangle (a,b,c)
+static inline double incircle(const double* a, const double* b, const double* c, const double* d) {
+  const double ax = a[0] - d[0], ay = a[1] - d[1], bx = b[0] - d[0], by = b[1] - d[1], cx = c[0] - d[0],
+               cy = c[1] - d[1];
+  return (ax * ax + ay * ay) * (bx * cy - by * cx) - (bx * bx + by * by) * (ax * cy - ay * cx) +
+         (cx * cx + cy * cy) * (ax * by - ay * bx);
+}
+
+struct Mesh {
+  int nv, nt;
+  double* x;     // [nv][2]
+  int32_t* tri;  // [nt][3]
+};
+
+// make every triangle counter-clockwise
+static void orient_ccw(Mesh& m) {
+  for (int t = 0; t < m.nt; ++t) {
+    int32_t* v = m.tri + 3 * t;
+    if (orient2d(m.x + 2 * v[0], m.x + 2 * v[1], m.x + 2 * v[2]) < 0) std::swap(v[1], v[2]);
+  }
+}
+
+// Remove interior vertex `rv`: ear-clip its star polygon.  Returns 0 ok, <0 failure (mesh untouched).
+static int remove_vertex(Mesh& m, int rv) {
+  int star[64], ns = 0;
+  for (int t = 0; t < m.nt; ++t) {
+    const int32_t* v = m.tri + 3 * t;
+    if (v[0] == rv || v[1] == rv || v[2] == rv) {
+      if (ns == 64) return -1;
+      star[ns++] = t;
+    }
+  }
+  if (ns < 3) return -2;
+  // ring edges (a -> b) with rv on the left (triangles are CCW: (rv, a, b) in cyclic order)
+  int ea[64], eb[64];
+  for (int s = 0; s < ns; ++s) {
+    const int32_t* v = m.tri + 3 * star[s];
+    const int k = v[0] == rv ? 0 : (v[1] == rv ? 1 : 2);
+    ea[s] = v[(k + 1) % 3];
+    eb[s] = v[(k + 2) % 3];
+  }
+  int ring[64];
+  ring[0] = ea[0];
+  int cur = eb[0];
+  for (int n = 1; n < ns; ++n) {
+    ring[n] = cur;
+    int f = -1;
+    for (int s = 0; s < ns; ++s)
+      if (ea[s] == cur) f = s;
+    if (f < 0) return -3;  // open star: rv is a boundary vertex
+    cur = eb[f];
+  }
+  if (cur != ring[0]) return -3;
+  // ear clipping of the CCW polygon ring[0..ns)
+  int poly[64], np_ = ns, newtri[62][3], nn = 0;
+  std::memcpy(poly, ring, sizeof(int) * ns);
+  int guard = 0;
+  while (np_ > 3 && guard++ < 4096) {
+    bool clipped = false;
+    for (int i = 0; i < np_ && !clipped; ++i) {
+      const int p0 = poly[(i + np_ - 1) % np_], p1 = poly[i], p2 = poly[(i + 1) % np_];
+      const double* A = m.x + 2 * p0;
+      const double* Bp = m.x + 2 * p1;
+      const double* Cp = m.x + 2 * p2;
+      if (orient2d(A, Bp, Cp) <= 0) continue;  // reflex corner
+      bool empty = true;
+      for (int j = 0; j < np_ && empty; ++j) {
+        const int q = poly[j];
+        if (q == p0 || q == p1 || q == p2) continue;
+        const double* Q = m.x + 2 * q;
+        if (orient2d(A, Bp, Q) >= 0 && orient2d(Bp, Cp, Q) >= 0 && orient2d(Cp, A, Q) >= 0) empty = false;
+      }
+      if (!empty) continue;
+      newtri[nn][0] = p0;
+      newtri[nn][1] = p1;
+      newtri[nn][2] = p2;
+      ++nn;
+      for (int j = i; j + 1 < np_; ++j) poly[j] = poly[j + 1];
+      --np_;
+      clipped = true;
+    }
+    if (!clipped) return -4;
+  }
+  if (np_ != 3) return -4;
+  newtri[nn][0] = poly[0];
+  newtri[nn][1] = poly[1];
+  newtri[nn][2] = poly[2];
+  ++nn;  // nn == ns - 2
+  // write the new triangles into the first nn star slots, compact the last two away
+  for (int s = 0; s < nn; ++s) std::memcpy(m.tri + 3 * star[s], newtri[s], sizeof(int32_t) * 3);
+  int dead[2] = {star[ns - 2], star[ns - 1]};
+  if (dead[0] < dead[1]) std::swap(dead[0], dead[1]);  // remove the higher slot first
+  for (int q = 0; q < 2; ++q) {
+    const int last = m.nt - 1;
+    if (dead[q] != last) std::memcpy(m.tri + 3 * dead[q], m.tri + 3 * last, sizeof(int32_t) * 3);
+    --m.nt;
+  }
+  // drop the vertex: ids above shift down
+  for (int i = 0; i < 3 * m.nt; ++i)
+    if (m.tri[i] > rv) --m.tri[i];
+  std::memmove(m.x + 2 * rv, m.x + 2 * (rv + 1), sizeof(double) * 2 * (m.nv - rv - 1));
+  --m.nv;
+  return 0;
+}
+
+// Lawson flips until every interior edge is locally Delaunay.  Returns number of flips, <0 on failure.
+static int make_delaunay(Mesh& m) {
+  const int nt = m.nt;
+  std::vector<int32_t> nbr(3 * nt, -1);  // nbr[3t+k]: triangle across the edge opposite local vertex k
+  {
+    EdgeMap em(3 * nt);
+    for (int t = 0; t < nt; ++t)
+      for (int k = 0; k < 3; ++k) {
+        const int a = m.tri[3 * t + (k + 1) % 3], b = m.tri[3 * t + (k + 2) % 3];
+        bool ins;
+        int32_t* slot = em.find_or_insert(a, b, ins);
+        if (ins) {
+          *slot = 3 * t + k;
+        } else {
+          const int o = *slot;
+          if (nbr[o] != -1) return -1;  // non-manifold
+          nbr[o] = t;
+          nbr[3 * t + k] = o / 3;
+        }
+      }
+  }
+  std::vector<int32_t> stack;
+  stack.reserve(3 * nt);
+  for (int t = 0; t < nt; ++t)
+    for (int k = 0; k < 3; ++k)
+      if (nbr[3 * t + k] > t) stack.push_back(3 * t + k);
+  int flips = 0;
+  long guard = 0;
+  while (!stack.empty()) {
+    if (++guard > 200000) return -2;
+    const int he = stack.back();
+    stack.pop_back();
+    const int t = he / 3, k = he % 3;
+    const int u = nbr[3 * t + k];
+    if (u < 0) continue;
+    int32_t* T = m.tri + 3 * t;
+    int32_t* U = m.tri + 3 * u;
+    const int a = T[k], b = T[(k + 1) % 3], c = T[(k + 2) % 3];  // edge (b,c), apex a in t
+    // local index of the apex of u (vertex not on the shared edge)
+    int ku = -1;
+    for (int j = 0; j < 3; ++j)
+      if (U[j] != b && U[j] != c) ku = j;
+    if (ku < 0 || nbr[3 * u + ku] != t) continue;  // stale half-edge
+    const int dd = U[ku];
+    if (incircle(m.x + 2 * a, m.x + 2 * b, m.x + 2 * c, m.x + 2 * dd) <= 0) continue;
+    // flip edge (b,c) -> (a,dd):  t = (a, b, dd),  u = (a, dd, c)   (both CCW)
+    const int t_ab = nbr[3 * t + (k + 2) % 3];  // across edge (a,b) in t (opposite c)
+    const int t_ca = nbr[3 * t + (k + 1) % 3];  // across edge (c,a) in t (opposite b)
+    // in u: vertices cyclic (dd, c, b) since u is CCW with edge (c,b); find neighbours across (dd,c)... by vertex
+    int u_bd = -1, u_dc = -1;
+    for (int j = 0; j < 3; ++j) {
+      if (U[j] == c) u_bd = nbr[3 * u + j];  // edge opposite c = (b,dd)
+      if (U[j] == b) u_dc = nbr[3 * u + j];  // edge opposite b = (dd,c)
+    }
+    T[0] = a; T[1] = b; T[2] = dd;
+    U[0] = a; U[1] = dd; U[2] = c;
+    // t = (a,b,dd): opposite a -> edge (b,dd): u_bd ; opposite b -> edge (dd,a): u ; opposite dd -> edge (a,b): t_ab
+    nbr[3 * t + 0] = u_bd; nbr[3 * t + 1] = u; nbr[3 * t + 2] = t_ab;
+    // u = (a,dd,c): opposite a -> edge (dd,c): u_dc ; opposite dd -> edge (c,a): t_ca ; opposite c -> edge (a,dd): t
+    nbr[3 * u + 0] = u_dc; nbr[3 * u + 1] = t_ca; nbr[3 * u + 2] = t;
+    auto relink = [&](int tri_id, int old_n, int new_n) {
+      if (tri_id < 0) return;
+      for (int j = 0; j < 3; ++j)
+        if (nbr[3 * tri_id + j] == old_n) {
+          // make sure it is the right edge (a triangle can touch old_n only once in a manifold mesh)
+          nbr[3 * tri_id + j] = new_n;
+          return;
+        }
+    };
+    relink(u_bd, u, t);   // edge (b,dd) now belongs to t
+    relink(t_ca, t, u);   // edge (c,a) now belongs to u
+    ++flips;
+    for (int j = 0; j < 3; ++j) {
+      if (j != 1) stack.push_back(3 * t + j);  // edges (b,dd) and (a,b)
+      if (j != 2) stack.push_back(3 * u + j);  // edges (dd,c) and (c,a)
+    }
+  }
+  return flips;
+}
+
+// DOLFIN MeshSmoothing::smooth on the triangle list (interior vertices only; every neighbour of an interior
+// vertex appears in exactly two incident triangles, so the centroid is accumulated over triangles)
+static void smooth(Mesh& m, const uint8_t* on_boundary, int iterations) {
+  const int nv = m.nv, nt = m.nt;
+  std::vector<int32_t> ptr(nv + 1, 0), inc(3 * nt);
+  for (int i = 0; i < 3 * nt; ++i) ++ptr[m.tri[i] + 1];
+  for (int v = 0; v < nv; ++v) ptr[v + 1] += ptr[v];
+  {
+    std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+    for (int t = 0; t < nt; ++t)
+      for (int k = 0; k < 3; ++k) inc[fill[m.tri[3 * t + k]]++] = 3 * t + k;
+  }
+  const double DOLFIN_EPS = 3.0e-16;
+  double* x = m.x;
+  for (int it = 0; it < iterations; ++it) {
+    for (int v = 0; v < nv; ++v) {
+      if (on_boundary[v]) continue;
+      const double px = x[2 * v], py = x[2 * v + 1];
+      double cx = 0.0, cy = 0.0, rmin = 0.0;
+      const int n0 = ptr[v], n1 = ptr[v + 1];
+      for (int q = n0; q < n1; ++q) {
+        const int t = inc[q] / 3, k = inc[q] % 3;
+        const int a = m.tri[3 * t + (k + 1) % 3], b = m.tri[3 * t + (k + 2) % 3];
+        const double ax = x[2 * a], ay = x[2 * a + 1], bx = x[2 * b], by = x[2 * b + 1];
+        cx += ax + bx;
+        cy += ay + by;
+        const double tx = bx - ax, ty = by - ay;
+        const double nn = std::sqrt(tx * tx + ty * ty);
+        const double r = std::fabs((ty * (px - ax) - tx * (py - ay)) / nn);
+        rmin = (rmin == 0.0) ? r : (r < rmin ? r : rmin);
+      }
+      const double cnt = 2.0 * (n1 - n0);
+      cx /= cnt;
+      cy /= cnt;
+      const double dx = cx - px, dy = cy - py;
+      const double r = std::sqrt(dx * dx + dy * dy);
+      if (r < DOLFIN_EPS) continue;
+      const double step = (0.5 * rmin < r) ? 0.5 * rmin : r;
+      x[2 * v] = px + step * dx / r;
+      x[2 * v + 1] = py + step * dy / r;
+    }
+  }
+}
+
+static int remesh_one(double* x, int32_t* tri, int32_t* nv, int32_t* nt, int remove_idx, int smooth_iters) {
+  if (remove_idx < 0) return 0;  // "do nothing" / invalid action: the reference leaves the mesh untouched
+  Mesh m{*nv, *nt, x, tri};
+  orient_ccw(m);
+  // boundary vertices = endpoints of edges with a single owner (before the removal: the removed vertex is interior)
+  int rc = 0;
+  if (remove_idx >= 0) {
+    rc = remove_vertex(m, remove_idx);
+    if (rc) return rc;
+  }
+  const int flips = make_delaunay(m);
+  if (flips < 0) return -10 + flips;
+  std::vector<uint8_t> onb(m.nv, 0);
+  {
+    EdgeMap em(3 * m.nt);
+    std::vector<int32_t> cnt;
+    std::vector<std::pair<int, int>> ed;
+    for (int t = 0; t < m.nt; ++t)
+      for (int k = 0; k < 3; ++k) {
+        const int a = m.tri[3 * t + (k + 1) % 3], b = m.tri[3 * t + (k + 2) % 3];
+        bool ins;
+        int32_t* s = em.find_or_insert(a, b, ins);
+        if (ins) {
+          *s = (int)cnt.size();
+          cnt.push_back(1);
+          ed.emplace_back(a, b);
+        } else {
+          ++cnt[*s];
+        }
+      }
+    for (size_t e = 0; e < cnt.size(); ++e)
+      if (cnt[e] == 1) onb[ed[e].first] = onb[ed[e].second] = 1;
+  }
+  if (smooth_iters > 0) smooth(m, onb.data(), smooth_iters);
+  // canonical cells: ascending vertex ids (DOLFIN mesh.order())
+  for (int t = 0; t < m.nt; ++t) std::sort(m.tri + 3 * t, m.tri + 3 * t + 3);
+  *nv = m.nv;
+  *nt = m.nt;
+  return 0;
+}
+
+}  // namespace mdq_host
+
+extern "C" int mdq_remesh_host(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv,
+                               int32_t* nt, const int32_t* remove_idx, int32_t smooth_iters, int32_t nthreads,
+                               int32_t* status) {
+  if (B <= 0 || !coords || !cells || !nv || !nt || !remove_idx || !status) return mdq_set_error("mdq_remesh_host: bad arguments");
+  auto work = [&](int b0, int b1) {
+    for (int b = b0; b < b1; ++b)
+      status[b] = mdq_host::remesh_one(coords + (size_t)b * NV * 2, cells + (size_t)b * NT * 3, nv + b, nt + b,
+                                        remove_idx[b], smooth_iters);
+  };
+  int T = nthreads > 0 ? nthreads : (int)std::thread::hardware_concurrency();
+  if (T < 1) T = 1;
+  if (T > B) T = B;
+  if (T == 1) {
+    work(0, B);
+  } else {
+    std::vector<std::thread> th;
+    for (int i = 0; i < T; ++i) th.emplace_back(work, (int)((int64_t)B * i / T), (int)((int64_t)B * (i + 1) / T));
+    for (auto& t : th) t.join();
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Topology + N-closest selection + state graph of every environment after a remesh
+// (MeshTopology / Env2DAirfoil._n_closest / get_state restated for the batched engine).
+namespace mdq_host {
+
+static inline double seg_dist(const double* p, const double* a, const double* b) {
+  const double abx = b[0] - a[0], aby = b[1] - a[1];
+  double t = ((p[0] - a[0]) * abx + (p[1] - a[1]) * aby) / (abx * abx + aby * aby);
+  t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+  const double qx = a[0] + t * abx - p[0], qy = a[1] + t * aby - p[1];
+  return std::sqrt(qx * qx + qy * qy);
+}
+
+static double polygon_distance(const double* poly, int np_, const double* p) {
+  bool inside = false;
+  for (int i = 0; i < np_; ++i) {
+    const double* a = poly + 2 * i;
+    const double* b = poly + 2 * ((i + 1) % np_);
+    if ((a[1] > p[1]) != (b[1] > p[1])) {
+      const double xin = a[0] + (p[1] - a[1]) * (b[0] - a[0]) / (b[1] - a[1]);
+      if (p[0] < xin) inside = !inside;
+    }
+  }
+  if (inside) return 0.0;
+  double d = 1e300;
+  for (int i = 0; i < np_; ++i) d = std::min(d, seg_dist(p, poly + 2 * i, poly + 2 * ((i + 1) % np_)));
+  return d;
+}
+
+static int topology_one(const mdq_env_topo_desc& D, int b) {
+  const int nv = D.nv[b], nt = D.nt[b];
+  const double* x = D.coords + (size_t)b * D.NV * 2;
+  const int32_t* tri = D.cells + (size_t)b * D.NT * 3;
+  int32_t* cd = D.cell_dofs + (size_t)b * 6 * D.NT;
+  double* pts = D.points + (size_t)b * D.NP * 2;
+  // ---- edges numbered by first appearance in (cell, local edge k opposite vertex k) order
+  EdgeMap em(3 * nt);
+  std::vector<int32_t> ea, eb, ecnt, eown;
+  ea.reserve(3 * nt / 2 + 64);
+  eb.reserve(3 * nt / 2 + 64);
+  for (int t = 0; t < nt; ++t) {
+    const int32_t* v = tri + 3 * t;
+    for (int k = 0; k < 3; ++k) {
+      const int a = v[k == 0 ? 1 : 0], bb = v[k == 2 ? 1 : 2];
+      bool ins;
+      int32_t* s = em.find_or_insert(a, bb, ins);
+      if (ins) {
+        *s = (int)ea.size();
+        ea.push_back(a);
+        eb.push_back(bb);
+        ecnt.push_back(1);
+        eown.push_back(3 * t + k);
+      } else {
+        ++ecnt[*s];
+      }
+      cd[(3 + k) * D.NT + t] = nv + *s;
+      cd[k * D.NT + t] = v[k];
+    }
+  }
+  const int ne = (int)ea.size();
+  if (nv + ne > D.NP) return -1;
+  D.ne[b] = ne;
+  for (int i = 0; i < nv; ++i) {
+    pts[2 * i] = x[2 * i];
+    pts[2 * i + 1] = x[2 * i + 1];
+  }
+  for (int e = 0; e < ne; ++e) {
+    pts[2 * (nv + e)] = 0.5 * (x[2 * ea[e]] + x[2 * eb[e]]);
+    pts[2 * (nv + e) + 1] = 0.5 * (x[2 * ea[e] + 1] + x[2 * eb[e] + 1]);
+  }
+  // ---- boundary vertices, airfoil facets (tag 1: all of both end points + midpoint strictly inside the box)
+  std::vector<uint8_t> onb(nv, 0);
+  int naf = 0;
+  int32_t* af = D.af_facets + (size_t)b * D.NAF * 2;
+  const double E = 3.0e-16;
+  auto in_air = [&](double px, double py) { return px < 3.0 - E && px > -0.5 + E && py < 0.5 - E && py > -0.5 + E; };
+  for (int e = 0; e < ne; ++e) {
+    if (ecnt[e] != 1) continue;
+    onb[ea[e]] = onb[eb[e]] = 1;
+    const double ax = x[2 * ea[e]], ay = x[2 * ea[e] + 1], bx = x[2 * eb[e]], by = x[2 * eb[e] + 1];
+    if (in_air(ax, ay) && in_air(bx, by) && in_air(0.5 * (ax + bx), 0.5 * (ay + by))) {
+      if (naf >= D.NAF) return -2;
+      af[2 * naf] = eown[e] / 3;
+      af[2 * naf + 1] = eown[e] % 3;
+      ++naf;
+    }
+  }
+  D.naf[b] = naf;
+  // ---- removable: `coord not in bmesh.coordinates()` = neither x nor y equals ANY boundary x / y (numpy quirk)
+  std::vector<double> bx, by;
+  for (int i = 0; i < nv; ++i)
+    if (onb[i]) {
+      bx.push_back(x[2 * i]);
+      by.push_back(x[2 * i + 1]);
+    }
+  std::sort(bx.begin(), bx.end());
+  std::sort(by.begin(), by.end());
+  std::vector<int32_t> removable;
+  removable.reserve(nv);
+  for (int i = 0; i < nv; ++i) {
+    const bool hit = std::binary_search(bx.begin(), bx.end(), x[2 * i]) || std::binary_search(by.begin(), by.end(), x[2 * i + 1]);
+    if (!hit) removable.push_back(i);
+  }
+  const int nrem = (int)removable.size();
+  D.nremovable[b] = nrem;
+  // ---- N closest removable vertices to the airfoil polygon (argsort of the distances, window by offset)
+  std::vector<double> dist(nrem);
+  for (int r = 0; r < nrem; ++r) dist[r] = polygon_distance(D.polygon, D.npoly, x + 2 * removable[r]);
+  std::vector<int32_t> order(nrem);
+  for (int r = 0; r < nrem; ++r) order[r] = r;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return dist[a] < dist[c]; });
+  const int off = D.offset[b];
+  int nsel = nrem - off;
+  if (nsel > D.N) nsel = D.N;
+  if (nsel < 0) nsel = 0;
+  D.nsel[b] = nsel;
+  int32_t* nc = D.n_closest + (size_t)b * D.N;
+  int32_t* cm = D.coord_map + (size_t)b * D.N;
+  std::vector<int32_t> inv(nv, -1);
+  for (int i = 0; i < nsel; ++i) {
+    nc[i] = order[off + i];
+    cm[i] = removable[order[off + i]];
+    inv[cm[i]] = i;
+  }
+  for (int i = nsel; i < D.N; ++i) nc[i] = cm[i] = 0;
+  // ---- state graph: cells whose three vertices are all selected -> edges (id1,id2),(id1,id3),(id2,id3)
+  int32_t* es = D.edge_src + (size_t)b * D.EMAX;
+  int32_t* ed = D.edge_dst + (size_t)b * D.EMAX;
+  double* el = D.edge_len + (size_t)b * D.EMAX;
+  int E_ = 0;
+  for (int t = 0; t < nt; ++t) {
+    const int32_t* v = tri + 3 * t;
+    const int i0 = inv[v[0]], i1 = inv[v[1]], i2 = inv[v[2]];
+    if (i0 < 0 || i1 < 0 || i2 < 0) continue;
+    if (E_ + 3 > D.EMAX) return -3;
+    const int pa[3] = {0, 0, 1}, pb[3] = {1, 2, 2}, id[3] = {i0, i1, i2};
+    for (int q = 0; q < 3; ++q) {
+      es[E_] = id[pa[q]];
+      ed[E_] = id[pb[q]];
+      const double dx = x[2 * v[pa[q]]] - x[2 * v[pb[q]]], dy = x[2 * v[pa[q]] + 1] - x[2 * v[pb[q]] + 1];
+      el[E_] = std::sqrt(dx * dx + dy * dy);
+      ++E_;
+    }
+  }
+  D.nedges[b] = E_;
+  return 0;
+}
+
+}  // namespace mdq_host
+
+extern "C" int mdq_env_topology_host(const mdq_env_topo_desc* d, int32_t nthreads, int32_t* status) {
+  if (!d || d->B <= 0 || !status) return mdq_set_error("mdq_env_topology_host: bad arguments");
+  const mdq_env_topo_desc D = *d;
+  auto work = [&](int b0, int b1) {
+    for (int b = b0; b < b1; ++b) status[b] = mdq_host::topology_one(D, b);
+  };
+  int T = nthreads > 0 ? nthreads : (int)std::thread::hardware_concurrency();
+  if (T < 1) T = 1;
+  if (T > D.B) T = D.B;
+  if (T == 1) {
+    work(0, D.B);
+  } else {
+    std::vector<std::thread> th;
+    for (int i = 0; i < T; ++i) th.emplace_back(work, (int)((int64_t)D.B * i / T), (int)((int64_t)D.B * (i + 1) / T));
+    for (auto& t : th) t.join();
+  }
+  return 0;
+}

@@ -3,3 +3,4 @@
 #include "mdq_ipcs.hip"
 #include "mdq_gcn.hip"
 #include "mdq_mesh.hip"
+#include "mdq_host_mesh.hip"

@@ -136,6 +136,23 @@ class FusedGcn:
         return (out, emb) if return_embedding else out
 
 
+    @torch.no_grad()
+    def forward_arrays(self, x, node_ptr, esrc, edst, edge_ptr, nmax, emax, stream=None):
+        """Same launch on pre-built arrays (what `VecEnv2DAirfoil.get_state` returns): x (sumN,F) f32,
+        node_ptr / edge_ptr (B+1,) i32, esrc / edst (sumE,) i32 local node ids."""
+        self._pack()
+        d = self.desc
+        B = node_ptr.numel() - 1
+        x = x.reshape(-1, x.shape[-1]).to(torch.float32).contiguous()
+        emb = torch.empty((B, 2 * d.C), dtype=torch.float32, device=x.device)
+        out = torch.empty((B, d.out_dim), dtype=torch.float32, device=x.device)
+        rc = self.lib.mdq_gcn_forward(C.byref(d), B, int(nmax), max(int(emax), 1), x.data_ptr(), node_ptr.data_ptr(),
+                                      esrc.data_ptr(), edst.data_ptr(), edge_ptr.data_ptr(), emb.data_ptr(),
+                                      out.data_ptr(), _lib.stream_ptr(stream))
+        _lib.check(rc, "mdq_gcn_forward")
+        return out
+
+
 def node_removal_forward(net, data):
     if not hasattr(net, "_fused"):
         net._fused = FusedGcn(net)

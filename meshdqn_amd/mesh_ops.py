@@ -201,3 +201,21 @@ def red_refine(coords: np.ndarray, cells: np.ndarray):
         np.stack([c[:, 2], ce[:, 1], ce[:, 0]], axis=1),
         np.stack([ce[:, 0], ce[:, 1], ce[:, 2]], axis=1)])
     return new_coords, new_cells.astype(np.int32)
+
+
+def remesh_batch(coords: np.ndarray, cells: np.ndarray, nv: np.ndarray, nt: np.ndarray, remove_idx: np.ndarray,
+                 smooth_iters: int = 50, nthreads: int = 0) -> np.ndarray:
+    """In-place batched vertex removal + Delaunay restoration + smoothing on the host engine
+    (`mdq_remesh_host`).  coords (B,NV,2) f8, cells (B,NT,3) i4, nv/nt (B,) i4, remove_idx (B,) i4.
+    Returns status (B,) (0 = ok)."""
+    lib = _lib.load()
+    B, NV = coords.shape[0], coords.shape[1]
+    NT = cells.shape[1]
+    assert coords.dtype == np.float64 and cells.dtype == np.int32 and coords.flags.c_contiguous and cells.flags.c_contiguous
+    assert nv.dtype == np.int32 and nt.dtype == np.int32
+    rem = np.ascontiguousarray(remove_idx, np.int32)
+    status = np.zeros(B, np.int32)
+    rc = lib.mdq_remesh_host(B, NV, NT, coords.ctypes.data, cells.ctypes.data, nv.ctypes.data, nt.ctypes.data,
+                             rem.ctypes.data, int(smooth_iters), int(nthreads), status.ctypes.data)
+    _lib.check(rc, "mdq_remesh_host")
+    return status

@@ -1,0 +1,212 @@
+"""`VecEnv2DAirfoil` - B `Env2DAirfoil` environments stepped together on one GPU.
+
+Same per-environment semantics as `meshdqn_amd.env.Env2DAirfoil` (= the reference's
+Env2DAirfoil.py:318-428 step / reward / state logic), batched:
+
+  host   mdq_remesh_host        vertex removal + Delaunay restoration + smooth(50)     (C++, threads over envs)
+  host   mdq_env_topology_host  edges / P2 dofs / airfoil facets / removable / N-closest / state graph
+  GPU    mdq_interpolate_snapshots   S snapshots onto every coarsened mesh              (one launch for all envs)
+  GPU    mdq_probe_forces            2S force integrals per env                         (one launch)
+  GPU    feature gather (torch indexing) and, optionally, the fused Q-network forward (mdq_gcn_forward)
+
+All environments start from the same smoothed original mesh and share its ground truth and snapshots
+(computed once by a base `Env2DAirfoil`, i.e. the reference's first `reset()`); terminated environments
+are reset in place.  Triangulations are identical to the reference's as SETS of cells; the cell ORDER
+(an artefact of Qhull in the reference) is the engine's own, so `edge_index` columns come in a different
+order than in the single-environment class.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .env import Env2DAirfoil
+from .mesh_ops import remesh_batch
+
+
+class VecEnv2DAirfoil:
+    def __init__(self, config, num_envs: int, compute_device="cuda", nthreads: int = 0, base_env: Env2DAirfoil | None = None,
+                 auto_reset: bool = True, emax: int = 1536):
+        self.lib = _lib.load()
+        self.B = int(num_envs)
+        self.device = torch.device(compute_device)
+        self.nthreads = int(nthreads)
+        self.auto_reset = auto_reset
+        base = base_env or Env2DAirfoil(config, compute_device=compute_device)
+        self.base = base
+        ap = config["agent_params"]
+        self.N = int(ap["N_closest"])
+        self.TIME_REWARD = float(ap["time_reward"])
+        self.threshold = float(ap["threshold"])
+        self.goal_vertices = float(ap["goal_vertices"])
+        self.timesteps = int(ap["timesteps"])
+        self.NEGATIVE_REWARD = -1.0
+        self.gt_drag = np.asarray(base.gt_drag, dtype=np.float64)
+        self.gt_lift = np.asarray(base.gt_lift, dtype=np.float64)
+        self.S = len(base.original_u)
+        topo0 = base._orig_topo
+        self.x0 = topo0.coords.copy()
+        self.cells0 = np.ascontiguousarray(topo0.cells, dtype=np.int32)
+        self.NV, self.NT = topo0.nv, topo0.nt
+        self.NE = topo0.ne
+        self.NP = self.NV + self.NE
+        self.EMAX = int(emax)
+        self.polygon = np.ascontiguousarray(base.polygon, dtype=np.float64)
+        self.interp = base._interp
+        self.mu = base.flow_solver.mu
+        B, NV, NT, NP, N = self.B, self.NV, self.NT, self.NP, self.N
+        self.NAF = int(max((topo0.facet_tags() == 1).sum(), 1))
+        # host state
+        self.coords = np.zeros((B, NV, 2))
+        self.cells = np.zeros((B, NT, 3), np.int32)
+        self.nv = np.zeros(B, np.int32)
+        self.nt = np.zeros(B, np.int32)
+        self.offset = np.zeros(B, np.int32)
+        self.steps = np.zeros(B, np.int64)
+        self.initial_num_node = NV
+        # outputs of the topology engine
+        h = dict(ne=np.zeros(B, np.int32), cell_dofs=np.zeros((B, 6, NT), np.int32), points=np.zeros((B, NP, 2)),
+                 naf=np.zeros(B, np.int32), af_facets=np.zeros((B, self.NAF, 2), np.int32), nremovable=np.zeros(B, np.int32),
+                 nsel=np.zeros(B, np.int32), n_closest=np.zeros((B, N), np.int32), coord_map=np.zeros((B, N), np.int32),
+                 nedges=np.zeros(B, np.int32), edge_src=np.zeros((B, self.EMAX), np.int32),
+                 edge_dst=np.zeros((B, self.EMAX), np.int32), edge_len=np.zeros((B, self.EMAX)))
+        self.h = h
+        d = _lib.EnvTopoDesc()
+        d.B, d.NV, d.NT, d.NP, d.NAF, d.N, d.EMAX, d.npoly = B, NV, NT, NP, self.NAF, N, self.EMAX, self.polygon.shape[0]
+        d.coords, d.cells, d.nv, d.nt = (a.ctypes.data for a in (self.coords, self.cells, self.nv, self.nt))
+        d.offset, d.polygon = self.offset.ctypes.data, self.polygon.ctypes.data
+        for k, a in h.items():
+            setattr(d, k, a.ctypes.data)
+        self.topo_desc = d
+        self.new_drags = np.zeros((B, self.S))
+        self.new_lifts = np.zeros((B, self.S))
+        self.reset_all()
+
+    # ------------------------------------------------------------------
+    def _reset_env(self, b):
+        self.coords[b] = self.x0
+        self.cells[b] = self.cells0
+        self.nv[b], self.nt[b] = self.NV, self.NT
+        self.offset[b] = 0
+        self.steps[b] = 0
+
+    def reset_all(self):
+        for b in range(self.B):
+            self._reset_env(b)
+        self._refresh()
+        return self.get_state()
+
+    def _refresh(self):
+        """Topology + selection on the host, snapshot interpolation + forces on the GPU, for all envs."""
+        status = np.zeros(self.B, np.int32)
+        rc = self.lib.mdq_env_topology_host(C.byref(self.topo_desc), self.nthreads, status.ctypes.data)
+        _lib.check(rc, "mdq_env_topology_host")
+        if (status != 0).any():
+            raise _lib.MeshDQNHipError(f"topology engine failed: {status[status != 0]}")
+        dev, h = self.device, self.h
+        B, NV, NT, NP = self.B, self.NV, self.NT, self.NP
+        t_pts = torch.from_numpy(h["points"]).to(dev)
+        npts = torch.from_numpy(self.nv + h["ne"]).to(dev)
+        np1 = torch.from_numpy(self.nv).to(dev)
+        it = self.interp
+        out_u = torch.zeros((B, self.S, NP, 2), dtype=torch.float64, device=dev)
+        out_p = torch.zeros((B, self.S, NV), dtype=torch.float64, device=dev)
+        d = _lib.InterpDesc()
+        d.B, d.S, d.NP, d.NP1 = B, self.S, NP, NV
+        d.src_nv, d.src_nt, d.src_n2 = it.topo.nv, it.topo.nt, it.topo.np2
+        d.gnx, d.gny, d.x0, d.y0, d.inv_hx, d.inv_hy = it.grid
+        d.npts, d.np1, d.points = npts.data_ptr(), np1.data_ptr(), t_pts.data_ptr()
+        for k, v in it.t.items():
+            setattr(d, k, v.data_ptr())
+        d.out_u, d.out_p, d.out_cell = out_u.data_ptr(), out_p.data_ptr(), None
+        _lib.check(self.lib.mdq_interpolate_snapshots(C.byref(d), _lib.stream_ptr()), "mdq_interpolate_snapshots")
+        # forces: light mesh descriptor over the batch
+        md = _lib.IpcsDesc()
+        md.B, md.NV, md.NT, md.NE, md.N2, md.NAF = B, NV, NT, self.NE, NP, self.NAF
+        md.mu = self.mu
+        t_coords = torch.from_numpy(self.coords).to(dev)
+        keep = dict(coords=t_coords, cell_dofs=torch.from_numpy(h["cell_dofs"]).to(dev),
+                    af_facets=torch.from_numpy(h["af_facets"]).to(dev), nv=np1,
+                    nt=torch.from_numpy(self.nt).to(dev), ne=torch.from_numpy(h["ne"]).to(dev),
+                    naf=torch.from_numpy(h["naf"]).to(dev))
+        for k, v in keep.items():
+            setattr(md, k, v.data_ptr())
+        drag = torch.empty((B, self.S), dtype=torch.float64, device=dev)
+        lift = torch.empty_like(drag)
+        _lib.check(self.lib.mdq_probe_forces(C.byref(md), self.S, out_u.data_ptr(), out_p.data_ptr(), drag.data_ptr(),
+                                             lift.data_ptr(), _lib.stream_ptr()), "mdq_probe_forces")
+        self.u, self.p, self._coords_dev = out_u, out_p, t_coords
+        self.new_drags = drag.cpu().numpy()
+        self.new_lifts = lift.cpu().numpy()
+
+    # ------------------------------------------------------------------
+    def get_state(self):
+        """dict of device tensors: x (B,N,2+3S) f32, esrc/edst (sumE,) i32 local ids, edge_ptr (B+1,) i32,
+        node_ptr (B+1,) i32 - directly consumable by the fused Q-network forward - plus host copies of
+        n_closest / coord_map / nedges."""
+        dev, h, B, N, S = self.device, self.h, self.B, self.N, self.S
+        nc = torch.from_numpy(h["n_closest"].astype(np.int64)).to(dev)  # (B,N)
+        bi = torch.arange(B, device=dev)[:, None]
+        x = torch.zeros((B, N, 2 + 3 * S), dtype=torch.float32, device=dev)
+        # the reference indexes every feature with n_closest (rank in the removable list), Env2DAirfoil.py:285-288
+        x[:, :, :2] = self._coords_dev[bi, nc].float()
+        vel = self.u[bi[:, :, None], torch.arange(S, device=dev)[None, :, None], nc[:, None, :]]  # (B,S,N,2)
+        x[:, :, 2:2 + 2 * S] = vel.reshape(B, N, 2 * S).float()  # raw reshape of the (S,N,2) block, as the reference does
+        prs = self.p[bi[:, :, None], torch.arange(S, device=dev)[None, :, None], nc[:, None, :]]  # (B,S,N)
+        x[:, :, 2 + 2 * S:] = prs.permute(0, 2, 1).float()
+        nsel = torch.from_numpy(h["nsel"].astype(np.int64)).to(dev)
+        x = x * (torch.arange(N, device=dev)[None, :] < nsel[:, None]).unsqueeze(-1)
+        ne = h["nedges"].astype(np.int64)
+        edge_ptr = np.zeros(B + 1, np.int32)
+        edge_ptr[1:] = np.cumsum(ne)
+        esrc = np.concatenate([h["edge_src"][b, :ne[b]] for b in range(B)]) if ne.sum() else np.zeros(0, np.int32)
+        edst = np.concatenate([h["edge_dst"][b, :ne[b]] for b in range(B)]) if ne.sum() else np.zeros(0, np.int32)
+        return dict(x=x, esrc=torch.from_numpy(esrc).to(dev), edst=torch.from_numpy(edst).to(dev),
+                    edge_ptr=torch.from_numpy(edge_ptr).to(dev),
+                    node_ptr=torch.arange(B + 1, dtype=torch.int32, device=dev) * N,
+                    n_closest=h["n_closest"].copy(), coord_map=h["coord_map"].copy(), nedges=h["nedges"].copy(),
+                    nsel=h["nsel"].copy())
+
+    # ------------------------------------------------------------------
+    def step(self, actions):
+        """actions (B,) ints in [0, N]; returns (state, rewards (B,), dones (B,), infos)."""
+        B, N, h = self.B, self.N, self.h
+        actions = np.asarray(actions).astype(np.int64)
+        rem = np.full(B, -1, np.int32)
+        code = np.zeros(B, np.int32)  # 0 ok, 2 broken (Env2DAirfoil.py:342-364)
+        for b in range(B):
+            a = actions[b]
+            if a == N:
+                self.offset[b] += 1
+            elif 0 <= a < h["nsel"][b]:
+                rem[b] = h["coord_map"][b, a]
+            else:
+                code[b] = 2  # KeyError in coord_map: "RAN OUT OF VERTICES"
+        status = remesh_batch(self.coords, self.cells, self.nv, self.nt, rem, 50, self.nthreads)
+        code[status != 0] = 2
+        self._refresh()
+        code[h["nsel"] < N] = 2  # out of vertices
+        rewards = np.zeros(B)
+        dones = np.zeros(B, bool)
+        drag_factor = -2 * np.log(0.5) / self.threshold
+        err = np.abs(self.gt_drag[None] - self.new_drags) / np.abs(self.gt_drag[None])
+        drag_reward = 2 * np.exp(-drag_factor * np.linalg.norm(err, axis=1)) - 1
+        time_reward = (self.initial_num_node - self.nv) * self.TIME_REWARD
+        acc = (np.abs(np.abs(self.gt_drag[None] - self.new_drags) / self.gt_drag[None]) > self.threshold).any(axis=1)
+        vert = self.nv < self.goal_vertices * self.initial_num_node
+        ok = code == 0
+        rewards[ok] = (drag_reward + time_reward)[ok]
+        dones[ok] = (acc | vert)[ok]
+        rewards[~ok] = self.NEGATIVE_REWARD
+        dones[~ok] = True
+        self.steps += 1
+        dones |= self.steps >= self.timesteps
+        infos = dict(code=code, nv=self.nv.copy(), new_drags=self.new_drags.copy(), new_lifts=self.new_lifts.copy())
+        if self.auto_reset and dones.any():
+            for b in np.flatnonzero(dones):
+                self._reset_env(b)
+            self._refresh()
+        return self.get_state(), rewards, dones, infos
