@@ -19,7 +19,96 @@
 
 #include "../../include/meshdqn_hip.h"
 
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+
 namespace mdq_host {
+
+// Persistent worker pool (created on first use, sized on demand): the batched engine is called once per
+// environment step, so per-call std::thread creation (~30 us each) would dominate at B = 128.
+class Pool {
+ public:
+  static Pool& get() {
+    static Pool p;
+    return p;
+  }
+  // run fn(i) for i in [0, n) on up to `nthreads` workers (the caller participates)
+  void parallel_for(int n, int nthreads, const std::function<void(int)>& fn) {
+    if (n <= 0) return;
+    if (nthreads <= 1 || n == 1) {
+      for (int i = 0; i < n; ++i) fn(i);
+      return;
+    }
+    std::unique_lock<std::mutex> call_lock(call_mu_);  // one parallel_for at a time
+    ensure(nthreads - 1);
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      fn_ = &fn;
+      next_ = 0;
+      n_ = n;
+      active_ = std::min<int>(nthreads - 1, (int)workers_.size());
+      pending_ = active_;
+      ++epoch_;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [&] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  Pool() = default;
+  ~Pool() {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      stop_ = true;
+      ++epoch_;
+    }
+    cv_.notify_all();
+    for (auto& t : workers_) t.join();
+  }
+  void ensure(int k) {
+    while ((int)workers_.size() < k) {
+      const int id = (int)workers_.size();
+      workers_.emplace_back([this, id] {
+        uint64_t seen = 0;
+        for (;;) {
+          {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return stop_ || (epoch_ != seen && id < active_); });
+            if (stop_) return;
+            seen = epoch_;
+          }
+          work();
+          {
+            std::lock_guard<std::mutex> g(mu_);
+            if (--pending_ == 0) done_cv_.notify_all();
+          }
+        }
+      });
+    }
+  }
+  void work() {
+    for (;;) {
+      int i;
+      {
+        std::lock_guard<std::mutex> g(mu_);
+        if (next_ >= n_) return;
+        i = next_++;
+      }
+      (*fn_)(i);
+    }
+  }
+  std::mutex mu_, call_mu_;
+  std::condition_variable cv_, done_cv_;
+  std::vector<std::thread> workers_;
+  const std::function<void(int)>* fn_ = nullptr;
+  int next_ = 0, n_ = 0, active_ = 0, pending_ = 0;
+  uint64_t epoch_ = 0;
+  bool stop_ = false;
+};
 
 struct EdgeMap {  // open addressing hash: key (a<b) -> value
   std::vector<int64_t> key;
@@ -329,21 +418,13 @@ extern "C" int mdq_remesh_host(int32_t B, int32_t NV, int32_t NT, double* coords
                                int32_t* nt, const int32_t* remove_idx, int32_t smooth_iters, int32_t nthreads,
                                int32_t* status) {
   if (B <= 0 || !coords || !cells || !nv || !nt || !remove_idx || !status) return mdq_set_error("mdq_remesh_host: bad arguments");
-  auto work = [&](int b0, int b1) {
-    for (int b = b0; b < b1; ++b)
-      status[b] = mdq_host::remesh_one(coords + (size_t)b * NV * 2, cells + (size_t)b * NT * 3, nv + b, nt + b,
-                                        remove_idx[b], smooth_iters);
-  };
   int T = nthreads > 0 ? nthreads : (int)std::thread::hardware_concurrency();
   if (T < 1) T = 1;
   if (T > B) T = B;
-  if (T == 1) {
-    work(0, B);
-  } else {
-    std::vector<std::thread> th;
-    for (int i = 0; i < T; ++i) th.emplace_back(work, (int)((int64_t)B * i / T), (int)((int64_t)B * (i + 1) / T));
-    for (auto& t : th) t.join();
-  }
+  mdq_host::Pool::get().parallel_for(B, T, [&](int b) {
+    status[b] = mdq_host::remesh_one(coords + (size_t)b * NV * 2, cells + (size_t)b * NT * 3, nv + b, nt + b,
+                                      remove_idx[b], smooth_iters);
+  });
   return 0;
 }
 
@@ -500,18 +581,9 @@ static int topology_one(const mdq_env_topo_desc& D, int b) {
 extern "C" int mdq_env_topology_host(const mdq_env_topo_desc* d, int32_t nthreads, int32_t* status) {
   if (!d || d->B <= 0 || !status) return mdq_set_error("mdq_env_topology_host: bad arguments");
   const mdq_env_topo_desc D = *d;
-  auto work = [&](int b0, int b1) {
-    for (int b = b0; b < b1; ++b) status[b] = mdq_host::topology_one(D, b);
-  };
   int T = nthreads > 0 ? nthreads : (int)std::thread::hardware_concurrency();
   if (T < 1) T = 1;
   if (T > D.B) T = D.B;
-  if (T == 1) {
-    work(0, D.B);
-  } else {
-    std::vector<std::thread> th;
-    for (int i = 0; i < T; ++i) th.emplace_back(work, (int)((int64_t)D.B * i / T), (int)((int64_t)D.B * (i + 1) / T));
-    for (auto& t : th) t.join();
-  }
+  mdq_host::Pool::get().parallel_for(D.B, T, [&](int b) { status[b] = mdq_host::topology_one(D, b); });
   return 0;
 }

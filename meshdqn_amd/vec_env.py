@@ -18,6 +18,7 @@ order than in the single-environment class.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -27,13 +28,28 @@ from .env import Env2DAirfoil
 from .mesh_ops import remesh_batch
 
 
+def _host_cores() -> int:
+    """Usable host cores: the cgroup CPU quota when one is set (the MI355X boxes expose 256 logical CPUs
+    under a 16-core quota), else the affinity mask.  The pool is sized 2x the quota: the mesh tasks are
+    uneven and the extra workers hide the tail."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, 2 * int(q) // int(per)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 class VecEnv2DAirfoil:
     def __init__(self, config, num_envs: int, compute_device="cuda", nthreads: int = 0, base_env: Env2DAirfoil | None = None,
                  auto_reset: bool = True, emax: int = 1536):
         self.lib = _lib.load()
         self.B = int(num_envs)
         self.device = torch.device(compute_device)
-        self.nthreads = int(nthreads)
+        # workers of the host engine's persistent pool (one environment per task)
+        self.nthreads = int(nthreads) if nthreads > 0 else max(1, min(_host_cores(), self.B))
         self.auto_reset = auto_reset
         base = base_env or Env2DAirfoil(config, compute_device=compute_device)
         self.base = base
@@ -97,7 +113,24 @@ class VecEnv2DAirfoil:
         for b in range(self.B):
             self._reset_env(b)
         self._refresh()
+        # every environment restarts from the same mesh: cache its derived data (row 0) for in-place resets
+        self._init_cache = dict(h={k: a[0].copy() for k, a in self.h.items()}, u=self.u[0].clone(), p=self.p[0].clone(),
+                                drags=self.new_drags[0].copy(), lifts=self.new_lifts[0].copy())
         return self.get_state()
+
+    def _restore_initial(self, idx):
+        """Reset environments `idx` in place from the cached initial-mesh data (no recomputation)."""
+        c = self._init_cache
+        for b in idx:
+            self._reset_env(b)
+            for k, a in self.h.items():
+                a[b] = c["h"][k]
+            self.new_drags[b] = c["drags"]
+            self.new_lifts[b] = c["lifts"]
+        ti = torch.as_tensor(np.asarray(idx), device=self.device)
+        self.u[ti] = c["u"]
+        self.p[ti] = c["p"]
+        self._coords_dev[ti] = torch.from_numpy(self.x0).to(self.device)
 
     def _refresh(self):
         """Topology + selection on the host, snapshot interpolation + forces on the GPU, for all envs."""
@@ -139,8 +172,8 @@ class VecEnv2DAirfoil:
         _lib.check(self.lib.mdq_probe_forces(C.byref(md), self.S, out_u.data_ptr(), out_p.data_ptr(), drag.data_ptr(),
                                              lift.data_ptr(), _lib.stream_ptr()), "mdq_probe_forces")
         self.u, self.p, self._coords_dev = out_u, out_p, t_coords
-        self.new_drags = drag.cpu().numpy()
-        self.new_lifts = lift.cpu().numpy()
+        self.new_drags = drag.cpu().numpy().copy()
+        self.new_lifts = lift.cpu().numpy().copy()
 
     # ------------------------------------------------------------------
     def get_state(self):
@@ -206,7 +239,5 @@ class VecEnv2DAirfoil:
         dones |= self.steps >= self.timesteps
         infos = dict(code=code, nv=self.nv.copy(), new_drags=self.new_drags.copy(), new_lifts=self.new_lifts.copy())
         if self.auto_reset and dones.any():
-            for b in np.flatnonzero(dones):
-                self._reset_env(b)
-            self._refresh()
+            self._restore_initial(np.flatnonzero(dones))
         return self.get_state(), rewards, dones, infos
