@@ -48,10 +48,77 @@ def cpu_baseline(budget_s=15.0, spinup=20):
         fs.evolve()
         n += 1
     dt = time.perf_counter() - t0
-    return dict(value=n / dt, unit="env steps/s", cores=1, kind="port",
-                sample=f"{n} FlowSolver.evolve() steps of 1 ys930 env (numpy/scipy oracle, sparse LU "
-                       f"back-substitution like the reference's MUMPS path), {dt:.1f} s on 1 core; "
-                       f"mesh smoothing / assembly / factorisation excluded")
+    out = dict(value=n / dt, unit="env steps/s", cores=1, kind="port",
+               sample=f"{n} FlowSolver.evolve() steps of 1 ys930 env (numpy/scipy oracle, sparse LU "
+                      f"back-substitution like the reference's MUMPS path), {dt:.1f} s on 1 core; "
+                      f"mesh smoothing / assembly / factorisation excluded")
+    # the same for S1 (reference-semantics env step: scipy Delaunay + smoothing + interpolation + probes + state)
+    from oracle.env import OracleEnv
+    agent = dict(solver_steps=20, episodes=10, timesteps=10000, threshold=0.001, N_closest=180, gt_drag=-1, gt_time=-1,
+                 u=-1, p=-1, time_reward=0.005, save_steps=4, goal_vertices=0.95, plot_dir="")
+    env = OracleEnv(z["coords"], z["cells"], agent)
+    env.get_state()
+    rng = np.random.default_rng(1370)
+    t0 = time.perf_counter()
+    for m in range(3):
+        env.step(int(rng.integers(0, 180)))
+    out["s1_value"] = 3 / (time.perf_counter() - t0)
+    out["s1_sample"] = "3 OracleEnv.step() calls of 1 ys930 env (python loops for interpolation / smoothing), 1 core"
+    return out
+
+
+def measure_s1(args, dev, dist, world):
+    """Unit of work S1: the reference-semantics Env2DAirfoil.step for every env of the batch - vertex
+    removal + Delaunay restoration + smooth(50) (host C++ pool), snapshot interpolation + 10 force integrals + state
+    (GPU), fused Q-network forward + epsilon-greedy action (GPU).  Returns env-steps/s over all ranks."""
+    import torch
+    from meshdqn_amd.airfoilgcnn import NodeRemovalNet
+    from meshdqn_amd.env import Env2DAirfoil
+    from meshdqn_amd.gcn_fused import FusedGcn
+    from meshdqn_amd.vec_env import VecEnv2DAirfoil
+    cfg = dict(flow_config=dict(flow_params=dict(mu=1e-3, rho=1.0, inflow="constant"),
+                                geometry_params=dict(mesh=os.path.join(ROOT, "tests", "golden", f"{args.mesh}.npz")),
+                                solver_params=dict(dt=0.001, solver_type="lu", smooth=True)),
+               agent_params=dict(solver_steps=args.s1_solver_steps, episodes=10, timesteps=10000, threshold=0.001,
+                                 N_closest=180, gt_drag=-1, gt_time=-1, u=-1, p=-1, time_reward=0.005,
+                                 save_steps=args.s1_solver_steps // 5, goal_vertices=0.95, plot_dir=""))
+    B = args.envs
+    venv = VecEnv2DAirfoil(cfg, B, compute_device=dev, base_env=Env2DAirfoil(cfg, compute_device=dev))
+    torch.manual_seed(0)
+    net = NodeRemovalNet(181, conv_width=128, topk=0.1)
+    net.set_num_nodes(17)
+    fused = FusedGcn(net.to(dev))
+    rng = np.random.default_rng(1370 + int(os.environ.get("RANK", "0")))
+    st = venv.get_state()
+
+    def one():
+        nonlocal st
+        q = fused.forward_arrays(st["x"], st["node_ptr"], st["esrc"], st["edst"], st["edge_ptr"], venv.N, venv.EMAX)
+        greedy = q.argmax(1).cpu().numpy()
+        acts = np.where(rng.random(B) < 0.5, rng.integers(0, 181, B), greedy)
+        st, _, _, _ = venv.step(acts)
+
+    for _ in range(3):
+        one()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.s1_steps):
+        one()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = tt.item()
+    return dict(value=world * B * args.s1_steps / el, unit="env steps/s", ms_per_batched_step=el / args.s1_steps * 1e3,
+                batched_steps=args.s1_steps, host_threads_per_rank=venv.nthreads,
+                what="S1 = reference-semantics Env2DAirfoil.step (remove vertex + Delaunay + smooth(50) on the host C++ "
+                     "pool; 5-snapshot interpolation + 10 force integrals + state graph + fused Q-forward on the GPU), "
+                     "epsilon = 0.5 policy, terminated envs reset in place; host-bound (mesh engine)")
 
 
 def main():
@@ -65,6 +132,8 @@ def main():
     ap.add_argument("--rtol", type=float, default=1e-10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--s1-steps", type=int, default=20, help="batched reference-semantics env steps (0 = skip)")
+    ap.add_argument("--s1-solver-steps", type=int, default=5000, help="IPCS steps of the ground-truth reset()")
     args = ap.parse_args()
 
     import torch
@@ -139,6 +208,8 @@ def main():
     survey_bytes = batch.algorithmic_bytes_per_step(iters2)  # SURVEY 8(d) assembled-CSR convention, whole step
     step_bytes = batch.implemented_bytes_per_step(iters2)     # bytes the implemented algorithm moves, whole step
 
+    s1 = measure_s1(args, dev, dist, world) if args.s1_steps > 0 else None
+
     if rank == 0:
         achieved = vel_bytes / (k_vel * 1e-3) / 1e9
         traffic = None
@@ -190,6 +261,7 @@ def main():
                                  "live in LDS/registers; the binding resources are FP64 VALU issue, LDS atomics and "
                                  "workgroup barriers on the B CUs in use (one CU per environment), not HBM"},
         }
+        res["rates"] = {"S2_ipcs_env_steps_per_s": res["value"], "S1_reference_step_env_steps_per_s": s1}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_budget)
         print(json.dumps(res), flush=True)

@@ -1,0 +1,132 @@
+"""Generates the derived golden vectors SURVEY.md section 8(c) lists, from OUR oracle (numpy/scipy):
+
+  oracle_flow.json      per mesh: facet-tag counts, BC-dof counts, drag / lift / |u|_2 / |p|_2 after IPCS steps
+                        1, 2, 3 and 1000, 2000, ..., 5000 (step 5000 is the reference-pinned KAT of kat_rows.json;
+                        the others are derived values that pin the oracle against regressions)
+  oracle_flow.npz       smoothed coordinates (mesh.smooth(50)), facet tags, u / p after step 3
+  oracle_episode.json   one scripted ys930 episode with 48 default_rng(1370) actions (>= 44 removals: crosses nv < 0.95 nv0):
+                        removed vertex ids, nv / nt, first selected ids, E, reward, new_drags / new_lifts
+  oracle_gcn.npz        a 180-node / 17-feature state graph + a 37-node graph, NodeRemovalNet(181,128,0.1) and
+                        AirfoilGCNN(64) outputs of the oracle networks under the closed-form weights of
+                        `formula_state_dict` (no RNG: reproducible on any torch build)
+
+Run from the repo root:  python tests/golden/make_oracle_fixtures.py        (~3 minutes on one core)
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+AGENT = dict(solver_steps=20, episodes=10, timesteps=10000, threshold=0.001, N_closest=180, gt_drag=-1, gt_time=-1,
+             u=-1, p=-1, time_reward=0.005, save_steps=4, goal_vertices=0.95, plot_dir="")
+FLOW_STEPS = [1, 2, 3, 1000, 2000, 3000, 4000, 5000]
+
+
+def formula_state_dict(module):
+    """Deterministic closed-form weights: w_k = 0.35*sin(0.731*k + 1.17*j) * cos(0.113*k) for the k-th element
+    of the j-th tensor of state_dict() (float64 -> float32)."""
+    import torch
+    sd = {}
+    for j, (name, v) in enumerate(module.state_dict().items()):
+        k = np.arange(v.numel(), dtype=np.float64)
+        w = 0.35 * np.sin(0.731 * k + 1.17 * j) * np.cos(0.113 * k)
+        sd[name] = torch.from_numpy(w.reshape(tuple(v.shape))).float()
+    return sd
+
+
+def formula_graph(n, e, feat, salt):
+    """Closed-form graph: features sin/cos lattice, edges (i*7+salt) % n -> (i*13+3*salt+1) % n (self loops skipped)."""
+    i = np.arange(n * feat, dtype=np.float64).reshape(n, feat)
+    x = (np.sin(0.37 * i + salt) + 0.5 * np.cos(0.011 * i * i)).astype(np.float32)
+    k = np.arange(e)
+    src, dst = (k * 7 + salt) % n, (k * 13 + 3 * salt + 1) % n
+    keep = src != dst
+    return x, np.stack([src[keep], dst[keep]]).astype(np.int64)
+
+
+def flow_fixtures():
+    from oracle.ipcs import OracleFlowSolver
+    meta, arrays = {}, {}
+    for name in ("ys930", "ah93w145"):
+        z = np.load(os.path.join(HERE, f"{name}.npz"))
+        o = OracleFlowSolver(z["coords"], z["cells"])
+        tags = o.mesh.facet_tags()
+        rec = dict(nv=int(o.mesh.nv), nt=int(o.mesh.nt), ne=int(o.mesh.ne),
+                   tag_counts=[int((np.asarray(list(tags.values())) == t).sum()) for t in range(4)],
+                   n_bcu=int(len(o.th.bcu_dofs)), n_bcp=int(len(o.th.bcp_dofs)),
+                   n_removable=int(np.count_nonzero(o.removable)), steps={})
+        arrays[f"{name}_coords_smoothed"] = o.mesh.coords.copy()
+        for s in range(1, 5001):
+            u, p, d, l = o.evolve()
+            if s in FLOW_STEPS:
+                rec["steps"][str(s)] = dict(drag=float(d), lift=float(l), u_norm=float(np.linalg.norm(u)),
+                                            p_norm=float(np.linalg.norm(p)))
+            if s == 3:
+                arrays[f"{name}_u3"] = u.copy()
+                arrays[f"{name}_p3"] = p.copy()
+        meta[name] = rec
+        print(name, rec["steps"]["5000"], flush=True)
+    json.dump(meta, open(os.path.join(HERE, "oracle_flow.json"), "w"), indent=1)
+    np.savez_compressed(os.path.join(HERE, "oracle_flow.npz"), **arrays)
+
+
+def episode_fixture():
+    from oracle.env import OracleEnv
+    z = np.load(os.path.join(HERE, "ys930.npz"))
+    env = OracleEnv(z["coords"], z["cells"], AGENT)
+    s0 = env.get_state()
+    rec = dict(mesh="ys930", agent_params=AGENT, seed=1370, gt_drag=env.gt_drag.tolist(), gt_lift=env.gt_lift.tolist(),
+               E0=int(s0["edge_index"].shape[1]), n_closest0=[int(v) for v in env.n_closest[:16]], steps=[])
+    rng = np.random.default_rng(1370)
+    # the 20-step ground truth makes every removal "terminal" (drag off by > 0.1 %): the script keeps stepping, as
+    # the parity tests do, until the vertex-count criterion (nv < 0.95 nv0) has also been crossed
+    while len(rec["steps"]) < 48:
+        a = int(rng.integers(0, 181))
+        removed = int(env.coord_map.get(a, -1))
+        st, r, done, _ = env.step(a)
+        rec["steps"].append(dict(action=a, removed_vertex=removed, nv=int(env.flow.mesh.nv), nt=int(env.flow.mesh.nt),
+                                 E=int(st["edge_index"].shape[1]), coord_map_head=[int(env.coord_map[i]) for i in range(8)],
+                                 reward=float(r), done=bool(done), new_drags=[float(v) for v in getattr(env, 'new_drags', [])],
+                                 new_lifts=[float(v) for v in getattr(env, 'new_lifts', [])],
+                                 x_sum=float(np.asarray(st["x"], dtype=np.float64).sum())))
+        print(len(rec["steps"]), a, removed, env.flow.mesh.nv, r, done, flush=True)
+    json.dump(rec, open(os.path.join(HERE, "oracle_episode.json"), "w"), indent=1)
+
+
+def gcn_fixture():
+    import torch
+    from oracle import gcn as ora
+    from meshdqn_amd.data import Batch, Data
+    graphs = []
+    arrays = {}
+    for g, (n, e, salt) in enumerate([(180, 372, 1), (180, 495, 2), (37, 60, 3)]):
+        x, ei = formula_graph(n, e, 17, salt)
+        arrays[f"x{g}"], arrays[f"ei{g}"] = x, ei
+        graphs.append(Data(x=torch.from_numpy(x), edge_index=torch.from_numpy(ei)))
+    batch = Batch.from_data_list(graphs)
+    with torch.no_grad():
+        net = ora.NodeRemovalNet(181, conv_width=128, topk=0.1)
+        net.set_num_nodes(17)
+        net.load_state_dict(formula_state_dict(net))
+        arrays["node_removal_q"] = net(batch).numpy()
+        arrays["node_removal_embedding"] = net(batch, embedding=True).numpy()
+        net2 = ora.AirfoilGCNN(conv_width=64)
+        net2.load_state_dict(formula_state_dict(net2))
+        arrays["airfoil_gcnn_out"] = net2(batch).numpy()
+    np.savez_compressed(os.path.join(HERE, "oracle_gcn.npz"), **arrays)
+    print("gcn", arrays["node_removal_q"].shape, arrays["airfoil_gcnn_out"].ravel())
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["gcn", "episode", "flow"]
+    if "gcn" in which:
+        gcn_fixture()
+    if "episode" in which:
+        episode_fixture()
+    if "flow" in which:
+        flow_fixtures()

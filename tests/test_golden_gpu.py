@@ -1,0 +1,132 @@
+"""GPU parity against the committed golden vectors (tests/golden/oracle_*.{json,npz}, kat_rows.json): nothing in
+this file executes the oracle - the HIP path is compared with stored numbers only."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle_util import interleaved_to_oracle_vel
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+FLOW = json.load(open(os.path.join(GOLDEN, "oracle_flow.json")))
+KAT = json.load(open(os.path.join(GOLDEN, "kat_rows.json")))
+NAMES = ["ys930", "ah93w145"]
+
+
+def _batch(meshes, **kw):
+    from meshdqn_amd.ipcs_batch import IpcsBatch, smooth_coords
+    from meshdqn_amd.topology import MeshTopology
+    topos = [MeshTopology(*meshes[n]) for n in NAMES]
+    xs = [smooth_coords(t, 50) for t in topos]
+    return IpcsBatch(topos, xs, device="cuda", **kw), topos, xs
+
+
+def test_first_steps_match_golden(meshes, lib_built):
+    z = np.load(os.path.join(GOLDEN, "oracle_flow.npz"))
+    batch, topos, xs = _batch(meshes, rtol=1e-12)
+    for b, n in enumerate(NAMES):
+        assert np.abs(xs[b] - z[f"{n}_coords_smoothed"]).max() < 1e-13
+    for s in (1, 2, 3):
+        drag, lift = batch.evolve(1)
+        torch.cuda.synchronize()
+        for b, n in enumerate(NAMES):
+            g = FLOW[n]["steps"][str(s)]
+            assert abs(drag[b, 0].item() - g["drag"]) < 1e-8 * abs(g["drag"])
+            assert abs(lift[b, 0].item() - g["lift"]) < 1e-8 * abs(g["lift"])
+    u = batch.u_n.cpu().numpy()
+    p = batch.p_n.cpu().numpy()
+    for b, n in enumerate(NAMES):
+        n2, nv = topos[b].nv + topos[b].ne, topos[b].nv
+        uo, po = z[f"{n}_u3"], z[f"{n}_p3"]
+        assert np.abs(interleaved_to_oracle_vel(u[b][:n2]) - uo).max() < 1e-8 * np.abs(uo).max()
+        assert np.abs(p[b][:nv] - po).max() < 1e-8 * np.abs(po).max()
+
+
+@pytest.mark.slow
+def test_trajectory_checkpoints_match_golden(meshes, lib_built):
+    """Default solver tolerances, 5000 steps from rest: every 1000th step against the derived vectors (1e-6) and
+    the last one against the reference CSV rows (north-star tolerance 1e-4, CSV print precision 5e-8)."""
+    batch, _, _ = _batch(meshes)
+    for k in range(1, 6):
+        for _ in range(10):
+            drag, lift = batch.evolve(100)
+        torch.cuda.synchronize()
+        for b, n in enumerate(NAMES):
+            g = FLOW[n]["steps"][str(1000 * k)]
+            assert abs(drag[b, -1].item() - g["drag"]) < 1e-6 * abs(g["drag"]), (n, k)
+            assert abs(lift[b, -1].item() - g["lift"]) < 1e-6 * abs(g["lift"]), (n, k)
+    for b, n in enumerate(NAMES):
+        assert abs(drag[b, -1].item() - KAT[n]["drag"]) < 1e-4 * abs(KAT[n]["drag"])
+        assert abs(lift[b, -1].item() - KAT[n]["lift"]) < 1e-4 * abs(KAT[n]["lift"])
+
+
+def _cfg(ep):
+    return dict(flow_config=dict(flow_params=dict(mu=1e-3, rho=1.0, inflow="constant"),
+                                 geometry_params=dict(mesh=os.path.join(GOLDEN, f"{ep['mesh']}.npz")),
+                                 solver_params=dict(dt=0.001, solver_type="lu", smooth=True, rtol=1e-12)),
+                agent_params=dict(ep["agent_params"]))
+
+
+def test_scripted_episode_matches_golden(lib_built):
+    """All 48 scripted actions (44+ removals, nv 876 -> 828) on the reference-surface environment."""
+    from meshdqn_amd.env import Env2DAirfoil
+    ep = json.load(open(os.path.join(GOLDEN, "oracle_episode.json")))
+    env = Env2DAirfoil(_cfg(ep))
+    assert np.allclose(env.gt_drag, ep["gt_drag"], rtol=1e-8, atol=0)
+    assert np.allclose(env.gt_lift, ep["gt_lift"], rtol=1e-8, atol=0)
+    s0 = env.get_state()
+    assert s0.edge_index.shape[1] == ep["E0"]
+    assert [int(v) for v in env.n_closest[:16]] == ep["n_closest0"]
+    for g in ep["steps"]:
+        removed = int(env.coord_map.get(g["action"], -1))
+        st, r, done, _ = env.step(g["action"])
+        assert removed == g["removed_vertex"]
+        mesh = env.flow_solver.mesh
+        assert (len(mesh.coordinates()), len(mesh.cells()), st.edge_index.shape[1]) == (g["nv"], g["nt"], g["E"])
+        assert [int(env.coord_map[i]) for i in range(8)] == g["coord_map_head"]
+        assert abs(r - g["reward"]) < 1e-6 and done == g["done"]
+        assert np.allclose(env.new_drags, g["new_drags"], rtol=1e-7, atol=0)
+        assert np.allclose(env.new_lifts, g["new_lifts"], rtol=1e-7, atol=0)
+        assert abs(float(st.x.double().sum()) - g["x_sum"]) < 1e-3
+
+
+def test_scripted_episode_batched_engine_matches_golden(lib_built):
+    """The same script through VecEnv2DAirfoil (C++ star re-triangulation instead of scipy Delaunay), B = 2."""
+    from meshdqn_amd.env import Env2DAirfoil
+    from meshdqn_amd.vec_env import VecEnv2DAirfoil
+    ep = json.load(open(os.path.join(GOLDEN, "oracle_episode.json")))
+    cfg = _cfg(ep)
+    venv = VecEnv2DAirfoil(cfg, 2, base_env=Env2DAirfoil(cfg), auto_reset=False, nthreads=2)
+    st = venv.get_state()
+    for g in ep["steps"]:
+        st, rew, done, info = venv.step([g["action"], 180])
+        assert info["nv"][0] == g["nv"] and info["nv"][1] == 876
+        assert st["coord_map"][0][:8].tolist() == g["coord_map_head"]
+        assert int(st["edge_ptr"][1] - st["edge_ptr"][0]) == g["E"]
+        assert np.allclose(info["new_drags"][0], g["new_drags"], rtol=1e-7, atol=0)
+        assert abs(rew[0] - g["reward"]) < 1e-6 and bool(done[0]) == g["done"]
+        assert abs(float(st["x"][0].double().sum()) - g["x_sum"]) < 1e-3
+
+
+def test_fused_gcn_matches_golden(lib_built):
+    sys.path.insert(0, GOLDEN)
+    from make_oracle_fixtures import formula_state_dict
+    from meshdqn_amd import airfoilgcnn as prod
+    from meshdqn_amd.data import Batch, Data
+    z = np.load(os.path.join(GOLDEN, "oracle_gcn.npz"))
+    graphs = [Data(x=torch.from_numpy(z[f"x{g}"]), edge_index=torch.from_numpy(z[f"ei{g}"])) for g in range(3)]
+    batch = Batch.from_data_list(graphs).to("cuda")
+    with torch.no_grad():
+        net = prod.NodeRemovalNet(181, conv_width=128, topk=0.1)
+        net.set_num_nodes(17)
+        net.load_state_dict(formula_state_dict(net))
+        q = net.cuda().forward_fused(batch).cpu().numpy()
+        assert np.abs(q - z["node_removal_q"]).max() < 2e-4 * np.abs(z["node_removal_q"]).max()
+        net2 = prod.AirfoilGCNN(conv_width=64)
+        net2.load_state_dict(formula_state_dict(net2))
+        y = net2.cuda().forward_fused(batch).cpu().numpy()
+        assert np.abs(y - z["airfoil_gcnn_out"]).max() < 2e-4 * np.abs(z["airfoil_gcnn_out"]).max()

@@ -1,0 +1,105 @@
+"""CPU: pins the oracle.  (1) against the reference's only known answers - the two CSV rows of
+tests/golden/kat_rows.json (drag / lift after 5000 IPCS steps, 7 printed digits); (2) against the derived vectors
+of tests/golden/oracle_*.{json,npz} (made by tests/golden/make_oracle_fixtures.py) so that a later edit of the
+oracle cannot drift silently."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+FLOW = json.load(open(os.path.join(GOLDEN, "oracle_flow.json")))
+KAT = json.load(open(os.path.join(GOLDEN, "kat_rows.json")))
+
+
+@pytest.mark.parametrize("name", ["ys930", "ah93w145"])
+def test_oracle_first_steps_and_setup_match_fixture(meshes, name):
+    from oracle.ipcs import OracleFlowSolver
+    z = np.load(os.path.join(GOLDEN, "oracle_flow.npz"))
+    o = OracleFlowSolver(*meshes[name])
+    rec = FLOW[name]
+    assert (o.mesh.nv, o.mesh.nt, o.mesh.ne) == (rec["nv"], rec["nt"], rec["ne"])
+    tags = np.asarray(list(o.mesh.facet_tags().values()))
+    assert [int((tags == t).sum()) for t in range(4)] == rec["tag_counts"]
+    assert (len(o.th.bcu_dofs), len(o.th.bcp_dofs)) == (rec["n_bcu"], rec["n_bcp"])
+    assert int(np.count_nonzero(o.removable)) == rec["n_removable"]
+    assert np.abs(o.mesh.coords - z[f"{name}_coords_smoothed"]).max() < 1e-14          # mesh.smooth(50)
+    for s in (1, 2, 3):
+        u, p, d, l = o.evolve()
+        g = rec["steps"][str(s)]
+        assert abs(d - g["drag"]) <= 1e-10 * abs(g["drag"]) and abs(l - g["lift"]) <= 1e-10 * abs(g["lift"])
+        assert abs(np.linalg.norm(u) - g["u_norm"]) <= 1e-10 * g["u_norm"]
+        assert abs(np.linalg.norm(p) - g["p_norm"]) <= 1e-10 * g["p_norm"]
+    assert np.abs(u - z[f"{name}_u3"]).max() <= 1e-10 * np.abs(u).max()
+    assert np.abs(p - z[f"{name}_p3"]).max() <= 1e-10 * np.abs(p).max()
+
+
+def test_fixture_step_5000_is_the_reference_csv_row():
+    """The fixture's last entry must itself reproduce the reference CSV rows to their 7 printed digits."""
+    for name in ("ys930", "ah93w145"):
+        g = FLOW[name]["steps"]["5000"]
+        assert abs(g["drag"] - KAT[name]["drag"]) < 5e-8
+        assert abs(g["lift"] - KAT[name]["lift"]) < 5e-8
+
+
+@pytest.mark.slow
+def test_oracle_5000_steps_reproduce_reference_csv_rows(meshes):
+    """The pin: oracle from rest, 5000 steps, vs `training_meshes/*.csv` rows (kat_rows.json).  ys930 only on the
+    CPU suite (about a minute); ah93w145 is covered by the fixture generator + the test above."""
+    from oracle.ipcs import OracleFlowSolver
+    o = OracleFlowSolver(*meshes["ys930"])
+    rec = FLOW["ys930"]["steps"]
+    for s in range(1, 5001):
+        u, p, d, l = o.evolve()
+        if str(s) in rec:
+            assert abs(d - rec[str(s)]["drag"]) <= 1e-9 * abs(d), s
+            assert abs(l - rec[str(s)]["lift"]) <= 1e-9 * abs(l), s
+    assert abs(d - KAT["ys930"]["drag"]) < 5e-8      # -0.1130622
+    assert abs(l - KAT["ys930"]["lift"]) < 5e-8      # -0.0462851
+
+
+def test_oracle_episode_prefix_matches_fixture(meshes):
+    from oracle.env import OracleEnv
+    ep = json.load(open(os.path.join(GOLDEN, "oracle_episode.json")))
+    env = OracleEnv(*meshes[ep["mesh"]], ep["agent_params"])
+    assert np.allclose(env.gt_drag, ep["gt_drag"], rtol=1e-10, atol=0)
+    s0 = env.get_state()
+    assert s0["edge_index"].shape[1] == ep["E0"]
+    assert [int(v) for v in env.n_closest[:16]] == ep["n_closest0"]
+    for g in ep["steps"][:4]:
+        removed = int(env.coord_map.get(g["action"], -1))
+        st, r, done, _ = env.step(g["action"])
+        assert removed == g["removed_vertex"]
+        assert (env.flow.mesh.nv, env.flow.mesh.nt, st["edge_index"].shape[1]) == (g["nv"], g["nt"], g["E"])
+        assert [int(env.coord_map[i]) for i in range(8)] == g["coord_map_head"]
+        assert abs(r - g["reward"]) < 1e-9 and done == g["done"]
+        assert np.allclose(env.new_drags, g["new_drags"], rtol=1e-9, atol=0)
+        assert abs(float(np.asarray(st["x"], dtype=np.float64).sum()) - g["x_sum"]) < 1e-3
+
+
+def test_gcn_oracle_and_module_match_fixture():
+    import sys
+    import torch
+    sys.path.insert(0, GOLDEN)
+    from make_oracle_fixtures import formula_graph, formula_state_dict
+    from meshdqn_amd import airfoilgcnn as prod
+    from meshdqn_amd.data import Batch, Data
+    from oracle import gcn as ora
+    z = np.load(os.path.join(GOLDEN, "oracle_gcn.npz"))
+    graphs = []
+    for g, (n, e, salt) in enumerate([(180, 372, 1), (180, 495, 2), (37, 60, 3)]):
+        x, ei = formula_graph(n, e, 17, salt)
+        assert np.array_equal(x, z[f"x{g}"]) and np.array_equal(ei, z[f"ei{g}"])
+        graphs.append(Data(x=torch.from_numpy(x), edge_index=torch.from_numpy(ei)))
+    batch = Batch.from_data_list(graphs)
+    for mod in (ora, prod):
+        with torch.no_grad():
+            net = mod.NodeRemovalNet(181, conv_width=128, topk=0.1)
+            net.set_num_nodes(17)
+            net.load_state_dict(formula_state_dict(net))
+            assert np.allclose(net(batch).numpy(), z["node_removal_q"], rtol=1e-4, atol=1e-7)
+            assert np.allclose(net(batch, embedding=True).numpy(), z["node_removal_embedding"], rtol=1e-4, atol=1e-5)
+            net2 = mod.AirfoilGCNN(conv_width=64)
+            net2.load_state_dict(formula_state_dict(net2))
+            assert np.allclose(net2(batch).numpy(), z["airfoil_gcnn_out"], rtol=1e-4, atol=1e-6)
