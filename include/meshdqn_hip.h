@@ -156,6 +156,17 @@ int64_t mdq_ipcs_workspace_doubles(int32_t B, int32_t NV, int32_t NT, int32_t NE
 int mdq_ipcs_assemble(const mdq_ipcs_desc* d, void* stream);
 
 /*
+ * Operator setup of the MATRIX-FREE path only (mode 3, CG pressure solver) - what `FlowSolver.remesh` would have to
+ * redo after every vertex removal (flow_solver.py:268-339 runs it in DEPLOY mode only): per-triangle geometry, the
+ * outflow-row blocks, Jacobi diagonals and Dirichlet lifting vectors of A1 / M accumulated row-wise from the element
+ * matrices (no global pattern), the scaled P1 Laplacian in SELL-64.  Needs from the descriptor: sizes, coords,
+ * cell_dofs, cell_outflow, g1_*, g2_*, sl1_off/sl1_col, bcu_*, bcp_flag, bo_* ; writes geom, bo_val, lift1, lift3,
+ * idiag1, sdiagM, sdiagK, K1s.  The pattern pointers (rowptr*, colidx*, asm*, sl2*) and A1/Ms may be NULL; such a
+ * descriptor is valid for mdq_ipcs_evolve with mode = 3 and pd_enabled = 0 only.
+ */
+int mdq_ipcs_setup_matfree(const mdq_ipcs_desc* d, void* stream);
+
+/*
  * Advance every environment by `nsteps` IPCS time steps.
  * Replaces `FlowSolver.evolve()` (flow_solver.py:362-396): per step three
  * right-hand-side assemblies, three linear solves (BiCGStab / CG / CG in place
@@ -281,6 +292,30 @@ int mdq_remesh_host(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* 
                     int32_t* nt, const int32_t* remove_idx, int32_t smooth_iters, int32_t nthreads,
                     int32_t* status);
 
+/* ---- optional outputs of mdq_env_topology_host: the index data of the matrix-free IPCS path (mode 3 with the CG
+ *      pressure solver) on every coarsened mesh, i.e. what FlowSolver.__init__/remesh derive from the mesh
+ *      (flow_solver.py:85-132,194-226) minus the assembled patterns.  Same layouts as the mdq_ipcs_desc fields of the
+ *      same names; feed them (uploaded) to mdq_ipcs_setup_matfree + mdq_ipcs_evolve. ---- */
+typedef struct mdq_ipcs_topo_out {
+  int32_t NBO, NBE, NSE1, _pad;  /* capacities: outflow rows, outflow entries, SELL-64 entries of the P1 Laplacian */
+  int32_t* mf_scat;       /* [B][6][NT]  dof | (outflow_edge+1) << 28 (word 0) */
+  int8_t* cell_outflow;   /* [B][NT]     local outflow facet or -1 */
+  uint8_t* bcu_flag;      /* [B][NP] */
+  double* bcu_gx;         /* [B][NP] */
+  uint8_t* bcp_flag;      /* [B][NV] */
+  int32_t* nbo;           /* [B] */
+  int32_t* bo_rows;       /* [B][NBO] */
+  int32_t* bo_ptr;        /* [B][NBO+1] */
+  int32_t* bo_col;        /* [B][NBE] */
+  int32_t* bo_src;        /* [B][NBE] */
+  int32_t* g1_ptr;        /* [B][NV+1] */
+  int32_t* g1_src;        /* [B][3*NT] */
+  int32_t* g2_ptr;        /* [B][NP+1] */
+  int32_t* g2_src;        /* [B][6*NT] */
+  int32_t* sl1_off;       /* [B][NV/64+2] */
+  int32_t* sl1_col;       /* [B][NSE1] */
+} mdq_ipcs_topo_out;
+
 /* ---- batched topology + N-closest selection + state graph (host arrays) ---- */
 typedef struct mdq_env_topo_desc {
   int32_t B, NV, NT, NP, NAF, N, EMAX, npoly;   /* capacities; N = N_closest; npoly = airfoil polygon points */
@@ -305,12 +340,14 @@ typedef struct mdq_env_topo_desc {
   int32_t* edge_src;        /* [B][EMAX] */
   int32_t* edge_dst;        /* [B][EMAX] */
   double* edge_len;         /* [B][EMAX] edge_attr */
+  const mdq_ipcs_topo_out* ipcs;  /* optional (NULL: skip) */
 } mdq_env_topo_desc;
 
 /*
  * Per environment: unique edges / P2 dof map / dof coordinates, boundary + airfoil facets, `removable`
  * (flow_solver.py:75-78 quirk), polygon distances + argsort + N-closest window (Env2DAirfoil.py:220-241,
- * 293-315) and the state graph edges (:258-280).  status[b] = 0 ok, <0 capacity exceeded.
+ * 293-315) and the state graph edges (:258-280).  status[b] = 0 ok, <0 capacity exceeded
+ * (-1 NP, -2 NAF, -3 EMAX, -4 more than 2 outflow rows per row-owner thread, -5 NBO/NBE, -6 NSE1).
  */
 int mdq_env_topology_host(const mdq_env_topo_desc* d, int32_t nthreads, int32_t* status);
 

@@ -71,7 +71,14 @@ class EnvTopoDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("B", "NV", "NT", "NP", "NAF", "N", "EMAX", "npoly")] + [
         (n, C.c_void_p) for n in ("coords", "cells", "nv", "nt", "offset", "polygon", "ne", "cell_dofs", "points", "naf",
                                   "af_facets", "nremovable", "nsel", "n_closest", "coord_map", "nedges", "edge_src",
-                                  "edge_dst", "edge_len")]
+                                  "edge_dst", "edge_len", "ipcs")]
+
+
+class IpcsTopoOut(C.Structure):
+    """Mirror of `mdq_ipcs_topo_out`."""
+    _fields_ = [(n, C.c_int32) for n in ("NBO", "NBE", "NSE1", "_pad")] + [
+        (n, C.c_void_p) for n in ("mf_scat", "cell_outflow", "bcu_flag", "bcu_gx", "bcp_flag", "nbo", "bo_rows", "bo_ptr",
+                                  "bo_col", "bo_src", "g1_ptr", "g1_src", "g2_ptr", "g2_src", "sl1_off", "sl1_col")]
 
 
 # every symbol include/meshdqn_hip.h declares: name -> (restype, argtypes)
@@ -80,6 +87,7 @@ SYMBOLS = {
     "mdq_last_error": (C.c_char_p, []),
     "mdq_ipcs_workspace_doubles": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "mdq_ipcs_assemble": (C.c_int, [C.POINTER(IpcsDesc), C.c_void_p]),
+    "mdq_ipcs_setup_matfree": (C.c_int, [C.POINTER(IpcsDesc), C.c_void_p]),
     "mdq_ipcs_evolve": (C.c_int, [C.POINTER(IpcsDesc), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdq_ipcs_evolve_timed": (C.c_int, [C.POINTER(IpcsDesc), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.POINTER(C.c_double)]),

@@ -457,6 +457,155 @@ static double polygon_distance(const double* poly, int np_, const double* p) {
   return d;
 }
 
+// Index data of the matrix-free IPCS path on one coarsened mesh (MeshTopology.boundary_conditions / facets /
+// dof_gathers / sell_layout + IpcsBatch._host_arrays restated for the batched engine; flow_solver.py:85-132,194-226).
+static int ipcs_topology_one(const mdq_env_topo_desc& D, const mdq_ipcs_topo_out& O, int b, int ne,
+                             const std::vector<int32_t>& ea, const std::vector<int32_t>& eb,
+                             const std::vector<int32_t>& ecnt, const std::vector<int32_t>& eown) {
+  const int nv = D.nv[b], nt = D.nt[b], n2 = nv + ne;
+  const double* x = D.coords + (size_t)b * D.NV * 2;
+  const int32_t* tri = D.cells + (size_t)b * D.NT * 3;
+  const int32_t* cd = D.cell_dofs + (size_t)b * 6 * D.NT;
+  int32_t* scat = O.mf_scat + (size_t)b * 6 * D.NT;
+  int8_t* cof = O.cell_outflow + (size_t)b * D.NT;
+  uint8_t* fl = O.bcu_flag + (size_t)b * D.NP;
+  double* gx = O.bcu_gx + (size_t)b * D.NP;
+  uint8_t* pf = O.bcp_flag + (size_t)b * D.NV;
+  std::fill(cof, cof + D.NT, (int8_t)-1);
+  std::fill(fl, fl + D.NP, (uint8_t)0);
+  std::fill(gx, gx + D.NP, 0.0);
+  std::fill(pf, pf + D.NV, (uint8_t)0);
+  // ---- facet tags: walls 0 / airfoil 1 / inflow 2 / outflow 3, later marks override (flow_solver.py:194-226)
+  const double E = 3.0e-16;
+  double bot = x[1], top = x[1];
+  for (int i = 1; i < nv; ++i) {
+    bot = std::min(bot, x[2 * i + 1]);
+    top = std::max(top, x[2 * i + 1]);
+  }
+  const double H = top - bot, Um = 1.5;
+  std::vector<int8_t> tag(ne, -1);
+  for (int e = 0; e < ne; ++e) {
+    if (ecnt[e] != 1) continue;
+    const double X[3] = {x[2 * ea[e]], x[2 * eb[e]], 0.5 * (x[2 * ea[e]] + x[2 * eb[e]])};
+    const double Y[3] = {x[2 * ea[e] + 1], x[2 * eb[e] + 1], 0.5 * (x[2 * ea[e] + 1] + x[2 * eb[e] + 1])};
+    bool walls = true, air = true, inflow = true, outflow = true;
+    for (int q = 0; q < 3; ++q) {
+      walls = walls && (Y[q] > 0.5 - 2 * E || Y[q] < -0.5 + 2 * E);
+      air = air && (X[q] < 3.0 - E && X[q] > -0.5 + E && Y[q] < 0.5 - E && Y[q] > -0.5 + E);
+      inflow = inflow && (X[q] < -0.5 + E);
+      outflow = outflow && (X[q] > 3.0 - 2 * E);
+    }
+    int t = 4;
+    if (walls) t = 0;
+    if (air) t = 1;
+    if (inflow) t = 2;
+    if (outflow) t = 3;
+    tag[e] = (int8_t)t;
+  }
+  // ---- Dirichlet data, list order [inlet, airfoil, walls]: later wins on shared dofs (flow_solver.py:123-132)
+  const int order[3] = {2, 1, 0};
+  for (int w = 0; w < 3; ++w)
+    for (int e = 0; e < ne; ++e) {
+      if (tag[e] != order[w]) continue;
+      const int dofs[3] = {ea[e], eb[e], nv + e};
+      for (int q = 0; q < 3; ++q) {
+        const int dq = dofs[q];
+        fl[dq] = 1;
+        if (order[w] == 2) {
+          const double y = q < 2 ? x[2 * dq + 1] : 0.5 * (x[2 * ea[e] + 1] + x[2 * eb[e] + 1]);
+          gx[dq] = -4.0 * Um * (y - bot) * (y - top) / H / H;
+        } else {
+          gx[dq] = 0.0;
+        }
+      }
+    }
+  // ---- outflow facets (edge-id order): pressure Dirichlet vertices, cell -> local facet, row list of the facet term
+  struct Ent {
+    int32_t row, col, src;
+    bool operator<(const Ent& o) const { return row != o.row ? row < o.row : (col != o.col ? col < o.col : src < o.src); }
+  };
+  std::vector<Ent> ent;
+  const int AL[3] = {1, 0, 0}, BL[3] = {2, 2, 1};
+  for (int e = 0; e < ne; ++e) {
+    if (tag[e] != 3) continue;
+    pf[ea[e]] = pf[eb[e]] = 1;
+    const int c = eown[e] / 3, k = eown[e] % 3;
+    cof[c] = (int8_t)k;
+    const int rows[3] = {AL[k], BL[k], 3 + k};
+    for (int q = 0; q < 3; ++q)
+      for (int j = 0; j < 6; ++j)
+        ent.push_back({cd[rows[q] * D.NT + c], cd[j * D.NT + c], c * 36 + rows[q] * 6 + j});
+  }
+  std::sort(ent.begin(), ent.end());
+  int32_t* bo_rows = O.bo_rows + (size_t)b * O.NBO;
+  int32_t* bo_ptr = O.bo_ptr + (size_t)b * (O.NBO + 1);
+  int32_t* bo_col = O.bo_col + (size_t)b * O.NBE;
+  int32_t* bo_src = O.bo_src + (size_t)b * O.NBE;
+  if ((int)ent.size() > O.NBE) return -5;
+  int nbo = 0;
+  int own[512];
+  std::fill(own, own + 512, 0);
+  bo_ptr[0] = 0;
+  for (size_t t = 0; t < ent.size(); ++t) {
+    if (t == 0 || ent[t].row != ent[t - 1].row) {
+      if (nbo >= O.NBO) return -5;
+      bo_rows[nbo++] = ent[t].row;
+      if (++own[ent[t].row % 512] > 2) return -4;
+    }
+    bo_col[t] = ent[t].col;
+    bo_src[t] = ent[t].src;
+    bo_ptr[nbo] = (int32_t)t + 1;
+  }
+  O.nbo[b] = nbo;
+  // ---- packed per-triangle metadata of the matrix-free operators
+  if (n2 > 4096) return -1;
+  for (int i = 0; i < 6; ++i)
+    for (int t = 0; t < nt; ++t) scat[i * D.NT + t] = cd[i * D.NT + t] | (i == 0 ? ((int32_t)(cof[t] + 1) << 28) : 0);
+  // ---- dof <- element-slot gathers (ascending slots)
+  auto gather = [&](int nl, int ndof, int32_t* ptr, int32_t* src) {
+    std::fill(ptr, ptr + ndof + 1, 0);
+    for (int t = 0; t < nt; ++t)
+      for (int i = 0; i < nl; ++i) ++ptr[cd[i * D.NT + t] + 1];
+    for (int i = 0; i < ndof; ++i) ptr[i + 1] += ptr[i];
+    std::vector<int32_t> fill(ptr, ptr + ndof);
+    for (int t = 0; t < nt; ++t)
+      for (int i = 0; i < nl; ++i) src[fill[cd[i * D.NT + t]]++] = t * nl + i;
+  };
+  int32_t* g1p = O.g1_ptr + (size_t)b * (D.NV + 1);
+  gather(3, nv, g1p, O.g1_src + (size_t)b * 3 * D.NT);
+  gather(6, n2, O.g2_ptr + (size_t)b * (D.NP + 1), O.g2_src + (size_t)b * 6 * D.NT);
+  // ---- SELL-64 pattern of the P1 Laplacian: row = {vertex} + neighbours, ascending; slice width = longest row
+  std::vector<int32_t> nptr(nv + 1, 0);
+  for (int e = 0; e < ne; ++e) {
+    ++nptr[ea[e] + 1];
+    ++nptr[eb[e] + 1];
+  }
+  for (int i = 0; i < nv; ++i) nptr[i + 1] += nptr[i] + 1;  // +1: the diagonal
+  std::vector<int32_t> cols(nptr[nv]), fillp(nptr.begin(), nptr.end() - 1);
+  for (int i = 0; i < nv; ++i) cols[fillp[i]++] = i;
+  for (int e = 0; e < ne; ++e) {
+    cols[fillp[ea[e]]++] = eb[e];
+    cols[fillp[eb[e]]++] = ea[e];
+  }
+  for (int i = 0; i < nv; ++i) std::sort(cols.begin() + nptr[i], cols.begin() + nptr[i + 1]);
+  int32_t* so = O.sl1_off + (size_t)b * (D.NV / 64 + 2);
+  int32_t* sc = O.sl1_col + (size_t)b * O.NSE1;
+  const int ns = (nv + 63) / 64;
+  so[0] = 0;
+  for (int s_ = 0; s_ < ns; ++s_) {
+    int w = 0;
+    for (int r = 64 * s_; r < std::min(nv, 64 * s_ + 64); ++r) w = std::max(w, nptr[r + 1] - nptr[r]);
+    so[s_ + 1] = so[s_] + 64 * w;
+    if (so[s_ + 1] > O.NSE1) return -6;
+    for (int l = 0; l < 64; ++l) {
+      const int r = 64 * s_ + l, rr = std::min(r, nv - 1);
+      const int len = r < nv ? nptr[r + 1] - nptr[r] : 0;
+      for (int j = 0; j < w; ++j) sc[so[s_] + 64 * j + l] = j < len ? cols[nptr[r] + j] : rr;  // padding: own row, value 0
+    }
+  }
+  return 0;
+}
+
 static int topology_one(const mdq_env_topo_desc& D, int b) {
   const int nv = D.nv[b], nt = D.nt[b];
   const double* x = D.coords + (size_t)b * D.NV * 2;
@@ -573,6 +722,7 @@ static int topology_one(const mdq_env_topo_desc& D, int b) {
     }
   }
   D.nedges[b] = E_;
+  if (D.ipcs) return ipcs_topology_one(D, *D.ipcs, b, ne, ea, eb, ecnt, eown);
   return 0;
 }
 

@@ -398,6 +398,149 @@ __global__ __launch_bounds__(WG) void assemble_kernel(mdq_ipcs_desc d) {
   }
 }
 
+// ================================================================== matrix-free operator setup
+//
+// Everything mode 3 (with the CG pressure solver) needs from a NEW mesh, without any global sparsity pattern:
+// geometry, outflow-row blocks, Jacobi diagonals and Dirichlet lifting vectors of A1 / M accumulated row-wise from
+// the element matrices (dof <- element-slot gathers g2/g1), the scaled + BC-eliminated P1 Laplacian in SELL-64.
+// Same numbers as assemble_kernel up to the summation order.  One workgroup per environment.
+__global__ __launch_bounds__(WG) void setup_matfree_kernel(mdq_ipcs_desc d) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const EnvView v = env_view(d, b);
+  const double a = d.rho / d.dt, mu = d.mu;
+  for (int e = tid; e < v.nt; e += WG) {
+    double X[3][2];
+    load_cell_coords(v, e, X);
+    const double J00 = X[1][0] - X[0][0], J01 = X[2][0] - X[0][0];
+    const double J10 = X[1][1] - X[0][1], J11 = X[2][1] - X[0][1];
+    const double det = J00 * J11 - J01 * J10;
+    v.geom[0 * v.NT + e] = J11 / det;
+    v.geom[1 * v.NT + e] = -J01 / det;
+    v.geom[2 * v.NT + e] = -J10 / det;
+    v.geom[3 * v.NT + e] = J00 / det;
+    v.geom[4 * v.NT + e] = fabs(det);
+  }
+  __syncthreads();
+  if (v.nbo > 0) {
+    const int nbe = v.bo_ptr[v.nbo];
+    for (int t = tid; t < nbe; t += WG) {
+      const int slot = v.bo_src[t];
+      const int e = slot / 36, ij = slot - e * 36, i = ij / 6, j = ij - i * 6;
+      const Geo g = load_geo(v, e);
+      double Bcd[2][2];
+      outflow_entry(v, e, v.cell_outflow[e], i, j, g, Bcd);
+      reinterpret_cast<double4*>(v.bo_val)[t] = make_double4(Bcd[0][0], Bcd[0][1], Bcd[1][0], Bcd[1][1]);
+    }
+  }
+  // ---- P2 rows: raw diagonals (kept in idiag1 / sdiagM until the outflow rows have been corrected) and lifts
+  for (int r = tid; r < v.n2; r += WG) {
+    double l1x = 0.0, l1y = 0.0, l3x = 0.0, dx = 0.0, dy = 0.0, dm = 0.0;
+    for (int s = v.g2_ptr[r]; s < v.g2_ptr[r + 1]; ++s) {
+      const int slot = v.g2_src[s];
+      const int e = slot / 6, i = slot - e * 6;
+      const Geo g = load_geo(v, e);
+      const double Ja[2][2] = {{g.j00, g.j01}, {g.j10, g.j11}};
+      for (int j = 0; j < 6; ++j) {
+        const int c = v.cell_dofs[j * v.NT + e];
+        const bool fc = v.bcu_flag[c] != 0;
+        if (j != i && !fc) continue;
+        const double m = g.det * c_tab.Mhat[i][j];
+        const double g00 = c_tab.Ghat[0][0][i][j], g01 = c_tab.Ghat[0][1][i][j];
+        const double g10 = c_tab.Ghat[1][0][i][j], g11 = c_tab.Ghat[1][1][i][j];
+        const double kxx = g.det * (Ja[0][0] * (Ja[0][0] * g00 + Ja[1][0] * g01) + Ja[1][0] * (Ja[0][0] * g10 + Ja[1][0] * g11));
+        const double kxy = g.det * (Ja[0][0] * (Ja[0][1] * g00 + Ja[1][1] * g01) + Ja[1][0] * (Ja[0][1] * g10 + Ja[1][1] * g11));
+        const double kyy = g.det * (Ja[0][1] * (Ja[0][1] * g00 + Ja[1][1] * g01) + Ja[1][1] * (Ja[0][1] * g10 + Ja[1][1] * g11));
+        const double L = kxx + kyy;
+        const double bx = a * m + 0.5 * mu * (L + kxx), bz = 0.5 * mu * kxy, bw = a * m + 0.5 * mu * (L + kyy);
+        if (j == i) {
+          dx += bx;
+          dy += bw;
+          dm += m;
+        }
+        if (fc) {
+          const double gx = v.bcu_gx[c];
+          l1x += bx * gx;
+          l1y += bz * gx;
+          l3x += m * gx;
+        }
+      }
+    }
+    v.lift1[r] = make_double2(l1x, l1y);
+    v.lift3[r] = make_double2(l3x, 0.0);
+    v.idiag1[r] = make_double2(dx, dy);
+    v.sdiagM[r] = dm;
+  }
+  __syncthreads();
+  // outflow rows: - mu/2 B on the diagonal and in the lifts (one thread per row: no conflicts)
+  for (int t = tid; t < v.nbo; t += WG) {
+    const int row = v.bo_rows[t];
+    double2 dg = v.idiag1[row], l1 = v.lift1[row];
+    for (int k = v.bo_ptr[t]; k < v.bo_ptr[t + 1]; ++k) {
+      const double4 bv = reinterpret_cast<const double4*>(v.bo_val)[k];
+      const int c = v.bo_col[k];
+      if (c == row) {
+        dg.x -= 0.5 * mu * bv.x;
+        dg.y -= 0.5 * mu * bv.w;
+      }
+      if (v.bcu_flag[c]) {
+        const double gx = v.bcu_gx[c];
+        l1.x -= 0.5 * mu * bv.x * gx;
+        l1.y -= 0.5 * mu * bv.z * gx;
+      }
+    }
+    v.idiag1[row] = dg;
+    v.lift1[row] = l1;
+  }
+  __syncthreads();
+  for (int r = tid; r < v.n2; r += WG) {
+    const bool fr = v.bcu_flag[r] != 0;
+    const double2 dg = v.idiag1[r];
+    v.idiag1[r] = fr ? make_double2(1.0, 1.0) : make_double2(1.0 / dg.x, 1.0 / dg.y);
+    v.sdiagM[r] = fr ? 1.0 : sqrt(v.sdiagM[r]);
+  }
+  // ---- P1 Laplacian: entry (r, c) = sum over the cells of r that contain c of |T| grad(l_r).grad(l_c)
+  auto k1_entry = [&](int r, int c) {
+    double kk = 0.0;
+    for (int s = v.g1_ptr[r]; s < v.g1_ptr[r + 1]; ++s) {
+      const int slot = v.g1_src[s];
+      const int e = slot / 3, i = slot - e * 3;
+      int j = -1;
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        if (v.cell_dofs[q * v.NT + e] == c) j = q;
+      if (j < 0) continue;
+      const Geo g = load_geo(v, e);
+      const double dix = sel3(i, -g.j00 - g.j10, g.j00, g.j10), diy = sel3(i, -g.j01 - g.j11, g.j01, g.j11);
+      const double djx = sel3(j, -g.j00 - g.j10, g.j00, g.j10), djy = sel3(j, -g.j01 - g.j11, g.j01, g.j11);
+      kk += 0.5 * g.det * (dix * djx + diy * djy);
+    }
+    return kk;
+  };
+  for (int r = tid; r < v.nv; r += WG) v.sdiagK[r] = v.bcp_flag[r] ? 1.0 : sqrt(k1_entry(r, r));
+  __syncthreads();
+  const int rows1 = ((v.nv + 63) >> 6) << 6;
+  for (int r = tid; r < rows1; r += WG) {
+    const int off = v.sl1_off[r >> 6];
+    const int width = (v.sl1_off[(r >> 6) + 1] - off) >> 6;
+    int prev = -1;
+    for (int j = 0; j < width; ++j) {
+      const int ps = off + j * 64 + (r & 63);
+      double kk = 0.0;
+      if (r < v.nv) {
+        const int c = v.sl1_col[ps];
+        if (c > prev) {  // real entry (columns ascend; the padding repeats the row index)
+          prev = c;
+          if (v.bcp_flag[r] || v.bcp_flag[c])
+            kk = (c == r) ? 1.0 : 0.0;
+          else
+            kk = k1_entry(r, c) / (v.sdiagK[r] * v.sdiagK[c]);
+        }
+      }
+      v.K1s[ps] = kk;
+    }
+  }
+}
+
 // ================================================================== element right-hand sides
 
 struct ElemIdx {
@@ -2914,6 +3057,21 @@ int mdq_ipcs_assemble(const mdq_ipcs_desc* d, void* stream) {
   hipLaunchKernelGGL(assemble_kernel, dim3(d->B), dim3(WG), 0, (hipStream_t)stream, *d);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail("assemble_kernel launch", e);
+  return 0;
+}
+
+int mdq_ipcs_setup_matfree(const mdq_ipcs_desc* d, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  if (!d->coords || !d->cell_dofs || !d->cell_outflow || !d->g1_ptr || !d->g1_src || !d->g2_ptr || !d->g2_src ||
+      !d->sl1_off || !d->sl1_col || !d->bcu_flag || !d->bcu_gx || !d->bcp_flag || !d->geom || !d->lift1 || !d->lift3 ||
+      !d->idiag1 || !d->sdiagM || !d->sdiagK || !d->K1s)
+    return fail_msg("mdq_ipcs_setup_matfree: incomplete descriptor");
+  if (d->nbo && (!d->bo_rows || !d->bo_ptr || !d->bo_col || !d->bo_src || !d->bo_val))
+    return fail_msg("mdq_ipcs_setup_matfree: outflow row list incomplete");
+  if (int rc = ensure_tables()) return rc;
+  hipLaunchKernelGGL(setup_matfree_kernel, dim3(d->B), dim3(WG), 0, (hipStream_t)stream, *d);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail("setup_matfree_kernel launch", e);
   return 0;
 }
 

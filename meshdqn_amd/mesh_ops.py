@@ -219,3 +219,62 @@ def remesh_batch(coords: np.ndarray, cells: np.ndarray, nv: np.ndarray, nt: np.n
                              rem.ctypes.data, int(smooth_iters), int(nthreads), status.ctypes.data)
     _lib.check(rc, "mdq_remesh_host")
     return status
+
+
+class HostTopologyBatch:
+    """Host arrays + descriptor of `mdq_env_topology_host` for B environments (capacities fixed at construction).
+
+    `h` holds the outputs (ne, cell_dofs, points, naf, af_facets, nremovable, nsel, n_closest, coord_map, nedges,
+    edge_src, edge_dst, edge_len); with `ipcs=True` also `hi`, the index data of the matrix-free IPCS path on every
+    mesh (mdq_ipcs_topo_out: mf_scat, cell_outflow, bcu_flag, bcu_gx, bcp_flag, nbo, bo_*, g1_*, g2_*, sl1_*)."""
+
+    def __init__(self, B, NV, NT, NE, NAF, N, EMAX, polygon, ipcs=False, nbo_cap=64, nse1_cap=0):
+        self.lib = _lib.load()
+        NP = NV + NE
+        self.B, self.NV, self.NT, self.NE, self.NP, self.NAF, self.N, self.EMAX = B, NV, NT, NE, NP, NAF, N, EMAX
+        self.polygon = np.ascontiguousarray(polygon, dtype=np.float64)
+        self.coords = np.zeros((B, NV, 2))
+        self.cells = np.zeros((B, NT, 3), np.int32)
+        self.nv = np.zeros(B, np.int32)
+        self.nt = np.zeros(B, np.int32)
+        self.offset = np.zeros(B, np.int32)
+        self.h = dict(ne=np.zeros(B, np.int32), cell_dofs=np.zeros((B, 6, NT), np.int32), points=np.zeros((B, NP, 2)),
+                      naf=np.zeros(B, np.int32), af_facets=np.zeros((B, NAF, 2), np.int32),
+                      nremovable=np.zeros(B, np.int32), nsel=np.zeros(B, np.int32), n_closest=np.zeros((B, N), np.int32),
+                      coord_map=np.zeros((B, N), np.int32), nedges=np.zeros(B, np.int32),
+                      edge_src=np.zeros((B, EMAX), np.int32), edge_dst=np.zeros((B, EMAX), np.int32),
+                      edge_len=np.zeros((B, EMAX)))
+        d = _lib.EnvTopoDesc()
+        d.B, d.NV, d.NT, d.NP, d.NAF, d.N, d.EMAX, d.npoly = B, NV, NT, NP, NAF, N, EMAX, self.polygon.shape[0]
+        d.coords, d.cells, d.nv, d.nt = (a.ctypes.data for a in (self.coords, self.cells, self.nv, self.nt))
+        d.offset, d.polygon = self.offset.ctypes.data, self.polygon.ctypes.data
+        for k, a in self.h.items():
+            setattr(d, k, a.ctypes.data)
+        self.hi = None
+        if ipcs:
+            NBO, NBE = int(nbo_cap), 6 * int(nbo_cap)
+            NSE1 = int(nse1_cap) if nse1_cap else 64 * 16 * (NV // 64 + 1)
+            self.NBO, self.NBE, self.NSE1 = NBO, NBE, NSE1
+            self.hi = dict(mf_scat=np.zeros((B, 6, NT), np.int32), cell_outflow=np.zeros((B, NT), np.int8),
+                           bcu_flag=np.zeros((B, NP), np.uint8), bcu_gx=np.zeros((B, NP)),
+                           bcp_flag=np.zeros((B, NV), np.uint8), nbo=np.zeros(B, np.int32),
+                           bo_rows=np.zeros((B, NBO), np.int32), bo_ptr=np.zeros((B, NBO + 1), np.int32),
+                           bo_col=np.zeros((B, NBE), np.int32), bo_src=np.zeros((B, NBE), np.int32),
+                           g1_ptr=np.zeros((B, NV + 1), np.int32), g1_src=np.zeros((B, 3 * NT), np.int32),
+                           g2_ptr=np.zeros((B, NP + 1), np.int32), g2_src=np.zeros((B, 6 * NT), np.int32),
+                           sl1_off=np.zeros((B, NV // 64 + 2), np.int32), sl1_col=np.zeros((B, NSE1), np.int32))
+            o = _lib.IpcsTopoOut()
+            o.NBO, o.NBE, o.NSE1 = NBO, NBE, NSE1
+            for k, a in self.hi.items():
+                setattr(o, k, a.ctypes.data)
+            self._ipcs_out = o
+            d.ipcs = C.cast(C.pointer(o), C.c_void_p)
+        self.desc = d
+
+    def run(self, nthreads=0):
+        status = np.zeros(self.B, np.int32)
+        _lib.check(self.lib.mdq_env_topology_host(C.byref(self.desc), int(nthreads), status.ctypes.data),
+                   "mdq_env_topology_host")
+        if (status != 0).any():
+            raise _lib.MeshDQNHipError(f"topology engine failed: env {np.flatnonzero(status)} status {status[status != 0]}")
+        return status

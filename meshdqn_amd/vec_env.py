@@ -25,7 +25,7 @@ import torch
 
 from . import _lib
 from .env import Env2DAirfoil
-from .mesh_ops import remesh_batch
+from .mesh_ops import HostTopologyBatch, remesh_batch
 
 
 def _host_cores() -> int:
@@ -44,13 +44,16 @@ def _host_cores() -> int:
 
 class VecEnv2DAirfoil:
     def __init__(self, config, num_envs: int, compute_device="cuda", nthreads: int = 0, base_env: Env2DAirfoil | None = None,
-                 auto_reset: bool = True, emax: int = 1536):
+                 auto_reset: bool = True, emax: int = 1536, flow_steps: int = 0, flow_rtol: float = 1e-10):
         self.lib = _lib.load()
         self.B = int(num_envs)
         self.device = torch.device(compute_device)
         # workers of the host engine's persistent pool (one environment per task)
         self.nthreads = int(nthreads) if nthreads > 0 else max(1, min(_host_cores(), self.B))
         self.auto_reset = auto_reset
+        # S3 ("north-star step"): after every remesh, `flow_steps` IPCS steps on the coarsened mesh warm-started
+        # from the interpolated last snapshot (0 = the reference's step, which never re-solves the flow)
+        self.flow_steps, self.flow_rtol = int(flow_steps), float(flow_rtol)
         base = base_env or Env2DAirfoil(config, compute_device=compute_device)
         self.base = base
         ap = config["agent_params"]
@@ -75,31 +78,72 @@ class VecEnv2DAirfoil:
         self.mu = base.flow_solver.mu
         B, NV, NT, NP, N = self.B, self.NV, self.NT, self.NP, self.N
         self.NAF = int(max((topo0.facet_tags() == 1).sum(), 1))
-        # host state
-        self.coords = np.zeros((B, NV, 2))
-        self.cells = np.zeros((B, NT, 3), np.int32)
-        self.nv = np.zeros(B, np.int32)
-        self.nt = np.zeros(B, np.int32)
-        self.offset = np.zeros(B, np.int32)
+        # host state + outputs of the topology engine
+        nbr_ptr = topo0.vertex_adjacency()[0]
+        deg = np.zeros(64 * (NV // 64 + 1), np.int64)
+        deg[:NV] = np.diff(nbr_ptr) + 1
+        nse1 = int(64 * deg.reshape(-1, 64).max(axis=1).sum())        # SELL-64 entries of the P1 Laplacian, initial mesh
+        self.topo = HostTopologyBatch(B, NV, NT, self.NE, self.NAF, N, self.EMAX, self.polygon, ipcs=self.flow_steps > 0,
+                                      nse1_cap=(int(1.2 * nse1) + 63) // 64 * 64)
+        if self.flow_steps > 0:
+            self._init_flow(base)
+        self.coords, self.cells, self.nv, self.nt, self.offset = (self.topo.coords, self.topo.cells, self.topo.nv,
+                                                                   self.topo.nt, self.topo.offset)
+        self.h = self.topo.h
         self.steps = np.zeros(B, np.int64)
         self.initial_num_node = NV
-        # outputs of the topology engine
-        h = dict(ne=np.zeros(B, np.int32), cell_dofs=np.zeros((B, 6, NT), np.int32), points=np.zeros((B, NP, 2)),
-                 naf=np.zeros(B, np.int32), af_facets=np.zeros((B, self.NAF, 2), np.int32), nremovable=np.zeros(B, np.int32),
-                 nsel=np.zeros(B, np.int32), n_closest=np.zeros((B, N), np.int32), coord_map=np.zeros((B, N), np.int32),
-                 nedges=np.zeros(B, np.int32), edge_src=np.zeros((B, self.EMAX), np.int32),
-                 edge_dst=np.zeros((B, self.EMAX), np.int32), edge_len=np.zeros((B, self.EMAX)))
-        self.h = h
-        d = _lib.EnvTopoDesc()
-        d.B, d.NV, d.NT, d.NP, d.NAF, d.N, d.EMAX, d.npoly = B, NV, NT, NP, self.NAF, N, self.EMAX, self.polygon.shape[0]
-        d.coords, d.cells, d.nv, d.nt = (a.ctypes.data for a in (self.coords, self.cells, self.nv, self.nt))
-        d.offset, d.polygon = self.offset.ctypes.data, self.polygon.ctypes.data
-        for k, a in h.items():
-            setattr(d, k, a.ctypes.data)
-        self.topo_desc = d
         self.new_drags = np.zeros((B, self.S))
         self.new_lifts = np.zeros((B, self.S))
         self.reset_all()
+
+    # ------------------------------------------------------------------
+    def _init_flow(self, base):
+        """Device arrays + descriptor of the matrix-free IPCS path (mode 3, CG pressure) over the batch."""
+        dev, tp = self.device, self.topo
+        B, NV, NT, NE, NP = self.B, self.NV, self.NT, self.NE, self.NP
+        t = {k: torch.from_numpy(a).to(dev) for k, a in tp.hi.items()}
+
+        def z(*shape):
+            return torch.zeros(shape, dtype=torch.float64, device=dev)
+
+        t.update(geom=z(B, 5, NT), bo_val=z(B, tp.NBE, 4), lift1=z(B, NP, 2), lift3=z(B, NP, 2), idiag1=z(B, NP, 2),
+                 sdiagM=z(B, NP), sdiagK=z(B, NV), K1s=z(B, tp.NSE1), u_n=z(B, NP, 2), p_n=z(B, NV))
+        nwork = int(self.lib.mdq_ipcs_workspace_doubles(B, NV, NT, NE))
+        t["work"] = z(nwork)
+        fs = base.flow_solver
+        d = _lib.IpcsDesc()
+        d.B, d.NV, d.NT, d.NE, d.N2, d.NAF = B, NV, NT, NE, NP, self.NAF
+        d.NSE1, d.NBO, d.NBE = tp.NSE1, tp.NBO, tp.NBE
+        d.mu, d.rho, d.dt, d.rtol = fs.mu, fs.rho, fs.dt_value, self.flow_rtol
+        d.maxit_u, d.maxit_p, d.maxit_m = 200, 4000, 200
+        d.mode, d.pd_enabled = 3, 0
+        for name, _typ in _lib.IpcsDesc._fields_:
+            if name in t:
+                setattr(d, name, t[name].data_ptr())
+        d.work_doubles = nwork
+        self.flow_t, self.flow_desc = t, d
+        self.flow_iters = torch.zeros((B, 3), dtype=torch.int32, device=dev)
+        self.flow_drag = np.zeros((B, self.flow_steps))
+        self.flow_lift = np.zeros((B, self.flow_steps))
+
+    def _flow(self, keep, out_u, out_p):
+        """`flow_steps` IPCS steps on every (coarsened) mesh, warm-started from the interpolated last snapshot."""
+        t, d, hi = self.flow_t, self.flow_desc, self.topo.hi
+        for k, a in hi.items():
+            t[k].copy_(torch.from_numpy(a), non_blocking=True)
+        for k in ("coords", "cell_dofs", "af_facets", "nv", "nt", "ne", "naf"):
+            setattr(d, k, keep[k].data_ptr())
+        t["u_n"].copy_(out_u[:, self.S - 1])
+        t["p_n"].copy_(out_p[:, self.S - 1])
+        t["work"].zero_()            # no initial-guess history on a new mesh
+        self.flow_iters.zero_()
+        _lib.check(self.lib.mdq_ipcs_setup_matfree(C.byref(d), _lib.stream_ptr()), "mdq_ipcs_setup_matfree")
+        drag = torch.empty((self.B, self.flow_steps), dtype=torch.float64, device=self.device)
+        lift = torch.empty_like(drag)
+        _lib.check(self.lib.mdq_ipcs_evolve(C.byref(d), self.flow_steps, drag.data_ptr(), lift.data_ptr(),
+                                            self.flow_iters.data_ptr(), _lib.stream_ptr()), "mdq_ipcs_evolve")
+        self._flow_keep = keep       # device buffers the descriptor points at
+        return drag, lift
 
     # ------------------------------------------------------------------
     def _reset_env(self, b):
@@ -134,11 +178,7 @@ class VecEnv2DAirfoil:
 
     def _refresh(self):
         """Topology + selection on the host, snapshot interpolation + forces on the GPU, for all envs."""
-        status = np.zeros(self.B, np.int32)
-        rc = self.lib.mdq_env_topology_host(C.byref(self.topo_desc), self.nthreads, status.ctypes.data)
-        _lib.check(rc, "mdq_env_topology_host")
-        if (status != 0).any():
-            raise _lib.MeshDQNHipError(f"topology engine failed: {status[status != 0]}")
+        self.topo.run(self.nthreads)
         dev, h = self.device, self.h
         B, NV, NT, NP = self.B, self.NV, self.NT, self.NP
         t_pts = torch.from_numpy(h["points"]).to(dev)
@@ -172,6 +212,9 @@ class VecEnv2DAirfoil:
         _lib.check(self.lib.mdq_probe_forces(C.byref(md), self.S, out_u.data_ptr(), out_p.data_ptr(), drag.data_ptr(),
                                              lift.data_ptr(), _lib.stream_ptr()), "mdq_probe_forces")
         self.u, self.p, self._coords_dev = out_u, out_p, t_coords
+        if self.flow_steps > 0:
+            fd, fl = self._flow(keep, out_u, out_p)
+            self.flow_drag, self.flow_lift = fd.cpu().numpy(), fl.cpu().numpy()
         self.new_drags = drag.cpu().numpy().copy()
         self.new_lifts = lift.cpu().numpy().copy()
 
@@ -238,6 +281,8 @@ class VecEnv2DAirfoil:
         self.steps += 1
         dones |= self.steps >= self.timesteps
         infos = dict(code=code, nv=self.nv.copy(), new_drags=self.new_drags.copy(), new_lifts=self.new_lifts.copy())
+        if self.flow_steps > 0:  # drag / lift of the re-solved flow on the coarsened meshes (before any auto-reset)
+            infos.update(flow_drag=self.flow_drag.copy(), flow_lift=self.flow_lift.copy())
         if self.auto_reset and dones.any():
             self._restore_initial(np.flatnonzero(dones))
         return self.get_state(), rewards, dones, infos

@@ -156,3 +156,39 @@ def test_vec_env_matches_single_envs(lib_built):
             if acts[b] != 180 or k > 0:
                 assert np.allclose(info["new_drags"][b], singles[b].new_drags, rtol=1e-8)
             assert info["nv"][b] == len(singles[b].flow_solver.mesh.coordinates())
+
+
+def test_vec_env_flow_step_matches_oracle(lib_built):
+    """S3: after every batched remesh, IPCS steps on the coarsened meshes (host-engine index data + pattern-free GPU
+    setup + matrix-free kernels, warm start = interpolated last snapshot) against the sparse-LU oracle solver built
+    on the very same mesh and started from the same fields."""
+    from meshdqn_amd.env import Env2DAirfoil
+    from meshdqn_amd.vec_env import VecEnv2DAirfoil
+    from oracle.ipcs import OracleFlowSolver
+    cfg = _config("ys930")
+    B, K = 2, 2
+    venv = VecEnv2DAirfoil(cfg, B, base_env=Env2DAirfoil(cfg), auto_reset=False, nthreads=2, flow_steps=K, flow_rtol=1e-12)
+    rngs = [np.random.default_rng(77 + b) for b in range(B)]
+    venv.get_state()
+    for k in range(3):
+        acts = [int(r.integers(0, 180)) for r in rngs]
+        st, rew, done, info = venv.step(acts)
+        assert info["flow_drag"].shape == (B, K)
+        it = venv.flow_iters.cpu().numpy()
+        assert (it > 0).all()
+        for b in range(B):
+            nv, nt = int(venv.nv[b]), int(venv.nt[b])
+            ne = int(venv.h["ne"][b])
+            n2 = nv + ne
+            o = OracleFlowSolver(venv.coords[b, :nv].copy(), venv.cells[b, :nt].copy(), smooth=False)
+            assert o.th.np2 == n2
+            u0 = venv.u[b, venv.S - 1, :n2].cpu().numpy()
+            o.u_n = np.concatenate([u0[:, 0], u0[:, 1]])
+            o.p_n = venv.p[b, venv.S - 1, :nv].cpu().numpy().copy()
+            for s in range(K):
+                uo, po, do, lo = o.evolve()
+                assert abs(info["flow_drag"][b, s] - do) < 1e-8 * abs(do), (k, b, s)
+                assert abs(info["flow_lift"][b, s] - lo) < 1e-8 * abs(lo), (k, b, s)
+            ug = venv.flow_t["u_n"][b, :n2].cpu().numpy()
+            assert np.abs(np.concatenate([ug[:, 0], ug[:, 1]]) - uo).max() < 1e-8 * np.abs(uo).max()
+            assert np.abs(venv.flow_t["p_n"][b, :nv].cpu().numpy() - po).max() < 1e-8 * np.abs(po).max()

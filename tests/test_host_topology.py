@@ -109,20 +109,69 @@ def test_pressure_direct_factors_reproduce_dense_solve(meshes):
         assert np.abs(x - xr).max() / np.abs(xr).max() < 1e-11
 
 
-def test_descriptor_layout_matches_c_header(tmp_path):
-    """ctypes mirror of mdq_ipcs_desc has the same size / field offsets as the C header."""
+@pytest.mark.parametrize("cname,pyname", [("mdq_ipcs_desc", "IpcsDesc"), ("mdq_interp_desc", "InterpDesc"),
+                                          ("mdq_env_topo_desc", "EnvTopoDesc"), ("mdq_ipcs_topo_out", "IpcsTopoOut")])
+def test_descriptor_layout_matches_c_header(tmp_path, cname, pyname):
+    """every ctypes mirror has the same size / field offsets as its struct in the C header."""
     import ctypes as C, os, subprocess
     from meshdqn_amd import _lib
+    cls = getattr(_lib, pyname)
     hdr = os.path.join(os.path.dirname(_lib.HERE), "include", "meshdqn_hip.h")
-    fields = [n for n, _ in _lib.IpcsDesc._fields_]
+    fields = [n for n, _ in cls._fields_]
     src = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{hdr}"', 'int main(){',
-           'printf("%zu\\n", sizeof(mdq_ipcs_desc));']
-    src += [f'printf("%zu\\n", offsetof(mdq_ipcs_desc, {f}));' for f in fields]
+           f'printf("%zu\\n", sizeof({cname}));']
+    src += [f'printf("%zu\\n", offsetof({cname}, {f}));' for f in fields]
     src.append('return 0;}')
     cfile = tmp_path / "lay.c"
     cfile.write_text("\n".join(src))
     exe = tmp_path / "lay"
     subprocess.check_call(["gcc", str(cfile), "-o", str(exe)])
     vals = [int(x) for x in subprocess.check_output([str(exe)]).decode().split()]
-    assert vals[0] == C.sizeof(_lib.IpcsDesc)
-    assert vals[1:] == [getattr(_lib.IpcsDesc, f).offset for f in fields]
+    assert vals[0] == C.sizeof(cls)
+    assert vals[1:] == [getattr(cls, f).offset for f in fields]
+
+
+@pytest.mark.parametrize("name", ["ys930", "ah93w145"])
+def test_host_engine_topology_matches_python_topology(meshes, lib_built, name):
+    """C++ batched engine (mdq_env_topology_host incl. the matrix-free IPCS index data) against MeshTopology /
+    IpcsBatch._host_arrays on the smoothed mesh and on a mesh with one vertex removed."""
+    from meshdqn_amd.ipcs_batch import IpcsBatch, smooth_coords
+    from meshdqn_amd.mesh_ops import HostTopologyBatch, remesh_batch
+    coords, cells = meshes[name]
+    t0 = MeshTopology(coords, cells)
+    x0 = smooth_coords(t0, 50)
+    tags = t0.facet_tags(x0)
+    polygon = x0[[v for v in range(t0.nv) if t0.on_boundary[v] and -0.5 < x0[v, 0] < 3 and -0.5 < x0[v, 1] < 0.5]]
+    B = 2
+    hb = HostTopologyBatch(B, t0.nv, t0.nt, t0.ne, int((tags == 1).sum()), 180, 1536, polygon, ipcs=True)
+    for b in range(B):
+        hb.coords[b], hb.cells[b], hb.nv[b], hb.nt[b] = x0, np.sort(cells, axis=1), t0.nv, t0.nt
+    interior = np.flatnonzero(~t0.on_boundary)
+    status = remesh_batch(hb.coords, hb.cells, hb.nv, hb.nt, np.array([-1, interior[40]], np.int32), 50, 2)
+    assert (status == 0).all() and hb.nv.tolist() == [t0.nv, t0.nv - 1]
+    hb.run(2)
+    for b in range(B):
+        nv, nt = int(hb.nv[b]), int(hb.nt[b])
+        t = MeshTopology(hb.coords[b, :nv], hb.cells[b, :nt])
+        ref = IpcsBatch._host_arrays(t, hb.coords[b, :nv])
+        ne, n2 = t.ne, t.np2
+        assert hb.h["ne"][b] == ne
+        assert np.array_equal(hb.h["cell_dofs"][b][:, :nt], ref["cell_dofs_soa"])
+        hi = hb.hi
+        assert np.array_equal(hi["cell_outflow"][b][:nt], ref["cell_outflow"])
+        assert np.array_equal(hi["bcu_flag"][b][:n2], ref["bcu_flag"])
+        assert np.array_equal(hi["bcu_gx"][b][:n2], ref["bcu_gx"])       # same formula, same operation order
+        assert np.array_equal(hi["bcp_flag"][b][:nv], ref["bcp_flag"])
+        nbo = int(hi["nbo"][b])
+        assert nbo == ref["bo_rows"].size
+        assert np.array_equal(hi["bo_rows"][b][:nbo], ref["bo_rows"])
+        assert np.array_equal(hi["bo_ptr"][b][:nbo + 1], ref["bo_ptr"])
+        nbe = int(ref["bo_ptr"][-1])
+        assert np.array_equal(hi["bo_col"][b][:nbe], ref["bo_col"]) and np.array_equal(hi["bo_src"][b][:nbe], ref["bo_src"])
+        assert np.array_equal(hi["mf_scat"][b][:, :nt] & 0xFFF, ref["mf_scat"] & 0xFFF)
+        assert np.array_equal((hi["mf_scat"][b][0, :nt] >> 28) & 3, (ref["mf_scat"][0] >> 28) & 3)
+        assert np.array_equal(hi["g1_ptr"][b][:nv + 1], ref["g1_ptr"]) and np.array_equal(hi["g1_src"][b][:3 * nt], ref["g1_src"])
+        assert np.array_equal(hi["g2_ptr"][b][:n2 + 1], ref["g2_ptr"]) and np.array_equal(hi["g2_src"][b][:6 * nt], ref["g2_src"])
+        ns = (nv + 63) // 64
+        assert np.array_equal(hi["sl1_off"][b][:ns + 1], ref["sl1_off"])
+        assert np.array_equal(hi["sl1_col"][b][:ref["sl1_col"].size], ref["sl1_col"])

@@ -198,3 +198,37 @@ def test_refined_mesh_c5_assembled_path(meshes, lib_built):
     assert np.abs(ug - uo).max() / np.abs(uo).max() < 1e-8
     assert np.abs(batch.p_n[1, :nv].cpu().numpy() - po).max() / np.abs(po).max() < 1e-8
     assert abs(drag[0, 0].item() - do) / abs(do) < 1e-8 and abs(lift[1, 0].item() - lo) / abs(lo) < 1e-8
+
+
+def test_setup_matfree_matches_assemble(meshes, lib_built):
+    """mdq_ipcs_setup_matfree (pattern-free operator setup of the matrix-free path) reproduces what
+    mdq_ipcs_assemble writes: geometry, outflow blocks, Jacobi diagonals, lifting vectors, scaled P1 Laplacian."""
+    import ctypes as C
+    import torch
+    from meshdqn_amd import _lib
+    batch, topos, xs = _make(meshes, ["ys930", "ah93w145"], pressure_direct=False)
+    batch.assemble()
+    torch.cuda.synchronize()
+    keys = ["geom", "bo_val", "lift1", "lift3", "idiag1", "sdiagM", "sdiagK", "K1s"]
+    ref = {k: batch.t[k].clone() for k in keys}
+    for k in keys:
+        batch.t[k].fill_(float("nan"))
+    _lib.check(batch.lib.mdq_ipcs_setup_matfree(C.byref(batch.desc), _lib.stream_ptr()), "mdq_ipcs_setup_matfree")
+    torch.cuda.synchronize()
+    for b, t in enumerate(topos):
+        n2, nv, nt = t.np2, t.nv, t.nt
+        nbe = int(batch.host["bo_ptr"][b][batch.host["nbo"][b]])
+        nse1 = int(batch.host["sl1_off"][b][(nv + 63) // 64])
+        views = dict(geom=lambda a: a[b, :, :nt], bo_val=lambda a: a[b, :nbe], lift1=lambda a: a[b, :n2],
+                     lift3=lambda a: a[b, :n2], idiag1=lambda a: a[b, :n2], sdiagM=lambda a: a[b, :n2],
+                     sdiagK=lambda a: a[b, :nv], K1s=lambda a: a[b, :nse1])
+        for k in keys:
+            got, want = views[k](batch.t[k]).cpu().numpy(), views[k](ref[k]).cpu().numpy()
+            assert np.isfinite(got).all(), k
+            assert np.abs(got - want).max() <= 1e-12 * max(np.abs(want).max(), 1e-30), (k, b)
+    # and the matrix-free step on top of it equals the step on the assembled setup
+    d1, l1 = batch.evolve(2)
+    b2, _, _ = _make(meshes, ["ys930", "ah93w145"], pressure_direct=False)
+    d2, l2 = b2.evolve(2)
+    torch.cuda.synchronize()
+    assert torch.allclose(d1, d2, rtol=1e-9, atol=0) and torch.allclose(l1, l2, rtol=1e-9, atol=0)
