@@ -31,6 +31,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+_BASE_ENV = None
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -67,7 +68,7 @@ def cpu_baseline(budget_s=15.0, spinup=20):
     return out
 
 
-def measure_s1(args, dev, dist, world):
+def measure_env_steps(args, dev, dist, world, flow_steps=0):
     """Unit of work S1: the reference-semantics Env2DAirfoil.step for every env of the batch - vertex
     removal + Delaunay restoration + smooth(50) (host C++ pool), snapshot interpolation + 10 force integrals + state
     (GPU), fused Q-network forward + epsilon-greedy action (GPU).  Returns env-steps/s over all ranks."""
@@ -83,7 +84,10 @@ def measure_s1(args, dev, dist, world):
                                  N_closest=180, gt_drag=-1, gt_time=-1, u=-1, p=-1, time_reward=0.005,
                                  save_steps=args.s1_solver_steps // 5, goal_vertices=0.95, plot_dir=""))
     B = args.envs
-    venv = VecEnv2DAirfoil(cfg, B, compute_device=dev, base_env=Env2DAirfoil(cfg, compute_device=dev))
+    global _BASE_ENV
+    if _BASE_ENV is None:
+        _BASE_ENV = Env2DAirfoil(cfg, compute_device=dev)      # ground truth + snapshots: 5000 IPCS steps, once
+    venv = VecEnv2DAirfoil(cfg, B, compute_device=dev, base_env=_BASE_ENV, flow_steps=flow_steps, flow_rtol=args.rtol)
     torch.manual_seed(0)
     net = NodeRemovalNet(181, conv_width=128, topk=0.1)
     net.set_num_nodes(17)
@@ -114,11 +118,20 @@ def measure_s1(args, dev, dist, world):
         tt = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = tt.item()
-    return dict(value=world * B * args.s1_steps / el, unit="env steps/s", ms_per_batched_step=el / args.s1_steps * 1e3,
-                batched_steps=args.s1_steps, host_threads_per_rank=venv.nthreads,
-                what="S1 = reference-semantics Env2DAirfoil.step (remove vertex + Delaunay + smooth(50) on the host C++ "
-                     "pool; 5-snapshot interpolation + 10 force integrals + state graph + fused Q-forward on the GPU), "
-                     "epsilon = 0.5 policy, terminated envs reset in place; host-bound (mesh engine)")
+    what = ("S1 = reference-semantics Env2DAirfoil.step (remove vertex + Delaunay + smooth(50) on the host C++ "
+            "pool; 5-snapshot interpolation + 10 force integrals + state graph + fused Q-forward on the GPU), "
+            "epsilon = 0.5 policy, terminated envs reset in place; host-bound (mesh engine)")
+    out = dict(value=world * B * args.s1_steps / el, unit="env steps/s", ms_per_batched_step=el / args.s1_steps * 1e3,
+               batched_steps=args.s1_steps, host_threads_per_rank=venv.nthreads)
+    if flow_steps > 0:
+        it = venv.flow_iters.cpu().numpy().astype(np.float64) / flow_steps
+        what = (f"S3 = S1 + {flow_steps} IPCS step(s) on every coarsened mesh: host engine emits the matrix-free index "
+                "data, mdq_ipcs_setup_matfree rebuilds geometry / diagonals / lifting vectors / P1 Laplacian on the GPU, "
+                "mode-3 kernels with Jacobi-CG pressure, warm start = interpolated last snapshot")
+        out["krylov_iters_per_ipcs_step"] = {"velocity_bicgstab": float(it[:, 0].mean()), "pressure_cg": float(it[:, 1].mean()),
+                                             "correction_cg": float(it[:, 2].mean())}
+    out["what"] = what
+    return out
 
 
 def main():
@@ -208,7 +221,8 @@ def main():
     survey_bytes = batch.algorithmic_bytes_per_step(iters2)  # SURVEY 8(d) assembled-CSR convention, whole step
     step_bytes = batch.implemented_bytes_per_step(iters2)     # bytes the implemented algorithm moves, whole step
 
-    s1 = measure_s1(args, dev, dist, world) if args.s1_steps > 0 else None
+    s1 = measure_env_steps(args, dev, dist, world, 0) if args.s1_steps > 0 else None
+    s3 = measure_env_steps(args, dev, dist, world, 1) if args.s1_steps > 0 else None
 
     if rank == 0:
         achieved = vel_bytes / (k_vel * 1e-3) / 1e9
@@ -261,7 +275,8 @@ def main():
                                  "live in LDS/registers; the binding resources are FP64 VALU issue, LDS atomics and "
                                  "workgroup barriers on the B CUs in use (one CU per environment), not HBM"},
         }
-        res["rates"] = {"S2_ipcs_env_steps_per_s": res["value"], "S1_reference_step_env_steps_per_s": s1}
+        res["rates"] = {"S2_ipcs_env_steps_per_s": res["value"], "S1_reference_step_env_steps_per_s": s1,
+                        "S3_north_star_step_env_steps_per_s": s3}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_budget)
         print(json.dumps(res), flush=True)

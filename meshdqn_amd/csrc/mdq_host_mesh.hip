@@ -433,16 +433,34 @@ extern "C" int mdq_remesh_host(int32_t B, int32_t NV, int32_t NT, double* coords
 // (MeshTopology / Env2DAirfoil._n_closest / get_state restated for the batched engine).
 namespace mdq_host {
 
-static inline double seg_dist(const double* p, const double* a, const double* b) {
+// squared distance from p to the segment ab (same operations as shapely's / the oracle's point-segment distance
+// up to the final square root, which the caller applies once to the minimum: sqrt is monotone and correctly
+// rounded, so sqrt(min d2) == min sqrt(d2) bit for bit)
+static inline double seg_dist2(const double* p, const double* a, const double* b) {
   const double abx = b[0] - a[0], aby = b[1] - a[1];
   double t = ((p[0] - a[0]) * abx + (p[1] - a[1]) * aby) / (abx * abx + aby * aby);
   t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
   const double qx = a[0] + t * abx - p[0], qy = a[1] + t * aby - p[1];
-  return std::sqrt(qx * qx + qy * qy);
+  return qx * qx + qy * qy;
 }
 
-static double polygon_distance(const double* poly, int np_, const double* p) {
+// Segment lengths of the (fixed) airfoil polygon, once per call.
+struct PolyAux {
+  std::vector<double> len;
+  double maxlen = 0.0;
+  PolyAux(const double* poly, int np_) : len(np_) {
+    for (int i = 0; i < np_; ++i) {
+      const double* a = poly + 2 * i;
+      const double* b = poly + 2 * ((i + 1) % np_);
+      len[i] = std::sqrt((b[0] - a[0]) * (b[0] - a[0]) + (b[1] - a[1]) * (b[1] - a[1]));
+      maxlen = std::max(maxlen, len[i]);
+    }
+  }
+};
+
+static double polygon_distance(const double* poly, int np_, const PolyAux& aux, const double* p) {
   bool inside = false;
+  double v2min = 1e300;  // squared distance to the nearest polygon VERTEX: an upper bound of the answer
   for (int i = 0; i < np_; ++i) {
     const double* a = poly + 2 * i;
     const double* b = poly + 2 * ((i + 1) % np_);
@@ -450,11 +468,22 @@ static double polygon_distance(const double* poly, int np_, const double* p) {
       const double xin = a[0] + (p[1] - a[1]) * (b[0] - a[0]) / (b[1] - a[1]);
       if (p[0] < xin) inside = !inside;
     }
+    const double dx = p[0] - a[0], dy = p[1] - a[1];
+    v2min = std::min(v2min, dx * dx + dy * dy);
   }
   if (inside) return 0.0;
-  double d = 1e300;
-  for (int i = 0; i < np_; ++i) d = std::min(d, seg_dist(p, poly + 2 * i, poly + 2 * ((i + 1) % np_)));
-  return d;
+  // a segment whose start vertex is farther than len + sqrt(bound) away cannot hold the minimum (1e-9 safety
+  // margin on the squared comparison: pruning never decides between candidates that are that close)
+  const double rb = std::sqrt(v2min);
+  double d2 = 1e300;
+  for (int i = 0; i < np_; ++i) {
+    const double* a = poly + 2 * i;
+    const double dx = p[0] - a[0], dy = p[1] - a[1];
+    const double reach = aux.len[i] + rb;
+    if (dx * dx + dy * dy > reach * reach * (1.0 + 1e-9)) continue;
+    d2 = std::min(d2, seg_dist2(p, a, poly + 2 * ((i + 1) % np_)));
+  }
+  return std::sqrt(d2);
 }
 
 // Index data of the matrix-free IPCS path on one coarsened mesh (MeshTopology.boundary_conditions / facets /
@@ -684,7 +713,8 @@ static int topology_one(const mdq_env_topo_desc& D, int b) {
   D.nremovable[b] = nrem;
   // ---- N closest removable vertices to the airfoil polygon (argsort of the distances, window by offset)
   std::vector<double> dist(nrem);
-  for (int r = 0; r < nrem; ++r) dist[r] = polygon_distance(D.polygon, D.npoly, x + 2 * removable[r]);
+  const PolyAux aux(D.polygon, D.npoly);
+  for (int r = 0; r < nrem; ++r) dist[r] = polygon_distance(D.polygon, D.npoly, aux, x + 2 * removable[r]);
   std::vector<int32_t> order(nrem);
   for (int r = 0; r < nrem; ++r) order[r] = r;
   std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return dist[a] < dist[c]; });

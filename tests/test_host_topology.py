@@ -157,6 +157,13 @@ def test_host_engine_topology_matches_python_topology(meshes, lib_built, name):
         ne, n2 = t.ne, t.np2
         assert hb.h["ne"][b] == ne
         assert np.array_equal(hb.h["cell_dofs"][b][:, :nt], ref["cell_dofs_soa"])
+        # N-closest selection: polygon distances (numpy restatement), argsort, window of 180 (Env2DAirfoil.py:293-315)
+        from meshdqn_amd.mesh_ops import polygon_distance
+        removable = np.flatnonzero(t.removable(hb.coords[b, :nv]))
+        assert hb.h["nremovable"][b] == removable.size
+        order = np.argsort(polygon_distance(polygon, hb.coords[b, :nv][removable]), kind="stable")[:180]
+        assert np.array_equal(hb.h["n_closest"][b], order)
+        assert np.array_equal(hb.h["coord_map"][b], removable[order])
         hi = hb.hi
         assert np.array_equal(hi["cell_outflow"][b][:nt], ref["cell_outflow"])
         assert np.array_equal(hi["bcu_flag"][b][:n2], ref["bcu_flag"])
