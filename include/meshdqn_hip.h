@@ -292,6 +292,17 @@ int mdq_remesh_host(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* 
                     int32_t* nt, const int32_t* remove_idx, int32_t smooth_iters, int32_t nthreads,
                     int32_t* status);
 
+/*
+ * DOLFIN `Mesh.smooth(n)` (flow_solver.py:65-67 and 236-237 after every remesh) for B meshes on the GPU: Gauss-Seidel
+ * over the interior vertices in index order, each moved towards the centroid of its neighbours by at most half the
+ * minimum altitude of its cells; boundary vertices (an incident edge with one owner) are fixed.  One workgroup per
+ * mesh runs the exact sequential dependency graph as a dataflow machine in LDS.  coords [B][NV][2] (in/out),
+ * cells [B][NT][3], nv / nt [B], iterations [B] (0 = leave that mesh alone); all device pointers.
+ * Capacity: NV <= 1024, NT <= 2048 (larger meshes: mdq_smooth_host).
+ */
+int mdq_smooth(int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t* cells, const int32_t* nv,
+               const int32_t* nt, const int32_t* iterations, void* stream);
+
 /* ---- optional outputs of mdq_env_topology_host: the index data of the matrix-free IPCS path (mode 3 with the CG
  *      pressure solver) on every coarsened mesh, i.e. what FlowSolver.__init__/remesh derive from the mesh
  *      (flow_solver.py:85-132,194-226) minus the assembled patterns.  Same layouts as the mdq_ipcs_desc fields of the

@@ -3,4 +3,5 @@
 #include "mdq_ipcs.hip"
 #include "mdq_gcn.hip"
 #include "mdq_mesh.hip"
+#include "mdq_smooth.hip"
 #include "mdq_host_mesh.hip"

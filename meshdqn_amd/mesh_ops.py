@@ -278,3 +278,16 @@ class HostTopologyBatch:
         if (status != 0).any():
             raise _lib.MeshDQNHipError(f"topology engine failed: env {np.flatnonzero(status)} status {status[status != 0]}")
         return status
+
+
+def smooth_batch_gpu(coords: torch.Tensor, cells: torch.Tensor, nv: torch.Tensor, nt: torch.Tensor,
+                     iterations: torch.Tensor, stream=None) -> None:
+    """In-place `mesh.smooth(n)` of B meshes on the GPU (`mdq_smooth`): coords (B,NV,2) f8, cells (B,NT,3) i4,
+    nv / nt / iterations (B,) i4 device tensors; iterations[b] = 0 leaves mesh b untouched."""
+    lib = _lib.load()
+    B, NV = coords.shape[0], coords.shape[1]
+    NT = cells.shape[1]
+    assert coords.dtype == torch.float64 and cells.dtype == torch.int32 and coords.is_contiguous() and cells.is_contiguous()
+    assert nv.dtype == torch.int32 and nt.dtype == torch.int32 and iterations.dtype == torch.int32
+    _lib.check(lib.mdq_smooth(B, NV, NT, coords.data_ptr(), cells.data_ptr(), nv.data_ptr(), nt.data_ptr(),
+                              iterations.data_ptr(), _lib.stream_ptr(stream)), "mdq_smooth")

@@ -25,7 +25,7 @@ import torch
 
 from . import _lib
 from .env import Env2DAirfoil
-from .mesh_ops import HostTopologyBatch, remesh_batch
+from .mesh_ops import HostTopologyBatch, remesh_batch, smooth_batch_gpu
 
 
 def _host_cores() -> int:
@@ -44,13 +44,15 @@ def _host_cores() -> int:
 
 class VecEnv2DAirfoil:
     def __init__(self, config, num_envs: int, compute_device="cuda", nthreads: int = 0, base_env: Env2DAirfoil | None = None,
-                 auto_reset: bool = True, emax: int = 1536, flow_steps: int = 0, flow_rtol: float = 1e-10):
+                 auto_reset: bool = True, emax: int = 1536, flow_steps: int = 0, flow_rtol: float = 1e-10,
+                 gpu_smoothing: bool = True):
         self.lib = _lib.load()
         self.B = int(num_envs)
         self.device = torch.device(compute_device)
         # workers of the host engine's persistent pool (one environment per task)
         self.nthreads = int(nthreads) if nthreads > 0 else max(1, min(_host_cores(), self.B))
         self.auto_reset = auto_reset
+        self.gpu_smoothing = bool(gpu_smoothing)   # mdq_smooth (dataflow kernel) instead of the host loop
         # S3 ("north-star step"): after every remesh, `flow_steps` IPCS steps on the coarsened mesh warm-started
         # from the interpolated last snapshot (0 = the reference's step, which never re-solves the flow)
         self.flow_steps, self.flow_rtol = int(flow_steps), float(flow_rtol)
@@ -261,7 +263,17 @@ class VecEnv2DAirfoil:
                 rem[b] = h["coord_map"][b, a]
             else:
                 code[b] = 2  # KeyError in coord_map: "RAN OUT OF VERTICES"
-        status = remesh_batch(self.coords, self.cells, self.nv, self.nt, rem, 50, self.nthreads)
+        if self.gpu_smoothing:
+            # host: cavity re-triangulation + Delaunay restoration only; GPU: smooth(50) of the changed meshes
+            status = remesh_batch(self.coords, self.cells, self.nv, self.nt, rem, 0, self.nthreads)
+            dev = self.device
+            tc = torch.from_numpy(self.coords).to(dev)
+            its = torch.from_numpy(np.where((rem >= 0) & (status == 0), 50, 0).astype(np.int32)).to(dev)
+            smooth_batch_gpu(tc, torch.from_numpy(self.cells).to(dev), torch.from_numpy(self.nv).to(dev),
+                             torch.from_numpy(self.nt).to(dev), its)
+            self.coords[:] = tc.cpu().numpy()
+        else:
+            status = remesh_batch(self.coords, self.cells, self.nv, self.nt, rem, 50, self.nthreads)
         code[status != 0] = 2
         self._refresh()
         code[h["nsel"] < N] = 2  # out of vertices

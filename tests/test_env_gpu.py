@@ -192,3 +192,37 @@ def test_vec_env_flow_step_matches_oracle(lib_built):
             ug = venv.flow_t["u_n"][b, :n2].cpu().numpy()
             assert np.abs(np.concatenate([ug[:, 0], ug[:, 1]]) - uo).max() < 1e-8 * np.abs(uo).max()
             assert np.abs(venv.flow_t["p_n"][b, :nv].cpu().numpy() - po).max() < 1e-8 * np.abs(po).max()
+
+
+def test_gpu_smoothing_matches_host_and_golden(lib_built, meshes):
+    """mdq_smooth (dataflow Gauss-Seidel in LDS) vs the sequential host loop and the oracle's golden coordinates;
+    untouched meshes (iterations 0) stay bit-identical; results are bitwise reproducible."""
+    from meshdqn_amd.ipcs_batch import smooth_coords
+    from meshdqn_amd.mesh_ops import smooth_batch_gpu
+    from meshdqn_amd.topology import MeshTopology
+    z = np.load(os.path.join(GOLDEN, "oracle_flow.npz"))
+    names = ["ys930", "ah93w145", "ys930"]
+    NV = max(meshes[n][0].shape[0] for n in names)
+    NT = max(meshes[n][1].shape[0] for n in names)
+    B = len(names)
+    coords = np.zeros((B, NV, 2))
+    cells = np.zeros((B, NT, 3), np.int32)
+    nv = np.zeros(B, np.int32)
+    nt = np.zeros(B, np.int32)
+    for b, n in enumerate(names):
+        c, t = meshes[n]
+        coords[b, :len(c)], cells[b, :len(t)], nv[b], nt[b] = c, np.sort(t, axis=1), len(c), len(t)
+    iters = np.array([50, 50, 0], np.int32)
+    outs = []
+    for rep in range(2):
+        tc = torch.from_numpy(coords).cuda()
+        smooth_batch_gpu(tc, torch.from_numpy(cells).cuda(), torch.from_numpy(nv).cuda(), torch.from_numpy(nt).cuda(),
+                         torch.from_numpy(iters).cuda())
+        torch.cuda.synchronize()
+        outs.append(tc.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0][2], coords[2])
+    for b, n in enumerate(names[:2]):
+        host = smooth_coords(MeshTopology(*meshes[n]), 50)
+        assert np.abs(outs[0][b, :nv[b]] - host).max() < 1e-13
+        assert np.abs(outs[0][b, :nv[b]] - z[f"{n}_coords_smoothed"]).max() < 1e-13
