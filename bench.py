@@ -76,7 +76,7 @@ def measure_env_steps(args, dev, dist, world, flow_steps=0):
     from meshdqn_amd.airfoilgcnn import NodeRemovalNet
     from meshdqn_amd.env import Env2DAirfoil
     from meshdqn_amd.gcn_fused import FusedGcn
-    from meshdqn_amd.vec_env import VecEnv2DAirfoil
+    from meshdqn_amd.vec_env import VecEnvGroups
     cfg = dict(flow_config=dict(flow_params=dict(mu=1e-3, rho=1.0, inflow="constant"),
                                 geometry_params=dict(mesh=os.path.join(ROOT, "tests", "golden", f"{args.mesh}.npz")),
                                 solver_params=dict(dt=0.001, solver_type="lu", smooth=True)),
@@ -87,29 +87,27 @@ def measure_env_steps(args, dev, dist, world, flow_steps=0):
     global _BASE_ENV
     if _BASE_ENV is None:
         _BASE_ENV = Env2DAirfoil(cfg, compute_device=dev)      # ground truth + snapshots: 5000 IPCS steps, once
-    venv = VecEnv2DAirfoil(cfg, B, compute_device=dev, base_env=_BASE_ENV, flow_steps=flow_steps, flow_rtol=args.rtol)
+    G = args.env_groups
+    groups = VecEnvGroups(cfg, B, G, compute_device=dev, base_env=_BASE_ENV, flow_steps=flow_steps, flow_rtol=args.rtol)
     torch.manual_seed(0)
     net = NodeRemovalNet(181, conv_width=128, topk=0.1)
     net.set_num_nodes(17)
-    fused = FusedGcn(net.to(dev))
-    rng = np.random.default_rng(1370 + int(os.environ.get("RANK", "0")))
-    st = venv.get_state()
+    net = net.to(dev)
+    fused = [FusedGcn(net) for _ in groups.envs]
+    rank = int(os.environ.get("RANK", "0"))
+    rngs = [np.random.default_rng(1370 + 64 * rank + g) for g in range(len(groups.envs))]
 
-    def one():
-        nonlocal st
-        q = fused.forward_arrays(st["x"], st["node_ptr"], st["esrc"], st["edst"], st["edge_ptr"], venv.N, venv.EMAX)
+    def act(g, env, st):
+        q = fused[g].forward_arrays(st["x"], st["node_ptr"], st["esrc"], st["edst"], st["edge_ptr"], env.N, env.EMAX)
         greedy = q.argmax(1).cpu().numpy()
-        acts = np.where(rng.random(B) < 0.5, rng.integers(0, 181, B), greedy)
-        st, _, _, _ = venv.step(acts)
+        return np.where(rngs[g].random(env.B) < 0.5, rngs[g].integers(0, 181, env.B), greedy)
 
-    for _ in range(3):
-        one()
+    groups.rollout(act, 8)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.s1_steps):
-        one()
+    groups.rollout(act, args.s1_steps)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -118,13 +116,14 @@ def measure_env_steps(args, dev, dist, world, flow_steps=0):
         tt = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = tt.item()
-    what = ("S1 = reference-semantics Env2DAirfoil.step (remove vertex + Delaunay + smooth(50) on the host C++ "
-            "pool; 5-snapshot interpolation + 10 force integrals + state graph + fused Q-forward on the GPU), "
-            "epsilon = 0.5 policy, terminated envs reset in place; host-bound (mesh engine)")
+    venv = groups.envs[0]
+    what = ("S1 = reference-semantics Env2DAirfoil.step (remove vertex + Delaunay restoration on the host C++ "
+            "pool, smooth(50) as a dataflow kernel on the GPU; 5-snapshot interpolation + 10 force integrals + state "
+            "graph + fused Q-forward on the GPU), epsilon = 0.5 policy, terminated envs reset in place")
     out = dict(value=world * B * args.s1_steps / el, unit="env steps/s", ms_per_batched_step=el / args.s1_steps * 1e3,
-               batched_steps=args.s1_steps, host_threads_per_rank=venv.nthreads)
+               batched_steps=args.s1_steps, host_threads_per_rank=venv.nthreads, env_groups=len(groups.envs))
     if flow_steps > 0:
-        it = venv.flow_iters.cpu().numpy().astype(np.float64) / flow_steps
+        it = np.concatenate([e.flow_iters.cpu().numpy() for e in groups.envs]).astype(np.float64) / flow_steps
         what = (f"S3 = S1 + {flow_steps} IPCS step(s) on every coarsened mesh: host engine emits the matrix-free index "
                 "data, mdq_ipcs_setup_matfree rebuilds geometry / diagonals / lifting vectors / P1 Laplacian on the GPU, "
                 "mode-3 kernels with Jacobi-CG pressure, warm start = interpolated last snapshot")
@@ -145,7 +144,8 @@ def main():
     ap.add_argument("--rtol", type=float, default=1e-10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
-    ap.add_argument("--s1-steps", type=int, default=20, help="batched reference-semantics env steps (0 = skip)")
+    ap.add_argument("--s1-steps", type=int, default=50, help="batched reference-semantics env steps (0 = skip)")
+    ap.add_argument("--env-groups", type=int, default=4, help="concurrently stepped env groups per GPU for S1 / S3")
     ap.add_argument("--s1-solver-steps", type=int, default=5000, help="IPCS steps of the ground-truth reset()")
     args = ap.parse_args()
 

@@ -298,3 +298,52 @@ class VecEnv2DAirfoil:
         if self.auto_reset and dones.any():
             self._restore_initial(np.flatnonzero(dones))
         return self.get_state(), rewards, dones, infos
+
+
+class VecEnvGroups:
+    """`num_envs` environments as G independent `VecEnv2DAirfoil` groups, each driven by its own Python thread on
+    its own HIP stream - the counterpart of the reference's asynchronous Ray workers (`num_parallel`,
+    airfoil_dqn.py:428-503) inside one process: while one group waits for its GPU kernels (the smoothing kernel is
+    latency-bound and occupies only as many CUs as the group has environments) another group runs its host mesh
+    engine calls (ctypes and torch release the GIL).  All groups share one base environment (ground truth,
+    snapshots, interpolation grid)."""
+
+    def __init__(self, config, num_envs: int, groups: int = 2, compute_device="cuda", base_env: Env2DAirfoil | None = None, **kw):
+        self.device = torch.device(compute_device)
+        base = base_env or Env2DAirfoil(config, compute_device=compute_device)
+        G = max(1, min(int(groups), int(num_envs)))
+        sizes = [num_envs // G + (1 if g < num_envs % G else 0) for g in range(G)]
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(G)]
+        self.envs = []
+        for g in range(G):
+            with torch.cuda.stream(self.streams[g]):
+                self.envs.append(VecEnv2DAirfoil(config, sizes[g], compute_device=compute_device, base_env=base, **kw))
+        torch.cuda.synchronize(self.device)
+        self.B = int(num_envs)
+
+    def rollout(self, act_fn, steps: int, barrier=None):
+        """Every group runs `steps` batched steps concurrently: state -> act_fn(group, env, state) -> env.step.
+        Returns the list of per-group (rewards, dones) of the last step.  Exceptions of the workers are re-raised."""
+        import threading
+        out, errs = [None] * len(self.envs), []
+
+        def work(g):
+            try:
+                env = self.envs[g]
+                with torch.cuda.stream(self.streams[g]):
+                    st = env.get_state()
+                    for _ in range(steps):
+                        st, rew, done, info = env.step(act_fn(g, env, st))
+                    self.streams[g].synchronize()
+                    out[g] = (rew, done)
+            except BaseException as exc:  # noqa: BLE001 - surfaced to the caller below
+                errs.append(exc)
+
+        threads = [threading.Thread(target=work, args=(g,)) for g in range(len(self.envs))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errs:
+            raise errs[0]
+        return out

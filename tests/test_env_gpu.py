@@ -226,3 +226,41 @@ def test_gpu_smoothing_matches_host_and_golden(lib_built, meshes):
         host = smooth_coords(MeshTopology(*meshes[n]), 50)
         assert np.abs(outs[0][b, :nv[b]] - host).max() < 1e-13
         assert np.abs(outs[0][b, :nv[b]] - z[f"{n}_coords_smoothed"]).max() < 1e-13
+
+
+def test_env_groups_equal_one_batch(lib_built):
+    """G concurrently stepped groups (threads + streams) give the same trajectories as one batch stepped in place."""
+    from meshdqn_amd.env import Env2DAirfoil
+    from meshdqn_amd.vec_env import VecEnv2DAirfoil, VecEnvGroups
+    cfg = _config("ys930")
+    base = Env2DAirfoil(cfg)
+    B, G, K = 4, 2, 4
+    one = VecEnv2DAirfoil(cfg, B, base_env=base, auto_reset=False, nthreads=2, flow_steps=1)
+    grp = VecEnvGroups(cfg, B, G, base_env=base, auto_reset=False, nthreads=2, flow_steps=1)
+    script = np.random.default_rng(5).integers(0, 180, size=(K, B))
+    one.get_state()
+    ref = []
+    for k in range(K):
+        _, rew, done, info = one.step(script[k])
+        ref.append((rew.copy(), info["new_drags"].copy(), info["flow_drag"].copy(), info["nv"].copy()))
+    counters = [0] * G
+    got = [[] for _ in range(G)]
+
+    def act(g, env, st):
+        k = counters[g]
+        counters[g] += 1
+        if k > 0:
+            got[g].append((env.new_drags.copy(), env.flow_drag.copy(), env.nv.copy()))
+        lo = sum(e.B for e in grp.envs[:g])
+        return script[k, lo:lo + env.B]
+
+    out = grp.rollout(act, K)
+    for g, env in enumerate(grp.envs):
+        got[g].append((env.new_drags.copy(), env.flow_drag.copy(), env.nv.copy()))
+        lo = sum(e.B for e in grp.envs[:g])
+        for k in range(K):
+            nd, fd, nv = got[g][k]
+            assert np.array_equal(nv, ref[k][3][lo:lo + env.B])
+            assert np.allclose(nd, ref[k][1][lo:lo + env.B], rtol=1e-12, atol=0)
+            assert np.allclose(fd, ref[k][2][lo:lo + env.B], rtol=1e-9, atol=0)
+        assert np.allclose(out[g][0], ref[-1][0][lo:lo + env.B], rtol=1e-9)
