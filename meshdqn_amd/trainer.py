@@ -248,6 +248,17 @@ class DQNTrainer:
         net = (self.policy_net_1, self.policy_net_2)[k]
         net.zero_grad(set_to_none=True)
         loss = self._loss(transitions)
+        if not loss.requires_grad:
+            # every sampled transition is terminal while the target network is the trained one (select False):
+            # nothing depends on the parameters.  All ranks still join the all-reduce with a zero gradient.
+            flat = torch.zeros(sum(p.numel() for p in net.parameters()), device=self.ctx.device)
+            self.ctx.allreduce_mean_(flat)
+            net.set_flat_gradients(flat)
+            self.opts[k].step()
+            self.scheds[k].step()
+            self.num_grads += 1
+            self.losses.append(float(loss.item()))
+            return self.losses[-1]
         loss.backward()
         flat = net.flat_gradients()
         self.ctx.allreduce_mean_(flat)
@@ -310,3 +321,54 @@ def train_loop_per_worker(trainer: DQNTrainer, env_factory, num_episodes: int, m
         if max_steps is not None and total >= max_steps:
             break
     return history
+
+
+def state_to_data_list(st: dict, n_nodes: int) -> List[Data]:
+    """Split the batched state dict of `VecEnv2DAirfoil.get_state()` into per-environment `Data` objects
+    (x (N,F) f32, edge_index (2,E) i64 with node ids local to the graph) for the replay memory."""
+    ep = st["edge_ptr"].cpu().numpy()
+    esrc, edst = st["esrc"].long(), st["edst"].long()
+    out = []
+    for b in range(st["x"].shape[0]):
+        e0, e1 = int(ep[b]), int(ep[b + 1])
+        out.append(Data(x=st["x"][b], edge_index=torch.stack([esrc[e0:e1], edst[e0:e1]])))
+    return out
+
+
+def train_loop_vec(trainer: DQNTrainer, venv, num_steps: int, optim_per_step: int = 1, eps_decay=10000, eps_start=1.0,
+                   eps_end=0.01, share_replay=False, e_max=1536):
+    """Batched counterpart of `train_loop_per_worker` for one rank: B environments of a `VecEnv2DAirfoil` stepped
+    together (configs[3] of BASELINE.json: 128 envs per GPU, 1024 over 8 ranks).  Per batched step: fused Q-forward
+    of policy_net_1 for all B states, epsilon-greedy per environment (per-env step counters, like the reference's
+    per-worker `steps_done`), `venv.step`, B transitions into the replay ring (optionally all-gathered over the
+    ranks), `optim_per_step` optimiser steps (each with ONE flat gradient all-reduce).  Terminated environments are
+    reset in place by the vector env.  Returns dict(rewards (num_steps,B), dones, losses)."""
+    from .gcn_fused import FusedGcn
+    ctx = trainer.ctx
+    B, N = venv.B, venv.N
+    fused = FusedGcn(trainer.policy_net_1)
+    steps_done = np.zeros(B, np.int64)
+    st = venv.get_state()
+    rewards, dones_hist = [], []
+    for _ in range(num_steps):
+        with torch.no_grad():
+            q = fused.forward_arrays(st["x"], st["node_ptr"], st["esrc"], st["edst"], st["edge_ptr"], N, venv.EMAX)
+        greedy = q.argmax(1).cpu().numpy()
+        eps = eps_end + (eps_start - eps_end) * np.exp(-1.0 * steps_done / eps_decay)
+        steps_done += 1
+        explore = np.random.random(B) <= eps
+        actions = np.where(explore, np.random.randint(0, trainer.n_actions + 1, B), greedy)
+        prev = state_to_data_list(st, N)
+        st, rew, done, _ = venv.step(actions)
+        nxt = state_to_data_list(st, N)
+        trs = [Transition(prev[b], torch.tensor([[int(actions[b])]], dtype=torch.long), None if done[b] else nxt[b],
+                          torch.tensor([float(rew[b])], dtype=torch.float32)) for b in range(B)]
+        if share_replay and ctx.world > 1:
+            trs = allgather_transitions(ctx, trs, N, st["x"].shape[2], e_max)
+        for t in trs:
+            trainer.memory.push(*t)
+        for _k in range(optim_per_step):
+            trainer.optimize()
+        rewards.append(rew.copy())
+        dones_hist.append(done.copy())
+    return dict(rewards=np.array(rewards), dones=np.array(dones_hist), losses=list(trainer.losses))

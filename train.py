@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Multi-GPU counterpart of `python3 airfoil_dqn.py` (reference airfoil_dqn.py:343-514):
+
+    python train.py --config configs/ray_ys930.yaml                                   # 1 GPU
+    torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train.py --config ...   # 8 GPUs (RCCL)
+
+One process per GPU; every rank steps `--envs` environments (VecEnv2DAirfoil), all ranks apply the same
+all-reduced gradient, replay transitions are optionally all-gathered.  The yaml is the reference's own format
+(`flow_config`, `agent_params`, `optimizer`, `epsilon`); `geometry_params.mesh` may point at an .xdmf or .npz file."""
+import argparse
+import os
+
+import numpy as np
+import yaml
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", required=True)
+    ap.add_argument("--envs", type=int, default=128, help="environments per GPU")
+    ap.add_argument("--steps", type=int, default=1000, help="batched rollout steps")
+    ap.add_argument("--flow-steps", type=int, default=0, help="IPCS steps on the coarsened mesh per env step (S3)")
+    ap.add_argument("--share-replay", action="store_true")
+    ap.add_argument("--save-dir", default="training_results/run")
+    args = ap.parse_args()
+    from meshdqn_amd.env import Env2DAirfoil
+    from meshdqn_amd.trainer import DistContext, DQNTrainer, train_loop_vec
+    from meshdqn_amd.vec_env import VecEnv2DAirfoil
+    cfg = yaml.safe_load(open(args.config))
+    ctx = DistContext()
+    opt = cfg.get("optimizer", {})          # reference yaml sections: optimizer / epsilon (configs/ray_ys930.yaml)
+    eps = cfg.get("epsilon", {})
+    ap_ = cfg["agent_params"]
+    trainer = DQNTrainer(n_actions=int(ap_["N_closest"]), num_inputs=2 + 3 * (int(ap_["solver_steps"]) // int(ap_["save_steps"])),
+                         ctx=ctx, lr=float(opt.get("lr", 1e-5)), weight_decay=float(opt.get("weight_decay", 1e-6)),
+                         batch_size=int(opt.get("batch_size", 32)), gamma=float(eps.get("gamma", 1.0)),
+                         target_update=int(ap_.get("target_update", 50)))
+    base = Env2DAirfoil(cfg, compute_device=ctx.device)          # ground truth + snapshots (the reference's first reset())
+    venv = VecEnv2DAirfoil(cfg, args.envs, compute_device=ctx.device, base_env=base, flow_steps=args.flow_steps)
+    out = train_loop_vec(trainer, venv, args.steps, eps_decay=float(eps.get("decay", 10000)),
+                         eps_start=float(eps.get("start", 1.0)), eps_end=float(eps.get("end", 0.01)),
+                         share_replay=args.share_replay)
+    if ctx.rank == 0:
+        os.makedirs(args.save_dir, exist_ok=True)
+        trainer.save(args.save_dir)
+        np.save(os.path.join(args.save_dir, "rewards.npy"), out["rewards"])
+        np.save(os.path.join(args.save_dir, "losses.npy"), np.array(out["losses"]))
+        yaml.safe_dump(cfg, open(os.path.join(args.save_dir, "config.yaml"), "w"))
+        print(f"ranks {ctx.world}: {args.steps} batched steps x {args.envs} envs/rank, mean reward {out['rewards'].mean():.4f}")
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
