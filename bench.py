@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--s1-steps", type=int, default=50, help="batched reference-semantics env steps (0 = skip)")
+    ap.add_argument("--cell-order", default="conflictfree", choices=["mesh", "conflictfree"])
     ap.add_argument("--s1-warmup", type=int, default=40)
     ap.add_argument("--env-groups", type=int, default=4, help="concurrently stepped env groups per GPU for S1 / S3")
     ap.add_argument("--s1-solver-steps", type=int, default=5000, help="IPCS steps of the ground-truth reset()")
@@ -186,7 +187,7 @@ def main():
     topo = MeshTopology(z["coords"], z["cells"])
     x = smooth_coords(topo, 50)
     B = args.envs
-    batch = IpcsBatch([topo] * B, [x] * B, device=dev, rtol=args.rtol)
+    batch = IpcsBatch([topo] * B, [x] * B, device=dev, rtol=args.rtol, cell_order=args.cell_order)
     batch.assemble()
     out = (torch.empty((B, 1), dtype=torch.float64, device=dev), torch.empty((B, 1), dtype=torch.float64, device=dev))
     # developed flow state (untimed); single-step launches like the timed region so that the

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .topology import TAG_AIRFOIL, TAG_OUTFLOW, MeshTopology
+from .topology import conflict_free_cell_order, TAG_AIRFOIL, TAG_OUTFLOW, MeshTopology
 
 
 def smooth_coords(topo: MeshTopology, iterations: int = 50, coords: np.ndarray | None = None) -> np.ndarray:
@@ -41,7 +41,8 @@ class IpcsBatch:
     def __init__(self, topos: Sequence[MeshTopology], coords: Sequence[np.ndarray] | None = None,
                  mu: float = 1e-3, rho: float = 1.0, dt: float = 1e-3, rtol: float = 1e-10,
                  maxit=(200, 4000, 200), device: str | torch.device = "cuda", capacities: dict | None = None,
-                 mode: int = -1, pressure_direct: bool = True, pressure_parts: int = 16):
+                 mode: int = -1, pressure_direct: bool = True, pressure_parts: int = 16,
+                 cell_order: str = "conflictfree"):
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -50,6 +51,16 @@ class IpcsBatch:
         B = len(self.topos)
         if B == 0:
             raise ValueError("empty batch")
+        if cell_order == "conflictfree":
+            # internal cell order: the 64 cells a wave handles in one instruction share no dof, so the LDS atomics of
+            # the matrix-free kernels never collide inside an instruction (dof numbering and all vectors unchanged)
+            cache = {}
+            for t in self.topos:
+                if id(t) not in cache:
+                    cache[id(t)] = t.permuted(conflict_free_cell_order(t.cells))
+            self.topos = [cache[id(t)] for t in self.topos]
+        elif cell_order != "mesh":
+            raise ValueError("cell_order must be 'conflictfree' or 'mesh'")
         coords = [t.coords for t in self.topos] if coords is None else list(coords)
         self.B = B
         self.mu, self.rho, self.dt, self.rtol = float(mu), float(rho), float(dt), float(rtol)

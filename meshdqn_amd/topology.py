@@ -76,6 +76,22 @@ class MeshTopology:
         self.np2 = nv + self.ne
         self.cell_dofs = np.concatenate([c, nv + self.cell_edges], axis=1)
 
+    def permuted(self, perm: np.ndarray) -> "MeshTopology":
+        """Same mesh, same vertex / edge / dof numbering, cells stored in the order `perm` (new cell i = old cell
+        perm[i]).  Only the cell-indexed arrays change; vectors over dofs are unaffected."""
+        import copy
+        perm = np.asarray(perm, dtype=np.int64)
+        if perm.shape != (self.nt,) or not np.array_equal(np.sort(perm), np.arange(self.nt)):
+            raise ValueError("perm must be a permutation of the cells")
+        t = copy.copy(self)
+        inv = np.empty_like(perm)
+        inv[perm] = np.arange(self.nt)
+        t.cells = self.cells[perm]
+        t.cell_edges = self.cell_edges[perm]
+        t.cell_dofs = self.cell_dofs[perm]
+        t.edge_cell = inv[self.edge_cell]
+        return t
+
     # ------------------------------------------------------------------
     def vertex_adjacency(self):
         """CSR vertex->neighbour vertices (edge order) and vertex->(cell,local)."""
@@ -276,3 +292,36 @@ class MeshTopology:
     def dof_gathers(self):
         return dict(p2=self._dof_gather(self.cell_dofs, self.np2),
                     p1=self._dof_gather(self.cells, self.nv))
+
+
+def conflict_free_cell_order(cells: np.ndarray, edges_of_cells: np.ndarray | None = None, block: int = 64) -> np.ndarray:
+    """Permutation of the cells such that the cells of one block of `block` consecutive positions share no vertex
+    (hence no P2 dof): a wave of the matrix-free kernels (lane = cell position % 64 inside a round) then never issues
+    two LDS atomics to the same address in one instruction.  Greedy first-fit over blocks; cells that fit nowhere
+    (rare) fill the remaining holes.  Returns `perm` with new_cells = cells[perm]."""
+    nt = cells.shape[0]
+    nblocks = (nt + block - 1) // block
+    used = [set() for _ in range(nblocks)]
+    fill = [[] for _ in range(nblocks)]
+    cap = [min(block, nt - b * block) for b in range(nblocks)]
+    left = []
+    start = 0
+    for t in range(nt):
+        vs = cells[t]
+        placed = False
+        for k in range(nblocks):
+            b = (start + k) % nblocks
+            if len(fill[b]) < cap[b] and not (vs[0] in used[b] or vs[1] in used[b] or vs[2] in used[b]):
+                fill[b].append(t)
+                used[b].update((int(vs[0]), int(vs[1]), int(vs[2])))
+                placed = True
+                break
+        start = (start + 1) % nblocks
+        if not placed:
+            left.append(t)
+    for t in left:
+        for b in range(nblocks):
+            if len(fill[b]) < cap[b]:
+                fill[b].append(t)
+                break
+    return np.array([t for f in fill for t in f], dtype=np.int64)
