@@ -45,7 +45,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // Deterministic workgroup-wide sum of N values; every thread returns the same bits.
 // `lds` must hold NWAVE*N doubles.  Two barriers.
-template <int N>
+template <int N, int NW = NWAVE>
 __device__ __forceinline__ void block_sum(double (&v)[N], double* lds) {
 #pragma unroll
   for (int n = 0; n < N; ++n) v[n] = wave_sum(v[n]);
@@ -60,7 +60,7 @@ __device__ __forceinline__ void block_sum(double (&v)[N], double* lds) {
   for (int n = 0; n < N; ++n) {
     double s = 0.0;
 #pragma unroll
-    for (int i = 0; i < NWAVE; ++i) s += lds[i * N + n];
+    for (int i = 0; i < NW; ++i) s += lds[i * N + n];
     v[n] = s;
   }
 }
@@ -132,12 +132,12 @@ __device__ __forceinline__ Facet facet_geometry(const double (&X)[3][2], int k) 
 // One-barrier variant: `lds` holds two buffers of NWAVE*N doubles used alternately (`sel` flips on
 // every call, workgroup-uniformly).  A buffer is rewritten two calls later, i.e. after the barrier
 // of the call in between, which every thread passes only after it has finished reading.
-template <int N>
+template <int N, int NW = NWAVE>
 __device__ __forceinline__ void block_sum1(double (&v)[N], double* lds, int& sel) {
 #pragma unroll
   for (int n = 0; n < N; ++n) v[n] = wave_sum(v[n]);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  double* buf = lds + sel * (NWAVE * 2);
+  double* buf = lds + sel * (NW * 2);
   sel ^= 1;
   if (lane == 0) {
 #pragma unroll
@@ -148,7 +148,7 @@ __device__ __forceinline__ void block_sum1(double (&v)[N], double* lds, int& sel
   for (int n = 0; n < N; ++n) {
     double s = 0.0;
 #pragma unroll
-    for (int i = 0; i < NWAVE; ++i) s += buf[i * N + n];
+    for (int i = 0; i < NW; ++i) s += buf[i * N + n];
     v[n] = s;
   }
 }

@@ -11,6 +11,7 @@
 //   flow_solver.py:362-396  evolve()
 //   probes.py:23-50         drag / lift surface integrals
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <cmath>
 #include <cstdio>
@@ -1903,15 +1904,18 @@ static hipError_t launch_evolve_mf(const mdq_ipcs_desc* d, size_t lds, int nstep
 
 constexpr int AT_PAIR = 2;  // triangles interleaved per thread per round
 
-struct AtMeta {
-  int w[AT_PAIR][6];
-  Geo g[AT_PAIR];
+template <int TPAIR = AT_PAIR>
+struct AtMetaT {
+  int w[TPAIR][6];
+  Geo g[TPAIR];
 };
+using AtMeta = AtMetaT<AT_PAIR>;
 
-__device__ __forceinline__ void at_prefetch(const EnvView& v, AtMeta& m, int round) {
+template <int TW = WG, int TPAIR = AT_PAIR>
+__device__ __forceinline__ void at_prefetch(const EnvView& v, AtMetaT<TPAIR>& m, int round) {
 #pragma unroll
-  for (int j = 0; j < AT_PAIR; ++j) {
-    const int e = threadIdx.x + (round * AT_PAIR + j) * WG;
+  for (int j = 0; j < TPAIR; ++j) {
+    const int e = threadIdx.x + (round * TPAIR + j) * TW;
     if (e < v.nt) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) m.w[j][i] = v.mf_scat[i * v.NT + e];
@@ -1924,16 +1928,16 @@ __device__ __forceinline__ void at_prefetch(const EnvView& v, AtMeta& m, int rou
 // op(e, geo, dofs, outflow_edge, ye).  On entry m holds round 0; on exit again (rolling prefetch).
 // INTERLEAVE = true computes the AT_PAIR triangles of a round side by side (FP64 ILP for the hot
 // operator applications); false runs them one after the other (register-hungry right-hand sides).
-template <bool INTERLEAVE, class ElemOp>
-__device__ __forceinline__ void atomic_accumulate(const EnvView& v, double* Yd, AtMeta& m, ElemOp op) {
-  const int nrounds = (v.nt + AT_PAIR * WG - 1) / (AT_PAIR * WG);
+template <bool INTERLEAVE, int TW = WG, int TPAIR = AT_PAIR, class ElemOp>
+__device__ __forceinline__ void atomic_accumulate(const EnvView& v, double* Yd, AtMetaT<TPAIR>& m, ElemOp op) {
+  const int nrounds = (v.nt + TPAIR * TW - 1) / (TPAIR * TW);
   for (int round = 0; round < nrounds; ++round) {
     if (INTERLEAVE) {
-      double2 ye[AT_PAIR][6];
-      int dof[AT_PAIR][6];
+      double2 ye[TPAIR][6];
+      int dof[TPAIR][6];
 #pragma unroll
-      for (int j = 0; j < AT_PAIR; ++j) {
-        const int e = threadIdx.x + (round * AT_PAIR + j) * WG;
+      for (int j = 0; j < TPAIR; ++j) {
+        const int e = threadIdx.x + (round * TPAIR + j) * TW;
         if (e < v.nt) {
           ElemIdx E;
 #pragma unroll
@@ -1942,8 +1946,8 @@ __device__ __forceinline__ void atomic_accumulate(const EnvView& v, double* Yd, 
         }
       }
 #pragma unroll
-      for (int j = 0; j < AT_PAIR; ++j) {
-        const int e = threadIdx.x + (round * AT_PAIR + j) * WG;
+      for (int j = 0; j < TPAIR; ++j) {
+        const int e = threadIdx.x + (round * TPAIR + j) * TW;
         if (e < v.nt) {
 #pragma unroll
           for (int i = 0; i < 6; ++i) {
@@ -1954,13 +1958,14 @@ __device__ __forceinline__ void atomic_accumulate(const EnvView& v, double* Yd, 
       }
     } else {
 #pragma unroll 1
-      for (int j = 0; j < AT_PAIR; ++j) {
-        const int e = threadIdx.x + (round * AT_PAIR + j) * WG;
+      for (int j = 0; j < TPAIR; ++j) {
+        const int e = threadIdx.x + (round * TPAIR + j) * TW;
         if (e < v.nt) {
           ElemIdx E;
           double2 ye[6];
-          const int* wj = j == 0 ? m.w[0] : m.w[1];
-          const Geo gj = j == 0 ? m.g[0] : m.g[1];
+          // (explicit selects: a runtime index into the register arrays would demote them to scratch)
+          const int* wj = (TPAIR == 1 || j == 0) ? m.w[0] : m.w[TPAIR - 1];
+          const Geo gj = (TPAIR == 1 || j == 0) ? m.g[0] : m.g[TPAIR - 1];
 #pragma unroll
           for (int i = 0; i < 6; ++i) E.dof[i] = wj[i] & 0xFFF;
           op(e, gj, E, ((wj[0] >> 28) & 3) - 1, ye);
@@ -1972,7 +1977,7 @@ __device__ __forceinline__ void atomic_accumulate(const EnvView& v, double* Yd, 
         }
       }
     }
-    at_prefetch(v, m, round + 1 < nrounds ? round + 1 : 0);
+    at_prefetch<TW, TPAIR>(v, m, round + 1 < nrounds ? round + 1 : 0);
   }
 }
 
@@ -1981,12 +1986,13 @@ constexpr int BO_OWN = 2;
 struct BoOwn {
   int t[BO_OWN];
 };
+template <int TW = WG>
 __device__ __forceinline__ BoOwn outflow_rows_owned(const EnvView& v) {
   BoOwn o;
 #pragma unroll
   for (int q = 0; q < BO_OWN; ++q) o.t[q] = -1;
   for (int t = 0; t < v.nbo; ++t) {
-    if ((v.bo_rows[t] % WG) == (int)threadIdx.x) {
+    if ((v.bo_rows[t] % TW) == (int)threadIdx.x) {
       if (o.t[0] < 0) o.t[0] = t;
       else o.t[1] = t;  // (a third owned row cannot occur: outflow rows are < 2*WG apart in practice; checked on the host)
     }
@@ -2017,460 +2023,10 @@ __device__ __forceinline__ void outflow_rows_add(const EnvView& v, const BoOwn& 
   }
 }
 
-template <bool K1_LDS>
-__global__ __launch_bounds__(WG) void evolve_at_kernel(mdq_ipcs_desc d, int nsteps, double* drag, double* lift,
-                                                        int32_t* iters) {
-  extern __shared__ __align__(16) double smem[];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const EnvView v = env_view(d, b);
-  const int n2 = v.n2, nv = v.nv;
-  const LdsPlan P = lds_plan(d.N2, d.NV, d.NSE1);
-  const double a = d.rho / d.dt, mu = d.mu;
-
-  double* red = smem;  // 64 doubles
-  double* U = smem + 64;
-  double* px = U;
-  double* pr = px + P.NVp;
-  double* pp = pr + P.NVp;
-  double* pq = pp + P.NVp;
-  double* lK = pq + P.NVp;
-  int32_t* lci = reinterpret_cast<int32_t*>(lK + d.NSE1);
-  int32_t* lso = lci + d.NSE1 + (d.NSE1 & 1);
-  double2* Pl = reinterpret_cast<double2*>(U);  // search direction p / staged operator input
-  double2* Rl = Pl + P.N2p;                      // residual r (= s)
-  double2* Yl = Rl + P.N2p;                      // operator result (atomic accumulation)
-  double* Yd = reinterpret_cast<double*>(Yl);
-
-  double* w = v.work;
-  double* escr1 = w;
-  double2* xs = reinterpret_cast<double2*>(w + 12 * (int64_t)d.NT);  // x of the velocity solve = u*
-  double* pnew = reinterpret_cast<double*>(xs + 6 * (int64_t)d.N2);
-
-  const int nsl1 = (nv + 63) >> 6;
-  const int32_t* so1 = K1_LDS ? lso : v.sl1_off;
-  const int32_t* ci1 = K1_LDS ? lci : v.sl1_col;
-  const double* K1 = K1_LDS ? lK : v.K1s;
-
-#ifdef MDQ_PROFILE
-  __shared__ long long sprof_s[16];
-  if (tid < 16) sprof_s[tid] = 0;
-  const_cast<EnvView&>(v).sprof = sprof_s;
-  __syncthreads();
-#endif
-  AtMeta tm;
-  at_prefetch(v, tm, 0);
-  const BoOwn bo_own = outflow_rows_owned(v);
-
-  int it_u = 0, it_p = 0, it_m = 0;
-  int rsel = 0;  // parity of the one-barrier reductions
-#ifdef MDQ_PROFILE
-  long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  long long tprev = __builtin_amdgcn_s_memtime();
-#endif
-  __syncthreads();
-
-  for (int step = 0; step < nsteps; ++step) {
-    MDQ_STAMP(7)
-    // ================= step 1: tentative velocity
-    float2 idg[MF_ROWS];
-#pragma unroll
-    for (int k = 0; k < MF_ROWS; ++k) {
-      const int row = tid + k * WG;
-      idg[k] = make_float2(0.f, 0.f);
-      if (row < n2) {
-        Yl[row] = make_double2(0.0, 0.0);
-        if (!v.bcu_flag[row]) {
-          const double2 t_ = v.idiag1[row];
-          idg[k] = make_float2((float)t_.x, (float)t_.y);
-        }
-      }
-    }
-    __syncthreads();
-    {
-      const double2* un = v.u_n;
-      const double* pn = v.p_n;
-      atomic_accumulate<false>(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
-        double2 ue[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) ue[i] = un[E.dof[i]];
-        double pe[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) pe[i] = pn[E.dof[i]];
-        elem_rhs1_vol(g, a, mu, d.rho, ue, pe, ye);
-      });
-    }
-    __syncthreads();
-    outflow_rows_add(v, bo_own, 0.5 * mu, v.u_n, Yl);  // + mu/2 <nabla_grad(u_n) n, v> on the outflow rows
-    MDQ_STAMP(0)
-    double acc[2] = {0.0, 0.0};
-    double2 f[MF_ROWS];
-#pragma unroll
-    for (int k = 0; k < MF_ROWS; ++k) {
-      const int row = tid + k * WG;
-      f[k] = make_double2(0.0, 0.0);
-      if (row < n2) {
-        f[k] = Yl[row];
-        Yl[row] = make_double2(0.0, 0.0);
-        const bool fl = v.bcu_flag[row] != 0;
-        const double2 g = make_double2(v.bcu_gx[row], 0.0);
-        const double2 x0 = fl ? g : v.u_n[row];  // initial guess satisfies the Dirichlet values
-        xs[row] = x0;
-        Pl[row] = x0;
-        const double2 l = v.lift1[row];
-        const double2 bi = fl ? g : make_double2((f[k].x - l.x) * idg[k].x, (f[k].y - l.y) * idg[k].y);
-        acc[0] += bi.x * bi.x + bi.y * bi.y;
-      }
-    }
-    __syncthreads();
-    atomic_accumulate<true>(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
-      double2 xe[6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) xe[i] = Pl[E.dof[i]];
-      elem_velocity(g, a, mu, xe, ye);
-    });
-    __syncthreads();
-    outflow_rows_add(v, bo_own, -0.5 * mu, Pl, Yl);
-    double2 vv[MF_ROWS];
-#pragma unroll
-    for (int k = 0; k < MF_ROWS; ++k) {
-      const int row = tid + k * WG;
-      vv[k] = make_double2(0.0, 0.0);
-      if (row < n2) {
-        const double2 ax = Yl[row];
-        // r0 = D^-1 (f - A_full x0) on free rows, 0 on constrained rows (idg = 0 there)
-        const double2 r0 = make_double2((f[k].x - ax.x) * idg[k].x, (f[k].y - ax.y) * idg[k].y);
-        Rl[row] = r0;
-        acc[1] += r0.x * r0.x + r0.y * r0.y;
-      }
-    }
-    block_sum<2>(acc, red);
-    // p = 0 (only now: the outflow rows above still gathered x0 from Pl until the barriers of the reduction)
-#pragma unroll
-    for (int k = 0; k < MF_ROWS; ++k) {
-      const int row = tid + k * WG;
-      if (row < n2) Pl[row] = make_double2(0.0, 0.0);
-    }
-    MDQ_STAMP(1)
-    {
-      const double bb = acc[0], tol2 = d.rtol * d.rtol * bb;
-      double rr = acc[1];
-      if (rr > tol2 && bb != 0.0) {
-        double rho = rr, rho_old = 1.0, alpha = 1.0, omega = 1.0;
-        int it = 0;
-        // shadow residual in registers (own rows).  BiCGStab accepts ANY fixed shadow vector with
-        // (rh, r0) != 0; we take r0 rounded to fp32, which halves its register footprint.
-        float2 rh[MF_ROWS];
-        {
-          double a0[1] = {0.0};
-#pragma unroll
-          for (int k = 0; k < MF_ROWS; ++k) {
-            const int row = tid + k * WG;
-            rh[k] = make_float2(0.f, 0.f);
-            if (row < n2) {
-              const double2 r0 = Rl[row];
-              rh[k] = make_float2((float)r0.x, (float)r0.y);
-              a0[0] += (double)rh[k].x * r0.x + (double)rh[k].y * r0.y;
-            }
-          }
-          block_sum1<1>(a0, red, rsel);
-          rho = a0[0];  // (rh, r0)
-        }
-#ifdef MDQ_PROFILE
-        long long tb = __builtin_amdgcn_s_memtime();
-#endif
-        while (it < d.maxit_u) {
-          ++it;
-          MDQ_BSTAMP(15)
-          const double beta = (rho / rho_old) * (alpha / omega);
-#pragma unroll
-          for (int k = 0; k < MF_ROWS; ++k) {
-            const int row = tid + k * WG;
-            if (row < n2) {
-              const double2 ri = Rl[row], pi = Pl[row];
-              Pl[row] = make_double2(ri.x + beta * (pi.x - omega * vv[k].x), ri.y + beta * (pi.y - omega * vv[k].y));
-              Yl[row] = make_double2(0.0, 0.0);
-            }
-          }
-          __syncthreads();
-          MDQ_BSTAMP(8)
-          atomic_accumulate<true>(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
-            double2 xe[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) xe[i] = Pl[E.dof[i]];
-            elem_velocity(g, a, mu, xe, ye);
-          });
-          MDQ_BSTAMP(9)
-          __syncthreads();
-          MDQ_BSTAMP(10)
-          outflow_rows_add(v, bo_own, -0.5 * mu, Pl, Yl);
-          double a1[1] = {0.0};
-#pragma unroll
-          for (int k = 0; k < MF_ROWS; ++k) {
-            const int row = tid + k * WG;
-            if (row < n2) {
-              const double2 yv = Yl[row];
-              vv[k] = make_double2(yv.x * idg[k].x, yv.y * idg[k].y);
-              a1[0] += rh[k].x * vv[k].x + rh[k].y * vv[k].y;
-            }
-          }
-          block_sum1<1>(a1, red, rsel);
-          MDQ_BSTAMP(11)
-          if (a1[0] == 0.0) break;
-          alpha = rho / a1[0];
-          // s = r - alpha v ; no early exit on |s| (saves a reduction; the check on |r| follows)
-#pragma unroll
-          for (int k = 0; k < MF_ROWS; ++k) {
-            const int row = tid + k * WG;
-            if (row < n2) {
-              const double2 ri = Rl[row];
-              Rl[row] = make_double2(ri.x - alpha * vv[k].x, ri.y - alpha * vv[k].y);
-              Yl[row] = make_double2(0.0, 0.0);
-            }
-          }
-          __syncthreads();  // publish s and the zeroed result vector
-          MDQ_BSTAMP(12)
-          atomic_accumulate<true>(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
-            double2 xe[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) xe[i] = Rl[E.dof[i]];
-            elem_velocity(g, a, mu, xe, ye);
-          });
-          // x of the own rows: issue the global reads now, they are consumed after the reduction
-          double2 xo[MF_ROWS];
-#pragma unroll
-          for (int k = 0; k < MF_ROWS; ++k) {
-            const int row = tid + k * WG;
-            xo[k] = row < n2 ? xs[row] : make_double2(0.0, 0.0);
-          }
-          __syncthreads();
-          outflow_rows_add(v, bo_own, -0.5 * mu, Rl, Yl);
-          double a3[2] = {0.0, 0.0};
-          double2 t[MF_ROWS];
-#pragma unroll
-          for (int k = 0; k < MF_ROWS; ++k) {
-            const int row = tid + k * WG;
-            t[k] = make_double2(0.0, 0.0);
-            if (row < n2) {
-              const double2 yv = Yl[row], sv = Rl[row];
-              t[k] = make_double2(yv.x * idg[k].x, yv.y * idg[k].y);
-              a3[0] += t[k].x * sv.x + t[k].y * sv.y;
-              a3[1] += t[k].x * t[k].x + t[k].y * t[k].y;
-            }
-          }
-          block_sum1<2>(a3, red, rsel);
-          MDQ_BSTAMP(13)
-          if (a3[1] == 0.0) break;
-          omega = a3[0] / a3[1];
-          double a4[2] = {0.0, 0.0};
-#pragma unroll
-          for (int k = 0; k < MF_ROWS; ++k) {
-            const int row = tid + k * WG;
-            if (row < n2) {
-              const double2 pi = Pl[row], sv = Rl[row];
-              xs[row] = make_double2(xo[k].x + alpha * pi.x + omega * sv.x, xo[k].y + alpha * pi.y + omega * sv.y);
-              const double2 rn = make_double2(sv.x - omega * t[k].x, sv.y - omega * t[k].y);
-              Rl[row] = rn;
-              a4[0] += rn.x * rn.x + rn.y * rn.y;
-              a4[1] += rh[k].x * rn.x + rh[k].y * rn.y;
-            }
-          }
-          block_sum1<2>(a4, red, rsel);
-          MDQ_BSTAMP(14)
-          rr = a4[0];
-          if (!(rr > tol2)) break;
-          rho_old = rho;
-          rho = a4[1];
-          if (rho == 0.0 || omega == 0.0) break;
-        }
-        it_u += it;
-      }
-    }
-    __syncthreads();  // xs (= u*) complete: the element loops of steps 2 and 3 gather it
-    MDQ_STAMP(2)
-
-    // ================= step 2: pressure
-    if (K1_LDS && !d.pd_enabled) {
-      const int ne1 = v.sl1_off[nsl1];
-      for (int kk = tid; kk < ne1; kk += WG) {
-        lK[kk] = v.K1s[kk];
-        lci[kk] = v.sl1_col[kk];
-      }
-      for (int kk = tid; kk <= nsl1; kk += WG) lso[kk] = v.sl1_off[kk];
-    }
-    rhs2_elements(v, d, xs, v.p_n, escr1);
-    __syncthreads();
-    for (int i = tid; i < nv; i += WG) {
-      double bsum = 0.0;
-      for (int s = v.g1_ptr[i]; s < v.g1_ptr[i + 1]; ++s) bsum += escr1[v.g1_src[s]];
-      const double sd = v.sdiagK[i];
-      pr[i] = v.bcp_flag[i] ? 0.0 : bsum / sd;
-      px[i] = v.p_n[i] * sd;
-    }
-    MDQ_STAMP(3)
-    if (d.pd_enabled) {
-      const PdView pd = pd_view(d, b);
-      pressure_direct(pd, nv, pr, px, pp, pq, lK);
-    } else {
-      it_p += cg_pressure(nv, so1, ci1, K1, d.rtol, d.maxit_p, px, pr, pp, pq, red);
-    }
-    MDQ_STAMP(4)
-    for (int i = tid; i < nv; i += WG) pnew[i] = px[i] / v.sdiagK[i];
-    __syncthreads();
-
-    // ================= step 3: velocity correction (mass solve, both components)
-    double2 x[MF_ROWS], r[MF_ROWS], p[MF_ROWS];
-    double ism[MF_ROWS];
-    double am[2] = {0.0, 0.0};
-#pragma unroll
-    for (int k = 0; k < MF_ROWS; ++k) {
-      const int row = tid + k * WG;
-      if (row < n2) Yl[row] = make_double2(0.0, 0.0);
-    }
-    __syncthreads();
-    {
-      const double* pold = v.p_n;
-      atomic_accumulate<false>(v, Yd, tm, [&](int, const Geo& g, const ElemIdx& E, int, double2(&ye)[6]) {
-        double2 ue[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) ue[i] = xs[E.dof[i]];
-        double dp[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) dp[i] = pnew[E.dof[i]] - pold[E.dof[i]];
-        elem_rhs3(g, d.dt, ue, dp, ye);
-      });
-    }
-    __syncthreads();
-    double2 f3[MF_ROWS];
-#pragma unroll
-    for (int k = 0; k < MF_ROWS; ++k) {
-      const int row = tid + k * WG;
-      ism[k] = 0.0;
-      x[k] = f3[k] = make_double2(0.0, 0.0);
-      if (row < n2) {
-        const bool fl = v.bcu_flag[row] != 0;
-        if (!fl) ism[k] = 1.0 / v.sdiagM[row];
-        f3[k] = Yl[row];
-        Yl[row] = make_double2(0.0, 0.0);
-        x[k] = xs[row];      // u* (satisfies the Dirichlet values)
-        Pl[row] = x[k];      // stage S^-1 (S x0) = x0
-        const double2 l = v.lift3[row];
-        const double2 bi = fl ? x[k] : make_double2((f3[k].x - l.x) * ism[k], (f3[k].y - l.y) * ism[k]);
-        am[0] += bi.x * bi.x + bi.y * bi.y;
-      }
-    }
-    __syncthreads();
-    atomic_accumulate<true>(v, Yd, tm, [&](int, const Geo& g, const ElemIdx& E, int, double2(&ye)[6]) {
-      double2 xe[6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) xe[i] = Pl[E.dof[i]];
-      elem_mass(g, xe, ye);
-    });
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < MF_ROWS; ++k) {
-      const int row = tid + k * WG;
-      r[k] = p[k] = make_double2(0.0, 0.0);
-      if (row < n2) {
-        const double2 ax = Yl[row];
-        r[k] = make_double2((f3[k].x - ax.x) * ism[k], (f3[k].y - ax.y) * ism[k]);  // 0 on constrained rows
-        p[k] = r[k];
-        am[1] += r[k].x * r[k].x + r[k].y * r[k].y;
-        if (ism[k] != 0.0) x[k] = make_double2(x[k].x / ism[k], x[k].y / ism[k]);  // scaled unknown S x
-      }
-    }
-    block_sum<2>(am, red);
-    MDQ_STAMP(5)
-    {
-      const double bb = am[0], tol2 = d.rtol * d.rtol * bb;
-      double rr = am[1];
-      if (rr > tol2 && bb != 0.0) {
-        int it = 0;
-        while (it < d.maxit_m) {
-          ++it;
-#pragma unroll
-          for (int k = 0; k < MF_ROWS; ++k) {
-            const int row = tid + k * WG;
-            if (row < n2) {
-              Pl[row] = make_double2(p[k].x * ism[k], p[k].y * ism[k]);
-              Yl[row] = make_double2(0.0, 0.0);
-            }
-          }
-          __syncthreads();
-          atomic_accumulate<true>(v, Yd, tm, [&](int, const Geo& g, const ElemIdx& E, int, double2(&ye)[6]) {
-            double2 xe[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) xe[i] = Pl[E.dof[i]];
-            elem_mass(g, xe, ye);
-          });
-          __syncthreads();
-          double a1[1] = {0.0};
-          double2 q[MF_ROWS];
-#pragma unroll
-          for (int k = 0; k < MF_ROWS; ++k) {
-            const int row = tid + k * WG;
-            q[k] = make_double2(0.0, 0.0);
-            if (row < n2) {
-              const double2 yv = Yl[row];
-              q[k] = make_double2(yv.x * ism[k], yv.y * ism[k]);
-              a1[0] += p[k].x * q[k].x + p[k].y * q[k].y;
-            }
-          }
-          block_sum1<1>(a1, red, rsel);
-          if (!(a1[0] > 0.0)) break;
-          const double alpha = rr / a1[0];
-          double a2[1] = {0.0};
-#pragma unroll
-          for (int k = 0; k < MF_ROWS; ++k) {
-            x[k] = make_double2(x[k].x + alpha * p[k].x, x[k].y + alpha * p[k].y);
-            r[k] = make_double2(r[k].x - alpha * q[k].x, r[k].y - alpha * q[k].y);
-            a2[0] += r[k].x * r[k].x + r[k].y * r[k].y;
-          }
-          block_sum1<1>(a2, red, rsel);
-          const double rr_new = a2[0];
-          if (!(rr_new > tol2)) break;
-          const double beta = rr_new / rr;
-          rr = rr_new;
-#pragma unroll
-          for (int k = 0; k < MF_ROWS; ++k)
-            p[k] = make_double2(r[k].x + beta * p[k].x, r[k].y + beta * p[k].y);
-        }
-        it_m += it;
-      }
-    }
-    MDQ_STAMP(6)
-
-    // ================= update state + probes
-#pragma unroll
-    for (int k = 0; k < MF_ROWS; ++k) {
-      const int row = tid + k * WG;
-      if (row < n2) v.u_n[row] = (ism[k] != 0.0) ? make_double2(x[k].x * ism[k], x[k].y * ism[k]) : x[k];
-    }
-    for (int i = tid; i < nv; i += WG) v.p_n[i] = pnew[i];
-    __syncthreads();
-    double dr, li;
-    forces(v, d.mu, v.u_n, v.p_n, red, dr, li);
-    if (tid == 0) {
-      drag[(int64_t)b * nsteps + step] = dr;
-      lift[(int64_t)b * nsteps + step] = li;
-    }
-  }
-#ifdef MDQ_PROFILE
-  if (tid == 0) {
-    double* pw = pnew + d.NV;
-    for (int k = 0; k < 8; ++k) pw[k] += (double)prof[k];
-    for (int k = 0; k < 16; ++k) pw[8 + k] += (double)sprof_s[k];
-  }
-#endif
-  if (tid == 0 && iters) {
-    iters[3 * b + 0] += it_u;
-    iters[3 * b + 1] += it_p;
-    iters[3 * b + 2] += it_m;
-  }
-}
-
 // ---- mode 3 as three kernels per time step (separate register allocation per phase: the BiCGStab
 // loop then runs without spill reloads; state is handed over through global memory as before) ----
-__global__ __launch_bounds__(WG) void at_velocity_kernel(mdq_ipcs_desc d, int32_t* iters) {
+template <int TW, int TROWS, int TPAIR>
+__global__ __launch_bounds__(TW) void at_velocity_kernel(mdq_ipcs_desc d, int32_t* iters) {
   extern __shared__ __align__(16) double smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const EnvView v = env_view(d, b);
@@ -2489,9 +2045,9 @@ __global__ __launch_bounds__(WG) void at_velocity_kernel(mdq_ipcs_desc d, int32_
   double2* Rl = Pl + P.N2p;                      // residual r (= s)
   double2* Yl = Rl + P.N2p;                      // operator result (atomic accumulation)
   double* Yd = reinterpret_cast<double*>(Yl);
-  AtMeta tm;
-  at_prefetch(v, tm, 0);
-  const BoOwn bo_own = outflow_rows_owned(v);
+  AtMetaT<TPAIR> tm;
+  at_prefetch<TW, TPAIR>(v, tm, 0);
+  const BoOwn bo_own = outflow_rows_owned<TW>(v);
   int it_u = 0;
   double2* hist = xs + d.N2;                                          // u* of the step before the last
   double* histc = reinterpret_cast<double*>(xs + 3 * (int64_t)d.N2);  // [0]: tentative velocities stored so far
@@ -2499,10 +2055,10 @@ __global__ __launch_bounds__(WG) void at_velocity_kernel(mdq_ipcs_desc d, int32_
   __syncthreads();
   {
     // ================= step 1: tentative velocity
-    float2 idg[MF_ROWS];
+    float2 idg[TROWS];
 #pragma unroll
-    for (int k = 0; k < MF_ROWS; ++k) {
-      const int row = tid + k * WG;
+    for (int k = 0; k < TROWS; ++k) {
+      const int row = tid + k * TW;
       idg[k] = make_float2(0.f, 0.f);
       if (row < n2) {
         Yl[row] = make_double2(0.0, 0.0);
@@ -2516,7 +2072,7 @@ __global__ __launch_bounds__(WG) void at_velocity_kernel(mdq_ipcs_desc d, int32_
     {
       const double2* un = v.u_n;
       const double* pn = v.p_n;
-      atomic_accumulate<false>(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
+      atomic_accumulate<false, TW, TPAIR>(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
         double2 ue[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) ue[i] = un[E.dof[i]];
@@ -2529,10 +2085,10 @@ __global__ __launch_bounds__(WG) void at_velocity_kernel(mdq_ipcs_desc d, int32_
     __syncthreads();
     outflow_rows_add(v, bo_own, 0.5 * mu, v.u_n, Yl);  // + mu/2 <nabla_grad(u_n) n, v> on the outflow rows
     double acc[2] = {0.0, 0.0};
-    double2 f[MF_ROWS];
+    double2 f[TROWS];
 #pragma unroll
-    for (int k = 0; k < MF_ROWS; ++k) {
-      const int row = tid + k * WG;
+    for (int k = 0; k < TROWS; ++k) {
+      const int row = tid + k * TW;
       f[k] = make_double2(0.0, 0.0);
       if (row < n2) {
         f[k] = Yl[row];
@@ -2557,7 +2113,7 @@ __global__ __launch_bounds__(WG) void at_velocity_kernel(mdq_ipcs_desc d, int32_
       }
     }
     __syncthreads();
-    atomic_accumulate<true>(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
+    atomic_accumulate<(TPAIR > 1), TW, TPAIR>(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
       double2 xe[6];
 #pragma unroll
       for (int i = 0; i < 6; ++i) xe[i] = Pl[E.dof[i]];
@@ -2565,10 +2121,10 @@ __global__ __launch_bounds__(WG) void at_velocity_kernel(mdq_ipcs_desc d, int32_
     });
     __syncthreads();
     outflow_rows_add(v, bo_own, -0.5 * mu, Pl, Yl);
-    double2 vv[MF_ROWS];
+    double2 vv[TROWS];
 #pragma unroll
-    for (int k = 0; k < MF_ROWS; ++k) {
-      const int row = tid + k * WG;
+    for (int k = 0; k < TROWS; ++k) {
+      const int row = tid + k * TW;
       vv[k] = make_double2(0.0, 0.0);
       if (row < n2) {
         const double2 ax = Yl[row];
@@ -2578,11 +2134,11 @@ __global__ __launch_bounds__(WG) void at_velocity_kernel(mdq_ipcs_desc d, int32_
         acc[1] += r0.x * r0.x + r0.y * r0.y;
       }
     }
-    block_sum<2>(acc, red);
+    block_sum<2, TW / 64>(acc, red);
     // p = 0 (only now: the outflow rows above still gathered x0 from Pl until the barriers of the reduction)
 #pragma unroll
-    for (int k = 0; k < MF_ROWS; ++k) {
-      const int row = tid + k * WG;
+    for (int k = 0; k < TROWS; ++k) {
+      const int row = tid + k * TW;
       if (row < n2) Pl[row] = make_double2(0.0, 0.0);
     }
     {
@@ -2593,12 +2149,12 @@ __global__ __launch_bounds__(WG) void at_velocity_kernel(mdq_ipcs_desc d, int32_
         int it = 0;
         // shadow residual in registers (own rows).  BiCGStab accepts ANY fixed shadow vector with
         // (rh, r0) != 0; we take r0 rounded to fp32, which halves its register footprint.
-        float2 rh[MF_ROWS];
+        float2 rh[TROWS];
         {
           double a0[1] = {0.0};
 #pragma unroll
-          for (int k = 0; k < MF_ROWS; ++k) {
-            const int row = tid + k * WG;
+          for (int k = 0; k < TROWS; ++k) {
+            const int row = tid + k * TW;
             rh[k] = make_float2(0.f, 0.f);
             if (row < n2) {
               const double2 r0 = Rl[row];
@@ -2606,15 +2162,15 @@ __global__ __launch_bounds__(WG) void at_velocity_kernel(mdq_ipcs_desc d, int32_
               a0[0] += (double)rh[k].x * r0.x + (double)rh[k].y * r0.y;
             }
           }
-          block_sum1<1>(a0, red, rsel);
+          block_sum1<1, TW / 64>(a0, red, rsel);
           rho = a0[0];  // (rh, r0)
         }
         while (it < d.maxit_u) {
           ++it;
           const double beta = (rho / rho_old) * (alpha / omega);
 #pragma unroll
-          for (int k = 0; k < MF_ROWS; ++k) {
-            const int row = tid + k * WG;
+          for (int k = 0; k < TROWS; ++k) {
+            const int row = tid + k * TW;
             if (row < n2) {
               const double2 ri = Rl[row], pi = Pl[row];
               Pl[row] = make_double2(ri.x + beta * (pi.x - omega * vv[k].x), ri.y + beta * (pi.y - omega * vv[k].y));
@@ -2622,7 +2178,7 @@ __global__ __launch_bounds__(WG) void at_velocity_kernel(mdq_ipcs_desc d, int32_
             }
           }
           __syncthreads();
-          atomic_accumulate<true>(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
+          atomic_accumulate<(TPAIR > 1), TW, TPAIR>(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
             double2 xe[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) xe[i] = Pl[E.dof[i]];
@@ -2632,21 +2188,21 @@ __global__ __launch_bounds__(WG) void at_velocity_kernel(mdq_ipcs_desc d, int32_
           outflow_rows_add(v, bo_own, -0.5 * mu, Pl, Yl);
           double a1[1] = {0.0};
 #pragma unroll
-          for (int k = 0; k < MF_ROWS; ++k) {
-            const int row = tid + k * WG;
+          for (int k = 0; k < TROWS; ++k) {
+            const int row = tid + k * TW;
             if (row < n2) {
               const double2 yv = Yl[row];
               vv[k] = make_double2(yv.x * idg[k].x, yv.y * idg[k].y);
               a1[0] += rh[k].x * vv[k].x + rh[k].y * vv[k].y;
             }
           }
-          block_sum1<1>(a1, red, rsel);
+          block_sum1<1, TW / 64>(a1, red, rsel);
           if (a1[0] == 0.0) break;
           alpha = rho / a1[0];
           // s = r - alpha v ; no early exit on |s| (saves a reduction; the check on |r| follows)
 #pragma unroll
-          for (int k = 0; k < MF_ROWS; ++k) {
-            const int row = tid + k * WG;
+          for (int k = 0; k < TROWS; ++k) {
+            const int row = tid + k * TW;
             if (row < n2) {
               const double2 ri = Rl[row];
               Rl[row] = make_double2(ri.x - alpha * vv[k].x, ri.y - alpha * vv[k].y);
@@ -2654,26 +2210,26 @@ __global__ __launch_bounds__(WG) void at_velocity_kernel(mdq_ipcs_desc d, int32_
             }
           }
           __syncthreads();  // publish s and the zeroed result vector
-          atomic_accumulate<true>(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
+          atomic_accumulate<(TPAIR > 1), TW, TPAIR>(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
             double2 xe[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) xe[i] = Rl[E.dof[i]];
             elem_velocity(g, a, mu, xe, ye);
           });
           // x of the own rows: issue the global reads now, they are consumed after the reduction
-          double2 xo[MF_ROWS];
+          double2 xo[TROWS];
 #pragma unroll
-          for (int k = 0; k < MF_ROWS; ++k) {
-            const int row = tid + k * WG;
+          for (int k = 0; k < TROWS; ++k) {
+            const int row = tid + k * TW;
             xo[k] = row < n2 ? xs[row] : make_double2(0.0, 0.0);
           }
           __syncthreads();
           outflow_rows_add(v, bo_own, -0.5 * mu, Rl, Yl);
           double a3[2] = {0.0, 0.0};
-          double2 t[MF_ROWS];
+          double2 t[TROWS];
 #pragma unroll
-          for (int k = 0; k < MF_ROWS; ++k) {
-            const int row = tid + k * WG;
+          for (int k = 0; k < TROWS; ++k) {
+            const int row = tid + k * TW;
             t[k] = make_double2(0.0, 0.0);
             if (row < n2) {
               const double2 yv = Yl[row], sv = Rl[row];
@@ -2682,13 +2238,13 @@ __global__ __launch_bounds__(WG) void at_velocity_kernel(mdq_ipcs_desc d, int32_
               a3[1] += t[k].x * t[k].x + t[k].y * t[k].y;
             }
           }
-          block_sum1<2>(a3, red, rsel);
+          block_sum1<2, TW / 64>(a3, red, rsel);
           if (a3[1] == 0.0) break;
           omega = a3[0] / a3[1];
           double a4[2] = {0.0, 0.0};
 #pragma unroll
-          for (int k = 0; k < MF_ROWS; ++k) {
-            const int row = tid + k * WG;
+          for (int k = 0; k < TROWS; ++k) {
+            const int row = tid + k * TW;
             if (row < n2) {
               const double2 pi = Pl[row], sv = Rl[row];
               xs[row] = make_double2(xo[k].x + alpha * pi.x + omega * sv.x, xo[k].y + alpha * pi.y + omega * sv.y);
@@ -2698,7 +2254,7 @@ __global__ __launch_bounds__(WG) void at_velocity_kernel(mdq_ipcs_desc d, int32_
               a4[1] += rh[k].x * rn.x + rh[k].y * rn.y;
             }
           }
-          block_sum1<2>(a4, red, rsel);
+          block_sum1<2, TW / 64>(a4, red, rsel);
           rr = a4[0];
           if (!(rr > tol2)) break;
           rho_old = rho;
@@ -2948,15 +2504,6 @@ __global__ __launch_bounds__(WG) void at_correction_kernel(mdq_ipcs_desc d, int 
   if (tid == 0 && iters) iters[3 * b + 2] += it_m;
 }
 
-template <bool K1_LDS>
-static hipError_t launch_evolve_at(const mdq_ipcs_desc* d, size_t lds, int nsteps, double* drag, double* lift,
-                                   int32_t* iters, hipStream_t stream) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&evolve_at_kernel<K1_LDS>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((evolve_at_kernel<K1_LDS>), dim3(d->B), dim3(WG), lds, stream, *d, nsteps, drag, lift, iters);
-  return hipGetLastError();
-}
 
 // ================================================================== host side
 
@@ -3125,8 +2672,11 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
     const size_t lds_c = red_bytes + 2 * sizeof(double2) * (size_t)P.N2p;
     static bool attr_set = false;
     if (!attr_set) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&at_velocity_kernel),
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&at_velocity_kernel<WG, MF_ROWS, AT_PAIR>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&at_velocity_kernel<768, 5, 1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&at_pressure_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -3139,6 +2689,13 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
       if (e != hipSuccess) return fail("hipFuncSetAttribute(mode 3 kernels)", e);
       attr_set = true;
     }
+    // velocity kernel variant: 12 waves x 1 triangle stream (3 waves per SIMD, <= 170 VGPRs) or 8 waves x 2 interleaved
+    // triangle streams (2 per SIMD, 256 VGPRs); MDQ_AT_WG=512|768 overrides
+    static const int vel_wg = [] {
+      const char* s_ = std::getenv("MDQ_AT_WG");
+      const int w_ = s_ ? std::atoi(s_) : 768;
+      return w_ == 512 ? 512 : 768;
+    }();
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     if (kernel_ms) {
       for (int i = 0; i < 4; ++i)
@@ -3147,7 +2704,10 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
     }
     for (int step = 0; step < nsteps; ++step) {
       if (kernel_ms) hipEventRecord(ev[0], st);
-      hipLaunchKernelGGL(at_velocity_kernel, dim3(d->B), dim3(WG), lds_v, st, *d, iters);
+      if (vel_wg == 768)
+        hipLaunchKernelGGL((at_velocity_kernel<768, 5, 1>), dim3(d->B), dim3(768), lds_v, st, *d, iters);
+      else
+        hipLaunchKernelGGL((at_velocity_kernel<WG, MF_ROWS, AT_PAIR>), dim3(d->B), dim3(WG), lds_v, st, *d, iters);
       if (kernel_ms) hipEventRecord(ev[1], st);
       if (k1_lds)
         hipLaunchKernelGGL(at_pressure_kernel<true>, dim3(d->B), dim3(WG), lds_p, st, *d, iters);
