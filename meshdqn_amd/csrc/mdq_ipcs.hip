@@ -2670,25 +2670,25 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
     const size_t lds_v = red_bytes + P.vel3_bytes;
     const size_t lds_p = red_bytes + P.prs_vec_bytes + (k1_lds ? P.prs_mat_bytes : 0);
     const size_t lds_c = red_bytes + 2 * sizeof(double2) * (size_t)P.N2p;
-    static bool attr_set = false;
-    if (!attr_set) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&at_velocity_kernel<WG, MF_ROWS, AT_PAIR>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&at_velocity_kernel<768, 5, 1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&at_pressure_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&at_pressure_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&at_correction_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return fail("hipFuncSetAttribute(mode 3 kernels)", e);
-      attr_set = true;
-    }
+    // once per process (thread-safe: several env groups call this entry point concurrently)
+    static const hipError_t attr_err = [] {
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&at_velocity_kernel<WG, MF_ROWS, AT_PAIR>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e_ == hipSuccess)
+        e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&at_velocity_kernel<768, 5, 1>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e_ == hipSuccess)
+        e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&at_pressure_kernel<true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e_ == hipSuccess)
+        e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&at_pressure_kernel<false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e_ == hipSuccess)
+        e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&at_correction_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      return e_;
+    }();
+    if (attr_err != hipSuccess) return fail("hipFuncSetAttribute(mode 3 kernels)", attr_err);
     // velocity kernel variant: 12 waves x 1 triangle stream (3 waves per SIMD, <= 170 VGPRs) or 8 waves x 2 interleaved
     // triangle streams (2 per SIMD, 256 VGPRs); MDQ_AT_WG=512|768 overrides
     static const int vel_wg = [] {

@@ -228,19 +228,37 @@ class HostTopologyBatch:
     edge_src, edge_dst, edge_len); with `ipcs=True` also `hi`, the index data of the matrix-free IPCS path on every
     mesh (mdq_ipcs_topo_out: mf_scat, cell_outflow, bcu_flag, bcu_gx, bcp_flag, nbo, bo_*, g1_*, g2_*, sl1_*)."""
 
+    def _zeros(self, name, shape, dtype):
+        """Zeroed host array; page-locked (and registered under `name` for `upload`) when a GPU is present."""
+        tdt = {np.float64: torch.float64, np.int32: torch.int32, np.int8: torch.int8, np.uint8: torch.uint8}[dtype]
+        t = torch.zeros(shape, dtype=tdt, pin_memory=self._pin)
+        self.pinned[name] = t
+        return t.numpy()
+
+    def upload(self, name, device):
+        """Asynchronous H2D copy of a registered array on the current stream (the host engine does not touch the
+        array again before the caller has synchronised on results of this step)."""
+        return self.pinned[name].to(device, non_blocking=True)
+
     def __init__(self, B, NV, NT, NE, NAF, N, EMAX, polygon, ipcs=False, nbo_cap=64, nse1_cap=0):
         self.lib = _lib.load()
         NP = NV + NE
         self.B, self.NV, self.NT, self.NE, self.NP, self.NAF, self.N, self.EMAX = B, NV, NT, NE, NP, NAF, N, EMAX
         self.polygon = np.ascontiguousarray(polygon, dtype=np.float64)
-        self.coords = np.zeros((B, NV, 2))
-        self.cells = np.zeros((B, NT, 3), np.int32)
-        self.nv = np.zeros(B, np.int32)
-        self.nt = np.zeros(B, np.int32)
+        # page-locked host arrays (when a GPU is present): uploads run at full PCIe rate and asynchronously
+        self._pin = torch.cuda.is_available()
+        self.pinned = {}
+        z = self._zeros
+        self.coords = z("coords", (B, NV, 2), np.float64)
+        self.cells = z("cells", (B, NT, 3), np.int32)
+        self.nv = z("nv", (B,), np.int32)
+        self.nt = z("nt", (B,), np.int32)
         self.offset = np.zeros(B, np.int32)
-        self.h = dict(ne=np.zeros(B, np.int32), cell_dofs=np.zeros((B, 6, NT), np.int32), points=np.zeros((B, NP, 2)),
-                      naf=np.zeros(B, np.int32), af_facets=np.zeros((B, NAF, 2), np.int32),
-                      nremovable=np.zeros(B, np.int32), nsel=np.zeros(B, np.int32), n_closest=np.zeros((B, N), np.int32),
+        self.h = dict(ne=z("ne", (B,), np.int32), cell_dofs=z("cell_dofs", (B, 6, NT), np.int32),
+                      points=z("points", (B, NP, 2), np.float64), naf=z("naf", (B,), np.int32),
+                      af_facets=z("af_facets", (B, NAF, 2), np.int32),
+                      nremovable=np.zeros(B, np.int32), nsel=z("nsel", (B,), np.int32),
+                      n_closest=z("n_closest", (B, N), np.int32),
                       coord_map=np.zeros((B, N), np.int32), nedges=np.zeros(B, np.int32),
                       edge_src=np.zeros((B, EMAX), np.int32), edge_dst=np.zeros((B, EMAX), np.int32),
                       edge_len=np.zeros((B, EMAX)))
@@ -255,14 +273,14 @@ class HostTopologyBatch:
             NBO, NBE = int(nbo_cap), 6 * int(nbo_cap)
             NSE1 = int(nse1_cap) if nse1_cap else 64 * 16 * (NV // 64 + 1)
             self.NBO, self.NBE, self.NSE1 = NBO, NBE, NSE1
-            self.hi = dict(mf_scat=np.zeros((B, 6, NT), np.int32), cell_outflow=np.zeros((B, NT), np.int8),
-                           bcu_flag=np.zeros((B, NP), np.uint8), bcu_gx=np.zeros((B, NP)),
-                           bcp_flag=np.zeros((B, NV), np.uint8), nbo=np.zeros(B, np.int32),
-                           bo_rows=np.zeros((B, NBO), np.int32), bo_ptr=np.zeros((B, NBO + 1), np.int32),
-                           bo_col=np.zeros((B, NBE), np.int32), bo_src=np.zeros((B, NBE), np.int32),
-                           g1_ptr=np.zeros((B, NV + 1), np.int32), g1_src=np.zeros((B, 3 * NT), np.int32),
-                           g2_ptr=np.zeros((B, NP + 1), np.int32), g2_src=np.zeros((B, 6 * NT), np.int32),
-                           sl1_off=np.zeros((B, NV // 64 + 2), np.int32), sl1_col=np.zeros((B, NSE1), np.int32))
+            self.hi = dict(mf_scat=z("mf_scat", (B, 6, NT), np.int32), cell_outflow=z("cell_outflow", (B, NT), np.int8),
+                           bcu_flag=z("bcu_flag", (B, NP), np.uint8), bcu_gx=z("bcu_gx", (B, NP), np.float64),
+                           bcp_flag=z("bcp_flag", (B, NV), np.uint8), nbo=z("nbo", (B,), np.int32),
+                           bo_rows=z("bo_rows", (B, NBO), np.int32), bo_ptr=z("bo_ptr", (B, NBO + 1), np.int32),
+                           bo_col=z("bo_col", (B, NBE), np.int32), bo_src=z("bo_src", (B, NBE), np.int32),
+                           g1_ptr=z("g1_ptr", (B, NV + 1), np.int32), g1_src=z("g1_src", (B, 3 * NT), np.int32),
+                           g2_ptr=z("g2_ptr", (B, NP + 1), np.int32), g2_src=z("g2_src", (B, 6 * NT), np.int32),
+                           sl1_off=z("sl1_off", (B, NV // 64 + 2), np.int32), sl1_col=z("sl1_col", (B, NSE1), np.int32))
             o = _lib.IpcsTopoOut()
             o.NBO, o.NBE, o.NSE1 = NBO, NBE, NSE1
             for k, a in self.hi.items():

@@ -131,8 +131,8 @@ class VecEnv2DAirfoil:
     def _flow(self, keep, out_u, out_p):
         """`flow_steps` IPCS steps on every (coarsened) mesh, warm-started from the interpolated last snapshot."""
         t, d, hi = self.flow_t, self.flow_desc, self.topo.hi
-        for k, a in hi.items():
-            t[k].copy_(torch.from_numpy(a), non_blocking=True)
+        for k in hi:
+            t[k].copy_(self.topo.pinned[k], non_blocking=True)
         for k in ("coords", "cell_dofs", "af_facets", "nv", "nt", "ne", "naf"):
             setattr(d, k, keep[k].data_ptr())
         t["u_n"].copy_(out_u[:, self.S - 1])
@@ -180,12 +180,14 @@ class VecEnv2DAirfoil:
 
     def _refresh(self):
         """Topology + selection on the host, snapshot interpolation + forces on the GPU, for all envs."""
+        torch.cuda.current_stream(self.device).synchronize()   # pending async uploads read the arrays the engine rewrites
         self.topo.run(self.nthreads)
         dev, h = self.device, self.h
         B, NV, NT, NP = self.B, self.NV, self.NT, self.NP
-        t_pts = torch.from_numpy(h["points"]).to(dev)
-        npts = torch.from_numpy(self.nv + h["ne"]).to(dev)
-        np1 = torch.from_numpy(self.nv).to(dev)
+        up = self.topo.upload
+        t_pts = up("points", dev)
+        np1 = up("nv", dev)
+        npts = np1 + up("ne", dev)
         it = self.interp
         out_u = torch.zeros((B, self.S, NP, 2), dtype=torch.float64, device=dev)
         out_p = torch.zeros((B, self.S, NV), dtype=torch.float64, device=dev)
@@ -202,11 +204,9 @@ class VecEnv2DAirfoil:
         md = _lib.IpcsDesc()
         md.B, md.NV, md.NT, md.NE, md.N2, md.NAF = B, NV, NT, self.NE, NP, self.NAF
         md.mu = self.mu
-        t_coords = torch.from_numpy(self.coords).to(dev)
-        keep = dict(coords=t_coords, cell_dofs=torch.from_numpy(h["cell_dofs"]).to(dev),
-                    af_facets=torch.from_numpy(h["af_facets"]).to(dev), nv=np1,
-                    nt=torch.from_numpy(self.nt).to(dev), ne=torch.from_numpy(h["ne"]).to(dev),
-                    naf=torch.from_numpy(h["naf"]).to(dev))
+        t_coords = up("coords", dev)
+        keep = dict(coords=t_coords, cell_dofs=up("cell_dofs", dev), af_facets=up("af_facets", dev), nv=np1,
+                    nt=up("nt", dev), ne=up("ne", dev), naf=up("naf", dev))
         for k, v in keep.items():
             setattr(md, k, v.data_ptr())
         drag = torch.empty((B, self.S), dtype=torch.float64, device=dev)
@@ -226,7 +226,7 @@ class VecEnv2DAirfoil:
         node_ptr (B+1,) i32 - directly consumable by the fused Q-network forward - plus host copies of
         n_closest / coord_map / nedges."""
         dev, h, B, N, S = self.device, self.h, self.B, self.N, self.S
-        nc = torch.from_numpy(h["n_closest"].astype(np.int64)).to(dev)  # (B,N)
+        nc = self.topo.upload("n_closest", dev).long()  # (B,N)
         bi = torch.arange(B, device=dev)[:, None]
         x = torch.zeros((B, N, 2 + 3 * S), dtype=torch.float32, device=dev)
         # the reference indexes every feature with n_closest (rank in the removable list), Env2DAirfoil.py:285-288
@@ -235,7 +235,7 @@ class VecEnv2DAirfoil:
         x[:, :, 2:2 + 2 * S] = vel.reshape(B, N, 2 * S).float()  # raw reshape of the (S,N,2) block, as the reference does
         prs = self.p[bi[:, :, None], torch.arange(S, device=dev)[None, :, None], nc[:, None, :]]  # (B,S,N)
         x[:, :, 2 + 2 * S:] = prs.permute(0, 2, 1).float()
-        nsel = torch.from_numpy(h["nsel"].astype(np.int64)).to(dev)
+        nsel = self.topo.upload("nsel", dev).long()
         x = x * (torch.arange(N, device=dev)[None, :] < nsel[:, None]).unsqueeze(-1)
         ne = h["nedges"].astype(np.int64)
         edge_ptr = np.zeros(B + 1, np.int32)
@@ -267,11 +267,11 @@ class VecEnv2DAirfoil:
             # host: cavity re-triangulation + Delaunay restoration only; GPU: smooth(50) of the changed meshes
             status = remesh_batch(self.coords, self.cells, self.nv, self.nt, rem, 0, self.nthreads)
             dev = self.device
-            tc = torch.from_numpy(self.coords).to(dev)
+            up = self.topo.upload
+            tc = up("coords", dev)
             its = torch.from_numpy(np.where((rem >= 0) & (status == 0), 50, 0).astype(np.int32)).to(dev)
-            smooth_batch_gpu(tc, torch.from_numpy(self.cells).to(dev), torch.from_numpy(self.nv).to(dev),
-                             torch.from_numpy(self.nt).to(dev), its)
-            self.coords[:] = tc.cpu().numpy()
+            smooth_batch_gpu(tc, up("cells", dev), up("nv", dev), up("nt", dev), its)
+            self.topo.pinned["coords"].copy_(tc)        # D2H into the page-locked array (synchronises this stream)
         else:
             status = remesh_batch(self.coords, self.cells, self.nv, self.nt, rem, 50, self.nthreads)
         code[status != 0] = 2

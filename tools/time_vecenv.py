@@ -32,4 +32,4 @@ for rep in range(2):
     torch.cuda.synchronize(); dt = time.time() - t0
     if rep: pr.disable()
     print(f"B={B}: {dt/n*1e3:.1f} ms per batched S1 step + Q-forward -> {B*n/dt:.0f} env-steps/s")
-pstats.Stats(pr).sort_stats("cumulative").print_stats(12)
+pstats.Stats(pr).sort_stats("tottime").print_stats(22)
