@@ -233,6 +233,19 @@ def main():
     survey_bytes = batch.algorithmic_bytes_per_step(iters2)  # SURVEY 8(d) assembled-CSR convention, whole step
     step_bytes = batch.implemented_bytes_per_step(iters2)     # bytes the implemented algorithm moves, whole step
 
+    # device-copy microbenchmark in the same run (check the 8 TB/s spec figure used as `peak`)
+    src = torch.empty(1 << 28, dtype=torch.float32, device=dev)  # 1 GiB
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    c0.record()
+    for _ in range(10):
+        dst.copy_(src)
+    c1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 10 * 2 * src.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9   # read + write
+    del src, dst
+
     s3 = measure_env_steps(args, dev, dist, world, 1) if args.s1_steps > 0 else None
     s1 = measure_env_steps(args, dev, dist, world, 0) if args.s1_steps > 0 else None
 
@@ -273,6 +286,7 @@ def main():
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "device_copy_GBs_same_run": copy_gbs,
                          "kernel": "at_velocity_kernel (rhs1 + matrix-free Jacobi-BiCGStab, LDS fp64 atomics)",
                          "launch_ms": k_vel, "algorithmic_bytes_per_launch": vel_bytes,
                          "kernels_ms_per_step": {"at_velocity_kernel": k_vel, "at_pressure_kernel": k_prs,
