@@ -182,3 +182,83 @@ def test_host_engine_topology_matches_python_topology(meshes, lib_built, name):
         ns = (nv + 63) // 64
         assert np.array_equal(hi["sl1_off"][b][:ns + 1], ref["sl1_off"])
         assert np.array_equal(hi["sl1_col"][b][:ref["sl1_col"].size], ref["sl1_col"])
+
+
+def _scipy_remove(coords, cells, idx):
+    """Reference semantics of Env2DAirfoil._remove_vertex (Env2DAirfoil.py:452-512): delete the vertex, global
+    scipy/Qhull Delaunay of the remaining points, drop simplices whose three vertices are all boundary vertices."""
+    from scipy.spatial import Delaunay
+    t = MeshTopology(coords, cells)
+    bnd = np.flatnonzero(t.on_boundary)
+    bnd = np.where(bnd > idx, bnd - 1, bnd)
+    keep = np.delete(np.arange(len(coords)), idx)
+    x = coords[keep]
+    tri = Delaunay(x).simplices
+    tri = tri[np.isin(tri, bnd).sum(axis=1) != 3]
+    return x, np.sort(tri, axis=1)
+
+
+@pytest.mark.parametrize("name", ["ys930", "ah93w145"])
+def test_host_remesh_equals_scipy_delaunay_over_an_episode(meshes, lib_built, name):
+    """C++ engine (star re-triangulation of the cavity + Lawson flips, then DOLFIN smoothing) against the reference's
+    own pipeline (global Qhull Delaunay + all-boundary filter) + the oracle smoother, 24 consecutive removals."""
+    from meshdqn_amd.ipcs_batch import smooth_coords
+    from meshdqn_amd.mesh_ops import remesh_batch
+    coords, cells = meshes[name]
+    t0 = MeshTopology(coords, cells)
+    x = smooth_coords(t0, 50)
+    c = np.sort(cells, axis=1)
+    NV, NT = t0.nv, t0.nt
+    hc = np.zeros((1, NV, 2)); hc[0] = x
+    ht = np.zeros((1, NT, 3), np.int32); ht[0] = c
+    nv = np.array([NV], np.int32); nt = np.array([NT], np.int32)
+    rng = np.random.default_rng(3)
+    ref_x, ref_c = x.copy(), c.copy()
+    for step in range(24):
+        t = MeshTopology(ref_x, ref_c)
+        interior = np.flatnonzero(~t.on_boundary)
+        idx = int(rng.choice(interior))
+        st = remesh_batch(hc, ht, nv, nt, np.array([idx], np.int32), 50, 1)
+        assert st[0] == 0
+        ref_x, ref_c = _scipy_remove(ref_x, ref_c, idx)
+        assert (nv[0], nt[0]) == (len(ref_x), len(ref_c))
+        mine = {tuple(r) for r in ht[0, :nt[0]].tolist()}
+        assert mine == {tuple(r) for r in ref_c.tolist()}, step            # same triangulation as a SET of cells
+        ref_x = smooth_coords(MeshTopology(ref_x, ref_c), 50)               # host smoother (pinned to the oracle above)
+        assert np.abs(hc[0, :nv[0]] - ref_x).max() < 1e-13
+    # (the host smoother itself is pinned to the python oracle by test_host_smoothing_matches_oracle)
+
+
+def test_host_engine_is_thread_safe(meshes, lib_built):
+    """Concurrent callers (the env groups of VecEnvGroups) share one worker pool: results equal the sequential ones."""
+    import threading
+    from meshdqn_amd.ipcs_batch import smooth_coords
+    from meshdqn_amd.mesh_ops import remesh_batch
+    coords, cells = meshes["ys930"]
+    t0 = MeshTopology(coords, cells)
+    x = smooth_coords(t0, 50)
+    c = np.sort(cells, axis=1).astype(np.int32)
+    interior = np.flatnonzero(~t0.on_boundary)
+    B, G = 6, 4
+
+    def run(g, out):
+        hc = np.repeat(x[None], B, 0).copy()
+        ht = np.repeat(c[None], B, 0).copy()
+        nv = np.full(B, t0.nv, np.int32); nt = np.full(B, t0.nt, np.int32)
+        for k in range(3):
+            rem = interior[(np.arange(B) * 17 + 31 * g + 5 * k) % (interior.size - 8)].astype(np.int32)
+            st = remesh_batch(hc, ht, nv, nt, rem, 10, 3)
+            assert (st == 0).all()
+        out[g] = (hc, ht, nv.copy(), nt.copy())
+
+    seq, par = {}, {}
+    for g in range(G):
+        run(g, seq)
+    threads = [threading.Thread(target=run, args=(g, par)) for g in range(G)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for g in range(G):
+        for a, b in zip(seq[g], par[g]):
+            assert np.array_equal(a, b)
