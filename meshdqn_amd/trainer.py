@@ -323,6 +323,43 @@ def train_loop_per_worker(trainer: DQNTrainer, env_factory, num_episodes: int, m
     return history
 
 
+class TrainingLog:
+    """The reference's on-disk training log (DataHandler, airfoil_dqn.py:79-133): `reward.npy` (sum per episode),
+    `rewards.npy` / `actions.npy` (per-episode lists), `losses.npy`, `eps.npy`, written under `save_dir + prefix`;
+    `restart=True` continues from existing files and switches to the `RESTART_` prefix like the reference."""
+    FILES = dict(rewards="reward.npy", ep_rewards="rewards.npy", losses="losses.npy", actions="actions.npy", epss="eps.npy")
+
+    def __init__(self, save_dir: str, prefix: str = "", restart: bool = False):
+        self.base = os.path.join(save_dir, prefix)
+        self.rewards, self.ep_rewards, self.losses, self.actions, self.epss = [], [], [], [], []
+        if restart:
+            for attr, fn in self.FILES.items():
+                try:
+                    setattr(self, attr, list(np.load(self.base + fn, allow_pickle=True)))
+                except OSError:
+                    pass
+            self.base += "RESTART_"
+
+    def add_eps(self, eps):
+        self.epss.append(float(eps))
+
+    def add_loss(self, loss):
+        self.losses.append(float(loss))
+
+    def add_episode(self, ep_rewards, ep_actions):
+        self.rewards.append(float(sum(ep_rewards)))
+        self.ep_rewards.append(list(ep_rewards))
+        self.actions.append(list(ep_actions))
+
+    def write(self):
+        os.makedirs(os.path.dirname(self.base) or ".", exist_ok=True)
+        np.save(self.base + "reward.npy", np.array(self.rewards))
+        np.save(self.base + "rewards.npy", np.array(self.ep_rewards, dtype=object), allow_pickle=True)
+        np.save(self.base + "losses.npy", np.array(self.losses))
+        np.save(self.base + "actions.npy", np.array(self.actions, dtype=object), allow_pickle=True)
+        np.save(self.base + "eps.npy", np.array(self.epss))
+
+
 def state_to_data_list(st: dict, n_nodes: int) -> List[Data]:
     """Split the batched state dict of `VecEnv2DAirfoil.get_state()` into per-environment `Data` objects
     (x (N,F) f32, edge_index (2,E) i64 with node ids local to the graph) for the replay memory."""
@@ -336,7 +373,7 @@ def state_to_data_list(st: dict, n_nodes: int) -> List[Data]:
 
 
 def train_loop_vec(trainer: DQNTrainer, venv, num_steps: int, optim_per_step: int = 1, eps_decay=10000, eps_start=1.0,
-                   eps_end=0.01, share_replay=False, e_max=1536):
+                   eps_end=0.01, share_replay=False, e_max=1536, log: Optional["TrainingLog"] = None):
     """Batched counterpart of `train_loop_per_worker` for one rank: B environments of a `VecEnv2DAirfoil` stepped
     together (configs[3] of BASELINE.json: 128 envs per GPU, 1024 over 8 ranks).  Per batched step: fused Q-forward
     of policy_net_1 for all B states, epsilon-greedy per environment (per-env step counters, like the reference's
@@ -350,6 +387,8 @@ def train_loop_vec(trainer: DQNTrainer, venv, num_steps: int, optim_per_step: in
     steps_done = np.zeros(B, np.int64)
     st = venv.get_state()
     rewards, dones_hist = [], []
+    ep_r = [[] for _ in range(B)]
+    ep_a = [[] for _ in range(B)]
     for _ in range(num_steps):
         with torch.no_grad():
             q = fused.forward_arrays(st["x"], st["node_ptr"], st["esrc"], st["edst"], st["edge_ptr"], N, venv.EMAX)
@@ -368,7 +407,17 @@ def train_loop_vec(trainer: DQNTrainer, venv, num_steps: int, optim_per_step: in
         for t in trs:
             trainer.memory.push(*t)
         for _k in range(optim_per_step):
-            trainer.optimize()
+            loss = trainer.optimize()
+            if log is not None and loss is not None:
+                log.add_loss(loss)
+        if log is not None:
+            log.add_eps(float(eps.mean()))
+            for b in range(B):
+                ep_r[b].append(float(rew[b]))
+                ep_a[b].append(int(actions[b]))
+                if done[b]:
+                    log.add_episode(ep_r[b], ep_a[b])
+                    ep_r[b], ep_a[b] = [], []
         rewards.append(rew.copy())
         dones_hist.append(done.copy())
     return dict(rewards=np.array(rewards), dones=np.array(dones_hist), losses=list(trainer.losses))

@@ -129,3 +129,21 @@ def test_double_dqn_select_toggles_every_target_update():
         seen.append(tr.select)
     # toggled when num_grads % 2 == 0 BEFORE the step (airfoil_dqn.py:185-186), starting from True
     assert seen == [False, False, True, True, False]
+
+
+def test_training_log_files_and_restart(tmp_path):
+    """reward / rewards / losses / actions / eps .npy with the reference's semantics (airfoil_dqn.py:79-133)."""
+    from meshdqn_amd.trainer import TrainingLog
+    d = str(tmp_path)
+    log = TrainingLog(d)
+    log.add_eps(0.9)
+    log.add_loss(0.25)
+    log.add_episode([1.0, -1.0], [3, 180])
+    log.add_episode([0.5], [7])
+    log.write()
+    assert np.load(os.path.join(d, "reward.npy")).tolist() == [0.0, 0.5]
+    again = TrainingLog(d, restart=True)
+    assert again.rewards == [0.0, 0.5] and [list(a) for a in again.actions] == [[3, 180], [7]]
+    again.add_episode([2.0], [1])
+    again.write()
+    assert np.load(os.path.join(d, "RESTART_reward.npy")).tolist() == [0.0, 0.5, 2.0]

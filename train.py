@@ -22,9 +22,10 @@ def main():
     ap.add_argument("--flow-steps", type=int, default=0, help="IPCS steps on the coarsened mesh per env step (S3)")
     ap.add_argument("--share-replay", action="store_true")
     ap.add_argument("--save-dir", default="training_results/run")
+    ap.add_argument("--restart", action="store_true", help="continue the logs found in --save-dir (RESTART_ prefix)")
     args = ap.parse_args()
     from meshdqn_amd.env import Env2DAirfoil
-    from meshdqn_amd.trainer import DistContext, DQNTrainer, train_loop_vec
+    from meshdqn_amd.trainer import DistContext, DQNTrainer, TrainingLog, train_loop_vec
     from meshdqn_amd.vec_env import VecEnv2DAirfoil
     cfg = yaml.safe_load(open(args.config))
     ctx = DistContext()
@@ -37,14 +38,15 @@ def main():
                          target_update=int(ap_.get("target_update", 50)))
     base = Env2DAirfoil(cfg, compute_device=ctx.device)          # ground truth + snapshots (the reference's first reset())
     venv = VecEnv2DAirfoil(cfg, args.envs, compute_device=ctx.device, base_env=base, flow_steps=args.flow_steps)
-    out = train_loop_vec(trainer, venv, args.steps, eps_decay=float(eps.get("decay", 10000)),
+    log = TrainingLog(args.save_dir, restart=args.restart) if ctx.rank == 0 else None
+    out = train_loop_vec(trainer, venv, args.steps, log=log, eps_decay=float(eps.get("decay", 10000)),
                          eps_start=float(eps.get("start", 1.0)), eps_end=float(eps.get("end", 0.01)),
                          share_replay=args.share_replay)
     if ctx.rank == 0:
         os.makedirs(args.save_dir, exist_ok=True)
         trainer.save(args.save_dir)
-        np.save(os.path.join(args.save_dir, "rewards.npy"), out["rewards"])
-        np.save(os.path.join(args.save_dir, "losses.npy"), np.array(out["losses"]))
+        log.write()                                              # reward / rewards / losses / actions / eps .npy
+        np.save(os.path.join(args.save_dir, "step_rewards.npy"), out["rewards"])
         yaml.safe_dump(cfg, open(os.path.join(args.save_dir, "config.yaml"), "w"))
         print(f"ranks {ctx.world}: {args.steps} batched steps x {args.envs} envs/rank, mean reward {out['rewards'].mean():.4f}")
     ctx.close()
