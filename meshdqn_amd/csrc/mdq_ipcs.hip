@@ -2050,6 +2050,9 @@ __global__ __launch_bounds__(TW) void at_velocity_kernel(mdq_ipcs_desc d, int32_
   const BoOwn bo_own = outflow_rows_owned<TW>(v);
   int it_u = 0;
   double2* hist = xs + d.N2;                                          // u* of the step before the last
+  double2* hist2 = xs + 2 * (int64_t)d.N2;                            // and of the one before that
+  double2* hist3 = xs + 4 * (int64_t)d.N2;                            // and one more (slot 3 holds the counter)
+  double2* hist4 = xs + 5 * (int64_t)d.N2;
   double* histc = reinterpret_cast<double*>(xs + 3 * (int64_t)d.N2);  // [0]: tentative velocities stored so far
   const int nhist = (int)histc[0];
   __syncthreads();
@@ -2095,13 +2098,32 @@ __global__ __launch_bounds__(TW) void at_velocity_kernel(mdq_ipcs_desc d, int32_
         Yl[row] = make_double2(0.0, 0.0);
         const bool fl = v.bcu_flag[row] != 0;
         const double2 g = make_double2(v.bcu_gx[row], 0.0);
-        // initial guess: linear extrapolation of the two previous tentative velocities (xs still holds
-        // u*_n, hist u*_{n-1}); u_n while there is no history.  It satisfies the Dirichlet values.
+        // initial guess: polynomial extrapolation in time of the previous tentative velocities (xs still holds
+        // u*_n, hist.. hist4 the four before it), up to quartic as the history fills; u_n while there is none.
+        // dt is far below the flow's time scales, so every order removes about two digits of initial residual
+        // (11 BiCGStab iterations without, 8 linear, 6 quadratic, 3 cubic, 2.6 quartic; beyond that the 1e-10
+        // solver noise of the history, amplified by the coefficients, is the floor).  Dirichlet values hold.
         const double2 us1 = xs[row];
         double2 x0 = v.u_n[row];
         if (nhist >= 2) {
           const double2 us2 = hist[row];
           x0 = make_double2(2.0 * us1.x - us2.x, 2.0 * us1.y - us2.y);
+          if (nhist >= 3) {  // quadratic extrapolation 3 u*_n - 3 u*_{n-1} + u*_{n-2}
+            const double2 us3 = hist2[row];
+            x0 = make_double2(3.0 * (us1.x - us2.x) + us3.x, 3.0 * (us1.y - us2.y) + us3.y);
+            if (nhist >= 4) {  // cubic: 4 u*_n - 6 u*_{n-1} + 4 u*_{n-2} - u*_{n-3}
+              const double2 us4 = hist3[row];
+              x0 = make_double2(4.0 * (us1.x + us3.x) - 6.0 * us2.x - us4.x, 4.0 * (us1.y + us3.y) - 6.0 * us2.y - us4.y);
+              if (nhist >= 5) {  // quartic: 5 u*_n - 10 u*_{n-1} + 10 u*_{n-2} - 5 u*_{n-3} + u*_{n-4}
+                const double2 us5 = hist4[row];
+                x0 = make_double2(5.0 * (us1.x - us4.x) - 10.0 * (us2.x - us3.x) + us5.x,
+                                  5.0 * (us1.y - us4.y) - 10.0 * (us2.y - us3.y) + us5.y);
+              }
+              hist4[row] = us4;
+            }
+            hist3[row] = us3;
+          }
+          hist2[row] = us2;
         }
         if (fl) x0 = g;
         hist[row] = us1;
@@ -2268,7 +2290,7 @@ __global__ __launch_bounds__(TW) void at_velocity_kernel(mdq_ipcs_desc d, int32_
 
   }
   if (tid == 0) {
-    histc[0] = (double)(nhist < 2 ? nhist + 1 : 2);
+    histc[0] = (double)(nhist < 5 ? nhist + 1 : 5);
     if (iters) iters[3 * b + 0] += it_u;
   }
 }
@@ -2395,7 +2417,9 @@ __global__ __launch_bounds__(WG) void at_correction_kernel(mdq_ipcs_desc d, int 
         f3[k] = Yl[row];
         Yl[row] = make_double2(0.0, 0.0);
         // initial guess: u* plus the previous step's correction (u_n - u*_n), i.e. a guess for
-        // u* - dt grad(dp); plain u* while there is no history.  Dirichlet rows keep u* = g.
+        // u* - dt grad(dp); plain u* while there is no history.  Dirichlet rows keep u* = g.  (Extrapolating a
+        // stored correction history to higher order saves two of the five CG iterations but costs more in
+        // history traffic than they do: measured, not kept.)
         x[k] = xs[row];
         if (!fl && nhist >= 2) {
           const double2 un = v.u_n[row], up = hist[row];
