@@ -293,6 +293,15 @@ int mdq_remesh_host(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* 
                     int32_t* status);
 
 /*
+ * Node features of the state graphs of B environments (Env2DAirfoil.get_state, Env2DAirfoil.py:282-290), including the
+ * reference's two indexing quirks (features indexed by n_closest = rank in the removable list; velocity block = raw
+ * reshape of the (S,N,2) array).  coords [B][NV][2], u [B][S][NP][2], p [B][S][NV] (f64), n_closest [B][N], nsel [B]
+ * (rows >= nsel are zero) -> x [B][N][2+3S] (f32).  All device pointers.
+ */
+int mdq_state_features(int32_t B, int32_t N, int32_t S, int32_t NV, int32_t NP, const double* coords, const double* u,
+                       const double* p, const int32_t* n_closest, const int32_t* nsel, float* x, void* stream);
+
+/*
  * DOLFIN `Mesh.smooth(n)` (flow_solver.py:65-67 and 236-237 after every remesh) for B meshes on the GPU: Gauss-Seidel
  * over the interior vertices in index order, each moved towards the centroid of its neighbours by at most half the
  * minimum altitude of its cells; boundary vertices (an incident edge with one owner) are fixed.  One workgroup per

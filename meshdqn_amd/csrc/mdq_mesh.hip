@@ -85,3 +85,55 @@ extern "C" int mdq_interpolate_snapshots(const mdq_interp_desc* d, void* stream)
   if (e != hipSuccess) return mdq_set_error(hipGetErrorString(e));
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// State features of B environments (Env2DAirfoil.get_state, Env2DAirfoil.py:282-290), one thread per output value:
+//   x[b][n][0:2]        = coordinates()[n_closest[n]]
+//   x[b][n][2:2+2S]     = velocities[:, n_closest, :].reshape(N, -1)   (raw row-major reshape of the (S,N,2) block)
+//   x[b][n][2+2S:2+3S]  = pressures[:, n_closest][:, :, 0].T
+// with the reference's quirk that n_closest (a rank inside the removable list) is used as a VERTEX index; rows
+// n >= nsel[b] (fewer than N selectable vertices left) are zero.
+namespace mdq_mesh {
+
+__global__ __launch_bounds__(256) void state_features_kernel(int B, int N, int S, int NV, int NP, const double* coords,
+                                                             const double* u, const double* p, const int32_t* n_closest,
+                                                             const int32_t* nsel, float* x) {
+  const int F = 2 + 3 * S;
+  const int64_t total = (int64_t)B * N * F;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int f = (int)(i % F);
+    const int n = (int)((i / F) % N);
+    const int b = (int)(i / ((int64_t)F * N));
+    const int32_t* nc = n_closest + (int64_t)b * N;
+    float val = 0.f;
+    if (n < nsel[b]) {
+      if (f < 2) {
+        val = (float)coords[((int64_t)b * NV + nc[n]) * 2 + f];
+      } else if (f < 2 + 2 * S) {
+        // element (n, f-2) of the reshaped block = flat index q of the (S, N, 2) array
+        const int q = n * 2 * S + (f - 2);
+        const int s = q / (2 * N), r = q - s * 2 * N, m = r >> 1, c = r & 1;
+        val = (float)u[(((int64_t)b * S + s) * NP + nc[m]) * 2 + c];
+      } else {
+        const int s = f - 2 - 2 * S;
+        val = (float)p[((int64_t)b * S + s) * NV + nc[n]];
+      }
+    }
+    x[i] = val;
+  }
+}
+
+}  // namespace mdq_mesh
+
+extern "C" int mdq_state_features(int32_t B, int32_t N, int32_t S, int32_t NV, int32_t NP, const double* coords,
+                                  const double* u, const double* p, const int32_t* n_closest, const int32_t* nsel,
+                                  float* x, void* stream) {
+  if (B <= 0 || N <= 0 || S <= 0 || !coords || !u || !p || !n_closest || !nsel || !x)
+    return mdq_set_error("mdq_state_features: bad arguments");
+  const int64_t total = (int64_t)B * N * (2 + 3 * S);
+  const int blocks = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(mdq_mesh::state_features_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, B, N, S, NV, NP,
+                     coords, u, p, n_closest, nsel, x);
+  if (hipGetLastError() != hipSuccess) return mdq_set_error("state_features_kernel launch failed");
+  return 0;
+}

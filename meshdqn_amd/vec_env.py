@@ -226,22 +226,16 @@ class VecEnv2DAirfoil:
         node_ptr (B+1,) i32 - directly consumable by the fused Q-network forward - plus host copies of
         n_closest / coord_map / nedges."""
         dev, h, B, N, S = self.device, self.h, self.B, self.N, self.S
-        nc = self.topo.upload("n_closest", dev).long()  # (B,N)
-        bi = torch.arange(B, device=dev)[:, None]
-        x = torch.zeros((B, N, 2 + 3 * S), dtype=torch.float32, device=dev)
-        # the reference indexes every feature with n_closest (rank in the removable list), Env2DAirfoil.py:285-288
-        x[:, :, :2] = self._coords_dev[bi, nc].float()
-        vel = self.u[bi[:, :, None], torch.arange(S, device=dev)[None, :, None], nc[:, None, :]]  # (B,S,N,2)
-        x[:, :, 2:2 + 2 * S] = vel.reshape(B, N, 2 * S).float()  # raw reshape of the (S,N,2) block, as the reference does
-        prs = self.p[bi[:, :, None], torch.arange(S, device=dev)[None, :, None], nc[:, None, :]]  # (B,S,N)
-        x[:, :, 2 + 2 * S:] = prs.permute(0, 2, 1).float()
-        nsel = self.topo.upload("nsel", dev).long()
-        x = x * (torch.arange(N, device=dev)[None, :] < nsel[:, None]).unsqueeze(-1)
+        x = torch.empty((B, N, 2 + 3 * S), dtype=torch.float32, device=dev)
+        nc, nsel = self.topo.upload("n_closest", dev), self.topo.upload("nsel", dev)
+        _lib.check(self.lib.mdq_state_features(B, N, S, self.NV, self.NP, self._coords_dev.data_ptr(), self.u.data_ptr(),
+                                               self.p.data_ptr(), nc.data_ptr(), nsel.data_ptr(), x.data_ptr(),
+                                               _lib.stream_ptr()), "mdq_state_features")
         ne = h["nedges"].astype(np.int64)
         edge_ptr = np.zeros(B + 1, np.int32)
         edge_ptr[1:] = np.cumsum(ne)
-        esrc = np.concatenate([h["edge_src"][b, :ne[b]] for b in range(B)]) if ne.sum() else np.zeros(0, np.int32)
-        edst = np.concatenate([h["edge_dst"][b, :ne[b]] for b in range(B)]) if ne.sum() else np.zeros(0, np.int32)
+        live = np.arange(self.EMAX)[None, :] < ne[:, None]          # (B,EMAX) valid edge slots, row-major = env order
+        esrc, edst = h["edge_src"][live], h["edge_dst"][live]
         return dict(x=x, esrc=torch.from_numpy(esrc).to(dev), edst=torch.from_numpy(edst).to(dev),
                     edge_ptr=torch.from_numpy(edge_ptr).to(dev),
                     node_ptr=torch.arange(B + 1, dtype=torch.int32, device=dev) * N,
