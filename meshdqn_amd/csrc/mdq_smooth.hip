@@ -5,8 +5,8 @@
 //   opposite edges of its cells, p <- p + min(|c-p|, r_min/2) (c-p)/|c-p|.
 // Update (sweep s, vertex v) needs neighbour w's value of sweep s if w < v and of sweep s-1 if w > v.  That
 // dependency graph has only ~6 independent updates per level on the reference meshes (ys930: 34 700 updates in
-// 5 454 levels), so the kernel is a latency-bound DATAFLOW machine, one 256-thread workgroup per mesh out of LDS:
-// 32 groups of 8 lanes, group g owns the interior vertices of rank g, g+32, ... and walks them in
+// 5 454 levels), so the kernel is a latency-bound DATAFLOW machine, one 512-thread workgroup per mesh out of LDS:
+// 64 groups of 8 lanes, group g owns the interior vertices of rank g, g+64, ... and walks them in
 // (sweep, index) order; the 8 lanes take one incident cell each (sqrt + division per cell in parallel), combine
 // with DPP, lane 0 publishes the new position and then the vertex's sweep counter; readiness is checked against
 // the neighbours' counters.  The globally smallest unfinished update is always at the head of its group and
@@ -20,7 +20,10 @@ namespace mdq_smoothing {
 
 constexpr int SNV = 1024;      // vertex capacity (ids must fit 10 bits)
 constexpr int SNT = 2048;      // triangle capacity (cell id must fit 12 bits)
-constexpr int SWG = 256;       // threads per workgroup: one wave per SIMD, so that spinning groups do not take
+#ifndef MDQ_SMOOTH_WG
+#define MDQ_SMOOTH_WG 512
+#endif
+constexpr int SWG = MDQ_SMOOTH_WG;  // threads per workgroup: 8 waves measured best (256: 3.9 ms, 512: 3.4 ms, 1024: 3.9 ms for ys930)
                                // issue slots from the group on the critical path
 constexpr int GRP = 8;         // lanes per vertex update
 constexpr int NGRP = SWG / GRP;
@@ -81,7 +84,8 @@ __device__ __forceinline__ void scan_inclusive(int* data, int* part) {
 }
 
 __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coords, const int32_t* cells,
-                                                     const int32_t* nv_, const int32_t* nt_, const int32_t* iters_) {
+                                                     const int32_t* nv_, const int32_t* nt_, const int32_t* iters_,
+                                                     long long* trace) {
 #pragma clang fp contract(off)
   __shared__ double2 pos[SNV];
   __shared__ int done[SNV];
@@ -149,10 +153,13 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
   }
   __syncthreads();
   scan_inclusive(cnt, part);
+  const int n_int = cnt[SNV - 1];
+  __syncthreads();
+  // queue order = index order (ranking the vertices by their dependency level inside a sweep and dealing the levels
+  // round-robin was tried: the setup costs more than the better-ordered queues gain)
   for (int v = tid; v < SNV; v += SWG)
     if (done[v] == 0) ivert[cnt[v] - 1] = (uint16_t)v;
   __syncthreads();
-  const int n_int = cnt[SNV - 1];
 
   // ---------------- dataflow Gauss-Seidel
   // group rank: consecutive ranks sit in DIFFERENT waves (they are usually neighbours on the dependency chain, and
@@ -192,6 +199,9 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
     const unsigned long long bal = __ballot(ok);
     const bool ready = ((bal >> ((tid & 63) & ~7)) & 0xFFull) == 0xFFull;
     if (ready) {
+#ifdef MDQ_SMOOTH_TRACE
+      const long long t_ready = clock64();
+#endif
       // (a counter that is high enough guarantees that a position read after it is the right version: the
       // neighbour cannot advance again before this vertex has; LDS operations of a wave complete in order)
       const double px = LD_X(v), py = LD_Y(v);
@@ -207,7 +217,11 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
         sx += ax + bx;
         sy += ay + by;
         const double tx = bx - ax, ty = by - ay;
+#ifdef MDQ_SMOOTH_NOMATH
+        rm = fmin(rm, fabs(ty * (px - ax) - tx * (py - ay)));
+#else
         rm = fmin(rm, fabs(ty * (px - ax) - tx * (py - ay)) * rsqrt_nr(tx * tx + ty * ty));
+#endif
       }
       // lane 0 carries the x component, lane 1 the y component (same instruction stream: free)
       const double tsx = grp_sum(sx), tsy = grp_sum(sy);  // (both by every lane: DPP needs the whole group active)
@@ -217,7 +231,11 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
       const double dc_ = sc * rcp2k[k] - pc;                // lane 0: dx, lane 1: dy
       const double dother = dpp8<0xB1>(dc_);                // the other component
       const double q2 = dc_ * dc_ + dother * dother;        // (x*x + y*y in lane 0, y*y + x*x in lane 1: same bits)
+#ifdef MDQ_SMOOTH_NOMATH
+      const double ir = 1.0;
+#else
       const double ir = rsqrt_nr(q2);
+#endif
       const double r = q2 * ir;
       if (l < 2) {
         if (!(r < EPS) && q2 > 0.0) {
@@ -228,6 +246,12 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (l == 0) __hip_atomic_store(&done[v], s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef MDQ_SMOOTH_TRACE
+      if (trace && b == 0 && l == 0) {
+        trace[2 * ((int64_t)s * SNV + v)] = t_ready;
+        trace[2 * ((int64_t)s * SNV + v) + 1] = clock64();
+      }
+#endif
       ++step;
       if (++j == nown) {
         j = 0;
@@ -245,13 +269,30 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
 
 }  // namespace mdq_smoothing
 
+#ifdef MDQ_SMOOTH_TRACE
+// debug builds only: [64 sweeps][SNV][2] shader-clock timestamps (ready, done) of every update of environment 0,
+// in page-locked host memory the kernel writes directly
+extern "C" long long* mdq_smooth_trace_host() {
+  static long long* g_trace = nullptr;
+  if (!g_trace) {
+    hipHostMalloc(reinterpret_cast<void**>(&g_trace), sizeof(long long) * 2 * 64 * mdq_smoothing::SNV, hipHostMallocDefault);
+    memset(g_trace, 0, sizeof(long long) * 2 * 64 * mdq_smoothing::SNV);
+  }
+  return g_trace;
+}
+#endif
+
 extern "C" int mdq_smooth(int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t* cells, const int32_t* nv,
                           const int32_t* nt, const int32_t* iterations, void* stream) {
   if (B <= 0 || !coords || !cells || !nv || !nt || !iterations) return mdq_set_error("mdq_smooth: bad arguments");
   if (NV > mdq_smoothing::SNV || NT > mdq_smoothing::SNT)
     return mdq_set_error("mdq_smooth: mesh capacity above 1024 vertices / 2048 triangles (use mdq_smooth_host)");
+  long long* trace = nullptr;
+#ifdef MDQ_SMOOTH_TRACE
+  trace = mdq_smooth_trace_host();
+#endif
   hipLaunchKernelGGL(mdq_smoothing::smooth_kernel, dim3(B), dim3(mdq_smoothing::SWG), 0, (hipStream_t)stream, NV, NT, coords,
-                     cells, nv, nt, iterations);
+                     cells, nv, nt, iterations, trace);
   if (hipGetLastError() != hipSuccess) return mdq_set_error("smooth_kernel launch failed");
   return 0;
 }
