@@ -36,6 +36,42 @@ _WARMED = False
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def _quota_note():
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return "" if q == "max" else f" under a cgroup quota of {int(q) / int(per):.0f} cores"
+    except (OSError, ValueError):
+        return ""
+
+
+def _cpu_worker(args):
+    """One oracle environment stepping for `budget_s` seconds (child process of the multi-process CPU baseline)."""
+    budget_s, spinup = args
+    os.environ["OMP_NUM_THREADS"] = "1"
+    os.environ["OPENBLAS_NUM_THREADS"] = "1"
+    from oracle.ipcs import OracleFlowSolver
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ys930.npz"))
+    fs = OracleFlowSolver(z["coords"], z["cells"])
+    for _ in range(spinup):
+        fs.evolve()
+    n = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        fs.evolve()
+        n += 1
+    return n, time.perf_counter() - t0
+
+
+def cpu_baseline_parallel(budget_s=8.0, procs=12):
+    """The reference's `num_parallel: 12` Ray workers (configs/ray_ys930.yaml:30) mirrored with P independent
+    single-threaded oracle processes: aggregate IPCS env-steps/s of the host."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")   # (the parent has initialised the GPU: no fork)
+    with ctx.Pool(procs) as pool:
+        res = pool.map(_cpu_worker, [(budget_s, 10)] * procs)
+    return sum(n / dt for n, dt in res)
+
+
 def cpu_baseline(budget_s=15.0, spinup=20):
     """Oracle (kind 'port') on one core: IPCS evolve() steps/s for ONE ys930 env."""
     os.environ.setdefault("OMP_NUM_THREADS", "1")
@@ -66,6 +102,17 @@ def cpu_baseline(budget_s=15.0, spinup=20):
         env.step(int(rng.integers(0, 180)))
     out["s1_value"] = 3 / (time.perf_counter() - t0)
     out["s1_sample"] = "3 OracleEnv.step() calls of 1 ys930 env (python loops for interpolation / smoothing), 1 core"
+    try:
+        procs = 12
+        if any(os.environ.get(k) for k in ("HSA_TOOLS_LIB", "ROCP_TOOL_LIB", "ROCPROFILER_LIBRARY")):
+            raise RuntimeError("skipped under a profiler (its preloaded tool may already hold the GPU: no child interpreters)")
+        out["parallel_value"] = cpu_baseline_parallel(8.0, procs)
+        out["parallel_sample"] = (f"{procs} independent single-threaded oracle processes (the reference's num_parallel: 12 "
+                                  f"workers), 8 s each, aggregate IPCS env-steps/s; host exposes {os.cpu_count()} logical "
+                                  f"CPUs" + _quota_note())
+    except Exception as exc:  # noqa: BLE001 - the baseline is informational
+        out["parallel_value"] = None
+        out["parallel_sample"] = f"failed: {exc!r}"
     return out
 
 
@@ -160,6 +207,12 @@ def main():
     ap.add_argument("--env-groups", type=int, default=4, help="concurrently stepped env groups per GPU for S1 / S3")
     ap.add_argument("--s1-solver-steps", type=int, default=5000, help="IPCS steps of the ground-truth reset()")
     args = ap.parse_args()
+
+    # CPU baseline FIRST, before anything initialises the GPU: its multi-process leg starts child interpreters
+    # (fork + exec), which must not happen from a process that already holds the device
+    cpu = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.cpu_budget)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -303,8 +356,8 @@ def main():
         }
         res["rates"] = {"S2_ipcs_env_steps_per_s": res["value"], "S1_reference_step_env_steps_per_s": s1,
                         "S3_north_star_step_env_steps_per_s": s3}
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.cpu_budget)
+        if cpu is not None:
+            res["cpu_baseline"] = cpu
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

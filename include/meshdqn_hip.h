@@ -175,6 +175,9 @@ int mdq_ipcs_setup_matfree(const mdq_ipcs_desc* d, void* stream);
  *   drag, lift : device double[B][nsteps]   (accumulated_drag / accumulated_lift)
  *   iters      : device int32[B][3] or NULL; Krylov iterations of the three
  *                solves are ADDED to it (velocity, pressure, correction)
+ * State carried between calls: u_n, p_n and (mode 3) the tentative-velocity history in `work` from which the initial
+ * guess of the velocity solve is extrapolated.  Zero `work` whenever u_n / p_n are replaced from outside or the mesh
+ * changes (stale history only costs iterations, never accuracy: every solve still runs to `rtol`).
  */
 int mdq_ipcs_evolve(const mdq_ipcs_desc* d, int32_t nsteps, double* drag, double* lift,
                     int32_t* iters, void* stream);
