@@ -204,7 +204,7 @@ def main():
     ap.add_argument("--s1-steps", type=int, default=50, help="batched reference-semantics env steps (0 = skip)")
     ap.add_argument("--cell-order", default="conflictfree", choices=["mesh", "conflictfree"])
     ap.add_argument("--s1-warmup", type=int, default=40)
-    ap.add_argument("--env-groups", type=int, default=4, help="concurrently stepped env groups per GPU for S1 / S3")
+    ap.add_argument("--env-groups", type=int, default=1, help="concurrently stepped env groups per GPU for S1 / S3")
     ap.add_argument("--s1-solver-steps", type=int, default=5000, help="IPCS steps of the ground-truth reset()")
     args = ap.parse_args()
 

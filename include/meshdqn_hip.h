@@ -374,6 +374,13 @@ typedef struct mdq_env_topo_desc {
  */
 int mdq_env_topology_host(const mdq_env_topo_desc* d, int32_t nthreads, int32_t* status);
 
+/*
+ * The same engine as a HIP kernel (one workgroup per environment, everything in LDS): every pointer of the descriptor
+ * (and of d->ipcs, a HOST struct holding device pointers) and `status` are DEVICE pointers.  All output arrays are
+ * bit-identical to mdq_env_topology_host's.  Capacity: NV <= 1024, NT <= 2048, NP <= 4096, npoly <= 256.
+ */
+int mdq_env_topology(const mdq_env_topo_desc* d, void* stream, int32_t* status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -99,6 +99,7 @@ SYMBOLS = {
     "mdq_remesh_host": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "mdq_env_topology_host": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "mdq_env_topology": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdq_state_features": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdq_smooth": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -4,4 +4,5 @@
 #include "mdq_gcn.hip"
 #include "mdq_mesh.hip"
 #include "mdq_smooth.hip"
+#include "mdq_topology.hip"
 #include "mdq_host_mesh.hip"

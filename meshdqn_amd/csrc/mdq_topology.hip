@@ -1,0 +1,630 @@
+// Device version of the batched topology engine (mdq_env_topology_host): one 512-thread workgroup per environment
+// derives, from coordinates + cells alone and entirely in LDS, everything the environment step needs from a mesh:
+//   unique edges numbered by first appearance / P2 dof map / dof coordinates (MeshTopology, flow_solver.py:85-86),
+//   boundary vertices + airfoil facets (flow_solver.py:194-226), `removable` (numpy-`in` quirk, flow_solver.py:75-78),
+//   polygon distances + stable argsort + N-closest window (Env2DAirfoil.py:220-241, 293-315), the state graph
+//   (Env2DAirfoil.py:258-280) and, optionally, the index data of the matrix-free IPCS path (mdq_ipcs_topo_out).
+// Sequential semantics (first-appearance edge ids, ordered lists, stable sort) are reproduced with parallel
+// primitives: an LDS hash table with atomicMin on the slot index, flag -> exclusive scan -> scatter compactions and
+// rank-by-counting sorts.  Floating point follows the host engine operation by operation (no FMA contraction, IEEE
+// sqrt / division), so every output array is bit-identical to mdq_env_topology_host's.
+#include <hip/hip_runtime.h>
+
+#include "../../include/meshdqn_hip.h"
+
+namespace mdq_topo {
+
+constexpr int TW = 512;
+constexpr int TNV = 1024, TNT = 2048, TNE = 3072, TNP = TNV + TNE, TNS = 3 * TNT;  // capacities (ids fit 10 / 12 bits)
+constexpr int HSZ = 8192;
+constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+constexpr int PER = TNS / TW;  // 12 entries per thread in the block scans
+constexpr int TNPOLY = 256;
+
+// exclusive scan of a[0..n) in place (n <= TNS), returns the total; `part` = TW ints of scratch
+__device__ inline int scan_excl(int* a, int n, int* part) {
+  const int tid = threadIdx.x;
+  int loc[PER], run = 0;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int idx = tid * PER + i;
+    loc[i] = run;
+    run += idx < n ? a[idx] : 0;
+  }
+  part[tid] = run;
+  __syncthreads();
+  for (int off = 1; off < TW; off <<= 1) {
+    const int add = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += add;
+    __syncthreads();
+  }
+  const int base = part[tid] - run, total = part[TW - 1];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int idx = tid * PER + i;
+    if (idx < n) a[idx] = base + loc[i];
+  }
+  __syncthreads();
+  return total;
+}
+
+__device__ __forceinline__ uint32_t hslot(uint32_t key) { return (key * 2654435761u) >> 19; }  // 13 bits
+
+// squared point-segment distance, operation order of the host engine (seg_dist2)
+__device__ __forceinline__ double seg_dist2(double px, double py, double ax, double ay, double bx, double by) {
+#pragma clang fp contract(off)
+  const double abx = bx - ax, aby = by - ay;
+  double t = ((px - ax) * abx + (py - ay) * aby) / (abx * abx + aby * aby);
+  t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+  const double qx = ax + t * abx - px, qy = ay + t * aby - py;
+  return qx * qx + qy * qy;
+}
+
+__global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_ipcs_topo_out O, int has_ipcs,
+                                                      int32_t* status) {
+#pragma clang fp contract(off)
+  extern __shared__ __align__(16) unsigned char smem[];
+  double2* X = reinterpret_cast<double2*>(smem);                              // [TNV]
+  uint32_t* hkey = reinterpret_cast<uint32_t*>(smem + 16384);                 // [HSZ]   | region R (64 KB), re-used
+  uint32_t* hval = hkey + HSZ;                                                // [HSZ]   | after the edge phase
+  int* scanb = reinterpret_cast<int*>(smem + 16384 + 65536);                  // [TNS]
+  uint16_t* eid_slot = reinterpret_cast<uint16_t*>(scanb + TNS);              // [TNS]
+  uint16_t* ea = eid_slot + TNS;                                              // [TNE]
+  uint16_t* eb = ea + TNE;
+  uint16_t* eown = eb + TNE;
+  uint8_t* eflag = reinterpret_cast<uint8_t*>(eown + TNE);                    // [TNE] bit0 boundary, bits 4-6 tag + 1
+  uint8_t* onb = eflag + TNE;                                                 // [TNV]
+  int* part = reinterpret_cast<int*>(onb + TNV);                              // [TW]
+  int* misc = part + TW;                                                      // [16]
+  // region R after the edge phase
+  unsigned char* R = smem + 16384;
+  uint16_t* blist = reinterpret_cast<uint16_t*>(R);                           // [TNV] boundary vertices
+  uint16_t* remv = blist + TNV;                                               // [TNV] removable vertices (ascending)
+  uint16_t* order = remv + TNV;                                               // [TNV]
+  int16_t* inv = reinterpret_cast<int16_t*>(order + TNV);                     // [TNV]
+  double* dist = reinterpret_cast<double*>(R + 8192);                         // [TNV]
+  double2* poly = reinterpret_cast<double2*>(R + 16384);                      // [TNPOLY]
+  int* cntd = reinterpret_cast<int*>(R + 20480);                              // [TNP + 1] counts / pointers (IPCS phase)
+  int* fill = cntd + TNP + 8;                                                 // [TNP]
+
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int nv = D.nv[b], nt = D.nt[b];
+  const int64_t Bq = b;
+  const double* xg = D.coords + Bq * D.NV * 2;
+  const int32_t* tri = D.cells + Bq * D.NT * 3;
+  int32_t* cd = D.cell_dofs + Bq * 6 * D.NT;
+  double* pts = D.points + Bq * D.NP * 2;
+  if (tid == 0) status[b] = 0;
+  for (int v = tid; v < TNV; v += TW) {
+    if (v < nv) X[v] = make_double2(xg[2 * v], xg[2 * v + 1]);
+    onb[v] = 0;
+  }
+  for (int h = tid; h < HSZ; h += TW) {
+    hkey[h] = EMPTY;
+    hval[h] = 0x7FFFFFFFu;
+  }
+  __syncthreads();
+
+  // ================= edges numbered by first appearance in (cell, local edge k opposite vertex k) order
+  auto slot_key = [&](int s, int& a, int& c) {
+    const int t = s / 3, k = s - 3 * t;
+    const int va = tri[3 * t + (k == 0 ? 1 : 0)], vb = tri[3 * t + (k == 2 ? 1 : 2)];
+    a = min(va, vb);
+    c = max(va, vb);
+    return ((uint32_t)a << 10) | (uint32_t)c;
+  };
+  auto probe = [&](uint32_t key) {
+    uint32_t h = hslot(key);
+    while (hkey[h] != key) h = (h + 1) & (HSZ - 1);
+    return h;
+  };
+  const int nslots = 3 * nt;
+  for (int s = tid; s < nslots; s += TW) {
+    int a, c;
+    const uint32_t key = slot_key(s, a, c);
+    uint32_t h = hslot(key);
+    for (;;) {
+      const uint32_t old = atomicCAS(&hkey[h], EMPTY, key);
+      if (old == EMPTY || old == key) break;
+      h = (h + 1) & (HSZ - 1);
+    }
+    atomicMin(&hval[h], (uint32_t)s);
+  }
+  __syncthreads();
+  for (int s = tid; s < TNS; s += TW) {
+    int first = 0;
+    if (s < nslots) {
+      int a, c;
+      const uint32_t h = probe(slot_key(s, a, c));
+      const uint32_t m = hval[h] & 0x7FFFFFFFu;
+      first = m == (uint32_t)s;
+      if (!first) atomicOr(&hval[h], 0x80000000u);  // a second owner: interior edge
+    }
+    scanb[s] = first;
+  }
+  __syncthreads();
+  // (the flags must be read back before the scan overwrites them)
+  bool isfirst[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) isfirst[i] = scanb[tid * PER + i] != 0;
+  __syncthreads();
+  const int ne = scan_excl(scanb, TNS, part);
+  const int n2 = nv + ne;
+  if (ne > TNE || n2 > D.NP) {
+    if (tid == 0) status[b] = -1;
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int s = tid * PER + i;
+    if (s < nslots && isfirst[i]) {
+      int a, c;
+      const uint32_t h = probe(slot_key(s, a, c));
+      const int e = scanb[s];
+      const bool shared = (hval[h] & 0x80000000u) != 0;
+      ea[e] = (uint16_t)a;
+      eb[e] = (uint16_t)c;
+      eown[e] = (uint16_t)s;
+      eflag[e] = shared ? 0 : 1;
+    }
+  }
+  __syncthreads();
+  for (int s = tid; s < nslots; s += TW) {
+    int a, c;
+    const uint32_t h = probe(slot_key(s, a, c));
+    const int e = scanb[hval[h] & 0x7FFFFFFFu];
+    eid_slot[s] = (uint16_t)e;
+    const int t = s / 3, k = s - 3 * t;
+    cd[(3 + k) * D.NT + t] = nv + e;
+    cd[k * D.NT + t] = tri[3 * t + k];
+  }
+  if (tid == 0) D.ne[b] = ne;
+  for (int i = tid; i < nv; i += TW) {
+    pts[2 * i] = X[i].x;
+    pts[2 * i + 1] = X[i].y;
+  }
+  __syncthreads();
+  // ================= P2 dof coordinates, boundary vertices, facet tags (later marks override earlier ones)
+  const double E = 3.0e-16;
+  double ymin = 1e300, ymax = -1e300;
+  for (int i = tid; i < nv; i += TW) {
+    ymin = fmin(ymin, X[i].y);
+    ymax = fmax(ymax, X[i].y);
+  }
+  for (int e = tid; e < ne; e += TW) {
+    const double2 A = X[ea[e]], Bp = X[eb[e]];
+    const double mx = 0.5 * (A.x + Bp.x), my = 0.5 * (A.y + Bp.y);
+    pts[2 * (nv + e)] = mx;
+    pts[2 * (nv + e) + 1] = my;
+    if (eflag[e] & 1) {
+      onb[ea[e]] = 1;
+      onb[eb[e]] = 1;
+      const double Xs[3] = {A.x, Bp.x, mx}, Ys[3] = {A.y, Bp.y, my};
+      bool walls = true, air = true, inflow = true, outflow = true;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        walls = walls && (Ys[q] > 0.5 - 2 * E || Ys[q] < -0.5 + 2 * E);
+        air = air && (Xs[q] < 3.0 - E && Xs[q] > -0.5 + E && Ys[q] < 0.5 - E && Ys[q] > -0.5 + E);
+        inflow = inflow && (Xs[q] < -0.5 + E);
+        outflow = outflow && (Xs[q] > 3.0 - 2 * E);
+      }
+      int tg = 4;
+      if (walls) tg = 0;
+      if (air) tg = 1;
+      if (inflow) tg = 2;
+      if (outflow) tg = 3;
+      eflag[e] = (uint8_t)(1 | ((tg + 1) << 4));
+    }
+  }
+  // y range of the mesh (inflow profile): workgroup min / max through LDS atomics on the bit patterns is awkward for
+  // doubles; 512 partial values through `dist` (free until the distance phase) instead
+  __syncthreads();   // (the hash region is dead from here on)
+  dist[tid] = ymin;
+  dist[TW + tid] = ymax;
+  __syncthreads();
+  for (int off = TW / 2; off > 0; off >>= 1) {
+    if (tid < off) {
+      dist[tid] = fmin(dist[tid], dist[tid + off]);
+      dist[TW + tid] = fmax(dist[TW + tid], dist[TW + tid + off]);
+    }
+    __syncthreads();
+  }
+  const double bot = dist[0], top = dist[TW];
+  __syncthreads();
+  // airfoil facets in edge order
+  for (int e = tid; e < TNS; e += TW) scanb[e] = (e < ne && (eflag[e] >> 4) == 2) ? 1 : 0;
+  __syncthreads();
+  bool flg[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) flg[i] = scanb[tid * PER + i] != 0;
+  __syncthreads();
+  const int naf = scan_excl(scanb, TNS, part);
+  if (naf > D.NAF) {
+    if (tid == 0) status[b] = -2;
+    return;
+  }
+  {
+    int32_t* af = D.af_facets + Bq * D.NAF * 2;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = tid * PER + i;
+      if (e < ne && flg[i]) {
+        const int q = scanb[e];
+        af[2 * q] = eown[e] / 3;
+        af[2 * q + 1] = eown[e] % 3;
+      }
+    }
+  }
+  if (tid == 0) D.naf[b] = naf;
+  __syncthreads();
+  // ================= removable: neither x nor y equals ANY boundary vertex's x / y (numpy `in` quirk)
+  for (int v = tid; v < TNS; v += TW) scanb[v] = (v < nv && onb[v]) ? 1 : 0;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < PER; ++i) flg[i] = scanb[tid * PER + i] != 0;
+  __syncthreads();
+  const int nb = scan_excl(scanb, TNS, part);
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int v = tid * PER + i;
+    if (v < nv && flg[i]) blist[scanb[v]] = (uint16_t)v;
+  }
+  __syncthreads();
+  for (int v = tid; v < TNS; v += TW) {
+    int r = 0;
+    if (v < nv) {
+      const double px = X[v].x, py = X[v].y;
+      bool hit = false;
+      for (int j = 0; j < nb; ++j) {
+        const double2 q = X[blist[j]];
+        hit = hit || q.x == px || q.y == py;
+      }
+      r = hit ? 0 : 1;
+    }
+    scanb[v] = r;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < PER; ++i) flg[i] = scanb[tid * PER + i] != 0;
+  __syncthreads();
+  const int nrem = scan_excl(scanb, TNS, part);
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int v = tid * PER + i;
+    if (v < nv && flg[i]) remv[scanb[v]] = (uint16_t)v;
+  }
+  if (tid == 0) D.nremovable[b] = nrem;
+  // ================= distances to the airfoil polygon (0 inside), stable argsort, window of N
+  const int np_ = D.npoly;
+  for (int i = tid; i < np_; i += TW) poly[i] = make_double2(D.polygon[2 * i], D.polygon[2 * i + 1]);
+  __syncthreads();
+  for (int r = tid; r < nrem; r += TW) {
+    const double px = X[remv[r]].x, py = X[remv[r]].y;
+    bool inside = false;
+    double d2 = 1e300;
+    for (int i = 0; i < np_; ++i) {
+      const double2 A = poly[i], Bp = poly[i + 1 == np_ ? 0 : i + 1];
+      if ((A.y > py) != (Bp.y > py)) {
+        const double xin = A.x + (py - A.y) * (Bp.x - A.x) / (Bp.y - A.y);
+        if (px < xin) inside = !inside;
+      }
+      d2 = fmin(d2, seg_dist2(px, py, A.x, A.y, Bp.x, Bp.y));
+    }
+    dist[r] = inside ? 0.0 : sqrt(d2);
+  }
+  __syncthreads();
+  for (int r = tid; r < nrem; r += TW) {
+    const double dr = dist[r];
+    int rank = 0;
+    for (int q = 0; q < nrem; ++q) {
+      const double dq = dist[q];
+      rank += (dq < dr) || (dq == dr && q < r);
+    }
+    order[rank] = (uint16_t)r;
+  }
+  for (int v = tid; v < TNV; v += TW) inv[v] = -1;
+  __syncthreads();
+  const int off = D.offset[b];
+  int nsel = nrem - off;
+  nsel = nsel > D.N ? D.N : (nsel < 0 ? 0 : nsel);
+  {
+    int32_t* nc = D.n_closest + Bq * D.N;
+    int32_t* cm = D.coord_map + Bq * D.N;
+    for (int i = tid; i < D.N; i += TW) {
+      if (i < nsel) {
+        const int r = order[off + i];
+        nc[i] = r;
+        cm[i] = remv[r];
+        inv[remv[r]] = (int16_t)i;
+      } else {
+        nc[i] = 0;
+        cm[i] = 0;
+      }
+    }
+  }
+  if (tid == 0) D.nsel[b] = nsel;
+  __syncthreads();
+  // ================= state graph: cells whose three vertices are all selected, in cell order
+  for (int t = tid; t < TNS; t += TW) {
+    int f = 0;
+    if (t < nt) f = (inv[tri[3 * t]] >= 0 && inv[tri[3 * t + 1]] >= 0 && inv[tri[3 * t + 2]] >= 0) ? 1 : 0;
+    scanb[t] = f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < PER; ++i) flg[i] = scanb[tid * PER + i] != 0;
+  __syncthreads();
+  const int ngood = scan_excl(scanb, TNS, part);
+  if (3 * ngood > D.EMAX) {
+    if (tid == 0) status[b] = -3;
+    return;
+  }
+  {
+    int32_t* es = D.edge_src + Bq * D.EMAX;
+    int32_t* ed = D.edge_dst + Bq * D.EMAX;
+    double* el = D.edge_len + Bq * D.EMAX;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int t = tid * PER + i;
+      if (t < nt && flg[i]) {
+        const int v0 = tri[3 * t], v1 = tri[3 * t + 1], v2 = tri[3 * t + 2];
+        const int vs[3] = {v0, v1, v2}, id[3] = {inv[v0], inv[v1], inv[v2]};
+        const int pa[3] = {0, 0, 1}, pb[3] = {1, 2, 2};
+        const int base = 3 * scanb[t];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          es[base + q] = id[pa[q]];
+          ed[base + q] = id[pb[q]];
+          const double dx = X[vs[pa[q]]].x - X[vs[pb[q]]].x, dy = X[vs[pa[q]]].y - X[vs[pb[q]]].y;
+          el[base + q] = sqrt(dx * dx + dy * dy);
+        }
+      }
+    }
+  }
+  if (tid == 0) D.nedges[b] = 3 * ngood;
+  if (!has_ipcs) return;
+  __syncthreads();
+
+  // ================= index data of the matrix-free IPCS path (ipcs_topology_one of the host engine)
+  int32_t* scat = O.mf_scat + Bq * 6 * D.NT;
+  int8_t* cof = O.cell_outflow + Bq * D.NT;
+  uint8_t* fl = O.bcu_flag + Bq * D.NP;
+  double* gx = O.bcu_gx + Bq * D.NP;
+  uint8_t* pf = O.bcp_flag + Bq * D.NV;
+  for (int t = tid; t < D.NT; t += TW) cof[t] = -1;
+  for (int i = tid; i < D.NP; i += TW) {
+    fl[i] = 0;
+    gx[i] = 0.0;
+  }
+  for (int i = tid; i < D.NV; i += TW) pf[i] = 0;
+  __syncthreads();
+  const double H = top - bot, Um = 1.5;
+  // Dirichlet data, list order [inlet, airfoil, walls]: later wins on shared dofs -> three ordered passes
+  for (int w = 0; w < 3; ++w) {
+    const int want = w == 0 ? 2 : (w == 1 ? 1 : 0);
+    for (int e = tid; e < ne; e += TW) {
+      if ((eflag[e] >> 4) != want + 1) continue;
+      const int dofs[3] = {ea[e], eb[e], nv + e};
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int dq = dofs[q];
+        fl[dq] = 1;
+        if (want == 2) {
+          const double y = q < 2 ? X[dq].y : 0.5 * (X[ea[e]].y + X[eb[e]].y);
+          gx[dq] = -4.0 * Um * (y - bot) * (y - top) / H / H;
+        } else {
+          gx[dq] = 0.0;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // outflow facets: pressure Dirichlet vertices, cell -> local facet, entries (row, col, src) of the facet term
+  for (int e = tid; e < TNS; e += TW) scanb[e] = (e < ne && (eflag[e] >> 4) == 4) ? 1 : 0;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < PER; ++i) flg[i] = scanb[tid * PER + i] != 0;
+  __syncthreads();
+  const int nof = scan_excl(scanb, TNS, part);
+  const int nent = 18 * nof;
+  if (nent > O.NBE || nent > 2 * TNV) {
+    if (tid == 0) status[b] = -5;
+    return;
+  }
+  // entry keys in LDS (aliasing dist / poly: both dead): key = row << 24 | col << 12 | (i * 6 + j), src kept beside it
+  uint32_t* ekey = reinterpret_cast<uint32_t*>(dist);      // [nent] (<= 2048)
+  int32_t* esrc = reinterpret_cast<int32_t*>(poly);        // [nent] -> spills into cntd for nent > 1024: keep it small
+  if (nent > 1024) {
+    if (tid == 0) status[b] = -5;
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int e = tid * PER + i;
+    if (e < ne && flg[i]) {
+      pf[ea[e]] = 1;
+      pf[eb[e]] = 1;
+      const int c = eown[e] / 3, k = eown[e] % 3;
+      cof[c] = (int8_t)k;
+      const int rows[3] = {k == 0 ? 1 : 0, k == 2 ? 1 : 2, 3 + k};
+      const int base = 18 * scanb[e];
+      for (int q = 0; q < 3; ++q)
+        for (int j = 0; j < 6; ++j) {
+          const int row = cd[rows[q] * D.NT + c], col = cd[j * D.NT + c];
+          ekey[base + 6 * q + j] = ((uint32_t)row << 20) | ((uint32_t)col << 8);  // (src breaks ties below)
+          esrc[base + 6 * q + j] = c * 36 + rows[q] * 6 + j;
+        }
+    }
+  }
+  __syncthreads();
+  {
+    int32_t* bo_rows = O.bo_rows + Bq * O.NBO;
+    int32_t* bo_ptr = O.bo_ptr + Bq * (O.NBO + 1);
+    int32_t* bo_col = O.bo_col + Bq * O.NBE;
+    int32_t* bo_src = O.bo_src + Bq * O.NBE;
+    // rank by counting over (row, col, src); then rows = runs of equal row
+    for (int t = tid; t < nent; t += TW) {
+      const uint32_t kt = ekey[t];
+      const int st = esrc[t];
+      int rank = 0;
+      for (int q = 0; q < nent; ++q) rank += (ekey[q] < kt) || (ekey[q] == kt && esrc[q] < st);
+      bo_col[rank] = (int32_t)((kt >> 8) & 0xFFF);
+      bo_src[rank] = st;
+      cntd[rank] = (int32_t)(kt >> 20);  // row of the sorted entry
+    }
+    __syncthreads();
+    for (int t = tid; t < TNS; t += TW) scanb[t] = (t < nent && (t == 0 || cntd[t] != cntd[t - 1])) ? 1 : 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER; ++i) flg[i] = scanb[tid * PER + i] != 0;
+    __syncthreads();
+    const int nbo = scan_excl(scanb, TNS, part);
+    if (nbo > O.NBO) {
+      if (tid == 0) status[b] = -5;
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int t = tid * PER + i;
+      if (t < nent && flg[i]) {
+        bo_rows[scanb[t]] = cntd[t];
+        bo_ptr[scanb[t]] = t;
+      }
+    }
+    if (tid == 0) {
+      bo_ptr[nbo] = nent;
+      O.nbo[b] = nbo;
+      misc[0] = 0;
+    }
+    __syncthreads();
+    // at most two outflow rows per row-owner thread of the 512-thread kernels
+    for (int t = tid; t < nbo; t += TW) {
+      int same = 0;
+      for (int q = 0; q < nbo; ++q) same += (bo_rows[q] % 512) == (bo_rows[t] % 512);
+      if (same > 2) misc[0] = 1;
+    }
+    __syncthreads();
+    if (misc[0]) {
+      if (tid == 0) status[b] = -4;
+      return;
+    }
+  }
+  // packed per-triangle metadata
+  for (int i = 0; i < 6; ++i)
+    for (int t = tid; t < nt; t += TW) scat[i * D.NT + t] = cd[i * D.NT + t] | (i == 0 ? ((int32_t)(cof[t] + 1) << 28) : 0);
+  // dof <- element-slot gathers, ascending slots: count, scan, unordered fill, per-dof sort of the (short) lists
+  auto gather = [&](int nl, int ndof, int32_t* gptr, int32_t* gsrc) {
+    for (int i = tid; i < TNS; i += TW) scanb[i] = 0;
+    __syncthreads();
+    for (int s = tid; s < nl * nt; s += TW) atomicAdd(&scanb[cd[(s % nl) * D.NT + s / nl]], 1);
+    __syncthreads();
+    const int tot = scan_excl(scanb, TNS, part);
+    (void)tot;
+    for (int i = tid; i <= ndof; i += TW) {
+      gptr[i] = i < ndof ? scanb[i] : nl * nt;
+      if (i < ndof) fill[i] = 0;
+    }
+    __syncthreads();
+    for (int s = tid; s < nl * nt; s += TW) {
+      const int dof = cd[(s % nl) * D.NT + s / nl];
+      gsrc[scanb[dof] + atomicAdd(&fill[dof], 1)] = s;   // slot = t * nl + i with t = s / nl, i = s % nl
+    }
+    __syncthreads();
+    for (int i = tid; i < ndof; i += TW) {
+      const int q0 = scanb[i], q1 = q0 + fill[i];
+      for (int a_ = q0 + 1; a_ < q1; ++a_) {
+        const int32_t w = gsrc[a_];
+        int j = a_ - 1;
+        while (j >= q0 && gsrc[j] > w) {
+          gsrc[j + 1] = gsrc[j];
+          --j;
+        }
+        gsrc[j + 1] = w;
+      }
+    }
+    __syncthreads();
+  };
+  gather(3, nv, O.g1_ptr + Bq * (D.NV + 1), O.g1_src + Bq * 3 * D.NT);
+  gather(6, n2, O.g2_ptr + Bq * (D.NP + 1), O.g2_src + Bq * 6 * D.NT);
+  // SELL-64 pattern of the P1 Laplacian: row = {vertex} + neighbours, ascending; slice width = longest row
+  for (int i = tid; i < TNS; i += TW) scanb[i] = i < nv ? 1 : 0;   // the diagonal
+  __syncthreads();
+  for (int e = tid; e < ne; e += TW) {
+    atomicAdd(&scanb[ea[e]], 1);
+    atomicAdd(&scanb[eb[e]], 1);
+  }
+  __syncthreads();
+  for (int i = tid; i < nv; i += TW) fill[i] = scanb[i];   // row lengths (1 + number of incident edges)
+  __syncthreads();
+  // every thread owns whole rows: it collects the columns of its row from the row's incident cells (g1 lists)
+  {
+    int32_t* so = O.sl1_off + Bq * (D.NV / 64 + 2);
+    int32_t* sc = O.sl1_col + Bq * O.NSE1;
+    const int ns = (nv + 63) / 64;
+    // slice widths -> offsets
+    for (int s_ = tid; s_ < TNS; s_ += TW) {
+      int w = 0;
+      if (s_ < ns)
+        for (int r = 64 * s_; r < min(nv, 64 * s_ + 64); ++r) w = max(w, fill[r]);
+      scanb[s_] = 64 * w;
+    }
+    __syncthreads();
+    const int total = scan_excl(scanb, TNS, part);
+    if (total > O.NSE1) {
+      if (tid == 0) status[b] = -6;
+      return;
+    }
+    for (int s_ = tid; s_ <= ns; s_ += TW) so[s_] = s_ < ns ? scanb[s_] : total;
+    const int32_t* g1p = O.g1_ptr + Bq * (D.NV + 1);
+    const int32_t* g1s = O.g1_src + Bq * 3 * D.NT;
+    for (int r = tid; r < 64 * ns; r += TW) {
+      const int s_ = r >> 6, l = r & 63;
+      const int base = scanb[s_], w = ((s_ + 1 < ns ? scanb[s_ + 1] : total) - base) >> 6;
+      int len = 0;
+      int cols[24];
+      if (r < nv) {
+        cols[len++] = r;
+        for (int q = g1p[r]; q < g1p[r + 1]; ++q) {
+          const int t = g1s[q] / 3;
+          for (int k = 0; k < 3; ++k) {
+            const int c = tri[3 * t + k];
+            bool seen = false;
+            for (int j = 0; j < len; ++j) seen = seen || cols[j] == c;
+            if (!seen && len < 24) cols[len++] = c;
+          }
+        }
+        for (int a_ = 1; a_ < len; ++a_) {
+          const int wv = cols[a_];
+          int j = a_ - 1;
+          while (j >= 0 && cols[j] > wv) {
+            cols[j + 1] = cols[j];
+            --j;
+          }
+          cols[j + 1] = wv;
+        }
+      }
+      const int rr = min(r, nv - 1);
+      for (int j = 0; j < w; ++j) sc[base + 64 * j + l] = j < len ? cols[j] : rr;
+    }
+  }
+}
+
+}  // namespace mdq_topo
+
+extern "C" int mdq_env_topology(const mdq_env_topo_desc* d, void* stream, int32_t* status) {
+  if (!d || d->B <= 0 || !status) return mdq_set_error("mdq_env_topology: bad arguments");
+  if (d->NV > mdq_topo::TNV || d->NT > mdq_topo::TNT || d->NP > mdq_topo::TNP || d->npoly > mdq_topo::TNPOLY)
+    return mdq_set_error("mdq_env_topology: capacity above 1024 vertices / 2048 triangles / 4096 P2 dofs / 256 polygon points");
+  mdq_ipcs_topo_out o = {};
+  if (d->ipcs) o = *d->ipcs;
+  const size_t lds = 16384 + 65536 + sizeof(int) * mdq_topo::TNS + sizeof(uint16_t) * mdq_topo::TNS +
+                     3 * sizeof(uint16_t) * mdq_topo::TNE + mdq_topo::TNE + mdq_topo::TNV + sizeof(int) * (mdq_topo::TW + 16);
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mdq_topo::topology_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (attr != hipSuccess) return mdq_set_error("hipFuncSetAttribute(topology_kernel) failed");
+  hipLaunchKernelGGL(mdq_topo::topology_kernel, dim3(d->B), dim3(mdq_topo::TW), lds, (hipStream_t)stream, *d, o,
+                     d->ipcs ? 1 : 0, status);
+  if (hipGetLastError() != hipSuccess) return mdq_set_error("topology_kernel launch failed");
+  return 0;
+}

@@ -309,3 +309,61 @@ def smooth_batch_gpu(coords: torch.Tensor, cells: torch.Tensor, nv: torch.Tensor
     assert nv.dtype == torch.int32 and nt.dtype == torch.int32 and iterations.dtype == torch.int32
     _lib.check(lib.mdq_smooth(B, NV, NT, coords.data_ptr(), cells.data_ptr(), nv.data_ptr(), nt.data_ptr(),
                               iterations.data_ptr(), _lib.stream_ptr(stream)), "mdq_smooth")
+
+
+class DeviceTopologyBatch:
+    """Device-resident counterpart of `HostTopologyBatch` (`mdq_env_topology`): inputs `coords` (B,NV,2), `cells`
+    (B,NT,3), `nv`, `nt`, `offset` and all outputs are device tensors (`t` for the mesh / state outputs, `ti` for the
+    matrix-free IPCS index data); nothing but what the caller asks for ever crosses PCIe."""
+
+    def __init__(self, B, NV, NT, NE, NAF, N, EMAX, polygon, device, ipcs=False, nbo_cap=64, nse1_cap=0):
+        self.lib = _lib.load()
+        dev = torch.device(device)
+        NP = NV + NE
+        self.B, self.NV, self.NT, self.NE, self.NP, self.NAF, self.N, self.EMAX = B, NV, NT, NE, NP, NAF, N, EMAX
+        self.device = dev
+
+        def z(shape, dt):
+            return torch.zeros(shape, dtype=dt, device=dev)
+
+        i32, f64 = torch.int32, torch.float64
+        self.polygon = torch.as_tensor(np.ascontiguousarray(polygon, dtype=np.float64), device=dev)
+        self.coords, self.cells = z((B, NV, 2), f64), z((B, NT, 3), i32)
+        self.nv, self.nt, self.offset = z((B,), i32), z((B,), i32), z((B,), i32)
+        self.status = z((B,), i32)
+        self.t = dict(ne=z((B,), i32), cell_dofs=z((B, 6, NT), i32), points=z((B, NP, 2), f64), naf=z((B,), i32),
+                      af_facets=z((B, NAF, 2), i32), nremovable=z((B,), i32), nsel=z((B,), i32),
+                      n_closest=z((B, N), i32), coord_map=z((B, N), i32), nedges=z((B,), i32),
+                      edge_src=z((B, EMAX), i32), edge_dst=z((B, EMAX), i32), edge_len=z((B, EMAX), f64))
+        d = _lib.EnvTopoDesc()
+        d.B, d.NV, d.NT, d.NP, d.NAF, d.N, d.EMAX, d.npoly = B, NV, NT, NP, NAF, N, EMAX, self.polygon.shape[0]
+        d.coords, d.cells, d.nv, d.nt = (a.data_ptr() for a in (self.coords, self.cells, self.nv, self.nt))
+        d.offset, d.polygon = self.offset.data_ptr(), self.polygon.data_ptr()
+        for k, a in self.t.items():
+            setattr(d, k, a.data_ptr())
+        self.ti = None
+        if ipcs:
+            NBO, NBE = int(nbo_cap), 6 * int(nbo_cap)
+            NSE1 = int(nse1_cap) if nse1_cap else 64 * 16 * (NV // 64 + 1)
+            self.NBO, self.NBE, self.NSE1 = NBO, NBE, NSE1
+            self.ti = dict(mf_scat=z((B, 6, NT), i32), cell_outflow=z((B, NT), torch.int8),
+                           bcu_flag=z((B, NP), torch.uint8), bcu_gx=z((B, NP), f64), bcp_flag=z((B, NV), torch.uint8),
+                           nbo=z((B,), i32), bo_rows=z((B, NBO), i32), bo_ptr=z((B, NBO + 1), i32),
+                           bo_col=z((B, NBE), i32), bo_src=z((B, NBE), i32), g1_ptr=z((B, NV + 1), i32),
+                           g1_src=z((B, 3 * NT), i32), g2_ptr=z((B, NP + 1), i32), g2_src=z((B, 6 * NT), i32),
+                           sl1_off=z((B, NV // 64 + 2), i32), sl1_col=z((B, NSE1), i32))
+            o = _lib.IpcsTopoOut()
+            o.NBO, o.NBE, o.NSE1 = NBO, NBE, NSE1
+            for k, a in self.ti.items():
+                setattr(o, k, a.data_ptr())
+            self._ipcs_out = o
+            d.ipcs = C.cast(C.pointer(o), C.c_void_p)
+        self.desc = d
+
+    def run(self, stream=None, check=True):
+        _lib.check(self.lib.mdq_env_topology(C.byref(self.desc), _lib.stream_ptr(stream), self.status.data_ptr()),
+                   "mdq_env_topology")
+        if check:
+            st = self.status.cpu().numpy()
+            if (st != 0).any():
+                raise _lib.MeshDQNHipError(f"topology kernel failed: env {np.flatnonzero(st)} status {st[st != 0]}")

@@ -25,7 +25,7 @@ import torch
 
 from . import _lib
 from .env import Env2DAirfoil
-from .mesh_ops import HostTopologyBatch, remesh_batch, smooth_batch_gpu
+from .mesh_ops import DeviceTopologyBatch, HostTopologyBatch, remesh_batch, smooth_batch_gpu
 
 
 def _host_cores() -> int:
@@ -45,7 +45,7 @@ def _host_cores() -> int:
 class VecEnv2DAirfoil:
     def __init__(self, config, num_envs: int, compute_device="cuda", nthreads: int = 0, base_env: Env2DAirfoil | None = None,
                  auto_reset: bool = True, emax: int = 1536, flow_steps: int = 0, flow_rtol: float = 1e-10,
-                 gpu_smoothing: bool = True):
+                 gpu_smoothing: bool = True, gpu_topology: bool = True):
         self.lib = _lib.load()
         self.B = int(num_envs)
         self.device = torch.device(compute_device)
@@ -53,6 +53,9 @@ class VecEnv2DAirfoil:
         self.nthreads = int(nthreads) if nthreads > 0 else max(1, min(_host_cores(), self.B))
         self.auto_reset = auto_reset
         self.gpu_smoothing = bool(gpu_smoothing)   # mdq_smooth (dataflow kernel) instead of the host loop
+        # mdq_env_topology (device engine, bit-identical to the host engine): the host then only re-triangulates the
+        # cavity of a removed vertex; needs the GPU smoothing path (coordinates stay on the device)
+        self.gpu_topology = bool(gpu_topology) and self.gpu_smoothing
         # S3 ("north-star step"): after every remesh, `flow_steps` IPCS steps on the coarsened mesh warm-started
         # from the interpolated last snapshot (0 = the reference's step, which never re-solves the flow)
         self.flow_steps, self.flow_rtol = int(flow_steps), float(flow_rtol)
@@ -85,13 +88,18 @@ class VecEnv2DAirfoil:
         deg = np.zeros(64 * (NV // 64 + 1), np.int64)
         deg[:NV] = np.diff(nbr_ptr) + 1
         nse1 = int(64 * deg.reshape(-1, 64).max(axis=1).sum())        # SELL-64 entries of the P1 Laplacian, initial mesh
-        self.topo = HostTopologyBatch(B, NV, NT, self.NE, self.NAF, N, self.EMAX, self.polygon, ipcs=self.flow_steps > 0,
-                                      nse1_cap=(int(1.2 * nse1) + 63) // 64 * 64)
+        nse1_cap = (int(1.2 * nse1) + 63) // 64 * 64
+        self.topo = HostTopologyBatch(B, NV, NT, self.NE, self.NAF, N, self.EMAX, self.polygon,
+                                      ipcs=self.flow_steps > 0 and not self.gpu_topology, nse1_cap=nse1_cap)
+        self.dtopo = None
+        if self.gpu_topology:
+            self.dtopo = DeviceTopologyBatch(B, NV, NT, self.NE, self.NAF, N, self.EMAX, self.polygon, self.device,
+                                             ipcs=self.flow_steps > 0, nse1_cap=nse1_cap)
         if self.flow_steps > 0:
             self._init_flow(base)
         self.coords, self.cells, self.nv, self.nt, self.offset = (self.topo.coords, self.topo.cells, self.topo.nv,
                                                                    self.topo.nt, self.topo.offset)
-        self.h = self.topo.h
+        self.h = self.topo.h   # (device engine: only nsel / n_closest / coord_map / nedges / ne are mirrored here)
         self.steps = np.zeros(B, np.int64)
         self.initial_num_node = NV
         self.new_drags = np.zeros((B, self.S))
@@ -101,9 +109,12 @@ class VecEnv2DAirfoil:
     # ------------------------------------------------------------------
     def _init_flow(self, base):
         """Device arrays + descriptor of the matrix-free IPCS path (mode 3, CG pressure) over the batch."""
-        dev, tp = self.device, self.topo
+        dev, tp = self.device, (self.dtopo if self.gpu_topology else self.topo)
         B, NV, NT, NE, NP = self.B, self.NV, self.NT, self.NE, self.NP
-        t = {k: torch.from_numpy(a).to(dev) for k, a in tp.hi.items()}
+        if self.gpu_topology:   # the device engine's outputs ARE the descriptor's index arrays
+            t = dict(tp.ti)
+        else:
+            t = {k: torch.from_numpy(a).to(dev) for k, a in tp.hi.items()}
 
         def z(*shape):
             return torch.zeros(shape, dtype=torch.float64, device=dev)
@@ -130,9 +141,10 @@ class VecEnv2DAirfoil:
 
     def _flow(self, keep, out_u, out_p):
         """`flow_steps` IPCS steps on every (coarsened) mesh, warm-started from the interpolated last snapshot."""
-        t, d, hi = self.flow_t, self.flow_desc, self.topo.hi
-        for k in hi:
-            t[k].copy_(self.topo.pinned[k], non_blocking=True)
+        t, d = self.flow_t, self.flow_desc
+        if not self.gpu_topology:
+            for k in self.topo.hi:
+                t[k].copy_(self.topo.pinned[k], non_blocking=True)
         for k in ("coords", "cell_dofs", "af_facets", "nv", "nt", "ne", "naf"):
             setattr(d, k, keep[k].data_ptr())
         t["u_n"].copy_(out_u[:, self.S - 1])
@@ -158,11 +170,26 @@ class VecEnv2DAirfoil:
     def reset_all(self):
         for b in range(self.B):
             self._reset_env(b)
+        if self.gpu_topology:
+            self._upload_mesh()
         self._refresh()
         # every environment restarts from the same mesh: cache its derived data (row 0) for in-place resets
         self._init_cache = dict(h={k: a[0].copy() for k, a in self.h.items()}, u=self.u[0].clone(), p=self.p[0].clone(),
                                 drags=self.new_drags[0].copy(), lifts=self.new_lifts[0].copy())
+        if self.gpu_topology:
+            self._init_cache["dev"] = {k: self.dtopo.t[k][0].clone() for k in self._STATE_KEYS}
         return self.get_state()
+
+    _STATE_KEYS = ("n_closest", "nsel", "coord_map", "nedges", "edge_src", "edge_dst")   # what get_state reads
+
+    def _upload_mesh(self):
+        """Host mesh (page-locked) -> the device engine's input tensors, asynchronously on the current stream."""
+        dt, pin = self.dtopo, self.topo.pinned
+        dt.coords.copy_(pin["coords"], non_blocking=True)
+        dt.cells.copy_(pin["cells"], non_blocking=True)
+        dt.nv.copy_(pin["nv"], non_blocking=True)
+        dt.nt.copy_(pin["nt"], non_blocking=True)
+        dt.offset.copy_(torch.from_numpy(self.offset), non_blocking=False)
 
     def _restore_initial(self, idx):
         """Reset environments `idx` in place from the cached initial-mesh data (no recomputation)."""
@@ -177,17 +204,26 @@ class VecEnv2DAirfoil:
         self.u[ti] = c["u"]
         self.p[ti] = c["p"]
         self._coords_dev[ti] = torch.from_numpy(self.x0).to(self.device)
+        if self.gpu_topology:
+            for k in self._STATE_KEYS:
+                self.dtopo.t[k][ti] = c["dev"][k]
 
     def _refresh(self):
         """Topology + selection on the host, snapshot interpolation + forces on the GPU, for all envs."""
-        torch.cuda.current_stream(self.device).synchronize()   # pending async uploads read the arrays the engine rewrites
-        self.topo.run(self.nthreads)
         dev, h = self.device, self.h
         B, NV, NT, NP = self.B, self.NV, self.NT, self.NP
-        up = self.topo.upload
-        t_pts = up("points", dev)
-        np1 = up("nv", dev)
-        npts = np1 + up("ne", dev)
+        if self.gpu_topology:
+            dt = self.dtopo
+            dt.run(check=False)                     # status is read back with the other results below
+            t_pts, np1 = dt.t["points"], dt.nv
+            npts = np1 + dt.t["ne"]
+        else:
+            torch.cuda.current_stream(dev).synchronize()   # pending async uploads read the arrays the engine rewrites
+            self.topo.run(self.nthreads)
+            up = self.topo.upload
+            t_pts = up("points", dev)
+            np1 = up("nv", dev)
+            npts = np1 + up("ne", dev)
         it = self.interp
         out_u = torch.zeros((B, self.S, NP, 2), dtype=torch.float64, device=dev)
         out_p = torch.zeros((B, self.S, NV), dtype=torch.float64, device=dev)
@@ -204,9 +240,14 @@ class VecEnv2DAirfoil:
         md = _lib.IpcsDesc()
         md.B, md.NV, md.NT, md.NE, md.N2, md.NAF = B, NV, NT, self.NE, NP, self.NAF
         md.mu = self.mu
-        t_coords = up("coords", dev)
-        keep = dict(coords=t_coords, cell_dofs=up("cell_dofs", dev), af_facets=up("af_facets", dev), nv=np1,
-                    nt=up("nt", dev), ne=up("ne", dev), naf=up("naf", dev))
+        if self.gpu_topology:
+            t_coords = dt.coords
+            keep = dict(coords=t_coords, cell_dofs=dt.t["cell_dofs"], af_facets=dt.t["af_facets"], nv=np1, nt=dt.nt,
+                        ne=dt.t["ne"], naf=dt.t["naf"])
+        else:
+            t_coords = up("coords", dev)
+            keep = dict(coords=t_coords, cell_dofs=up("cell_dofs", dev), af_facets=up("af_facets", dev), nv=np1,
+                        nt=up("nt", dev), ne=up("ne", dev), naf=up("naf", dev))
         for k, v in keep.items():
             setattr(md, k, v.data_ptr())
         drag = torch.empty((B, self.S), dtype=torch.float64, device=dev)
@@ -219,6 +260,12 @@ class VecEnv2DAirfoil:
             self.flow_drag, self.flow_lift = fd.cpu().numpy(), fl.cpu().numpy()
         self.new_drags = drag.cpu().numpy().copy()
         self.new_lifts = lift.cpu().numpy().copy()
+        if self.gpu_topology:
+            st = dt.status.cpu().numpy()
+            if (st != 0).any():
+                raise _lib.MeshDQNHipError(f"topology kernel failed: env {np.flatnonzero(st)} status {st[st != 0]}")
+            for k in ("nsel", "coord_map", "nedges", "n_closest", "ne"):   # small mirrors the host logic needs
+                h[k][...] = dt.t[k].cpu().numpy()
 
     # ------------------------------------------------------------------
     def get_state(self):
@@ -227,7 +274,10 @@ class VecEnv2DAirfoil:
         n_closest / coord_map / nedges."""
         dev, h, B, N, S = self.device, self.h, self.B, self.N, self.S
         x = torch.empty((B, N, 2 + 3 * S), dtype=torch.float32, device=dev)
-        nc, nsel = self.topo.upload("n_closest", dev), self.topo.upload("nsel", dev)
+        if self.gpu_topology:
+            nc, nsel = self.dtopo.t["n_closest"], self.dtopo.t["nsel"]
+        else:
+            nc, nsel = self.topo.upload("n_closest", dev), self.topo.upload("nsel", dev)
         _lib.check(self.lib.mdq_state_features(B, N, S, self.NV, self.NP, self._coords_dev.data_ptr(), self.u.data_ptr(),
                                                self.p.data_ptr(), nc.data_ptr(), nsel.data_ptr(), x.data_ptr(),
                                                _lib.stream_ptr()), "mdq_state_features")
@@ -235,8 +285,12 @@ class VecEnv2DAirfoil:
         edge_ptr = np.zeros(B + 1, np.int32)
         edge_ptr[1:] = np.cumsum(ne)
         live = np.arange(self.EMAX)[None, :] < ne[:, None]          # (B,EMAX) valid edge slots, row-major = env order
-        esrc, edst = h["edge_src"][live], h["edge_dst"][live]
-        return dict(x=x, esrc=torch.from_numpy(esrc).to(dev), edst=torch.from_numpy(edst).to(dev),
+        if self.gpu_topology:
+            live_d = torch.from_numpy(live).to(dev)
+            esrc_d, edst_d = self.dtopo.t["edge_src"][live_d], self.dtopo.t["edge_dst"][live_d]
+        else:
+            esrc_d, edst_d = torch.from_numpy(h["edge_src"][live]).to(dev), torch.from_numpy(h["edge_dst"][live]).to(dev)
+        return dict(x=x, esrc=esrc_d, edst=edst_d,
                     edge_ptr=torch.from_numpy(edge_ptr).to(dev),
                     node_ptr=torch.arange(B + 1, dtype=torch.int32, device=dev) * N,
                     n_closest=h["n_closest"].copy(), coord_map=h["coord_map"].copy(), nedges=h["nedges"].copy(),
@@ -261,11 +315,19 @@ class VecEnv2DAirfoil:
             # host: cavity re-triangulation + Delaunay restoration only; GPU: smooth(50) of the changed meshes
             status = remesh_batch(self.coords, self.cells, self.nv, self.nt, rem, 0, self.nthreads)
             dev = self.device
-            up = self.topo.upload
-            tc = up("coords", dev)
             its = torch.from_numpy(np.where((rem >= 0) & (status == 0), 50, 0).astype(np.int32)).to(dev)
-            smooth_batch_gpu(tc, up("cells", dev), up("nv", dev), up("nt", dev), its)
-            self.topo.pinned["coords"].copy_(tc)        # D2H into the page-locked array (synchronises this stream)
+            if self.gpu_topology:
+                self._upload_mesh()
+                dt = self.dtopo
+                smooth_batch_gpu(dt.coords, dt.cells, dt.nv, dt.nt, its)
+                # the host engine needs the smoothed coordinates for its next cavity: asynchronous D2H into the
+                # page-locked array, complete before this step's results are read back
+                self.topo.pinned["coords"].copy_(dt.coords, non_blocking=True)
+            else:
+                up = self.topo.upload
+                tc = up("coords", dev)
+                smooth_batch_gpu(tc, up("cells", dev), up("nv", dev), up("nt", dev), its)
+                self.topo.pinned["coords"].copy_(tc)    # D2H into the page-locked array (synchronises this stream)
         else:
             status = remesh_batch(self.coords, self.cells, self.nv, self.nt, rem, 50, self.nthreads)
         code[status != 0] = 2

@@ -264,3 +264,59 @@ def test_env_groups_equal_one_batch(lib_built):
             assert np.allclose(nd, ref[k][1][lo:lo + env.B], rtol=1e-12, atol=0)
             assert np.allclose(fd, ref[k][2][lo:lo + env.B], rtol=1e-9, atol=0)
         assert np.allclose(out[g][0], ref[-1][0][lo:lo + env.B], rtol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["ys930", "ah93w145"])
+def test_device_topology_engine_is_bit_identical_to_host_engine(lib_built, meshes, name):
+    """mdq_env_topology (one workgroup per mesh in LDS) against mdq_env_topology_host, every output array, on the
+    smoothed mesh, after vertex removals and with a shifted selection window; includes the IPCS index data."""
+    from meshdqn_amd.ipcs_batch import smooth_coords
+    from meshdqn_amd.mesh_ops import DeviceTopologyBatch, HostTopologyBatch, remesh_batch
+    from meshdqn_amd.topology import MeshTopology
+    coords, cells = meshes[name]
+    t0 = MeshTopology(coords, cells)
+    x0 = smooth_coords(t0, 50)
+    tags = t0.facet_tags(x0)
+    polygon = x0[[v for v in range(t0.nv) if t0.on_boundary[v] and -0.5 < x0[v, 0] < 3 and -0.5 < x0[v, 1] < 0.5]]
+    B = 3
+    args = (B, t0.nv, t0.nt, t0.ne, int((tags == 1).sum()), 180, 1536, polygon)
+    hb = HostTopologyBatch(*args, ipcs=True)
+    for b in range(B):
+        hb.coords[b], hb.cells[b], hb.nv[b], hb.nt[b] = x0, np.sort(cells, axis=1), t0.nv, t0.nt
+    interior = np.flatnonzero(~t0.on_boundary)
+    for rnd in range(3):
+        rem = np.array([-1, interior[40 + 7 * rnd], interior[300 + 11 * rnd]], np.int32)
+        assert (remesh_batch(hb.coords, hb.cells, hb.nv, hb.nt, rem, 50, 2) == 0).all()
+    hb.offset[:] = [0, 3, 0]
+    hb.run(2)
+    db = DeviceTopologyBatch(*args, device="cuda", ipcs=True, nse1_cap=hb.NSE1)
+    db.coords.copy_(torch.from_numpy(hb.coords)); db.cells.copy_(torch.from_numpy(hb.cells))
+    db.nv.copy_(torch.from_numpy(hb.nv)); db.nt.copy_(torch.from_numpy(hb.nt)); db.offset.copy_(torch.from_numpy(hb.offset))
+    db.run()
+    torch.cuda.synchronize()
+    g = {k: v.cpu().numpy() for k, v in db.t.items()}
+    gi = {k: v.cpu().numpy() for k, v in db.ti.items()}
+    for b in range(B):
+        nv, nt, ne = int(hb.nv[b]), int(hb.nt[b]), int(hb.h["ne"][b])
+        n2 = nv + ne
+        for k in ("ne", "naf", "nremovable", "nsel", "nedges"):
+            assert g[k][b] == hb.h[k][b], (k, b)
+        naf, nE = int(hb.h["naf"][b]), int(hb.h["nedges"][b])
+        assert np.array_equal(g["cell_dofs"][b][:, :nt], hb.h["cell_dofs"][b][:, :nt])
+        assert np.array_equal(g["points"][b][:n2], hb.h["points"][b][:n2])                 # bitwise
+        assert np.array_equal(g["af_facets"][b][:naf], hb.h["af_facets"][b][:naf])
+        assert np.array_equal(g["n_closest"][b], hb.h["n_closest"][b])
+        assert np.array_equal(g["coord_map"][b], hb.h["coord_map"][b])
+        for k in ("edge_src", "edge_dst", "edge_len"):
+            assert np.array_equal(g[k][b][:nE], hb.h[k][b][:nE]), (k, b)
+        hi = hb.hi
+        assert gi["nbo"][b] == hi["nbo"][b]
+        nbo = int(hi["nbo"][b])
+        nbe = int(hi["bo_ptr"][b][nbo])
+        checks = dict(cell_outflow=nt, bcu_flag=n2, bcu_gx=n2, bcp_flag=nv, bo_rows=nbo, bo_ptr=nbo + 1, bo_col=nbe,
+                      bo_src=nbe, g1_ptr=nv + 1, g1_src=3 * nt, g2_ptr=n2 + 1, g2_src=6 * nt, sl1_off=(nv + 63) // 64 + 1)
+        for k, n in checks.items():
+            assert np.array_equal(gi[k][b][:n], hi[k][b][:n]), (k, b)
+        assert np.array_equal(gi["mf_scat"][b][:, :nt], hi["mf_scat"][b][:, :nt])
+        nse = int(hi["sl1_off"][b][(nv + 63) // 64])
+        assert np.array_equal(gi["sl1_col"][b][:nse], hi["sl1_col"][b][:nse])

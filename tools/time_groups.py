@@ -6,6 +6,7 @@ from meshdqn_amd.env import Env2DAirfoil
 from meshdqn_amd.vec_env import VecEnvGroups
 from meshdqn_amd.airfoilgcnn import NodeRemovalNet
 from meshdqn_amd.gcn_fused import FusedGcn
+sys.setswitchinterval(float(os.environ.get("SWI", "0.005")))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 FLOW = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 G_ = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
