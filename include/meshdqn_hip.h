@@ -315,6 +315,17 @@ int mdq_state_features(int32_t B, int32_t N, int32_t S, int32_t NV, int32_t NP, 
 int mdq_smooth(int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t* cells, const int32_t* nv,
                const int32_t* nt, const int32_t* iterations, void* stream);
 
+/*
+ * Env2DAirfoil._remove_vertex (Env2DAirfoil.py:452-512) for B meshes on the GPU, WITHOUT the smoothing (mdq_smooth):
+ * ear clipping of the removed vertex's star polygon + Lawson flips to the (unique) Delaunay triangulation = the
+ * reference's global scipy Delaunay + all-boundary filter as a set of cells; vertex ids above the removed one shift
+ * down; cells are written with ascending vertex ids.  remove_idx[b] < 0 leaves mesh b untouched.  status[b]: 0 ok,
+ * -1..-4 star / boundary vertex / ear clipping failures, -11 non-manifold, -12 flip work list exhausted (mesh b is
+ * untouched on failure).  All pointers are device pointers.  Capacity: NV <= 1024, NT <= 2048.
+ */
+int mdq_remesh(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv, int32_t* nt,
+               const int32_t* remove_idx, int32_t* status, void* stream);
+
 /* ---- optional outputs of mdq_env_topology_host: the index data of the matrix-free IPCS path (mode 3 with the CG
  *      pressure solver) on every coarsened mesh, i.e. what FlowSolver.__init__/remesh derive from the mesh
  *      (flow_solver.py:85-132,194-226) minus the assembled patterns.  Same layouts as the mdq_ipcs_desc fields of the

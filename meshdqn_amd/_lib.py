@@ -96,6 +96,8 @@ SYMBOLS = {
     "mdq_gcn_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdq_interpolate_snapshots": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mdq_remesh": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                             C.c_void_p, C.c_void_p]),
     "mdq_remesh_host": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "mdq_env_topology_host": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),

@@ -376,13 +376,23 @@ static int remesh_one(double* x, int32_t* tri, int32_t* nv, int32_t* nt, int rem
   Mesh m{*nv, *nt, x, tri};
   orient_ccw(m);
   // boundary vertices = endpoints of edges with a single owner (before the removal: the removed vertex is interior)
+  // (on failure the cells go back to their canonical ascending order: orient_ccw has swapped some of them)
+  auto canonical = [&] {
+    for (int t = 0; t < m.nt; ++t) std::sort(m.tri + 3 * t, m.tri + 3 * t + 3);
+  };
   int rc = 0;
   if (remove_idx >= 0) {
     rc = remove_vertex(m, remove_idx);
-    if (rc) return rc;
+    if (rc) {
+      canonical();
+      return rc;
+    }
   }
   const int flips = make_delaunay(m);
-  if (flips < 0) return -10 + flips;
+  if (flips < 0) {
+    canonical();
+    return -10 + flips;
+  }
   std::vector<uint8_t> onb(m.nv, 0);
   {
     EdgeMap em(3 * m.nt);

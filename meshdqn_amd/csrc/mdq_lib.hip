@@ -5,4 +5,5 @@
 #include "mdq_mesh.hip"
 #include "mdq_smooth.hip"
 #include "mdq_topology.hip"
+#include "mdq_remesh.hip"
 #include "mdq_host_mesh.hip"

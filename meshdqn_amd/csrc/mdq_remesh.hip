@@ -1,0 +1,335 @@
+// Device version of mdq_remesh_host without the smoothing (which is mdq_smooth): Env2DAirfoil._remove_vertex
+// (Env2DAirfoil.py:452-512) for B meshes, one 256-thread workgroup per mesh out of LDS.
+//
+// The reference deletes the vertex and re-runs a GLOBAL scipy/Qhull Delaunay of the remaining points, then drops the
+// simplices whose vertices are all boundary vertices.  Because the boundary never changes, that equals: re-triangulate
+// the cavity of the removed vertex (ear clipping of its star polygon) and restore the Delaunay property of the whole
+// triangulation with Lawson flips (the smoothing of the previous step has moved every vertex, so edges anywhere may
+// have to flip; measured 0.3-0.4 triangles per step outside the cavity).  The Delaunay triangulation is unique, so
+// the result is the reference's as a SET of cells (verified against scipy for the host engine, which this kernel
+// reproduces slot for slot).
+//
+// Parallel: orientation, star search, vertex renumbering, neighbour table (LDS hash), detection of the edges that
+// violate the empty-circle test, final cell ordering.  Serial (lane 0, a few thousand instructions): ear clipping of
+// the <= 64-gon and the flip work list.  Predicates are the host engine's, operation by operation (no FMA).
+#include <hip/hip_runtime.h>
+
+#include "../../include/meshdqn_hip.h"
+
+namespace mdq_rm {
+
+constexpr int RW = 256;
+constexpr int RNV = 1024, RNT = 2048, RNS = 3 * RNT, RHS = 8192;
+constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+
+__device__ __forceinline__ double orient2d(double2 a, double2 b, double2 c) {
+#pragma clang fp contract(off)
+  return (b.x - a.x) * (c.y - a.y) - (b.y - a.y) * (c.x - a.x);
+}
+// > 0 when d lies inside the circumcircle of the CCW triangle (a,b,c)
+__device__ __forceinline__ double incircle(double2 a, double2 b, double2 c, double2 d) {
+#pragma clang fp contract(off)
+  const double ax = a.x - d.x, ay = a.y - d.y, bx = b.x - d.x, by = b.y - d.y, cx = c.x - d.x, cy = c.y - d.y;
+  return (ax * ax + ay * ay) * (bx * cy - by * cx) - (bx * bx + by * by) * (ax * cy - ay * cx) +
+         (cx * cx + cy * cy) * (ax * by - ay * bx);
+}
+__device__ __forceinline__ uint32_t hslot(uint32_t key) { return (key * 2654435761u) >> 19; }
+
+__global__ __launch_bounds__(RW) void remesh_kernel(int NV, int NT, double* coords, int32_t* cells, int32_t* nv_,
+                                                    int32_t* nt_, const int32_t* remove_idx, int32_t* status) {
+#pragma clang fp contract(off)
+  extern __shared__ __align__(16) unsigned char smem[];
+  double2* X = reinterpret_cast<double2*>(smem);                     // [RNV]            16 KB
+  int* tri = reinterpret_cast<int*>(smem + 16384);                   // [RNT][3]         24 KB
+  int* nbr = tri + RNS;                                              // [RNT][3]         24 KB
+  uint32_t* hkey = reinterpret_cast<uint32_t*>(nbr + RNS);           // [RHS]            32 KB | the flip stack re-uses
+  uint32_t* hval = hkey + RHS;                                       // [RHS]            32 KB | this region
+  int* stack = reinterpret_cast<int*>(hkey);                         // [2 * RHS]
+  int* misc = reinterpret_cast<int*>(hval + RHS);                    // [80]: counters, star list
+  int* star = misc + 8;                                              // [64]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int rv = remove_idx[b];
+  if (tid == 0) status[b] = 0;
+  if (rv < 0) return;  // "do nothing" / invalid action: the reference leaves the mesh untouched
+  int nv = nv_[b], nt = nt_[b];
+  double2* xg = reinterpret_cast<double2*>(coords) + (int64_t)b * NV;
+  int32_t* tg = cells + (int64_t)b * NT * 3;
+  for (int v = tid; v < nv; v += RW) X[v] = xg[v];
+  if (tid == 0) misc[0] = 0;
+  __syncthreads();
+  // counter-clockwise cells
+  for (int t = tid; t < nt; t += RW) {
+    int v0 = tg[3 * t], v1 = tg[3 * t + 1], v2 = tg[3 * t + 2];
+    if (orient2d(X[v0], X[v1], X[v2]) < 0) {
+      const int w = v1;
+      v1 = v2;
+      v2 = w;
+    }
+    tri[3 * t] = v0;
+    tri[3 * t + 1] = v1;
+    tri[3 * t + 2] = v2;
+    if (v0 == rv || v1 == rv || v2 == rv) {
+      const int q = atomicAdd(&misc[0], 1);
+      if (q < 64) star[q] = t;
+    }
+  }
+  __syncthreads();
+  const int ns = misc[0];
+  // ---------------- lane 0: ring of the star, ear clipping, slot bookkeeping (host remove_vertex, slot for slot)
+  if (tid == 0) {
+    int rc = 0;
+    int ea[64], eb[64], ring[64], poly[64];
+    if (ns > 64) rc = -1;
+    else if (ns < 3) rc = -2;
+    if (rc == 0) {
+      for (int i = 1; i < ns; ++i) {  // ascending cell ids, like the host's scan
+        const int w = star[i];
+        int j = i - 1;
+        while (j >= 0 && star[j] > w) {
+          star[j + 1] = star[j];
+          --j;
+        }
+        star[j + 1] = w;
+      }
+      for (int s = 0; s < ns; ++s) {
+        const int* v = tri + 3 * star[s];
+        const int k = v[0] == rv ? 0 : (v[1] == rv ? 1 : 2);
+        ea[s] = v[(k + 1) % 3];
+        eb[s] = v[(k + 2) % 3];
+      }
+      ring[0] = ea[0];
+      int cur = eb[0];
+      for (int n = 1; n < ns && rc == 0; ++n) {
+        ring[n] = cur;
+        int f = -1;
+        for (int s = 0; s < ns; ++s)
+          if (ea[s] == cur) f = s;
+        if (f < 0) rc = -3;  // open star: rv is a boundary vertex
+        else cur = eb[f];
+      }
+      if (rc == 0 && cur != ring[0]) rc = -3;
+    }
+    int nn = 0;
+    if (rc == 0) {
+      int np_ = ns;
+      for (int i = 0; i < ns; ++i) poly[i] = ring[i];
+      int* newtri = stack;  // (the stack region is free until the flip phase)
+      int guard = 0;
+      while (np_ > 3 && guard++ < 4096 && rc == 0) {
+        bool clipped = false;
+        for (int i = 0; i < np_ && !clipped; ++i) {
+          const int p0 = poly[(i + np_ - 1) % np_], p1 = poly[i], p2 = poly[(i + 1) % np_];
+          const double2 A = X[p0], Bp = X[p1], Cp = X[p2];
+          if (orient2d(A, Bp, Cp) <= 0) continue;  // reflex corner
+          bool empty = true;
+          for (int j = 0; j < np_ && empty; ++j) {
+            const int q = poly[j];
+            if (q == p0 || q == p1 || q == p2) continue;
+            const double2 Q = X[q];
+            if (orient2d(A, Bp, Q) >= 0 && orient2d(Bp, Cp, Q) >= 0 && orient2d(Cp, A, Q) >= 0) empty = false;
+          }
+          if (!empty) continue;
+          newtri[3 * nn] = p0;
+          newtri[3 * nn + 1] = p1;
+          newtri[3 * nn + 2] = p2;
+          ++nn;
+          for (int j = i; j + 1 < np_; ++j) poly[j] = poly[j + 1];
+          --np_;
+          clipped = true;
+        }
+        if (!clipped) rc = -4;
+      }
+      if (rc == 0 && np_ != 3) rc = -4;
+      if (rc == 0) {
+        newtri[3 * nn] = poly[0];
+        newtri[3 * nn + 1] = poly[1];
+        newtri[3 * nn + 2] = poly[2];
+        ++nn;  // nn == ns - 2
+        for (int s = 0; s < nn; ++s)
+          for (int k = 0; k < 3; ++k) tri[3 * star[s] + k] = newtri[3 * s + k];
+        int dead0 = star[ns - 2], dead1 = star[ns - 1];
+        if (dead0 < dead1) {
+          const int w = dead0;
+          dead0 = dead1;
+          dead1 = w;
+        }
+        const int dead[2] = {dead0, dead1};  // the higher slot first
+        for (int q = 0; q < 2; ++q) {
+          const int last = nt - 1;
+          if (dead[q] != last)
+            for (int k = 0; k < 3; ++k) tri[3 * dead[q] + k] = tri[3 * last + k];
+          --nt;
+        }
+      }
+    }
+    misc[1] = rc;
+    misc[2] = nt;
+  }
+  __syncthreads();
+  if (misc[1] != 0) {
+    if (tid == 0) status[b] = misc[1];
+    return;  // mesh untouched (nothing has been written back)
+  }
+  nt = misc[2];
+  // drop the vertex: ids above shift down, coordinates move up
+  for (int i = tid; i < 3 * nt; i += RW)
+    if (tri[i] > rv) --tri[i];
+  double2 moved[RNV / RW];
+#pragma unroll
+  for (int i = 0; i < RNV / RW; ++i) {
+    const int v = tid + i * RW;
+    moved[i] = (v >= rv && v + 1 < nv) ? X[v + 1] : make_double2(0.0, 0.0);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < RNV / RW; ++i) {
+    const int v = tid + i * RW;
+    if (v >= rv && v + 1 < nv) X[v] = moved[i];
+  }
+  --nv;
+  // ---------------- neighbour table: nbr[3t+k] = cell across the edge opposite local vertex k
+  for (int h = tid; h < RHS; h += RW) {
+    hkey[h] = EMPTY;
+    hval[h] = EMPTY;
+  }
+  for (int s = tid; s < 3 * nt; s += RW) nbr[s] = -1;
+  if (tid == 0) {
+    misc[3] = 0;  // non-manifold flag
+    misc[4] = 0;  // stack size
+  }
+  __syncthreads();
+  for (int s = tid; s < 3 * nt; s += RW) {
+    const int t = s / 3, k = s - 3 * t;
+    const int a = tri[3 * t + (k + 1) % 3], c = tri[3 * t + (k + 2) % 3];
+    const uint32_t key = ((uint32_t)min(a, c) << 10) | (uint32_t)max(a, c);
+    uint32_t h = hslot(key);
+    for (;;) {
+      const uint32_t old = atomicCAS(&hkey[h], EMPTY, key);
+      if (old == EMPTY || old == key) break;
+      h = (h + 1) & (RHS - 1);
+    }
+    const uint32_t o = atomicCAS(&hval[h], EMPTY, (uint32_t)s);
+    if (o != EMPTY) {  // the second owner links both half-edges
+      if (atomicCAS(reinterpret_cast<unsigned int*>(&nbr[o]), 0xFFFFFFFFu, (unsigned int)t) != 0xFFFFFFFFu) misc[3] = 1;
+      nbr[s] = (int)(o / 3);
+    }
+  }
+  __syncthreads();
+  if (misc[3]) {
+    if (tid == 0) status[b] = -11;  // non-manifold (-10 + make_delaunay's -1)
+    return;
+  }
+  // ---------------- edges that violate the empty-circle test (each interior edge once, from its lower cell)
+  // (the hash is dead: its memory becomes the work list; the barrier above separates the two uses)
+  for (int s = tid; s < 3 * nt; s += RW) {
+    const int t = s / 3, k = s - 3 * t, u = nbr[s];
+    if (u > t) {
+      const int a = tri[3 * t + k], bb = tri[3 * t + (k + 1) % 3], c = tri[3 * t + (k + 2) % 3];
+      int dd = -1;
+      for (int j = 0; j < 3; ++j) {
+        const int w = tri[3 * u + j];
+        if (w != bb && w != c) dd = w;
+      }
+      if (dd >= 0 && incircle(X[a], X[bb], X[c], X[dd]) > 0) stack[atomicAdd(&misc[4], 1)] = s;
+    }
+  }
+  __syncthreads();
+  // ---------------- lane 0: Lawson flips from the violating edges (host make_delaunay's loop)
+  if (tid == 0) {
+    int sp = misc[4];
+    for (int i = 1; i < sp; ++i) {  // deterministic order of the initial list
+      const int w = stack[i];
+      int j = i - 1;
+      while (j >= 0 && stack[j] > w) {
+        stack[j + 1] = stack[j];
+        --j;
+      }
+      stack[j + 1] = w;
+    }
+    int rc = 0, guard = 0;
+    while (sp > 0) {
+      if (++guard > 200000 || sp + 4 > 2 * RHS) {
+        rc = -12;
+        break;
+      }
+      const int he = stack[--sp];
+      const int t = he / 3, k = he % 3;
+      const int u = nbr[3 * t + k];
+      if (u < 0) continue;
+      int* T = tri + 3 * t;
+      int* U = tri + 3 * u;
+      const int a = T[k], bb = T[(k + 1) % 3], c = T[(k + 2) % 3];  // edge (bb,c), apex a in t
+      int ku = -1;
+      for (int j = 0; j < 3; ++j)
+        if (U[j] != bb && U[j] != c) ku = j;
+      if (ku < 0 || nbr[3 * u + ku] != t) continue;  // stale half-edge
+      const int dd = U[ku];
+      if (incircle(X[a], X[bb], X[c], X[dd]) <= 0) continue;
+      const int t_ab = nbr[3 * t + (k + 2) % 3];
+      const int t_ca = nbr[3 * t + (k + 1) % 3];
+      int u_bd = -1, u_dc = -1;
+      for (int j = 0; j < 3; ++j) {
+        if (U[j] == c) u_bd = nbr[3 * u + j];
+        if (U[j] == bb) u_dc = nbr[3 * u + j];
+      }
+      T[0] = a; T[1] = bb; T[2] = dd;
+      U[0] = a; U[1] = dd; U[2] = c;
+      nbr[3 * t + 0] = u_bd; nbr[3 * t + 1] = u; nbr[3 * t + 2] = t_ab;
+      nbr[3 * u + 0] = u_dc; nbr[3 * u + 1] = t_ca; nbr[3 * u + 2] = t;
+      if (u_bd >= 0)
+        for (int j = 0; j < 3; ++j)
+          if (nbr[3 * u_bd + j] == u) {
+            nbr[3 * u_bd + j] = t;
+            break;
+          }
+      if (t_ca >= 0)
+        for (int j = 0; j < 3; ++j)
+          if (nbr[3 * t_ca + j] == t) {
+            nbr[3 * t_ca + j] = u;
+            break;
+          }
+      stack[sp++] = 3 * t + 0;
+      stack[sp++] = 3 * t + 2;
+      stack[sp++] = 3 * u + 0;
+      stack[sp++] = 3 * u + 1;
+    }
+    misc[1] = rc;
+  }
+  __syncthreads();
+  if (misc[1] != 0) {
+    if (tid == 0) status[b] = misc[1];
+    return;
+  }
+  // ---------------- canonical cells (ascending vertex ids, DOLFIN mesh.order()) and write-back
+  for (int t = tid; t < nt; t += RW) {
+    int v0 = tri[3 * t], v1 = tri[3 * t + 1], v2 = tri[3 * t + 2], w;
+    if (v0 > v1) { w = v0; v0 = v1; v1 = w; }
+    if (v1 > v2) { w = v1; v1 = v2; v2 = w; }
+    if (v0 > v1) { w = v0; v0 = v1; v1 = w; }
+    tg[3 * t] = v0;
+    tg[3 * t + 1] = v1;
+    tg[3 * t + 2] = v2;
+  }
+  for (int v = tid; v < nv; v += RW) xg[v] = X[v];
+  if (tid == 0) {
+    nv_[b] = nv;
+    nt_[b] = nt;
+  }
+}
+
+}  // namespace mdq_rm
+
+extern "C" int mdq_remesh(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv, int32_t* nt,
+                          const int32_t* remove_idx, int32_t* status, void* stream) {
+  if (B <= 0 || !coords || !cells || !nv || !nt || !remove_idx || !status) return mdq_set_error("mdq_remesh: bad arguments");
+  if (NV > mdq_rm::RNV || NT > mdq_rm::RNT)
+    return mdq_set_error("mdq_remesh: capacity above 1024 vertices / 2048 triangles (use mdq_remesh_host)");
+  const size_t lds = 16384 + 2 * sizeof(int) * mdq_rm::RNS + 2 * sizeof(uint32_t) * mdq_rm::RHS + sizeof(int) * 80;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mdq_rm::remesh_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (attr != hipSuccess) return mdq_set_error("hipFuncSetAttribute(remesh_kernel) failed");
+  hipLaunchKernelGGL(mdq_rm::remesh_kernel, dim3(B), dim3(mdq_rm::RW), lds, (hipStream_t)stream, NV, NT, coords, cells, nv,
+                     nt, remove_idx, status);
+  if (hipGetLastError() != hipSuccess) return mdq_set_error("remesh_kernel launch failed");
+  return 0;
+}

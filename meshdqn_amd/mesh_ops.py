@@ -367,3 +367,16 @@ class DeviceTopologyBatch:
             st = self.status.cpu().numpy()
             if (st != 0).any():
                 raise _lib.MeshDQNHipError(f"topology kernel failed: env {np.flatnonzero(st)} status {st[st != 0]}")
+
+
+def remesh_batch_gpu(coords: torch.Tensor, cells: torch.Tensor, nv: torch.Tensor, nt: torch.Tensor,
+                     remove_idx: torch.Tensor, status: torch.Tensor, stream=None) -> None:
+    """In-place batched vertex removal + Delaunay restoration on the GPU (`mdq_remesh`; no smoothing: follow with
+    `smooth_batch_gpu`).  coords (B,NV,2) f8, cells (B,NT,3) i4, nv / nt / remove_idx / status (B,) i4 device tensors."""
+    lib = _lib.load()
+    B, NV, NT = coords.shape[0], coords.shape[1], cells.shape[1]
+    assert coords.dtype == torch.float64 and cells.dtype == torch.int32 and coords.is_contiguous() and cells.is_contiguous()
+    for a in (nv, nt, remove_idx, status):
+        assert a.dtype == torch.int32 and a.is_cuda
+    _lib.check(lib.mdq_remesh(B, NV, NT, coords.data_ptr(), cells.data_ptr(), nv.data_ptr(), nt.data_ptr(),
+                              remove_idx.data_ptr(), status.data_ptr(), _lib.stream_ptr(stream)), "mdq_remesh")

@@ -25,7 +25,7 @@ import torch
 
 from . import _lib
 from .env import Env2DAirfoil
-from .mesh_ops import DeviceTopologyBatch, HostTopologyBatch, remesh_batch, smooth_batch_gpu
+from .mesh_ops import DeviceTopologyBatch, HostTopologyBatch, remesh_batch, remesh_batch_gpu, smooth_batch_gpu
 
 
 def _host_cores() -> int:
@@ -45,7 +45,7 @@ def _host_cores() -> int:
 class VecEnv2DAirfoil:
     def __init__(self, config, num_envs: int, compute_device="cuda", nthreads: int = 0, base_env: Env2DAirfoil | None = None,
                  auto_reset: bool = True, emax: int = 1536, flow_steps: int = 0, flow_rtol: float = 1e-10,
-                 gpu_smoothing: bool = True, gpu_topology: bool = True):
+                 gpu_smoothing: bool = True, gpu_topology: bool = True, gpu_remesh: bool = True):
         self.lib = _lib.load()
         self.B = int(num_envs)
         self.device = torch.device(compute_device)
@@ -56,6 +56,9 @@ class VecEnv2DAirfoil:
         # mdq_env_topology (device engine, bit-identical to the host engine): the host then only re-triangulates the
         # cavity of a removed vertex; needs the GPU smoothing path (coordinates stay on the device)
         self.gpu_topology = bool(gpu_topology) and self.gpu_smoothing
+        # mdq_remesh (cavity re-triangulation + Lawson flips on the device): with it the meshes never leave the GPU;
+        # the host arrays `coords / cells / nv / nt` are then read-only mirrors refreshed every step
+        self.gpu_remesh = bool(gpu_remesh) and self.gpu_topology
         # S3 ("north-star step"): after every remesh, `flow_steps` IPCS steps on the coarsened mesh warm-started
         # from the interpolated last snapshot (0 = the reference's step, which never re-solves the flow)
         self.flow_steps, self.flow_rtol = int(flow_steps), float(flow_rtol)
@@ -95,6 +98,11 @@ class VecEnv2DAirfoil:
         if self.gpu_topology:
             self.dtopo = DeviceTopologyBatch(B, NV, NT, self.NE, self.NAF, N, self.EMAX, self.polygon, self.device,
                                              ipcs=self.flow_steps > 0, nse1_cap=nse1_cap)
+        if self.gpu_remesh:
+            self._rstat = torch.zeros(B, dtype=torch.int32, device=self.device)
+            self._rstat_host = torch.zeros(B, dtype=torch.int32, pin_memory=True)
+            self._x0_dev = torch.from_numpy(topo0.coords.copy()).to(self.device)
+            self._cells0_dev = torch.from_numpy(np.ascontiguousarray(topo0.cells, dtype=np.int32)).to(self.device)
         if self.flow_steps > 0:
             self._init_flow(base)
         self.coords, self.cells, self.nv, self.nt, self.offset = (self.topo.coords, self.topo.cells, self.topo.nv,
@@ -207,6 +215,11 @@ class VecEnv2DAirfoil:
         if self.gpu_topology:
             for k in self._STATE_KEYS:
                 self.dtopo.t[k][ti] = c["dev"][k]
+        if self.gpu_remesh:     # the device holds the meshes: reset them there as well
+            dt = self.dtopo
+            dt.cells[ti] = self._cells0_dev
+            dt.nv[ti] = self.NV
+            dt.nt[ti] = self.NT
 
     def _refresh(self):
         """Topology + selection on the host, snapshot interpolation + forces on the GPU, for all envs."""
@@ -311,7 +324,21 @@ class VecEnv2DAirfoil:
                 rem[b] = h["coord_map"][b, a]
             else:
                 code[b] = 2  # KeyError in coord_map: "RAN OUT OF VERTICES"
-        if self.gpu_smoothing:
+        if self.gpu_remesh:
+            dev, dt = self.device, self.dtopo
+            rem_d = torch.from_numpy(rem).to(dev)
+            dt.offset.copy_(torch.from_numpy(self.offset))
+            remesh_batch_gpu(dt.coords, dt.cells, dt.nv, dt.nt, rem_d, self._rstat)
+            its = torch.where((rem_d >= 0) & (self._rstat == 0), 50, 0).to(torch.int32)
+            smooth_batch_gpu(dt.coords, dt.cells, dt.nv, dt.nt, its)
+            pin = self.topo.pinned                      # host mirrors (asynchronous; valid after this step's sync)
+            pin["coords"].copy_(dt.coords, non_blocking=True)
+            pin["cells"].copy_(dt.cells, non_blocking=True)
+            pin["nv"].copy_(dt.nv, non_blocking=True)
+            pin["nt"].copy_(dt.nt, non_blocking=True)
+            self._rstat_host.copy_(self._rstat, non_blocking=True)
+            status = None
+        elif self.gpu_smoothing:
             # host: cavity re-triangulation + Delaunay restoration only; GPU: smooth(50) of the changed meshes
             status = remesh_batch(self.coords, self.cells, self.nv, self.nt, rem, 0, self.nthreads)
             dev = self.device
@@ -330,8 +357,10 @@ class VecEnv2DAirfoil:
                 self.topo.pinned["coords"].copy_(tc)    # D2H into the page-locked array (synchronises this stream)
         else:
             status = remesh_batch(self.coords, self.cells, self.nv, self.nt, rem, 50, self.nthreads)
-        code[status != 0] = 2
         self._refresh()
+        if status is None:
+            status = self._rstat_host.numpy()           # (the reads in _refresh have synchronised the stream)
+        code[status != 0] = 2
         code[h["nsel"] < N] = 2  # out of vertices
         rewards = np.zeros(B)
         dones = np.zeros(B, bool)

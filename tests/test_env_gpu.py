@@ -320,3 +320,46 @@ def test_device_topology_engine_is_bit_identical_to_host_engine(lib_built, meshe
         assert np.array_equal(gi["mf_scat"][b][:, :nt], hi["mf_scat"][b][:, :nt])
         nse = int(hi["sl1_off"][b][(nv + 63) // 64])
         assert np.array_equal(gi["sl1_col"][b][:nse], hi["sl1_col"][b][:nse])
+
+
+@pytest.mark.parametrize("name", ["ys930", "ah93w145"])
+def test_device_remesh_matches_host_engine_over_an_episode(lib_built, meshes, name):
+    """mdq_remesh + mdq_smooth against mdq_remesh_host (itself pinned to scipy Delaunay on the CPU suite): 30
+    consecutive removals on 4 meshes with different action streams, incl. "do nothing" and a boundary vertex."""
+    from meshdqn_amd.ipcs_batch import smooth_coords
+    from meshdqn_amd.mesh_ops import remesh_batch, remesh_batch_gpu, smooth_batch_gpu
+    from meshdqn_amd.topology import MeshTopology
+    coords, cells = meshes[name]
+    t0 = MeshTopology(coords, cells)
+    x0 = smooth_coords(t0, 50)
+    B, NV, NT = 4, t0.nv, t0.nt
+    hc = np.repeat(x0[None], B, 0).copy()
+    ht = np.repeat(np.sort(cells, axis=1)[None].astype(np.int32), B, 0).copy()
+    hnv = np.full(B, NV, np.int32); hnt = np.full(B, NT, np.int32)
+    dc, dtri = torch.from_numpy(hc).cuda(), torch.from_numpy(ht).cuda()
+    dnv, dnt = torch.from_numpy(hnv).cuda(), torch.from_numpy(hnt).cuda()
+    dst = torch.zeros(B, dtype=torch.int32, device="cuda")
+    rng = np.random.default_rng(11)
+    for step in range(30):
+        rem = np.empty(B, np.int32)
+        for b in range(B):
+            t = MeshTopology(hc[b, :hnv[b]], ht[b, :hnt[b]])
+            interior = np.flatnonzero(~t.on_boundary)
+            rem[b] = rng.choice(interior)
+        if step % 7 == 3:
+            rem[1] = -1                       # do nothing
+        if step == 5:
+            rem[2] = 0                        # a boundary vertex: must be refused, mesh untouched
+        hst = remesh_batch(hc, ht, hnv, hnt, rem, 50, 2)
+        drem = torch.from_numpy(rem).cuda()
+        remesh_batch_gpu(dc, dtri, dnv, dnt, drem, dst)
+        its = torch.where((drem >= 0) & (dst == 0), 50, 0).to(torch.int32)
+        smooth_batch_gpu(dc, dtri, dnv, dnt, its)
+        torch.cuda.synchronize()
+        assert np.array_equal(dst.cpu().numpy() != 0, hst != 0), (step, dst.cpu().numpy(), hst)
+        assert np.array_equal(dnv.cpu().numpy(), hnv) and np.array_equal(dnt.cpu().numpy(), hnt)
+        gc, gt = dc.cpu().numpy(), dtri.cpu().numpy()
+        for b in range(B):
+            mine = {tuple(r) for r in gt[b, :hnt[b]].tolist()}
+            assert mine == {tuple(r) for r in ht[b, :hnt[b]].tolist()}, (step, b)
+            assert np.abs(gc[b, :hnv[b]] - hc[b, :hnv[b]]).max() < 1e-12
