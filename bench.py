@@ -174,15 +174,17 @@ def measure_env_steps(args, dev, dist, world, flow_steps=0):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = tt.item()
     venv = groups.envs[0]
-    what = ("S1 = reference-semantics Env2DAirfoil.step (remove vertex + Delaunay restoration on the host C++ "
-            "pool, smooth(50) as a dataflow kernel on the GPU; 5-snapshot interpolation + 10 force integrals + state "
-            "graph + fused Q-forward on the GPU), epsilon = 0.5 policy, terminated envs reset in place")
+    what = ("S1 = reference-semantics Env2DAirfoil.step, meshes resident on the GPU for the whole step: remove vertex + "
+            "Delaunay restoration (mdq_remesh), smooth(50) (mdq_smooth, dataflow kernel), topology + N-closest selection "
+            "+ state graph (mdq_env_topology), 5-snapshot interpolation, 10 force integrals, node features, fused "
+            "Q-forward; the host maps actions to vertex ids and evaluates the reward formula; epsilon = 0.5 policy, "
+            "terminated envs reset in place")
     out = dict(value=world * B * args.s1_steps / el, unit="env steps/s", ms_per_batched_step=el / args.s1_steps * 1e3,
                batched_steps=args.s1_steps, host_threads_per_rank=venv.nthreads, env_groups=len(groups.envs))
     if flow_steps > 0:
         it = np.concatenate([e.flow_iters.cpu().numpy() for e in groups.envs]).astype(np.float64) / flow_steps
-        what = (f"S3 = S1 + {flow_steps} IPCS step(s) on every coarsened mesh: host engine emits the matrix-free index "
-                "data, mdq_ipcs_setup_matfree rebuilds geometry / diagonals / lifting vectors / P1 Laplacian on the GPU, "
+        what = (f"S3 = S1 + {flow_steps} IPCS step(s) on every coarsened mesh: mdq_env_topology emits the matrix-free "
+                "index data, mdq_ipcs_setup_matfree rebuilds geometry / diagonals / lifting vectors / P1 Laplacian, "
                 "mode-3 kernels with Jacobi-CG pressure, warm start = interpolated last snapshot")
         out["krylov_iters_per_ipcs_step"] = {"velocity_bicgstab": float(it[:, 0].mean()), "pressure_cg": float(it[:, 1].mean()),
                                              "correction_cg": float(it[:, 2].mean())}

@@ -25,7 +25,10 @@ constexpr int SNT = 2048;      // triangle capacity (cell id must fit 12 bits)
 #endif
 constexpr int SWG = MDQ_SMOOTH_WG;  // threads per workgroup: 8 waves measured best (256: 3.9 ms, 512: 3.4 ms, 1024: 3.9 ms for ys930)
                                // issue slots from the group on the critical path
-constexpr int GRP = 8;         // lanes per vertex update
+#ifndef MDQ_SMOOTH_GRP
+#define MDQ_SMOOTH_GRP 8
+#endif
+constexpr int GRP = MDQ_SMOOTH_GRP;  // lanes per vertex update (8 or 16)
 constexpr int NGRP = SWG / GRP;
 constexpr int PER = SNV / SWG; // entries per thread in the setup scans
 
@@ -40,6 +43,9 @@ __device__ __forceinline__ double grp_sum(double v) {
   v += dpp8<0xB1>(v);
   v += dpp8<0x4E>(v);
   v += dpp8<0x141>(v);
+#if MDQ_SMOOTH_GRP == 16
+  v += dpp8<0x140>(v);  // row_mirror: the other half of the row of 16
+#endif
   return v;
 }
 // 1/sqrt(x) to double precision (not correctly rounded: ~1 ulp): hardware estimate + two Newton steps.  The IEEE
@@ -57,6 +63,9 @@ __device__ __forceinline__ double grp_min(double v) {
   v = fmin(v, dpp8<0xB1>(v));
   v = fmin(v, dpp8<0x4E>(v));
   v = fmin(v, dpp8<0x141>(v));
+#if MDQ_SMOOTH_GRP == 16
+  v = fmin(v, dpp8<0x140>(v));
+#endif
   return v;
 }
 
@@ -197,7 +206,8 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
       ok = ok && LD_DONE(a) >= (a < v ? s + 1 : s) && LD_DONE(c) >= (c < v ? s + 1 : s);
     }
     const unsigned long long bal = __ballot(ok);
-    const bool ready = ((bal >> ((tid & 63) & ~7)) & 0xFFull) == 0xFFull;
+    constexpr unsigned long long GMASK = (1ull << GRP) - 1;
+    const bool ready = ((bal >> ((tid & 63) & ~(GRP - 1))) & GMASK) == GMASK;
     if (ready) {
 #ifdef MDQ_SMOOTH_TRACE
       const long long t_ready = clock64();
