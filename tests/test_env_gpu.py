@@ -363,3 +363,33 @@ def test_device_remesh_matches_host_engine_over_an_episode(lib_built, meshes, na
             mine = {tuple(r) for r in gt[b, :hnt[b]].tolist()}
             assert mine == {tuple(r) for r in ht[b, :hnt[b]].tolist()}, (step, b)
             assert np.abs(gc[b, :hnv[b]] - hc[b, :hnv[b]]).max() < 1e-12
+
+
+def test_vec_env_host_and_device_engines_agree(lib_built):
+    """The batched env with the C++ host engine, with GPU smoothing only, with the device topology engine and fully
+    device-resident (default): same trajectories (identical selections, forces to 1e-9)."""
+    from meshdqn_amd.env import Env2DAirfoil
+    from meshdqn_amd.vec_env import VecEnv2DAirfoil
+    cfg = _config("ys930")
+    base = Env2DAirfoil(cfg)
+    B, K = 5, 6
+    script = np.random.default_rng(21).integers(0, 181, size=(K, B))
+    script[2, 1] = 180
+    runs = []
+    for kw in (dict(gpu_smoothing=False, gpu_topology=False, gpu_remesh=False), dict(gpu_topology=False, gpu_remesh=False),
+               dict(gpu_remesh=False), dict()):
+        env = VecEnv2DAirfoil(cfg, B, base_env=base, auto_reset=False, nthreads=2, flow_steps=1, **kw)
+        env.get_state()
+        out = []
+        for k in range(K):
+            st, rew, done, info = env.step(script[k])
+            out.append((info["nv"].copy(), st["coord_map"].copy(), st["nedges"].copy(), info["new_drags"].copy(),
+                        info["flow_drag"].copy(), rew.copy(), done.copy(), st["x"].cpu().numpy()))
+        runs.append(out)
+    ref = runs[0]
+    for run in runs[1:]:
+        for a, r in zip(run, ref):
+            assert np.array_equal(a[0], r[0]) and np.array_equal(a[1], r[1]) and np.array_equal(a[2], r[2])
+            assert np.allclose(a[3], r[3], rtol=1e-9, atol=0) and np.allclose(a[4], r[4], rtol=1e-8, atol=0)
+            assert np.allclose(a[5], r[5], rtol=1e-9) and np.array_equal(a[6], r[6])
+            assert np.allclose(a[7], r[7], rtol=1e-5, atol=1e-6)
