@@ -271,14 +271,25 @@ class VecEnv2DAirfoil:
         if self.flow_steps > 0:
             fd, fl = self._flow(keep, out_u, out_p)
             self.flow_drag, self.flow_lift = fd.cpu().numpy(), fl.cpu().numpy()
-        self.new_drags = drag.cpu().numpy().copy()
-        self.new_lifts = lift.cpu().numpy().copy()
         if self.gpu_topology:
-            st = dt.status.cpu().numpy()
+            # one read-back for everything the host logic needs: forces + status + the small integer mirrors
+            N = self.N
+            ints = torch.cat([dt.status, dt.t["nsel"], dt.t["nedges"], dt.t["ne"], dt.t["coord_map"].reshape(-1),
+                              dt.t["n_closest"].reshape(-1)]).cpu().numpy()
+            fl64 = torch.cat([drag.reshape(-1), lift.reshape(-1)]).cpu().numpy()
+            self.new_drags = fl64[:B * self.S].reshape(B, self.S).copy()
+            self.new_lifts = fl64[B * self.S:].reshape(B, self.S).copy()
+            st = ints[:B]
             if (st != 0).any():
                 raise _lib.MeshDQNHipError(f"topology kernel failed: env {np.flatnonzero(st)} status {st[st != 0]}")
-            for k in ("nsel", "coord_map", "nedges", "n_closest", "ne"):   # small mirrors the host logic needs
-                h[k][...] = dt.t[k].cpu().numpy()
+            h["nsel"][...] = ints[B:2 * B]
+            h["nedges"][...] = ints[2 * B:3 * B]
+            h["ne"][...] = ints[3 * B:4 * B]
+            h["coord_map"][...] = ints[4 * B:4 * B + B * N].reshape(B, N)
+            h["n_closest"][...] = ints[4 * B + B * N:].reshape(B, N)
+        else:
+            self.new_drags = drag.cpu().numpy().copy()
+            self.new_lifts = lift.cpu().numpy().copy()
 
     # ------------------------------------------------------------------
     def get_state(self):
@@ -314,16 +325,12 @@ class VecEnv2DAirfoil:
         """actions (B,) ints in [0, N]; returns (state, rewards (B,), dones (B,), infos)."""
         B, N, h = self.B, self.N, self.h
         actions = np.asarray(actions).astype(np.int64)
-        rem = np.full(B, -1, np.int32)
         code = np.zeros(B, np.int32)  # 0 ok, 2 broken (Env2DAirfoil.py:342-364)
-        for b in range(B):
-            a = actions[b]
-            if a == N:
-                self.offset[b] += 1
-            elif 0 <= a < h["nsel"][b]:
-                rem[b] = h["coord_map"][b, a]
-            else:
-                code[b] = 2  # KeyError in coord_map: "RAN OUT OF VERTICES"
+        shift = actions == N                                   # "do nothing": move the selection window
+        pick = (actions >= 0) & (actions < h["nsel"]) & ~shift
+        self.offset[shift] += 1
+        rem = np.where(pick, h["coord_map"][np.arange(B), np.clip(actions, 0, N - 1)], -1).astype(np.int32)
+        code[~shift & ~pick] = 2                               # KeyError in coord_map: "RAN OUT OF VERTICES"
         if self.gpu_remesh:
             dev, dt = self.device, self.dtopo
             rem_d = torch.from_numpy(rem).to(dev)
