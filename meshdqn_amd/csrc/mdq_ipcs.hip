@@ -33,9 +33,14 @@ constexpr int MF_CH = 1024;  // triangles per LDS tile: 2 per thread, interleave
 
 __host__ __device__ inline int64_t work_per_env(int NV, int NT, int NE) {
   const int64_t N2 = (int64_t)NV + NE;
-  // escr 12*NT | 6 velocity vectors (double2[N2]) | p_new[NV] | 8 spare
-  const int64_t n = 12 * (int64_t)NT + 12 * N2 + NV + 24;
+  // escr 12*NT | 6 velocity vectors (double2[N2]) | p_new[NV] | 24 spare | assembled modes: 5 history vectors + counter
+  const int64_t n = 12 * (int64_t)NT + 12 * N2 + NV + 26 + 10 * N2 + 2;
   return (n + 31) & ~(int64_t)31;  // keep every environment's slab 256-byte aligned
+}
+// offset (in doubles, even) of the tentative-velocity history of the assembled modes 0-2 inside an environment's slab
+__host__ __device__ inline int64_t work_hist_offset(int NV, int NT, int NE) {
+  const int64_t N2 = (int64_t)NV + NE;
+  return (12 * (int64_t)NT + 12 * N2 + NV + 24 + 1) & ~(int64_t)1;
 }
 
 struct EnvView {
@@ -1229,6 +1234,12 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
   double2* vp = vh + d.N2;
   double2* vv = vp + d.N2;
   double2* vt = vv + d.N2;
+  double2* h1 = reinterpret_cast<double2*>(w + work_hist_offset(d.NV, d.NT, d.NE));  // u* history of the velocity solve
+  double2* h2 = h1 + d.N2;
+  double2* h3 = h2 + d.N2;
+  double2* h4 = h3 + d.N2;
+  double2* h5 = h4 + d.N2;
+  double* hcnt = reinterpret_cast<double*>(h5 + d.N2);
   double* pnew = reinterpret_cast<double*>(vt + d.N2);
   // velocity view of the union
   double2* L0 = reinterpret_cast<double2*>(U);
@@ -1284,6 +1295,7 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
     __syncthreads();
     MDQ_STAMP(0)
     double acc[2] = {0.0, 0.0};
+    const int nhist = (int)hcnt[0];
     for (int i = tid; i < n2; i += WG) {
       double2 f = make_double2(0.0, 0.0);
       for (int s = v.g2_ptr[i]; s < v.g2_ptr[i + 1]; ++s) {
@@ -1295,7 +1307,28 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
       const bool fl = v.bcu_flag[i] != 0;
       const double2 g = make_double2(v.bcu_gx[i], 0.0);
       const double2 bi = fl ? g : make_double2((f.x - l.x) * id.x, (f.y - l.y) * id.y);
-      const double2 x0 = fl ? g : v.u_n[i];  // initial guess satisfies the Dirichlet values
+      // initial guess: polynomial extrapolation in time of the previous tentative velocities h1 = u*_n .. h5 (the
+      // correction solve re-uses xs, so the history is kept separately; see at_velocity_kernel), u_n while there is
+      // no history; Dirichlet values hold
+      double2 x0 = v.u_n[i];
+      if (nhist >= 2) {
+        const double2 us1 = h1[i], us2 = h2[i];
+        x0 = make_double2(2.0 * us1.x - us2.x, 2.0 * us1.y - us2.y);
+        if (nhist >= 3) {
+          const double2 us3 = h3[i];
+          x0 = make_double2(3.0 * (us1.x - us2.x) + us3.x, 3.0 * (us1.y - us2.y) + us3.y);
+          if (nhist >= 4) {
+            const double2 us4 = h4[i];
+            x0 = make_double2(4.0 * (us1.x + us3.x) - 6.0 * us2.x - us4.x, 4.0 * (us1.y + us3.y) - 6.0 * us2.y - us4.y);
+            if (nhist >= 5) {
+              const double2 us5 = h5[i];
+              x0 = make_double2(5.0 * (us1.x - us4.x) - 10.0 * (us2.x - us3.x) + us5.x,
+                                5.0 * (us1.y - us4.y) - 10.0 * (us2.y - us3.y) + us5.y);
+            }
+          }
+        }
+      }
+      if (fl) x0 = g;
       xs[i] = x0;
       if (MODE == 2) {
         L0[i] = x0;
@@ -1318,6 +1351,15 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
     block_sum<2>(acc, red);
     MDQ_STAMP(1)
     it_u += bicgstab_velocity<MODE>(v, vc, d.rtol, d.maxit_u, acc[0], acc[1], red);
+    __syncthreads();
+    for (int i = tid; i < n2; i += WG) {  // shift the history, newest first: h1 = u* of this step
+      if (nhist >= 4) h5[i] = h4[i];
+      if (nhist >= 3) h4[i] = h3[i];
+      if (nhist >= 2) h3[i] = h2[i];
+      if (nhist >= 1) h2[i] = h1[i];
+      h1[i] = xs[i];
+    }
+    if (tid == 0) hcnt[0] = (double)(nhist < 5 ? nhist + 1 : 5);
     MDQ_STAMP(2)
 
     // ---------------- step 2: pressure  (flow_solver.py:115-116)

@@ -17,7 +17,7 @@ for direct in (True, False):
     batch.assemble(); torch.cuda.synchronize()
     print("setup s", round(time.time() - t, 1), "mode", batch.desc.mode, flush=True)
     out = (torch.empty((B, 1), dtype=torch.float64, device="cuda"), torch.empty((B, 1), dtype=torch.float64, device="cuda"))
-    for _ in range(60):
+    for _ in range(int(os.environ.get("SPINUP", "300"))):
         batch.evolve(1, out=out)
     batch.iters.zero_(); torch.cuda.synchronize(); n = 20; t = time.time()
     for _ in range(n):
