@@ -116,6 +116,15 @@ def cpu_baseline(budget_s=15.0, spinup=20):
     return out
 
 
+def _env_config(args):
+    return dict(flow_config=dict(flow_params=dict(mu=1e-3, rho=1.0, inflow="constant"),
+                                 geometry_params=dict(mesh=os.path.join(ROOT, "tests", "golden", f"{args.mesh}.npz")),
+                                 solver_params=dict(dt=0.001, solver_type="lu", smooth=True)),
+                agent_params=dict(solver_steps=args.s1_solver_steps, episodes=10, timesteps=10000, threshold=0.001,
+                                  N_closest=180, gt_drag=-1, gt_time=-1, u=-1, p=-1, time_reward=0.005,
+                                  save_steps=args.s1_solver_steps // 5, goal_vertices=0.95, plot_dir=""))
+
+
 def measure_env_steps(args, dev, dist, world, flow_steps=0):
     """Unit of work S1: the reference-semantics Env2DAirfoil.step for every env of the batch - vertex
     removal + Delaunay restoration + smooth(50) (host C++ pool), snapshot interpolation + 10 force integrals + state
@@ -125,12 +134,7 @@ def measure_env_steps(args, dev, dist, world, flow_steps=0):
     from meshdqn_amd.env import Env2DAirfoil
     from meshdqn_amd.gcn_fused import FusedGcn
     from meshdqn_amd.vec_env import VecEnvGroups
-    cfg = dict(flow_config=dict(flow_params=dict(mu=1e-3, rho=1.0, inflow="constant"),
-                                geometry_params=dict(mesh=os.path.join(ROOT, "tests", "golden", f"{args.mesh}.npz")),
-                                solver_params=dict(dt=0.001, solver_type="lu", smooth=True)),
-               agent_params=dict(solver_steps=args.s1_solver_steps, episodes=10, timesteps=10000, threshold=0.001,
-                                 N_closest=180, gt_drag=-1, gt_time=-1, u=-1, p=-1, time_reward=0.005,
-                                 save_steps=args.s1_solver_steps // 5, goal_vertices=0.95, plot_dir=""))
+    cfg = _env_config(args)
     B = args.envs
     global _BASE_ENV
     if _BASE_ENV is None:
@@ -192,6 +196,38 @@ def measure_env_steps(args, dev, dist, world, flow_steps=0):
     return out
 
 
+def measure_train(args, dev, dist, world):
+    """The learning loop of airfoil_dqn.py:428-503 at scale (BASELINE configs[3]): per batched step every rank steps
+    its envs (S1), pushes B transitions, and all ranks take ONE optimiser step on the all-reduced (RCCL) gradient of
+    a 32-transition minibatch each.  Returns env-steps/s over all ranks."""
+    import torch
+    from meshdqn_amd.trainer import DistContext, DQNTrainer, train_loop_vec
+    from meshdqn_amd.vec_env import VecEnv2DAirfoil
+    ctx = DistContext(device=dev)                 # re-uses the process group bench.py has initialised
+    trainer = DQNTrainer(n_actions=180, num_inputs=17, ctx=ctx)
+    cfg = _env_config(args)
+    venv = VecEnv2DAirfoil(cfg, args.envs, compute_device=dev, base_env=_BASE_ENV)
+    train_loop_vec(trainer, venv, 4)              # fills the replay ring past one minibatch, warms the autograd path
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    train_loop_vec(trainer, venv, args.train_steps)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = tt.item()
+    return dict(value=world * args.envs * args.train_steps / el, unit="env steps/s",
+                ms_per_batched_step=el / args.train_steps * 1e3, batched_steps=args.train_steps,
+                what="S1 rollout + replay push + one double-DQN optimiser step per batched step (minibatch 32 per rank, "
+                     "PyTorch autograd for the trained network, fused HIP forward for the target network, one flat "
+                     "gradient all-reduce over the ranks)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,6 +241,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--s1-steps", type=int, default=50, help="batched reference-semantics env steps (0 = skip)")
     ap.add_argument("--cell-order", default="conflictfree", choices=["mesh", "conflictfree"])
+    ap.add_argument("--train-steps", type=int, default=20, help="batched learning-loop steps (0 = skip)")
     ap.add_argument("--s1-warmup", type=int, default=40)
     ap.add_argument("--env-groups", type=int, default=1, help="concurrently stepped env groups per GPU for S1 / S3")
     ap.add_argument("--s1-solver-steps", type=int, default=5000, help="IPCS steps of the ground-truth reset()")
@@ -303,6 +340,7 @@ def main():
 
     s3 = measure_env_steps(args, dev, dist, world, 1) if args.s1_steps > 0 else None
     s1 = measure_env_steps(args, dev, dist, world, 0) if args.s1_steps > 0 else None
+    tr = measure_train(args, dev, dist, world) if args.s1_steps > 0 and args.train_steps > 0 else None
 
     if rank == 0:
         achieved = vel_bytes / (k_vel * 1e-3) / 1e9
@@ -357,7 +395,7 @@ def main():
                                  "workgroup barriers on the B CUs in use (one CU per environment), not HBM"},
         }
         res["rates"] = {"S2_ipcs_env_steps_per_s": res["value"], "S1_reference_step_env_steps_per_s": s1,
-                        "S3_north_star_step_env_steps_per_s": s3}
+                        "S3_north_star_step_env_steps_per_s": s3, "training_loop_env_steps_per_s": tr}
         if cpu is not None:
             res["cpu_baseline"] = cpu
         print(json.dumps(res), flush=True)

@@ -216,19 +216,20 @@ class DQNTrainer:
         action_batch = torch.cat([a.reshape(1, 1) for a in batch.action]).to(dev)
         reward_batch = torch.cat([r.reshape(1) for r in batch.reward]).to(dev).float()
         net_a, net_b = (self.policy_net_1, self.policy_net_2)
+        fused = dev.type == "cuda"   # the network evaluated WITHOUT gradient runs through the fused HIP forward
         states = Batch.from_data_list([s.to(dev) for s in batch.state])
         if self.select:
             out = net_a(states)
         else:
             with torch.no_grad():
-                out = net_a(states)
+                out = net_a.forward_fused(states) if fused else net_a(states)
         q_sa = out.gather(1, action_batch).squeeze(1)
         next_vals = torch.zeros(len(transitions), device=dev)
         if non_final_next:
             nb = Batch.from_data_list([s.to(dev) for s in non_final_next])
             if self.select:
                 with torch.no_grad():
-                    nv = net_b(nb).max(1)[0].float()
+                    nv = (net_b.forward_fused(nb) if fused else net_b(nb)).max(1)[0].float()
             else:
                 nv = net_b(nb).max(1)[0].float()
             next_vals[non_final_mask] = nv
@@ -360,16 +361,45 @@ class TrainingLog:
         np.save(self.base + "eps.npy", np.array(self.epss))
 
 
+class StateRef:
+    """One environment's state graph inside a batched state dict of `VecEnv2DAirfoil.get_state()`, materialised as a
+    `Data` only when a sampled transition needs it (the replay ring holds 128 of these per batched step; building
+    `Data` objects eagerly cost more than the environment step itself)."""
+    __slots__ = ("st", "b", "e0", "e1", "_data")
+
+    def __init__(self, st, b, e0, e1):
+        self.st, self.b, self.e0, self.e1, self._data = st, b, e0, e1, None
+
+    def data(self) -> Data:
+        if self._data is None:
+            st = self.st
+            self._data = Data(x=st["x"][self.b], edge_index=torch.stack([st["esrc"][self.e0:self.e1].long(),
+                                                                          st["edst"][self.e0:self.e1].long()]))
+        return self._data
+
+    # the little of the Data interface the trainer / the transition packing use
+    @property
+    def x(self):
+        return self.data().x
+
+    @property
+    def edge_index(self):
+        return self.data().edge_index
+
+    def to(self, device):
+        return self.data().to(device)
+
+
 def state_to_data_list(st: dict, n_nodes: int) -> List[Data]:
     """Split the batched state dict of `VecEnv2DAirfoil.get_state()` into per-environment `Data` objects
-    (x (N,F) f32, edge_index (2,E) i64 with node ids local to the graph) for the replay memory."""
+    (x (N,F) f32, edge_index (2,E) i64 with node ids local to the graph)."""
+    return [r.data() for r in state_refs(st)]
+
+
+def state_refs(st: dict) -> List[StateRef]:
+    """Per-environment lazy references into a batched state dict (one host read of the edge offsets)."""
     ep = st["edge_ptr"].cpu().numpy()
-    esrc, edst = st["esrc"].long(), st["edst"].long()
-    out = []
-    for b in range(st["x"].shape[0]):
-        e0, e1 = int(ep[b]), int(ep[b + 1])
-        out.append(Data(x=st["x"][b], edge_index=torch.stack([esrc[e0:e1], edst[e0:e1]])))
-    return out
+    return [StateRef(st, b, int(ep[b]), int(ep[b + 1])) for b in range(st["x"].shape[0])]
 
 
 def train_loop_vec(trainer: DQNTrainer, venv, num_steps: int, optim_per_step: int = 1, eps_decay=10000, eps_start=1.0,
@@ -397,9 +427,9 @@ def train_loop_vec(trainer: DQNTrainer, venv, num_steps: int, optim_per_step: in
         steps_done += 1
         explore = np.random.random(B) <= eps
         actions = np.where(explore, np.random.randint(0, trainer.n_actions + 1, B), greedy)
-        prev = state_to_data_list(st, N)
+        prev = state_refs(st)
         st, rew, done, _ = venv.step(actions)
-        nxt = state_to_data_list(st, N)
+        nxt = state_refs(st)
         trs = [Transition(prev[b], torch.tensor([[int(actions[b])]], dtype=torch.long), None if done[b] else nxt[b],
                           torch.tensor([float(rew[b])], dtype=torch.float32)) for b in range(B)]
         if share_replay and ctx.world > 1:
