@@ -132,6 +132,52 @@ def global_mean_pool(x, batch):
 gmp, gap = global_max_pool, global_mean_pool
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Static-shape ("dense batch") formulation of the same layers for training: every graph of a minibatch has the same
+# number of nodes (N_closest rows, padded states are zero rows exactly as in the reference) and its edge list is
+# padded to a fixed length with a 0/1 mask.  No host synchronisation, no data-dependent shapes: the whole
+# forward + backward is a fixed sequence of kernels that a HIP graph can replay (trainer.DQNTrainer).  Numerically
+# the same sums as the ragged path above, in a different order.
+
+def _dense_sage(conv: SAGEConv, x, src, dst, m):
+    C = x.shape[-1]
+    xs = torch.gather(x, 1, src.unsqueeze(-1).expand(-1, -1, C)) * m.unsqueeze(-1)
+    agg = torch.zeros_like(x).scatter_add(1, dst.unsqueeze(-1).expand(-1, -1, C), xs)
+    cnt = torch.zeros(x.shape[:2], dtype=x.dtype, device=x.device).scatter_add(1, dst, m)
+    agg = agg / cnt.clamp(min=1).unsqueeze(-1)
+    return conv.lin_l(agg) + conv.lin_r(x)
+
+
+def _dense_gcn(conv: GCNConv, x, src, dst, m):
+    deg = torch.ones(x.shape[:2], dtype=x.dtype, device=x.device).scatter_add(1, dst, m)
+    dis = deg.pow(-0.5)
+    h = conv.lin(x)
+    C = h.shape[-1]
+    w = torch.gather(dis, 1, src) * torch.gather(dis, 1, dst) * m
+    hs = torch.gather(h, 1, src.unsqueeze(-1).expand(-1, -1, C)) * w.unsqueeze(-1)
+    out = (h * (dis * dis).unsqueeze(-1)).scatter_add(1, dst.unsqueeze(-1).expand(-1, -1, C), hs)
+    return out + conv.bias
+
+
+def _dense_topk(pool: TopKPooling, x, src, dst, m):
+    B, n, C = x.shape
+    k = int(math.ceil(pool.ratio * n))
+    score = torch.tanh((x * pool.weight).sum(dim=-1) / pool.weight.norm(p=2, dim=-1))
+    # stable descending order (ties keep the lower node id first, like the ragged path's stable argsort)
+    order = torch.argsort(score, dim=1, descending=True, stable=True)[:, :k]
+    sc = torch.gather(score, 1, order)
+    xo = torch.gather(x, 1, order.unsqueeze(-1).expand(-1, -1, C)) * sc.unsqueeze(-1)
+    new_id = torch.full((B, n), -1, dtype=torch.long, device=x.device).scatter(
+        1, order, torch.arange(k, device=x.device).unsqueeze(0).expand(B, -1))
+    s2, d2 = torch.gather(new_id, 1, src), torch.gather(new_id, 1, dst)
+    m2 = m * ((s2 >= 0) & (d2 >= 0)).to(m.dtype)
+    return xo, s2.clamp(min=0), d2.clamp(min=0), m2
+
+
+def _dense_readout(x):
+    return torch.cat([x.max(dim=1).values, x.mean(dim=1)], dim=1)
+
+
 class _WeightAccessors:
     """`get_weights/set_weights/get_gradients/set_gradients` (called at airfoil_dqn.py:194-206,
     291-310, never defined by the reference): Ray parameter-server example semantics."""
@@ -236,6 +282,59 @@ class NodeRemovalNet(nn.Module, _WeightAccessors):
         """Inference (no autograd) on the fused HIP kernels: one workgroup per graph, MFMA head."""
         from .gcn_fused import node_removal_forward
         return node_removal_forward(self, data)
+
+    def forward_dense(self, x, src, dst, mask, embedding=False):
+        """Autograd path with static shapes: x (B,n,F) f32, src/dst (B,E) int64 local node ids, mask (B,E) 0/1 float
+        (padded edges have mask 0 and any valid node id).  Same function as `forward` on the equivalent Batch."""
+        x = F.relu(_dense_sage(self.conv1, x.float(), src, dst, mask))
+        x, src, dst, mask = _dense_topk(self.pool1, x, src, dst, mask)
+        x1 = _dense_readout(x)
+        x = F.relu(_dense_sage(self.conv2, x, src, dst, mask))
+        x, src, dst, mask = _dense_topk(self.pool2, x, src, dst, mask)
+        x2 = _dense_readout(x)
+        x = F.relu(_dense_gcn(self.conv4, x, src, dst, mask))
+        x, src, dst, mask = _dense_topk(self.pool4, x, src, dst, mask)
+        x4 = _dense_readout(x)
+        x = F.relu(_dense_gcn(self.conv5, x, src, dst, mask))
+        x, src, dst, mask = _dense_topk(self.pool5, x, src, dst, mask)
+        x5 = _dense_readout(x)
+        x = x1 + x2 + x4 + x5
+        if embedding:
+            return x
+        x = F.relu(self.lin1(x))
+        x = F.relu(self.lin2(x))
+        return F.softmax(self.lin3(x), dim=1)
+
+
+def dense_batch(data_list, e_max: int, device=None):
+    """Stack graphs with equal node counts into the static-shape inputs of `forward_dense`:
+    x (B,n,F), src / dst (B,e_max) int64, mask (B,e_max) float32."""
+    B = len(data_list)
+    n = data_list[0].x.shape[0]
+    dev = device if device is not None else data_list[0].x.device
+    x = torch.stack([d.x.to(dev) for d in data_list]).float()
+    src = torch.zeros((B, e_max), dtype=torch.long, device=dev)
+    dst = torch.zeros((B, e_max), dtype=torch.long, device=dev)
+    mask = torch.zeros((B, e_max), dtype=torch.float32, device=dev)
+    cnt = [int(d.edge_index.shape[1]) for d in data_list]
+    if any(d.x.shape[0] != n for d in data_list):
+        raise ValueError("dense_batch needs graphs with equal node counts")
+    if max(cnt) > e_max:
+        raise ValueError(f"graph with {max(cnt)} edges exceeds e_max {e_max}")
+    total = sum(cnt)
+    if total:
+        # one scatter for the whole minibatch (row b, column = position inside graph b's edge list)
+        # (index arithmetic in numpy, not torch-CPU: torch's intra-op thread pool on a many-core host keeps spinning
+        # after a parallel region and starves the autograd thread; measured 25 ms per backward on a 256-CPU box)
+        c = np.asarray(cnt, dtype=np.int64)
+        rows = np.repeat(np.arange(B, dtype=np.int64), c)
+        cols = np.arange(total, dtype=np.int64) - np.repeat(np.cumsum(c) - c, c)
+        lin = torch.from_numpy(rows * e_max + cols).to(dev)   # scatter_ on the flat views below
+        allE = torch.cat([d.edge_index.to(dev) for d in data_list], dim=1)
+        src.view(-1).scatter_(0, lin, allE[0])
+        dst.view(-1).scatter_(0, lin, allE[1])
+        mask.view(-1).scatter_(0, lin, torch.ones(total, dtype=torch.float32, device=dev))
+    return x, src, dst, mask
 
 
 class AirfoilGCNN(nn.Module, _WeightAccessors):

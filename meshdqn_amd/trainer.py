@@ -26,7 +26,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .airfoilgcnn import NodeRemovalNet
+from .airfoilgcnn import NodeRemovalNet, dense_batch
 from .data import Batch, Data
 
 Transition = namedtuple("Transition", ("state", "action", "next_state", "reward"))
@@ -173,9 +173,12 @@ def allgather_transitions(ctx: DistContext, trs: List[Transition], n_nodes: int,
 class DQNTrainer:
     def __init__(self, n_actions: int, num_inputs: int, ctx: Optional[DistContext] = None, lr=1e-5, weight_decay=1e-6,
                  batch_size=32, gamma=1.0, target_update=50, replay_capacity=10000, conv_width=128, topk=0.1,
-                 seed=1370):
+                 seed=1370, dense: bool = True, e_max: int = 1536):
         self.ctx = ctx or DistContext()
+        self.dense, self.e_max = bool(dense), int(e_max)   # static-shape autograd path for equal-sized graphs
         dev = self.ctx.device
+        self.graphs = dev.type == "cuda"                   # replay forward + backward as a HIP graph when possible
+        self._graph, self._graph_error = None, None
         torch.manual_seed(seed)  # identical initial replicas on every rank (airfoil_dqn.py:28-32)
         self.policy_net_1 = NodeRemovalNet(n_actions + 1, conv_width=conv_width, topk=topk).float()
         self.policy_net_2 = NodeRemovalNet(n_actions + 1, conv_width=conv_width, topk=topk).float()
@@ -184,6 +187,7 @@ class DQNTrainer:
         self.policy_net_1.to(dev)
         self.policy_net_2.to(dev)
         self.n_actions, self.batch_size, self.gamma, self.target_update = n_actions, batch_size, gamma, target_update
+        # (torch's fused=True Adam measured 4x slower than the foreach implementation on this ROCm build)
         self.opts = [torch.optim.Adam(n.parameters(), lr=lr, weight_decay=weight_decay)
                      for n in (self.policy_net_1, self.policy_net_2)]
         self.scheds = [torch.optim.lr_scheduler.MultiStepLR(o, milestones=[500000, 1000000, 1500000], gamma=0.1)
@@ -217,10 +221,15 @@ class DQNTrainer:
         reward_batch = torch.cat([r.reshape(1) for r in batch.reward]).to(dev).float()
         net_a, net_b = (self.policy_net_1, self.policy_net_2)
         fused = dev.type == "cuda"   # the network evaluated WITHOUT gradient runs through the fused HIP forward
-        states = Batch.from_data_list([s.to(dev) for s in batch.state])
+        datas = [s.to(dev) for s in batch.state]
         if self.select:
-            out = net_a(states)
+            if self.dense and all(d.x.shape[0] == datas[0].x.shape[0] for d in datas):
+                # static-shape autograd path (no host syncs, fixed kernel sequence)
+                out = net_a.forward_dense(*dense_batch(datas, self.e_max, dev))
+            else:
+                out = net_a(Batch.from_data_list(datas))
         else:
+            states = Batch.from_data_list(datas)
             with torch.no_grad():
                 out = net_a.forward_fused(states) if fused else net_a(states)
         q_sa = out.gather(1, action_batch).squeeze(1)
@@ -230,11 +239,79 @@ class DQNTrainer:
             if self.select:
                 with torch.no_grad():
                     nv = (net_b.forward_fused(nb) if fused else net_b(nb)).max(1)[0].float()
+            elif self.dense and all(d.x.shape[0] == non_final_next[0].x.shape[0] for d in non_final_next):
+                nv = net_b.forward_dense(*dense_batch([d.to(dev) for d in non_final_next], self.e_max, dev)).max(1)[0].float()
             else:
                 nv = net_b(nb).max(1)[0].float()
             next_vals[non_final_mask] = nv
         expected = next_vals * self.gamma + reward_batch
         return self.criterion(q_sa.float(), expected.float())
+
+    def _optimize_graphed(self, transitions: List[Transition]):
+        """select == True on a GPU: forward_dense + Huber loss + backward of policy_net_1 as ONE replayed HIP graph
+        (static minibatch shape), targets from the fused no-grad forward of policy_net_2.  Returns the loss value, or
+        None when the minibatch is not eligible (ragged node counts) or capture is unsupported (eager path runs)."""
+        dev = self.ctx.device
+        batch = Transition(*zip(*transitions))
+        datas = [s_.to(dev) for s_ in batch.state]
+        n0 = datas[0].x.shape[0]
+        if any(d.x.shape[0] != n0 for d in datas):
+            return None
+        net = self.policy_net_1
+        try:
+            with torch.no_grad():
+                non_final = [s_ for s_ in batch.next_state if s_ is not None]
+                next_vals = torch.zeros(len(transitions), device=dev)
+                if non_final:
+                    mask_nf = torch.tensor([s_ is not None for s_ in batch.next_state], dtype=torch.bool, device=dev)
+                    nb = Batch.from_data_list([s_.to(dev) for s_ in non_final])
+                    next_vals[mask_nf] = self.policy_net_2.forward_fused(nb).max(1)[0].float()
+                reward = torch.cat([r.reshape(1) for r in batch.reward]).to(dev).float()
+                expected = next_vals * self.gamma + reward
+            action = torch.cat([a.reshape(1, 1) for a in batch.action]).to(dev)
+            x, src, dst, mask = dense_batch(datas, self.e_max, dev)
+            g = self._graph
+            if g is None or g["x"].shape != x.shape:
+                st = dict(x=x.clone(), src=src.clone(), dst=dst.clone(), mask=mask.clone(), act=action.clone(),
+                          exp=expected.clone())
+
+                def fwd_bwd():
+                    q = net.forward_dense(st["x"], st["src"], st["dst"], st["mask"]).gather(1, st["act"]).squeeze(1)
+                    loss_ = self.criterion(q.float(), st["exp"])
+                    loss_.backward()
+                    return loss_
+
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):      # warm-up outside capture (allocator, autograd buffers)
+                    for _ in range(3):
+                        net.zero_grad(set_to_none=True)
+                        fwd_bwd()
+                torch.cuda.current_stream(dev).wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                net.zero_grad(set_to_none=True)
+                with torch.cuda.graph(graph):
+                    loss_static = fwd_bwd()
+                st.update(graph=graph, loss=loss_static, grads=[p.grad for p in net.parameters()])
+                self._graph = g = st
+            else:
+                for k_, v_ in (("x", x), ("src", src), ("dst", dst), ("mask", mask), ("act", action), ("exp", expected)):
+                    g[k_].copy_(v_)
+            g["graph"].replay()
+            flat = torch.cat([(gr if gr is not None else torch.zeros_like(p)).reshape(-1)
+                              for gr, p in zip(g["grads"], net.parameters())])
+        except RuntimeError as exc:   # capture not supported for some op on this build: stay on the eager path
+            self.graphs = False
+            self._graph = None
+            self._graph_error = repr(exc)
+            return None
+        self.ctx.allreduce_mean_(flat)
+        net.set_flat_gradients(flat)
+        self.opts[0].step()
+        self.scheds[0].step()
+        self.num_grads += 1
+        self.losses.append(float(g["loss"].item()))
+        return self.losses[-1]
 
     def optimize(self, transitions: Optional[List[Transition]] = None):
         """One optimiser step (airfoil_dqn.py:315-340 + :184-200 + :286-310): local loss/backward, ONE flat
@@ -247,6 +324,10 @@ class DQNTrainer:
             self.select = not self.select
         k = 0 if self.select else 1
         net = (self.policy_net_1, self.policy_net_2)[k]
+        if self.select and self.graphs and self.dense and len(transitions) == self.batch_size:
+            done = self._optimize_graphed(transitions)
+            if done is not None:
+                return done
         net.zero_grad(set_to_none=True)
         loss = self._loss(transitions)
         if not loss.requires_grad:

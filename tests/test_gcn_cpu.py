@@ -102,3 +102,31 @@ def test_weight_accessors_and_loader():
     assert torch.allclose(flat, net.flat_gradients())
     net2.set_flat_gradients(flat * 2)
     assert torch.allclose(net2.flat_gradients(), flat * 2)
+
+
+def test_dense_static_shape_path_equals_ragged_path():
+    """`forward_dense` (fixed shapes, masked padded edges: the HIP-graph-capturable training path) against `forward`
+    on the equivalent Batch: values and parameter gradients."""
+    from meshdqn_amd.airfoilgcnn import dense_batch
+    rng = np.random.default_rng(9)
+    net = prod.NodeRemovalNet(181, conv_width=128, topk=0.1)
+    net.set_num_nodes(17)
+    sd = {k: torch.from_numpy(rng.standard_normal(tuple(v.shape)) * 0.3).float() for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    graphs = [_graph(rng, 180, e, 17) for e in (372, 495, 0, 611, 37)]
+    batch = Batch.from_data_list(graphs)
+    x, src, dst, mask = dense_batch(graphs, 640)
+    q_r = net(batch)
+    q_d = net.forward_dense(x, src, dst, mask)
+    assert torch.allclose(q_d, q_r, rtol=1e-4, atol=1e-6)
+    assert torch.allclose(net.forward_dense(x, src, dst, mask, embedding=True), net(batch, embedding=True), rtol=1e-4, atol=1e-5)
+    act = torch.tensor([[3], [50], [180], [7], [99]])
+    for q in (q_r, q_d):
+        net.zero_grad()
+        torch.nn.functional.huber_loss(q.gather(1, act).squeeze(1), torch.linspace(0, 1, 5)).backward()
+        if q is q_r:
+            g_r = [p.grad.clone() if p.grad is not None else None for p in net.parameters()]
+    for p, g in zip(net.parameters(), g_r):
+        assert (p.grad is None) == (g is None)
+        if g is not None:
+            assert torch.allclose(p.grad, g, rtol=2e-3, atol=1e-7), (p.shape, (p.grad - g).abs().max())
