@@ -234,9 +234,36 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
 #endif
       }
       // lane 0 carries the x component, lane 1 the y component (same instruction stream: free)
-      const double tsx = grp_sum(sx), tsy = grp_sum(sy);  // (both by every lane: DPP needs the whole group active)
+      // the three group reductions step by step side by side (three independent dependency chains in flight instead
+      // of one after the other; every lane takes part: DPP needs the whole group active)
+      double tsx = sx, tsy = sy;
+      {
+        double ax_ = dpp8<0xB1>(tsx), ay_ = dpp8<0xB1>(tsy), am_ = dpp8<0xB1>(rm);
+        tsx += ax_;
+        tsy += ay_;
+        rm = fmin(rm, am_);
+        ax_ = dpp8<0x4E>(tsx);
+        ay_ = dpp8<0x4E>(tsy);
+        am_ = dpp8<0x4E>(rm);
+        tsx += ax_;
+        tsy += ay_;
+        rm = fmin(rm, am_);
+        ax_ = dpp8<0x141>(tsx);
+        ay_ = dpp8<0x141>(tsy);
+        am_ = dpp8<0x141>(rm);
+        tsx += ax_;
+        tsy += ay_;
+        rm = fmin(rm, am_);
+#if MDQ_SMOOTH_GRP == 16
+        ax_ = dpp8<0x140>(tsx);
+        ay_ = dpp8<0x140>(tsy);
+        am_ = dpp8<0x140>(rm);
+        tsx += ax_;
+        tsy += ay_;
+        rm = fmin(rm, am_);
+#endif
+      }
       const double sc = l == 0 ? tsx : tsy;
-      rm = grp_min(rm);
       const double pc = l == 0 ? px : py;
       const double dc_ = sc * rcp2k[k] - pc;                // lane 0: dx, lane 1: dy
       const double dother = dpp8<0xB1>(dc_);                // the other component
