@@ -3,22 +3,25 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch: every one of the `--envs`
-(default 128, BASELINE.json configs[1]) environments of a rank advances by ONE
-IPCS time step (`FlowSolver.evolve`, flow_solver.py:362-396: three right-hand
-sides, three Krylov solves, drag/lift probes) - unit-of-work definition S2 of
-SURVEY.md section 8(d).  Inputs (meshes, operators, flow state) are resident in
-HBM before the timed region; the flow state is a developed flow obtained by
-`--spinup` untimed IPCS steps from rest so that Krylov iteration counts are
-representative.  value = (ranks x envs x K) / max-over-ranks time.
+`value`: a "step" is one pass of the IPCS kernel set over one batch: every one of the `--envs` (default 128,
+BASELINE.json configs[1]) environments of a rank advances by ONE IPCS time step (`FlowSolver.evolve`,
+flow_solver.py:362-396: three right-hand sides, three Krylov solves, drag/lift probes) - unit-of-work S2 of
+SURVEY.md section 8(d).  Inputs (meshes, operators, flow state) are resident in HBM before the timed region; the
+flow state is a developed flow obtained by `--spinup` untimed IPCS steps from rest so that Krylov iteration counts
+are representative.  value = (ranks x envs x K) / max-over-ranks time.
 
-For N > 1 launch with torchrun (one rank per GPU); environments are independent
-so they are sharded across ranks with no data-path collective (weak scaling).
+For N > 1 launch with torchrun (one rank per GPU); environments are independent so they are sharded across ranks
+with no data-path collective (weak scaling).
 
-Extra objects in the JSON line: `roofline` (dominant kernel = evolve_kernel,
-algorithmic bytes per launch / measured launch duration vs the 8 TB/s HBM peak)
-and `cpu_baseline` (the numpy/scipy sparse-LU oracle timed on one host core on
-a bounded sample of the same workload, rank 0 at N=1 only).
+Extra objects in the JSON line:
+  roofline      dominant kernel (at_velocity_kernel): algorithmic bytes per launch / launch duration measured with
+                HIP events on the launch stream vs the 8 TB/s HBM peak; PMC traffic from profiles/traffic.json;
+                a device-copy microbenchmark of the same run
+  rates         S1 = the reference-semantics Env2DAirfoil.step incl. Q-forward, S3 = S1 + one IPCS step on every
+                coarsened mesh (the literal north-star step), training_loop = S1 rollout + replay + optimiser step
+                (with the RCCL gradient all-reduce for N > 1); all resident on the GPU
+  cpu_baseline  the numpy/scipy sparse-LU oracle on one host core, on 12 processes (the reference's num_parallel)
+                and for S1; rank 0 at N = 1 only, measured BEFORE the GPU is initialised
 """
 import argparse
 import json
