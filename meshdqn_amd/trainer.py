@@ -178,7 +178,7 @@ class DQNTrainer:
         self.dense, self.e_max = bool(dense), int(e_max)   # static-shape autograd path for equal-sized graphs
         dev = self.ctx.device
         self.graphs = dev.type == "cuda"                   # replay forward + backward as a HIP graph when possible
-        self._graph, self._graph_error = None, None
+        self._graphs, self._graph_error = {}, None
         torch.manual_seed(seed)  # identical initial replicas on every rank (airfoil_dqn.py:28-32)
         self.policy_net_1 = NodeRemovalNet(n_actions + 1, conv_width=conv_width, topk=topk).float()
         self.policy_net_2 = NodeRemovalNet(n_actions + 1, conv_width=conv_width, topk=topk).float()
@@ -248,36 +248,47 @@ class DQNTrainer:
         return self.criterion(q_sa.float(), expected.float())
 
     def _optimize_graphed(self, transitions: List[Transition]):
-        """select == True on a GPU: forward_dense + Huber loss + backward of policy_net_1 as ONE replayed HIP graph
-        (static minibatch shape), targets from the fused no-grad forward of policy_net_2.  Returns the loss value, or
-        None when the minibatch is not eligible (ragged node counts) or capture is unsupported (eager path runs)."""
+        """The autograd half of an optimiser step as ONE replayed HIP graph (static minibatch shape):
+          select True : loss(q1(s)[a], r + gamma max q2(s'))   - gradient through policy_net_1 on the states,
+                        targets from the fused no-grad forward of policy_net_2;
+          select False: the same loss with the gradient through policy_net_2 on the NEXT states (the reference's
+                        toggle, airfoil_dqn.py:240-310), q1(s)[a] from the fused no-grad forward; terminal
+                        transitions ride along as masked rows (their own state as a placeholder, weight 0).
+        Returns the loss value, or None when the minibatch is not eligible (ragged node counts) or capture is
+        unsupported (the eager path runs)."""
         dev = self.ctx.device
         batch = Transition(*zip(*transitions))
-        datas = [s_.to(dev) for s_ in batch.state]
-        n0 = datas[0].x.shape[0]
-        if any(d.x.shape[0] != n0 for d in datas):
+        sel = self.select
+        k = 0 if sel else 1
+        net = (self.policy_net_1, self.policy_net_2)[k]
+        states = [s_.to(dev) for s_ in batch.state]
+        n0 = states[0].x.shape[0]
+        nexts = [(s_.to(dev) if s_ is not None else states[i]) for i, s_ in enumerate(batch.next_state)]
+        if any(d.x.shape[0] != n0 for d in states) or any(d.x.shape[0] != n0 for d in nexts):
             return None
-        net = self.policy_net_1
         try:
-            with torch.no_grad():
-                non_final = [s_ for s_ in batch.next_state if s_ is not None]
-                next_vals = torch.zeros(len(transitions), device=dev)
-                if non_final:
-                    mask_nf = torch.tensor([s_ is not None for s_ in batch.next_state], dtype=torch.bool, device=dev)
-                    nb = Batch.from_data_list([s_.to(dev) for s_ in non_final])
-                    next_vals[mask_nf] = self.policy_net_2.forward_fused(nb).max(1)[0].float()
-                reward = torch.cat([r.reshape(1) for r in batch.reward]).to(dev).float()
-                expected = next_vals * self.gamma + reward
+            nonfinal = torch.tensor([0.0 if s_ is None else 1.0 for s_ in batch.next_state], device=dev)
+            reward = torch.cat([r.reshape(1) for r in batch.reward]).to(dev).float()
             action = torch.cat([a.reshape(1, 1) for a in batch.action]).to(dev)
-            x, src, dst, mask = dense_batch(datas, self.e_max, dev)
-            g = self._graph
+            with torch.no_grad():
+                if sel:   # targets: fused forward of the other network on the next states
+                    aux = self.policy_net_2.forward_fused(Batch.from_data_list(nexts)).max(1)[0].float() * nonfinal
+                    aux = aux * self.gamma + reward                      # = expected
+                else:     # q1(s)[a]: fused forward of the other network on the states
+                    aux = self.policy_net_1.forward_fused(Batch.from_data_list(states)).gather(1, action).squeeze(1).float()
+            x, src, dst, mask = dense_batch(states if sel else nexts, self.e_max, dev)
+            g = self._graphs.get(k)
             if g is None or g["x"].shape != x.shape:
                 st = dict(x=x.clone(), src=src.clone(), dst=dst.clone(), mask=mask.clone(), act=action.clone(),
-                          exp=expected.clone())
+                          aux=aux.clone(), rew=reward.clone(), nf=nonfinal.clone())
 
                 def fwd_bwd():
-                    q = net.forward_dense(st["x"], st["src"], st["dst"], st["mask"]).gather(1, st["act"]).squeeze(1)
-                    loss_ = self.criterion(q.float(), st["exp"])
+                    out = net.forward_dense(st["x"], st["src"], st["dst"], st["mask"])
+                    if sel:
+                        loss_ = self.criterion(out.gather(1, st["act"]).squeeze(1).float(), st["aux"])
+                    else:
+                        expected = out.max(1)[0].float() * st["nf"] * self.gamma + st["rew"]
+                        loss_ = self.criterion(st["aux"], expected)
                     loss_.backward()
                     return loss_
 
@@ -293,22 +304,23 @@ class DQNTrainer:
                 with torch.cuda.graph(graph):
                     loss_static = fwd_bwd()
                 st.update(graph=graph, loss=loss_static, grads=[p.grad for p in net.parameters()])
-                self._graph = g = st
+                self._graphs[k] = g = st
             else:
-                for k_, v_ in (("x", x), ("src", src), ("dst", dst), ("mask", mask), ("act", action), ("exp", expected)):
+                for k_, v_ in (("x", x), ("src", src), ("dst", dst), ("mask", mask), ("act", action), ("aux", aux),
+                               ("rew", reward), ("nf", nonfinal)):
                     g[k_].copy_(v_)
             g["graph"].replay()
             flat = torch.cat([(gr if gr is not None else torch.zeros_like(p)).reshape(-1)
                               for gr, p in zip(g["grads"], net.parameters())])
         except RuntimeError as exc:   # capture not supported for some op on this build: stay on the eager path
             self.graphs = False
-            self._graph = None
+            self._graphs = {}
             self._graph_error = repr(exc)
             return None
         self.ctx.allreduce_mean_(flat)
         net.set_flat_gradients(flat)
-        self.opts[0].step()
-        self.scheds[0].step()
+        self.opts[k].step()
+        self.scheds[k].step()
         self.num_grads += 1
         self.losses.append(float(g["loss"].item()))
         return self.losses[-1]
@@ -324,7 +336,7 @@ class DQNTrainer:
             self.select = not self.select
         k = 0 if self.select else 1
         net = (self.policy_net_1, self.policy_net_2)[k]
-        if self.select and self.graphs and self.dense and len(transitions) == self.batch_size:
+        if self.graphs and self.dense and len(transitions) == self.batch_size:
             done = self._optimize_graphed(transitions)
             if done is not None:
                 return done

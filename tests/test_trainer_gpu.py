@@ -49,17 +49,21 @@ def test_graphed_optimiser_step_equals_eager_step(lib_built):
     trs = [Transition(graph(int(rng.integers(200, 600))), torch.tensor([[int(rng.integers(0, 181))]]),
                       None if i % 5 == 0 else graph(int(rng.integers(200, 600))), torch.tensor([float(rng.standard_normal())]))
            for i in range(8)]
-    grads = []
-    for use_graph in (False, True, True):
-        tr = DQNTrainer(n_actions=180, num_inputs=17, ctx=DistContext(), batch_size=8, lr=0.0)
-        tr.graphs = use_graph
-        tr.num_grads = 1                      # keep select = True (the trained network is policy_net_1)
-        tr.select = True
-        for _ in range(2 if use_graph else 1):   # second call = pure replay
-            loss = tr.optimize(trs)
-        assert use_graph is False or tr._graph is not None, tr._graph_error
-        grads.append((loss, [p.grad.clone() for p in tr.policy_net_1.parameters()]))
-    for loss, g in grads[1:]:
-        assert abs(loss - grads[0][0]) < 1e-6
-        for a, b in zip(g, grads[0][1]):
+    for sel in (True, False):
+        grads = []
+        for use_graph in (False, True):
+            tr = DQNTrainer(n_actions=180, num_inputs=17, ctx=DistContext(), batch_size=8, lr=0.0)
+            tr.graphs = use_graph
+            for _ in range(2 if use_graph else 1):   # the second call is a pure replay
+                tr.num_grads = 1                      # (not a multiple of target_update: `select` stays as set)
+                tr.select = sel
+                loss = tr.optimize(trs)
+            assert use_graph is False or (0 if sel else 1) in tr._graphs, tr._graph_error
+            net = tr.policy_net_1 if sel else tr.policy_net_2
+            grads.append((loss, [p.grad.clone() for p in net.parameters()]))
+        assert abs(grads[1][0] - grads[0][0]) < 1e-6
+        nonzero = 0
+        for a, b in zip(grads[1][1], grads[0][1]):
             assert torch.allclose(a, b, rtol=1e-3, atol=1e-7)
+            nonzero += int(b.abs().max() > 0)
+        assert nonzero > 10
