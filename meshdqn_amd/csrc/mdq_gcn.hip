@@ -92,15 +92,29 @@ __device__ inline void conv_dense_small_n(const Lds& L, int n, int fin, int C, c
   float acc[NACC];
 #pragma unroll
   for (int r = 0; r < NACC; ++r) acc[r] = 0.f;
-  for (int f = 0; f < fin; ++f) {
-    const float w1 = wl[f * C + c];
-    const float w2 = ROOT ? wr[f * C + c] : 0.f;
+  // weights stream from global / L2: fetch FB feature rows at once so that FB (2 FB with the root weight) loads are
+  // in flight instead of one dependent round trip per feature (128 of them per level: this loop WAS the kernel)
+  constexpr int FB = 16;
+  for (int f0 = 0; f0 < fin; f0 += FB) {
+    float w1[FB], w2[FB];
 #pragma unroll
-    for (int r = 0; r < NACC; ++r) {
-      const int i = g + r * G;
-      if (i < n) {
-        acc[r] = fmaf(w1, A[i * fin + f], acc[r]);
-        if (ROOT) acc[r] = fmaf(w2, X[i * fin + f], acc[r]);
+    for (int q = 0; q < FB; ++q) {
+      const int f = f0 + q;
+      w1[q] = f < fin ? wl[f * C + c] : 0.f;
+      w2[q] = (ROOT && f < fin) ? wr[f * C + c] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < FB; ++q) {
+      const int f = f0 + q;
+      if (f < fin) {
+#pragma unroll
+        for (int r = 0; r < NACC; ++r) {
+          const int i = g + r * G;
+          if (i < n) {
+            acc[r] = fmaf(w1[q], A[i * fin + f], acc[r]);
+            if (ROOT) acc[r] = fmaf(w2[q], X[i * fin + f], acc[r]);
+          }
+        }
       }
     }
   }
@@ -170,8 +184,11 @@ __device__ inline void run_level(const Lds& L, const Level& lv, int C, double ra
   (void)G;
   __syncthreads();
   // ---- relu + score = tanh(h . w / |w|)
+  // pool weights once into LDS (L.deg is free here: the aggregation is done), norm in the same fixed order as before
+  for (int c = tid; c < C; c += WGT) L.deg[c] = lv.pw[c];
+  __syncthreads();
   float wn = 0.f;
-  for (int c = 0; c < C; ++c) wn = fmaf(lv.pw[c], lv.pw[c], wn);
+  for (int c = 0; c < C; ++c) wn = fmaf(L.deg[c], L.deg[c], wn);
   wn = sqrtf(wn);
   for (int i = tid; i < n; i += WGT) {
     float s = 0.f;
@@ -179,7 +196,7 @@ __device__ inline void run_level(const Lds& L, const Level& lv, int C, double ra
       float hv = L.h[i * (C + 1) + c];
       hv = hv > 0.f ? hv : 0.f;
       L.h[i * (C + 1) + c] = hv;
-      s = fmaf(hv, lv.pw[c], s);
+      s = fmaf(hv, L.deg[c], s);
     }
     L.score[i] = tanhf(s / wn);
   }
@@ -257,7 +274,7 @@ __global__ __launch_bounds__(WGT) void gcn_embed_kernel(mdq_gcn_net net, int NMA
   L.h = p;      p += (size_t)NMAX * (C + 1);
   L.agg = p;    p += XS;
   L.score = p;  p += NMAX;
-  L.deg = p;    p += NMAX;
+  L.deg = p;    p += (NMAX > C ? NMAX : C);  // (also stages the C pooling weights)
   int* q = reinterpret_cast<int*>(p);
   L.adj_ptr = q; q += NMAX + 1;
   L.adj = q;     q += EMAX;
@@ -379,7 +396,8 @@ extern "C" int mdq_gcn_forward(const mdq_gcn_net* net, int32_t B, int32_t NMAX, 
     for (int j = 0; j < l; ++j) n = std::ceil(net->ratio * n);
     if (net->levels[l].fin > 32 && n > NACC * (WGT / C)) return mdq_set_error("mdq_gcn_forward: too many nodes at a wide level");
   }
-  size_t lds = sizeof(float) * ((size_t)mdq_gcn_xs(*net, NMAX) * 2 + (size_t)NMAX * (C + 1) + 2 * (size_t)NMAX) +
+  size_t lds = sizeof(float) * ((size_t)mdq_gcn_xs(*net, NMAX) * 2 + (size_t)NMAX * (C + 1) + (size_t)NMAX +
+                                (size_t)(NMAX > C ? NMAX : C)) +
                sizeof(int) * ((size_t)NMAX + 1 + 3 * (size_t)EMAX + NMAX + 8);
   if (lds > 160 * 1024) return mdq_set_error("mdq_gcn_forward: graph does not fit in LDS");
   hipStream_t st = (hipStream_t)stream;
