@@ -43,11 +43,24 @@ __device__ inline void build_csr(const Lds& L, int n, int E) {
     L.adj_ptr[i + 1] = c;
   }
   __syncthreads();
-  if (tid == 0) {
-    L.adj_ptr[0] = 0;
-    for (int i = 0; i < n; ++i) L.adj_ptr[i + 1] += L.adj_ptr[i];
+  // inclusive scan of the counts (adj_ptr[1..n]): Hillis-Steele inside chunks of WGT nodes, carry between chunks
+  if (tid == 0) L.adj_ptr[0] = 0;
+  for (int base = 0; base < n; base += WGT) {
+    const int i = base + tid;
+    for (int off = 1; off < WGT; off <<= 1) {
+      int add = 0;
+      if (i < n && tid >= off) add = L.adj_ptr[i + 1 - off];
+      __syncthreads();
+      if (i < n) L.adj_ptr[i + 1] += add;
+      __syncthreads();
+    }
+    if (base > 0) {
+      const int carry = L.adj_ptr[base];
+      __syncthreads();
+      if (i < n) L.adj_ptr[i + 1] += carry;
+      __syncthreads();
+    }
   }
-  __syncthreads();
   for (int i = tid; i < n; i += WGT) {
     int p = L.adj_ptr[i];
     for (int e = 0; e < E; ++e)
@@ -84,41 +97,71 @@ __device__ inline void conv_dense_small_fin(const Lds& L, int n, int fin, int C,
 }
 
 // Form (b): feature-outer loop, up to NACC nodes per thread (n <= NACC * WGT/C), any fin.
+// `wbuf` (LDS, fin*C floats, 16-byte aligned) or nullptr: when given, each weight matrix is first staged into LDS with
+// one coalesced cooperative copy (all its loads in flight at once) - streaming the rows from global memory one
+// dependent round trip per feature was 60 % of the whole kernel.
 template <bool ROOT>
 __device__ inline void conv_dense_small_n(const Lds& L, int n, int fin, int C, const float* __restrict__ wl,
                                           const float* __restrict__ b, const float* __restrict__ wr, const float* A,
-                                          const float* X) {
+                                          const float* X, float* wbuf) {
   const int tid = threadIdx.x, c = tid % C, g = tid / C, G = WGT / C;
   float acc[NACC];
 #pragma unroll
   for (int r = 0; r < NACC; ++r) acc[r] = 0.f;
-  // weights stream from global / L2: fetch FB feature rows at once so that FB (2 FB with the root weight) loads are
-  // in flight instead of one dependent round trip per feature (128 of them per level: this loop WAS the kernel)
-  constexpr int FB = 16;
-  for (int f0 = 0; f0 < fin; f0 += FB) {
-    float w1[FB], w2[FB];
+  if (wbuf) {
+    for (int idx = tid * 4; idx < fin * C; idx += WGT * 4)
+      *reinterpret_cast<float4*>(wbuf + idx) = *reinterpret_cast<const float4*>(wl + idx);
+    __syncthreads();
+    for (int f = 0; f < fin; ++f) {
+      const float w = wbuf[f * C + c];
 #pragma unroll
-    for (int q = 0; q < FB; ++q) {
-      const int f = f0 + q;
-      w1[q] = f < fin ? wl[f * C + c] : 0.f;
-      w2[q] = (ROOT && f < fin) ? wr[f * C + c] : 0.f;
+      for (int r = 0; r < NACC; ++r) {
+        const int i = g + r * G;
+        if (i < n) acc[r] = fmaf(w, A[i * fin + f], acc[r]);
+      }
     }
-#pragma unroll
-    for (int q = 0; q < FB; ++q) {
-      const int f = f0 + q;
-      if (f < fin) {
+    if (ROOT) {
+      __syncthreads();  // everybody is done with the first matrix
+      for (int idx = tid * 4; idx < fin * C; idx += WGT * 4)
+        *reinterpret_cast<float4*>(wbuf + idx) = *reinterpret_cast<const float4*>(wr + idx);
+      __syncthreads();
+      for (int f = 0; f < fin; ++f) {
+        const float w = wbuf[f * C + c];
 #pragma unroll
         for (int r = 0; r < NACC; ++r) {
           const int i = g + r * G;
-          if (i < n) {
-            acc[r] = fmaf(w1[q], A[i * fin + f], acc[r]);
-            if (ROOT) acc[r] = fmaf(w2[q], X[i * fin + f], acc[r]);
+          if (i < n) acc[r] = fmaf(w, X[i * fin + f], acc[r]);
+        }
+      }
+    }
+  } else {
+    constexpr int FB = 16;
+    for (int f0 = 0; f0 < fin; f0 += FB) {
+      float w1[FB], w2[FB];
+#pragma unroll
+      for (int q = 0; q < FB; ++q) {
+        const int f = f0 + q;
+        w1[q] = f < fin ? wl[f * C + c] : 0.f;
+        w2[q] = (ROOT && f < fin) ? wr[f * C + c] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < FB; ++q) {
+        const int f = f0 + q;
+        if (f < fin) {
+#pragma unroll
+          for (int r = 0; r < NACC; ++r) {
+            const int i = g + r * G;
+            if (i < n) {
+              acc[r] = fmaf(w1[q], A[i * fin + f], acc[r]);
+              if (ROOT) acc[r] = fmaf(w2[q], X[i * fin + f], acc[r]);
+            }
           }
         }
       }
     }
   }
   const float bc = b[c];
+  __syncthreads();  // (the staging buffer lives behind the rows of L.h written below; keep phases apart)
 #pragma unroll
   for (int r = 0; r < NACC; ++r) {
     const int i = g + r * G;
@@ -140,7 +183,7 @@ struct Level {
 
 // one conv + relu + TopK pool + readout level; features in L.x ([n][fin]) are replaced by the pooled ones
 __device__ inline void run_level(const Lds& L, const Level& lv, int C, double ratio, int& n, int& E, float& rmax,
-                                 float& rmean) {
+                                 float& rmean, int NMAX) {
   const int tid = threadIdx.x, fin = lv.fin;
   build_csr(L, n, E);
   // ---- aggregation into L.agg
@@ -176,29 +219,50 @@ __device__ inline void run_level(const Lds& L, const Level& lv, int C, double ra
       conv_dense_small_fin<false>(L, n, fin, C, lv.wl, lv.b, nullptr, L.agg, L.x);
   } else {
     // (n <= NACC*G is guaranteed by the host-side check)
+    // (staging each weight matrix in LDS behind the rows of L.h - conv_dense_small_n's `wbuf` path - was measured
+    // SLOWER than the blocked global loads, 0.50 vs 0.33 ms for 128 graphs, so it stays off)
+    (void)NMAX;
+    float* wbuf = nullptr;
     if (lv.type == 0)
-      conv_dense_small_n<true>(L, n, fin, C, lv.wl, lv.b, lv.wr, L.agg, L.x);
+      conv_dense_small_n<true>(L, n, fin, C, lv.wl, lv.b, lv.wr, L.agg, L.x, wbuf);
     else
-      conv_dense_small_n<false>(L, n, fin, C, lv.wl, lv.b, nullptr, L.agg, L.x);
+      conv_dense_small_n<false>(L, n, fin, C, lv.wl, lv.b, nullptr, L.agg, L.x, wbuf);
   }
   (void)G;
   __syncthreads();
   // ---- relu + score = tanh(h . w / |w|)
-  // pool weights once into LDS (L.deg is free here: the aggregation is done), norm in the same fixed order as before
+  // pool weights once into LDS (L.deg is free here: the aggregation is done)
   for (int c = tid; c < C; c += WGT) L.deg[c] = lv.pw[c];
   __syncthreads();
   float wn = 0.f;
   for (int c = 0; c < C; ++c) wn = fmaf(L.deg[c], L.deg[c], wn);
   wn = sqrtf(wn);
-  for (int i = tid; i < n; i += WGT) {
-    float s = 0.f;
-    for (int c = 0; c < C; ++c) {
-      float hv = L.h[i * (C + 1) + c];
-      hv = hv > 0.f ? hv : 0.f;
-      L.h[i * (C + 1) + c] = hv;
-      s = fmaf(hv, L.deg[c], s);
+  if (n > WGT / 16) {
+    // many nodes: one thread per node walks the channels (relu in place + dot product)
+    for (int i = tid; i < n; i += WGT) {
+      float sp = 0.f;
+      for (int c = 0; c < C; ++c) {
+        float hv = L.h[i * (C + 1) + c];
+        hv = hv > 0.f ? hv : 0.f;
+        L.h[i * (C + 1) + c] = hv;
+        sp = fmaf(hv, L.deg[c], sp);
+      }
+      L.score[i] = tanhf(sp / wn);
     }
-    L.score[i] = tanhf(s / wn);
+  } else {
+    // few nodes (the pooled levels): 16 lanes per node, each lane a strided slice of the channels, butterfly sum
+    const int i = tid / 16, sub = tid % 16;
+    float sp = 0.f;
+    if (i < n)
+      for (int c = sub; c < C; c += 16) {
+        float hv = L.h[i * (C + 1) + c];
+        hv = hv > 0.f ? hv : 0.f;
+        L.h[i * (C + 1) + c] = hv;
+        sp = fmaf(hv, L.deg[c], sp);
+      }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) sp += __shfl_xor(sp, off, 16);
+    if (i < n && sub == 0) L.score[i] = tanhf(sp / wn);
   }
   __syncthreads();
   // ---- top-k by rank counting (descending score, ties by lower index = stable sort)
@@ -214,11 +278,18 @@ __device__ inline void run_level(const Lds& L, const Level& lv, int C, double ra
   }
   __syncthreads();
   // ---- pooled features x'[r][c] = h[perm r][c] * score[perm r]  -> L.x with stride C
-  for (int i = tid; i < n; i += WGT) {
-    const int r = L.newid[i];
-    if (r >= 0) {
-      const float s = L.score[i];
-      for (int c = 0; c < C; ++c) L.x[r * C + c] = L.h[i * (C + 1) + c] * s;
+  if (n > WGT / 16) {
+    for (int i = tid; i < n; i += WGT) {
+      const int r = L.newid[i];
+      if (r >= 0) {
+        const float sc = L.score[i];
+        for (int c = 0; c < C; ++c) L.x[r * C + c] = L.h[i * (C + 1) + c] * sc;
+      }
+    }
+  } else {
+    for (int idx = tid; idx < n * C; idx += WGT) {
+      const int i = idx / C, c = idx - i * C, r = L.newid[i];
+      if (r >= 0) L.x[r * C + c] = L.h[i * (C + 1) + c] * L.score[i];
     }
   }
   // ---- filter + relabel edges, preserving edge order (wave 0, ballot compaction)
@@ -298,7 +369,7 @@ __global__ __launch_bounds__(WGT) void gcn_embed_kernel(mdq_gcn_net net, int NMA
     lv.b = net.levels[l].b;
     lv.wr = net.levels[l].w_r;
     lv.pw = net.levels[l].pool_w;
-    run_level(L, lv, C, net.ratio, n, E, rmax, rmean);
+    run_level(L, lv, C, net.ratio, n, E, rmax, rmean, NMAX);
   }
   if (tid < C) {
     emb[(size_t)b * 2 * C + tid] = rmax;
