@@ -393,3 +393,30 @@ def test_vec_env_host_and_device_engines_agree(lib_built):
             assert np.allclose(a[3], r[3], rtol=1e-9, atol=0) and np.allclose(a[4], r[4], rtol=1e-8, atol=0)
             assert np.allclose(a[5], r[5], rtol=1e-9) and np.array_equal(a[6], r[6])
             assert np.allclose(a[7], r[7], rtol=1e-5, atol=1e-6)
+
+
+def test_device_resident_env_soak(lib_built):
+    """80 batched steps of 32 environments under a random / greedy policy with auto-reset: finite outputs, vertex
+    counts inside [0.95 nv0 - 1, nv0], state graphs well-formed, no engine failure codes."""
+    from meshdqn_amd.airfoilgcnn import NodeRemovalNet
+    from meshdqn_amd.env import Env2DAirfoil
+    from meshdqn_amd.gcn_fused import FusedGcn
+    from meshdqn_amd.vec_env import VecEnv2DAirfoil
+    cfg = _config("ys930")
+    venv = VecEnv2DAirfoil(cfg, 32, base_env=Env2DAirfoil(cfg), flow_steps=1)
+    net = NodeRemovalNet(181, conv_width=128, topk=0.1)
+    net.set_num_nodes(17)
+    fused = FusedGcn(net.cuda())
+    rng = np.random.default_rng(0)
+    st = venv.get_state()
+    finished = 0
+    for k in range(80):
+        q = fused.forward_arrays(st["x"], st["node_ptr"], st["esrc"], st["edst"], st["edge_ptr"], venv.N, venv.EMAX)
+        assert torch.isfinite(q).all()
+        acts = np.where(rng.random(32) < 0.7, rng.integers(0, 181, 32), q.argmax(1).cpu().numpy())
+        st, rew, done, info = venv.step(acts)
+        assert np.isfinite(rew).all() and np.isfinite(info["new_drags"]).all() and np.isfinite(info["flow_drag"]).all()
+        assert (info["nv"] <= venv.NV).all() and (info["nv"] >= 0.95 * venv.NV - 2).all()
+        assert (st["nedges"] % 3 == 0).all() and (st["nsel"] == 180).all() and (info["code"] == 0).all()
+        finished += int(done.sum())
+    assert finished > 0
