@@ -1973,6 +1973,7 @@ __device__ __forceinline__ void at_prefetch(const EnvView& v, AtMetaT<TPAIR>& m,
 template <bool INTERLEAVE, int TW = WG, int TPAIR = AT_PAIR, class ElemOp>
 __device__ __forceinline__ void atomic_accumulate(const EnvView& v, double* Yd, AtMetaT<TPAIR>& m, ElemOp op) {
   const int nrounds = (v.nt + TPAIR * TW - 1) / (TPAIR * TW);
+  // (delaying the odd waves by 256-1536 cycles to de-phase LDS and FP64 phases only added the delay: measured)
   for (int round = 0; round < nrounds; ++round) {
     if (INTERLEAVE) {
       double2 ye[TPAIR][6];
