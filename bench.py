@@ -296,6 +296,11 @@ def main():
         batch.evolve(1, out=out)
     batch.iters.zero_()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()            # (events are created lazily at their first record: not inside the timed region)
+    ev1.record()
+    import gc
+    gc.collect()
+    gc.disable()            # no collector pause inside a timed region that may be only a few milliseconds long
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -310,6 +315,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     kern_ms = ev0.elapsed_time(ev1) / args.steps  # average launch duration (HIP events, same stream)
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)

@@ -301,7 +301,9 @@ class DQNTrainer:
                 torch.cuda.current_stream(dev).wait_stream(side)
                 graph = torch.cuda.CUDAGraph()
                 net.zero_grad(set_to_none=True)
-                with torch.cuda.graph(graph):
+                # thread_local: other threads of the process (the RCCL watchdog, env-group workers) may touch the
+                # device while this thread captures
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     loss_static = fwd_bwd()
                 st.update(graph=graph, loss=loss_static, grads=[p.grad for p in net.parameters()])
                 self._graphs[k] = g = st
