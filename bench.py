@@ -186,8 +186,13 @@ def measure_env_steps(args, dev, dist, world, flow_steps=0):
             "+ state graph (mdq_env_topology), 5-snapshot interpolation, 10 force integrals, node features, fused "
             "Q-forward; the host maps actions to vertex ids and evaluates the reward formula; epsilon = 0.5 policy, "
             "terminated envs reset in place")
-    out = dict(value=world * B * args.s1_steps / el, unit="env steps/s", ms_per_batched_step=el / args.s1_steps * 1e3,
-               batched_steps=args.s1_steps, host_threads_per_rank=venv.nthreads, env_groups=len(groups.envs))
+    rate = world * B * args.s1_steps / el
+    # S1 moves ~0.7 MB of algorithmic traffic per env step (5 snapshots read + written, mesh a few times)
+    out = dict(value=rate, unit="env steps/s", ms_per_batched_step=el / args.s1_steps * 1e3,
+               batched_steps=args.s1_steps, host_threads_per_rank=venv.nthreads, env_groups=len(groups.envs),
+               roofline=dict(bound="latency (smoothing dependency chain)", algorithmic_bytes_per_env_step=0.7e6,
+                             achieved_GBs=rate * 0.7e6 / 1e9 / world, peak_GBs=HBM_PEAK_GBS,
+                             frac=rate * 0.7e6 / 1e9 / world / HBM_PEAK_GBS))
     if flow_steps > 0:
         it = np.concatenate([e.flow_iters.cpu().numpy() for e in groups.envs]).astype(np.float64) / flow_steps
         what = (f"S3 = S1 + {flow_steps} IPCS step(s) on every coarsened mesh: mdq_env_topology emits the matrix-free "
