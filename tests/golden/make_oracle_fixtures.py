@@ -6,6 +6,7 @@
   oracle_flow.npz       smoothed coordinates (mesh.smooth(50)), facet tags, u / p after step 3
   oracle_episode.json   one scripted ys930 episode with 48 default_rng(1370) actions (>= 44 removals: crosses nv < 0.95 nv0):
                         removed vertex ids, nv / nt, first selected ids, E, reward, new_drags / new_lifts
+  oracle_episode_ah93w145.json   the same for the second geometry (default_rng(2370))
   oracle_gcn.npz        a 180-node / 17-feature state graph + a 37-node graph, NodeRemovalNet(181,128,0.1) and
                         AirfoilGCNN(64) outputs of the oracle networks under the closed-form weights of
                         `formula_state_dict` (no RNG: reproducible on any torch build)
@@ -75,14 +76,14 @@ def flow_fixtures():
     np.savez_compressed(os.path.join(HERE, "oracle_flow.npz"), **arrays)
 
 
-def episode_fixture():
+def episode_fixture(mesh="ys930", seed=1370, out="oracle_episode.json"):
     from oracle.env import OracleEnv
-    z = np.load(os.path.join(HERE, "ys930.npz"))
+    z = np.load(os.path.join(HERE, f"{mesh}.npz"))
     env = OracleEnv(z["coords"], z["cells"], AGENT)
     s0 = env.get_state()
-    rec = dict(mesh="ys930", agent_params=AGENT, seed=1370, gt_drag=env.gt_drag.tolist(), gt_lift=env.gt_lift.tolist(),
+    rec = dict(mesh=mesh, agent_params=AGENT, seed=seed, gt_drag=env.gt_drag.tolist(), gt_lift=env.gt_lift.tolist(),
                E0=int(s0["edge_index"].shape[1]), n_closest0=[int(v) for v in env.n_closest[:16]], steps=[])
-    rng = np.random.default_rng(1370)
+    rng = np.random.default_rng(seed)
     # the 20-step ground truth makes every removal "terminal" (drag off by > 0.1 %): the script keeps stepping, as
     # the parity tests do, until the vertex-count criterion (nv < 0.95 nv0) has also been crossed
     while len(rec["steps"]) < 48:
@@ -95,7 +96,7 @@ def episode_fixture():
                                  new_lifts=[float(v) for v in getattr(env, 'new_lifts', [])],
                                  x_sum=float(np.asarray(st["x"], dtype=np.float64).sum())))
         print(len(rec["steps"]), a, removed, env.flow.mesh.nv, r, done, flush=True)
-    json.dump(rec, open(os.path.join(HERE, "oracle_episode.json"), "w"), indent=1)
+    json.dump(rec, open(os.path.join(HERE, out), "w"), indent=1)
 
 
 def gcn_fixture():
@@ -123,10 +124,12 @@ def gcn_fixture():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gcn", "episode", "flow"]
+    which = sys.argv[1:] or ["gcn", "episode", "episode2", "flow"]
     if "gcn" in which:
         gcn_fixture()
     if "episode" in which:
         episode_fixture()
+    if "episode2" in which:   # second geometry, different action stream (44 actions reach nv < 0.95 nv0 = 757)
+        episode_fixture("ah93w145", 2370, "oracle_episode_ah93w145.json")
     if "flow" in which:
         flow_fixtures()

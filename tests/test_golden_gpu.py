@@ -71,10 +71,11 @@ def _cfg(ep):
                 agent_params=dict(ep["agent_params"]))
 
 
-def test_scripted_episode_matches_golden(lib_built):
-    """All 48 scripted actions (44+ removals, nv 876 -> 828) on the reference-surface environment."""
+@pytest.mark.parametrize("fixture", ["oracle_episode.json", "oracle_episode_ah93w145.json"])
+def test_scripted_episode_matches_golden(lib_built, fixture):
+    """All 48 scripted actions (44+ removals, nv 876 -> 828 / 797 -> 749) on the reference-surface environment."""
     from meshdqn_amd.env import Env2DAirfoil
-    ep = json.load(open(os.path.join(GOLDEN, "oracle_episode.json")))
+    ep = json.load(open(os.path.join(GOLDEN, fixture)))
     env = Env2DAirfoil(_cfg(ep))
     assert np.allclose(env.gt_drag, ep["gt_drag"], rtol=1e-8, atol=0)
     assert np.allclose(env.gt_lift, ep["gt_lift"], rtol=1e-8, atol=0)
@@ -94,17 +95,18 @@ def test_scripted_episode_matches_golden(lib_built):
         assert abs(float(st.x.double().sum()) - g["x_sum"]) < 1e-3
 
 
-def test_scripted_episode_batched_engine_matches_golden(lib_built):
-    """The same script through VecEnv2DAirfoil (C++ star re-triangulation instead of scipy Delaunay), B = 2."""
+@pytest.mark.parametrize("fixture", ["oracle_episode.json", "oracle_episode_ah93w145.json"])
+def test_scripted_episode_batched_engine_matches_golden(lib_built, fixture):
+    """The same scripts through VecEnv2DAirfoil (device-resident: mdq_remesh / mdq_smooth / mdq_env_topology), B = 2."""
     from meshdqn_amd.env import Env2DAirfoil
     from meshdqn_amd.vec_env import VecEnv2DAirfoil
-    ep = json.load(open(os.path.join(GOLDEN, "oracle_episode.json")))
+    ep = json.load(open(os.path.join(GOLDEN, fixture)))
     cfg = _cfg(ep)
     venv = VecEnv2DAirfoil(cfg, 2, base_env=Env2DAirfoil(cfg), auto_reset=False, nthreads=2)
     st = venv.get_state()
     for g in ep["steps"]:
         st, rew, done, info = venv.step([g["action"], 180])
-        assert info["nv"][0] == g["nv"] and info["nv"][1] == 876
+        assert info["nv"][0] == g["nv"] and info["nv"][1] == venv.NV
         assert st["coord_map"][0][:8].tolist() == g["coord_map_head"]
         assert int(st["edge_ptr"][1] - st["edge_ptr"][0]) == g["E"]
         assert np.allclose(info["new_drags"][0], g["new_drags"], rtol=1e-7, atol=0)

@@ -59,9 +59,10 @@ def test_oracle_5000_steps_reproduce_reference_csv_rows(meshes):
     assert abs(l - KAT["ys930"]["lift"]) < 5e-8      # -0.0462851
 
 
-def test_oracle_episode_prefix_matches_fixture(meshes):
+@pytest.mark.parametrize("fixture", ["oracle_episode.json", "oracle_episode_ah93w145.json"])
+def test_oracle_episode_prefix_matches_fixture(meshes, fixture):
     from oracle.env import OracleEnv
-    ep = json.load(open(os.path.join(GOLDEN, "oracle_episode.json")))
+    ep = json.load(open(os.path.join(GOLDEN, fixture)))
     env = OracleEnv(*meshes[ep["mesh"]], ep["agent_params"])
     assert np.allclose(env.gt_drag, ep["gt_drag"], rtol=1e-10, atol=0)
     s0 = env.get_state()
