@@ -261,22 +261,44 @@ class DQNTrainer:
         sel = self.select
         k = 0 if sel else 1
         net = (self.policy_net_1, self.policy_net_2)[k]
-        states = [s_.to(dev) for s_ in batch.state]
-        n0 = states[0].x.shape[0]
-        nexts = [(s_.to(dev) if s_ is not None else states[i]) for i, s_ in enumerate(batch.next_state)]
-        if any(d.x.shape[0] != n0 for d in states) or any(d.x.shape[0] != n0 for d in nexts):
-            return None
+        lazy = all(isinstance(s_, StateRef) for s_ in batch.state) and \
+            all(s_ is None or isinstance(s_, StateRef) for s_ in batch.next_state)
+        if lazy:   # replay filled by train_loop_vec: minibatch arrays without per-graph Data objects
+            s_refs = list(batch.state)
+            n_refs = [(s_ if s_ is not None else batch.state[i]) for i, s_ in enumerate(batch.next_state)]
+        else:
+            states = [s_.to(dev) for s_ in batch.state]
+            n0 = states[0].x.shape[0]
+            nexts = [(s_.to(dev) if s_ is not None else states[i]) for i, s_ in enumerate(batch.next_state)]
+            if any(d.x.shape[0] != n0 for d in states) or any(d.x.shape[0] != n0 for d in nexts):
+                return None
         try:
             nonfinal = torch.tensor([0.0 if s_ is None else 1.0 for s_ in batch.next_state], device=dev)
             reward = torch.cat([r.reshape(1) for r in batch.reward]).to(dev).float()
             action = torch.cat([a.reshape(1, 1) for a in batch.action]).to(dev)
-            with torch.no_grad():
-                if sel:   # targets: fused forward of the other network on the next states
-                    aux = self.policy_net_2.forward_fused(Batch.from_data_list(nexts)).max(1)[0].float() * nonfinal
-                    aux = aux * self.gamma + reward                      # = expected
-                else:     # q1(s)[a]: fused forward of the other network on the states
-                    aux = self.policy_net_1.forward_fused(Batch.from_data_list(states)).gather(1, action).squeeze(1).float()
-            x, src, dst, mask = dense_batch(states if sel else nexts, self.e_max, dev)
+            if lazy:
+                from .gcn_fused import FusedGcn
+                ga = gather_state_refs(s_refs, self.e_max, dev)
+                gb = gather_state_refs(n_refs, self.e_max, dev)
+                other = self.policy_net_2 if sel else self.policy_net_1
+                if not hasattr(other, "_fused"):
+                    other._fused = FusedGcn(other)
+                go = gb if sel else ga
+                with torch.no_grad():
+                    qo = other._fused.forward_arrays(go["x"], go["node_ptr"], go["esrc"], go["edst"], go["edge_ptr"],
+                                                     go["n"], self.e_max)
+                    aux = (qo.max(1)[0].float() * nonfinal * self.gamma + reward) if sel else \
+                        qo.gather(1, action).squeeze(1).float()
+                gd = ga if sel else gb
+                x, src, dst, mask = gd["x"], gd["src"], gd["dst"], gd["mask"]
+            else:
+                with torch.no_grad():
+                    if sel:   # targets: fused forward of the other network on the next states
+                        aux = self.policy_net_2.forward_fused(Batch.from_data_list(nexts)).max(1)[0].float() * nonfinal
+                        aux = aux * self.gamma + reward                      # = expected
+                    else:     # q1(s)[a]: fused forward of the other network on the states
+                        aux = self.policy_net_1.forward_fused(Batch.from_data_list(states)).gather(1, action).squeeze(1).float()
+                x, src, dst, mask = dense_batch(states if sel else nexts, self.e_max, dev)
             g = self._graphs.get(k)
             if g is None or g["x"].shape != x.shape:
                 st = dict(x=x.clone(), src=src.clone(), dst=dst.clone(), mask=mask.clone(), act=action.clone(),
@@ -483,6 +505,39 @@ class StateRef:
 
     def to(self, device):
         return self.data().to(device)
+
+
+def gather_state_refs(refs: List["StateRef"], e_max: int, device):
+    """Minibatch arrays straight from lazy state references, without materialising per-graph `Data` objects:
+    x (B,n,F) f32; esrc / edst (sumE,) i32 local node ids + edge_ptr (B+1,) i32 + node_ptr for the fused forward;
+    src / dst (B,e_max) i64 + mask (B,e_max) f32 for the dense autograd path.  A handful of kernels per minibatch."""
+    B = len(refs)
+    x = torch.stack([r.st["x"][r.b] for r in refs]).to(device)
+    n = x.shape[1]
+    cnt = np.array([r.e1 - r.e0 for r in refs], dtype=np.int64)
+    if cnt.max(initial=0) > e_max:
+        raise ValueError(f"graph with {int(cnt.max())} edges exceeds e_max {e_max}")
+    total = int(cnt.sum())
+    if total:
+        esrc = torch.cat([r.st["esrc"][r.e0:r.e1] for r in refs]).to(device)
+        edst = torch.cat([r.st["edst"][r.e0:r.e1] for r in refs]).to(device)
+    else:
+        esrc = edst = torch.zeros(0, dtype=torch.int32, device=device)
+    edge_ptr = np.zeros(B + 1, np.int32)
+    np.cumsum(cnt, out=edge_ptr[1:])
+    src = torch.zeros((B, e_max), dtype=torch.long, device=device)
+    dst = torch.zeros((B, e_max), dtype=torch.long, device=device)
+    mask = torch.zeros((B, e_max), dtype=torch.float32, device=device)
+    if total:
+        rows = np.repeat(np.arange(B, dtype=np.int64), cnt)
+        cols = np.arange(total, dtype=np.int64) - np.repeat(edge_ptr[:-1].astype(np.int64), cnt)
+        lin = torch.from_numpy(rows * e_max + cols).to(device)
+        src.view(-1).scatter_(0, lin, esrc.long())
+        dst.view(-1).scatter_(0, lin, edst.long())
+        mask.view(-1).scatter_(0, lin, torch.ones(total, dtype=torch.float32, device=device))
+    return dict(x=x, n=n, esrc=esrc.to(torch.int32), edst=edst.to(torch.int32),
+                edge_ptr=torch.from_numpy(edge_ptr).to(device),
+                node_ptr=torch.arange(B + 1, dtype=torch.int32, device=device) * n, src=src, dst=dst, mask=mask)
 
 
 def state_to_data_list(st: dict, n_nodes: int) -> List[Data]:

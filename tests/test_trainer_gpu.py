@@ -67,3 +67,35 @@ def test_graphed_optimiser_step_equals_eager_step(lib_built):
             assert torch.allclose(a, b, rtol=1e-3, atol=1e-7)
             nonzero += int(b.abs().max() > 0)
         assert nonzero > 10
+
+
+def test_lazy_minibatch_path_equals_data_path(lib_built):
+    """Optimiser step on a replay of lazy state references (what train_loop_vec stores) vs the same transitions as
+    materialised Data objects: same loss, same gradient, for both halves of the double-DQN cycle."""
+    from meshdqn_amd.trainer import DistContext, DQNTrainer, StateRef, Transition
+    rng = np.random.default_rng(8)
+    B, N, F = 8, 180, 17
+    counts = rng.integers(150, 500, size=B)
+    ep = np.zeros(B + 1, np.int64); ep[1:] = np.cumsum(counts)
+    def state():
+        return dict(x=torch.from_numpy(rng.standard_normal((B, N, F))).float().cuda(),
+                    esrc=torch.from_numpy(rng.integers(0, N, size=int(ep[-1]))).int().cuda(),
+                    edst=torch.from_numpy(rng.integers(0, N, size=int(ep[-1]))).int().cuda())
+    st0, st1 = state(), state()
+    refs0 = [StateRef(st0, b, int(ep[b]), int(ep[b + 1])) for b in range(B)]
+    refs1 = [StateRef(st1, b, int(ep[b]), int(ep[b + 1])) for b in range(B)]
+    acts = [torch.tensor([[int(rng.integers(0, 181))]]) for _ in range(B)]
+    rews = [torch.tensor([float(rng.standard_normal())]) for _ in range(B)]
+    lazy = [Transition(refs0[b], acts[b], None if b % 4 == 0 else refs1[b], rews[b]) for b in range(B)]
+    data = [Transition(refs0[b].data(), acts[b], None if b % 4 == 0 else refs1[b].data(), rews[b]) for b in range(B)]
+    for sel in (True, False):
+        res = []
+        for trs in (data, lazy):
+            tr = DQNTrainer(n_actions=180, num_inputs=17, ctx=DistContext(), batch_size=B, lr=0.0)
+            tr.num_grads, tr.select = 1, sel
+            loss = tr.optimize(trs)
+            net = tr.policy_net_1 if sel else tr.policy_net_2
+            res.append((loss, [p.grad.clone() for p in net.parameters()]))
+        assert abs(res[0][0] - res[1][0]) < 1e-6
+        for a, b_ in zip(res[0][1], res[1][1]):
+            assert torch.allclose(a, b_, rtol=1e-3, atol=1e-7)
