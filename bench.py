@@ -264,7 +264,7 @@ def main():
     import torch
     # the GPU boxes expose 256 logical CPUs under a 16-core quota: a 256-thread intra-op pool that keeps spinning after
     # any stray CPU tensor op starves the threads that matter (measured: 25 ms per autograd backward)
-    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    torch.set_num_threads(1)   # (the CPU-side tensor ops of this program are tiny: no intra-op pool at all)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

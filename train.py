@@ -28,7 +28,7 @@ def main():
     from meshdqn_amd.trainer import DistContext, DQNTrainer, TrainingLog, train_loop_vec
     from meshdqn_amd.vec_env import VecEnv2DAirfoil
     import torch
-    torch.set_num_threads(min(8, os.cpu_count() or 1))   # (many-core hosts under a CPU quota: keep the intra-op pool small)
+    torch.set_num_threads(1)   # (many-core hosts under a CPU quota: the CPU-side tensor ops are tiny, no intra-op pool)
     cfg = yaml.safe_load(open(args.config))
     ctx = DistContext()
     opt = cfg.get("optimizer", {})          # reference yaml sections: optimizer / epsilon (configs/ray_ys930.yaml)
