@@ -24,6 +24,12 @@ Extra objects in the JSON line:
                 and for S1; rank 0 at N = 1 only, measured BEFORE the GPU is initialised
 """
 import argparse
+import os as _os
+
+# single-threaded BLAS / OpenMP pools BEFORE numpy / scipy / torch are imported: the hosts expose hundreds of logical CPUs
+# under a small CPU quota, and idle pool threads that keep spinning starve the threads that launch kernels
+for _k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    _os.environ.setdefault(_k, "1")
 import json
 import os
 import sys
@@ -93,6 +99,9 @@ def cpu_baseline(budget_s=15.0, spinup=20):
                sample=f"{n} FlowSolver.evolve() steps of 1 ys930 env (numpy/scipy oracle, sparse LU "
                       f"back-substitution like the reference's MUMPS path), {dt:.1f} s on 1 core; "
                       f"mesh smoothing / assembly / factorisation excluded")
+    legs = os.environ.get("MDQ_BENCH_CPU_LEGS", "s1,parallel").split(",")   # (debug knob)
+    if "s1" not in legs:
+        return out
     # the same for S1 (reference-semantics env step: scipy Delaunay + smoothing + interpolation + probes + state)
     from oracle.env import OracleEnv
     agent = dict(solver_steps=20, episodes=10, timesteps=10000, threshold=0.001, N_closest=180, gt_drag=-1, gt_time=-1,
@@ -107,6 +116,8 @@ def cpu_baseline(budget_s=15.0, spinup=20):
     out["s1_sample"] = "3 OracleEnv.step() calls of 1 ys930 env (python loops for interpolation / smoothing), 1 core"
     try:
         procs = 12
+        if "parallel" not in legs:
+            raise RuntimeError("skipped (MDQ_BENCH_CPU_LEGS)")
         if any(os.environ.get(k) for k in ("HSA_TOOLS_LIB", "ROCP_TOOL_LIB", "ROCPROFILER_LIBRARY")):
             raise RuntimeError("skipped under a profiler (its preloaded tool may already hold the GPU: no child interpreters)")
         out["parallel_value"] = cpu_baseline_parallel(8.0, procs)
@@ -247,6 +258,7 @@ def main():
     ap.add_argument("--rtol", type=float, default=1e-10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--s1-steps", type=int, default=50, help="batched reference-semantics env steps (0 = skip)")
     ap.add_argument("--cell-order", default="conflictfree", choices=["mesh", "conflictfree"])
     ap.add_argument("--train-steps", type=int, default=20, help="batched learning-loop steps (0 = skip)")
@@ -258,8 +270,20 @@ def main():
     # CPU baseline FIRST, before anything initialises the GPU: its multi-process leg starts child interpreters
     # (fork + exec), which must not happen from a process that already holds the device
     cpu = None
+    if args.cpu_baseline_child:                      # child interpreter: CPU legs only, JSON on stdout
+        print(json.dumps(cpu_baseline(args.cpu_budget)), flush=True)
+        return
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.cpu_budget)
+        # in a child interpreter (started before this process touches the GPU): whatever the numpy / scipy / Qhull
+        # heavy oracle run leaves behind in the process state was measured to slow the later learning loop by 30 %
+        import subprocess
+        try:
+            txt = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--cpu-budget",
+                                  str(args.cpu_budget)], check=True, capture_output=True, text=True).stdout
+            cpu = json.loads(txt.strip().splitlines()[-1])
+        except Exception as exc:  # noqa: BLE001 - fall back to the in-process measurement
+            sys.stderr.write(f"[bench] cpu baseline child failed ({exc!r}); measuring in-process\n")
+            cpu = cpu_baseline(args.cpu_budget)
 
     import torch
     # the GPU boxes expose 256 logical CPUs under a 16-core quota: a 256-thread intra-op pool that keeps spinning after

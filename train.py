@@ -8,6 +8,12 @@ One process per GPU; every rank steps `--envs` environments (VecEnv2DAirfoil), a
 all-reduced gradient, replay transitions are optionally all-gathered.  The yaml is the reference's own format
 (`flow_config`, `agent_params`, `optimizer`, `epsilon`); `geometry_params.mesh` may point at an .xdmf or .npz file."""
 import argparse
+import os as _os
+
+# single-threaded BLAS / OpenMP pools BEFORE numpy / scipy / torch are imported: the hosts expose hundreds of logical CPUs
+# under a small CPU quota, and idle pool threads that keep spinning starve the threads that launch kernels
+for _k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    _os.environ.setdefault(_k, "1")
 import os
 
 import numpy as np
