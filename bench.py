@@ -17,7 +17,8 @@ Extra objects in the JSON line:
   roofline      dominant kernel (at_velocity_kernel): algorithmic bytes per launch / launch duration measured with
                 HIP events on the launch stream vs the 8 TB/s HBM peak; PMC traffic from profiles/traffic.json;
                 a device-copy microbenchmark of the same run
-  rates         S1 = the reference-semantics Env2DAirfoil.step incl. Q-forward, S3 = S1 + one IPCS step on every
+  rates         S2_full_chip = the same S2 workload with 256 envs (one workgroup on every CU);
+                S1 = the reference-semantics Env2DAirfoil.step incl. Q-forward, S3 = S1 + one IPCS step on every
                 coarsened mesh (the literal north-star step), training_loop = S1 rollout + replay + optimiser step
                 (with the RCCL gradient all-reduce for N > 1); all resident on the GPU
   cpu_baseline  the numpy/scipy sparse-LU oracle on one host core, on 12 processes (the reference's num_parallel)
@@ -215,6 +216,31 @@ def measure_env_steps(args, dev, dist, world, flow_steps=0):
     return out
 
 
+def measure_s2_full_chip(args, dev, topo, x, envs=256):
+    """The S2 workload with one workgroup on EVERY CU (256 envs per GPU instead of BASELINE's 128, which leave half of
+    the chip idle): rate + velocity-kernel roofline, rank-local, short."""
+    import torch
+    from meshdqn_amd.ipcs_batch import IpcsBatch
+    batch = IpcsBatch([topo] * envs, [x] * envs, device=dev, rtol=args.rtol, cell_order=args.cell_order)
+    out = (torch.empty((envs, 1), dtype=torch.float64, device=dev), torch.empty((envs, 1), dtype=torch.float64, device=dev))
+    for _ in range(args.spinup + args.warmup):
+        batch.evolve(1, out=out)
+    n = max(args.steps // 2, 10)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        batch.evolve(1, out=out)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    batch.iters.zero_()
+    outs = (torch.empty((envs, n), dtype=torch.float64, device=dev), torch.empty((envs, n), dtype=torch.float64, device=dev))
+    _, _, kms = batch.evolve_timed(n, out=outs)
+    it = batch.iters.cpu().numpy().astype(np.float64) / n
+    vb = batch.velocity_kernel_bytes(it)
+    return dict(envs_per_gpu=envs, value=envs * n / el, unit="env steps/s (this rank)", ms_per_step=el / n * 1e3,
+                velocity_kernel_ms=kms[0] / n, velocity_kernel_roofline_frac=vb / (kms[0] / n * 1e-3) / 1e9 / HBM_PEAK_GBS)
+
+
 def measure_train(args, dev, dist, world):
     """The learning loop of airfoil_dqn.py:428-503 at scale (BASELINE configs[3]): per batched step every rank steps
     its envs (S1), pushes B transitions, and all ranks take ONE optimiser step on the all-reduced (RCCL) gradient of
@@ -379,6 +405,7 @@ def main():
     copy_gbs = 10 * 2 * src.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9   # read + write
     del src, dst
 
+    full = measure_s2_full_chip(args, dev, topo, x) if args.s1_steps > 0 else None
     s3 = measure_env_steps(args, dev, dist, world, 1) if args.s1_steps > 0 else None
     s1 = measure_env_steps(args, dev, dist, world, 0) if args.s1_steps > 0 else None
     tr = measure_train(args, dev, dist, world) if args.s1_steps > 0 and args.train_steps > 0 else None
@@ -435,7 +462,8 @@ def main():
                                  "live in LDS/registers; the binding resources are FP64 VALU issue, LDS atomics and "
                                  "workgroup barriers on the B CUs in use (one CU per environment), not HBM"},
         }
-        res["rates"] = {"S2_ipcs_env_steps_per_s": res["value"], "S1_reference_step_env_steps_per_s": s1,
+        res["rates"] = {"S2_ipcs_env_steps_per_s": res["value"], "S2_full_chip": full,
+                        "S1_reference_step_env_steps_per_s": s1,
                         "S3_north_star_step_env_steps_per_s": s3, "training_loop_env_steps_per_s": tr}
         if cpu is not None:
             res["cpu_baseline"] = cpu
