@@ -183,7 +183,7 @@ int mdq_ipcs_evolve(const mdq_ipcs_desc* d, int32_t nsteps, double* drag, double
                     int32_t* iters, void* stream);
 
 /*
- * Same as mdq_ipcs_evolve for the three-kernel mode 3, with HIP events recorded on `stream` around every
+ * Same as mdq_ipcs_evolve (`FlowSolver.evolve`, flow_solver.py:362-396) for the three-kernel mode 3, with HIP events recorded on `stream` around every
  * kernel launch; the accumulated durations (milliseconds over all nsteps) of the velocity / pressure /
  * correction kernels are returned in host array kernel_ms[3].  Synchronises the stream (measurement aid).
  */
@@ -226,7 +226,8 @@ typedef struct mdq_gcn_net {
 
 /*
  * Batched forward of B graphs (one workgroup per graph, whole network out of LDS; dense head on MFMA).
- * Replaces `NodeRemovalNet.forward(Batch)` / `AirfoilGCNN.forward(Batch)` and the PyG layers they call.
+ * Replaces `NodeRemovalNet.forward(Batch)` (airfoilgcnn.py:85-145) / `AirfoilGCNN.forward(Batch)` (airfoilgcnn.py:170-209)
+ * and the PyG layers they call (SAGEConv / GCNConv / TopKPooling / global max + mean pool, airfoilgcnn.py:30-41).
  *   x        device float [sum_nodes][fin0]     node features, graphs concatenated
  *   node_ptr device int32 [B+1]                 first node of every graph
  *   esrc/edst device int32 [sum_edges]          edge end points, LOCAL node ids (0..n_g-1), j -> i
