@@ -587,10 +587,11 @@ __device__ inline void rhs1_elements(const EnvView& v, const mdq_ipcs_desc& d, c
   }
 }
 
+template <int NTH = WG>
 __device__ inline void rhs2_elements(const EnvView& v, const mdq_ipcs_desc& d, const double2* __restrict__ u,
                                      const double* __restrict__ p, double* __restrict__ escr) {
   const double idt = 1.0 / d.dt;
-  for (int e = threadIdx.x; e < v.nt; e += WG) {
+  for (int e = threadIdx.x; e < v.nt; e += NTH) {
     const ElemIdx E = load_dofs(v, e);
     const Geo g = load_geo(v, e);
     double2 ue[6];
@@ -1036,17 +1037,18 @@ __device__ __forceinline__ PdView pd_view(const mdq_ipcs_desc& d, int b) {
 }
 
 // x = K^-1 b.  b, x: LDS vectors in natural node order (x may alias b); t0,t1,t2: LDS scratch
-// of at least max(n, WG) doubles each.
+// of at least max(n, NTH) doubles each (NTH = threads of the calling kernel).
+template <int NTH = WG>
 __device__ inline void pressure_direct(const PdView& pd, int n, const double* b, double* x, double* t0, double* t1,
                                        double* t2) {
   const int tid = threadIdx.x, nI = pd.nI, nG = pd.nG;
   double* bp = t0;  // permuted right-hand side
   double* y = t1;   // W b_I  |  separator: g, then x_G
   __syncthreads();
-  for (int q = tid; q < n; q += WG) bp[q] = b[pd.node[q]];
+  for (int q = tid; q < n; q += NTH) bp[q] = b[pd.node[q]];
   __syncthreads();
   // y_I = W b_I
-  for (int q = tid; q < nI; q += WG) {
+  for (int q = tid; q < nI; q += NTH) {
     const int32_t* m6 = pd.meta + 6 * pd.rowblk[q];
     const int q0 = m6[0], m = m6[1];
     const double* Wc = pd.W + m6[2] + (q - q0);
@@ -1057,7 +1059,7 @@ __device__ inline void pressure_direct(const PdView& pd, int n, const double* b,
   }
   __syncthreads();
   // g = b_G - K[G,I] y_I
-  for (int g = tid; g < nG; g += WG) {
+  for (int g = tid; g < nG; g += NTH) {
     double acc = bp[nI + g];
     for (int k = pd.gk_ptr[g]; k < pd.gk_ptr[g + 1]; ++k) acc -= pd.gk_val[k] * y[pd.gk_col[k]];
     y[nI + g] = acc;
@@ -1065,9 +1067,9 @@ __device__ inline void pressure_direct(const PdView& pd, int n, const double* b,
   __syncthreads();
   // x_G = Sinv g : rows split over column slices so that all waves stream Sinv
   const int NGP = (nG + 63) & ~63;
-  const int nsl = NGP > 0 ? (WG / NGP > 0 ? WG / NGP : 1) : 1;
+  const int nsl = NGP > 0 ? (NTH / NGP > 0 ? NTH / NGP : 1) : 1;
   const int cw = (nG + nsl - 1) / nsl;
-  for (int idx = tid; idx < nsl * NGP; idx += WG) {
+  for (int idx = tid; idx < nsl * NGP; idx += NTH) {
     const int sl = idx / NGP, row = idx - sl * NGP;
     double acc = 0.0;
     if (row < nG) {
@@ -1079,14 +1081,14 @@ __device__ inline void pressure_direct(const PdView& pd, int n, const double* b,
     t2[idx] = acc;
   }
   __syncthreads();
-  for (int g = tid; g < nG; g += WG) {
+  for (int g = tid; g < nG; g += NTH) {
     double acc = 0.0;
     for (int sl = 0; sl < nsl; ++sl) acc += t2[sl * NGP + g];
     bp[g] = acc;  // x_G (bp is free now)
   }
   __syncthreads();
   // x_I = y_I - F x_G ; scatter back to natural order
-  for (int q = tid; q < nI; q += WG) {
+  for (int q = tid; q < nI; q += NTH) {
     const int32_t* m6 = pd.meta + 6 * pd.rowblk[q];
     const int q0 = m6[0], m = m6[1], gs = m6[4];
     const double* Fc = pd.F + m6[3] + (q - q0);
@@ -1095,7 +1097,7 @@ __device__ inline void pressure_direct(const PdView& pd, int n, const double* b,
     for (int c = 0; c < gs; ++c) acc -= Fc[(int64_t)c * m] * bp[gi[c]];
     x[pd.node[q]] = acc;
   }
-  for (int g = tid; g < nG; g += WG) x[pd.node[nI + g]] = bp[g];
+  for (int g = tid; g < nG; g += NTH) x[pd.node[nI + g]] = bp[g];
   __syncthreads();
 }
 
@@ -1194,7 +1196,7 @@ struct LdsPlan {
 __host__ __device__ inline LdsPlan lds_plan(int N2, int NV, int NSE1) {
   LdsPlan P;
   P.N2p = (N2 + 1) & ~1;
-  P.NVp = ((NV > WG ? NV : WG) + 63) & ~63;
+  P.NVp = ((NV > 1024 ? NV : 1024) + 63) & ~63;  // (>= the 1024 threads of the direct pressure kernel)
   P.vel1_bytes = 2 * sizeof(double2) * (size_t)P.N2p;
   P.vel2_bytes = sizeof(double2) * ((size_t)P.N2p + 6 * MF_CH);  // stage + tile
   P.vel3_bytes = 3 * sizeof(double2) * (size_t)P.N2p;  // p, r, result vector
@@ -2338,8 +2340,10 @@ __global__ __launch_bounds__(TW) void at_velocity_kernel(mdq_ipcs_desc d, int32_
   }
 }
 
-template <bool K1_LDS>
-__global__ __launch_bounds__(WG) void at_pressure_kernel(mdq_ipcs_desc d, int32_t* iters) {
+// NTH = 1024 for the direct solver (its dense phases are latency-bound streams of 0.8 MB of factors: twice the loads
+// in flight per CU); the CG variant keeps the 512-thread shape its reductions are written for.
+template <bool K1_LDS, int NTH = WG>
+__global__ __launch_bounds__(NTH) void at_pressure_kernel(mdq_ipcs_desc d, int32_t* iters) {
   extern __shared__ __align__(16) double smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const EnvView v = env_view(d, b);
@@ -2371,15 +2375,15 @@ __global__ __launch_bounds__(WG) void at_pressure_kernel(mdq_ipcs_desc d, int32_
     // ================= step 2: pressure
     if (K1_LDS && !d.pd_enabled) {
       const int ne1 = v.sl1_off[nsl1];
-      for (int kk = tid; kk < ne1; kk += WG) {
+      for (int kk = tid; kk < ne1; kk += NTH) {
         lK[kk] = v.K1s[kk];
         lci[kk] = v.sl1_col[kk];
       }
-      for (int kk = tid; kk <= nsl1; kk += WG) lso[kk] = v.sl1_off[kk];
+      for (int kk = tid; kk <= nsl1; kk += NTH) lso[kk] = v.sl1_off[kk];
     }
-    rhs2_elements(v, d, xs, v.p_n, escr1);
+    rhs2_elements<NTH>(v, d, xs, v.p_n, escr1);
     __syncthreads();
-    for (int i = tid; i < nv; i += WG) {
+    for (int i = tid; i < nv; i += NTH) {
       double bsum = 0.0;
       for (int s = v.g1_ptr[i]; s < v.g1_ptr[i + 1]; ++s) bsum += escr1[v.g1_src[s]];
       const double sd = v.sdiagK[i];
@@ -2388,11 +2392,11 @@ __global__ __launch_bounds__(WG) void at_pressure_kernel(mdq_ipcs_desc d, int32_
     }
     if (d.pd_enabled) {
       const PdView pd = pd_view(d, b);
-      pressure_direct(pd, nv, pr, px, pp, pq, lK);
+      pressure_direct<NTH>(pd, nv, pr, px, pp, pq, lK);
     } else {
       it_p += cg_pressure(nv, so1, ci1, K1, d.rtol, d.maxit_p, px, pr, pp, pq, red);
     }
-    for (int i = tid; i < nv; i += WG) pnew[i] = px[i] / v.sdiagK[i];
+    for (int i = tid; i < nv; i += NTH) pnew[i] = px[i] / v.sdiagK[i];
     __syncthreads();
 
   }
@@ -2751,6 +2755,9 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
         e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&at_pressure_kernel<false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e_ == hipSuccess)
+        e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&at_pressure_kernel<false, 1024>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e_ == hipSuccess)
         e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&at_correction_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       return e_;
@@ -2776,7 +2783,9 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
       else
         hipLaunchKernelGGL((at_velocity_kernel<WG, MF_ROWS, AT_PAIR>), dim3(d->B), dim3(WG), lds_v, st, *d, iters);
       if (kernel_ms) hipEventRecord(ev[1], st);
-      if (k1_lds)
+      if (d->pd_enabled)
+        hipLaunchKernelGGL((at_pressure_kernel<false, 1024>), dim3(d->B), dim3(1024), lds_p, st, *d, iters);
+      else if (k1_lds)
         hipLaunchKernelGGL(at_pressure_kernel<true>, dim3(d->B), dim3(WG), lds_p, st, *d, iters);
       else
         hipLaunchKernelGGL(at_pressure_kernel<false>, dim3(d->B), dim3(WG), lds_p, st, *d, iters);
