@@ -17,7 +17,11 @@
 
 namespace mdq_gcn {
 
-constexpr int WGT = 256;
+#ifndef MDQ_GCN_WG
+#define MDQ_GCN_WG 512
+#endif
+constexpr int WGT = MDQ_GCN_WG;  // threads of the embedding kernel (one workgroup per graph)
+constexpr int WGH = 256;         // threads of the MFMA head kernel (4 waves, one 32x32 block each per pass)
 constexpr int NACC = 24;  // accumulators per thread of the "feature-outer" small-graph convolution
 
 struct Lds {
@@ -386,7 +390,7 @@ __device__ inline void head_layer(const float* in, int in_stride, int K, const f
                                   const float* __restrict__ bias, int ncols, float* out, int out_stride, bool relu) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nblk = (ncols + 31) / 32;
-  for (int blk = wave; blk < nblk; blk += WGT / 64) {
+  for (int blk = wave; blk < nblk; blk += WGH / 64) {
     const int col = blk * 32 + (lane & 31);
     const bool cv = col < ncols;
     floatx16 acc;
@@ -411,7 +415,7 @@ __device__ inline void head_layer(const float* in, int in_stride, int K, const f
   }
 }
 
-__global__ __launch_bounds__(WGT) void mlp_head_kernel(mdq_gcn_net net, int B, const float* emb, float* out) {
+__global__ __launch_bounds__(WGH) void mlp_head_kernel(mdq_gcn_net net, int B, const float* emb, float* out) {
   extern __shared__ __align__(16) float sm[];
   const int tid = threadIdx.x, K1 = 2 * net.C, OUT = net.out_dim;
   const int OUTP = (OUT + 31) & ~31;
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(WGT) void mlp_head_kernel(mdq_gcn_net net, int B, c
   float* a2 = a1 + 32 * 129;         // [32][65]
   float* a3 = a2 + 32 * 65;          // [32][OUTP]
   const int g0 = blockIdx.x * 32;
-  for (int idx = tid; idx < 32 * K1; idx += WGT) {
+  for (int idx = tid; idx < 32 * K1; idx += WGH) {
     const int r = idx / K1, c = idx - r * K1;
     a0[r * (K1 + 1) + c] = (g0 + r < B) ? emb[(size_t)(g0 + r) * K1 + c] : 0.f;
   }
@@ -434,7 +438,7 @@ __global__ __launch_bounds__(WGT) void mlp_head_kernel(mdq_gcn_net net, int B, c
   __syncthreads();
   // softmax (optional) + store: one wave per row, 8 rows per wave
   const int lane = tid & 63, wave = tid >> 6;
-  for (int r = wave; r < 32; r += WGT / 64) {
+  for (int r = wave; r < 32; r += WGH / 64) {
     if (g0 + r >= B) continue;
     const float* row = a3 + r * OUTP;
     if (net.softmax) {
@@ -484,7 +488,7 @@ extern "C" int mdq_gcn_forward(const mdq_gcn_net* net, int32_t B, int32_t NMAX, 
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)lds2);
   if (e != hipSuccess) return mdq_set_error(hipGetErrorString(e));
-  hipLaunchKernelGGL(mlp_head_kernel, dim3((B + 31) / 32), dim3(WGT), lds2, st, *net, B, emb, out);
+  hipLaunchKernelGGL(mlp_head_kernel, dim3((B + 31) / 32), dim3(WGH), lds2, st, *net, B, emb, out);
   e = hipGetLastError();
   if (e != hipSuccess) return mdq_set_error(hipGetErrorString(e));
   return 0;
