@@ -321,12 +321,20 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # MDQ_SHARE_GPU=1 + MDQ_DIST_BACKEND=gloo: debugging aid that lets the multi-rank control flow be exercised on
+        # a box with fewer GPUs than ranks (RCCL refuses two ranks on one device); never set by the driver
+        dev_index = local_rank % torch.cuda.device_count() if os.environ.get("MDQ_SHARE_GPU") else local_rank
+        torch.cuda.set_device(dev_index)
+        backend = os.environ.get("MDQ_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     else:
         dist = None
+        dev_index = 0
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", dev_index)
 
     from meshdqn_amd import build as _b
     if rank == 0:

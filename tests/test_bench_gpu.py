@@ -1,0 +1,48 @@
+"""GPU: bench.py's contract line, single rank and two torchrun ranks.  The two-rank case shares cuda:0 between the
+ranks (MDQ_SHARE_GPU=1) over gloo, because RCCL refuses two ranks on one device: it exercises the multi-rank control
+flow (rank-0 build, barriers, max-over-ranks timing, sharded envs, the gradient all-reduce of the learning loop), not
+RCCL itself."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--steps", "20", "--warmup", "5", "--spinup", "60", "--envs", "16", "--s1-steps", "4", "--s1-warmup", "3",
+         "--train-steps", "3", "--s1-solver-steps", "200"]
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline", "rates"}
+
+
+def _line(cmd, env):
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_rank_line(lib_built):
+    res = _line([sys.executable, "bench.py", "--cpu-budget", "1"] + SMALL, dict(os.environ, MDQ_BENCH_CPU_LEGS="s2only"))
+    assert KEYS | {"cpu_baseline"} <= set(res)
+    assert res["n_gpus"] == 1 and res["steps"] == 20 and res["warmup"] == 5 and res["scaling"] == "weak"
+    assert res["value"] > 0 and abs(res["value"] - 16 * 20 / (res["ms_per_step"] * 20e-3)) < 1e-6 * res["value"]
+    roof = res["roofline"]
+    assert roof["bound"] == "hbm" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
+    cpu = res["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0
+    for k in ("S1_reference_step_env_steps_per_s", "S3_north_star_step_env_steps_per_s", "training_loop_env_steps_per_s"):
+        assert res["rates"][k]["value"] > 0
+
+
+def test_bench_two_ranks_share_one_gpu(lib_built):
+    env = dict(os.environ, MDQ_SHARE_GPU="1", MDQ_DIST_BACKEND="gloo")
+    res = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                 "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2"] + SMALL, env)
+    assert KEYS <= set(res) and "cpu_baseline" not in res          # the CPU leg is rank 0 at N = 1 only
+    assert res["n_gpus"] == 2
+    assert abs(res["value"] - 2 * 16 * 20 / (res["ms_per_step"] * 20e-3)) < 1e-6 * res["value"]
+    assert res["rates"]["training_loop_env_steps_per_s"]["value"] > 0
