@@ -2068,6 +2068,63 @@ __device__ __forceinline__ void outflow_rows_add(const EnvView& v, const BoOwn& 
   }
 }
 
+#ifdef MDQ_AT_TRACE
+// debug build only: s_memtime deltas of thread 0 of environment 0 at the phase boundaries of at_velocity_kernel
+__device__ long long mdq_at_trace_buf[16];
+#define AT_STAMP(k) { const long long tn_ = __builtin_amdgcn_s_memtime(); if (tid == 0 && b == 0) mdq_at_trace_buf[k] += tn_ - tq_; tq_ = tn_; }
+extern "C" int mdq_at_trace_host(long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mdq_at_trace_buf), sizeof(long long) * 16) != hipSuccess) return -1;
+  if (reset) { long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(mdq_at_trace_buf), z, sizeof z) != hipSuccess) return -1; }
+  return 0;
+}
+#else
+#define AT_STAMP(k)
+#endif
+
+// The same outflow-facet term, one ENTRY per thread (18 entries per outflow facet, a few hundred per mesh): every
+// thread adds coef * B_entry x[col] to Y[row] with LDS atomics, between the barrier that publishes the zeroed Y
+// and the element loop, so that the term costs one global-load latency of the waves that own entries instead of a
+// serial per-row chain of them between two barriers.  (row, col) of entry `tid` is found once per launch from the
+// element slot list (bo_src = cell * 36 + i * 6 + j) and kept packed in one register; entries beyond the
+// workgroup size (never on the training meshes) are looked up on the fly.
+struct BoEnt {
+  int rc;   // row << 12 | col of entry threadIdx.x, -1 if none
+  int nbe;  // entries of this environment
+};
+__device__ __forceinline__ int outflow_entry_rc(const EnvView& v, int t) {
+  const int slot = v.bo_src[t];
+  const int e = slot / 36, ij = slot - e * 36, i = ij / 6, j = ij - i * 6;
+  return ((v.mf_scat[i * v.NT + e] & 0xFFF) << 12) | (v.mf_scat[j * v.NT + e] & 0xFFF);
+}
+__device__ __forceinline__ BoEnt outflow_entries_owned(const EnvView& v) {
+  BoEnt o;
+  o.nbe = v.nbo > 0 ? v.bo_ptr[v.nbo] : 0;
+  o.rc = (int)threadIdx.x < o.nbe ? outflow_entry_rc(v, threadIdx.x) : -1;
+  return o;
+}
+__device__ __forceinline__ void outflow_entry_apply(const EnvView& v, int t, int rc, double coef, const double2* x,
+                                                    double* Yd) {
+  const double4 bv = reinterpret_cast<const double4*>(v.bo_val)[t];
+  const double2 xc = x[rc & 0xFFF];
+  const int row = rc >> 12;
+  unsafeAtomicAdd(Yd + 2 * row, coef * (bv.x * xc.x + bv.y * xc.y));
+  unsafeAtomicAdd(Yd + 2 * row + 1, coef * (bv.z * xc.x + bv.w * xc.y));
+}
+template <int TW>
+__device__ __forceinline__ void outflow_entries_add(const EnvView& v, const BoEnt& o, double coef, const double2* x,
+                                                    double* Yd) {
+  if (o.rc >= 0) outflow_entry_apply(v, threadIdx.x, o.rc, coef, x, Yd);
+  for (int t = threadIdx.x + TW; t < o.nbe; t += TW) outflow_entry_apply(v, t, outflow_entry_rc(v, t), coef, x, Yd);
+}
+
+// float kept in a register -> double at the point of use: the asm stops the compiler from hoisting the conversion
+// out of the Krylov loop, which turns 4-byte loop invariants into 8-byte ones (measured: they were then spilled to
+// scratch and re-read one by one in every vector phase of every iteration)
+__device__ __forceinline__ double f2d(float f) {
+  asm volatile("" : "+v"(f));
+  return (double)f;
+}
+
 // ---- mode 3 as three kernels per time step (separate register allocation per phase: the BiCGStab
 // loop then runs without spill reloads; state is handed over through global memory as before) ----
 template <int TW, int TROWS, int TPAIR>
@@ -2092,7 +2149,7 @@ __global__ __launch_bounds__(TW) void at_velocity_kernel(mdq_ipcs_desc d, int32_
   double* Yd = reinterpret_cast<double*>(Yl);
   AtMetaT<TPAIR> tm;
   at_prefetch<TW, TPAIR>(v, tm, 0);
-  const BoOwn bo_own = outflow_rows_owned<TW>(v);
+  const BoEnt bo_ent = outflow_entries_owned(v);
   int it_u = 0;
   double2* hist = xs + d.N2;                                          // u* of the step before the last
   double2* hist2 = xs + 2 * (int64_t)d.N2;                            // and of the one before that
@@ -2100,7 +2157,11 @@ __global__ __launch_bounds__(TW) void at_velocity_kernel(mdq_ipcs_desc d, int32_
   double2* hist4 = xs + 5 * (int64_t)d.N2;
   double* histc = reinterpret_cast<double*>(xs + 3 * (int64_t)d.N2);  // [0]: tentative velocities stored so far
   const int nhist = (int)histc[0];
+#ifdef MDQ_AT_TRACE
+  long long tq_ = __builtin_amdgcn_s_memtime();
+#endif
   __syncthreads();
+  AT_STAMP(0)
   {
     // ================= step 1: tentative velocity
     float2 idg[TROWS];
@@ -2117,6 +2178,7 @@ __global__ __launch_bounds__(TW) void at_velocity_kernel(mdq_ipcs_desc d, int32_
       }
     }
     __syncthreads();
+    outflow_entries_add<TW>(v, bo_ent, 0.5 * mu, v.u_n, Yd);  // + mu/2 <nabla_grad(u_n) n, v> on the outflow rows
     {
       const double2* un = v.u_n;
       const double* pn = v.p_n;
@@ -2131,7 +2193,7 @@ __global__ __launch_bounds__(TW) void at_velocity_kernel(mdq_ipcs_desc d, int32_
       });
     }
     __syncthreads();
-    outflow_rows_add(v, bo_own, 0.5 * mu, v.u_n, Yl);  // + mu/2 <nabla_grad(u_n) n, v> on the outflow rows
+    AT_STAMP(1)
     double acc[2] = {0.0, 0.0};
     double2 f[TROWS];
 #pragma unroll
@@ -2175,11 +2237,13 @@ __global__ __launch_bounds__(TW) void at_velocity_kernel(mdq_ipcs_desc d, int32_
         xs[row] = x0;
         Pl[row] = x0;
         const double2 l = v.lift1[row];
-        const double2 bi = fl ? g : make_double2((f[k].x - l.x) * idg[k].x, (f[k].y - l.y) * idg[k].y);
+        const double2 bi = fl ? g : make_double2((f[k].x - l.x) * f2d(idg[k].x), (f[k].y - l.y) * f2d(idg[k].y));
         acc[0] += bi.x * bi.x + bi.y * bi.y;
       }
     }
     __syncthreads();
+    AT_STAMP(2)
+    outflow_entries_add<TW>(v, bo_ent, -0.5 * mu, Pl, Yd);
     atomic_accumulate<(TPAIR > 1), TW, TPAIR>(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
       double2 xe[6];
 #pragma unroll
@@ -2187,7 +2251,7 @@ __global__ __launch_bounds__(TW) void at_velocity_kernel(mdq_ipcs_desc d, int32_
       elem_velocity(g, a, mu, xe, ye);
     });
     __syncthreads();
-    outflow_rows_add(v, bo_own, -0.5 * mu, Pl, Yl);
+    AT_STAMP(3)
     double2 vv[TROWS];
 #pragma unroll
     for (int k = 0; k < TROWS; ++k) {
@@ -2196,7 +2260,7 @@ __global__ __launch_bounds__(TW) void at_velocity_kernel(mdq_ipcs_desc d, int32_
       if (row < n2) {
         const double2 ax = Yl[row];
         // r0 = D^-1 (f - A_full x0) on free rows, 0 on constrained rows (idg = 0 there)
-        const double2 r0 = make_double2((f[k].x - ax.x) * idg[k].x, (f[k].y - ax.y) * idg[k].y);
+        const double2 r0 = make_double2((f[k].x - ax.x) * f2d(idg[k].x), (f[k].y - ax.y) * f2d(idg[k].y));
         Rl[row] = r0;
         acc[1] += r0.x * r0.x + r0.y * r0.y;
       }
@@ -2232,6 +2296,7 @@ __global__ __launch_bounds__(TW) void at_velocity_kernel(mdq_ipcs_desc d, int32_
           block_sum1<1, TW / 64>(a0, red, rsel);
           rho = a0[0];  // (rh, r0)
         }
+        AT_STAMP(4)
         while (it < d.maxit_u) {
           ++it;
           const double beta = (rho / rho_old) * (alpha / omega);
@@ -2245,6 +2310,8 @@ __global__ __launch_bounds__(TW) void at_velocity_kernel(mdq_ipcs_desc d, int32_
             }
           }
           __syncthreads();
+          AT_STAMP(5)
+          outflow_entries_add<TW>(v, bo_ent, -0.5 * mu, Pl, Yd);
           atomic_accumulate<(TPAIR > 1), TW, TPAIR>(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
             double2 xe[6];
 #pragma unroll
@@ -2252,18 +2319,19 @@ __global__ __launch_bounds__(TW) void at_velocity_kernel(mdq_ipcs_desc d, int32_
             elem_velocity(g, a, mu, xe, ye);
           });
           __syncthreads();
-          outflow_rows_add(v, bo_own, -0.5 * mu, Pl, Yl);
+          AT_STAMP(6)
           double a1[1] = {0.0};
 #pragma unroll
           for (int k = 0; k < TROWS; ++k) {
             const int row = tid + k * TW;
             if (row < n2) {
               const double2 yv = Yl[row];
-              vv[k] = make_double2(yv.x * idg[k].x, yv.y * idg[k].y);
-              a1[0] += rh[k].x * vv[k].x + rh[k].y * vv[k].y;
+              vv[k] = make_double2(yv.x * f2d(idg[k].x), yv.y * f2d(idg[k].y));
+              a1[0] += f2d(rh[k].x) * vv[k].x + f2d(rh[k].y) * vv[k].y;
             }
           }
           block_sum1<1, TW / 64>(a1, red, rsel);
+          AT_STAMP(7)
           if (a1[0] == 0.0) break;
           alpha = rho / a1[0];
           // s = r - alpha v ; no early exit on |s| (saves a reduction; the check on |r| follows)
@@ -2277,6 +2345,8 @@ __global__ __launch_bounds__(TW) void at_velocity_kernel(mdq_ipcs_desc d, int32_
             }
           }
           __syncthreads();  // publish s and the zeroed result vector
+          AT_STAMP(8)
+          outflow_entries_add<TW>(v, bo_ent, -0.5 * mu, Rl, Yd);
           atomic_accumulate<(TPAIR > 1), TW, TPAIR>(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
             double2 xe[6];
 #pragma unroll
@@ -2291,7 +2361,7 @@ __global__ __launch_bounds__(TW) void at_velocity_kernel(mdq_ipcs_desc d, int32_
             xo[k] = row < n2 ? xs[row] : make_double2(0.0, 0.0);
           }
           __syncthreads();
-          outflow_rows_add(v, bo_own, -0.5 * mu, Rl, Yl);
+          AT_STAMP(9)
           double a3[2] = {0.0, 0.0};
           double2 t[TROWS];
 #pragma unroll
@@ -2300,12 +2370,13 @@ __global__ __launch_bounds__(TW) void at_velocity_kernel(mdq_ipcs_desc d, int32_
             t[k] = make_double2(0.0, 0.0);
             if (row < n2) {
               const double2 yv = Yl[row], sv = Rl[row];
-              t[k] = make_double2(yv.x * idg[k].x, yv.y * idg[k].y);
+              t[k] = make_double2(yv.x * f2d(idg[k].x), yv.y * f2d(idg[k].y));
               a3[0] += t[k].x * sv.x + t[k].y * sv.y;
               a3[1] += t[k].x * t[k].x + t[k].y * t[k].y;
             }
           }
           block_sum1<2, TW / 64>(a3, red, rsel);
+          AT_STAMP(10)
           if (a3[1] == 0.0) break;
           omega = a3[0] / a3[1];
           double a4[2] = {0.0, 0.0};
@@ -2318,10 +2389,11 @@ __global__ __launch_bounds__(TW) void at_velocity_kernel(mdq_ipcs_desc d, int32_
               const double2 rn = make_double2(sv.x - omega * t[k].x, sv.y - omega * t[k].y);
               Rl[row] = rn;
               a4[0] += rn.x * rn.x + rn.y * rn.y;
-              a4[1] += rh[k].x * rn.x + rh[k].y * rn.y;
+              a4[1] += f2d(rh[k].x) * rn.x + f2d(rh[k].y) * rn.y;
             }
           }
           block_sum1<2, TW / 64>(a4, red, rsel);
+          AT_STAMP(11)
           rr = a4[0];
           if (!(rr > tol2)) break;
           rho_old = rho;
@@ -2332,7 +2404,7 @@ __global__ __launch_bounds__(TW) void at_velocity_kernel(mdq_ipcs_desc d, int32_
       }
     }
     __syncthreads();  // xs (= u*) complete: the element loops of steps 2 and 3 gather it
-
+    AT_STAMP(12)
   }
   if (tid == 0) {
     histc[0] = (double)(nhist < 5 ? nhist + 1 : 5);

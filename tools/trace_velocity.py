@@ -1,0 +1,42 @@
+"""Debug: per-phase s_memtime cycles of at_velocity_kernel (library built with MDQ_CFLAGS=-DMDQ_AT_TRACE).
+usage: python tools/trace_velocity.py [envs] [steps]"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from meshdqn_amd import _lib
+from meshdqn_amd.ipcs_batch import IpcsBatch, smooth_coords
+from meshdqn_amd.topology import MeshTopology
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+z = np.load(os.path.join(ROOT, "tests", "golden", "ys930.npz"))
+topo = MeshTopology(z["coords"], z["cells"])
+x = smooth_coords(topo, 50)
+batch = IpcsBatch([topo] * B, [x] * B, device="cuda")
+batch.assemble()
+for _ in range(300):
+    batch.evolve(1)
+torch.cuda.synchronize()
+lib = ctypes.CDLL(_lib.LIB_PATH)
+buf = (ctypes.c_longlong * 16)()
+lib.mdq_at_trace_host(buf, 1)
+batch.iters.zero_()
+for _ in range(steps):
+    batch.evolve(1)
+torch.cuda.synchronize()
+lib.mdq_at_trace_host(buf, 0)
+it = batch.iters.cpu().numpy()[:, 0].mean() / steps
+names = ["prologue (prefetch, outflow rows)", "zero + rhs1 element loop", "outflow + x0 extrapolation/history", "A x0 element loop",
+         "r0, 2 reductions, p=0", "it: p update + barrier", "it: A p element loop", "it: v, (rh,v) reduction",
+         "it: s update + barrier", "it: A s element loop (+xs loads)", "it: t, 2 dots reduction", "it: x update, 2 dots reduction",
+         "tail barrier"]
+tot = sum(buf[:13])
+print(f"B={B} steps={steps} bicgstab iters/step={it:.2f}  total {tot / steps:.0f} ticks/step")
+for k, n in enumerate(names):
+    print(f"{k:2d} {n:40s} {buf[k] / steps:9.0f} ticks/step  {100.0 * buf[k] / tot:5.1f} %")
