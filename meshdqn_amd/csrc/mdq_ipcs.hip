@@ -2164,80 +2164,136 @@ __global__ __launch_bounds__(TW) void at_velocity_kernel(mdq_ipcs_desc d, int32_
   AT_STAMP(0)
   {
     // ================= step 1: tentative velocity
+    // Row loops: thread `tid` owns rows tid + k * TW.  All reads use the clamped row (rows past n2 re-read row
+    // n2 - 1, value unused) and come first, so that the TROWS loads of a phase are in flight together instead of
+    // one conditional block (and one LDS / L2 round trip) per row; only the writes are predicated.
+    int rc[TROWS];
     float2 idg[TROWS];
+    unsigned flm = 0;  // bit k: row k of this thread carries a Dirichlet value
 #pragma unroll
-    for (int k = 0; k < TROWS; ++k) {
-      const int row = tid + k * TW;
-      idg[k] = make_float2(0.f, 0.f);
-      if (row < n2) {
-        Yl[row] = make_double2(0.0, 0.0);
-        if (!v.bcu_flag[row]) {
-          const double2 t_ = v.idiag1[row];
-          idg[k] = make_float2((float)t_.x, (float)t_.y);
+    for (int k = 0; k < TROWS; ++k) rc[k] = min(tid + k * TW, n2 - 1);
+    {
+      // u_n and p_n staged in LDS (p and r are free until the solve starts): the right-hand-side element loop
+      // gathers 6 + 3 values per triangle from LDS instead of from L2
+      double2 un_[TROWS], dg_[TROWS];
+      unsigned char fl_[TROWS];
+#pragma unroll
+      for (int k = 0; k < TROWS; ++k) {
+        un_[k] = v.u_n[rc[k]];
+        dg_[k] = v.idiag1[rc[k]];
+        fl_[k] = v.bcu_flag[rc[k]];
+      }
+      double* Pn = reinterpret_cast<double*>(Rl);
+      for (int i = tid; i < nv; i += TW) Pn[i] = v.p_n[i];
+#pragma unroll
+      for (int k = 0; k < TROWS; ++k) {
+        const int row = tid + k * TW;
+        idg[k] = (row < n2 && !fl_[k]) ? make_float2((float)dg_[k].x, (float)dg_[k].y) : make_float2(0.f, 0.f);
+        flm |= fl_[k] ? 1u << k : 0u;
+        if (row < n2) {
+          Pl[row] = un_[k];
+          Yl[row] = make_double2(0.0, 0.0);
         }
       }
     }
     __syncthreads();
-    outflow_entries_add<TW>(v, bo_ent, 0.5 * mu, v.u_n, Yd);  // + mu/2 <nabla_grad(u_n) n, v> on the outflow rows
+    outflow_entries_add<TW>(v, bo_ent, 0.5 * mu, Pl, Yd);  // + mu/2 <nabla_grad(u_n) n, v> on the outflow rows
     {
-      const double2* un = v.u_n;
-      const double* pn = v.p_n;
+      const double* Pn = reinterpret_cast<const double*>(Rl);
       atomic_accumulate<false, TW, TPAIR>(v, Yd, tm, [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
         double2 ue[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) ue[i] = un[E.dof[i]];
+        for (int i = 0; i < 6; ++i) ue[i] = Pl[E.dof[i]];
         double pe[3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) pe[i] = pn[E.dof[i]];
+        for (int i = 0; i < 3; ++i) pe[i] = Pn[E.dof[i]];
         elem_rhs1_vol(g, a, mu, d.rho, ue, pe, ye);
       });
+    }
+    // initial guess: polynomial extrapolation in time of the previous tentative velocities (xs still holds
+    // u*_n, hist.. hist4 the four before it), up to quartic as the history fills; u_n while there is none.
+    // dt is far below the flow's time scales, so every order removes about two digits of initial residual
+    // (11 BiCGStab iterations without, 8 linear, 6 quadratic, 3 cubic, 2.6 quartic; beyond that the 1e-10
+    // solver noise of the history, amplified by the coefficients, is the floor).  Dirichlet values hold.
+    // The history loads are issued here, in front of the barrier that ends the element loop.
+    double2 x0[TROWS];
+    {
+      // binomial coefficients of the order in use: x0 = c1 u*_n + c2 u*_{n-1} + ... (alternating signs)
+      const double c1 = nhist >= 5 ? 5.0 : nhist == 4 ? 4.0 : nhist == 3 ? 3.0 : 2.0;
+      const double c2 = nhist >= 5 ? -10.0 : nhist == 4 ? -6.0 : nhist == 3 ? -3.0 : -1.0;
+      const double c3 = nhist >= 5 ? 10.0 : nhist == 4 ? 4.0 : 1.0;
+      const double c4 = nhist >= 5 ? -5.0 : -1.0;
+      double2 us1[TROWS];
+#pragma unroll
+      for (int k = 0; k < TROWS; ++k) us1[k] = xs[rc[k]];
+      if (nhist >= 2) {
+        double2 h[TROWS];
+#pragma unroll
+        for (int k = 0; k < TROWS; ++k) h[k] = hist[rc[k]];
+#pragma unroll
+        for (int k = 0; k < TROWS; ++k) x0[k] = make_double2(c1 * us1[k].x + c2 * h[k].x, c1 * us1[k].y + c2 * h[k].y);
+        if (nhist >= 3) {
+          double2 h2[TROWS];
+#pragma unroll
+          for (int k = 0; k < TROWS; ++k) h2[k] = hist2[rc[k]];
+#pragma unroll
+          for (int k = 0; k < TROWS; ++k) x0[k] = make_double2(x0[k].x + c3 * h2[k].x, x0[k].y + c3 * h2[k].y);
+          if (nhist >= 4) {
+            double2 h3[TROWS];
+#pragma unroll
+            for (int k = 0; k < TROWS; ++k) h3[k] = hist3[rc[k]];
+#pragma unroll
+            for (int k = 0; k < TROWS; ++k) x0[k] = make_double2(x0[k].x + c4 * h3[k].x, x0[k].y + c4 * h3[k].y);
+            if (nhist >= 5) {
+#pragma unroll
+              for (int k = 0; k < TROWS; ++k) {
+                const double2 h4 = hist4[rc[k]];
+                x0[k] = make_double2(x0[k].x + h4.x, x0[k].y + h4.y);
+              }
+            }
+#pragma unroll
+            for (int k = 0; k < TROWS; ++k)
+              if (tid + k * TW < n2) hist4[tid + k * TW] = h3[k];
+          }
+#pragma unroll
+          for (int k = 0; k < TROWS; ++k)
+            if (tid + k * TW < n2) hist3[tid + k * TW] = h2[k];
+        }
+#pragma unroll
+        for (int k = 0; k < TROWS; ++k)
+          if (tid + k * TW < n2) hist2[tid + k * TW] = h[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < TROWS; ++k) x0[k] = v.u_n[rc[k]];
+      }
+#pragma unroll
+      for (int k = 0; k < TROWS; ++k)
+        if (tid + k * TW < n2) hist[tid + k * TW] = us1[k];
+    }
+    double2 lf[TROWS];
+    double gx[TROWS];
+#pragma unroll
+    for (int k = 0; k < TROWS; ++k) {
+      lf[k] = v.lift1[rc[k]];
+      gx[k] = v.bcu_gx[rc[k]];
     }
     __syncthreads();
     AT_STAMP(1)
     double acc[2] = {0.0, 0.0};
     double2 f[TROWS];
 #pragma unroll
+    for (int k = 0; k < TROWS; ++k) f[k] = Yl[rc[k]];
+#pragma unroll
     for (int k = 0; k < TROWS; ++k) {
       const int row = tid + k * TW;
-      f[k] = make_double2(0.0, 0.0);
+      const bool fl = (flm >> k) & 1u;
+      const double2 g = make_double2(gx[k], 0.0);
+      if (fl) x0[k] = g;
       if (row < n2) {
-        f[k] = Yl[row];
         Yl[row] = make_double2(0.0, 0.0);
-        const bool fl = v.bcu_flag[row] != 0;
-        const double2 g = make_double2(v.bcu_gx[row], 0.0);
-        // initial guess: polynomial extrapolation in time of the previous tentative velocities (xs still holds
-        // u*_n, hist.. hist4 the four before it), up to quartic as the history fills; u_n while there is none.
-        // dt is far below the flow's time scales, so every order removes about two digits of initial residual
-        // (11 BiCGStab iterations without, 8 linear, 6 quadratic, 3 cubic, 2.6 quartic; beyond that the 1e-10
-        // solver noise of the history, amplified by the coefficients, is the floor).  Dirichlet values hold.
-        const double2 us1 = xs[row];
-        double2 x0 = v.u_n[row];
-        if (nhist >= 2) {
-          const double2 us2 = hist[row];
-          x0 = make_double2(2.0 * us1.x - us2.x, 2.0 * us1.y - us2.y);
-          if (nhist >= 3) {  // quadratic extrapolation 3 u*_n - 3 u*_{n-1} + u*_{n-2}
-            const double2 us3 = hist2[row];
-            x0 = make_double2(3.0 * (us1.x - us2.x) + us3.x, 3.0 * (us1.y - us2.y) + us3.y);
-            if (nhist >= 4) {  // cubic: 4 u*_n - 6 u*_{n-1} + 4 u*_{n-2} - u*_{n-3}
-              const double2 us4 = hist3[row];
-              x0 = make_double2(4.0 * (us1.x + us3.x) - 6.0 * us2.x - us4.x, 4.0 * (us1.y + us3.y) - 6.0 * us2.y - us4.y);
-              if (nhist >= 5) {  // quartic: 5 u*_n - 10 u*_{n-1} + 10 u*_{n-2} - 5 u*_{n-3} + u*_{n-4}
-                const double2 us5 = hist4[row];
-                x0 = make_double2(5.0 * (us1.x - us4.x) - 10.0 * (us2.x - us3.x) + us5.x,
-                                  5.0 * (us1.y - us4.y) - 10.0 * (us2.y - us3.y) + us5.y);
-              }
-              hist4[row] = us4;
-            }
-            hist3[row] = us3;
-          }
-          hist2[row] = us2;
-        }
-        if (fl) x0 = g;
-        hist[row] = us1;
-        xs[row] = x0;
-        Pl[row] = x0;
-        const double2 l = v.lift1[row];
-        const double2 bi = fl ? g : make_double2((f[k].x - l.x) * f2d(idg[k].x), (f[k].y - l.y) * f2d(idg[k].y));
+        xs[row] = x0[k];
+        Pl[row] = x0[k];
+        const double2 bi = fl ? g : make_double2((f[k].x - lf[k].x) * f2d(idg[k].x), (f[k].y - lf[k].y) * f2d(idg[k].y));
         acc[0] += bi.x * bi.x + bi.y * bi.y;
       }
     }

@@ -48,8 +48,10 @@ def test_first_steps_match_golden(meshes, lib_built):
 
 @pytest.mark.slow
 def test_trajectory_checkpoints_match_golden(meshes, lib_built):
-    """Default solver tolerances, 5000 steps from rest: every 1000th step against the derived vectors (1e-6) and
-    the last one against the reference CSV rows (north-star tolerance 1e-4, CSV print precision 5e-8)."""
+    """Default solver tolerances, 5000 steps from rest: every 1000th step against the derived vectors (5e-6: the LDS
+    atomics make the run reproducible to round-off only, and over thousands of steps at rtol 1e-10 the run-to-run
+    spread of drag / lift is 1e-8 .. 1.6e-6, measured with tools/traj_spread.py) and the last one against the
+    reference CSV rows (north-star tolerance 1e-4, CSV print precision 5e-8)."""
     batch, _, _ = _batch(meshes)
     for k in range(1, 6):
         for _ in range(10):
@@ -57,8 +59,8 @@ def test_trajectory_checkpoints_match_golden(meshes, lib_built):
         torch.cuda.synchronize()
         for b, n in enumerate(NAMES):
             g = FLOW[n]["steps"][str(1000 * k)]
-            assert abs(drag[b, -1].item() - g["drag"]) < 1e-6 * abs(g["drag"]), (n, k)
-            assert abs(lift[b, -1].item() - g["lift"]) < 1e-6 * abs(g["lift"]), (n, k)
+            assert abs(drag[b, -1].item() - g["drag"]) < 5e-6 * abs(g["drag"]), (n, k)
+            assert abs(lift[b, -1].item() - g["lift"]) < 5e-6 * abs(g["lift"]), (n, k)
     for b, n in enumerate(NAMES):
         assert abs(drag[b, -1].item() - KAT[n]["drag"]) < 1e-4 * abs(KAT[n]["drag"])
         assert abs(lift[b, -1].item() - KAT[n]["lift"]) < 1e-4 * abs(KAT[n]["lift"])

@@ -32,6 +32,8 @@ for _ in range(steps):
 torch.cuda.synchronize()
 lib.mdq_at_trace_host(buf, 0)
 it = batch.iters.cpu().numpy()[:, 0].mean() / steps
+_, _, kms = batch.evolve_timed(steps)
+print("HIP-event kernel ms/step (velocity, pressure, correction):", [round(m / steps, 4) for m in kms])
 names = ["prologue (prefetch, outflow rows)", "zero + rhs1 element loop", "outflow + x0 extrapolation/history", "A x0 element loop",
          "r0, 2 reductions, p=0", "it: p update + barrier", "it: A p element loop", "it: v, (rh,v) reduction",
          "it: s update + barrier", "it: A s element loop (+xs loads)", "it: t, 2 dots reduction", "it: x update, 2 dots reduction",
