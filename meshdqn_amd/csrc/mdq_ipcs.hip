@@ -1996,8 +1996,13 @@ __device__ __forceinline__ void atomic_accumulate(const EnvView& v, double* Yd, 
         if (e < v.nt) {
 #pragma unroll
           for (int i = 0; i < 6; ++i) {
+#ifdef MDQ_AT_U64HACK   // timing experiment only (wrong numerics): 64-bit integer atomics instead of fp64 ones
+            atomicAdd(reinterpret_cast<unsigned long long*>(Yd) + 2 * dof[j][i], (unsigned long long)__double_as_longlong(ye[j][i].x) >> 40);
+            atomicAdd(reinterpret_cast<unsigned long long*>(Yd) + 2 * dof[j][i] + 1, (unsigned long long)__double_as_longlong(ye[j][i].y) >> 40);
+#else
             unsafeAtomicAdd(Yd + 2 * dof[j][i], ye[j][i].x);
             unsafeAtomicAdd(Yd + 2 * dof[j][i] + 1, ye[j][i].y);
+#endif
           }
         }
       }
@@ -2016,8 +2021,13 @@ __device__ __forceinline__ void atomic_accumulate(const EnvView& v, double* Yd, 
           op(e, gj, E, ((wj[0] >> 28) & 3) - 1, ye);
 #pragma unroll
           for (int i = 0; i < 6; ++i) {
+#ifdef MDQ_AT_U64HACK
+            atomicAdd(reinterpret_cast<unsigned long long*>(Yd) + 2 * E.dof[i], (unsigned long long)__double_as_longlong(ye[i].x) >> 40);
+            atomicAdd(reinterpret_cast<unsigned long long*>(Yd) + 2 * E.dof[i] + 1, (unsigned long long)__double_as_longlong(ye[i].y) >> 40);
+#else
             unsafeAtomicAdd(Yd + 2 * E.dof[i], ye[i].x);
             unsafeAtomicAdd(Yd + 2 * E.dof[i] + 1, ye[i].y);
+#endif
           }
         }
       }
@@ -2077,8 +2087,16 @@ extern "C" int mdq_at_trace_host(long long* out, int reset) {
   if (reset) { long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(mdq_at_trace_buf), z, sizeof z) != hipSuccess) return -1; }
   return 0;
 }
+__device__ long long mdq_ct_trace_buf[16];
+#define CT_STAMP(k) { const long long tn_ = __builtin_amdgcn_s_memtime(); if (tid == 0 && b == 0) mdq_ct_trace_buf[k] += tn_ - tq_; tq_ = tn_; }
+extern "C" int mdq_ct_trace_host(long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mdq_ct_trace_buf), sizeof(long long) * 16) != hipSuccess) return -1;
+  if (reset) { long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(mdq_ct_trace_buf), z, sizeof z) != hipSuccess) return -1; }
+  return 0;
+}
 #else
 #define AT_STAMP(k)
+#define CT_STAMP(k)
 #endif
 
 // The same outflow-facet term, one ENTRY per thread (18 entries per outflow facet, a few hundred per mesh): every
@@ -2555,58 +2573,92 @@ __global__ __launch_bounds__(WG) void at_correction_kernel(mdq_ipcs_desc d, int 
   int it_m = 0;
   const double2* hist = xs + d.N2;  // u* of the previous step (shifted by the velocity kernel of this step)
   const int nhist = (int)reinterpret_cast<const double*>(xs + 3 * (int64_t)d.N2)[0];
+#ifdef MDQ_AT_TRACE
+  long long tq_ = __builtin_amdgcn_s_memtime();
+#endif
   __syncthreads();
+  CT_STAMP(0)
   {
     // ================= step 3: velocity correction (mass solve, both components)
     double2 x[MF_ROWS], r[MF_ROWS], p[MF_ROWS];
     double ism[MF_ROWS];
     double am[2] = {0.0, 0.0};
+    // Row loops as in at_velocity_kernel: clamped rows, all loads of a phase issued before their first use.
+    int rc[MF_ROWS];
 #pragma unroll
-    for (int k = 0; k < MF_ROWS; ++k) {
-      const int row = tid + k * WG;
-      if (row < n2) Yl[row] = make_double2(0.0, 0.0);
-    }
-    __syncthreads();
+    for (int k = 0; k < MF_ROWS; ++k) rc[k] = min(tid + k * WG, n2 - 1);
+    double* Dp = reinterpret_cast<double*>(Yl + P.N2p);   // [nv] pressure increment, staged for the element loop
     {
-      const double* pold = v.p_n;
-      atomic_accumulate<false>(v, Yd, tm, [&](int, const Geo& g, const ElemIdx& E, int, double2(&ye)[6]) {
-        double2 ue[6];
+      // u* and p_new - p_n staged in LDS: the right-hand-side element loop gathers from LDS instead of from L2
+      double2 us[MF_ROWS];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) ue[i] = xs[E.dof[i]];
-        double dp[3];
+      for (int k = 0; k < MF_ROWS; ++k) us[k] = xs[rc[k]];
+      for (int i = tid; i < nv; i += WG) Dp[i] = pnew[i] - v.p_n[i];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) dp[i] = pnew[E.dof[i]] - pold[E.dof[i]];
-        elem_rhs3(g, d.dt, ue, dp, ye);
-      });
-    }
-    __syncthreads();
-    double2 f3[MF_ROWS];
-#pragma unroll
-    for (int k = 0; k < MF_ROWS; ++k) {
-      const int row = tid + k * WG;
-      ism[k] = 0.0;
-      x[k] = f3[k] = make_double2(0.0, 0.0);
-      if (row < n2) {
-        const bool fl = v.bcu_flag[row] != 0;
-        if (!fl) ism[k] = 1.0 / v.sdiagM[row];
-        f3[k] = Yl[row];
-        Yl[row] = make_double2(0.0, 0.0);
-        // initial guess: u* plus the previous step's correction (u_n - u*_n), i.e. a guess for
-        // u* - dt grad(dp); plain u* while there is no history.  Dirichlet rows keep u* = g.  (Extrapolating a
-        // stored correction history to higher order saves two of the five CG iterations but costs more in
-        // history traffic than they do: measured, not kept.)
-        x[k] = xs[row];
-        if (!fl && nhist >= 2) {
-          const double2 un = v.u_n[row], up = hist[row];
-          x[k] = make_double2(x[k].x + (un.x - up.x), x[k].y + (un.y - up.y));
+      for (int k = 0; k < MF_ROWS; ++k) {
+        const int row = tid + k * WG;
+        if (row < n2) {
+          Pl[row] = us[k];
+          Yl[row] = make_double2(0.0, 0.0);
         }
-        Pl[row] = x[k];      // stage S^-1 (S x0) = x0
-        const double2 l = v.lift3[row];
-        const double2 bi = fl ? x[k] : make_double2((f3[k].x - l.x) * ism[k], (f3[k].y - l.y) * ism[k]);
-        am[0] += bi.x * bi.x + bi.y * bi.y;
       }
     }
     __syncthreads();
+    atomic_accumulate<true>(v, Yd, tm, [&](int, const Geo& g, const ElemIdx& E, int, double2(&ye)[6]) {
+      double2 ue[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) ue[i] = Pl[E.dof[i]];
+      double dp[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) dp[i] = Dp[E.dof[i]];
+      elem_rhs3(g, d.dt, ue, dp, ye);
+    });
+    // own rows of the global vectors of the next phase: issued in front of the barrier that ends the element loop
+    double2 l3[MF_ROWS], dlt[MF_ROWS];
+    unsigned flm = 0;
+#pragma unroll
+    for (int k = 0; k < MF_ROWS; ++k) {
+      l3[k] = v.lift3[rc[k]];
+      ism[k] = v.sdiagM[rc[k]];
+      flm |= v.bcu_flag[rc[k]] ? 1u << k : 0u;
+      dlt[k] = make_double2(0.0, 0.0);
+    }
+    if (nhist >= 2) {
+#pragma unroll
+      for (int k = 0; k < MF_ROWS; ++k) {
+        const double2 un = v.u_n[rc[k]], up = hist[rc[k]];
+        dlt[k] = make_double2(un.x - up.x, un.y - up.y);
+      }
+    }
+    __syncthreads();
+    CT_STAMP(1)
+    double2 f3[MF_ROWS];
+#pragma unroll
+    for (int k = 0; k < MF_ROWS; ++k) {
+      f3[k] = Yl[rc[k]];
+      x[k] = Pl[rc[k]];      // u* (own row)
+    }
+#pragma unroll
+    for (int k = 0; k < MF_ROWS; ++k) {
+      const int row = tid + k * WG;
+      const bool fl = (flm >> k) & 1u;
+      ism[k] = (row < n2 && !fl) ? 1.0 / ism[k] : 0.0;
+      // initial guess: u* plus the previous step's correction (u_n - u*_n), i.e. a guess for
+      // u* - dt grad(dp); plain u* while there is no history.  Dirichlet rows keep u* = g.  (Extrapolating a
+      // stored correction history to higher order saves two of the five CG iterations but costs more in
+      // history traffic than they do: measured, not kept.)
+      if (!fl) x[k] = make_double2(x[k].x + dlt[k].x, x[k].y + dlt[k].y);
+      if (row < n2) {
+        Yl[row] = make_double2(0.0, 0.0);
+        Pl[row] = x[k];      // stage S^-1 (S x0) = x0
+        const double2 bi = fl ? x[k] : make_double2((f3[k].x - l3[k].x) * ism[k], (f3[k].y - l3[k].y) * ism[k]);
+        am[0] += bi.x * bi.x + bi.y * bi.y;
+      } else {
+        x[k] = f3[k] = make_double2(0.0, 0.0);
+      }
+    }
+    __syncthreads();
+    CT_STAMP(2)
     atomic_accumulate<true>(v, Yd, tm, [&](int, const Geo& g, const ElemIdx& E, int, double2(&ye)[6]) {
       double2 xe[6];
 #pragma unroll
@@ -2614,6 +2666,7 @@ __global__ __launch_bounds__(WG) void at_correction_kernel(mdq_ipcs_desc d, int 
       elem_mass(g, xe, ye);
     });
     __syncthreads();
+    CT_STAMP(3)
 #pragma unroll
     for (int k = 0; k < MF_ROWS; ++k) {
       const int row = tid + k * WG;
@@ -2627,6 +2680,7 @@ __global__ __launch_bounds__(WG) void at_correction_kernel(mdq_ipcs_desc d, int 
       }
     }
     block_sum<2>(am, red);
+    CT_STAMP(4)
     {
       const double bb = am[0], tol2 = d.rtol * d.rtol * bb;
       double rr = am[1];
@@ -2643,6 +2697,7 @@ __global__ __launch_bounds__(WG) void at_correction_kernel(mdq_ipcs_desc d, int 
             }
           }
           __syncthreads();
+          CT_STAMP(5)
           atomic_accumulate<true>(v, Yd, tm, [&](int, const Geo& g, const ElemIdx& E, int, double2(&ye)[6]) {
             double2 xe[6];
 #pragma unroll
@@ -2650,6 +2705,7 @@ __global__ __launch_bounds__(WG) void at_correction_kernel(mdq_ipcs_desc d, int 
             elem_mass(g, xe, ye);
           });
           __syncthreads();
+          CT_STAMP(6)
           double a1[1] = {0.0};
           double2 q[MF_ROWS];
 #pragma unroll
@@ -2663,6 +2719,7 @@ __global__ __launch_bounds__(WG) void at_correction_kernel(mdq_ipcs_desc d, int 
             }
           }
           block_sum1<1>(a1, red, rsel);
+          CT_STAMP(7)
           if (!(a1[0] > 0.0)) break;
           const double alpha = rr / a1[0];
           double a2[1] = {0.0};
@@ -2673,6 +2730,7 @@ __global__ __launch_bounds__(WG) void at_correction_kernel(mdq_ipcs_desc d, int 
             a2[0] += r[k].x * r[k].x + r[k].y * r[k].y;
           }
           block_sum1<1>(a2, red, rsel);
+          CT_STAMP(8)
           const double rr_new = a2[0];
           if (!(rr_new > tol2)) break;
           const double beta = rr_new / rr;
@@ -2693,8 +2751,10 @@ __global__ __launch_bounds__(WG) void at_correction_kernel(mdq_ipcs_desc d, int 
     }
     for (int i = tid; i < nv; i += WG) v.p_n[i] = pnew[i];
     __syncthreads();
+    CT_STAMP(9)
     double dr, li;
     forces(v, d.mu, v.u_n, v.p_n, red, dr, li);
+    CT_STAMP(10)
     if (tid == 0) {
       drag[(int64_t)b * nsteps + step] = dr;
       lift[(int64_t)b * nsteps + step] = li;
@@ -2868,7 +2928,7 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
   if (mode == 3) {
     const size_t lds_v = red_bytes + P.vel3_bytes;
     const size_t lds_p = red_bytes + P.prs_vec_bytes + (k1_lds ? P.prs_mat_bytes : 0);
-    const size_t lds_c = red_bytes + 2 * sizeof(double2) * (size_t)P.N2p;
+    const size_t lds_c = red_bytes + 2 * sizeof(double2) * (size_t)P.N2p + sizeof(double) * (size_t)P.NVp;  // p, result, dp
     // once per process (thread-safe: several env groups call this entry point concurrently)
     static const hipError_t attr_err = [] {
       hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&at_velocity_kernel<WG, MF_ROWS, AT_PAIR>),

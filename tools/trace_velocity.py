@@ -26,6 +26,7 @@ torch.cuda.synchronize()
 lib = ctypes.CDLL(_lib.LIB_PATH)
 buf = (ctypes.c_longlong * 16)()
 lib.mdq_at_trace_host(buf, 1)
+lib.mdq_ct_trace_host((ctypes.c_longlong * 16)(), 1)
 batch.iters.zero_()
 for _ in range(steps):
     batch.evolve(1)
@@ -42,3 +43,14 @@ tot = sum(buf[:13])
 print(f"B={B} steps={steps} bicgstab iters/step={it:.2f}  total {tot / steps:.0f} ticks/step")
 for k, n in enumerate(names):
     print(f"{k:2d} {n:40s} {buf[k] / steps:9.0f} ticks/step  {100.0 * buf[k] / tot:5.1f} %")
+
+cb = (ctypes.c_longlong * 16)()
+lib.mdq_ct_trace_host(cb, 0)
+cn = ["prologue", "zero + rhs3 element loop", "f3 / x0 / lift phase", "M x0 element loop", "r, p init + 2 reductions",
+      "it: stage p + barrier", "it: M p element loop", "it: q, (p,q) reduction", "it: x, r update + reduction",
+      "state update + barrier", "forces"]
+tot = sum(cb[:11])
+n_all = steps + steps     # (evolve + evolve_timed passes)
+print(f"correction kernel: total {tot / n_all:.0f} ticks/step")
+for k, n in enumerate(cn):
+    print(f"{k:2d} {n:40s} {cb[k] / n_all:9.0f} ticks/step  {100.0 * cb[k] / tot:5.1f} %")
