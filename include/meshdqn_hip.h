@@ -306,6 +306,15 @@ int mdq_state_features(int32_t B, int32_t N, int32_t S, int32_t NV, int32_t NP, 
                        const double* p, const int32_t* n_closest, const int32_t* nsel, float* x, void* stream);
 
 /*
+ * Env2DAirfoil.reset (Env2DAirfoil.py:102-129: mesh, snapshots and selection back to the initial ones) for a SUBSET
+ * of the batched environments, in one launch: for each of the n (<= 16) device tensors dst[t], laid out [B][row_bytes[t]],
+ * row idx[i] (i < n_idx) is overwritten with the cached initial row src[t].  dst / src / row_bytes are host arrays
+ * of device pointers / sizes (4-byte aligned multiples of 4 bytes); idx is a device pointer.
+ */
+int mdq_restore_rows(int32_t n, void* const* dst, const void* const* src, const int64_t* row_bytes, int32_t n_idx,
+                     const int32_t* idx, void* stream);
+
+/*
  * DOLFIN `Mesh.smooth(n)` (flow_solver.py:65-67 and 236-237 after every remesh) for B meshes on the GPU: Gauss-Seidel
  * over the interior vertices in index order, each moved towards the centroid of its neighbours by at most half the
  * minimum altitude of its cells; boundary vertices (an incident edge with one owner) are fixed.  One workgroup per

@@ -125,6 +125,41 @@ __global__ __launch_bounds__(256) void state_features_kernel(int B, int N, int S
 
 }  // namespace mdq_mesh
 
+namespace mdq_mesh {
+constexpr int RESTORE_MAX = 16;
+struct RestoreArgs {
+  uint32_t* dst[RESTORE_MAX];
+  const uint32_t* src[RESTORE_MAX];
+  int64_t words[RESTORE_MAX];
+};
+// blockIdx.x = position in the index list, blockIdx.y = tensor: one cached row -> row idx of that tensor
+__global__ __launch_bounds__(256) void restore_rows_kernel(RestoreArgs a, const int32_t* idx) {
+  const int t = blockIdx.y;
+  const int64_t n = a.words[t];
+  uint32_t* d = a.dst[t] + (int64_t)idx[blockIdx.x] * n;
+  const uint32_t* s = a.src[t];
+  for (int64_t i = threadIdx.x; i < n; i += 256) d[i] = s[i];
+}
+}  // namespace mdq_mesh
+
+extern "C" int mdq_restore_rows(int32_t n, void* const* dst, const void* const* src, const int64_t* row_bytes,
+                                int32_t n_idx, const int32_t* idx, void* stream) {
+  if (n <= 0 || n > mdq_mesh::RESTORE_MAX || !dst || !src || !row_bytes || n_idx < 0 || (n_idx > 0 && !idx))
+    return mdq_set_error("mdq_restore_rows: bad arguments (at most 16 tensors)");
+  if (n_idx == 0) return 0;
+  mdq_mesh::RestoreArgs a;
+  for (int t = 0; t < n; ++t) {
+    if (!dst[t] || !src[t] || row_bytes[t] <= 0 || (row_bytes[t] & 3) || ((uintptr_t)dst[t] & 3) || ((uintptr_t)src[t] & 3))
+      return mdq_set_error("mdq_restore_rows: rows must be non-empty, 4-byte aligned multiples of 4 bytes");
+    a.dst[t] = static_cast<uint32_t*>(dst[t]);
+    a.src[t] = static_cast<const uint32_t*>(src[t]);
+    a.words[t] = row_bytes[t] / 4;
+  }
+  hipLaunchKernelGGL(mdq_mesh::restore_rows_kernel, dim3(n_idx, n), dim3(256), 0, (hipStream_t)stream, a, idx);
+  if (hipGetLastError() != hipSuccess) return mdq_set_error("restore_rows_kernel launch failed");
+  return 0;
+}
+
 extern "C" int mdq_state_features(int32_t B, int32_t N, int32_t S, int32_t NV, int32_t NP, const double* coords,
                                   const double* u, const double* p, const int32_t* n_closest, const int32_t* nsel,
                                   float* x, void* stream) {

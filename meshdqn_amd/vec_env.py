@@ -98,11 +98,14 @@ class VecEnv2DAirfoil:
         if self.gpu_topology:
             self.dtopo = DeviceTopologyBatch(B, NV, NT, self.NE, self.NAF, N, self.EMAX, self.polygon, self.device,
                                              ipcs=self.flow_steps > 0, nse1_cap=nse1_cap)
+        # the initial mesh on the device: source rows of the in-place resets (mdq_restore_rows)
+        self._x0_dev = torch.from_numpy(np.ascontiguousarray(topo0.coords, dtype=np.float64)).to(self.device)
+        self._cells0_dev = torch.from_numpy(np.ascontiguousarray(topo0.cells, dtype=np.int32)).to(self.device)
+        self._nv0_dev = torch.tensor([NV], dtype=torch.int32, device=self.device)
+        self._nt0_dev = torch.tensor([NT], dtype=torch.int32, device=self.device)
         if self.gpu_remesh:
             self._rstat = torch.zeros(B, dtype=torch.int32, device=self.device)
             self._rstat_host = torch.zeros(B, dtype=torch.int32, pin_memory=True)
-            self._x0_dev = torch.from_numpy(topo0.coords.copy()).to(self.device)
-            self._cells0_dev = torch.from_numpy(np.ascontiguousarray(topo0.cells, dtype=np.int32)).to(self.device)
         if self.flow_steps > 0:
             self._init_flow(base)
         self.coords, self.cells, self.nv, self.nt, self.offset = (self.topo.coords, self.topo.cells, self.topo.nv,
@@ -202,24 +205,32 @@ class VecEnv2DAirfoil:
     def _restore_initial(self, idx):
         """Reset environments `idx` in place from the cached initial-mesh data (no recomputation)."""
         c = self._init_cache
-        for b in idx:
-            self._reset_env(b)
-            for k, a in self.h.items():
-                a[b] = c["h"][k]
-            self.new_drags[b] = c["drags"]
-            self.new_lifts[b] = c["lifts"]
-        ti = torch.as_tensor(np.asarray(idx), device=self.device)
-        self.u[ti] = c["u"]
-        self.p[ti] = c["p"]
-        self._coords_dev[ti] = torch.from_numpy(self.x0).to(self.device)
+        idx = np.asarray(idx)
+        self.coords[idx] = self.x0
+        self.cells[idx] = self.cells0
+        self.nv[idx], self.nt[idx] = self.NV, self.NT
+        self.offset[idx] = 0
+        self.steps[idx] = 0
+        for k, a in self.h.items():
+            a[idx] = c["h"][k]
+        self.new_drags[idx] = c["drags"]
+        self.new_lifts[idx] = c["lifts"]
+        # device side: ONE launch restores the rows of every tensor (a dozen index_put launches otherwise)
+        pairs = [(self.u, c["u"]), (self.p, c["p"]), (self._coords_dev, self._x0_dev)]
         if self.gpu_topology:
-            for k in self._STATE_KEYS:
-                self.dtopo.t[k][ti] = c["dev"][k]
+            pairs += [(self.dtopo.t[k], c["dev"][k]) for k in self._STATE_KEYS]
         if self.gpu_remesh:     # the device holds the meshes: reset them there as well
             dt = self.dtopo
-            dt.cells[ti] = self._cells0_dev
-            dt.nv[ti] = self.NV
-            dt.nt[ti] = self.NT
+            pairs += [(dt.cells, self._cells0_dev), (dt.nv, self._nv0_dev), (dt.nt, self._nt0_dev)]
+        n = len(pairs)
+        dst = (C.c_void_p * n)(*[a.data_ptr() for a, _ in pairs])
+        src = (C.c_void_p * n)(*[b_.data_ptr() for _, b_ in pairs])
+        nbytes = (C.c_int64 * n)(*[a[0].numel() * a.element_size() for a, _ in pairs])
+        for (a, b_), nb in zip(pairs, nbytes):
+            assert a.is_contiguous() and b_.is_contiguous() and b_.numel() * b_.element_size() == nb and a.dtype == b_.dtype
+        ti = torch.from_numpy(np.asarray(idx, dtype=np.int32)).to(self.device)
+        _lib.check(self.lib.mdq_restore_rows(n, dst, src, nbytes, int(ti.numel()), ti.data_ptr(), _lib.stream_ptr()),
+                   "mdq_restore_rows")
 
     def _refresh(self):
         """Topology + selection on the host, snapshot interpolation + forces on the GPU, for all envs."""
@@ -274,9 +285,11 @@ class VecEnv2DAirfoil:
         if self.gpu_topology:
             # one read-back for everything the host logic needs: forces + status + the small integer mirrors
             N = self.N
-            ints = torch.cat([dt.status, dt.t["nsel"], dt.t["nedges"], dt.t["ne"], dt.t["coord_map"].reshape(-1),
-                              dt.t["n_closest"].reshape(-1)]).cpu().numpy()
-            fl64 = torch.cat([drag.reshape(-1), lift.reshape(-1)]).cpu().numpy()
+            packed = torch.cat([drag.reshape(-1).view(torch.int32), lift.reshape(-1).view(torch.int32), dt.status,
+                                dt.t["nsel"], dt.t["nedges"], dt.t["ne"], dt.t["coord_map"].reshape(-1),
+                                dt.t["n_closest"].reshape(-1)]).cpu().numpy()
+            fl64 = packed[:4 * B * self.S].view(np.float64)
+            ints = packed[4 * B * self.S:]
             self.new_drags = fl64[:B * self.S].reshape(B, self.S).copy()
             self.new_lifts = fl64[B * self.S:].reshape(B, self.S).copy()
             st = ints[:B]
@@ -308,11 +321,17 @@ class VecEnv2DAirfoil:
         ne = h["nedges"].astype(np.int64)
         edge_ptr = np.zeros(B + 1, np.int32)
         edge_ptr[1:] = np.cumsum(ne)
-        live = np.arange(self.EMAX)[None, :] < ne[:, None]          # (B,EMAX) valid edge slots, row-major = env order
         if self.gpu_topology:
-            live_d = torch.from_numpy(live).to(dev)
-            esrc_d, edst_d = self.dtopo.t["edge_src"][live_d], self.dtopo.t["edge_dst"][live_d]
+            # flat positions of the valid edge slots of the padded (B,EMAX) device arrays, env by env: a gather with a
+            # host-built index (the counts are on the host already) instead of a boolean mask, which costs a
+            # device-to-host synchronisation per indexed tensor
+            ne32 = h["nedges"].astype(np.int32)
+            idx = np.arange(int(edge_ptr[-1]), dtype=np.int32) + np.repeat(np.arange(B, dtype=np.int32) * self.EMAX - edge_ptr[:-1], ne32)
+            idx_d = torch.from_numpy(idx).to(dev)
+            esrc_d = self.dtopo.t["edge_src"].reshape(-1).index_select(0, idx_d)
+            edst_d = self.dtopo.t["edge_dst"].reshape(-1).index_select(0, idx_d)
         else:
+            live = np.arange(self.EMAX)[None, :] < ne[:, None]      # (B,EMAX) valid edge slots, row-major = env order
             esrc_d, edst_d = torch.from_numpy(h["edge_src"][live]).to(dev), torch.from_numpy(h["edge_dst"][live]).to(dev)
         return dict(x=x, esrc=esrc_d, edst=edst_d,
                     edge_ptr=torch.from_numpy(edge_ptr).to(dev),
