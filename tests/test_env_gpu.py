@@ -420,3 +420,31 @@ def test_device_resident_env_soak(lib_built):
         assert (st["nedges"] % 3 == 0).all() and (st["nsel"] == 180).all() and (info["code"] == 0).all()
         finished += int(done.sum())
     assert finished > 0
+
+
+def test_restore_rows_overwrites_exactly_the_listed_rows(lib_built):
+    """mdq_restore_rows through the C ABI: mixed dtypes / row sizes, duplicate-free index list, bad arguments."""
+    import ctypes as C
+    from meshdqn_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    tens = [torch.rand((9, 7, 3), dtype=torch.float64, generator=g).cuda(), torch.randint(0, 99, (9, 5), dtype=torch.int32, generator=g).cuda(),
+            torch.rand((9, 1), dtype=torch.float32, generator=g).cuda()]
+    srcs = [torch.rand((7, 3), dtype=torch.float64, generator=g).cuda(), torch.randint(0, 99, (5,), dtype=torch.int32, generator=g).cuda(),
+            torch.rand((1,), dtype=torch.float32, generator=g).cuda()]
+    before = [t.clone() for t in tens]
+    idx = torch.tensor([6, 0, 3], dtype=torch.int32, device="cuda")
+    n = len(tens)
+    dst = (C.c_void_p * n)(*[t.data_ptr() for t in tens])
+    src = (C.c_void_p * n)(*[t.data_ptr() for t in srcs])
+    nb = (C.c_int64 * n)(*[t[0].numel() * t.element_size() for t in tens])
+    _lib.check(lib.mdq_restore_rows(n, dst, src, nb, 3, idx.data_ptr(), _lib.stream_ptr()), "mdq_restore_rows")
+    torch.cuda.synchronize()
+    for t, s, b in zip(tens, srcs, before):
+        for r in range(9):
+            assert torch.equal(t[r], s if r in (6, 0, 3) else b[r])
+    assert lib.mdq_restore_rows(n, dst, src, nb, 0, None, _lib.stream_ptr()) == 0          # empty list: nothing to do
+    assert lib.mdq_restore_rows(17, dst, src, nb, 3, idx.data_ptr(), _lib.stream_ptr()) != 0
+    bad = (C.c_int64 * n)(6, 20, 4)                                                            # 6 bytes: not a multiple of 4
+    assert lib.mdq_restore_rows(n, dst, src, bad, 3, idx.data_ptr(), _lib.stream_ptr()) != 0
+    assert b"4-byte" in lib.mdq_last_error()
