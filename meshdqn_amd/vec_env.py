@@ -106,6 +106,9 @@ class VecEnv2DAirfoil:
         if self.gpu_remesh:
             self._rstat = torch.zeros(B, dtype=torch.int32, device=self.device)
             self._rstat_host = torch.zeros(B, dtype=torch.int32, pin_memory=True)
+            self._mirror_stream = torch.cuda.Stream(device=self.device)
+            self._mirror_ev = torch.cuda.Event()
+            self._mirror_done = torch.cuda.Event()
         if self.flow_steps > 0:
             self._init_flow(base)
         self.coords, self.cells, self.nv, self.nt, self.offset = (self.topo.coords, self.topo.cells, self.topo.nv,
@@ -279,19 +282,29 @@ class VecEnv2DAirfoil:
         _lib.check(self.lib.mdq_probe_forces(C.byref(md), self.S, out_u.data_ptr(), out_p.data_ptr(), drag.data_ptr(),
                                              lift.data_ptr(), _lib.stream_ptr()), "mdq_probe_forces")
         self.u, self.p, self._coords_dev = out_u, out_p, t_coords
+        fd = fl = None
         if self.flow_steps > 0:
             fd, fl = self._flow(keep, out_u, out_p)
-            self.flow_drag, self.flow_lift = fd.cpu().numpy(), fl.cpu().numpy()
+            if not self.gpu_topology:
+                self.flow_drag, self.flow_lift = fd.cpu().numpy(), fl.cpu().numpy()
         if self.gpu_topology:
             # one read-back for everything the host logic needs: forces + status + the small integer mirrors
             N = self.N
-            packed = torch.cat([drag.reshape(-1).view(torch.int32), lift.reshape(-1).view(torch.int32), dt.status,
-                                dt.t["nsel"], dt.t["nedges"], dt.t["ne"], dt.t["coord_map"].reshape(-1),
-                                dt.t["n_closest"].reshape(-1)]).cpu().numpy()
-            fl64 = packed[:4 * B * self.S].view(np.float64)
-            ints = packed[4 * B * self.S:]
+            parts = [drag.reshape(-1).view(torch.int32), lift.reshape(-1).view(torch.int32)]
+            nflow = 0
+            if fd is not None:      # forces of the re-solved flow ride along (no extra synchronisation)
+                parts += [fd.reshape(-1).view(torch.int32), fl.reshape(-1).view(torch.int32)]
+                nflow = fd.numel()
+            nf = 2 * B * self.S + 2 * nflow
+            packed = torch.cat(parts + [dt.status, dt.t["nsel"], dt.t["nedges"], dt.t["ne"], dt.t["coord_map"].reshape(-1),
+                                        dt.t["n_closest"].reshape(-1)]).cpu().numpy()
+            fl64 = packed[:2 * nf].view(np.float64)
+            ints = packed[2 * nf:]
+            if fd is not None:
+                self.flow_drag = fl64[2 * B * self.S:2 * B * self.S + nflow].reshape(tuple(fd.shape)).copy()
+                self.flow_lift = fl64[2 * B * self.S + nflow:].reshape(tuple(fd.shape)).copy()
             self.new_drags = fl64[:B * self.S].reshape(B, self.S).copy()
-            self.new_lifts = fl64[B * self.S:].reshape(B, self.S).copy()
+            self.new_lifts = fl64[B * self.S:2 * B * self.S].reshape(B, self.S).copy()
             st = ints[:B]
             if (st != 0).any():
                 raise _lib.MeshDQNHipError(f"topology kernel failed: env {np.flatnonzero(st)} status {st[st != 0]}")
@@ -357,12 +370,18 @@ class VecEnv2DAirfoil:
             remesh_batch_gpu(dt.coords, dt.cells, dt.nv, dt.nt, rem_d, self._rstat)
             its = torch.where((rem_d >= 0) & (self._rstat == 0), 50, 0).to(torch.int32)
             smooth_batch_gpu(dt.coords, dt.cells, dt.nv, dt.nt, its)
-            pin = self.topo.pinned                      # host mirrors (asynchronous; valid after this step's sync)
-            pin["coords"].copy_(dt.coords, non_blocking=True)
-            pin["cells"].copy_(dt.cells, non_blocking=True)
-            pin["nv"].copy_(dt.nv, non_blocking=True)
-            pin["nt"].copy_(dt.nt, non_blocking=True)
-            self._rstat_host.copy_(self._rstat, non_blocking=True)
+            # host mirrors of the meshes: device-to-host copies on a side stream, off the critical path of the step
+            # (4 MB per 128 meshes; complete before the host logic below reads nv / status)
+            pin = self.topo.pinned
+            self._mirror_ev.record(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(self._mirror_stream):
+                self._mirror_stream.wait_event(self._mirror_ev)
+                pin["coords"].copy_(dt.coords, non_blocking=True)
+                pin["cells"].copy_(dt.cells, non_blocking=True)
+                pin["nv"].copy_(dt.nv, non_blocking=True)
+                pin["nt"].copy_(dt.nt, non_blocking=True)
+                self._rstat_host.copy_(self._rstat, non_blocking=True)
+                self._mirror_done.record(self._mirror_stream)
             status = None
         elif self.gpu_smoothing:
             # host: cavity re-triangulation + Delaunay restoration only; GPU: smooth(50) of the changed meshes
@@ -385,7 +404,8 @@ class VecEnv2DAirfoil:
             status = remesh_batch(self.coords, self.cells, self.nv, self.nt, rem, 50, self.nthreads)
         self._refresh()
         if status is None:
-            status = self._rstat_host.numpy()           # (the reads in _refresh have synchronised the stream)
+            self._mirror_done.synchronize()
+            status = self._rstat_host.numpy()
         code[status != 0] = 2
         code[h["nsel"] < N] = 2  # out of vertices
         rewards = np.zeros(B)
