@@ -390,14 +390,14 @@ class IpcsBatch:
         """Global-memory bytes of ONE launch of the dominant kernel (at_velocity_kernel, mode 3) for the whole
         batch, no cache credit: per operator application 64 B of triangle metadata (6 packed words + 5 geometry
         doubles), 2 + 2*it applications (rhs1, A x0, two per BiCGStab iteration); x read + written per iteration
-        (32 B per dof); per launch u_n, p_n gathered by the rhs1 element loop (6x16 + 3x8 B per triangle), u_n,
-        u* history, idiag, lift, Dirichlet data and the final u* (9 x 16 B + 2 B per dof)."""
+        (32 B per dof); per launch and dof: u_n (staged in LDS once), u* and its four predecessors read, five history
+        slots written (the shift + the initial guess), idiag, lift, Dirichlet value and flag = 217 B; p_n once."""
         tot = 0.0
         for b, p in enumerate(self.per):
             nv, nt, ne = p["nv"], p["nt"], p["ne"]
             n2 = nv + ne
             iu = iters_per_step[b][0]
-            tot += (2 + 2 * iu) * 64.0 * nt + 32.0 * n2 * iu + 120.0 * nt + 146.0 * n2
+            tot += (2 + 2 * iu) * 64.0 * nt + 32.0 * n2 * iu + 217.0 * n2 + 8.0 * nv
         return tot
 
     def velocity_kernel_flops(self, iters_per_step) -> float:
