@@ -193,6 +193,8 @@ class DQNTrainer:
         self.scheds = [torch.optim.lr_scheduler.MultiStepLR(o, milestones=[500000, 1000000, 1500000], gamma=0.1)
                        for o in self.opts]
         self.memory = ReplayMemory(replay_capacity)
+        self.replay_capacity = replay_capacity
+        self.device_memory = None   # DeviceReplay, created by train_loop_vec when the vector env provides padded edges
         self.criterion = torch.nn.HuberLoss()
         self.num_grads = 0
         self.select = True
@@ -257,13 +259,16 @@ class DQNTrainer:
         Returns the loss value, or None when the minibatch is not eligible (ragged node counts) or capture is
         unsupported (the eager path runs)."""
         dev = self.ctx.device
-        batch = Transition(*zip(*transitions))
         sel = self.select
         k = 0 if sel else 1
         net = (self.policy_net_1, self.policy_net_2)[k]
-        lazy = all(isinstance(s_, StateRef) for s_ in batch.state) and \
-            all(s_ is None or isinstance(s_, StateRef) for s_ in batch.next_state)
-        if lazy:   # replay filled by train_loop_vec: minibatch arrays without per-graph Data objects
+        devb = transitions if isinstance(transitions, DeviceBatch) else None
+        batch = None if devb is not None else Transition(*zip(*transitions))
+        lazy = devb is not None or (all(isinstance(s_, StateRef) for s_ in batch.state) and
+                                    all(s_ is None or isinstance(s_, StateRef) for s_ in batch.next_state))
+        if devb is not None:
+            pass
+        elif lazy:   # replay filled by train_loop_vec: minibatch arrays without per-graph Data objects
             s_refs = list(batch.state)
             n_refs = [(s_ if s_ is not None else batch.state[i]) for i, s_ in enumerate(batch.next_state)]
         else:
@@ -273,13 +278,16 @@ class DQNTrainer:
             if any(d.x.shape[0] != n0 for d in states) or any(d.x.shape[0] != n0 for d in nexts):
                 return None
         try:
-            nonfinal = torch.tensor([0.0 if s_ is None else 1.0 for s_ in batch.next_state], device=dev)
-            reward = torch.cat([r.reshape(1) for r in batch.reward]).to(dev).float()
-            action = torch.cat([a.reshape(1, 1) for a in batch.action]).to(dev)
+            if devb is not None:
+                nonfinal, reward, action = devb.nonfinal, devb.reward, devb.action
+            else:
+                nonfinal = torch.tensor([0.0 if s_ is None else 1.0 for s_ in batch.next_state], device=dev)
+                reward = torch.cat([r.reshape(1) for r in batch.reward]).to(dev).float()
+                action = torch.cat([a.reshape(1, 1) for a in batch.action]).to(dev)
             if lazy:
                 from .gcn_fused import FusedGcn
-                ga = gather_state_refs(s_refs, self.e_max, dev)
-                gb = gather_state_refs(n_refs, self.e_max, dev)
+                ga = devb.ga if devb is not None else gather_state_refs(s_refs, self.e_max, dev)
+                gb = devb.gb if devb is not None else gather_state_refs(n_refs, self.e_max, dev)
                 other = self.policy_net_2 if sel else self.policy_net_1
                 if not hasattr(other, "_fused"):
                     other._fused = FusedGcn(other)
@@ -353,9 +361,10 @@ class DQNTrainer:
         """One optimiser step (airfoil_dqn.py:315-340 + :184-200 + :286-310): local loss/backward, ONE flat
         all-reduce of the gradient over all ranks, identical Adam step on every rank."""
         if transitions is None:
-            if self.memory.size() < self.batch_size:
+            mem = self.device_memory if self.device_memory is not None else self.memory
+            if mem.size() < self.batch_size:
                 return None
-            transitions = self.memory.sample(self.batch_size)
+            transitions = mem.sample(self.batch_size)
         if (self.num_grads % self.target_update) == 0:
             self.select = not self.select
         k = 0 if self.select else 1
@@ -364,6 +373,8 @@ class DQNTrainer:
             done = self._optimize_graphed(transitions)
             if done is not None:
                 return done
+        if isinstance(transitions, DeviceBatch):      # eager path: per-graph objects
+            transitions = transitions.to_transitions()
         net.zero_grad(set_to_none=True)
         loss = self._loss(transitions)
         if not loss.requires_grad:
@@ -540,6 +551,112 @@ def gather_state_refs(refs: List["StateRef"], e_max: int, device):
                 node_ptr=torch.arange(B + 1, dtype=torch.int32, device=device) * n, src=src, dst=dst, mask=mask)
 
 
+class DeviceBatch:
+    """A sampled minibatch of a `DeviceReplay`: everything `_optimize_graphed` needs, already on the device."""
+
+    def __init__(self, replay, s_slots, n_slots, actions, rewards):
+        dev = replay.device
+        self.replay, self.s_slots, self.n_slots = replay, s_slots, n_slots
+        self.n = len(s_slots)
+        self.nonfinal = torch.from_numpy((n_slots >= 0).astype(np.float32)).to(dev)
+        self.reward = torch.from_numpy(rewards.astype(np.float32)).to(dev)
+        self.action = torch.from_numpy(actions.astype(np.int64)).reshape(-1, 1).to(dev)
+        self.ga = replay.gather(s_slots)
+        self.gb = replay.gather(np.where(n_slots >= 0, n_slots, s_slots))   # terminal: own state as a masked placeholder
+
+    def __len__(self):
+        return self.n
+
+    def to_transitions(self) -> List[Transition]:
+        """The same minibatch as `Transition`s of `Data` graphs (eager fallback, tests)."""
+        rp = self.replay
+        act, rew = self.action.cpu(), self.reward.cpu()
+        return [Transition(rp.data(int(self.s_slots[i])), act[i].reshape(1, 1),
+                           rp.data(int(self.n_slots[i])) if self.n_slots[i] >= 0 else None, rew[i].reshape(1))
+                for i in range(self.n)]
+
+
+class DeviceReplay:
+    """Replay ring of the batched loop, resident on the GPU (the reference's `ReplayMemory`, airfoil_dqn.py:48-67, for
+    B environments stepped together).  Every batched state is stored ONCE - node features (B,N,F) f32 and the padded
+    edge lists (B,e_max) i32 of `VecEnv2DAirfoil.get_state()` copied into ring tensors, three copy kernels per
+    step - and a transition is four host numbers (state slot, next-state slot or -1, action, reward).  Sampling a
+    minibatch is a few gathers instead of a Python loop over per-graph objects.  Holds capacity/B + 2 batched states
+    so that the next state of the oldest live transition is still there."""
+
+    def __init__(self, capacity: int, B: int, N: int, F: int, e_max: int, device):
+        self.capacity, self.B, self.N, self.F, self.e_max, self.device = int(capacity), B, N, F, e_max, device
+        self.K = (self.capacity + B - 1) // B + 2
+        S = self.K * B
+        self.RX = torch.zeros((S, N, F), dtype=torch.float32, device=device)
+        self.RS = torch.zeros((S, e_max), dtype=torch.int32, device=device)
+        self.RD = torch.zeros((S, e_max), dtype=torch.int32, device=device)
+        self.cnt = np.zeros(S, np.int64)
+        self.t_s = np.zeros(self.capacity, np.int64)
+        self.t_n = np.zeros(self.capacity, np.int64)
+        self.t_a = np.zeros(self.capacity, np.int64)
+        self.t_r = np.zeros(self.capacity, np.float32)
+        self.position, self.count, self.step = 0, 0, 0
+        self._cols = torch.arange(e_max, device=device)[None, :]
+
+    @staticmethod
+    def eligible(st: dict, e_max: int) -> bool:
+        return "edge_src_pad" in st and st["edge_src_pad"].shape[1] == e_max
+
+    def store(self, st: dict) -> int:
+        """Copy a batched state into the ring; returns the slot of its environment 0."""
+        base = (self.step % self.K) * self.B
+        self.step += 1
+        self.RX[base:base + self.B].copy_(st["x"])
+        self.RS[base:base + self.B].copy_(st["edge_src_pad"])
+        self.RD[base:base + self.B].copy_(st["edge_dst_pad"])
+        self.cnt[base:base + self.B] = st["nedges"]
+        return base
+
+    def push(self, base_prev: int, base_next: int, actions, rewards, dones):
+        """B transitions (state slot base_prev + b -> base_next + b, -1 if terminal)."""
+        B = self.B
+        pos = (self.position + np.arange(B)) % self.capacity
+        self.t_s[pos] = base_prev + np.arange(B)
+        self.t_n[pos] = np.where(np.asarray(dones, bool), -1, base_next + np.arange(B))
+        self.t_a[pos] = np.asarray(actions, np.int64)
+        self.t_r[pos] = np.asarray(rewards, np.float32)
+        self.position = int((self.position + B) % self.capacity)
+        self.count = min(self.count + B, self.capacity)
+
+    def size(self):
+        return self.count
+
+    __len__ = size
+
+    def sample(self, batch_size: int) -> DeviceBatch:
+        idx = np.asarray(random.sample(range(self.count), batch_size), np.int64)
+        return DeviceBatch(self, self.t_s[idx], self.t_n[idx], self.t_a[idx], self.t_r[idx])
+
+    def gather(self, slots) -> dict:
+        """Minibatch arrays of the states in `slots` (same keys as `gather_state_refs`)."""
+        dev, e_max, n = self.device, self.e_max, len(slots)
+        idx_d = torch.from_numpy(np.asarray(slots, np.int64)).to(dev)
+        cnt = self.cnt[slots]
+        x = self.RX.index_select(0, idx_d)
+        sp, dp = self.RS.index_select(0, idx_d), self.RD.index_select(0, idx_d)
+        live = self._cols < torch.from_numpy(cnt).to(dev)[:, None]
+        src = torch.where(live, sp, 0).long()          # (slots past the count hold stale entries of earlier steps)
+        dst = torch.where(live, dp, 0).long()
+        edge_ptr = np.zeros(n + 1, np.int32)
+        np.cumsum(cnt, out=edge_ptr[1:])
+        flat = np.arange(int(edge_ptr[-1]), dtype=np.int64) + np.repeat(np.arange(n, dtype=np.int64) * e_max - edge_ptr[:-1], cnt)
+        flat_d = torch.from_numpy(flat).to(dev)
+        return dict(x=x, n=self.N, esrc=sp.reshape(-1).index_select(0, flat_d), edst=dp.reshape(-1).index_select(0, flat_d),
+                    edge_ptr=torch.from_numpy(edge_ptr).to(dev),
+                    node_ptr=torch.arange(n + 1, dtype=torch.int32, device=dev) * self.N, src=src, dst=dst,
+                    mask=live.float())
+
+    def data(self, slot: int) -> Data:
+        c = int(self.cnt[slot])
+        return Data(x=self.RX[slot].clone(), edge_index=torch.stack([self.RS[slot, :c].long(), self.RD[slot, :c].long()]))
+
+
 def state_to_data_list(st: dict, n_nodes: int) -> List[Data]:
     """Split the batched state dict of `VecEnv2DAirfoil.get_state()` into per-environment `Data` objects
     (x (N,F) f32, edge_index (2,E) i64 with node ids local to the graph)."""
@@ -553,7 +670,8 @@ def state_refs(st: dict) -> List[StateRef]:
 
 
 def train_loop_vec(trainer: DQNTrainer, venv, num_steps: int, optim_per_step: int = 1, eps_decay=10000, eps_start=1.0,
-                   eps_end=0.01, share_replay=False, e_max=1536, log: Optional["TrainingLog"] = None):
+                   eps_end=0.01, share_replay=False, e_max=1536, log: Optional["TrainingLog"] = None,
+                   device_replay: bool = True):
     """Batched counterpart of `train_loop_per_worker` for one rank: B environments of a `VecEnv2DAirfoil` stepped
     together (configs[3] of BASELINE.json: 128 envs per GPU, 1024 over 8 ranks).  Per batched step: fused Q-forward
     of policy_net_1 for all B states, epsilon-greedy per environment (per-env step counters, like the reference's
@@ -566,6 +684,17 @@ def train_loop_vec(trainer: DQNTrainer, venv, num_steps: int, optim_per_step: in
     fused = FusedGcn(trainer.policy_net_1)
     steps_done = np.zeros(B, np.int64)
     st = venv.get_state()
+    # GPU-resident replay (states stored once per batched step, minibatches gathered on the device) whenever the
+    # environment hands out its padded edge lists; the per-transition list of lazy references otherwise (and when the
+    # ranks exchange transitions)
+    rep_dev = None
+    if device_replay and not (share_replay and ctx.world > 1) and trainer.graphs and trainer.dense and \
+            DeviceReplay.eligible(st, trainer.e_max):
+        rep_dev = trainer.device_memory
+        if rep_dev is None or (rep_dev.B, rep_dev.N, rep_dev.F) != (B, N, st["x"].shape[2]):
+            rep_dev = trainer.device_memory = DeviceReplay(trainer.replay_capacity, B, N, st["x"].shape[2], trainer.e_max,
+                                                           ctx.device)
+        base_prev = rep_dev.store(st)
     rewards, dones_hist = [], []
     ep_r = [[] for _ in range(B)]
     ep_a = [[] for _ in range(B)]
@@ -577,15 +706,22 @@ def train_loop_vec(trainer: DQNTrainer, venv, num_steps: int, optim_per_step: in
         steps_done += 1
         explore = np.random.random(B) <= eps
         actions = np.where(explore, np.random.randint(0, trainer.n_actions + 1, B), greedy)
-        prev = state_refs(st)
-        st, rew, done, _ = venv.step(actions)
-        nxt = state_refs(st)
-        trs = [Transition(prev[b], torch.tensor([[int(actions[b])]], dtype=torch.long), None if done[b] else nxt[b],
-                          torch.tensor([float(rew[b])], dtype=torch.float32)) for b in range(B)]
-        if share_replay and ctx.world > 1:
-            trs = allgather_transitions(ctx, trs, N, st["x"].shape[2], e_max)
-        for t in trs:
-            trainer.memory.push(*t)
+        if rep_dev is not None:
+            st, rew, done, _ = venv.step(actions)
+            base_next = rep_dev.store(st)
+            rep_dev.push(base_prev, base_next, actions, rew, done)
+            base_prev = base_next
+        else:
+            prev = state_refs(st)
+            st, rew, done, _ = venv.step(actions)
+            nxt = state_refs(st)
+            a_t = torch.from_numpy(np.asarray(actions, np.int64)).reshape(B, 1, 1).unbind(0)
+            r_t = torch.from_numpy(np.asarray(rew, np.float32)).reshape(B, 1).unbind(0)
+            trs = [Transition(prev[b], a_t[b], None if done[b] else nxt[b], r_t[b]) for b in range(B)]
+            if share_replay and ctx.world > 1:
+                trs = allgather_transitions(ctx, trs, N, st["x"].shape[2], e_max)
+            for t in trs:
+                trainer.memory.push(*t)
         for _k in range(optim_per_step):
             loss = trainer.optimize()
             if log is not None and loss is not None:

@@ -346,7 +346,10 @@ class VecEnv2DAirfoil:
         else:
             live = np.arange(self.EMAX)[None, :] < ne[:, None]      # (B,EMAX) valid edge slots, row-major = env order
             esrc_d, edst_d = torch.from_numpy(h["edge_src"][live]).to(dev), torch.from_numpy(h["edge_dst"][live]).to(dev)
-        return dict(x=x, esrc=esrc_d, edst=edst_d,
+        pad = {}
+        if self.gpu_topology:   # the padded (B,EMAX) edge lists as well (views of the engine's output, valid until
+            pad = dict(edge_src_pad=self.dtopo.t["edge_src"], edge_dst_pad=self.dtopo.t["edge_dst"])   # the next step)
+        return dict(x=x, esrc=esrc_d, edst=edst_d, **pad,
                     edge_ptr=torch.from_numpy(edge_ptr).to(dev),
                     node_ptr=torch.arange(B + 1, dtype=torch.int32, device=dev) * N,
                     n_closest=h["n_closest"].copy(), coord_map=h["coord_map"].copy(), nedges=h["nedges"].copy(),

@@ -25,15 +25,19 @@ def test_batched_train_loop_runs_and_learns_something(lib_built):
     w0 = [p.detach().clone() for p in trainer.policy_net_1.parameters()]
     out = train_loop_vec(trainer, venv, num_steps=5, eps_decay=2)   # fast epsilon decay: greedy actions are exercised
     assert out["rewards"].shape == (5, 6) and out["dones"].shape == (5, 6)
-    assert trainer.memory.size() == 30
+    assert trainer.device_memory is not None and trainer.device_memory.size() == 30 and trainer.memory.size() == 0
     assert len(out["losses"]) == 4 and np.isfinite(out["losses"]).all()       # 6 < 8 transitions after the first step
     changed = [not torch.equal(a, b) for a, b in zip(w0, trainer.policy_net_1.parameters()) if b.grad is not None]
     changed2 = any(p.grad is not None for p in trainer.policy_net_2.parameters())
     assert any(changed) or changed2
     # transitions hold per-environment graphs with local node ids
-    tr = trainer.memory.sample(4)
+    tr = trainer.device_memory.sample(4).to_transitions()
     for t in tr:
         assert t.state.x.shape == (180, 17) and int(t.state.edge_index.max()) < 180
+    # the per-transition replay of lazy references (used when ranks exchange transitions) still works
+    trainer2 = DQNTrainer(n_actions=180, num_inputs=17, ctx=ctx, batch_size=8, lr=1e-3)
+    out2 = train_loop_vec(trainer2, venv, num_steps=3, eps_decay=2, device_replay=False)
+    assert trainer2.device_memory is None and trainer2.memory.size() == 18 and len(out2["losses"]) == 2
 
 
 def test_graphed_optimiser_step_equals_eager_step(lib_built):
@@ -99,3 +103,60 @@ def test_lazy_minibatch_path_equals_data_path(lib_built):
         assert abs(res[0][0] - res[1][0]) < 1e-6
         for a, b_ in zip(res[0][1], res[1][1]):
             assert torch.allclose(a, b_, rtol=1e-3, atol=1e-7)
+
+
+def test_device_replay_minibatch_equals_lazy_reference_path(lib_built):
+    """A minibatch gathered from the GPU-resident replay ring gives the loss and gradient of the same transitions
+    held as lazy state references, for both halves of the double-DQN cycle; ring wrap-around keeps live states."""
+    from meshdqn_amd.trainer import DeviceBatch, DeviceReplay, DistContext, DQNTrainer, StateRef, Transition
+    rng = np.random.default_rng(21)
+    B, N, F, EM = 8, 180, 17, 1536
+
+    def state():
+        cnt = rng.integers(150, 500, size=B)
+        ep = np.zeros(B + 1, np.int64); ep[1:] = np.cumsum(cnt)
+        sp = rng.integers(0, N, size=(B, EM)).astype(np.int32)        # (entries past the count are garbage on purpose)
+        dp = rng.integers(0, N, size=(B, EM)).astype(np.int32)
+        live = np.arange(EM)[None, :] < cnt[:, None]
+        return dict(x=torch.from_numpy(rng.standard_normal((B, N, F))).float().cuda(),
+                    edge_src_pad=torch.from_numpy(sp).cuda(), edge_dst_pad=torch.from_numpy(dp).cuda(), nedges=cnt.astype(np.int32),
+                    esrc=torch.from_numpy(sp[live]).cuda(), edst=torch.from_numpy(dp[live]).cuda(), ep=ep)
+
+    rep = DeviceReplay(capacity=3 * B, B=B, N=N, F=F, e_max=EM, device=torch.device("cuda"))
+    assert rep.K == 5
+    states = [state() for _ in range(8)]
+    bases = [rep.store(states[0])]
+    acts, rews, dones = [], [], []
+    for t in range(7):                      # 7 batched steps through a ring of 3 steps of transitions / 5 of states
+        bases.append(rep.store(states[t + 1]))
+        acts.append(rng.integers(0, 181, size=B)); rews.append(rng.standard_normal(B).astype(np.float32))
+        dones.append(rng.random(B) < 0.25)
+        rep.push(bases[t], bases[t + 1], acts[-1], rews[-1], dones[-1])
+    assert rep.size() == 3 * B
+    # the live transitions are those of steps 4, 5, 6: rebuild them as lazy references
+    lazy = {}
+    for t in (4, 5, 6):
+        s0, s1 = states[t], states[t + 1]
+        for b in range(B):
+            r0 = StateRef(s0, b, int(s0["ep"][b]), int(s0["ep"][b + 1]))
+            r1 = None if dones[t][b] else StateRef(s1, b, int(s1["ep"][b]), int(s1["ep"][b + 1]))
+            lazy[(bases[t] + b)] = Transition(r0, torch.tensor([[int(acts[t][b])]]), r1, torch.tensor([float(rews[t][b])]))
+    idx = rng.permutation(3 * B)[:8]
+    devb = DeviceBatch(rep, rep.t_s[idx], rep.t_n[idx], rep.t_a[idx], rep.t_r[idx])
+    ref = [lazy[int(sl)] for sl in rep.t_s[idx]]
+    for sel in (True, False):
+        res = []
+        for trs in (ref, devb):
+            tr = DQNTrainer(n_actions=180, num_inputs=17, ctx=DistContext(), batch_size=8, lr=0.0)
+            tr.num_grads, tr.select = 1, sel
+            loss = tr.optimize(trs)
+            assert (0 if sel else 1) in tr._graphs, tr._graph_error
+            net = tr.policy_net_1 if sel else tr.policy_net_2
+            res.append((loss, [p.grad.clone() for p in net.parameters()]))
+        assert abs(res[0][0] - res[1][0]) < 1e-6
+        for a, b_ in zip(res[0][1], res[1][1]):
+            assert torch.allclose(a, b_, rtol=1e-3, atol=1e-7)
+    # eager fallback objects
+    for t_, r_ in zip(devb.to_transitions(), ref):
+        assert torch.equal(t_.state.x.cpu(), r_.state.x.cpu()) and torch.equal(t_.state.edge_index.cpu(), r_.state.edge_index.cpu())
+        assert (t_.next_state is None) == (r_.next_state is None)

@@ -19,7 +19,7 @@ torch.cuda.synchronize(); t0 = time.time(); n = 10
 train_loop_vec(trainer, venv, n)
 torch.cuda.synchronize(); dt = time.time() - t0
 print(f"B={B}: {dt/n*1e3:.1f} ms per batched training step (env step + {B} replay pushes + 1 optimise) -> {B*n/dt:.0f} env-steps/s")
-trs = trainer.memory.sample(32)
+trs = (trainer.device_memory or trainer.memory).sample(32)
 torch.cuda.synchronize(); t0 = time.time()
 for _ in range(10): trainer.optimize(trs)
 torch.cuda.synchronize(); print(f"optimise alone: {(time.time()-t0)/10*1e3:.1f} ms")
