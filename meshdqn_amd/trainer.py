@@ -342,15 +342,24 @@ class DQNTrainer:
                                ("rew", reward), ("nf", nonfinal)):
                     g[k_].copy_(v_)
             g["graph"].replay()
-            flat = torch.cat([(gr if gr is not None else torch.zeros_like(p)).reshape(-1)
-                              for gr, p in zip(g["grads"], net.parameters())])
+            flat = None
+            if self.ctx.world > 1:
+                flat = torch.cat([(gr if gr is not None else torch.zeros_like(p)).reshape(-1)
+                                  for gr, p in zip(g["grads"], net.parameters())])
         except RuntimeError as exc:   # capture not supported for some op on this build: stay on the eager path
             self.graphs = False
             self._graphs = {}
             self._graph_error = repr(exc)
             return None
-        self.ctx.allreduce_mean_(flat)
-        net.set_flat_gradients(flat)
+        if flat is not None:
+            self.ctx.allreduce_mean_(flat)
+            net.set_flat_gradients(flat)
+        else:   # one rank: the graph has written the gradients where the optimiser reads them
+            if "zeros" not in g:   # parameters outside the graph (conv3 / conv6, unused pools) keep a zero gradient, as
+                g["zeros"] = [None if gr is not None else torch.zeros_like(p)        # with the flat round trip
+                              for p, gr in zip(net.parameters(), g["grads"])]
+            for p, gr, z in zip(net.parameters(), g["grads"], g["zeros"]):
+                p.grad = gr if gr is not None else z
         self.opts[k].step()
         self.scheds[k].step()
         self.num_grads += 1
