@@ -139,27 +139,28 @@ gmp, gap = global_max_pool, global_mean_pool
 # forward + backward is a fixed sequence of kernels that a HIP graph can replay (trainer.DQNTrainer).  Numerically
 # the same sums as the ragged path above, in a different order.
 
-def _dense_sage(conv: SAGEConv, x, src, dst, m):
-    C = x.shape[-1]
-    xs = torch.gather(x, 1, src.unsqueeze(-1).expand(-1, -1, C)) * m.unsqueeze(-1)
-    agg = torch.zeros_like(x).scatter_add(1, dst.unsqueeze(-1).expand(-1, -1, C), xs)
-    cnt = torch.zeros(x.shape[:2], dtype=x.dtype, device=x.device).scatter_add(1, dst, m)
-    agg = agg / cnt.clamp(min=1).unsqueeze(-1)
+def _dense_adjacency(n: int, src, dst, m):
+    """A[b, i, j] = number of edges j -> i of graph b (duplicates counted, padded edges have weight 0): with the graphs
+    of a minibatch padded to n nodes, every aggregation of the conv / pool stack is a small batched matrix product -
+    no gathers or atomic scatters over the e_max edge slots at any level, in the forward or the backward pass."""
+    B = src.shape[0]
+    A = torch.zeros((B, n * n), dtype=m.dtype, device=m.device).scatter_add(1, dst * n + src, m)
+    return A.view(B, n, n)
+
+
+def _dense_sage(conv: SAGEConv, x, A):
+    cnt = A.sum(dim=-1, keepdim=True)
+    agg = torch.bmm(A, x) / cnt.clamp(min=1)
     return conv.lin_l(agg) + conv.lin_r(x)
 
 
-def _dense_gcn(conv: GCNConv, x, src, dst, m):
-    deg = torch.ones(x.shape[:2], dtype=x.dtype, device=x.device).scatter_add(1, dst, m)
-    dis = deg.pow(-0.5)
-    h = conv.lin(x)
-    C = h.shape[-1]
-    w = torch.gather(dis, 1, src) * torch.gather(dis, 1, dst) * m
-    hs = torch.gather(h, 1, src.unsqueeze(-1).expand(-1, -1, C)) * w.unsqueeze(-1)
-    out = (h * (dis * dis).unsqueeze(-1)).scatter_add(1, dst.unsqueeze(-1).expand(-1, -1, C), hs)
-    return out + conv.bias
+def _dense_gcn(conv: GCNConv, x, A):
+    dis = (1.0 + A.sum(dim=-1, keepdim=True)).pow(-0.5)          # degree over targets incl. the self-loop
+    h = conv.lin(x) * dis
+    return (torch.bmm(A, h) + h) * dis + conv.bias
 
 
-def _dense_topk(pool: TopKPooling, x, src, dst, m):
+def _dense_topk(pool: TopKPooling, x, A):
     B, n, C = x.shape
     k = int(math.ceil(pool.ratio * n))
     score = torch.tanh((x * pool.weight).sum(dim=-1) / pool.weight.norm(p=2, dim=-1))
@@ -167,11 +168,9 @@ def _dense_topk(pool: TopKPooling, x, src, dst, m):
     order = torch.argsort(score, dim=1, descending=True, stable=True)[:, :k]
     sc = torch.gather(score, 1, order)
     xo = torch.gather(x, 1, order.unsqueeze(-1).expand(-1, -1, C)) * sc.unsqueeze(-1)
-    new_id = torch.full((B, n), -1, dtype=torch.long, device=x.device).scatter(
-        1, order, torch.arange(k, device=x.device).unsqueeze(0).expand(B, -1))
-    s2, d2 = torch.gather(new_id, 1, src), torch.gather(new_id, 1, dst)
-    m2 = m * ((s2 >= 0) & (d2 >= 0)).to(m.dtype)
-    return xo, s2.clamp(min=0), d2.clamp(min=0), m2
+    # induced subgraph on the kept nodes, relabelled in score order
+    A2 = torch.gather(torch.gather(A, 1, order.unsqueeze(-1).expand(-1, -1, n)), 2, order.unsqueeze(1).expand(-1, k, -1))
+    return xo, A2
 
 
 def _dense_readout(x):
@@ -286,17 +285,18 @@ class NodeRemovalNet(nn.Module, _WeightAccessors):
     def forward_dense(self, x, src, dst, mask, embedding=False):
         """Autograd path with static shapes: x (B,n,F) f32, src/dst (B,E) int64 local node ids, mask (B,E) 0/1 float
         (padded edges have mask 0 and any valid node id).  Same function as `forward` on the equivalent Batch."""
-        x = F.relu(_dense_sage(self.conv1, x.float(), src, dst, mask))
-        x, src, dst, mask = _dense_topk(self.pool1, x, src, dst, mask)
+        A = _dense_adjacency(x.shape[1], src, dst, mask)
+        x = F.relu(_dense_sage(self.conv1, x.float(), A))
+        x, A = _dense_topk(self.pool1, x, A)
         x1 = _dense_readout(x)
-        x = F.relu(_dense_sage(self.conv2, x, src, dst, mask))
-        x, src, dst, mask = _dense_topk(self.pool2, x, src, dst, mask)
+        x = F.relu(_dense_sage(self.conv2, x, A))
+        x, A = _dense_topk(self.pool2, x, A)
         x2 = _dense_readout(x)
-        x = F.relu(_dense_gcn(self.conv4, x, src, dst, mask))
-        x, src, dst, mask = _dense_topk(self.pool4, x, src, dst, mask)
+        x = F.relu(_dense_gcn(self.conv4, x, A))
+        x, A = _dense_topk(self.pool4, x, A)
         x4 = _dense_readout(x)
-        x = F.relu(_dense_gcn(self.conv5, x, src, dst, mask))
-        x, src, dst, mask = _dense_topk(self.pool5, x, src, dst, mask)
+        x = F.relu(_dense_gcn(self.conv5, x, A))
+        x, A = _dense_topk(self.pool5, x, A)
         x5 = _dense_readout(x)
         x = x1 + x2 + x4 + x5
         if embedding:
