@@ -268,9 +268,10 @@ def measure_train(args, dev, dist, world):
         el = tt.item()
     return dict(value=world * args.envs * args.train_steps / el, unit="env steps/s",
                 ms_per_batched_step=el / args.train_steps * 1e3, batched_steps=args.train_steps,
-                what="S1 rollout + replay push + one double-DQN optimiser step per batched step (minibatch 32 per rank, "
-                     "PyTorch autograd for the trained network, fused HIP forward for the target network, one flat "
-                     "gradient all-reduce over the ranks)")
+                what="S1 rollout + GPU-resident replay ring (every batched state stored once) + one double-DQN optimiser "
+                     "step per batched step (minibatch 32 per rank gathered on the device, fused HIP forward for the "
+                     "no-grad network, dense adjacency autograd path of the trained network replayed as a HIP graph, "
+                     "one flat gradient all-reduce over the ranks)")
 
 
 def main():
