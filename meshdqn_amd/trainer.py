@@ -680,7 +680,7 @@ def state_refs(st: dict) -> List[StateRef]:
 
 def train_loop_vec(trainer: DQNTrainer, venv, num_steps: int, optim_per_step: int = 1, eps_decay=10000, eps_start=1.0,
                    eps_end=0.01, share_replay=False, e_max=1536, log: Optional["TrainingLog"] = None,
-                   device_replay: bool = True):
+                   device_replay: bool = True, overlap_optimise: bool = True):
     """Batched counterpart of `train_loop_per_worker` for one rank: B environments of a `VecEnv2DAirfoil` stepped
     together (configs[3] of BASELINE.json: 128 envs per GPU, 1024 over 8 ranks).  Per batched step: fused Q-forward
     of policy_net_1 for all B states, epsilon-greedy per environment (per-env step counters, like the reference's
@@ -704,6 +704,14 @@ def train_loop_vec(trainer: DQNTrainer, venv, num_steps: int, optim_per_step: in
             rep_dev = trainer.device_memory = DeviceReplay(trainer.replay_capacity, B, N, st["x"].shape[2], trainer.e_max,
                                                            ctx.device)
         base_prev = rep_dev.store(st)
+    # the optimiser step runs on a second stream between the two halves of the environment step: its launches and
+    # host work overlap the (latency-bound, half-chip) smoothing kernel; it samples the replay as of the previous step
+    overlap = overlap_optimise and rep_dev is not None and hasattr(venv, "step_begin") and ctx.device.type == "cuda"
+    if overlap:
+        if getattr(trainer, "_opt_stream", None) is None:
+            trainer._opt_stream = torch.cuda.Stream(device=ctx.device)
+        opt_stream, ev_store = trainer._opt_stream, torch.cuda.Event()
+        ev_store.record(torch.cuda.current_stream(ctx.device))
     rewards, dones_hist = [], []
     ep_r = [[] for _ in range(B)]
     ep_a = [[] for _ in range(B)]
@@ -715,7 +723,21 @@ def train_loop_vec(trainer: DQNTrainer, venv, num_steps: int, optim_per_step: in
         steps_done += 1
         explore = np.random.random(B) <= eps
         actions = np.where(explore, np.random.randint(0, trainer.n_actions + 1, B), greedy)
-        if rep_dev is not None:
+        if overlap:
+            venv.step_begin(actions)
+            opt_stream.wait_event(ev_store)            # (the ring rows written by the last store)
+            with torch.cuda.stream(opt_stream):
+                for _k in range(optim_per_step):
+                    loss = trainer.optimize()
+                    if log is not None and loss is not None:
+                        log.add_loss(loss)
+            st, rew, done, _ = venv.step_end()
+            torch.cuda.current_stream(ctx.device).wait_stream(opt_stream)   # the next Q-forward reads the new weights
+            base_next = rep_dev.store(st)
+            ev_store.record(torch.cuda.current_stream(ctx.device))
+            rep_dev.push(base_prev, base_next, actions, rew, done)
+            base_prev = base_next
+        elif rep_dev is not None:
             st, rew, done, _ = venv.step(actions)
             base_next = rep_dev.store(st)
             rep_dev.push(base_prev, base_next, actions, rew, done)
@@ -731,7 +753,7 @@ def train_loop_vec(trainer: DQNTrainer, venv, num_steps: int, optim_per_step: in
                 trs = allgather_transitions(ctx, trs, N, st["x"].shape[2], e_max)
             for t in trs:
                 trainer.memory.push(*t)
-        for _k in range(optim_per_step):
+        for _k in range(0 if overlap else optim_per_step):
             loss = trainer.optimize()
             if log is not None and loss is not None:
                 log.add_loss(loss)

@@ -98,6 +98,7 @@ class VecEnv2DAirfoil:
         if self.gpu_topology:
             self.dtopo = DeviceTopologyBatch(B, NV, NT, self.NE, self.NAF, N, self.EMAX, self.polygon, self.device,
                                              ipcs=self.flow_steps > 0, nse1_cap=nse1_cap)
+        self._packed_host, self._packed_ev, self._pending, self._step_pending = None, torch.cuda.Event(), None, None
         # the initial mesh on the device: source rows of the in-place resets (mdq_restore_rows)
         self._x0_dev = torch.from_numpy(np.ascontiguousarray(topo0.coords, dtype=np.float64)).to(self.device)
         self._cells0_dev = torch.from_numpy(np.ascontiguousarray(topo0.cells, dtype=np.int32)).to(self.device)
@@ -236,7 +237,12 @@ class VecEnv2DAirfoil:
                    "mdq_restore_rows")
 
     def _refresh(self):
-        """Topology + selection on the host, snapshot interpolation + forces on the GPU, for all envs."""
+        """Topology + selection, snapshot interpolation + forces on the GPU, for all envs."""
+        self._refresh_launch()
+        self._refresh_collect()
+
+    def _refresh_launch(self):
+        """Everything of `_refresh` that is enqueued on the stream, up to the asynchronous read-back."""
         dev, h = self.device, self.h
         B, NV, NT, NP = self.B, self.NV, self.NT, self.NP
         if self.gpu_topology:
@@ -297,12 +303,27 @@ class VecEnv2DAirfoil:
                 nflow = fd.numel()
             nf = 2 * B * self.S + 2 * nflow
             packed = torch.cat(parts + [dt.status, dt.t["nsel"], dt.t["nedges"], dt.t["ne"], dt.t["coord_map"].reshape(-1),
-                                        dt.t["n_closest"].reshape(-1)]).cpu().numpy()
+                                        dt.t["n_closest"].reshape(-1)])
+            if self._packed_host is None or self._packed_host.numel() != packed.numel():
+                self._packed_host = torch.empty(packed.numel(), dtype=torch.int32, pin_memory=True)
+            self._packed_host.copy_(packed, non_blocking=True)      # page-locked: the copy is queued behind the kernels
+            self._packed_ev.record(torch.cuda.current_stream(dev))
+            self._pending = (nf, nflow, None if fd is None else tuple(fd.shape))
+        else:
+            self._pending = (drag, lift)
+
+    def _refresh_collect(self):
+        """Wait for the read-back of `_refresh_launch` and update the host mirrors."""
+        h, B, N = self.h, self.B, self.N
+        if self.gpu_topology:
+            nf, nflow, fshape = self._pending
+            self._packed_ev.synchronize()
+            packed = self._packed_host.numpy()
             fl64 = packed[:2 * nf].view(np.float64)
             ints = packed[2 * nf:]
-            if fd is not None:
-                self.flow_drag = fl64[2 * B * self.S:2 * B * self.S + nflow].reshape(tuple(fd.shape)).copy()
-                self.flow_lift = fl64[2 * B * self.S + nflow:].reshape(tuple(fd.shape)).copy()
+            if fshape is not None:
+                self.flow_drag = fl64[2 * B * self.S:2 * B * self.S + nflow].reshape(fshape).copy()
+                self.flow_lift = fl64[2 * B * self.S + nflow:].reshape(fshape).copy()
             self.new_drags = fl64[:B * self.S].reshape(B, self.S).copy()
             self.new_lifts = fl64[B * self.S:2 * B * self.S].reshape(B, self.S).copy()
             st = ints[:B]
@@ -314,8 +335,10 @@ class VecEnv2DAirfoil:
             h["coord_map"][...] = ints[4 * B:4 * B + B * N].reshape(B, N)
             h["n_closest"][...] = ints[4 * B + B * N:].reshape(B, N)
         else:
+            drag, lift = self._pending
             self.new_drags = drag.cpu().numpy().copy()
             self.new_lifts = lift.cpu().numpy().copy()
+        self._pending = None
 
     # ------------------------------------------------------------------
     def get_state(self):
@@ -358,6 +381,13 @@ class VecEnv2DAirfoil:
     # ------------------------------------------------------------------
     def step(self, actions):
         """actions (B,) ints in [0, N]; returns (state, rewards (B,), dones (B,), infos)."""
+        self.step_begin(actions)
+        return self.step_end()
+
+    def step_begin(self, actions):
+        """First half of `step`: everything that is only ENQUEUED (vertex removal, smoothing, topology, interpolation,
+        forces, the asynchronous read-back).  The caller may overlap other work (e.g. an optimiser step on another
+        stream) with the GPU before `step_end` waits for the results."""
         B, N, h = self.B, self.N, self.h
         actions = np.asarray(actions).astype(np.int64)
         code = np.zeros(B, np.int32)  # 0 ok, 2 broken (Env2DAirfoil.py:342-364)
@@ -405,7 +435,15 @@ class VecEnv2DAirfoil:
                 self.topo.pinned["coords"].copy_(tc)    # D2H into the page-locked array (synchronises this stream)
         else:
             status = remesh_batch(self.coords, self.cells, self.nv, self.nt, rem, 50, self.nthreads)
-        self._refresh()
+        self._refresh_launch()
+        self._step_pending = (code, status)
+
+    def step_end(self):
+        """Second half of `step`: wait for the results, rewards / terminal flags / in-place resets, next state."""
+        B, N, h = self.B, self.N, self.h
+        code, status = self._step_pending
+        self._step_pending = None
+        self._refresh_collect()
         if status is None:
             self._mirror_done.synchronize()
             status = self._rstat_host.numpy()

@@ -26,7 +26,8 @@ def test_batched_train_loop_runs_and_learns_something(lib_built):
     out = train_loop_vec(trainer, venv, num_steps=5, eps_decay=2)   # fast epsilon decay: greedy actions are exercised
     assert out["rewards"].shape == (5, 6) and out["dones"].shape == (5, 6)
     assert trainer.device_memory is not None and trainer.device_memory.size() == 30 and trainer.memory.size() == 0
-    assert len(out["losses"]) == 4 and np.isfinite(out["losses"]).all()       # 6 < 8 transitions after the first step
+    # the optimiser step overlaps the environment step and samples the replay as of the previous step: 0, 6 < 8
+    assert len(out["losses"]) == 3 and np.isfinite(out["losses"]).all()
     changed = [not torch.equal(a, b) for a, b in zip(w0, trainer.policy_net_1.parameters()) if b.grad is not None]
     changed2 = any(p.grad is not None for p in trainer.policy_net_2.parameters())
     assert any(changed) or changed2
@@ -38,6 +39,10 @@ def test_batched_train_loop_runs_and_learns_something(lib_built):
     trainer2 = DQNTrainer(n_actions=180, num_inputs=17, ctx=ctx, batch_size=8, lr=1e-3)
     out2 = train_loop_vec(trainer2, venv, num_steps=3, eps_decay=2, device_replay=False)
     assert trainer2.device_memory is None and trainer2.memory.size() == 18 and len(out2["losses"]) == 2
+    # device replay without the overlap: push first, then optimise
+    trainer3 = DQNTrainer(n_actions=180, num_inputs=17, ctx=ctx, batch_size=8, lr=1e-3)
+    out3 = train_loop_vec(trainer3, venv, num_steps=3, eps_decay=2, overlap_optimise=False)
+    assert trainer3.device_memory.size() == 18 and len(out3["losses"]) == 2
 
 
 def test_graphed_optimiser_step_equals_eager_step(lib_built):
