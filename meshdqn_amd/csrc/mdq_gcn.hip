@@ -24,6 +24,20 @@ constexpr int WGT = MDQ_GCN_WG;  // threads of the embedding kernel (one workgro
 constexpr int WGH = 256;         // threads of the MFMA head kernel (4 waves, one 32x32 block each per pass)
 constexpr int NACC = 24;  // accumulators per thread of the "feature-outer" small-graph convolution
 
+#ifdef MDQ_GCN_TRACE
+// debug build only: s_memtime deltas of thread 0 of graph 0 at the phase boundaries, [level][phase]
+__device__ long long mdq_gcn_trace_buf[8 * 10];
+__device__ int mdq_gcn_trace_level;
+#define GT_STAMP(k) { const long long tn_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) mdq_gcn_trace_buf[mdq_gcn_trace_level * 10 + (k)] += tn_ - tq_; tq_ = tn_; }
+extern "C" int mdq_gcn_trace_host(long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mdq_gcn_trace_buf), sizeof(long long) * 80) != hipSuccess) return -1;
+  if (reset) { long long z[80] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(mdq_gcn_trace_buf), z, sizeof z) != hipSuccess) return -1; }
+  return 0;
+}
+#else
+#define GT_STAMP(k)
+#endif
+
 struct Lds {
   float* x;      // level input features  [n][fin]      (row stride = fin)
   float* h;      // conv output           [n][C+1]
@@ -38,51 +52,80 @@ struct Lds {
   int* misc;     // [8]
 };
 
-// CSR by target (sources kept in edge order => deterministic sums)
+// CSR by target (sources kept in edge order => deterministic sums).  T = 1..8 threads per target node, each scanning
+// a contiguous part of the edge list four entries per LDS read (esrc / edst / adj are 16-byte aligned; the padding of
+// the last quad never matches).  Counting the (node, part) pairs in lane order, a workgroup-wide inclusive scan
+// (wave shuffles + one exchange of the wave totals) gives every pair the position of its first entry directly.
 __device__ inline void build_csr(const Lds& L, int n, int E) {
-  const int tid = threadIdx.x;
-  for (int i = tid; i < n; i += WGT) {
-    int c = 0;
-    for (int e = 0; e < E; ++e) c += (L.edst[e] == i);
-    L.adj_ptr[i + 1] = c;
-  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int E4 = (E + 3) >> 2;
+  const int4* d4 = reinterpret_cast<const int4*>(L.edst);
+  const int4* s4 = reinterpret_cast<const int4*>(L.esrc);
+  if (tid < 4 && E + tid < 4 * E4) L.edst[E + tid] = -1;   // the tail of the last quad matches no node
+  int* wtot = L.misc + 8;   // [WGT / 64] wave totals
+  int sh = 0;               // log2(T)
+  while (sh < 3 && (n << (sh + 1)) <= WGT) ++sh;
+  const int T = 1 << sh, QP = (E4 + T - 1) >> sh;          // quads per part
   __syncthreads();
-  // inclusive scan of the counts (adj_ptr[1..n]): Hillis-Steele inside chunks of WGT nodes, carry between chunks
-  if (tid == 0) L.adj_ptr[0] = 0;
-  for (int base = 0; base < n; base += WGT) {
-    const int i = base + tid;
-    for (int off = 1; off < WGT; off <<= 1) {
-      int add = 0;
-      if (i < n && tid >= off) add = L.adj_ptr[i + 1 - off];
-      __syncthreads();
-      if (i < n) L.adj_ptr[i + 1] += add;
-      __syncthreads();
+  int carry = 0;
+  for (int base = 0; base < (n << sh); base += WGT) {       // (n * T <= WGT whenever n <= WGT: one pass)
+    const int el = base + tid, i = el >> sh, t = el & (T - 1);
+    const int qa = min(t * QP, E4), qb = min(qa + QP, E4);
+    int c = 0;
+    if (i < n)
+      for (int q = qa; q < qb; ++q) {
+        const int4 d = d4[q];
+        c += (d.x == i) + (d.y == i) + (d.z == i) + (d.w == i);
+      }
+    int v = c;   // inclusive scan inside the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int u = __shfl_up(v, off, 64);
+      if (lane >= off) v += u;
     }
-    if (base > 0) {
-      const int carry = L.adj_ptr[base];
-      __syncthreads();
-      if (i < n) L.adj_ptr[i + 1] += carry;
-      __syncthreads();
+    if (lane == 63) wtot[wave] = v;
+    __syncthreads();
+    int pre = carry, all = carry;
+    for (int w = 0; w < WGT / 64; ++w) {
+      const int wt = wtot[w];
+      if (w < wave) pre += wt;
+      all += wt;
     }
+    int p = pre + v - c;   // first entry of this (node, part)
+    if (i < n) {
+      if (t == 0) L.adj_ptr[i] = p;
+      for (int q = qa; q < qb; ++q) {
+        const int4 d = d4[q];
+        if ((d.x == i) | (d.y == i) | (d.z == i) | (d.w == i)) {
+          const int4 sv = s4[q];
+          if (d.x == i) L.adj[p++] = sv.x;
+          if (d.y == i) L.adj[p++] = sv.y;
+          if (d.z == i) L.adj[p++] = sv.z;
+          if (d.w == i) L.adj[p++] = sv.w;
+        }
+      }
+    }
+    carry = all;
+    __syncthreads();   // (wtot is rewritten by the next pass)
   }
-  for (int i = tid; i < n; i += WGT) {
-    int p = L.adj_ptr[i];
-    for (int e = 0; e < E; ++e)
-      if (L.edst[e] == i) L.adj[p++] = L.esrc[e];
-  }
+  if (tid == 0) L.adj_ptr[n] = carry;
   __syncthreads();
 }
 
 // out[i][c] = relu( b[c] + sum_f wl[f][c] * A[i][f] (+ wr[f][c] * X[i][f]) ) ;  A, X in LDS with stride fin
 // Form (a): per node, weights of channel c in registers (fin <= 32).
-template <bool ROOT>
-__device__ inline void conv_dense_small_fin(const Lds& L, int n, int fin, int C, const float* __restrict__ wl,
+// FIN > 0: the feature count is a compile-time constant (the reference's two models: 17 and 2) - the generic
+// version spends most of its instructions on the 32 `f < fin` tests per node (measured: 52 of the kernel's 280 us).
+template <bool ROOT, int FIN>
+__device__ inline void conv_dense_small_fin(const Lds& L, int n, int fin_rt, int C, const float* __restrict__ wl,
                                             const float* __restrict__ b, const float* __restrict__ wr,
                                             const float* A, const float* X) {
   const int tid = threadIdx.x, c = tid % C, g = tid / C, G = WGT / C;
-  float wlr[32], wrr[32];
+  constexpr int NF = FIN > 0 ? FIN : 32;
+  const int fin = FIN > 0 ? FIN : fin_rt;
+  float wlr[NF], wrr[NF];
 #pragma unroll
-  for (int f = 0; f < 32; ++f) {
+  for (int f = 0; f < NF; ++f) {
     wlr[f] = f < fin ? wl[f * C + c] : 0.f;
     wrr[f] = (ROOT && f < fin) ? wr[f * C + c] : 0.f;
   }
@@ -90,8 +133,8 @@ __device__ inline void conv_dense_small_fin(const Lds& L, int n, int fin, int C,
   for (int i = g; i < n; i += G) {
     float acc = 0.f;
 #pragma unroll
-    for (int f = 0; f < 32; ++f) {
-      if (f < fin) {
+    for (int f = 0; f < NF; ++f) {
+      if (FIN > 0 || f < fin) {
         acc = fmaf(wlr[f], A[i * fin + f], acc);
         if (ROOT) acc = fmaf(wrr[f], X[i * fin + f], acc);
       }
@@ -99,15 +142,29 @@ __device__ inline void conv_dense_small_fin(const Lds& L, int n, int fin, int C,
     L.h[i * (C + 1) + c] = acc + bc;
   }
 }
+template <bool ROOT>
+__device__ inline void conv_dense_small_fin_any(const Lds& L, int n, int fin, int C, const float* __restrict__ wl,
+                                                const float* __restrict__ b, const float* __restrict__ wr,
+                                                const float* A, const float* X) {
+  if (fin == 17)
+    conv_dense_small_fin<ROOT, 17>(L, n, fin, C, wl, b, wr, A, X);
+  else if (fin == 2)
+    conv_dense_small_fin<ROOT, 2>(L, n, fin, C, wl, b, wr, A, X);
+  else
+    conv_dense_small_fin<ROOT, 0>(L, n, fin, C, wl, b, wr, A, X);
+}
 
 // Form (b): feature-outer loop, up to NACC nodes per thread (n <= NACC * WGT/C), any fin.
 // `wbuf` (LDS, fin*C floats, 16-byte aligned) or nullptr: when given, each weight matrix is first staged into LDS with
 // one coalesced cooperative copy (all its loads in flight at once) - streaming the rows from global memory one
 // dependent round trip per feature was 60 % of the whole kernel.
-template <bool ROOT>
+// NA = accumulators (nodes) per thread: the unrolled node loop costs its instructions whether a node exists or not,
+// so the pooled levels (18, 2, 1 nodes) run instances with 8 / 1 accumulators instead of the 24 of the widest case.
+template <bool ROOT, int NA>
 __device__ inline void conv_dense_small_n(const Lds& L, int n, int fin, int C, const float* __restrict__ wl,
                                           const float* __restrict__ b, const float* __restrict__ wr, const float* A,
                                           const float* X, float* wbuf) {
+  constexpr int NACC = NA;   // (shadows the namespace constant inside this instance)
   const int tid = threadIdx.x, c = tid % C, g = tid / C, G = WGT / C;
   float acc[NACC];
 #pragma unroll
@@ -140,6 +197,8 @@ __device__ inline void conv_dense_small_n(const Lds& L, int n, int fin, int C, c
     }
   } else {
     constexpr int FB = 16;
+    // (issuing the next block's weight loads before the current block is used was measured slower: 18 -> 25 k cycles
+    // on the one-node levels)
     for (int f0 = 0; f0 < fin; f0 += FB) {
       float w1[FB], w2[FB];
 #pragma unroll
@@ -150,16 +209,14 @@ __device__ inline void conv_dense_small_n(const Lds& L, int n, int fin, int C, c
       }
 #pragma unroll
       for (int q = 0; q < FB; ++q) {
-        const int f = f0 + q;
-        if (f < fin) {
+        const int f = min(f0 + q, fin - 1);   // (features past fin: weight 0, any valid address)
 #pragma unroll
-          for (int r = 0; r < NACC; ++r) {
-            const int i = g + r * G;
-            if (i < n) {
-              acc[r] = fmaf(w1[q], A[i * fin + f], acc[r]);
-              if (ROOT) acc[r] = fmaf(w2[q], X[i * fin + f], acc[r]);
-            }
-          }
+        for (int r = 0; r < NACC; ++r) {
+          // rows past n re-read row n - 1 (never stored): unconditional reads, so that the LDS loads of a block
+          // are in flight together instead of one conditional block - one LDS round trip - per (feature, row)
+          const int i = min(g + r * G, n - 1);
+          acc[r] = fmaf(w1[q], A[i * fin + f], acc[r]);
+          if (ROOT) acc[r] = fmaf(w2[q], X[i * fin + f], acc[r]);
         }
       }
     }
@@ -189,7 +246,11 @@ struct Level {
 __device__ inline void run_level(const Lds& L, const Level& lv, int C, double ratio, int& n, int& E, float& rmax,
                                  float& rmean, int NMAX) {
   const int tid = threadIdx.x, fin = lv.fin;
+#ifdef MDQ_GCN_TRACE
+  long long tq_ = __builtin_amdgcn_s_memtime();
+#endif
   build_csr(L, n, E);
+  GT_STAMP(0)
   // ---- aggregation into L.agg
   if (lv.type == 0) {  // SAGE: mean over incoming edges (duplicates count), 0 for isolated nodes
     for (int idx = tid; idx < n * fin; idx += WGT) {
@@ -214,37 +275,47 @@ __device__ inline void run_level(const Lds& L, const Level& lv, int C, double ra
     }
   }
   __syncthreads();
+  GT_STAMP(1)
   // ---- dense part
   const int G = WGT / C;
   if (fin <= 32) {
     if (lv.type == 0)
-      conv_dense_small_fin<true>(L, n, fin, C, lv.wl, lv.b, lv.wr, L.agg, L.x);
+      conv_dense_small_fin_any<true>(L, n, fin, C, lv.wl, lv.b, lv.wr, L.agg, L.x);
     else
-      conv_dense_small_fin<false>(L, n, fin, C, lv.wl, lv.b, nullptr, L.agg, L.x);
+      conv_dense_small_fin_any<false>(L, n, fin, C, lv.wl, lv.b, nullptr, L.agg, L.x);
   } else {
     // (n <= NACC*G is guaranteed by the host-side check)
     // (staging each weight matrix in LDS behind the rows of L.h - conv_dense_small_n's `wbuf` path - was measured
     // SLOWER than the blocked global loads, 0.50 vs 0.33 ms for 128 graphs, so it stays off)
     (void)NMAX;
     float* wbuf = nullptr;
-    if (lv.type == 0)
-      conv_dense_small_n<true>(L, n, fin, C, lv.wl, lv.b, lv.wr, L.agg, L.x, wbuf);
-    else
-      conv_dense_small_n<false>(L, n, fin, C, lv.wl, lv.b, nullptr, L.agg, L.x, wbuf);
+    const int per = (n + G - 1) / G;   // nodes per thread (workgroup-uniform)
+    if (lv.type == 0) {
+      if (per <= 1) conv_dense_small_n<true, 1>(L, n, fin, C, lv.wl, lv.b, lv.wr, L.agg, L.x, wbuf);
+      else if (per <= 8) conv_dense_small_n<true, 8>(L, n, fin, C, lv.wl, lv.b, lv.wr, L.agg, L.x, wbuf);
+      else conv_dense_small_n<true, NACC>(L, n, fin, C, lv.wl, lv.b, lv.wr, L.agg, L.x, wbuf);
+    } else {
+      if (per <= 1) conv_dense_small_n<false, 1>(L, n, fin, C, lv.wl, lv.b, nullptr, L.agg, L.x, wbuf);
+      else if (per <= 8) conv_dense_small_n<false, 8>(L, n, fin, C, lv.wl, lv.b, nullptr, L.agg, L.x, wbuf);
+      else conv_dense_small_n<false, NACC>(L, n, fin, C, lv.wl, lv.b, nullptr, L.agg, L.x, wbuf);
+    }
   }
   (void)G;
   __syncthreads();
+  GT_STAMP(2)
   // ---- relu + score = tanh(h . w / |w|)
   // pool weights once into LDS (L.deg is free here: the aggregation is done)
   for (int c = tid; c < C; c += WGT) L.deg[c] = lv.pw[c];
   __syncthreads();
   float wn = 0.f;
+#pragma unroll 16
   for (int c = 0; c < C; ++c) wn = fmaf(L.deg[c], L.deg[c], wn);
   wn = sqrtf(wn);
   if (n > WGT / 16) {
     // many nodes: one thread per node walks the channels (relu in place + dot product)
     for (int i = tid; i < n; i += WGT) {
       float sp = 0.f;
+#pragma unroll 8
       for (int c = 0; c < C; ++c) {
         float hv = L.h[i * (C + 1) + c];
         hv = hv > 0.f ? hv : 0.f;
@@ -269,11 +340,13 @@ __device__ inline void run_level(const Lds& L, const Level& lv, int C, double ra
     if (i < n && sub == 0) L.score[i] = tanhf(sp / wn);
   }
   __syncthreads();
+  GT_STAMP(3)
   // ---- top-k by rank counting (descending score, ties by lower index = stable sort)
   const int k = (int)ceil(ratio * (double)n);
   for (int i = tid; i < n; i += WGT) {
     const float si = L.score[i];
     int rank = 0;
+#pragma unroll 8
     for (int j = 0; j < n; ++j) {
       const float sj = L.score[j];
       rank += (sj > si) || (sj == si && j < i);
@@ -281,12 +354,14 @@ __device__ inline void run_level(const Lds& L, const Level& lv, int C, double ra
     L.newid[i] = rank < k ? rank : -1;
   }
   __syncthreads();
+  GT_STAMP(4)
   // ---- pooled features x'[r][c] = h[perm r][c] * score[perm r]  -> L.x with stride C
   if (n > WGT / 16) {
     for (int i = tid; i < n; i += WGT) {
       const int r = L.newid[i];
       if (r >= 0) {
         const float sc = L.score[i];
+#pragma unroll 8
         for (int c = 0; c < C; ++c) L.x[r * C + c] = L.h[i * (C + 1) + c] * sc;
       }
     }
@@ -296,6 +371,7 @@ __device__ inline void run_level(const Lds& L, const Level& lv, int C, double ra
       if (r >= 0) L.x[r * C + c] = L.h[i * (C + 1) + c] * L.score[i];
     }
   }
+  GT_STAMP(5)
   // ---- filter + relabel edges, preserving edge order (wave 0, ballot compaction)
   if (tid < 64) {
     int outp = 0;
@@ -319,6 +395,7 @@ __device__ inline void run_level(const Lds& L, const Level& lv, int C, double ra
     if (tid == 0) L.misc[0] = outp;
   }
   __syncthreads();
+  GT_STAMP(6)
   E = L.misc[0];
   n = k;
   // ---- readout over the pooled nodes: thread c < C
@@ -333,6 +410,7 @@ __device__ inline void run_level(const Lds& L, const Level& lv, int C, double ra
     rmean += sm / (float)n;
   }
   __syncthreads();
+  GT_STAMP(7)
 }
 
 __global__ __launch_bounds__(WGT) void gcn_embed_kernel(mdq_gcn_net net, int NMAX, int EMAX, const float* x,
@@ -350,13 +428,15 @@ __global__ __launch_bounds__(WGT) void gcn_embed_kernel(mdq_gcn_net net, int NMA
   L.agg = p;    p += XS;
   L.score = p;  p += NMAX;
   L.deg = p;    p += (NMAX > C ? NMAX : C);  // (also stages the C pooling weights)
-  int* q = reinterpret_cast<int*>(p);
-  L.adj_ptr = q; q += NMAX + 1;
-  L.adj = q;     q += EMAX;
-  L.esrc = q;    q += EMAX;
-  L.edst = q;    q += EMAX;
+  // integer arrays: 16-byte aligned, edge arrays padded to whole quads (build_csr reads them as int4)
+  int* q = reinterpret_cast<int*>((reinterpret_cast<uintptr_t>(p) + 15) & ~(uintptr_t)15);
+  const int EQ = (EMAX + 3) & ~3;
+  L.adj_ptr = q; q += (NMAX + 1 + 3) & ~3;
+  L.adj = q;     q += EQ;
+  L.esrc = q;    q += EQ;
+  L.edst = q;    q += EQ;
   L.newid = q;   q += NMAX;
-  L.misc = q;
+  L.misc = q;    // [8 + WGT / 64]
   for (int idx = tid; idx < nn * net.fin0; idx += WGT) L.x[idx] = x[(size_t)n0 * net.fin0 + idx];
   for (int e = tid; e < ne; e += WGT) {
     L.esrc[e] = esrc[e0 + e];
@@ -373,6 +453,10 @@ __global__ __launch_bounds__(WGT) void gcn_embed_kernel(mdq_gcn_net net, int NMA
     lv.b = net.levels[l].b;
     lv.wr = net.levels[l].w_r;
     lv.pw = net.levels[l].pool_w;
+#ifdef MDQ_GCN_TRACE
+    if (tid == 0 && b == 0) mdq_gcn_trace_level = l;
+    __syncthreads();
+#endif
     run_level(L, lv, C, net.ratio, n, E, rmax, rmean, NMAX);
   }
   if (tid < C) {
@@ -473,7 +557,7 @@ extern "C" int mdq_gcn_forward(const mdq_gcn_net* net, int32_t B, int32_t NMAX, 
   }
   size_t lds = sizeof(float) * ((size_t)mdq_gcn_xs(*net, NMAX) * 2 + (size_t)NMAX * (C + 1) + (size_t)NMAX +
                                 (size_t)(NMAX > C ? NMAX : C)) +
-               sizeof(int) * ((size_t)NMAX + 1 + 3 * (size_t)EMAX + NMAX + 8);
+               sizeof(int) * ((size_t)NMAX + 4 + 3 * ((size_t)EMAX + 3) + NMAX + 8 + WGT / 64) + 16;
   if (lds > 160 * 1024) return mdq_set_error("mdq_gcn_forward: graph does not fit in LDS");
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gcn_embed_kernel),
