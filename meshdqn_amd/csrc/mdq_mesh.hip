@@ -132,13 +132,24 @@ struct RestoreArgs {
   const uint32_t* src[RESTORE_MAX];
   int64_t words[RESTORE_MAX];
 };
-// blockIdx.x = position in the index list, blockIdx.y = tensor: one cached row -> row idx of that tensor
+// blockIdx.x = position in the index list, blockIdx.y = tensor, blockIdx.z = 16 KB chunk of the row:
+// one cached row -> row idx of that tensor, 16 bytes per thread and step where the row allows it
+constexpr int RESTORE_CHUNK = 4096;   // words per block
 __global__ __launch_bounds__(256) void restore_rows_kernel(RestoreArgs a, const int32_t* idx) {
   const int t = blockIdx.y;
   const int64_t n = a.words[t];
+  const int64_t w0 = (int64_t)blockIdx.z * RESTORE_CHUNK;
+  if (w0 >= n) return;
+  const int64_t w1 = w0 + RESTORE_CHUNK < n ? w0 + RESTORE_CHUNK : n;
   uint32_t* d = a.dst[t] + (int64_t)idx[blockIdx.x] * n;
   const uint32_t* s = a.src[t];
-  for (int64_t i = threadIdx.x; i < n; i += 256) d[i] = s[i];
+  if ((n & 3) == 0 && ((reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(s)) & 15) == 0) {
+    uint4* d4 = reinterpret_cast<uint4*>(d);
+    const uint4* s4 = reinterpret_cast<const uint4*>(s);
+    for (int64_t i = (w0 >> 2) + threadIdx.x; i < (w1 >> 2); i += 256) d4[i] = s4[i];
+  } else {
+    for (int64_t i = w0 + threadIdx.x; i < w1; i += 256) d[i] = s[i];
+  }
 }
 }  // namespace mdq_mesh
 
@@ -155,7 +166,10 @@ extern "C" int mdq_restore_rows(int32_t n, void* const* dst, const void* const* 
     a.src[t] = static_cast<const uint32_t*>(src[t]);
     a.words[t] = row_bytes[t] / 4;
   }
-  hipLaunchKernelGGL(mdq_mesh::restore_rows_kernel, dim3(n_idx, n), dim3(256), 0, (hipStream_t)stream, a, idx);
+  int64_t wmax = 0;
+  for (int t = 0; t < n; ++t) wmax = a.words[t] > wmax ? a.words[t] : wmax;
+  const int chunks = (int)((wmax + mdq_mesh::RESTORE_CHUNK - 1) / mdq_mesh::RESTORE_CHUNK);
+  hipLaunchKernelGGL(mdq_mesh::restore_rows_kernel, dim3(n_idx, n, chunks), dim3(256), 0, (hipStream_t)stream, a, idx);
   if (hipGetLastError() != hipSuccess) return mdq_set_error("restore_rows_kernel launch failed");
   return 0;
 }
