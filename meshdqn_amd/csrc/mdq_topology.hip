@@ -31,15 +31,26 @@ __device__ inline int scan_excl(int* a, int n, int* part) {
     loc[i] = run;
     run += idx < n ? a[idx] : 0;
   }
-  part[tid] = run;
-  __syncthreads();
-  for (int off = 1; off < TW; off <<= 1) {
-    const int add = tid >= off ? part[tid - off] : 0;
-    __syncthreads();
-    part[tid] += add;
-    __syncthreads();
+  // thread totals: inclusive scan inside the wave by shuffles, then the TW / 64 wave totals through LDS
+  // (two barriers; the Hillis-Steele scan over the 512 thread totals took 19, ten times per launch)
+  const int lane = tid & 63, wave = tid >> 6;
+  int v = run;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int u = __shfl_up(v, off, 64);
+    if (lane >= off) v += u;
   }
-  const int base = part[tid] - run, total = part[TW - 1];
+  __syncthreads();   // (the previous call's readers of `part` are done)
+  if (lane == 63) part[wave] = v;
+  __syncthreads();
+  int pre = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < TW / 64; ++w) {
+    const int wt = part[w];
+    if (w < wave) pre += wt;
+    total += wt;
+  }
+  const int base = pre + v - run;
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     const int idx = tid * PER + i;
@@ -61,9 +72,25 @@ __device__ __forceinline__ double seg_dist2(double px, double py, double ax, dou
   return qx * qx + qy * qy;
 }
 
+#ifdef MDQ_TOPO_TRACE
+// debug build only: s_memtime deltas of thread 0 of mesh 0 at the section boundaries
+__device__ long long mdq_topo_trace_buf[16];
+#define TT_STAMP(k) { const long long tn_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) mdq_topo_trace_buf[k] += tn_ - tq_; tq_ = tn_; }
+extern "C" int mdq_topo_trace_host(long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mdq_topo_trace_buf), sizeof(long long) * 16) != hipSuccess) return -1;
+  if (reset) { long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(mdq_topo_trace_buf), z, sizeof z) != hipSuccess) return -1; }
+  return 0;
+}
+#else
+#define TT_STAMP(k)
+#endif
+
 __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_ipcs_topo_out O, int has_ipcs,
                                                       int32_t* status) {
 #pragma clang fp contract(off)
+#ifdef MDQ_TOPO_TRACE
+  long long tq_ = __builtin_amdgcn_s_memtime();
+#endif
   extern __shared__ __align__(16) unsigned char smem[];
   double2* X = reinterpret_cast<double2*>(smem);                              // [TNV]
   uint32_t* hkey = reinterpret_cast<uint32_t*>(smem + 16384);                 // [HSZ]   | region R (64 KB), re-used
@@ -106,6 +133,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   }
   __syncthreads();
 
+  TT_STAMP(0)
   // ================= edges numbered by first appearance in (cell, local edge k opposite vertex k) order
   auto slot_key = [&](int s, int& a, int& c) {
     const int t = s / 3, k = s - 3 * t;
@@ -185,6 +213,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     pts[2 * i + 1] = X[i].y;
   }
   __syncthreads();
+  TT_STAMP(1)
   // ================= P2 dof coordinates, boundary vertices, facet tags (later marks override earlier ones)
   const double E = 3.0e-16;
   double ymin = 1e300, ymax = -1e300;
@@ -258,6 +287,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   }
   if (tid == 0) D.naf[b] = naf;
   __syncthreads();
+  TT_STAMP(2)
   // ================= removable: neither x nor y equals ANY boundary vertex's x / y (numpy `in` quirk)
   for (int v = tid; v < TNS; v += TW) scanb[v] = (v < nv && onb[v]) ? 1 : 0;
   __syncthreads();
@@ -271,14 +301,29 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     if (v < nv && flg[i]) blist[scanb[v]] = (uint16_t)v;
   }
   __syncthreads();
+  // boundary coordinates packed (the distance buffer is free until the next section): the comparison loop then reads
+  // consecutive entries, independent of each other, instead of an index and a dependent gather per boundary vertex
+  double2* bxy = reinterpret_cast<double2*>(dist);   // [nb] <= TNV / 2 entries fit the TNV doubles of `dist`
+  const bool packed = nb <= TNV / 2;
+  if (packed)
+    for (int j = tid; j < nb; j += TW) bxy[j] = X[blist[j]];
+  __syncthreads();
   for (int v = tid; v < TNS; v += TW) {
     int r = 0;
     if (v < nv) {
       const double px = X[v].x, py = X[v].y;
-      bool hit = false;
-      for (int j = 0; j < nb; ++j) {
-        const double2 q = X[blist[j]];
-        hit = hit || q.x == px || q.y == py;
+      int hit = 0;
+      if (packed) {
+#pragma unroll 8
+        for (int j = 0; j < nb; ++j) {
+          const double2 q = bxy[j];
+          hit |= (q.x == px) | (q.y == py);
+        }
+      } else {
+        for (int j = 0; j < nb; ++j) {
+          const double2 q = X[blist[j]];
+          hit |= (q.x == px) | (q.y == py);
+        }
       }
       r = hit ? 0 : 1;
     }
@@ -295,6 +340,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     if (v < nv && flg[i]) remv[scanb[v]] = (uint16_t)v;
   }
   if (tid == 0) D.nremovable[b] = nrem;
+  TT_STAMP(3)
   // ================= distances to the airfoil polygon (0 inside), stable argsort, window of N
   const int np_ = D.npoly;
   for (int i = tid; i < np_; i += TW) poly[i] = make_double2(D.polygon[2 * i], D.polygon[2 * i + 1]);
@@ -302,6 +348,9 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   for (int r = tid; r < nrem; r += TW) {
     const double px = X[remv[r]].x, py = X[remv[r]].y;
     bool inside = false;
+    // (skipping segments whose bounding box is farther than the nearest polygon vertex - what the host twin does -
+    // was measured SLOWER here, 234 k vs 188 k cycles: the 64 vertices of a wave are near different segments, so the
+    // wave evaluates almost every segment anyway and pays the bound on top)
     double d2 = 1e300;
     for (int i = 0; i < np_; ++i) {
       const double2 A = poly[i], Bp = poly[i + 1 == np_ ? 0 : i + 1];
@@ -317,9 +366,10 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   for (int r = tid; r < nrem; r += TW) {
     const double dr = dist[r];
     int rank = 0;
+#pragma unroll 8
     for (int q = 0; q < nrem; ++q) {
       const double dq = dist[q];
-      rank += (dq < dr) || (dq == dr && q < r);
+      rank += (dq < dr) | ((dq == dr) & (q < r));
     }
     order[rank] = (uint16_t)r;
   }
@@ -345,6 +395,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   }
   if (tid == 0) D.nsel[b] = nsel;
   __syncthreads();
+  TT_STAMP(4)
   // ================= state graph: cells whose three vertices are all selected, in cell order
   for (int t = tid; t < TNS; t += TW) {
     int f = 0;
@@ -383,6 +434,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     }
   }
   if (tid == 0) D.nedges[b] = 3 * ngood;
+  TT_STAMP(5)
   if (!has_ipcs) return;
   __syncthreads();
 
@@ -608,6 +660,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
       for (int j = 0; j < w; ++j) sc[base + 64 * j + l] = j < len ? cols[j] : rr;
     }
   }
+  TT_STAMP(6)
 }
 
 }  // namespace mdq_topo
