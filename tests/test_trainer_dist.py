@@ -147,3 +147,49 @@ def test_training_log_files_and_restart(tmp_path):
     again.add_episode([2.0], [1])
     again.write()
     assert np.load(os.path.join(d, "RESTART_reward.npy")).tolist() == [0.0, 0.5, 2.0]
+
+
+def test_device_replay_ring_on_cpu_tensors():
+    """DeviceReplay bookkeeping (pure torch ops, here on CPU tensors): slots of states / next states across the ring
+    wrap-around, terminal flags, compacted and padded edge arrays of a gathered minibatch."""
+    import numpy as np
+    from meshdqn_amd.trainer import DeviceReplay
+    rng = np.random.default_rng(3)
+    B, N, F, EM = 4, 6, 3, 16
+
+    def state(tag):
+        cnt = rng.integers(1, EM + 1, size=B)
+        sp = rng.integers(0, N, size=(B, EM)).astype(np.int32)
+        dp = rng.integers(0, N, size=(B, EM)).astype(np.int32)
+        return dict(x=torch.full((B, N, F), float(tag)) + torch.arange(B).reshape(B, 1, 1), edge_src_pad=torch.from_numpy(sp),
+                    edge_dst_pad=torch.from_numpy(dp), nedges=cnt.astype(np.int32))
+
+    rep = DeviceReplay(capacity=2 * B, B=B, N=N, F=F, e_max=EM, device=torch.device("cpu"))
+    assert rep.K == 4 and DeviceReplay.eligible(state(0), EM) and not DeviceReplay.eligible(dict(x=None), EM)
+    states = [state(t) for t in range(7)]
+    bases = [rep.store(states[0])]
+    for t in range(6):
+        bases.append(rep.store(states[t + 1]))
+        rep.push(bases[t], bases[t + 1], np.full(B, t), np.full(B, 0.5 * t, np.float32), np.arange(B) == t % B)
+    assert rep.size() == 2 * B and bases == [0, 4, 8, 12, 0, 4, 8]
+    # the live transitions are those of steps 4 and 5; their states are still in the ring
+    live = {}
+    for t in (4, 5):
+        for b in range(B):
+            live[(t, b)] = (bases[t] + b, -1 if b == t % B else bases[t + 1] + b)
+    got = sorted(zip(rep.t_s.tolist(), rep.t_n.tolist(), rep.t_a.tolist()))
+    assert got == sorted((s, n, t) for (t, b), (s, n) in live.items())
+    slots = np.array([bases[5] + 2, bases[6] + 1, bases[4] + 0])
+    g = rep.gather(slots)
+    src_states = [(states[5], 2), (states[6], 1), (states[4], 0)]
+    off = 0
+    for i, (st, b) in enumerate(src_states):
+        c = int(st["nedges"][b])
+        assert torch.equal(g["x"][i], st["x"][b])
+        assert torch.equal(g["esrc"][off:off + c], st["edge_src_pad"][b, :c]) and torch.equal(g["edst"][off:off + c], st["edge_dst_pad"][b, :c])
+        assert torch.equal(g["src"][i, :c], st["edge_src_pad"][b, :c].long()) and int(g["src"][i, c:].abs().sum()) == 0
+        assert g["mask"][i].sum().item() == c and int(g["edge_ptr"][i]) == off
+        off += c
+    assert int(g["edge_ptr"][-1]) == off and g["node_ptr"].tolist() == [0, N, 2 * N, 3 * N]
+    d = rep.data(int(slots[0]))
+    assert d.x.shape == (N, F) and d.edge_index.shape == (2, int(states[5]["nedges"][2]))
