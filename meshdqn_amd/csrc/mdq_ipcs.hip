@@ -2590,11 +2590,56 @@ __global__ __launch_bounds__(WG) void at_correction_kernel(mdq_ipcs_desc d, int 
 #pragma unroll
     for (int k = 0; k < MF_ROWS; ++k) rc[k] = min(tid + k * WG, n2 - 1);
     double* Dp = reinterpret_cast<double*>(Yl + P.N2p);   // [nv] pressure increment, staged for the element loop
-    {
-      // u* and p_new - p_n staged in LDS: the right-hand-side element loop gathers from LDS instead of from L2
-      double2 us[MF_ROWS];
+    // initial guess of the correction: extrapolation in time of the stored ones (constant, linear, quadratic as the
+    // ring fills): 5.0 CG iterations per step with the previous correction alone, 1.7 with the quadratic guess (the
+    // velocity solve then needs 2.9 instead of 2.6 iterations: u_n now carries the full 1e-10 solver noise).
+    // Dirichlet rows keep u* = g (their stored corrections are 0).
+    auto load_delta = [&](double2(&dl)[MF_ROWS]) {
 #pragma unroll
-      for (int k = 0; k < MF_ROWS; ++k) us[k] = xs[rc[k]];
+      for (int k = 0; k < MF_ROWS; ++k) dl[k] = make_double2(0.0, 0.0);
+      if (nc >= 1) {
+        const double2* c1 = cring + (int64_t)((rp + 2) % 3) * d.N2;   // newest
+        const double2* c2 = cring + (int64_t)((rp + 1) % 3) * d.N2;
+        const double2* c3 = cring + (int64_t)rp * d.N2;               // oldest (overwritten at the end of this launch)
+#pragma unroll
+        for (int k = 0; k < MF_ROWS; ++k) dl[k] = c1[rc[k]];
+        if (nc >= 2) {
+          const double w1 = nc >= 3 ? 3.0 : 2.0, w2 = nc >= 3 ? -3.0 : -1.0;
+#pragma unroll
+          for (int k = 0; k < MF_ROWS; ++k) {
+            const double2 b2 = c2[rc[k]];
+            dl[k] = make_double2(w1 * dl[k].x + w2 * b2.x, w1 * dl[k].y + w2 * b2.y);
+          }
+          if (nc >= 3) {
+#pragma unroll
+            for (int k = 0; k < MF_ROWS; ++k) {
+              const double2 b3 = c3[rc[k]];
+              dl[k] = make_double2(dl[k].x + b3.x, dl[k].y + b3.y);
+            }
+          }
+        }
+      }
+    };
+    // FUSED start (15 of 16 steps once the ring is full): with x0 = u* + delta0 the initial residual is
+    //   f3 - M x0 = (M u* - g) - M (u* + delta0) = -g - M delta0,
+    // ONE element loop (the right-hand-side operator applied to -delta0) instead of two (f3, then M x0), and no
+    // lifting vector (delta0 vanishes on the Dirichlet rows).  What it cannot give is |b| of the stopping test
+    // rtol |b|, which needs f3 itself: the value of the last exact start is used (it changes by < 1e-3 per step);
+    // every 16th step, and while the ring fills, the exact two-loop start runs and refreshes it.
+    const double bb_lag = ccnt[2];
+    const int cstep = (int)ccnt[3];
+    const bool fused = nc >= 3 && bb_lag > 0.0 && (cstep & 15) != 0;
+    {
+      // operator input (u*, or -delta0) and p_new - p_n staged in LDS: the element loop gathers from LDS, not L2
+      double2 us[MF_ROWS];
+      if (!fused) {
+#pragma unroll
+        for (int k = 0; k < MF_ROWS; ++k) us[k] = xs[rc[k]];
+      } else {
+        load_delta(us);
+#pragma unroll
+        for (int k = 0; k < MF_ROWS; ++k) us[k] = make_double2(-us[k].x, -us[k].y);
+      }
       for (int i = tid; i < nv; i += WG) Dp[i] = pnew[i] - v.p_n[i];
 #pragma unroll
       for (int k = 0; k < MF_ROWS; ++k) {
@@ -2618,89 +2663,93 @@ __global__ __launch_bounds__(WG) void at_correction_kernel(mdq_ipcs_desc d, int 
     // own rows of the global vectors of the next phase: issued in front of the barrier that ends the element loop
     double2 l3[MF_ROWS], dlt[MF_ROWS];
     unsigned flm = 0;
+    if (!fused) load_delta(dlt);   // (the fused start reads delta0 back from its LDS copy below)
 #pragma unroll
     for (int k = 0; k < MF_ROWS; ++k) {
-      l3[k] = v.lift3[rc[k]];
+      l3[k] = fused ? xs[rc[k]] : v.lift3[rc[k]];     // fused start: u* of the own rows (the LDS copy holds -delta0)
       ism[k] = v.sdiagM[rc[k]];
       flm |= v.bcu_flag[rc[k]] ? 1u << k : 0u;
-      dlt[k] = make_double2(0.0, 0.0);
-    }
-    if (nc >= 1) {
-      // initial guess of the correction: extrapolation in time of the stored ones (constant, linear, quadratic as
-      // the ring fills): 5.0 CG iterations per step with the previous correction alone, 1.7 with the quadratic guess
-      // (the velocity solve then needs 2.9 instead of 2.6 iterations: u_n now carries the full 1e-10 solver noise)
-      const double2* c1 = cring + (int64_t)((rp + 2) % 3) * d.N2;   // newest
-      const double2* c2 = cring + (int64_t)((rp + 1) % 3) * d.N2;
-      const double2* c3 = cring + (int64_t)rp * d.N2;               // oldest (overwritten at the end of this launch)
-#pragma unroll
-      for (int k = 0; k < MF_ROWS; ++k) dlt[k] = c1[rc[k]];
-      if (nc >= 2) {
-        const double w1 = nc >= 3 ? 3.0 : 2.0, w2 = nc >= 3 ? -3.0 : -1.0;
-#pragma unroll
-        for (int k = 0; k < MF_ROWS; ++k) {
-          const double2 b2 = c2[rc[k]];
-          dlt[k] = make_double2(w1 * dlt[k].x + w2 * b2.x, w1 * dlt[k].y + w2 * b2.y);
-        }
-        if (nc >= 3) {
-#pragma unroll
-          for (int k = 0; k < MF_ROWS; ++k) {
-            const double2 b3 = c3[rc[k]];
-            dlt[k] = make_double2(dlt[k].x + b3.x, dlt[k].y + b3.y);
-          }
-        }
-      }
     }
     __syncthreads();
     CT_STAMP(1)
-    double2 f3[MF_ROWS];
+    double bb;
+    if (fused) {
 #pragma unroll
-    for (int k = 0; k < MF_ROWS; ++k) {
-      f3[k] = Yl[rc[k]];
-      x[k] = Pl[rc[k]];      // u* (own row)
-    }
-#pragma unroll
-    for (int k = 0; k < MF_ROWS; ++k) {
-      const int row = tid + k * WG;
-      const bool fl = (flm >> k) & 1u;
-      ism[k] = (row < n2 && !fl) ? 1.0 / ism[k] : 0.0;
-      // initial guess: u* plus the extrapolated correction, i.e. a guess for u* - dt grad(dp); plain u* while
-      // there is no history.  Dirichlet rows keep u* = g (their stored corrections are 0).
-      if (!fl) x[k] = make_double2(x[k].x + dlt[k].x, x[k].y + dlt[k].y);
-      if (row < n2) {
-        Yl[row] = make_double2(0.0, 0.0);
-        Pl[row] = x[k];      // stage S^-1 (S x0) = x0
-        const double2 bi = fl ? x[k] : make_double2((f3[k].x - l3[k].x) * ism[k], (f3[k].y - l3[k].y) * ism[k]);
-        am[0] += bi.x * bi.x + bi.y * bi.y;
-      } else {
-        x[k] = f3[k] = make_double2(0.0, 0.0);
+      for (int k = 0; k < MF_ROWS; ++k) {
+        r[k] = Yl[rc[k]];
+        const double2 md = Pl[rc[k]];
+        dlt[k] = make_double2(-md.x, -md.y);
       }
-    }
-    __syncthreads();
-    CT_STAMP(2)
-    atomic_accumulate<true>(v, Yd, tm, [&](int, const Geo& g, const ElemIdx& E, int, double2(&ye)[6]) {
-      double2 xe[6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) xe[i] = Pl[E.dof[i]];
-      elem_mass(g, xe, ye);
-    });
-    __syncthreads();
-    CT_STAMP(3)
-#pragma unroll
-    for (int k = 0; k < MF_ROWS; ++k) {
-      const int row = tid + k * WG;
-      r[k] = p[k] = make_double2(0.0, 0.0);
-      if (row < n2) {
-        const double2 ax = Yl[row];
-        r[k] = make_double2((f3[k].x - ax.x) * ism[k], (f3[k].y - ax.y) * ism[k]);  // 0 on constrained rows
+      for (int k = 0; k < MF_ROWS; ++k) {
+        const int row = tid + k * WG;
+        const bool fl = (flm >> k) & 1u;
+        ism[k] = (row < n2 && !fl) ? 1.0 / ism[k] : 0.0;
+        r[k] = make_double2(r[k].x * ism[k], r[k].y * ism[k]);          // 0 on constrained rows and past n2
         p[k] = r[k];
         am[1] += r[k].x * r[k].x + r[k].y * r[k].y;
-        if (ism[k] != 0.0) x[k] = make_double2(x[k].x / ism[k], x[k].y / ism[k]);  // scaled unknown S x
+        // scaled unknown S x0 on the free rows, u* = g on the Dirichlet rows
+        x[k] = fl ? l3[k] : make_double2((l3[k].x + dlt[k].x) / (ism[k] != 0.0 ? ism[k] : 1.0),
+                                          (l3[k].y + dlt[k].y) / (ism[k] != 0.0 ? ism[k] : 1.0));
+        if (row >= n2) x[k] = make_double2(0.0, 0.0);
       }
+      double a1r[1] = {am[1]};
+      block_sum<1>(a1r, red);
+      am[1] = a1r[0];
+      bb = bb_lag;
+      CT_STAMP(2)
+      CT_STAMP(3)
+    } else {
+      double2 f3[MF_ROWS];
+#pragma unroll
+      for (int k = 0; k < MF_ROWS; ++k) {
+        f3[k] = Yl[rc[k]];
+        x[k] = Pl[rc[k]];      // u* (own row)
+      }
+#pragma unroll
+      for (int k = 0; k < MF_ROWS; ++k) {
+        const int row = tid + k * WG;
+        const bool fl = (flm >> k) & 1u;
+        ism[k] = (row < n2 && !fl) ? 1.0 / ism[k] : 0.0;
+        if (!fl) x[k] = make_double2(x[k].x + dlt[k].x, x[k].y + dlt[k].y);
+        if (row < n2) {
+          Yl[row] = make_double2(0.0, 0.0);
+          Pl[row] = x[k];      // stage S^-1 (S x0) = x0
+          const double2 bi = fl ? x[k] : make_double2((f3[k].x - l3[k].x) * ism[k], (f3[k].y - l3[k].y) * ism[k]);
+          am[0] += bi.x * bi.x + bi.y * bi.y;
+        } else {
+          x[k] = f3[k] = make_double2(0.0, 0.0);
+        }
+      }
+      __syncthreads();
+      CT_STAMP(2)
+      atomic_accumulate<true>(v, Yd, tm, [&](int, const Geo& g, const ElemIdx& E, int, double2(&ye)[6]) {
+        double2 xe[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) xe[i] = Pl[E.dof[i]];
+        elem_mass(g, xe, ye);
+      });
+      __syncthreads();
+      CT_STAMP(3)
+#pragma unroll
+      for (int k = 0; k < MF_ROWS; ++k) {
+        const int row = tid + k * WG;
+        r[k] = p[k] = make_double2(0.0, 0.0);
+        if (row < n2) {
+          const double2 ax = Yl[row];
+          r[k] = make_double2((f3[k].x - ax.x) * ism[k], (f3[k].y - ax.y) * ism[k]);  // 0 on constrained rows
+          p[k] = r[k];
+          am[1] += r[k].x * r[k].x + r[k].y * r[k].y;
+          if (ism[k] != 0.0) x[k] = make_double2(x[k].x / ism[k], x[k].y / ism[k]);  // scaled unknown S x
+        }
+      }
+      block_sum<2>(am, red);
+      bb = am[0];
+      if (tid == 0) ccnt[2] = bb;
     }
-    block_sum<2>(am, red);
     CT_STAMP(4)
     {
-      const double bb = am[0], tol2 = d.rtol * d.rtol * bb;
+      const double tol2 = d.rtol * d.rtol * bb;
       double rr = am[1];
       if (rr > tol2 && bb != 0.0) {
         int it = 0;
@@ -2780,6 +2829,7 @@ __global__ __launch_bounds__(WG) void at_correction_kernel(mdq_ipcs_desc d, int 
     if (tid == 0) {
       ccnt[0] = (double)(nc < 3 ? nc + 1 : 3);
       ccnt[1] = (double)((rp + 1) % 3);
+      ccnt[3] = (double)((cstep + 1) & 1023);
     }
     for (int i = tid; i < nv; i += WG) v.p_n[i] = pnew[i];
     __syncthreads();
