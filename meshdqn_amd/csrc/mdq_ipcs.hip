@@ -607,6 +607,44 @@ __device__ inline void rhs2_elements(const EnvView& v, const mdq_ipcs_desc& d, c
   }
 }
 
+// The same right-hand side accumulated straight into an LDS vector with fp64 LDS atomics (mode 3): no element
+// scratch in global memory and no per-row gather lists (a dependent chain of three global round trips per row and
+// one more per incident cell: 36 % of the direct pressure kernel).  Two triangles per thread, their loads issued
+// together.  `acc` must be zeroed and published by the caller.
+template <int NTH>
+__device__ inline void rhs2_accumulate_lds(const EnvView& v, const mdq_ipcs_desc& d, const double2* __restrict__ u,
+                                           const double* __restrict__ p, double* acc) {
+  const double idt = 1.0 / d.dt;
+  for (int e0 = threadIdx.x; e0 < v.nt; e0 += 2 * NTH) {
+    const int e1 = e0 + NTH;
+    const bool two = e1 < v.nt;
+    const int ec = two ? e1 : e0;   // (clamped: the second triangle's loads are always issued)
+    const ElemIdx Ea = load_dofs(v, e0), Eb = load_dofs(v, ec);
+    const Geo ga = load_geo(v, e0), gb = load_geo(v, ec);
+    double2 ua[6], ub[6];
+    double pa[3], pb[3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      ua[i] = u[Ea.dof[i]];
+      ub[i] = u[Eb.dof[i]];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      pa[i] = p[Ea.dof[i]];
+      pb[i] = p[Eb.dof[i]];
+    }
+    double ra[3], rb[3];
+    elem_rhs2(ga, idt, ua, pa, ra);
+    elem_rhs2(gb, idt, ub, pb, rb);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) unsafeAtomicAdd(acc + Ea.dof[j], ra[j]);
+    if (two) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) unsafeAtomicAdd(acc + Eb.dof[j], rb[j]);
+    }
+  }
+}
+
 __device__ inline void rhs3_elements(const EnvView& v, const mdq_ipcs_desc& d, const double2* __restrict__ u,
                                      const double* __restrict__ pnew, const double* __restrict__ pold,
                                      double2* __restrict__ escr) {
@@ -1005,6 +1043,35 @@ __device__ inline int cg_pressure(int n, const int32_t* sl_off, const int32_t* s
   return it;
 }
 
+#ifdef MDQ_AT_TRACE
+// debug build only: s_memtime deltas of thread 0 of environment 0 at the phase boundaries of at_velocity_kernel
+__device__ long long mdq_at_trace_buf[16];
+#define AT_STAMP(k) { const long long tn_ = __builtin_amdgcn_s_memtime(); if (tid == 0 && b == 0) mdq_at_trace_buf[k] += tn_ - tq_; tq_ = tn_; }
+extern "C" int mdq_at_trace_host(long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mdq_at_trace_buf), sizeof(long long) * 16) != hipSuccess) return -1;
+  if (reset) { long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(mdq_at_trace_buf), z, sizeof z) != hipSuccess) return -1; }
+  return 0;
+}
+__device__ long long mdq_pt_trace_buf[16];
+#define PT_STAMP(k) { const long long tn_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) mdq_pt_trace_buf[k] += tn_ - tqp_; tqp_ = tn_; }
+extern "C" int mdq_pt_trace_host(long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mdq_pt_trace_buf), sizeof(long long) * 16) != hipSuccess) return -1;
+  if (reset) { long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(mdq_pt_trace_buf), z, sizeof z) != hipSuccess) return -1; }
+  return 0;
+}
+__device__ long long mdq_ct_trace_buf[16];
+#define CT_STAMP(k) { const long long tn_ = __builtin_amdgcn_s_memtime(); if (tid == 0 && b == 0) mdq_ct_trace_buf[k] += tn_ - tq_; tq_ = tn_; }
+extern "C" int mdq_ct_trace_host(long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mdq_ct_trace_buf), sizeof(long long) * 16) != hipSuccess) return -1;
+  if (reset) { long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(mdq_ct_trace_buf), z, sizeof z) != hipSuccess) return -1; }
+  return 0;
+}
+#else
+#define AT_STAMP(k)
+#define CT_STAMP(k)
+#define PT_STAMP(k)
+#endif
+
 // ================================================================== direct pressure solve
 //
 // Solve phase of the substructuring factorisation built by meshdqn_amd/pressure_direct.py
@@ -1036,6 +1103,28 @@ __device__ __forceinline__ PdView pd_view(const mdq_ipcs_desc& d, int b) {
   return p;
 }
 
+// sum_j A[j * stride] * x[idx(j)], j in [0, len): the strided global loads in batches of PDU, ALL of a batch in flight
+// together; the last batch is padded with clamped (re-read, weight 0) entries, so there is no serial remainder loop
+// (with `#pragma unroll 8/16` the remainder of a 55-column block is up to 15 dependent round trips to the memory side).
+constexpr int PDU = 16;
+template <class Idx>
+__device__ __forceinline__ double pd_dot(const double* __restrict__ A, int64_t stride, int len, const double* x, Idx idx) {
+  double acc = 0.0;
+  for (int j0 = 0; j0 < len; j0 += PDU) {
+    double av[PDU];
+    int xi[PDU];
+#pragma unroll
+    for (int u = 0; u < PDU; ++u) {
+      const int j = min(j0 + u, len - 1);
+      av[u] = A[(int64_t)j * stride];
+      xi[u] = idx(j);
+    }
+#pragma unroll
+    for (int u = 0; u < PDU; ++u) acc += (j0 + u < len ? av[u] : 0.0) * x[xi[u]];
+  }
+  return acc;
+}
+
 // x = K^-1 b.  b, x: LDS vectors in natural node order (x may alias b); t0,t1,t2: LDS scratch
 // of at least max(n, NTH) doubles each (NTH = threads of the calling kernel).
 template <int NTH = WG>
@@ -1044,20 +1133,22 @@ __device__ inline void pressure_direct(const PdView& pd, int n, const double* b,
   const int tid = threadIdx.x, nI = pd.nI, nG = pd.nG;
   double* bp = t0;  // permuted right-hand side
   double* y = t1;   // W b_I  |  separator: g, then x_G
+#ifdef MDQ_AT_TRACE
+  long long tqp_ = __builtin_amdgcn_s_memtime();
+#endif
   __syncthreads();
   for (int q = tid; q < n; q += NTH) bp[q] = b[pd.node[q]];
   __syncthreads();
+  PT_STAMP(1)
   // y_I = W b_I
   for (int q = tid; q < nI; q += NTH) {
     const int32_t* m6 = pd.meta + 6 * pd.rowblk[q];
     const int q0 = m6[0], m = m6[1];
     const double* Wc = pd.W + m6[2] + (q - q0);
-    double acc = 0.0;
-#pragma unroll 8
-    for (int j = 0; j < m; ++j) acc += Wc[(int64_t)j * m] * bp[q0 + j];
-    y[q] = acc;
+    y[q] = pd_dot(Wc, m, m, bp, [&](int j) { return q0 + j; });
   }
   __syncthreads();
+  PT_STAMP(2)
   // g = b_G - K[G,I] y_I
   for (int g = tid; g < nG; g += NTH) {
     double acc = bp[nI + g];
@@ -1065,6 +1156,7 @@ __device__ inline void pressure_direct(const PdView& pd, int n, const double* b,
     y[nI + g] = acc;
   }
   __syncthreads();
+  PT_STAMP(3)
   // x_G = Sinv g : rows split over column slices so that all waves stream Sinv
   const int NGP = (nG + 63) & ~63;
   const int nsl = NGP > 0 ? (NTH / NGP > 0 ? NTH / NGP : 1) : 1;
@@ -1076,7 +1168,7 @@ __device__ inline void pressure_direct(const PdView& pd, int n, const double* b,
       const int c1 = min(nG, (sl + 1) * cw);
       const double* Sc = pd.Sinv + row;
 #pragma unroll 8
-      for (int c = sl * cw; c < c1; ++c) acc += Sc[(int64_t)c * nG] * y[nI + c];
+      for (int c = sl * cw; c < c1; ++c) acc += Sc[(int64_t)c * nG] * y[nI + c];   // (pd_dot was slower here: 13 columns)
     }
     t2[idx] = acc;
   }
@@ -1087,6 +1179,7 @@ __device__ inline void pressure_direct(const PdView& pd, int n, const double* b,
     bp[g] = acc;  // x_G (bp is free now)
   }
   __syncthreads();
+  PT_STAMP(4)
   // x_I = y_I - F x_G ; scatter back to natural order
   for (int q = tid; q < nI; q += NTH) {
     const int32_t* m6 = pd.meta + 6 * pd.rowblk[q];
@@ -1094,11 +1187,12 @@ __device__ inline void pressure_direct(const PdView& pd, int n, const double* b,
     const double* Fc = pd.F + m6[3] + (q - q0);
     const int32_t* gi = pd.gidx + m6[5];
     double acc = y[q];
-    for (int c = 0; c < gs; ++c) acc -= Fc[(int64_t)c * m] * bp[gi[c]];
+    if (gs > 0) acc -= pd_dot(Fc, m, gs, bp, [&](int c) { return gi[c]; });
     x[pd.node[q]] = acc;
   }
   for (int g = tid; g < nG; g += NTH) x[pd.node[nI + g]] = bp[g];
   __syncthreads();
+  PT_STAMP(5)
 }
 
 // ================================================================== probes
@@ -2078,26 +2172,6 @@ __device__ __forceinline__ void outflow_rows_add(const EnvView& v, const BoOwn& 
   }
 }
 
-#ifdef MDQ_AT_TRACE
-// debug build only: s_memtime deltas of thread 0 of environment 0 at the phase boundaries of at_velocity_kernel
-__device__ long long mdq_at_trace_buf[16];
-#define AT_STAMP(k) { const long long tn_ = __builtin_amdgcn_s_memtime(); if (tid == 0 && b == 0) mdq_at_trace_buf[k] += tn_ - tq_; tq_ = tn_; }
-extern "C" int mdq_at_trace_host(long long* out, int reset) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mdq_at_trace_buf), sizeof(long long) * 16) != hipSuccess) return -1;
-  if (reset) { long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(mdq_at_trace_buf), z, sizeof z) != hipSuccess) return -1; }
-  return 0;
-}
-__device__ long long mdq_ct_trace_buf[16];
-#define CT_STAMP(k) { const long long tn_ = __builtin_amdgcn_s_memtime(); if (tid == 0 && b == 0) mdq_ct_trace_buf[k] += tn_ - tq_; tq_ = tn_; }
-extern "C" int mdq_ct_trace_host(long long* out, int reset) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mdq_ct_trace_buf), sizeof(long long) * 16) != hipSuccess) return -1;
-  if (reset) { long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(mdq_ct_trace_buf), z, sizeof z) != hipSuccess) return -1; }
-  return 0;
-}
-#else
-#define AT_STAMP(k)
-#define CT_STAMP(k)
-#endif
 
 // The same outflow-facet term, one ENTRY per thread (18 entries per outflow facet, a few hundred per mesh): every
 // thread adds coef * B_entry x[col] to Y[row] with LDS atomics, between the barrier that publishes the zeroed Y
@@ -2517,6 +2591,9 @@ __global__ __launch_bounds__(NTH) void at_pressure_kernel(mdq_ipcs_desc d, int32
   const int32_t* ci1 = K1_LDS ? lci : v.sl1_col;
   const double* K1 = K1_LDS ? lK : v.K1s;
   int it_p = 0;
+#ifdef MDQ_AT_TRACE
+  const long long tq0_ = __builtin_amdgcn_s_memtime();
+#endif
   {
     // ================= step 2: pressure
     if (K1_LDS && !d.pd_enabled) {
@@ -2527,17 +2604,40 @@ __global__ __launch_bounds__(NTH) void at_pressure_kernel(mdq_ipcs_desc d, int32
       }
       for (int kk = tid; kk <= nsl1; kk += NTH) lso[kk] = v.sl1_off[kk];
     }
-    rhs2_elements<NTH>(v, d, xs, v.p_n, escr1);
+    (void)escr1;
+    for (int i = tid; i < nv; i += NTH) pr[i] = 0.0;
     __syncthreads();
-    for (int i = tid; i < nv; i += NTH) {
-      double bsum = 0.0;
-      for (int s = v.g1_ptr[i]; s < v.g1_ptr[i + 1]; ++s) bsum += escr1[v.g1_src[s]];
+    rhs2_accumulate_lds<NTH>(v, d, xs, v.p_n, pr);
+    // own-row data of the scaling, loaded in front of the barrier that ends the accumulation
+    constexpr int PRW = 2048 / NTH;   // own rows per thread held in registers (vertex capacity of the LDS modes < 2048)
+    double sd_[PRW], pn_[PRW];
+    unsigned fl_ = 0;
+#pragma unroll
+    for (int k = 0; k < PRW; ++k) {
+      const int i = min(tid + k * NTH, nv - 1);
+      sd_[k] = v.sdiagK[i];
+      pn_[k] = v.p_n[i];
+      fl_ |= v.bcp_flag[i] ? 1u << k : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PRW; ++k) {
+      const int i = tid + k * NTH;
+      if (i < nv) {
+        pr[i] = ((fl_ >> k) & 1u) ? 0.0 : pr[i] / sd_[k];
+        px[i] = pn_[k] * sd_[k];
+      }
+    }
+    for (int i = tid + PRW * NTH; i < nv; i += NTH) {   // (nv beyond 2048: generic tail)
       const double sd = v.sdiagK[i];
-      pr[i] = v.bcp_flag[i] ? 0.0 : bsum / sd;
+      pr[i] = v.bcp_flag[i] ? 0.0 : pr[i] / sd;
       px[i] = v.p_n[i] * sd;
     }
     if (d.pd_enabled) {
       const PdView pd = pd_view(d, b);
+#ifdef MDQ_AT_TRACE
+      { const long long tn_ = __builtin_amdgcn_s_memtime(); if (tid == 0 && b == 0) mdq_pt_trace_buf[0] += tn_ - tq0_; }
+#endif
       pressure_direct<NTH>(pd, nv, pr, px, pp, pq, lK);
     } else {
       it_p += cg_pressure(nv, so1, ci1, K1, d.rtol, d.maxit_p, px, pr, pp, pq, red);

@@ -54,3 +54,12 @@ n_all = steps + steps     # (evolve + evolve_timed passes)
 print(f"correction kernel: total {tot / n_all:.0f} ticks/step")
 for k, n in enumerate(cn):
     print(f"{k:2d} {n:40s} {cb[k] / n_all:9.0f} ticks/step  {100.0 * cb[k] / tot:5.1f} %")
+
+pb = (ctypes.c_longlong * 16)()
+lib.mdq_pt_trace_host(pb, 0)
+pn = ["rhs2 element loop + row gather (before the solve)", "permute b", "y_I = W b_I", "g = b_G - K_GI y_I", "x_G = Sinv g (+ slice sum)", "x_I = y_I - F x_G, scatter"]
+n_all = 300 + 3 * steps
+tot = sum(pb[:6])
+print(f"pressure kernel (direct): total {tot / n_all:.0f} ticks/step (all launches since process start: {n_all})")
+for k, n in enumerate(pn):
+    print(f"{k:2d} {n:52s} {pb[k] / n_all:9.0f} ticks/step  {100.0 * pb[k] / max(tot, 1):5.1f} %")
