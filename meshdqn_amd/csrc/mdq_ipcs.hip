@@ -1043,6 +1043,91 @@ __device__ inline int cg_pressure(int n, const int32_t* sl_off, const int32_t* s
   return it;
 }
 
+// Jacobi-scaled CG on the SELL-64 P1 Laplacian for the three-kernel mode 3: every thread keeps x, r, q of its own
+// two rows (slice = wave, wave + NTH/64; lane = row in the slice: the rows its SpMV produces) in registers, only the
+// search direction lives in LDS for the gather; one-barrier reductions.  3 barriers per iteration instead of 6.
+// Needs n <= 2 * NTH (the caller falls back to cg_pressure otherwise).  x, r, p: LDS vectors as in cg_pressure.
+template <int NTH>
+__device__ inline int cg_pressure_reg(int n, const int32_t* sl_off, const int32_t* sl_col, const double* A, double rtol,
+                                      int maxit, double* x, double* r, double* p, double* red, int& rsel) {
+  constexpr int NW = NTH / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nsl = (n + 63) >> 6;
+  int base[2], wid[2], row[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int s_ = wave + NW * k;
+    row[k] = (s_ << 6) + lane;
+    base[k] = s_ < nsl ? sl_off[s_] : 0;
+    wid[k] = s_ < nsl ? (sl_off[s_ + 1] - base[k]) >> 6 : 0;
+  }
+  auto spmv = [&](const double* vec, double(&y)[2]) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const double* a = A + base[k] + lane;
+      const int32_t* c = sl_col + base[k] + lane;
+      double y0 = 0.0;
+#pragma unroll 4
+      for (int j = 0; j < wid[k]; ++j) y0 += a[j * 64] * vec[c[j * 64]];
+      y[k] = y0;
+    }
+  };
+  __syncthreads();
+  double y[2], xv[2], rv[2], pv[2];
+  spmv(x, y);
+  double acc[2] = {0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    xv[k] = rv[k] = pv[k] = 0.0;
+    if (row[k] < n) {
+      const double b = r[row[k]];
+      xv[k] = x[row[k]];
+      rv[k] = pv[k] = b - y[k];
+      p[row[k]] = pv[k];
+      acc[0] += b * b;
+      acc[1] += rv[k] * rv[k];
+    }
+  }
+  block_sum<2, NW>(acc, red);
+  const double bb = acc[0], tol2 = rtol * rtol * bb;
+  double rr = acc[1];
+  int it = 0;
+  if (rr > tol2 && bb != 0.0) {
+    while (it < maxit) {
+      ++it;
+      double q[2];
+      spmv(p, q);
+      double a1[1] = {pv[0] * q[0] + pv[1] * q[1]};
+      block_sum1<1, NW>(a1, red, rsel);
+      if (!(a1[0] > 0.0)) break;
+      const double alpha = rr / a1[0];
+      double a2[1] = {0.0};
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        xv[k] += alpha * pv[k];
+        rv[k] -= alpha * q[k];
+        a2[0] += rv[k] * rv[k];
+      }
+      block_sum1<1, NW>(a2, red, rsel);
+      const double rr_new = a2[0];
+      if (!(rr_new > tol2)) break;
+      const double beta = rr_new / rr;
+      rr = rr_new;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        pv[k] = rv[k] + beta * pv[k];
+        if (row[k] < n) p[row[k]] = pv[k];
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+    if (row[k] < n) x[row[k]] = xv[k];
+  __syncthreads();
+  return it;
+}
+
 #ifdef MDQ_AT_TRACE
 // debug build only: s_memtime deltas of thread 0 of environment 0 at the phase boundaries of at_velocity_kernel
 __device__ long long mdq_at_trace_buf[16];
@@ -2640,7 +2725,10 @@ __global__ __launch_bounds__(NTH) void at_pressure_kernel(mdq_ipcs_desc d, int32
 #endif
       pressure_direct<NTH>(pd, nv, pr, px, pp, pq, lK);
     } else {
-      it_p += cg_pressure(nv, so1, ci1, K1, d.rtol, d.maxit_p, px, pr, pp, pq, red);
+      if (nv <= 2 * NTH)
+        it_p += cg_pressure_reg<NTH>(nv, so1, ci1, K1, d.rtol, d.maxit_p, px, pr, pp, red, rsel);
+      else
+        it_p += cg_pressure(nv, so1, ci1, K1, d.rtol, d.maxit_p, px, pr, pp, pq, red);
     }
     for (int i = tid; i < nv; i += NTH) pnew[i] = px[i] / v.sdiagK[i];
     __syncthreads();
