@@ -99,6 +99,7 @@ class VecEnv2DAirfoil:
             self.dtopo = DeviceTopologyBatch(B, NV, NT, self.NE, self.NAF, N, self.EMAX, self.polygon, self.device,
                                              ipcs=self.flow_steps > 0, nse1_cap=nse1_cap)
         self._packed_host, self._packed_ev, self._pending, self._step_pending = None, torch.cuda.Event(), None, None
+        self._restore_args = None
         # the initial mesh on the device: source rows of the in-place resets (mdq_restore_rows)
         self._x0_dev = torch.from_numpy(np.ascontiguousarray(topo0.coords, dtype=np.float64)).to(self.device)
         self._cells0_dev = torch.from_numpy(np.ascontiguousarray(topo0.cells, dtype=np.int32)).to(self.device)
@@ -219,22 +220,28 @@ class VecEnv2DAirfoil:
             a[idx] = c["h"][k]
         self.new_drags[idx] = c["drags"]
         self.new_lifts[idx] = c["lifts"]
-        # device side: ONE launch restores the rows of every tensor (a dozen index_put launches otherwise)
-        pairs = [(self.u, c["u"]), (self.p, c["p"]), (self._coords_dev, self._x0_dev)]
-        if self.gpu_topology:
-            pairs += [(self.dtopo.t[k], c["dev"][k]) for k in self._STATE_KEYS]
-        if self.gpu_remesh:     # the device holds the meshes: reset them there as well
-            dt = self.dtopo
-            pairs += [(dt.cells, self._cells0_dev), (dt.nv, self._nv0_dev), (dt.nt, self._nt0_dev)]
-        n = len(pairs)
-        dst = (C.c_void_p * n)(*[a.data_ptr() for a, _ in pairs])
-        src = (C.c_void_p * n)(*[b_.data_ptr() for _, b_ in pairs])
-        nbytes = (C.c_int64 * n)(*[a[0].numel() * a.element_size() for a, _ in pairs])
-        for (a, b_), nb in zip(pairs, nbytes):
-            assert a.is_contiguous() and b_.is_contiguous() and b_.numel() * b_.element_size() == nb and a.dtype == b_.dtype
-        ti = torch.from_numpy(np.asarray(idx, dtype=np.int32)).to(self.device)
-        _lib.check(self.lib.mdq_restore_rows(n, dst, src, nbytes, int(ti.numel()), ti.data_ptr(), _lib.stream_ptr()),
-                   "mdq_restore_rows")
+        # device side: ONE launch restores the rows of every tensor (a dozen index_put launches otherwise).  The
+        # argument arrays are built once; only the two per-step buffers (u, p) change their addresses.
+        ra = self._restore_args
+        if ra is None or ra["coords"] != self._coords_dev.data_ptr():
+            pairs = [(self.u, c["u"]), (self.p, c["p"]), (self._coords_dev, self._x0_dev)]
+            if self.gpu_topology:
+                pairs += [(self.dtopo.t[k], c["dev"][k]) for k in self._STATE_KEYS]
+            if self.gpu_remesh:     # the device holds the meshes: reset them there as well
+                dt = self.dtopo
+                pairs += [(dt.cells, self._cells0_dev), (dt.nv, self._nv0_dev), (dt.nt, self._nt0_dev)]
+            n = len(pairs)
+            nbytes = [a[0].numel() * a.element_size() for a, _ in pairs]
+            for (a, b_), nb in zip(pairs, nbytes):
+                assert a.is_contiguous() and b_.is_contiguous() and b_.numel() * b_.element_size() == nb and a.dtype == b_.dtype
+            ra = self._restore_args = dict(n=n, dst=(C.c_void_p * n)(*[a.data_ptr() for a, _ in pairs]),
+                                           src=(C.c_void_p * n)(*[b_.data_ptr() for _, b_ in pairs]),
+                                           nbytes=(C.c_int64 * n)(*nbytes), coords=self._coords_dev.data_ptr(),
+                                           keep=pairs)
+        ra["dst"][0], ra["dst"][1] = self.u.data_ptr(), self.p.data_ptr()
+        ti = torch.from_numpy(idx.astype(np.int32)).to(self.device)
+        _lib.check(self.lib.mdq_restore_rows(ra["n"], ra["dst"], ra["src"], ra["nbytes"], int(ti.numel()), ti.data_ptr(),
+                                             _lib.stream_ptr()), "mdq_restore_rows")
 
     def _refresh(self):
         """Topology + selection, snapshot interpolation + forces on the GPU, for all envs."""
