@@ -306,6 +306,14 @@ int mdq_state_features(int32_t B, int32_t N, int32_t S, int32_t NV, int32_t NP, 
                        const double* p, const int32_t* n_closest, const int32_t* nsel, float* x, void* stream);
 
 /*
+ * Edge lists of the state graphs (Env2DAirfoil.get_state, Env2DAirfoil.py:258-280) from the padded per-environment
+ * arrays of mdq_env_topology to the packed form mdq_gcn_forward reads: the first edge_ptr[b+1] - edge_ptr[b]
+ * entries of src_pad / dst_pad [B][EMAX] go to esrc / edst [edge_ptr[b] ...).  All device pointers.
+ */
+int mdq_compact_edges(int32_t B, int32_t EMAX, const int32_t* src_pad, const int32_t* dst_pad, const int32_t* edge_ptr,
+                      int32_t* esrc, int32_t* edst, void* stream);
+
+/*
  * Env2DAirfoil.reset (Env2DAirfoil.py:102-129: mesh, snapshots and selection back to the initial ones) for a SUBSET
  * of the batched environments, in one launch: for each of the n (<= 16) device tensors dst[t], laid out [B][row_bytes[t]],
  * row idx[i] (i < n_idx) is overwritten with the cached initial row src[t].  dst / src / row_bytes are host arrays

@@ -174,6 +174,32 @@ extern "C" int mdq_restore_rows(int32_t n, void* const* dst, const void* const* 
   return 0;
 }
 
+namespace mdq_mesh {
+// blockIdx.x = environment: its first edge_ptr[b+1] - edge_ptr[b] padded entries -> the packed lists
+__global__ __launch_bounds__(256) void compact_edges_kernel(int EMAX, const int32_t* __restrict__ src_pad,
+                                                             const int32_t* __restrict__ dst_pad,
+                                                             const int32_t* __restrict__ edge_ptr, int32_t* __restrict__ esrc,
+                                                             int32_t* __restrict__ edst) {
+  const int b = blockIdx.x, e0 = edge_ptr[b], n = edge_ptr[b + 1] - e0;
+  const int32_t* s = src_pad + (int64_t)b * EMAX;
+  const int32_t* d = dst_pad + (int64_t)b * EMAX;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    esrc[e0 + i] = s[i];
+    edst[e0 + i] = d[i];
+  }
+}
+}  // namespace mdq_mesh
+
+extern "C" int mdq_compact_edges(int32_t B, int32_t EMAX, const int32_t* src_pad, const int32_t* dst_pad,
+                                 const int32_t* edge_ptr, int32_t* esrc, int32_t* edst, void* stream) {
+  if (B <= 0 || EMAX <= 0 || !src_pad || !dst_pad || !edge_ptr || !esrc || !edst)
+    return mdq_set_error("mdq_compact_edges: bad arguments");
+  hipLaunchKernelGGL(mdq_mesh::compact_edges_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, EMAX, src_pad, dst_pad,
+                     edge_ptr, esrc, edst);
+  if (hipGetLastError() != hipSuccess) return mdq_set_error("compact_edges_kernel launch failed");
+  return 0;
+}
+
 extern "C" int mdq_state_features(int32_t B, int32_t N, int32_t S, int32_t NV, int32_t NP, const double* coords,
                                   const double* u, const double* p, const int32_t* n_closest, const int32_t* nsel,
                                   float* x, void* stream) {

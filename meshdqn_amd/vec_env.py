@@ -100,6 +100,7 @@ class VecEnv2DAirfoil:
                                              ipcs=self.flow_steps > 0, nse1_cap=nse1_cap)
         self._packed_host, self._packed_ev, self._pending, self._step_pending = None, torch.cuda.Event(), None, None
         self._restore_args = None
+        self._deferred_mirror = None
         # the initial mesh on the device: source rows of the in-place resets (mdq_restore_rows)
         self._x0_dev = torch.from_numpy(np.ascontiguousarray(topo0.coords, dtype=np.float64)).to(self.device)
         self._cells0_dev = torch.from_numpy(np.ascontiguousarray(topo0.cells, dtype=np.int32)).to(self.device)
@@ -211,13 +212,14 @@ class VecEnv2DAirfoil:
         """Reset environments `idx` in place from the cached initial-mesh data (no recomputation)."""
         c = self._init_cache
         idx = np.asarray(idx)
-        self.coords[idx] = self.x0
-        self.cells[idx] = self.cells0
+        self._deferred_mirror = idx     # coords / cells host mirrors: written after the next state has been launched
         self.nv[idx], self.nt[idx] = self.NV, self.NT
         self.offset[idx] = 0
         self.steps[idx] = 0
-        for k, a in self.h.items():
-            a[idx] = c["h"][k]
+        # (device engine: only these are mirrored on the host, see _refresh_collect; the others are dead rows)
+        keys = ("nsel", "n_closest", "coord_map", "nedges", "ne") if self.gpu_topology else tuple(self.h)
+        for k in keys:
+            self.h[k][idx] = c["h"][k]
         self.new_drags[idx] = c["drags"]
         self.new_lifts[idx] = c["lifts"]
         # device side: ONE launch restores the rows of every tensor (a dozen index_put launches otherwise).  The
@@ -365,14 +367,15 @@ class VecEnv2DAirfoil:
         edge_ptr = np.zeros(B + 1, np.int32)
         edge_ptr[1:] = np.cumsum(ne)
         if self.gpu_topology:
-            # flat positions of the valid edge slots of the padded (B,EMAX) device arrays, env by env: a gather with a
-            # host-built index (the counts are on the host already) instead of a boolean mask, which costs a
-            # device-to-host synchronisation per indexed tensor
-            ne32 = h["nedges"].astype(np.int32)
-            idx = np.arange(int(edge_ptr[-1]), dtype=np.int32) + np.repeat(np.arange(B, dtype=np.int32) * self.EMAX - edge_ptr[:-1], ne32)
-            idx_d = torch.from_numpy(idx).to(dev)
-            esrc_d = self.dtopo.t["edge_src"].reshape(-1).index_select(0, idx_d)
-            edst_d = self.dtopo.t["edge_dst"].reshape(-1).index_select(0, idx_d)
+            # packed edge lists from the padded (B,EMAX) device arrays: one small kernel driven by the offsets (the counts
+            # are on the host already, so the output size is known without a device-to-host synchronisation)
+            total = int(edge_ptr[-1])
+            edge_ptr_d = torch.from_numpy(edge_ptr).to(dev)
+            esrc_d = torch.empty(total, dtype=torch.int32, device=dev)
+            edst_d = torch.empty(total, dtype=torch.int32, device=dev)
+            _lib.check(self.lib.mdq_compact_edges(B, self.EMAX, self.dtopo.t["edge_src"].data_ptr(),
+                                                  self.dtopo.t["edge_dst"].data_ptr(), edge_ptr_d.data_ptr(),
+                                                  esrc_d.data_ptr(), edst_d.data_ptr(), _lib.stream_ptr()), "mdq_compact_edges")
         else:
             live = np.arange(self.EMAX)[None, :] < ne[:, None]      # (B,EMAX) valid edge slots, row-major = env order
             esrc_d, edst_d = torch.from_numpy(h["edge_src"][live]).to(dev), torch.from_numpy(h["edge_dst"][live]).to(dev)
@@ -380,7 +383,7 @@ class VecEnv2DAirfoil:
         if self.gpu_topology:   # the padded (B,EMAX) edge lists as well (views of the engine's output, valid until
             pad = dict(edge_src_pad=self.dtopo.t["edge_src"], edge_dst_pad=self.dtopo.t["edge_dst"])   # the next step)
         return dict(x=x, esrc=esrc_d, edst=edst_d, **pad,
-                    edge_ptr=torch.from_numpy(edge_ptr).to(dev),
+                    edge_ptr=edge_ptr_d if self.gpu_topology else torch.from_numpy(edge_ptr).to(dev),
                     node_ptr=torch.arange(B + 1, dtype=torch.int32, device=dev) * N,
                     n_closest=h["n_closest"].copy(), coord_map=h["coord_map"].copy(), nedges=h["nedges"].copy(),
                     nsel=h["nsel"].copy())
@@ -476,7 +479,12 @@ class VecEnv2DAirfoil:
             infos.update(flow_drag=self.flow_drag.copy(), flow_lift=self.flow_lift.copy())
         if self.auto_reset and dones.any():
             self._restore_initial(np.flatnonzero(dones))
-        return self.get_state(), rewards, dones, infos
+        state = self.get_state()
+        if self._deferred_mirror is not None:   # (off the critical path: the GPU is already working on the next state)
+            self.coords[self._deferred_mirror] = self.x0
+            self.cells[self._deferred_mirror] = self.cells0
+            self._deferred_mirror = None
+        return state, rewards, dones, infos
 
 
 class VecEnvGroups:

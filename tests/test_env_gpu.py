@@ -448,3 +448,23 @@ def test_restore_rows_overwrites_exactly_the_listed_rows(lib_built):
     bad = (C.c_int64 * n)(6, 20, 4)                                                            # 6 bytes: not a multiple of 4
     assert lib.mdq_restore_rows(n, dst, src, bad, 3, idx.data_ptr(), _lib.stream_ptr()) != 0
     assert b"4-byte" in lib.mdq_last_error()
+
+
+def test_compact_edges_matches_mask_indexing(lib_built):
+    """mdq_compact_edges through the C ABI: packed edge lists == boolean-mask indexing of the padded arrays."""
+    from meshdqn_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    B, EM = 7, 96
+    cnt = rng.integers(0, EM + 1, size=B); cnt[3] = 0; cnt[5] = EM
+    sp = torch.from_numpy(rng.integers(0, 180, size=(B, EM)).astype(np.int32)).cuda()
+    dp = torch.from_numpy(rng.integers(0, 180, size=(B, EM)).astype(np.int32)).cuda()
+    ep = np.zeros(B + 1, np.int32); ep[1:] = np.cumsum(cnt)
+    ep_d = torch.from_numpy(ep).cuda()
+    es = torch.full((int(ep[-1]),), -7, dtype=torch.int32, device="cuda"); ed = es.clone()
+    _lib.check(lib.mdq_compact_edges(B, EM, sp.data_ptr(), dp.data_ptr(), ep_d.data_ptr(), es.data_ptr(), ed.data_ptr(),
+                                     _lib.stream_ptr()), "mdq_compact_edges")
+    torch.cuda.synchronize()
+    live = torch.from_numpy(np.arange(EM)[None, :] < cnt[:, None]).cuda()
+    assert torch.equal(es, sp[live]) and torch.equal(ed, dp[live])
+    assert lib.mdq_compact_edges(0, EM, sp.data_ptr(), dp.data_ptr(), ep_d.data_ptr(), es.data_ptr(), ed.data_ptr(), _lib.stream_ptr()) != 0
