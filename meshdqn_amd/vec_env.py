@@ -101,6 +101,7 @@ class VecEnv2DAirfoil:
         self._packed_host, self._packed_ev, self._pending, self._step_pending = None, torch.cuda.Event(), None, None
         self._restore_args = None
         self._deferred_mirror = None
+        self._node_ptr = torch.arange(B + 1, dtype=torch.int32, device=self.device) * N   # (constant: N rows per graph)
         # the initial mesh on the device: source rows of the in-place resets (mdq_restore_rows)
         self._x0_dev = torch.from_numpy(np.ascontiguousarray(topo0.coords, dtype=np.float64)).to(self.device)
         self._cells0_dev = torch.from_numpy(np.ascontiguousarray(topo0.cells, dtype=np.int32)).to(self.device)
@@ -384,7 +385,7 @@ class VecEnv2DAirfoil:
             pad = dict(edge_src_pad=self.dtopo.t["edge_src"], edge_dst_pad=self.dtopo.t["edge_dst"])   # the next step)
         return dict(x=x, esrc=esrc_d, edst=edst_d, **pad,
                     edge_ptr=edge_ptr_d if self.gpu_topology else torch.from_numpy(edge_ptr).to(dev),
-                    node_ptr=torch.arange(B + 1, dtype=torch.int32, device=dev) * N,
+                    node_ptr=self._node_ptr,
                     n_closest=h["n_closest"].copy(), coord_map=h["coord_map"].copy(), nedges=h["nedges"].copy(),
                     nsel=h["nsel"].copy())
 
