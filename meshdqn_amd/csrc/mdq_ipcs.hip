@@ -410,10 +410,25 @@ __global__ __launch_bounds__(WG) void assemble_kernel(mdq_ipcs_desc d) {
 // geometry, outflow-row blocks, Jacobi diagonals and Dirichlet lifting vectors of A1 / M accumulated row-wise from
 // the element matrices (dof <- element-slot gathers g2/g1), the scaled + BC-eliminated P1 Laplacian in SELL-64.
 // Same numbers as assemble_kernel up to the summation order.  One workgroup per environment.
+#ifdef MDQ_SETUP_TRACE
+__device__ long long mdq_st_trace_buf[16];
+#define ST_STAMP(k) { __syncthreads(); const long long tn_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) mdq_st_trace_buf[k] += tn_ - tq_; tq_ = tn_; }
+extern "C" int mdq_st_trace_host(long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mdq_st_trace_buf), sizeof(long long) * 16) != hipSuccess) return -1;
+  if (reset) { long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(mdq_st_trace_buf), z, sizeof z) != hipSuccess) return -1; }
+  return 0;
+}
+#else
+#define ST_STAMP(k)
+#endif
+
 __global__ __launch_bounds__(WG) void setup_matfree_kernel(mdq_ipcs_desc d) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const EnvView v = env_view(d, b);
   const double a = d.rho / d.dt, mu = d.mu;
+#ifdef MDQ_SETUP_TRACE
+  long long tq_ = __builtin_amdgcn_s_memtime();
+#endif
   for (int e = tid; e < v.nt; e += WG) {
     double X[3][2];
     load_cell_coords(v, e, X);
@@ -427,6 +442,7 @@ __global__ __launch_bounds__(WG) void setup_matfree_kernel(mdq_ipcs_desc d) {
     v.geom[4 * v.NT + e] = fabs(det);
   }
   __syncthreads();
+  ST_STAMP(0)
   if (v.nbo > 0) {
     const int nbe = v.bo_ptr[v.nbo];
     for (int t = tid; t < nbe; t += WG) {
@@ -438,6 +454,7 @@ __global__ __launch_bounds__(WG) void setup_matfree_kernel(mdq_ipcs_desc d) {
       reinterpret_cast<double4*>(v.bo_val)[t] = make_double4(Bcd[0][0], Bcd[0][1], Bcd[1][0], Bcd[1][1]);
     }
   }
+  ST_STAMP(1)
   // ---- P2 rows: raw diagonals (kept in idiag1 / sdiagM until the outflow rows have been corrected) and lifts
   for (int r = tid; r < v.n2; r += WG) {
     double l1x = 0.0, l1y = 0.0, l3x = 0.0, dx = 0.0, dy = 0.0, dm = 0.0;
@@ -446,9 +463,20 @@ __global__ __launch_bounds__(WG) void setup_matfree_kernel(mdq_ipcs_desc d) {
       const int e = slot / 6, i = slot - e * 6;
       const Geo g = load_geo(v, e);
       const double Ja[2][2] = {{g.j00, g.j01}, {g.j10, g.j11}};
+      // the six dofs of the cell, then their Dirichlet flags and values: three batches of loads instead of one
+      // dependent chain per local column
+      int cj[6];
+      bool fj[6];
+      double gj[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) cj[j] = v.cell_dofs[j * v.NT + e];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) fj[j] = v.bcu_flag[cj[j]] != 0;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) gj[j] = v.bcu_gx[cj[j]];
+#pragma unroll
       for (int j = 0; j < 6; ++j) {
-        const int c = v.cell_dofs[j * v.NT + e];
-        const bool fc = v.bcu_flag[c] != 0;
+        const bool fc = fj[j];
         if (j != i && !fc) continue;
         const double m = g.det * c_tab.Mhat[i][j];
         const double g00 = c_tab.Ghat[0][0][i][j], g01 = c_tab.Ghat[0][1][i][j];
@@ -464,7 +492,7 @@ __global__ __launch_bounds__(WG) void setup_matfree_kernel(mdq_ipcs_desc d) {
           dm += m;
         }
         if (fc) {
-          const double gx = v.bcu_gx[c];
+          const double gx = gj[j];
           l1x += bx * gx;
           l1y += bz * gx;
           l3x += m * gx;
@@ -477,6 +505,7 @@ __global__ __launch_bounds__(WG) void setup_matfree_kernel(mdq_ipcs_desc d) {
     v.sdiagM[r] = dm;
   }
   __syncthreads();
+  ST_STAMP(2)
   // outflow rows: - mu/2 B on the diagonal and in the lifts (one thread per row: no conflicts)
   for (int t = tid; t < v.nbo; t += WG) {
     const int row = v.bo_rows[t];
@@ -504,6 +533,7 @@ __global__ __launch_bounds__(WG) void setup_matfree_kernel(mdq_ipcs_desc d) {
     v.idiag1[r] = fr ? make_double2(1.0, 1.0) : make_double2(1.0 / dg.x, 1.0 / dg.y);
     v.sdiagM[r] = fr ? 1.0 : sqrt(v.sdiagM[r]);
   }
+  ST_STAMP(3)
   // ---- P1 Laplacian: entry (r, c) = sum over the cells of r that contain c of |T| grad(l_r).grad(l_c)
   auto k1_entry = [&](int r, int c) {
     double kk = 0.0;
@@ -524,10 +554,65 @@ __global__ __launch_bounds__(WG) void setup_matfree_kernel(mdq_ipcs_desc d) {
   };
   for (int r = tid; r < v.nv; r += WG) v.sdiagK[r] = v.bcp_flag[r] ? 1.0 : sqrt(k1_entry(r, r));
   __syncthreads();
+  ST_STAMP(4)
   const int rows1 = ((v.nv + 63) >> 6) << 6;
+  constexpr int KW = 16;   // widest row handled by the one-pass path (vertex degree + 1; wider rows: generic path)
   for (int r = tid; r < rows1; r += WG) {
     const int off = v.sl1_off[r >> 6];
     const int width = (v.sl1_off[(r >> 6) + 1] - off) >> 6;
+    if (width <= KW) {
+      // ONE pass over the cells of the row: every cell adds its three entries (r, c_q) to the row's column list held in
+      // registers (the generic path walks all cells of the row again for every entry: 7x the dependent loads; it
+      // was 47 % of this kernel).  Same contributions in the same (cell) order per entry: same bits.
+      int cols[KW];
+      double vals[KW];
+      int prev = -1;
+#pragma unroll
+      for (int j = 0; j < KW; ++j) {
+        int c = -1;
+        if (j < width && r < v.nv) {
+          c = v.sl1_col[off + j * 64 + (r & 63)];
+          if (c > prev) prev = c; else c = -1;   // (columns ascend; the padding repeats the row index)
+        }
+        cols[j] = c;
+        vals[j] = 0.0;
+      }
+      if (r < v.nv) {
+        if (v.bcp_flag[r]) {
+#pragma unroll
+          for (int j = 0; j < KW; ++j) vals[j] = cols[j] == r ? 1.0 : 0.0;
+        } else {
+          for (int s_ = v.g1_ptr[r]; s_ < v.g1_ptr[r + 1]; ++s_) {
+            const int slot = v.g1_src[s_];
+            const int e = slot / 3, i = slot - e * 3;
+            const Geo g = load_geo(v, e);
+            int cq[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) cq[q] = v.cell_dofs[q * v.NT + e];
+            const double dix = sel3(i, -g.j00 - g.j10, g.j00, g.j10), diy = sel3(i, -g.j01 - g.j11, g.j01, g.j11);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+              const double djx = sel3(q, -g.j00 - g.j10, g.j00, g.j10), djy = sel3(q, -g.j01 - g.j11, g.j01, g.j11);
+              const double val = 0.5 * g.det * (dix * djx + diy * djy);
+#pragma unroll
+              for (int j = 0; j < KW; ++j) vals[j] += cols[j] == cq[q] ? val : 0.0;
+            }
+          }
+          const double sr = v.sdiagK[r];
+#pragma unroll
+          for (int j = 0; j < KW; ++j) {
+            if (cols[j] >= 0) {
+              const int c = cols[j];
+              vals[j] = v.bcp_flag[c] ? (c == r ? 1.0 : 0.0) : vals[j] / (sr * v.sdiagK[c]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < KW; ++j)
+        if (j < width) v.K1s[off + j * 64 + (r & 63)] = cols[j] >= 0 ? vals[j] : 0.0;
+      continue;
+    }
     int prev = -1;
     for (int j = 0; j < width; ++j) {
       const int ps = off + j * 64 + (r & 63);
@@ -545,6 +630,7 @@ __global__ __launch_bounds__(WG) void setup_matfree_kernel(mdq_ipcs_desc d) {
       v.K1s[ps] = kk;
     }
   }
+  ST_STAMP(5)
 }
 
 // ================================================================== element right-hand sides

@@ -1,0 +1,28 @@
+"""Debug: per-phase s_memtime cycles of setup_matfree_kernel (library built with MDQ_CFLAGS=-DMDQ_SETUP_TRACE)."""
+import ctypes, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from meshdqn_amd import _lib
+from meshdqn_amd.vec_env import VecEnv2DAirfoil
+G = os.path.join(ROOT, "tests", "golden")
+cfg = dict(flow_config=dict(flow_params=dict(mu=1e-3, rho=1.0, inflow="constant"), geometry_params=dict(mesh=os.path.join(G, "ys930.npz")),
+                            solver_params=dict(dt=0.001, solver_type="lu", smooth=True)),
+           agent_params=dict(solver_steps=200, episodes=10, timesteps=10000, threshold=0.001, N_closest=180, gt_drag=-1, gt_time=-1, u=-1, p=-1,
+                             time_reward=0.005, save_steps=40, goal_vertices=0.95, plot_dir=""))
+venv = VecEnv2DAirfoil(cfg, 128, flow_steps=1)
+lib = ctypes.CDLL(_lib.LIB_PATH)
+buf = (ctypes.c_longlong * 16)()
+rng = np.random.default_rng(0)
+for _ in range(3):
+    venv.step(rng.integers(0, 181, 128))
+torch.cuda.synchronize(); lib.mdq_st_trace_host(buf, 1)
+n = 10
+for _ in range(n):
+    venv.step(rng.integers(0, 181, 128))
+torch.cuda.synchronize(); lib.mdq_st_trace_host(buf, 0)
+names = ["geometry", "outflow entries", "P2 rows: diagonals + lifting vectors", "outflow rows + inverses", "P1 diagonal", "P1 Laplacian SELL values"]
+tot = sum(buf[:6])
+print(f"setup_matfree_kernel, mesh 0: {tot / n:.0f} ticks per launch")
+for k, nm in enumerate(names):
+    print(f"{k} {nm:40s} {buf[k] / n:9.0f}  {100.0 * buf[k] / max(tot, 1):5.1f} %")
