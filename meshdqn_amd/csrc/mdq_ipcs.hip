@@ -426,6 +426,12 @@ __global__ __launch_bounds__(WG) void setup_matfree_kernel(mdq_ipcs_desc d) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const EnvView v = env_view(d, b);
   const double a = d.rho / d.dt, mu = d.mu;
+  // reference-element tables in LDS: the row loops index them with the (lane-dependent) local row of a slot; from
+  // constant memory that is one more dependent round trip per local column inside the conditional column loop
+  __shared__ double sMhat[6][6];
+  __shared__ double sGhat[2][2][6][6];
+  for (int q = tid; q < 36; q += WG) sMhat[q / 6][q % 6] = c_tab.Mhat[q / 6][q % 6];
+  for (int q = tid; q < 144; q += WG) sGhat[q / 72][(q / 36) % 2][(q / 6) % 6][q % 6] = c_tab.Ghat[q / 72][(q / 36) % 2][(q / 6) % 6][q % 6];
 #ifdef MDQ_SETUP_TRACE
   long long tq_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -458,44 +464,75 @@ __global__ __launch_bounds__(WG) void setup_matfree_kernel(mdq_ipcs_desc d) {
   // ---- P2 rows: raw diagonals (kept in idiag1 / sdiagM until the outflow rows have been corrected) and lifts
   for (int r = tid; r < v.n2; r += WG) {
     double l1x = 0.0, l1y = 0.0, l3x = 0.0, dx = 0.0, dy = 0.0, dm = 0.0;
-    for (int s = v.g2_ptr[r]; s < v.g2_ptr[r + 1]; ++s) {
-      const int slot = v.g2_src[s];
-      const int e = slot / 6, i = slot - e * 6;
-      const Geo g = load_geo(v, e);
-      const double Ja[2][2] = {{g.j00, g.j01}, {g.j10, g.j11}};
-      // the six dofs of the cell, then their Dirichlet flags and values: three batches of loads instead of one
-      // dependent chain per local column
-      int cj[6];
-      bool fj[6];
-      double gj[6];
+    // incident cells two at a time: the four dependent load levels of a cell (slot -> geometry / dofs -> Dirichlet
+    // flags -> values) are paid once per pair; the second cell of an odd tail is the first one again, not added
+    const int s0 = v.g2_ptr[r], s1 = v.g2_ptr[r + 1];
+    for (int s = s0; s < s1; s += 2) {
+      const bool two = s + 1 < s1;
+      int ee[2], ii[2];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) cj[j] = v.cell_dofs[j * v.NT + e];
+      for (int u = 0; u < 2; ++u) {
+        const int slot = v.g2_src[(u == 1 && two) ? s + 1 : s];
+        ee[u] = slot / 6;
+        ii[u] = slot - ee[u] * 6;
+      }
+      Geo gg[2];
+      int cj[2][6];
+      bool fj[2][6];
+      double gj[2][6];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) fj[j] = v.bcu_flag[cj[j]] != 0;
+      for (int u = 0; u < 2; ++u) {
+        gg[u] = load_geo(v, ee[u]);
 #pragma unroll
-      for (int j = 0; j < 6; ++j) gj[j] = v.bcu_gx[cj[j]];
+        for (int j = 0; j < 6; ++j) cj[u][j] = v.cell_dofs[j * v.NT + ee[u]];
+      }
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const bool fc = fj[j];
-        if (j != i && !fc) continue;
-        const double m = g.det * c_tab.Mhat[i][j];
-        const double g00 = c_tab.Ghat[0][0][i][j], g01 = c_tab.Ghat[0][1][i][j];
-        const double g10 = c_tab.Ghat[1][0][i][j], g11 = c_tab.Ghat[1][1][i][j];
-        const double kxx = g.det * (Ja[0][0] * (Ja[0][0] * g00 + Ja[1][0] * g01) + Ja[1][0] * (Ja[0][0] * g10 + Ja[1][0] * g11));
-        const double kxy = g.det * (Ja[0][0] * (Ja[0][1] * g00 + Ja[1][1] * g01) + Ja[1][0] * (Ja[0][1] * g10 + Ja[1][1] * g11));
-        const double kyy = g.det * (Ja[0][1] * (Ja[0][1] * g00 + Ja[1][1] * g01) + Ja[1][1] * (Ja[0][1] * g10 + Ja[1][1] * g11));
-        const double L = kxx + kyy;
-        const double bx = a * m + 0.5 * mu * (L + kxx), bz = 0.5 * mu * kxy, bw = a * m + 0.5 * mu * (L + kyy);
-        if (j == i) {
-          dx += bx;
-          dy += bw;
-          dm += m;
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) fj[u][j] = v.bcu_flag[cj[u][j]] != 0;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) gj[u][j] = v.bcu_gx[cj[u][j]];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (u == 1 && !two) break;
+        const Geo g = gg[u];
+        const int i = ii[u];
+        const double Ja[2][2] = {{g.j00, g.j01}, {g.j10, g.j11}};
+        // row i of the reference tables, read in one batch in front of the (conditional) column loop
+        double mh[6], gh[4][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          mh[j] = sMhat[i][j];
+          gh[0][j] = sGhat[0][0][i][j];
+          gh[1][j] = sGhat[0][1][i][j];
+          gh[2][j] = sGhat[1][0][i][j];
+          gh[3][j] = sGhat[1][1][i][j];
         }
-        if (fc) {
-          const double gx = gj[j];
-          l1x += bx * gx;
-          l1y += bz * gx;
-          l3x += m * gx;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const bool fc = fj[u][j];
+          if (j != i && !fc) continue;
+          const double m = g.det * mh[j];
+          const double g00 = gh[0][j], g01 = gh[1][j];
+          const double g10 = gh[2][j], g11 = gh[3][j];
+          const double kxx = g.det * (Ja[0][0] * (Ja[0][0] * g00 + Ja[1][0] * g01) + Ja[1][0] * (Ja[0][0] * g10 + Ja[1][0] * g11));
+          const double kxy = g.det * (Ja[0][0] * (Ja[0][1] * g00 + Ja[1][1] * g01) + Ja[1][0] * (Ja[0][1] * g10 + Ja[1][1] * g11));
+          const double kyy = g.det * (Ja[0][1] * (Ja[0][1] * g00 + Ja[1][1] * g01) + Ja[1][1] * (Ja[0][1] * g10 + Ja[1][1] * g11));
+          const double L = kxx + kyy;
+          const double bx = a * m + 0.5 * mu * (L + kxx), bz = 0.5 * mu * kxy, bw = a * m + 0.5 * mu * (L + kyy);
+          if (j == i) {
+            dx += bx;
+            dy += bw;
+            dm += m;
+          }
+          if (fc) {
+            const double gx = gj[u][j];
+            l1x += bx * gx;
+            l1y += bz * gx;
+            l3x += m * gx;
+          }
         }
       }
     }
