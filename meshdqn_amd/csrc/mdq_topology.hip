@@ -472,6 +472,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     }
     __syncthreads();
   }
+  TT_STAMP(7)
   // outflow facets: pressure Dirichlet vertices, cell -> local facet, entries (row, col, src) of the facet term
   for (int e = tid; e < TNS; e += TW) scanb[e] = (e < ne && (eflag[e] >> 4) == 4) ? 1 : 0;
   __syncthreads();
@@ -562,6 +563,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
       return;
     }
   }
+  TT_STAMP(8)
   // packed per-triangle metadata
   for (int i = 0; i < 6; ++i)
     for (int t = tid; t < nt; t += TW) scat[i * D.NT + t] = cd[i * D.NT + t] | (i == 0 ? ((int32_t)(cof[t] + 1) << 28) : 0);
@@ -597,8 +599,11 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     }
     __syncthreads();
   };
+  TT_STAMP(9)
   gather(3, nv, O.g1_ptr + Bq * (D.NV + 1), O.g1_src + Bq * 3 * D.NT);
+  TT_STAMP(10)
   gather(6, n2, O.g2_ptr + Bq * (D.NP + 1), O.g2_src + Bq * 6 * D.NT);
+  TT_STAMP(11)
   // SELL-64 pattern of the P1 Laplacian: row = {vertex} + neighbours, ascending; slice width = longest row
   for (int i = tid; i < TNS; i += TW) scanb[i] = i < nv ? 1 : 0;   // the diagonal
   __syncthreads();
