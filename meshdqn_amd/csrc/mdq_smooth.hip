@@ -59,6 +59,14 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
   return y;
 }
 
+// 1/x to double precision (~1 ulp): hardware estimate + two Newton steps
+__device__ __forceinline__ double rcp_nr(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = y * (2.0 - x * y);
+  y = y * (2.0 - x * y);
+  return y;
+}
+
 __device__ __forceinline__ double grp_min(double v) {
   v = fmin(v, dpp8<0xB1>(v));
   v = fmin(v, dpp8<0x4E>(v));
@@ -230,7 +238,10 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
 #ifdef MDQ_SMOOTH_NOMATH
         rm = fmin(rm, fabs(ty * (px - ax) - tx * (py - ay)));
 #else
-        rm = fmin(rm, fabs(ty * (px - ax) - tx * (py - ay)) * rsqrt_nr(tx * tx + ty * ty));
+        // SQUARED distance to the line through the opposite edge: the comparison with the step length below is done
+        // on squares, so that the common case (full step to the centroid) needs no square root at all
+        const double cr = ty * (px - ax) - tx * (py - ay);
+        rm = fmin(rm, cr * cr * rcp_nr(tx * tx + ty * ty));
 #endif
       }
       // lane 0 carries the x component, lane 1 the y component (same instruction stream: free)
@@ -268,16 +279,19 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
       const double dc_ = sc * rcp2k[k] - pc;                // lane 0: dx, lane 1: dy
       const double dother = dpp8<0xB1>(dc_);                // the other component
       const double q2 = dc_ * dc_ + dother * dother;        // (x*x + y*y in lane 0, y*y + x*x in lane 1: same bits)
-#ifdef MDQ_SMOOTH_NOMATH
-      const double ir = 1.0;
-#else
-      const double ir = rsqrt_nr(q2);
-#endif
-      const double r = q2 * ir;
+      // rm holds the SQUARED minimum altitude.  |c - p| <= r_min / 2  <=>  q2 <= rm / 4: the vertex moves to the
+      // centroid itself (p + d: the reference's p + r (d / r) up to one rounding); only a LIMITED step needs the
+      // lengths (two reciprocal square roots, off the common path)
       if (l < 2) {
-        if (!(r < EPS) && q2 > 0.0) {
-          const double stp = (0.5 * rm < r) ? 0.5 * rm : r;
-          const double pn = pc + (stp * ir) * dc_;
+        if (q2 >= EPS * EPS && q2 > 0.0) {
+          double pn = pc + dc_;
+#ifndef MDQ_SMOOTH_NOMATH
+          if (0.25 * rm < q2) {
+            const double ir = rsqrt_nr(q2);
+            const double rmin = rm * rsqrt_nr(rm);   // sqrt(rm)
+            pn = pc + (0.5 * rmin * ir) * dc_;
+          }
+#endif
           __hip_atomic_store(l == 0 ? &pos[v].x : &pos[v].y, pn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
