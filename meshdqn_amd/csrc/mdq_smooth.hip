@@ -295,7 +295,10 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
           __hip_atomic_store(l == 0 ? &pos[v].x : &pos[v].y, pn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      // (the position stores and the counter store below go to LDS from the SAME wave: the LDS executes a wave's
+      // operations in issue order, so a compiler-level fence is enough - the workgroup-scope release fence waited
+      // for the position stores to complete before the counter store could even be issued, on the critical path)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       if (l == 0) __hip_atomic_store(&done[v], s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifdef MDQ_SMOOTH_TRACE
       if (trace && b == 0 && l == 0) {
