@@ -207,11 +207,15 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
     }
     // poll: sweep counters of the neighbours in my cell(s) (cells l, l + 8, ...; the first one from registers)
     bool ok = true;
-    if (l < k) ok = LD_DONE(a0) >= (a0 < v ? s + 1 : s) && LD_DONE(c0) >= (c0 < v ? s + 1 : s);
+    if (l < k) {   // both counters loaded before either is tested: ONE LDS round trip per poll (a short-circuit `&&`
+      const int da = LD_DONE(a0), dc = LD_DONE(c0);   // made the second load wait for the first, on the critical path)
+      ok = (da >= (a0 < v ? s + 1 : s)) & (dc >= (c0 < v ? s + 1 : s));
+    }
     for (int q = l + GRP; q < k; q += GRP) {
       const uint32_t w = inc[q0 + q];
       const int a = w & 0x3FF, c = (w >> 10) & 0x3FF;
-      ok = ok && LD_DONE(a) >= (a < v ? s + 1 : s) && LD_DONE(c) >= (c < v ? s + 1 : s);
+      const int da = LD_DONE(a), dc = LD_DONE(c);
+      ok = ok & (da >= (a < v ? s + 1 : s)) & (dc >= (c < v ? s + 1 : s));
     }
     const unsigned long long bal = __ballot(ok);
     constexpr unsigned long long GMASK = (1ull << GRP) - 1;
