@@ -224,6 +224,10 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
 #ifdef MDQ_SMOOTH_TRACE
       const long long t_ready = clock64();
 #endif
+#ifndef MDQ_SMOOTH_NOPRIO
+      // a wave that computes an update outranks the waves that only poll (they share the SIMD's issue slots)
+      __builtin_amdgcn_s_setprio(3);
+#endif
       // (a counter that is high enough guarantees that a position read after it is the right version: the
       // neighbour cannot advance again before this vertex has; LDS operations of a wave complete in order)
       const double px = LD_X(v), py = LD_Y(v);
@@ -316,7 +320,15 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
         ++s;
       }
       fresh = true;
+#ifndef MDQ_SMOOTH_NOPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
+#ifdef MDQ_SMOOTH_SLEEP
+    else if (bal == 0) {
+      __builtin_amdgcn_s_sleep(MDQ_SMOOTH_SLEEP);
+    }
+#endif
   }
 #undef LD_DONE
 #undef LD_X
