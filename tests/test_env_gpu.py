@@ -468,3 +468,29 @@ def test_compact_edges_matches_mask_indexing(lib_built):
     live = torch.from_numpy(np.arange(EM)[None, :] < cnt[:, None]).cuda()
     assert torch.equal(es, sp[live]) and torch.equal(ed, dp[live])
     assert lib.mdq_compact_edges(0, EM, sp.data_ptr(), dp.data_ptr(), ep_d.data_ptr(), es.data_ptr(), ed.data_ptr(), _lib.stream_ptr()) != 0
+
+
+@pytest.mark.parametrize("name", ["ys930", "ah93w145"])
+def test_gpu_smoothing_is_bitwise_reproducible(lib_built, meshes, name):
+    """The dataflow smoothing kernel hands positions from wave to wave through LDS with relaxed atomics and a
+    wavefront-scope fence: any stale read would show up as a difference between environments or launches."""
+    from meshdqn_amd.ipcs_batch import smooth_coords
+    from meshdqn_amd.mesh_ops import smooth_batch_gpu
+    from meshdqn_amd.topology import MeshTopology
+    coords, cells = meshes[name]
+    ref = smooth_coords(MeshTopology(coords, cells), 50)
+    B = 192
+    c0 = torch.from_numpy(np.repeat(np.asarray(coords, np.float64)[None], B, 0).copy()).cuda()
+    ct = torch.from_numpy(np.repeat(np.sort(np.asarray(cells), 1)[None].astype(np.int32), B, 0).copy()).cuda()
+    nv = torch.full((B,), len(coords), dtype=torch.int32, device="cuda")
+    nt = torch.full((B,), len(cells), dtype=torch.int32, device="cuda")
+    it = torch.full((B,), 50, dtype=torch.int32, device="cuda")
+    first = None
+    for _ in range(6):
+        c = c0.clone()
+        smooth_batch_gpu(c, ct, nv, nt, it)
+        out = c.cpu().numpy()
+        assert (out == out[0]).all()
+        first = out[0].copy() if first is None else first
+        assert (out[0] == first).all()
+    assert np.abs(first - ref).max() < 1e-13
