@@ -3,34 +3,67 @@
 // The algorithm is a Gauss-Seidel sweep over the interior vertices IN INDEX ORDER, repeated n times:
 //   c = mean of the edge-connected neighbours, r_min = min distance from the vertex to the lines through the
 //   opposite edges of its cells, p <- p + min(|c-p|, r_min/2) (c-p)/|c-p|.
-// Update (sweep s, vertex v) needs neighbour w's value of sweep s if w < v and of sweep s-1 if w > v.  That
-// dependency graph has only ~6 independent updates per level on the reference meshes (ys930: 34 700 updates in
-// 5 454 levels), so the kernel is a latency-bound DATAFLOW machine, one 512-thread workgroup per mesh out of LDS:
-// 64 groups of 8 lanes, group g owns the interior vertices of rank g, g+64, ... and walks them in
-// (sweep, index) order; the 8 lanes take one incident cell each (sqrt + division per cell in parallel), combine
-// with DPP, lane 0 publishes the new position and then the vertex's sweep counter; readiness is checked against
-// the neighbours' counters.  The globally smallest unfinished update is always at the head of its group and
-// always ready, so the machine cannot deadlock.  Cell contributions are summed in a fixed lane order: results
-// are bitwise reproducible and agree with the sequential host loop to round-off (different association).
+// Inside a sweep vertex v needs the new value of its neighbours w < v and the old value of w > v, so the updates of
+// one sweep form a dependency graph whose depth is the longest ascending path of the mesh numbering: 113 levels
+// for the 694 interior vertices of ys930 (the ring of consecutively numbered vertices around the airfoil), 6 updates
+// per level on average.  That is a LATENCY problem (34 700 updates, ~5 500 of them in sequence), and one wavefront
+// runs it faster than eight did: a first version polled per-vertex sweep counters from 64 queue-owning lane groups
+// in 8 waves (dataflow); its waves were busy a quarter of the time, every hand-off paid a poll, and an update waited
+// on average several thousand cycles for its group to reach it (in-order queues).  Now:
+//   * the setup phase (256 threads) level-schedules one sweep (level = 1 + max level of the lower interior
+//     neighbours) and packs each level into passes of up to 8 independent updates;
+//   * ONE wave walks the passes, sweep after sweep, 8 lanes per update (one incident cell each): no flags, no
+//     polling, no barriers - the LDS serves a wave's operations in order, so the position loads of a pass see the
+//     stores of the pass before;
+//   * a vertex record holds (x, y, y, x): odd lanes read the swapped pair, so that the first stage of the centroid
+//     reduction exchanges the component a lane does NOT keep - x and y are summed over the 8 lanes with three
+//     exchanges instead of six (even lanes end with the x sum, odd lanes with the y sum);
+//   * the step limit |c - p| <= r_min / 2 is DECIDED in fp32 with a safety margin (squared altitudes by one
+//     v_rcp_f32, 8-lane minimum by three integer minima on the bit patterns); only an undecided or limited update
+//     (none on the reference meshes) runs the exact fp64 path, which also handles degree > 8;
+//   * the metadata of a pass (record addresses of each lane's cell) is prefetched one pass ahead, its vertex list
+//     two passes ahead.
+// Updates of one pass are independent and every reduction is group-local in a fixed lane order: results are
+// bitwise reproducible and agree with the sequential host loop to round-off (different association).
 #include <hip/hip_runtime.h>
 
 #include "../../include/meshdqn_hip.h"
 
 namespace mdq_smoothing {
 
-constexpr int SNV = 1024;      // vertex capacity (ids must fit 10 bits)
+constexpr int SNV = 1024;      // vertex capacity (record offsets must fit 16 bits)
 constexpr int SNT = 2048;      // triangle capacity (cell id must fit 12 bits)
-#ifndef MDQ_SMOOTH_WG
-#define MDQ_SMOOTH_WG 512
-#endif
-constexpr int SWG = MDQ_SMOOTH_WG;  // threads per workgroup: 8 waves measured best (256: 3.9 ms, 512: 3.4 ms, 1024: 3.9 ms for ys930)
-                               // issue slots from the group on the critical path
-#ifndef MDQ_SMOOTH_GRP
-#define MDQ_SMOOTH_GRP 8
-#endif
-constexpr int GRP = MDQ_SMOOTH_GRP;  // lanes per vertex update (8 or 16)
-constexpr int NGRP = SWG / GRP;
+constexpr int SWG = 256;       // threads per workgroup (setup phase; the sweeps run in wave 0)
+constexpr int GRP = 8;         // lanes per vertex update
 constexpr int PER = SNV / SWG; // entries per thread in the setup scans
+constexpr int REC = 32;        // bytes per vertex record: x, y, y, x
+constexpr int ZREC = SNV * REC;        // all-zero record: the unused lanes of a vertex with fewer than 8 cells, empty pass slots
+constexpr int AREC = (SNV + 1) * REC;  // (0, -1000) and
+constexpr int CREC = (SNV + 2) * REC;  // (1, -1000): the far-away edge that keeps an empty pass slot on the fast path
+constexpr int ROW = 48;        // bytes per metadata row of an interior vertex: 8 lane words a | c << 16 (record addresses of the
+                               // lane's cell), 1 / (2 degree), record address of the vertex, lower limit of |c - p|^2 for the fast path
+
+// LDS carve-up (one array: the records start at LDS address 0, so record offsets ARE ds_* addresses)
+constexpr int OFF_REC = 0;
+constexpr int OFF_ROW = OFF_REC + (SNV + 3) * REC;
+constexpr int OFF_PT = OFF_ROW + (SNV + 1) * ROW;           // passes: 8 row offsets (uint16) each; even count + 2 wrapped around
+constexpr int OFF_PTR = OFF_PT + (SNV + 4) * GRP * 2;
+constexpr int OFF_CNT = OFF_PTR + (SNV + 1) * 4 + 12;
+constexpr int OFF_INC = OFF_CNT + SNV * 4;
+constexpr int OFF_IVERT = OFF_INC + 3 * SNT * 4;
+constexpr int OFF_LEV = OFF_IVERT + SNV * 2;
+constexpr int OFF_FILL = OFF_LEV + (SNV + 4) * 4;
+constexpr int OFF_PART = OFF_FILL + SNV * 4;
+constexpr int LDS_BYTES = OFF_PART + SWG * 4;
+static_assert(OFF_ROW % 16 == 0 && OFF_PT % 16 == 0 && OFF_PTR % 16 == 0 && OFF_CNT % 16 == 0, "LDS alignment");
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef __attribute__((address_space(3))) int lds_i32;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) d2 lds_d2;
 
 template <int CTRL>
 __device__ __forceinline__ double dpp8(double v) {
@@ -43,14 +76,15 @@ __device__ __forceinline__ double grp_sum(double v) {
   v += dpp8<0xB1>(v);
   v += dpp8<0x4E>(v);
   v += dpp8<0x141>(v);
-#if MDQ_SMOOTH_GRP == 16
-  v += dpp8<0x140>(v);  // row_mirror: the other half of the row of 16
-#endif
   return v;
 }
-// 1/sqrt(x) to double precision (not correctly rounded: ~1 ulp): hardware estimate + two Newton steps.  The IEEE
-// sqrt + division sequences are ~25 dependent fp64 instructions each and every one of them is on the critical path
-// of this latency-bound kernel.
+__device__ __forceinline__ double grp_min(double v) {
+  v = fmin(v, dpp8<0xB1>(v));
+  v = fmin(v, dpp8<0x4E>(v));
+  v = fmin(v, dpp8<0x141>(v));
+  return v;
+}
+// 1/sqrt(x) and 1/x to double precision (~1 ulp): hardware estimate + two Newton steps (exact path only)
 __device__ __forceinline__ double rsqrt_nr(double x) {
   double y = __builtin_amdgcn_rsq(x);
   const double h = 0.5 * x;
@@ -58,23 +92,11 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
   y = y * (1.5 - h * y * y);
   return y;
 }
-
-// 1/x to double precision (~1 ulp): hardware estimate + two Newton steps
 __device__ __forceinline__ double rcp_nr(double x) {
   double y = __builtin_amdgcn_rcp(x);
   y = y * (2.0 - x * y);
   y = y * (2.0 - x * y);
   return y;
-}
-
-__device__ __forceinline__ double grp_min(double v) {
-  v = fmin(v, dpp8<0xB1>(v));
-  v = fmin(v, dpp8<0x4E>(v));
-  v = fmin(v, dpp8<0x141>(v));
-#if MDQ_SMOOTH_GRP == 16
-  v = fmin(v, dpp8<0x140>(v));
-#endif
-  return v;
 }
 
 // inclusive scan of data[0..SNV) in place (SWG threads, PER consecutive entries each; part = SWG ints of scratch)
@@ -100,29 +122,66 @@ __device__ __forceinline__ void scan_inclusive(int* data, int* part) {
   __syncthreads();
 }
 
+// exact fp64 update of vertex `v` by the 8 lanes of its group (any degree, limited steps): returns the new value of
+// the lane's component (lane 0: x, lane 1: y) in `pn` and whether the vertex moves at all
+__device__ __forceinline__ bool exact_update(const lds_u8* recb, const lds_i32* ptr, const lds_u32* inc, int v, int l,
+                                             double& pn) {
+#pragma clang fp contract(off)
+  const double EPS = 3.0e-16;
+  const int q0 = ptr[v], k = ptr[v + 1] - q0;
+  const d2 p = *reinterpret_cast<const lds_d2*>(recb + v * REC);
+  double sx = 0.0, sy = 0.0, rm = 1e300;
+  for (int q = l; q < k; q += GRP) {
+    const uint32_t w = inc[q0 + q];
+    const int a = w & 0x3FF, c = (w >> 10) & 0x3FF;
+    const d2 pa = *reinterpret_cast<const lds_d2*>(recb + a * REC);
+    const d2 pc = *reinterpret_cast<const lds_d2*>(recb + c * REC);
+    sx += pa.x + pc.x;
+    sy += pa.y + pc.y;
+    const double tx = pc.x - pa.x, ty = pc.y - pa.y;
+    const double cr = ty * (p.x - pa.x) - tx * (p.y - pa.y);
+    rm = fmin(rm, cr * cr * rcp_nr(tx * tx + ty * ty));   // SQUARED distance to the line through the opposite edge
+  }
+  sx = grp_sum(sx);
+  sy = grp_sum(sy);
+  rm = grp_min(rm);
+  const double r2k = 1.0 / (2.0 * k);
+  const double pc_ = l == 0 ? p.x : p.y;
+  const double dc_ = (l == 0 ? sx : sy) * r2k - pc_;    // lane 0: dx, lane 1: dy
+  const double dother = dpp8<0xB1>(dc_);
+  const double q2 = dc_ * dc_ + dother * dother;
+  pn = pc_;
+  if (!(q2 >= EPS * EPS && q2 > 0.0)) return false;     // |c - p| < DOLFIN_EPS: the vertex stays
+  pn = pc_ + dc_;                                       // |c - p| <= r_min / 2: to the centroid itself
+  if (0.25 * rm < q2) {                                 // limited step: needs the lengths
+    const double ir = rsqrt_nr(q2);
+    const double rmin = rm * rsqrt_nr(rm);
+    pn = pc_ + (0.5 * rmin * ir) * dc_;
+  }
+  return true;
+}
+
 __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coords, const int32_t* cells,
                                                      const int32_t* nv_, const int32_t* nt_, const int32_t* iters_,
                                                      long long* trace) {
-#pragma clang fp contract(off)
-  __shared__ double2 pos[SNV];
-  __shared__ int done[SNV];
-  __shared__ int ptr[SNV + 1];
-  __shared__ int cnt[SNV];
-  __shared__ uint32_t inc[3 * SNT];   // a | b << 10 | cell << 20 of every (vertex, incident cell), grouped by vertex, ascending cell
-  __shared__ uint16_t ivert[SNV];     // interior vertices in index order
-  __shared__ int part[SWG];
-  __shared__ double rcp2k[32];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  unsigned char* recb = lds + OFF_REC;
+  unsigned char* rows = lds + OFF_ROW;
+  uint16_t* passtab = reinterpret_cast<uint16_t*>(lds + OFF_PT);
+  int* ptr = reinterpret_cast<int*>(lds + OFF_PTR);
+  int* cnt = reinterpret_cast<int*>(lds + OFF_CNT);
+  uint32_t* inc = reinterpret_cast<uint32_t*>(lds + OFF_INC);   // a | b << 10 | cell << 20 of every (vertex, incident cell), grouped by vertex, ascending cell
+  uint16_t* ivert = reinterpret_cast<uint16_t*>(lds + OFF_IVERT);   // interior vertices in index order
+  int* levv = reinterpret_cast<int*>(lds + OFF_LEV);            // level of a vertex inside a sweep (boundary: 0)
+  int* fill = reinterpret_cast<int*>(lds + OFF_FILL);           // slots handed out per level
+  int* part = reinterpret_cast<int*>(lds + OFF_PART);
   const int b = blockIdx.x, tid = threadIdx.x;
   const int iters = iters_[b];
   if (iters <= 0) return;
   const int nv = nv_[b], nt = nt_[b];
   double2* x = reinterpret_cast<double2*>(coords) + (int64_t)b * NV;
   const int32_t* tri = cells + (int64_t)b * NT * 3;
-  for (int v = tid; v < SNV; v += SWG) {
-    if (v < nv) pos[v] = x[v];
-    cnt[v] = 0;
-  }
-  if (tid < 32) rcp2k[tid] = tid ? 1.0 / (2.0 * tid) : 0.0;
+  for (int v = tid; v < SNV; v += SWG) cnt[v] = 0;
   __syncthreads();
   for (int t = tid; t < nt; t += SWG)
     for (int k = 0; k < 3; ++k) atomicAdd(&cnt[tri[3 * t + k]], 1);
@@ -143,8 +202,9 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
   }
   __syncthreads();
   // per vertex: order the incident cells by cell id (fixed summation order), boundary test (a neighbour seen once)
-  for (int v = tid; v < SNV; v += SWG) {
+  for (int v = tid; v <= SNV; v += SWG) {
     bool interior = false;
+    d2 p = {0.0, 0.0};
     if (v < nv) {
       const int q0 = ptr[v], q1 = ptr[v + 1];
       for (int i = q0 + 1; i < q1; ++i) {
@@ -164,177 +224,246 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
           for (int j = q0; j < q1; ++j) seen += ((inc[j] & 0x3FF) == nb) + (((inc[j] >> 10) & 0x3FF) == nb);
           if (seen != 2) interior = false;
         }
+      const double2 xv = x[v];
+      p.x = xv.x;
+      p.y = xv.y;
     }
-    done[v] = interior ? 0 : 0x3FFFFFFF;
-    cnt[v] = interior ? 1 : 0;
+    // record: (x, y) for the even lanes, (y, x) for the odd lanes (record SNV: zeros)
+    *reinterpret_cast<d2*>(recb + v * REC) = p;
+    *reinterpret_cast<d2*>(recb + v * REC + 16) = d2{p.y, p.x};
+    if (v < SNV) cnt[v] = interior ? 1 : 0;
+    levv[v] = 0;
+  }
+  if (tid < 2) {
+    const d2 p = {(double)tid, -1000.0};
+    *reinterpret_cast<d2*>(recb + AREC + tid * REC) = p;
+    *reinterpret_cast<d2*>(recb + AREC + tid * REC + 16) = d2{p.y, p.x};
   }
   __syncthreads();
   scan_inclusive(cnt, part);
   const int n_int = cnt[SNV - 1];
   __syncthreads();
-  // queue order = index order (ranking the vertices by their dependency level inside a sweep and dealing the levels
-  // round-robin was tried: the setup costs more than the better-ordered queues gain)
-  for (int v = tid; v < SNV; v += SWG)
-    if (done[v] == 0) ivert[cnt[v] - 1] = (uint16_t)v;
+  for (int v = tid; v < nv; v += SWG)
+    if (cnt[v] != (v ? cnt[v - 1] : 0)) ivert[cnt[v] - 1] = (uint16_t)v;
   __syncthreads();
-
-  // ---------------- dataflow Gauss-Seidel
-  // group rank: consecutive ranks sit in DIFFERENT waves (they are usually neighbours on the dependency chain, and
-  // the groups of one wave serialise whenever one of them computes)
-  const int l = tid % GRP;
-  const int g = (tid >> 6) + (SWG / 64) * ((tid & 63) / GRP);
-  const int nown = g < n_int ? (n_int - g + NGRP - 1) / NGRP : 0;
-  const double EPS = 3.0e-16;
-  int s = 0, j = 0;
-  const int total = nown * iters;
-#define LD_DONE(i) __hip_atomic_load(&done[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-#define LD_X(i) __hip_atomic_load(&pos[i].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-#define LD_Y(i) __hip_atomic_load(&pos[i].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-  // metadata of the update at the head of the group's queue (reloaded only when the head advances)
-  int v = 0, k = 0, q0 = 0, a0 = 0, c0 = 0;
-  bool fresh = true;
-  for (int step = 0; step < total;) {
-    if (fresh) {
-      v = ivert[g + NGRP * j];
-      q0 = ptr[v];
-      k = ptr[v + 1] - q0;
+  // metadata rows.  Row n_int is the empty pass slot: vertex and cells on the zero record except lane 0, whose cell
+  // is the far-away edge (a finite altitude keeps the slot on the fast path; it stores zeros into the zero record)
+  for (int e = tid; e < (n_int + 1) * GRP; e += SWG) {
+    const int r = e / GRP, l = e % GRP;
+    const uint32_t par16 = (l & 1) * 16;
+    uint32_t w = ((uint32_t)ZREC + par16) * 0x10001u, wv = (uint32_t)ZREC;
+    double r2k = 0.0;
+    float thr = -1.0f;
+    if (r < n_int) {
+      const int v = ivert[r], q0 = ptr[v], k = ptr[v + 1] - q0;
       if (l < k) {
-        const uint32_t w = inc[q0 + l];
-        a0 = w & 0x3FF;
-        c0 = (w >> 10) & 0x3FF;
+        const uint32_t i = inc[q0 + l];
+        w = ((i & 0x3FF) * REC + par16) | ((((i >> 10) & 0x3FF) * REC + par16) << 16);
       }
-      fresh = false;
+      wv = (uint32_t)(v * REC);
+      r2k = 1.0 / (2.0 * k);
+      thr = k <= GRP ? 4.0e-31f : __builtin_inff();   // degree > 8: always the exact path
+    } else if (l == 0) {
+      w = (uint32_t)AREC | ((uint32_t)CREC << 16);
     }
-    // poll: sweep counters of the neighbours in my cell(s) (cells l, l + 8, ...; the first one from registers)
-    bool ok = true;
-    if (l < k) {   // both counters loaded before either is tested: ONE LDS round trip per poll (a short-circuit `&&`
-      const int da = LD_DONE(a0), dc = LD_DONE(c0);   // made the second load wait for the first, on the critical path)
-      ok = (da >= (a0 < v ? s + 1 : s)) & (dc >= (c0 < v ? s + 1 : s));
+    *reinterpret_cast<uint32_t*>(rows + r * ROW + 4 * l) = w;
+    if (l == 0) {
+      *reinterpret_cast<double*>(rows + r * ROW + 32) = r2k;
+      *reinterpret_cast<uint32_t*>(rows + r * ROW + 40) = wv;
+      *reinterpret_cast<float*>(rows + r * ROW + 44) = thr;
     }
-    for (int q = l + GRP; q < k; q += GRP) {
-      const uint32_t w = inc[q0 + q];
-      const int a = w & 0x3FF, c = (w >> 10) & 0x3FF;
-      const int da = LD_DONE(a), dc = LD_DONE(c);
-      ok = ok & (da >= (a < v ? s + 1 : s)) & (dc >= (c < v ? s + 1 : s));
-    }
-    const unsigned long long bal = __ballot(ok);
-    constexpr unsigned long long GMASK = (1ull << GRP) - 1;
-    const bool ready = ((bal >> ((tid & 63) & ~(GRP - 1))) & GMASK) == GMASK;
-    if (ready) {
-#ifdef MDQ_SMOOTH_TRACE
-      const long long t_ready = clock64();
-#endif
-#ifndef MDQ_SMOOTH_NOPRIO
-      // a wave that computes an update outranks the waves that only poll (they share the SIMD's issue slots)
-      __builtin_amdgcn_s_setprio(3);
-#endif
-      // (a counter that is high enough guarantees that a position read after it is the right version: the
-      // neighbour cannot advance again before this vertex has; LDS operations of a wave complete in order)
-      const double px = LD_X(v), py = LD_Y(v);
-      double sx = 0.0, sy = 0.0, rm = 1e300;
-      for (int q = l; q < k; q += GRP) {
-        int a = a0, c = c0;
-        if (q != l) {
-          const uint32_t w = inc[q0 + q];
+  }
+  // levels of one sweep: 1 + the largest level among the lower-numbered interior neighbours.  Monotone relaxation in
+  // place (a value only grows towards the fixed point): every thread owns up to LPT CONSECUTIVE interior vertices and
+  // walks them in index order with the level addresses of their cells in registers, so a chain of consecutively
+  // numbered vertices advances LPT levels per round; the waves run LROUNDS rounds between two barriers
+  {
+    constexpr int LPT = SNV / SWG, LROUNDS = 4;
+    const int r0 = tid * LPT;
+    uint32_t la[LPT][GRP];     // per cell: level addresses (vertex index) of its two other vertices, lower ones only
+    int vown[LPT];
+#pragma unroll
+    for (int j = 0; j < LPT; ++j) {
+      const int r = r0 + j;
+      vown[j] = r < n_int ? ivert[r] : SNV;
+      const int q0 = r < n_int ? ptr[vown[j]] : 0, k = r < n_int ? ptr[vown[j] + 1] - q0 : 0;
+#pragma unroll
+      for (int i = 0; i < GRP; ++i) {
+        uint32_t a = SNV, c = SNV;      // levv[SNV] stays 0
+        if (i < k) {
+          const uint32_t w = inc[q0 + i];
           a = w & 0x3FF;
           c = (w >> 10) & 0x3FF;
+          if ((int)a > vown[j]) a = SNV;
+          if ((int)c > vown[j]) c = SNV;
         }
-        const double ax = LD_X(a), ay = LD_Y(a), bx = LD_X(c), by = LD_Y(c);
-        sx += ax + bx;
-        sy += ay + by;
-        const double tx = bx - ax, ty = by - ay;
-#ifdef MDQ_SMOOTH_NOMATH
-        rm = fmin(rm, fabs(ty * (px - ax) - tx * (py - ay)));
-#else
-        // SQUARED distance to the line through the opposite edge: the comparison with the step length below is done
-        // on squares, so that the common case (full step to the centroid) needs no square root at all
-        const double cr = ty * (px - ax) - tx * (py - ay);
-        rm = fmin(rm, cr * cr * rcp_nr(tx * tx + ty * ty));
-#endif
+        la[j][i] = a | (c << 16);
       }
-      // lane 0 carries the x component, lane 1 the y component (same instruction stream: free)
-      // the three group reductions step by step side by side (three independent dependency chains in flight instead
-      // of one after the other; every lane takes part: DPP needs the whole group active)
-      double tsx = sx, tsy = sy;
-      {
-        double ax_ = dpp8<0xB1>(tsx), ay_ = dpp8<0xB1>(tsy), am_ = dpp8<0xB1>(rm);
-        tsx += ax_;
-        tsy += ay_;
-        rm = fmin(rm, am_);
-        ax_ = dpp8<0x4E>(tsx);
-        ay_ = dpp8<0x4E>(tsy);
-        am_ = dpp8<0x4E>(rm);
-        tsx += ax_;
-        tsy += ay_;
-        rm = fmin(rm, am_);
-        ax_ = dpp8<0x141>(tsx);
-        ay_ = dpp8<0x141>(tsy);
-        am_ = dpp8<0x141>(rm);
-        tsx += ax_;
-        tsy += ay_;
-        rm = fmin(rm, am_);
-#if MDQ_SMOOTH_GRP == 16
-        ax_ = dpp8<0x140>(tsx);
-        ay_ = dpp8<0x140>(tsy);
-        am_ = dpp8<0x140>(rm);
-        tsx += ax_;
-        tsy += ay_;
-        rm = fmin(rm, am_);
-#endif
-      }
-      const double sc = l == 0 ? tsx : tsy;
-      const double pc = l == 0 ? px : py;
-      const double dc_ = sc * rcp2k[k] - pc;                // lane 0: dx, lane 1: dy
-      const double dother = dpp8<0xB1>(dc_);                // the other component
-      const double q2 = dc_ * dc_ + dother * dother;        // (x*x + y*y in lane 0, y*y + x*x in lane 1: same bits)
-      // rm holds the SQUARED minimum altitude.  |c - p| <= r_min / 2  <=>  q2 <= rm / 4: the vertex moves to the
-      // centroid itself (p + d: the reference's p + r (d / r) up to one rounding); only a LIMITED step needs the
-      // lengths (two reciprocal square roots, off the common path)
-      if (l < 2) {
-        if (q2 >= EPS * EPS && q2 > 0.0) {
-          double pn = pc + dc_;
-#ifndef MDQ_SMOOTH_NOMATH
-          if (0.25 * rm < q2) {
-            const double ir = rsqrt_nr(q2);
-            const double rmin = rm * rsqrt_nr(rm);   // sqrt(rm)
-            pn = pc + (0.5 * rmin * ir) * dc_;
+      // (degree > 8: the cells beyond the eighth are read from the list in every round)
+    }
+    for (;;) {
+      bool changed = false;
+      for (int round = 0; round < LROUNDS; ++round) {
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+          const int v = vown[j];
+          if (v < SNV) {
+            int L = 0;
+#pragma unroll
+            for (int i = 0; i < GRP; ++i) {
+              L = max(L, __hip_atomic_load(&levv[la[j][i] & 0xFFFF], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+              L = max(L, __hip_atomic_load(&levv[la[j][i] >> 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            }
+            const int q0 = ptr[v], q1 = ptr[v + 1];
+            for (int i = q0 + GRP; i < q1; ++i) {
+              const uint32_t w = inc[i];
+              const int a = w & 0x3FF, c = (w >> 10) & 0x3FF;
+              if (a < v) L = max(L, __hip_atomic_load(&levv[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+              if (c < v) L = max(L, __hip_atomic_load(&levv[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            }
+            ++L;
+            if (L != __hip_atomic_load(&levv[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+              __hip_atomic_store(&levv[v], L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              changed = true;
+            }
           }
-#endif
-          __hip_atomic_store(l == 0 ? &pos[v].x : &pos[v].y, pn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
-      // (the position stores and the counter store below go to LDS from the SAME wave: the LDS executes a wave's
-      // operations in issue order, so a compiler-level fence is enough - the workgroup-scope release fence waited
-      // for the position stores to complete before the counter store could even be issued, on the critical path)
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      if (l == 0) __hip_atomic_store(&done[v], s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#ifdef MDQ_SMOOTH_TRACE
-      if (trace && b == 0 && l == 0) {
-        trace[2 * ((int64_t)s * SNV + v)] = t_ready;
-        trace[2 * ((int64_t)s * SNV + v) + 1] = clock64();
-      }
-#endif
-      ++step;
-      if (++j == nown) {
-        j = 0;
-        ++s;
-      }
-      fresh = true;
-#ifndef MDQ_SMOOTH_NOPRIO
-      __builtin_amdgcn_s_setprio(0);
-#endif
+      if (!__syncthreads_or(changed)) break;
     }
-#ifdef MDQ_SMOOTH_SLEEP
-    else if (bal == 0) {
-      __builtin_amdgcn_s_sleep(MDQ_SMOOTH_SLEEP);
-    }
-#endif
   }
-#undef LD_DONE
-#undef LD_X
-#undef LD_Y
+  // passes: level L takes ceil(width / 8) of them, slots inside a level in arrival order (the updates of a level are
+  // independent, so the slot order does not change any result); an even number of passes (the walk below is unrolled
+  // by two) and the first two passes again behind the last one (the prefetch runs two passes ahead, into the next sweep)
+  for (int v = tid; v < SNV; v += SWG) {
+    cnt[v] = 0;
+    fill[v] = 0;
+  }
   __syncthreads();
-  for (int v = tid; v < nv; v += SWG) x[v] = pos[v];
+  for (int r = tid; r < n_int; r += SWG) atomicAdd(&cnt[levv[ivert[r]] - 1], 1);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < PER; ++i) cnt[tid * PER + i] = (cnt[tid * PER + i] + GRP - 1) / GRP;
+  __syncthreads();
+  scan_inclusive(cnt, part);
+  const int npass = (cnt[SNV - 1] + 1) & ~1;
+  for (int e = tid; e < npass * GRP; e += SWG) passtab[e] = (uint16_t)(n_int * ROW);
+  __syncthreads();
+  for (int r = tid; r < n_int; r += SWG) {
+    const int i = levv[ivert[r]] - 1;
+    const int pos = atomicAdd(&fill[i], 1);
+    passtab[((i ? cnt[i - 1] : 0) + (pos >> 3)) * GRP + (pos & 7)] = (uint16_t)(r * ROW);
+  }
+  __syncthreads();
+  if (tid < 2 * GRP) passtab[npass * GRP + tid] = passtab[tid];
+  __syncthreads();
+
+  // ---------------- the sweeps: wave 0 walks the passes
+  if (tid < 64 && npass > 0) {
+    const int lane = tid, l = lane & 7;
+    const uint32_t par16 = (lane & 1) * 16;
+    const int gsh = lane & ~7;
+    const uint32_t lrow = OFF_ROW + 4 * l;                 // this lane's word of a metadata row
+    const uint32_t st1 = 8 * (lane & 1), st2 = 24 - 8 * (lane & 1);   // where a lane's component goes inside a record
+    const lds_u8* R = (const lds_u8*)lds;
+    // pass p: the lane's cell words W (record addresses a | c << 16) and M = (1 / 2k, vertex record, lower limit) of the
+    // group's vertex; RKN: row offsets of pass p + 1 (its metadata are fetched into W1 / M1 during pass p), RK2: those
+    // of pass p + 2 (fetched from the pass table at PT)
+#define MDQ_SMOOTH_PASS(W, M, RKN, W1, M1, RK2, PT)                                                                     \
+  {                                                                                                                     \
+    d2 pa, pc, pv;                                                                                                      \
+    const uint32_t vrec = (M).z;                                                                                        \
+    /* positions first, then the prefetches; wait for the positions only */                                            \
+    asm volatile(                                                                                                       \
+        "ds_read_b128 %0, %6\n\t"                                                                                       \
+        "ds_read_b128 %1, %7\n\t"                                                                                       \
+        "ds_read_b128 %2, %8\n\t"                                                                                       \
+        "ds_read_b32 %3, %9\n\t"                                                                                        \
+        "ds_read_b128 %4, %10 offset:%c12\n\t"                                                                          \
+        "ds_read_u16 %5, %11\n\t"                                                                                       \
+        "s_waitcnt lgkmcnt(3)"                                                                                          \
+        : "=&v"(pa), "=&v"(pc), "=&v"(pv), "=&v"(W1), "=&v"(M1), "=&v"(RK2)                                             \
+        : "v"((W) & 0xFFFF), "v"((W) >> 16), "v"(vrec | par16), "v"((RKN) + lrow), "v"(RKN), "v"(PT), "n"(OFF_ROW + 32) \
+        : "memory");                                                                                                    \
+    MDQ_SMOOTH_STAMP(t_ready)                                                                                           \
+    /* component 0 of a lane is the one it keeps (even lanes x, odd lanes y), component 1 the one it hands over */      \
+    double S = pa.x + pc.x;                                                                                             \
+    const double T = pa.y + pc.y;                                                                                       \
+    const double e0 = pc.x - pa.x, e1 = pc.y - pa.y;                                                                    \
+    const double w0 = pv.x - pa.x, w1_ = pv.y - pa.y;                                                                   \
+    const double cr = __builtin_fma(e1, w0, -(e0 * w1_));                                                               \
+    const double len2 = __builtin_fma(e0, e0, e1 * e1);                                                                 \
+    /* squared altitude, ~1e-6 relative; an unused lane (both vertices the zero record) gives 0 * inf = NaN, whose */   \
+    /* bit pattern sorts above every number: never the minimum (three DPP-fused unsigned minima over the 8 lanes) */    \
+    uint32_t ab = __float_as_uint((float)(cr * cr) * __builtin_amdgcn_rcpf((float)len2));                               \
+    /* centroid sums: stage 1 exchanges the other component with the neighbour lane, stages 2 and 3 add like */         \
+    /* components (lanes 0..3 of the group end with the totals: lane 0 x, lane 1 y) */                                  \
+    S += dpp8<0xB1>(T);                                                                                                 \
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(ab));               \
+    S += dpp8<0x4E>(S);                                                                                                 \
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(ab));               \
+    {                                                                                                                   \
+      const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(S), 0x104, 0xF, 0x5, true); /* row_shl:4 */          \
+      const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(S), 0x104, 0xF, 0x5, true);                          \
+      S += __hiloint2double(hi, lo);                                                                                    \
+    }                                                                                                                   \
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5" : "+v"(ab));                         \
+    const double d = __builtin_fma(S, __hiloint2double((int)(M).y, (int)(M).x), -pv.x); /* lane 0: dx, lane 1: dy */    \
+    const float df = (float)d, t2 = df * df;                                                                            \
+    float q2f;                                                                                                          \
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(q2f) : "v"(t2));    \
+    /* fast decision (lanes 0 and 1 hold the same q2f and minimum): the vertex moves (|d| clearly above DOLFIN_EPS) */  \
+    /* and the full step is clearly allowed (q2 < r_min^2 / 4 with a 1e-3 margin over the fp32 errors) */               \
+    const bool fast = (q2f > __uint_as_float((M).w)) & (q2f < 0.24975f * __uint_as_float(ab));                          \
+    double pn = pv.x + d;                                                                                               \
+    const unsigned long long slowm = 0x0101010101010101ull & ~__builtin_amdgcn_ballot_w64(fast);                        \
+    if (slowm) { /* wave-uniform and rare: exact fp64 update for the groups that could not decide */                    \
+      if ((slowm >> gsh) & 1ull)                                                                                        \
+        exact_update(R, (const lds_i32*)(lds + OFF_PTR), (const lds_u32*)(lds + OFF_INC), (int)(vrec / REC), l, pn);    \
+    }                                                                                                                   \
+    /* the prefetched metadata has long arrived */                                                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(W1), "+v"(M1), "+v"(RK2)::"memory");                                     \
+    if (l < 2) asm volatile("ds_write_b64 %0, %2\n\tds_write_b64 %1, %2" ::"v"(vrec + st1), "v"(vrec + st2), "v"(pn) : "memory"); \
+    MDQ_SMOOTH_TRACE_OUT(vrec)                                                                                          \
+  }
+#ifdef MDQ_SMOOTH_TRACE
+#define MDQ_SMOOTH_STAMP(t) const long long t = clock64();
+#define MDQ_SMOOTH_TRACE_OUT(vrec)                                     \
+  if (trace && b == 0 && l == 0 && (vrec) != (uint32_t)ZREC) {         \
+    trace[2 * ((int64_t)sweep * SNV + (vrec) / REC)] = t_ready;        \
+    trace[2 * ((int64_t)sweep * SNV + (vrec) / REC) + 1] = clock64();  \
+  }
+#else
+#define MDQ_SMOOTH_STAMP(t)
+#define MDQ_SMOOTH_TRACE_OUT(vrec)
+#endif
+    uint32_t wA, wB = 0, rkA = 0, rkB;
+    u4 mA, mB = {0, 0, 0, 0};
+    {
+      const uint32_t rk0 = passtab[lane >> 3];
+      wA = *reinterpret_cast<const uint32_t*>(rows + rk0 + 4 * l);
+      mA = *reinterpret_cast<const u4*>(rows + rk0 + 32);
+      rkB = passtab[GRP + (lane >> 3)];
+    }
+    const uint32_t lpt = OFF_PT + 2 * (lane >> 3);         // this group's slot of a pass
+    for (int sweep = 0; sweep < iters; ++sweep) {
+      uint32_t pt = lpt + 2 * (GRP * 2);
+      for (int q = 0; q < npass; q += 2) {
+        MDQ_SMOOTH_PASS(wA, mA, rkB, wB, mB, rkA, pt)
+        MDQ_SMOOTH_PASS(wB, mB, rkA, wA, mA, rkB, pt + GRP * 2)
+        pt += 2 * (GRP * 2);
+      }
+    }
+#undef MDQ_SMOOTH_PASS
+#undef MDQ_SMOOTH_STAMP
+#undef MDQ_SMOOTH_TRACE_OUT
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  for (int v = tid; v < nv; v += SWG) {
+    const d2 p = *reinterpret_cast<const d2*>(recb + v * REC);
+    x[v] = double2{p.x, p.y};
+  }
 }
 
 }  // namespace mdq_smoothing

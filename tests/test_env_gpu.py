@@ -195,7 +195,7 @@ def test_vec_env_flow_step_matches_oracle(lib_built):
 
 
 def test_gpu_smoothing_matches_host_and_golden(lib_built, meshes):
-    """mdq_smooth (dataflow Gauss-Seidel in LDS) vs the sequential host loop and the oracle's golden coordinates;
+    """mdq_smooth (level-scheduled Gauss-Seidel in LDS) vs the sequential host loop and the oracle's golden coordinates;
     untouched meshes (iterations 0) stay bit-identical; results are bitwise reproducible."""
     from meshdqn_amd.ipcs_batch import smooth_coords
     from meshdqn_amd.mesh_ops import smooth_batch_gpu
@@ -226,6 +226,53 @@ def test_gpu_smoothing_matches_host_and_golden(lib_built, meshes):
         host = smooth_coords(MeshTopology(*meshes[n]), 50)
         assert np.abs(outs[0][b, :nv[b]] - host).max() < 1e-13
         assert np.abs(outs[0][b, :nv[b]] - z[f"{n}_coords_smoothed"]).max() < 1e-13
+
+
+def _fan_mesh(seed):
+    """A hub of degree 12 inside a strongly jittered ring of 12 interior vertices inside a boundary ring: exercises the
+    exact fp64 path of mdq_smooth (degree > 8, step limited to half the minimum altitude)."""
+    rng = np.random.default_rng(seed)
+    n = 12
+    ang = 2 * np.pi * np.arange(n) / n
+    r1 = rng.uniform(0.25, 1.75, n)
+    ring1 = np.stack([r1 * np.cos(ang + rng.uniform(-0.2, 0.2, n)), r1 * np.sin(ang)], 1)
+    ring2 = 2.5 * np.stack([np.cos(ang + np.pi / n), np.sin(ang + np.pi / n)], 1)
+    coords = np.concatenate([ring2, [[0.3, -0.2]], ring1])      # boundary ids first, like the reference meshes
+    hub, i1, i2 = n, n + 1 + np.arange(n), np.arange(n)
+    cells = []
+    for j in range(n):
+        k = (j + 1) % n
+        cells += [[hub, i1[j], i1[k]], [i1[j], i2[j], i1[k]], [i1[j], i2[(j - 1) % n], i2[j]]]
+    return coords, np.sort(np.array(cells, np.int32), axis=1)
+
+
+def test_gpu_smoothing_exact_path(lib_built):
+    """Limited steps and a vertex of degree 12: the fp32 fast decision must hand these updates to the exact fp64 path.
+    Oracle = the plain DOLFIN loop (oracle/mesh.py), which is also asked how many steps were limited."""
+    from meshdqn_amd.mesh_ops import smooth_batch_gpu
+    from oracle.mesh import OracleMesh
+    limited_total = 0
+    for seed in range(6):
+        coords, cells = _fan_mesh(seed)
+        m = OracleMesh(coords, cells)
+        assert (~m.on_boundary).sum() == 13 and max(len(n) for n in m.nbrs) == 12
+        # count the limited steps of the first sweep with the oracle's own formulae
+        x = m.coords.copy()
+        for v in np.nonzero(~m.on_boundary)[0]:
+            c = np.mean([x[w] for w in m.nbrs[v]], axis=0)
+            cross = lambda e, w: e[0] * w[1] - e[1] * w[0]  # noqa: E731
+            rmin = min(abs(cross(x[o[1]] - x[o[0]], x[v] - x[o[0]])) / np.linalg.norm(x[o[1]] - x[o[0]])
+                       for o in ([m.cells[cc, j] for j in range(3) if j != k] for cc, k in m.vcells[v]))
+            r = np.linalg.norm(c - x[v])
+            limited_total += r > 0.5 * rmin
+            x[v] = x[v] + min(r, 0.5 * rmin) * (c - x[v]) / r
+        for iters in (1, 7):
+            ref = OracleMesh(coords, cells).smooth(iters).coords
+            tc = torch.from_numpy(coords[None].copy()).cuda()
+            one = lambda v: torch.tensor([v], dtype=torch.int32, device="cuda")  # noqa: E731
+            smooth_batch_gpu(tc, torch.from_numpy(cells[None].copy()).cuda(), one(len(coords)), one(len(cells)), one(iters))
+            assert np.abs(tc[0].cpu().numpy() - ref).max() < 1e-12, (seed, iters)
+    assert limited_total >= 6, "the synthetic meshes no longer exercise the limited step"
 
 
 def test_env_groups_equal_one_batch(lib_built):
@@ -472,8 +519,9 @@ def test_compact_edges_matches_mask_indexing(lib_built):
 
 @pytest.mark.parametrize("name", ["ys930", "ah93w145"])
 def test_gpu_smoothing_is_bitwise_reproducible(lib_built, meshes, name):
-    """The dataflow smoothing kernel hands positions from wave to wave through LDS with relaxed atomics and a
-    wavefront-scope fence: any stale read would show up as a difference between environments or launches."""
+    """The smoothing kernel hands positions from pass to pass through LDS (in-order service of one wave's operations,
+    slots of a level filled in arrival order): any stale read or order dependence would show up as a difference
+    between environments or launches."""
     from meshdqn_amd.ipcs_batch import smooth_coords
     from meshdqn_amd.mesh_ops import smooth_batch_gpu
     from meshdqn_amd.topology import MeshTopology
