@@ -64,6 +64,9 @@ typedef __attribute__((address_space(3))) unsigned char lds_u8;
 typedef __attribute__((address_space(3))) int lds_i32;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(3))) d2 lds_d2;
+typedef __attribute__((address_space(3))) u4 lds_u4;
+typedef __attribute__((address_space(3))) double lds_f64;
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
 
 template <int CTRL>
 __device__ __forceinline__ double dpp8(double v) {
@@ -178,6 +181,13 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
   const int b = blockIdx.x, tid = threadIdx.x;
   const int iters = iters_[b];
   if (iters <= 0) return;
+#ifdef MDQ_SMOOTH_TRACE
+  int phase_ = 0;   // setup phase stamps of environment 0 in the slots of sweep 63
+#define MDQ_SMOOTH_PHASE() if (trace && b == 0 && tid == 0) trace[2 * (63 * SNV + phase_++)] = clock64();
+#else
+#define MDQ_SMOOTH_PHASE()
+#endif
+  MDQ_SMOOTH_PHASE()
   const int nv = nv_[b], nt = nt_[b];
   double2* x = reinterpret_cast<double2*>(coords) + (int64_t)b * NV;
   const int32_t* tri = cells + (int64_t)b * NT * 3;
@@ -186,10 +196,28 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
   for (int t = tid; t < nt; t += SWG)
     for (int k = 0; k < 3; ++k) atomicAdd(&cnt[tri[3 * t + k]], 1);
   __syncthreads();
+  MDQ_SMOOTH_PHASE()   /* 1: counted */
   scan_inclusive(cnt, part);
   for (int v = tid; v < SNV; v += SWG) ptr[v + 1] = cnt[v];
   if (tid == 0) ptr[0] = 0;
   __syncthreads();
+  // vertex records: (x, y) for the even lanes, (y, x) for the odd lanes; record SNV: zeros, SNV + 1 / + 2: the far edge
+  for (int v = tid; v < SNV + 3; v += SWG) {
+    d2 p = {0.0, 0.0};
+    if (v < nv) {
+      const double2 xv = x[v];
+      p = d2{xv.x, xv.y};
+    } else if (v > SNV) {
+      p = d2{(double)(v - SNV - 1), -1000.0};
+    }
+    *reinterpret_cast<d2*>(recb + v * REC) = p;
+    *reinterpret_cast<d2*>(recb + v * REC + 16) = d2{p.y, p.x};
+    levv[v] = 0;
+  }
+  // cell lists in arrival order (scratch: the metadata rows are not built yet), owner of every entry
+  uint32_t* tmp = reinterpret_cast<uint32_t*>(rows);
+  uint16_t* own = reinterpret_cast<uint16_t*>(rows + 3 * SNT * 4);
+  static_assert(3 * SNT * 6 <= (SNV + 1) * ROW, "scratch inside the row area");
   for (int v = tid; v < SNV; v += SWG) cnt[v] = 0;
   __syncthreads();
   for (int t = tid; t < nt; t += SWG) {
@@ -197,82 +225,91 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
     for (int k = 0; k < 3; ++k) {
       const int v = vs[k], a = vs[(k + 1) % 3], c = vs[(k + 2) % 3];
       const int q = ptr[v] + atomicAdd(&cnt[v], 1);
-      inc[q] = (uint32_t)a | ((uint32_t)c << 10) | ((uint32_t)t << 20);
+      tmp[q] = (uint32_t)a | ((uint32_t)c << 10) | ((uint32_t)t << 20);
+      own[q] = (uint16_t)v;
     }
   }
   __syncthreads();
-  // per vertex: order the incident cells by cell id (fixed summation order), boundary test (a neighbour seen once)
-  for (int v = tid; v <= SNV; v += SWG) {
-    bool interior = false;
-    d2 p = {0.0, 0.0};
-    if (v < nv) {
-      const int q0 = ptr[v], q1 = ptr[v + 1];
-      for (int i = q0 + 1; i < q1; ++i) {
-        const uint32_t w = inc[i];
-        int j = i - 1;
-        while (j >= q0 && (inc[j] >> 20) > (w >> 20)) {
-          inc[j + 1] = inc[j];
-          --j;
-        }
-        inc[j + 1] = w;
-      }
-      interior = q1 > q0;
-      for (int i = q0; i < q1 && interior; ++i)
-        for (int h = 0; h < 2; ++h) {
-          const uint32_t nb = h ? (inc[i] >> 10) & 0x3FF : inc[i] & 0x3FF;
-          int seen = 0;
-          for (int j = q0; j < q1; ++j) seen += ((inc[j] & 0x3FF) == nb) + (((inc[j] >> 10) & 0x3FF) == nb);
-          if (seen != 2) interior = false;
-        }
-      const double2 xv = x[v];
-      p.x = xv.x;
-      p.y = xv.y;
+  MDQ_SMOOTH_PHASE()   /* 2: cell lists filled */
+  for (int v = tid; v < SNV; v += SWG) cnt[v] = 0;   // now: 1 = a neighbour of the vertex is not seen exactly twice
+  __syncthreads();
+  // one thread per (vertex, incident cell): rank of the cell among the vertex's cells (ascending cell id: the fixed
+  // order the lanes of an update take them in), boundary test of its two other vertices
+  for (int e = tid; e < 3 * nt; e += SWG) {
+    const int v = own[e], q0 = ptr[v], q1 = ptr[v + 1];
+    const uint32_t my = tmp[e], a = my & 0x3FF, c = (my >> 10) & 0x3FF;
+    // entries beyond the vertex's own: a sentinel (the vertex itself as both other vertices - never a neighbour of
+    // itself - and the largest cell id), so that the counting below needs no range test
+    const uint32_t sent = (uint32_t)v | ((uint32_t)v << 10) | 0xFFF00000u;
+    uint32_t o[GRP];
+#pragma unroll
+    for (int j = 0; j < GRP; ++j) o[j] = tmp[min(q0 + j, q1 - 1)];   // (all loads in flight together)
+    uint32_t rank = 0, sa = 0, sc = 0;   // differences are counted: xor + min(., 1) + add, no compare masks
+    const uint32_t mykey = my >> 20;
+#pragma unroll
+    for (int j = 0; j < GRP; ++j) {
+      const uint32_t oj = q0 + j < q1 ? o[j] : sent, oa = oj & 0x3FF, oc = (oj >> 10) & 0x3FF;
+      rank += min(mykey - min(oj >> 20, mykey), 1u);   // 1 if the other cell id is smaller
+      sa += min(oa ^ a, 1u) + min(oc ^ a, 1u);
+      sc += min(oa ^ c, 1u) + min(oc ^ c, 1u);
     }
-    // record: (x, y) for the even lanes, (y, x) for the odd lanes (record SNV: zeros)
-    *reinterpret_cast<d2*>(recb + v * REC) = p;
-    *reinterpret_cast<d2*>(recb + v * REC + 16) = d2{p.y, p.x};
-    if (v < SNV) cnt[v] = interior ? 1 : 0;
-    levv[v] = 0;
-  }
-  if (tid < 2) {
-    const d2 p = {(double)tid, -1000.0};
-    *reinterpret_cast<d2*>(recb + AREC + tid * REC) = p;
-    *reinterpret_cast<d2*>(recb + AREC + tid * REC + 16) = d2{p.y, p.x};
+    sa = 2 * GRP - sa;   // matches = slots - differences
+    sc = 2 * GRP - sc;
+    for (int j = q0 + GRP; j < q1; ++j) {   // degree > 8
+      const uint32_t oj = tmp[j], oa = oj & 0x3FF, oc = (oj >> 10) & 0x3FF;
+      rank += (oj >> 20) < mykey;
+      sa += (oa == a) + (oc == a);
+      sc += (oa == c) + (oc == c);
+    }
+    inc[q0 + rank] = my;
+    if (sa != 2 || sc != 2) cnt[v] = 1;
   }
   __syncthreads();
+  for (int v = tid; v < SNV; v += SWG) {
+    const bool interior = v < nv && ptr[v + 1] > ptr[v] && cnt[v] == 0;
+    cnt[v] = interior ? 1 : 0;
+    levv[v] = interior ? 0 : 1;   // level 0; not interior: final (see the level relaxation below)
+  }
+  if (tid == 0) levv[SNV] = 1;
+  if (tid < 32) part[tid] = 0;   // (1 / 2k table below)
+  __syncthreads();
+  MDQ_SMOOTH_PHASE()   /* 3: sorted, interior test, records */
   scan_inclusive(cnt, part);
   const int n_int = cnt[SNV - 1];
   __syncthreads();
   for (int v = tid; v < nv; v += SWG)
     if (cnt[v] != (v ? cnt[v - 1] : 0)) ivert[cnt[v] - 1] = (uint16_t)v;
   __syncthreads();
+  MDQ_SMOOTH_PHASE()   /* 4: interior ranks */
+  double* r2ktab = reinterpret_cast<double*>(fill);   // 1 / (2 k), k < 32 (the slot counters are zeroed later)
+  if (tid < 32) r2ktab[tid] = tid ? 1.0 / (2.0 * tid) : 0.0;
+  __syncthreads();
   // metadata rows.  Row n_int is the empty pass slot: vertex and cells on the zero record except lane 0, whose cell
   // is the far-away edge (a finite altitude keeps the slot on the fast path; it stores zeros into the zero record)
-  for (int e = tid; e < (n_int + 1) * GRP; e += SWG) {
-    const int r = e / GRP, l = e % GRP;
-    const uint32_t par16 = (l & 1) * 16;
-    uint32_t w = ((uint32_t)ZREC + par16) * 0x10001u, wv = (uint32_t)ZREC;
+  for (int r = tid; r <= n_int; r += SWG) {
+    uint32_t w[GRP], wv = (uint32_t)ZREC;
     double r2k = 0.0;
     float thr = -1.0f;
+#pragma unroll
+    for (int l = 0; l < GRP; ++l) w[l] = ((uint32_t)ZREC + (l & 1) * 16) * 0x10001u;
     if (r < n_int) {
       const int v = ivert[r], q0 = ptr[v], k = ptr[v + 1] - q0;
-      if (l < k) {
-        const uint32_t i = inc[q0 + l];
-        w = ((i & 0x3FF) * REC + par16) | ((((i >> 10) & 0x3FF) * REC + par16) << 16);
+#pragma unroll
+      for (int l = 0; l < GRP; ++l) {
+        const uint32_t i = inc[min(q0 + l, q0 + k - 1)], par16 = (l & 1) * 16;
+        if (l < k) w[l] = ((i & 0x3FF) * REC + par16) | ((((i >> 10) & 0x3FF) * REC + par16) << 16);
       }
       wv = (uint32_t)(v * REC);
-      r2k = 1.0 / (2.0 * k);
+      r2k = k < 32 ? r2ktab[k] : 1.0 / (2.0 * k);
       thr = k <= GRP ? 4.0e-31f : __builtin_inff();   // degree > 8: always the exact path
-    } else if (l == 0) {
-      w = (uint32_t)AREC | ((uint32_t)CREC << 16);
+    } else {
+      w[0] = (uint32_t)AREC | ((uint32_t)CREC << 16);
     }
-    *reinterpret_cast<uint32_t*>(rows + r * ROW + 4 * l) = w;
-    if (l == 0) {
-      *reinterpret_cast<double*>(rows + r * ROW + 32) = r2k;
-      *reinterpret_cast<uint32_t*>(rows + r * ROW + 40) = wv;
-      *reinterpret_cast<float*>(rows + r * ROW + 44) = thr;
-    }
+#pragma unroll
+    for (int l = 0; l < GRP; l += 4) *reinterpret_cast<u4*>(rows + r * ROW + 4 * l) = u4{w[l], w[l + 1], w[l + 2], w[l + 3]};
+    *reinterpret_cast<u4*>(rows + r * ROW + 32) = u4{(uint32_t)__double2loint(r2k), (uint32_t)__double2hiint(r2k), wv, __float_as_uint(thr)};
   }
+  MDQ_SMOOTH_PHASE()   /* 5: rows */
   // levels of one sweep: 1 + the largest level among the lower-numbered interior neighbours.  Monotone relaxation in
   // place (a value only grows towards the fixed point): every thread owns up to LPT CONSECUTIVE interior vertices and
   // walks them in index order with the level addresses of their cells in registers, so a chain of consecutively
@@ -280,7 +317,7 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
   {
     constexpr int LPT = SNV / SWG, LROUNDS = 4;
     const int r0 = tid * LPT;
-    uint32_t la[LPT][GRP];     // per cell: level addresses (vertex index) of its two other vertices, lower ones only
+    uint32_t la[LPT][GRP];     // per cell: byte offsets into levv of its two other vertices, lower ones only
     int vown[LPT];
 #pragma unroll
     for (int j = 0; j < LPT; ++j) {
@@ -289,7 +326,7 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
       const int q0 = r < n_int ? ptr[vown[j]] : 0, k = r < n_int ? ptr[vown[j] + 1] - q0 : 0;
 #pragma unroll
       for (int i = 0; i < GRP; ++i) {
-        uint32_t a = SNV, c = SNV;      // levv[SNV] stays 0
+        uint32_t a = SNV, c = SNV;      // levv[SNV]: level 0, final
         if (i < k) {
           const uint32_t w = inc[q0 + i];
           a = w & 0x3FF;
@@ -297,44 +334,61 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
           if ((int)a > vown[j]) a = SNV;
           if ((int)c > vown[j]) c = SNV;
         }
-        la[j][i] = a | (c << 16);
+        la[j][i] = (a * 4) | ((c * 4) << 16);
       }
       // (degree > 8: the cells beyond the eighth are read from the list in every round)
     }
+    // a stored value is 2 * level + final (final: all lower neighbours final, the level will not change): maxima of
+    // stored values are maxima of levels, the AND of their low bits says whether all are final.  A final vertex is not
+    // visited again
+    const lds_u8* LV = (const lds_u8*)(lds + OFF_LEV);
+    bool fin[LPT];
+#pragma unroll
+    for (int j = 0; j < LPT; ++j) fin[j] = vown[j] >= SNV;
     for (;;) {
-      bool changed = false;
       for (int round = 0; round < LROUNDS; ++round) {
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {
           const int v = vown[j];
-          if (v < SNV) {
-            int L = 0;
+          if (!fin[j]) {
+            asm volatile("" ::: "memory");   // (re-read the levels: other threads raise them)
+            int lv[2 * GRP];
 #pragma unroll
             for (int i = 0; i < GRP; ++i) {
-              L = max(L, __hip_atomic_load(&levv[la[j][i] & 0xFFFF], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-              L = max(L, __hip_atomic_load(&levv[la[j][i] >> 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+              lv[2 * i] = *reinterpret_cast<const lds_i32*>(LV + (la[j][i] & 0xFFFF));
+              lv[2 * i + 1] = *reinterpret_cast<const lds_i32*>(LV + (la[j][i] >> 16));
+            }
+            int L = 0, allfin = 1;
+#pragma unroll
+            for (int i = 0; i < GRP; ++i) {
+              L = max(L, max(lv[2 * i], lv[2 * i + 1]));
+              allfin &= lv[2 * i] & lv[2 * i + 1];
             }
             const int q0 = ptr[v], q1 = ptr[v + 1];
             for (int i = q0 + GRP; i < q1; ++i) {
               const uint32_t w = inc[i];
               const int a = w & 0x3FF, c = (w >> 10) & 0x3FF;
-              if (a < v) L = max(L, __hip_atomic_load(&levv[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-              if (c < v) L = max(L, __hip_atomic_load(&levv[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+              const int xa = a < v ? levv[a] : 1, xc = c < v ? levv[c] : 1;
+              L = max(L, max(xa, xc));
+              allfin &= xa & xc;
             }
-            ++L;
-            if (L != __hip_atomic_load(&levv[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-              __hip_atomic_store(&levv[v], L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              changed = true;
-            }
+            levv[v] = ((L >> 1) + 1) * 2 + allfin;
+            fin[j] = allfin != 0;
           }
         }
       }
-      if (!__syncthreads_or(changed)) break;
+      bool open = false;
+#pragma unroll
+      for (int j = 0; j < LPT; ++j) open |= !fin[j];
+      if (!__syncthreads_or(open)) break;
     }
+    for (int v = tid; v < SNV; v += SWG) levv[v] >>= 1;
+    __syncthreads();
   }
+  MDQ_SMOOTH_PHASE()   /* 6: levels */
   // passes: level L takes ceil(width / 8) of them, slots inside a level in arrival order (the updates of a level are
   // independent, so the slot order does not change any result); an even number of passes (the walk below is unrolled
-  // by two) and the first two passes again behind the last one (the prefetch runs two passes ahead, into the next sweep)
+  // by two) and the first three passes again behind the last one (the prefetch runs up to three passes ahead, into the next sweep)
   for (int v = tid; v < SNV; v += SWG) {
     cnt[v] = 0;
     fill[v] = 0;
@@ -355,9 +409,10 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
     passtab[((i ? cnt[i - 1] : 0) + (pos >> 3)) * GRP + (pos & 7)] = (uint16_t)(r * ROW);
   }
   __syncthreads();
-  if (tid < 2 * GRP) passtab[npass * GRP + tid] = passtab[tid];
+  if (tid < 3 * GRP) passtab[npass * GRP + tid] = passtab[tid];
   __syncthreads();
 
+  MDQ_SMOOTH_PHASE()   /* 7: pass table */
   // ---------------- the sweeps: wave 0 walks the passes
   if (tid < 64 && npass > 0) {
     const int lane = tid, l = lane & 7;
@@ -366,6 +421,7 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
     const uint32_t lrow = OFF_ROW + 4 * l;                 // this lane's word of a metadata row
     const uint32_t st1 = 8 * (lane & 1), st2 = 24 - 8 * (lane & 1);   // where a lane's component goes inside a record
     const lds_u8* R = (const lds_u8*)lds;
+    lds_u8* RW = (lds_u8*)lds;
     // pass p: the lane's cell words W (record addresses a | c << 16) and M = (1 / 2k, vertex record, lower limit) of the
     // group's vertex; RKN: row offsets of pass p + 1 (its metadata are fetched into W1 / M1 during pass p), RK2: those
     // of pass p + 2 (fetched from the pass table at PT)
@@ -437,21 +493,118 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
 #define MDQ_SMOOTH_STAMP(t)
 #define MDQ_SMOOTH_TRACE_OUT(vrec)
 #endif
-    uint32_t wA, wB = 0, rkA = 0, rkB;
-    u4 mA, mB = {0, 0, 0, 0};
+    // ---- speculative walk: the new position is stored BEFORE the step-limit test of the update has been evaluated;
+    // the test (same fp32 decision, from the registers the update was computed from) runs behind the position loads of
+    // the next pass, i.e. in their LDS latency.  An update that is not clearly a full step (none on the reference
+    // meshes) abandons the walk: the records are reloaded and the sweeps run again with the test in front of the store.
+#define MDQ_SMOOTH_SPEC(PA, PC, PV, M, PA1, PC1, PV1, W1, M1, RKIN, RKOUT, PT)                                          \
+  {                                                                                                                     \
+    MDQ_SMOOTH_STAMP(t_ready)                                                                                           \
+    double S = PA.x + PC.x;                                                                                             \
+    const double T = PA.y + PC.y;                                                                                       \
+    S += dpp8<0xB1>(T);                                                                                                 \
+    S += dpp8<0x4E>(S);                                                                                                 \
+    {                                                                                                                   \
+      const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(S), 0x104, 0xF, 0x5, true); /* row_shl:4 */          \
+      const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(S), 0x104, 0xF, 0x5, true);                          \
+      S += __hiloint2double(hi, lo);                                                                                    \
+    }                                                                                                                   \
+    const double d = __builtin_fma(S, __hiloint2double((int)(M).y, (int)(M).x), -PV.x); /* lane 0: dx, lane 1: dy */    \
+    const double pn = PV.x + d;                                                                                         \
+    const uint32_t vrec = (M).z, thr = (M).w;                                                                           \
+    if (l < 2) {                                                                                                        \
+      *reinterpret_cast<lds_f64*>(RW + vrec + st1) = pn;                                                                \
+      *reinterpret_cast<lds_f64*>(RW + vrec + st2) = pn;                                                                \
+    }                                                                                                                   \
+    MDQ_SMOOTH_TRACE_OUT(vrec)                                                                                          \
+    asm volatile("" ::: "memory");                                                                                      \
+    /* positions of the next pass, metadata of the one behind it, vertex list of the third */                           \
+    PA1 = *reinterpret_cast<const lds_d2*>(R + ((W1) & 0xFFFF));                                                        \
+    PC1 = *reinterpret_cast<const lds_d2*>(R + ((W1) >> 16));                                                           \
+    PV1 = *reinterpret_cast<const lds_d2*>(R + ((M1).z | par16));                                                       \
+    const uint32_t wnew = *reinterpret_cast<const lds_u32*>(R + (RKIN) + lrow);                                         \
+    const u4 mnew = *reinterpret_cast<const lds_u4*>(R + (RKIN) + (OFF_ROW + 32));                                      \
+    RKOUT = *reinterpret_cast<const lds_u16*>(R + (PT));                                                                \
+    /* the step-limit test of THIS pass */                                                                              \
+    const double e0 = PC.x - PA.x, e1 = PC.y - PA.y;                                                                    \
+    const double w0 = PV.x - PA.x, w1_ = PV.y - PA.y;                                                                   \
+    const double cr = __builtin_fma(e1, w0, -(e0 * w1_));                                                               \
+    const double len2 = __builtin_fma(e0, e0, e1 * e1);                                                                 \
+    uint32_t ab = __float_as_uint((float)(cr * cr) * __builtin_amdgcn_rcpf((float)len2));                               \
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(ab));               \
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(ab));               \
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5" : "+v"(ab));                         \
+    const float df = (float)d, t2 = df * df;                                                                            \
+    float q2f;                                                                                                          \
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(q2f) : "v"(t2));    \
+    const bool fast = (q2f > __uint_as_float(thr)) & (q2f < 0.24975f * __uint_as_float(ab));                            \
+    undecided |= 0x0101010101010101ull & ~__builtin_amdgcn_ballot_w64(fast);                                            \
+    W1 = wnew;                                                                                                          \
+    M = mnew;                                                                                                           \
+  }
+    bool failed = false;
     {
-      const uint32_t rk0 = passtab[lane >> 3];
-      wA = *reinterpret_cast<const uint32_t*>(rows + rk0 + 4 * l);
-      mA = *reinterpret_cast<const u4*>(rows + rk0 + 32);
-      rkB = passtab[GRP + (lane >> 3)];
+      unsigned long long undecided = 0;   // groups whose update was not clearly a full step (tested once per sweep: a
+                                          // branch behind every test would keep the next loads behind it)
+      // pass 0 in set A, pass 1 in set B, vertex list of pass 2
+      d2 paA, pcA, pvA, paB = {0, 0}, pcB = {0, 0}, pvB = {0, 0};
+      uint32_t wN, rkP, rkQ = 0;     // wN: cell words of the pass whose positions are loaded next
+      u4 mA, mB;
+      {
+        const uint32_t rk0 = passtab[lane >> 3], rk1 = passtab[GRP + (lane >> 3)];
+        const uint32_t wA = *reinterpret_cast<const uint32_t*>(rows + rk0 + 4 * l);
+        mA = *reinterpret_cast<const u4*>(rows + rk0 + 32);
+        wN = *reinterpret_cast<const uint32_t*>(rows + rk1 + 4 * l);
+        mB = *reinterpret_cast<const u4*>(rows + rk1 + 32);
+        rkP = passtab[2 * GRP + (lane >> 3)];
+        paA = *reinterpret_cast<const lds_d2*>(R + (wA & 0xFFFF));
+        pcA = *reinterpret_cast<const lds_d2*>(R + (wA >> 16));
+        pvA = *reinterpret_cast<const lds_d2*>(R + (mA.z | par16));
+      }
+      const uint32_t lpt = OFF_PT + 2 * (lane >> 3);         // this group's slot of a pass
+      for (int sweep = 0; sweep < iters; ++sweep) {
+        uint32_t pt = lpt + 3 * (GRP * 2);
+        for (int q = 0; q < npass; q += 2) {
+          // pass q (set A): loads the positions of pass q + 1 (set B), the metadata of pass q + 2 (into set A)
+          MDQ_SMOOTH_SPEC(paA, pcA, pvA, mA, paB, pcB, pvB, wN, mB, rkP, rkQ, pt)
+          MDQ_SMOOTH_SPEC(paB, pcB, pvB, mB, paA, pcA, pvA, wN, mA, rkQ, rkP, pt + GRP * 2)
+          pt += 2 * (GRP * 2);
+        }
+        if (undecided) {
+          failed = true;
+          break;
+        }
+      }
     }
-    const uint32_t lpt = OFF_PT + 2 * (lane >> 3);         // this group's slot of a pass
-    for (int sweep = 0; sweep < iters; ++sweep) {
-      uint32_t pt = lpt + 2 * (GRP * 2);
-      for (int q = 0; q < npass; q += 2) {
-        MDQ_SMOOTH_PASS(wA, mA, rkB, wB, mB, rkA, pt)
-        MDQ_SMOOTH_PASS(wB, mB, rkA, wA, mA, rkB, pt + GRP * 2)
-        pt += 2 * (GRP * 2);
+#undef MDQ_SMOOTH_SPEC
+    if (failed) {
+      // ---- careful walk from the original coordinates: decision in front of every store, exact fp64 path where needed
+      for (int v = lane; v < nv; v += 64) {
+        const double2 xv = x[v];
+        *reinterpret_cast<d2*>(recb + v * REC) = d2{xv.x, xv.y};
+        *reinterpret_cast<d2*>(recb + v * REC + 16) = d2{xv.y, xv.x};
+      }
+      if (lane == 0) {
+        *reinterpret_cast<d2*>(recb + ZREC) = d2{0.0, 0.0};
+        *reinterpret_cast<d2*>(recb + ZREC + 16) = d2{0.0, 0.0};
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      uint32_t wA, wB = 0, rkA = 0, rkB;
+      u4 mA, mB = {0, 0, 0, 0};
+      {
+        const uint32_t rk0 = passtab[lane >> 3];
+        wA = *reinterpret_cast<const uint32_t*>(rows + rk0 + 4 * l);
+        mA = *reinterpret_cast<const u4*>(rows + rk0 + 32);
+        rkB = passtab[GRP + (lane >> 3)];
+      }
+      const uint32_t lpt = OFF_PT + 2 * (lane >> 3);
+      for (int sweep = 0; sweep < iters; ++sweep) {
+        uint32_t pt = lpt + 2 * (GRP * 2);
+        for (int q = 0; q < npass; q += 2) {
+          MDQ_SMOOTH_PASS(wA, mA, rkB, wB, mB, rkA, pt)
+          MDQ_SMOOTH_PASS(wB, mB, rkA, wA, mA, rkB, pt + GRP * 2)
+          pt += 2 * (GRP * 2);
+        }
       }
     }
 #undef MDQ_SMOOTH_PASS
@@ -460,10 +613,13 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   __syncthreads();
+  MDQ_SMOOTH_PHASE()   /* 8: sweeps */
   for (int v = tid; v < nv; v += SWG) {
     const d2 p = *reinterpret_cast<const d2*>(recb + v * REC);
     x[v] = double2{p.x, p.y};
   }
+  MDQ_SMOOTH_PHASE()   /* 9: written back */
+#undef MDQ_SMOOTH_PHASE
 }
 
 }  // namespace mdq_smoothing

@@ -143,6 +143,10 @@ int main(int argc, char** argv) {
     FILE* tf = fopen(tp ? tp : "smooth_trace.bin", "wb");
     fwrite(mdq_smooth_trace_host(), sizeof(long long), 2 * 64 * 1024, tf);
     fclose(tf);
+    const long long* ph = mdq_smooth_trace_host() + 2 * 63 * 1024;
+    printf("setup phases (cycles):");
+    for (int i = 1; i < 10 && ph[2 * i]; ++i) printf(" %lld", ph[2 * i] - ph[2 * (i - 1)]);
+    printf("\n");
   }
 #endif
   printf("%s B=%d iters=%d: min %.3f ms mean %.3f ms | max|gpu-host| %.3e | bitwise identical over envs and launches: %s\n",
