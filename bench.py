@@ -1,28 +1,35 @@
 #!/usr/bin/env python3
-"""Benchmark of the MI355X hot path: batched Env2DAirfoil IPCS steps on the ys930 mesh.
+"""Benchmark of the MI355X hot path: batched Env2DAirfoil steps on the ys930 mesh.
 
     python bench.py --gpus N --steps K --warmup W
 
-`value`: a "step" is one pass of the IPCS kernel set over one batch: every one of the `--envs` (default 128,
-BASELINE.json configs[1]) environments of a rank advances by ONE IPCS time step (`FlowSolver.evolve`,
-flow_solver.py:362-396: three right-hand sides, three Krylov solves, drag/lift probes) - unit-of-work S2 of
-SURVEY.md section 8(d).  Inputs (meshes, operators, flow state) are resident in HBM before the timed region; the
-flow state is a developed flow obtained by `--spinup` untimed IPCS steps from rest so that Krylov iteration counts
-are representative.  value = (ranks x envs x K) / max-over-ranks time.
+`value`: a "step" is one batched ENVIRONMENT step of unit-of-work S3 (the north-star step): every
+one of the `--envs` (default 128, BASELINE.json configs[1]) environments of a rank removes a vertex and restores the
+Delaunay triangulation (Env2DAirfoil.py:452-512), smooths the mesh (flow_solver.py:236-237), interpolates the five
+snapshots and evaluates the ten force integrals (Env2DAirfoil.py:547-602, :380-428), builds the state graph
+(:244-290), runs ONE IPCS time step on the coarsened mesh (flow_solver.py:362-396, warm start = interpolated last
+snapshot) and the Q-network forward (airfoilgcnn.py:85-145); actions follow `default_rng(1370 + ...)` streams with
+epsilon = 0.5, so the meshes of the batch diverge; terminated environments are reset in place.  Everything is resident
+in HBM before the timed region.  K steps are timed `--repeats` (5) times, each between a barrier + synchronize pair;
+value = (ranks x envs x K) / median-over-repeats of the max-over-ranks time (min / max are reported as well).
 
 For N > 1 launch with torchrun (one rank per GPU); environments are independent so they are sharded across ranks
 with no data-path collective (weak scaling).
 
-Extra objects in the JSON line:
-  roofline      dominant kernel (at_velocity_kernel): algorithmic bytes per launch / launch duration measured with
-                HIP events on the launch stream vs the 8 TB/s HBM peak; PMC traffic from profiles/traffic.json;
-                a device-copy microbenchmark of the same run
-  rates         S2_full_chip = the same S2 workload with 256 envs (one workgroup on every CU);
-                S1 = the reference-semantics Env2DAirfoil.step incl. Q-forward, S3 = S1 + one IPCS step on every
-                coarsened mesh (the literal north-star step), training_loop = S1 rollout + replay + optimiser step
-                (with the RCCL gradient all-reduce for N > 1); all resident on the GPU
-  cpu_baseline  the numpy/scipy sparse-LU oracle on one host core, on 12 processes (the reference's num_parallel)
-                and for S1; rank 0 at N = 1 only, measured BEFORE the GPU is initialised
+Top-level extras: s1_env_steps_per_s (the reference-semantics step without the flow re-solve), s2_ipcs_env_steps_per_s
+(one FlowSolver.evolve per env on 128 identical, developed-flow meshes), s3_env_steps_per_s (= value),
+training_env_steps_per_s (S1 rollout + replay + optimiser step, RCCL all-reduce for N > 1).
+  roofline      dominant kernel of an S3 step (smooth_kernel): algorithmic bytes per launch / launch duration measured
+                with HIP events on the launch stream in this run vs the 8 TB/s HBM peak (a latency-bound kernel: the
+                fraction is tiny and says so); `step` = the whole S3 step's algorithmic bytes (S1 part + the IPCS leg in
+                the SURVEY 8(d) convention with the measured iteration counts) over the step time
+  roofline_s2_velocity   the dominant S2 kernel (at_velocity_kernel), bound by LDS fp64 atomics / FP64 issue: fraction
+                by the implemented algorithm's bytes and by the PMC counter traffic (profiles/, rocprofv3 --pmc)
+  rates         details of every measurement, incl. BASELINE configs C2 (S2 on diverged meshes), C3 (ah93w145) and C5
+                (red-refined mesh)
+  cpu_baseline  the numpy/scipy oracle on the host: the same S3 step on one core (bounded sample), plus the IPCS step
+                alone on 1 core and on 12 processes (the reference's num_parallel); rank 0 at N = 1 only, measured
+                BEFORE the GPU is initialised
 """
 import argparse
 import os as _os
@@ -41,7 +48,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-_BASE_ENV = None
 _WARMED = False
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -82,6 +88,30 @@ def cpu_baseline_parallel(budget_s=8.0, procs=12):
     return sum(n / dt for n, dt in res)
 
 
+def cpu_baseline_s3(budget_s=20.0):
+    """The S3 env step of ONE ys930 env with the oracle on one core: OracleEnv.step (scipy Delaunay, smoothing,
+    interpolation, probes, state) + FlowSolver on the coarsened mesh (assembly + sparse LU, like the reference's
+    remesh under DEPLOY) + one evolve() from the interpolated last snapshot.  Returns (steps, seconds)."""
+    from oracle.env import OracleEnv
+    from oracle.ipcs import OracleFlowSolver
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ys930.npz"))
+    agent = dict(solver_steps=20, episodes=10, timesteps=10000, threshold=0.001, N_closest=180, gt_drag=-1, gt_time=-1,
+                 u=-1, p=-1, time_reward=0.005, save_steps=4, goal_vertices=0.95, plot_dir="")
+    env = OracleEnv(z["coords"], z["cells"], agent)
+    env.get_state()
+    rng = np.random.default_rng(1370)
+    n = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        env.step(int(rng.integers(0, 180)))
+        m = env.flow.mesh
+        fs = OracleFlowSolver(m.coords, m.cells, smooth=False)
+        fs.u_n, fs.p_n = env.u[-1].copy(), env.p[-1].copy()
+        fs.evolve()
+        n += 1
+    return n, time.perf_counter() - t0
+
+
 def cpu_baseline(budget_s=15.0, spinup=20):
     """Oracle (kind 'port') on one core: IPCS evolve() steps/s for ONE ys930 env."""
     os.environ.setdefault("OMP_NUM_THREADS", "1")
@@ -96,75 +126,94 @@ def cpu_baseline(budget_s=15.0, spinup=20):
         fs.evolve()
         n += 1
     dt = time.perf_counter() - t0
-    out = dict(value=n / dt, unit="env steps/s", cores=1, kind="port",
-               sample=f"{n} FlowSolver.evolve() steps of 1 ys930 env (numpy/scipy oracle, sparse LU "
-                      f"back-substitution like the reference's MUMPS path), {dt:.1f} s on 1 core; "
-                      f"mesh smoothing / assembly / factorisation excluded")
-    legs = os.environ.get("MDQ_BENCH_CPU_LEGS", "s1,parallel").split(",")   # (debug knob)
-    if "s1" not in legs:
-        return out
-    # the same for S1 (reference-semantics env step: scipy Delaunay + smoothing + interpolation + probes + state)
-    from oracle.env import OracleEnv
-    agent = dict(solver_steps=20, episodes=10, timesteps=10000, threshold=0.001, N_closest=180, gt_drag=-1, gt_time=-1,
-                 u=-1, p=-1, time_reward=0.005, save_steps=4, goal_vertices=0.95, plot_dir="")
-    env = OracleEnv(z["coords"], z["cells"], agent)
-    env.get_state()
-    rng = np.random.default_rng(1370)
-    t0 = time.perf_counter()
-    for m in range(3):
-        env.step(int(rng.integers(0, 180)))
-    out["s1_value"] = 3 / (time.perf_counter() - t0)
-    out["s1_sample"] = "3 OracleEnv.step() calls of 1 ys930 env (python loops for interpolation / smoothing), 1 core"
+    s2 = dict(value=n / dt, unit="IPCS env steps/s", cores=1,
+              sample=f"{n} FlowSolver.evolve() steps of 1 ys930 env (numpy/scipy oracle, sparse LU back-substitution like "
+                     f"the reference's MUMPS path), {dt:.1f} s on 1 core; mesh smoothing / assembly / factorisation excluded")
+    legs = os.environ.get("MDQ_BENCH_CPU_LEGS", "s3,parallel").split(",")   # (debug knob)
+    out = dict(value=None, unit="env steps/s", cores=1, kind="port", sample="S3 leg skipped (MDQ_BENCH_CPU_LEGS)", s2_ipcs=s2)
+    if "s3" in legs:
+        n3, dt3 = cpu_baseline_s3(max(budget_s, 10.0))
+        out.update(value=n3 / dt3,
+                   sample=f"{n3} S3 env steps of 1 ys930 env in {dt3:.1f} s on 1 core: OracleEnv.step (scipy Delaunay, "
+                          "python-loop smoothing / interpolation / probes / state) + Taylor-Hood assembly and sparse LU of "
+                          "the coarsened mesh + one evolve() from the interpolated last snapshot (numpy/scipy oracle); no "
+                          "Q-network forward (negligible)")
     try:
         procs = 12
         if "parallel" not in legs:
             raise RuntimeError("skipped (MDQ_BENCH_CPU_LEGS)")
         if any(os.environ.get(k) for k in ("HSA_TOOLS_LIB", "ROCP_TOOL_LIB", "ROCPROFILER_LIBRARY")):
             raise RuntimeError("skipped under a profiler (its preloaded tool may already hold the GPU: no child interpreters)")
-        out["parallel_value"] = cpu_baseline_parallel(8.0, procs)
-        out["parallel_sample"] = (f"{procs} independent single-threaded oracle processes (the reference's num_parallel: 12 "
-                                  f"workers), 8 s each, aggregate IPCS env-steps/s; host exposes {os.cpu_count()} logical "
-                                  f"CPUs" + _quota_note())
+        s2["parallel_value"] = cpu_baseline_parallel(8.0, procs)
+        s2["parallel_sample"] = (f"{procs} independent single-threaded oracle processes (the reference's num_parallel: 12 "
+                                 f"workers), 8 s each, aggregate IPCS env-steps/s; host exposes {os.cpu_count()} logical "
+                                 f"CPUs" + _quota_note())
     except Exception as exc:  # noqa: BLE001 - the baseline is informational
-        out["parallel_value"] = None
-        out["parallel_sample"] = f"failed: {exc!r}"
+        s2["parallel_value"] = None
+        s2["parallel_sample"] = f"failed: {exc!r}"
     return out
 
 
-def _env_config(args):
+def _env_config(args, mesh=None):
     return dict(flow_config=dict(flow_params=dict(mu=1e-3, rho=1.0, inflow="constant"),
-                                 geometry_params=dict(mesh=os.path.join(ROOT, "tests", "golden", f"{args.mesh}.npz")),
+                                 geometry_params=dict(mesh=os.path.join(ROOT, "tests", "golden", f"{mesh or args.mesh}.npz")),
                                  solver_params=dict(dt=0.001, solver_type="lu", smooth=True)),
                 agent_params=dict(solver_steps=args.s1_solver_steps, episodes=10, timesteps=10000, threshold=0.001,
                                   N_closest=180, gt_drag=-1, gt_time=-1, u=-1, p=-1, time_reward=0.005,
                                   save_steps=args.s1_solver_steps // 5, goal_vertices=0.95, plot_dir=""))
 
 
-def measure_env_steps(args, dev, dist, world, flow_steps=0):
-    """Unit of work S1: the reference-semantics Env2DAirfoil.step for every env of the batch - vertex
-    removal + Delaunay restoration + smooth(50) (host C++ pool), snapshot interpolation + 10 force integrals + state
-    (GPU), fused Q-network forward + epsilon-greedy action (GPU).  Returns env-steps/s over all ranks."""
+_BASE_ENVS = {}
+
+
+def _timed(dist, dev, fn):
+    """fn() between two barrier + synchronize pairs; the max over the ranks of the elapsed time."""
+    import torch
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = tt.item()
+    return el
+
+
+def measure_env_steps(args, dev, dist, world, flow_steps=0, steps=None, warmup=8, repeats=1, mesh=None, keep=None):
+    """Units of work S1 / S3 for every env of the batch, all on the GPU: vertex removal + Delaunay
+    restoration (mdq_remesh), smooth(50) (mdq_smooth), topology / N-closest / state graph (mdq_env_topology), snapshot
+    interpolation + 10 force integrals + node features, fused Q-network forward + epsilon-greedy action; with
+    flow_steps > 0 (S3) also the matrix-free IPCS set-up and `flow_steps` IPCS steps on every coarsened mesh.
+    `steps` batched steps are timed `repeats` times.  Returns env-steps/s over all ranks (median) and the details."""
     import torch
     from meshdqn_amd.airfoilgcnn import NodeRemovalNet
     from meshdqn_amd.env import Env2DAirfoil
     from meshdqn_amd.gcn_fused import FusedGcn
     from meshdqn_amd.vec_env import VecEnvGroups
-    cfg = _env_config(args)
+    mesh = mesh or args.mesh
+    steps = steps or args.s1_steps
+    cfg = _env_config(args, mesh)
     B = args.envs
-    global _BASE_ENV
-    if _BASE_ENV is None:
-        _BASE_ENV = Env2DAirfoil(cfg, compute_device=dev)      # ground truth + snapshots: 5000 IPCS steps, once
+    if mesh not in _BASE_ENVS:
+        _BASE_ENVS[mesh] = Env2DAirfoil(cfg, compute_device=dev)      # ground truth + snapshots: 5000 IPCS steps, once
+    base = _BASE_ENVS[mesh]
     G = args.env_groups
     global _WARMED
     if not _WARMED:
         # process-level warm-up: the first rollout of a process runs with 8-20 ms jitter per step for about a second
         # (host thread pool, per-thread heaps, HIP per-thread state); a throw-away rollout absorbs it
         _WARMED = True
-        w = VecEnvGroups(cfg, B, G, compute_device=dev, base_env=_BASE_ENV, flow_steps=1, flow_rtol=args.rtol)
+        w = VecEnvGroups(cfg, B, G, compute_device=dev, base_env=base, flow_steps=1, flow_rtol=args.rtol)
         wr = np.random.default_rng(0)
         w.rollout(lambda g, env, st: wr.integers(0, 181, env.B), args.s1_warmup)
         del w
-    groups = VecEnvGroups(cfg, B, G, compute_device=dev, base_env=_BASE_ENV, flow_steps=flow_steps, flow_rtol=args.rtol)
+    groups = VecEnvGroups(cfg, B, G, compute_device=dev, base_env=base, flow_steps=flow_steps, flow_rtol=args.rtol)
     torch.manual_seed(0)
     net = NodeRemovalNet(181, conv_width=128, topk=0.1)
     net.set_num_nodes(17)
@@ -178,42 +227,47 @@ def measure_env_steps(args, dev, dist, world, flow_steps=0):
         greedy = q.argmax(1).cpu().numpy()
         return np.where(rngs[g].random(env.B) < 0.5, rngs[g].integers(0, 181, env.B), greedy)
 
-    groups.rollout(act, 8)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    groups.rollout(act, args.s1_steps)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = tt.item()
+    groups.rollout(act, warmup)
+    times = [_timed(dist, dev, lambda: groups.rollout(act, steps)) for _ in range(repeats)]
+    el = float(np.median(times))
     venv = groups.envs[0]
-    what = ("S1 = reference-semantics Env2DAirfoil.step, meshes resident on the GPU for the whole step: remove vertex + "
-            "Delaunay restoration (mdq_remesh), smooth(50) (mdq_smooth, dataflow kernel), topology + N-closest selection "
-            "+ state graph (mdq_env_topology), 5-snapshot interpolation, 10 force integrals, node features, fused "
-            "Q-forward; the host maps actions to vertex ids and evaluates the reward formula; epsilon = 0.5 policy, "
-            "terminated envs reset in place")
-    rate = world * B * args.s1_steps / el
-    # S1 moves ~0.7 MB of algorithmic traffic per env step (5 snapshots read + written, mesh a few times)
-    out = dict(value=rate, unit="env steps/s", ms_per_batched_step=el / args.s1_steps * 1e3,
-               batched_steps=args.s1_steps, host_threads_per_rank=venv.nthreads, env_groups=len(groups.envs),
-               roofline=dict(bound="latency (smoothing dependency chain)", algorithmic_bytes_per_env_step=0.7e6,
-                             achieved_GBs=rate * 0.7e6 / 1e9 / world, peak_GBs=HBM_PEAK_GBS,
-                             frac=rate * 0.7e6 / 1e9 / world / HBM_PEAK_GBS))
+    rate = world * B * steps / el
+    out = dict(value=rate, unit="env steps/s", ms_per_batched_step=el / steps * 1e3, batched_steps=steps, repeats=repeats,
+               value_min=world * B * steps / max(times), value_max=world * B * steps / min(times),
+               seconds_per_repeat=times, mesh=mesh, envs_per_gpu=B, env_groups=len(groups.envs),
+               vertices_min_max=[int(min(e.nv.min() for e in groups.envs)), int(max(e.nv.max() for e in groups.envs))])
     if flow_steps > 0:
         it = np.concatenate([e.flow_iters.cpu().numpy() for e in groups.envs]).astype(np.float64) / flow_steps
-        what = (f"S3 = S1 + {flow_steps} IPCS step(s) on every coarsened mesh: mdq_env_topology emits the matrix-free "
-                "index data, mdq_ipcs_setup_matfree rebuilds geometry / diagonals / lifting vectors / P1 Laplacian, "
-                "mode-3 kernels with Jacobi-CG pressure, warm start = interpolated last snapshot")
         out["krylov_iters_per_ipcs_step"] = {"velocity_bicgstab": float(it[:, 0].mean()), "pressure_cg": float(it[:, 1].mean()),
                                              "correction_cg": float(it[:, 2].mean())}
-    out["what"] = what
+    if keep is not None:
+        keep.append(groups)
     return out
+
+
+def measure_smooth_kernel(dev, groups, reps=20):
+    """Launch duration of smooth_kernel (HIP events on the launch stream, this run) on the diverged meshes the S3
+    rollout has left in the first env group, all of them smoothed (50 sweeps); algorithmic bytes = coordinates read
+    and written + cells read."""
+    import torch
+    from meshdqn_amd.mesh_ops import smooth_batch_gpu
+    dt = groups.envs[0].dtopo
+    nv, nt = dt.nv.cpu().numpy(), dt.nt.cpu().numpy()
+    its = torch.full_like(dt.nv, 50)
+    c0 = dt.coords.clone()
+    smooth_batch_gpu(c0.clone(), dt.cells, dt.nv, dt.nt, its)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ms = []
+    for _ in range(reps):
+        c = c0.clone()
+        e0.record()
+        smooth_batch_gpu(c, dt.cells, dt.nv, dt.nt, its)
+        e1.record()
+        torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    nbytes = float((nv.astype(np.float64) * 32 + nt.astype(np.float64) * 12).sum())
+    return dict(launch_ms=float(np.mean(ms)), launch_ms_min=float(np.min(ms)), launches=reps, meshes=int(len(nv)),
+                algorithmic_bytes_per_launch=nbytes)
 
 
 def measure_s2_full_chip(args, dev, topo, x, envs=256):
@@ -223,9 +277,9 @@ def measure_s2_full_chip(args, dev, topo, x, envs=256):
     from meshdqn_amd.ipcs_batch import IpcsBatch
     batch = IpcsBatch([topo] * envs, [x] * envs, device=dev, rtol=args.rtol, cell_order=args.cell_order)
     out = (torch.empty((envs, 1), dtype=torch.float64, device=dev), torch.empty((envs, 1), dtype=torch.float64, device=dev))
-    for _ in range(args.spinup + args.warmup):
+    for _ in range(args.spinup + 20):
         batch.evolve(1, out=out)
-    n = max(args.steps // 2, 10)
+    n = max(args.s2_steps // 2, 10)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n):
@@ -251,7 +305,7 @@ def measure_train(args, dev, dist, world):
     ctx = DistContext(device=dev)                 # re-uses the process group bench.py has initialised
     trainer = DQNTrainer(n_actions=180, num_inputs=17, ctx=ctx)
     cfg = _env_config(args)
-    venv = VecEnv2DAirfoil(cfg, args.envs, compute_device=dev, base_env=_BASE_ENV)
+    venv = VecEnv2DAirfoil(cfg, args.envs, compute_device=dev, base_env=_BASE_ENVS[args.mesh])
     train_loop_vec(trainer, venv, 4)              # fills the replay ring past one minibatch, warms the autograd path
     torch.cuda.synchronize()
     if dist is not None:
@@ -274,24 +328,74 @@ def measure_train(args, dev, dist, world):
                      "one flat gradient all-reduce over the ranks)")
 
 
+def measure_s2(args, dev, dist, world, topos, xs, steps, warmup, spinup, **kw):
+    """Unit of work S2: one FlowSolver.evolve() per env (three launches: velocity, pressure, correction).  Returns the
+    rate, the per-kernel durations (HIP events recorded by the library on the launch stream) and the byte counts."""
+    import torch
+    from meshdqn_amd.ipcs_batch import IpcsBatch
+    B = len(topos)
+    batch = IpcsBatch(topos, xs, device=dev, rtol=args.rtol, cell_order=args.cell_order, **kw)
+    batch.assemble()
+    out = (torch.empty((B, 1), dtype=torch.float64, device=dev), torch.empty((B, 1), dtype=torch.float64, device=dev))
+    for _ in range(spinup + warmup):
+        batch.evolve(1, out=out)
+    batch.iters.zero_()
+
+    def run():
+        for _ in range(steps):
+            batch.evolve(1, out=out)
+
+    elapsed = _timed(dist, dev, run)
+    iters = batch.iters.cpu().numpy().astype(np.float64) / steps
+    res = dict(value=world * B * steps / elapsed, unit="env steps/s", ms_per_step=elapsed / steps * 1e3, steps=steps,
+               envs_per_gpu=B, mode=int(batch.desc.mode), pressure_direct=bool(batch.desc.pd_enabled),
+               krylov_iters_per_step={"velocity_bicgstab": float(iters[:, 0].mean()), "pressure": float(iters[:, 1].mean()),
+                                      "correction_cg": float(iters[:, 2].mean())},
+               drag_env0=float(out[0][0, 0].item()), lift_env0=float(out[1][0, 0].item()))
+    return res, batch
+
+
+def _diverged_meshes(args, n_envs, removals=20):
+    """BASELINE C2: `n_envs` ys930 meshes after `removals` scripted interior-vertex removals each (default_rng(1370 +
+    env), host engine: Delaunay restoration + smooth(50) per removal) -> list of (MeshTopology, coordinates)."""
+    from meshdqn_amd.mesh_ops import remesh_batch
+    from meshdqn_amd.topology import MeshTopology
+    z = np.load(os.path.join(ROOT, "tests", "golden", f"{args.mesh}.npz"))
+    nv0, nt0 = z["coords"].shape[0], z["cells"].shape[0]
+    coords = np.repeat(z["coords"][None].astype(np.float64), n_envs, 0).copy()
+    cells = np.repeat(np.sort(z["cells"], axis=1).astype(np.int32)[None], n_envs, 0).copy()
+    nv, nt = np.full(n_envs, nv0, np.int32), np.full(n_envs, nt0, np.int32)
+    assert (remesh_batch(coords, cells, nv, nt, np.full(n_envs, -1, np.int32), 50) == 0).all()
+    interior = ~MeshTopology(z["coords"], z["cells"]).on_boundary       # (boundary vertices have the lowest ids and stay)
+    nb = int((~interior).sum())
+    rngs = [np.random.default_rng(1370 + b) for b in range(n_envs)]
+    for _ in range(removals):
+        rem = np.array([int(r.integers(nb, nv[b])) for b, r in enumerate(rngs)], np.int32)
+        assert (remesh_batch(coords, cells, nv, nt, rem, 50) == 0).all()
+    return [(MeshTopology(coords[b, :nv[b]], cells[b, :nt[b]]), coords[b, :nv[b]].copy()) for b in range(n_envs)]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50, help="K: batched S3 env steps per timed repeat")
+    ap.add_argument("--warmup", type=int, default=10, help="W: untimed batched S3 env steps in front")
+    ap.add_argument("--repeats", type=int, default=5, help="timed repeats of the K steps (median reported)")
     ap.add_argument("--envs", type=int, default=128, help="environments per GPU")
-    ap.add_argument("--spinup", type=int, default=300, help="untimed IPCS steps from rest before warmup")
+    ap.add_argument("--spinup", type=int, default=300, help="S2: untimed IPCS steps from rest before warmup")
+    ap.add_argument("--s2-steps", type=int, default=200)
     ap.add_argument("--mesh", default="ys930")
     ap.add_argument("--rtol", type=float, default=1e-10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--s1-steps", type=int, default=50, help="batched reference-semantics env steps (0 = skip)")
+    ap.add_argument("--s1-steps", type=int, default=50, help="batched steps of the S1 / C3 side measurements (0 = skip all side measurements)")
     ap.add_argument("--cell-order", default="conflictfree", choices=["mesh", "conflictfree"])
     ap.add_argument("--train-steps", type=int, default=20, help="batched learning-loop steps (0 = skip)")
     ap.add_argument("--s1-warmup", type=int, default=40)
     ap.add_argument("--env-groups", type=int, default=1, help="concurrently stepped env groups per GPU for S1 / S3")
     ap.add_argument("--s1-solver-steps", type=int, default=5000, help="IPCS steps of the ground-truth reset()")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C2 / C3 / C5 side measurements")
     args = ap.parse_args()
 
     # CPU baseline FIRST, before anything initialises the GPU: its multi-process leg starts child interpreters
@@ -319,6 +423,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    rccl = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -329,8 +434,13 @@ def main():
         backend = os.environ.get("MDQ_DIST_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            try:
+                rccl = dict(backend="nccl (RCCL)", version=".".join(str(v) for v in torch.cuda.nccl.version()), ranks=world)
+            except Exception:  # noqa: BLE001
+                rccl = dict(backend="nccl (RCCL)", ranks=world)
         else:
             dist.init_process_group(backend)
+            rccl = dict(backend=backend, ranks=world)
     else:
         dist = None
         dev_index = 0
@@ -342,64 +452,43 @@ def main():
         _b.build()
     if dist is not None:
         dist.barrier()
-    from meshdqn_amd.ipcs_batch import IpcsBatch, smooth_coords
+    from meshdqn_amd.ipcs_batch import smooth_coords
     from meshdqn_amd.topology import MeshTopology
+    import gc
+    side = args.s1_steps > 0
 
+    # ---------------- headline: S3, K steps x repeats
+    gc.collect()
+    gc.disable()            # no collector pause inside the timed regions
+    keep = []
+    s3 = measure_env_steps(args, dev, dist, world, 1, steps=args.steps, warmup=args.warmup, repeats=args.repeats, keep=keep)
+    smk = measure_smooth_kernel(dev, keep[0])
+    del keep
+    gc.enable()
+
+    # ---------------- S2 on the BASELINE configuration (128 identical meshes, developed flow)
     z = np.load(os.path.join(ROOT, "tests", "golden", f"{args.mesh}.npz"))
     topo = MeshTopology(z["coords"], z["cells"])
     x = smooth_coords(topo, 50)
     B = args.envs
-    batch = IpcsBatch([topo] * B, [x] * B, device=dev, rtol=args.rtol, cell_order=args.cell_order)
-    batch.assemble()
-    out = (torch.empty((B, 1), dtype=torch.float64, device=dev), torch.empty((B, 1), dtype=torch.float64, device=dev))
-    # developed flow state (untimed); single-step launches like the timed region so that the
-    # rocprofv3 --stats average of evolve_kernel over the whole run is comparable with launch_ms
-    for _ in range(args.spinup):
-        batch.evolve(1, out=out)
-    for _ in range(args.warmup):
-        batch.evolve(1, out=out)
-    batch.iters.zero_()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record()            # (events are created lazily at their first record: not inside the timed region)
-    ev1.record()
-    import gc
-    gc.collect()
-    gc.disable()            # no collector pause inside a timed region that may be only a few milliseconds long
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        batch.evolve(1, out=out)  # one launch of evolve_kernel on torch's current stream
-    ev1.record()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    gc.enable()
-    kern_ms = ev0.elapsed_time(ev1) / args.steps  # average launch duration (HIP events, same stream)
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = tt.item()
-
-    iters = batch.iters.cpu().numpy().astype(np.float64) / args.steps  # (B,3) per step
-    drag = out[0][:, 0].cpu().numpy()
-    lift = out[1][:, 0].cpu().numpy()
+    s2, batch = measure_s2(args, dev, dist, world, [topo] * B, [x] * B, args.s2_steps, 20, args.spinup)
     # second pass over the same number of steps with HIP events around every kernel launch (recorded by the
     # library on the launch stream): average duration of each of the three kernels of a step
     batch.iters.zero_()
-    _, _, kms = batch.evolve_timed(args.steps, out=(torch.empty((B, args.steps), dtype=torch.float64, device=dev),
-                                                   torch.empty((B, args.steps), dtype=torch.float64, device=dev)))
-    iters2 = batch.iters.cpu().numpy().astype(np.float64) / args.steps
-    k_vel, k_prs, k_cor = (m / args.steps for m in kms)
+    n2 = args.s2_steps
+    _, _, kms = batch.evolve_timed(n2, out=(torch.empty((B, n2), dtype=torch.float64, device=dev),
+                                           torch.empty((B, n2), dtype=torch.float64, device=dev)))
+    iters2 = batch.iters.cpu().numpy().astype(np.float64) / n2
+    k_vel, k_prs, k_cor = (m / n2 for m in kms)
     vel_bytes = batch.velocity_kernel_bytes(iters2)
     vel_flops = batch.velocity_kernel_flops(iters2)
     survey_bytes = batch.algorithmic_bytes_per_step(iters2)  # SURVEY 8(d) assembled-CSR convention, whole step
     step_bytes = batch.implemented_bytes_per_step(iters2)     # bytes the implemented algorithm moves, whole step
+    # the IPCS leg of an S3 step in the SURVEY 8(d) convention, with the iteration counts measured in the S3 rollout
+    it3 = s3["krylov_iters_per_ipcs_step"]
+    s3_ipcs_bytes = batch.algorithmic_bytes_per_step(np.tile(np.array([[it3["velocity_bicgstab"], it3["pressure_cg"],
+                                                                         it3["correction_cg"]]]), (B, 1)))
+    del batch
 
     # device-copy microbenchmark in the same run (check the 8 TB/s spec figure used as `peak`)
     src = torch.empty(1 << 28, dtype=torch.float32, device=dev)  # 1 GiB
@@ -414,66 +503,121 @@ def main():
     copy_gbs = 10 * 2 * src.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9   # read + write
     del src, dst
 
-    full = measure_s2_full_chip(args, dev, topo, x) if args.s1_steps > 0 else None
-    s3 = measure_env_steps(args, dev, dist, world, 1) if args.s1_steps > 0 else None
-    s1 = measure_env_steps(args, dev, dist, world, 0) if args.s1_steps > 0 else None
-    tr = measure_train(args, dev, dist, world) if args.s1_steps > 0 and args.train_steps > 0 else None
+    full = measure_s2_full_chip(args, dev, topo, x) if side else None
+    s1 = measure_env_steps(args, dev, dist, world, 0, repeats=3) if side else None
+    tr = measure_train(args, dev, dist, world) if side and args.train_steps > 0 else None
+    cfgs = {}
+    if side and not args.no_configs and world == 1:
+        # BASELINE configs beyond C1 / C2-identical: iteration counts included, rank-local, short
+        try:
+            dm = _diverged_meshes(args, B)
+            c2, b2 = measure_s2(args, dev, None, 1, [t for t, _ in dm], [c for _, c in dm], 50, 10, args.spinup,
+                                pressure_direct=False)
+            c2["what"] = ("C2: S2 on 128 DIFFERENT ys930 meshes (20 scripted removals each, default_rng(1370 + env), Delaunay "
+                          "restoration + smooth(50) per removal), developed flow, Jacobi-CG pressure (no factorisation of a "
+                          "coarsened mesh)")
+            c2["vertices_min_max"] = [int(min(t.nv for t, _ in dm)), int(max(t.nv for t, _ in dm))]
+            del b2
+            cfgs["C2_s2_diverged_meshes"] = c2
+        except Exception as exc:  # noqa: BLE001 - side measurement
+            cfgs["C2_s2_diverged_meshes"] = dict(error=repr(exc))
+        try:
+            c3 = measure_env_steps(args, dev, None, 1, 1, steps=args.s1_steps, repeats=3, mesh="ah93w145")
+            c3["what"] = "C3: the S3 step on the second airfoil geometry (ah93w145, 797 vertices), 128 envs"
+            cfgs["C3_s3_ah93w145"] = c3
+        except Exception as exc:  # noqa: BLE001
+            cfgs["C3_s3_ah93w145"] = dict(error=repr(exc))
+        try:
+            from meshdqn_amd.mesh_ops import red_refine
+            rc_, rcells = red_refine(x, z["cells"])
+            rt = MeshTopology(rc_, rcells)
+            c5, b5 = measure_s2(args, dev, None, 1, [rt] * B, [rc_] * B, 20, 5, 100)
+            it5 = np.tile(np.array([[c5["krylov_iters_per_step"][k] for k in ("velocity_bicgstab", "pressure", "correction_cg")]]), (B, 1))
+            by5 = b5.algorithmic_bytes_per_step(it5)
+            c5.update(what="C5: S2 on ys930 red-refined once (assembled SELL path: the mesh does not fit the LDS-resident modes), "
+                           "100 spin-up steps from rest", vertices=int(rt.nv), triangles=int(rt.nt),
+                      survey_csr_bytes_per_step=by5, survey_equivalent_GBs=by5 / (c5["ms_per_step"] * 1e-3) / 1e9,
+                      frac_of_hbm_peak=by5 / (c5["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS)
+            del b5
+            cfgs["C5_s2_refined_mesh"] = c5
+        except Exception as exc:  # noqa: BLE001
+            cfgs["C5_s2_refined_mesh"] = dict(error=repr(exc))
 
     if rank == 0:
-        achieved = vel_bytes / (k_vel * 1e-3) / 1e9
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp):
+        def prof(name, key):
+            fp = os.path.join(ROOT, "profiles", name)
             try:
-                traffic = json.load(open(tp)).get("velocity_kernel_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        nt, nv, ne = topo.nt, topo.nv, topo.ne
+                return json.load(open(fp)).get(key)
+            except Exception:  # noqa: BLE001
+                return None
+        nt, nv = topo.nt, topo.nv
+        sm_gbs = smk["algorithmic_bytes_per_launch"] / (smk["launch_ms"] * 1e-3) / 1e9
+        s3_step_bytes = (0.7e6 * B + s3_ipcs_bytes)            # S1 part 0.7 MB per env step + the IPCS leg
+        s3_gbs = s3_step_bytes / (s3["ms_per_batched_step"] * 1e-3) / 1e9
+        vel_gbs = vel_bytes / (k_vel * 1e-3) / 1e9
+        vel_traffic = prof("traffic.json", "velocity_kernel_hbm_bytes_per_launch")
         res = {
             "metric": "env steps/sec (ys930 ~2k-tri)",
-            "value": world * B * args.steps / elapsed,
+            "value": s3["value"],
             "unit": "env steps/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": s3["ms_per_batched_step"],
+            "repeats": args.repeats,
+            "value_min": s3["value_min"],
+            "value_max": s3["value_max"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "s3_env_steps_per_s": s3["value"],
+            "s1_env_steps_per_s": None if s1 is None else s1["value"],
+            "s2_ipcs_env_steps_per_s": s2["value"],
+            "training_env_steps_per_s": None if tr is None else tr["value"],
             "config": {
-                "workload": f"{args.mesh} ({nv} vertices / {nt} triangles, smoothed), {B} batched envs per GPU, "
-                            f"step = S2: one IPCS evolve() per env (3 RHS + BiCGStab / direct pressure / CG + drag/lift), "
-                            f"developed flow after {args.spinup} untimed steps from rest",
+                "workload": f"{args.mesh} ({nv} vertices / {nt} triangles), {B} batched envs per GPU, step = S3 (north-star env "
+                            f"step): remove vertex + Delaunay restoration + smooth(50) + 5-snapshot interpolation + 10 force "
+                            f"integrals + state graph + ONE IPCS step on every coarsened mesh (matrix-free, Jacobi-BiCGStab / "
+                            f"CG, rtol {args.rtol:g}, warm start = interpolated last snapshot) + fused Q-network forward; "
+                            f"epsilon = 0.5 actions from default_rng(1370 + ...), meshes diverge (vertices "
+                            f"{s3['vertices_min_max'][0]}..{s3['vertices_min_max'][1]} at the end), terminated envs reset in place",
                 "envs_per_gpu": B, "rtol": args.rtol, "dt": 1e-3, "mu": 1e-3, "rho": 1.0,
-                "krylov_iters_per_step": {"velocity_bicgstab": float(iters[:, 0].mean()),
-                                          "pressure": float(iters[:, 1].mean()),
-                                          "correction_cg": float(iters[:, 2].mean())},
-                "drag_env0": float(drag[0]), "lift_env0": float(lift[0]),
+                "krylov_iters_per_ipcs_step": s3["krylov_iters_per_ipcs_step"],
                 "parallelism": f"dp{world} (independent envs sharded, no data-path collective)",
+                "collective_backend": rccl,
                 "reference_published": "45.8 IPCS steps/s for 1 env (FEniCS, unknown hardware; BASELINE.md) - context only",
             },
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "roofline": {"bound": "hbm", "achieved": sm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sm_gbs / HBM_PEAK_GBS,
+                         "traffic": prof("r02_smooth_pmc_summary.json", "hbm_bytes_per_launch"),
+                         "kernel": "smooth_kernel (DOLFIN smooth(50): level-scheduled Gauss-Seidel, one wave per mesh out of LDS)",
+                         "launch_ms": smk["launch_ms"], "launches_timed": smk["launches"],
+                         "algorithmic_bytes_per_launch": smk["algorithmic_bytes_per_launch"],
+                         "share_of_step": smk["launch_ms"] / s3["ms_per_batched_step"],
                          "device_copy_GBs_same_run": copy_gbs,
-                         "kernel": "at_velocity_kernel (rhs1 + matrix-free Jacobi-BiCGStab, LDS fp64 atomics)",
-                         "launch_ms": k_vel, "algorithmic_bytes_per_launch": vel_bytes,
-                         "kernels_ms_per_step": {"at_velocity_kernel": k_vel, "at_pressure_kernel": k_prs,
-                                                 "at_correction_kernel": k_cor},
-                         "whole_step": {"implemented_bytes": step_bytes, "survey_csr_convention_bytes": survey_bytes,
-                                        "survey_equivalent_GBs": survey_bytes / (elapsed / args.steps) / 1e9},
-                         "fp64_valu": {"flops_per_launch": vel_flops,
-                                       "achieved_TFLOPs": vel_flops / (k_vel * 1e-3) / 1e12,
-                                       "peak_TFLOPs_on_used_CUs": 78.6 * min(B, 256) / 256.0,
-                                       "frac": vel_flops / (k_vel * 1e-3) / 1e12 / (78.6 * min(B, 256) / 256.0)},
-                         "note": "matrix-free: operators are re-derived per triangle from 64 B of metadata, Krylov vectors "
-                                 "live in LDS/registers; the binding resources are FP64 VALU issue, LDS atomics and "
-                                 "workgroup barriers on the B CUs in use (one CU per environment), not HBM"},
+                         "note": "LATENCY-bound, not HBM-bound: ~7 000 dependent passes per launch (the mesh numbering makes a "
+                                 "sweep a chain of ~113-141 levels), ~170 ns each; the mesh (47 KB) lives in LDS. The HBM fraction "
+                                 "is reported because the contract asks for it; it is not the resource that binds",
+                         "step": {"algorithmic_bytes_per_batched_step": s3_step_bytes, "s1_part_bytes_per_env": 0.7e6,
+                                  "ipcs_leg_bytes_survey_csr_convention": s3_ipcs_bytes, "achieved_GBs": s3_gbs,
+                                  "frac": s3_gbs / HBM_PEAK_GBS}},
+            "roofline_s2_velocity": {
+                "bound": "lds-atomic/fp64", "kernel": "at_velocity_kernel (rhs1 + matrix-free Jacobi-BiCGStab, LDS fp64 atomics)",
+                "launch_ms": k_vel, "algorithmic_bytes_per_launch": vel_bytes, "achieved_GBs_model": vel_gbs,
+                "frac_of_hbm_peak_model": vel_gbs / HBM_PEAK_GBS,
+                "pmc_traffic_bytes_per_launch": vel_traffic,
+                "frac_of_hbm_peak_pmc": None if not vel_traffic else vel_traffic / (k_vel * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "kernels_ms_per_step": {"at_velocity_kernel": k_vel, "at_pressure_kernel": k_prs, "at_correction_kernel": k_cor},
+                "whole_step": {"implemented_bytes": step_bytes, "survey_csr_convention_bytes": survey_bytes},
+                "fp64_valu": {"flops_per_launch": vel_flops, "achieved_TFLOPs": vel_flops / (k_vel * 1e-3) / 1e12,
+                              "peak_TFLOPs_on_used_CUs": 78.6 * min(B, 256) / 256.0,
+                              "frac": vel_flops / (k_vel * 1e-3) / 1e12 / (78.6 * min(B, 256) / 256.0)},
+                "note": "matrix-free: operators are re-derived per triangle from 64 B of metadata, Krylov vectors live in "
+                        "LDS/registers; one workgroup (one CU) per environment: 128 of 256 CUs at the BASELINE configuration"},
         }
-        res["rates"] = {"S2_ipcs_env_steps_per_s": res["value"], "S2_full_chip": full,
-                        "S1_reference_step_env_steps_per_s": s1,
-                        "S3_north_star_step_env_steps_per_s": s3, "training_loop_env_steps_per_s": tr}
+        res["rates"] = {"S3_north_star_step": s3, "S1_reference_step": s1, "S2_ipcs_step": s2, "S2_full_chip": full,
+                        "training_loop": tr, **cfgs}
         if cpu is not None:
             res["cpu_baseline"] = cpu
         print(json.dumps(res), flush=True)

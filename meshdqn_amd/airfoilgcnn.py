@@ -199,11 +199,20 @@ class _WeightAccessors:
     def flat_gradients(self) -> torch.Tensor:
         return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.parameters()])
 
+    def unused_parameters(self):
+        """Parameters that are constructed (and part of the `state_dict`) but never enter `forward` - the reference's
+        conv3 / pool3 / conv6 / pool6 of `NodeRemovalNet` (airfoilgcnn.py:106-110,124-128).  Their `.grad` stays None,
+        as it does under autograd in the reference, so that an optimiser with weight decay leaves them alone."""
+        return []
+
     def set_flat_gradients(self, flat: torch.Tensor):
+        """Gradients from a flat buffer laid out like `flat_gradients()` (all parameters, so that the message of the
+        all-reduce has the same 173 493 elements on every rank); entries of `unused_parameters()` are ignored."""
+        skip = {id(p) for p in self.unused_parameters()}
         off = 0
         for p in self.parameters():
             n = p.numel()
-            p.grad = flat[off:off + n].view_as(p).clone()
+            p.grad = None if id(p) in skip else flat[off:off + n].view_as(p).clone()
             off += n
 
 
@@ -231,6 +240,9 @@ class NodeRemovalNet(nn.Module, _WeightAccessors):
         self.lin3 = torch.nn.Linear(64, output_dim)
         torch.manual_seed(0)
         self.reset()
+
+    def unused_parameters(self):
+        return [p for m in (self.conv3, self.pool3, self.conv6, self.pool6) for p in m.parameters()]
 
     def reset(self):
         """Initialisation scheme of airfoilgcnn.py:50-76."""

@@ -354,12 +354,9 @@ class DQNTrainer:
         if flat is not None:
             self.ctx.allreduce_mean_(flat)
             net.set_flat_gradients(flat)
-        else:   # one rank: the graph has written the gradients where the optimiser reads them
-            if "zeros" not in g:   # parameters outside the graph (conv3 / conv6, unused pools) keep a zero gradient, as
-                g["zeros"] = [None if gr is not None else torch.zeros_like(p)        # with the flat round trip
-                              for p, gr in zip(net.parameters(), g["grads"])]
-            for p, gr, z in zip(net.parameters(), g["grads"], g["zeros"]):
-                p.grad = gr if gr is not None else z
+        else:   # one rank: the graph has written the gradients where the optimiser reads them; parameters outside the
+            for p, gr in zip(net.parameters(), g["grads"]):   # graph (conv3 / conv6, unused pools) keep grad None
+                p.grad = gr
         self.opts[k].step()
         self.scheds[k].step()
         self.num_grads += 1
@@ -410,18 +407,61 @@ class DQNTrainer:
     def state_dicts(self):
         return self.policy_net_1.state_dict(), self.policy_net_2.state_dict()
 
-    def save(self, save_dir, prefix=""):
-        """`ParameterServer.write` (airfoil_dqn.py:214-218): PyG-keyed state dicts."""
+    def save(self, save_dir, prefix="", extra: Optional[dict] = None):
+        """`ParameterServer.write` (airfoil_dqn.py:214-218): PyG-keyed state dicts `{prefix}policy_net_{1,2}.pt`, plus
+        `{prefix}trainer_state.pt` (both Adam states, both schedulers, gradient count, the double-DQN toggle and
+        whatever the loop hands over in `extra`, e.g. its epsilon step counters) - what a restart needs beyond the
+        reference's two files."""
         os.makedirs(save_dir, exist_ok=True)
         torch.save(self.policy_net_1.state_dict(), os.path.join(save_dir, f"{prefix}policy_net_1.pt"))
         torch.save(self.policy_net_2.state_dict(), os.path.join(save_dir, f"{prefix}policy_net_2.pt"))
+        torch.save(dict(opts=[o.state_dict() for o in self.opts], scheds=[s_.state_dict() for s_ in self.scheds],
+                        num_grads=self.num_grads, select=self.select, extra=extra or {}),
+                   os.path.join(save_dir, f"{prefix}trainer_state.pt"))
+
+    def load(self, save_dir, prefix="", scheduler_steps: Optional[int] = None) -> dict:
+        """RESTART of the reference (airfoil_dqn.py:163-179,230-234): load `{prefix}policy_net_{1,2}.pt` into both
+        Q-networks (in place: captured HIP graphs and the fused forward keep working on the same tensors).  When
+        `{prefix}trainer_state.pt` exists the optimisers, schedulers, gradient count and toggle continue as well;
+        with reference-style checkpoints (two files only) the schedulers are advanced by `scheduler_steps` like the
+        reference's hard-coded fast-forward (:177-179).  Returns the `extra` dict of the checkpoint."""
+        dev = self.ctx.device
+        for net, name in ((self.policy_net_1, "policy_net_1.pt"), (self.policy_net_2, "policy_net_2.pt")):
+            net.load_state_dict(torch.load(os.path.join(save_dir, prefix + name), map_location=dev))
+        path = os.path.join(save_dir, f"{prefix}trainer_state.pt")
+        extra = {}
+        if os.path.exists(path):
+            st = torch.load(path, map_location=dev, weights_only=False)
+            for o, sd in zip(self.opts, st["opts"]):
+                o.load_state_dict(sd)
+            for s_, sd in zip(self.scheds, st["scheds"]):
+                s_.load_state_dict(sd)
+            self.num_grads, self.select, extra = int(st["num_grads"]), bool(st["select"]), st.get("extra", {})
+        elif scheduler_steps:
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")       # (scheduler stepped before the optimiser: intended here)
+                for s_ in self.scheds:
+                    for _ in range(int(scheduler_steps)):
+                        s_.step()
+        return extra
 
 
 def train_loop_per_worker(trainer: DQNTrainer, env_factory, num_episodes: int, max_steps: Optional[int] = None,
-                          eps_decay=10000, eps_start=1.0, eps_end=0.01, share_replay=False, e_max=1024):
+                          eps_decay=10000, eps_start=1.0, eps_end=0.01, share_replay=False, e_max=None):
     """Rollout loop of one rank (airfoil_dqn.py:428-503): epsilon-greedy over N_closest+1 actions, push the
-    transition, optimise, rebuild the env every episode.  Returns per-episode reward lists."""
+    transition, optimise, rebuild the env every episode.  Returns per-episode reward lists.
+
+    With more than one rank every step issues collectives (the gradient all-reduce of `optimize`, the transition
+    all-gather), so all ranks must take the SAME number of steps: episode lengths differ between ranks (per-rank
+    seeds), hence the loop must be bounded by `max_steps` (episodes are then cut at that common step count)."""
     ctx = trainer.ctx
+    if ctx.world > 1 and max_steps is None:
+        raise ValueError("train_loop_per_worker with more than one rank needs max_steps (a step count common to all "
+                         "ranks): ranks that finish their episodes early would leave the others blocked in a collective")
+    if ctx.world > 1:
+        num_episodes = max(num_episodes, max_steps)   # the step count, not the episode count, ends the loop
+    e_max = trainer.e_max if e_max is None else int(e_max)
     n_actions = trainer.n_actions
     steps_done = 0
     env = env_factory()
@@ -467,10 +507,12 @@ class TrainingLog:
     `restart=True` continues from existing files and switches to the `RESTART_` prefix like the reference."""
     FILES = dict(rewards="reward.npy", ep_rewards="rewards.npy", losses="losses.npy", actions="actions.npy", epss="eps.npy")
 
-    def __init__(self, save_dir: str, prefix: str = "", restart: bool = False):
+    def __init__(self, save_dir: str, prefix: str = "", restart: bool = False, restart_num: int = 1):
         self.base = os.path.join(save_dir, prefix)
         self.rewards, self.ep_rewards, self.losses, self.actions, self.epss = [], [], [], [], []
         if restart:
+            # the n-th restart reads the files of restart n - 1 and writes with one more prefix (airfoil_dqn.py:87-110)
+            self.base += "RESTART_" * (max(int(restart_num), 1) - 1)
             for attr, fn in self.FILES.items():
                 try:
                     setattr(self, attr, list(np.load(self.base + fn, allow_pickle=True)))
@@ -680,18 +722,21 @@ def state_refs(st: dict) -> List[StateRef]:
 
 def train_loop_vec(trainer: DQNTrainer, venv, num_steps: int, optim_per_step: int = 1, eps_decay=10000, eps_start=1.0,
                    eps_end=0.01, share_replay=False, e_max=1536, log: Optional["TrainingLog"] = None,
-                   device_replay: bool = True, overlap_optimise: bool = True):
+                   device_replay: bool = True, overlap_optimise: bool = True, steps_done0=None, every: int = 0,
+                   on_every=None):
     """Batched counterpart of `train_loop_per_worker` for one rank: B environments of a `VecEnv2DAirfoil` stepped
     together (configs[3] of BASELINE.json: 128 envs per GPU, 1024 over 8 ranks).  Per batched step: fused Q-forward
     of policy_net_1 for all B states, epsilon-greedy per environment (per-env step counters, like the reference's
     per-worker `steps_done`), `venv.step`, B transitions into the replay ring (optionally all-gathered over the
     ranks), `optim_per_step` optimiser steps (each with ONE flat gradient all-reduce).  Terminated environments are
-    reset in place by the vector env.  Returns dict(rewards (num_steps,B), dones, losses)."""
+    reset in place by the vector env.  `steps_done0` continues the per-environment epsilon counters of an earlier run;
+    `on_every(step, steps_done)` is called after every `every`-th batched step (periodic checkpoints / log writes).
+    Returns dict(rewards (num_steps,B), dones, losses, steps_done)."""
     from .gcn_fused import FusedGcn
     ctx = trainer.ctx
     B, N = venv.B, venv.N
     fused = FusedGcn(trainer.policy_net_1)
-    steps_done = np.zeros(B, np.int64)
+    steps_done = np.zeros(B, np.int64) if steps_done0 is None else np.asarray(steps_done0, np.int64).copy()
     st = venv.get_state()
     # GPU-resident replay (states stored once per batched step, minibatches gathered on the device) whenever the
     # environment hands out its padded edge lists; the per-transition list of lazy references otherwise (and when the
@@ -715,7 +760,7 @@ def train_loop_vec(trainer: DQNTrainer, venv, num_steps: int, optim_per_step: in
     rewards, dones_hist = [], []
     ep_r = [[] for _ in range(B)]
     ep_a = [[] for _ in range(B)]
-    for _ in range(num_steps):
+    for step_no in range(num_steps):
         with torch.no_grad():
             q = fused.forward_arrays(st["x"], st["node_ptr"], st["esrc"], st["edst"], st["edge_ptr"], N, venv.EMAX)
         greedy = q.argmax(1).cpu().numpy()
@@ -767,4 +812,6 @@ def train_loop_vec(trainer: DQNTrainer, venv, num_steps: int, optim_per_step: in
                     ep_r[b], ep_a[b] = [], []
         rewards.append(rew.copy())
         dones_hist.append(done.copy())
-    return dict(rewards=np.array(rewards), dones=np.array(dones_hist), losses=list(trainer.losses))
+        if every and on_every is not None and (step_no + 1) % every == 0:
+            on_every(step_no + 1, steps_done)
+    return dict(rewards=np.array(rewards), dones=np.array(dones_hist), losses=list(trainer.losses), steps_done=steps_done)

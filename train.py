@@ -28,7 +28,11 @@ def main():
     ap.add_argument("--flow-steps", type=int, default=0, help="IPCS steps on the coarsened mesh per env step (S3)")
     ap.add_argument("--share-replay", action="store_true")
     ap.add_argument("--save-dir", default="training_results/run")
-    ap.add_argument("--restart", action="store_true", help="continue the logs found in --save-dir (RESTART_ prefix)")
+    ap.add_argument("--restart", action="store_true",
+                    help="continue the run found in --save-dir: both Q-networks, optimiser / scheduler state, epsilon "
+                         "counters and the logs (files of restart n carry n 'restart_' / 'RESTART_' prefixes, like the "
+                         "reference's RESTART_NUM chain, airfoil_dqn.py:359-366)")
+    ap.add_argument("--save-every", type=int, default=50, help="batched steps between checkpoints / log writes (0 = only at the end)")
     args = ap.parse_args()
     from meshdqn_amd.env import Env2DAirfoil
     from meshdqn_amd.trainer import DistContext, DQNTrainer, TrainingLog, train_loop_vec
@@ -44,17 +48,35 @@ def main():
                          ctx=ctx, lr=float(opt.get("lr", 1e-5)), weight_decay=float(opt.get("weight_decay", 1e-6)),
                          batch_size=int(opt.get("batch_size", 32)), gamma=float(eps.get("gamma", 1.0)),
                          target_update=int(ap_.get("target_update", 50)))
+    # restart chain: restart n reads the checkpoint with n - 1 "restart_" prefixes and writes with n (every rank loads the
+    # same files, so the replicas stay identical)
+    restart_num, steps_done0 = 0, None
+    if args.restart:
+        restart_num = sum(f.endswith("policy_net_1.pt") for f in os.listdir(args.save_dir))
+        if restart_num == 0:
+            raise SystemExit(f"--restart: no policy_net_1.pt checkpoint in {args.save_dir}")
+        extra = trainer.load(args.save_dir, "restart_" * (restart_num - 1))
+        steps_done0 = extra.get("steps_done")
+        if steps_done0 is not None and len(steps_done0) != args.envs:      # other batch size: restart the counters at the mean
+            steps_done0 = np.full(args.envs, int(np.mean(steps_done0)), np.int64)
+    prefix = "restart_" * restart_num
     base = Env2DAirfoil(cfg, compute_device=ctx.device)          # ground truth + snapshots (the reference's first reset())
     venv = VecEnv2DAirfoil(cfg, args.envs, compute_device=ctx.device, base_env=base, flow_steps=args.flow_steps)
-    log = TrainingLog(args.save_dir, restart=args.restart) if ctx.rank == 0 else None
+    log = TrainingLog(args.save_dir, restart=args.restart, restart_num=restart_num) if ctx.rank == 0 else None
+
+    def checkpoint(step, steps_done):
+        if ctx.rank == 0:                                        # (the reference writes after every episode)
+            trainer.save(args.save_dir, prefix, extra=dict(steps_done=np.asarray(steps_done).copy(), batched_steps=step))
+            log.write()                                          # reward / rewards / losses / actions / eps .npy
+
     out = train_loop_vec(trainer, venv, args.steps, log=log, eps_decay=float(eps.get("decay", 10000)),
                          eps_start=float(eps.get("start", 1.0)), eps_end=float(eps.get("end", 0.01)),
-                         share_replay=args.share_replay)
+                         share_replay=args.share_replay, steps_done0=steps_done0, every=args.save_every,
+                         on_every=checkpoint)
     if ctx.rank == 0:
         os.makedirs(args.save_dir, exist_ok=True)
-        trainer.save(args.save_dir)
-        log.write()                                              # reward / rewards / losses / actions / eps .npy
-        np.save(os.path.join(args.save_dir, "step_rewards.npy"), out["rewards"])
+        checkpoint(args.steps, out["steps_done"])
+        np.save(os.path.join(args.save_dir, prefix + "step_rewards.npy"), out["rewards"])
         yaml.safe_dump(cfg, open(os.path.join(args.save_dir, "config.yaml"), "w"))
         print(f"ranks {ctx.world}: {args.steps} batched steps x {args.envs} envs/rank, mean reward {out['rewards'].mean():.4f}")
     ctx.close()
