@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MDQ_ABI_VERSION 1
+#define MDQ_ABI_VERSION 2
 
 /* ---- error handling ----------------------------------------------------- */
 int mdq_abi_version(void);
@@ -239,6 +239,18 @@ typedef struct mdq_gcn_net {
 int mdq_gcn_forward(const mdq_gcn_net* net, int32_t B, int32_t NMAX, int32_t EMAX, const float* x,
                     const int32_t* node_ptr, const int32_t* esrc, const int32_t* edst,
                     const int32_t* edge_ptr, float* emb, float* out, void* stream);
+
+/*
+ * The same forward with two optional device outputs (either may be NULL):
+ *   perm   int32 [B][nlevels][NMAX]  TopKPooling's `perm` of every level (airfoilgcnn.py:96: kept node r of level l =
+ *                                    node perm[r] of the level's input; entries past ceil(ratio n) are -1) - the INDEX
+ *                                    work of the Q-path, which the parity tests hold bit-exact against the oracle
+ *   status int32 [B]                 0 ok, -1 / -2: graph b has more nodes / edges than NMAX / EMAX (its outputs are NaN;
+ *                                    the LDS carve-up is sized from those bounds, a larger graph is never staged)
+ */
+int mdq_gcn_forward_ex(const mdq_gcn_net* net, int32_t B, int32_t NMAX, int32_t EMAX, const float* x,
+                       const int32_t* node_ptr, const int32_t* esrc, const int32_t* edst,
+                       const int32_t* edge_ptr, float* emb, float* out, int32_t* perm, int32_t* status, void* stream);
 
 /* ---- snapshot interpolation onto coarsened meshes (Env2DAirfoil.py:556-593, :515-522) ---- */
 typedef struct mdq_interp_desc {

@@ -243,7 +243,7 @@ struct Level {
 };
 
 // one conv + relu + TopK pool + readout level; features in L.x ([n][fin]) are replaced by the pooled ones
-__device__ inline void run_level(const Lds& L, const Level& lv, int C, double ratio, int& n, int& E, float& rmax,
+__device__ inline void run_level(const Lds& L, const Level& lv, int C, double ratio, int& n, int& E, int32_t* perm, float& rmax,
                                  float& rmean, int NMAX) {
   const int tid = threadIdx.x, fin = lv.fin;
 #ifdef MDQ_GCN_TRACE
@@ -352,6 +352,10 @@ __device__ inline void run_level(const Lds& L, const Level& lv, int C, double ra
       rank += (sj > si) || (sj == si && j < i);
     }
     L.newid[i] = rank < k ? rank : -1;
+    if (perm) {               // TopKPooling's `perm` (kept node r of this level = node perm[r] of its input), on request
+      if (rank < k) perm[rank] = i;
+      if (i >= k) perm[i] = -1;
+    }
   }
   __syncthreads();
   GT_STAMP(4)
@@ -415,11 +419,19 @@ __device__ inline void run_level(const Lds& L, const Level& lv, int C, double ra
 
 __global__ __launch_bounds__(WGT) void gcn_embed_kernel(mdq_gcn_net net, int NMAX, int EMAX, const float* x,
                                                          const int32_t* node_ptr, const int32_t* esrc,
-                                                         const int32_t* edst, const int32_t* edge_ptr, float* emb) {
+                                                         const int32_t* edst, const int32_t* edge_ptr, float* emb,
+                                                         int32_t* perm, int32_t* status) {
   extern __shared__ __align__(16) float sm[];
   const int b = blockIdx.x, tid = threadIdx.x, C = net.C;
   const int n0 = node_ptr[b], nn = node_ptr[b + 1] - n0;
   const int e0 = edge_ptr[b], ne = edge_ptr[b + 1] - e0;
+  if (status && tid == 0) status[b] = (nn > NMAX || nn < 0) ? -1 : (ne > EMAX || ne < 0) ? -2 : 0;
+  if (nn > NMAX || ne > EMAX || nn < 0 || ne < 0) {
+    // the LDS carve-up is sized from NMAX / EMAX: a larger graph must not be staged.  Its outputs are NaN (never a
+    // plausible Q-value) and, where the caller passed one, its status says why
+    if (tid < 2 * C) emb[(size_t)b * 2 * C + tid] = __builtin_nanf("");
+    return;
+  }
   const int XS = mdq_gcn_xs(net, NMAX);  // floats of the level-input / aggregation buffers
   Lds L;
   float* p = sm;
@@ -457,7 +469,7 @@ __global__ __launch_bounds__(WGT) void gcn_embed_kernel(mdq_gcn_net net, int NMA
     if (tid == 0 && b == 0) mdq_gcn_trace_level = l;
     __syncthreads();
 #endif
-    run_level(L, lv, C, net.ratio, n, E, rmax, rmean, NMAX);
+    run_level(L, lv, C, net.ratio, n, E, perm ? perm + ((size_t)b * net.nlevels + l) * NMAX : nullptr, rmax, rmean, NMAX);
   }
   if (tid < C) {
     emb[(size_t)b * 2 * C + tid] = rmax;
@@ -557,6 +569,13 @@ __global__ __launch_bounds__(WGH) void mlp_head_kernel(mdq_gcn_net net, int B, c
 extern "C" int mdq_gcn_forward(const mdq_gcn_net* net, int32_t B, int32_t NMAX, int32_t EMAX, const float* x,
                                const int32_t* node_ptr, const int32_t* esrc, const int32_t* edst,
                                const int32_t* edge_ptr, float* emb, float* out, void* stream) {
+  return mdq_gcn_forward_ex(net, B, NMAX, EMAX, x, node_ptr, esrc, edst, edge_ptr, emb, out, nullptr, nullptr, stream);
+}
+
+extern "C" int mdq_gcn_forward_ex(const mdq_gcn_net* net, int32_t B, int32_t NMAX, int32_t EMAX, const float* x,
+                                  const int32_t* node_ptr, const int32_t* esrc, const int32_t* edst,
+                                  const int32_t* edge_ptr, float* emb, float* out, int32_t* perm, int32_t* status,
+                                  void* stream) {
   using namespace mdq_gcn;
   if (!net || B <= 0 || !x || !node_ptr || !edge_ptr || !emb || !out) return mdq_set_error("mdq_gcn_forward: bad arguments");
   const int C = net->C;
@@ -577,7 +596,7 @@ extern "C" int mdq_gcn_forward(const mdq_gcn_net* net, int32_t B, int32_t NMAX, 
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return mdq_set_error(hipGetErrorString(e));
   hipLaunchKernelGGL(gcn_embed_kernel, dim3(B), dim3(WGT), lds, st, *net, NMAX, EMAX, x, node_ptr, esrc, edst,
-                     edge_ptr, emb);
+                     edge_ptr, emb, perm, status);
   e = hipGetLastError();
   if (e != hipSuccess) return mdq_set_error(hipGetErrorString(e));
   const int OUTP = (net->out_dim + 31) & ~31;

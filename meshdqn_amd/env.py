@@ -131,6 +131,59 @@ class Env2DAirfoil(object):
     def return_vals(self):
         return self.gt_drag, self.gt_time
 
+    def plot_state(self, title="{}", filename="initial_state"):
+        """Env2DAirfoil.py:171-217: the mesh with removable / non-removable vertices, the N-closest selection and the
+        edges of the state graph, written to `./{plot_dir}/{filename}.png` (matplotlib, when it is installed) or
+        `.svg` (written directly otherwise).  Like the reference it recomputes the state first (`get_state`)."""
+        state = self.get_state()
+        mesh = self.flow_solver.mesh
+        coords, cells = mesh.coordinates(), mesh.cells()
+        removable = np.array(self.flow_solver.removable).astype(bool)
+        sel = np.array(list(self.coord_map.values()), dtype=np.int64)
+        mesh_edges = np.unique(np.sort(np.concatenate([cells[:, [0, 1]], cells[:, [0, 2]], cells[:, [1, 2]]]), axis=1), axis=0)
+        ei = state.edge_index.cpu().numpy()
+        graph_edges = np.stack([sel[ei[0]], sel[ei[1]]], axis=1) if ei.shape[1] else np.zeros((0, 2), np.int64)
+        base = os.path.join(".", self.plot_dir, filename)
+        os.makedirs(os.path.dirname(base) or ".", exist_ok=True)
+        text = title.format(self.N_CLOSEST)
+        try:
+            import matplotlib
+            matplotlib.use("Agg")
+            import matplotlib.pyplot as plt
+            from matplotlib.collections import LineCollection
+            fig, ax = plt.subplots(figsize=(10, 5))
+            ax.add_collection(LineCollection(coords[mesh_edges], colors="#888888", linewidths=0.75, zorder=0))
+            ax.scatter(coords[:, 0], coords[:, 1], color=np.array(["r", "k"])[removable.astype(int)], s=6, zorder=1)
+            ax.add_collection(LineCollection(coords[graph_edges], colors="b", linewidths=0.75, zorder=2))
+            ax.scatter(coords[sel, 0], coords[sel, 1], color="b", s=6, zorder=3)
+            ax.set_title(text, fontsize=18, y=0.975)
+            ax.autoscale()
+            ax.set_axis_off()
+            fig.savefig(base + ".png", bbox_inches="tight")
+            plt.close(fig)
+            return base + ".png"
+        except ImportError:
+            pass
+        lo, hi = coords.min(axis=0), coords.max(axis=0)
+        sc = 1000.0 / (hi[0] - lo[0])
+        px = lambda q: ((q[0] - lo[0]) * sc, (hi[1] - q[1]) * sc + 30.0)   # noqa: E731
+        out = [f'<svg xmlns="http://www.w3.org/2000/svg" width="1000" height="{(hi[1] - lo[1]) * sc + 40:.0f}">',
+               f'<text x="500" y="20" text-anchor="middle" font-size="18">{text}</text>']
+        for edges, col in ((mesh_edges, "#888888"), (graph_edges, "blue")):
+            for a, b in edges:
+                (x1, y1), (x2, y2) = px(coords[a]), px(coords[b])
+                out.append(f'<line x1="{x1:.1f}" y1="{y1:.1f}" x2="{x2:.1f}" y2="{y2:.1f}" stroke="{col}" stroke-width="0.75"/>')
+        in_state = np.zeros(len(coords), bool)
+        in_state[sel] = True
+        for i, q in enumerate(coords):
+            x1, y1 = px(q)
+            col = "blue" if in_state[i] else ("black" if removable[i] else "red")
+            out.append(f'<circle cx="{x1:.1f}" cy="{y1:.1f}" r="1.5" fill="{col}"/>')
+        out.append("</svg>")
+        with open(base + ".svg", "w") as f:
+            f.write("\n".join(out))
+        return base + ".svg"
+
     # ------------------------------------------------------------------
     def _get_distance_lookup(self):
         coords = self.flow_solver.mesh.coordinates()
@@ -239,7 +292,7 @@ class Env2DAirfoil(object):
             self.new_drags = drag[0].cpu().numpy()
             self.new_lifts = lift[0].cpu().numpy()
         except Exception:
-            print("\\n\\nSAMPLING BROKE\\n\\n")
+            print("\n\nSAMPLING BROKE\n\n")
             return self.NEGATIVE_REWARD, True, True
         drag_factor = -2 * np.log(0.5) / self.threshold
         error_val = np.linalg.norm(np.abs(self.gt_drag - self.new_drags) / np.abs(self.gt_drag))
@@ -248,7 +301,7 @@ class Env2DAirfoil(object):
         acc_thresh = any(np.abs(np.abs(self.gt_drag - self.new_drags) / self.gt_drag) > self.threshold)
         vert_thresh = len(self.flow_solver.mesh.coordinates()) < self.goal_vertices * self.initial_num_node
         if vert_thresh:
-            print("\\nMAXIMUM REMOVALS REACHED\\n")
+            print("\nMAXIMUM REMOVALS REACHED\n")
         return float(drag_reward + time_reward), False, bool(acc_thresh or vert_thresh)
 
     def set_plot_dir(self, plot_dir):
@@ -278,7 +331,7 @@ class Env2DAirfoil(object):
             new_coords, cells = remove_vertex_delaunay(coords, boundary_vertices, idx)
         except ValueError:  # Qhull could not triangulate
             self.coordinate_list.insert(selected_coord, selected_coord)
-            print("\\nMESH BROKE, COULDN'T TRIANGULATE")
+            print("\nMESH BROKE, COULDN'T TRIANGULATE")
             return 2
         try:
             mesh = Mesh(new_coords, cells)
@@ -295,12 +348,16 @@ class Env2DAirfoil(object):
 
     def _check_mesh(self, mesh, selected_coord):
         if selected_coord in self.removable:
+            old = self.flow_solver.snapshot()       # (the reference keeps `old_mesh`, Env2DAirfoil.py:552)
             self.flow_solver.remesh(mesh)  # smooth(50) again, new removable / probes
             topo = self.flow_solver.mesh.topology_
             try:
                 out_u, out_p = self._interp.interpolate([topo], [topo.coords])
             except Exception:
                 print("INTERPOLATION BROKE")
+                # back to the old mesh (Env2DAirfoil.py:556-558) - together with everything remesh() derived from the
+                # new one, so that u / p / velocities and the solver's mesh keep belonging together
+                self.flow_solver.restore(old)
                 self.coordinate_list.insert(selected_coord, selected_coord)
                 return 2
             for i in range(len(self.original_u)):
@@ -313,5 +370,5 @@ class Env2DAirfoil(object):
             return 0
         else:
             self.coordinate_list.insert(selected_coord, selected_coord)
-            print("\\nMESH BROKE. SKIPPING VERTEX REMOVAL\\n")
+            print("\nMESH BROKE. SKIPPING VERTEX REMOVAL\n")
             return 2

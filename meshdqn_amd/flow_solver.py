@@ -160,6 +160,17 @@ class FlowSolver(object):
     def deploy(self):
         self.DEPLOY = True
 
+    _MESH_STATE = ("mesh", "removable", "bnd_tags", "_light", "batch", "u_n", "p_n", "u_", "p_", "drag_probe", "lift_probe",
+                   "accumulated_drag", "accumulated_lift", "num_vertices", "gtime")
+
+    def snapshot(self) -> dict:
+        """Everything `remesh` replaces (the caller can go back to the old mesh when the new one turns out unusable)."""
+        return {k: getattr(self, k) for k in self._MESH_STATE}
+
+    def restore(self, snap: dict):
+        for k, v in snap.items():
+            setattr(self, k, v)
+
     def remesh(self, mesh: Mesh):
         """flow_solver.py:233-359: swap the mesh, smooth again, recompute `removable`, new spaces /
         functions / probes; operators are re-assembled (and the clock reset) only in DEPLOY mode."""

@@ -137,19 +137,32 @@ class FusedGcn:
 
 
     @torch.no_grad()
-    def forward_arrays(self, x, node_ptr, esrc, edst, edge_ptr, nmax, emax, stream=None):
+    def forward_arrays(self, x, node_ptr, esrc, edst, edge_ptr, nmax, emax, stream=None, edge_counts=None,
+                       return_perm=False, return_status=False):
         """Same launch on pre-built arrays (what `VecEnv2DAirfoil.get_state` returns): x (sumN,F) f32,
-        node_ptr / edge_ptr (B+1,) i32, esrc / edst (sumE,) i32 local node ids."""
+        node_ptr / edge_ptr (B+1,) i32, esrc / edst (sumE,) i32 local node ids.  `nmax` / `emax` size the kernel's LDS
+        carve-up: `edge_counts` (host array of the per-graph edge counts, where the caller has them) is checked against
+        `emax` before the launch, and the kernel itself refuses larger graphs (NaN outputs, `return_status`).
+        `return_perm`: also the (B, levels, nmax) TopKPooling `perm` arrays."""
         self._pack()
         d = self.desc
         B = node_ptr.numel() - 1
+        if edge_counts is not None and len(edge_counts) and int(max(edge_counts)) > int(emax):
+            raise ValueError(f"graph with {int(max(edge_counts))} edges exceeds emax {int(emax)}")
         x = x.reshape(-1, x.shape[-1]).to(torch.float32).contiguous()
+        if x.shape[0] > B * int(nmax):
+            raise ValueError(f"{x.shape[0]} nodes in {B} graphs exceed nmax {int(nmax)}")
         emb = torch.empty((B, 2 * d.C), dtype=torch.float32, device=x.device)
         out = torch.empty((B, d.out_dim), dtype=torch.float32, device=x.device)
-        rc = self.lib.mdq_gcn_forward(C.byref(d), B, int(nmax), max(int(emax), 1), x.data_ptr(), node_ptr.data_ptr(),
-                                      esrc.data_ptr(), edst.data_ptr(), edge_ptr.data_ptr(), emb.data_ptr(),
-                                      out.data_ptr(), _lib.stream_ptr(stream))
-        _lib.check(rc, "mdq_gcn_forward")
+        perm = torch.full((B, d.nlevels, int(nmax)), -1, dtype=torch.int32, device=x.device) if return_perm else None
+        status = torch.zeros(B, dtype=torch.int32, device=x.device) if return_status else None
+        rc = self.lib.mdq_gcn_forward_ex(C.byref(d), B, int(nmax), max(int(emax), 1), x.data_ptr(), node_ptr.data_ptr(),
+                                         esrc.data_ptr(), edst.data_ptr(), edge_ptr.data_ptr(), emb.data_ptr(),
+                                         out.data_ptr(), None if perm is None else perm.data_ptr(),
+                                         None if status is None else status.data_ptr(), _lib.stream_ptr(stream))
+        _lib.check(rc, "mdq_gcn_forward_ex")
+        if return_perm or return_status:
+            return (out,) + ((perm,) if return_perm else ()) + ((status,) if return_status else ())
         return out
 
 

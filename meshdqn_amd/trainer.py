@@ -294,7 +294,7 @@ class DQNTrainer:
                 go = gb if sel else ga
                 with torch.no_grad():
                     qo = other._fused.forward_arrays(go["x"], go["node_ptr"], go["esrc"], go["edst"], go["edge_ptr"],
-                                                     go["n"], self.e_max)
+                                                     go["n"], self.e_max, edge_counts=go.get("cnt"))
                     aux = (qo.max(1)[0].float() * nonfinal * self.gamma + reward) if sel else \
                         qo.gather(1, action).squeeze(1).float()
                 gd = ga if sel else gb
@@ -597,7 +597,7 @@ def gather_state_refs(refs: List["StateRef"], e_max: int, device):
         src.view(-1).scatter_(0, lin, esrc.long())
         dst.view(-1).scatter_(0, lin, edst.long())
         mask.view(-1).scatter_(0, lin, torch.ones(total, dtype=torch.float32, device=device))
-    return dict(x=x, n=n, esrc=esrc.to(torch.int32), edst=edst.to(torch.int32),
+    return dict(x=x, n=n, cnt=cnt, esrc=esrc.to(torch.int32), edst=edst.to(torch.int32),
                 edge_ptr=torch.from_numpy(edge_ptr).to(device),
                 node_ptr=torch.arange(B + 1, dtype=torch.int32, device=device) * n, src=src, dst=dst, mask=mask)
 
@@ -698,7 +698,7 @@ class DeviceReplay:
         np.cumsum(cnt, out=edge_ptr[1:])
         flat = np.arange(int(edge_ptr[-1]), dtype=np.int64) + np.repeat(np.arange(n, dtype=np.int64) * e_max - edge_ptr[:-1], cnt)
         flat_d = torch.from_numpy(flat).to(dev)
-        return dict(x=x, n=self.N, esrc=sp.reshape(-1).index_select(0, flat_d), edst=dp.reshape(-1).index_select(0, flat_d),
+        return dict(x=x, n=self.N, cnt=cnt, esrc=sp.reshape(-1).index_select(0, flat_d), edst=dp.reshape(-1).index_select(0, flat_d),
                     edge_ptr=torch.from_numpy(edge_ptr).to(dev),
                     node_ptr=torch.arange(n + 1, dtype=torch.int32, device=dev) * self.N, src=src, dst=dst,
                     mask=live.float())
@@ -762,7 +762,8 @@ def train_loop_vec(trainer: DQNTrainer, venv, num_steps: int, optim_per_step: in
     ep_a = [[] for _ in range(B)]
     for step_no in range(num_steps):
         with torch.no_grad():
-            q = fused.forward_arrays(st["x"], st["node_ptr"], st["esrc"], st["edst"], st["edge_ptr"], N, venv.EMAX)
+            q = fused.forward_arrays(st["x"], st["node_ptr"], st["esrc"], st["edst"], st["edge_ptr"], N, venv.EMAX,
+                                     edge_counts=st["nedges"])
         greedy = q.argmax(1).cpu().numpy()
         eps = eps_end + (eps_start - eps_end) * np.exp(-1.0 * steps_done / eps_decay)
         steps_done += 1

@@ -136,27 +136,48 @@ class NodeRemovalNet(nn.Module):
         self.initial_num_nodes = n
         self.conv1 = SAGEConv(n, self.conv_width)
 
-    def forward(self, data, embedding=False):
+    def forward(self, data, embedding=False, return_perm=False):
+        """`return_perm`: also the four TopKPooling `perm` index arrays (airfoilgcnn.py:96,102,114,120; indices into the
+        node set entering the level) and the pooling scores of the kept nodes - the index work of the Q-path."""
         x, edge_index, batch = data.x.float(), data.edge_index, data.batch
+        perms, scores = [], []
         x = F.relu(self.conv1(x, edge_index))
-        x, edge_index, _, batch, _, _ = self.pool1(x, edge_index, None, batch)
+        x, edge_index, _, batch, perm, score = self.pool1(x, edge_index, None, batch)
+        perms.append(perm), scores.append(score)
         x1 = torch.cat([gmp(x, batch), gap(x, batch)], dim=1)
         x = F.relu(self.conv2(x, edge_index))
-        x, edge_index, _, batch, _, _ = self.pool2(x, edge_index, None, batch)
+        x, edge_index, _, batch, perm, score = self.pool2(x, edge_index, None, batch)
+        perms.append(perm), scores.append(score)
         x2 = torch.cat([gmp(x, batch), gap(x, batch)], dim=1)
         x = F.relu(self.conv4(x, edge_index))
-        x, edge_index, _, batch, _, _ = self.pool4(x, edge_index, None, batch)
+        x, edge_index, _, batch, perm, score = self.pool4(x, edge_index, None, batch)
+        perms.append(perm), scores.append(score)
         x4 = torch.cat([gmp(x, batch), gap(x, batch)], dim=1)
         x = F.relu(self.conv5(x, edge_index))
-        x, edge_index, _, batch, _, _ = self.pool5(x, edge_index, None, batch)
+        x, edge_index, _, batch, perm, score = self.pool5(x, edge_index, None, batch)
+        perms.append(perm), scores.append(score)
         x5 = torch.cat([gmp(x, batch), gap(x, batch)], dim=1)
         x = x1 + x2 + x4 + x5
-        if embedding:
-            return x
-        x = F.relu(self.lin1(x))
-        x = F.relu(self.lin2(x))
-        x = self.lin3(x)
-        return F.softmax(x, dim=1)
+        if not embedding:
+            x = F.relu(self.lin1(x))
+            x = F.relu(self.lin2(x))
+            x = self.lin3(x)
+            x = F.softmax(x, dim=1)
+        return (x, perms, scores) if return_perm else x
+
+
+def _node_removal_pool_scores(self, data):
+    """TopKPooling scores of EVERY node entering each of the four levels (for the tie analysis of the parity tests)."""
+    x, edge_index, batch = data.x.float(), data.edge_index, data.batch
+    out = []
+    for conv, pool in ((self.conv1, self.pool1), (self.conv2, self.pool2), (self.conv4, self.pool4), (self.conv5, self.pool5)):
+        x = F.relu(conv(x, edge_index))
+        out.append(torch.tanh((x * pool.weight).sum(dim=1) / pool.weight.norm(p=2)))
+        x, edge_index, _, batch, _, _ = pool(x, edge_index, None, batch)
+    return out
+
+
+NodeRemovalNet.pool_scores = _node_removal_pool_scores
 
 
 class AirfoilGCNN(nn.Module):

@@ -6,6 +6,9 @@ Run in the build container (where /root/reference exists):
 Outputs (data only, no reference source):
   * ys930.npz, ah93w145.npz  - coords (nv,2) f8, cells (nt,3) i4 exactly as
     stored in the reference's xdmf_files/*.h5 (file order, unsorted cells).
+  * xdmf/ah93w145_0.14000_triangle.{xdmf,h5} - the smaller of the reference's two mesh DATA files, byte for byte (an
+    XDMF3 descriptor + the meshio-written HDF5 container: superblock v0, chunked + deflate datasets), so that the
+    dependency-free reader `meshdqn_amd/io_xdmf.py` is tested on the format the reference ships.
   * kat_rows.json - the two benchmark rows of the reference's
     training_results/benchmark_results/*.csv that correspond to the shipped
     meshes: NUM_COORDS, DRAG, LIFT after 5000 IPCS steps.
@@ -32,6 +35,12 @@ MESHES = {
 
 
 def main():
+    import shutil
+    os.makedirs(os.path.join(HERE, "xdmf"), exist_ok=True)
+    for ext in ("xdmf", "h5"):
+        shutil.copyfile(os.path.join(REF, f"xdmf_files/ah93w145_0.14000_triangle.{ext}"),
+                        os.path.join(HERE, "xdmf", f"ah93w145_0.14000_triangle.{ext}"))
+        os.chmod(os.path.join(HERE, "xdmf", f"ah93w145_0.14000_triangle.{ext}"), 0o644)
     kat = {}
     for name, (xdmf, bench_csv) in MESHES.items():
         coords, cells = read_xdmf_mesh(os.path.join(REF, xdmf))

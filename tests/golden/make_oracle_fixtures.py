@@ -116,6 +116,12 @@ def gcn_fixture():
         net.load_state_dict(formula_state_dict(net))
         arrays["node_removal_q"] = net(batch).numpy()
         arrays["node_removal_embedding"] = net(batch, embedding=True).numpy()
+        # index work of the Q-path, per graph: the four TopKPooling perm arrays (local node ids) and the greedy action
+        for g, data in enumerate(graphs):
+            q1, perms, _ = net(data, return_perm=True)
+            for l, pm in enumerate(perms):
+                arrays[f"perm{g}_{l}"] = pm.numpy().astype(np.int32)
+            arrays[f"argmax{g}"] = np.int32(q1.argmax(1)[0])
         net2 = ora.AirfoilGCNN(conv_width=64)
         net2.load_state_dict(formula_state_dict(net2))
         arrays["airfoil_gcnn_out"] = net2(batch).numpy()

@@ -542,3 +542,74 @@ def test_gpu_smoothing_is_bitwise_reproducible(lib_built, meshes, name):
         first = out[0].copy() if first is None else first
         assert (out[0] == first).all()
     assert np.abs(first - ref).max() < 1e-13
+
+
+def test_reference_driver_call_sequences(lib_built, tmp_path, monkeypatch):
+    """The reference drivers' own call sequences against meshdqn_amd (the drop-in boundary of SURVEY 8b):
+    airfoil_dqn.py:394-401 (main process: env, set_plot_dir, plot_state, ground truth into the config), :435/:448 (the
+    workers rebuild the env from that config: the snapshot-reload branch Env2DAirfoil.py:126-153), and
+    deploy_dqn.py:84-92 (plot_state with a title, flow_solver.deploy(), snapshots handed over as functions)."""
+    from meshdqn_amd.env import Env2DAirfoil
+    monkeypatch.chdir(tmp_path)
+    flow_config = _config("ys930")
+    flow_config["agent_params"].update(solver_steps=200, save_steps=40)
+    save_dir = "training_results/run0"
+    # ---- airfoil_dqn.py:394-401
+    env = Env2DAirfoil(flow_config)
+    env.set_plot_dir(save_dir)
+    written = env.plot_state()
+    assert os.path.isfile(written) and os.path.dirname(written).endswith(save_dir)
+    flow_config["agent_params"]["plot_dir"] = save_dir
+    flow_config["agent_params"]["gt_drag"] = env.gt_drag
+    flow_config["agent_params"]["gt_time"] = env.gt_time
+    n_actions = flow_config["agent_params"]["N_closest"]
+    assert n_actions == env.action_space.n == 180
+    for f in ("velocities.npy", "pressures.npy", "save_velocities.npy", "save_pressures.npy"):
+        assert os.path.isfile(os.path.join(save_dir, "snapshots", f))
+    # ---- airfoil_dqn.py:435,448: a worker's env (u = p = -1 in the yaml: snapshots come back from the files)
+    worker = Env2DAirfoil(flow_config)
+    assert len(worker.original_u) == len(env.original_u) == 5
+    for a, b in zip(worker.original_u + worker.original_p, env.original_u + env.original_p):
+        assert torch.equal(a.data, b.data)
+    assert np.array_equal(worker.gt_drag, env.gt_drag)
+    s_w, s_e = worker.get_state(), env.get_state()
+    assert torch.equal(s_w.x, s_e.x) and torch.equal(s_w.edge_index, s_e.edge_index)
+    out_w, out_e = worker.step(7), env.step(7)
+    assert out_w[1] == out_e[1] and out_w[2] == out_e[2] and torch.equal(out_w[0].x, out_e[0].x)
+    assert np.array_equal(worker.new_drags, env.new_drags)
+    # ---- deploy_dqn.py:84-92
+    dcfg = _config("ys930")
+    dcfg["agent_params"].update(solver_steps=200, save_steps=40, plot_dir=save_dir)
+    denv = Env2DAirfoil(dcfg)
+    assert os.path.isfile(denv.plot_state(title="{} Closest Vertices to Airfoil", filename="deploy_state"))
+    denv.flow_solver.deploy()
+    dcfg["agent_params"]["gt_drag"] = denv.gt_drag
+    dcfg["agent_params"]["gt_time"] = denv.gt_time
+    dcfg["agent_params"]["u"] = [u.copy(deepcopy=True) for u in denv.original_u]
+    dcfg["agent_params"]["p"] = [p.copy(deepcopy=True) for p in denv.original_p]
+    assert denv.action_space.n == 180
+    env2 = Env2DAirfoil(dcfg)                        # deploy_dqn.py:299-300 style re-creation from the functions
+    assert torch.equal(env2.original_u[-1].data, denv.original_u[-1].data)
+    gt = env2.return_vals()
+    assert np.array_equal(gt[0], denv.gt_drag)
+
+
+def test_interpolation_failure_restores_the_solver(lib_built, monkeypatch):
+    """Env2DAirfoil.py:556-558: when the interpolation onto the new mesh fails the solver goes back to the old mesh
+    (and here to everything derived from it), the step reports code 2 = terminal with the negative reward."""
+    from meshdqn_amd.env import Env2DAirfoil
+    cfg = _config("ys930")
+    cfg["agent_params"].update(solver_steps=100, save_steps=20)
+    env = Env2DAirfoil(cfg)
+    env.get_state()
+    old_mesh, old_removable = env.flow_solver.mesh, list(env.flow_solver.removable)
+    nv0 = len(old_mesh.coordinates())
+
+    def boom(*a, **k):
+        raise RuntimeError("no cell found")
+    monkeypatch.setattr(env._interp, "interpolate", boom)
+    st, rew, done, _ = env.step(5)
+    assert rew == -1.0 and done
+    assert env.flow_solver.mesh is old_mesh and len(env.flow_solver.mesh.coordinates()) == nv0
+    assert list(env.flow_solver.removable) == old_removable
+    assert st.x.shape == (180, 17) and env.velocities.shape[1] == nv0
