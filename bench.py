@@ -38,6 +38,7 @@ import os as _os
 # under a small CPU quota, and idle pool threads that keep spinning starve the threads that launch kernels
 for _k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
     _os.environ.setdefault(_k, "1")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # concurrent streams on separate hardware queues (meshdqn_amd/__init__.py)
 import json
 import os
 import sys
@@ -213,7 +214,8 @@ def measure_env_steps(args, dev, dist, world, flow_steps=0, steps=None, warmup=8
         wr = np.random.default_rng(0)
         w.rollout(lambda g, env, st: wr.integers(0, 181, env.B), args.s1_warmup)
         del w
-    groups = VecEnvGroups(cfg, B, G, compute_device=dev, base_env=base, flow_steps=flow_steps, flow_rtol=args.rtol)
+    groups = VecEnvGroups(cfg, B, G, compute_device=dev, base_env=base, flow_steps=flow_steps, flow_rtol=args.rtol,
+                          flow_overlap=flow_steps > 0 and not args.no_flow_overlap)
     torch.manual_seed(0)
     net = NodeRemovalNet(181, conv_width=128, topk=0.1)
     net.set_num_nodes(17)
@@ -235,7 +237,8 @@ def measure_env_steps(args, dev, dist, world, flow_steps=0, steps=None, warmup=8
     out = dict(value=rate, unit="env steps/s", ms_per_batched_step=el / steps * 1e3, batched_steps=steps, repeats=repeats,
                value_min=world * B * steps / max(times), value_max=world * B * steps / min(times),
                seconds_per_repeat=times, mesh=mesh, envs_per_gpu=B, env_groups=len(groups.envs),
-               vertices_min_max=[int(min(e.nv.min() for e in groups.envs)), int(max(e.nv.max() for e in groups.envs))])
+               vertices_min_max=[int(min(e.nv.min() for e in groups.envs)), int(max(e.nv.max() for e in groups.envs))],
+               flow_overlap=bool(flow_steps > 0 and not args.no_flow_overlap))
     if flow_steps > 0:
         it = np.concatenate([e.flow_iters.cpu().numpy() for e in groups.envs]).astype(np.float64) / flow_steps
         out["krylov_iters_per_ipcs_step"] = {"velocity_bicgstab": float(it[:, 0].mean()), "pressure_cg": float(it[:, 1].mean()),
@@ -396,6 +399,8 @@ def main():
     ap.add_argument("--env-groups", type=int, default=1, help="concurrently stepped env groups per GPU for S1 / S3")
     ap.add_argument("--s1-solver-steps", type=int, default=5000, help="IPCS steps of the ground-truth reset()")
     ap.add_argument("--no-configs", action="store_true", help="skip the C2 / C3 / C5 side measurements")
+    ap.add_argument("--no-flow-overlap", action="store_true",
+                    help="S3: run the IPCS step of an env step in line instead of beside the next step's mesh kernels")
     args = ap.parse_args()
 
     # CPU baseline FIRST, before anything initialises the GPU: its multi-process leg starts child interpreters
@@ -580,7 +585,10 @@ def main():
                 "workload": f"{args.mesh} ({nv} vertices / {nt} triangles), {B} batched envs per GPU, step = S3 (north-star env "
                             f"step): remove vertex + Delaunay restoration + smooth(50) + 5-snapshot interpolation + 10 force "
                             f"integrals + state graph + ONE IPCS step on every coarsened mesh (matrix-free, Jacobi-BiCGStab / "
-                            f"CG, rtol {args.rtol:g}, warm start = interpolated last snapshot) + fused Q-network forward; "
+                            f"CG, rtol {args.rtol:g}, warm start = interpolated last snapshot"
+                            + ("" if args.no_flow_overlap else "; it runs on a second stream beside the NEXT step's removal / "
+                               "smoothing / topology kernels, its drag / lift are delivered one step later")
+                            + ") + fused Q-network forward; "
                             f"epsilon = 0.5 actions from default_rng(1370 + ...), meshes diverge (vertices "
                             f"{s3['vertices_min_max'][0]}..{s3['vertices_min_max'][1]} at the end), terminated envs reset in place",
                 "envs_per_gpu": B, "rtol": args.rtol, "dt": 1e-3, "mu": 1e-3, "rho": 1.0,

@@ -45,7 +45,8 @@ def _host_cores() -> int:
 class VecEnv2DAirfoil:
     def __init__(self, config, num_envs: int, compute_device="cuda", nthreads: int = 0, base_env: Env2DAirfoil | None = None,
                  auto_reset: bool = True, emax: int = 1536, flow_steps: int = 0, flow_rtol: float = 1e-10,
-                 gpu_smoothing: bool = True, gpu_topology: bool = True, gpu_remesh: bool = True):
+                 gpu_smoothing: bool = True, gpu_topology: bool = True, gpu_remesh: bool = True,
+                 flow_overlap: bool = False):
         self.lib = _lib.load()
         self.B = int(num_envs)
         self.device = torch.device(compute_device)
@@ -62,6 +63,13 @@ class VecEnv2DAirfoil:
         # S3 ("north-star step"): after every remesh, `flow_steps` IPCS steps on the coarsened mesh warm-started
         # from the interpolated last snapshot (0 = the reference's step, which never re-solves the flow)
         self.flow_steps, self.flow_rtol = int(flow_steps), float(flow_rtol)
+        # S3 with the IPCS step of env step k running on a second stream BESIDE the Q-forward of step k and the vertex
+        # removal / smoothing of step k + 1 (the state and the reward do not depend on the re-solved flow; the smoothing
+        # kernel is one wave per mesh, the IPCS kernels take the other half of the chip): the flow stream works on a
+        # private copy of the meshes and the drag / lift of the re-solved flow are reported one step later
+        # (`infos["flow_lag"] = 1`).  The streams must sit on different hardware queues: GPU_MAX_HW_QUEUES >= 8 (set by
+        # the package at import when the variable is not set)
+        self.flow_overlap = bool(flow_overlap) and self.flow_steps > 0 and self.gpu_remesh
         base = base_env or Env2DAirfoil(config, compute_device=compute_device)
         self.base = base
         ap = config["agent_params"]
@@ -97,9 +105,14 @@ class VecEnv2DAirfoil:
         self.dtopo = None
         if self.gpu_topology:
             self.dtopo = DeviceTopologyBatch(B, NV, NT, self.NE, self.NAF, N, self.EMAX, self.polygon, self.device,
-                                             ipcs=self.flow_steps > 0, nse1_cap=nse1_cap)
+                                             ipcs=self.flow_steps > 0 and not self.flow_overlap, nse1_cap=nse1_cap)
+            if self.flow_overlap:
+                # the flow stream's own engine: a private copy of the meshes, the full topology (with the IPCS index data,
+                # which only the flow needs: 0.19 ms less on the critical path) and the IPCS step run there
+                self._ftopo = DeviceTopologyBatch(B, NV, NT, self.NE, self.NAF, N, self.EMAX, self.polygon, self.device,
+                                                  ipcs=True, nse1_cap=nse1_cap)
         self._packed_host, self._packed_ev, self._pending, self._step_pending = None, torch.cuda.Event(), None, None
-        self._restore_args = None
+        self._restore_args = {}
         self._deferred_mirror = None
         self._node_ptr = torch.arange(B + 1, dtype=torch.int32, device=self.device) * N   # (constant: N rows per graph)
         # the initial mesh on the device: source rows of the in-place resets (mdq_restore_rows)
@@ -126,47 +139,69 @@ class VecEnv2DAirfoil:
 
     # ------------------------------------------------------------------
     def _init_flow(self, base):
-        """Device arrays + descriptor of the matrix-free IPCS path (mode 3, CG pressure) over the batch."""
+        """Device arrays + descriptor(s) of the matrix-free IPCS path (mode 3, CG pressure) over the batch."""
         dev, tp = self.device, (self.dtopo if self.gpu_topology else self.topo)
+        if self.flow_overlap:
+            tp = self._ftopo
         B, NV, NT, NE, NP = self.B, self.NV, self.NT, self.NE, self.NP
-        if self.gpu_topology:   # the device engine's outputs ARE the descriptor's index arrays
-            t = dict(tp.ti)
-        else:
-            t = {k: torch.from_numpy(a).to(dev) for k, a in tp.hi.items()}
 
         def z(*shape):
             return torch.zeros(shape, dtype=torch.float64, device=dev)
 
-        t.update(geom=z(B, 5, NT), bo_val=z(B, tp.NBE, 4), lift1=z(B, NP, 2), lift3=z(B, NP, 2), idiag1=z(B, NP, 2),
-                 sdiagM=z(B, NP), sdiagK=z(B, NV), K1s=z(B, tp.NSE1), u_n=z(B, NP, 2), p_n=z(B, NV))
+        own = dict(geom=z(B, 5, NT), bo_val=z(B, tp.NBE, 4), lift1=z(B, NP, 2), lift3=z(B, NP, 2), idiag1=z(B, NP, 2),
+                   sdiagM=z(B, NP), sdiagK=z(B, NV), K1s=z(B, tp.NSE1), u_n=z(B, NP, 2), p_n=z(B, NV))
         nwork = int(self.lib.mdq_ipcs_workspace_doubles(B, NV, NT, NE))
-        t["work"] = z(nwork)
+        own["work"] = z(nwork)
         fs = base.flow_solver
-        d = _lib.IpcsDesc()
-        d.B, d.NV, d.NT, d.NE, d.N2, d.NAF = B, NV, NT, NE, NP, self.NAF
-        d.NSE1, d.NBO, d.NBE = tp.NSE1, tp.NBO, tp.NBE
-        d.mu, d.rho, d.dt, d.rtol = fs.mu, fs.rho, fs.dt_value, self.flow_rtol
-        d.maxit_u, d.maxit_p, d.maxit_m = 200, 4000, 200
-        d.mode, d.pd_enabled = 3, 0
-        for name, _typ in _lib.IpcsDesc._fields_:
-            if name in t:
-                setattr(d, name, t[name].data_ptr())
-        d.work_doubles = nwork
-        self.flow_t, self.flow_desc = t, d
+        if self.gpu_topology:   # the device engine's outputs ARE the descriptor's index arrays
+            index_sets = [dict(tp.ti)]
+        else:
+            index_sets = [{k: torch.from_numpy(a).to(dev) for k, a in tp.hi.items()}]
+        self.flow_descs, self.flow_ts = [], []
+        for idx in index_sets:
+            t = dict(idx)
+            t.update(own)
+            d = _lib.IpcsDesc()
+            d.B, d.NV, d.NT, d.NE, d.N2, d.NAF = B, NV, NT, NE, NP, self.NAF
+            d.NSE1, d.NBO, d.NBE = tp.NSE1, tp.NBO, tp.NBE
+            d.mu, d.rho, d.dt, d.rtol = fs.mu, fs.rho, fs.dt_value, self.flow_rtol
+            d.maxit_u, d.maxit_p, d.maxit_m = 200, 4000, 200
+            d.mode, d.pd_enabled = 3, 0
+            for name, _typ in _lib.IpcsDesc._fields_:
+                if name in t:
+                    setattr(d, name, t[name].data_ptr())
+            d.work_doubles = nwork
+            self.flow_descs.append(d)
+            self.flow_ts.append(t)
+        self.flow_t, self.flow_desc = self.flow_ts[0], self.flow_descs[0]
         self.flow_iters = torch.zeros((B, 3), dtype=torch.int32, device=dev)
         self.flow_drag = np.zeros((B, self.flow_steps))
         self.flow_lift = np.zeros((B, self.flow_steps))
+        if self.flow_overlap:
+            self._flow_stream = torch.cuda.Stream(device=dev)
+            self._flow_ready = torch.cuda.Event()
+            # page-locked result buffers (two: the results of step k are read while step k + 1 is in flight) + events
+            self._flow_res = [dict(host=torch.zeros((2, B, self.flow_steps), dtype=torch.float64, pin_memory=True),
+                                   done=torch.cuda.Event()) for _ in range(2)]
+            self._flow_n = 0          # flows launched
+            self._flow_prev = None
 
     def _flow(self, keep, out_u, out_p):
         """`flow_steps` IPCS steps on every (coarsened) mesh, warm-started from the interpolated last snapshot."""
-        t, d = self.flow_t, self.flow_desc
+        t, d = self.flow_ts[0], self.flow_descs[0]
         if not self.gpu_topology:
-            for k in self.topo.hi:
-                t[k].copy_(self.topo.pinned[k], non_blocking=True)
-        for k in ("coords", "cell_dofs", "af_facets", "nv", "nt", "ne", "naf"):
-            setattr(d, k, keep[k].data_ptr())
-        t["u_n"].copy_(out_u[:, self.S - 1])
-        t["p_n"].copy_(out_p[:, self.S - 1])
+            for kk in self.topo.hi:
+                t[kk].copy_(self.topo.pinned[kk], non_blocking=True)
+        if self.flow_overlap:
+            return self._flow_overlapped(out_u, out_p)
+        for kk in ("coords", "cell_dofs", "af_facets", "nv", "nt", "ne", "naf"):
+            setattr(d, kk, keep[kk].data_ptr())
+        return self._flow_launch(t, d, keep, out_u, out_p)
+
+    def _flow_launch(self, t, d, keep, out_u, out_p):
+        if out_u is not None:
+            t["u_n"].copy_(out_u[:, self.S - 1])
+            t["p_n"].copy_(out_p[:, self.S - 1])
         t["work"].zero_()            # no initial-guess history on a new mesh
         self.flow_iters.zero_()
         _lib.check(self.lib.mdq_ipcs_setup_matfree(C.byref(d), _lib.stream_ptr()), "mdq_ipcs_setup_matfree")
@@ -176,6 +211,46 @@ class VecEnv2DAirfoil:
                                             self.flow_iters.data_ptr(), _lib.stream_ptr()), "mdq_ipcs_evolve")
         self._flow_keep = keep       # device buffers the descriptor points at
         return drag, lift
+
+    def _flow_overlapped(self, out_u, out_p):
+        """The same on the flow stream: the meshes are copied to the flow's own engine (on the main stream, behind the
+        last flow), which derives topology + IPCS index data itself; results land in page-locked memory."""
+        ft, dt = self._ftopo, self.dtopo
+        t, d = self.flow_ts[0], self.flow_descs[0]
+        main = torch.cuda.current_stream(self.device)
+        if self._flow_prev is not None:
+            main.wait_event(self._flow_res[self._flow_prev]["done"])     # the previous flow still reads the private meshes
+        ft.coords.copy_(dt.coords)
+        ft.cells.copy_(dt.cells)
+        ft.nv.copy_(dt.nv)
+        ft.nt.copy_(dt.nt)
+        # the warm start as well: the in-place reset of a terminated environment rewrites its rows of out_u / out_p
+        t["u_n"].copy_(out_u[:, self.S - 1])
+        t["p_n"].copy_(out_p[:, self.S - 1])
+        self._flow_ready.record(main)
+        keep = dict(coords=ft.coords, cell_dofs=ft.t["cell_dofs"], af_facets=ft.t["af_facets"], nv=ft.nv, nt=ft.nt,
+                    ne=ft.t["ne"], naf=ft.t["naf"])
+        for kk, v in keep.items():
+            setattr(d, kk, v.data_ptr())
+        res = self._flow_res[self._flow_n % 2]
+        with torch.cuda.stream(self._flow_stream):
+            self._flow_stream.wait_event(self._flow_ready)
+            ft.run(check=False)                  # (same meshes, same deterministic kernel as the main stream's run)
+            drag, lift = self._flow_launch(t, d, keep, None, None)
+            res["host"][0].copy_(drag, non_blocking=True)
+            res["host"][1].copy_(lift, non_blocking=True)
+            res["done"].record(self._flow_stream)
+        self._flow_prev = self._flow_n % 2
+        self._flow_n += 1
+        return None, None
+
+    def flow_wait(self):
+        """Overlap mode: wait for the IPCS step launched last and return its (drag, lift), or None."""
+        if not self.flow_overlap or self._flow_prev is None:
+            return None
+        res = self._flow_res[self._flow_prev]
+        res["done"].synchronize()
+        return res["host"][0].numpy().copy(), res["host"][1].numpy().copy()
 
     # ------------------------------------------------------------------
     def _reset_env(self, b):
@@ -225,7 +300,8 @@ class VecEnv2DAirfoil:
         self.new_lifts[idx] = c["lifts"]
         # device side: ONE launch restores the rows of every tensor (a dozen index_put launches otherwise).  The
         # argument arrays are built once; only the two per-step buffers (u, p) change their addresses.
-        ra = self._restore_args
+        key = 0
+        ra = self._restore_args.get(key)
         if ra is None or ra["coords"] != self._coords_dev.data_ptr():
             pairs = [(self.u, c["u"]), (self.p, c["p"]), (self._coords_dev, self._x0_dev)]
             if self.gpu_topology:
@@ -237,7 +313,7 @@ class VecEnv2DAirfoil:
             nbytes = [a[0].numel() * a.element_size() for a, _ in pairs]
             for (a, b_), nb in zip(pairs, nbytes):
                 assert a.is_contiguous() and b_.is_contiguous() and b_.numel() * b_.element_size() == nb and a.dtype == b_.dtype
-            ra = self._restore_args = dict(n=n, dst=(C.c_void_p * n)(*[a.data_ptr() for a, _ in pairs]),
+            ra = self._restore_args[key] = dict(n=n, dst=(C.c_void_p * n)(*[a.data_ptr() for a, _ in pairs]),
                                            src=(C.c_void_p * n)(*[b_.data_ptr() for _, b_ in pairs]),
                                            nbytes=(C.c_int64 * n)(*nbytes), coords=self._coords_dev.data_ptr(),
                                            keep=pairs)
@@ -454,6 +530,13 @@ class VecEnv2DAirfoil:
         B, N, h = self.B, self.N, self.h
         code, status = self._step_pending
         self._step_pending = None
+        prev_flow = None
+        if self.flow_overlap:     # results of the IPCS step launched in the PREVIOUS env step (this step's is still running)
+            prev, self._flow_prev2 = getattr(self, "_flow_prev2", None), self._flow_prev
+            if prev is not None:
+                res = self._flow_res[prev]
+                res["done"].synchronize()
+                prev_flow = (res["host"][0].numpy().copy(), res["host"][1].numpy().copy())
         self._refresh_collect()
         if status is None:
             self._mirror_done.synchronize()
@@ -476,8 +559,11 @@ class VecEnv2DAirfoil:
         self.steps += 1
         dones |= self.steps >= self.timesteps
         infos = dict(code=code, nv=self.nv.copy(), new_drags=self.new_drags.copy(), new_lifts=self.new_lifts.copy())
-        if self.flow_steps > 0:  # drag / lift of the re-solved flow on the coarsened meshes (before any auto-reset)
-            infos.update(flow_drag=self.flow_drag.copy(), flow_lift=self.flow_lift.copy())
+        if self.flow_overlap:    # drag / lift of the re-solved flow of the PREVIOUS step's meshes (None at the first step)
+            infos.update(flow_lag=1, flow_drag=None if prev_flow is None else prev_flow[0],
+                         flow_lift=None if prev_flow is None else prev_flow[1])
+        elif self.flow_steps > 0:  # drag / lift of the re-solved flow on the coarsened meshes (before any auto-reset)
+            infos.update(flow_lag=0, flow_drag=self.flow_drag.copy(), flow_lift=self.flow_lift.copy())
         if self.auto_reset and dones.any():
             self._restore_initial(np.flatnonzero(dones))
         state = self.get_state()

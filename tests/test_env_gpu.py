@@ -613,3 +613,36 @@ def test_interpolation_failure_restores_the_solver(lib_built, monkeypatch):
     assert env.flow_solver.mesh is old_mesh and len(env.flow_solver.mesh.coordinates()) == nv0
     assert list(env.flow_solver.removable) == old_removable
     assert st.x.shape == (180, 17) and env.velocities.shape[1] == nv0
+
+
+def test_overlapped_flow_step_equals_inline_flow_step(lib_built):
+    """S3 with the IPCS step on a second stream beside the next env step (double-buffered topology outputs, forces
+    delivered one step later) vs the in-line IPCS step: same states, rewards, dones, and the SAME flow forces shifted
+    by one step (both are the same kernels on the same data; only the stream and the reporting step differ)."""
+    from meshdqn_amd.env import Env2DAirfoil
+    from meshdqn_amd.vec_env import VecEnv2DAirfoil
+    cfg = _config("ys930")
+    cfg["agent_params"].update(solver_steps=200, save_steps=40)
+    base = Env2DAirfoil(cfg)
+    B, K = 6, 9
+    envs = [VecEnv2DAirfoil(cfg, B, base_env=base, flow_steps=1, flow_rtol=1e-12, flow_overlap=ov) for ov in (False, True)]
+    rng = np.random.default_rng(3)
+    acts = [[int(rng.integers(0, 181)) for _ in range(B)] for _ in range(K)]
+    for e in envs:
+        e.get_state()
+    hist = [[], []]
+    for k in range(K):
+        for i, e in enumerate(envs):
+            st, rew, done, info = e.step(acts[k])
+            hist[i].append((st["x"].cpu().numpy(), rew.copy(), done.copy(), info))
+    for k in range(K):
+        a, b = hist[0][k], hist[1][k]
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert a[3]["flow_lag"] == 0 and b[3]["flow_lag"] == 1
+        if k == 0:
+            assert b[3]["flow_drag"] is None
+        else:
+            assert np.allclose(b[3]["flow_drag"], hist[0][k - 1][3]["flow_drag"], rtol=1e-6, atol=0)   # (LDS fp64 atomics: not bitwise)
+            assert np.allclose(b[3]["flow_lift"], hist[0][k - 1][3]["flow_lift"], rtol=1e-6, atol=0)
+    last = envs[1].flow_wait()
+    assert np.allclose(last[0], hist[0][K - 1][3]["flow_drag"], rtol=1e-6, atol=0)

@@ -9,13 +9,14 @@ from meshdqn_amd.gcn_fused import FusedGcn
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 FLOW = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 GSM = bool(int(sys.argv[3])) if len(sys.argv) > 3 else False
+OVL = bool(int(sys.argv[4])) if len(sys.argv) > 4 else False
 G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 cfg = dict(flow_config=dict(flow_params=dict(mu=1e-3, rho=1.0, inflow="constant"), geometry_params=dict(mesh=os.path.join(G, "ys930.npz")),
                             solver_params=dict(dt=0.001, solver_type="lu", smooth=True)),
            agent_params=dict(solver_steps=500, episodes=10, timesteps=10000, threshold=0.001, N_closest=180, gt_drag=-1, gt_time=-1, u=-1, p=-1,
                              time_reward=0.005, save_steps=100, goal_vertices=0.95, plot_dir=""))
 print("host cores", os.cpu_count())
-t0 = time.time(); venv = VecEnv2DAirfoil(cfg, B, flow_steps=FLOW, gpu_smoothing=GSM); print("init s", time.time() - t0)
+t0 = time.time(); venv = VecEnv2DAirfoil(cfg, B, flow_steps=FLOW, gpu_smoothing=GSM, flow_overlap=OVL); print("init s", time.time() - t0)
 net = NodeRemovalNet(181, conv_width=128, topk=0.1); net.set_num_nodes(17); net = net.cuda(); fused = FusedGcn(net)
 st = venv.get_state()
 rng = np.random.default_rng(0)

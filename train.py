@@ -14,6 +14,7 @@ import os as _os
 # under a small CPU quota, and idle pool threads that keep spinning starve the threads that launch kernels
 for _k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
     _os.environ.setdefault(_k, "1")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # concurrent streams on separate hardware queues (meshdqn_amd/__init__.py)
 import os
 
 import numpy as np
