@@ -229,8 +229,23 @@ def measure_env_steps(args, dev, dist, world, flow_steps=0, steps=None, warmup=8
         greedy = q.argmax(1).cpu().numpy()
         return np.where(rngs[g].random(env.B) < 0.5, rngs[g].integers(0, 181, env.B), greedy)
 
-    groups.rollout(act, warmup)
-    times = [_timed(dist, dev, lambda: groups.rollout(act, steps)) for _ in range(repeats)]
+    def draw(k):
+        """The epsilon = 0.5 random streams of `act`, drawn ahead for k steps (same order of draws)."""
+        ex, ra = [], []
+        for g, env in enumerate(groups.envs):
+            pairs = [(rngs[g].random(env.B) < 0.5, rngs[g].integers(0, 181, env.B)) for _ in range(k)]
+            ex.append(np.array([p_[0] for p_ in pairs]))
+            ra.append(np.array([p_[1] for p_ in pairs]))
+        return ex, ra
+
+    if args.host_step:      # state -> host -> action -> host -> step: two host round trips per batched step
+        run = lambda k: groups.rollout(act, k)                      # noqa: E731
+    else:                   # device-resident: action selection / decoding / reward / reset logic as kernels
+        def run(k):
+            ex, ra = draw(k)
+            groups.rollout_device(fused, k, ex, ra)
+    run(warmup)
+    times = [_timed(dist, dev, lambda: run(steps)) for _ in range(repeats)]
     el = float(np.median(times))
     venv = groups.envs[0]
     rate = world * B * steps / el
@@ -238,7 +253,7 @@ def measure_env_steps(args, dev, dist, world, flow_steps=0, steps=None, warmup=8
                value_min=world * B * steps / max(times), value_max=world * B * steps / min(times),
                seconds_per_repeat=times, mesh=mesh, envs_per_gpu=B, env_groups=len(groups.envs),
                vertices_min_max=[int(min(e.nv.min() for e in groups.envs)), int(max(e.nv.max() for e in groups.envs))],
-               flow_overlap=bool(flow_steps > 0 and not args.no_flow_overlap))
+               flow_overlap=bool(flow_steps > 0 and not args.no_flow_overlap), device_resident_step=not args.host_step)
     if flow_steps > 0:
         it = np.concatenate([e.flow_iters.cpu().numpy() for e in groups.envs]).astype(np.float64) / flow_steps
         out["krylov_iters_per_ipcs_step"] = {"velocity_bicgstab": float(it[:, 0].mean()), "pressure_cg": float(it[:, 1].mean()),
@@ -399,6 +414,8 @@ def main():
     ap.add_argument("--env-groups", type=int, default=1, help="concurrently stepped env groups per GPU for S1 / S3")
     ap.add_argument("--s1-solver-steps", type=int, default=5000, help="IPCS steps of the ground-truth reset()")
     ap.add_argument("--no-configs", action="store_true", help="skip the C2 / C3 / C5 side measurements")
+    ap.add_argument("--host-step", action="store_true",
+                    help="S1 / S3: the step() path with its two host round trips per batched step instead of rollout_device")
     ap.add_argument("--no-flow-overlap", action="store_true",
                     help="S3: run the IPCS step of an env step in line instead of beside the next step's mesh kernels")
     args = ap.parse_args()
@@ -588,7 +605,9 @@ def main():
                             f"CG, rtol {args.rtol:g}, warm start = interpolated last snapshot"
                             + ("" if args.no_flow_overlap else "; it runs on a second stream beside the NEXT step's removal / "
                                "smoothing / topology kernels, its drag / lift are delivered one step later")
-                            + ") + fused Q-network forward; "
+                            + ") + fused Q-network forward"
+                            + ("" if args.host_step else "; action selection / decoding, reward / terminal logic and in-place "
+                               "resets are kernels too (rollout_device: no host round trip inside a step)") + "; "
                             f"epsilon = 0.5 actions from default_rng(1370 + ...), meshes diverge (vertices "
                             f"{s3['vertices_min_max'][0]}..{s3['vertices_min_max'][1]} at the end), terminated envs reset in place",
                 "envs_per_gpu": B, "rtol": args.rtol, "dt": 1e-3, "mu": 1e-3, "rho": 1.0,

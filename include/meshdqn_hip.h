@@ -325,6 +325,47 @@ int mdq_state_features(int32_t B, int32_t N, int32_t S, int32_t NV, int32_t NP, 
 int mdq_compact_edges(int32_t B, int32_t EMAX, const int32_t* src_pad, const int32_t* dst_pad, const int32_t* edge_ptr,
                       int32_t* esrc, int32_t* edst, void* stream);
 
+/* ---- control logic of the batched env step on the device (Env2DAirfoil.step, Env2DAirfoil.py:318-377; calculate_reward
+ *      :380-428): with these entry points a rollout is one uninterrupted stream of launches - no read-back between the
+ *      Q-network forward and the next vertex removal.  All array arguments are device pointers over B environments. ---- */
+
+/*
+ * Action selection + decoding.  q [B][N+1] (or NULL: `action` holds the actions already): the greedy action is the first
+ * maximum of a row (torch.argmax, airfoil_dqn.py:208-209); environment b takes rand_action[b] instead where explore[b]
+ * (the host draws both arrays from its own random streams ahead of time).  Decoding as in Env2DAirfoil.step: action N
+ * shifts the N-closest window (offset[b] += 1), an action without a vertex behind it (>= nsel[b]) gives code 2, otherwise
+ * rem[b] = coord_map[b][action] (else -1).  Outputs: action, rem, code [B].
+ */
+int mdq_env_act(int32_t B, int32_t N, const float* q, const uint8_t* explore, const int32_t* rand_action,
+                const int32_t* nsel, const int32_t* coord_map, int32_t* offset, int32_t* action, int32_t* rem,
+                int32_t* code, void* stream);
+
+/* its[b] = iterations where a vertex was removed (rem >= 0) and the re-triangulation succeeded (rstat == 0), else 0:
+ * the smoothing request of flow_solver.py:236-237 for mdq_smooth. */
+int mdq_env_smooth_iters(int32_t B, const int32_t* rem, const int32_t* rstat, int32_t iterations, int32_t* its,
+                         void* stream);
+
+/*
+ * Reward and terminal flag (Env2DAirfoil.calculate_reward, Env2DAirfoil.py:380-428, + the bookkeeping of step()):
+ * new_drags [B][S] (interpolated snapshots' drags on the current mesh), gt_drag [S]; drag reward
+ * 2 exp(-(2 ln 2 / threshold) |rel. error|_2) - 1 + time_reward (nv0 - nv); terminal when any relative drag error exceeds
+ * the threshold, nv < goal_vertices nv0, the step count reaches `timesteps`, or the step failed (code 2: rstat != 0,
+ * nsel < N, topology status != 0 - the latter also sets bit 0 of *err_flag); failed steps get negative_reward.
+ * code / steps [B] in/out (steps restart at 0 for terminated environments when auto_reset); reward f64 [B], done u8 [B].
+ */
+int mdq_env_result(int32_t B, int32_t N, int32_t S, const double* new_drags, const double* gt_drag, const int32_t* nv,
+                   int32_t nv0, const int32_t* rstat, const int32_t* topo_status, const int32_t* nsel, int32_t* code,
+                   int32_t* steps, double threshold, double time_reward, double goal_vertices, int32_t timesteps,
+                   double negative_reward, int32_t auto_reset, double* reward, uint8_t* done, int32_t* err_flag,
+                   void* stream);
+
+/* mdq_restore_rows for the environments with mask[b] != 0 (device array): the in-place reset without a host-side list. */
+int mdq_restore_rows_masked(int32_t n, void* const* dst, const void* const* src, const int64_t* row_bytes, int32_t B,
+                            const uint8_t* mask, void* stream);
+
+/* edge_ptr [B+1] = exclusive prefix sums of nedges [B] (offsets of mdq_compact_edges / mdq_gcn_forward). */
+int mdq_edge_ptr(int32_t B, const int32_t* nedges, int32_t* edge_ptr, void* stream);
+
 /*
  * Env2DAirfoil.reset (Env2DAirfoil.py:102-129: mesh, snapshots and selection back to the initial ones) for a SUBSET
  * of the batched environments, in one launch: for each of the n (<= 16) device tensors dst[t], laid out [B][row_bytes[t]],

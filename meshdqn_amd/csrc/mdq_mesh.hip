@@ -212,3 +212,197 @@ extern "C" int mdq_state_features(int32_t B, int32_t N, int32_t S, int32_t NV, i
   if (hipGetLastError() != hipSuccess) return mdq_set_error("state_features_kernel launch failed");
   return 0;
 }
+
+// ================================================================== control logic of the batched env step on the device
+//
+// `VecEnv2DAirfoil.step` (Env2DAirfoil.step, Env2DAirfoil.py:318-377; calculate_reward :380-428) decides four things
+// per environment: which vertex an action removes, how often the smoothing runs, reward + terminal flag, and which
+// environments restart.  With these kernels the decisions stay on the device, so that a rollout is one uninterrupted
+// stream of launches: no read-back between the Q-network forward and the next vertex removal.
+namespace mdq_mesh {
+
+// one wave per environment: greedy action = first maximum of q[b][0..NA) (torch.argmax), epsilon-greedy choice, then
+// Env2DAirfoil.step's action decoding: N = "do nothing" (shift the N-closest window), an action without a vertex
+// behind it = code 2 ("RAN OUT OF VERTICES"), otherwise the vertex id coord_map[b][action]
+__global__ __launch_bounds__(64) void env_act_kernel(int N, const float* q, const uint8_t* explore, const int32_t* rand_action,
+                                                      const int32_t* nsel, const int32_t* coord_map, int32_t* offset,
+                                                      int32_t* action, int32_t* rem, int32_t* code) {
+  const int b = blockIdx.x, lane = threadIdx.x, NA = N + 1;
+  int a;
+  if (q) {
+    float best = -__builtin_inff();
+    int bi = 0x7FFFFFFF;
+    for (int i = lane; i < NA; i += 64) {
+      const float v = q[(int64_t)b * NA + i];
+      if (v > best || (v == best && i < bi) || (bi == 0x7FFFFFFF && !(v < best))) {   // (NaN rows: first index)
+        best = v;
+        bi = i;
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(best, off);
+      const int oi = __shfl_xor(bi, off);
+      if (ov > best || (ov == best && oi < bi)) {
+        best = ov;
+        bi = oi;
+      }
+    }
+    a = (explore && explore[b]) ? rand_action[b] : bi;
+  } else {
+    a = action[b];
+  }
+  if (lane == 0) {
+    const bool shift = a == N;
+    const bool pick = a >= 0 && a < nsel[b] && !shift;
+    if (shift) offset[b] += 1;
+    action[b] = a;
+    rem[b] = pick ? coord_map[(int64_t)b * N + min(max(a, 0), N - 1)] : -1;
+    code[b] = (!shift && !pick) ? 2 : 0;
+  }
+}
+
+__global__ void env_smooth_iters_kernel(int B, const int32_t* rem, const int32_t* rstat, int32_t iterations, int32_t* its) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) its[b] = (rem[b] >= 0 && rstat[b] == 0) ? iterations : 0;
+}
+
+// reward / terminal flag (Env2DAirfoil.calculate_reward + the bookkeeping of step()): one thread per environment
+__global__ void env_result_kernel(int B, int N, int S, const double* new_drags, const double* gt_drag, const int32_t* nv,
+                                  int32_t nv0, const int32_t* rstat, const int32_t* topo_status, const int32_t* nsel,
+                                  int32_t* code, int32_t* steps, double threshold, double time_reward, double goal_vertices,
+                                  int32_t timesteps, double negative_reward, int32_t auto_reset, double* reward,
+                                  uint8_t* done, int32_t* err_flag) {
+#pragma clang fp contract(off)
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int c = code[b];
+  if (rstat[b] != 0 || nsel[b] < N) c = 2;
+  if (topo_status && topo_status[b] != 0) {
+    c = 2;
+    atomicOr(err_flag, 1);
+  }
+  const double drag_factor = -2.0 * log(0.5) / threshold;
+  double ss = 0.0;
+  bool acc = false;
+  for (int s = 0; s < S; ++s) {
+    const double g = gt_drag[s], d = new_drags[(int64_t)b * S + s];
+    const double e = fabs(g - d) / fabs(g);
+    ss += e * e;
+    acc = acc || fabs(fabs(g - d) / g) > threshold;
+  }
+  const double drag_reward = 2.0 * exp(-drag_factor * sqrt(ss)) - 1.0;
+  const double tr = (double)(nv0 - nv[b]) * time_reward;
+  const bool vert = (double)nv[b] < goal_vertices * (double)nv0;
+  const bool ok = c == 0;
+  double r = ok ? drag_reward + tr : negative_reward;
+  bool dn = ok ? (acc || vert) : true;
+  const int st = steps[b] + 1;
+  dn = dn || st >= timesteps;
+  reward[b] = r;
+  done[b] = dn ? 1 : 0;
+  code[b] = c;
+  steps[b] = (dn && auto_reset) ? 0 : st;
+}
+
+__global__ __launch_bounds__(256) void restore_rows_masked_kernel(RestoreArgs a, const uint8_t* mask) {
+  if (!mask[blockIdx.x]) return;
+  const int t = blockIdx.y;
+  const int64_t n = a.words[t];
+  const int64_t w0 = (int64_t)blockIdx.z * RESTORE_CHUNK;
+  if (w0 >= n) return;
+  const int64_t w1 = w0 + RESTORE_CHUNK < n ? w0 + RESTORE_CHUNK : n;
+  uint32_t* d = a.dst[t] + (int64_t)blockIdx.x * n;
+  const uint32_t* s = a.src[t];
+  if ((n & 3) == 0 && ((reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(s)) & 15) == 0) {
+    uint4* d4 = reinterpret_cast<uint4*>(d);
+    const uint4* s4 = reinterpret_cast<const uint4*>(s);
+    for (int64_t i = (w0 >> 2) + threadIdx.x; i < (w1 >> 2); i += 256) d4[i] = s4[i];
+  } else {
+    for (int64_t i = w0 + threadIdx.x; i < w1; i += 256) d[i] = s[i];
+  }
+}
+
+// edge_ptr = exclusive prefix sums of nedges (one block; B <= 1024 per launch is plenty: environments per GPU)
+__global__ __launch_bounds__(1024) void edge_ptr_kernel(int B, const int32_t* nedges, int32_t* edge_ptr) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x;
+  int run = 0;
+  for (int base = 0; base < B; base += 1024) {
+    const int i = base + tid;
+    part[tid] = i < B ? nedges[i] : 0;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const int add = tid >= off ? part[tid - off] : 0;
+      __syncthreads();
+      part[tid] += add;
+      __syncthreads();
+    }
+    if (i < B) edge_ptr[i + 1] = run + part[tid];
+    run += part[1023];
+    __syncthreads();
+  }
+  if (tid == 0) edge_ptr[0] = 0;
+}
+
+}  // namespace mdq_mesh
+
+extern "C" int mdq_env_act(int32_t B, int32_t N, const float* q, const uint8_t* explore, const int32_t* rand_action,
+                           const int32_t* nsel, const int32_t* coord_map, int32_t* offset, int32_t* action, int32_t* rem,
+                           int32_t* code, void* stream) {
+  if (B <= 0 || N <= 0 || !nsel || !coord_map || !offset || !action || !rem || !code || (explore && !rand_action))
+    return mdq_set_error("mdq_env_act: bad arguments");
+  hipLaunchKernelGGL(mdq_mesh::env_act_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, N, q, explore, rand_action, nsel,
+                     coord_map, offset, action, rem, code);
+  if (hipGetLastError() != hipSuccess) return mdq_set_error("env_act_kernel launch failed");
+  return 0;
+}
+
+extern "C" int mdq_env_smooth_iters(int32_t B, const int32_t* rem, const int32_t* rstat, int32_t iterations, int32_t* its,
+                                    void* stream) {
+  if (B <= 0 || !rem || !rstat || !its) return mdq_set_error("mdq_env_smooth_iters: bad arguments");
+  hipLaunchKernelGGL(mdq_mesh::env_smooth_iters_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, rem, rstat,
+                     iterations, its);
+  if (hipGetLastError() != hipSuccess) return mdq_set_error("env_smooth_iters_kernel launch failed");
+  return 0;
+}
+
+extern "C" int mdq_env_result(int32_t B, int32_t N, int32_t S, const double* new_drags, const double* gt_drag, const int32_t* nv,
+                              int32_t nv0, const int32_t* rstat, const int32_t* topo_status, const int32_t* nsel,
+                              int32_t* code, int32_t* steps, double threshold, double time_reward, double goal_vertices,
+                              int32_t timesteps, double negative_reward, int32_t auto_reset, double* reward, uint8_t* done,
+                              int32_t* err_flag, void* stream) {
+  if (B <= 0 || S <= 0 || !new_drags || !gt_drag || !nv || !rstat || !nsel || !code || !steps || !reward || !done || !err_flag)
+    return mdq_set_error("mdq_env_result: bad arguments");
+  hipLaunchKernelGGL(mdq_mesh::env_result_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream, B, N, S, new_drags,
+                     gt_drag, nv, nv0, rstat, topo_status, nsel, code, steps, threshold, time_reward, goal_vertices, timesteps,
+                     negative_reward, auto_reset, reward, done, err_flag);
+  if (hipGetLastError() != hipSuccess) return mdq_set_error("env_result_kernel launch failed");
+  return 0;
+}
+
+extern "C" int mdq_restore_rows_masked(int32_t n, void* const* dst, const void* const* src, const int64_t* row_bytes,
+                                       int32_t B, const uint8_t* mask, void* stream) {
+  if (n <= 0 || n > mdq_mesh::RESTORE_MAX || !dst || !src || !row_bytes || B <= 0 || !mask)
+    return mdq_set_error("mdq_restore_rows_masked: bad arguments (at most 16 tensors)");
+  mdq_mesh::RestoreArgs a;
+  for (int t = 0; t < n; ++t) {
+    if (!dst[t] || !src[t] || row_bytes[t] <= 0 || (row_bytes[t] & 3) || ((uintptr_t)dst[t] & 3) || ((uintptr_t)src[t] & 3))
+      return mdq_set_error("mdq_restore_rows_masked: rows must be non-empty, 4-byte aligned multiples of 4 bytes");
+    a.dst[t] = static_cast<uint32_t*>(dst[t]);
+    a.src[t] = static_cast<const uint32_t*>(src[t]);
+    a.words[t] = row_bytes[t] / 4;
+  }
+  int64_t wmax = 0;
+  for (int t = 0; t < n; ++t) wmax = a.words[t] > wmax ? a.words[t] : wmax;
+  const int chunks = (int)((wmax + mdq_mesh::RESTORE_CHUNK - 1) / mdq_mesh::RESTORE_CHUNK);
+  hipLaunchKernelGGL(mdq_mesh::restore_rows_masked_kernel, dim3(B, n, chunks), dim3(256), 0, (hipStream_t)stream, a, mask);
+  if (hipGetLastError() != hipSuccess) return mdq_set_error("restore_rows_masked_kernel launch failed");
+  return 0;
+}
+
+extern "C" int mdq_edge_ptr(int32_t B, const int32_t* nedges, int32_t* edge_ptr, void* stream) {
+  if (B <= 0 || !nedges || !edge_ptr) return mdq_set_error("mdq_edge_ptr: bad arguments");
+  hipLaunchKernelGGL(mdq_mesh::edge_ptr_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, nedges, edge_ptr);
+  if (hipGetLastError() != hipSuccess) return mdq_set_error("edge_ptr_kernel launch failed");
+  return 0;
+}

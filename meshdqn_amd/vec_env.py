@@ -120,6 +120,7 @@ class VecEnv2DAirfoil:
         self._cells0_dev = torch.from_numpy(np.ascontiguousarray(topo0.cells, dtype=np.int32)).to(self.device)
         self._nv0_dev = torch.tensor([NV], dtype=torch.int32, device=self.device)
         self._nt0_dev = torch.tensor([NT], dtype=torch.int32, device=self.device)
+        self._zero_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
         if self.gpu_remesh:
             self._rstat = torch.zeros(B, dtype=torch.int32, device=self.device)
             self._rstat_host = torch.zeros(B, dtype=torch.int32, pin_memory=True)
@@ -300,35 +301,41 @@ class VecEnv2DAirfoil:
         self.new_lifts[idx] = c["lifts"]
         # device side: ONE launch restores the rows of every tensor (a dozen index_put launches otherwise).  The
         # argument arrays are built once; only the two per-step buffers (u, p) change their addresses.
-        key = 0
-        ra = self._restore_args.get(key)
+        ra = self._restore_arg_arrays()
+        ti = torch.from_numpy(idx.astype(np.int32)).to(self.device)
+        _lib.check(self.lib.mdq_restore_rows(ra["n"], ra["dst"], ra["src"], ra["nbytes"], int(ti.numel()), ti.data_ptr(),
+                                             _lib.stream_ptr()), "mdq_restore_rows")
+
+    def _restore_arg_arrays(self):
+        c = self._init_cache
+        ra = self._restore_args.get(0)
         if ra is None or ra["coords"] != self._coords_dev.data_ptr():
             pairs = [(self.u, c["u"]), (self.p, c["p"]), (self._coords_dev, self._x0_dev)]
             if self.gpu_topology:
                 pairs += [(self.dtopo.t[k], c["dev"][k]) for k in self._STATE_KEYS]
             if self.gpu_remesh:     # the device holds the meshes: reset them there as well
                 dt = self.dtopo
-                pairs += [(dt.cells, self._cells0_dev), (dt.nv, self._nv0_dev), (dt.nt, self._nt0_dev)]
+                pairs += [(dt.cells, self._cells0_dev), (dt.nv, self._nv0_dev), (dt.nt, self._nt0_dev),
+                          (dt.offset, self._zero_dev)]
             n = len(pairs)
             nbytes = [a[0].numel() * a.element_size() for a, _ in pairs]
             for (a, b_), nb in zip(pairs, nbytes):
                 assert a.is_contiguous() and b_.is_contiguous() and b_.numel() * b_.element_size() == nb and a.dtype == b_.dtype
-            ra = self._restore_args[key] = dict(n=n, dst=(C.c_void_p * n)(*[a.data_ptr() for a, _ in pairs]),
-                                           src=(C.c_void_p * n)(*[b_.data_ptr() for _, b_ in pairs]),
-                                           nbytes=(C.c_int64 * n)(*nbytes), coords=self._coords_dev.data_ptr(),
-                                           keep=pairs)
+            ra = self._restore_args[0] = dict(n=n, dst=(C.c_void_p * n)(*[a.data_ptr() for a, _ in pairs]),
+                                              src=(C.c_void_p * n)(*[b_.data_ptr() for _, b_ in pairs]),
+                                              nbytes=(C.c_int64 * n)(*nbytes), coords=self._coords_dev.data_ptr(),
+                                              keep=pairs)
         ra["dst"][0], ra["dst"][1] = self.u.data_ptr(), self.p.data_ptr()
-        ti = torch.from_numpy(idx.astype(np.int32)).to(self.device)
-        _lib.check(self.lib.mdq_restore_rows(ra["n"], ra["dst"], ra["src"], ra["nbytes"], int(ti.numel()), ti.data_ptr(),
-                                             _lib.stream_ptr()), "mdq_restore_rows")
+        return ra
 
     def _refresh(self):
         """Topology + selection, snapshot interpolation + forces on the GPU, for all envs."""
         self._refresh_launch()
         self._refresh_collect()
 
-    def _refresh_launch(self):
-        """Everything of `_refresh` that is enqueued on the stream, up to the asynchronous read-back."""
+    def _refresh_launch(self, readback=True):
+        """Everything of `_refresh` that is enqueued on the stream, up to the asynchronous read-back (`readback=False`:
+        the device-resident rollout keeps the results on the device)."""
         dev, h = self.device, self.h
         B, NV, NT, NP = self.B, self.NV, self.NT, self.NP
         if self.gpu_topology:
@@ -374,11 +381,15 @@ class VecEnv2DAirfoil:
         _lib.check(self.lib.mdq_probe_forces(C.byref(md), self.S, out_u.data_ptr(), out_p.data_ptr(), drag.data_ptr(),
                                              lift.data_ptr(), _lib.stream_ptr()), "mdq_probe_forces")
         self.u, self.p, self._coords_dev = out_u, out_p, t_coords
+        self._dev_drag, self._dev_lift = drag, lift
         fd = fl = None
         if self.flow_steps > 0:
             fd, fl = self._flow(keep, out_u, out_p)
             if not self.gpu_topology:
                 self.flow_drag, self.flow_lift = fd.cpu().numpy(), fl.cpu().numpy()
+        if not readback:
+            self._pending = None
+            return
         if self.gpu_topology:
             # one read-back for everything the host logic needs: forces + status + the small integer mirrors
             N = self.N
@@ -574,6 +585,113 @@ class VecEnv2DAirfoil:
         return state, rewards, dones, infos
 
 
+    # ------------------------------------------------------------------ device-resident rollout
+    def _state_device(self):
+        """`get_state` without the host: features, edge offsets and packed edge lists from device data only."""
+        dev, B, N, S, dt = self.device, self.B, self.N, self.S, self.dtopo
+        if getattr(self, "_dstate", None) is None:
+            self._dstate = dict(esrc=torch.empty(B * self.EMAX, dtype=torch.int32, device=dev),
+                                edst=torch.empty(B * self.EMAX, dtype=torch.int32, device=dev),
+                                edge_ptr=torch.empty(B + 1, dtype=torch.int32, device=dev))
+        ds = self._dstate
+        x = torch.empty((B, N, 2 + 3 * S), dtype=torch.float32, device=dev)
+        _lib.check(self.lib.mdq_state_features(B, N, S, self.NV, self.NP, self._coords_dev.data_ptr(), self.u.data_ptr(),
+                                               self.p.data_ptr(), dt.t["n_closest"].data_ptr(), dt.t["nsel"].data_ptr(),
+                                               x.data_ptr(), _lib.stream_ptr()), "mdq_state_features")
+        _lib.check(self.lib.mdq_edge_ptr(B, dt.t["nedges"].data_ptr(), ds["edge_ptr"].data_ptr(), _lib.stream_ptr()),
+                   "mdq_edge_ptr")
+        _lib.check(self.lib.mdq_compact_edges(B, self.EMAX, dt.t["edge_src"].data_ptr(), dt.t["edge_dst"].data_ptr(),
+                                              ds["edge_ptr"].data_ptr(), ds["esrc"].data_ptr(), ds["edst"].data_ptr(),
+                                              _lib.stream_ptr()), "mdq_compact_edges")
+        return dict(x=x, esrc=ds["esrc"], edst=ds["edst"], edge_ptr=ds["edge_ptr"], node_ptr=self._node_ptr,
+                    edge_src_pad=dt.t["edge_src"], edge_dst_pad=dt.t["edge_dst"])
+
+    def rollout_device(self, fused, steps: int, explore=None, rand_actions=None, actions=None):
+        """`steps` batched env steps WITHOUT a host round trip inside a step: the Q-network forward (`fused`: a
+        `FusedGcn`), the epsilon-greedy choice (`explore` (steps,B) bool + `rand_actions` (steps,B) ints, drawn by the
+        caller from its own random streams; greedy = first maximum of the Q-row) or given `actions` (steps,B), the
+        action decoding, vertex removal, smoothing, topology, interpolation, forces, (S3: the IPCS step), reward /
+        terminal logic and the in-place resets are all kernels on the current stream (`mdq_env_act`, `mdq_remesh`,
+        `mdq_env_smooth_iters`, `mdq_smooth`, `mdq_env_topology`, ..., `mdq_env_result`, `mdq_restore_rows_masked`).
+        Same semantics as `steps` calls of `step()` (tested against it).  Returns dict(rewards (steps,B), dones,
+        actions, codes, nv) - read back ONCE at the end, when the host mirrors of the environments are refreshed too."""
+        if not self.gpu_remesh:
+            raise _lib.MeshDQNHipError("rollout_device needs the device mesh engine (gpu_remesh=True)")
+        dev, dt, lib, B, N, S, K = self.device, self.dtopo, self.lib, self.B, self.N, self.S, int(steps)
+        i32 = torch.int32
+        if self._pending is not None:
+            self._refresh_collect()
+        if actions is not None:
+            act_all = torch.from_numpy(np.ascontiguousarray(actions, dtype=np.int32).reshape(K, B)).to(dev)
+            expl_all = rand_all = None
+        else:
+            act_all = torch.empty((K, B), dtype=i32, device=dev)
+            expl_all = torch.from_numpy(np.ascontiguousarray(explore, dtype=np.uint8).reshape(K, B)).to(dev)
+            rand_all = torch.from_numpy(np.ascontiguousarray(rand_actions, dtype=np.int32).reshape(K, B)).to(dev)
+        rew_all = torch.empty((K, B), dtype=torch.float64, device=dev)
+        done_all = torch.empty((K, B), dtype=torch.uint8, device=dev)
+        code_all = torch.empty((K, B), dtype=i32, device=dev)
+        nv_all = torch.empty((K, B), dtype=i32, device=dev)
+        rem, its = torch.empty(B, dtype=i32, device=dev), torch.empty(B, dtype=i32, device=dev)
+        d_steps = torch.from_numpy(self.steps.astype(np.int32)).to(dev)
+        err = torch.zeros(1, dtype=i32, device=dev)
+        if getattr(self, "_gt_drag_dev", None) is None:
+            self._gt_drag_dev = torch.from_numpy(np.ascontiguousarray(self.gt_drag, dtype=np.float64)).to(dev)
+        dt.offset.copy_(torch.from_numpy(self.offset))
+        sp = _lib.stream_ptr
+        st = self._state_device()
+        for k in range(K):
+            q = None
+            if actions is None:
+                q = fused.forward_arrays(st["x"], st["node_ptr"], st["esrc"], st["edst"], st["edge_ptr"], N, self.EMAX)
+            _lib.check(lib.mdq_env_act(B, N, None if q is None else q.data_ptr(),
+                                       None if expl_all is None else expl_all[k].data_ptr(),
+                                       None if rand_all is None else rand_all[k].data_ptr(), dt.t["nsel"].data_ptr(),
+                                       dt.t["coord_map"].data_ptr(), dt.offset.data_ptr(), act_all[k].data_ptr(),
+                                       rem.data_ptr(), code_all[k].data_ptr(), sp()), "mdq_env_act")
+            remesh_batch_gpu(dt.coords, dt.cells, dt.nv, dt.nt, rem, self._rstat)
+            _lib.check(lib.mdq_env_smooth_iters(B, rem.data_ptr(), self._rstat.data_ptr(), 50, its.data_ptr(), sp()),
+                       "mdq_env_smooth_iters")
+            smooth_batch_gpu(dt.coords, dt.cells, dt.nv, dt.nt, its)
+            self._refresh_launch(readback=False)
+            nv_all[k].copy_(dt.nv)
+            _lib.check(lib.mdq_env_result(B, N, S, self._dev_drag.data_ptr(), self._gt_drag_dev.data_ptr(), dt.nv.data_ptr(),
+                                          int(self.initial_num_node), self._rstat.data_ptr(), dt.status.data_ptr(),
+                                          dt.t["nsel"].data_ptr(), code_all[k].data_ptr(), d_steps.data_ptr(),
+                                          self.threshold, self.TIME_REWARD, self.goal_vertices, int(self.timesteps),
+                                          self.NEGATIVE_REWARD, 1 if self.auto_reset else 0, rew_all[k].data_ptr(),
+                                          done_all[k].data_ptr(), err.data_ptr(), sp()), "mdq_env_result")
+            if self.auto_reset:
+                ra = self._restore_arg_arrays()
+                _lib.check(lib.mdq_restore_rows_masked(ra["n"], ra["dst"], ra["src"], ra["nbytes"], B,
+                                                       done_all[k].data_ptr(), sp()), "mdq_restore_rows_masked")
+            st = self._state_device()
+        # one read-back; host mirrors of the environments follow the device
+        out = dict(rewards=rew_all.cpu().numpy(), dones=done_all.cpu().numpy().astype(bool), actions=act_all.cpu().numpy(),
+                   codes=code_all.cpu().numpy(), nv=nv_all.cpu().numpy())
+        if int(err.item()) != 0:
+            raise _lib.MeshDQNHipError("topology kernel failed inside rollout_device")
+        self._sync_host_from_device(d_steps, out["dones"][-1] if K and self.auto_reset else None)
+        return out
+
+    def _sync_host_from_device(self, d_steps, last_done=None):
+        dt, h = self.dtopo, self.h
+        self.coords[...] = dt.coords.cpu().numpy()
+        self.cells[...] = dt.cells.cpu().numpy()
+        self.nv[...] = dt.nv.cpu().numpy()
+        self.nt[...] = dt.nt.cpu().numpy()
+        self.offset[...] = dt.offset.cpu().numpy()
+        self.steps[...] = d_steps.cpu().numpy()
+        for k in ("nsel", "nedges", "ne", "coord_map", "n_closest"):
+            h[k][...] = dt.t[k].cpu().numpy()
+        self.new_drags = self._dev_drag.cpu().numpy().copy()
+        self.new_lifts = self._dev_lift.cpu().numpy().copy()
+        if last_done is not None and last_done.any():      # (restarted environments: the cached initial forces, like step())
+            self.new_drags[last_done] = self._init_cache["drags"]
+            self.new_lifts[last_done] = self._init_cache["lifts"]
+        self._deferred_mirror = None
+
+
 class VecEnvGroups:
     """`num_envs` environments as G independent `VecEnv2DAirfoil` groups, each driven by its own Python thread on
     its own HIP stream - the counterpart of the reference's asynchronous Ray workers (`num_parallel`,
@@ -618,6 +736,32 @@ class VecEnvGroups:
             t.start()
         for t in threads:
             t.join()
+        if errs:
+            raise errs[0]
+        return out
+
+    def rollout_device(self, fused, steps: int, explore, rand_actions):
+        """Every group runs `VecEnv2DAirfoil.rollout_device` (no host round trip inside a step) on its own stream:
+        fused[g] / explore[g] / rand_actions[g] per group.  Returns the per-group result dicts."""
+        import threading
+        out, errs = [None] * len(self.envs), []
+
+        def work(g):
+            try:
+                with torch.cuda.stream(self.streams[g]):
+                    out[g] = self.envs[g].rollout_device(fused[g], steps, explore[g], rand_actions[g])
+                    self.streams[g].synchronize()
+            except BaseException as exc:  # noqa: BLE001 - surfaced to the caller below
+                errs.append(exc)
+
+        if len(self.envs) == 1:
+            work(0)
+        else:
+            threads = [threading.Thread(target=work, args=(g,)) for g in range(len(self.envs))]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
         if errs:
             raise errs[0]
         return out

@@ -646,3 +646,60 @@ def test_overlapped_flow_step_equals_inline_flow_step(lib_built):
             assert np.allclose(b[3]["flow_lift"], hist[0][k - 1][3]["flow_lift"], rtol=1e-6, atol=0)
     last = envs[1].flow_wait()
     assert np.allclose(last[0], hist[0][K - 1][3]["flow_drag"], rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("flow", [0, 1])
+def test_device_resident_rollout_equals_host_logic_steps(lib_built, flow):
+    """`rollout_device` (action decoding, smoothing request, reward / terminal logic and in-place resets as kernels:
+    mdq_env_act / mdq_env_smooth_iters / mdq_env_result / mdq_restore_rows_masked, one read-back at the end) against the
+    same number of `step()` calls (host logic of Env2DAirfoil.py:318-428) - scripted actions incl. "do nothing" (180),
+    invalid actions and enough removals in some environments to reach the terminal condition and the in-place reset;
+    then with the fused Q-network choosing (epsilon-greedy from given random streams)."""
+    from meshdqn_amd.airfoilgcnn import NodeRemovalNet
+    from meshdqn_amd.env import Env2DAirfoil
+    from meshdqn_amd.gcn_fused import FusedGcn
+    from meshdqn_amd.vec_env import VecEnv2DAirfoil
+    cfg = _config("ys930")
+    cfg["agent_params"].update(solver_steps=200, save_steps=40, goal_vertices=0.992)      # 8 removals end an episode
+    base = Env2DAirfoil(cfg)
+    B, K = 8, 14
+    host = VecEnv2DAirfoil(cfg, B, base_env=base, flow_steps=flow, flow_overlap=bool(flow))
+    devi = VecEnv2DAirfoil(cfg, B, base_env=base, flow_steps=flow, flow_overlap=bool(flow))
+    rng = np.random.default_rng(12)
+    acts = rng.integers(0, 181, size=(K, B))
+    acts[3, 0], acts[5, 1], acts[:, 2] = 180, 180, 180            # window shifts; env 2 never removes anything
+    host.get_state()
+    ref = [host.step(acts[k]) for k in range(K)]
+    out = devi.rollout_device(None, K, actions=acts)
+    assert out["dones"].any() and (out["codes"] == 0).all()
+    for k in range(K):
+        _, rew, done, info = ref[k]
+        assert np.array_equal(out["dones"][k], done), k
+        assert np.array_equal(out["nv"][k], info["nv"]), k
+        assert np.array_equal(out["codes"][k], info["code"]), k
+        assert np.abs(out["rewards"][k] - rew).max() < 1e-12, k
+    # the host mirrors follow the device: the two environments are in the same state and continue identically
+    for a in ("nv", "nt", "offset", "steps"):
+        assert np.array_equal(getattr(devi, a), getattr(host, a)), a
+    nvm = int(host.nv.max())
+    assert np.array_equal(devi.coords[:, :nvm], host.coords[:, :nvm]) or np.abs(devi.coords[:, :nvm] - host.coords[:, :nvm]).max() < 1e-15
+    sh, sd = host.get_state(), devi.get_state()
+    assert torch.equal(sh["x"], sd["x"]) and torch.equal(sh["esrc"], sd["esrc"]) and torch.equal(sh["edge_ptr"], sd["edge_ptr"])
+    # policy-driven: the fused Q-network + given random streams on both paths
+    torch.manual_seed(1)
+    net = NodeRemovalNet(181, conv_width=128, topk=0.1)
+    net.set_num_nodes(17)
+    fused = FusedGcn(net.cuda())
+    explore = rng.random((6, B)) < 0.5
+    rand = rng.integers(0, 181, size=(6, B))
+    st = host.get_state()
+    hist = []
+    for k in range(6):
+        q = fused.forward_arrays(st["x"], st["node_ptr"], st["esrc"], st["edst"], st["edge_ptr"], host.N, host.EMAX)
+        a = np.where(explore[k], rand[k], q.argmax(1).cpu().numpy())
+        st, rew, done, info = host.step(a)
+        hist.append((a, rew, done))
+    out = devi.rollout_device(fused, 6, explore=explore, rand_actions=rand)
+    for k in range(6):
+        assert np.array_equal(out["actions"][k], hist[k][0]), k
+        assert np.abs(out["rewards"][k] - hist[k][1]).max() < 1e-12 and np.array_equal(out["dones"][k], hist[k][2])

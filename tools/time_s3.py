@@ -30,9 +30,16 @@ def act_for(n):
     return act
 for n in groups:
     groups[n].rollout(act_for(n), 30)
+def dev_run(n, k):
+    ex = [np.array([rngs[n].random(B) < 0.5 for _ in range(k)])]
+    ra = [np.array([rngs[n].integers(0, 181, B) for _ in range(k)])]
+    groups[n].rollout_device([fused[n]], k, ex, ra)
+for n in groups:
+    dev_run(n, 10)
 for rep in range(4):
     for n in groups:
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        groups[n].rollout(act_for(n), K)
-        torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        print(f"rep {rep} {n:12s}: {dt / K * 1e3:.3f} ms per batched step -> {B * K / dt:.0f} env-steps/s", flush=True)
+        for mode in ("host", "device"):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            groups[n].rollout(act_for(n), K) if mode == "host" else dev_run(n, K)
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            print(f"rep {rep} {n:12s} {mode:6s}: {dt / K * 1e3:.3f} ms per batched step -> {B * K / dt:.0f} env-steps/s", flush=True)
