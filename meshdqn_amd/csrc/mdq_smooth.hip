@@ -51,12 +51,16 @@ constexpr int OFF_PTR = OFF_PT + (SNV + 4) * GRP * 2;
 constexpr int OFF_CNT = OFF_PTR + (SNV + 1) * 4 + 12;
 constexpr int OFF_INC = OFF_CNT + SNV * 4;
 constexpr int OFF_IVERT = OFF_INC + 3 * SNT * 4;
-constexpr int OFF_LEV = OFF_IVERT + SNV * 2;
-constexpr int OFF_FILL = OFF_LEV + (SNV + 4) * 4;
-constexpr int OFF_PART = OFF_FILL + SNV * 4;
+constexpr int OFF_RK = OFF_IVERT + SNV * 2;                 // interior rank of a vertex (0xFFFF: not interior)
+constexpr int OFF_DEG = OFF_RK + (SNV + 8) * 2;             // unscheduled lower neighbours per interior rank (x 2)
+constexpr int OFF_R2K = OFF_DEG + SNV * 4;                  // 1 / (2 k)
+constexpr int OFF_RB = OFF_R2K + 32 * 8;                    // ready bitmap over the interior ranks
+constexpr int OFF_PART = OFF_RB + 2 * (SNV / 64) * 8;
 constexpr int LDS_BYTES = OFF_PART + SWG * 4;
-static_assert(OFF_ROW % 16 == 0 && OFF_PT % 16 == 0 && OFF_PTR % 16 == 0 && OFF_CNT % 16 == 0, "LDS alignment");
+static_assert(OFF_ROW % 16 == 0 && OFF_PT % 16 == 0 && OFF_PTR % 16 == 0 && OFF_CNT % 16 == 0 && OFF_R2K % 8 == 0 &&
+                  OFF_RB % 8 == 0 && OFF_DEG % 4 == 0, "LDS alignment");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+static_assert(SNV * GRP * 4 <= (SNV + 3) * REC, "scheduler scratch inside the record area");
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
@@ -175,8 +179,12 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
   int* cnt = reinterpret_cast<int*>(lds + OFF_CNT);
   uint32_t* inc = reinterpret_cast<uint32_t*>(lds + OFF_INC);   // a | b << 10 | cell << 20 of every (vertex, incident cell), grouped by vertex, ascending cell
   uint16_t* ivert = reinterpret_cast<uint16_t*>(lds + OFF_IVERT);   // interior vertices in index order
-  int* levv = reinterpret_cast<int*>(lds + OFF_LEV);            // level of a vertex inside a sweep (boundary: 0)
-  int* fill = reinterpret_cast<int*>(lds + OFF_FILL);           // slots handed out per level
+  uint16_t* rk = reinterpret_cast<uint16_t*>(lds + OFF_RK);
+  int* indeg2 = reinterpret_cast<int*>(lds + OFF_DEG);
+  unsigned long long* rb = reinterpret_cast<unsigned long long*>(lds + OFF_RB);
+  unsigned long long* bigdeg = rb + SNV / 64;                   // interior ranks of degree > 8
+  unsigned char* hwt = recb;   // scheduler scratch in the record area (the records are loaded behind the scheduler):
+                               // per interior rank and cell the interior ranks of its higher-numbered vertices
   int* part = reinterpret_cast<int*>(lds + OFF_PART);
   const int b = blockIdx.x, tid = threadIdx.x;
   const int iters = iters_[b];
@@ -201,19 +209,6 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
   for (int v = tid; v < SNV; v += SWG) ptr[v + 1] = cnt[v];
   if (tid == 0) ptr[0] = 0;
   __syncthreads();
-  // vertex records: (x, y) for the even lanes, (y, x) for the odd lanes; record SNV: zeros, SNV + 1 / + 2: the far edge
-  for (int v = tid; v < SNV + 3; v += SWG) {
-    d2 p = {0.0, 0.0};
-    if (v < nv) {
-      const double2 xv = x[v];
-      p = d2{xv.x, xv.y};
-    } else if (v > SNV) {
-      p = d2{(double)(v - SNV - 1), -1000.0};
-    }
-    *reinterpret_cast<d2*>(recb + v * REC) = p;
-    *reinterpret_cast<d2*>(recb + v * REC + 16) = d2{p.y, p.x};
-    levv[v] = 0;
-  }
   // cell lists in arrival order (scratch: the metadata rows are not built yet), owner of every entry
   uint32_t* tmp = reinterpret_cast<uint32_t*>(rows);
   uint16_t* own = reinterpret_cast<uint16_t*>(rows + 3 * SNT * 4);
@@ -268,22 +263,22 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
   for (int v = tid; v < SNV; v += SWG) {
     const bool interior = v < nv && ptr[v + 1] > ptr[v] && cnt[v] == 0;
     cnt[v] = interior ? 1 : 0;
-    levv[v] = interior ? 0 : 1;   // level 0; not interior: final (see the level relaxation below)
   }
-  if (tid == 0) levv[SNV] = 1;
-  if (tid < 32) part[tid] = 0;   // (1 / 2k table below)
   __syncthreads();
   MDQ_SMOOTH_PHASE()   /* 3: sorted, interior test, records */
   scan_inclusive(cnt, part);
   const int n_int = cnt[SNV - 1];
   __syncthreads();
-  for (int v = tid; v < nv; v += SWG)
-    if (cnt[v] != (v ? cnt[v - 1] : 0)) ivert[cnt[v] - 1] = (uint16_t)v;
+  for (int v = tid; v < SNV + 8; v += SWG) {
+    const bool interior = v < nv && cnt[v] != (v ? cnt[v - 1] : 0);
+    rk[v] = interior ? (uint16_t)(cnt[v] - 1) : (uint16_t)0xFFFF;
+    if (interior) ivert[cnt[v] - 1] = (uint16_t)v;
+  }
+  double* r2ktab = reinterpret_cast<double*>(lds + OFF_R2K);   // 1 / (2 k), k < 32
+  if (tid < 32) r2ktab[tid] = tid ? 1.0 / (2.0 * tid) : 0.0;
+  if (tid < SNV / 64) rb[tid] = bigdeg[tid] = 0ull;
   __syncthreads();
   MDQ_SMOOTH_PHASE()   /* 4: interior ranks */
-  double* r2ktab = reinterpret_cast<double*>(fill);   // 1 / (2 k), k < 32 (the slot counters are zeroed later)
-  if (tid < 32) r2ktab[tid] = tid ? 1.0 / (2.0 * tid) : 0.0;
-  __syncthreads();
   // metadata rows.  Row n_int is the empty pass slot: vertex and cells on the zero record except lane 0, whose cell
   // is the far-away edge (a finite altitude keeps the slot on the fast path; it stores zeros into the zero record)
   for (int r = tid; r <= n_int; r += SWG) {
@@ -302,6 +297,24 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
       wv = (uint32_t)(v * REC);
       r2k = k < 32 ? r2ktab[k] : 1.0 / (2.0 * k);
       thr = k <= GRP ? 4.0e-31f : __builtin_inff();   // degree > 8: always the exact path
+      // dependencies inside a sweep: the lower-numbered interior neighbours (each is seen in two cells: counted twice);
+      // per cell the interior ranks of the higher-numbered ones (the vertices this one releases when it is scheduled)
+      int dep = 0;
+      uint32_t hw[GRP];
+#pragma unroll
+      for (int l = 0; l < GRP; ++l) hw[l] = 0xFFFFFFFFu;
+      for (int i = q0; i < q0 + k; ++i) {
+        const uint32_t wi = inc[i];
+        const int a = wi & 0x3FF, c = (wi >> 10) & 0x3FF;
+        const uint32_t ra = rk[a], rc = rk[c];
+        dep += (a < v && ra != 0xFFFF) + (c < v && rc != 0xFFFF);
+        if (i - q0 < GRP) hw[i - q0] = (a > v ? ra : 0xFFFFu) | ((c > v ? rc : 0xFFFFu) << 16);
+      }
+      indeg2[r] = dep;
+      if (dep == 0) atomicOr(&rb[r >> 6], 1ull << (r & 63));
+      if (k > GRP) atomicOr(&bigdeg[r >> 6], 1ull << (r & 63));
+#pragma unroll
+      for (int l = 0; l < GRP; l += 4) *reinterpret_cast<u4*>(hwt + (r * GRP + l) * 4) = u4{hw[l], hw[l + 1], hw[l + 2], hw[l + 3]};
     } else {
       w[0] = (uint32_t)AREC | ((uint32_t)CREC << 16);
     }
@@ -310,108 +323,98 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
     *reinterpret_cast<u4*>(rows + r * ROW + 32) = u4{(uint32_t)__double2loint(r2k), (uint32_t)__double2hiint(r2k), wv, __float_as_uint(thr)};
   }
   MDQ_SMOOTH_PHASE()   /* 5: rows */
-  // levels of one sweep: 1 + the largest level among the lower-numbered interior neighbours.  Monotone relaxation in
-  // place (a value only grows towards the fixed point): every thread owns up to LPT CONSECUTIVE interior vertices and
-  // walks them in index order with the level addresses of their cells in registers, so a chain of consecutively
-  // numbered vertices advances LPT levels per round; the waves run LROUNDS rounds between two barriers
-  {
-    constexpr int LPT = SNV / SWG, LROUNDS = 4;
-    const int r0 = tid * LPT;
-    uint32_t la[LPT][GRP];     // per cell: byte offsets into levv of its two other vertices, lower ones only
-    int vown[LPT];
-#pragma unroll
-    for (int j = 0; j < LPT; ++j) {
-      const int r = r0 + j;
-      vown[j] = r < n_int ? ivert[r] : SNV;
-      const int q0 = r < n_int ? ptr[vown[j]] : 0, k = r < n_int ? ptr[vown[j] + 1] - q0 : 0;
-#pragma unroll
-      for (int i = 0; i < GRP; ++i) {
-        uint32_t a = SNV, c = SNV;      // levv[SNV]: level 0, final
-        if (i < k) {
-          const uint32_t w = inc[q0 + i];
-          a = w & 0x3FF;
-          c = (w >> 10) & 0x3FF;
-          if ((int)a > vown[j]) a = SNV;
-          if ((int)c > vown[j]) c = SNV;
+  __syncthreads();
+  // passes of one sweep by LIST SCHEDULING (wave 0): a vertex is ready when its lower-numbered interior neighbours are
+  // scheduled; every pass takes the (up to) 8 ready vertices with the smallest indices, then releases their
+  // higher-numbered neighbours.  Lowest-index-first follows the long ascending chains of the mesh numbering: 119
+  // passes for ys930 (level by level: 141; the critical path: 113), and no level computation at all.  The ready set
+  // is a bitmap over the interior ranks (one 64-bit word per lane 0..15), the release runs 8 lanes per scheduled
+  // vertex (one incident cell each) with LDS atomics.
+  int npass_w = 0;
+  if (tid < 64) {
+    const int lane = tid, l = lane & 7, g = lane >> 3;
+    int remaining = n_int, p = 0;
+    while (remaining > 0) {
+      unsigned long long word = lane < SNV / 64 ? rb[lane] : 0ull;
+      const int c = __popcll(word);
+      // inclusive prefix sums over the 16 bitmap lanes (one DPP row): row_shr 1, 2, 4, 8
+      int incl = c;
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);
+      const int total = __builtin_amdgcn_readlane(incl, SNV / 64 - 1);
+      int take = min(total, GRP);
+      const int excl = incl - c;
+      if (take == 0) {
+        // cannot happen on a consistent mesh (the smallest unscheduled vertex is always ready); stay safe anyway:
+        // schedule the smallest unscheduled rank alone
+        int first = n_int;
+        for (int r = lane; r < n_int; r += 64)
+          if (indeg2[r] >= 0) first = min(first, r);
+        for (int off = 32; off > 0; off >>= 1) first = min(first, __shfl_xor(first, off));
+        if (lane == 0) passtab[p * GRP] = (uint16_t)(first * ROW);
+        take = 1;
+      } else if (lane < SNV / 64) {
+        // (a walk over the words with one lane per BIT and ballots was tried: slower, 234 k cycles against 167 k)
+        const int mine = min(max(GRP - excl, 0), c);     // how many of this lane's lowest ready bits are taken
+        for (int i = 0; i < mine; ++i) {
+          const int bit = __ffsll((long long)word) - 1;
+          passtab[p * GRP + excl + i] = (uint16_t)((lane * 64 + bit) * ROW);
+          word &= word - 1;
         }
-        la[j][i] = (a * 4) | ((c * 4) << 16);
+        if (mine > 0) rb[lane] = word;
       }
-      // (degree > 8: the cells beyond the eighth are read from the list in every round)
-    }
-    // a stored value is 2 * level + final (final: all lower neighbours final, the level will not change): maxima of
-    // stored values are maxima of levels, the AND of their low bits says whether all are final.  A final vertex is not
-    // visited again
-    const lds_u8* LV = (const lds_u8*)(lds + OFF_LEV);
-    bool fin[LPT];
-#pragma unroll
-    for (int j = 0; j < LPT; ++j) fin[j] = vown[j] >= SNV;
-    for (;;) {
-      for (int round = 0; round < LROUNDS; ++round) {
-#pragma unroll
-        for (int j = 0; j < LPT; ++j) {
-          const int v = vown[j];
-          if (!fin[j]) {
-            asm volatile("" ::: "memory");   // (re-read the levels: other threads raise them)
-            int lv[2 * GRP];
-#pragma unroll
-            for (int i = 0; i < GRP; ++i) {
-              lv[2 * i] = *reinterpret_cast<const lds_i32*>(LV + (la[j][i] & 0xFFFF));
-              lv[2 * i + 1] = *reinterpret_cast<const lds_i32*>(LV + (la[j][i] >> 16));
-            }
-            int L = 0, allfin = 1;
-#pragma unroll
-            for (int i = 0; i < GRP; ++i) {
-              L = max(L, max(lv[2 * i], lv[2 * i + 1]));
-              allfin &= lv[2 * i] & lv[2 * i + 1];
-            }
-            const int q0 = ptr[v], q1 = ptr[v + 1];
-            for (int i = q0 + GRP; i < q1; ++i) {
-              const uint32_t w = inc[i];
-              const int a = w & 0x3FF, c = (w >> 10) & 0x3FF;
-              const int xa = a < v ? levv[a] : 1, xc = c < v ? levv[c] : 1;
-              L = max(L, max(xa, xc));
-              allfin &= xa & xc;
-            }
-            levv[v] = ((L >> 1) + 1) * 2 + allfin;
-            fin[j] = allfin != 0;
+      if (lane >= take && lane < GRP) passtab[p * GRP + lane] = (uint16_t)(n_int * ROW);   // empty slots
+      // release: group g = scheduled vertex g, lane l = its l-th cell
+      if (g < take) {
+        const int r = passtab[p * GRP + g] / ROW;
+        const uint32_t h2 = *reinterpret_cast<const uint32_t*>(hwt + (r * GRP + l) * 4);
+        const bool big = (bigdeg[r >> 6] >> (r & 63)) & 1ull;
+        if (l == 0) indeg2[r] = -1;                 // scheduled
+        auto release = [&](uint32_t ru) {
+          if (ru != 0xFFFF && atomicSub(&indeg2[ru], 1) == 1) atomicOr(&rb[ru >> 6], 1ull << (ru & 63));
+        };
+        release(h2 & 0xFFFF);
+        release(h2 >> 16);
+        if (big && l == 0) {                          // degree > 8: the cells beyond the eighth
+          const int v = ivert[r], q0 = ptr[v], k = ptr[v + 1] - q0;
+          for (int i = q0 + GRP; i < q0 + k; ++i) {
+            const uint32_t wi = inc[i];
+            const int a = wi & 0x3FF, cc = (wi >> 10) & 0x3FF;
+            if (a > v) release(rk[a]);
+            if (cc > v) release(rk[cc]);
           }
         }
       }
-      bool open = false;
-#pragma unroll
-      for (int j = 0; j < LPT; ++j) open |= !fin[j];
-      if (!__syncthreads_or(open)) break;
+      remaining -= take;
+      ++p;
     }
-    for (int v = tid; v < SNV; v += SWG) levv[v] >>= 1;
-    __syncthreads();
+    // an even number of passes (the walk below is unrolled by two) and the first three passes again behind the last
+    // one (the prefetch runs up to three passes ahead, into the next sweep)
+    if (p & 1) {
+      if (lane < GRP) passtab[p * GRP + lane] = (uint16_t)(n_int * ROW);
+      ++p;
+    }
+    if (lane < 3 * GRP) passtab[p * GRP + lane] = passtab[lane];
+    npass_w = p;
   }
-  MDQ_SMOOTH_PHASE()   /* 6: levels */
-  // passes: level L takes ceil(width / 8) of them, slots inside a level in arrival order (the updates of a level are
-  // independent, so the slot order does not change any result); an even number of passes (the walk below is unrolled
-  // by two) and the first three passes again behind the last one (the prefetch runs up to three passes ahead, into the next sweep)
-  for (int v = tid; v < SNV; v += SWG) {
-    cnt[v] = 0;
-    fill[v] = 0;
-  }
+  if (tid == 0) part[0] = npass_w;
   __syncthreads();
-  for (int r = tid; r < n_int; r += SWG) atomicAdd(&cnt[levv[ivert[r]] - 1], 1);
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < PER; ++i) cnt[tid * PER + i] = (cnt[tid * PER + i] + GRP - 1) / GRP;
-  __syncthreads();
-  scan_inclusive(cnt, part);
-  const int npass = (cnt[SNV - 1] + 1) & ~1;
-  for (int e = tid; e < npass * GRP; e += SWG) passtab[e] = (uint16_t)(n_int * ROW);
-  __syncthreads();
-  for (int r = tid; r < n_int; r += SWG) {
-    const int i = levv[ivert[r]] - 1;
-    const int pos = atomicAdd(&fill[i], 1);
-    passtab[((i ? cnt[i - 1] : 0) + (pos >> 3)) * GRP + (pos & 7)] = (uint16_t)(r * ROW);
+  const int npass = part[0];
+  // vertex records: (x, y) for the even lanes, (y, x) for the odd lanes; record SNV: zeros, SNV + 1 / + 2: the far edge
+  for (int v = tid; v < SNV + 3; v += SWG) {
+    d2 p = {0.0, 0.0};
+    if (v < nv) {
+      const double2 xv = x[v];
+      p = d2{xv.x, xv.y};
+    } else if (v > SNV) {
+      p = d2{(double)(v - SNV - 1), -1000.0};
+    }
+    *reinterpret_cast<d2*>(recb + v * REC) = p;
+    *reinterpret_cast<d2*>(recb + v * REC + 16) = d2{p.y, p.x};
   }
   __syncthreads();
-  if (tid < 3 * GRP) passtab[npass * GRP + tid] = passtab[tid];
-  __syncthreads();
-
   MDQ_SMOOTH_PHASE()   /* 7: pass table */
   // ---------------- the sweeps: wave 0 walks the passes
   if (tid < 64 && npass > 0) {
