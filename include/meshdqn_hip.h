@@ -387,6 +387,13 @@ int mdq_smooth(int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t*
                const int32_t* nt, const int32_t* iterations, void* stream);
 
 /*
+ * Diagnostics of mdq_smooth since the last reset (no reference counterpart): out64[s], s < 63 = speculative sweeps s
+ * that met an update that was not clearly a full step and were redone by careful sweeps (see mdq_smooth.hip).
+ * out64 is a HOST array of 64 int64 (may be NULL); reset != 0 zeroes the counters.  Synchronises the device.
+ */
+int mdq_smooth_stats(int64_t* out64, int32_t reset);
+
+/*
  * Env2DAirfoil._remove_vertex (Env2DAirfoil.py:452-512) for B meshes on the GPU, WITHOUT the smoothing (mdq_smooth):
  * ear clipping of the removed vertex's star polygon + Lawson flips to the (unique) Delaunay triangulation = the
  * reference's global scipy Delaunay + all-boundary filter as a set of cells; vertex ids above the removed one shift

@@ -118,6 +118,7 @@ SYMBOLS = {
     "mdq_edge_ptr": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdq_smooth": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_void_p]),
+    "mdq_smooth_stats": (C.c_int, [C.c_void_p, C.c_int32]),
     "mdq_smooth_host": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
 }

@@ -30,6 +30,8 @@
 #include "../../include/meshdqn_hip.h"
 
 namespace mdq_smoothing {
+// diagnostics (mdq_smooth_stats): [s] = speculative sweeps s that were abandoned for a careful redo, [63] = workgroups run
+__device__ unsigned long long g_abandoned[64];
 
 constexpr int SNV = 1024;      // vertex capacity (record offsets must fit 16 bits)
 constexpr int SNT = 2048;      // triangle capacity (cell id must fit 12 bits)
@@ -57,6 +59,7 @@ constexpr int OFF_R2K = OFF_DEG + SNV * 4;                  // 1 / (2 k)
 constexpr int OFF_RB = OFF_R2K + 32 * 8;                    // ready bitmap over the interior ranks
 constexpr int OFF_PART = OFF_RB + 2 * (SNV / 64) * 8;
 constexpr int LDS_BYTES = OFF_PART + SWG * 4;
+constexpr int MAXBP = SWG - 2;                               // pass pairs with a vertex of more than 8 cells (listed behind part[1])
 static_assert(OFF_ROW % 16 == 0 && OFF_PT % 16 == 0 && OFF_PTR % 16 == 0 && OFF_CNT % 16 == 0 && OFF_R2K % 8 == 0 &&
                   OFF_RB % 8 == 0 && OFF_DEG % 4 == 0, "LDS alignment");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
   int npass_w = 0;
   if (tid < 64) {
     const int lane = tid, l = lane & 7, g = lane >> 3;
-    int remaining = n_int, p = 0;
+    int remaining = n_int, p = 0, nbp = 0, lastbp = -1;
     while (remaining > 0) {
       unsigned long long word = lane < SNV / 64 ? rb[lane] : 0ull;
       const int c = __popcll(word);
@@ -367,10 +370,11 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
       }
       if (lane >= take && lane < GRP) passtab[p * GRP + lane] = (uint16_t)(n_int * ROW);   // empty slots
       // release: group g = scheduled vertex g, lane l = its l-th cell
+      bool big = false;
       if (g < take) {
         const int r = passtab[p * GRP + g] / ROW;
         const uint32_t h2 = *reinterpret_cast<const uint32_t*>(hwt + (r * GRP + l) * 4);
-        const bool big = (bigdeg[r >> 6] >> (r & 63)) & 1ull;
+        big = (bigdeg[r >> 6] >> (r & 63)) & 1ull;
         if (l == 0) indeg2[r] = -1;                 // scheduled
         auto release = [&](uint32_t ru) {
           if (ru != 0xFFFF && atomicSub(&indeg2[ru], 1) == 1) atomicOr(&rb[ru >> 6], 1ull << (ru & 63));
@@ -387,9 +391,17 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
           }
         }
       }
+      // pass pairs (the walk is unrolled by two) that hold a vertex of more than 8 cells: the speculative sweeps run
+      // them as careful passes
+      if (__builtin_amdgcn_ballot_w64(big) && lastbp != (p & ~1)) {
+        lastbp = p & ~1;
+        if (lane == 0 && nbp < MAXBP) part[2 + nbp] = lastbp;
+        ++nbp;
+      }
       remaining -= take;
       ++p;
     }
+    if (lane == 0) part[1] = nbp;
     // an even number of passes (the walk below is unrolled by two) and the first three passes again behind the last
     // one (the prefetch runs up to three passes ahead, into the next sweep)
     if (p & 1) {
@@ -401,7 +413,7 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
   }
   if (tid == 0) part[0] = npass_w;
   __syncthreads();
-  const int npass = part[0];
+  const int npass = part[0], nbp = part[1];
   // vertex records: (x, y) for the even lanes, (y, x) for the odd lanes; record SNV: zeros, SNV + 1 / + 2: the far edge
   for (int v = tid; v < SNV + 3; v += SWG) {
     d2 p = {0.0, 0.0};
@@ -485,6 +497,15 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
     if (l < 2) asm volatile("ds_write_b64 %0, %2\n\tds_write_b64 %1, %2" ::"v"(vrec + st1), "v"(vrec + st2), "v"(pn) : "memory"); \
     MDQ_SMOOTH_TRACE_OUT(vrec)                                                                                          \
   }
+#ifdef MDQ_SMOOTH_DIAGNOSE   /* debug builds: the last undecided update of a speculative sweep in slots 40.. */
+#define MDQ_SMOOTH_DIAG(fast, vrec, q2f, ab, thr)                                                     \
+  if (l == 0 && !(fast) && (vrec) != (uint32_t)ZREC) {                                                 \
+    g_abandoned[40] = b; g_abandoned[41] = (vrec) / REC; g_abandoned[42] = __float_as_uint(q2f);       \
+    g_abandoned[43] = ab; g_abandoned[44] = thr; g_abandoned[45] = sweep; g_abandoned[46] = nv;        \
+  }
+#else
+#define MDQ_SMOOTH_DIAG(fast, vrec, q2f, ab, thr)
+#endif
 #ifdef MDQ_SMOOTH_TRACE
 #define MDQ_SMOOTH_STAMP(t) const long long t = clock64();
 #define MDQ_SMOOTH_TRACE_OUT(vrec)                                     \
@@ -542,74 +563,144 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
     asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(q2f) : "v"(t2));    \
     const bool fast = (q2f > __uint_as_float(thr)) & (q2f < 0.24975f * __uint_as_float(ab));                            \
     undecided |= 0x0101010101010101ull & ~__builtin_amdgcn_ballot_w64(fast);                                            \
+    MDQ_SMOOTH_DIAG(fast, vrec, q2f, ab, thr)                                                                          \
     W1 = wnew;                                                                                                          \
     M = mnew;                                                                                                           \
   }
-    bool failed = false;
-    {
-      unsigned long long undecided = 0;   // groups whose update was not clearly a full step (tested once per sweep: a
-                                          // branch behind every test would keep the next loads behind it)
-      // pass 0 in set A, pass 1 in set B, vertex list of pass 2
-      d2 paA, pcA, pvA, paB = {0, 0}, pcB = {0, 0}, pvB = {0, 0};
-      uint32_t wN, rkP, rkQ = 0;     // wN: cell words of the pass whose positions are loaded next
-      u4 mA, mB;
+    // The walk alternates between the two kinds of sweeps.  A vertex removal leaves a cavity whose neighbours take a
+    // LIMITED first step in most environments (tools: 5 of 8 removals on ys930, always in sweep 0), so the first sweeps
+    // run careful; the rest run speculative from a checkpoint of the records in the coordinate array (this kernel owns
+    // it until the write-back).  A speculative sweep with an undecided update is abandoned: back to the checkpoint,
+    // careful through that sweep and `extra` more (doubling), checkpoint, speculative again.
+    const uint32_t lpt = OFF_PT + 2 * (lane >> 3);         // this group's slot of a pass
+    int done = 0, ncareful = iters < 3 || nbp > MAXBP ? iters : 3, extra = 2;
+    while (true) {
+      if (ncareful > 0) {
+        // ---- careful sweeps: decision in front of every store, exact fp64 path where needed
+        uint32_t wA, wB = 0, rkA = 0, rkB;
+        u4 mA, mB = {0, 0, 0, 0};
+        {
+          const uint32_t rk0 = passtab[lane >> 3];
+          wA = *reinterpret_cast<const uint32_t*>(rows + rk0 + 4 * l);
+          mA = *reinterpret_cast<const u4*>(rows + rk0 + 32);
+          rkB = passtab[GRP + (lane >> 3)];
+        }
+        for (int sweep = done; sweep < done + ncareful; ++sweep) {
+          uint32_t pt = lpt + 2 * (GRP * 2);
+          for (int q = 0; q < npass; q += 2) {
+            MDQ_SMOOTH_PASS(wA, mA, rkB, wB, mB, rkA, pt)
+            MDQ_SMOOTH_PASS(wB, mB, rkA, wA, mA, rkB, pt + GRP * 2)
+            pt += 2 * (GRP * 2);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        done += ncareful;
+      }
+      if (done >= iters) break;
+      // ---- checkpoint, then speculative sweeps
+      for (int v = lane; v < nv; v += 64) {
+        const d2 p = *reinterpret_cast<const d2*>(recb + v * REC);
+        x[v] = double2{p.x, p.y};
+      }
+      int bad = -1;
       {
-        const uint32_t rk0 = passtab[lane >> 3], rk1 = passtab[GRP + (lane >> 3)];
-        const uint32_t wA = *reinterpret_cast<const uint32_t*>(rows + rk0 + 4 * l);
-        mA = *reinterpret_cast<const u4*>(rows + rk0 + 32);
-        wN = *reinterpret_cast<const uint32_t*>(rows + rk1 + 4 * l);
-        mB = *reinterpret_cast<const u4*>(rows + rk1 + 32);
-        rkP = passtab[2 * GRP + (lane >> 3)];
-        paA = *reinterpret_cast<const lds_d2*>(R + (wA & 0xFFFF));
-        pcA = *reinterpret_cast<const lds_d2*>(R + (wA >> 16));
-        pvA = *reinterpret_cast<const lds_d2*>(R + (mA.z | par16));
-      }
-      const uint32_t lpt = OFF_PT + 2 * (lane >> 3);         // this group's slot of a pass
-      for (int sweep = 0; sweep < iters; ++sweep) {
-        uint32_t pt = lpt + 3 * (GRP * 2);
-        for (int q = 0; q < npass; q += 2) {
-          // pass q (set A): loads the positions of pass q + 1 (set B), the metadata of pass q + 2 (into set A)
-          MDQ_SMOOTH_SPEC(paA, pcA, pvA, mA, paB, pcB, pvB, wN, mB, rkP, rkQ, pt)
-          MDQ_SMOOTH_SPEC(paB, pcB, pvB, mB, paA, pcA, pvA, wN, mA, rkQ, rkP, pt + GRP * 2)
-          pt += 2 * (GRP * 2);
+        unsigned long long undecided = 0;   // groups whose update was not clearly a full step (tested once per sweep: a
+                                            // branch behind every test would keep the next loads behind it)
+        // pass 0 in set A, pass 1 in set B, vertex list of pass 2
+        d2 paA, pcA, pvA, paB = {0, 0}, pcB = {0, 0}, pvB = {0, 0};
+        uint32_t wN, rkP, rkQ = 0;     // wN: cell words of the pass whose positions are loaded next
+        u4 mA, mB;
+        {
+          const uint32_t rk0 = passtab[lane >> 3], rk1 = passtab[GRP + (lane >> 3)];
+          const uint32_t wA = *reinterpret_cast<const uint32_t*>(rows + rk0 + 4 * l);
+          mA = *reinterpret_cast<const u4*>(rows + rk0 + 32);
+          wN = *reinterpret_cast<const uint32_t*>(rows + rk1 + 4 * l);
+          mB = *reinterpret_cast<const u4*>(rows + rk1 + 32);
+          rkP = passtab[2 * GRP + (lane >> 3)];
+          paA = *reinterpret_cast<const lds_d2*>(R + (wA & 0xFFFF));
+          pcA = *reinterpret_cast<const lds_d2*>(R + (wA >> 16));
+          pvA = *reinterpret_cast<const lds_d2*>(R + (mA.z | par16));
         }
-        if (undecided) {
-          failed = true;
-          break;
+        if (nbp == 0) {
+          for (int sweep = done; sweep < iters; ++sweep) {
+            uint32_t pt = lpt + 3 * (GRP * 2);
+            for (int q = 0; q < npass; q += 2) {
+              // pass q (set A): loads the positions of pass q + 1 (set B), the metadata of pass q + 2 (into set A)
+              MDQ_SMOOTH_SPEC(paA, pcA, pvA, mA, paB, pcB, pvB, wN, mB, rkP, rkQ, pt)
+              MDQ_SMOOTH_SPEC(paB, pcB, pvB, mB, paA, pcA, pvA, wN, mA, rkQ, rkP, pt + GRP * 2)
+              pt += 2 * (GRP * 2);
+            }
+            if (undecided) {
+              bad = sweep;
+              break;
+            }
+          }
+        } else {
+          // the mesh has vertices of more than 8 cells (the fast path has one lane per cell): the listed pass pairs run
+          // careful (exact path for those vertices), the passes between them speculative as above; both pipelines
+          // are primed again at every switch (~1.5 % of a sweep per listed pair)
+          for (int sweep = done; sweep < iters; ++sweep) {
+            int q0 = 0;
+            for (int k = 0; k <= nbp; ++k) {
+              const int bp = k < nbp ? part[2 + k] : npass;
+              if (bp > q0) {
+                {
+                  const uint32_t rk0 = passtab[q0 * GRP + (lane >> 3)], rk1 = passtab[(q0 + 1) * GRP + (lane >> 3)];
+                  const uint32_t wA = *reinterpret_cast<const uint32_t*>(rows + rk0 + 4 * l);
+                  mA = *reinterpret_cast<const u4*>(rows + rk0 + 32);
+                  wN = *reinterpret_cast<const uint32_t*>(rows + rk1 + 4 * l);
+                  mB = *reinterpret_cast<const u4*>(rows + rk1 + 32);
+                  rkP = passtab[(q0 + 2) * GRP + (lane >> 3)];
+                  paA = *reinterpret_cast<const lds_d2*>(R + (wA & 0xFFFF));
+                  pcA = *reinterpret_cast<const lds_d2*>(R + (wA >> 16));
+                  pvA = *reinterpret_cast<const lds_d2*>(R + (mA.z | par16));
+                }
+                uint32_t pt = lpt + (q0 + 3) * (GRP * 2);
+                for (int q = q0; q < bp; q += 2) {
+                  MDQ_SMOOTH_SPEC(paA, pcA, pvA, mA, paB, pcB, pvB, wN, mB, rkP, rkQ, pt)
+                  MDQ_SMOOTH_SPEC(paB, pcB, pvB, mB, paA, pcA, pvA, wN, mA, rkQ, rkP, pt + GRP * 2)
+                  pt += 2 * (GRP * 2);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              }
+              if (bp < npass) {
+                uint32_t cwA, cwB = 0, crkA = 0, crkB;
+                u4 cmA, cmB = {0, 0, 0, 0};
+                {
+                  const uint32_t rk0 = passtab[bp * GRP + (lane >> 3)];
+                  cwA = *reinterpret_cast<const uint32_t*>(rows + rk0 + 4 * l);
+                  cmA = *reinterpret_cast<const u4*>(rows + rk0 + 32);
+                  crkB = passtab[(bp + 1) * GRP + (lane >> 3)];
+                }
+                const uint32_t pt = lpt + (bp + 2) * (GRP * 2);
+                MDQ_SMOOTH_PASS(cwA, cmA, crkB, cwB, cmB, crkA, pt)
+                MDQ_SMOOTH_PASS(cwB, cmB, crkA, cwA, cmA, crkB, pt + GRP * 2)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              }
+              q0 = bp + 2;
+            }
+            if (undecided) {
+              bad = sweep;
+              break;
+            }
+          }
         }
       }
-    }
-#undef MDQ_SMOOTH_SPEC
-    if (failed) {
-      // ---- careful walk from the original coordinates: decision in front of every store, exact fp64 path where needed
+      if (bad < 0) break;
+      if (lane == 0) atomicAdd(&g_abandoned[bad < 63 ? bad : 62], 1ull);
+      // ---- back to the checkpoint (each lane reads what it wrote itself)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       for (int v = lane; v < nv; v += 64) {
         const double2 xv = x[v];
         *reinterpret_cast<d2*>(recb + v * REC) = d2{xv.x, xv.y};
         *reinterpret_cast<d2*>(recb + v * REC + 16) = d2{xv.y, xv.x};
       }
-      if (lane == 0) {
-        *reinterpret_cast<d2*>(recb + ZREC) = d2{0.0, 0.0};
-        *reinterpret_cast<d2*>(recb + ZREC + 16) = d2{0.0, 0.0};
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      uint32_t wA, wB = 0, rkA = 0, rkB;
-      u4 mA, mB = {0, 0, 0, 0};
-      {
-        const uint32_t rk0 = passtab[lane >> 3];
-        wA = *reinterpret_cast<const uint32_t*>(rows + rk0 + 4 * l);
-        mA = *reinterpret_cast<const u4*>(rows + rk0 + 32);
-        rkB = passtab[GRP + (lane >> 3)];
-      }
-      const uint32_t lpt = OFF_PT + 2 * (lane >> 3);
-      for (int sweep = 0; sweep < iters; ++sweep) {
-        uint32_t pt = lpt + 2 * (GRP * 2);
-        for (int q = 0; q < npass; q += 2) {
-          MDQ_SMOOTH_PASS(wA, mA, rkB, wB, mB, rkA, pt)
-          MDQ_SMOOTH_PASS(wB, mB, rkA, wA, mA, rkB, pt + GRP * 2)
-          pt += 2 * (GRP * 2);
-        }
-      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      ncareful = bad - done + 1 + extra;
+      if (ncareful > iters - done) ncareful = iters - done;
+      extra *= 2;
     }
+#undef MDQ_SMOOTH_SPEC
 #undef MDQ_SMOOTH_PASS
 #undef MDQ_SMOOTH_STAMP
 #undef MDQ_SMOOTH_TRACE_OUT
@@ -639,6 +730,17 @@ extern "C" long long* mdq_smooth_trace_host() {
   return g_trace;
 }
 #endif
+
+extern "C" int mdq_smooth_stats(int64_t* out64, int32_t reset) {
+  if (out64 && hipMemcpyFromSymbol(out64, HIP_SYMBOL(mdq_smoothing::g_abandoned), 64 * sizeof(int64_t)) != hipSuccess)
+    return mdq_set_error("mdq_smooth_stats: copy failed");
+  if (reset) {
+    const int64_t zero[64] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mdq_smoothing::g_abandoned), zero, sizeof(zero)) != hipSuccess)
+      return mdq_set_error("mdq_smooth_stats: reset failed");
+  }
+  return 0;
+}
 
 extern "C" int mdq_smooth(int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t* cells, const int32_t* nv,
                           const int32_t* nt, const int32_t* iterations, void* stream) {

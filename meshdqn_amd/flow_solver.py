@@ -96,8 +96,13 @@ class FlowSolver(object):
         self.viscosity, self.density = self.mu, self.rho
         self.DEPLOY = False
         self.device = torch.device(device)
-        if flow_params.get("inflow", "constant") != "constant":
-            raise NotImplementedError("only the reference's 'constant' (time independent parabolic) inflow is supported")
+        # flow_solver.py:70-73: 'constant' = the time independent parabola, anything else = the caller's own profile.  The
+        # reference takes a dolfin Expression with a `time` attribute; here: a callable profile(x, y, t) -> x-velocity
+        # at the inlet dof coordinates (every boundary condition of the reference has zero y-velocity)
+        inflow = flow_params.get("inflow", "constant")
+        if inflow != "constant" and not callable(inflow):
+            raise TypeError("flow_params['inflow'] must be 'constant' or a callable profile(x, y, t) -> x-velocity")
+        self.inflow_profile = None if inflow == "constant" else inflow
         coords, cells = load_mesh(geometry_params["mesh"])
         self.mesh = Mesh(coords, cells)
         self.smooth = solver_params.get("smooth", False)
@@ -186,10 +191,21 @@ class FlowSolver(object):
         `nsteps > 1` runs several steps in one kernel launch and returns the last values."""
         if self.batch is None:
             raise RuntimeError("operators are only (re-)assembled in DEPLOY mode after remesh (flow_solver.py:268)")
-        drag, lift = self.batch.evolve(nsteps)
-        self.gtime += self.dt_value * nsteps
-        d = drag[0].tolist()
-        l = lift[0].tolist()
+        if self.inflow_profile is None:
+            drag, lift = self.batch.evolve(nsteps)
+            self.gtime += self.dt_value * nsteps
+            d = drag[0].tolist()
+            l = lift[0].tolist()
+        else:
+            # time dependent inflow (flow_solver.py:366-371): the clock advances, the profile is evaluated at the new
+            # time, then the step runs with those boundary values - one launch per step
+            d, l = [], []
+            for _ in range(nsteps):
+                self.gtime += self.dt_value
+                self.batch.update_inflow(self.inflow_profile, self.gtime)
+                dr, li = self.batch.evolve(1)
+                d.append(dr[0, 0].item())
+                l.append(li[0, 0].item())
         self.accumulated_drag.extend(d)
         self.accumulated_lift.extend(l)
         return self.u_, self.p_, d[-1], l[-1]

@@ -247,6 +247,23 @@ class IpcsBatch:
         if self.pressure_direct:
             self._factorize_pressure()
 
+    def update_inflow(self, profile, time: float, stream=None):
+        """Time dependent inflow (flow_solver.py:70-73,369-371: `inflow.time = gtime` before the three assemblies apply
+        the boundary conditions): new Dirichlet values profile(x, y, t) at the inlet dofs of every environment, then the
+        vectors that depend on them (the lifting vectors A1[:, bc] g and M[:, bc] g) rebuilt on the device by
+        `mdq_ipcs_setup_matfree` (which leaves the operators' other data as they are: same mesh)."""
+        if not hasattr(self, "_inlet"):
+            self._inlet = []
+            for t_, p_ in zip(self.topos, self.per):
+                d = t_.boundary_conditions(p_["coords"])["inlet_dofs"]
+                self._inlet.append((d, t_.dof_coords(p_["coords"])[d]))
+            self._gx_host = self.t["bcu_gx"].cpu().numpy().copy()
+        for b, (d, xy) in enumerate(self._inlet):
+            self._gx_host[b, d] = np.asarray(profile(xy[:, 0], xy[:, 1], float(time)), dtype=np.float64)
+        self.t["bcu_gx"].copy_(torch.from_numpy(self._gx_host), non_blocking=True)
+        rc = self.lib.mdq_ipcs_setup_matfree(C.byref(self.desc), _lib.stream_ptr(stream))
+        _lib.check(rc, "mdq_ipcs_setup_matfree")
+
     def _factorize_pressure(self):
         """Host factorisation of every environment's (scaled, BC-eliminated) pressure matrix
         (`LUSolver('mumps')` of A2, flow_solver.py:150-159) -> substructuring factors on the device."""

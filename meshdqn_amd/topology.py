@@ -147,12 +147,16 @@ class MeshTopology:
         x = self.coords if coords is None else coords
         return np.concatenate([x, 0.5 * (x[self.edges[:, 0]] + x[self.edges[:, 1]])])
 
-    def boundary_conditions(self, coords=None):
+    def boundary_conditions(self, coords=None, inflow=None, time=0.0):
         """Dirichlet data of `flow_solver.py:123-132`.
 
         Returns dict with
           bcu_flag (np2,) uint8, bcu_gx (np2,) f8 (x-velocity value; y value is 0
-          for every BC of the reference), bcp_flag (nv,) uint8.
+          for every BC of the reference), bcp_flag (nv,) uint8, inlet_dofs (scalar P2 dofs whose value is the inflow
+          profile's: the inlet dofs the airfoil / wall conditions do not override).
+        `inflow`: None = the reference's time independent parabola (`constant_profile`, flow_solver.py:33-44), or a
+        callable profile(x, y, t) -> x-velocity at the dof coordinates (the reference's time dependent expression,
+        flow_solver.py:70-73,369-371).
         """
         x = self.coords if coords is None else coords
         tags = self.facet_tags(x)
@@ -165,19 +169,25 @@ class MeshTopology:
         H = top - bot
         Um = 1.5
         # list order [inlet, airfoil, walls]: later wins on shared dofs
+        inlet = np.zeros(self.np2, dtype=bool)
         for want in (TAG_INFLOW, TAG_AIRFOIL, TAG_WALL):
             es = be[tags == want]
             d = np.concatenate([self.edges[es, 0], self.edges[es, 1], nv + es])
             flag[d] = 1
             if want == TAG_INFLOW:
                 y = dofx[d, 1]
-                gx[d] = -4.0 * Um * (y - bot) * (y - top) / H / H
+                if inflow is None:
+                    gx[d] = -4.0 * Um * (y - bot) * (y - top) / H / H
+                else:
+                    gx[d] = np.asarray(inflow(dofx[d, 0], y, float(time)), dtype=np.float64)
+                inlet[d] = True
             else:
                 gx[d] = 0.0
+                inlet[d] = False
         pflag = np.zeros(nv, dtype=np.uint8)
         es = be[tags == TAG_OUTFLOW]
         pflag[self.edges[es].ravel()] = 1
-        return dict(bcu_flag=flag, bcu_gx=gx, bcp_flag=pflag, tags=tags)
+        return dict(bcu_flag=flag, bcu_gx=gx, bcp_flag=pflag, tags=tags, inlet_dofs=np.flatnonzero(inlet))
 
     # ------------------------------------------------------------------
     def facets(self, tags, want):

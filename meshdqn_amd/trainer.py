@@ -158,6 +158,107 @@ def unpack_transitions(rec: torch.Tensor, n_nodes: int, n_feat: int, e_max: int)
     return out
 
 
+def pack_transitions_device(st_prev: dict, st_next: dict, actions, rewards, dones, e_max: int) -> torch.Tensor:
+    """The records of `pack_transitions` for the B transitions of one batched env step, built ON THE DEVICE from the two
+    batched state dicts of `VecEnv2DAirfoil.get_state()` (x (B,N,F) f32, padded edge lists (B,e_max) i32 + `nedges`):
+    a handful of vectorised torch ops, no per-field host copies.  actions / rewards / dones: (B,) arrays or tensors."""
+    x0, x1 = st_prev["x"], st_next["x"]
+    dev, B = x0.device, x0.shape[0]
+
+    def dv(a, dt):
+        return a.to(dev, dt) if torch.is_tensor(a) else torch.as_tensor(np.asarray(a), dtype=dt, device=dev)
+
+    done = dv(dones, torch.float32).reshape(B, 1)
+    cols = torch.arange(e_max, device=dev)[None, :]
+
+    def edges(st):
+        if st["edge_src_pad"].shape[1] != e_max:
+            raise ValueError(f"padded edge lists have {st['edge_src_pad'].shape[1]} slots, e_max is {e_max}")
+        cnt = dv(st["nedges"], torch.int64).reshape(B, 1)
+        live = cols < cnt
+        return (torch.where(live, st["edge_src_pad"], 0).float(), torch.where(live, st["edge_dst_pad"], 0).float(), cnt.float())
+    s0, d0, c0 = edges(st_prev)
+    s1, d1, c1 = edges(st_next)
+    keep = 1.0 - done                                   # terminal: no next state (zeros, like the host packing)
+    return torch.cat([x0.reshape(B, -1).float(), x1.reshape(B, -1).float() * keep, s0, d0, s1 * keep, d1 * keep, c0, c1 * keep,
+                      dv(actions, torch.float32).reshape(B, 1), dv(rewards, torch.float32).reshape(B, 1), done], dim=1)
+
+
+class SharedDeviceReplay:
+    """Replay ring of fixed-size transition RECORDS on the device (layout of `pack_transitions`): what the ranks
+    exchange when the replay is shared (all-gather of transition records; 1024 envs -> 35 MB per step over
+    xGMI).  `push_records` takes the (world * B, record) tensor of an all-gather as it is; `sample` returns the same
+    `DeviceBatch` interface as `DeviceReplay` (minibatch arrays gathered by a few torch ops, nothing read back)."""
+
+    def __init__(self, capacity: int, N: int, F: int, e_max: int, device):
+        self.capacity, self.N, self.F, self.e_max, self.device = int(capacity), int(N), int(F), int(e_max), device
+        self.rec_len = 2 * N * F + 4 * e_max + 5
+        self.R = torch.zeros((self.capacity, self.rec_len), dtype=torch.float32, device=device)
+        self.position, self.count = 0, 0
+        self._cols = torch.arange(e_max, device=device)[None, :]
+
+    def push_records(self, rec: torch.Tensor):
+        m = rec.shape[0]
+        if rec.shape[1] != self.rec_len:
+            raise ValueError(f"record length {rec.shape[1]}, expected {self.rec_len}")
+        pos = (self.position + torch.arange(m, device=self.device)) % self.capacity
+        self.R.index_copy_(0, pos, rec.to(self.device))
+        self.position = int((self.position + m) % self.capacity)
+        self.count = min(self.count + m, self.capacity)
+
+    def size(self):
+        return self.count
+
+    __len__ = size
+
+    def _graphs(self, rows: torch.Tensor, k: int) -> dict:
+        """Minibatch arrays (keys of `DeviceReplay.gather`) of graph k (0: state, 1: next state) of the record rows."""
+        N, F, EM, n = self.N, self.F, self.e_max, rows.shape[0]
+        nf = N * F
+        x = rows[:, k * nf:(k + 1) * nf].reshape(n, N, F)
+        base = 2 * nf + k * 2 * EM
+        sp, dp = rows[:, base:base + EM].to(torch.int32), rows[:, base + EM:base + 2 * EM].to(torch.int32)
+        cnt = rows[:, 2 * nf + 4 * EM + k].to(torch.int64)
+        live = self._cols < cnt[:, None]
+        edge_ptr = torch.zeros(n + 1, dtype=torch.int64, device=rows.device)
+        edge_ptr[1:] = torch.cumsum(cnt, 0)
+        # packed edge lists without a host synchronisation: dead slots are scattered into one dump slot behind the end
+        posn = torch.where(live, edge_ptr[:-1, None] + self._cols, n * EM)
+        esrc = torch.zeros(n * EM + 1, dtype=torch.int32, device=rows.device).scatter_(0, posn.reshape(-1), sp.reshape(-1))
+        edst = torch.zeros(n * EM + 1, dtype=torch.int32, device=rows.device).scatter_(0, posn.reshape(-1), dp.reshape(-1))
+        return dict(x=x, n=N, cnt=None, esrc=esrc[:-1], edst=edst[:-1], edge_ptr=edge_ptr.to(torch.int32),
+                    node_ptr=torch.arange(n + 1, dtype=torch.int32, device=rows.device) * N,
+                    src=torch.where(live, sp, 0).long(), dst=torch.where(live, dp, 0).long(), mask=live.float())
+
+    def sample(self, batch_size: int) -> "DeviceBatch":
+        idx = torch.from_numpy(np.asarray(random.sample(range(self.count), batch_size), np.int64)).to(self.device)
+        rows = self.R.index_select(0, idx)
+        nf, E = self.N * self.F, self.e_max
+        off = 2 * nf + 4 * E
+        done = (rows[:, off + 4] > 0.5)[:, None]
+        # terminal transitions: the own state as a masked placeholder for the missing next state (as `DeviceBatch` does)
+        nxt = rows.clone()
+        nxt[:, nf:2 * nf] = torch.where(done, rows[:, :nf], rows[:, nf:2 * nf])
+        nxt[:, 2 * nf + 2 * E:off] = torch.where(done, rows[:, 2 * nf:2 * nf + 2 * E], rows[:, 2 * nf + 2 * E:off])
+        nxt[:, off + 1] = torch.where(done[:, 0], rows[:, off], rows[:, off + 1])
+        return DeviceBatch.from_arrays(self, self._graphs(rows, 0), self._graphs(nxt, 1), nonfinal=(~done[:, 0]).float(),
+                                       reward=rows[:, off + 3].contiguous(), action=rows[:, off + 2].to(torch.int64).reshape(-1, 1))
+
+
+def allgather_records(ctx: DistContext, rec: torch.Tensor) -> torch.Tensor:
+    """One all-gather of the (B, record) tensors of all ranks -> (world * B, record), rank order (RCCL: one call)."""
+    if ctx.world == 1:
+        return rec
+    out = torch.empty((ctx.world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
+    try:
+        dist.all_gather_into_tensor(out, rec.contiguous())
+    except (RuntimeError, NotImplementedError):      # backends without the flat form (older gloo)
+        bufs = [torch.empty_like(rec) for _ in range(ctx.world)]
+        dist.all_gather(bufs, rec.contiguous())
+        out = torch.cat(bufs)
+    return out
+
+
 def allgather_transitions(ctx: DistContext, trs: List[Transition], n_nodes: int, n_feat: int, e_max: int):
     """All ranks contribute the same number of transitions per call (one per environment step)."""
     rec = pack_transitions(trs, n_nodes, n_feat, e_max).to(ctx.device)
@@ -615,11 +716,31 @@ class DeviceBatch:
         self.ga = replay.gather(s_slots)
         self.gb = replay.gather(np.where(n_slots >= 0, n_slots, s_slots))   # terminal: own state as a masked placeholder
 
+    @classmethod
+    def from_arrays(cls, replay, ga, gb, nonfinal, reward, action):
+        """A minibatch whose arrays are already gathered (`SharedDeviceReplay.sample`)."""
+        self = cls.__new__(cls)
+        self.replay, self.s_slots, self.n_slots = replay, None, None
+        self.n = int(reward.shape[0])
+        self.nonfinal, self.reward, self.action, self.ga, self.gb = nonfinal, reward, action, ga, gb
+        return self
+
     def __len__(self):
         return self.n
 
     def to_transitions(self) -> List[Transition]:
         """The same minibatch as `Transition`s of `Data` graphs (eager fallback, tests)."""
+        if self.s_slots is None:       # gathered arrays: rebuild the graphs from them
+            out = []
+            ep0, ep1 = self.ga["edge_ptr"].cpu().numpy(), self.gb["edge_ptr"].cpu().numpy()
+            nf = self.nonfinal.cpu().numpy()
+            for i in range(self.n):
+                def graph(g, ep):
+                    return Data(x=g["x"][i].clone(), edge_index=torch.stack([g["esrc"][ep[i]:ep[i + 1]].long(),
+                                                                              g["edst"][ep[i]:ep[i + 1]].long()]))
+                out.append(Transition(graph(self.ga, ep0), self.action[i].reshape(1, 1).cpu(),
+                                      graph(self.gb, ep1) if nf[i] > 0.5 else None, self.reward[i].reshape(1).cpu()))
+            return out
         rp = self.replay
         act, rew = self.action.cpu(), self.reward.cpu()
         return [Transition(rp.data(int(self.s_slots[i])), act[i].reshape(1, 1),
@@ -741,11 +862,23 @@ def train_loop_vec(trainer: DQNTrainer, venv, num_steps: int, optim_per_step: in
     # GPU-resident replay (states stored once per batched step, minibatches gathered on the device) whenever the
     # environment hands out its padded edge lists; the per-transition list of lazy references otherwise (and when the
     # ranks exchange transitions)
-    rep_dev = None
-    if device_replay and not (share_replay and ctx.world > 1) and trainer.graphs and trainer.dense and \
-            DeviceReplay.eligible(st, trainer.e_max):
+    rep_dev = rep_sh = None
+    dev_ok = device_replay and trainer.graphs and trainer.dense and DeviceReplay.eligible(st, trainer.e_max)
+    if dev_ok and share_replay and ctx.world > 1:
+        # shared replay: every rank keeps ALL transitions as fixed-size records on its device; per batched step ONE
+        # all-gather of the (B, record) tensor packed on the device
+        rep_sh = trainer.device_memory
+        if not isinstance(rep_sh, SharedDeviceReplay):
+            rep_sh = trainer.device_memory = SharedDeviceReplay(trainer.replay_capacity, N, st["x"].shape[2], trainer.e_max,
+                                                                ctx.device)
+
+        def snapshot(st_):     # (the padded edge lists are views of buffers the next env step rewrites)
+            return dict(x=st_["x"], edge_src_pad=st_["edge_src_pad"].clone(), edge_dst_pad=st_["edge_dst_pad"].clone(),
+                        nedges=np.array(st_["nedges"]))
+        prev_pack = snapshot(st)
+    elif dev_ok:
         rep_dev = trainer.device_memory
-        if rep_dev is None or (rep_dev.B, rep_dev.N, rep_dev.F) != (B, N, st["x"].shape[2]):
+        if not isinstance(rep_dev, DeviceReplay) or (rep_dev.B, rep_dev.N, rep_dev.F) != (B, N, st["x"].shape[2]):
             rep_dev = trainer.device_memory = DeviceReplay(trainer.replay_capacity, B, N, st["x"].shape[2], trainer.e_max,
                                                            ctx.device)
         base_prev = rep_dev.store(st)
@@ -788,6 +921,11 @@ def train_loop_vec(trainer: DQNTrainer, venv, num_steps: int, optim_per_step: in
             base_next = rep_dev.store(st)
             rep_dev.push(base_prev, base_next, actions, rew, done)
             base_prev = base_next
+        elif rep_sh is not None:
+            st, rew, done, _ = venv.step(actions)
+            rec = pack_transitions_device(prev_pack, st, actions, rew, done, trainer.e_max)
+            rep_sh.push_records(allgather_records(ctx, rec))
+            prev_pack = snapshot(st)
         else:
             prev = state_refs(st)
             st, rew, done, _ = venv.step(actions)

@@ -652,7 +652,14 @@ class VecEnv2DAirfoil:
             remesh_batch_gpu(dt.coords, dt.cells, dt.nv, dt.nt, rem, self._rstat)
             _lib.check(lib.mdq_env_smooth_iters(B, rem.data_ptr(), self._rstat.data_ptr(), 50, its.data_ptr(), sp()),
                        "mdq_env_smooth_iters")
+            tm = getattr(self, "smooth_events", None)     # (bench: HIP events around the launch, on this stream)
+            if tm is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             smooth_batch_gpu(dt.coords, dt.cells, dt.nv, dt.nt, its)
+            if tm is not None:
+                e1.record()
+                tm.append((e0, e1))
             self._refresh_launch(readback=False)
             nv_all[k].copy_(dt.nv)
             _lib.check(lib.mdq_env_result(B, N, S, self._dev_drag.data_ptr(), self._gt_drag_dev.data_ptr(), dt.nv.data_ptr(),

@@ -211,7 +211,7 @@ class TaylorHood:
         tags = m.facet_tags()
         self.tags = tags
         # velocity: bcu = [inlet(tag 2), airfoil, walls] - later wins
-        val = {}
+        val, src = {}, {}
         for want, fn in ((2, "inlet"), (1, "zero"), (0, "zero")):
             for e, t in tags.items():
                 if t != want:
@@ -221,8 +221,12 @@ class TaylorHood:
                         val[int(d)] = float(self.inflow_profile(self.dof_coords[d:d + 1])[0])
                     else:
                         val[int(d)] = 0.0
+                    src[int(d)] = fn
         sd = np.array(sorted(val), dtype=np.int64)
         self.bcu_scalar_dofs = sd
+        # positions (in bcu_vals) and dof ids of the dofs that carry the inflow profile (flow_solver.py:369-371)
+        self.inlet_pos = np.array([i for i, d in enumerate(sd) if src[int(d)] == "inlet"], dtype=np.int64)
+        self.inlet_dofs = sd[self.inlet_pos]
         self.bcu_dofs = np.concatenate([sd, n2 + sd])
         gx = np.array([val[int(d)] for d in sd])
         # inlet gives ux = parabola, uy = 0 ; airfoil / walls give zero for both

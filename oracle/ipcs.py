@@ -16,7 +16,10 @@ from .mesh import OracleMesh
 
 class OracleFlowSolver:
     def __init__(self, coords, cells, mu=1e-3, rho=1.0, dt=1e-3, smooth=True, smooth_iters=50,
-                 factorize=True):
+                 factorize=True, inflow=None):
+        # inflow: None = the reference's constant parabola; callable profile(x, y, t) -> x-velocity = a time dependent
+        # inflow expression (flow_solver.py:70-73; `inflow.time = gtime` at the top of evolve, :369-371)
+        self.inflow = inflow
         self.mesh = OracleMesh(coords, cells)
         if smooth:
             self.mesh.smooth(smooth_iters)
@@ -57,6 +60,14 @@ class OracleFlowSolver:
 
     def evolve(self):
         self.gtime += self.dt
+        if self.inflow is not None:
+            th = self.th
+            xy = th.dof_coords[th.inlet_dofs]
+            th.bcu_vals[th.inlet_pos] = self.inflow(xy[:, 0], xy[:, 1], self.gtime)
+            g = np.zeros(th.A1_full.shape[0])
+            g[th.bcu_dofs] = th.bcu_vals
+            self.lift1 = th.A1_full @ g       # the lifting of the symmetric elimination follows the boundary values
+            self.lift3 = th.Mv @ g
         u_s = self.lu1.solve(self.rhs1(self.u_n, self.p_n))
         p_new = self.lu2.solve(self.rhs2(u_s, self.p_n))
         u_new = self.lu3.solve(self.rhs3(u_s, p_new, self.p_n))

@@ -285,3 +285,37 @@ def test_resolution_sweep_lands_in_the_reference_convergence_band(meshes, lib_bu
           f"lift {fine[:, 2].min():.7f}..{fine[:, 2].max():.7f}")
     assert abs(d - fine[0, 1]) < 1e-2 * abs(fine[0, 1])
     assert -0.0504 < l < -0.0445
+
+
+def test_time_dependent_inflow_matches_oracle(lib_built):
+    """flow_solver.py:70-73,369-371: an inflow profile that depends on time (the reference passes a dolfin Expression
+    whose `time` attribute evolve() sets; here a callable profile(x, y, t)).  A ramped, pulsating parabola through the
+    FlowSolver surface against the oracle's sparse-LU path with the same boundary values."""
+    import numpy as np
+    from meshdqn_amd.flow_solver import FlowSolver
+    from oracle.ipcs import OracleFlowSolver
+    mesh = os.path.join(GOLDEN, "ys930.npz")
+    z = np.load(mesh)
+
+    def profile(x, y, t):
+        return -4.0 * 1.5 * (y + 0.5) * (y - 0.5) * (0.5 + 100.0 * t + 0.2 * np.sin(2000.0 * t))
+
+    fs = FlowSolver(flow_params={"mu": 1e-3, "rho": 1.0, "inflow": profile}, geometry_params={"mesh": mesh},
+                    solver_params={"dt": 0.001, "smooth": True, "rtol": 1e-12})
+    o = OracleFlowSolver(z["coords"], z["cells"], inflow=profile)
+    for k in range(4):
+        u, p, drag, lift = fs.evolve()
+        uo, po, do, lo = o.evolve()
+        assert abs(drag - do) < 1e-8 * abs(do) and abs(lift - lo) < 1e-8 * abs(lo), k
+    n2 = o.th.np2
+    ug = u.vector().get_local().reshape(n2, 2)
+    assert np.abs(np.concatenate([ug[:, 0], ug[:, 1]]) - uo).max() < 1e-8 * np.abs(uo).max()
+    assert abs(fs.gtime - 0.004) < 1e-15
+    # two steps in one call = two single calls
+    fs2 = FlowSolver(flow_params={"mu": 1e-3, "rho": 1.0, "inflow": profile}, geometry_params={"mesh": mesh},
+                     solver_params={"dt": 0.001, "smooth": True, "rtol": 1e-12})
+    fs2.evolve(4)
+    assert abs(fs2.accumulated_drag[-1] - drag) < 1e-9 * abs(drag)
+    with pytest.raises(TypeError):
+        FlowSolver(flow_params={"mu": 1e-3, "rho": 1.0, "inflow": "ramp"}, geometry_params={"mesh": mesh},
+                   solver_params={"dt": 0.001, "smooth": False})

@@ -193,3 +193,116 @@ def test_device_replay_ring_on_cpu_tensors():
     assert int(g["edge_ptr"][-1]) == off and g["node_ptr"].tolist() == [0, N, 2 * N, 3 * N]
     d = rep.data(int(slots[0]))
     assert d.x.shape == (N, F) and d.edge_index.shape == (2, int(states[5]["nedges"][2]))
+
+
+def _batched_state(rng, B=4, N=180, F=17, EM=512):
+    cnt = rng.integers(50, EM, size=B).astype(np.int32)
+    return dict(x=torch.from_numpy(rng.standard_normal((B, N, F))).float(),
+                edge_src_pad=torch.from_numpy(rng.integers(0, N, size=(B, EM)).astype(np.int32)),
+                edge_dst_pad=torch.from_numpy(rng.integers(0, N, size=(B, EM)).astype(np.int32)), nedges=cnt)
+
+
+def _state_data(st, b):
+    c = int(st["nedges"][b])
+    return Data(x=st["x"][b].clone(), edge_index=torch.stack([st["edge_src_pad"][b, :c].long(), st["edge_dst_pad"][b, :c].long()]),
+                edge_attr=[])
+
+
+def test_device_packing_equals_host_packing_and_feeds_the_shared_replay():
+    """`pack_transitions_device` (vectorised, no per-field host copies) writes exactly the records of `pack_transitions`;
+    `SharedDeviceReplay` gives the same minibatch arrays as the transitions they were packed from."""
+    from meshdqn_amd.trainer import SharedDeviceReplay, pack_transitions_device
+    rng = np.random.default_rng(5)
+    B, N, F, EM = 4, 180, 17, 512
+    st0, st1 = _batched_state(rng), _batched_state(rng)
+    acts = rng.integers(0, 181, size=B)
+    rews = rng.standard_normal(B).astype(np.float32)
+    dones = np.array([False, True, False, False])
+    rec = pack_transitions_device(st0, st1, acts, rews, dones, EM)
+    trs = [Transition(_state_data(st0, b), torch.tensor([[int(acts[b])]]), None if dones[b] else _state_data(st1, b),
+                      torch.tensor([float(rews[b])])) for b in range(B)]
+    assert torch.equal(rec, pack_transitions(trs, N, F, EM))
+    rep = SharedDeviceReplay(16, N, F, EM, torch.device("cpu"))
+    rep.push_records(rec)
+    rep.push_records(rec)
+    assert rep.size() == 8
+    import random
+    random.seed(0)
+    mb = rep.sample(8)
+    back = mb.to_transitions()
+    for t in back:
+        # every sampled transition is one of the four originals
+        match = [o for o in trs if torch.equal(o.state.x, t.state.x)]
+        assert len(match) == 1
+        o = match[0]
+        assert torch.equal(o.state.edge_index, t.state.edge_index) and int(o.action) == int(t.action)
+        assert (o.next_state is None) == (t.next_state is None)
+        if o.next_state is not None:
+            assert torch.equal(o.next_state.x, t.next_state.x) and torch.equal(o.next_state.edge_index, t.next_state.edge_index)
+    # ring wrap-around keeps the newest records
+    for _ in range(3):
+        rep.push_records(rec)
+    assert rep.size() == 16 and rep.position == (5 * B) % 16
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from meshdqn_amd.trainer import SharedDeviceReplay, allgather_records, pack_transitions_device
+    ctx = DistContext(backend="gloo", device=torch.device("cpu"))
+    rng = np.random.default_rng(100 + rank)
+    st0, st1 = _batched_state(rng), _batched_state(rng)
+    rec = pack_transitions_device(st0, st1, np.full(4, rank), np.full(4, 0.5 * rank, np.float32), np.zeros(4, bool), 512)
+    allrec = allgather_records(ctx, rec)
+    rep = SharedDeviceReplay(32, 180, 17, 512, torch.device("cpu"))
+    rep.push_records(allrec)
+    q.put((rank, tuple(allrec.shape), float(allrec[:, -3].sum()), float(allrec.sum()), rep.size()))
+    ctx.barrier()
+    ctx.close()
+
+
+def test_two_rank_record_allgather():
+    world, port = 2, _free_port()
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    procs = [ctxm.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # both ranks hold the same 8 records (4 of each rank, rank order); the action column sums to 4 * 0 + 4 * 1
+    assert res[0][1] == res[1][1] == (8, 2 * 180 * 17 + 4 * 512 + 5)
+    assert res[0][2] == res[1][2] == 4.0 and res[0][3] == res[1][3] and res[0][4] == res[1][4] == 8
+
+
+def test_per_worker_loop_with_several_ranks_needs_a_common_step_count():
+    from meshdqn_amd.trainer import train_loop_per_worker
+    tr = DQNTrainer(180, 17, ctx=DistContext(device=torch.device("cpu")))
+    tr.ctx.world = 2            # (no process group needed: the check comes first)
+    with pytest.raises(ValueError, match="max_steps"):
+        train_loop_per_worker(tr, lambda: None, num_episodes=3)
+
+
+def test_trainer_save_load_roundtrip(tmp_path):
+    """RESTART (airfoil_dqn.py:163-179): both networks, optimiser / scheduler state, gradient count, toggle and the
+    caller's extras come back; reference-style checkpoints (two .pt files only) load too."""
+    tr = DQNTrainer(180, 17, ctx=DistContext(device=torch.device("cpu")), lr=1e-3, target_update=2)
+    for i in range(3):
+        tr.optimize(_transitions(i, 4))
+    tr.save(str(tmp_path), "restart_", extra=dict(steps_done=np.arange(5)))
+    tr2 = DQNTrainer(180, 17, ctx=DistContext(device=torch.device("cpu")), lr=1e-3, target_update=2, seed=99)
+    extra = tr2.load(str(tmp_path), "restart_")
+    assert extra["steps_done"].tolist() == [0, 1, 2, 3, 4] and tr2.num_grads == 3 and tr2.select == tr.select
+    for a, b in zip(tr.policy_net_1.state_dict().values(), tr2.policy_net_1.state_dict().values()):
+        assert torch.equal(a, b)
+    # the next optimiser step is identical on both (Adam moments restored)
+    l1, l2 = tr.optimize(_transitions(7, 4)), tr2.optimize(_transitions(7, 4))
+    assert abs(l1 - l2) < 1e-7
+    for a, b in zip(tr.policy_net_2.parameters(), tr2.policy_net_2.parameters()):
+        assert torch.allclose(a, b, atol=1e-7)
+    os.remove(os.path.join(str(tmp_path), "restart_trainer_state.pt"))
+    tr3 = DQNTrainer(180, 17, ctx=DistContext(device=torch.device("cpu")))
+    assert tr3.load(str(tmp_path), "restart_", scheduler_steps=10) == {} and tr3.scheds[0].last_epoch == 10

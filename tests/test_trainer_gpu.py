@@ -213,3 +213,92 @@ def test_graphed_optimiser_step_matches_the_oracle_learning_step(lib_built, sele
             assert p.grad is None, k
         else:
             assert float((p.grad.cpu() - g).abs().max()) < 1e-4 * scale, k
+
+
+def test_shared_device_replay_minibatch_equals_its_transitions(lib_built):
+    """A minibatch sampled from the record ring of the shared replay (what the ranks all-gather) through the HIP-graph
+    optimiser step vs the same transitions as `Data` objects on the eager path: same loss, same gradient."""
+    import random
+    from meshdqn_amd.trainer import DistContext, DQNTrainer, SharedDeviceReplay, pack_transitions_device
+    rng = np.random.default_rng(31)
+    B, N, F, EM = 8, 180, 17, 1536
+    dev = torch.device("cuda")
+
+    def state():
+        return dict(x=torch.from_numpy(rng.standard_normal((B, N, F))).float().to(dev),
+                    edge_src_pad=torch.from_numpy(rng.integers(0, N, size=(B, EM)).astype(np.int32)).to(dev),
+                    edge_dst_pad=torch.from_numpy(rng.integers(0, N, size=(B, EM)).astype(np.int32)).to(dev),
+                    nedges=rng.integers(150, 500, size=B).astype(np.int32))
+    rep = SharedDeviceReplay(64, N, F, EM, dev)
+    for _ in range(3):
+        rep.push_records(pack_transitions_device(state(), state(), rng.integers(0, 181, size=B), rng.standard_normal(B),
+                                                 rng.random(B) < 0.3, EM))
+    for sel in (True, False):
+        res = []
+        random.seed(4)
+        mb = rep.sample(8)
+        for trs in (mb, mb.to_transitions()):
+            tr = DQNTrainer(n_actions=180, num_inputs=17, ctx=DistContext(), batch_size=8, lr=0.0)
+            tr.graphs = trs is mb
+            tr.num_grads, tr.select = 1, sel
+            loss = tr.optimize(trs)
+            assert trs is not mb or (0 if sel else 1) in tr._graphs, tr._graph_error
+            net = tr.policy_net_1 if sel else tr.policy_net_2
+            res.append((loss, [None if p.grad is None else p.grad.clone() for p in net.parameters()]))
+        assert abs(res[0][0] - res[1][0]) < 1e-6
+        for a, b_ in zip(res[0][1], res[1][1]):
+            assert (a is None) == (b_ is None)
+            assert a is None or torch.allclose(a, b_, rtol=1e-3, atol=1e-7)
+
+
+def _rccl_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import numpy as np
+    import torch
+    from meshdqn_amd.data import Data
+    from meshdqn_amd.trainer import (DistContext, DQNTrainer, Transition, allgather_records, pack_transitions_device)
+    ctx = DistContext(backend="nccl", device=torch.device("cuda", rank))
+    tr = DQNTrainer(180, 17, ctx=ctx, lr=1e-3, target_update=2, batch_size=8)
+    rng = np.random.default_rng(50 + rank)
+
+    def graph():
+        e = int(rng.integers(200, 500))
+        return Data(x=torch.from_numpy(rng.standard_normal((180, 17))).float(),
+                    edge_index=torch.from_numpy(rng.integers(0, 180, size=(2, e))).long())
+    losses = []
+    for step in range(3):
+        trs = [Transition(graph(), torch.tensor([[int(rng.integers(0, 181))]]), None if i % 4 == 3 else graph(),
+                          torch.tensor([float(rng.standard_normal())])) for i in range(8)]
+        losses.append(tr.optimize(trs))
+    w1 = torch.cat([p.detach().reshape(-1) for p in tr.policy_net_1.parameters()]).cpu().numpy()
+    w2 = torch.cat([p.detach().reshape(-1) for p in tr.policy_net_2.parameters()]).cpu().numpy()
+    rec = torch.full((4, 7), float(rank), device=ctx.device)
+    allrec = allgather_records(ctx, rec).cpu().numpy()
+    q.put((rank, w1, w2, losses, allrec))
+    ctx.barrier()
+    ctx.close()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
+def test_two_gpu_rccl_gradient_allreduce_and_record_allgather(lib_built):
+    """The first multi-GPU lease exercises RCCL itself: two ranks on two GPUs take three optimiser steps on different
+    data (HIP-graph path, one flat all-reduce each) and must end with identical replicas; one all-gather of records."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    procs = [ctxm.Process(target=_rccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    assert res[0][3] != res[1][3]
+    assert np.array_equal(res[0][4], res[1][4]) and res[0][4][:4].max() == 0.0 and res[0][4][4:].min() == 1.0

@@ -33,3 +33,30 @@ for name in ("ys930", "ah93w145"):
         st = remesh_batch(coords, cells, nv, nt, np.array([int(rng.choice(cand))], np.int32), 50)
         assert st[0] == 0
     write(name + "_r20", coords[0, :nv[0]], cells[0, :nt[0]])
+
+# meshes as the smoothing kernel meets them inside an env step: smoothed, then ONE more vertex removed and not yet
+# smoothed (the cavity's neighbours usually take a limited first step: the careful-sweeps-first path of the kernel)
+z = np.load(os.path.join(ROOT, "tests", "golden", "ys930.npz"))
+rng = np.random.default_rng(5)
+coords = z["coords"][None].copy()
+cells = np.sort(z["cells"], axis=1).astype(np.int32)[None].copy()
+nv = np.array([coords.shape[1]], np.int32)
+nt = np.array([cells.shape[1]], np.int32)
+remesh_batch(coords, cells, nv, nt, np.array([-1], np.int32), 50)
+for k in range(6):
+    onb = OracleMesh(coords[0, :nv[0]], cells[0, :nt[0]]).on_boundary
+    cand = np.nonzero(~onb)[0]
+    assert remesh_batch(coords, cells, nv, nt, np.array([int(rng.choice(cand))], np.int32), 0)[0] == 0
+    write("ys930_rm%d" % k, coords[0, :nv[0]], cells[0, :nt[0]])
+    remesh_batch(coords, cells, nv, nt, np.array([-1], np.int32), 50)
+
+# ... and one with an interior vertex of more than 8 cells (the exact path inside the speculative sweeps)
+while True:
+    m = OracleMesh(coords[0, :nv[0]], cells[0, :nt[0]])
+    deg = np.array([len(m.vcells[v]) for v in range(m.nv)])
+    if (deg[~m.on_boundary] > 8).any():
+        break
+    cand = np.nonzero(~m.on_boundary)[0]
+    assert remesh_batch(coords, cells, nv, nt, np.array([int(rng.choice(cand))], np.int32), 50)[0] == 0
+print("interior degrees > 8:", np.nonzero((deg > 8) & ~m.on_boundary)[0], deg[(deg > 8) & ~m.on_boundary])
+write("ys930_big", coords[0, :nv[0]], cells[0, :nt[0]])

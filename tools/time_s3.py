@@ -43,3 +43,22 @@ for rep in range(4):
             groups[n].rollout(act_for(n), K) if mode == "host" else dev_run(n, K)
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
             print(f"rep {rep} {n:12s} {mode:6s}: {dt / K * 1e3:.3f} ms per batched step -> {B * K / dt:.0f} env-steps/s", flush=True)
+# in-rollout duration of the smoothing launches (HIP events) per variant
+for n in groups:
+    env = groups[n].envs[0]
+    env.smooth_events = []
+    from meshdqn_amd import _lib as _L
+    _L.load().mdq_smooth_stats(None, 1)
+    dev_run(n, 30)
+    torch.cuda.synchronize()
+    ms = np.array([a.elapsed_time(b) for a, b in env.smooth_events])
+    env.smooth_events = None
+    print(f"{n:12s}: smooth_kernel in the rollout {ms.mean():.3f} ms (min {ms.min():.3f}, max {ms.max():.3f})")
+    st = np.zeros(64, np.int64)
+    _L.load().mdq_smooth_stats(st.ctypes.data, 0)
+    print(f"{'':12s}  {len(ms)} launches; abandoned speculative sweeps by sweep index: {dict((int(i), int(c)) for i, c in enumerate(st) if c)}")
+    if st[46]:
+        f32 = lambda u: float(np.array([u], np.uint32).view(np.float32)[0])
+        print(f"{'':12s}  last undecided update: env {st[40]} vertex {st[41]} of {st[46]} sweep {st[45]} q2 {f32(st[42]):.4e} "
+              f"r_min^2 {f32(st[43]):.4e} lower limit {f32(st[44]):.4e}")
+    print(f"{'':12s}  launch durations (ms) deciles: {np.round(np.percentile(ms, np.arange(0, 101, 10)), 3).tolist()}")
