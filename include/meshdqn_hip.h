@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MDQ_ABI_VERSION 2
+#define MDQ_ABI_VERSION 3
 
 /* ---- error handling ----------------------------------------------------- */
 int mdq_abi_version(void);
@@ -251,6 +251,117 @@ int mdq_gcn_forward(const mdq_gcn_net* net, int32_t B, int32_t NMAX, int32_t EMA
 int mdq_gcn_forward_ex(const mdq_gcn_net* net, int32_t B, int32_t NMAX, int32_t EMAX, const float* x,
                        const int32_t* node_ptr, const int32_t* esrc, const int32_t* edst,
                        const int32_t* edge_ptr, float* emb, float* out, int32_t* perm, int32_t* status, void* stream);
+
+/* ---- the learning step of the graph Q-network (airfoil_dqn.py:240-310 DataWorker.compute_gradients) ---- */
+/* Offsets (in floats) of every trained parameter inside the flat gradient: the parameters of the module in
+ * `parameters()` order, each in torch layout [out][in] - the message of the gradient all-reduce. */
+typedef struct mdq_gcn_grad_layout {
+  int32_t w_l[6], b[6], w_r[6], pool_w[6]; /* per level: lin_l.weight | lin.weight, lin_l.bias | bias, lin_r.weight (SAGE), pool weight */
+  int32_t lin1_w, lin1_b, lin2_w, lin2_b, lin3_w, lin3_b;
+  int32_t total;                           /* floats of the flat gradient (ALL parameters of the module) */
+  int32_t _pad;
+} mdq_gcn_grad_layout;
+
+typedef struct mdq_gcn_train_desc {
+  int32_t B, NMAX, EMAX;   /* graphs of the minibatch; bounds of nodes / edges per graph (size the LDS carve-up) */
+  int32_t mode;            /* which side of the double-DQN loss this network is on (the reference's `select` toggle):
+                              0: loss_b = huber(out[b][action_b] - (reward_b + gamma nonfinal_b max_j q_other[b][j]))
+                              1: loss_b = huber(q_other[b][action_b] - (reward_b + gamma nonfinal_b max_j out[b][j])) */
+  double gamma;
+  const float* x;          /* graphs as for mdq_gcn_forward: the states (mode 0) / the next states (mode 1) */
+  const int32_t* node_ptr;
+  const int32_t* esrc;
+  const int32_t* edst;
+  const int32_t* edge_ptr;
+  const float* q_other;    /* device [B][out_dim] outputs of the OTHER network (no gradient): on the next states (mode 0) / the states (mode 1) */
+  const int64_t* action;   /* device [B] */
+  const float* reward;     /* device [B] */
+  const float* nonfinal;   /* device [B] 1 where the transition has a next state, else 0 */
+  float* workspace;        /* device [B][mdq_gcn_train_workspace()] floats of scratch */
+  float* partial;          /* device [B][layout.total]: per-graph gradients; zero-filled ONCE by the caller (the slots of
+                              parameters the forward never uses are never written and must read 0) */
+  float* grad;             /* device [layout.total] (out): flat gradient of the mean loss */
+  float* loss;             /* device [1] (out): mean Huber loss (delta 1) over the minibatch */
+  float* out;              /* device [B][out_dim] (out, may be NULL): head outputs of this network */
+  mdq_gcn_grad_layout layout;
+} mdq_gcn_train_desc;
+
+/* floats of workspace per graph for mdq_gcn_train_step (-1: bad arguments) */
+int64_t mdq_gcn_train_workspace(const mdq_gcn_net* net, int32_t NMAX, int32_t EMAX);
+
+/*
+ * Forward + double-DQN Huber loss + full backward of `net` over a minibatch, without autograd: replaces
+ * `loss.backward()` in DataWorker.compute_gradients (airfoil_dqn.py:286-310) and the PyG backward passes of SAGEConv /
+ * GCNConv / TopKPooling / global max + mean pool behind it.  One workgroup per graph (forward out of LDS, backward over
+ * the rows TopKPooling kept), then a reduction of the per-graph gradients in graph order: bitwise reproducible.
+ */
+int mdq_gcn_train_step(const mdq_gcn_net* net, const mdq_gcn_train_desc* d, void* stream);
+
+/* Parameters of the module (torch layout) into the layout the kernels read, all segments in ONE launch:
+ * segment s is a [rows][cols] matrix written transposed ([cols][rows]); cols == 1: a plain copy of `rows` floats. */
+#define MDQ_GCN_PACK_MAX 32
+typedef struct mdq_gcn_pack_table {
+  int32_t n, _pad;
+  const float* src[MDQ_GCN_PACK_MAX];
+  float* dst[MDQ_GCN_PACK_MAX];
+  int32_t rows[MDQ_GCN_PACK_MAX], cols[MDQ_GCN_PACK_MAX];
+} mdq_gcn_pack_table;
+int mdq_gcn_pack(const mdq_gcn_pack_table* table, void* stream);
+
+/* ---- device-resident replay memory + optimiser update (airfoil_dqn.py:48-67 ReplayMemory, :184-200 apply_gradients) ---- */
+/*
+ * Transition records (float32; the layout trainer.pack_transitions writes and the ranks all-gather), N*F = nf, EM edge slots:
+ *   [ x(s) nf | x(s') nf | src(s) EM | dst(s) EM | src(s') EM | dst(s') EM | edges(s) | edges(s') | action | reward | done ]
+ * rec_len = 2 nf + 4 EM + 5; a terminal transition has zeros for s'.
+ *
+ * mdq_replay_step: `ReplayMemory.push` for the B environments of a batched step, in two halves, because the state arrays
+ * of the vector environment are rewritten by the next step: the CURRENT batched state (x [B][nf], padded edge lists
+ * [B][EM] + nedges [B], as VecEnv2DAirfoil hands them out) becomes s of the records (base_cur + b) % capacity and s' of
+ * the records (base_prev + b) % capacity, whose action / reward / done [B] (of the step that led to this state) are
+ * filled in too.  base_cur or base_prev < 0: that half is skipped.  All pointers device.
+ */
+int mdq_replay_step(float* ring, int32_t rec_len, int32_t capacity, int32_t B, int32_t nf, int32_t EM, const float* x,
+                    const int32_t* edge_src, const int32_t* edge_dst, const int32_t* nedges, int32_t base_cur,
+                    int32_t base_prev, const int32_t* action, const double* reward, const uint8_t* done, void* stream);
+
+/*
+ * `ReplayMemory.sample` + the batching of DataWorker._get_data (airfoil_dqn.py:63-64,240-262): records idx[0..n) of the
+ * ring -> the graph arrays of mdq_gcn_forward / mdq_gcn_train_step for the states (`_s`) and the next states (`_n`; a
+ * terminal transition contributes its own state as a placeholder, nonfinal = 0), edge lists packed back to back.
+ */
+typedef struct mdq_replay_sample_desc {
+  int32_t n, rec_len, nf, EM;
+  const float* R;             /* ring */
+  const int32_t* idx;         /* [n] record numbers */
+  float* x_s;                 /* [n][nf] */
+  float* x_n;
+  int32_t* esrc_s;            /* [n * EM] packed */
+  int32_t* edst_s;
+  int32_t* esrc_n;
+  int32_t* edst_n;
+  int32_t* edge_ptr_s;        /* [n + 1] */
+  int32_t* edge_ptr_n;
+  int64_t* action;            /* [n] */
+  float* reward;              /* [n] */
+  float* nonfinal;            /* [n] */
+} mdq_replay_sample_desc;
+int mdq_replay_sample(const mdq_replay_sample_desc* d, void* stream);
+
+/*
+ * torch.optim.Adam.step (amsgrad False; weight decay added to the gradient) for up to 32 parameter tensors in one
+ * launch: segment s updates param[s][0..len[s]) from grad / exp_avg / exp_avg_sq [offset[s] ..] (flat buffers laid out
+ * like the flat gradient).  bias_correction{1,2} = 1 - beta{1,2}^step, computed by the caller.
+ */
+typedef struct mdq_adam_desc {
+  int32_t n, _pad;
+  float* param[MDQ_GCN_PACK_MAX];
+  int32_t offset[MDQ_GCN_PACK_MAX], len[MDQ_GCN_PACK_MAX];
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  double lr, beta1, beta2, eps, weight_decay, bias_correction1, bias_correction2;
+} mdq_adam_desc;
+int mdq_adam_step(const mdq_adam_desc* d, void* stream);
 
 /* ---- snapshot interpolation onto coarsened meshes (Env2DAirfoil.py:556-593, :515-522) ---- */
 typedef struct mdq_interp_desc {

@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmeshdqn_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class MeshDQNHipError(RuntimeError):
@@ -119,6 +119,13 @@ SYMBOLS = {
     "mdq_smooth": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_void_p]),
     "mdq_smooth_stats": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mdq_gcn_train_workspace": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32]),
+    "mdq_gcn_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mdq_gcn_pack": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mdq_replay_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mdq_replay_sample": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mdq_adam_step": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mdq_smooth_host": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
 }

@@ -242,13 +242,31 @@ struct Level {
   const float *wl, *b, *wr, *pw;
 };
 
+// what the backward pass of one level needs from its forward pass (training kernel, mdq_gcn_train.hip): the rows of
+// the k kept nodes only - TopKPooling passes a gradient to nothing else.  Pointers into the graph's global workspace.
+struct TapeLevel {
+  float* hsel;    // [k][C]   relu(conv) of kept node r
+  float* ssel;    // [k]      its score
+  float* aggsel;  // [k][fin] aggregated input features (the operand of lin_l / lin)
+  float* xsel;    // [k][fin] its own input features (the operand of lin_r)
+  int* perm;      // [k]      node id inside the level's input
+  int* amax;      // [C]      kept node holding the channel maximum of the readout
+  int* esrc;      // [E]      the level's input edges (nullptr: not wanted, level 0)
+  int* edst;
+};
+
 // one conv + relu + TopK pool + readout level; features in L.x ([n][fin]) are replaced by the pooled ones
 __device__ inline void run_level(const Lds& L, const Level& lv, int C, double ratio, int& n, int& E, int32_t* perm, float& rmax,
-                                 float& rmean, int NMAX) {
+                                 float& rmean, int NMAX, const TapeLevel* tape = nullptr) {
   const int tid = threadIdx.x, fin = lv.fin;
 #ifdef MDQ_GCN_TRACE
   long long tq_ = __builtin_amdgcn_s_memtime();
 #endif
+  if (tape && tape->esrc)
+    for (int e = tid; e < E; e += WGT) {
+      tape->esrc[e] = L.esrc[e];
+      tape->edst[e] = L.edst[e];
+    }
   build_csr(L, n, E);
   GT_STAMP(0)
   // ---- aggregation into L.agg
@@ -359,6 +377,27 @@ __device__ inline void run_level(const Lds& L, const Level& lv, int C, double ra
   }
   __syncthreads();
   GT_STAMP(4)
+  if (tape) {   // rows of the kept nodes, before the pooled features overwrite the level input
+    for (int idx = tid; idx < n * C; idx += WGT) {
+      const int i = idx / C, c = idx - i * C, r = L.newid[i];
+      if (r >= 0) tape->hsel[r * C + c] = L.h[i * (C + 1) + c];
+    }
+    for (int idx = tid; idx < n * fin; idx += WGT) {
+      const int i = idx / fin, f = idx - i * fin, r = L.newid[i];
+      if (r >= 0) {
+        tape->aggsel[r * fin + f] = L.agg[idx];
+        tape->xsel[r * fin + f] = L.x[idx];
+      }
+    }
+    for (int i = tid; i < n; i += WGT) {
+      const int r = L.newid[i];
+      if (r >= 0) {
+        tape->ssel[r] = L.score[i];
+        tape->perm[r] = i;
+      }
+    }
+    __syncthreads();
+  }
   // ---- pooled features x'[r][c] = h[perm r][c] * score[perm r]  -> L.x with stride C
   if (n > WGT / 16) {
     for (int i = tid; i < n; i += WGT) {
@@ -405,13 +444,16 @@ __device__ inline void run_level(const Lds& L, const Level& lv, int C, double ra
   // ---- readout over the pooled nodes: thread c < C
   if (tid < C) {
     float mx = -INFINITY, sm = 0.f;
+    int arg = 0;
     for (int r = 0; r < n; ++r) {
       const float v = L.x[r * C + tid];
+      if (v > mx) arg = r;      // first maximum (where torch's max sends the gradient)
       mx = fmaxf(mx, v);
       sm += v;
     }
     rmax += mx;
     rmean += sm / (float)n;
+    if (tape) tape->amax[tid] = arg;
   }
   __syncthreads();
   GT_STAMP(7)

@@ -2,6 +2,8 @@
 // the thread-local error string in one place; no relocatable device code needed).
 #include "mdq_ipcs.hip"
 #include "mdq_gcn.hip"
+#include "mdq_gcn_train.hip"
+#include "mdq_replay.hip"
 #include "mdq_mesh.hip"
 #include "mdq_smooth.hip"
 #include "mdq_topology.hip"

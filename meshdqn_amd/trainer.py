@@ -505,6 +505,154 @@ class DQNTrainer:
         self.losses.append(float(loss.item()))
         return self.losses[-1]
 
+    # --- learning on the device: hand-written forward + backward, replay sampling and Adam as kernels --------------
+    def _fused_of(self, net):
+        from .gcn_fused import FusedGcn
+        if not hasattr(net, "_fused"):
+            net._fused = FusedGcn(net)
+        return net._fused
+
+    def _adam_state(self, k: int, total: int):
+        """Flat first / second moment buffers of network k laid out like the flat gradient.  The entries of the torch
+        optimiser's `state` ARE views of them (so `state_dict()` checkpoints, `load_state_dict` and an occasional
+        `opts[k].step()` on the host path all see the same moments); after a `load_state_dict` the loaded tensors are
+        copied in and re-aliased."""
+        net, opt = (self.policy_net_1, self.policy_net_2)[k], self.opts[k]
+        ad = getattr(self, "_adam", None)
+        if ad is None:
+            ad = self._adam = [None, None]
+        skip = {id(p_) for p_ in net.unused_parameters()}
+        prm = [p_ for p_ in net.parameters() if id(p_) not in skip]
+        a = ad[k]
+        ok = a is not None and a["m"].numel() == total and all(
+            p_ in opt.state and opt.state[p_].get("exp_avg") is not None and
+            opt.state[p_]["exp_avg"].data_ptr() == a["views"][id(p_)][0].data_ptr() for p_ in prm[:1])
+        if ok:
+            return a
+        dev = self.ctx.device
+        a = dict(m=torch.zeros(total, device=dev), v=torch.zeros(total, device=dev), views={}, params=prm)
+        off = 0
+        for p_ in net.parameters():
+            n = p_.numel()
+            if id(p_) not in skip:
+                mv, vv = a["m"][off:off + n].view_as(p_), a["v"][off:off + n].view_as(p_)
+                old = opt.state.get(p_, {})
+                step = old.get("step", torch.tensor(0.0))
+                if old.get("exp_avg") is not None:
+                    mv.copy_(old["exp_avg"])
+                    vv.copy_(old["exp_avg_sq"])
+                opt.state[p_] = dict(step=step.detach().to("cpu", torch.float32).reshape(()).clone(), exp_avg=mv, exp_avg_sq=vv)
+                a["views"][id(p_)] = (mv, vv, off)
+            off += n
+        from .gcn_fused import PACK_MAX
+        import ctypes as C
+
+        class AdamDesc(C.Structure):
+            _fields_ = [("n", C.c_int32), ("_pad", C.c_int32), ("param", C.c_void_p * PACK_MAX),
+                        ("offset", C.c_int32 * PACK_MAX), ("len", C.c_int32 * PACK_MAX), ("grad", C.c_void_p),
+                        ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("lr", C.c_double), ("beta1", C.c_double),
+                        ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double),
+                        ("bias_correction1", C.c_double), ("bias_correction2", C.c_double)]
+        d = AdamDesc()
+        if len(prm) > PACK_MAX:
+            raise ValueError("too many trained parameter tensors for mdq_adam_step")
+        d.n = len(prm)
+        for i, p_ in enumerate(prm):
+            d.param[i], d.offset[i], d.len[i] = p_.data_ptr(), a["views"][id(p_)][2], p_.numel()
+        d.exp_avg, d.exp_avg_sq = a["m"].data_ptr(), a["v"].data_ptr()
+        a["desc"] = d
+        ad[k] = a
+        return a
+
+    def _adam_step_device(self, k: int, flat: torch.Tensor):
+        """`opts[k].step()` + `scheds[k].step()` with ONE kernel launch for the update (mdq_adam_step)."""
+        import ctypes as C
+        from . import _lib
+        opt = self.opts[k]
+        a = self._adam_state(k, flat.numel())
+        g = opt.param_groups[0]
+        if g.get("amsgrad") or g.get("maximize"):
+            raise ValueError("mdq_adam_step: amsgrad / maximize are not supported")
+        for p_ in a["params"]:
+            opt.state[p_]["step"] += 1
+        step = float(opt.state[a["params"][0]]["step"])
+        d = a["desc"]
+        if any(d.param[i] != p_.data_ptr() for i, p_ in enumerate(a["params"][:1])):
+            for i, p_ in enumerate(a["params"]):
+                d.param[i] = p_.data_ptr()
+        d.grad = flat.data_ptr()
+        d.lr, (d.beta1, d.beta2), d.eps, d.weight_decay = float(g["lr"]), g["betas"], float(g["eps"]), float(g["weight_decay"])
+        d.bias_correction1, d.bias_correction2 = 1.0 - d.beta1 ** step, 1.0 - d.beta2 ** step
+        _lib.check(_lib.load().mdq_adam_step(C.byref(d), _lib.stream_ptr()), "mdq_adam_step")
+        # the kernel wrote the parameters behind torch's back (no `_version` bump): tell the fused kernels' packed copy
+        net = (self.policy_net_1, self.policy_net_2)[k]
+        net._mdq_version = getattr(net, "_mdq_version", 0) + 1
+        opt._opt_called = True          # (lr_scheduler's "step() before optimizer.step()" check)
+        self.scheds[k].step()
+
+    def optimize_device(self, rep: "SharedDeviceReplay", idx, loss_out: Optional[torch.Tensor] = None):
+        """One optimiser step on a minibatch of the record ring WITHOUT host synchronisation and without autograd:
+        `mdq_replay_sample` (records `idx` -> graph arrays), fused forward of the network without gradient,
+        `mdq_gcn_train_step` of the other one (forward + double-DQN Huber loss + backward), ONE flat all-reduce over the
+        ranks, `mdq_adam_step`.  Everything is enqueued on the current stream; the loss goes to `loss_out` (a (1,)
+        device tensor, e.g. a slot of a log ring) and is also returned as a device tensor.  Same `select` toggling as
+        `optimize` (airfoil_dqn.py:315-340 + :184-200 + :240-310)."""
+        import ctypes as C
+        from . import _lib
+        from .gcn_fused import FusedGcn  # noqa: F401
+        dev = self.ctx.device
+        if (self.num_grads % self.target_update) == 0:
+            self.select = not self.select
+        sel = self.select
+        k = 0 if sel else 1
+        net, other = ((self.policy_net_1, self.policy_net_2) if sel else (self.policy_net_2, self.policy_net_1))
+        mb, N, F, EM = len(idx), rep.N, rep.F, rep.e_max
+        bufs = getattr(self, "_mb_bufs", None)
+        if bufs is None or bufs["key"] != (mb, N, F, EM):
+            i32, f32 = torch.int32, torch.float32
+
+            class SampleDesc(C.Structure):
+                _fields_ = [("n", C.c_int32), ("rec_len", C.c_int32), ("nf", C.c_int32), ("EM", C.c_int32)] + \
+                           [(nm, C.c_void_p) for nm in ("R", "idx", "x_s", "x_n", "esrc_s", "edst_s", "esrc_n", "edst_n",
+                                                        "edge_ptr_s", "edge_ptr_n", "action", "reward", "nonfinal")]
+            bufs = dict(key=(mb, N, F, EM), idx=torch.empty(mb, dtype=i32, device=dev),
+                        x_s=torch.empty((mb, N, F), dtype=f32, device=dev), x_n=torch.empty((mb, N, F), dtype=f32, device=dev),
+                        esrc_s=torch.zeros(mb * EM, dtype=i32, device=dev), edst_s=torch.zeros(mb * EM, dtype=i32, device=dev),
+                        esrc_n=torch.zeros(mb * EM, dtype=i32, device=dev), edst_n=torch.zeros(mb * EM, dtype=i32, device=dev),
+                        edge_ptr_s=torch.zeros(mb + 1, dtype=i32, device=dev), edge_ptr_n=torch.zeros(mb + 1, dtype=i32, device=dev),
+                        action=torch.zeros(mb, dtype=torch.int64, device=dev), reward=torch.zeros(mb, dtype=f32, device=dev),
+                        nonfinal=torch.zeros(mb, dtype=f32, device=dev),
+                        node_ptr=torch.arange(mb + 1, dtype=i32, device=dev) * N)
+            d = SampleDesc()
+            d.n, d.rec_len, d.nf, d.EM = mb, rep.rec_len, N * F, EM
+            for nm in ("idx", "x_s", "x_n", "esrc_s", "edst_s", "esrc_n", "edst_n", "edge_ptr_s", "edge_ptr_n", "action",
+                       "reward", "nonfinal"):
+                setattr(d, nm, bufs[nm].data_ptr())
+            bufs["desc"] = d
+            self._mb_bufs = bufs
+        b = bufs
+        if torch.is_tensor(idx):      # already on the device (the loop uploads a whole chunk of minibatches at once)
+            if idx.dtype != torch.int32 or idx.device != dev or not idx.is_contiguous():
+                raise ValueError("optimize_device: device indices must be contiguous int32")
+            b["desc"].idx = idx.data_ptr()
+        else:
+            b["idx"].copy_(torch.as_tensor(np.asarray(idx, dtype=np.int32)))     # (pageable source: a blocking copy)
+            b["desc"].idx = b["idx"].data_ptr()
+        b["desc"].R = rep.R.data_ptr()
+        _lib.check(_lib.load().mdq_replay_sample(C.byref(b["desc"]), _lib.stream_ptr()), "mdq_replay_sample")
+        gs = dict(x=b["x_s"], esrc=b["esrc_s"], edst=b["edst_s"], edge_ptr=b["edge_ptr_s"])
+        gn = dict(x=b["x_n"], esrc=b["esrc_n"], edst=b["edst_n"], edge_ptr=b["edge_ptr_n"])
+        go, gd = (gn, gs) if sel else (gs, gn)
+        qo = self._fused_of(other).forward_arrays(go["x"], b["node_ptr"], go["esrc"], go["edst"], go["edge_ptr"], N, EM)
+        loss, flat = self._fused_of(net).train_step(gd["x"], b["node_ptr"], gd["esrc"], gd["edst"], gd["edge_ptr"], N, EM,
+                                                    0 if sel else 1, qo, b["action"], b["reward"], b["nonfinal"], self.gamma,
+                                                    loss_out=loss_out)
+        if self.ctx.world > 1:
+            self.ctx.allreduce_mean_(flat)
+        self._adam_step_device(k, flat)
+        self.num_grads += 1
+        return loss
+
     def state_dicts(self):
         return self.policy_net_1.state_dict(), self.policy_net_2.state_dict()
 
@@ -953,4 +1101,121 @@ def train_loop_vec(trainer: DQNTrainer, venv, num_steps: int, optim_per_step: in
         dones_hist.append(done.copy())
         if every and on_every is not None and (step_no + 1) % every == 0:
             on_every(step_no + 1, steps_done)
+    return dict(rewards=np.array(rewards), dones=np.array(dones_hist), losses=list(trainer.losses), steps_done=steps_done)
+
+
+def train_loop_device(trainer: DQNTrainer, venv, num_steps: int, optim_per_step: int = 1, eps_decay=10000, eps_start=1.0,
+                      eps_end=0.01, share_replay=False, log: Optional["TrainingLog"] = None, steps_done0=None, every: int = 0,
+                      on_every=None, chunk: int = 64):
+    """`train_loop_vec` WITHOUT a host round trip inside a batched step (one rank of configs[3]): the environment step is
+    `VecEnv2DAirfoil.rollout_step` (Q-forward, epsilon-greedy choice, vertex removal ... reward / reset logic as kernels),
+    the B transitions go into the record ring with one launch (`mdq_replay_step`; with `share_replay` the ranks
+    all-gather their B records per step), and the optimiser step (`DQNTrainer.optimize_device`: replay sampling,
+    hand-written forward + backward, flat gradient all-reduce, Adam as kernels) runs on a second stream beside the
+    latency-bound smoothing kernel of the same env step.  The host only draws the random numbers (same streams as
+    `train_loop_vec`: numpy for epsilon-greedy, `random.sample` for the minibatch) and enqueues; rewards / dones /
+    losses are read back once per `chunk` steps.  Same returns as `train_loop_vec`."""
+    from . import _lib
+    ctx = trainer.ctx
+    dev = ctx.device
+    if dev.type != "cuda" or not getattr(venv, "gpu_remesh", False) or not venv.auto_reset:
+        raise _lib.MeshDQNHipError("train_loop_device needs a GPU and a vector env with the device mesh engine and auto_reset")
+    lib = _lib.load()
+    B, N = venv.B, venv.N
+    W = B * ctx.world if (share_replay and ctx.world > 1) else B     # records per batched step in this rank's ring
+    steps_done = np.zeros(B, np.int64) if steps_done0 is None else np.asarray(steps_done0, np.int64).copy()
+    fused1 = trainer._fused_of(trainer.policy_net_1)
+    fused2 = trainer._fused_of(trainer.policy_net_2)
+    main = torch.cuda.current_stream(dev)
+    if getattr(trainer, "_opt_stream", None) is None:
+        trainer._opt_stream = torch.cuda.Stream(device=dev)
+    opt_stream = trainer._opt_stream
+    rep = None
+    rewards, dones_hist, losses = [], [], []
+    ep_r = [[] for _ in range(B)]
+    ep_a = [[] for _ in range(B)]
+    step_no, prev = 0, None      # prev: (record base, act, rew, done) of the step whose records await their next state
+    G = 0
+    while step_no < num_steps:
+        K = min(int(chunk), num_steps - step_no)
+        # random numbers of the chunk, drawn step by step in train_loop_vec's order
+        explore, rand_act, eps_mean = np.zeros((K, B), bool), np.zeros((K, B), np.int32), []
+        for k in range(K):
+            eps = eps_end + (eps_start - eps_end) * np.exp(-1.0 * steps_done / eps_decay)
+            steps_done += 1
+            explore[k] = np.random.random(B) <= eps
+            rand_act[k] = np.random.randint(0, trainer.n_actions + 1, B)
+            eps_mean.append(float(eps.mean()))
+        ro = venv.rollout_begin(K, explore, rand_act)
+        st = ro["state"]
+        if rep is None:
+            F = st["x"].shape[2]
+            if st["edge_src_pad"].shape[1] != trainer.e_max:
+                raise ValueError(f"vector env pads edge lists to {st['edge_src_pad'].shape[1]}, trainer.e_max is {trainer.e_max}")
+            rep = trainer.device_memory
+            cap = max(2, trainer.replay_capacity // W) * W          # whole groups of W records
+            if not isinstance(rep, SharedDeviceReplay) or (rep.capacity, rep.N, rep.F) != (cap, N, F):
+                rep = trainer.device_memory = SharedDeviceReplay(cap, N, F, trainer.e_max, dev)
+            G = rep.capacity // W
+            loss_ring = torch.zeros(int(chunk) * max(1, optim_per_step), dtype=torch.float32, device=dev)
+        # minibatches of the chunk: the number of finished records at every step is known in advance; one upload
+        mbs = []
+        for k in range(K):
+            t = step_no + k
+            count = min(t, G - 1) * W                          # finished groups (the one being written is not)
+            for _k in range(optim_per_step if count >= trainer.batch_size else 0):
+                idx = np.asarray(random.sample(range(count), trainer.batch_size), np.int64)
+                if t >= G:                                     # wrapped: skip over the group being written
+                    idx = np.where(idx < (t % G) * W, idx, idx + W)
+                mbs.append(idx.astype(np.int32))
+        mb_dev = torch.from_numpy(np.stack(mbs)).to(dev) if mbs else None
+        n_loss = 0
+        for k in range(K):
+            g = (step_no + k) % G                              # the ring group this step's records go to
+            main.wait_stream(opt_stream)                       # the weights of the previous optimiser step
+            fused1._pack()
+            fused2._pack()
+            base_cur = g * W + (ctx.rank * B if W != B else 0)
+            _lib.check(lib.mdq_replay_step(rep.R.data_ptr(), rep.rec_len, rep.capacity, B, N * st["x"].shape[2], rep.e_max,
+                                           st["x"].data_ptr(), st["edge_src_pad"].data_ptr(), st["edge_dst_pad"].data_ptr(),
+                                           st["nedges_dev"].data_ptr(), base_cur, -1 if prev is None else prev[0],
+                                           None if prev is None else prev[1].data_ptr(), None if prev is None else prev[2].data_ptr(),
+                                           None if prev is None else prev[3].data_ptr(), _lib.stream_ptr()), "mdq_replay_step")
+            if prev is not None and W != B:                    # shared replay: everybody's finished records of that step
+                gp = prev[0] // W
+                own = rep.R[prev[0]:prev[0] + B].clone()
+                dist.all_gather_into_tensor(rep.R[gp * W:(gp + 1) * W].view(-1), own.view(-1))
+            ev = torch.cuda.Event()
+            ev.record(main)
+            if min(step_no + k, G - 1) * W >= trainer.batch_size:
+                with torch.cuda.stream(opt_stream):
+                    opt_stream.wait_event(ev)
+                    for _k in range(optim_per_step):
+                        trainer.optimize_device(rep, mb_dev[n_loss], loss_out=loss_ring[n_loss:n_loss + 1])
+                        n_loss += 1
+            venv.rollout_step(ro, fused1)
+            prev = (base_cur, ro["act"][k], ro["rew"][k], ro["done"][k])
+            st = ro["state"]
+        out = venv.rollout_end(ro)                              # the one synchronisation of the chunk
+        new_losses = loss_ring[:n_loss].cpu().numpy().tolist()
+        trainer.losses.extend(new_losses)
+        losses.extend(new_losses)
+        for k in range(K):
+            rew, done = out["rewards"][k], out["dones"][k]
+            rewards.append(rew.copy())
+            dones_hist.append(done.copy())
+            if log is not None:
+                log.add_eps(eps_mean[k])
+                for b in range(B):
+                    ep_r[b].append(float(rew[b]))
+                    ep_a[b].append(int(out["actions"][k][b]))
+                    if done[b]:
+                        log.add_episode(ep_r[b], ep_a[b])
+                        ep_r[b], ep_a[b] = [], []
+        if log is not None:
+            for l_ in new_losses:
+                log.add_loss(l_)
+        step_no += K
+        if every and on_every is not None and (step_no // every) > ((step_no - K) // every):
+            on_every(step_no, steps_done)
     return dict(rewards=np.array(rewards), dones=np.array(dones_hist), losses=list(trainer.losses), steps_done=steps_done)

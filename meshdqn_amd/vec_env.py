@@ -604,7 +604,7 @@ class VecEnv2DAirfoil:
                                               ds["edge_ptr"].data_ptr(), ds["esrc"].data_ptr(), ds["edst"].data_ptr(),
                                               _lib.stream_ptr()), "mdq_compact_edges")
         return dict(x=x, esrc=ds["esrc"], edst=ds["edst"], edge_ptr=ds["edge_ptr"], node_ptr=self._node_ptr,
-                    edge_src_pad=dt.t["edge_src"], edge_dst_pad=dt.t["edge_dst"])
+                    edge_src_pad=dt.t["edge_src"], edge_dst_pad=dt.t["edge_dst"], nedges_dev=dt.t["nedges"])
 
     def rollout_device(self, fused, steps: int, explore=None, rand_actions=None, actions=None):
         """`steps` batched env steps WITHOUT a host round trip inside a step: the Q-network forward (`fused`: a
@@ -615,9 +615,18 @@ class VecEnv2DAirfoil:
         `mdq_env_smooth_iters`, `mdq_smooth`, `mdq_env_topology`, ..., `mdq_env_result`, `mdq_restore_rows_masked`).
         Same semantics as `steps` calls of `step()` (tested against it).  Returns dict(rewards (steps,B), dones,
         actions, codes, nv) - read back ONCE at the end, when the host mirrors of the environments are refreshed too."""
+        ro = self.rollout_begin(steps, explore, rand_actions, actions)
+        for k in range(int(steps)):
+            self.rollout_step(ro, fused)
+        return self.rollout_end(ro)
+
+    def rollout_begin(self, steps: int, explore=None, rand_actions=None, actions=None):
+        """First third of `rollout_device` (the learning loop interleaves its own launches with the steps): uploads the
+        per-step action inputs, allocates the per-step outputs; `ro["state"]` is the current batched state on the device
+        (x, packed and padded edge lists, `nedges`)."""
         if not self.gpu_remesh:
             raise _lib.MeshDQNHipError("rollout_device needs the device mesh engine (gpu_remesh=True)")
-        dev, dt, lib, B, N, S, K = self.device, self.dtopo, self.lib, self.B, self.N, self.S, int(steps)
+        dev, dt, B, K = self.device, self.dtopo, self.B, int(steps)
         i32 = torch.int32
         if self._pending is not None:
             self._refresh_collect()
@@ -628,57 +637,67 @@ class VecEnv2DAirfoil:
             act_all = torch.empty((K, B), dtype=i32, device=dev)
             expl_all = torch.from_numpy(np.ascontiguousarray(explore, dtype=np.uint8).reshape(K, B)).to(dev)
             rand_all = torch.from_numpy(np.ascontiguousarray(rand_actions, dtype=np.int32).reshape(K, B)).to(dev)
-        rew_all = torch.empty((K, B), dtype=torch.float64, device=dev)
-        done_all = torch.empty((K, B), dtype=torch.uint8, device=dev)
-        code_all = torch.empty((K, B), dtype=i32, device=dev)
-        nv_all = torch.empty((K, B), dtype=i32, device=dev)
-        rem, its = torch.empty(B, dtype=i32, device=dev), torch.empty(B, dtype=i32, device=dev)
-        d_steps = torch.from_numpy(self.steps.astype(np.int32)).to(dev)
-        err = torch.zeros(1, dtype=i32, device=dev)
+        ro = dict(K=K, k=0, given=actions is not None, act=act_all, explore=expl_all, rand=rand_all,
+                  rew=torch.empty((K, B), dtype=torch.float64, device=dev), done=torch.empty((K, B), dtype=torch.uint8, device=dev),
+                  code=torch.empty((K, B), dtype=i32, device=dev), nv=torch.empty((K, B), dtype=i32, device=dev),
+                  rem=torch.empty(B, dtype=i32, device=dev), its=torch.empty(B, dtype=i32, device=dev),
+                  d_steps=torch.from_numpy(self.steps.astype(np.int32)).to(dev), err=torch.zeros(1, dtype=i32, device=dev))
         if getattr(self, "_gt_drag_dev", None) is None:
             self._gt_drag_dev = torch.from_numpy(np.ascontiguousarray(self.gt_drag, dtype=np.float64)).to(dev)
         dt.offset.copy_(torch.from_numpy(self.offset))
+        ro["state"] = self._state_device()
+        return ro
+
+    def rollout_step(self, ro, fused):
+        """One batched env step of a `rollout_begin` context, enqueued on the current stream; afterwards `ro["state"]`
+        is the new batched state and `ro["act"][k] / ro["rew"][k] / ro["done"][k]` (device) describe the step (k = ro["k"] - 1)."""
+        dt, lib, B, N, S, k = self.dtopo, self.lib, self.B, self.N, self.S, ro["k"]
+        if k >= ro["K"]:
+            raise IndexError("rollout_step beyond the steps of rollout_begin")
         sp = _lib.stream_ptr
-        st = self._state_device()
-        for k in range(K):
-            q = None
-            if actions is None:
-                q = fused.forward_arrays(st["x"], st["node_ptr"], st["esrc"], st["edst"], st["edge_ptr"], N, self.EMAX)
-            _lib.check(lib.mdq_env_act(B, N, None if q is None else q.data_ptr(),
-                                       None if expl_all is None else expl_all[k].data_ptr(),
-                                       None if rand_all is None else rand_all[k].data_ptr(), dt.t["nsel"].data_ptr(),
-                                       dt.t["coord_map"].data_ptr(), dt.offset.data_ptr(), act_all[k].data_ptr(),
-                                       rem.data_ptr(), code_all[k].data_ptr(), sp()), "mdq_env_act")
-            remesh_batch_gpu(dt.coords, dt.cells, dt.nv, dt.nt, rem, self._rstat)
-            _lib.check(lib.mdq_env_smooth_iters(B, rem.data_ptr(), self._rstat.data_ptr(), 50, its.data_ptr(), sp()),
-                       "mdq_env_smooth_iters")
-            tm = getattr(self, "smooth_events", None)     # (bench: HIP events around the launch, on this stream)
-            if tm is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            smooth_batch_gpu(dt.coords, dt.cells, dt.nv, dt.nt, its)
-            if tm is not None:
-                e1.record()
-                tm.append((e0, e1))
-            self._refresh_launch(readback=False)
-            nv_all[k].copy_(dt.nv)
-            _lib.check(lib.mdq_env_result(B, N, S, self._dev_drag.data_ptr(), self._gt_drag_dev.data_ptr(), dt.nv.data_ptr(),
-                                          int(self.initial_num_node), self._rstat.data_ptr(), dt.status.data_ptr(),
-                                          dt.t["nsel"].data_ptr(), code_all[k].data_ptr(), d_steps.data_ptr(),
-                                          self.threshold, self.TIME_REWARD, self.goal_vertices, int(self.timesteps),
-                                          self.NEGATIVE_REWARD, 1 if self.auto_reset else 0, rew_all[k].data_ptr(),
-                                          done_all[k].data_ptr(), err.data_ptr(), sp()), "mdq_env_result")
-            if self.auto_reset:
-                ra = self._restore_arg_arrays()
-                _lib.check(lib.mdq_restore_rows_masked(ra["n"], ra["dst"], ra["src"], ra["nbytes"], B,
-                                                       done_all[k].data_ptr(), sp()), "mdq_restore_rows_masked")
-            st = self._state_device()
-        # one read-back; host mirrors of the environments follow the device
-        out = dict(rewards=rew_all.cpu().numpy(), dones=done_all.cpu().numpy().astype(bool), actions=act_all.cpu().numpy(),
-                   codes=code_all.cpu().numpy(), nv=nv_all.cpu().numpy())
-        if int(err.item()) != 0:
+        st, rem, its = ro["state"], ro["rem"], ro["its"]
+        q = None
+        if not ro["given"]:
+            q = fused.forward_arrays(st["x"], st["node_ptr"], st["esrc"], st["edst"], st["edge_ptr"], N, self.EMAX)
+        _lib.check(lib.mdq_env_act(B, N, None if q is None else q.data_ptr(),
+                                   None if ro["explore"] is None else ro["explore"][k].data_ptr(),
+                                   None if ro["rand"] is None else ro["rand"][k].data_ptr(), dt.t["nsel"].data_ptr(),
+                                   dt.t["coord_map"].data_ptr(), dt.offset.data_ptr(), ro["act"][k].data_ptr(),
+                                   rem.data_ptr(), ro["code"][k].data_ptr(), sp()), "mdq_env_act")
+        remesh_batch_gpu(dt.coords, dt.cells, dt.nv, dt.nt, rem, self._rstat)
+        _lib.check(lib.mdq_env_smooth_iters(B, rem.data_ptr(), self._rstat.data_ptr(), 50, its.data_ptr(), sp()),
+                   "mdq_env_smooth_iters")
+        tm = getattr(self, "smooth_events", None)     # (bench: HIP events around the launch, on this stream)
+        if tm is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        smooth_batch_gpu(dt.coords, dt.cells, dt.nv, dt.nt, its)
+        if tm is not None:
+            e1.record()
+            tm.append((e0, e1))
+        self._refresh_launch(readback=False)
+        ro["nv"][k].copy_(dt.nv)
+        _lib.check(lib.mdq_env_result(B, N, S, self._dev_drag.data_ptr(), self._gt_drag_dev.data_ptr(), dt.nv.data_ptr(),
+                                      int(self.initial_num_node), self._rstat.data_ptr(), dt.status.data_ptr(),
+                                      dt.t["nsel"].data_ptr(), ro["code"][k].data_ptr(), ro["d_steps"].data_ptr(),
+                                      self.threshold, self.TIME_REWARD, self.goal_vertices, int(self.timesteps),
+                                      self.NEGATIVE_REWARD, 1 if self.auto_reset else 0, ro["rew"][k].data_ptr(),
+                                      ro["done"][k].data_ptr(), ro["err"].data_ptr(), sp()), "mdq_env_result")
+        if self.auto_reset:
+            ra = self._restore_arg_arrays()
+            _lib.check(lib.mdq_restore_rows_masked(ra["n"], ra["dst"], ra["src"], ra["nbytes"], B,
+                                                   ro["done"][k].data_ptr(), sp()), "mdq_restore_rows_masked")
+        ro["state"] = self._state_device()
+        ro["k"] = k + 1
+
+    def rollout_end(self, ro):
+        """The one read-back of a rollout; the host mirrors of the environments follow the device."""
+        K = ro["k"]
+        out = dict(rewards=ro["rew"][:K].cpu().numpy(), dones=ro["done"][:K].cpu().numpy().astype(bool),
+                   actions=ro["act"][:K].cpu().numpy(), codes=ro["code"][:K].cpu().numpy(), nv=ro["nv"][:K].cpu().numpy())
+        if int(ro["err"].item()) != 0:
             raise _lib.MeshDQNHipError("topology kernel failed inside rollout_device")
-        self._sync_host_from_device(d_steps, out["dones"][-1] if K and self.auto_reset else None)
+        self._sync_host_from_device(ro["d_steps"], out["dones"][-1] if K and self.auto_reset else None)
         return out
 
     def _sync_host_from_device(self, d_steps, last_done=None):
