@@ -325,35 +325,56 @@ def measure_s2_full_chip(args, dev, topo, x, envs=256):
 
 def measure_train(args, dev, dist, world):
     """The learning loop of airfoil_dqn.py:428-503 at scale (BASELINE configs[3]): per batched step every rank steps
-    its envs (S1), pushes B transitions, and all ranks take ONE optimiser step on the all-reduced (RCCL) gradient of
-    a 32-transition minibatch each.  Returns env-steps/s over all ranks."""
+    its envs, pushes B transitions, and all ranks take ONE optimiser step on the all-reduced (RCCL) gradient of a
+    32-transition minibatch each.  Measured for the device-resident loop (`train_loop_device`: no host round trip inside
+    a step) on the S3 env step (the headline's) and on S1, and for the host-driven loop (`train_loop_vec`) on S1.
+    Returns env-steps/s over all ranks (value = the S3 device loop)."""
     import torch
-    from meshdqn_amd.trainer import DistContext, DQNTrainer, train_loop_vec
+    from meshdqn_amd.trainer import DistContext, DQNTrainer, train_loop_device, train_loop_vec
     from meshdqn_amd.vec_env import VecEnv2DAirfoil
     ctx = DistContext(device=dev)                 # re-uses the process group bench.py has initialised
-    trainer = DQNTrainer(n_actions=180, num_inputs=17, ctx=ctx)
     cfg = _env_config(args)
-    venv = VecEnv2DAirfoil(cfg, args.envs, compute_device=dev, base_env=_BASE_ENVS[args.mesh])
-    train_loop_vec(trainer, venv, 4)              # fills the replay ring past one minibatch, warms the autograd path
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    train_loop_vec(trainer, venv, args.train_steps)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = tt.item()
-    return dict(value=world * args.envs * args.train_steps / el, unit="env steps/s",
-                ms_per_batched_step=el / args.train_steps * 1e3, batched_steps=args.train_steps,
-                what="S1 rollout + GPU-resident replay ring (every batched state stored once) + one double-DQN optimiser "
-                     "step per batched step (minibatch 32 per rank gathered on the device, fused HIP forward for the "
-                     "no-grad network, dense adjacency autograd path of the trained network replayed as a HIP graph, "
-                     "one flat gradient all-reduce over the ranks)")
+
+    def run(loop, flow_steps, n):
+        trainer = DQNTrainer(n_actions=180, num_inputs=17, ctx=ctx)
+        venv = VecEnv2DAirfoil(cfg, args.envs, compute_device=dev, base_env=_BASE_ENVS[args.mesh], flow_steps=flow_steps,
+                               flow_rtol=args.rtol, flow_overlap=flow_steps > 0 and not args.no_flow_overlap)
+        loop(trainer, venv, 4)                    # fills the replay ring past one minibatch, warms every path
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        out = loop(trainer, venv, n)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = tt.item()
+        if hasattr(venv, "flow_wait"):
+            venv.flow_wait()
+        del venv
+        return dict(value=world * args.envs * n / el, ms_per_batched_step=el / n * 1e3, batched_steps=n,
+                    optimiser_steps=len(out["losses"]), last_loss=float(out["losses"][-1]) if out["losses"] else None)
+    def guarded(*a):       # (a side measurement must not take the bench line down; every rank fails or succeeds alike)
+        try:
+            return run(*a)
+        except Exception as exc:  # noqa: BLE001
+            return dict(value=0.0, ms_per_batched_step=None, batched_steps=0, optimiser_steps=0, error=repr(exc))
+    s3 = guarded(train_loop_device, 1, args.train_steps)
+    s1 = guarded(train_loop_device, 0, args.train_steps)
+    host = guarded(train_loop_vec, 0, args.train_steps)
+    best = next((r for r in (s3, s1, host) if r["value"] > 0), s3)
+    return dict(value=best["value"], unit="env steps/s", ms_per_batched_step=best["ms_per_batched_step"],
+                batched_steps=args.train_steps, device_loop_s3=s3, device_loop_s1=s1, host_loop_s1=host,
+                what="per batched step: S3 env step for every env (device-resident: Q-forward, epsilon-greedy choice ... reward / "
+                     "reset logic as kernels), B transitions into the record ring (mdq_replay_step), one double-DQN optimiser "
+                     "step (minibatch 32 per rank: mdq_replay_sample, fused forward of the no-grad network, hand-written "
+                     "forward + backward of the trained one = mdq_gcn_train_step, one flat gradient all-reduce over the "
+                     "ranks, mdq_adam_step) on a second stream beside the smoothing kernel; host_loop_s1 = the host-driven "
+                     "loop (autograd replayed as a HIP graph) on S1 for comparison")
 
 
 def measure_s2(args, dev, dist, world, topos, xs, steps, warmup, spinup, **kw):

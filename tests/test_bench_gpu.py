@@ -43,6 +43,8 @@ def test_bench_single_rank_line(lib_built):
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["s2_ipcs"]["value"] > 0
     for k in ("S1_reference_step", "S2_ipcs_step", "training_loop", "C2_s2_diverged_meshes", "C3_s3_ah93w145", "C5_s2_refined_mesh"):
         assert res["rates"][k]["value"] > 0, (k, res["rates"][k])
+    for k in ("device_loop_s3", "device_loop_s1", "host_loop_s1"):    # learning loop: device-resident (S3, S1) and host-driven
+        assert res["rates"]["training_loop"][k]["value"] > 0 and res["rates"]["training_loop"][k]["optimiser_steps"] > 0
     for k in ("s1_env_steps_per_s", "s2_ipcs_env_steps_per_s", "training_env_steps_per_s"):
         assert res[k] > 0
 

@@ -125,7 +125,7 @@ def test_fused_learning_step_matches_autograd_and_is_reproducible(lib_built, kin
                 pred = fwd(other, bs).gather(1, action.reshape(-1, 1)).squeeze(1)
             ref = torch.nn.HuberLoss()(pred, fwd(net, bn).max(1)[0] * nonfinal * gamma + reward)
         ref.backward()
-        assert abs(loss - float(ref)) < 2e-5 * max(abs(float(ref)), 1e-3)
+        assert abs(loss - float(ref.detach())) < 2e-5 * max(abs(float(ref.detach())), 1e-3)
         scale = max(float(p.grad.abs().max()) for p in net.parameters() if p.grad is not None)
         assert scale > 1e-7
         for name, p in net.named_parameters():

@@ -34,9 +34,12 @@ def main():
                          "counters and the logs (files of restart n carry n 'restart_' / 'RESTART_' prefixes, like the "
                          "reference's RESTART_NUM chain, airfoil_dqn.py:359-366)")
     ap.add_argument("--save-every", type=int, default=50, help="batched steps between checkpoints / log writes (0 = only at the end)")
+    ap.add_argument("--host-loop", action="store_true",
+                    help="host-driven loop (train_loop_vec: autograd replayed as a HIP graph, one read-back per step) instead "
+                         "of the device-resident one (train_loop_device: replay, sampling, forward + backward and Adam as kernels)")
     args = ap.parse_args()
     from meshdqn_amd.env import Env2DAirfoil
-    from meshdqn_amd.trainer import DistContext, DQNTrainer, TrainingLog, train_loop_vec
+    from meshdqn_amd.trainer import DistContext, DQNTrainer, TrainingLog, train_loop_device, train_loop_vec
     from meshdqn_amd.vec_env import VecEnv2DAirfoil
     import torch
     torch.set_num_threads(1)   # (many-core hosts under a CPU quota: the CPU-side tensor ops are tiny, no intra-op pool)
@@ -62,7 +65,8 @@ def main():
             steps_done0 = np.full(args.envs, int(np.mean(steps_done0)), np.int64)
     prefix = "restart_" * restart_num
     base = Env2DAirfoil(cfg, compute_device=ctx.device)          # ground truth + snapshots (the reference's first reset())
-    venv = VecEnv2DAirfoil(cfg, args.envs, compute_device=ctx.device, base_env=base, flow_steps=args.flow_steps)
+    venv = VecEnv2DAirfoil(cfg, args.envs, compute_device=ctx.device, base_env=base, flow_steps=args.flow_steps,
+                           flow_overlap=args.flow_steps > 0)
     log = TrainingLog(args.save_dir, restart=args.restart, restart_num=restart_num) if ctx.rank == 0 else None
 
     def checkpoint(step, steps_done):
@@ -70,10 +74,11 @@ def main():
             trainer.save(args.save_dir, prefix, extra=dict(steps_done=np.asarray(steps_done).copy(), batched_steps=step))
             log.write()                                          # reward / rewards / losses / actions / eps .npy
 
-    out = train_loop_vec(trainer, venv, args.steps, log=log, eps_decay=float(eps.get("decay", 10000)),
-                         eps_start=float(eps.get("start", 1.0)), eps_end=float(eps.get("end", 0.01)),
-                         share_replay=args.share_replay, steps_done0=steps_done0, every=args.save_every,
-                         on_every=checkpoint)
+    device_loop = ctx.device.type == "cuda" and venv.gpu_remesh and not args.host_loop
+    loop = train_loop_device if device_loop else train_loop_vec
+    out = loop(trainer, venv, args.steps, log=log, eps_decay=float(eps.get("decay", 10000)),
+               eps_start=float(eps.get("start", 1.0)), eps_end=float(eps.get("end", 0.01)),
+               share_replay=args.share_replay, steps_done0=steps_done0, every=args.save_every, on_every=checkpoint)
     if ctx.rank == 0:
         os.makedirs(args.save_dir, exist_ok=True)
         checkpoint(args.steps, out["steps_done"])
