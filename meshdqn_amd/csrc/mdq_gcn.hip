@@ -56,7 +56,7 @@ struct Lds {
 // a contiguous part of the edge list four entries per LDS read (esrc / edst / adj are 16-byte aligned; the padding of
 // the last quad never matches).  Counting the (node, part) pairs in lane order, a workgroup-wide inclusive scan
 // (wave shuffles + one exchange of the wave totals) gives every pair the position of its first entry directly.
-__device__ inline void build_csr(const Lds& L, int n, int E) {
+__device__ __forceinline__ void build_csr(const Lds& L, int n, int E) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int E4 = (E + 3) >> 2;
   const int4* d4 = reinterpret_cast<const int4*>(L.edst);
@@ -117,7 +117,7 @@ __device__ inline void build_csr(const Lds& L, int n, int E) {
 // FIN > 0: the feature count is a compile-time constant (the reference's two models: 17 and 2) - the generic
 // version spends most of its instructions on the 32 `f < fin` tests per node (measured: 52 of the kernel's 280 us).
 template <bool ROOT, int FIN>
-__device__ inline void conv_dense_small_fin(const Lds& L, int n, int fin_rt, int C, const float* __restrict__ wl,
+__device__ __forceinline__ void conv_dense_small_fin(const Lds& L, int n, int fin_rt, int C, const float* __restrict__ wl,
                                             const float* __restrict__ b, const float* __restrict__ wr,
                                             const float* A, const float* X) {
   const int tid = threadIdx.x, c = tid % C, g = tid / C, G = WGT / C;
@@ -143,7 +143,7 @@ __device__ inline void conv_dense_small_fin(const Lds& L, int n, int fin_rt, int
   }
 }
 template <bool ROOT>
-__device__ inline void conv_dense_small_fin_any(const Lds& L, int n, int fin, int C, const float* __restrict__ wl,
+__device__ __forceinline__ void conv_dense_small_fin_any(const Lds& L, int n, int fin, int C, const float* __restrict__ wl,
                                                 const float* __restrict__ b, const float* __restrict__ wr,
                                                 const float* A, const float* X) {
   if (fin == 17)
@@ -161,7 +161,7 @@ __device__ inline void conv_dense_small_fin_any(const Lds& L, int n, int fin, in
 // NA = accumulators (nodes) per thread: the unrolled node loop costs its instructions whether a node exists or not,
 // so the pooled levels (18, 2, 1 nodes) run instances with 8 / 1 accumulators instead of the 24 of the widest case.
 template <bool ROOT, int NA>
-__device__ inline void conv_dense_small_n(const Lds& L, int n, int fin, int C, const float* __restrict__ wl,
+__device__ __forceinline__ void conv_dense_small_n(const Lds& L, int n, int fin, int C, const float* __restrict__ wl,
                                           const float* __restrict__ b, const float* __restrict__ wr, const float* A,
                                           const float* X, float* wbuf) {
   constexpr int NACC = NA;   // (shadows the namespace constant inside this instance)
@@ -256,13 +256,15 @@ struct TapeLevel {
 };
 
 // one conv + relu + TopK pool + readout level; features in L.x ([n][fin]) are replaced by the pooled ones
-__device__ inline void run_level(const Lds& L, const Level& lv, int C, double ratio, int& n, int& E, int32_t* perm, float& rmax,
+// TAPE: the training kernel's instance (keeps the rows of the kept nodes); the inference instance carries none of it
+template <bool TAPE = false>
+__device__ __forceinline__ void run_level(const Lds& L, const Level& lv, int C, double ratio, int& n, int& E, int32_t* perm, float& rmax,
                                  float& rmean, int NMAX, const TapeLevel* tape = nullptr) {
   const int tid = threadIdx.x, fin = lv.fin;
 #ifdef MDQ_GCN_TRACE
   long long tq_ = __builtin_amdgcn_s_memtime();
 #endif
-  if (tape && tape->esrc)
+  if (TAPE && tape->esrc)
     for (int e = tid; e < E; e += WGT) {
       tape->esrc[e] = L.esrc[e];
       tape->edst[e] = L.edst[e];
@@ -377,7 +379,7 @@ __device__ inline void run_level(const Lds& L, const Level& lv, int C, double ra
   }
   __syncthreads();
   GT_STAMP(4)
-  if (tape) {   // rows of the kept nodes, before the pooled features overwrite the level input
+  if (TAPE) {   // rows of the kept nodes, before the pooled features overwrite the level input
     for (int idx = tid; idx < n * C; idx += WGT) {
       const int i = idx / C, c = idx - i * C, r = L.newid[i];
       if (r >= 0) tape->hsel[r * C + c] = L.h[i * (C + 1) + c];
@@ -447,13 +449,13 @@ __device__ inline void run_level(const Lds& L, const Level& lv, int C, double ra
     int arg = 0;
     for (int r = 0; r < n; ++r) {
       const float v = L.x[r * C + tid];
-      if (v > mx) arg = r;      // first maximum (where torch's max sends the gradient)
+      if (TAPE && v > mx) arg = r;      // first maximum (where torch's max sends the gradient)
       mx = fmaxf(mx, v);
       sm += v;
     }
     rmax += mx;
     rmean += sm / (float)n;
-    if (tape) tape->amax[tid] = arg;
+    if (TAPE) tape->amax[tid] = arg;
   }
   __syncthreads();
   GT_STAMP(7)

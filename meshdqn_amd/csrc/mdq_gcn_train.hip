@@ -176,7 +176,7 @@ __global__ __launch_bounds__(WGT) void gcn_train_kernel(mdq_gcn_net net, mdq_gcn
     tp[l].edst = off[l].edst >= 0 ? reinterpret_cast<int*>(ws + off[l].edst) : nullptr;
     nl[l] = n;
     El[l] = E;
-    run_level(L, lv, C, net.ratio, n, E, nullptr, rmax, rmean, NMAX, &tp[l]);
+    run_level<true>(L, lv, C, net.ratio, n, E, nullptr, rmax, rmean, NMAX, &tp[l]);
     kl[l] = n;
     TP_STAMP(1 + l)
   }

@@ -9,9 +9,10 @@ mkdir -p $OUT
 cd $R && python3 bench.py > $OUT/r02_bench.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
 ARGS="--no-cpu-baseline --train-steps 0 --no-configs"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py $ARGS > $OUT/r02_bench_profiled.json 2> $OUT/kt.log
+# (the kernel trace includes the learning loops: gcn_train_kernel, replay / Adam kernels)
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py --no-cpu-baseline --no-configs > $OUT/r02_bench_profiled.json 2> $OUT/kt.log
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d $OUT/$C -- python3 $R/bench.py $ARGS --s1-steps 0 --s2-steps 20 --spinup 20 --repeats 2 > $OUT/$C.log 2>&1
+  timeout 600 rocprofv3 --pmc $C --output-format csv -d $OUT/$C -- python3 $R/bench.py $ARGS --s1-steps 0 --s2-steps 20 --spinup 20 --repeats 2 > $OUT/$C.log 2>&1
 done
 cd $R
 python3 - "$OUT" <<'PY'
@@ -45,7 +46,7 @@ if sm:
                hbm_bytes_per_launch=(2 * f_ + w_) * 1024)
 json.dump(pmc, open(f"{out}/r02_smooth_pmc_summary.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in pmc.items() if k != "per_kernel"}, indent=1))
-print(json.dumps({k: v for k, v in summ.items() if "smooth" in k or "topology" in k or "gcn" in k}, indent=1))
+print(json.dumps({k: v for k, v in summ.items() if "smooth" in k or "topology" in k or "gcn" in k or "replay" in k or "adam" in k}, indent=1))
 PY
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*agent_info.csv" -delete; find $OUT -name "*counter_collection.csv" -delete
 ls $OUT
