@@ -339,12 +339,13 @@ def measure_train(args, dev, dist, world):
         trainer = DQNTrainer(n_actions=180, num_inputs=17, ctx=ctx)
         venv = VecEnv2DAirfoil(cfg, args.envs, compute_device=dev, base_env=_BASE_ENVS[args.mesh], flow_steps=flow_steps,
                                flow_rtol=args.rtol, flow_overlap=flow_steps > 0 and not args.no_flow_overlap)
-        loop(trainer, venv, 4)                    # fills the replay ring past one minibatch, warms every path
+        kw = dict(share_replay=True) if args.share_replay else {}
+        loop(trainer, venv, 4, **kw)              # fills the replay ring past one minibatch, warms every path
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         t0 = time.perf_counter()
-        out = loop(trainer, venv, n)
+        out = loop(trainer, venv, n, **kw)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -357,7 +358,9 @@ def measure_train(args, dev, dist, world):
             venv.flow_wait()
         del venv
         return dict(value=world * args.envs * n / el, ms_per_batched_step=el / n * 1e3, batched_steps=n,
-                    optimiser_steps=len(out["losses"]), last_loss=float(out["losses"][-1]) if out["losses"] else None)
+                    optimiser_steps=len(out["losses"]), last_loss=float(out["losses"][-1]) if out["losses"] else None,
+                    shared_replay=bool(args.share_replay and world > 1),
+                    replay_records=int(trainer.device_memory.size()) if trainer.device_memory is not None else None)
     def guarded(*a):       # (a side measurement must not take the bench line down; every rank fails or succeeds alike)
         try:
             return run(*a)
@@ -441,6 +444,8 @@ def main():
     ap.add_argument("--s1-steps", type=int, default=50, help="batched steps of the S1 / C3 side measurements (0 = skip all side measurements)")
     ap.add_argument("--cell-order", default="conflictfree", choices=["mesh", "conflictfree"])
     ap.add_argument("--train-steps", type=int, default=20, help="batched learning-loop steps (0 = skip)")
+    ap.add_argument("--share-replay", action="store_true",
+                    help="learning loops with the shared replay: every rank all-gathers the transition records of all ranks")
     ap.add_argument("--s1-warmup", type=int, default=40)
     ap.add_argument("--env-groups", type=int, default=1, help="concurrently stepped env groups per GPU for S1 / S3")
     ap.add_argument("--s1-solver-steps", type=int, default=5000, help="IPCS steps of the ground-truth reset()")

@@ -1131,7 +1131,7 @@ def train_loop_device(trainer: DQNTrainer, venv, num_steps: int, optim_per_step:
         trainer._opt_stream = torch.cuda.Stream(device=dev)
     opt_stream = trainer._opt_stream
     rep = None
-    rewards, dones_hist, losses = [], [], []
+    rewards, dones_hist, losses, actions_hist = [], [], [], []
     ep_r = [[] for _ in range(B)]
     ep_a = [[] for _ in range(B)]
     step_no, prev = 0, None      # prev: (record base, act, rew, done) of the step whose records await their next state
@@ -1157,11 +1157,12 @@ def train_loop_device(trainer: DQNTrainer, venv, num_steps: int, optim_per_step:
             if not isinstance(rep, SharedDeviceReplay) or (rep.capacity, rep.N, rep.F) != (cap, N, F):
                 rep = trainer.device_memory = SharedDeviceReplay(cap, N, F, trainer.e_max, dev)
             G = rep.capacity // W
+            t0 = int(getattr(rep, "steps_pushed", 0))           # the ring continues where an earlier call stopped
             loss_ring = torch.zeros(int(chunk) * max(1, optim_per_step), dtype=torch.float32, device=dev)
         # minibatches of the chunk: the number of finished records at every step is known in advance; one upload
         mbs = []
         for k in range(K):
-            t = step_no + k
+            t = t0 + step_no + k
             count = min(t, G - 1) * W                          # finished groups (the one being written is not)
             for _k in range(optim_per_step if count >= trainer.batch_size else 0):
                 idx = np.asarray(random.sample(range(count), trainer.batch_size), np.int64)
@@ -1171,7 +1172,7 @@ def train_loop_device(trainer: DQNTrainer, venv, num_steps: int, optim_per_step:
         mb_dev = torch.from_numpy(np.stack(mbs)).to(dev) if mbs else None
         n_loss = 0
         for k in range(K):
-            g = (step_no + k) % G                              # the ring group this step's records go to
+            g = (t0 + step_no + k) % G                         # the ring group this step's records go to
             main.wait_stream(opt_stream)                       # the weights of the previous optimiser step
             fused1._pack()
             fused2._pack()
@@ -1182,12 +1183,11 @@ def train_loop_device(trainer: DQNTrainer, venv, num_steps: int, optim_per_step:
                                            None if prev is None else prev[1].data_ptr(), None if prev is None else prev[2].data_ptr(),
                                            None if prev is None else prev[3].data_ptr(), _lib.stream_ptr()), "mdq_replay_step")
             if prev is not None and W != B:                    # shared replay: everybody's finished records of that step
-                gp = prev[0] // W
-                own = rep.R[prev[0]:prev[0] + B].clone()
-                dist.all_gather_into_tensor(rep.R[gp * W:(gp + 1) * W].view(-1), own.view(-1))
+                gp = prev[0] // W                               # (rank r's B records sit at group base + r * B on every rank)
+                rep.R[gp * W:(gp + 1) * W].copy_(allgather_records(ctx, rep.R[prev[0]:prev[0] + B].clone()))
             ev = torch.cuda.Event()
             ev.record(main)
-            if min(step_no + k, G - 1) * W >= trainer.batch_size:
+            if min(t0 + step_no + k, G - 1) * W >= trainer.batch_size:
                 with torch.cuda.stream(opt_stream):
                     opt_stream.wait_event(ev)
                     for _k in range(optim_per_step):
@@ -1196,6 +1196,17 @@ def train_loop_device(trainer: DQNTrainer, venv, num_steps: int, optim_per_step:
             venv.rollout_step(ro, fused1)
             prev = (base_cur, ro["act"][k], ro["rew"][k], ro["done"][k])
             st = ro["state"]
+        if step_no + K >= num_steps and prev is not None:       # last chunk: finish the records of the last step too
+            _lib.check(lib.mdq_replay_step(rep.R.data_ptr(), rep.rec_len, rep.capacity, B, N * st["x"].shape[2], rep.e_max,
+                                           st["x"].data_ptr(), st["edge_src_pad"].data_ptr(), st["edge_dst_pad"].data_ptr(),
+                                           st["nedges_dev"].data_ptr(), -1, prev[0], prev[1].data_ptr(), prev[2].data_ptr(),
+                                           prev[3].data_ptr(), _lib.stream_ptr()), "mdq_replay_step")
+            if W != B:
+                gp = prev[0] // W
+                rep.R[gp * W:(gp + 1) * W].copy_(allgather_records(ctx, rep.R[prev[0]:prev[0] + B].clone()))
+            rep.steps_pushed = t0 + num_steps
+            rep.count = min(rep.steps_pushed, G) * W
+            rep.position = (rep.steps_pushed % G) * W
         out = venv.rollout_end(ro)                              # the one synchronisation of the chunk
         new_losses = loss_ring[:n_loss].cpu().numpy().tolist()
         trainer.losses.extend(new_losses)
@@ -1204,6 +1215,7 @@ def train_loop_device(trainer: DQNTrainer, venv, num_steps: int, optim_per_step:
             rew, done = out["rewards"][k], out["dones"][k]
             rewards.append(rew.copy())
             dones_hist.append(done.copy())
+            actions_hist.append(out["actions"][k].copy())
             if log is not None:
                 log.add_eps(eps_mean[k])
                 for b in range(B):
@@ -1218,4 +1230,5 @@ def train_loop_device(trainer: DQNTrainer, venv, num_steps: int, optim_per_step:
         step_no += K
         if every and on_every is not None and (step_no // every) > ((step_no - K) // every):
             on_every(step_no, steps_done)
-    return dict(rewards=np.array(rewards), dones=np.array(dones_hist), losses=list(trainer.losses), steps_done=steps_done)
+    return dict(rewards=np.array(rewards), dones=np.array(dones_hist), losses=list(trainer.losses), steps_done=steps_done,
+                actions=np.array(actions_hist))

@@ -52,8 +52,11 @@ def test_bench_single_rank_line(lib_built):
 def test_bench_two_ranks_share_one_gpu(lib_built):
     env = dict(os.environ, MDQ_SHARE_GPU="1", MDQ_DIST_BACKEND="gloo")
     res = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                 "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2"] + SMALL, env)
+                 "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2", "--share-replay"] + SMALL, env)
     assert KEYS <= set(res) and "cpu_baseline" not in res          # the CPU leg is rank 0 at N = 1 only
     assert res["n_gpus"] == 2
     assert abs(res["value"] - 2 * 16 * 6 / (res["ms_per_step"] * 6e-3)) < 1e-6 * res["value"]
     assert res["rates"]["training_loop"]["value"] > 0 and res["config"]["collective_backend"]["ranks"] == 2
+    for k in ("device_loop_s3", "device_loop_s1", "host_loop_s1"):   # every loop ran (no fallback), with the record all-gather
+        r = res["rates"]["training_loop"][k]
+        assert "error" not in r and r["optimiser_steps"] > 0 and r["shared_replay"], (k, r)

@@ -155,3 +155,46 @@ def test_device_learning_loop_follows_the_host_loop(lib_built):
     for (name, p), q in zip(trainers[0].policy_net_1.named_parameters(), trainers[1].policy_net_1.parameters()):
         assert float((p - q).detach().abs().max()) < 2e-4 * max(1e-2, float(p.detach().abs().max())), name
     assert trainers[0].num_grads == trainers[1].num_grads and trainers[0].select == trainers[1].select
+
+
+def test_device_loop_record_ring_wraps_and_continues(lib_built):
+    """A record ring much smaller than the run (5 groups of B records): the two halves of `mdq_replay_step` land in the
+    right records across the wrap-around and across two calls of the loop (the second continues the ring): every
+    record carries the action / reward / done of the step that wrote it last, and the next state of a non-terminal
+    transition is the state its environment's next transition starts from."""
+    from meshdqn_amd.env import Env2DAirfoil
+    from meshdqn_amd.trainer import DistContext, DQNTrainer, train_loop_device
+    from meshdqn_amd.vec_env import VecEnv2DAirfoil
+    cfg = _cfg()
+    np.random.seed(5)
+    random.seed(5)
+    B, G = 6, 5
+    tr = DQNTrainer(n_actions=180, num_inputs=17, ctx=DistContext(), batch_size=8, lr=1e-3, replay_capacity=B * G)
+    venv = VecEnv2DAirfoil(cfg, B, base_env=Env2DAirfoil(cfg), nthreads=2)
+    outs = [train_loop_device(tr, venv, 7, eps_decay=2, chunk=3)]
+    rep = tr.device_memory
+    assert rep.capacity == B * G and rep.steps_pushed == 7 and rep.size() == B * G
+    assert len(outs[0]["losses"]) == 5 and np.isfinite(outs[0]["losses"]).all()      # steps 2..6 (12 >= 8 records from step 2)
+
+    def check(acts, rews, dones, t_last):
+        R = rep.R.cpu().numpy()
+        nf, EM = rep.N * rep.F, rep.e_max
+        off = 2 * nf + 4 * EM
+        for t in range(t_last - G + 1, t_last + 1):             # the G steps whose records are in the ring
+            rows = R[(t % G) * B:(t % G + 1) * B]
+            assert np.array_equal(rows[:, off + 2], acts[t].astype(np.float32)), t
+            assert np.allclose(rows[:, off + 3], rews[t].astype(np.float32), rtol=0, atol=0) and np.array_equal(rows[:, off + 4] > 0.5, dones[t]), t
+            assert (rows[dones[t], nf:2 * nf] == 0).all() and (rows[dones[t], off + 1] == 0).all()
+            if t < t_last:                                       # s' of step t = s of step t + 1 of the same environment
+                nxt = R[((t + 1) % G) * B:((t + 1) % G + 1) * B]
+                live = ~dones[t]
+                assert np.array_equal(rows[live, nf:2 * nf], nxt[live, :nf]) and np.array_equal(rows[live, off + 1], nxt[live, off])
+                assert np.array_equal(rows[live][:, 2 * nf + 2 * EM:off], nxt[live][:, 2 * nf:2 * nf + 2 * EM])
+    check(outs[0]["actions"], outs[0]["rewards"], outs[0]["dones"], 6)
+    outs.append(train_loop_device(tr, venv, 4, eps_decay=2, chunk=3))                # continues the ring: steps 7..10
+    assert rep.steps_pushed == 11
+    acts = np.concatenate([o["actions"] for o in outs])
+    rews = np.concatenate([o["rewards"] for o in outs])
+    dones = np.concatenate([o["dones"] for o in outs])
+    check(acts, rews, dones, 10)
+    assert len(outs[1]["losses"]) == 5 + 4 and np.isfinite(outs[1]["losses"]).all()  # every step of the second call optimises
