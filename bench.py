@@ -186,7 +186,7 @@ def _timed(dist, dev, fn):
     return el
 
 
-def measure_env_steps(args, dev, dist, world, flow_steps=0, steps=None, warmup=8, repeats=1, mesh=None, keep=None):
+def measure_env_steps(args, dev, dist, world, flow_steps=0, steps=None, warmup=8, repeats=1, mesh=None, keep=None, envs=None):
     """Units of work S1 / S3 for every env of the batch, all on the GPU: vertex removal + Delaunay
     restoration (mdq_remesh), smooth(50) (mdq_smooth), topology / N-closest / state graph (mdq_env_topology), snapshot
     interpolation + 10 force integrals + node features, fused Q-network forward + epsilon-greedy action; with
@@ -200,7 +200,7 @@ def measure_env_steps(args, dev, dist, world, flow_steps=0, steps=None, warmup=8
     mesh = mesh or args.mesh
     steps = steps or args.s1_steps
     cfg = _env_config(args, mesh)
-    B = args.envs
+    B = envs or args.envs
     if mesh not in _BASE_ENVS:
         _BASE_ENVS[mesh] = Env2DAirfoil(cfg, compute_device=dev)      # ground truth + snapshots: 5000 IPCS steps, once
     base = _BASE_ENVS[mesh]
@@ -585,6 +585,14 @@ def main():
             cfgs["C3_s3_ah93w145"] = c3
         except Exception as exc:  # noqa: BLE001
             cfgs["C3_s3_ah93w145"] = dict(error=repr(exc))
+        try:
+            f3 = measure_env_steps(args, dev, None, 1, 1, steps=args.s1_steps, repeats=3, envs=2 * B)
+            f3["what"] = (f"the S3 step with {2 * B} envs on the GPU (one workgroup per env on every CU): at the BASELINE batch of "
+                          f"{B} the kernels of the step are latency-bound with half of the chip idle; twice the batch costs "
+                          "less than twice the time (the IPCS leg no longer hides beside a smoothing kernel that owns every CU)")
+            cfgs["S3_full_chip"] = f3
+        except Exception as exc:  # noqa: BLE001
+            cfgs["S3_full_chip"] = dict(error=repr(exc))
         try:
             from meshdqn_amd.mesh_ops import red_refine
             rc_, rcells = red_refine(x, z["cells"])

@@ -41,7 +41,8 @@ def test_bench_single_rank_line(lib_built):
     assert res["roofline_s2_velocity"]["bound"] == "lds-atomic/fp64"
     cpu = res["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["s2_ipcs"]["value"] > 0
-    for k in ("S1_reference_step", "S2_ipcs_step", "training_loop", "C2_s2_diverged_meshes", "C3_s3_ah93w145", "C5_s2_refined_mesh"):
+    for k in ("S1_reference_step", "S2_ipcs_step", "training_loop", "C2_s2_diverged_meshes", "C3_s3_ah93w145", "S3_full_chip",
+              "C5_s2_refined_mesh"):
         assert res["rates"][k]["value"] > 0, (k, res["rates"][k])
     for k in ("device_loop_s3", "device_loop_s1", "host_loop_s1"):    # learning loop: device-resident (S3, S1) and host-driven
         assert res["rates"]["training_loop"][k]["value"] > 0 and res["rates"]["training_loop"][k]["optimiser_steps"] > 0
