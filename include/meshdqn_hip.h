@@ -200,6 +200,19 @@ int mdq_ipcs_evolve_timed(const mdq_ipcs_desc* d, int32_t nsteps, double* drag, 
 int mdq_probe_forces(const mdq_ipcs_desc* d, int32_t nfields, const double* u, const double* p,
                      double* drag, double* lift, void* stream);
 
+/*
+ * The factorisation half of `LUSolver("mumps")` (flow_solver.py:150-159; repeated by the reference for every
+ * coarsened mesh, :318-328) on the device: builds the substructuring factors pd_* of every environment's scaled,
+ * boundary-eliminated pressure matrix (K1s, as written by mdq_ipcs_assemble / mdq_ipcs_setup_matfree) - recursive
+ * coordinate bisection into 8 parts, vertex separator, dense inverses of the interior blocks and of the Schur
+ * complement by Gauss-Jordan in LDS.  The pd_* arrays of `d` must be allocated with capacities NPART >= 8,
+ * NPW >= 8 * 112^2, NPF >= 8 * 112 * 48, NPGI >= 8 * 48, NPS >= 112^2, NPGK >= 112 * 16 (written here although the
+ * descriptor declares them const: they are this call's outputs).  status (device int32 [B], may be NULL): 0 ok;
+ * < 0: the mesh exceeds those limits - its header says nparts = 0 and mdq_ipcs_evolve (pd_enabled = 1) runs the
+ * Krylov pressure solve for that environment.
+ */
+int mdq_ipcs_factorize_pressure(const mdq_ipcs_desc* d, int32_t* status, void* stream);
+
 /* ---- graph Q-network forward (airfoilgcnn.py:85-145 NodeRemovalNet, :170-209 AirfoilGCNN) ---- */
 typedef struct mdq_gcn_level {
   int32_t type;          /* 0 = SAGEConv (mean aggr, root weight), 1 = GCNConv (self loops, sym. norm) */

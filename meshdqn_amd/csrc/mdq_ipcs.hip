@@ -2841,7 +2841,9 @@ __global__ __launch_bounds__(NTH) void at_pressure_kernel(mdq_ipcs_desc d, int32
       pr[i] = v.bcp_flag[i] ? 0.0 : pr[i] / sd;
       px[i] = v.p_n[i] * sd;
     }
-    if (d.pd_enabled) {
+    // (an environment whose factors could not be built on the device - mdq_ipcs_factorize_pressure, header nparts = 0 -
+    // falls back to the Krylov solve)
+    if (d.pd_enabled && d.pd_hdr[4 * (int64_t)b + 2] > 0) {
       const PdView pd = pd_view(d, b);
 #ifdef MDQ_AT_TRACE
       { const long long tn_ = __builtin_amdgcn_s_memtime(); if (tid == 0 && b == 0) mdq_pt_trace_buf[0] += tn_ - tq0_; }

@@ -1,6 +1,7 @@
 // Single translation unit of libmeshdqn_hip.so (keeps __constant__ tables and
 // the thread-local error string in one place; no relocatable device code needed).
 #include "mdq_ipcs.hip"
+#include "mdq_pressure_factor.hip"
 #include "mdq_gcn.hip"
 #include "mdq_gcn_train.hip"
 #include "mdq_replay.hip"

@@ -130,7 +130,7 @@ class FlowSolver(object):
         if reassemble:
             self.batch = IpcsBatch([topo], [topo.coords], mu=self.mu, rho=self.rho, dt=self.dt_value,
                                    rtol=self.rtol, device=self.device,
-                                   pressure_direct=(self.solver_type == "lu"))
+                                   pressure_direct=("device" if self.solver_type == "lu" else False))
             self.batch.assemble()
             self.u_n = Function(topo, self.batch.u_n[0, :n2], "velocity")
             self.p_n = Function(topo, self.batch.p_n[0, :nv], "pressure")

@@ -171,7 +171,9 @@ class IpcsBatch:
         d.pd_enabled = 0
         self.desc = d
         self.assembled = False
-        self.pressure_direct = bool(pressure_direct)
+        # True: substructuring factors built on the host (numpy, pressure_direct.py); "device": built by
+        # mdq_ipcs_factorize_pressure (one workgroup per environment, no host work); False: Jacobi-CG
+        self.pressure_direct = "device" if pressure_direct == "device" else bool(pressure_direct)
         self.pressure_parts = int(pressure_parts)
         self._pd_cache = {}
 
@@ -244,8 +246,40 @@ class IpcsBatch:
         rc = self.lib.mdq_ipcs_assemble(C.byref(self.desc), _lib.stream_ptr(stream))
         _lib.check(rc, "mdq_ipcs_assemble")
         self.assembled = True
-        if self.pressure_direct:
+        if self.pressure_direct == "device":
+            self.factorize_pressure_device(stream)
+        elif self.pressure_direct:
             self._factorize_pressure()
+
+    # capacities of the device-built factors (limits of mdq_ipcs_factorize_pressure: 8 parts, 112 interior nodes per
+    # part, 48 separator nodes per part, 112 separator nodes)
+    PD_DEVICE_CAP = dict(NPART=8, NPW=8 * 112 * 112, NPF=8 * 112 * 48, NPGI=8 * 48, NPS=112 * 112, NPGK=4096)
+
+    def factorize_pressure_device(self, stream=None):
+        """The factorisation of every environment's pressure matrix ON THE DEVICE (`mdq_ipcs_factorize_pressure`: the
+        reference re-factorises with MUMPS after every remesh, flow_solver.py:318-328): fills the pd_* arrays the
+        solve phase reads and switches the descriptor to the direct solve.  Needs the operators' set-up data (after
+        `assemble()` or `mdq_ipcs_setup_matfree`).  `self.pd_status` (device int32 [B]): 0, or < 0 where a mesh exceeds
+        the kernel's limits (that environment keeps the Krylov solve)."""
+        d, B, NV, dev = self.desc, self.B, self.cap["NV"], self.device
+        if getattr(self, "_pd_dev", None) is None:
+            cap = self.PD_DEVICE_CAP
+            i32, f64 = torch.int32, torch.float64
+            z = lambda n, dt: torch.zeros((B, n), dtype=dt, device=dev)   # noqa: E731
+            self._pd_dev = dict(pd_hdr=z(4, i32), pd_node=z(NV, i32), pd_meta=z(cap["NPART"] * 6, i32), pd_rowblk=z(NV, i32),
+                                pd_W=z(cap["NPW"], f64), pd_F=z(cap["NPF"], f64), pd_gidx=z(cap["NPGI"], i32),
+                                pd_Sinv=z(cap["NPS"], f64), pd_gk_ptr=z(NV + 1, i32), pd_gk_col=z(cap["NPGK"], i32),
+                                pd_gk_val=z(cap["NPGK"], f64))
+            self.pd_status = torch.zeros(B, dtype=i32, device=dev)
+        for k, a in self._pd_dev.items():
+            self.t[k] = a
+            setattr(d, k, a.data_ptr())
+        cap = self.PD_DEVICE_CAP
+        d.NPART, d.NPW, d.NPF, d.NPGI, d.NPS, d.NPGK = (cap[k] for k in ("NPART", "NPW", "NPF", "NPGI", "NPS", "NPGK"))
+        _lib.check(self.lib.mdq_ipcs_factorize_pressure(C.byref(d), self.pd_status.data_ptr(), _lib.stream_ptr(stream)),
+                   "mdq_ipcs_factorize_pressure")
+        d.pd_enabled = 1
+        self.pds = None
 
     def update_inflow(self, profile, time: float, stream=None):
         """Time dependent inflow (flow_solver.py:70-73,369-371: `inflow.time = gtime` before the three assemblies apply

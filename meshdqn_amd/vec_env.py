@@ -46,7 +46,7 @@ class VecEnv2DAirfoil:
     def __init__(self, config, num_envs: int, compute_device="cuda", nthreads: int = 0, base_env: Env2DAirfoil | None = None,
                  auto_reset: bool = True, emax: int = 1536, flow_steps: int = 0, flow_rtol: float = 1e-10,
                  gpu_smoothing: bool = True, gpu_topology: bool = True, gpu_remesh: bool = True,
-                 flow_overlap: bool = False):
+                 flow_overlap: bool = False, flow_pressure: str = "cg"):
         self.lib = _lib.load()
         self.B = int(num_envs)
         self.device = torch.device(compute_device)
@@ -70,6 +70,12 @@ class VecEnv2DAirfoil:
         # (`infos["flow_lag"] = 1`).  The streams must sit on different hardware queues: GPU_MAX_HW_QUEUES >= 8 (set by
         # the package at import when the variable is not set)
         self.flow_overlap = bool(flow_overlap) and self.flow_steps > 0 and self.gpu_remesh
+        # pressure solve of the S3 flow step on the freshly coarsened mesh: "cg" (Jacobi-CG, ~160 iterations, 0.28 ms) or
+        # "direct" (the reference's behaviour: re-factorise after every remesh - mdq_ipcs_factorize_pressure on the
+        # device, 2.3 ms per batch, then 0 iterations; worth it only when a mesh is solved on many times)
+        if flow_pressure not in ("cg", "direct"):
+            raise ValueError("flow_pressure: 'cg' or 'direct'")
+        self.flow_pressure = flow_pressure
         base = base_env or Env2DAirfoil(config, compute_device=compute_device)
         self.base = base
         ap = config["agent_params"]
@@ -175,6 +181,22 @@ class VecEnv2DAirfoil:
             self.flow_descs.append(d)
             self.flow_ts.append(t)
         self.flow_t, self.flow_desc = self.flow_ts[0], self.flow_descs[0]
+        if self.flow_pressure == "direct":      # outputs of mdq_ipcs_factorize_pressure (capacities: its limits)
+            from .ipcs_batch import IpcsBatch
+            cap = IpcsBatch.PD_DEVICE_CAP
+            i32, f64 = torch.int32, torch.float64
+            zz = lambda n, dt_: torch.zeros((B, n), dtype=dt_, device=dev)   # noqa: E731
+            pdt = dict(pd_hdr=zz(4, i32), pd_node=zz(NV, i32), pd_meta=zz(cap["NPART"] * 6, i32), pd_rowblk=zz(NV, i32),
+                       pd_W=zz(cap["NPW"], f64), pd_F=zz(cap["NPF"], f64), pd_gidx=zz(cap["NPGI"], i32),
+                       pd_Sinv=zz(cap["NPS"], f64), pd_gk_ptr=zz(NV + 1, i32), pd_gk_col=zz(cap["NPGK"], i32),
+                       pd_gk_val=zz(cap["NPGK"], f64))
+            for t, d in zip(self.flow_ts, self.flow_descs):
+                t.update(pdt)
+                for k, a in pdt.items():
+                    setattr(d, k, a.data_ptr())
+                d.NPART, d.NPW, d.NPF, d.NPGI, d.NPS, d.NPGK = (cap[k] for k in ("NPART", "NPW", "NPF", "NPGI", "NPS", "NPGK"))
+                d.pd_enabled = 1
+            self.flow_pd_status = torch.zeros(B, dtype=i32, device=dev)
         self.flow_iters = torch.zeros((B, 3), dtype=torch.int32, device=dev)
         self.flow_drag = np.zeros((B, self.flow_steps))
         self.flow_lift = np.zeros((B, self.flow_steps))
@@ -206,6 +228,9 @@ class VecEnv2DAirfoil:
         t["work"].zero_()            # no initial-guess history on a new mesh
         self.flow_iters.zero_()
         _lib.check(self.lib.mdq_ipcs_setup_matfree(C.byref(d), _lib.stream_ptr()), "mdq_ipcs_setup_matfree")
+        if self.flow_pressure == "direct":
+            _lib.check(self.lib.mdq_ipcs_factorize_pressure(C.byref(d), self.flow_pd_status.data_ptr(), _lib.stream_ptr()),
+                       "mdq_ipcs_factorize_pressure")
         drag = torch.empty((self.B, self.flow_steps), dtype=torch.float64, device=self.device)
         lift = torch.empty_like(drag)
         _lib.check(self.lib.mdq_ipcs_evolve(C.byref(d), self.flow_steps, drag.data_ptr(), lift.data_ptr(),

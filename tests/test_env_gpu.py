@@ -158,16 +158,20 @@ def test_vec_env_matches_single_envs(lib_built):
             assert info["nv"][b] == len(singles[b].flow_solver.mesh.coordinates())
 
 
-def test_vec_env_flow_step_matches_oracle(lib_built):
+@pytest.mark.parametrize("pressure", ["cg", "direct"])
+def test_vec_env_flow_step_matches_oracle(lib_built, pressure):
     """S3: after every batched remesh, IPCS steps on the coarsened meshes (host-engine index data + pattern-free GPU
     setup + matrix-free kernels, warm start = interpolated last snapshot) against the sparse-LU oracle solver built
-    on the very same mesh and started from the same fields."""
+    on the very same mesh and started from the same fields.  `direct`: the pressure matrix of every coarsened mesh is
+    re-factorised on the device (mdq_ipcs_factorize_pressure; the reference re-factorises at every remesh,
+    flow_solver.py:318-328): no Krylov iteration in the pressure solve."""
     from meshdqn_amd.env import Env2DAirfoil
     from meshdqn_amd.vec_env import VecEnv2DAirfoil
     from oracle.ipcs import OracleFlowSolver
     cfg = _config("ys930")
     B, K = 2, 2
-    venv = VecEnv2DAirfoil(cfg, B, base_env=Env2DAirfoil(cfg), auto_reset=False, nthreads=2, flow_steps=K, flow_rtol=1e-12)
+    venv = VecEnv2DAirfoil(cfg, B, base_env=Env2DAirfoil(cfg), auto_reset=False, nthreads=2, flow_steps=K, flow_rtol=1e-12,
+                           flow_pressure=pressure)
     rngs = [np.random.default_rng(77 + b) for b in range(B)]
     venv.get_state()
     for k in range(3):
@@ -175,7 +179,10 @@ def test_vec_env_flow_step_matches_oracle(lib_built):
         st, rew, done, info = venv.step(acts)
         assert info["flow_drag"].shape == (B, K)
         it = venv.flow_iters.cpu().numpy()
-        assert (it > 0).all()
+        if pressure == "direct":
+            assert (it[:, [0, 2]] > 0).all() and (it[:, 1] == 0).all() and (venv.flow_pd_status.cpu().numpy() == 0).all()
+        else:
+            assert (it > 0).all()
         for b in range(B):
             nv, nt = int(venv.nv[b]), int(venv.nt[b])
             ne = int(venv.h["ne"][b])

@@ -64,10 +64,12 @@ def test_assembly_matches_oracle(meshes, oracle_solvers, lib_built):
         assert np.abs(l3 - o.lift3)[free].max() <= 1e-13 * max(1.0, np.abs(o.lift3).max())
 
 
-@pytest.mark.parametrize("mode,direct", [(3, True), (3, False), (2, True), (2, False), (1, True), (1, False), (0, False)])
+@pytest.mark.parametrize("mode,direct", [(3, True), (3, False), (3, "device"), (2, True), (2, False), (2, "device"), (1, True),
+                                         (1, False), (0, False)])
 def test_first_steps_match_oracle(meshes, lib_built, mode, direct):
     """Per-step parity of u, p, drag, lift against the sparse-LU oracle, for every operator
-    mode (0/1 assembled SELL, 2 matrix-free tiles) and both pressure solvers (direct / CG)."""
+    mode (0/1 assembled SELL, 2 matrix-free tiles) and the pressure solvers (direct with factors built on the host /
+    on the device by mdq_ipcs_factorize_pressure, CG)."""
     import torch
     from oracle.ipcs import OracleFlowSolver
     names = ["ys930", "ah93w145"]
@@ -89,6 +91,10 @@ def test_first_steps_match_oracle(meshes, lib_built, mode, direct):
     it = batch.iters.cpu().numpy()
     assert (it[:, 0] > 0).all() and (it[:, 2] > 0).all()
     assert ((it[:, 1] == 0) if direct else (it[:, 1] > 0)).all()
+    if direct == "device":
+        assert (batch.pd_status.cpu().numpy() == 0).all()
+        hdr = batch.t["pd_hdr"].cpu().numpy()
+        assert (hdr[:, 0] + hdr[:, 1] == [o.th.nv for o in oracles]).all() and (hdr[:, 2] == 8).all() and (hdr[:, 1] <= 112).all()
 
 
 def test_multi_step_launch_equals_single_steps(meshes, lib_built):
