@@ -42,8 +42,12 @@ def test_bench_single_rank_line(lib_built):
     cpu = res["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["s2_ipcs"]["value"] > 0
     for k in ("S1_reference_step", "S2_ipcs_step", "training_loop", "C2_s2_diverged_meshes", "C3_s3_ah93w145", "S3_full_chip",
-              "C5_s2_refined_mesh"):
+              "S3_refactorised_pressure", "C5_s2_refined_mesh"):
         assert res["rates"][k]["value"] > 0, (k, res["rates"][k])
+    c2 = res["rates"]["C2_s2_diverged_meshes"]     # factors built on the device for every coarsened mesh: no pressure iterations
+    assert c2["krylov_iters_per_step"]["pressure"] == 0 and c2["factorisation_status_ok"] and c2["factorisation_ms_per_batch"] > 0
+    assert c2["jacobi_cg_variant"]["krylov_iters_per_step"]["pressure"] > 15 and c2["value"] > c2["jacobi_cg_variant"]["value"]
+    assert res["rates"]["S3_refactorised_pressure"]["krylov_iters_per_ipcs_step"]["pressure_cg"] == 0
     for k in ("device_loop_s3", "device_loop_s1", "host_loop_s1"):    # learning loop: device-resident (S3, S1) and host-driven
         assert res["rates"]["training_loop"][k]["value"] > 0 and res["rates"]["training_loop"][k]["optimiser_steps"] > 0
     for k in ("s1_env_steps_per_s", "s2_ipcs_env_steps_per_s", "training_env_steps_per_s"):
