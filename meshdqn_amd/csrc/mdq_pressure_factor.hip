@@ -15,6 +15,18 @@
 
 namespace mdq_pf {
 
+#ifdef MDQ_PF_TRACE
+__device__ long long mdq_pf_trace_buf[16];
+#define PF_STAMP(k) { const long long tn_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) mdq_pf_trace_buf[k] += tn_ - tq_; tq_ = tn_; }
+extern "C" int mdq_pf_trace_host(long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mdq_pf_trace_buf), sizeof(long long) * 16) != hipSuccess) return -1;
+  if (reset) { long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(mdq_pf_trace_buf), z, sizeof z) != hipSuccess) return -1; }
+  return 0;
+}
+#else
+#define PF_STAMP(k)
+#endif
+
 constexpr int TH = 1024;      // threads (16 waves)
 constexpr int PARTS = 8;      // subdomains (3 bisection levels)
 constexpr int MMAX = 112;     // interior nodes of a subdomain (K_II: 112^2 doubles = 98 KB of LDS)
@@ -150,6 +162,9 @@ __global__ __launch_bounds__(TH) void pressure_factor_kernel(mdq_ipcs_desc d, in
     }
   };
 
+#ifdef MDQ_PF_TRACE
+  long long tq_ = __builtin_amdgcn_s_memtime();
+#endif
   // ---------------------------------------------------------------- recursive coordinate bisection
   double* cx = BIG;
   double* cy = BIG + NVMAX;
@@ -204,6 +219,7 @@ __global__ __launch_bounds__(TH) void pressure_factor_kernel(mdq_ipcs_desc d, in
     (void)ng;
     __syncthreads();
   }
+  PF_STAMP(0)
   // ---------------------------------------------------------------- vertex separator
   for (int v = tid; v < nv; v += TH) {
     bool s = false;
@@ -251,6 +267,7 @@ __global__ __launch_bounds__(TH) void pressure_factor_kernel(mdq_ipcs_desc d, in
       return;
     }
   }
+  PF_STAMP(1)
   // ---------------------------------------------------------------- K[G, I] as CSR (permuted interior numbering), S = K[G, G]
   for (int idx = tid; idx < nG * nG; idx += TH) o_S[idx] = 0.0;
   __threadfence();
@@ -292,6 +309,7 @@ __global__ __launch_bounds__(TH) void pressure_factor_kernel(mdq_ipcs_desc d, in
   }
   __threadfence();
   __syncthreads();
+  PF_STAMP(2)
   // ---------------------------------------------------------------- subdomains
   int woff = 0, foff = 0, gioff = 0;
   for (int s = 0; s < nparts; ++s) {
@@ -332,7 +350,9 @@ __global__ __launch_bounds__(TH) void pressure_factor_kernel(mdq_ipcs_desc d, in
       });
     }
     __syncthreads();
+    PF_STAMP(3)
     invert_spd(BIG, m, rk, ck);
+    PF_STAMP(4)
     for (int idx = tid; idx < m * m; idx += TH) o_W[woff + idx] = BIG[idx];
     // F_s = W_s K_IG (registers first: F takes the K_II buffer afterwards)
     constexpr int FPT = (MMAX * GMAX + TH - 1) / TH;
@@ -357,6 +377,7 @@ __global__ __launch_bounds__(TH) void pressure_factor_kernel(mdq_ipcs_desc d, in
       }
     }
     __syncthreads();
+    PF_STAMP(5)
     // S[loc, loc] -= K_GI F_s  (device-scope atomics: the element may have been written by another thread earlier)
     for (int idx = tid; idx < gs * gs; idx += TH) {
       const int bq = idx / gs, a = idx - bq * gs;
@@ -373,6 +394,7 @@ __global__ __launch_bounds__(TH) void pressure_factor_kernel(mdq_ipcs_desc d, in
     gioff += gs;
     __threadfence();
     __syncthreads();
+    PF_STAMP(6)
   }
   // ---------------------------------------------------------------- inverse Schur complement
   for (int idx = tid; idx < nG * nG; idx += TH)
@@ -380,6 +402,7 @@ __global__ __launch_bounds__(TH) void pressure_factor_kernel(mdq_ipcs_desc d, in
   __syncthreads();
   if (nG > 0) invert_spd(BIG, nG, rk, ck);
   for (int idx = tid; idx < nG * nG; idx += TH) o_S[idx] = BIG[idx];
+  PF_STAMP(7)
   if (tid == 0) {
     hdr[0] = nI;
     hdr[1] = nG;

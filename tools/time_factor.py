@@ -21,6 +21,16 @@ for pd in ("device", True, False):
         for _ in range(20):
             batch.factorize_pressure_device()
         e1.record(); torch.cuda.synchronize()
+        import ctypes
+        from meshdqn_amd import _lib
+        L = ctypes.CDLL(_lib.LIB_PATH)
+        if hasattr(L, "mdq_pf_trace_host"):
+            buf = (ctypes.c_longlong * 16)()
+            L.mdq_pf_trace_host(buf, 0)
+            names = ["bisection", "separator + ordering", "K[G,I] CSR + S init", "subdomain: K_II / K_IG fill", "subdomain: Gauss-Jordan",
+                     "subdomain: W out + F", "subdomain: Schur update", "S inverse"]
+            tot = sum(buf[:8])
+            print("phases of mesh 0 (share of the kernel):", ", ".join(f"{n} {100.0 * buf[i] / max(tot, 1):.1f} %" for i, n in enumerate(names)))
         print(f"mdq_ipcs_factorize_pressure, {B} ys930 meshes: {e0.elapsed_time(e1) / 20:.3f} ms per launch; status {batch.pd_status.unique().tolist()}, "
               f"header (nI, nG, parts) {batch.t['pd_hdr'][0].tolist()}")
     t0 = time.perf_counter()
