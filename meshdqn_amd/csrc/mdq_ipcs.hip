@@ -1685,7 +1685,7 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
       px[i] = v.p_n[i] * sd;
     }
     MDQ_STAMP(3)
-    if (d.pd_enabled) {
+    if (d.pd_enabled && d.pd_hdr[4 * (int64_t)b + 2] > 0) {   // (nparts = 0: no factors for this environment -> Krylov)
       const PdView pd = pd_view(d, b);
       pressure_direct(pd, nv, pr, px, pp, pq, lK);
     } else {
@@ -2074,7 +2074,7 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
       px[i] = v.p_n[i] * sd;
     }
     MDQ_STAMP(3)
-    if (d.pd_enabled) {
+    if (d.pd_enabled && d.pd_hdr[4 * (int64_t)b + 2] > 0) {   // (nparts = 0: no factors for this environment -> Krylov)
       const PdView pd = pd_view(d, b);
       pressure_direct(pd, nv, pr, px, pp, pq, lK);
     } else {

@@ -325,3 +325,41 @@ def test_time_dependent_inflow_matches_oracle(lib_built):
     with pytest.raises(TypeError):
         FlowSolver(flow_params={"mu": 1e-3, "rho": 1.0, "inflow": "ramp"}, geometry_params={"mesh": mesh},
                    solver_params={"dt": 0.001, "smooth": False})
+
+
+@pytest.mark.parametrize("mode", [3, 2])
+def test_device_factorisation_falls_back_per_environment(meshes, lib_built, mode):
+    """mdq_ipcs_factorize_pressure refuses a mesh beyond its LDS-sized limits (here: forced by a descriptor that offers
+    too little room for the Schur complement): that environment's header says nparts = 0, its status is negative, and
+    the pressure kernel runs the Krylov solve for it - same fields as the all-Krylov batch, while its neighbour in the
+    batch keeps the direct solve."""
+    import torch
+    names = ["ys930", "ah93w145"]
+    ref, _, _ = _make(meshes, names, rtol=1e-12, mode=mode, pressure_direct=False)
+    bat, _, _ = _make(meshes, names, rtol=1e-12, mode=mode, pressure_direct="device")
+    ref.assemble()
+    bat.assemble()
+    hdr = bat.t["pd_hdr"].cpu().numpy()
+    assert (hdr[:, 2] == 8).all()
+    # room for the smaller Schur complement only: ys930 (95 separator nodes) is refused, ah93w145 stays direct
+    nG = sorted(hdr[:, 1].tolist())
+    assert nG[0] < nG[1]
+    bat.desc.NPS = int(nG[0]) ** 2
+    # (the buffers keep their size; only the capacity the kernel checks shrinks - but then the per-environment stride
+    # shrinks with it, so hand the kernel buffers laid out with that stride)
+    bat._pd_dev["pd_Sinv"] = torch.zeros((bat.B, bat.desc.NPS), dtype=torch.float64, device="cuda")
+    bat.PD_DEVICE_CAP = dict(bat.PD_DEVICE_CAP, NPS=bat.desc.NPS)
+    bat.factorize_pressure_device()
+    torch.cuda.synchronize()
+    st = bat.pd_status.cpu().numpy()
+    hdr = bat.t["pd_hdr"].cpu().numpy()
+    assert sorted(st.tolist()) == [-2, 0] and (hdr[st < 0, 2] == 0).all() and (hdr[st == 0, 2] == 8).all()
+    for _ in range(2):
+        ref.evolve(1)
+        bat.evolve(1)
+    torch.cuda.synchronize()
+    it = bat.iters.cpu().numpy()
+    assert (it[st < 0, 1] > 0).all() and (it[st == 0, 1] == 0).all()
+    for b in range(2):
+        assert torch.allclose(bat.u_n[b], ref.u_n[b], rtol=0, atol=1e-9 * float(ref.u_n[b].abs().max()))
+        assert torch.allclose(bat.p_n[b], ref.p_n[b], rtol=0, atol=1e-9 * float(ref.p_n[b].abs().max()))
