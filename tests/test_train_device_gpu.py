@@ -198,3 +198,35 @@ def test_device_loop_record_ring_wraps_and_continues(lib_built):
     dones = np.concatenate([o["dones"] for o in outs])
     check(acts, rews, dones, 10)
     assert len(outs[1]["losses"]) == 5 + 4 and np.isfinite(outs[1]["losses"]).all()  # every step of the second call optimises
+
+
+def test_checkpoint_restart_continues_the_device_adam_state(lib_built, tmp_path):
+    """`DQNTrainer.save` / `.load` (the reference's RESTART, airfoil_dqn.py:163-179) around the kernel optimiser: the
+    moments and step counts written by mdq_adam_step travel through the torch optimiser's `state_dict`, and a restarted
+    trainer continues with bit-identical updates."""
+    from meshdqn_amd.trainer import DistContext, DQNTrainer
+    dev = torch.device("cuda")
+    mk = lambda: DQNTrainer(n_actions=180, num_inputs=17, ctx=DistContext(device=dev), lr=2e-3, weight_decay=1e-3)   # noqa: E731
+    a = mk()
+    total = sum(p.numel() for p in a.policy_net_1.parameters())
+    g = torch.Generator(device="cpu").manual_seed(4)
+    flats = [torch.randn(total, generator=g).to(dev) * 0.1 for _ in range(5)]
+    for f in flats[:3]:
+        a._adam_step_device(0, f)
+        a._adam_step_device(1, f * 0.5)
+    a.num_grads, a.select = 6, False
+    a.save(str(tmp_path), "restart_", extra=dict(steps_done=np.arange(4)))
+    b = mk()
+    extra = b.load(str(tmp_path), "restart_")
+    assert b.num_grads == 6 and b.select is False and np.array_equal(extra["steps_done"], np.arange(4))
+    for f in flats[3:]:
+        for t in (a, b):
+            t._adam_step_device(0, f)
+            t._adam_step_device(1, f * 0.5)
+    torch.cuda.synchronize()
+    for na, nb in ((a.policy_net_1, b.policy_net_1), (a.policy_net_2, b.policy_net_2)):
+        for (name, p), q in zip(na.named_parameters(), nb.parameters()):
+            assert torch.equal(p, q), name
+    sa, sb = a.opts[0].state_dict()["state"], b.opts[0].state_dict()["state"]
+    assert sorted(sa) == sorted(sb) and all(float(sa[k]["step"]) == float(sb[k]["step"]) == 5.0 for k in sa)
+    assert all(torch.equal(sa[k]["exp_avg"], sb[k]["exp_avg"]) and torch.equal(sa[k]["exp_avg_sq"], sb[k]["exp_avg_sq"]) for k in sa)
