@@ -61,33 +61,59 @@ __device__ __forceinline__ unsigned long long ord_key(double x) {   // order-pre
   return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
 }
 
-// in-place inverse of the SPD m x m matrix A (column-major, LDS, m <= 128) by Gauss-Jordan; rk / ck: m doubles of scratch
-// each.  Thread (i, jg) = (tid & 127, tid >> 7) owns row i of every eighth column: no index divisions in the m steps.
-__device__ inline void invert_spd(double* A, int m, double* rk, double* ck) {
+// in-place inverse of the SPD m x m matrix A (column-major, LDS, m <= MMAX) by Gauss-Jordan with the matrix held in
+// REGISTERS for the m elimination steps: thread (i, jg) = (tid & 127, tid >> 7) owns row i of the columns jg, jg + 8, ...
+// (14 doubles).  A step is one rank-1 update A -= c (x) r: the owners of row k / column k publish them through LDS
+// (double-buffered by the parity of k: ONE barrier per step), and the special cases of the textbook formulas
+//    a_kj' = a_kj / p,  a_ik' = -a_ik / p,  a_kk' = 1 / p,  a_ij' = a_ij - a_ik a_kj / p
+// come out of the same update with c_k := p - 1 and r_k := p + 1 in place of p (then c_i r_j / p gives all four).
+// rc: 2 x (128 + 128 + 2) doubles of scratch.
+constexpr int NQ = (MMAX + 7) / 8;
+__device__ inline void invert_spd(double* A, int m, double* rc) {
   const int tid = threadIdx.x, i = tid & 127, jg = tid >> 7;
-  for (int k = 0; k < m; ++k) {
-    const double ip = 1.0 / A[k * m + k];
-    if (tid < m) {
-      rk[tid] = tid == k ? ip : A[tid * m + k] * ip;   // new row k: a_kj / p (a_kk -> 1 / p)
-      ck[tid] = A[k * m + tid];                        // old column k: a_ik
-    }
-    __syncthreads();
-    if (i < m) {
-      const double ci = ck[i];
-      for (int j = jg; j < m; j += TH / 128) {
-        double v;
-        if (i == k)
-          v = rk[j];
-        else if (j == k)
-          v = -ci * ip;
-        else
-          v = A[j * m + i] - ci * rk[j];
-        A[j * m + i] = v;
+  double a[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int j = jg + 8 * q;
+    a[q] = (i < m && j < m) ? A[j * m + i] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int kq = 0; kq < NQ; ++kq) {
+    for (int kj = 0; kj < 8; ++kj) {
+      const int k = kq * 8 + kj;
+      if (k >= m) break;
+      double* rowb = rc + (k & 1) * 258;     // row k (raw; entry k holds p + 1)
+      double* colb = rowb + 128;             // column k (raw; entry k holds p - 1)
+      if (i == k) {   // (entries past m are zeros: the update below needs no bounds)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) rowb[jg + 8 * q] = (q == kq && jg == kj) ? a[q] + 1.0 : a[q];
+      }
+      if (jg == kj) {
+        colb[i] = i == k ? a[kq] - 1.0 : a[kq];
+        if (i == k) colb[128] = 1.0 / a[kq];
+      }
+      __syncthreads();
+      {
+        // branch-free: all 14 row entries are fetched together (rows / columns past m hold zeros and stay zero)
+        const double t = colb[i] * colb[128];   // c_i / p
+        double r[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) r[q] = rowb[jg + 8 * q];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) a[q] = fma(-t, r[q], a[q]);
+        if (i == k && jg == kj) a[kq] = colb[128];   // (the pivot's 1 / p without the cancellation of p - (p^2 - 1) / p)
       }
     }
-    __syncthreads();
   }
-  // symmetrise (what the host does after numpy's inverse)
+  __syncthreads();
+  // back to LDS, then symmetrise (what the host does after numpy's inverse)
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int j = jg + 8 * q;
+    if (i < m && j < m) A[j * m + i] = a[q];
+  }
+  __syncthreads();
   if (i < m)
     for (int j = jg; j < m; j += TH / 128)
       if (i < j) {
@@ -123,9 +149,8 @@ __global__ __launch_bounds__(TH) void pressure_factor_kernel(mdq_ipcs_desc d, in
   // LDS
   double* BIG = sm;                               // [MMAX * MMAX]: keys of the bisection, then K_II / F_s, then S
   double* KIG = BIG + MMAX * MMAX;                // [MMAX * GMAX]
-  double* rk = KIG + MMAX * GMAX;                 // [128]
-  double* ck = rk + 128;                          // [128]
-  unsigned long long* ext = reinterpret_cast<unsigned long long*>(ck + 128);   // [PARTS][4] min x, max x, min y, max y
+  double* rk = KIG + MMAX * GMAX;                 // [2 x 258] row / column / 1 / p of an elimination step, by parity
+  unsigned long long* ext = reinterpret_cast<unsigned long long*>(rk + 520);   // [PARTS][4] min x, max x, min y, max y
   int* gsize = reinterpret_cast<int*>(ext + PARTS * 4);                        // [PARTS]
   int* wtot = gsize + PARTS;                                                   // [TH / 64]
   int* misc = wtot + TH / 64;                                                  // [16]
@@ -351,7 +376,7 @@ __global__ __launch_bounds__(TH) void pressure_factor_kernel(mdq_ipcs_desc d, in
     }
     __syncthreads();
     PF_STAMP(3)
-    invert_spd(BIG, m, rk, ck);
+    invert_spd(BIG, m, rk);
     PF_STAMP(4)
     for (int idx = tid; idx < m * m; idx += TH) o_W[woff + idx] = BIG[idx];
     // F_s = W_s K_IG (registers first: F takes the K_II buffer afterwards)
@@ -400,7 +425,7 @@ __global__ __launch_bounds__(TH) void pressure_factor_kernel(mdq_ipcs_desc d, in
   for (int idx = tid; idx < nG * nG; idx += TH)
     BIG[idx] = __hip_atomic_load(&o_S[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
-  if (nG > 0) invert_spd(BIG, nG, rk, ck);
+  if (nG > 0) invert_spd(BIG, nG, rk);
   for (int idx = tid; idx < nG * nG; idx += TH) o_S[idx] = BIG[idx];
   PF_STAMP(7)
   if (tid == 0) {
@@ -420,7 +445,7 @@ extern "C" int mdq_ipcs_factorize_pressure(const mdq_ipcs_desc* d, int32_t* stat
       !d->pd_Sinv || !d->pd_gk_ptr || !d->pd_gk_col || !d->pd_gk_val || !d->K1s || !d->sl1_off || !d->sl1_col || !d->coords)
     return mdq_set_error("mdq_ipcs_factorize_pressure: bad arguments");
   if (d->NPART < 1) return mdq_set_error("mdq_ipcs_factorize_pressure: NPART < 1");
-  const size_t lds = sizeof(double) * ((size_t)MMAX * MMAX + (size_t)MMAX * GMAX + 256) + sizeof(unsigned long long) * PARTS * 4 +
+  const size_t lds = sizeof(double) * ((size_t)MMAX * MMAX + (size_t)MMAX * GMAX + 520) + sizeof(unsigned long long) * PARTS * 4 +
                      sizeof(int) * (PARTS + TH / 64 + 16) + sizeof(uint16_t) * (2 * NVMAX + NGMAX + 16) + 2 * NVMAX + NGMAX + 16 + GMAX + 16 + 64;
   if (lds > 160 * 1024) return mdq_set_error("mdq_ipcs_factorize_pressure: LDS plan exceeds 160 KB");
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pressure_factor_kernel),
