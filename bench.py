@@ -604,8 +604,8 @@ def main():
             sd = measure_env_steps(args, dev, None, 1, 1, steps=args.s1_steps, repeats=3, flow_pressure="direct")
             sd["what"] = ("the S3 step with the pressure matrix of every coarsened mesh re-factorised on the device in every step "
                           "(mdq_ipcs_factorize_pressure: what the reference's MUMPS does at a remesh) and a direct pressure solve: 0 "
-                          "Krylov iterations in the pressure solve, but the 2.3 ms factorisation of 128 meshes is longer than the "
-                          "env step it hides behind - for ONE solve per mesh the 160-iteration Jacobi-CG (0.28 ms) is the faster choice")
+                          "Krylov iterations in the pressure solve, but the factorisation of 128 meshes (0.86 ms alone on the chip) no longer "
+                          "hides beside the smoothing kernel - for ONE solve per mesh the 160-iteration Jacobi-CG (0.28 ms) is the faster choice")
             cfgs["S3_refactorised_pressure"] = sd
         except Exception as exc:  # noqa: BLE001
             cfgs["S3_refactorised_pressure"] = dict(error=repr(exc))

@@ -206,7 +206,7 @@ int mdq_probe_forces(const mdq_ipcs_desc* d, int32_t nfields, const double* u, c
  * boundary-eliminated pressure matrix (K1s, as written by mdq_ipcs_assemble / mdq_ipcs_setup_matfree) - recursive
  * coordinate bisection into 8 parts, vertex separator, dense inverses of the interior blocks and of the Schur
  * complement by Gauss-Jordan in LDS.  The pd_* arrays of `d` must be allocated with capacities NPART >= 8,
- * NPW >= 8 * 112^2, NPF >= 8 * 112 * 48, NPGI >= 8 * 48, NPS >= 112^2, NPGK >= 112 * 16 (written here although the
+ * NPW >= 8 * 112^2, NPF >= 8 * 112 * 48, NPGI >= 8 * 48, NPS >= 112^2 + 8 * 48^2 (the inverse Schur complement in front, scratch behind it), NPGK >= 112 * 16 (written here although the
  * descriptor declares them const: they are this call's outputs).  status (device int32 [B], may be NULL): 0 ok;
  * < 0: the mesh exceeds those limits - its header says nparts = 0 and mdq_ipcs_evolve (pd_enabled = 1) runs the
  * Krylov pressure solve for that environment.

@@ -61,66 +61,83 @@ __device__ __forceinline__ unsigned long long ord_key(double x) {   // order-pre
   return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
 }
 
-// in-place inverse of the SPD m x m matrix A (column-major, LDS, m <= MMAX) by Gauss-Jordan with the matrix held in
-// REGISTERS for the m elimination steps: thread (i, jg) = (tid & 127, tid >> 7) owns row i of the columns jg, jg + 8, ...
-// (14 doubles).  A step is one rank-1 update A -= c (x) r: the owners of row k / column k publish them through LDS
-// (double-buffered by the parity of k: ONE barrier per step), and the special cases of the textbook formulas
+// in-place inverse of the SPD m x m matrix A (column-major, LDS, m <= MMAX = 112) by Gauss-Jordan with the matrix held in
+// REGISTERS for the m elimination steps: thread (ti, tj) = (tid % 28, tid / 28) of the first 784 owns the 4 x 4 tile of
+// rows 4 ti .. and columns 4 tj ..; a step is one rank-1 update A -= c (x) r / p for which a thread fetches 4 + 4 values
+// (four 16-byte LDS reads for 16 FMAs: with one row per thread it was 15 reads for 14 FMAs, and the 16 waves of the
+// workgroup were bound by the LDS bandwidth of their one CU).  The owners of row k / column k publish them through LDS,
+// double-buffered by the parity of k: ONE barrier per step.  The special cases of the textbook formulas
 //    a_kj' = a_kj / p,  a_ik' = -a_ik / p,  a_kk' = 1 / p,  a_ij' = a_ij - a_ik a_kj / p
-// come out of the same update with c_k := p - 1 and r_k := p + 1 in place of p (then c_i r_j / p gives all four).
-// rc: 2 x (128 + 128 + 2) doubles of scratch.
-constexpr int NQ = (MMAX + 7) / 8;
+// come out of the same update with c_k := p - 1 and r_k := p + 1 in place of p.
+// rc: 2 x (128 + 128 + 2) doubles of scratch (16-byte aligned).
+constexpr int TL = MMAX / 4;   // 28 tiles per side
+static_assert(MMAX % 4 == 0 && TL * TL <= TH, "tile layout");
+typedef double d2v __attribute__((ext_vector_type(2)));
 __device__ inline void invert_spd(double* A, int m, double* rc) {
-  const int tid = threadIdx.x, i = tid & 127, jg = tid >> 7;
-  double a[NQ];
+  const int tid = threadIdx.x;
+  const bool act = tid < TL * TL;
+  const int ti = act ? tid % TL : 0, tj = act ? tid / TL : 0;
+  double a[4][4];   // a[r][c] = A(4 ti + r, 4 tj + c)
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const int j = jg + 8 * q;
-    a[q] = (i < m && j < m) ? A[j * m + i] : 0.0;
-  }
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int i = 4 * ti + r, j = 4 * tj + c;
+      a[r][c] = (act && i < m && j < m) ? A[j * m + i] : 0.0;
+    }
   __syncthreads();
+  const int mt = (m + 3) >> 2;
+  for (int kt = 0; kt < mt; ++kt) {
 #pragma unroll
-  for (int kq = 0; kq < NQ; ++kq) {
-    for (int kj = 0; kj < 8; ++kj) {
-      const int k = kq * 8 + kj;
+    for (int kr = 0; kr < 4; ++kr) {
+      const int k = 4 * kt + kr;
       if (k >= m) break;
-      double* rowb = rc + (k & 1) * 258;     // row k (raw; entry k holds p + 1)
-      double* colb = rowb + 128;             // column k (raw; entry k holds p - 1)
-      if (i == k) {   // (entries past m are zeros: the update below needs no bounds)
+      double* rowb = rc + (k & 1) * 258;     // row k (raw; entry k holds p + 1; zeros past m)
+      double* colb = rowb + 128;             // column k (raw; entry k holds p - 1; zeros past m); [128] = 1 / p
+      if (act && ti == kt) {                 // this tile holds row k: its four entries of it
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) rowb[jg + 8 * q] = (q == kq && jg == kj) ? a[q] + 1.0 : a[q];
+        for (int c = 0; c < 4; ++c) rowb[4 * tj + c] = (tj == kt && c == kr) ? a[kr][c] + 1.0 : a[kr][c];
       }
-      if (jg == kj) {
-        colb[i] = i == k ? a[kq] - 1.0 : a[kq];
-        if (i == k) colb[128] = 1.0 / a[kq];
+      if (act && tj == kt) {                 // ... column k
+#pragma unroll
+        for (int r = 0; r < 4; ++r) colb[4 * ti + r] = (ti == kt && r == kr) ? a[r][kr] - 1.0 : a[r][kr];
+        if (ti == kt) colb[128] = 1.0 / a[kr][kr];
       }
       __syncthreads();
       {
-        // branch-free: all 14 row entries are fetched together (rows / columns past m hold zeros and stay zero)
-        const double t = colb[i] * colb[128];   // c_i / p
-        double r[NQ];
+        const double ip = colb[128];
+        const d2v c01 = *reinterpret_cast<const d2v*>(colb + 4 * ti), c23 = *reinterpret_cast<const d2v*>(colb + 4 * ti + 2);
+        const d2v r01 = *reinterpret_cast<const d2v*>(rowb + 4 * tj), r23 = *reinterpret_cast<const d2v*>(rowb + 4 * tj + 2);
+        const double cv[4] = {c01.x * ip, c01.y * ip, c23.x * ip, c23.y * ip};
+        const double rv[4] = {r01.x, r01.y, r23.x, r23.y};
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) r[q] = rowb[jg + 8 * q];
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) a[q] = fma(-t, r[q], a[q]);
-        if (i == k && jg == kj) a[kq] = colb[128];   // (the pivot's 1 / p without the cancellation of p - (p^2 - 1) / p)
+          for (int c = 0; c < 4; ++c) a[r][c] = fma(-cv[r], rv[c], a[r][c]);
+        if (act && ti == kt && tj == kt) a[kr][kr] = ip;   // (the pivot's 1 / p without the cancellation of p - (p^2 - 1) / p)
       }
     }
   }
   __syncthreads();
   // back to LDS, then symmetrise (what the host does after numpy's inverse)
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const int j = jg + 8 * q;
-    if (i < m && j < m) A[j * m + i] = a[q];
-  }
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int i = 4 * ti + r, j = 4 * tj + c;
+      if (act && i < m && j < m) A[j * m + i] = a[r][c];
+    }
   __syncthreads();
-  if (i < m)
-    for (int j = jg; j < m; j += TH / 128)
-      if (i < j) {
-        const double sv = 0.5 * (A[j * m + i] + A[i * m + j]);
-        A[j * m + i] = sv;
-        A[i * m + j] = sv;
-      }
+  {
+    const int i = tid & 127, jg = tid >> 7;
+    if (i < m)
+      for (int j = jg; j < m; j += TH / 128)
+        if (i < j) {
+          const double sv = 0.5 * (A[j * m + i] + A[i * m + j]);
+          A[j * m + i] = sv;
+          A[i * m + j] = sv;
+        }
+  }
   __syncthreads();
 }
 
@@ -148,8 +165,9 @@ __global__ __launch_bounds__(TH) void pressure_factor_kernel(mdq_ipcs_desc d, in
   const double* xg = d.coords + B * d.NV * 2;
   // LDS
   double* BIG = sm;                               // [MMAX * MMAX]: keys of the bisection, then K_II / F_s, then S
-  double* KIG = BIG + MMAX * MMAX;                // [MMAX * GMAX]
-  double* rk = KIG + MMAX * GMAX;                 // [2 x 258] row / column / 1 / p of an elimination step, by parity
+  double* KIG = BIG + MMAX * MMAX;                // [(MMAX + 1) * GMAX]: K_IG, column stride ldk (odd: no LDS bank conflicts
+                                                  // when the lanes of a wave read different columns)
+  double* rk = KIG + (MMAX + 2) * GMAX;               // [2 x 258] row / column / 1 / p of an elimination step, by parity
   unsigned long long* ext = reinterpret_cast<unsigned long long*>(rk + 520);   // [PARTS][4] min x, max x, min y, max y
   int* gsize = reinterpret_cast<int*>(ext + PARTS * 4);                        // [PARTS]
   int* wtot = gsize + PARTS;                                                   // [TH / 64]
@@ -216,28 +234,39 @@ __global__ __launch_bounds__(TH) void pressure_factor_kernel(mdq_ipcs_desc d, in
       atomicAdd(&gsize[g], 1);
     }
     __syncthreads();
-    for (int v = tid; v < nv; v += TH) {
-      const int g = part[v];
-      // extents from the ordered keys back to doubles
-      auto back = [](unsigned long long u) {
-        const unsigned long long w = (u >> 63) ? (u & 0x7FFFFFFFFFFFFFFFull) : ~u;
-        return __longlong_as_double((long long)w);
-      };
-      const double ex = back(ext[g * 4 + 1]) - back(ext[g * 4 + 0]), ey = back(ext[g * 4 + 3]) - back(ext[g * 4 + 2]);
-      key[v] = ex >= ey ? cx[v] : cy[v];       // (argmax of the extents: x on a tie)
+    // composite sort key: part | top 51 bits of the order-preserving coordinate key | vertex id, so that ONE unsigned
+    // comparison ranks a vertex inside its part (rank over all vertices minus the sizes of the smaller parts); a tie
+    // of the truncated coordinates goes by the vertex id - the bisection stays exactly balanced either way
+    unsigned long long* ckey = reinterpret_cast<unsigned long long*>(key);
+    for (int v = tid; v < NVMAX; v += TH) {
+      unsigned long long kk = ~0ull;           // (slots past nv: larger than every real key)
+      if (v < nv) {
+        const int g = part[v];
+        auto back = [](unsigned long long u) {
+          const unsigned long long w = (u >> 63) ? (u & 0x7FFFFFFFFFFFFFFFull) : ~u;
+          return __longlong_as_double((long long)w);
+        };
+        const double ex = back(ext[g * 4 + 1]) - back(ext[g * 4 + 0]), ey = back(ext[g * 4 + 3]) - back(ext[g * 4 + 2]);
+        const unsigned long long ok = ord_key(ex >= ey ? cx[v] : cy[v]);       // (argmax of the extents: x on a tie)
+        kk = ((unsigned long long)g << 61) | ((ok >> 13) << 10) | (unsigned long long)v;
+      }
+      ckey[v] = kk;
     }
     __syncthreads();
     int np_ = 0;
     if (tid < nv) {
       const int v = tid, g = part[v];
-      const double kv = key[v];
+      const unsigned long long kv = ckey[v];
       int r = 0;
-      for (int u = 0; u < nv; ++u) {
-        const double ku = key[u];
-        r += (part[u] == g) & ((ku < kv) | ((ku == kv) & (u < v)));
+      const int nv4 = (nv + 3) & ~3;
+      for (int u = 0; u < nv4; u += 4) {
+        const ulonglong2 k01 = *reinterpret_cast<const ulonglong2*>(ckey + u), k23 = *reinterpret_cast<const ulonglong2*>(ckey + u + 2);
+        r += (k01.x < kv) + (k01.y < kv) + (k23.x < kv) + (k23.y < kv);
       }
+      int below = 0;
+      for (int q = 0; q < g; ++q) below += gsize[q];
       const int sz = gsize[g];
-      np_ = 2 * g + ((sz > 1 && r >= sz / 2) ? 1 : 0);
+      np_ = 2 * g + ((sz > 1 && r - below >= sz / 2) ? 1 : 0);
     }
     __syncthreads();
     if (tid < nv) part[tid] = (uint8_t)np_;
@@ -287,7 +316,7 @@ __global__ __launch_bounds__(TH) void pressure_factor_kernel(mdq_ipcs_desc d, in
   {
     int mmax = 0;
     for (int s = 0; s < nparts; ++s) mmax = max(mmax, ms[s]);
-    if (mmax > MMAX || nG > NGMAX || nparts > d.NPART || (int64_t)nG * nG > d.NPS) {
+    if (mmax > MMAX || nG > NGMAX || nparts > d.NPART || (int64_t)NGMAX * NGMAX + (int64_t)PARTS * GMAX * GMAX > d.NPS) {
       fail(-2);
       return;
     }
@@ -337,6 +366,7 @@ __global__ __launch_bounds__(TH) void pressure_factor_kernel(mdq_ipcs_desc d, in
   PF_STAMP(2)
   // ---------------------------------------------------------------- subdomains
   int woff = 0, foff = 0, gioff = 0;
+  int gss[PARTS], gios[PARTS];
   for (int s = 0; s < nparts; ++s) {
     const int q0 = q0s[s], m = ms[s];
     for (int idx = tid; idx < m * m; idx += TH) BIG[idx] = 0.0;
@@ -366,12 +396,13 @@ __global__ __launch_bounds__(TH) void pressure_factor_kernel(mdq_ipcs_desc d, in
       fail(-4);
       return;
     }
-    for (int idx = tid; idx < m * gs; idx += TH) KIG[idx] = 0.0;
+    const int ldk = m | 1;
+    for (int idx = tid; idx < ldk * gs; idx += TH) KIG[idx] = 0.0;
     __syncthreads();
     for (int li = tid; li < m; li += TH) {
       const int v = node[q0 + li];
       for_row(v, [&](int c, double val) {
-        if (sepf[c]) KIG[gpos[inv[c] - nI] * m + li] = val;
+        if (sepf[c]) KIG[gpos[inv[c] - nI] * ldk + li] = val;
       });
     }
     __syncthreads();
@@ -388,7 +419,7 @@ __global__ __launch_bounds__(TH) void pressure_factor_kernel(mdq_ipcs_desc d, in
       double acc = 0.0;
       if (idx < m * gs) {
         const int k = idx / m, i = idx - k * m;
-        for (int j = 0; j < m; ++j) acc += BIG[j * m + i] * KIG[k * m + j];
+        for (int j = 0; j < m; ++j) acc += BIG[j * m + i] * KIG[k * ldk + j];
       }
       fv[q] = acc;
     }
@@ -404,27 +435,60 @@ __global__ __launch_bounds__(TH) void pressure_factor_kernel(mdq_ipcs_desc d, in
     __syncthreads();
     PF_STAMP(5)
     // S[loc, loc] -= K_GI F_s  (device-scope atomics: the element may have been written by another thread earlier)
-    for (int idx = tid; idx < gs * gs; idx += TH) {
-      const int bq = idx / gs, a = idx - bq * gs;
-      double acc = 0.0;
-      for (int i = 0; i < m; ++i) acc += KIG[a * m + i] * BIG[bq * m + i];
-      atomicAdd(&o_S[(int64_t)glist[bq] * nG + glist[a]], -acc);     // separator-local ids of the two columns
+    // (the update is symmetric: the gs (gs + 1) / 2 pairs a <= bq, one per thread, written to both positions)
+    for (int idx = tid; idx < gs * (gs + 1) / 2; idx += TH) {
+      int bq = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+      while (bq * (bq + 1) / 2 > idx) --bq;                   // (the float estimate may be off by one either way)
+      while ((bq + 1) * (bq + 2) / 2 <= idx) ++bq;
+      const int a = idx - bq * (bq + 1) / 2;
+      const double* ka = KIG + a * ldk;
+      const double* fb = BIG + bq * m;
+      double acc0 = 0.0, acc1 = 0.0;
+      int i = 0;
+      for (; i + 1 < m; i += 2) {
+        acc0 = fma(ka[i], fb[i], acc0);
+        acc1 = fma(ka[i + 1], fb[i + 1], acc1);
+      }
+      if (i < m) acc0 = fma(ka[i], fb[i], acc0);
+      const double acc = acc0 + acc1;
+      // the subdomain's Schur term goes to a slice of its own (plain stores, nothing is read back here: a load would
+      // wait behind the W / F stores of this subdomain, ~20 us); the slices are subtracted from K_GG at the end
+      double* sl = o_S + NGMAX * NGMAX + s * GMAX * GMAX;
+      sl[bq * gs + a] = acc;
+      if (a != bq) sl[a * gs + bq] = acc;
     }
     if (tid == 0) {
       int32_t* m6 = o_meta + 6 * s;
       m6[0] = q0; m6[1] = m; m6[2] = woff; m6[3] = foff; m6[4] = gs; m6[5] = gioff;
     }
+    gss[s] = gs;
+    gios[s] = gioff;
     woff += m * m;
     foff += m * gs;
     gioff += gs;
-    __threadfence();
+    // (no fence here: nothing this subdomain wrote to global memory is read before the end of the loop; the barrier
+    // only hands the LDS buffers to the next subdomain)
     __syncthreads();
     PF_STAMP(6)
   }
+  __threadfence();      // the slices and separator lists written above are read back below
+  __syncthreads();
   // ---------------------------------------------------------------- inverse Schur complement
   for (int idx = tid; idx < nG * nG; idx += TH)
     BIG[idx] = __hip_atomic_load(&o_S[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
+  for (int s = 0; s < nparts; ++s) {      // S = K_GG - sum of the subdomains' terms (in subdomain order: deterministic)
+    const int gs = gss[s];
+    const double* sl = o_S + NGMAX * NGMAX + s * GMAX * GMAX;
+    const int32_t* gl = o_gidx + gios[s];
+    for (int idx = tid; idx < gs * gs; idx += TH) {
+      const int bq = idx / gs, a = idx - bq * gs;
+      const int ga = __hip_atomic_load(&gl[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int gb = __hip_atomic_load(&gl[bq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      BIG[gb * nG + ga] -= __hip_atomic_load(&sl[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+  }
   if (nG > 0) invert_spd(BIG, nG, rk);
   for (int idx = tid; idx < nG * nG; idx += TH) o_S[idx] = BIG[idx];
   PF_STAMP(7)
@@ -445,7 +509,7 @@ extern "C" int mdq_ipcs_factorize_pressure(const mdq_ipcs_desc* d, int32_t* stat
       !d->pd_Sinv || !d->pd_gk_ptr || !d->pd_gk_col || !d->pd_gk_val || !d->K1s || !d->sl1_off || !d->sl1_col || !d->coords)
     return mdq_set_error("mdq_ipcs_factorize_pressure: bad arguments");
   if (d->NPART < 1) return mdq_set_error("mdq_ipcs_factorize_pressure: NPART < 1");
-  const size_t lds = sizeof(double) * ((size_t)MMAX * MMAX + (size_t)MMAX * GMAX + 520) + sizeof(unsigned long long) * PARTS * 4 +
+  const size_t lds = sizeof(double) * ((size_t)MMAX * MMAX + (size_t)(MMAX + 2) * GMAX + 520) + sizeof(unsigned long long) * PARTS * 4 +
                      sizeof(int) * (PARTS + TH / 64 + 16) + sizeof(uint16_t) * (2 * NVMAX + NGMAX + 16) + 2 * NVMAX + NGMAX + 16 + GMAX + 16 + 64;
   if (lds > 160 * 1024) return mdq_set_error("mdq_ipcs_factorize_pressure: LDS plan exceeds 160 KB");
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pressure_factor_kernel),

@@ -253,7 +253,7 @@ class IpcsBatch:
 
     # capacities of the device-built factors (limits of mdq_ipcs_factorize_pressure: 8 parts, 112 interior nodes per
     # part, 48 separator nodes per part, 112 separator nodes)
-    PD_DEVICE_CAP = dict(NPART=8, NPW=8 * 112 * 112, NPF=8 * 112 * 48, NPGI=8 * 48, NPS=112 * 112, NPGK=4096)
+    PD_DEVICE_CAP = dict(NPART=8, NPW=8 * 112 * 112, NPF=8 * 112 * 48, NPGI=8 * 48, NPS=112 * 112 + 8 * 48 * 48, NPGK=4096)
 
     def factorize_pressure_device(self, stream=None):
         """The factorisation of every environment's pressure matrix ON THE DEVICE (`mdq_ipcs_factorize_pressure`: the

@@ -72,7 +72,7 @@ class VecEnv2DAirfoil:
         self.flow_overlap = bool(flow_overlap) and self.flow_steps > 0 and self.gpu_remesh
         # pressure solve of the S3 flow step on the freshly coarsened mesh: "cg" (Jacobi-CG, ~160 iterations, 0.28 ms) or
         # "direct" (the reference's behaviour: re-factorise after every remesh - mdq_ipcs_factorize_pressure on the
-        # device, 2.3 ms per batch, then 0 iterations; worth it only when a mesh is solved on many times)
+        # device, 0.86 ms per batch, then 0 iterations; worth it only when a mesh is solved on many times)
         if flow_pressure not in ("cg", "direct"):
             raise ValueError("flow_pressure: 'cg' or 'direct'")
         self.flow_pressure = flow_pressure
@@ -261,8 +261,15 @@ class VecEnv2DAirfoil:
         res = self._flow_res[self._flow_n % 2]
         with torch.cuda.stream(self._flow_stream):
             self._flow_stream.wait_event(self._flow_ready)
+            fe = getattr(self, "flow_events", None)     # (tools: HIP events around the leg, on the flow stream)
+            if fe is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             ft.run(check=False)                  # (same meshes, same deterministic kernel as the main stream's run)
             drag, lift = self._flow_launch(t, d, keep, None, None)
+            if fe is not None:
+                e1.record()
+                fe.append((e0, e1))
             res["host"][0].copy_(drag, non_blocking=True)
             res["host"][1].copy_(lift, non_blocking=True)
             res["done"].record(self._flow_stream)

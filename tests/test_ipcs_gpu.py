@@ -329,8 +329,8 @@ def test_time_dependent_inflow_matches_oracle(lib_built):
 
 @pytest.mark.parametrize("mode", [3, 2])
 def test_device_factorisation_falls_back_per_environment(meshes, lib_built, mode):
-    """mdq_ipcs_factorize_pressure refuses a mesh beyond its LDS-sized limits (here: forced by a descriptor that offers
-    too little room for the Schur complement): that environment's header says nparts = 0, its status is negative, and
+    """mdq_ipcs_factorize_pressure refuses a mesh beyond its limits (here: forced by a descriptor that offers too little
+    room for the inverses of the interior blocks): that environment's header says nparts = 0, its status is negative, and
     the pressure kernel runs the Krylov solve for it - same fields as the all-Krylov batch, while its neighbour in the
     batch keeps the direct solve."""
     import torch
@@ -341,19 +341,19 @@ def test_device_factorisation_falls_back_per_environment(meshes, lib_built, mode
     bat.assemble()
     hdr = bat.t["pd_hdr"].cpu().numpy()
     assert (hdr[:, 2] == 8).all()
-    # room for the smaller Schur complement only: ys930 (95 separator nodes) is refused, ah93w145 stays direct
-    nG = sorted(hdr[:, 1].tolist())
-    assert nG[0] < nG[1]
-    bat.desc.NPS = int(nG[0]) ** 2
-    # (the buffers keep their size; only the capacity the kernel checks shrinks - but then the per-environment stride
-    # shrinks with it, so hand the kernel buffers laid out with that stride)
-    bat._pd_dev["pd_Sinv"] = torch.zeros((bat.B, bat.desc.NPS), dtype=torch.float64, device="cuda")
-    bat.PD_DEVICE_CAP = dict(bat.PD_DEVICE_CAP, NPS=bat.desc.NPS)
+    # room for the interior blocks of the smaller mesh only: ys930 is refused, ah93w145 stays direct
+    meta = bat.t["pd_meta"].cpu().numpy().reshape(bat.B, -1, 6)
+    need = sorted(int((meta[b, :8, 1].astype(np.int64) ** 2).sum()) for b in range(bat.B))
+    assert need[0] < need[1]
+    bat.desc.NPW = need[0]
+    # (the per-environment stride of the buffer is the capacity the kernel is told: a buffer laid out with it)
+    bat._pd_dev["pd_W"] = torch.zeros((bat.B, need[0]), dtype=torch.float64, device="cuda")
+    bat.PD_DEVICE_CAP = dict(bat.PD_DEVICE_CAP, NPW=need[0])
     bat.factorize_pressure_device()
     torch.cuda.synchronize()
     st = bat.pd_status.cpu().numpy()
     hdr = bat.t["pd_hdr"].cpu().numpy()
-    assert sorted(st.tolist()) == [-2, 0] and (hdr[st < 0, 2] == 0).all() and (hdr[st == 0, 2] == 8).all()
+    assert sorted(st.tolist()) == [-4, 0] and (hdr[st < 0, 2] == 0).all() and (hdr[st == 0, 2] == 8).all()
     for _ in range(2):
         ref.evolve(1)
         bat.evolve(1)

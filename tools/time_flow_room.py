@@ -18,13 +18,22 @@ net = NodeRemovalNet(181, conv_width=128, topk=0.1); net.set_num_nodes(17); net 
 rng = np.random.default_rng(1370)
 B, K = 128, 40
 for name, kw in (("flow_steps=1 cg", dict(flow_steps=1)), ("flow_steps=2 cg", dict(flow_steps=2)), ("flow_steps=3 cg", dict(flow_steps=3)),
-                 ("flow_steps=1 direct", dict(flow_steps=1, flow_pressure="direct"))):
-    env = VecEnv2DAirfoil(cfg, B, base_env=base, flow_overlap=True, **kw)
+                 ("flow_steps=1 direct", dict(flow_steps=1, flow_pressure="direct")),
+                 ("inline flow_steps=0", dict(flow_steps=0, flow_overlap=False)),
+                 ("inline flow_steps=1 cg", dict(flow_steps=1, flow_overlap=False)),
+                 ("inline flow_steps=1 direct", dict(flow_steps=1, flow_pressure="direct", flow_overlap=False))):
+    kw = dict(dict(flow_overlap=True), **kw)
+    env = VecEnv2DAirfoil(cfg, B, base_env=base, **kw)
     fg = FusedGcn(net)
     def run(k):
         t0 = time.perf_counter()
         env.rollout_device(fg, k, rng.random((k, B)) < 0.5, rng.integers(0, 181, (k, B)))
         torch.cuda.synchronize(); return (time.perf_counter() - t0) / k * 1e3
     run(10)
-    print(f"{name:22s}: {min(run(K) for _ in range(3)):.3f} ms per batched step", flush=True)
+    best = min(run(K) for _ in range(3))
+    env.flow_events = []
+    run(20)
+    leg = np.median([a.elapsed_time(b) for a, b in env.flow_events]) if env.flow_events else float("nan")
+    env.flow_events = None
+    print(f"{name:28s}: {best:.3f} ms per batched step; flow leg on its stream {leg:.3f} ms", flush=True)
     env.flow_wait(); del env
