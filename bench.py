@@ -222,6 +222,13 @@ def measure_env_steps(args, dev, dist, world, flow_steps=0, steps=None, warmup=8
     net.set_num_nodes(17)
     net = net.to(dev)
     fused = [FusedGcn(net) for _ in groups.envs]
+    calib = []
+    if flow_steps > 0 and not args.no_flow_overlap and not args.host_step:
+        # a flow stream that really runs beside the group's stream (HIP's stream -> hardware queue mapping: see
+        # VecEnv2DAirfoil.calibrate_streams), found by timing a few real steps; the envs are reset afterwards
+        for g, env in enumerate(groups.envs):
+            with torch.cuda.stream(groups.streams[g]):
+                calib.append(env.calibrate_streams(fused[g]))
     rank = int(os.environ.get("RANK", "0"))
     rngs = [np.random.default_rng(1370 + 64 * rank + g) for g in range(len(groups.envs))]
 
@@ -604,8 +611,9 @@ def main():
             sd = measure_env_steps(args, dev, None, 1, 1, steps=args.s1_steps, repeats=3, flow_pressure="direct")
             sd["what"] = ("the S3 step with the pressure matrix of every coarsened mesh re-factorised on the device in every step "
                           "(mdq_ipcs_factorize_pressure: what the reference's MUMPS does at a remesh) and a direct pressure solve: 0 "
-                          "Krylov iterations in the pressure solve, but the factorisation of 128 meshes (0.86 ms alone on the chip) no longer "
-                          "hides beside the smoothing kernel - for ONE solve per mesh the 160-iteration Jacobi-CG (0.28 ms) is the faster choice")
+                          "Krylov iterations in the pressure solve; the flow leg grows from 1.05 to 1.7 ms on its stream and still "
+                          "mostly hides beside the smoothing kernel (VecEnv2DAirfoil(flow_pressure='direct')); the headline keeps "
+                          "the Jacobi-CG: one solve per mesh does not pay for a factorisation")
             cfgs["S3_refactorised_pressure"] = sd
         except Exception as exc:  # noqa: BLE001
             cfgs["S3_refactorised_pressure"] = dict(error=repr(exc))

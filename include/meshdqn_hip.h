@@ -376,6 +376,11 @@ typedef struct mdq_adam_desc {
 } mdq_adam_desc;
 int mdq_adam_step(const mdq_adam_desc* d, void* stream);
 
+/* Probe kernel for meshdqn_amd/streams.py (no reference counterpart): `wgs` workgroups that each hold `lds_bytes` of LDS and
+ * spin for `ticks_100mhz` ticks of the 100 MHz wall clock - with more workgroups than CUs it keeps the dispatcher of its
+ * hardware queue busy, which is how two HIP streams are tested for really running beside each other. */
+int mdq_spin(int32_t wgs, int32_t lds_bytes, int64_t ticks_100mhz, void* stream);
+
 /* ---- snapshot interpolation onto coarsened meshes (Env2DAirfoil.py:556-593, :515-522) ---- */
 typedef struct mdq_interp_desc {
   int32_t B, S;            /* target meshes (environments), snapshots                         */

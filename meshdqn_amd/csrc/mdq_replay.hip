@@ -155,3 +155,30 @@ extern "C" int mdq_adam_step(const mdq_adam_desc* d, void* stream) {
   if (hipGetLastError() != hipSuccess) return mdq_set_error("adam_kernel launch failed");
   return 0;
 }
+
+// ---------------------------------------------------------------- stream-concurrency probe
+// A kernel that keeps the workgroup dispatcher of its hardware queue busy: `wgs` workgroups that each hold `lds` bytes of
+// LDS (one per CU at 150 KB) and spin for `ticks` of the 100 MHz wall clock.  meshdqn_amd/streams.py launches it with
+// more workgroups than CUs on one stream and a tiny kernel on another: the tiny kernel finishes at once only if the
+// two streams sit on hardware queues that dispatch independently.
+namespace mdq_replay {
+__global__ __launch_bounds__(64) void spin_kernel(long long ticks, int* sink) {
+  extern __shared__ int spin_lds[];
+  const long long t0 = wall_clock64();
+  int acc = 0;
+  while (wall_clock64() - t0 < ticks) acc += 1;
+  spin_lds[threadIdx.x] = acc;
+  if (sink && acc < 0) sink[0] = spin_lds[0];
+}
+}  // namespace mdq_replay
+
+extern "C" int mdq_spin(int32_t wgs, int32_t lds_bytes, int64_t ticks_100mhz, void* stream) {
+  if (wgs <= 0 || lds_bytes < 256 || lds_bytes > 160 * 1024) return mdq_set_error("mdq_spin: bad arguments");
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mdq_replay::spin_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) return mdq_set_error(hipGetErrorString(e));
+  hipLaunchKernelGGL(mdq_replay::spin_kernel, dim3(wgs), dim3(64), lds_bytes, (hipStream_t)stream, (long long)ticks_100mhz,
+                     (int*)nullptr);
+  if (hipGetLastError() != hipSuccess) return mdq_set_error("spin_kernel launch failed");
+  return 0;
+}

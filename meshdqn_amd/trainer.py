@@ -1035,7 +1035,8 @@ def train_loop_vec(trainer: DQNTrainer, venv, num_steps: int, optim_per_step: in
     overlap = overlap_optimise and rep_dev is not None and hasattr(venv, "step_begin") and ctx.device.type == "cuda"
     if overlap:
         if getattr(trainer, "_opt_stream", None) is None:
-            trainer._opt_stream = torch.cuda.Stream(device=ctx.device)
+            from .streams import concurrent_stream
+            trainer._opt_stream = concurrent_stream(ctx.device, [getattr(venv, "_flow_stream", None)])
         opt_stream, ev_store = trainer._opt_stream, torch.cuda.Event()
         ev_store.record(torch.cuda.current_stream(ctx.device))
     rewards, dones_hist = [], []
@@ -1127,8 +1128,23 @@ def train_loop_device(trainer: DQNTrainer, venv, num_steps: int, optim_per_step:
     fused1 = trainer._fused_of(trainer.policy_net_1)
     fused2 = trainer._fused_of(trainer.policy_net_2)
     main = torch.cuda.current_stream(dev)
+    if main == torch.cuda.default_stream(dev):
+        # the loop does not run on the legacy default stream (see VecEnv2DAirfoil.rollout_device): a stream of its own
+        if getattr(trainer, "_main_stream", None) is None:
+            from .streams import concurrent_stream
+            trainer._main_stream = concurrent_stream(dev, [getattr(venv, "_flow_stream", None)])
+        trainer._main_stream.wait_stream(main)
+        with torch.cuda.stream(trainer._main_stream):
+            out = train_loop_device(trainer, venv, num_steps, optim_per_step=optim_per_step, eps_decay=eps_decay,
+                                    eps_start=eps_start, eps_end=eps_end, share_replay=share_replay, log=log,
+                                    steps_done0=steps_done0, every=every, on_every=on_every, chunk=chunk)
+        main.wait_stream(trainer._main_stream)
+        return out
+    if getattr(venv, "flow_overlap", False) and getattr(venv, "_calibrated_for", None) != main:
+        venv.calibrate_streams(fused1)       # (a flow stream that really overlaps with this loop's stream; resets the envs)
     if getattr(trainer, "_opt_stream", None) is None:
-        trainer._opt_stream = torch.cuda.Stream(device=dev)
+        from .streams import concurrent_stream
+        trainer._opt_stream = concurrent_stream(dev, [getattr(venv, "_flow_stream", None)])
     opt_stream = trainer._opt_stream
     rep = None
     rewards, dones_hist, losses, actions_hist = [], [], [], []
