@@ -121,8 +121,10 @@ __global__ __launch_bounds__(WGT) void gcn_train_kernel(mdq_gcn_net net, mdq_gcn
   float* ws = D.workspace + (size_t)b * wstride;
   float* gp = D.partial + (size_t)b * D.layout.total;
   if (nn > NMAX || ne > EMAX || nn <= 0 || ne < 0) {
-    // a graph the LDS carve-up was not sized for: its loss term is NaN (so is the loss), it adds no gradient
+    // a graph the LDS carve-up was not sized for: its loss term is NaN (so is the loss), it adds no gradient (its slice
+    // still holds the previous minibatch's values: cleared)
     if (tid == 0) ws[0] = __builtin_nanf("");
+    for (int i = tid; i < D.layout.total; i += WGT) gp[i] = 0.f;
     return;
   }
   const int XS = mdq_gcn_xs(net, NMAX);

@@ -184,3 +184,58 @@ def test_pack_kernel_equals_transposed_parameters(lib_built):
                 p.add_(0.25)
         assert rep == 1 or fg._version[:-2] != tuple(p._version for p in net.parameters())
     assert fg._table_key == table
+
+
+def test_fused_learning_step_edge_cases(lib_built):
+    """Ragged minibatch (graphs with fewer nodes than NMAX, a graph without edges, one with a single edge) against
+    autograd; and a graph beyond EMAX: NaN loss, and its gradient slice must not leak the previous minibatch's values."""
+    from meshdqn_amd.airfoilgcnn import NodeRemovalNet
+    from meshdqn_amd.data import Batch, Data
+    from meshdqn_amd.gcn_fused import FusedGcn
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(11)
+    torch.manual_seed(7)
+    nets = [NodeRemovalNet(181, conv_width=128, topk=0.1) for _ in range(2)]
+    for m in nets:
+        m.set_num_nodes(17)
+        m.to(dev)
+
+    def graph(n, e):
+        ei = rng.integers(0, n, size=(2, e)) if e else np.zeros((2, 0), np.int64)
+        return Data(x=torch.from_numpy(rng.standard_normal((n, 17))).float(), edge_index=torch.from_numpy(ei).long())
+    states = [graph(180, 300), graph(97, 150), graph(180, 0), graph(40, 1), graph(11, 30)]
+    nexts = [graph(180, 250), graph(180, 0), graph(60, 90), graph(180, 400), graph(25, 60)]
+    action = torch.tensor([3, 180, 0, 17, 99], dtype=torch.int64, device=dev)
+    reward = torch.tensor([0.3, -1.0, 0.1, 0.0, 0.7], dtype=torch.float32, device=dev)
+    nonfinal = torch.tensor([1.0, 0.0, 1.0, 1.0, 1.0], dtype=torch.float32, device=dev)
+    net, other = nets
+    f_net, f_other = FusedGcn(net), FusedGcn(other)
+    qo = f_other.forward_arrays(*_arrays(nexts, dev), 180, 512)
+    loss, flat = f_net.train_step(*_arrays(states, dev), 180, 512, 0, qo, action, reward, nonfinal, 0.9)
+    torch.cuda.synchronize()
+    flat = flat.clone()
+    with torch.no_grad():
+        nv = other(Batch.from_data_list(nexts).to(dev)).max(1)[0] * nonfinal
+    net.zero_grad(set_to_none=True)
+    pred = net(Batch.from_data_list(states).to(dev)).gather(1, action.reshape(-1, 1)).squeeze(1)
+    ref = torch.nn.HuberLoss()(pred, nv * 0.9 + reward)
+    ref.backward()
+    assert abs(float(loss.item()) - float(ref.detach())) < 2e-5 * max(abs(float(ref.detach())), 1e-3)
+    scale = max(float(p.grad.abs().max()) for p in net.parameters() if p.grad is not None)
+    off = 0
+    for name, p in net.named_parameters():
+        g = flat[off:off + p.numel()].view_as(p)
+        off += p.numel()
+        if p.grad is not None:
+            own = float(p.grad.abs().max())
+            assert float((g - p.grad).abs().max()) < 5e-4 * max(own, 1e-6 * scale), name
+    # the same minibatch with graph 0 beyond the edge capacity: NaN loss; the other graphs' gradient only
+    loss2, flat2 = f_net.train_step(*_arrays(states, dev), 180, 256, 0, qo, action, reward, nonfinal, 0.9)
+    torch.cuda.synchronize()
+    assert torch.isnan(loss2).all() and torch.isfinite(flat2).all()
+    sub = [1, 2, 3, 4]
+    loss3, flat3 = f_net.train_step(*_arrays([states[i] for i in sub], dev), 180, 256, 0, qo[sub].contiguous(), action[sub].contiguous(),
+                                    reward[sub].contiguous(), nonfinal[sub].contiguous(), 0.9)
+    torch.cuda.synchronize()
+    # (mean over 5 graphs vs mean over 4: the refused graph contributes nothing)
+    assert torch.allclose(flat2 * 5.0, flat3 * 4.0, rtol=1e-4, atol=1e-5 * float(flat3.abs().max()))
