@@ -508,7 +508,7 @@ int mdq_restore_rows(int32_t n, void* const* dst, const void* const* src, const 
  * DOLFIN `Mesh.smooth(n)` (flow_solver.py:65-67 and 236-237 after every remesh) for B meshes on the GPU: Gauss-Seidel
  * over the interior vertices in index order, each moved towards the centroid of its neighbours by at most half the
  * minimum altitude of its cells; boundary vertices (an incident edge with one owner) are fixed.  One workgroup per
- * mesh runs the exact sequential dependency graph as a dataflow machine in LDS.  coords [B][NV][2] (in/out),
+ * mesh: a list schedule of the sweep's dependency graph, walked by one wave out of LDS (exact sequential semantics).  coords [B][NV][2] (in/out),
  * cells [B][NT][3], nv / nt [B], iterations [B] (0 = leave that mesh alone); all device pointers.
  * Capacity: NV <= 1024, NT <= 2048 (larger meshes: mdq_smooth_host).
  */

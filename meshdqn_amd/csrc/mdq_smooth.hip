@@ -10,8 +10,9 @@
 // runs it faster than eight did: a first version polled per-vertex sweep counters from 64 queue-owning lane groups
 // in 8 waves (dataflow); its waves were busy a quarter of the time, every hand-off paid a poll, and an update waited
 // on average several thousand cycles for its group to reach it (in-order queues).  Now:
-//   * the setup phase (256 threads) level-schedules one sweep (level = 1 + max level of the lower interior
-//     neighbours) and packs each level into passes of up to 8 independent updates;
+//   * the setup phase (256 threads) LIST-schedules one sweep: a vertex is ready when its lower-numbered interior
+//     neighbours are scheduled, every pass takes the 8 ready vertices with the smallest indices (119 passes per sweep
+//     on ys930; level by level it was 141, the critical path is 113);
 //   * ONE wave walks the passes, sweep after sweep, 8 lanes per update (one incident cell each): no flags, no
 //     polling, no barriers - the LDS serves a wave's operations in order, so the position loads of a pass see the
 //     stores of the pass before;
@@ -19,10 +20,15 @@
 //     reduction exchanges the component a lane does NOT keep - x and y are summed over the 8 lanes with three
 //     exchanges instead of six (even lanes end with the x sum, odd lanes with the y sum);
 //   * the step limit |c - p| <= r_min / 2 is DECIDED in fp32 with a safety margin (squared altitudes by one
-//     v_rcp_f32, 8-lane minimum by three integer minima on the bit patterns); only an undecided or limited update
-//     (none on the reference meshes) runs the exact fp64 path, which also handles degree > 8;
-//   * the metadata of a pass (record addresses of each lane's cell) is prefetched one pass ahead, its vertex list
-//     two passes ahead.
+//     v_rcp_f32, 8-lane minimum by three integer minima on the bit patterns); an undecided or limited update runs the
+//     exact fp64 path (exact_update, any degree);
+//   * the first three sweeps are CAREFUL (decision in front of the store): right after a vertex removal the cavity's
+//     neighbours take limited steps in most launches.  The rest are SPECULATIVE: the position is stored first and the
+//     test of a pass runs behind the position loads of the next pass; the records are checkpointed in the coordinate
+//     array, and a sweep with an undecided update is redone careful from the checkpoint (doubling back-off);
+//   * vertices of more than 8 cells (a few after removals) sit in listed pass pairs that run careful between
+//     speculative segments (a branch for them inside the speculative loop body cost 20 %);
+//   * the metadata of a pass (record addresses of each lane's cell) is prefetched up to three passes ahead.
 // Updates of one pass are independent and every reduction is group-local in a fixed lane order: results are
 // bitwise reproducible and agree with the sequential host loop to round-off (different association).
 #include <hip/hip_runtime.h>
@@ -30,7 +36,7 @@
 #include "../../include/meshdqn_hip.h"
 
 namespace mdq_smoothing {
-// diagnostics (mdq_smooth_stats): [s] = speculative sweeps s that were abandoned for a careful redo, [63] = workgroups run
+// diagnostics (mdq_smooth_stats): [s] = speculative sweeps s that were abandoned for a careful redo
 __device__ unsigned long long g_abandoned[64];
 
 constexpr int SNV = 1024;      // vertex capacity (record offsets must fit 16 bits)
