@@ -689,6 +689,13 @@ def main():
                             f"epsilon = 0.5 actions from default_rng(1370 + ...), meshes diverge (vertices "
                             f"{s3['vertices_min_max'][0]}..{s3['vertices_min_max'][1]} at the end), terminated envs reset in place",
                 "envs_per_gpu": B, "rtol": args.rtol, "dt": 1e-3, "mu": 1e-3, "rho": 1.0,
+                "numerics": {
+                    "ipcs": "mode 3: operator results accumulated with LDS fp64 atomics => reproducible to round-off only; run-to-run "
+                            "spread of drag / lift after 5000 steps 1e-8 .. 1.6e-6 relative (tools/traj_spread.py), inside the 1e-4 "
+                            "contract (5000-step values within 1e-5 of the FEniCS CSV rows, tests/test_golden_gpu.py); the correction "
+                            "solve starts fused on 15 of 16 steps and takes the |b| of its stopping test from the last exact start",
+                    "bitwise_reproducible": "vertex removal / Delaunay restoration, smoothing, topology / N-closest / state graph, "
+                                            "fused Q-forward, learning-step gradient (per-graph slices reduced in graph order)"},
                 "krylov_iters_per_ipcs_step": s3["krylov_iters_per_ipcs_step"],
                 "parallelism": f"dp{world} (independent envs sharded, no data-path collective)",
                 "collective_backend": rccl,
