@@ -710,3 +710,37 @@ def test_device_resident_rollout_equals_host_logic_steps(lib_built, flow):
     for k in range(6):
         assert np.array_equal(out["actions"][k], hist[k][0]), k
         assert np.abs(out["rewards"][k] - hist[k][1]).max() < 1e-12 and np.array_equal(out["dones"][k], hist[k][2])
+
+
+def test_stream_calibration_keeps_a_working_flow_stream_and_resets_the_envs(lib_built):
+    """`VecEnv2DAirfoil.calibrate_streams` (a few real steps per candidate flow stream, the fastest stays) leaves the
+    environments in their initial state and the overlapped flow path working: the rollout that follows equals the one
+    of an uncalibrated twin action by action; `streams.concurrent_stream` hands out a stream that is not the current one."""
+    from meshdqn_amd.airfoilgcnn import NodeRemovalNet
+    from meshdqn_amd.env import Env2DAirfoil
+    from meshdqn_amd.gcn_fused import FusedGcn
+    from meshdqn_amd.streams import concurrent_stream
+    from meshdqn_amd.vec_env import VecEnv2DAirfoil
+    cfg = _config("ys930")
+    base = Env2DAirfoil(cfg)
+    B, K = 6, 5
+    torch.manual_seed(0)
+    net = NodeRemovalNet(181, conv_width=128, topk=0.1)
+    net.set_num_nodes(17)
+    net.cuda()
+    outs = []
+    for calibrate in (False, True):
+        venv = VecEnv2DAirfoil(cfg, B, base_env=base, nthreads=2, flow_steps=1, flow_overlap=True)
+        fg = FusedGcn(net)
+        if calibrate:
+            ms = venv.calibrate_streams(fg, tries=3, steps=3)
+            assert 1 <= len(ms) <= 3 and all(m > 0 for m in ms)
+            assert (venv.nv == venv.NV).all() and (venv.steps == 0).all() and (venv.offset == 0).all()
+        rng = np.random.default_rng(3)
+        outs.append(venv.rollout_device(fg, K, rng.random((K, B)) < 0.5, rng.integers(0, 181, (K, B))))
+        venv.flow_wait()
+    a, b = outs
+    assert np.array_equal(a["actions"], b["actions"]) and np.array_equal(a["dones"], b["dones"]) and np.array_equal(a["nv"], b["nv"])
+    assert np.allclose(a["rewards"], b["rewards"], rtol=1e-9, atol=1e-12)
+    s = concurrent_stream("cuda")
+    assert isinstance(s, torch.cuda.Stream) and s != torch.cuda.current_stream()
