@@ -256,6 +256,8 @@ def measure_env_steps(args, dev, dist, world, flow_steps=0, steps=None, warmup=8
     if keep is not None and not args.host_step:     # HIP events around every smoothing launch of the timed rollouts
         for e in groups.envs:
             e.smooth_events = []
+        from meshdqn_amd import _lib as _L           # ... and the kernel's own count of abandoned speculative sweeps
+        _L.load().mdq_smooth_stats(None, 1)
     times = [_timed(dist, dev, lambda: run(steps)) for _ in range(repeats)]
     el = float(np.median(times))
     venv = groups.envs[0]
@@ -276,6 +278,12 @@ def measure_env_steps(args, dev, dist, world, flow_steps=0, steps=None, warmup=8
             ms = np.array([a.elapsed_time(b_) for a, b_ in ev])
             out["smooth_kernel_in_rollout_ms"] = dict(mean=float(ms.mean()), min=float(ms.min()), max=float(ms.max()),
                                                       launches=int(ms.size))
+            from meshdqn_amd import _lib as _L
+            st = np.zeros(64, np.int64)
+            _L.load().mdq_smooth_stats(st.ctypes.data, 0)
+            out["smooth_kernel_in_rollout_ms"]["abandoned_speculative_sweeps"] = dict(
+                total=int(st[:63].sum()), mesh_launches=int(ms.size) * B,
+                by_sweep={str(i): int(c) for i, c in enumerate(st[:63]) if c})
         for e in groups.envs:
             e.smooth_events = None
     return out
@@ -703,10 +711,13 @@ def main():
             },
             "roofline": {"bound": "hbm", "achieved": sm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sm_gbs / HBM_PEAK_GBS,
                          "traffic": prof("r02_smooth_pmc_summary.json", "hbm_bytes_per_launch"),
-                         "kernel": "smooth_kernel (DOLFIN smooth(50): level-scheduled Gauss-Seidel, one wave per mesh out of LDS)",
+                         "kernel": "smooth_kernel (DOLFIN smooth(50): list-scheduled Gauss-Seidel, one wave per mesh out of LDS)",
                          "launch_ms": sm_ms, "launches_timed": insitu["launches"] if insitu else smk["launches"],
                          "launch_ms_min_max": [insitu["min"], insitu["max"]] if insitu else None,
                          "launch_ms_alone": smk["launch_ms"],
+                         "abandoned_speculative_sweeps": insitu.get("abandoned_speculative_sweeps") if insitu else None,
+                         "traffic_source": "profiles/r02_smooth_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                           "command, gfx950 wide-read correction; counters cannot be read inside the run)",
                          "algorithmic_bytes_per_launch": smk["algorithmic_bytes_per_launch"],
                          "share_of_step": sm_ms / s3["ms_per_batched_step"],
                          "device_copy_GBs_same_run": copy_gbs,
