@@ -372,9 +372,12 @@ def measure_train(args, dev, dist, world):
             el = tt.item()
         if hasattr(venv, "flow_wait"):
             venv.flow_wait()
+        venv_cal = venv
         del venv
         return dict(value=world * args.envs * n / el, ms_per_batched_step=el / n * 1e3, batched_steps=n,
                     optimiser_steps=len(out["losses"]), last_loss=float(out["losses"][-1]) if out["losses"] else None,
+                    stream_calibration_ms=dict(flow=[round(v, 3) for v in getattr(venv_cal, "calibration_ms", [])],
+                                               optimiser=[round(v, 3) for v in getattr(trainer, "opt_calibration_ms", [])]),
                     shared_replay=bool(args.share_replay and world > 1),
                     replay_records=int(trainer.device_memory.size()) if trainer.device_memory is not None else None)
     def guarded(*a):       # (a side measurement must not take the bench line down; every rank fails or succeeds alike)

@@ -590,6 +590,65 @@ class DQNTrainer:
         opt._opt_called = True          # (lr_scheduler's "step() before optimizer.step()" check)
         self.scheds[k].step()
 
+    def calibrate_opt_stream(self, venv, fused_act, tries: int = 6, steps: int = 6):
+        """Pick, by measurement, a stream for the optimiser chain that really runs beside the env step (its main stream
+        = the current one, and its flow stream): like `VecEnv2DAirfoil.calibrate_streams` - HIP's stream -> hardware queue
+        mapping leaves pairs that overlap only partly, and the learning loop then runs at 2.6 instead of 1.95 ms per
+        batched step.  Every candidate carries a stand-in chain (fused forward of one network + `mdq_gcn_train_step` of
+        the other on a fixed random minibatch: the kernels of `optimize_device`, no parameter is changed) through a few
+        real env steps with the loop's own synchronisation; the fastest stays.  The environments are reset afterwards."""
+        dev = self.ctx.device
+        main = torch.cuda.current_stream(dev)
+        B, N = venv.B, venv.N
+        st0 = venv._state_device()
+        F_ = st0["x"].shape[2]
+        mb, EM = self.batch_size, self.e_max
+        g = torch.Generator(device="cpu").manual_seed(7)
+        ne = 600
+        x = torch.randn((mb, N, F_), generator=g).to(dev)
+        esrc = torch.randint(0, N, (mb * ne,), generator=g, dtype=torch.int32).to(dev)
+        edst = torch.randint(0, N, (mb * ne,), generator=g, dtype=torch.int32).to(dev)
+        node_ptr = torch.arange(mb + 1, dtype=torch.int32, device=dev) * N
+        edge_ptr = torch.arange(mb + 1, dtype=torch.int32, device=dev) * ne
+        action = torch.zeros(mb, dtype=torch.int64, device=dev)
+        reward = torch.zeros(mb, dtype=torch.float32, device=dev)
+        nonfinal = torch.ones(mb, dtype=torch.float32, device=dev)
+        f1, f2 = self._fused_of(self.policy_net_1), self._fused_of(self.policy_net_2)
+        f1._pack()
+        f2._pack()
+        rng = np.random.default_rng(977)
+
+        def timed(cand, k):
+            ro = venv.rollout_begin(k, rng.random((k, B)) < 0.5, rng.integers(0, N + 1, (k, B)))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(main)
+            for _ in range(k):
+                main.wait_stream(cand)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                with torch.cuda.stream(cand):
+                    cand.wait_event(ev)
+                    qo = f2.forward_arrays(x, node_ptr, esrc, edst, edge_ptr, N, EM)
+                    f1.train_step(x, node_ptr, esrc, edst, edge_ptr, N, EM, 0, qo, action, reward, nonfinal, self.gamma)
+                venv.rollout_step(ro, fused_act)
+            main.wait_stream(cand)
+            e1.record(main)
+            venv.rollout_end(ro)
+            return e0.elapsed_time(e1) / k
+        results = []
+        for t in range(max(1, int(tries))):
+            cand = self._opt_stream if (t == 0 and getattr(self, "_opt_stream", None) is not None) else torch.cuda.Stream(device=dev)
+            timed(cand, 2)
+            results.append((timed(cand, int(steps)), cand))
+            ms = [r[0] for r in results]
+            if len(ms) >= 2 and min(ms) < 0.85 * max(ms) and ms[-1] <= 1.03 * min(ms):
+                break
+        self._opt_stream = min(results, key=lambda r: r[0])[1]
+        self._opt_calibrated_for = (main, getattr(venv, "_flow_stream", None))
+        self.opt_calibration_ms = [r[0] for r in results]
+        venv.reset_all()
+        return self.opt_calibration_ms
+
     def optimize_device(self, rep: "SharedDeviceReplay", idx, loss_out: Optional[torch.Tensor] = None):
         """One optimiser step on a minibatch of the record ring WITHOUT host synchronisation and without autograd:
         `mdq_replay_sample` (records `idx` -> graph arrays), fused forward of the network without gradient,
@@ -632,7 +691,7 @@ class DQNTrainer:
             self._mb_bufs = bufs
         b = bufs
         if torch.is_tensor(idx):      # already on the device (the loop uploads a whole chunk of minibatches at once)
-            if idx.dtype != torch.int32 or idx.device != dev or not idx.is_contiguous():
+            if idx.dtype != torch.int32 or idx.device.type != "cuda" or not idx.is_contiguous():
                 raise ValueError("optimize_device: device indices must be contiguous int32")
             b["desc"].idx = idx.data_ptr()
         else:
@@ -1140,11 +1199,17 @@ def train_loop_device(trainer: DQNTrainer, venv, num_steps: int, optim_per_step:
                                     steps_done0=steps_done0, every=every, on_every=on_every, chunk=chunk)
         main.wait_stream(trainer._main_stream)
         return out
-    if getattr(venv, "flow_overlap", False) and getattr(venv, "_calibrated_for", None) != main:
+    # (torch.cuda.Stream defines `==` between streams only: `None != stream` is False, hence the explicit tests)
+    cal = getattr(venv, "_calibrated_for", None)
+    if getattr(venv, "flow_overlap", False) and (cal is None or not (cal == main)):
         venv.calibrate_streams(fused1)       # (a flow stream that really overlaps with this loop's stream; resets the envs)
     if getattr(trainer, "_opt_stream", None) is None:
         from .streams import concurrent_stream
         trainer._opt_stream = concurrent_stream(dev, [getattr(venv, "_flow_stream", None)])
+    ocal, flow_now = getattr(trainer, "_opt_calibrated_for", None), getattr(venv, "_flow_stream", None)
+    if ocal is None or not (ocal[0] == main) or not ((ocal[1] is None and flow_now is None) or
+                                                     (ocal[1] is not None and flow_now is not None and ocal[1] == flow_now)):
+        trainer.calibrate_opt_stream(venv, fused1)    # (an optimiser stream that really overlaps; resets the envs)
     opt_stream = trainer._opt_stream
     rep = None
     rewards, dones_hist, losses, actions_hist = [], [], [], []

@@ -705,8 +705,9 @@ class VecEnv2DAirfoil:
         self.flow_wait()
         self._flow_stream = best[1]
         self._calibrated_for = cur
+        self.calibration_ms = [r[0] for r in results]
         self.reset_all()
-        return [r[0] for r in results]
+        return self.calibration_ms
 
     def rollout_begin(self, steps: int, explore=None, rand_actions=None, actions=None):
         """First third of `rollout_device` (the learning loop interleaves its own launches with the steps): uploads the
