@@ -73,7 +73,7 @@ class VecEnv2DAirfoil:
         # pressure solve of the S3 flow step on the freshly coarsened mesh: "cg" (Jacobi-CG, ~165 iterations, 0.28 ms on the
         # flow stream) or "direct" = what the reference does at a remesh (re-factorise: mdq_ipcs_factorize_pressure on the
         # device, 0.86 ms per batch, then a direct solve with 0 iterations; an environment whose mesh exceeds the kernel's
-        # limits falls back to CG by itself).  Beside the smoothing kernel "direct" costs 2-5 % of the env step, 18 % of the
+        # limits falls back to CG by itself).  Beside the smoothing kernel "direct" costs 1-5 % of the env step, 11 % of the
         # learning loop (its flow leg no longer hides next to the optimiser chain): one solve per mesh does not pay for a
         # factorisation, so "cg" is the default here; FlowSolver / deploy (thousands of steps per mesh) factorise
         if flow_pressure not in ("cg", "direct"):
