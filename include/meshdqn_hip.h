@@ -376,6 +376,12 @@ typedef struct mdq_adam_desc {
 } mdq_adam_desc;
 int mdq_adam_step(const mdq_adam_desc* d, void* stream);
 
+/* Up to 8 buffer copies in one launch (no reference counterpart; the env step hands its meshes and the warm-start fields
+ * to the flow engine with it): buffer t = rows[t] rows of row_bytes[t] bytes, consecutive rows src_stride_bytes[t] /
+ * dst_stride_bytes[t] apart (all multiples of 4, pointers 4-byte aligned; device pointers, host arrays of them). */
+int mdq_copy_strided(int32_t n, void* const* dst, const void* const* src, const int64_t* rows, const int64_t* row_bytes,
+                     const int64_t* src_stride_bytes, const int64_t* dst_stride_bytes, void* stream);
+
 /* Probe kernel for meshdqn_amd/streams.py (no reference counterpart): `wgs` workgroups that each hold `lds_bytes` of LDS and
  * spin for `ticks_100mhz` ticks of the 100 MHz wall clock - with more workgroups than CUs it keeps the dispatcher of its
  * hardware queue busy, which is how two HIP streams are tested for really running beside each other. */

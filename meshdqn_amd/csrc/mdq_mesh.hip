@@ -175,6 +175,60 @@ extern "C" int mdq_restore_rows(int32_t n, void* const* dst, const void* const* 
 }
 
 namespace mdq_mesh {
+// up to 8 (strided) buffer copies in ONE launch: blockIdx.y = buffer, blockIdx.x walks its rows x 16 KB chunks
+struct CopyArgs {
+  uint32_t* dst[8];
+  const uint32_t* src[8];
+  int64_t rows[8], row_words[8], src_stride[8], dst_stride[8];   // strides in words
+};
+__global__ __launch_bounds__(256) void copy_strided_kernel(CopyArgs a) {
+  const int t = blockIdx.y;
+  const int64_t rw = a.row_words[t];
+  const int64_t chunks = (rw + RESTORE_CHUNK - 1) / RESTORE_CHUNK;
+  for (int64_t job = blockIdx.x; job < a.rows[t] * chunks; job += gridDim.x) {
+    const int64_t r = job / chunks, c = job - r * chunks;
+    const int64_t w0 = c * RESTORE_CHUNK, w1 = w0 + RESTORE_CHUNK < rw ? w0 + RESTORE_CHUNK : rw;
+    uint32_t* d = a.dst[t] + r * a.dst_stride[t];
+    const uint32_t* s = a.src[t] + r * a.src_stride[t];
+    if (((rw | a.dst_stride[t] | a.src_stride[t]) & 3) == 0 && ((reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(s)) & 15) == 0) {
+      uint4* d4 = reinterpret_cast<uint4*>(d);
+      const uint4* s4 = reinterpret_cast<const uint4*>(s);
+      for (int64_t i = (w0 >> 2) + threadIdx.x; i < (w1 >> 2); i += 256) d4[i] = s4[i];
+    } else {
+      for (int64_t i = w0 + threadIdx.x; i < w1; i += 256) d[i] = s[i];
+    }
+  }
+}
+}  // namespace mdq_mesh
+
+extern "C" int mdq_copy_strided(int32_t n, void* const* dst, const void* const* src, const int64_t* rows,
+                                const int64_t* row_bytes, const int64_t* src_stride_bytes, const int64_t* dst_stride_bytes,
+                                void* stream) {
+  if (n <= 0 || n > 8 || !dst || !src || !rows || !row_bytes || !src_stride_bytes || !dst_stride_bytes)
+    return mdq_set_error("mdq_copy_strided: bad arguments (at most 8 buffers)");
+  mdq_mesh::CopyArgs a;
+  int64_t jobs = 1;
+  for (int t = 0; t < 8; ++t) {
+    const int q = t < n ? t : 0;
+    if (!dst[q] || !src[q] || rows[q] <= 0 || row_bytes[q] <= 0 || ((row_bytes[q] | src_stride_bytes[q] | dst_stride_bytes[q]) & 3) ||
+        (((uintptr_t)dst[q] | (uintptr_t)src[q]) & 3))
+      return mdq_set_error("mdq_copy_strided: rows and strides must be non-empty, 4-byte aligned multiples of 4 bytes");
+    a.dst[t] = static_cast<uint32_t*>(dst[q]);
+    a.src[t] = static_cast<const uint32_t*>(src[q]);
+    a.rows[t] = rows[q];
+    a.row_words[t] = row_bytes[q] / 4;
+    a.src_stride[t] = src_stride_bytes[q] / 4;
+    a.dst_stride[t] = dst_stride_bytes[q] / 4;
+    const int64_t j = a.rows[t] * ((a.row_words[t] + mdq_mesh::RESTORE_CHUNK - 1) / mdq_mesh::RESTORE_CHUNK);
+    jobs = j > jobs ? j : jobs;
+  }
+  const int gx = (int)(jobs < 1024 ? jobs : 1024);
+  hipLaunchKernelGGL(mdq_mesh::copy_strided_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, a);
+  if (hipGetLastError() != hipSuccess) return mdq_set_error("copy_strided_kernel launch failed");
+  return 0;
+}
+
+namespace mdq_mesh {
 // blockIdx.x = environment: its first edge_ptr[b+1] - edge_ptr[b] padded entries -> the packed lists
 __global__ __launch_bounds__(256) void compact_edges_kernel(int EMAX, const int32_t* __restrict__ src_pad,
                                                              const int32_t* __restrict__ dst_pad,
