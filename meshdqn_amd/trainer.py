@@ -1166,13 +1166,14 @@ def train_loop_vec(trainer: DQNTrainer, venv, num_steps: int, optim_per_step: in
 
 def train_loop_device(trainer: DQNTrainer, venv, num_steps: int, optim_per_step: int = 1, eps_decay=10000, eps_start=1.0,
                       eps_end=0.01, share_replay=False, log: Optional["TrainingLog"] = None, steps_done0=None, every: int = 0,
-                      on_every=None, chunk: int = 64):
+                      on_every=None, chunk: int = 64, optimiser_stream: str = "auto"):
     """`train_loop_vec` WITHOUT a host round trip inside a batched step (one rank of configs[3]): the environment step is
     `VecEnv2DAirfoil.rollout_step` (Q-forward, epsilon-greedy choice, vertex removal ... reward / reset logic as kernels),
     the B transitions go into the record ring with one launch (`mdq_replay_step`; with `share_replay` the ranks
     all-gather their B records per step), and the optimiser step (`DQNTrainer.optimize_device`: replay sampling,
-    hand-written forward + backward, flat gradient all-reduce, Adam as kernels) runs on a second stream beside the
-    latency-bound smoothing kernel of the same env step.  The host only draws the random numbers (same streams as
+    hand-written forward + backward, flat gradient all-reduce, Adam as kernels) runs on a side stream beside the
+    latency-bound smoothing kernel of the same env step (`optimiser_stream`: the env's flow stream, behind the flow
+    leg of the previous step, or a stream of its own).  The host only draws the random numbers (same streams as
     `train_loop_vec`: numpy for epsilon-greedy, `random.sample` for the minibatch) and enqueues; rewards / dones /
     losses are read back once per `chunk` steps.  Same returns as `train_loop_vec`."""
     from . import _lib
@@ -1196,21 +1197,34 @@ def train_loop_device(trainer: DQNTrainer, venv, num_steps: int, optim_per_step:
         with torch.cuda.stream(trainer._main_stream):
             out = train_loop_device(trainer, venv, num_steps, optim_per_step=optim_per_step, eps_decay=eps_decay,
                                     eps_start=eps_start, eps_end=eps_end, share_replay=share_replay, log=log,
-                                    steps_done0=steps_done0, every=every, on_every=on_every, chunk=chunk)
+                                    steps_done0=steps_done0, every=every, on_every=on_every, chunk=chunk,
+                                    optimiser_stream=optimiser_stream)
         main.wait_stream(trainer._main_stream)
         return out
     # (torch.cuda.Stream defines `==` between streams only: `None != stream` is False, hence the explicit tests)
     cal = getattr(venv, "_calibrated_for", None)
     if getattr(venv, "flow_overlap", False) and (cal is None or not (cal == main)):
         venv.calibrate_streams(fused1)       # (a flow stream that really overlaps with this loop's stream; resets the envs)
-    if getattr(trainer, "_opt_stream", None) is None:
-        from .streams import concurrent_stream
-        trainer._opt_stream = concurrent_stream(dev, [getattr(venv, "_flow_stream", None)])
-    ocal, flow_now = getattr(trainer, "_opt_calibrated_for", None), getattr(venv, "_flow_stream", None)
-    if ocal is None or not (ocal[0] == main) or not ((ocal[1] is None and flow_now is None) or
-                                                     (ocal[1] is not None and flow_now is not None and ocal[1] == flow_now)):
-        trainer.calibrate_opt_stream(venv, fused1)    # (an optimiser stream that really overlaps; resets the envs)
-    opt_stream = trainer._opt_stream
+    # "auto": on the flow stream when the env step has one and its leg is short (Jacobi-CG pressure: flow leg 1.05 ms +
+    # optimiser chain 0.6 ms still end before the 1.8 ms main chain: 69.3 k env-steps/s, against 68.2 k with a third stream
+    # that has to be calibrated as well); with the per-step re-factorisation (leg 1.7 ms) a stream of its own is better
+    if optimiser_stream == "auto":
+        optimiser_stream = "flow" if (getattr(venv, "flow_overlap", False) and getattr(venv, "flow_pressure", "cg") == "cg") else "own"
+    on_flow = optimiser_stream == "flow" and getattr(venv, "flow_overlap", False)
+    if on_flow:
+        # the optimiser chain rides on the (calibrated) flow stream, behind the flow leg of the previous env step: one side
+        # stream instead of two
+        opt_stream = venv._flow_stream
+    else:
+        if getattr(trainer, "_opt_stream", None) is None:
+            from .streams import concurrent_stream
+            trainer._opt_stream = concurrent_stream(dev, [getattr(venv, "_flow_stream", None)])
+        ocal, flow_now = getattr(trainer, "_opt_calibrated_for", None), getattr(venv, "_flow_stream", None)
+        if ocal is None or not (ocal[0] == main) or not ((ocal[1] is None and flow_now is None) or
+                                                         (ocal[1] is not None and flow_now is not None and ocal[1] == flow_now)):
+            trainer.calibrate_opt_stream(venv, fused1)    # (an optimiser stream that really overlaps; resets the envs)
+        opt_stream = trainer._opt_stream
+    ev_opt = None
     rep = None
     rewards, dones_hist, losses, actions_hist = [], [], [], []
     ep_r = [[] for _ in range(B)]
@@ -1254,7 +1268,8 @@ def train_loop_device(trainer: DQNTrainer, venv, num_steps: int, optim_per_step:
         n_loss = 0
         for k in range(K):
             g = (t0 + step_no + k) % G                         # the ring group this step's records go to
-            main.wait_stream(opt_stream)                       # the weights of the previous optimiser step
+            if ev_opt is not None:
+                main.wait_event(ev_opt)                        # the weights of the previous optimiser step
             fused1._pack()
             fused2._pack()
             base_cur = g * W + (ctx.rank * B if W != B else 0)
@@ -1274,6 +1289,8 @@ def train_loop_device(trainer: DQNTrainer, venv, num_steps: int, optim_per_step:
                     for _k in range(optim_per_step):
                         trainer.optimize_device(rep, mb_dev[n_loss], loss_out=loss_ring[n_loss:n_loss + 1])
                         n_loss += 1
+                    ev_opt = torch.cuda.Event()
+                    ev_opt.record(opt_stream)
             venv.rollout_step(ro, fused1)
             prev = (base_cur, ro["act"][k], ro["rew"][k], ro["done"][k])
             st = ro["state"]

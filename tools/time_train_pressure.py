@@ -22,16 +22,16 @@ dev = torch.device("cuda", 0)
 cfg = bench._env_config(Args)
 base = Env2DAirfoil(cfg, compute_device=dev)
 for rep in range(3):
-    for fp in ("cg", "direct"):
+    for fp, osm in (("cg", "own"), ("cg", "flow"), ("direct", "own"), ("direct", "flow")):
         tr = DQNTrainer(n_actions=180, num_inputs=17, ctx=DistContext(device=dev))
         venv = VecEnv2DAirfoil(cfg, 128, compute_device=dev, base_env=base, flow_steps=1, flow_overlap=True, flow_pressure=fp)
-        train_loop_device(tr, venv, 4)
+        train_loop_device(tr, venv, 4, optimiser_stream=osm)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        train_loop_device(tr, venv, 40)
+        train_loop_device(tr, venv, 40, optimiser_stream=osm)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 40
-        print(f"rep {rep} flow_pressure={fp:6s}: {dt * 1e3:.3f} ms per batched step ({128 / dt:.0f} env-steps/s); "
-              f"calibration flow {[round(v, 2) for v in venv.calibration_ms]} optimiser {[round(v, 2) for v in tr.opt_calibration_ms]}", flush=True)
+        print(f"rep {rep} flow_pressure={fp:6s} optimiser on {osm:4s} stream: {dt * 1e3:.3f} ms per batched step ({128 / dt:.0f} env-steps/s); "
+              f"calibration flow {[round(v, 2) for v in venv.calibration_ms]} optimiser {[round(v, 2) for v in getattr(tr, 'opt_calibration_ms', [])]}", flush=True)
         venv.flow_wait()
         del venv, tr
