@@ -1306,6 +1306,8 @@ def train_loop_device(trainer: DQNTrainer, venv, num_steps: int, optim_per_step:
             rep.count = min(rep.steps_pushed, G) * W
             rep.position = (rep.steps_pushed % G) * W
         out = venv.rollout_end(ro)                              # the one synchronisation of the chunk
+        if ev_opt is not None:
+            ev_opt.synchronize()                                # (the last optimiser chain writes its loss on the side stream)
         new_losses = loss_ring[:n_loss].cpu().numpy().tolist()
         trainer.losses.extend(new_losses)
         losses.extend(new_losses)
