@@ -446,7 +446,82 @@ def _diverged_meshes(args, n_envs, removals=20):
     return [(MeshTopology(coords[b, :nv[b]], cells[b, :nt[b]]), coords[b, :nv[b]].copy()) for b in range(n_envs)]
 
 
-def main():
+def _visible_gpus():
+    """GPUs the kernel driver exposes (kfd topology nodes with SIMDs), without touching the HIP runtime; None if the
+    topology cannot be read (the ranks then find out themselves)."""
+    import glob
+    n, seen = 0, False
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(l.split()[:2] for l in open(f).read().splitlines() if len(l.split()) >= 2)
+        except OSError:
+            continue
+        seen = True
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    return n if seen else None
+
+
+def launch_ranks(args, argv):
+    """`bench.py --gpus N` started by hand or by the driver as ONE process: this parent - which never imports torch or
+    touches a GPU - measures the CPU baseline (child interpreters), then starts N fresh rank processes (one per GPU:
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment, the same command line), relays
+    rank 0's JSON line, and exits non-zero if any rank fails (the reference starts its own workers as well:
+    airfoil_dqn.py:508-514)."""
+    import socket
+    import subprocess
+    import tempfile
+    n = args.gpus
+    have = _visible_gpus()
+    if have is not None and have < n and not os.environ.get("MDQ_SHARE_GPU"):
+        sys.stderr.write(f"[bench] --gpus {n} needs {n} GPUs on this node, the driver exposes {have}: refusing "
+                         "(MDQ_SHARE_GPU=1 MDQ_DIST_BACKEND=gloo lets several ranks share a GPU, for debugging only)\n")
+        return 2
+    env = dict(os.environ)
+    cpu_file = None
+    if not args.no_cpu_baseline:
+        try:
+            txt = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--cpu-budget",
+                                  str(args.cpu_budget)], check=True, capture_output=True, text=True).stdout
+            fd, cpu_file = tempfile.mkstemp(prefix="mdq_cpu_", suffix=".json")
+            with os.fdopen(fd, "w") as f:
+                f.write(txt.strip().splitlines()[-1])
+            env["MDQ_BENCH_CPU_JSON"] = cpu_file
+        except Exception as exc:  # noqa: BLE001 - the baseline is informational
+            sys.stderr.write(f"[bench] cpu baseline child failed ({exc!r})\n")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=env.get("MASTER_PORT", str(port)))
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    out0 = procs[0].communicate()[0]          # (rank 0 ends last: it prints after the final barrier of all ranks)
+    rcs = []
+    for p_ in procs:
+        try:
+            rcs.append(p_.wait(timeout=120))
+        except subprocess.TimeoutExpired:
+            p_.kill()                          # exactly the process this parent started
+            rcs.append(p_.wait())
+    if cpu_file:
+        os.unlink(cpu_file)
+    if any(rcs):
+        sys.stderr.write(f"[bench] rank exit codes {rcs}: no result line\n")
+        sys.stderr.write(out0[-2000:])
+        return 1
+    lines = [l for l in out0.splitlines() if l.startswith("{")]
+    if not lines:
+        sys.stderr.write("[bench] rank 0 printed no JSON line\n")
+        return 1
+    print(lines[-1], flush=True)
+    return 0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50, help="K: batched S3 env steps per timed repeat")
@@ -473,15 +548,28 @@ def main():
                     help="S1 / S3: the step() path with its two host round trips per batched step instead of rollout_device")
     ap.add_argument("--no-flow-overlap", action="store_true",
                     help="S3: run the IPCS step of an env step in line instead of beside the next step's mesh kernels")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+
+    if args.cpu_baseline_child:                      # child interpreter: CPU legs only, JSON on stdout
+        print(json.dumps(cpu_baseline(args.cpu_budget)), flush=True)
+        return 0
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        return launch_ranks(args, argv)              # N fresh rank processes; this one stays off the GPU
+    if int(env_world or "1") != args.gpus:
+        sys.stderr.write(f"[bench] --gpus {args.gpus} but WORLD_SIZE={env_world}: the launcher's world and the flag disagree, "
+                         "refusing to report a line with the wrong n_gpus\n")
+        return 2
 
     # CPU baseline FIRST, before anything initialises the GPU: its multi-process leg starts child interpreters
     # (fork + exec), which must not happen from a process that already holds the device
     cpu = None
-    if args.cpu_baseline_child:                      # child interpreter: CPU legs only, JSON on stdout
-        print(json.dumps(cpu_baseline(args.cpu_budget)), flush=True)
-        return
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
+    if os.environ.get("MDQ_BENCH_CPU_JSON") and int(os.environ.get("RANK", "0")) == 0:
+        try:                                         # measured by the launching parent (launch_ranks) before the ranks started
+            cpu = json.load(open(os.environ["MDQ_BENCH_CPU_JSON"]))
+        except Exception as exc:  # noqa: BLE001
+            sys.stderr.write(f"[bench] cannot read the parent's cpu baseline ({exc!r})\n")
+    elif int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
         # in a child interpreter (started before this process touches the GPU): whatever the numpy / scipy / Qhull
         # heavy oracle run leaves behind in the process state was measured to slow the later learning loop by 30 %
         import subprocess
@@ -506,7 +594,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # MDQ_SHARE_GPU=1 + MDQ_DIST_BACKEND=gloo: debugging aid that lets the multi-rank control flow be exercised on
         # a box with fewer GPUs than ranks (RCCL refuses two ranks on one device); never set by the driver
-        dev_index = local_rank % torch.cuda.device_count() if os.environ.get("MDQ_SHARE_GPU") else local_rank
+        ndev = torch.cuda.device_count()
+        if ndev < 1 or (local_rank >= ndev and not os.environ.get("MDQ_SHARE_GPU")):
+            sys.stderr.write(f"[bench] rank {rank}: local rank {local_rank} has no GPU of its own ({ndev} visible): --gpus "
+                             f"{args.gpus} needs {args.gpus} GPUs on this node\n")
+            return 2
+        dev_index = local_rank % ndev if os.environ.get("MDQ_SHARE_GPU") else local_rank
         torch.cuda.set_device(dev_index)
         backend = os.environ.get("MDQ_DIST_BACKEND", "nccl")
         if backend == "nccl":
@@ -584,8 +677,9 @@ def main():
     s1 = measure_env_steps(args, dev, dist, world, 0, repeats=3) if side else None
     tr = measure_train(args, dev, dist, world) if side and args.train_steps > 0 else None
     cfgs = {}
-    if side and not args.no_configs and world == 1:
-        # BASELINE configs beyond C1 / C2-identical: iteration counts included, rank-local, short
+    if side and not args.no_configs and rank == 0:
+        # BASELINE configs beyond C1 / C2-identical: iteration counts included, RANK-LOCAL (rank 0's GPU; the other ranks
+        # wait at the final barrier), short
         try:
             dm = _diverged_meshes(args, B)
             c2, b2 = measure_s2(args, dev, None, 1, [t for t, _ in dm], [c for _, c in dm], 50, 10, args.spinup,
@@ -687,6 +781,7 @@ def main():
             "s1_env_steps_per_s": None if s1 is None else s1["value"],
             "s2_ipcs_env_steps_per_s": s2["value"],
             "training_env_steps_per_s": None if tr is None else tr["value"],
+            "collective_backend": rccl,          # backend, RCCL version, ranks (None for a single rank)
             "config": {
                 "workload": f"{args.mesh} ({nv} vertices / {nt} triangles), {B} batched envs per GPU, step = S3 (north-star env "
                             f"step): remove vertex + Delaunay restoration + smooth(50) + 5-snapshot interpolation + 10 force "
@@ -730,9 +825,14 @@ def main():
                                  "kernels of the previous env step run beside them); launch_ms_alone = the same meshes with "
                                  "nothing else on the chip. The HBM fraction is reported because the contract asks for it; "
                                  "it is not the resource that binds",
-                         "step": {"algorithmic_bytes_per_batched_step": s3_step_bytes, "s1_part_bytes_per_env": 0.7e6,
-                                  "ipcs_leg_bytes_survey_csr_convention": s3_ipcs_bytes, "achieved_GBs": s3_gbs,
-                                  "frac": s3_gbs / HBM_PEAK_GBS}},
+                         "traffic_measured_in_run": False,
+                         "step_survey_convention_equivalent": {
+                             "note": "NOT a roofline fraction: the bytes an assembled-CSR implementation would stream per batched "
+                                     "step by SURVEY 8(d)'s convention, divided by the step time; the matrix-free kernels move "
+                                     "~2 % of them (PMC)",
+                             "survey_bytes_per_batched_step": s3_step_bytes, "s1_part_bytes_per_env": 0.7e6,
+                             "ipcs_leg_bytes_survey_csr_convention": s3_ipcs_bytes, "survey_equivalent_GBs": s3_gbs,
+                             "survey_equivalent_over_hbm_peak": s3_gbs / HBM_PEAK_GBS}},
             "roofline_s2_velocity": {
                 "bound": "lds-atomic/fp64", "kernel": "at_velocity_kernel (rhs1 + matrix-free Jacobi-BiCGStab, LDS fp64 atomics)",
                 "launch_ms": k_vel, "algorithmic_bytes_per_launch": vel_bytes, "achieved_GBs_model": vel_gbs,
@@ -758,4 +858,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

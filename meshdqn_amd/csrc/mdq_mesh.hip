@@ -320,7 +320,10 @@ __global__ void env_smooth_iters_kernel(int B, const int32_t* rem, const int32_t
   if (b < B) its[b] = (rem[b] >= 0 && rstat[b] == 0) ? iterations : 0;
 }
 
-// reward / terminal flag (Env2DAirfoil.calculate_reward + the bookkeeping of step()): one thread per environment
+// reward / terminal flag (Env2DAirfoil.calculate_reward + the bookkeeping of step()): one thread per environment.
+// Codes as in Env2DAirfoil.py:342-364: 0 = removed (reward from calculate_reward), 1 = "already removed" (reward -1, NOT
+// terminal), 2 = broken / out of vertices (reward -1, terminal).  The reference's _remove_vertex / _check_mesh only ever
+// return 0 or 2 (:458,:491,:573,:587,:598,:602) and nothing here produces 1 either; the branch is kept for parity.
 __global__ void env_result_kernel(int B, int N, int S, const double* new_drags, const double* gt_drag, const int32_t* nv,
                                   int32_t nv0, const int32_t* rstat, const int32_t* topo_status, const int32_t* nsel,
                                   int32_t* code, int32_t* steps, double threshold, double time_reward, double goal_vertices,
@@ -349,7 +352,7 @@ __global__ void env_result_kernel(int B, int N, int S, const double* new_drags, 
   const bool vert = (double)nv[b] < goal_vertices * (double)nv0;
   const bool ok = c == 0;
   double r = ok ? drag_reward + tr : negative_reward;
-  bool dn = ok ? (acc || vert) : true;
+  bool dn = ok ? (acc || vert) : (c != 1);
   const int st = steps[b] + 1;
   dn = dn || st >= timesteps;
   reward[b] = r;

@@ -245,13 +245,17 @@ class FusedGcn:
 
     @torch.no_grad()
     def forward_arrays(self, x, node_ptr, esrc, edst, edge_ptr, nmax, emax, stream=None, edge_counts=None,
-                       return_perm=False, return_status=False):
+                       return_perm=False, return_status=False, pack=True):
         """Same launch on pre-built arrays (what `VecEnv2DAirfoil.get_state` returns): x (sumN,F) f32,
         node_ptr / edge_ptr (B+1,) i32, esrc / edst (sumE,) i32 local node ids.  `nmax` / `emax` size the kernel's LDS
         carve-up: `edge_counts` (host array of the per-graph edge counts, where the caller has them) is checked against
         `emax` before the launch, and the kernel itself refuses larger graphs (NaN outputs, `return_status`).
-        `return_perm`: also the (B, levels, nmax) TopKPooling `perm` arrays."""
-        self._pack(stream)
+        `return_perm`: also the (B, levels, nmax) TopKPooling `perm` arrays.  `pack=False`: use the packed parameter copy
+        as it is (the caller has called `_pack()` at a point ordered against the writers of the parameters)."""
+        if pack:
+            self._pack(stream)
+        elif self.desc is None:
+            raise _lib.MeshDQNHipError("forward_arrays(pack=False) before the first _pack()")
         d = self.desc
         B = node_ptr.numel() - 1
         if edge_counts is not None and len(edge_counts) and int(max(edge_counts)) > int(emax):

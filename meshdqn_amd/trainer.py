@@ -259,6 +259,20 @@ def allgather_records(ctx: DistContext, rec: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def allgather_records_into(ctx: DistContext, R: torch.Tensor, base: int, B: int, W: int):
+    """The record all-gather of the device loop, IN PLACE in the record ring `R`: every rank has written its B finished
+    records at `base` = group base + rank * B; afterwards the group of W = world * B rows holds everybody's records in
+    rank order on every rank.  RCCL: the in-place form of the all-gather (the input is this rank's slice of the output:
+    no staging copy, no copy back); other backends (gloo, CPU tests) go through a staging buffer.  Enqueued on the
+    CURRENT stream."""
+    gp = base // W
+    out, inp = R[gp * W:(gp + 1) * W], R[base:base + B]
+    if dist.get_backend() == "nccl":
+        dist.all_gather_into_tensor(out, inp)
+    else:
+        out.copy_(allgather_records(ctx, inp.clone()))
+
+
 def allgather_transitions(ctx: DistContext, trs: List[Transition], n_nodes: int, n_feat: int, e_max: int):
     """All ranks contribute the same number of transitions per call (one per environment step)."""
     rec = pack_transitions(trs, n_nodes, n_feat, e_max).to(ctx.device)
@@ -506,11 +520,17 @@ class DQNTrainer:
         return self.losses[-1]
 
     # --- learning on the device: hand-written forward + backward, replay sampling and Adam as kernels --------------
-    def _fused_of(self, net):
+    def _fused_of(self, net, role: str = "act"):
+        """The packed device copy of `net`'s parameters + launchers.  Two copies per network: "act" (the Q-forward of
+        the env step, repacked on the MAIN stream of a device loop, only behind the event of the last optimiser chain)
+        and "train" (the learning step and its no-grad forward, repacked on the OPTIMISER stream, in order with the
+        `mdq_adam_step` launches of that stream) - one shared copy was repacked by the acting forward while the Adam
+        kernel of the other stream was writing the parameters."""
         from .gcn_fused import FusedGcn
-        if not hasattr(net, "_fused"):
-            net._fused = FusedGcn(net)
-        return net._fused
+        attr = "_fused" if role == "act" else "_fused_train"
+        if not hasattr(net, attr):
+            setattr(net, attr, FusedGcn(net))
+        return getattr(net, attr)
 
     def _adam_state(self, k: int, total: int):
         """Flat first / second moment buffers of network k laid out like the flat gradient.  The entries of the torch
@@ -613,7 +633,7 @@ class DQNTrainer:
         action = torch.zeros(mb, dtype=torch.int64, device=dev)
         reward = torch.zeros(mb, dtype=torch.float32, device=dev)
         nonfinal = torch.ones(mb, dtype=torch.float32, device=dev)
-        f1, f2 = self._fused_of(self.policy_net_1), self._fused_of(self.policy_net_2)
+        f1, f2 = self._fused_of(self.policy_net_1, "train"), self._fused_of(self.policy_net_2, "train")
         f1._pack()
         f2._pack()
         rng = np.random.default_rng(977)
@@ -702,8 +722,8 @@ class DQNTrainer:
         gs = dict(x=b["x_s"], esrc=b["esrc_s"], edst=b["edst_s"], edge_ptr=b["edge_ptr_s"])
         gn = dict(x=b["x_n"], esrc=b["esrc_n"], edst=b["edst_n"], edge_ptr=b["edge_ptr_n"])
         go, gd = (gn, gs) if sel else (gs, gn)
-        qo = self._fused_of(other).forward_arrays(go["x"], b["node_ptr"], go["esrc"], go["edst"], go["edge_ptr"], N, EM)
-        loss, flat = self._fused_of(net).train_step(gd["x"], b["node_ptr"], gd["esrc"], gd["edst"], gd["edge_ptr"], N, EM,
+        qo = self._fused_of(other, "train").forward_arrays(go["x"], b["node_ptr"], go["esrc"], go["edst"], go["edge_ptr"], N, EM)
+        loss, flat = self._fused_of(net, "train").train_step(gd["x"], b["node_ptr"], gd["esrc"], gd["edst"], gd["edge_ptr"], N, EM,
                                                     0 if sel else 1, qo, b["action"], b["reward"], b["nonfinal"], self.gamma,
                                                     loss_out=loss_out)
         if self.ctx.world > 1:
@@ -1186,7 +1206,6 @@ def train_loop_device(trainer: DQNTrainer, venv, num_steps: int, optim_per_step:
     W = B * ctx.world if (share_replay and ctx.world > 1) else B     # records per batched step in this rank's ring
     steps_done = np.zeros(B, np.int64) if steps_done0 is None else np.asarray(steps_done0, np.int64).copy()
     fused1 = trainer._fused_of(trainer.policy_net_1)
-    fused2 = trainer._fused_of(trainer.policy_net_2)
     main = torch.cuda.current_stream(dev)
     if main == torch.cuda.default_stream(dev):
         # the loop does not run on the legacy default stream (see VecEnv2DAirfoil.rollout_device): a stream of its own
@@ -1270,28 +1289,33 @@ def train_loop_device(trainer: DQNTrainer, venv, num_steps: int, optim_per_step:
             g = (t0 + step_no + k) % G                         # the ring group this step's records go to
             if ev_opt is not None:
                 main.wait_event(ev_opt)                        # the weights of the previous optimiser step
+            # the ACTING copy follows the parameters here and only here: behind the event of the last optimiser chain and
+            # in front of the next one (which waits for `ev` below); rollout_step must not repack (pack=False): by then
+            # the host has already bumped the version for an Adam kernel that is still in flight on the other stream
             fused1._pack()
-            fused2._pack()
             base_cur = g * W + (ctx.rank * B if W != B else 0)
             _lib.check(lib.mdq_replay_step(rep.R.data_ptr(), rep.rec_len, rep.capacity, B, N * st["x"].shape[2], rep.e_max,
                                            st["x"].data_ptr(), st["edge_src_pad"].data_ptr(), st["edge_dst_pad"].data_ptr(),
                                            st["nedges_dev"].data_ptr(), base_cur, -1 if prev is None else prev[0],
                                            None if prev is None else prev[1].data_ptr(), None if prev is None else prev[2].data_ptr(),
                                            None if prev is None else prev[3].data_ptr(), _lib.stream_ptr()), "mdq_replay_step")
-            if prev is not None and W != B:                    # shared replay: everybody's finished records of that step
-                gp = prev[0] // W                               # (rank r's B records sit at group base + r * B on every rank)
-                rep.R[gp * W:(gp + 1) * W].copy_(allgather_records(ctx, rep.R[prev[0]:prev[0] + B].clone()))
             ev = torch.cuda.Event()
             ev.record(main)
-            if min(t0 + step_no + k, G - 1) * W >= trainer.batch_size:
+            gather = prev is not None and W != B               # shared replay: everybody's finished records of that step
+            do_opt = min(t0 + step_no + k, G - 1) * W >= trainer.batch_size
+            if gather or do_opt:
                 with torch.cuda.stream(opt_stream):
                     opt_stream.wait_event(ev)
-                    for _k in range(optim_per_step):
+                    if gather:
+                        # on the optimiser stream, in front of the chain that may sample those records, in place in the ring
+                        # (rank r's B records sit at group base + r * B on every rank): off the latency chain of the env step
+                        allgather_records_into(ctx, rep.R, prev[0], B, W)
+                    for _k in range(optim_per_step if do_opt else 0):
                         trainer.optimize_device(rep, mb_dev[n_loss], loss_out=loss_ring[n_loss:n_loss + 1])
                         n_loss += 1
                     ev_opt = torch.cuda.Event()
                     ev_opt.record(opt_stream)
-            venv.rollout_step(ro, fused1)
+            venv.rollout_step(ro, fused1, pack=False)
             prev = (base_cur, ro["act"][k], ro["rew"][k], ro["done"][k])
             st = ro["state"]
         if step_no + K >= num_steps and prev is not None:       # last chunk: finish the records of the last step too
@@ -1300,8 +1324,9 @@ def train_loop_device(trainer: DQNTrainer, venv, num_steps: int, optim_per_step:
                                            st["nedges_dev"].data_ptr(), -1, prev[0], prev[1].data_ptr(), prev[2].data_ptr(),
                                            prev[3].data_ptr(), _lib.stream_ptr()), "mdq_replay_step")
             if W != B:
-                gp = prev[0] // W
-                rep.R[gp * W:(gp + 1) * W].copy_(allgather_records(ctx, rep.R[prev[0]:prev[0] + B].clone()))
+                if ev_opt is not None:
+                    main.wait_event(ev_opt)
+                allgather_records_into(ctx, rep.R, prev[0], B, W)
             rep.steps_pushed = t0 + num_steps
             rep.count = min(rep.steps_pushed, G) * W
             rep.position = (rep.steps_pushed % G) * W

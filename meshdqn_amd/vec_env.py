@@ -621,7 +621,7 @@ class VecEnv2DAirfoil:
         rewards[ok] = (drag_reward + time_reward)[ok]
         dones[ok] = (acc | vert)[ok]
         rewards[~ok] = self.NEGATIVE_REWARD
-        dones[~ok] = True
+        dones[~ok] = code[~ok] != 1        # (code 1 = "already removed": -1, not terminal, Env2DAirfoil.py:359-360; never produced)
         self.steps += 1
         dones |= self.steps >= self.timesteps
         infos = dict(code=code, nv=self.nv.copy(), new_drags=self.new_drags.copy(), new_lifts=self.new_lifts.copy())
@@ -756,9 +756,11 @@ class VecEnv2DAirfoil:
         ro["state"] = self._state_device()
         return ro
 
-    def rollout_step(self, ro, fused):
+    def rollout_step(self, ro, fused, pack: bool = True):
         """One batched env step of a `rollout_begin` context, enqueued on the current stream; afterwards `ro["state"]`
-        is the new batched state and `ro["act"][k] / ro["rew"][k] / ro["done"][k]` (device) describe the step (k = ro["k"] - 1)."""
+        is the new batched state and `ro["act"][k] / ro["rew"][k] / ro["done"][k]` (device) describe the step (k = ro["k"] - 1).
+        `pack=False`: the Q-forward uses the packed parameter copy as it is (a learning loop whose optimiser runs on another
+        stream brings it up to date itself, at a point that is ordered against the parameter writes)."""
         dt, lib, B, N, S, k = self.dtopo, self.lib, self.B, self.N, self.S, ro["k"]
         if k >= ro["K"]:
             raise IndexError("rollout_step beyond the steps of rollout_begin")
@@ -766,7 +768,7 @@ class VecEnv2DAirfoil:
         st, rem, its = ro["state"], ro["rem"], ro["its"]
         q = None
         if not ro["given"]:
-            q = fused.forward_arrays(st["x"], st["node_ptr"], st["esrc"], st["edst"], st["edge_ptr"], N, self.EMAX)
+            q = fused.forward_arrays(st["x"], st["node_ptr"], st["esrc"], st["edst"], st["edge_ptr"], N, self.EMAX, pack=pack)
         _lib.check(lib.mdq_env_act(B, N, None if q is None else q.data_ptr(),
                                    None if ro["explore"] is None else ro["explore"][k].data_ptr(),
                                    None if ro["rand"] is None else ro["rand"][k].data_ptr(), dt.t["nsel"].data_ptr(),

@@ -1,7 +1,8 @@
-"""GPU: bench.py's contract line, single rank and two torchrun ranks.  The two-rank case shares cuda:0 between the
-ranks (MDQ_SHARE_GPU=1) over gloo, because RCCL refuses two ranks on one device: it exercises the multi-rank control
-flow (rank-0 build, barriers, max-over-ranks timing, sharded envs, the gradient all-reduce of the learning loop), not
-RCCL itself."""
+"""GPU: bench.py's contract line, single rank and two ranks - started by bench.py itself (`--gpus 2`: the parent starts
+the rank processes) and by torchrun (the driver's form).  The two-rank cases share cuda:0 between the ranks
+(MDQ_SHARE_GPU=1) over gloo, because RCCL refuses two ranks on one device: they exercise the multi-rank control flow
+(rank-0 build, barriers, max-over-ranks timing, sharded envs, the gradient all-reduce and the record all-gather of the
+learning loop), not RCCL itself."""
 import json
 import os
 import subprocess
@@ -37,7 +38,8 @@ def test_bench_single_rank_line(lib_built):
     assert "S3" in res["config"]["workload"] and res["config"]["krylov_iters_per_ipcs_step"]["velocity_bicgstab"] > 0
     roof = res["roofline"]
     assert roof["bound"] == "hbm" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
-    assert "smooth_kernel" in roof["kernel"] and roof["launch_ms"] > 0 and roof["step"]["ipcs_leg_bytes_survey_csr_convention"] > 0
+    assert "smooth_kernel" in roof["kernel"] and roof["launch_ms"] > 0 and roof["step_survey_convention_equivalent"]["ipcs_leg_bytes_survey_csr_convention"] > 0
+    assert roof["traffic_measured_in_run"] is False and "step" not in roof
     assert res["roofline_s2_velocity"]["bound"] == "lds-atomic/fp64"
     cpu = res["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["s2_ipcs"]["value"] > 0
@@ -54,14 +56,44 @@ def test_bench_single_rank_line(lib_built):
         assert res[k] > 0
 
 
-def test_bench_two_ranks_share_one_gpu(lib_built):
-    env = dict(os.environ, MDQ_SHARE_GPU="1", MDQ_DIST_BACKEND="gloo")
-    res = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                 "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2", "--share-replay"] + SMALL, env)
-    assert KEYS <= set(res) and "cpu_baseline" not in res          # the CPU leg is rank 0 at N = 1 only
-    assert res["n_gpus"] == 2
+def test_bench_gpus_flag_starts_the_ranks_itself(lib_built):
+    """`python bench.py --gpus 2` (no torchrun, WORLD_SIZE unset): the parent starts two rank processes, measures the CPU
+    baseline itself and relays rank 0's line, which keeps `cpu_baseline` and the rank-local C2 / C3 / C5 entries."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MDQ_SHARE_GPU="1", MDQ_DIST_BACKEND="gloo", MDQ_BENCH_CPU_LEGS="s2only")
+    res = _line([sys.executable, "bench.py", "--gpus", "2", "--share-replay", "--cpu-budget", "1"] + SMALL, env)
+    assert KEYS | {"cpu_baseline", "collective_backend"} <= set(res)
+    assert res["n_gpus"] == 2 and res["collective_backend"]["ranks"] == 2
     assert abs(res["value"] - 2 * 16 * 6 / (res["ms_per_step"] * 6e-3)) < 1e-6 * res["value"]
-    assert res["rates"]["training_loop"]["value"] > 0 and res["config"]["collective_backend"]["ranks"] == 2
+    assert res["cpu_baseline"]["s2_ipcs"]["value"] > 0
+    for k in ("C2_s2_diverged_meshes", "C3_s3_ah93w145", "C5_s2_refined_mesh"):
+        assert res["rates"][k]["value"] > 0, (k, res["rates"][k])
     for k in ("device_loop_s3", "device_loop_s1", "host_loop_s1"):   # every loop ran (no fallback), with the record all-gather
         r = res["rates"]["training_loop"][k]
         assert "error" not in r and r["optimiser_steps"] > 0 and r["shared_replay"], (k, r)
+
+
+def test_bench_gpus_flag_refuses_a_node_with_fewer_gpus(lib_built):
+    """One GPU here: `--gpus 2` without the debugging override must fail loudly, not print an n_gpus: 1 line."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with a single GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MDQ_SHARE_GPU")}
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--no-cpu-baseline"] + SMALL, cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "needs 2 GPUs" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    # and a launcher world that disagrees with the flag is refused as well
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--no-cpu-baseline"] + SMALL, cwd=ROOT,
+                         env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "disagree" in out.stderr
+
+
+def test_bench_two_torchrun_ranks_share_one_gpu(lib_built):
+    """The driver's form for N > 1: torchrun starts the ranks (headline only here: --s1-steps 0 skips the side measurements)."""
+    env = dict(os.environ, MDQ_SHARE_GPU="1", MDQ_DIST_BACKEND="gloo")
+    small = list(SMALL)
+    small[small.index("--s1-steps") + 1] = "0"
+    res = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                 "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2"] + small, env)
+    assert res["n_gpus"] == 2 and res["collective_backend"]["ranks"] == 2 and res["config"]["collective_backend"]["ranks"] == 2
+    assert abs(res["value"] - 2 * 16 * 6 / (res["ms_per_step"] * 6e-3)) < 1e-6 * res["value"]

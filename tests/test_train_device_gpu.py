@@ -157,6 +157,57 @@ def test_device_learning_loop_follows_the_host_loop(lib_built):
     assert trainers[0].num_grads == trainers[1].num_grads and trainers[0].select == trainers[1].select
 
 
+@pytest.mark.parametrize("target_update,optim_per_step", [(1, 1), (2, 1), (1, 2)])
+def test_device_loop_trains_the_acting_network_on_the_side_stream(lib_built, target_update, optim_per_step):
+    """The double-DQN toggle flipping every 1 / 2 gradient applications: policy_net_1 - the network the env step acts
+    with on the main stream - is the one the optimiser chain of the side stream writes.  The acting copy of its packed
+    parameters must follow every update exactly once, at a point ordered against `mdq_adam_step` (it was repacked by
+    the acting forward while the Adam kernel was in flight, and stayed one update stale).  Against the host loop from
+    the same seeds: same actions / rewards / terminations (the greedy actions see the same weights), same losses and
+    the same two networks; afterwards both packed copies equal the parameters."""
+    from meshdqn_amd.env import Env2DAirfoil
+    from meshdqn_amd.trainer import DistContext, DQNTrainer, train_loop_device, train_loop_vec
+    from meshdqn_amd.vec_env import VecEnv2DAirfoil
+    cfg = _cfg()
+    base = Env2DAirfoil(cfg)
+    outs, trainers = [], []
+    for loop in (train_loop_vec, train_loop_device):
+        np.random.seed(23)
+        random.seed(23)
+        tr = DQNTrainer(n_actions=180, num_inputs=17, ctx=DistContext(), batch_size=8, lr=1e-3, target_update=target_update)
+        venv = VecEnv2DAirfoil(cfg, 6, base_env=base, nthreads=2)
+        kw = dict(chunk=5) if loop is train_loop_device else {}
+        # eps_end = 0.6: a good share of greedy actions, which depend on the acting weights
+        outs.append(loop(tr, venv, 12, eps_decay=2, eps_end=0.6, optim_per_step=optim_per_step, **kw))
+        trainers.append(tr)
+    a, b = outs
+    assert np.array_equal(a["dones"], b["dones"])
+    assert np.allclose(a["rewards"], b["rewards"], rtol=1e-9, atol=1e-12)
+    assert len(a["losses"]) == len(b["losses"]) == 10 * optim_per_step and np.isfinite(b["losses"]).all()
+    assert np.allclose(a["losses"], b["losses"], rtol=2e-3, atol=1e-6), (a["losses"], b["losses"])
+    for n1, n2 in ((trainers[0].policy_net_1, trainers[1].policy_net_1), (trainers[0].policy_net_2, trainers[1].policy_net_2)):
+        for (name, p), q in zip(n1.named_parameters(), n2.parameters()):
+            assert float((p - q).detach().abs().max()) < 2e-4 * max(1e-2, float(p.detach().abs().max())), name
+    assert trainers[0].num_grads == trainers[1].num_grads and trainers[0].select == trainers[1].select
+    # the packed copies of the device trainer: a repack now must not change anything the kernels would read
+    tr = trainers[1]
+    torch.cuda.synchronize()
+    for net in (tr.policy_net_1, tr.policy_net_2):
+        for role in ("act", "train"):
+            f = tr._fused_of(net, role)
+            if f.desc is None:
+                continue
+            f._pack()
+            torch.cuda.synchronize()
+            after = [t.clone() for t in f._keep]
+            f._version = None
+            f._pack()
+            torch.cuda.synchronize()
+            assert all(torch.equal(x, y) for x, y in zip(after, f._keep))
+            w = net.lin3.weight.detach()
+            assert torch.equal(after[-2].reshape(w.shape[1], w.shape[0]), w.t().contiguous())   # lin3_w, packed [in][out]
+
+
 def test_device_loop_record_ring_wraps_and_continues(lib_built):
     """A record ring much smaller than the run (5 groups of B records): the two halves of `mdq_replay_step` land in the
     right records across the wrap-around and across two calls of the loop (the second continues the ring): every
