@@ -522,6 +522,19 @@ int mdq_smooth(int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t*
                const int32_t* nt, const int32_t* iterations, void* stream);
 
 /*
+ * The same smoothing, faster: the first three sweeps by mdq_smooth's kernel (right after a vertex removal the cavity's
+ * neighbours take limited steps), the remaining FULL-STEP sweeps as blocked triangular solves of the linear system a
+ * Gauss-Seidel sweep is ((D - L) x_new = U x_old, 32-row blocks, inverses built once per launch), every sweep validated
+ * in parallel (was each update clearly a full step?); an environment with a sweep that was not is rolled back to the
+ * start of that sweep and finished by mdq_smooth's kernel: exact sequential semantics, results equal to mdq_smooth to
+ * round-off (different association).  Same arguments as mdq_smooth + a device workspace of at least
+ * mdq_smooth_fast_workspace_bytes(B, NV) bytes, 16-byte aligned (block inverses, per-environment roll-back counters).
+ */
+int64_t mdq_smooth_fast_workspace_bytes(int32_t B, int32_t NV);
+int mdq_smooth_fast(int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t* cells, const int32_t* nv,
+                    const int32_t* nt, const int32_t* iterations, void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
  * Diagnostics of mdq_smooth since the last reset (no reference counterpart): out64[s], s < 63 = speculative sweeps s
  * that met an update that was not clearly a full step and were redone by careful sweeps (see mdq_smooth.hip).
  * out64 is a HOST array of 64 int64 (may be NULL); reset != 0 zeroes the counters.  Synchronises the device.

@@ -119,6 +119,9 @@ SYMBOLS = {
     "mdq_smooth": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_void_p]),
     "mdq_smooth_stats": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mdq_smooth_fast_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
+    "mdq_smooth_fast": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_int64, C.c_void_p]),
     "mdq_ipcs_factorize_pressure": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdq_gcn_train_workspace": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32]),
     "mdq_gcn_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -7,6 +7,7 @@
 #include "mdq_replay.hip"
 #include "mdq_mesh.hip"
 #include "mdq_smooth.hip"
+#include "mdq_smooth_linear.hip"
 #include "mdq_topology.hip"
 #include "mdq_remesh.hip"
 #include "mdq_host_mesh.hip"

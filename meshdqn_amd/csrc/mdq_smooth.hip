@@ -179,7 +179,7 @@ __device__ __forceinline__ bool exact_update(const lds_u8* recb, const lds_i32* 
 
 __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coords, const int32_t* cells,
                                                      const int32_t* nv_, const int32_t* nt_, const int32_t* iters_,
-                                                     long long* trace) {
+                                                     int cap, long long* trace) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
   unsigned char* recb = lds + OFF_REC;
   unsigned char* rows = lds + OFF_ROW;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
                                // per interior rank and cell the interior ranks of its higher-numbered vertices
   int* part = reinterpret_cast<int*>(lds + OFF_PART);
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int iters = iters_[b];
+  const int iters = cap > 0 ? min(iters_[b], cap) : iters_[b];   // (cap: mdq_smooth_fast runs only the first sweeps here)
   if (iters <= 0) return;
 #ifdef MDQ_SMOOTH_TRACE
   int phase_ = 0;   // setup phase stamps of environment 0 in the slots of sweep 63
@@ -758,7 +758,7 @@ extern "C" int mdq_smooth(int32_t B, int32_t NV, int32_t NT, double* coords, con
   trace = mdq_smooth_trace_host();
 #endif
   hipLaunchKernelGGL(mdq_smoothing::smooth_kernel, dim3(B), dim3(mdq_smoothing::SWG), 0, (hipStream_t)stream, NV, NT, coords,
-                     cells, nv, nt, iterations, trace);
+                     cells, nv, nt, iterations, 0, trace);
   if (hipGetLastError() != hipSuccess) return mdq_set_error("smooth_kernel launch failed");
   return 0;
 }

@@ -298,17 +298,44 @@ class HostTopologyBatch:
         return status
 
 
+_SMOOTH_WS = {}
+
+
 def smooth_batch_gpu(coords: torch.Tensor, cells: torch.Tensor, nv: torch.Tensor, nt: torch.Tensor,
-                     iterations: torch.Tensor, stream=None) -> None:
-    """In-place `mesh.smooth(n)` of B meshes on the GPU (`mdq_smooth`): coords (B,NV,2) f8, cells (B,NT,3) i4,
-    nv / nt / iterations (B,) i4 device tensors; iterations[b] = 0 leaves mesh b untouched."""
+                     iterations: torch.Tensor, stream=None, fast: bool = True) -> None:
+    """In-place `mesh.smooth(n)` of B meshes on the GPU: coords (B,NV,2) f8, cells (B,NT,3) i4, nv / nt / iterations (B,) i4
+    device tensors; iterations[b] = 0 leaves mesh b untouched.  `fast` (default): `mdq_smooth_fast` - three careful sweeps,
+    then the full-step sweeps as blocked triangular solves, validated in parallel; `fast=False`: `mdq_smooth` (the
+    per-vertex walk, every sweep), which the fast path is tested against."""
     lib = _lib.load()
     B, NV = coords.shape[0], coords.shape[1]
     NT = cells.shape[1]
     assert coords.dtype == torch.float64 and cells.dtype == torch.int32 and coords.is_contiguous() and cells.is_contiguous()
     assert nv.dtype == torch.int32 and nt.dtype == torch.int32 and iterations.dtype == torch.int32
-    _lib.check(lib.mdq_smooth(B, NV, NT, coords.data_ptr(), cells.data_ptr(), nv.data_ptr(), nt.data_ptr(),
-                              iterations.data_ptr(), _lib.stream_ptr(stream)), "mdq_smooth")
+    if not fast:
+        _lib.check(lib.mdq_smooth(B, NV, NT, coords.data_ptr(), cells.data_ptr(), nv.data_ptr(), nt.data_ptr(),
+                                  iterations.data_ptr(), _lib.stream_ptr(stream)), "mdq_smooth")
+        return
+    # workspace (block inverses of every mesh): one per (device, stream, B, NV) - launches on one stream are ordered
+    sp = _lib.stream_ptr(stream)
+    key = (coords.device, int(sp.value or 0), B, NV)
+    ws = _SMOOTH_WS.get(key)
+    if ws is None:
+        nbytes = int(lib.mdq_smooth_fast_workspace_bytes(B, NV))
+        ws = _SMOOTH_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=coords.device)
+    _lib.check(lib.mdq_smooth_fast(B, NV, NT, coords.data_ptr(), cells.data_ptr(), nv.data_ptr(), nt.data_ptr(),
+                                   iterations.data_ptr(), ws.data_ptr(), ws.numel(), sp), "mdq_smooth_fast")
+
+
+def smooth_fast_rollbacks(device, B: int, NV: int, stream=None) -> np.ndarray:
+    """Diagnostics of the last `smooth_batch_gpu(fast=True)` launch with these sizes on this stream: per environment the
+    number of sweeps that were handed back to the careful walk (0 = every sweep of the blocked solve was validated)."""
+    ws = _SMOOTH_WS.get((torch.device(device) if not isinstance(device, torch.device) else device,
+                         int(_lib.stream_ptr(stream).value or 0), B, NV))
+    if ws is None:
+        raise KeyError("no mdq_smooth_fast workspace for these sizes on this stream")
+    off = B * ((NV + 31) // 32 + 2) * 1024 * 8            # behind the block inverses (mdq_smooth_fast_workspace_bytes)
+    return ws[off:off + 4 * B].view(torch.int32).cpu().numpy()
 
 
 class DeviceTopologyBatch:

@@ -282,6 +282,88 @@ def test_gpu_smoothing_exact_path(lib_built):
     assert limited_total >= 6, "the synthetic meshes no longer exercise the limited step"
 
 
+def _coarsened(meshes, name, removals, seed):
+    """`name` smoothed, then `removals` interior vertices removed (host engine, smoothed after each); the LAST removal is
+    left unsmoothed: the state the smoothing kernels meet inside an env step."""
+    from meshdqn_amd.mesh_ops import remesh_batch
+    from meshdqn_amd.topology import MeshTopology
+    c0, t0 = meshes[name]
+    coords = np.asarray(c0, np.float64)[None].copy()
+    cells = np.sort(np.asarray(t0), axis=1).astype(np.int32)[None].copy()
+    nv, nt = np.array([coords.shape[1]], np.int32), np.array([cells.shape[1]], np.int32)
+    assert remesh_batch(coords, cells, nv, nt, np.array([-1], np.int32), 50)[0] == 0
+    rng = np.random.default_rng(seed)
+    for k in range(removals):
+        interior = np.flatnonzero(~MeshTopology(coords[0, :nv[0]], cells[0, :nt[0]]).on_boundary)
+        assert remesh_batch(coords, cells, nv, nt, np.array([int(rng.choice(interior))], np.int32),
+                            50 if k < removals - 1 else 0)[0] == 0
+    return coords[0, :nv[0]].copy(), cells[0, :nt[0]].copy()
+
+
+def _smooth_both(batch, iters):
+    """The same batch of meshes through mdq_smooth_fast and mdq_smooth; returns (fast, walk, rollbacks per env)."""
+    from meshdqn_amd.mesh_ops import smooth_batch_gpu, smooth_fast_rollbacks
+    B = len(batch)
+    NV, NT = max(len(c) for c, _ in batch), max(len(t) for _, t in batch)
+    coords, cells = np.zeros((B, NV, 2)), np.zeros((B, NT, 3), np.int32)
+    nv, nt = np.zeros(B, np.int32), np.zeros(B, np.int32)
+    for b, (c, t) in enumerate(batch):
+        coords[b, :len(c)], cells[b, :len(t)], nv[b], nt[b] = c, t, len(c), len(t)
+    dev = lambda a: torch.from_numpy(a).cuda()   # noqa: E731
+    outs = []
+    for fast in (True, False):
+        tc = dev(coords.copy())
+        smooth_batch_gpu(tc, dev(cells), dev(nv), dev(nt), dev(np.asarray(iters, np.int32)), fast=fast)
+        torch.cuda.synchronize()
+        outs.append(tc.cpu().numpy())
+    return outs[0], outs[1], smooth_fast_rollbacks(tc.device, B, NV), nv
+
+
+def test_fast_smoothing_equals_the_walk_on_env_step_meshes(lib_built, meshes):
+    """mdq_smooth_fast (three careful sweeps, then blocked triangular solves validated in parallel) against mdq_smooth
+    (the per-vertex walk, exact sequential semantics) on the meshes an env step produces: both airfoils after 1 .. 40
+    removals, the last removal not yet smoothed; 50, 4 and 3 iterations, and an untouched mesh.  Equal to round-off
+    (different association of the same sums), no environment rolled back, bitwise reproducible."""
+    batch = [_coarsened(meshes, n, k, 100 + k) for n in ("ys930", "ah93w145") for k in (1, 2, 9, 40)]
+    iters = [50] * len(batch)
+    iters[1], iters[2], iters[5] = 4, 3, 0
+    fast, walk, redo, nv = _smooth_both(batch, iters)
+    for b in range(len(batch)):
+        assert np.abs(fast[b, :nv[b]] - walk[b, :nv[b]]).max() < 1e-13, b
+    assert np.array_equal(fast[5], walk[5]) and (redo == 0).all()
+    again, _, _, _ = _smooth_both(batch, iters)
+    assert np.array_equal(fast, again)
+    # and against the sequential host loop (the oracle-pinned twin)
+    from meshdqn_amd.ipcs_batch import smooth_coords
+    from meshdqn_amd.topology import MeshTopology
+    host = smooth_coords(MeshTopology(*batch[0]), 50)
+    assert np.abs(fast[0, :nv[0]] - host).max() < 1e-13
+
+
+def test_fast_smoothing_rolls_back_sweeps_with_limited_steps(lib_built, meshes):
+    """Interior vertices thrown far off their place: the step limit (half the smallest altitude) binds for many sweeps,
+    so the validation of the blocked solve must reject those sweeps, roll the environment back to the start of the
+    first rejected sweep and hand it to the careful walk - same result as the walk on its own, to round-off; the
+    well-behaved meshes of the same launch are not rolled back."""
+    from meshdqn_amd.topology import MeshTopology
+    rng = np.random.default_rng(3)
+    batch = []
+    for n, moved in (("ys930", 6), ("ys930", 0), ("ah93w145", 25), ("ah93w145", 1)):   # (0.97: limited steps through ~7 sweeps)
+        c, t = _coarsened(meshes, n, 3, 7)
+        topo = MeshTopology(c, t)
+        interior = np.flatnonzero(~topo.on_boundary)
+        for v in rng.choice(interior, moved, replace=False):
+            # move the vertex 97 % of the way towards one of the vertices it shares a cell with: thin, valid cells
+            cellsv = t[(t == v).any(axis=1)]
+            w = int([u for u in cellsv[0] if u != v][0])
+            c[v] = c[v] + 0.97 * (c[w] - c[v])
+        batch.append((c, t))
+    fast, walk, redo, nv = _smooth_both(batch, [50] * len(batch))
+    for b in range(len(batch)):
+        assert np.abs(fast[b, :nv[b]] - walk[b, :nv[b]]).max() < 1e-12, b
+    assert redo[0] > 0 and redo[2] > 0 and redo[3] > 0 and redo[1] == 0, redo
+
+
 def test_env_groups_equal_one_batch(lib_built):
     """G concurrently stepped groups (threads + streams) give the same trajectories as one batch stepped in place."""
     from meshdqn_amd.env import Env2DAirfoil

@@ -20,6 +20,9 @@ static int mdq_set_error(const char* m) {
 #define SMOOTH_SRC "../../meshdqn_amd/csrc/mdq_smooth.hip"
 #endif
 #include SMOOTH_SRC
+#ifdef SMOOTH_FAST
+#include "../../meshdqn_amd/csrc/mdq_smooth_linear.hip"
+#endif
 
 static void host_smooth(std::vector<double>& x, const std::vector<int>& tri, int nv, int nt, int iters) {
   std::vector<std::vector<int>> vc(nv), nb(nv);
@@ -122,7 +125,37 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dx, dx0, sizeof(double) * 2 * NV * B, hipMemcpyDeviceToDevice));
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
+#ifdef SMOOTH_FAST
+    static void* ws = nullptr;
+    const int64_t wsb = mdq_smooth_fast_workspace_bytes(B, NV);
+    if (!ws) CK(hipMalloc(&ws, wsb));
+    if (getenv("SMOOTH_PARTS")) {   // the three launches of mdq_smooth_fast one by one, timed
+      const int64_t blocks = (NV + mdq_smooth_lin::BS - 1) / mdq_smooth_lin::BS + 2, mstride = blocks * mdq_smooth_lin::MBLK;
+      double* mws = reinterpret_cast<double*>(ws);
+      int32_t* redo = reinterpret_cast<int32_t*>(mws + (int64_t)B * mstride);
+      hipEvent_t ev[4];
+      for (auto& e : ev) CK(hipEventCreate(&e));
+      CK(hipEventRecord(ev[0], 0));
+      hipLaunchKernelGGL(mdq_smoothing::smooth_kernel, dim3(B), dim3(mdq_smoothing::SWG), 0, 0, NV, NT, dx, dt, dnv, dnt, dit, 3, nullptr);
+      CK(hipEventRecord(ev[1], 0));
+      hipLaunchKernelGGL(mdq_smooth_lin::smooth_linear_kernel, dim3(B), dim3(mdq_smooth_lin::LWG), 0, 0, NV, NT, dx, dt, dnv, dnt, dit, mws, mstride, redo);
+      CK(hipEventRecord(ev[2], 0));
+      hipLaunchKernelGGL(mdq_smoothing::smooth_kernel, dim3(B), dim3(mdq_smoothing::SWG), 0, 0, NV, NT, dx, dt, dnv, dnt, redo, 0, nullptr);
+      CK(hipEventRecord(ev[3], 0));
+      CK(hipDeviceSynchronize());
+      float a, b_, c;
+      CK(hipEventElapsedTime(&a, ev[0], ev[1]));
+      CK(hipEventElapsedTime(&b_, ev[1], ev[2]));
+      CK(hipEventElapsedTime(&c, ev[2], ev[3]));
+      std::vector<int> hr(B);
+      CK(hipMemcpy(hr.data(), redo, 4 * B, hipMemcpyDeviceToHost));
+      int nr = 0;
+      for (int v : hr) nr += v > 0;
+      if (rep == reps - 1) printf("  parts: careful(3) %.3f ms, linear %.3f ms, redo %.3f ms (%d envs rolled back)\n", a, b_, c, nr);
+    } else if (mdq_smooth_fast(B, NV, NT, dx, dt, dnv, dnt, dit, ws, wsb, nullptr)) return 3;
+#else
     if (mdq_smooth(B, NV, NT, dx, dt, dnv, dnt, dit, nullptr)) return 3;
+#endif
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms;
