@@ -79,6 +79,40 @@ def _cpu_worker(args):
     return n, time.perf_counter() - t0
 
 
+def _cpu_worker_s3(args):
+    """One oracle environment taking S3 env steps for `budget_s` seconds (child of the multi-process CPU baseline)."""
+    budget_s, seed = args
+    os.environ["OMP_NUM_THREADS"] = "1"
+    os.environ["OPENBLAS_NUM_THREADS"] = "1"
+    from oracle.env import OracleEnv
+    from oracle.ipcs import OracleFlowSolver
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ys930.npz"))
+    agent = dict(solver_steps=20, episodes=10, timesteps=10000, threshold=0.001, N_closest=180, gt_drag=-1, gt_time=-1,
+                 u=-1, p=-1, time_reward=0.005, save_steps=4, goal_vertices=0.95, plot_dir="")
+    env = OracleEnv(z["coords"], z["cells"], agent)
+    env.get_state()
+    rng = np.random.default_rng(1370 + seed)
+    n = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        env.step(int(rng.integers(0, 180)))
+        m = env.flow.mesh
+        fs = OracleFlowSolver(m.coords, m.cells, smooth=False)
+        fs.u_n, fs.p_n = env.u[-1].copy(), env.p[-1].copy()
+        fs.evolve()
+        n += 1
+    return n, time.perf_counter() - t0
+
+
+def cpu_baseline_parallel_s3(budget_s=10.0, procs=12):
+    """BASELINE.md B2 for the headline unit: P independent single-threaded oracle processes taking S3 env steps."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(procs) as pool:
+        res = pool.map(_cpu_worker_s3, [(budget_s, k) for k in range(procs)])
+    return sum(n / dt for n, dt in res)
+
+
 def cpu_baseline_parallel(budget_s=8.0, procs=12):
     """The reference's `num_parallel: 12` Ray workers (configs/ray_ys930.yaml:30) mirrored with P independent
     single-threaded oracle processes: aggregate IPCS env-steps/s of the host."""
@@ -145,6 +179,12 @@ def cpu_baseline(budget_s=15.0, spinup=20):
             raise RuntimeError("skipped (MDQ_BENCH_CPU_LEGS)")
         if any(os.environ.get(k) for k in ("HSA_TOOLS_LIB", "ROCP_TOOL_LIB", "ROCPROFILER_LIBRARY")):
             raise RuntimeError("skipped under a profiler (its preloaded tool may already hold the GPU: no child interpreters)")
+        if "s3" in legs:
+            out["parallel_value"] = cpu_baseline_parallel_s3(10.0, procs)
+            out["parallel_cores"] = procs
+            out["parallel_sample"] = (f"{procs} independent single-threaded oracle processes (BASELINE.md B2, the reference's "
+                                      f"num_parallel: 12), 10 s of S3 env steps each, aggregate env-steps/s; host exposes "
+                                      f"{os.cpu_count()} logical CPUs" + _quota_note())
         s2["parallel_value"] = cpu_baseline_parallel(8.0, procs)
         s2["parallel_sample"] = (f"{procs} independent single-threaded oracle processes (the reference's num_parallel: 12 "
                                  f"workers), 8 s each, aggregate IPCS env-steps/s; host exposes {os.cpu_count()} logical "
@@ -397,6 +437,41 @@ def measure_train(args, dev, dist, world):
                      "forward + backward of the trained one = mdq_gcn_train_step, one flat gradient all-reduce over the "
                      "ranks, mdq_adam_step) on a second stream beside the smoothing kernel; host_loop_s1 = the host-driven "
                      "loop (autograd replayed as a HIP graph) on S1 for comparison")
+
+
+def measure_deploy(args, dev, removals=44):
+    """The deployment evaluator (deploy_dqn.py:318-463,495-517) on one ys930 episode at the stock values:
+    `removals` scripted removals (default_rng(1370) actions over [0, 180), replayed like the reference's best-episode
+    replay), every coarsened mesh + the final mesh re-simulated for `solver_steps` IPCS steps from rest - all of them as ONE
+    IpcsBatch (`deploy(batched=True)`); beside it the reference's order (one mesh at a time inside the loop) on the first
+    three removals of the same script."""
+    from meshdqn_amd.deploy import deploy
+    from meshdqn_amd.env import Env2DAirfoil
+    base = _BASE_ENVS[args.mesh]
+
+    def env():
+        cfg = _env_config(args)
+        cfg["agent_params"].update(gt_drag=base.gt_drag, gt_time=base.gt_time, u=base.original_u, p=base.original_p)
+        e = Env2DAirfoil(cfg, compute_device=dev)
+        e.gt_lift = base.gt_lift
+        return e
+    script = np.random.default_rng(1370).integers(0, 180, removals).tolist()
+    t0 = time.perf_counter()
+    out = deploy(env(), actions=script, stop_on_done=False, batched=True)
+    t_b = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    seq = deploy(env(), actions=script[:3], stop_on_done=False, batched=False)
+    t_s = time.perf_counter() - t0
+    k = 3
+    return dict(value=t_b, unit="s per deployed episode", removals=removals, solver_steps=int(base.solver_steps),
+                resimulated_meshes=int(out["resimulated_meshes"]), rollout_s=out["rollout_seconds"],
+                resimulation_s=out["resimulation_seconds"], drag_error_percent=out.get("drag_error_percent"),
+                final_vertices=out.get("final_vertices"),
+                sequential_3_removals_s=t_s,
+                same_first_rows=bool(np.allclose(out["drag_trajectory"][:k + 1], seq["drag_trajectory"], rtol=1e-7)),
+                what="deploy_dqn.py on the HIP path: policy rolled first, then ALL coarsened meshes of the episode and the final "
+                     "mesh re-simulated from rest as one batch (one workgroup per mesh); sequential_* = the reference's order "
+                     "(re-assemble, re-factorise and re-simulate inside the loop, one mesh on the chip at a time)")
 
 
 def measure_s2(args, dev, dist, world, topos, xs, steps, warmup, spinup, **kw):
@@ -730,6 +805,10 @@ def main(argv=None):
             cfgs["S3_full_chip"] = f3
         except Exception as exc:  # noqa: BLE001
             cfgs["S3_full_chip"] = dict(error=repr(exc))
+        try:
+            cfgs["deploy_episode_s"] = measure_deploy(args, dev)
+        except Exception as exc:  # noqa: BLE001
+            cfgs["deploy_episode_s"] = dict(error=repr(exc))
         try:
             from meshdqn_amd.mesh_ops import red_refine
             rc_, rcells = red_refine(x, z["cells"])

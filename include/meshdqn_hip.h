@@ -557,7 +557,10 @@ int mdq_remesh(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells
  *      (flow_solver.py:85-132,194-226) minus the assembled patterns.  Same layouts as the mdq_ipcs_desc fields of the
  *      same names; feed them (uploaded) to mdq_ipcs_setup_matfree + mdq_ipcs_evolve. ---- */
 typedef struct mdq_ipcs_topo_out {
-  int32_t NBO, NBE, NSE1, _pad;  /* capacities: outflow rows, outflow entries, SELL-64 entries of the P1 Laplacian */
+  int32_t NBO, NBE, NSE1;  /* capacities: outflow rows, outflow entries, SELL-64 entries of the P1 Laplacian */
+  int32_t flow_only;      /* mdq_env_topology: != 0 skips `removable`, the polygon distances / N-closest window and the state
+                             graph (nremovable / nsel / n_closest / coord_map / nedges / edge_* are left untouched): the run of
+                             an engine that only feeds the IPCS step (the flow stream of the S3 env step) */
   int32_t* mf_scat;       /* [B][6][NT]  dof | (outflow_edge+1) << 28 (word 0) */
   int8_t* cell_outflow;   /* [B][NT]     local outflow facet or -1 */
   uint8_t* bcu_flag;      /* [B][NP] */

@@ -76,7 +76,7 @@ class EnvTopoDesc(C.Structure):
 
 class IpcsTopoOut(C.Structure):
     """Mirror of `mdq_ipcs_topo_out`."""
-    _fields_ = [(n, C.c_int32) for n in ("NBO", "NBE", "NSE1", "_pad")] + [
+    _fields_ = [(n, C.c_int32) for n in ("NBO", "NBE", "NSE1", "flow_only")] + [
         (n, C.c_void_p) for n in ("mf_scat", "cell_outflow", "bcu_flag", "bcu_gx", "bcp_flag", "nbo", "bo_rows", "bo_ptr",
                                   "bo_col", "bo_src", "g1_ptr", "g1_src", "g2_ptr", "g2_src", "sl1_off", "sl1_col")]
 

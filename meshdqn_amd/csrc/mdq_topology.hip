@@ -288,6 +288,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   if (tid == 0) D.naf[b] = naf;
   __syncthreads();
   TT_STAMP(2)
+  if (!(has_ipcs && O.flow_only)) {   // (an engine that only feeds the IPCS step skips the selection and the state graph)
   // ================= removable: neither x nor y equals ANY boundary vertex's x / y (numpy `in` quirk)
   for (int v = tid; v < TNS; v += TW) scanb[v] = (v < nv && onb[v]) ? 1 : 0;
   __syncthreads();
@@ -435,6 +436,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   }
   if (tid == 0) D.nedges[b] = 3 * ngood;
   TT_STAMP(5)
+  }
   if (!has_ipcs) return;
   __syncthreads();
 

@@ -132,6 +132,15 @@ class FlowSolver(object):
                                    rtol=self.rtol, device=self.device,
                                    pressure_direct=("device" if self.solver_type == "lu" else False))
             self.batch.assemble()
+            # solver_type 'lu' = device factorisation of the pressure matrix; a mesh beyond its limits (1024 vertices, 112
+            # interior / separator nodes per part) keeps the Jacobi-CG pressure solve (rtol-limited instead of exact): say so
+            # once per mesh (remesh is not on the hot path)
+            st = getattr(self.batch, "pd_status", None)
+            if self.solver_type == "lu" and st is not None and int(st.min().item()) < 0:
+                import warnings
+                warnings.warn(f"FlowSolver: mesh with {nv} vertices exceeds the limits of the device pressure factorisation "
+                              f"(status {int(st.min().item())}); the pressure solve falls back to Jacobi-CG at rtol {self.rtol:g}",
+                              RuntimeWarning, stacklevel=2)
             self.u_n = Function(topo, self.batch.u_n[0, :n2], "velocity")
             self.p_n = Function(topo, self.batch.p_n[0, :nv], "pressure")
         else:

@@ -343,7 +343,7 @@ class DeviceTopologyBatch:
     (B,NT,3), `nv`, `nt`, `offset` and all outputs are device tensors (`t` for the mesh / state outputs, `ti` for the
     matrix-free IPCS index data); nothing but what the caller asks for ever crosses PCIe."""
 
-    def __init__(self, B, NV, NT, NE, NAF, N, EMAX, polygon, device, ipcs=False, nbo_cap=64, nse1_cap=0):
+    def __init__(self, B, NV, NT, NE, NAF, N, EMAX, polygon, device, ipcs=False, nbo_cap=64, nse1_cap=0, flow_only=False):
         self.lib = _lib.load()
         dev = torch.device(device)
         NP = NV + NE
@@ -381,6 +381,8 @@ class DeviceTopologyBatch:
                            sl1_off=z((B, NV // 64 + 2), i32), sl1_col=z((B, NSE1), i32))
             o = _lib.IpcsTopoOut()
             o.NBO, o.NBE, o.NSE1 = NBO, NBE, NSE1
+            # an engine that only feeds the IPCS step (the flow stream's private engine): no selection, no state graph
+            o.flow_only = 1 if flow_only else 0
             for k, a in self.ti.items():
                 setattr(o, k, a.data_ptr())
             self._ipcs_out = o

@@ -759,7 +759,17 @@ class DQNTrainer:
         path = os.path.join(save_dir, f"{prefix}trainer_state.pt")
         extra = {}
         if os.path.exists(path):
-            st = torch.load(path, map_location=dev, weights_only=False)
+            # optimiser / scheduler state dicts + numpy arrays of the loops (`extra`): the safe unpickler with numpy's array
+            # reconstruction allow-listed - a checkpoint directory is not a code-execution vector
+            _ma = (getattr(np, "_core", None) or np.core).multiarray      # (numpy >= 2: numpy._core)
+            safe = [np.ndarray, np.dtype, type(np.dtype(np.int64)), type(np.dtype(np.float64)), type(np.dtype(np.float32)),
+                    type(np.dtype(np.int32)), type(np.dtype(np.bool_))]
+            for name in ("_reconstruct", "scalar"):
+                fn = getattr(_ma, name, None)
+                if fn is not None:
+                    safe.append(fn)
+            with torch.serialization.safe_globals(safe):
+                st = torch.load(path, map_location=dev, weights_only=True)
             for o, sd in zip(self.opts, st["opts"]):
                 o.load_state_dict(sd)
             for s_, sd in zip(self.scheds, st["scheds"]):
@@ -1224,11 +1234,11 @@ def train_loop_device(trainer: DQNTrainer, venv, num_steps: int, optim_per_step:
     cal = getattr(venv, "_calibrated_for", None)
     if getattr(venv, "flow_overlap", False) and (cal is None or not (cal == main)):
         venv.calibrate_streams(fused1)       # (a flow stream that really overlaps with this loop's stream; resets the envs)
-    # "auto": on the flow stream when the env step has one and its leg is short (Jacobi-CG pressure: flow leg 1.05 ms +
-    # optimiser chain 0.6 ms still end before the 1.8 ms main chain: 69.3 k env-steps/s, against 68.2 k with a third stream
-    # that has to be calibrated as well); with the per-step re-factorisation (leg 1.7 ms) a stream of its own is better
+    # "auto": a stream of its own.  (With the 1.8 ms smoothing walk the optimiser chain rode on the flow stream behind the flow
+    # leg - 1.05 + 0.6 ms still ended before the main chain; since the blocked smoothing solve the main chain is 1.16 ms and
+    # that placement costs 1.63 ms per batched step against 1.41 ms with a third stream: tools/time_train_device.py.)
     if optimiser_stream == "auto":
-        optimiser_stream = "flow" if (getattr(venv, "flow_overlap", False) and getattr(venv, "flow_pressure", "cg") == "cg") else "own"
+        optimiser_stream = "own"
     on_flow = optimiser_stream == "flow" and getattr(venv, "flow_overlap", False)
     if on_flow:
         # the optimiser chain rides on the (calibrated) flow stream, behind the flow leg of the previous env step: one side

@@ -119,7 +119,7 @@ class VecEnv2DAirfoil:
                 # the flow stream's own engine: a private copy of the meshes, the full topology (with the IPCS index data,
                 # which only the flow needs: 0.19 ms less on the critical path) and the IPCS step run there
                 self._ftopo = DeviceTopologyBatch(B, NV, NT, self.NE, self.NAF, N, self.EMAX, self.polygon, self.device,
-                                                  ipcs=True, nse1_cap=nse1_cap)
+                                                  ipcs=True, nse1_cap=nse1_cap, flow_only=True)
         self._packed_host, self._packed_ev, self._pending, self._step_pending = None, torch.cuda.Event(), None, None
         self._restore_args = {}
         self._deferred_mirror = None
@@ -310,6 +310,12 @@ class VecEnv2DAirfoil:
         self.steps[b] = 0
 
     def reset_all(self):
+        if getattr(self, "flow_overlap", False) and getattr(self, "_flow_prev", None) is not None:
+            # results of a flow leg launched before the reset belong to meshes that no longer exist: the first step
+            # after a reset (or a stream calibration) reports no "previous step" forces
+            self.flow_wait()
+            self._flow_prev = None
+            self._flow_prev2 = None
         for b in range(self.B):
             self._reset_env(b)
         if self.gpu_topology:
@@ -400,7 +406,8 @@ class VecEnv2DAirfoil:
             npts = np1 + up("ne", dev)
         it = self.interp
         # two persistent (ping-pong) result sets, zero-filled once: the interpolation writes every valid dof of the current
-        # meshes and nothing reads the padding behind them (two 45 MB fills per step were ~30 us of the main chain); the
+        # meshes and nothing reads the padding behind them (INVARIANT: rows behind nv / np2 of a set hold stale values of
+        # earlier, larger meshes, not zeros) (two 45 MB fills per step were ~30 us of the main chain); the
         # set of the previous step stays intact for whoever still holds it
         if getattr(self, "_interp_bufs", None) is None:
             self._interp_bufs = [(torch.zeros((B, self.S, NP, 2), dtype=torch.float64, device=dev),

@@ -76,34 +76,64 @@ def test_bad_actions_follow_reference_error_codes(lib_built):
 
 
 def test_deploy_resimulation_matches_oracle(lib_built, meshes, tmp_path):
-    """deploy_dqn.py semantics: after every removal the operators are re-assembled on the coarsened mesh
-    and the flow is re-simulated from rest; trajectories in the reference's row layouts."""
+    """deploy_dqn.py semantics: after every removal the operators are re-assembled on the coarsened mesh and the flow is
+    re-simulated from rest; trajectories, complete_drags / complete_lifts and the final re-simulation (best mesh put
+    back, re-meshed - smoothed - once more, :440-441,:495-517) in the reference's layouts.  Both orders of the work - the
+    reference's (re-simulate inside the loop, one mesh at a time) and the batched one (policy first, all meshes as one
+    IpcsBatch) - against the oracle, and against each other to 1e-9."""
     from meshdqn_amd.deploy import deploy
     from meshdqn_amd.env import Env2DAirfoil
     from oracle.env import OracleEnv
     from oracle.ipcs import OracleFlowSolver
-    env = Env2DAirfoil(_config("ah93w145"))
+    from oracle.mesh import OracleMesh
     coords, cells = meshes["ah93w145"]
+    acts = [17, 180, 42, 3]
+    outs = []
+    for batched in (False, True):
+        env = Env2DAirfoil(_config("ah93w145"))
+        d = os.path.join(str(tmp_path), "batched" if batched else "sequential")
+        # (the 20-step toy ground truth terminates episodes immediately: keep going to exercise the loop)
+        outs.append(deploy(env, actions=acts, complete_traj=True, save_dir=d, prefix="t_", stop_on_done=False, batched=batched))
+        assert len(env.flow_solver.mesh.coordinates()) == 794            # the last mesh is put back
+        for k in ("interpolate_drag_trajectory", "drag_trajectory", "complete_drags", "complete_lifts", "actions"):
+            assert os.path.exists(os.path.join(d, f"t_{k}.npy")), k
+    seq, bat = outs
+    assert seq["actions"].tolist() == acts and np.isnan(seq["selected"][1]) and bat["resimulated_meshes"] == 4
+    for k in ("interpolate_drag_trajectory", "drag_trajectory", "complete_drags", "complete_lifts"):
+        assert seq[k].shape == bat[k].shape and np.allclose(seq[k], bat[k], rtol=1e-9, atol=0), k
+    assert abs(seq["new_drag"] - bat["new_drag"]) < 1e-9 * abs(seq["new_drag"])
+    out = bat
+    S = 5
+    # rows: the initial mesh, then one per step (interpolated) / one per removal (re-simulated), [nv, S drags, S lifts]
+    assert out["interpolate_drag_trajectory"].shape == (1 + len(acts), 1 + 2 * S)
+    assert out["drag_trajectory"].shape == (1 + 3, 1 + 2 * S) and out["complete_drags"].shape == (1 + 3, S)
+    assert out["traj_vertices"].tolist() == [797, 796, 795, 794] and out["est_vertices"].tolist() == [797, 796, 796, 795, 794]
+    assert np.array_equal(out["drag_trajectory"][0, 1:1 + S], out["gt_drag"]) and np.array_equal(out["complete_lifts"][0], out["gt_lift"])
+    # oracle: same removals, a fresh IPCS run from rest on every coarsened (already smoothed) mesh, and on the final mesh
+    # smoothed once more
     ora = OracleEnv(coords, cells, AGENT)
-    acts = [17, 180, 42]
-    # (the 20-step toy ground truth terminates episodes immediately: keep going to exercise the loop)
-    out = deploy(env, actions=acts, complete_traj=True, save_dir=str(tmp_path), prefix="t_", stop_on_done=False)
-    assert out["actions"].tolist() == acts
-    assert out["drag_trajectory"].shape == (2, 1 + 5 + 5) and out["interpolate_drag_trajectory"].shape[1] == 11
-    assert os.path.exists(os.path.join(str(tmp_path), "t_drag_trajectory.npy"))
-    # oracle: same removals, then a fresh IPCS run from rest on the final coarsened (already smoothed) mesh
     ora.get_state()
+    row = 0
     for a in acts:
         ora.step(a)
-    m = ora.flow.mesh
+        if a == 180:
+            continue
+        row += 1
+        m = ora.flow.mesh
+        fs = OracleFlowSolver(m.coords, m.cells, smooth=False)
+        dr, li = [], []
+        for i in range(AGENT["solver_steps"]):
+            _, _, d, l = fs.evolve()
+            if (i + 1) % AGENT["save_steps"] == 0:
+                dr.append(d)
+                li.append(l)
+        assert np.allclose(out["traj_drag"][row], dr, rtol=1e-7) and np.allclose(out["complete_lifts"][row], li, rtol=1e-7)
+    m = OracleMesh(ora.flow.mesh.coords.copy(), ora.flow.mesh.cells.copy()).smooth(50)
     fs = OracleFlowSolver(m.coords, m.cells, smooth=False)
-    dr = []
     for i in range(AGENT["solver_steps"]):
         _, _, d, l = fs.evolve()
-        if (i + 1) % AGENT["save_steps"] == 0:
-            dr.append(d)
-    assert out["traj_vertices"].tolist() == [796, 795]
-    assert np.allclose(out["traj_drag"][-1], dr, rtol=1e-7)
+    assert abs(out["new_drag"] - d) < 1e-7 * abs(d)
+    assert abs(out["drag_error_percent"] - 100 * abs(d - ora.gt_drag[-1]) / abs(ora.gt_drag[-1])) < 1e-4
 
 
 def test_vec_env_matches_single_envs(lib_built):
