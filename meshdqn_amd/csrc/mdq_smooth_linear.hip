@@ -20,14 +20,20 @@
 // in parallel: sweep s is validated by the other waves WHILE the solver waves run sweep s + 1, from two snapshots of the
 // position array (before / after sweep s: the positions an update saw are the new ones of its lower-numbered interior
 // neighbours and the old ones of everything else), with the same conservative fp32 decision as mdq_smooth.hip.  A sweep
-// with an update that is not clearly a full step is rolled back (its snapshot goes to the coordinate array) and the
-// environment is handed to the careful walk of mdq_smooth.hip for the remaining sweeps (`redo`): exact sequential
+// with an update that is not clearly a full step is rolled back to its snapshot and redone (below): exact sequential
 // semantics either way.  Results are bitwise reproducible (fixed summation orders) and agree with the sequential loop to
 // round-off (different association: 1e-15 per sweep, 4e-15 after 47 sweeps on the lab meshes).
 //
-// mdq_smooth_fast (below) = mdq_smooth's kernel for the first three sweeps (careful: right after a vertex removal the
-// cavity's neighbours take limited steps) -> this kernel for the rest -> mdq_smooth's kernel for the environments that
-// were rolled back (normally none: it returns at once).
+// Limited steps (right after a vertex removal the cavity's neighbours take them in the first sweep or two) are handled here
+// as well: a sweep that fails its validation is redone from its snapshot with the offending vertices FLAGGED - they get
+// DOLFIN's exact update (exact_vertex), and the rows of their block behind them the correction M[:, i] (x* - x_i) / M_ii,
+// i.e. the linear solve with row i's right-hand side moved so that x_i = x* (repair_sweep) - until a round flags nothing
+// new.  The kernel starts in this CHECKED mode (solve, validate with all waves, repair) and switches to the PIPELINED mode
+// above after the first sweep that passes at the first try.
+//
+// mdq_smooth_fast (below) = this kernel -> mdq_smooth's kernel for the environments that were handed back (a mesh beyond
+// this kernel's limits - more than 16 cells at a vertex, 14 gather slots - or a sweep that did not settle within MAXROUNDS
+// repair rounds; normally none: it returns at once).
 #include <hip/hip_runtime.h>
 
 #include "../../include/meshdqn_hip.h"
@@ -44,7 +50,7 @@ constexpr int SROW = 32;           // bytes per solver row: [7 x u16 gather offs
 constexpr int ZOFF = LNV * 16;     // the zero record of a position buffer (byte offset)
 constexpr int PBUF = (LNV + 1) * 16;
 constexpr int MBLK = 2 * 8 * 32 * 2;   // doubles per block of M in the workspace: [half][t][row][2]
-constexpr int CAREFUL = 3;         // sweeps the careful walk takes first
+constexpr int MAXROUNDS = 5;       // repair rounds of one checked sweep before the careful walk takes over
 
 constexpr int OFF_CUR = 0;                                   // positions, updated in place by the solver waves
 constexpr int OFF_SNAP = OFF_CUR + PBUF;                     // two snapshots (state at the start of sweep s: slot s & 1)
@@ -57,8 +63,9 @@ constexpr int OFF_LMETA = OFF_IVERT + LNV * 2;               // per rank: local 
 constexpr int OFF_KDEG = OFF_LMETA + LNV * MAXLOW;           // per rank: number of neighbours | in-block lower count << 8
 constexpr int OFF_G = OFF_KDEG + LNV * 2;                    // g of the block in flight, per component
 constexpr int OFF_R2K = OFF_G + 2 * BS * 8;                  // 1 / (2 k)
-constexpr int OFF_MISC = OFF_R2K + 32 * 8;                   // [0] n_int  [1] bad  [2] eligible
-constexpr int OFF_PART = OFF_MISC + 64;
+constexpr int OFF_MISC = OFF_R2K + 32 * 8;                   // [0] n_int  [1] bad / newly flagged  [2] eligible
+constexpr int OFF_FIXV = OFF_MISC + 64;                      // per vertex: takes the exact update in the sweep at hand
+constexpr int OFF_PART = OFF_FIXV + LNV + 16;
 constexpr int LDS_BYTES = OFF_PART + LWG * 4;
 // setup scratch inside the position buffers (the positions are loaded last): per-vertex neighbour lists, then the rows of
 // the block inverses under construction
@@ -128,7 +135,8 @@ __device__ __forceinline__ void scan_inclusive(int* data, int* part) {   // data
 // the altitude over this cell's opposite edge, taken with the positions the update saw (the new ones of lower-numbered
 // interior neighbours, the old ones otherwise) - the same conservative fp32 decision as mdq_smooth.hip, per cell instead
 // of on the minimum over the cells.  Returns true if this entry is NOT clearly a full step.
-__device__ __forceinline__ bool validate_entry(const unsigned char* lds, int e, int ne, const unsigned char* OLD,
+template <bool FLAG>
+__device__ __forceinline__ bool validate_entry(unsigned char* lds, int e, int ne, const unsigned char* OLD,
                                                const unsigned char* NEW) {
   const uint32_t* inc = reinterpret_cast<const uint32_t*>(lds + OFF_INC);
   const uint32_t w = e < ne ? inc[e] : 0xFFFFFFFFu;
@@ -144,7 +152,13 @@ __device__ __forceinline__ bool validate_entry(const unsigned char* lds, int e, 
   const double len2 = __builtin_fma(e0, e0, e1 * e1);
   const float alt2 = (float)(cr * cr) * __builtin_amdgcn_rcpf((float)len2);   // squared altitude, ~1e-6 relative
   const bool fast = (q2f > 4.0e-31f) & (q2f < 0.24975f * alt2);
-  return (w != 0xFFFFFFFFu) & !fast;
+  bool bad = (w != 0xFFFFFFFFu) & !fast;
+  if (FLAG) {            // checked sweeps: vertices that already take the exact update are exempt, new ones are flagged
+    unsigned char* fixv = lds + OFF_FIXV;
+    bad = bad && !fixv[v];
+    if (bad) fixv[v] = 1;
+  }
+  return bad;
 }
 
 // the block step of a solver wave (component COMP): lane = row i | half h << 5.  M: the lane's 16 entries of row i
@@ -211,14 +225,135 @@ __device__ __forceinline__ void solve_sweep(unsigned char* lds, const d2* mg, in
   }
 }
 
+__device__ __forceinline__ double grp8_mind(double v) {
+  v = fmin(v, dppd<0xB1>(v));
+  v = fmin(v, dppd<0x4E>(v));
+  v = fmin(v, dppd<0x141>(v));
+  return v;
+}
+// 1/sqrt(x) and 1/x to double precision (~1 ulp): hardware estimate + two Newton steps
+__device__ __forceinline__ double lin_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  y = y * (1.5 - hx * y * y);
+  y = y * (1.5 - hx * y * y);
+  return y;
+}
+__device__ __forceinline__ double lin_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = y * (2.0 - x * y);
+  y = y * (2.0 - x * y);
+  return y;
+}
+
+// DOLFIN's update of vertex v in exact fp64 (any degree, limited step, "stays" rule), by every group of 8 lanes of the
+// wave redundantly: the vertex's old position from OLD, its neighbours' positions as the update sees them (the new ones
+// of lower-numbered interior neighbours = cur, the old ones otherwise).  Same arithmetic as exact_update of mdq_smooth.hip.
+__device__ __forceinline__ d2 exact_vertex(const unsigned char* lds, int v, int l, const unsigned char* OLD) {
+#pragma clang fp contract(off)
+  const double EPS = 3.0e-16;
+  const int* ptr = reinterpret_cast<const int*>(lds + OFF_PTR);
+  const uint32_t* inc = reinterpret_cast<const uint32_t*>(lds + OFF_INC);
+  const unsigned char* CUR = lds + OFF_CUR;
+  const int q0 = ptr[v], k = ptr[v + 1] - q0;
+  const d2 p = *reinterpret_cast<const d2*>(OLD + v * 16);
+  double sx = 0.0, sy = 0.0, rm = 1e300;
+  for (int q = l; q < k; q += 8) {
+    const uint32_t w = inc[q0 + q];
+    const int a = w & 0x3FF, c = (w >> 10) & 0x3FF;
+    const d2 pa = *reinterpret_cast<const d2*>(((w >> 30) & 1 ? CUR : OLD) + a * 16);
+    const d2 pc = *reinterpret_cast<const d2*>((w >> 31 ? CUR : OLD) + c * 16);
+    sx += pa.x + pc.x;
+    sy += pa.y + pc.y;
+    const double tx = pc.x - pa.x, ty = pc.y - pa.y;
+    const double cr = ty * (p.x - pa.x) - tx * (p.y - pa.y);
+    rm = fmin(rm, cr * cr * lin_rcp(tx * tx + ty * ty));   // SQUARED distance to the line through the opposite edge
+  }
+  sx = grp8_sum(sx);
+  sy = grp8_sum(sy);
+  rm = grp8_mind(rm);
+  const double r2k = 1.0 / (2.0 * k);
+  const double dx = sx * r2k - p.x, dy = sy * r2k - p.y;
+  const double q2 = dx * dx + dy * dy;
+  if (!(q2 >= EPS * EPS && q2 > 0.0)) return p;          // |c - p| < DOLFIN_EPS: the vertex stays
+  if (0.25 * rm < q2) {                                  // limited step: needs the lengths
+    const double f = 0.5 * (rm * lin_rsqrt(rm)) * lin_rsqrt(q2);
+    return d2{p.x + f * dx, p.y + f * dy};
+  }
+  return d2{p.x + dx, p.y + dy};                         // |c - p| <= r_min / 2: to the centroid itself
+}
+
+// a sweep with vertices that do NOT take the full step (flags in OFF_FIXV), by ONE wave for both components: per block the
+// same gather and mat-vec as solve_block; then, in row order, every flagged row i gets its exact update x* (its lower
+// in-block neighbours are final by then) and the block's rows behind it the correction M[:, i] (x* - x_i) / M_ii - the
+// linear solve with the right-hand side of row i moved so that x_i = x* (what a sequential sweep does with a limited step)
+__device__ __forceinline__ void repair_sweep(unsigned char* lds, const d2* mg, int nb, int lane, const unsigned char* OLD) {
+  const int i = lane & 31, h = lane >> 5, l = lane & 7;
+  const unsigned char* fixv = lds + OFF_FIXV;
+  const double* mgs = reinterpret_cast<const double*>(mg);
+  unsigned char* cur = lds + OFF_CUR;
+  double* G = reinterpret_cast<double*>(lds + OFF_G);
+  const int* ptr = reinterpret_cast<const int*>(lds + OFF_PTR);
+  for (int b = 0; b < nb; ++b) {
+    const u4 meta = *reinterpret_cast<const u4*>(lds + OFF_SROW + (b * BS + i) * SROW + h * 16);
+    d2 M[8];
+    load_m(M, mg, b, i, h);
+    const d2 v0 = *reinterpret_cast<const d2*>(cur + (meta.x & 0xFFFF)), v1 = *reinterpret_cast<const d2*>(cur + (meta.x >> 16));
+    const d2 v2 = *reinterpret_cast<const d2*>(cur + (meta.y & 0xFFFF)), v3 = *reinterpret_cast<const d2*>(cur + (meta.y >> 16));
+    const d2 v4 = *reinterpret_cast<const d2*>(cur + (meta.z & 0xFFFF)), v5 = *reinterpret_cast<const d2*>(cur + (meta.z >> 16));
+    const d2 v6 = *reinterpret_cast<const d2*>(cur + (meta.w & 0xFFFF));
+    const double gx = halves_sum(((v0.x + v1.x) + (v2.x + v3.x)) + ((v4.x + v5.x) + v6.x));
+    const double gy = halves_sum(((v0.y + v1.y) + (v2.y + v3.y)) + ((v4.y + v5.y) + v6.y));
+    if (h == 0) {
+      G[i] = gx;
+      G[BS + i] = gy;
+    }
+    asm volatile("" ::: "memory");
+    const d2* gqx = reinterpret_cast<const d2*>(G + 16 * h);
+    const d2* gqy = reinterpret_cast<const d2*>(G + BS + 16 * h);
+    double ax0 = 0.0, ax1 = 0.0, ay0 = 0.0, ay1 = 0.0;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const d2 ggx = gqx[t], ggy = gqy[t];
+      ax0 = __builtin_fma(M[t].x, ggx.x, ax0);
+      ax1 = __builtin_fma(M[t].y, ggx.y, ax1);
+      ay0 = __builtin_fma(M[t].x, ggy.x, ay0);
+      ay1 = __builtin_fma(M[t].y, ggy.y, ay1);
+    }
+    const double xx = halves_sum(ax0 + ax1), xy = halves_sum(ay0 + ay1);
+    const int soff = meta.w >> 16;                        // (h = 1 lanes: the zero record)
+    if (h == 0) *reinterpret_cast<d2*>(cur + soff) = d2{xx, xy};
+    asm volatile("" ::: "memory");
+    unsigned long long fm = __builtin_amdgcn_ballot_w64(h == 0 && fixv[soff >> 4] != 0);
+    while (fm) {
+      const int r = __ffsll((long long)fm) - 1;
+      fm &= fm - 1;
+      const int v = __builtin_amdgcn_readlane(soff, r) >> 4;
+      const d2 xs = exact_vertex(lds, v, l, OLD);
+      const d2 xt = *reinterpret_cast<const d2*>(cur + v * 16);
+      const double kk = (double)(ptr[v + 1] - ptr[v]);   // 1 / M_rr
+      const double ddx = (xs.x - xt.x) * kk, ddy = (xs.y - xt.y) * kk;
+      const double mjr = mgs[(((size_t)(b * 2 + (r >> 4)) * 8 + ((r & 15) >> 1)) * 32 + i) * 2 + (r & 1)];   // M[i][r]
+      if (h == 0 && i >= r) {
+        d2 xc = *reinterpret_cast<const d2*>(cur + soff);
+        xc.x = __builtin_fma(mjr, ddx, xc.x);
+        xc.y = __builtin_fma(mjr, ddy, xc.y);
+        if (i == r) xc = xs;
+        *reinterpret_cast<d2*>(cur + soff) = xc;
+      }
+      asm volatile("" ::: "memory");
+    }
+  }
+}
+
 __global__ __launch_bounds__(LWG) void smooth_linear_kernel(int NV, int NT, double* coords, const int32_t* cells,
                                                             const int32_t* nv_, const int32_t* nt_, const int32_t* iters_,
-                                                            double* mws, int64_t mstride, int32_t* redo) {
+                                                            double* mws, int64_t mstride, int32_t* redo, int32_t* stats) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int S = iters_[b] - CAREFUL;           // sweeps of this kernel
+  const int S = iters_[b];                     // sweeps
   if (S <= 0) {
-    if (tid == 0) redo[b] = 0;
+    if (tid == 0) redo[b] = stats[3 * b] = stats[3 * b + 1] = stats[3 * b + 2] = 0;
     return;
   }
   const int nv = nv_[b], nt = nt_[b];
@@ -354,8 +489,11 @@ __global__ __launch_bounds__(LWG) void smooth_linear_kernel(int NV, int NT, doub
   }
   __syncthreads();
   const bool eligible = misc[2] != 0 && n_int > 0;
-  if (!eligible) {                               // the careful walk takes all the remaining sweeps
-    if (tid == 0) redo[b] = S;
+  if (!eligible) {                               // the careful walk takes all the sweeps
+    if (tid == 0) {
+      redo[b] = S;
+      stats[3 * b] = stats[3 * b + 1] = stats[3 * b + 2] = 0;
+    }
     return;
   }
   // ---- block inverses: one wave per block, lane j = column j; row i of (I - N)^-1 = e_i + (1 / k_i) sum of the rows of
@@ -407,58 +545,119 @@ __global__ __launch_bounds__(LWG) void smooth_linear_kernel(int NV, int NT, doub
     *reinterpret_cast<d2*>(lds + OFF_SNAP + PBUF + v * 16) = p;
   }
   __syncthreads();   // (also orders the workspace stores of this workgroup before its loads: same CU, same L2)
-  // ---- sweeps: waves 0 / 1 solve sweep s, waves 2, 3, 6, 7 validate sweep s - 1 (waves 4 / 5 stay off the solvers' SIMDs)
+  // ---- sweeps.  Two modes:
+  //  CHECKED (from sweep 0 until a sweep passes at the first try): solve, then ALL waves validate at once; vertices whose
+  //    update was not clearly a full step are flagged and the sweep is redone from its snapshot by repair_sweep (exact
+  //    update for the flagged vertices), until a round flags nothing new.  Right after a vertex removal the cavity's
+  //    neighbours take limited steps in the first sweeps: one or two repair rounds in sweep 0, rarely later.
+  //  PIPELINED: waves 0 / 1 solve sweep s WHILE waves 2, 3, 6, 7 validate sweep s - 1 from the two snapshots (waves 4 / 5
+  //    stay off the solvers' SIMDs); a sweep that fails goes back to its snapshot and to the CHECKED mode.
   const d2* mgd = reinterpret_cast<const d2*>(mg);
   const int vw = wave == 2 ? 0 : wave == 3 ? 1 : wave == 6 ? 2 : wave == 7 ? 3 : -1;
   const int ne = 3 * nt, npass = (ne + 63) / 64;
-  int failed = -1;
-  for (int s = 0; s <= S; ++s) {
-#ifndef LIN_NOSOLVE
-    if (s < S) {
-      if (wave == 0) {
-        __builtin_amdgcn_s_setprio(3);
-        solve_sweep<0>(lds, mgd, nb, lane);
-        __builtin_amdgcn_s_setprio(0);
-      } else if (wave == 1) {
-        __builtin_amdgcn_s_setprio(3);
-        solve_sweep<1>(lds, mgd, nb, lane);
-        __builtin_amdgcn_s_setprio(0);
+  unsigned char* fixv = lds + OFF_FIXV;
+  auto copy_pos = [&](int dst_off, int src_off) {
+    for (int v = tid; v < nv; v += LWG)
+      *reinterpret_cast<d2*>(lds + dst_off + v * 16) = *reinterpret_cast<const d2*>(lds + src_off + v * 16);
+  };
+  auto solve_fast = [&]() {
+    if (wave == 0) {
+      __builtin_amdgcn_s_setprio(3);
+      solve_sweep<0>(lds, mgd, nb, lane);
+      __builtin_amdgcn_s_setprio(0);
+    } else if (wave == 1) {
+      __builtin_amdgcn_s_setprio(3);
+      solve_sweep<1>(lds, mgd, nb, lane);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  };
+  int s = 0, failed = -1, n_repaired = 0, n_rounds = 0, n_sentback = 0;   // (diagnostics)
+  bool checked = true, pending = false;     // pending: sweep s - 1 still awaits its validation (pipelined mode)
+  while (true) {
+    if (s >= S && !pending) break;
+    if (checked) {
+      const int snap = OFF_SNAP + (s & 1) * PBUF;                 // state at the start of sweep s
+      for (int v = tid; v < LNV + 16; v += LWG) fixv[v] = 0;
+      int rounds = 0, nflag = 0;
+      while (true) {
+        __syncthreads();
+        if (nflag == 0) {
+          solve_fast();
+        } else if (wave == 0) {
+          repair_sweep(lds, mgd, nb, lane, lds + snap);
+        }
+        if (tid == 0) misc[1] = 0;
+        __syncthreads();
+        bool bad = false;
+        for (int p = wave; p < npass; p += LWG / 64) bad |= validate_entry<true>(lds, 64 * p + lane, ne, lds + snap, lds + OFF_CUR);
+        if (bad) misc[1] = 1;
+        __syncthreads();
+        if (!misc[1]) break;
+        nflag = 1;
+        ++n_rounds;
+        if (++rounds >= MAXROUNDS) {
+          failed = s;
+          break;
+        }
+        copy_pos(OFF_CUR, snap);                                   // back to the start of the sweep
       }
-    }
-#endif
-#ifndef LIN_NOVALID
-    if (s > 0) {
-      // sweep s - 1: OLD = snapshot (s - 1) & 1, NEW = snapshot s & 1
-      const unsigned char* OLD = lds + OFF_SNAP + ((s - 1) & 1) * PBUF;
-      const unsigned char* NEW = lds + OFF_SNAP + (s & 1) * PBUF;
-      bool bad = false;
-      if (s < S) {
-        if (vw >= 0)
-          for (int p = vw; p < npass; p += 4) bad |= validate_entry(lds, 64 * p + lane, ne, OLD, NEW);
-      } else {                                   // behind the last sweep: everybody
-        for (int p = wave; p < npass; p += LWG / 64) bad |= validate_entry(lds, 64 * p + lane, ne, OLD, NEW);
-      }
-      if (bad) misc[1] = 1;
-    }
-#endif
-    __syncthreads();
-    if (misc[1]) {
-      failed = s - 1;
-      break;
-    }
-    if (s < S) {                                 // snapshot = state at the start of sweep s + 1
-      for (int v = tid; v < nv; v += LWG)
-        *reinterpret_cast<d2*>(lds + OFF_SNAP + ((s + 1) & 1) * PBUF + v * 16) = *reinterpret_cast<const d2*>(lds + OFF_CUR + v * 16);
+      if (failed >= 0) break;
+      copy_pos(OFF_SNAP + ((s + 1) & 1) * PBUF, OFF_CUR);
       __syncthreads();
+      ++s;
+      if (rounds == 0) {
+        checked = false;
+        pending = false;
+      } else {
+        ++n_repaired;
+      }
+    } else {
+      if (s < S) solve_fast();
+      bool bad = false;
+      if (pending) {                            // sweep s - 1: OLD = snapshot (s - 1) & 1, NEW = snapshot s & 1
+        const unsigned char* OLD = lds + OFF_SNAP + ((s - 1) & 1) * PBUF;
+        const unsigned char* NEW = lds + OFF_SNAP + (s & 1) * PBUF;
+        if (s < S) {
+          if (vw >= 0)
+            for (int p = vw; p < npass; p += 4) bad |= validate_entry<false>(lds, 64 * p + lane, ne, OLD, NEW);
+        } else {                                // behind the last sweep: everybody
+          for (int p = wave; p < npass; p += LWG / 64) bad |= validate_entry<false>(lds, 64 * p + lane, ne, OLD, NEW);
+        }
+      }
+      if (tid == 0) misc[1] = 0;
+      __syncthreads();
+      if (bad) misc[1] = 1;
+      __syncthreads();
+      if (misc[1]) {                            // sweep s - 1 was not all full steps: redo it checked
+        --s;
+        ++n_sentback;
+        copy_pos(OFF_CUR, OFF_SNAP + (s & 1) * PBUF);
+        checked = true;
+        pending = false;
+        __syncthreads();
+        continue;
+      }
+      if (s >= S) break;
+      copy_pos(OFF_SNAP + ((s + 1) & 1) * PBUF, OFF_CUR);
+      __syncthreads();
+      pending = true;
+      ++s;
     }
   }
-  // ---- result: the final positions, or - rolled back - the positions at the start of the failed sweep
+  // ---- result: the final positions, or - a sweep that did not settle within MAXROUNDS repair rounds - the positions at
+  // the start of that sweep: the careful walk takes the rest
+  __syncthreads();
   const unsigned char* src = failed < 0 ? lds + OFF_CUR : lds + OFF_SNAP + (failed & 1) * PBUF;
   for (int v = tid; v < nv; v += LWG) {
     const d2 p = *reinterpret_cast<const d2*>(src + v * 16);
     x[v] = double2{p.x, p.y};
   }
-  if (tid == 0) redo[b] = failed < 0 ? 0 : S - failed;
+  if (tid == 0) {
+    redo[b] = failed < 0 ? 0 : S - failed;
+    stats[3 * b] = n_repaired;       // sweeps that took repair rounds (vertices with limited steps)
+    stats[3 * b + 1] = n_rounds;     // repair rounds in total
+    stats[3 * b + 2] = n_sentback;   // pipelined sweeps whose validation failed (redone checked)
+  }
 }
 
 // diagnostics: environments handed back to the careful walk by the last launches
@@ -471,7 +670,7 @@ __global__ void count_redo_kernel(int B, const int32_t* redo, unsigned long long
 extern "C" int64_t mdq_smooth_fast_workspace_bytes(int32_t B, int32_t NV) {
   if (B <= 0 || NV <= 0) return 0;
   const int64_t blocks = (NV + mdq_smooth_lin::BS - 1) / mdq_smooth_lin::BS + 2;     // two blocks of padding (prefetch)
-  return (int64_t)B * blocks * mdq_smooth_lin::MBLK * 8 + (int64_t)B * 4 + 256;
+  return (int64_t)B * blocks * mdq_smooth_lin::MBLK * 8 + (int64_t)B * 16 + 256;   // block inverses, [B] redo, [B][3] diagnostics
 }
 
 extern "C" int mdq_smooth_fast(int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t* cells, const int32_t* nv,
@@ -492,13 +691,11 @@ extern "C" int mdq_smooth_fast(int32_t B, int32_t NV, int32_t NT, double* coords
 #ifdef MDQ_SMOOTH_TRACE
   trace = mdq_smooth_trace_host();
 #endif
-  // 1. the first sweeps: careful walk (limited steps right after a vertex removal)
-  hipLaunchKernelGGL(mdq_smoothing::smooth_kernel, dim3(B), dim3(mdq_smoothing::SWG), 0, st, NV, NT, coords, cells, nv, nt,
-                     iterations, mdq_smooth_lin::CAREFUL, trace);
-  // 2. the remaining sweeps as blocked triangular solves, validated in parallel
+  // 1. every sweep as a blocked triangular solve: checked + repaired while limited steps occur, then validated in parallel
   hipLaunchKernelGGL(mdq_smooth_lin::smooth_linear_kernel, dim3(B), dim3(mdq_smooth_lin::LWG), 0, st, NV, NT, coords, cells, nv,
-                     nt, iterations, mws, mstride, redo);
-  // 3. environments that were rolled back (normally none: the kernel returns at once)
+                     nt, iterations, mws, mstride, redo, redo + B);
+  // 2. environments handed back (meshes beyond the kernel's limits, sweeps that did not settle; normally none: the kernel
+  //    returns at once)
   hipLaunchKernelGGL(mdq_smoothing::smooth_kernel, dim3(B), dim3(mdq_smoothing::SWG), 0, st, NV, NT, coords, cells, nv, nt,
                      redo, 0, trace);
   if (hipGetLastError() != hipSuccess) return mdq_set_error("mdq_smooth_fast: launch failed");

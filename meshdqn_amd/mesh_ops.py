@@ -327,15 +327,17 @@ def smooth_batch_gpu(coords: torch.Tensor, cells: torch.Tensor, nv: torch.Tensor
                                    iterations.data_ptr(), ws.data_ptr(), ws.numel(), sp), "mdq_smooth_fast")
 
 
-def smooth_fast_rollbacks(device, B: int, NV: int, stream=None) -> np.ndarray:
-    """Diagnostics of the last `smooth_batch_gpu(fast=True)` launch with these sizes on this stream: per environment the
-    number of sweeps that were handed back to the careful walk (0 = every sweep of the blocked solve was validated)."""
+def smooth_fast_stats(device, B: int, NV: int, stream=None) -> np.ndarray:
+    """Diagnostics of the last `smooth_batch_gpu(fast=True)` launch with these sizes on this stream, (B, 4) int32 per
+    environment: [sweeps handed back to the careful walk (0 = everything ran in the blocked solve), sweeps that needed repair
+    rounds (vertices with limited steps), repair rounds in total, pipelined sweeps whose validation failed]."""
     ws = _SMOOTH_WS.get((torch.device(device) if not isinstance(device, torch.device) else device,
                          int(_lib.stream_ptr(stream).value or 0), B, NV))
     if ws is None:
         raise KeyError("no mdq_smooth_fast workspace for these sizes on this stream")
     off = B * ((NV + 31) // 32 + 2) * 1024 * 8            # behind the block inverses (mdq_smooth_fast_workspace_bytes)
-    return ws[off:off + 4 * B].view(torch.int32).cpu().numpy()
+    raw = ws[off:off + 16 * B].view(torch.int32).cpu().numpy()
+    return np.concatenate([raw[:B, None], raw[B:4 * B].reshape(B, 3)], axis=1)
 
 
 class DeviceTopologyBatch:
