@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MDQ_ABI_VERSION 3
+#define MDQ_ABI_VERSION 4
 
 /* ---- error handling ----------------------------------------------------- */
 int mdq_abi_version(void);
@@ -264,6 +264,13 @@ int mdq_gcn_forward(const mdq_gcn_net* net, int32_t B, int32_t NMAX, int32_t EMA
 int mdq_gcn_forward_ex(const mdq_gcn_net* net, int32_t B, int32_t NMAX, int32_t EMAX, const float* x,
                        const int32_t* node_ptr, const int32_t* esrc, const int32_t* edst,
                        const int32_t* edge_ptr, float* emb, float* out, int32_t* perm, int32_t* status, void* stream);
+
+/* The same forward on edge lists PADDED to EMAX slots per graph (graph b: esrc_pad / edst_pad [b * EMAX .. + edge_cnt[b])) -
+ * the layout mdq_env_topology writes (edge_src / edge_dst / nedges): no offsets, no compaction in front of the Q-forward
+ * of a device-resident env step. */
+int mdq_gcn_forward_padded(const mdq_gcn_net* net, int32_t B, int32_t NMAX, int32_t EMAX, const float* x,
+                           const int32_t* node_ptr, const int32_t* esrc_pad, const int32_t* edst_pad,
+                           const int32_t* edge_cnt, float* emb, float* out, int32_t* perm, int32_t* status, void* stream);
 
 /* ---- the learning step of the graph Q-network (airfoil_dqn.py:240-310 DataWorker.compute_gradients) ---- */
 /* Offsets (in floats) of every trained parameter inside the flat gradient: the parameters of the module in
@@ -492,7 +499,7 @@ int mdq_env_result(int32_t B, int32_t N, int32_t S, const double* new_drags, con
                    int32_t nv0, const int32_t* rstat, const int32_t* topo_status, const int32_t* nsel, int32_t* code,
                    int32_t* steps, double threshold, double time_reward, double goal_vertices, int32_t timesteps,
                    double negative_reward, int32_t auto_reset, double* reward, uint8_t* done, int32_t* err_flag,
-                   void* stream);
+                   int32_t* nv_out /* optional [B]: copy of nv (the vertex counts of this step) */, void* stream);
 
 /* mdq_restore_rows for the environments with mask[b] != 0 (device array): the in-place reset without a host-side list. */
 int mdq_restore_rows_masked(int32_t n, void* const* dst, const void* const* src, const int64_t* row_bytes, int32_t B,
@@ -522,17 +529,24 @@ int mdq_smooth(int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t*
                const int32_t* nt, const int32_t* iterations, void* stream);
 
 /*
- * The same smoothing, faster: the first three sweeps by mdq_smooth's kernel (right after a vertex removal the cavity's
- * neighbours take limited steps), the remaining FULL-STEP sweeps as blocked triangular solves of the linear system a
- * Gauss-Seidel sweep is ((D - L) x_new = U x_old, 32-row blocks, inverses built once per launch), every sweep validated
- * in parallel (was each update clearly a full step?); an environment with a sweep that was not is rolled back to the
- * start of that sweep and finished by mdq_smooth's kernel: exact sequential semantics, results equal to mdq_smooth to
- * round-off (different association).  Same arguments as mdq_smooth + a device workspace of at least
- * mdq_smooth_fast_workspace_bytes(B, NV) bytes, 16-byte aligned (block inverses, per-environment roll-back counters).
+ * The same smoothing, faster: a Gauss-Seidel sweep in which every vertex takes the full step is the linear system
+ * (D - L) x_new = U x_old: the sweeps run as blocked triangular solves (32-row blocks, inverses built once per launch),
+ * every sweep is validated in parallel (was each update clearly a full step?), and a sweep that was not is redone from
+ * its snapshot with the offending vertices on DOLFIN's exact (limited-step) update and a rank-1 correction of their block:
+ * exact sequential semantics, results equal to mdq_smooth to round-off (different association).  A mesh beyond the
+ * kernel's limits (more than 16 cells at a vertex) is handed to mdq_smooth's kernel.  Same arguments as mdq_smooth + a
+ * device workspace of at least mdq_smooth_fast_workspace_bytes(B, NV) bytes, 16-byte aligned (block inverses,
+ * per-environment diagnostics).
  */
 int64_t mdq_smooth_fast_workspace_bytes(int32_t B, int32_t NV);
 int mdq_smooth_fast(int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t* cells, const int32_t* nv,
                     const int32_t* nt, const int32_t* iterations, void* workspace, int64_t workspace_bytes, void* stream);
+/* Inside an env step (Env2DAirfoil._check_mesh -> flow_solver.remesh -> smooth(50), flow_solver.py:236-237): `iterations`
+ * sweeps for the environments whose vertex removal succeeded (rem[b] >= 0 and rstat[b] == 0, the outputs of mdq_env_act /
+ * mdq_remesh), none for the others - mdq_env_smooth_iters + mdq_smooth_fast in one launch. */
+int mdq_smooth_fast_env(int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t* cells, const int32_t* nv,
+                        const int32_t* nt, const int32_t* rem, const int32_t* rstat, int32_t iterations, void* workspace,
+                        int64_t workspace_bytes, void* stream);
 
 /*
  * Diagnostics of mdq_smooth since the last reset (no reference counterpart): out64[s], s < 63 = speculative sweeps s

@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmeshdqn_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class MeshDQNHipError(RuntimeError):
@@ -97,6 +97,8 @@ SYMBOLS = {
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdq_gcn_forward_ex": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mdq_gcn_forward_padded": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdq_interpolate_snapshots": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mdq_remesh": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_void_p]),
@@ -113,7 +115,7 @@ SYMBOLS = {
     "mdq_env_smooth_iters": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mdq_env_result": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int32,
-                                 C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                 C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdq_restore_rows_masked": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mdq_edge_ptr": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdq_smooth": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -122,6 +124,8 @@ SYMBOLS = {
     "mdq_smooth_fast_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
     "mdq_smooth_fast": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int64, C.c_void_p]),
+    "mdq_smooth_fast_env": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "mdq_ipcs_factorize_pressure": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdq_gcn_train_workspace": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32]),
     "mdq_gcn_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -463,12 +463,14 @@ __device__ __forceinline__ void run_level(const Lds& L, const Level& lv, int C, 
 
 __global__ __launch_bounds__(WGT) void gcn_embed_kernel(mdq_gcn_net net, int NMAX, int EMAX, const float* x,
                                                          const int32_t* node_ptr, const int32_t* esrc,
-                                                         const int32_t* edst, const int32_t* edge_ptr, float* emb,
-                                                         int32_t* perm, int32_t* status) {
+                                                         const int32_t* edst, const int32_t* edge_ptr,
+                                                         const int32_t* edge_cnt, float* emb, int32_t* perm,
+                                                         int32_t* status) {
   extern __shared__ __align__(16) float sm[];
   const int b = blockIdx.x, tid = threadIdx.x, C = net.C;
   const int n0 = node_ptr[b], nn = node_ptr[b + 1] - n0;
-  const int e0 = edge_ptr[b], ne = edge_ptr[b + 1] - e0;
+  // edge lists: packed (offsets edge_ptr) or padded to EMAX slots per graph with the counts beside them (edge_cnt)
+  const int e0 = edge_cnt ? b * EMAX : edge_ptr[b], ne = edge_cnt ? edge_cnt[b] : edge_ptr[b + 1] - e0;
   if (status && tid == 0) status[b] = (nn > NMAX || nn < 0) ? -1 : (ne > EMAX || ne < 0) ? -2 : 0;
   if (nn > NMAX || ne > EMAX || nn < 0 || ne < 0) {
     // the LDS carve-up is sized from NMAX / EMAX: a larger graph must not be staged.  Its outputs are NaN (never a
@@ -616,12 +618,31 @@ extern "C" int mdq_gcn_forward(const mdq_gcn_net* net, int32_t B, int32_t NMAX, 
   return mdq_gcn_forward_ex(net, B, NMAX, EMAX, x, node_ptr, esrc, edst, edge_ptr, emb, out, nullptr, nullptr, stream);
 }
 
+static int gcn_forward_impl(const mdq_gcn_net* net, int32_t B, int32_t NMAX, int32_t EMAX, const float* x,
+                            const int32_t* node_ptr, const int32_t* esrc, const int32_t* edst, const int32_t* edge_ptr,
+                            const int32_t* edge_cnt, float* emb, float* out, int32_t* perm, int32_t* status, void* stream);
+
 extern "C" int mdq_gcn_forward_ex(const mdq_gcn_net* net, int32_t B, int32_t NMAX, int32_t EMAX, const float* x,
                                   const int32_t* node_ptr, const int32_t* esrc, const int32_t* edst,
                                   const int32_t* edge_ptr, float* emb, float* out, int32_t* perm, int32_t* status,
                                   void* stream) {
+  if (!edge_ptr) return mdq_set_error("mdq_gcn_forward: bad arguments");
+  return gcn_forward_impl(net, B, NMAX, EMAX, x, node_ptr, esrc, edst, edge_ptr, nullptr, emb, out, perm, status, stream);
+}
+
+extern "C" int mdq_gcn_forward_padded(const mdq_gcn_net* net, int32_t B, int32_t NMAX, int32_t EMAX, const float* x,
+                                      const int32_t* node_ptr, const int32_t* esrc_pad, const int32_t* edst_pad,
+                                      const int32_t* edge_cnt, float* emb, float* out, int32_t* perm, int32_t* status,
+                                      void* stream) {
+  if (!edge_cnt) return mdq_set_error("mdq_gcn_forward_padded: bad arguments");
+  return gcn_forward_impl(net, B, NMAX, EMAX, x, node_ptr, esrc_pad, edst_pad, nullptr, edge_cnt, emb, out, perm, status, stream);
+}
+
+static int gcn_forward_impl(const mdq_gcn_net* net, int32_t B, int32_t NMAX, int32_t EMAX, const float* x,
+                            const int32_t* node_ptr, const int32_t* esrc, const int32_t* edst, const int32_t* edge_ptr,
+                            const int32_t* edge_cnt, float* emb, float* out, int32_t* perm, int32_t* status, void* stream) {
   using namespace mdq_gcn;
-  if (!net || B <= 0 || !x || !node_ptr || !edge_ptr || !emb || !out) return mdq_set_error("mdq_gcn_forward: bad arguments");
+  if (!net || B <= 0 || !x || !node_ptr || (!edge_ptr && !edge_cnt) || !emb || !out) return mdq_set_error("mdq_gcn_forward: bad arguments");
   const int C = net->C;
   if (C != 64 && C != 128 && C != 256 && C != 32) return mdq_set_error("mdq_gcn_forward: conv width must divide 256");
   if (net->fin0 > 32 && NMAX > NACC * (WGT / C)) return mdq_set_error("mdq_gcn_forward: graph too large for the input width");
@@ -640,7 +661,7 @@ extern "C" int mdq_gcn_forward_ex(const mdq_gcn_net* net, int32_t B, int32_t NMA
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return mdq_set_error(hipGetErrorString(e));
   hipLaunchKernelGGL(gcn_embed_kernel, dim3(B), dim3(WGT), lds, st, *net, NMAX, EMAX, x, node_ptr, esrc, edst,
-                     edge_ptr, emb, perm, status);
+                     edge_ptr, edge_cnt, emb, perm, status);
   e = hipGetLastError();
   if (e != hipSuccess) return mdq_set_error(hipGetErrorString(e));
   const int OUTP = (net->out_dim + 31) & ~31;

@@ -328,7 +328,7 @@ __global__ void env_result_kernel(int B, int N, int S, const double* new_drags, 
                                   int32_t nv0, const int32_t* rstat, const int32_t* topo_status, const int32_t* nsel,
                                   int32_t* code, int32_t* steps, double threshold, double time_reward, double goal_vertices,
                                   int32_t timesteps, double negative_reward, int32_t auto_reset, double* reward,
-                                  uint8_t* done, int32_t* err_flag) {
+                                  uint8_t* done, int32_t* err_flag, int32_t* nv_out) {
 #pragma clang fp contract(off)
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
@@ -356,6 +356,7 @@ __global__ void env_result_kernel(int B, int N, int S, const double* new_drags, 
   const int st = steps[b] + 1;
   dn = dn || st >= timesteps;
   reward[b] = r;
+  if (nv_out) nv_out[b] = nv[b];      // (the vertex count of the step, before an in-place reset rewrites nv)
   done[b] = dn ? 1 : 0;
   code[b] = c;
   steps[b] = (dn && auto_reset) ? 0 : st;
@@ -427,12 +428,12 @@ extern "C" int mdq_env_result(int32_t B, int32_t N, int32_t S, const double* new
                               int32_t nv0, const int32_t* rstat, const int32_t* topo_status, const int32_t* nsel,
                               int32_t* code, int32_t* steps, double threshold, double time_reward, double goal_vertices,
                               int32_t timesteps, double negative_reward, int32_t auto_reset, double* reward, uint8_t* done,
-                              int32_t* err_flag, void* stream) {
+                              int32_t* err_flag, int32_t* nv_out, void* stream) {
   if (B <= 0 || S <= 0 || !new_drags || !gt_drag || !nv || !rstat || !nsel || !code || !steps || !reward || !done || !err_flag)
     return mdq_set_error("mdq_env_result: bad arguments");
   hipLaunchKernelGGL(mdq_mesh::env_result_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream, B, N, S, new_drags,
                      gt_drag, nv, nv0, rstat, topo_status, nsel, code, steps, threshold, time_reward, goal_vertices, timesteps,
-                     negative_reward, auto_reset, reward, done, err_flag);
+                     negative_reward, auto_reset, reward, done, err_flag, nv_out);
   if (hipGetLastError() != hipSuccess) return mdq_set_error("env_result_kernel launch failed");
   return 0;
 }

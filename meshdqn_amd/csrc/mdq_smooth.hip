@@ -177,10 +177,10 @@ __device__ __forceinline__ bool exact_update(const lds_u8* recb, const lds_i32* 
   return true;
 }
 
-__global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coords, const int32_t* cells,
-                                                     const int32_t* nv_, const int32_t* nt_, const int32_t* iters_,
-                                                     int cap, long long* trace) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+// one environment (b) by the whole workgroup
+__device__ __forceinline__ void smooth_env(unsigned char* lds, const int b, int NV, int NT, double* coords, const int32_t* cells,
+                                           const int32_t* nv_, const int32_t* nt_, const int32_t* iters_, int cap,
+                                           long long* trace) {
   unsigned char* recb = lds + OFF_REC;
   unsigned char* rows = lds + OFF_ROW;
   uint16_t* passtab = reinterpret_cast<uint16_t*>(lds + OFF_PT);
@@ -195,8 +195,8 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
   unsigned char* hwt = recb;   // scheduler scratch in the record area (the records are loaded behind the scheduler):
                                // per interior rank and cell the interior ranks of its higher-numbered vertices
   int* part = reinterpret_cast<int*>(lds + OFF_PART);
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int iters = cap > 0 ? min(iters_[b], cap) : iters_[b];   // (cap: mdq_smooth_fast runs only the first sweeps here)
+  const int tid = threadIdx.x;
+  const int iters = cap > 0 ? min(iters_[b], cap) : iters_[b];   // (cap: only the first sweeps)
   if (iters <= 0) return;
 #ifdef MDQ_SMOOTH_TRACE
   int phase_ = 0;   // setup phase stamps of environment 0 in the slots of sweep 63
@@ -722,6 +722,19 @@ __global__ __launch_bounds__(SWG) void smooth_kernel(int NV, int NT, double* coo
 #undef MDQ_SMOOTH_PHASE
 }
 
+// B environments over the workgroups of the grid (mdq_smooth: one workgroup per environment; the hand-back launch of
+// mdq_smooth_fast: ONE workgroup that walks over the - normally zero - environments with iterations left: a single
+// workgroup of 141 KB LDS finds a compute unit at once, 128 of them wait for the kernels of other streams to drain)
+__global__ __launch_bounds__(SWG) void smooth_kernel(int B, int NV, int NT, double* coords, const int32_t* cells,
+                                                     const int32_t* nv_, const int32_t* nt_, const int32_t* iters_,
+                                                     int cap, long long* trace) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    smooth_env(lds, b, NV, NT, coords, cells, nv_, nt_, iters_, cap, trace);
+    __syncthreads();
+  }
+}
+
 }  // namespace mdq_smoothing
 
 #ifdef MDQ_SMOOTH_TRACE
@@ -757,7 +770,7 @@ extern "C" int mdq_smooth(int32_t B, int32_t NV, int32_t NT, double* coords, con
 #ifdef MDQ_SMOOTH_TRACE
   trace = mdq_smooth_trace_host();
 #endif
-  hipLaunchKernelGGL(mdq_smoothing::smooth_kernel, dim3(B), dim3(mdq_smoothing::SWG), 0, (hipStream_t)stream, NV, NT, coords,
+  hipLaunchKernelGGL(mdq_smoothing::smooth_kernel, dim3(B), dim3(mdq_smoothing::SWG), 0, (hipStream_t)stream, B, NV, NT, coords,
                      cells, nv, nt, iterations, 0, trace);
   if (hipGetLastError() != hipSuccess) return mdq_set_error("smooth_kernel launch failed");
   return 0;

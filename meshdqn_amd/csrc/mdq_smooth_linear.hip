@@ -346,12 +346,28 @@ __device__ __forceinline__ void repair_sweep(unsigned char* lds, const d2* mg, i
   }
 }
 
+// a sweep in plain index order by one wave, every interior vertex on the exact update (in place: an update sees the new
+// positions of everything before it) - the way out for a checked sweep that does not settle within MAXROUNDS repair rounds
+__device__ __forceinline__ void sequential_sweep(unsigned char* lds, int n_int, int lane) {
+  const uint16_t* ivert = reinterpret_cast<const uint16_t*>(lds + OFF_IVERT);
+  unsigned char* cur = lds + OFF_CUR;
+  for (int r = 0; r < n_int; ++r) {
+    const int v = ivert[r];
+    const d2 xs = exact_vertex(lds, v, lane & 7, cur);
+    if (lane == 0) *reinterpret_cast<d2*>(cur + v * 16) = xs;
+    asm volatile("" ::: "memory");
+  }
+}
+
 __global__ __launch_bounds__(LWG) void smooth_linear_kernel(int NV, int NT, double* coords, const int32_t* cells,
                                                             const int32_t* nv_, const int32_t* nt_, const int32_t* iters_,
+                                                            const int32_t* rem, const int32_t* rstat, int iters_env,
                                                             double* mws, int64_t mstride, int32_t* redo, int32_t* stats) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int S = iters_[b];                     // sweeps
+  // sweeps: given per environment, or - inside an env step - `iters_env` where a vertex was removed successfully
+  // (Env2DAirfoil._check_mesh -> flow_solver.remesh -> smooth(50), flow_solver.py:236-237; nothing otherwise)
+  const int S = iters_ ? iters_[b] : ((rem[b] >= 0 && rstat[b] == 0) ? iters_env : 0);
   if (S <= 0) {
     if (tid == 0) redo[b] = stats[3 * b] = stats[3 * b + 1] = stats[3 * b + 2] = 0;
     return;
@@ -571,7 +587,7 @@ __global__ __launch_bounds__(LWG) void smooth_linear_kernel(int NV, int NT, doub
       __builtin_amdgcn_s_setprio(0);
     }
   };
-  int s = 0, failed = -1, n_repaired = 0, n_rounds = 0, n_sentback = 0;   // (diagnostics)
+  int s = 0, n_repaired = 0, n_rounds = 0, n_sentback = 0, n_seq = 0;   // (diagnostics)
   bool checked = true, pending = false;     // pending: sweep s - 1 still awaits its validation (pipelined mode)
   while (true) {
     if (s >= S && !pending) break;
@@ -595,13 +611,15 @@ __global__ __launch_bounds__(LWG) void smooth_linear_kernel(int NV, int NT, doub
         if (!misc[1]) break;
         nflag = 1;
         ++n_rounds;
-        if (++rounds >= MAXROUNDS) {
-          failed = s;
+        copy_pos(OFF_CUR, snap);                                   // back to the start of the sweep
+        if (++rounds >= MAXROUNDS) {                               // does not settle: this sweep in plain index order
+          __syncthreads();
+          if (wave == 0) sequential_sweep(lds, n_int, lane);
+          __syncthreads();
+          ++n_seq;
           break;
         }
-        copy_pos(OFF_CUR, snap);                                   // back to the start of the sweep
       }
-      if (failed >= 0) break;
       copy_pos(OFF_SNAP + ((s + 1) & 1) * PBUF, OFF_CUR);
       __syncthreads();
       ++s;
@@ -644,19 +662,17 @@ __global__ __launch_bounds__(LWG) void smooth_linear_kernel(int NV, int NT, doub
       ++s;
     }
   }
-  // ---- result: the final positions, or - a sweep that did not settle within MAXROUNDS repair rounds - the positions at
-  // the start of that sweep: the careful walk takes the rest
+  // ---- result
   __syncthreads();
-  const unsigned char* src = failed < 0 ? lds + OFF_CUR : lds + OFF_SNAP + (failed & 1) * PBUF;
   for (int v = tid; v < nv; v += LWG) {
-    const d2 p = *reinterpret_cast<const d2*>(src + v * 16);
+    const d2 p = *reinterpret_cast<const d2*>(lds + OFF_CUR + v * 16);
     x[v] = double2{p.x, p.y};
   }
   if (tid == 0) {
-    redo[b] = failed < 0 ? 0 : S - failed;
+    redo[b] = 0;
     stats[3 * b] = n_repaired;       // sweeps that took repair rounds (vertices with limited steps)
     stats[3 * b + 1] = n_rounds;     // repair rounds in total
-    stats[3 * b + 2] = n_sentback;   // pipelined sweeps whose validation failed (redone checked)
+    stats[3 * b + 2] = n_sentback | (n_seq << 16);   // pipelined sweeps whose validation failed (redone checked) | sweeps in plain order << 16
   }
 }
 
@@ -673,15 +689,16 @@ extern "C" int64_t mdq_smooth_fast_workspace_bytes(int32_t B, int32_t NV) {
   return (int64_t)B * blocks * mdq_smooth_lin::MBLK * 8 + (int64_t)B * 16 + 256;   // block inverses, [B] redo, [B][3] diagnostics
 }
 
-extern "C" int mdq_smooth_fast(int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t* cells, const int32_t* nv,
-                               const int32_t* nt, const int32_t* iterations, void* workspace, int64_t workspace_bytes,
-                               void* stream) {
-  if (B <= 0 || !coords || !cells || !nv || !nt || !iterations || !workspace)
+static int smooth_fast_impl(const char* who, int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t* cells,
+                            const int32_t* nv, const int32_t* nt, const int32_t* iterations, const int32_t* rem,
+                            const int32_t* rstat, int32_t iters_env, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (B <= 0 || !coords || !cells || !nv || !nt || (!iterations && (!rem || !rstat)) || !workspace)
     return mdq_set_error("mdq_smooth_fast: bad arguments");
   if (NV > mdq_smooth_lin::LNV || NT > mdq_smooth_lin::LNT)
     return mdq_set_error("mdq_smooth_fast: mesh capacity above 1024 vertices / 2048 triangles (use mdq_smooth_host)");
   if (workspace_bytes < mdq_smooth_fast_workspace_bytes(B, NV) || (reinterpret_cast<uintptr_t>(workspace) & 15))
     return mdq_set_error("mdq_smooth_fast: workspace too small or not 16-byte aligned (mdq_smooth_fast_workspace_bytes)");
+  (void)who;
   const int64_t blocks = (NV + mdq_smooth_lin::BS - 1) / mdq_smooth_lin::BS + 2;
   const int64_t mstride = blocks * mdq_smooth_lin::MBLK;
   double* mws = reinterpret_cast<double*>(workspace);
@@ -693,11 +710,28 @@ extern "C" int mdq_smooth_fast(int32_t B, int32_t NV, int32_t NT, double* coords
 #endif
   // 1. every sweep as a blocked triangular solve: checked + repaired while limited steps occur, then validated in parallel
   hipLaunchKernelGGL(mdq_smooth_lin::smooth_linear_kernel, dim3(B), dim3(mdq_smooth_lin::LWG), 0, st, NV, NT, coords, cells, nv,
-                     nt, iterations, mws, mstride, redo, redo + B);
-  // 2. environments handed back (meshes beyond the kernel's limits, sweeps that did not settle; normally none: the kernel
-  //    returns at once)
-  hipLaunchKernelGGL(mdq_smoothing::smooth_kernel, dim3(B), dim3(mdq_smoothing::SWG), 0, st, NV, NT, coords, cells, nv, nt,
+                     nt, iterations, rem, rstat, iters_env, mws, mstride, redo, redo + B);
+  // 2. environments handed back (meshes beyond the kernel's limits: more than 16 cells at a vertex, 14 gather slots per
+  //    row, 8 lower neighbours inside a block): the per-vertex walk, ONE workgroup over the - normally zero - environments
+  //    with sweeps left (128 workgroups of 141 KB LDS each would wait for the other streams' kernels to leave the CUs)
+  hipLaunchKernelGGL(mdq_smoothing::smooth_kernel, dim3(1), dim3(mdq_smoothing::SWG), 0, st, B, NV, NT, coords, cells, nv, nt,
                      redo, 0, trace);
   if (hipGetLastError() != hipSuccess) return mdq_set_error("mdq_smooth_fast: launch failed");
   return 0;
+}
+
+extern "C" int mdq_smooth_fast(int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t* cells, const int32_t* nv,
+                               const int32_t* nt, const int32_t* iterations, void* workspace, int64_t workspace_bytes,
+                               void* stream) {
+  if (!iterations) return mdq_set_error("mdq_smooth_fast: bad arguments");
+  return smooth_fast_impl("mdq_smooth_fast", B, NV, NT, coords, cells, nv, nt, iterations, nullptr, nullptr, 0, workspace,
+                          workspace_bytes, stream);
+}
+
+extern "C" int mdq_smooth_fast_env(int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t* cells, const int32_t* nv,
+                                   const int32_t* nt, const int32_t* rem, const int32_t* rstat, int32_t iterations,
+                                   void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!rem || !rstat) return mdq_set_error("mdq_smooth_fast_env: bad arguments");
+  return smooth_fast_impl("mdq_smooth_fast_env", B, NV, NT, coords, cells, nv, nt, nullptr, rem, rstat, iterations, workspace,
+                          workspace_bytes, stream);
 }

@@ -245,13 +245,15 @@ class FusedGcn:
 
     @torch.no_grad()
     def forward_arrays(self, x, node_ptr, esrc, edst, edge_ptr, nmax, emax, stream=None, edge_counts=None,
-                       return_perm=False, return_status=False, pack=True):
+                       return_perm=False, return_status=False, pack=True, edge_cnt=None):
         """Same launch on pre-built arrays (what `VecEnv2DAirfoil.get_state` returns): x (sumN,F) f32,
         node_ptr / edge_ptr (B+1,) i32, esrc / edst (sumE,) i32 local node ids.  `nmax` / `emax` size the kernel's LDS
         carve-up: `edge_counts` (host array of the per-graph edge counts, where the caller has them) is checked against
         `emax` before the launch, and the kernel itself refuses larger graphs (NaN outputs, `return_status`).
         `return_perm`: also the (B, levels, nmax) TopKPooling `perm` arrays.  `pack=False`: use the packed parameter copy
-        as it is (the caller has called `_pack()` at a point ordered against the writers of the parameters)."""
+        as it is (the caller has called `_pack()` at a point ordered against the writers of the parameters).  `edge_cnt`
+        ((B,) i32 device tensor): the edge lists are PADDED - esrc / edst are (B, emax) arrays, graph b owns the first
+        edge_cnt[b] slots of its row (what `mdq_env_topology` writes) - and `edge_ptr` is ignored."""
         if pack:
             self._pack(stream)
         elif self.desc is None:
@@ -267,11 +269,20 @@ class FusedGcn:
         out = torch.empty((B, d.out_dim), dtype=torch.float32, device=x.device)
         perm = torch.full((B, d.nlevels, int(nmax)), -1, dtype=torch.int32, device=x.device) if return_perm else None
         status = torch.zeros(B, dtype=torch.int32, device=x.device) if return_status else None
-        rc = self.lib.mdq_gcn_forward_ex(C.byref(d), B, int(nmax), max(int(emax), 1), x.data_ptr(), node_ptr.data_ptr(),
-                                         esrc.data_ptr(), edst.data_ptr(), edge_ptr.data_ptr(), emb.data_ptr(),
-                                         out.data_ptr(), None if perm is None else perm.data_ptr(),
-                                         None if status is None else status.data_ptr(), _lib.stream_ptr(stream))
-        _lib.check(rc, "mdq_gcn_forward_ex")
+        if edge_cnt is not None:
+            if esrc.shape[-1] != int(emax) or esrc.numel() != B * int(emax) or edge_cnt.numel() != B:
+                raise ValueError("padded edge lists must be (B, emax) with (B,) counts")
+            rc = self.lib.mdq_gcn_forward_padded(C.byref(d), B, int(nmax), int(emax), x.data_ptr(), node_ptr.data_ptr(),
+                                                 esrc.data_ptr(), edst.data_ptr(), edge_cnt.data_ptr(), emb.data_ptr(),
+                                                 out.data_ptr(), None if perm is None else perm.data_ptr(),
+                                                 None if status is None else status.data_ptr(), _lib.stream_ptr(stream))
+            _lib.check(rc, "mdq_gcn_forward_padded")
+        else:
+            rc = self.lib.mdq_gcn_forward_ex(C.byref(d), B, int(nmax), max(int(emax), 1), x.data_ptr(), node_ptr.data_ptr(),
+                                             esrc.data_ptr(), edst.data_ptr(), edge_ptr.data_ptr(), emb.data_ptr(),
+                                             out.data_ptr(), None if perm is None else perm.data_ptr(),
+                                             None if status is None else status.data_ptr(), _lib.stream_ptr(stream))
+            _lib.check(rc, "mdq_gcn_forward_ex")
         if return_perm or return_status:
             return (out,) + ((perm,) if return_perm else ()) + ((status,) if return_status else ())
         return out

@@ -327,6 +327,22 @@ def smooth_batch_gpu(coords: torch.Tensor, cells: torch.Tensor, nv: torch.Tensor
                                    iterations.data_ptr(), ws.data_ptr(), ws.numel(), sp), "mdq_smooth_fast")
 
 
+def smooth_env_gpu(coords: torch.Tensor, cells: torch.Tensor, nv: torch.Tensor, nt: torch.Tensor, rem: torch.Tensor,
+                   rstat: torch.Tensor, iterations: int = 50, stream=None) -> None:
+    """The smoothing of an env step (`mdq_smooth_fast_env`): `iterations` sweeps for the environments whose vertex removal
+    succeeded (rem >= 0 and rstat == 0: the outputs of `mdq_env_act` / `mdq_remesh`), the others untouched."""
+    lib = _lib.load()
+    B, NV, NT = coords.shape[0], coords.shape[1], cells.shape[1]
+    sp = _lib.stream_ptr(stream)
+    key = (coords.device, int(sp.value or 0), B, NV)
+    ws = _SMOOTH_WS.get(key)
+    if ws is None:
+        ws = _SMOOTH_WS[key] = torch.empty(int(lib.mdq_smooth_fast_workspace_bytes(B, NV)), dtype=torch.uint8, device=coords.device)
+    _lib.check(lib.mdq_smooth_fast_env(B, NV, NT, coords.data_ptr(), cells.data_ptr(), nv.data_ptr(), nt.data_ptr(),
+                                       rem.data_ptr(), rstat.data_ptr(), int(iterations), ws.data_ptr(), ws.numel(), sp),
+               "mdq_smooth_fast_env")
+
+
 def smooth_fast_stats(device, B: int, NV: int, stream=None) -> np.ndarray:
     """Diagnostics of the last `smooth_batch_gpu(fast=True)` launch with these sizes on this stream, (B, 4) int32 per
     environment: [sweeps handed back to the careful walk (0 = everything ran in the blocked solve), sweeps that needed repair
@@ -337,7 +353,8 @@ def smooth_fast_stats(device, B: int, NV: int, stream=None) -> np.ndarray:
         raise KeyError("no mdq_smooth_fast workspace for these sizes on this stream")
     off = B * ((NV + 31) // 32 + 2) * 1024 * 8            # behind the block inverses (mdq_smooth_fast_workspace_bytes)
     raw = ws[off:off + 16 * B].view(torch.int32).cpu().numpy()
-    return np.concatenate([raw[:B, None], raw[B:4 * B].reshape(B, 3)], axis=1)
+    out = np.concatenate([raw[:B, None], raw[B:4 * B].reshape(B, 3)], axis=1)
+    return out          # (column 3: pipelined sweeps redone checked | sweeps taken in plain index order << 16)
 
 
 class DeviceTopologyBatch:

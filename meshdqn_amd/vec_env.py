@@ -25,7 +25,7 @@ import torch
 
 from . import _lib
 from .env import Env2DAirfoil
-from .mesh_ops import DeviceTopologyBatch, HostTopologyBatch, remesh_batch, remesh_batch_gpu, smooth_batch_gpu
+from .mesh_ops import DeviceTopologyBatch, HostTopologyBatch, remesh_batch, remesh_batch_gpu, smooth_batch_gpu, smooth_env_gpu
 
 
 def _host_cores() -> int:
@@ -649,24 +649,16 @@ class VecEnv2DAirfoil:
 
     # ------------------------------------------------------------------ device-resident rollout
     def _state_device(self):
-        """`get_state` without the host: features, edge offsets and packed edge lists from device data only."""
+        """`get_state` without the host: node features from device data only; the edge lists stay in the padded (B, EMAX)
+        layout the topology engine writes (`mdq_gcn_forward_padded` and `mdq_replay_step` read them as they are: no edge
+        offsets, no compaction launches)."""
         dev, B, N, S, dt = self.device, self.B, self.N, self.S, self.dtopo
-        if getattr(self, "_dstate", None) is None:
-            self._dstate = dict(esrc=torch.empty(B * self.EMAX, dtype=torch.int32, device=dev),
-                                edst=torch.empty(B * self.EMAX, dtype=torch.int32, device=dev),
-                                edge_ptr=torch.empty(B + 1, dtype=torch.int32, device=dev))
-        ds = self._dstate
         x = torch.empty((B, N, 2 + 3 * S), dtype=torch.float32, device=dev)
         _lib.check(self.lib.mdq_state_features(B, N, S, self.NV, self.NP, self._coords_dev.data_ptr(), self.u.data_ptr(),
                                                self.p.data_ptr(), dt.t["n_closest"].data_ptr(), dt.t["nsel"].data_ptr(),
                                                x.data_ptr(), _lib.stream_ptr()), "mdq_state_features")
-        _lib.check(self.lib.mdq_edge_ptr(B, dt.t["nedges"].data_ptr(), ds["edge_ptr"].data_ptr(), _lib.stream_ptr()),
-                   "mdq_edge_ptr")
-        _lib.check(self.lib.mdq_compact_edges(B, self.EMAX, dt.t["edge_src"].data_ptr(), dt.t["edge_dst"].data_ptr(),
-                                              ds["edge_ptr"].data_ptr(), ds["esrc"].data_ptr(), ds["edst"].data_ptr(),
-                                              _lib.stream_ptr()), "mdq_compact_edges")
-        return dict(x=x, esrc=ds["esrc"], edst=ds["edst"], edge_ptr=ds["edge_ptr"], node_ptr=self._node_ptr,
-                    edge_src_pad=dt.t["edge_src"], edge_dst_pad=dt.t["edge_dst"], nedges_dev=dt.t["nedges"])
+        return dict(x=x, node_ptr=self._node_ptr, edge_src_pad=dt.t["edge_src"], edge_dst_pad=dt.t["edge_dst"],
+                    nedges_dev=dt.t["nedges"])
 
     def rollout_device(self, fused, steps: int, explore=None, rand_actions=None, actions=None):
         """`steps` batched env steps WITHOUT a host round trip inside a step: the Q-network forward (`fused`: a
@@ -674,7 +666,7 @@ class VecEnv2DAirfoil:
         caller from its own random streams; greedy = first maximum of the Q-row) or given `actions` (steps,B), the
         action decoding, vertex removal, smoothing, topology, interpolation, forces, (S3: the IPCS step), reward /
         terminal logic and the in-place resets are all kernels on the current stream (`mdq_env_act`, `mdq_remesh`,
-        `mdq_env_smooth_iters`, `mdq_smooth`, `mdq_env_topology`, ..., `mdq_env_result`, `mdq_restore_rows_masked`).
+        `mdq_smooth_fast_env`, `mdq_env_topology`, ..., `mdq_env_result`, `mdq_restore_rows_masked`).
         Same semantics as `steps` calls of `step()` (tested against it).  Returns dict(rewards (steps,B), dones,
         actions, codes, nv) - read back ONCE at the end, when the host mirrors of the environments are refreshed too."""
         cur = torch.cuda.current_stream(self.device)
@@ -775,31 +767,31 @@ class VecEnv2DAirfoil:
         st, rem, its = ro["state"], ro["rem"], ro["its"]
         q = None
         if not ro["given"]:
-            q = fused.forward_arrays(st["x"], st["node_ptr"], st["esrc"], st["edst"], st["edge_ptr"], N, self.EMAX, pack=pack)
+            q = fused.forward_arrays(st["x"], st["node_ptr"], st["edge_src_pad"], st["edge_dst_pad"], None, N, self.EMAX,
+                                     pack=pack, edge_cnt=st["nedges_dev"])
         _lib.check(lib.mdq_env_act(B, N, None if q is None else q.data_ptr(),
                                    None if ro["explore"] is None else ro["explore"][k].data_ptr(),
                                    None if ro["rand"] is None else ro["rand"][k].data_ptr(), dt.t["nsel"].data_ptr(),
                                    dt.t["coord_map"].data_ptr(), dt.offset.data_ptr(), ro["act"][k].data_ptr(),
                                    rem.data_ptr(), ro["code"][k].data_ptr(), sp()), "mdq_env_act")
         remesh_batch_gpu(dt.coords, dt.cells, dt.nv, dt.nt, rem, self._rstat)
-        _lib.check(lib.mdq_env_smooth_iters(B, rem.data_ptr(), self._rstat.data_ptr(), 50, its.data_ptr(), sp()),
-                   "mdq_env_smooth_iters")
         tm = getattr(self, "smooth_events", None)     # (bench: HIP events around the launch, on this stream)
         if tm is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        smooth_batch_gpu(dt.coords, dt.cells, dt.nv, dt.nt, its)
+        # smooth(50) where a vertex was removed (mdq_env_smooth_iters folded into the smoothing launch)
+        smooth_env_gpu(dt.coords, dt.cells, dt.nv, dt.nt, rem, self._rstat, 50)
         if tm is not None:
             e1.record()
             tm.append((e0, e1))
         self._refresh_launch(readback=False)
-        ro["nv"][k].copy_(dt.nv)
         _lib.check(lib.mdq_env_result(B, N, S, self._dev_drag.data_ptr(), self._gt_drag_dev.data_ptr(), dt.nv.data_ptr(),
                                       int(self.initial_num_node), self._rstat.data_ptr(), dt.status.data_ptr(),
                                       dt.t["nsel"].data_ptr(), ro["code"][k].data_ptr(), ro["d_steps"].data_ptr(),
                                       self.threshold, self.TIME_REWARD, self.goal_vertices, int(self.timesteps),
                                       self.NEGATIVE_REWARD, 1 if self.auto_reset else 0, ro["rew"][k].data_ptr(),
-                                      ro["done"][k].data_ptr(), ro["err"].data_ptr(), sp()), "mdq_env_result")
+                                      ro["done"][k].data_ptr(), ro["err"].data_ptr(), ro["nv"][k].data_ptr(), sp()),
+                   "mdq_env_result")
         if self.auto_reset:
             ra = self._restore_arg_arrays()
             _lib.check(lib.mdq_restore_rows_masked(ra["n"], ra["dst"], ra["src"], ra["nbytes"], B,

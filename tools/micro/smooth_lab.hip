@@ -136,9 +136,9 @@ int main(int argc, char** argv) {
       hipEvent_t ev[3];
       for (auto& e : ev) CK(hipEventCreate(&e));
       CK(hipEventRecord(ev[0], 0));
-      hipLaunchKernelGGL(mdq_smooth_lin::smooth_linear_kernel, dim3(B), dim3(mdq_smooth_lin::LWG), 0, 0, NV, NT, dx, dt, dnv, dnt, dit, mws, mstride, redo, redo + B);
+      hipLaunchKernelGGL(mdq_smooth_lin::smooth_linear_kernel, dim3(B), dim3(mdq_smooth_lin::LWG), 0, 0, NV, NT, dx, dt, dnv, dnt, dit, nullptr, nullptr, 0, mws, mstride, redo, redo + B);
       CK(hipEventRecord(ev[1], 0));
-      hipLaunchKernelGGL(mdq_smoothing::smooth_kernel, dim3(B), dim3(mdq_smoothing::SWG), 0, 0, NV, NT, dx, dt, dnv, dnt, redo, 0, nullptr);
+      hipLaunchKernelGGL(mdq_smoothing::smooth_kernel, dim3(1), dim3(mdq_smoothing::SWG), 0, 0, B, NV, NT, dx, dt, dnv, dnt, redo, 0, nullptr);
       CK(hipEventRecord(ev[2], 0));
       CK(hipDeviceSynchronize());
       float b_, c;
