@@ -521,6 +521,14 @@ def _diverged_meshes(args, n_envs, removals=20):
     return [(MeshTopology(coords[b, :nv[b]], cells[b, :nt[b]]), coords[b, :nv[b]].copy()) for b in range(n_envs)]
 
 
+def _stream_log():
+    try:
+        from meshdqn_amd import streams
+        return list(streams.LOG)
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def _visible_gpus():
     """GPUs the kernel driver exposes (kfd topology nodes with SIMDs), without touching the HIP runtime; None if the
     topology cannot be read (the ranks then find out themselves)."""
@@ -861,6 +869,7 @@ def main(argv=None):
             "s2_ipcs_env_steps_per_s": s2["value"],
             "training_env_steps_per_s": None if tr is None else tr["value"],
             "collective_backend": rccl,          # backend, RCCL version, ranks (None for a single rank)
+            "stream_setup": _stream_log(),       # rank 0: how the main / flow / optimiser streams were chosen
             "config": {
                 "workload": f"{args.mesh} ({nv} vertices / {nt} triangles), {B} batched envs per GPU, step = S3 (north-star env "
                             f"step): remove vertex + Delaunay restoration + smooth(50) + 5-snapshot interpolation + 10 force "

@@ -39,7 +39,7 @@ class IpcsDesc(C.Structure):
         ("nbo", C.c_void_p), ("bo_rows", C.c_void_p), ("bo_ptr", C.c_void_p), ("bo_col", C.c_void_p),
         ("bo_src", C.c_void_p), ("bo_val", C.c_void_p),
         ("pd_enabled", C.c_int32), ("NPART", C.c_int32), ("NPW", C.c_int32), ("NPF", C.c_int32),
-        ("NPGI", C.c_int32), ("NPS", C.c_int32), ("NPGK", C.c_int32), ("_pad1", C.c_int32),
+        ("NPGI", C.c_int32), ("NPS", C.c_int32), ("NPGK", C.c_int32), ("pcg_degree", C.c_int32),
         ("pd_hdr", C.c_void_p), ("pd_node", C.c_void_p), ("pd_meta", C.c_void_p), ("pd_rowblk", C.c_void_p),
         ("pd_W", C.c_void_p), ("pd_F", C.c_void_p), ("pd_gidx", C.c_void_p), ("pd_Sinv", C.c_void_p),
         ("pd_gk_ptr", C.c_void_p), ("pd_gk_col", C.c_void_p), ("pd_gk_val", C.c_void_p),

@@ -1251,6 +1251,168 @@ __device__ inline int cg_pressure_reg(int n, const int32_t* sl_off, const int32_
   return it;
 }
 
+// The same CG with the matrix rows of a thread in REGISTERS (values + column offsets of its two rows: they do not change
+// over the iterations, and the LDS-resident version paid two dependent LDS round trips per entry - column, then vector
+// element) and, for degree > 1, a CHEBYSHEV polynomial preconditioner on top of the Jacobi scaling: z = p_m(A) r with
+// p_m the degree-(m - 1) Chebyshev approximation of 1 / lambda on [lmax / CHEB_RATIO, lmax] (lmax: Gershgorin bound of the
+// scaled matrix, computed here).  p_m(A) is symmetric positive definite for any spectrum inside (0, lmax], so this is a
+// plain preconditioned CG; it trades reductions (two workgroup barriers each) for operator applications (one barrier):
+// m - 1 extra applications per iteration, roughly m times fewer iterations.  Needs n <= 2 * NTH and SELL slices of at
+// most PCG_W entries per row (else: returns -1 and the caller takes cg_pressure_reg).
+constexpr int PCG_W = 12;
+constexpr double CHEB_RATIO = 30.0;
+template <int NTH>
+__device__ inline int cg_pressure_cheb(int n, const int32_t* sl_off, const int32_t* sl_col, const double* A, double rtol,
+                                       int maxit, int degree, double* x, double* r, double* p, double* red, int& rsel) {
+  constexpr int NW = NTH / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nsl = (n + 63) >> 6;
+  int row[2], wid[2];
+  double av[2][PCG_W];
+  int cv[2][PCG_W];
+  bool fits = true;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int s_ = wave + NW * k;
+    row[k] = (s_ << 6) + lane;
+    const int base = s_ < nsl ? sl_off[s_] : 0;
+    wid[k] = s_ < nsl ? (sl_off[s_ + 1] - base) >> 6 : 0;
+    fits = fits && wid[k] <= PCG_W;
+#pragma unroll
+    for (int j = 0; j < PCG_W; ++j) {
+      const bool in = j < wid[k];
+      av[k][j] = in ? A[base + lane + j * 64] : 0.0;
+      cv[k][j] = in ? sl_col[base + lane + j * 64] : 0;
+    }
+  }
+  // workgroup-wide OR of `!fits` through the (still unused) search-direction vector: __syncthreads_or would add a static
+  // LDS word to kernels that already ask for the whole 160 KB dynamically
+  if (threadIdx.x == 0) p[NW] = 0.0;
+  __syncthreads();
+  if (!fits) p[NW] = 1.0;
+  __syncthreads();
+  const bool toowide = p[NW] != 0.0;
+  __syncthreads();
+  if (toowide) return -1;
+  auto spmv = [&](const double* vec, double(&y)[2]) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      double y0 = 0.0, y1 = 0.0;
+#pragma unroll
+      for (int j = 0; j < PCG_W; j += 2) {
+        if (j < wid[k]) y0 += av[k][j] * vec[cv[k][j]];            // (wid is uniform over the wave: scalar branches)
+        if (j + 1 < wid[k]) y1 += av[k][j + 1] * vec[cv[k][j + 1]];
+      }
+      y[k] = y0 + y1;
+    }
+  };
+  // Gershgorin bound of the largest eigenvalue (the scaled matrix has a unit diagonal; rows of constrained vertices are
+  // identity rows)
+  double lmax = 0.0;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    double s_ = 0.0;
+#pragma unroll
+    for (int j = 0; j < PCG_W; ++j) s_ += fabs(av[k][j]);
+    lmax = fmax(lmax, row[k] < n ? s_ : 0.0);
+  }
+  for (int off = 32; off > 0; off >>= 1) lmax = fmax(lmax, __shfl_xor(lmax, off));
+  {
+    double* buf = p;                          // (the search direction is not in use yet)
+    if (lane == 0) buf[wave] = lmax;
+    __syncthreads();
+    double m_ = 0.0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) m_ = fmax(m_, buf[i]);
+    lmax = m_;
+    __syncthreads();
+  }
+  const int M = degree < 1 ? 1 : degree;
+  const double lmin = lmax / CHEB_RATIO, theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+  double y[2], xv[2], rv[2], pv[2], zv[2];
+  spmv(x, y);
+  double acc[2] = {0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    xv[k] = rv[k] = pv[k] = zv[k] = 0.0;
+    if (row[k] < n) {
+      const double b = r[row[k]];
+      xv[k] = x[row[k]];
+      rv[k] = b - y[k];
+      acc[0] += b * b;
+      acc[1] += rv[k] * rv[k];
+    }
+  }
+  block_sum<2, NW>(acc, red);
+  const double bb = acc[0], tol2 = rtol * rtol * bb;
+  double rr = acc[1];
+  int it = 0;
+  if (rr > tol2 && bb != 0.0) {
+    double rz_old = 1.0;
+    // `r` (LDS) is free from here on: the polynomial's iterates are staged there for the gathers
+    double* zs = r;
+    while (it < maxit) {
+      // z = p_M(A) r  (Chebyshev iteration for A z = r from z = 0, M - 1 further applications)
+      double dv[2];
+      double rho = 1.0 / sigma;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        dv[k] = rv[k] / theta;
+        zv[k] = dv[k];
+      }
+      for (int m_ = 1; m_ < M; ++m_) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          if (row[k] < n) zs[row[k]] = zv[k];
+        __syncthreads();
+        double az[2];
+        spmv(zs, az);
+        const double rho_n = 1.0 / (2.0 * sigma - rho);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          dv[k] = rho_n * rho * dv[k] + (2.0 * rho_n / delta) * (rv[k] - az[k]);
+          zv[k] += dv[k];
+        }
+        rho = rho_n;
+        __syncthreads();                         // (everybody has gathered from zs before the next round rewrites it)
+      }
+      double a0[1] = {rv[0] * zv[0] + rv[1] * zv[1]};
+      block_sum1<1, NW>(a0, red, rsel);
+      const double rz = a0[0];
+      const double beta = it == 0 ? 0.0 : rz / rz_old;
+      rz_old = rz;
+      ++it;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        pv[k] = zv[k] + beta * pv[k];
+        if (row[k] < n) p[row[k]] = pv[k];
+      }
+      __syncthreads();
+      double q[2];
+      spmv(p, q);
+      double a1[1] = {pv[0] * q[0] + pv[1] * q[1]};
+      block_sum1<1, NW>(a1, red, rsel);
+      if (!(a1[0] > 0.0)) break;
+      const double alpha = rz / a1[0];
+      double a2[1] = {0.0};
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        xv[k] += alpha * pv[k];
+        rv[k] -= alpha * q[k];
+        a2[0] += rv[k] * rv[k];
+      }
+      block_sum1<1, NW>(a2, red, rsel);
+      rr = a2[0];
+      if (!(rr > tol2)) break;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+    if (row[k] < n) x[row[k]] = xv[k];
+  __syncthreads();
+  return it;
+}
+
 #ifdef MDQ_AT_TRACE
 // debug build only: s_memtime deltas of thread 0 of environment 0 at the phase boundaries of at_velocity_kernel
 __device__ long long mdq_at_trace_buf[16];
@@ -2850,7 +3012,12 @@ __global__ __launch_bounds__(NTH) void at_pressure_kernel(mdq_ipcs_desc d, int32
 #endif
       pressure_direct<NTH>(pd, nv, pr, px, pp, pq, lK);
     } else {
-      if (nv <= 2 * NTH)
+      int itc = -1;
+      if (nv <= 2 * NTH && d.pcg_degree > 0)   // rows in registers, Chebyshev-preconditioned (degree 1: Jacobi only)
+        itc = cg_pressure_cheb<NTH>(nv, so1, ci1, K1, d.rtol, d.maxit_p, d.pcg_degree, px, pr, pp, red, rsel);
+      if (itc >= 0)
+        it_p += itc;
+      else if (nv <= 2 * NTH)
         it_p += cg_pressure_reg<NTH>(nv, so1, ci1, K1, d.rtol, d.maxit_p, px, pr, pp, red, rsel);
       else
         it_p += cg_pressure(nv, so1, ci1, K1, d.rtol, d.maxit_p, px, pr, pp, pq, red);

@@ -42,7 +42,7 @@ class IpcsBatch:
                  mu: float = 1e-3, rho: float = 1.0, dt: float = 1e-3, rtol: float = 1e-10,
                  maxit=(200, 4000, 200), device: str | torch.device = "cuda", capacities: dict | None = None,
                  mode: int = -1, pressure_direct: bool = True, pressure_parts: int = 16,
-                 cell_order: str = "conflictfree"):
+                 cell_order: str = "conflictfree", pcg_degree: int = 0):
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -169,6 +169,12 @@ class IpcsBatch:
                 setattr(d, name, t[name].data_ptr())
         d.work_doubles = nwork
         d.pd_enabled = 0
+        # Krylov pressure solve of mode 3: degree of the Chebyshev polynomial preconditioner (0, default: the plain Jacobi-CG
+        # kernel).  Measured on ys930 (tools/time_pcg.py): iterations 154 -> 95 / 67 / 52 / 37 / 30 for degree 2 / 3 / 4 / 6 / 8,
+        # kernel time unchanged (251-283 us against 253 us): the solve is bound by the LDS gathers of the operator
+        # application (~1.6 us each, bank conflicts of the random vertex gather), not by its reductions, and the polynomial
+        # trades the one for the other.  Kept as an option (the reference's Krylov option is CG + AMG, flow_solver.py:152-155).
+        d.pcg_degree = int(pcg_degree)
         self.desc = d
         self.assembled = False
         # True: substructuring factors built on the host (numpy, pressure_direct.py); "device": built by

@@ -55,3 +55,55 @@ def concurrent_stream(device, others=(), attempts: int = 12) -> torch.cuda.Strea
                 return cand
             rejected.append(cand)
         return cand
+
+
+# ---------------------------------------------------------------------------- process-level stream roles
+#
+# The engines of this package need three streams that run beside each other: MAIN (the env step's kernel chain; rollouts
+# move off the legacy default stream), FLOW (the IPCS leg of the S3 step) and OPT (the optimiser chain of the learning
+# loop).  They are created ONCE per process and device, in this fixed order, the first time an engine asks: the
+# stream -> hardware-queue mapping is round-robin in creation order, so every process that uses the package the same way
+# gets the same mapping (it used to depend on how many environments / trainers a process had built before).  ONE probe
+# per pair (`_overlaps`) verifies the roles; a pair that fails it is replaced through `concurrent_stream`.  The choice of
+# a flow stream by timing real env steps (`VecEnv2DAirfoil.calibrate_streams`) remains as the second line of defence - a
+# few pairs overlap only partly and pass every synthetic probe - but its verdict is kept here, so it runs once per
+# process and main stream, not once per environment object.  `LOG` records which path was taken (bench.py prints it).
+_ROLES = {}
+_CALIBRATED = {}
+LOG = []
+
+
+def role_streams(device) -> dict:
+    """dict(main=, flow=, opt=) of torch streams for `device` (created and verified on first use)."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    r = _ROLES.get(idx)
+    if r is not None:
+        return r
+    dev = torch.device("cuda", idx)
+    with torch.cuda.device(dev):
+        r = dict(main=torch.cuda.Stream(device=dev), flow=torch.cuda.Stream(device=dev), opt=torch.cuda.Stream(device=dev))
+        how = {}
+        for a, b in (("flow", "main"), ("opt", "main"), ("opt", "flow")):
+            if _overlaps(r[a], r[b], dev):
+                how[f"{a}/{b}"] = "probe ok"
+            else:                                     # same queue / shared dispatcher pipe: another stream for role a
+                with torch.cuda.stream(r["main"]):
+                    r[a] = concurrent_stream(dev, [v for k, v in r.items() if k not in (a, "main")])
+                how[f"{a}/{b}"] = "probe failed: replaced"
+    _ROLES[idx] = r
+    LOG.append(dict(device=idx, event="roles created in fixed order", probes=how))
+    return r
+
+
+def calibrated_flow_stream(device, main):
+    """The flow stream `calibrate_streams` chose for rollouts on `main` in this process (None: not calibrated yet)."""
+    for (idx, m), st in _CALIBRATED.items():
+        if idx == torch.device(device).index and m == main:
+            return st
+    return None
+
+
+def remember_flow_stream(device, main, flow, ms, how):
+    _CALIBRATED[(torch.device(device).index, main)] = flow
+    LOG.append(dict(device=torch.device(device).index, event="flow stream calibrated", how=how, ms_per_step=[round(v, 3) for v in ms]))

@@ -1220,8 +1220,8 @@ def train_loop_device(trainer: DQNTrainer, venv, num_steps: int, optim_per_step:
     if main == torch.cuda.default_stream(dev):
         # the loop does not run on the legacy default stream (see VecEnv2DAirfoil.rollout_device): a stream of its own
         if getattr(trainer, "_main_stream", None) is None:
-            from .streams import concurrent_stream
-            trainer._main_stream = concurrent_stream(dev, [getattr(venv, "_flow_stream", None)])
+            from .streams import role_streams
+            trainer._main_stream = role_streams(dev)["main"]
         trainer._main_stream.wait_stream(main)
         with torch.cuda.stream(trainer._main_stream):
             out = train_loop_device(trainer, venv, num_steps, optim_per_step=optim_per_step, eps_decay=eps_decay,
@@ -1246,8 +1246,8 @@ def train_loop_device(trainer: DQNTrainer, venv, num_steps: int, optim_per_step:
         opt_stream = venv._flow_stream
     else:
         if getattr(trainer, "_opt_stream", None) is None:
-            from .streams import concurrent_stream
-            trainer._opt_stream = concurrent_stream(dev, [getattr(venv, "_flow_stream", None)])
+            from .streams import role_streams
+            trainer._opt_stream = role_streams(dev)["opt"]
         ocal, flow_now = getattr(trainer, "_opt_calibrated_for", None), getattr(venv, "_flow_stream", None)
         if ocal is None or not (ocal[0] == main) or not ((ocal[1] is None and flow_now is None) or
                                                          (ocal[1] is not None and flow_now is not None and ocal[1] == flow_now)):

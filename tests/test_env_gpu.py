@@ -848,7 +848,9 @@ def test_stream_calibration_keeps_a_working_flow_stream_and_resets_the_envs(lib_
         fg = FusedGcn(net)
         if calibrate:
             ms = venv.calibrate_streams(fg, tries=3, steps=3)
-            assert 1 <= len(ms) <= 3 and all(m > 0 for m in ms)
+            # (an empty list: this process has already chosen a flow stream for this main stream - streams.LOG says how)
+            assert len(ms) <= 3 and all(m > 0 for m in ms)
+            assert venv.calibrate_streams(fg, tries=3, steps=3) == []      # once per process and main stream
             assert (venv.nv == venv.NV).all() and (venv.steps == 0).all() and (venv.offset == 0).all()
         rng = np.random.default_rng(3)
         outs.append(venv.rollout_device(fg, K, rng.random((K, B)) < 0.5, rng.integers(0, 181, (K, B))))
@@ -858,3 +860,8 @@ def test_stream_calibration_keeps_a_working_flow_stream_and_resets_the_envs(lib_
     assert np.allclose(a["rewards"], b["rewards"], rtol=1e-9, atol=1e-12)
     s = concurrent_stream("cuda")
     assert isinstance(s, torch.cuda.Stream) and s != torch.cuda.current_stream()
+    from meshdqn_amd import streams
+    r = streams.role_streams("cuda")
+    assert r is streams.role_streams("cuda:0") and len({id(v) for v in r.values()}) == 3 and venv._flow_stream is not None
+    assert any(e["event"].startswith("roles created") for e in streams.LOG)
+    assert any(e["event"] == "flow stream calibrated" for e in streams.LOG)
