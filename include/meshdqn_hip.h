@@ -60,7 +60,9 @@ typedef struct mdq_ipcs_desc {
   int32_t maxit_u, maxit_p, maxit_m;
   int32_t mode;         /* operator application: -1 auto, 0 assembled SELL (global gather vectors),
                            1 assembled SELL (LDS gather vectors), 2 matrix-free LDS element tiles (bitwise
-                           reproducible), 3 matrix-free with LDS fp64 atomics (fastest; round-off reproducible) */
+                           reproducible), 3 matrix-free with LDS fp64 atomics (fastest; round-off reproducible),
+                           4 assembled SELL with TWO workgroups per environment (any mesh size, rows / cells / slices
+                           dealt out over the team, agent-scope team barriers; auto picks it over 0 when 4 B <= CUs) */
   /* per-environment counts, device int32[B] */
   const int32_t* nv;
   const int32_t* nt;

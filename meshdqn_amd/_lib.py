@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmeshdqn_hip.so")
+# (MDQ_LIB_PATH: a differently built copy of the library, e.g. an experiment of tools/: development knob)
+LIB_PATH = os.environ.get("MDQ_LIB_PATH") or os.path.join(HERE, "libmeshdqn_hip.so")
 
 ABI_VERSION = 4
 

@@ -25,6 +25,8 @@ def _hipcc() -> str:
 
 
 def _stale() -> bool:
+    if os.environ.get("MDQ_LIB_PATH"):      # an explicitly chosen library: nothing to build
+        return False
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)

@@ -896,7 +896,10 @@ __device__ __forceinline__ void spmv_sell_b2(const int32_t* __restrict__ sl_off,
     const double4* a = A4 + base + lane;
     const int32_t* c = sl_col + base + lane;
     double y0 = 0.0, y1 = 0.0;
-#pragma unroll 4
+#ifndef MDQ_SPMV_UNROLL
+#define MDQ_SPMV_UNROLL 4
+#endif
+#pragma unroll MDQ_SPMV_UNROLL
     for (int j = 0; j < w; ++j) {
       const double4 av = a[j * 64];
       const double2 xv = x[c[j * 64]];
@@ -1940,6 +1943,476 @@ static hipError_t launch_evolve(const mdq_ipcs_desc* d, size_t lds, int nsteps, 
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((evolve_kernel<MODE, K1_LDS>), dim3(d->B), dim3(WG), lds, stream, *d, nsteps, drag, lift,
+                     iters);
+  return hipGetLastError();
+}
+
+// ================================================================== assembled operators, TWO workgroups per environment
+//
+// evolve_kernel<0> gives one workgroup - one CU - to an environment: with the BASELINE batch of 128 environments half of
+// the chip idles, and on meshes whose operators no longer fit a CU's caches (BASELINE configs[4]: ys930 red-refined,
+// 6 MB of velocity blocks per environment) the step is bound by what ONE CU pulls from L2 / HBM (~22 GB/s).  Here a TEAM
+// of two workgroups shares an environment: element loops, row loops and SELL slices are dealt out alternately
+// (global thread id = rank * WG + tid, stride 2 WG), all vectors live in the environment's workspace slab, and every
+// barrier that separates a producer phase from a consumer phase is a TEAM barrier: agent-scope release by every wave,
+// workgroup barrier, one arrival counter per team polled by one lane (bounded spin), workgroup barrier, agent-scope
+// acquire - correct for any placement of the two workgroups (cdna_hip_programming.md, Guideline 16).  Reductions: each
+// workgroup's deterministic block sum goes to the team's slot array and both workgroups add the two partials in rank
+// order: every thread of the team sees the same bits.  The pressure solve (3 322 unknowns, LDS-resident vectors, direct
+// factors or CG) stays with rank 0.  Same arithmetic as evolve_kernel<0> except for the association of the reductions.
+constexpr int TEAM = 2;
+struct Team {
+  int rank;
+  unsigned* ctr;     // [0] arrivals of the team, [1] set when a bounded spin ran out (the step's forces become NaN)
+  double* slot;      // [2 parities][TEAM][4] partial sums
+  unsigned epoch;
+  int par;
+};
+__device__ __forceinline__ void team_sync(Team& t) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // every wave: its stores are visible device-wide
+  __syncthreads();
+  ++t.epoch;
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(t.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned target = t.epoch * TEAM;
+    if (!__hip_atomic_load(t.ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+      unsigned spins = 0;
+      while (__hip_atomic_load(t.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1u << 22)) {                        // the partner never arrived (not resident?): give up, loudly
+          __hip_atomic_store(t.ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // every wave: no stale lines of the partner's data in this CU's L1
+}
+template <int N>
+__device__ __forceinline__ void team_sum(double (&v)[N], double* red, Team& t) {
+  static_assert(N <= 4, "slot capacity");
+  block_sum<N>(v, red);
+  double* mine = t.slot + (t.par * TEAM + t.rank) * 4;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int n = 0; n < N; ++n) mine[n] = v[n];
+  }
+  team_sync(t);
+  const double* s0 = t.slot + (t.par * TEAM) * 4;
+#pragma unroll
+  for (int n = 0; n < N; ++n) v[n] = s0[n] + s0[4 + n];
+  t.par ^= 1;
+}
+
+__global__ void team_reset_kernel(mdq_ipcs_desc d) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= d.B) return;
+  double* w = d.work + (int64_t)b * work_per_env(d.NV, d.NT, d.NE);
+  double* spare = w + 12 * (int64_t)d.NT + 12 * (int64_t)d.N2 + d.NV;
+  unsigned* ctr = reinterpret_cast<unsigned*>(spare + 8);
+  ctr[0] = ctr[1] = 0u;
+}
+
+template <bool K1_LDS>
+__global__ __launch_bounds__(WG) void evolve_team_kernel(mdq_ipcs_desc d, int nsteps, double* drag, double* lift,
+                                                          int32_t* iters) {
+  extern __shared__ __align__(16) double smem[];
+  // teams on neighbouring-by-8 block ids: with the dispatcher's round-robin both workgroups tend to share an XCD's L2
+  // (a speed choice only: the protocol is placement-independent)
+  const int q = blockIdx.x / (8 * TEAM), r8 = blockIdx.x % (8 * TEAM);
+  const int b = q * 8 + (r8 & 7), rank = r8 >> 3;
+  if (b >= d.B) return;
+  const int tid = threadIdx.x, gt = rank * WG + tid;
+  constexpr int GS = TEAM * WG;
+  const EnvView v = env_view(d, b);
+  const int n2 = v.n2, nv = v.nv;
+  const LdsPlan P = lds_plan(d.N2, d.NV, d.NSE1);
+  double* red = smem;
+  double* U = smem + 64;
+  double* px = U;
+  double* pr = px + P.NVp;
+  double* pp = pr + P.NVp;
+  double* pq = pp + P.NVp;
+  double* lK = pq + P.NVp;
+  int32_t* lci = reinterpret_cast<int32_t*>(lK + d.NSE1);
+  int32_t* lso = lci + d.NSE1 + (d.NSE1 & 1);
+  double* w = v.work;
+  double2* escr2 = reinterpret_cast<double2*>(w);
+  double* escr1 = w;
+  double2* xs = reinterpret_cast<double2*>(w + 12 * (int64_t)d.NT);
+  double2* vr = xs + d.N2;
+  double2* vh = vr + d.N2;
+  double2* vp = vh + d.N2;
+  double2* vv = vp + d.N2;
+  double2* vt = vv + d.N2;
+  double2* h1 = reinterpret_cast<double2*>(w + work_hist_offset(d.NV, d.NT, d.NE));
+  double2* h2 = h1 + d.N2;
+  double2* h3 = h2 + d.N2;
+  double2* h4 = h3 + d.N2;
+  double2* h5 = h4 + d.N2;
+  double* hcnt = reinterpret_cast<double*>(h5 + d.N2);
+  double* pnew = reinterpret_cast<double*>(vt + d.N2);
+  double* spare = pnew + d.NV;
+  Team T;
+  T.rank = rank;
+  T.ctr = reinterpret_cast<unsigned*>(spare + 8);
+  T.slot = spare + 9;
+  T.epoch = 0;
+  T.par = 0;
+  const int nsl1 = (nv + 63) >> 6;
+  const int32_t* so1 = K1_LDS ? lso : v.sl1_off;
+  const int32_t* ci1 = K1_LDS ? lci : v.sl1_col;
+  const double* K1 = K1_LDS ? lK : v.K1s;
+  const double a = d.rho / d.dt;
+  int it_u = 0, it_p = 0, it_m = 0;
+  const int lane = tid & 63, gw = rank * NWAVE + (tid >> 6);
+  constexpr int GW = TEAM * NWAVE;
+  // SELL operator applications over the team's slices
+  auto spmv_vel = [&](const double2* x, auto epi) {
+    const int nsl = (n2 + 63) >> 6;
+    const double4* A4 = reinterpret_cast<const double4*>(v.A1);
+    for (int s = gw; s < nsl; s += GW) {
+      const int base = v.sl2_off[s], wd = (v.sl2_off[s + 1] - base) >> 6;
+      const double4* aa = A4 + base + lane;
+      const int32_t* c = v.sl2_col + base + lane;
+      double y0 = 0.0, y1 = 0.0;
+#pragma unroll 4
+      for (int j = 0; j < wd; ++j) {
+        const double4 av = aa[j * 64];
+        const double2 xv = x[c[j * 64]];
+        y0 += av.x * xv.x + av.y * xv.y;
+        y1 += av.z * xv.x + av.w * xv.y;
+      }
+      const int row = (s << 6) + lane;
+      if (row < n2) epi(row, y0, y1);
+    }
+  };
+  auto spmv_mass = [&](const double2* x, auto epi) {
+    const int nsl = (n2 + 63) >> 6;
+    for (int s = gw; s < nsl; s += GW) {
+      const int base = v.sl2_off[s], wd = (v.sl2_off[s + 1] - base) >> 6;
+      const double* aa = v.Ms + base + lane;
+      const int32_t* c = v.sl2_col + base + lane;
+      double y0 = 0.0, y1 = 0.0;
+#pragma unroll 4
+      for (int j = 0; j < wd; ++j) {
+        const double av = aa[j * 64];
+        const double2 xv = x[c[j * 64]];
+        y0 += av * xv.x;
+        y1 += av * xv.y;
+      }
+      const int row = (s << 6) + lane;
+      if (row < n2) epi(row, y0, y1);
+    }
+  };
+  team_sync(T);
+  for (int step = 0; step < nsteps; ++step) {
+    // ---------------- step 1: tentative velocity
+    for (int e = gt; e < v.nt; e += GS) {
+      const ElemIdx E = load_dofs(v, e);
+      const Geo g = load_geo(v, e);
+      double2 ue[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) ue[i] = v.u_n[E.dof[i]];
+      double pe[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) pe[i] = v.p_n[E.dof[i]];
+      double2 rr_[6];
+      elem_rhs1_vol(g, a, d.mu, d.rho, ue, pe, rr_);
+      const int ko = v.cell_outflow[e];
+      if (ko >= 0) {
+        double X[3][2];
+        load_cell_coords(v, e, X);
+        elem_outflow_add(g, X, ko, 0.5 * d.mu, ue, rr_);
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) escr2[e * 6 + i] = rr_[i];
+    }
+    team_sync(T);
+    double acc[2] = {0.0, 0.0};
+    const int nhist = (int)hcnt[0];
+    for (int i = gt; i < n2; i += GS) {
+      double2 f = make_double2(0.0, 0.0);
+      for (int s_ = v.g2_ptr[i]; s_ < v.g2_ptr[i + 1]; ++s_) {
+        const double2 c = escr2[v.g2_src[s_]];
+        f.x += c.x;
+        f.y += c.y;
+      }
+      const double2 l = v.lift1[i], id = v.idiag1[i];
+      const bool fl = v.bcu_flag[i] != 0;
+      const double2 g = make_double2(v.bcu_gx[i], 0.0);
+      const double2 bi = fl ? g : make_double2((f.x - l.x) * id.x, (f.y - l.y) * id.y);
+      double2 x0 = v.u_n[i];
+      if (nhist >= 2) {
+        const double2 us1 = h1[i], us2 = h2[i];
+        x0 = make_double2(2.0 * us1.x - us2.x, 2.0 * us1.y - us2.y);
+        if (nhist >= 3) {
+          const double2 us3 = h3[i];
+          x0 = make_double2(3.0 * (us1.x - us2.x) + us3.x, 3.0 * (us1.y - us2.y) + us3.y);
+          if (nhist >= 4) {
+            const double2 us4 = h4[i];
+            x0 = make_double2(4.0 * (us1.x + us3.x) - 6.0 * us2.x - us4.x, 4.0 * (us1.y + us3.y) - 6.0 * us2.y - us4.y);
+            if (nhist >= 5) {
+              const double2 us5 = h5[i];
+              x0 = make_double2(5.0 * (us1.x - us4.x) - 10.0 * (us2.x - us3.x) + us5.x,
+                                5.0 * (us1.y - us4.y) - 10.0 * (us2.y - us3.y) + us5.y);
+            }
+          }
+        }
+      }
+      if (fl) x0 = g;
+      xs[i] = x0;
+      vr[i] = bi;
+      acc[0] += bi.x * bi.x + bi.y * bi.y;
+    }
+    team_sync(T);
+    spmv_vel(xs, [&](int row, double y0, double y1) {
+      const double2 bi = vr[row];
+      const double2 r0 = make_double2(bi.x - y0, bi.y - y1);
+      vr[row] = r0;
+      vh[row] = r0;
+      vp[row] = make_double2(0.0, 0.0);
+      vv[row] = make_double2(0.0, 0.0);
+      acc[1] += r0.x * r0.x + r0.y * r0.y;
+    });
+    team_sum<2>(acc, red, T);
+    {  // BiCGStab (bicgstab_velocity<0>, rows and slices over the team)
+      const double bb = acc[0], tol2 = d.rtol * d.rtol * bb;
+      double rr = acc[1];
+      if (rr > tol2 && bb != 0.0) {
+        double rho = rr, rho_old = 1.0, alpha = 1.0, omega = 1.0;
+        int it = 0;
+        while (it < d.maxit_u) {
+          ++it;
+          const double beta = (rho / rho_old) * (alpha / omega);
+          for (int i = gt; i < n2; i += GS) {
+            const double2 ri = vr[i], pi = vp[i], vi = vv[i];
+            vp[i] = make_double2(ri.x + beta * (pi.x - omega * vi.x), ri.y + beta * (pi.y - omega * vi.y));
+          }
+          team_sync(T);
+          double a1[1] = {0.0};
+          spmv_vel(vp, [&](int row, double y0, double y1) {
+            vv[row] = make_double2(y0, y1);
+            const double2 h = vh[row];
+            a1[0] += h.x * y0 + h.y * y1;
+          });
+          team_sum<1>(a1, red, T);
+          if (a1[0] == 0.0) break;
+          alpha = rho / a1[0];
+          double a2[1] = {0.0};
+          for (int i = gt; i < n2; i += GS) {
+            const double2 ri = vr[i], vi = vv[i];
+            const double2 sv = make_double2(ri.x - alpha * vi.x, ri.y - alpha * vi.y);
+            vr[i] = sv;
+            a2[0] += sv.x * sv.x + sv.y * sv.y;
+          }
+          team_sum<1>(a2, red, T);       // (its team barrier also publishes s)
+          if (!(a2[0] > tol2)) {
+            for (int i = gt; i < n2; i += GS) {
+              const double2 xi = xs[i], pi = vp[i];
+              xs[i] = make_double2(xi.x + alpha * pi.x, xi.y + alpha * pi.y);
+            }
+            break;
+          }
+          double a3[2] = {0.0, 0.0};
+          spmv_vel(vr, [&](int row, double y0, double y1) {
+            vt[row] = make_double2(y0, y1);
+            const double2 sv = vr[row];
+            a3[0] += y0 * sv.x + y1 * sv.y;
+            a3[1] += y0 * y0 + y1 * y1;
+          });
+          team_sum<2>(a3, red, T);
+          if (a3[1] == 0.0) break;
+          omega = a3[0] / a3[1];
+          double a4[2] = {0.0, 0.0};
+          for (int i = gt; i < n2; i += GS) {
+            const double2 ti = vt[i], xi = xs[i], pi = vp[i], si = vr[i], hi = vh[i];
+            xs[i] = make_double2(xi.x + alpha * pi.x + omega * si.x, xi.y + alpha * pi.y + omega * si.y);
+            const double2 rn = make_double2(si.x - omega * ti.x, si.y - omega * ti.y);
+            vr[i] = rn;
+            a4[0] += rn.x * rn.x + rn.y * rn.y;
+            a4[1] += hi.x * rn.x + hi.y * rn.y;
+          }
+          team_sum<2>(a4, red, T);
+          rr = a4[0];
+          if (!(rr > tol2)) break;
+          rho_old = rho;
+          rho = a4[1];
+          if (rho == 0.0 || omega == 0.0) break;
+        }
+        it_u += it;
+      }
+    }
+    team_sync(T);
+    for (int i = gt; i < n2; i += GS) {  // history, newest first
+      if (nhist >= 4) h5[i] = h4[i];
+      if (nhist >= 3) h4[i] = h3[i];
+      if (nhist >= 2) h3[i] = h2[i];
+      if (nhist >= 1) h2[i] = h1[i];
+      h1[i] = xs[i];
+    }
+    // ---------------- step 2: pressure (element loop by the team, the solve by rank 0)
+    {
+      const double idt = 1.0 / d.dt;
+      for (int e = gt; e < v.nt; e += GS) {
+        const ElemIdx E = load_dofs(v, e);
+        const Geo g = load_geo(v, e);
+        double2 ue[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) ue[i] = xs[E.dof[i]];
+        double pe[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pe[i] = v.p_n[E.dof[i]];
+        double r3[3];
+        elem_rhs2(g, idt, ue, pe, r3);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) escr1[e * 3 + j] = r3[j];
+      }
+    }
+    team_sync(T);
+    if (rank == 0) {
+      if (tid == 0) hcnt[0] = (double)(nhist < 5 ? nhist + 1 : 5);
+      if (K1_LDS && !d.pd_enabled) {
+        const int ne1 = v.sl1_off[nsl1];
+        for (int k = tid; k < ne1; k += WG) {
+          lK[k] = v.K1s[k];
+          lci[k] = v.sl1_col[k];
+        }
+        for (int k = tid; k <= nsl1; k += WG) lso[k] = v.sl1_off[k];
+      }
+      for (int i = tid; i < nv; i += WG) {
+        double bsum = 0.0;
+        for (int s_ = v.g1_ptr[i]; s_ < v.g1_ptr[i + 1]; ++s_) bsum += escr1[v.g1_src[s_]];
+        const double sd = v.sdiagK[i];
+        pr[i] = v.bcp_flag[i] ? 0.0 : bsum / sd;
+        px[i] = v.p_n[i] * sd;
+      }
+      if (d.pd_enabled && d.pd_hdr[4 * (int64_t)b + 2] > 0) {
+        const PdView pd = pd_view(d, b);
+        pressure_direct(pd, nv, pr, px, pp, pq, lK);
+      } else {
+        it_p += cg_pressure(nv, so1, ci1, K1, d.rtol, d.maxit_p, px, pr, pp, pq, red);
+      }
+      for (int i = tid; i < nv; i += WG) pnew[i] = px[i] / v.sdiagK[i];
+    }
+    team_sync(T);
+    // ---------------- step 3: velocity correction
+    for (int e = gt; e < v.nt; e += GS) {
+      const ElemIdx E = load_dofs(v, e);
+      const Geo g = load_geo(v, e);
+      double2 ue[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) ue[i] = xs[E.dof[i]];
+      double dp[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) dp[i] = pnew[E.dof[i]] - v.p_n[E.dof[i]];
+      double2 rr_[6];
+      elem_rhs3(g, d.dt, ue, dp, rr_);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) escr2[e * 6 + i] = rr_[i];
+    }
+    team_sync(T);
+    double am[2] = {0.0, 0.0};
+    for (int i = gt; i < n2; i += GS) {
+      double2 f = make_double2(0.0, 0.0);
+      for (int s_ = v.g2_ptr[i]; s_ < v.g2_ptr[i + 1]; ++s_) {
+        const double2 c = escr2[v.g2_src[s_]];
+        f.x += c.x;
+        f.y += c.y;
+      }
+      const double2 l = v.lift3[i];
+      const double sd = v.sdiagM[i];
+      const bool fl = v.bcu_flag[i] != 0;
+      const double2 g = make_double2(v.bcu_gx[i], 0.0);
+      const double2 bi = fl ? g : make_double2((f.x - l.x) / sd, (f.y - l.y) / sd);
+      const double2 x0 = fl ? g : xs[i];
+      xs[i] = make_double2(x0.x * sd, x0.y * sd);
+      vr[i] = bi;
+      am[0] += bi.x * bi.x + bi.y * bi.y;
+    }
+    team_sync(T);
+    spmv_mass(xs, [&](int row, double y0, double y1) {
+      const double2 bi = vr[row];
+      const double2 r0 = make_double2(bi.x - y0, bi.y - y1);
+      vr[row] = r0;
+      vp[row] = r0;
+      am[1] += r0.x * r0.x + r0.y * r0.y;
+    });
+    team_sum<2>(am, red, T);
+    {  // CG on the mass system (cg_mass<0>)
+      const double bb = am[0], tol2 = d.rtol * d.rtol * bb;
+      double rr = am[1];
+      if (rr > tol2 && bb != 0.0) {
+        int it = 0;
+        while (it < d.maxit_m) {
+          ++it;
+          double a1[1] = {0.0};
+          spmv_mass(vp, [&](int row, double y0, double y1) {
+            vv[row] = make_double2(y0, y1);
+            const double2 pi = vp[row];
+            a1[0] += pi.x * y0 + pi.y * y1;
+          });
+          team_sum<1>(a1, red, T);
+          if (!(a1[0] > 0.0)) break;
+          const double alpha = rr / a1[0];
+          double a2[1] = {0.0};
+          for (int i = gt; i < n2; i += GS) {
+            const double2 xi = xs[i], pi = vp[i], ri = vr[i], qi = vv[i];
+            xs[i] = make_double2(xi.x + alpha * pi.x, xi.y + alpha * pi.y);
+            const double2 rn = make_double2(ri.x - alpha * qi.x, ri.y - alpha * qi.y);
+            vr[i] = rn;
+            a2[0] += rn.x * rn.x + rn.y * rn.y;
+          }
+          team_sum<1>(a2, red, T);
+          const double rr_new = a2[0];
+          if (!(rr_new > tol2)) break;
+          const double beta = rr_new / rr;
+          rr = rr_new;
+          for (int i = gt; i < n2; i += GS) {
+            const double2 ri = vr[i], pi = vp[i];
+            vp[i] = make_double2(ri.x + beta * pi.x, ri.y + beta * pi.y);
+          }
+          team_sync(T);
+        }
+        it_m += it;
+      }
+    }
+    team_sync(T);
+    // ---------------- update state + probes
+    for (int i = gt; i < n2; i += GS) {
+      const double sd = v.sdiagM[i];
+      const double2 x = xs[i];
+      v.u_n[i] = make_double2(x.x / sd, x.y / sd);
+    }
+    for (int i = gt; i < nv; i += GS) v.p_n[i] = pnew[i];
+    team_sync(T);
+    if (rank == 0) {
+      double dr, li;
+      forces(v, d.mu, v.u_n, v.p_n, red, dr, li);
+      if (tid == 0) {
+        const bool failed = __hip_atomic_load(T.ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        drag[(int64_t)b * nsteps + step] = failed ? __builtin_nan("") : dr;
+        lift[(int64_t)b * nsteps + step] = failed ? __builtin_nan("") : li;
+      }
+    }
+  }
+  if (rank == 0 && tid == 0 && iters) {
+    iters[3 * b + 0] += it_u;
+    iters[3 * b + 1] += it_p;
+    iters[3 * b + 2] += it_m;
+  }
+}
+
+template <bool K1_LDS>
+static hipError_t launch_evolve_team(const mdq_ipcs_desc* d, size_t lds, int nsteps, double* drag, double* lift,
+                                     int32_t* iters, hipStream_t stream) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&evolve_team_kernel<K1_LDS>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(team_reset_kernel, dim3((d->B + 63) / 64), dim3(64), 0, stream, *d);
+  const int teams8 = (d->B + 7) / 8;                       // blocks: groups of 8 environments x TEAM ranks
+  hipLaunchKernelGGL((evolve_team_kernel<K1_LDS>), dim3(teams8 * 8 * TEAM), dim3(WG), lds, stream, *d, nsteps, drag, lift,
                      iters);
   return hipGetLastError();
 }
@@ -3469,11 +3942,25 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
   if (red_bytes + P.prs_vec_bytes > LDS_MAX) return fail_msg("mesh too large for the LDS-resident pressure vectors");
   const bool k1_lds = !d->pd_enabled && red_bytes + P.prs_vec_bytes + P.prs_mat_bytes <= LDS_MAX;
   int mode = d->mode;
-  if (mode < 0 || mode > 3) {  // auto: fastest variant that fits
+  if (mode < 0 || mode > 4) {  // auto: fastest variant that fits
     mode = 0;
     if (red_bytes + P.vel1_bytes <= LDS_MAX) mode = 1;
     if (red_bytes + P.vel2_bytes <= LDS_MAX && d->N2 <= MF_ROWS * WG) mode = 2;
     if (red_bytes + P.vel3_bytes <= LDS_MAX && d->N2 <= MF_ROWS * WG) mode = 3;
+    if (mode == 0) {
+      // a mesh that only fits the assembled global-memory path: two workgroups per environment while the batch leaves
+      // at least half of the chip idle even so (measured on ys930 red-refined, ms per step one / two workgroups: B = 1
+      // 13.7 / 8.0, 32: 16.7 / 11.9, 64: 24.5 / 22.0, 96: 26.0 / 29.3, 128: 20.0 / 26.1 - from ~64 environments on the
+      // step is bound by the memory system as a whole, and the team barriers' cache write-backs / invalidations only add)
+      static const int ncu = [] {
+        int dev_ = 0, n_ = 0;
+        if (hipGetDevice(&dev_) != hipSuccess ||
+            hipDeviceGetAttribute(&n_, hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess)
+          return 0;
+        return n_;
+      }();
+      if (2 * TEAM * d->B <= ncu) mode = 4;
+    }
   }
   if (kernel_ms && mode != 3) return fail_msg("per-kernel timing exists for the three-kernel mode 3 only");
   if (mode == 3 && (red_bytes + P.vel3_bytes > LDS_MAX || d->N2 > MF_ROWS * WG))
@@ -3560,6 +4047,9 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
   else if (mode == 1)
     e = k1_lds ? launch_evolve<1, true>(d, lds, nsteps, drag, lift, iters, st)
                : launch_evolve<1, false>(d, lds, nsteps, drag, lift, iters, st);
+  else if (mode == 4)
+    e = k1_lds ? launch_evolve_team<true>(d, lds, nsteps, drag, lift, iters, st)
+               : launch_evolve_team<false>(d, lds, nsteps, drag, lift, iters, st);
   else
     e = k1_lds ? launch_evolve<0, true>(d, lds, nsteps, drag, lift, iters, st)
                : launch_evolve<0, false>(d, lds, nsteps, drag, lift, iters, st);

@@ -263,6 +263,44 @@ def test_la_solve_key_selects_direct_or_krylov_solvers(lib_built):
         FlowSolver(flow_params=fp, geometry_params=gp, solver_params={"dt": 0.001, "smooth": False, "la_solve": "amg"})
 
 
+def test_two_workgroups_per_environment_match_one(meshes, lib_built):
+    """mode 4 (evolve_team_kernel: the assembled SELL path with TWO workgroups per environment - rows, cells and slices
+    dealt out over the team, agent-scope team barriers, reductions through the team's slots) against mode 0 (one
+    workgroup) on ys930 red-refined (BASELINE configs[4]'s mesh: 6 280 triangles, does not fit the LDS-resident modes):
+    same forces to round-off (only the association of the reductions differs), same iteration counts, every environment
+    of the batch bitwise equal; and against the oracle's golden first steps on ys930."""
+    import torch
+    from meshdqn_amd.ipcs_batch import IpcsBatch, smooth_coords
+    from meshdqn_amd.mesh_ops import red_refine
+    from meshdqn_amd.topology import MeshTopology
+    coords, cells = meshes["ys930"]
+    t0 = MeshTopology(coords, cells)
+    x0 = smooth_coords(t0, 50)
+    flow = json.load(open(os.path.join(GOLDEN, "oracle_flow.json")))["ys930"]["steps"]
+    b = IpcsBatch([t0] * 3, [x0] * 3, rtol=1e-12, mode=4)
+    for s_ in (1, 2, 3):
+        d, l = b.evolve(1)
+        g = flow[str(s_)]
+        assert abs(d[1, 0].item() - g["drag"]) < 1e-8 * abs(g["drag"]) and abs(l[2, 0].item() - g["lift"]) < 1e-8 * abs(g["lift"])
+    rc, rcells = red_refine(x0, cells)
+    rt = MeshTopology(rc, rcells)
+    out = {}
+    for mode in (0, 4):
+        bb = IpcsBatch([rt] * 5, [rc] * 5, rtol=1e-10, mode=mode)
+        d, l = bb.evolve(6)
+        torch.cuda.synchronize()
+        out[mode] = (d.cpu().numpy(), l.cpu().numpy(), bb.u_n.cpu().numpy(), bb.iters.cpu().numpy())
+    assert np.isfinite(out[4][0]).all() and (out[4][0] == out[4][0][0]).all()
+    assert np.abs(out[4][0] - out[0][0]).max() < 1e-11 * np.abs(out[0][0]).max()
+    assert np.abs(out[4][1] - out[0][1]).max() < 1e-11 * np.abs(out[0][1]).max()
+    assert np.abs(out[4][2] - out[0][2]).max() < 1e-8 * np.abs(out[0][2]).max()
+    assert np.array_equal(out[4][3], out[0][3])
+    # auto mode: a small batch of a mesh that only fits the assembled path takes the team kernel (same bits as mode 4)
+    ba = IpcsBatch([rt] * 5, [rc] * 5, rtol=1e-10)
+    d, _ = ba.evolve(6)
+    assert np.array_equal(d.cpu().numpy(), out[4][0])
+
+
 def test_polynomial_preconditioned_pressure_cg_matches_oracle(meshes, lib_built):
     """The Krylov pressure solve of the three-kernel mode with the Chebyshev polynomial preconditioner (degree 4 and 8 on
     top of the Jacobi scaling; the reference's Krylov option is CG + an AMG preconditioner, flow_solver.py:152-155): same

@@ -14,7 +14,7 @@ topo = MeshTopology(rc, rcells)
 print("refined mesh", topo.nv, topo.nt, topo.ne, flush=True)
 for direct in ((True,) if PMC else (True, False)):
     t = time.time()
-    batch = IpcsBatch([topo] * B, [rc] * B, rtol=1e-10, pressure_direct=direct)
+    batch = IpcsBatch([topo] * B, [rc] * B, rtol=1e-10, pressure_direct=direct, mode=int(os.environ.get("MDQ_MODE", "-1")))
     batch.assemble(); torch.cuda.synchronize()
     print("setup s", round(time.time() - t, 1), "mode", batch.desc.mode, flush=True)
     out = (torch.empty((B, 1), dtype=torch.float64, device="cuda"), torch.empty((B, 1), dtype=torch.float64, device="cuda"))
