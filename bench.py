@@ -296,8 +296,6 @@ def measure_env_steps(args, dev, dist, world, flow_steps=0, steps=None, warmup=8
     if keep is not None and not args.host_step:     # HIP events around every smoothing launch of the timed rollouts
         for e in groups.envs:
             e.smooth_events = []
-        from meshdqn_amd import _lib as _L           # ... and the kernel's own count of abandoned speculative sweeps
-        _L.load().mdq_smooth_stats(None, 1)
     times = [_timed(dist, dev, lambda: run(steps)) for _ in range(repeats)]
     el = float(np.median(times))
     venv = groups.envs[0]
@@ -318,12 +316,15 @@ def measure_env_steps(args, dev, dist, world, flow_steps=0, steps=None, warmup=8
             ms = np.array([a.elapsed_time(b_) for a, b_ in ev])
             out["smooth_kernel_in_rollout_ms"] = dict(mean=float(ms.mean()), min=float(ms.min()), max=float(ms.max()),
                                                       launches=int(ms.size))
-            from meshdqn_amd import _lib as _L
-            st = np.zeros(64, np.int64)
-            _L.load().mdq_smooth_stats(st.ctypes.data, 0)
-            out["smooth_kernel_in_rollout_ms"]["abandoned_speculative_sweeps"] = dict(
-                total=int(st[:63].sum()), mesh_launches=int(ms.size) * B,
-                by_sweep={str(i): int(c) for i, c in enumerate(st[:63]) if c})
+            try:        # the kernel's own diagnostics of the LAST launch of the timed rollouts (per environment)
+                from meshdqn_amd.mesh_ops import smooth_fast_stats
+                st = smooth_fast_stats(dev, groups.envs[0].B, groups.envs[0].NV, groups.streams[0])
+                out["smooth_kernel_in_rollout_ms"]["last_launch_diagnostics"] = dict(
+                    environments=int(st.shape[0]), handed_back_to_the_walk=int((st[:, 0] > 0).sum()),
+                    sweeps_with_repair_rounds=int(st[:, 1].sum()), repair_rounds=int(st[:, 2].sum()),
+                    pipelined_sweeps_redone=int((st[:, 3] & 0xFFFF).sum()), sweeps_in_plain_order=int((st[:, 3] >> 16).sum()))
+            except Exception as exc:  # noqa: BLE001
+                out["smooth_kernel_in_rollout_ms"]["last_launch_diagnostics"] = repr(exc)
         for e in groups.envs:
             e.smooth_events = None
     return out
@@ -350,8 +351,10 @@ def measure_smooth_kernel(dev, groups, reps=20):
         torch.cuda.synchronize()
         ms.append(e0.elapsed_time(e1))
     nbytes = float((nv.astype(np.float64) * 32 + nt.astype(np.float64) * 12).sum())
+    nblk = (np.maximum(nv - 182, 1) + 31) // 32          # (interior vertices of a ys930-family mesh: all but 182 boundary ones)
     return dict(launch_ms=float(np.mean(ms)), launch_ms_min=float(np.min(ms)), launches=reps, meshes=int(len(nv)),
-                algorithmic_bytes_per_launch=nbytes)
+                algorithmic_bytes_per_launch=nbytes,
+                workspace_bytes_per_launch=float((nblk * 8192.0 * (1 + 50)).sum()))   # block inverses: written once, read per sweep
 
 
 def measure_s2_full_chip(args, dev, topo, x, envs=256):
@@ -896,23 +899,28 @@ def main(argv=None):
                 "reference_published": "45.8 IPCS steps/s for 1 env (FEniCS, unknown hardware; BASELINE.md) - context only",
             },
             "roofline": {"bound": "hbm", "achieved": sm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sm_gbs / HBM_PEAK_GBS,
-                         "traffic": prof("r02_smooth_pmc_summary.json", "hbm_bytes_per_launch"),
-                         "kernel": "smooth_kernel (DOLFIN smooth(50): list-scheduled Gauss-Seidel, one wave per mesh out of LDS)",
+                         "traffic": ((prof("r03_pmc_summary.json", "hbm_bytes_per_launch") or {}).get("s3") or {}).get(
+                             "mdq_smooth_lin::smooth_linear_kernel", {}).get("corrected"),
+                         "kernel": "smooth_linear_kernel (DOLFIN smooth(50) as blocked triangular solves: 32-row block inverses built "
+                                   "per launch, 22 dependent block steps per sweep, validation in parallel, limited steps repaired)",
                          "launch_ms": sm_ms, "launches_timed": insitu["launches"] if insitu else smk["launches"],
                          "launch_ms_min_max": [insitu["min"], insitu["max"]] if insitu else None,
                          "launch_ms_alone": smk["launch_ms"],
-                         "abandoned_speculative_sweeps": insitu.get("abandoned_speculative_sweeps") if insitu else None,
-                         "traffic_source": "profiles/r02_smooth_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                         "last_launch_diagnostics": insitu.get("last_launch_diagnostics") if insitu else None,
+                         "traffic_source": "profiles/r03_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                            "command, gfx950 wide-read correction; counters cannot be read inside the run)",
+                         "workspace_bytes_per_launch": smk.get("workspace_bytes_per_launch"),
                          "algorithmic_bytes_per_launch": smk["algorithmic_bytes_per_launch"],
                          "share_of_step": sm_ms / s3["ms_per_batched_step"],
                          "device_copy_GBs_same_run": copy_gbs,
-                         "note": "LATENCY-bound, not HBM-bound: ~6 000 dependent passes per launch (the mesh numbering makes a "
-                                 "sweep a chain of 113 levels, list-scheduled into ~119 passes), ~170 ns each; the mesh (47 KB) "
-                                 "lives in LDS. launch_ms = HIP events around the launches of the timed rollouts (the IPCS "
-                                 "kernels of the previous env step run beside them); launch_ms_alone = the same meshes with "
-                                 "nothing else on the chip. The HBM fraction is reported because the contract asks for it; "
-                                 "it is not the resource that binds",
+                         "note": "ISSUE / LATENCY-bound, not HBM-bound: 50 sweeps x 22 dependent block steps per launch, each ~75 "
+                                 "instructions of ONE wave per component (a lone wave issues one VALU instruction per ~4.5 cycles) "
+                                 "+ two LDS round trips, ~630 cycles; the mesh (47 KB) lives in LDS, the block inverses (176 KB "
+                                 "per mesh, written once per launch) stream from L2 (workspace_bytes_per_launch: mostly L2 hits, "
+                                 "see traffic). launch_ms = HIP events around the smoothing launches of the timed rollouts (the "
+                                 "IPCS kernels of the previous env step run beside them); launch_ms_alone = the same meshes with "
+                                 "nothing else on the chip. algorithmic bytes = coordinates in / out + cells; the HBM fraction is "
+                                 "reported because the contract asks for it; it is not the resource that binds",
                          "traffic_measured_in_run": False,
                          "step_survey_convention_equivalent": {
                              "note": "NOT a roofline fraction: the bytes an assembled-CSR implementation would stream per batched "

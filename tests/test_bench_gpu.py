@@ -38,11 +38,14 @@ def test_bench_single_rank_line(lib_built):
     assert "S3" in res["config"]["workload"] and res["config"]["krylov_iters_per_ipcs_step"]["velocity_bicgstab"] > 0
     roof = res["roofline"]
     assert roof["bound"] == "hbm" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
-    assert "smooth_kernel" in roof["kernel"] and roof["launch_ms"] > 0 and roof["step_survey_convention_equivalent"]["ipcs_leg_bytes_survey_csr_convention"] > 0
+    assert "smooth_linear_kernel" in roof["kernel"] and roof["launch_ms"] > 0 and roof["step_survey_convention_equivalent"]["ipcs_leg_bytes_survey_csr_convention"] > 0
     assert roof["traffic_measured_in_run"] is False and "step" not in roof
     assert res["roofline_s2_velocity"]["bound"] == "lds-atomic/fp64"
     cpu = res["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["s2_ipcs"]["value"] > 0
+    dep = res["rates"]["deploy_episode_s"]
+    assert dep["value"] > 0 and dep["resimulated_meshes"] == 45 and dep["same_first_rows"] and dep["sequential_3_removals_s"] > 0
+    assert isinstance(res["stream_setup"], list) and res["stream_setup"]
     for k in ("S1_reference_step", "S2_ipcs_step", "training_loop", "C2_s2_diverged_meshes", "C3_s3_ah93w145", "S3_full_chip",
               "S3_refactorised_pressure", "C5_s2_refined_mesh"):
         assert res["rates"][k]["value"] > 0, (k, res["rates"][k])

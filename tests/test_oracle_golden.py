@@ -79,6 +79,30 @@ def test_oracle_episode_prefix_matches_fixture(meshes, fixture):
         assert abs(float(np.asarray(st["x"], dtype=np.float64).sum()) - g["x_sum"]) < 1e-3
 
 
+def test_oracle_stock_episode_replays_from_its_snapshots(meshes):
+    """The stock-configuration fixtures (make_stock_fixtures.py: solver_steps 5000; non-terminal steps, un-saturated rewards,
+    the accuracy flip): the oracle, restarted from the stored ground truth (the snapshot-reload branch), reproduces the
+    shortest random episode of ys930 step by step, and the stored ground truth ends on the reference's CSV row."""
+    from oracle.env import OracleEnv
+    ep = json.load(open(os.path.join(GOLDEN, "oracle_stock_ys930.json")))
+    z = np.load(os.path.join(GOLDEN, "oracle_stock_ys930.npz"))
+    kat = json.load(open(os.path.join(GOLDEN, "kat_rows.json")))["ys930"]
+    assert abs(z["gt_drag"][-1] - kat["drag"]) < 5e-7 * abs(kat["drag"]) and abs(z["gt_lift"][-1] - kat["lift"]) < 5e-7 * abs(kat["lift"])
+    ff = ep["episodes"]["far_field"]
+    assert ff["removals"] == 44 and ff["steps"][-1]["done"] and ff["steps"][-1]["nv"] == 832 and not ff["steps"][-2]["done"]
+    env = OracleEnv(*meshes["ys930"], ep["agent_params"],
+                    snapshots=dict(gt_drag=z["gt_drag"], gt_lift=z["gt_lift"], u=z["u"], p=z["p"]))
+    env.get_state()
+    steps = ep["episodes"]["random_1372"]["steps"]
+    assert [g["done"] for g in steps] == [False, False, True]
+    for g in steps:
+        removed = int(env.coord_map.get(g["action"], -1))
+        st, r, done, _ = env.step(g["action"])
+        assert removed == g["removed_vertex"] and (env.flow.mesh.nv, env.flow.mesh.nt) == (g["nv"], g["nt"])
+        assert abs(r - g["reward"]) < 1e-9 and done == g["done"]
+        assert np.allclose(env.new_drags, g["new_drags"], rtol=1e-9, atol=0)
+
+
 def test_gcn_oracle_and_module_match_fixture():
     import sys
     import torch
