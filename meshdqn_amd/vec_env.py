@@ -688,6 +688,73 @@ class VecEnv2DAirfoil:
             self.rollout_step(ro, fused)
         return self.rollout_end(ro)
 
+    # host-side fields `rollout_step` moves along; a graph replay has to leave them where the capture left them
+    _GRAPH_HOST_STATE = ("u", "p", "_coords_dev", "_dev_drag", "_dev_lift", "_interp_i", "_flow_n", "_flow_prev", "_flow_keep")
+
+    def rollout_graph(self, fused, steps: int, explore=None, rand_actions=None, actions=None):
+        """`rollout_device` with the whole rollout - `steps` env steps, main chain AND the flow leg on its stream - replayed
+        from ONE HIP graph: the first call with a given (steps, kind of input, network) runs eagerly (it creates every
+        lazily allocated buffer), the second captures the launches of `rollout_step` (the state of step 0 is recomputed by
+        the graph's first node; inputs and outputs live in static buffers) and replays them, later calls copy their inputs
+        in and replay.  Same results as `rollout_device` (tested); the host enqueues ~0.06 ms per env step instead of
+        ~0.26 ms.  `steps` must be even (the interpolation results ping-pong between two buffer sets); host-driven steps
+        or eager rollouts between two replays are fine as long as they leave that parity alone (else: a new capture)."""
+        K = int(steps)
+        if K <= 0 or K % 2:
+            raise ValueError("rollout_graph needs an even, positive number of steps")
+        cur = torch.cuda.current_stream(self.device)
+        if cur == torch.cuda.default_stream(self.device):
+            if getattr(self, "_main_stream", None) is None:
+                from .streams import role_streams
+                self._main_stream = role_streams(self.device)["main"]
+            self._main_stream.wait_stream(cur)
+            with torch.cuda.stream(self._main_stream):
+                out = self.rollout_graph(fused, K, explore, rand_actions, actions)
+            cur.wait_stream(self._main_stream)
+            return out
+        graphs = self.__dict__.setdefault("_graphs", {})
+        key = (K, actions is not None, id(fused), int(cur.cuda_stream))
+        ent = graphs.get(key)
+        if ent is None:                               # first call: eager (warms every lazily created buffer)
+            graphs[key] = "warm"
+            return self.rollout_device(fused, K, explore, rand_actions, actions)
+        if ent != "warm" and (ent["interp_i"] != getattr(self, "_interp_i", 0) or
+                              (self.flow_overlap and ent["flow_par"] != self._flow_n % 2)):
+            ent = "warm"                              # the ping-pong parity moved since the capture: capture again
+        if self.flow_overlap:
+            self.flow_wait()                          # the last flow leg (eager or replayed) still reads the private meshes
+        if fused is not None:
+            fused._pack()
+        if ent == "warm":
+            ro = self.rollout_begin(K, explore, rand_actions, actions)
+            interp_i, flow_par = getattr(self, "_interp_i", 0), (self._flow_n % 2 if self.flow_overlap else 0)
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=cur):
+                ro["state"] = self._state_device()    # (the graph's first node: the state from the current device data)
+                for _ in range(K):
+                    self.rollout_step(ro, fused, pack=False)
+                if self.flow_overlap:
+                    cur.wait_stream(self._flow_stream)   # the flow leg joins before the capture ends
+            ent = graphs[key] = dict(g=g, ro=ro, interp_i=interp_i, flow_par=flow_par,
+                                     post={k: getattr(self, k, None) for k in self._GRAPH_HOST_STATE})
+        else:
+            ro = ent["ro"]
+            if self._pending is not None:
+                self._refresh_collect()
+            if actions is not None:
+                ro["act"].copy_(torch.from_numpy(np.ascontiguousarray(actions, dtype=np.int32).reshape(K, self.B)))
+            else:
+                ro["explore"].copy_(torch.from_numpy(np.ascontiguousarray(explore, dtype=np.uint8).reshape(K, self.B)))
+                ro["rand"].copy_(torch.from_numpy(np.ascontiguousarray(rand_actions, dtype=np.int32).reshape(K, self.B)))
+            ro["d_steps"].copy_(torch.from_numpy(self.steps.astype(np.int32)))
+            ro["err"].zero_()
+            self.dtopo.offset.copy_(torch.from_numpy(self.offset))
+        ent["g"].replay()
+        for k, v in ent["post"].items():              # the host-side view of the buffers, as the captured steps left it
+            setattr(self, k, v)
+        return self.rollout_end(ro)
+
     def calibrate_streams(self, fused, tries: int = 6, steps: int = 8):
         """Pick a flow stream that REALLY runs beside the current (main) stream, by measurement.  HIP maps streams
         round-robin onto hardware queues; besides the pairs that land on one queue (the flow leg then runs behind the
