@@ -160,6 +160,14 @@ int64_t mdq_ipcs_workspace_doubles(int32_t B, int32_t NV, int32_t NT, int32_t NE
 int mdq_ipcs_assemble(const mdq_ipcs_desc* d, void* stream);
 
 /*
+ * A new mesh in the same descriptor (FlowSolver.remesh, flow_solver.py:233-359: the solvers restart without history): the
+ * counters of the extrapolated initial guesses inside the workspace back to zero (the vectors behind them are not read
+ * while their counter is zero), and - when `iters` is not NULL - the [B][3] iteration counters too.  Replaces a fill of
+ * the whole workspace in front of mdq_ipcs_setup_matfree.
+ */
+int mdq_ipcs_reset_history(const mdq_ipcs_desc* d, int32_t* iters, void* stream);
+
+/*
  * Operator setup of the MATRIX-FREE path only (mode 3, CG pressure solver) - what `FlowSolver.remesh` would have to
  * redo after every vertex removal (flow_solver.py:268-339 runs it in DEPLOY mode only): per-triangle geometry, the
  * outflow-row blocks, Jacobi diagonals and Dirichlet lifting vectors of A1 / M accumulated row-wise from the element

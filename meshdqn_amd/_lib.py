@@ -128,6 +128,7 @@ SYMBOLS = {
     "mdq_smooth_fast_env": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "mdq_ipcs_factorize_pressure": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mdq_ipcs_reset_history": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdq_gcn_train_workspace": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32]),
     "mdq_gcn_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdq_gcn_pack": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -2005,6 +2005,23 @@ __device__ __forceinline__ void team_sum(double (&v)[N], double* red, Team& t) {
   t.par ^= 1;
 }
 
+// "No initial-guess history on a new mesh" (FlowSolver.remesh restarts u_n / p_n and the solvers, flow_solver.py:233-359):
+// the counters of the extrapolated initial guesses (tentative velocities stored, corrections stored / ring position / lagged
+// |b| / step parity of the fused correction start), of every operator mode, back to zero - instead of a fill of the whole
+// workspace (100 MB per 128 environments in every S3 env step) - and, optionally, the iteration counters.
+__global__ void reset_history_kernel(mdq_ipcs_desc d, int32_t* iters) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= d.B) return;
+  double* w = d.work + (int64_t)b * work_per_env(d.NV, d.NT, d.NE);
+  double2* xs = reinterpret_cast<double2*>(w + 12 * (int64_t)d.NT);
+  reinterpret_cast<double*>(xs + 3 * (int64_t)d.N2)[0] = 0.0;                       // mode 3: histc
+  double2* h1 = reinterpret_cast<double2*>(w + work_hist_offset(d.NV, d.NT, d.NE));
+  double* ccnt = reinterpret_cast<double*>(h1 + 3 * (int64_t)d.N2);                  // mode 3: correction ring
+  ccnt[0] = ccnt[1] = ccnt[2] = ccnt[3] = 0.0;
+  reinterpret_cast<double*>(h1 + 5 * (int64_t)d.N2)[0] = 0.0;                        // modes 0-2, 4: hcnt
+  if (iters) iters[3 * b] = iters[3 * b + 1] = iters[3 * b + 2] = 0;
+}
+
 __global__ void team_reset_kernel(mdq_ipcs_desc d) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= d.B) return;
@@ -3890,6 +3907,14 @@ const char* mdq_last_error(void) { return g_err.c_str(); }
 
 int64_t mdq_ipcs_workspace_doubles(int32_t B, int32_t NV, int32_t NT, int32_t NE) {
   return (int64_t)B * work_per_env(NV, NT, NE);
+}
+
+int mdq_ipcs_reset_history(const mdq_ipcs_desc* d, int32_t* iters, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  hipLaunchKernelGGL(reset_history_kernel, dim3((d->B + 63) / 64), dim3(64), 0, (hipStream_t)stream, *d, iters);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail("reset_history_kernel launch", e);
+  return 0;
 }
 
 int mdq_ipcs_assemble(const mdq_ipcs_desc* d, void* stream) {

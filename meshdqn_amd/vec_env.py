@@ -231,8 +231,10 @@ class VecEnv2DAirfoil:
         if out_u is not None:
             t["u_n"].copy_(out_u[:, self.S - 1])
             t["p_n"].copy_(out_p[:, self.S - 1])
-        t["work"].zero_()            # no initial-guess history on a new mesh
-        self.flow_iters.zero_()
+        # no initial-guess history on a new mesh: the counters inside the workspace (not a fill of its 100 MB) + the
+        # iteration counters, one small launch
+        _lib.check(self.lib.mdq_ipcs_reset_history(C.byref(d), self.flow_iters.data_ptr(), _lib.stream_ptr()),
+                   "mdq_ipcs_reset_history")
         _lib.check(self.lib.mdq_ipcs_setup_matfree(C.byref(d), _lib.stream_ptr()), "mdq_ipcs_setup_matfree")
         if self.flow_pressure == "direct":
             _lib.check(self.lib.mdq_ipcs_factorize_pressure(C.byref(d), self.flow_pd_status.data_ptr(), _lib.stream_ptr()),
