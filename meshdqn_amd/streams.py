@@ -82,7 +82,9 @@ def role_streams(device) -> dict:
         return r
     dev = torch.device("cuda", idx)
     with torch.cuda.device(dev):
-        r = dict(main=torch.cuda.Stream(device=dev), flow=torch.cuda.Stream(device=dev), opt=torch.cuda.Stream(device=dev))
+        import os
+        fp = int(os.environ.get("MDQ_FLOW_PRIORITY", "0"))     # (experiment knob: -1 = high priority for the flow stream)
+        r = dict(main=torch.cuda.Stream(device=dev), flow=torch.cuda.Stream(device=dev, priority=fp), opt=torch.cuda.Stream(device=dev))
         how = {}
         for a, b in (("flow", "main"), ("opt", "main"), ("opt", "flow")):
             if _overlaps(r[a], r[b], dev):

@@ -793,7 +793,8 @@ class VecEnv2DAirfoil:
         for t in range(max(1, int(tries))):
             if t > 0:
                 self.flow_wait()
-                self._flow_stream = torch.cuda.Stream(device=dev)
+                import os as _os
+                self._flow_stream = torch.cuda.Stream(device=dev, priority=int(_os.environ.get("MDQ_FLOW_PRIORITY", "0")))
             timed(3)
             results.append((timed(int(steps)), self._flow_stream))
             ms = [r[0] for r in results]
