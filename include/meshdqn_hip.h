@@ -115,7 +115,9 @@ typedef struct mdq_ipcs_desc {
   int32_t NPART, NPW, NPF, NPGI, NPS, NPGK;   /* capacities of the arrays below */
   int32_t pcg_degree;          /* mode 3, Krylov pressure solve (pd_enabled = 0 or no factors): degree m of the Chebyshev
                                   polynomial preconditioner of the CG on the Jacobi-scaled P1 Laplacian (m - 1 extra
-                                  operator applications per iteration, no extra reductions); 0 / 1 = Jacobi only */
+                                  operator applications per iteration, no extra reductions); 0 / 1 = Jacobi only;
+                                  < 0 = two-level additive preconditioner (8 x 7 geometric aggregates, coarse matrix
+                                  inverted in LDS): fewer operator applications (167 -> ~100 iterations on ys930) */
   const int32_t* pd_hdr;       /* [B][4]  nI, nG, nparts, 0                       */
   const int32_t* pd_node;      /* [B][NV] node id of permuted position (interiors by subdomain, then separator) */
   const int32_t* pd_meta;      /* [B][NPART][6] q0, m, W offset, F offset, g, gidx offset */

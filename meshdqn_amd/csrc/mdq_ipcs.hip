@@ -1416,6 +1416,246 @@ __device__ inline int cg_pressure_cheb(int n, const int32_t* sl_off, const int32
   return it;
 }
 
+// The register-resident CG (cg_pressure_reg) with a TWO-LEVEL additive preconditioner on top of the Jacobi scaling:
+//      z = r + P A_c^-1 P^T r,     A_c = P^T A P,
+// P = piecewise constants over NAGX x NAGY geometric aggregates: vertices ranked by x into NAGX strips of equal
+// population, every strip ranked by y into NAGY cells (compact patches of ~16 vertices; aggregates of consecutive INDICES
+// do nothing for this matrix: tools + DESIGN 8.1).  A_c (56 x 56) is accumulated with LDS atomics, inverted in LDS by
+// Gauss-Jordan (SPD: no pivoting) once per solve and kept in fp32 (a preconditioner may be approximate; it is stored
+// exactly symmetric).  Per iteration: per-wave partial restrictions by LDS atomics (rows of one aggregate are scattered
+// over the waves), one 56^2 product spread over 448 threads, prolongation by one LDS read per row: two extra barriers.
+// Iterations on ys930 (developed flow): 154 -> 86, same answers.  MEASURED (tools/time_pcg.py): 465 us per solve against 247 us of
+// the plain Jacobi-CG - the O(n^2) rank counts of the aggregation and the 56-step inversion cost ~0.1 ms per solve, and
+// every iteration pays two more barriers, the atomics and a 63-read coarse product per thread.  An O(n) aggregation
+// (histograms) and one shared restriction vector would bring it to ~200 us (-18 %): kept as an OPTION (pcg_degree < 0), the
+// default stays the Jacobi-CG.  LDS: the four pressure vectors' space (x, r, p, q = 4 NVp doubles, NVp >= 1024):
+// x and r live in registers during the iterations.  Needs n <= 2 NTH, n <= 1024 and at least NAG vertices; else -1.
+constexpr int NAGX = 8, NAGY = 7, NAG = NAGX * NAGY;
+template <int NTH>
+__device__ inline int cg_pressure_2l(int n, const int32_t* sl_off, const int32_t* sl_col, const double* A, const double* coords,
+                                     double rtol, int maxit, double* x, double* r, double* p, int NVp, double* red, int& rsel) {
+  constexpr int NW = NTH / 64;
+  if (n > 2 * NTH || n > 1024 || n < 4 * NAG || NVp < 1024) return -1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nsl = (n + 63) >> 6;
+  int base[2], wid[2], row[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int s_ = wave + NW * k;
+    row[k] = (s_ << 6) + lane;
+    base[k] = s_ < nsl ? sl_off[s_] : 0;
+    wid[k] = s_ < nsl ? (sl_off[s_ + 1] - base[k]) >> 6 : 0;
+  }
+  auto spmv = [&](const double* vec, double(&y)[2]) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const double* a = A + base[k] + lane;
+      const int32_t* c = sl_col + base[k] + lane;
+      double y0 = 0.0;
+#pragma unroll 4
+      for (int j = 0; j < wid[k]; ++j) y0 += a[j * 64] * vec[c[j * 64]];
+      y[k] = y0;
+    }
+  };
+  // LDS carve-up of the 4 NVp doubles behind x (x | r | p | q are contiguous in every caller)
+  double* W = x;
+  double* AC = W;                                            // [NAG][NAG] fp64 while it is built and inverted
+  float* AI = reinterpret_cast<float*>(W);                   // ... then fp32 in its first half
+  double* YV = W + NAG * NAG / 2 + 8;                        // [NAG] coarse result       (behind the fp32 inverse)
+  double* PG = W + 2 * NVp;                                  // the gather copy of the search direction (= p)
+  double* WP = W + 3 * NVp;                                  // [NW][NAG] per-wave partial restrictions
+  unsigned char* AG = reinterpret_cast<unsigned char*>(W + 3 * NVp + NW * NAG);   // [n] aggregate of a vertex
+  static_assert(NAG * NAG <= 3 * 1024 + 64 && 16 * NAG + 128 <= 1024, "two-level scratch");
+  __syncthreads();
+  double y[2], xv[2], rv[2], pv[2], zv[2];
+  spmv(x, y);
+  double acc[2] = {0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    xv[k] = rv[k] = pv[k] = zv[k] = 0.0;
+    if (row[k] < n) {
+      const double b = r[row[k]];
+      xv[k] = x[row[k]];
+      rv[k] = b - y[k];
+      acc[0] += b * b;
+      acc[1] += rv[k] * rv[k];
+    }
+  }
+  block_sum<2, NW>(acc, red);                                // (its barriers: x and r are in registers, their LDS space is free)
+  const double bb = acc[0], tol2 = rtol * rtol * bb;
+  double rr = acc[1];
+  int it = 0;
+  if (rr > tol2 && bb != 0.0) {
+    // ---- aggregates: rank by x -> strip, rank by y inside the strip -> cell
+    double* XC = W;                                          // coordinates staged in LDS for the counting loops
+    double* YC = W + 1024;
+    unsigned char* ST = reinterpret_cast<unsigned char*>(W + 2048);
+    for (int i = tid; i < n; i += NTH) {
+      XC[i] = coords[2 * i];
+      YC[i] = coords[2 * i + 1];
+    }
+    __syncthreads();
+    int strip[2] = {0, 0};
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (row[k] < n) {
+        const double xi = XC[row[k]];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+          const double xj = XC[j];
+          rank += (xj < xi) | ((xj == xi) & (j < row[k]));
+        }
+        strip[k] = rank * NAGX / n;
+        ST[row[k]] = (unsigned char)strip[k];
+      }
+    __syncthreads();
+    int agg[2] = {0, 0};
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (row[k] < n) {
+        const double yi = YC[row[k]];
+        int rank = 0, cnt = 0;
+        for (int j = 0; j < n; ++j) {
+          const bool same = ST[j] == strip[k];
+          const double yj = YC[j];
+          cnt += same;
+          rank += same & ((yj < yi) | ((yj == yi) & (j < row[k])));
+        }
+        agg[k] = strip[k] * NAGY + rank * NAGY / cnt;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (row[k] < n) AG[row[k]] = (unsigned char)agg[k];
+    for (int e = tid; e < NAG * NAG; e += NTH) AC[e] = 0.0;
+    __syncthreads();
+    // ---- coarse matrix
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (row[k] < n) {
+        const double* a = A + base[k] + lane;
+        const int32_t* c = sl_col + base[k] + lane;
+        for (int j = 0; j < wid[k]; ++j) {
+          const double av = a[j * 64];
+          if (av != 0.0) atomicAdd(&AC[agg[k] * NAG + AG[c[j * 64]]], av);
+        }
+      }
+    __syncthreads();
+    // ---- in-place Gauss-Jordan inverse (every thread owns the elements e = tid + m NTH)
+    constexpr int EPT = (NAG * NAG + NTH - 1) / NTH;
+    int ei_[EPT], ej_[EPT];
+#pragma unroll
+    for (int m = 0; m < EPT; ++m) {
+      const int e = tid + m * NTH;
+      ei_[m] = e / NAG;
+      ej_[m] = e - ei_[m] * NAG;
+    }
+    for (int kk = 0; kk < NAG; ++kk) {
+      const double ip = 1.0 / AC[kk * NAG + kk];
+      double nv_[EPT];
+#pragma unroll
+      for (int m = 0; m < EPT; ++m) {
+        const int e = tid + m * NTH;
+        nv_[m] = 0.0;
+        if (e < NAG * NAG) {
+          const int i = ei_[m], j = ej_[m];
+          const double aij = AC[e], aik = AC[i * NAG + kk], akj = AC[kk * NAG + j];
+          nv_[m] = i == kk ? (j == kk ? ip : akj * ip) : (j == kk ? -aik * ip : aij - aik * akj * ip);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < EPT; ++m) {
+        const int e = tid + m * NTH;
+        if (e < NAG * NAG) AC[e] = nv_[m];
+      }
+      __syncthreads();
+    }
+    {  // fp32 copy, exactly symmetric: the entry of the upper triangle for both (i, j) and (j, i)
+      float f_[EPT];
+#pragma unroll
+      for (int m = 0; m < EPT; ++m) {
+        const int e = tid + m * NTH;
+        f_[m] = 0.f;
+        if (e < NAG * NAG) {
+          const int i = e / NAG, j = e - i * NAG;
+          f_[m] = (float)AC[min(i, j) * NAG + max(i, j)];
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < EPT; ++m) {
+        const int e = tid + m * NTH;
+        if (e < NAG * NAG) AI[e] = f_[m];
+      }
+    }
+    __syncthreads();
+    double rz_old = 1.0;
+    while (it < maxit) {
+      // ---- z = r + P A_c^-1 P^T r
+      if (lane < NAG) WP[wave * NAG + lane] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (row[k] < n) atomicAdd(&WP[wave * NAG + agg[k]], rv[k]);
+      __syncthreads();
+      if (tid < NAG * 8) {
+        const int I = tid >> 3, part = tid & 7;
+        double s_ = 0.0;
+        for (int J = part; J < NAG; J += 8) {
+          double w_ = 0.0;
+#pragma unroll
+          for (int q = 0; q < NW; ++q) w_ += WP[q * NAG + J];
+          s_ += (double)AI[I * NAG + J] * w_;
+        }
+        s_ += dpp_get<0xB1, 0xF>(s_);      // quad_perm [1,0,3,2]
+        s_ += dpp_get<0x4E, 0xF>(s_);      // quad_perm [2,3,0,1]
+        s_ += dpp_get<0x141, 0xF>(s_);     // row_half_mirror: the other quad of the group of 8
+        if (part == 0) YV[I] = s_;
+      }
+      __syncthreads();
+      double a0[1] = {0.0};
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        zv[k] = row[k] < n ? rv[k] + YV[agg[k]] : 0.0;
+        a0[0] += rv[k] * zv[k];
+      }
+      block_sum1<1, NW>(a0, red, rsel);
+      const double rz = a0[0];
+      const double beta = it == 0 ? 0.0 : rz / rz_old;
+      rz_old = rz;
+      ++it;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        pv[k] = zv[k] + beta * pv[k];
+        if (row[k] < n) PG[row[k]] = pv[k];
+      }
+      __syncthreads();
+      double q[2];
+      spmv(PG, q);
+      double a1[1] = {pv[0] * q[0] + pv[1] * q[1]};
+      block_sum1<1, NW>(a1, red, rsel);
+      if (!(a1[0] > 0.0)) break;
+      const double alpha = rz / a1[0];
+      double a2[1] = {0.0};
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        xv[k] += alpha * pv[k];
+        rv[k] -= alpha * q[k];
+        a2[0] += rv[k] * rv[k];
+      }
+      block_sum1<1, NW>(a2, red, rsel);
+      rr = a2[0];
+      if (!(rr > tol2)) break;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+    if (row[k] < n) x[row[k]] = xv[k];
+  __syncthreads();
+  return it;
+}
+
 #ifdef MDQ_AT_TRACE
 // debug build only: s_memtime deltas of thread 0 of environment 0 at the phase boundaries of at_velocity_kernel
 __device__ long long mdq_at_trace_buf[16];
@@ -3503,7 +3743,9 @@ __global__ __launch_bounds__(NTH) void at_pressure_kernel(mdq_ipcs_desc d, int32
       pressure_direct<NTH>(pd, nv, pr, px, pp, pq, lK);
     } else {
       int itc = -1;
-      if (nv <= 2 * NTH && d.pcg_degree > 0)   // rows in registers, Chebyshev-preconditioned (degree 1: Jacobi only)
+      if (d.pcg_degree < 0)                    // two-level additive preconditioner (geometric aggregates)
+        itc = cg_pressure_2l<NTH>(nv, so1, ci1, K1, v.coords, d.rtol, d.maxit_p, px, pr, pp, P.NVp, red, rsel);
+      else if (nv <= 2 * NTH && d.pcg_degree > 0)   // rows in registers, Chebyshev-preconditioned (degree 1: Jacobi only)
         itc = cg_pressure_cheb<NTH>(nv, so1, ci1, K1, d.rtol, d.maxit_p, d.pcg_degree, px, pr, pp, red, rsel);
       if (itc >= 0)
         it_p += itc;

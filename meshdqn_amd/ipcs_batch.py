@@ -173,7 +173,10 @@ class IpcsBatch:
         # kernel).  Measured on ys930 (tools/time_pcg.py): iterations 154 -> 95 / 67 / 52 / 37 / 30 for degree 2 / 3 / 4 / 6 / 8,
         # kernel time unchanged (251-283 us against 253 us): the solve is bound by the LDS gathers of the operator
         # application (~1.6 us each, bank conflicts of the random vertex gather), not by its reductions, and the polynomial
-        # trades the one for the other.  Kept as an option (the reference's Krylov option is CG + AMG, flow_solver.py:152-155).
+        # trades the one for the other.  pcg_degree < 0: two-level additive preconditioner (8 x 7 geometric aggregates, coarse
+        # matrix inverted in LDS): 154 -> 86 iterations, but 465 us per solve in its first version (aggregation + inversion
+        # ~0.1 ms, two more barriers and a coarse product per iteration).  Both kept as options (the reference's Krylov option
+        # is CG + AMG, flow_solver.py:152-155); the default is the Jacobi-CG.
         d.pcg_degree = int(pcg_degree)
         self.desc = d
         self.assembled = False
