@@ -265,11 +265,10 @@ def test_gpu_smoothing_matches_host_and_golden(lib_built, meshes):
         assert np.abs(outs[0][b, :nv[b]] - z[f"{n}_coords_smoothed"]).max() < 1e-13
 
 
-def _fan_mesh(seed):
-    """A hub of degree 12 inside a strongly jittered ring of 12 interior vertices inside a boundary ring: exercises the
+def _fan_mesh(seed, n=12):
+    """A hub of degree n (12) inside a strongly jittered ring of n interior vertices inside a boundary ring: exercises the
     exact fp64 path of mdq_smooth (degree > 8, step limited to half the minimum altitude)."""
     rng = np.random.default_rng(seed)
-    n = 12
     ang = 2 * np.pi * np.arange(n) / n
     r1 = rng.uniform(0.25, 1.75, n)
     ring1 = np.stack([r1 * np.cos(ang + rng.uniform(-0.2, 0.2, n)), r1 * np.sin(ang)], 1)
@@ -394,6 +393,32 @@ def test_fast_smoothing_rolls_back_sweeps_with_limited_steps(lib_built, meshes):
         assert np.abs(fast[b, :nv[b]] - walk[b, :nv[b]]).max() < 1e-12, b
     assert (redo[:, 0] == 0).all(), redo                              # nothing handed back: repaired in the kernel
     assert redo[0, 1] >= 4 and redo[2, 1] >= 4 and redo[3, 1] >= 3 and redo[1, 1] <= 2, redo   # sweeps with repair rounds
+
+
+def test_fast_smoothing_hands_meshes_beyond_its_limits_to_the_walk(lib_built):
+    """A hub of 18 cells (more than the 16 cells / 14 gather slots per row the blocked solve is laid out for): the kernel
+    leaves the mesh untouched and reports all sweeps as handed back; the per-vertex walk (one workgroup over the handed-back
+    environments) does them - same result as mdq_smooth on its own, bitwise; the ordinary mesh beside it in the same
+    launch runs in the blocked solve."""
+    from meshdqn_amd.mesh_ops import smooth_batch_gpu, smooth_fast_stats
+    big = _fan_mesh(1, n=18)
+    small = _fan_mesh(2)
+    NV, NT = len(big[0]), len(big[1])
+    coords, cells = np.zeros((2, NV, 2)), np.zeros((2, NT, 3), np.int32)
+    nv, nt = np.array([len(big[0]), len(small[0])], np.int32), np.array([len(big[1]), len(small[1])], np.int32)
+    for b, (c, t) in enumerate((big, small)):
+        coords[b, :len(c)], cells[b, :len(t)] = c, t
+    dev = lambda a: torch.from_numpy(a).cuda()   # noqa: E731
+    outs = []
+    for fast in (True, False):
+        tc = dev(coords.copy())
+        smooth_batch_gpu(tc, dev(cells), dev(nv), dev(nt), dev(np.array([5, 5], np.int32)), fast=fast)
+        torch.cuda.synchronize()
+        outs.append(tc.cpu().numpy())
+    st = smooth_fast_stats(tc.device, 2, NV)
+    assert st[0, 0] == 5 and st[1, 0] == 0, st
+    assert np.array_equal(outs[0][0], outs[1][0])                       # handed back: the walk's own result
+    assert np.abs(outs[0][1, :nv[1]] - outs[1][1, :nv[1]]).max() < 1e-13
 
 
 def test_env_groups_equal_one_batch(lib_built):
