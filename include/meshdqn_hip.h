@@ -408,6 +408,13 @@ int mdq_copy_strided(int32_t n, void* const* dst, const void* const* src, const 
  * hardware queue busy, which is how two HIP streams are tested for really running beside each other. */
 int mdq_spin(int32_t wgs, int32_t lds_bytes, int64_t ticks_100mhz, void* stream);
 
+/* A HIP stream restricted to the compute units of `mask` (nwords 32-bit words; bit i = compute unit i in the driver's
+ * numbering, which goes round-robin over the XCDs and then over the shader engines of an XCD), and its release.  No
+ * reference counterpart: meshdqn_amd/streams.py gives the env step's main chain and its flow leg disjoint halves of the
+ * chip (both are chains of kernels with one workgroup per environment). */
+int mdq_stream_create_cu_mask(const uint32_t* mask, int32_t nwords, void** stream);
+int mdq_stream_destroy(void* stream);
+
 /* ---- snapshot interpolation onto coarsened meshes (Env2DAirfoil.py:556-593, :515-522) ---- */
 typedef struct mdq_interp_desc {
   int32_t B, S;            /* target meshes (environments), snapshots                         */

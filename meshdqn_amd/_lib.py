@@ -137,6 +137,8 @@ SYMBOLS = {
     "mdq_replay_sample": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mdq_adam_step": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mdq_spin": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
+    "mdq_stream_create_cu_mask": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "mdq_stream_destroy": (C.c_int, [C.c_void_p]),
     "mdq_copy_strided": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdq_smooth_host": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),

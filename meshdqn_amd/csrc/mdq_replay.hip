@@ -182,3 +182,25 @@ extern "C" int mdq_spin(int32_t wgs, int32_t lds_bytes, int64_t ticks_100mhz, vo
   if (hipGetLastError() != hipSuccess) return mdq_set_error("spin_kernel launch failed");
   return 0;
 }
+
+// A stream whose kernels may only be placed on the compute units of `mask` (bit i of word i / 32 = compute unit i in the
+// driver's numbering: on a multi-XCD part consecutive bits go round-robin over the XCDs, then over the shader engines of
+// an XCD, so "the first half of the bits" is half of every shader engine of every XCD).  meshdqn_amd/streams.py gives the
+// main chain and the flow leg of the env step disjoint halves of the chip: both are chains of one-workgroup-per-
+// environment kernels (128 workgroups that each want a compute unit of their own), and left to the dispatcher the
+// workgroups of the two chains are packed onto shared compute units whenever their LDS fits.
+extern "C" int mdq_stream_create_cu_mask(const uint32_t* mask, int32_t nwords, void** stream) {
+  if (!mask || nwords <= 0 || !stream) return mdq_set_error("mdq_stream_create_cu_mask: bad arguments");
+  hipStream_t s = nullptr;
+  hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)nwords, mask);
+  if (e != hipSuccess) return mdq_set_error(hipGetErrorString(e));
+  *stream = s;
+  return 0;
+}
+
+extern "C" int mdq_stream_destroy(void* stream) {
+  if (!stream) return 0;
+  hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  if (e != hipSuccess) return mdq_set_error(hipGetErrorString(e));
+  return 0;
+}

@@ -346,34 +346,151 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   const int np_ = D.npoly;
   for (int i = tid; i < np_; i += TW) poly[i] = make_double2(D.polygon[2 * i], D.polygon[2 * i + 1]);
   __syncthreads();
-  for (int r = tid; r < nrem; r += TW) {
-    const double px = X[remv[r]].x, py = X[remv[r]].y;
-    bool inside = false;
-    // (skipping segments whose bounding box is farther than the nearest polygon vertex - what the host twin does -
-    // was measured SLOWER here, 234 k vs 188 k cycles: the 64 vertices of a wave are near different segments, so the
-    // wave evaluates almost every segment anyway and pays the bound on top)
-    double d2 = 1e300;
-    for (int i = 0; i < np_; ++i) {
-      const double2 A = poly[i], Bp = poly[i + 1 == np_ ? 0 : i + 1];
-      if ((A.y > py) != (Bp.y > py)) {
-        const double xin = A.x + (py - A.y) * (Bp.x - A.x) / (Bp.y - A.y);
-        if (px < xin) inside = !inside;
+  // Four lanes per vertex, a quarter of the polygon each.  The old loop evaluated `seg_dist2` and the crossing abscissa in
+  // fp64 for EVERY (vertex, segment) pair, one LDS round trip per pair, although a vertex's distance is decided by the one
+  // or two segments next to it and its inside flag by the two segments its horizontal ray meets.  Now an fp32 estimate of
+  // every pair picks the segments that CAN hold the minimum - estimate (as a distance) no larger than the estimated
+  // distance to the nearest polygon VERTEX + 2 eta, eta = a bound on an estimate's absolute error: the true nearest
+  // segment is at most as far as the nearest vertex, so it always qualifies - and only those are evaluated with
+  // `seg_dist2`; the straddle test (exact comparisons) picks the segments whose crossing abscissa is evaluated.  Both sets
+  // are bit masks walked in wave-uniform loops (a branch inside the segment loop would run for every segment: the lanes
+  // of a wave are near different segments).  The minimum over a superset of the segments that can attain it and the
+  // parity over exactly the straddled segments are the values of the full loop, bit for bit.
+  const int QS = (((np_ + 3) >> 2) + 3) & ~3;                                 // segments per quarter (multiple of 4, <= 64)
+  const int NSEG = 4 * QS;                                                    // <= TNPOLY
+  float4* segf = reinterpret_cast<float4*>(R + 20480);                        // [NSEG] {ax, ay, bx - ax, by - ay}
+  float* segr = reinterpret_cast<float*>(R + 20480 + TNPOLY * 16);            // [NSEG] 1 / |b - a|^2
+  double* ye = reinterpret_cast<double*>(R + 20480 + TNPOLY * 20);            // [NSEG + 1] y of polygon vertex i (closed)
+  float* pmx = reinterpret_cast<float*>(ye + TNPOLY + 2);                     // [TW / 64] wave maxima of |polygon coordinate|
+  {
+    float m = 0.f;
+    for (int i = tid; i <= NSEG; i += TW) {
+      if (i < np_) {
+        const double2 A = poly[i], Bp = poly[i + 1 == np_ ? 0 : i + 1];
+        const double abx = Bp.x - A.x, aby = Bp.y - A.y, l2 = abx * abx + aby * aby;
+        segf[i] = make_float4((float)A.x, (float)A.y, (float)abx, (float)aby);
+        segr[i] = l2 > 0.0 ? 1.0f / (float)l2 : 0.f;
+        ye[i] = A.y;
+        m = fmaxf(m, fmaxf(fabsf((float)A.x), fabsf((float)A.y)));
+      } else {                                   // padding: far away, never straddled
+        if (i < NSEG) {
+          segf[i] = make_float4(1.0e18f, 1.0e18f, 0.f, 0.f);
+          segr[i] = 0.f;
+        }
+        ye[i] = poly[0].y;
       }
-      d2 = fmin(d2, seg_dist2(px, py, A.x, A.y, Bp.x, Bp.y));
     }
-    dist[r] = inside ? 0.0 : sqrt(d2);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((tid & 63) == 0) pmx[tid >> 6] = m;
   }
   __syncthreads();
-  for (int r = tid; r < nrem; r += TW) {
-    const double dr = dist[r];
-    int rank = 0;
-#pragma unroll 8
-    for (int q = 0; q < nrem; ++q) {
-      const double dq = dist[q];
-      rank += (dq < dr) | ((dq == dr) & (q < r));
+  float mpoly = 0.f;
+#pragma unroll
+  for (int w = 0; w < TW / 64; ++w) mpoly = fmaxf(mpoly, pmx[w]);
+  for (int it0 = 0; it0 < 4 * nrem; it0 += TW) {
+    const int it = it0 + tid, r = min(it >> 2, nrem - 1), part = it & 3;
+    const double px = X[remv[r]].x, py = X[remv[r]].y;
+    const float pxf = (float)px, pyf = (float)py;
+    const int i0 = part * QS;
+    // absolute error bound of an fp32 distance estimate: ~24 ulp of the largest coordinate; 64 taken
+    const float eta = 64.0f * 5.9604645e-8f * fmaxf(mpoly, fmaxf(fabsf(pxf), fabsf(pyf)));
+    // pass 0: nearest polygon vertex (estimate)
+    float vmin = 3.0e38f;
+#pragma unroll 4
+    for (int k = 0; k < QS; ++k) {
+      const float4 sg = segf[i0 + k];
+      const float wx = pxf - sg.x, wy = pyf - sg.y;
+      vmin = fminf(vmin, wx * wx + wy * wy);
     }
-    order[rank] = (uint16_t)r;
+    vmin = fminf(vmin, __shfl_xor(vmin, 1, 64));
+    vmin = fminf(vmin, __shfl_xor(vmin, 2, 64));
+    const float dm = sqrtf(vmin) + 2.0f * eta;
+    const float thr = dm * dm * 1.000001f;
+    // pass 1: segments that can hold the minimum, segments the ray straddles (bit k of word h: segment i0 + 32 h + k)
+    uint32_t cm[2] = {0u, 0u}, sm[2] = {0u, 0u};
+    bool sa = ye[i0] > py;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int kn = min(32, QS - 32 * h);
+#pragma unroll 4
+      for (int k = 0; k < kn; ++k) {
+        const int i = i0 + 32 * h + k;
+        const float4 sg = segf[i];
+        const float wx = pxf - sg.x, wy = pyf - sg.y;
+        float t = (wx * sg.z + wy * sg.w) * segr[i];
+        t = fminf(fmaxf(t, 0.f), 1.f);
+        const float cx = wx - t * sg.z, cy = wy - t * sg.w;
+        const float a = cx * cx + cy * cy;
+        cm[h] |= (a <= thr ? 1u : 0u) << k;
+        const bool sb = ye[i + 1] > py;
+        sm[h] |= (sa != sb ? 1u : 0u) << k;
+        sa = sb;
+      }
+    }
+    double d2 = 1e300;
+    bool inside = false;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      uint32_t m = cm[h];
+      while (__any(m != 0u)) {
+        if (m != 0u) {
+          const int i = i0 + 32 * h + __ffs((int)m) - 1;
+          m &= m - 1u;
+          const double2 A = poly[i], Bp = poly[i + 1 == np_ ? 0 : i + 1];
+          d2 = fmin(d2, seg_dist2(px, py, A.x, A.y, Bp.x, Bp.y));
+        }
+      }
+      m = sm[h];
+      while (__any(m != 0u)) {
+        if (m != 0u) {
+          const int i = i0 + 32 * h + __ffs((int)m) - 1;
+          m &= m - 1u;
+          const double2 A = poly[i], Bp = poly[i + 1 == np_ ? 0 : i + 1];
+          const double xin = A.x + (py - A.y) * (Bp.x - A.x) / (Bp.y - A.y);
+          if (px < xin) inside = !inside;
+        }
+      }
+    }
+    d2 = fmin(d2, __shfl_xor(d2, 1, 64));
+    d2 = fmin(d2, __shfl_xor(d2, 2, 64));
+    int par = inside ? 1 : 0;
+    par ^= __shfl_xor(par, 1, 64);
+    par ^= __shfl_xor(par, 2, 64);
+    if (part == 0 && (it >> 2) < nrem) dist[r] = par ? 0.0 : sqrt(d2);
   }
+  __syncthreads();
+  TT_STAMP(12)
+  // stable argsort by counting, four lanes per entry (a quarter of the list each): rank = entries with a smaller distance
+  // + entries with the SAME distance and a smaller index; the second count only runs for entries that have a twin
+  {
+    const int QL = (nrem + 3) >> 2;
+    for (int it0 = 0; it0 < 4 * nrem; it0 += TW) {
+      const int it = it0 + tid, r = min(it >> 2, nrem - 1), part = it & 3;
+      const double dr = dist[r];
+      const int q0 = part * QL, q1 = min(nrem, q0 + QL);
+      int lt = 0, eq = 0;
+#pragma unroll 8
+      for (int q = q0; q < q1; ++q) {
+        const double dq = dist[q];
+        lt += dq < dr ? 1 : 0;
+        eq += dq == dr ? 1 : 0;
+      }
+      lt += __shfl_xor(lt, 1, 64);
+      lt += __shfl_xor(lt, 2, 64);
+      eq += __shfl_xor(eq, 1, 64);
+      eq += __shfl_xor(eq, 2, 64);
+      int tie = 0;
+      if (eq > 1) {                                // (its own entry counts once)
+        const int qe = min(q1, r);
+        for (int q = q0; q < qe; ++q) tie += dist[q] == dr ? 1 : 0;
+      }
+      tie += __shfl_xor(tie, 1, 64);
+      tie += __shfl_xor(tie, 2, 64);
+      if (part == 0 && (it >> 2) < nrem) order[lt + tie] = (uint16_t)r;
+    }
+  }
+  TT_STAMP(13)
   for (int v = tid; v < TNV; v += TW) inv[v] = -1;
   __syncthreads();
   const int off = D.offset[b];

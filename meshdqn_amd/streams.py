@@ -73,6 +73,67 @@ _CALIBRATED = {}
 LOG = []
 
 
+def _cu_partition(dev):
+    """Compute-unit ranges (lo, hi) of the three roles, or None (plain torch streams).  `MDQ_CU_PARTITION`:
+      "full" (default)  every role gets a stream created with a CU mask that covers the WHOLE chip.  Such a stream owns a
+                        hardware queue of its own instead of a slot in the round-robin pool of `GPU_MAX_HW_QUEUES`
+                        queues, which is what removes the stream lottery: measured over repeated processes, plain
+                        streams gave 123 k env-steps/s or - flow leg behind the main chain - 85 k depending on the
+                        creation history, full-mask streams 123-125 k every time with every probe passing.
+      "0"               plain torch streams (the round-2 behaviour: probes + calibration have to sort the pairs out)
+      "1"               main on the first half of the driver's CU numbering, flow + optimiser chain on the second half
+                        (the numbering goes round-robin over XCDs and shader engines: each half is half of every shader
+                        engine).  Measured SLOWER (97-120 k): the chains do not suffer from sharing compute units.
+      "lo:hi,lo:hi,lo:hi"  explicit ranges of main, flow, opt ("-" = a plain stream)."""
+    import os
+    spec = os.environ.get("MDQ_CU_PARTITION", _CU_PARTITION_DEFAULT)
+    if spec in ("", "0"):
+        return None
+    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+    if spec == "full":
+        return dict(main=(0, ncu), flow=(0, ncu), opt=(0, ncu))
+    if spec == "1":
+        return dict(main=(0, ncu // 2), flow=(ncu // 2, ncu), opt=(ncu // 2, ncu))
+    out = {}
+    for k, part in zip(("main", "flow", "opt"), spec.split(",")):
+        if part.strip() == "-":
+            out[k] = None
+        else:
+            lo, hi = (int(v) for v in part.split(":"))
+            if not 0 <= lo < hi <= ncu:
+                raise ValueError(f"MDQ_CU_PARTITION: range {part!r} outside 0..{ncu}")
+            out[k] = (lo, hi)
+    if len(out) != 3:
+        raise ValueError("MDQ_CU_PARTITION: three ranges (main, flow, opt) expected")
+    return out
+
+
+def _masked_stream(dev, lo, hi):
+    """A torch stream object around a HIP stream restricted to compute units lo..hi-1 (kept for the process's lifetime)."""
+    import ctypes as C
+    from . import _lib
+    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+    words = (ncu + 31) // 32
+    mask = (C.c_uint32 * words)()
+    for i in range(lo, hi):
+        mask[i // 32] |= 1 << (i % 32)
+    out = C.c_void_p()
+    _lib.check(_lib.load().mdq_stream_create_cu_mask(mask, words, C.byref(out)), "mdq_stream_create_cu_mask")
+    return torch.cuda.ExternalStream(out.value, device=dev)
+
+
+_CU_PARTITION_DEFAULT = "full"
+
+
+def new_flow_candidate(dev):
+    """Another stream for the flow role (the calibration's candidates): same compute-unit range as the role's stream."""
+    import os
+    part = _cu_partition(dev)
+    if part is not None and part["flow"] is not None:
+        return _masked_stream(dev, *part["flow"])
+    return torch.cuda.Stream(device=dev, priority=int(os.environ.get("MDQ_FLOW_PRIORITY", "0")))
+
+
 def role_streams(device) -> dict:
     """dict(main=, flow=, opt=) of torch streams for `device` (created and verified on first use)."""
     device = torch.device(device)
@@ -84,7 +145,11 @@ def role_streams(device) -> dict:
     with torch.cuda.device(dev):
         import os
         fp = int(os.environ.get("MDQ_FLOW_PRIORITY", "0"))     # (experiment knob: -1 = high priority for the flow stream)
-        r = dict(main=torch.cuda.Stream(device=dev), flow=torch.cuda.Stream(device=dev, priority=fp), opt=torch.cuda.Stream(device=dev))
+        part = _cu_partition(dev)
+        if part is not None:
+            r = {k: (_masked_stream(dev, *part[k]) if part[k] is not None else torch.cuda.Stream(device=dev)) for k in ("main", "flow", "opt")}
+        else:
+            r = dict(main=torch.cuda.Stream(device=dev), flow=torch.cuda.Stream(device=dev, priority=fp), opt=torch.cuda.Stream(device=dev))
         how = {}
         for a, b in (("flow", "main"), ("opt", "main"), ("opt", "flow")):
             if _overlaps(r[a], r[b], dev):
@@ -94,7 +159,8 @@ def role_streams(device) -> dict:
                     r[a] = concurrent_stream(dev, [v for k, v in r.items() if k not in (a, "main")])
                 how[f"{a}/{b}"] = "probe failed: replaced"
     _ROLES[idx] = r
-    LOG.append(dict(device=idx, event="roles created in fixed order", probes=how))
+    LOG.append(dict(device=idx, event="roles created in fixed order", probes=how,
+                    cu_partition=None if part is None else {k: (list(v) if v else None) for k, v in part.items()}))
     return r
 
 

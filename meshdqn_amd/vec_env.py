@@ -793,8 +793,7 @@ class VecEnv2DAirfoil:
         for t in range(max(1, int(tries))):
             if t > 0:
                 self.flow_wait()
-                import os as _os
-                self._flow_stream = torch.cuda.Stream(device=dev, priority=int(_os.environ.get("MDQ_FLOW_PRIORITY", "0")))
+                self._flow_stream = _st.new_flow_candidate(dev)
             timed(3)
             results.append((timed(int(steps)), self._flow_stream))
             ms = [r[0] for r in results]
