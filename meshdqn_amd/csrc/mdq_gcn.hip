@@ -22,6 +22,9 @@ namespace mdq_gcn {
 #endif
 constexpr int WGT = MDQ_GCN_WG;  // threads of the embedding kernel (one workgroup per graph)
 constexpr int WGH = 256;         // threads of the MFMA head kernel (4 waves, one 32x32 block each per pass)
+#ifndef MDQ_GCN_FORMC_MAXFIN
+#define MDQ_GCN_FORMC_MAXFIN 32   // widest input the node-per-lane convolution (form (c)) takes
+#endif
 constexpr int NACC = 24;  // accumulators per thread of the "feature-outer" small-graph convolution
 
 #ifdef MDQ_GCN_TRACE
@@ -195,6 +198,37 @@ __device__ __forceinline__ void conv_dense_small_n(const Lds& L, int n, int fin,
         }
       }
     }
+  } else if ((fin & 63) == 0 && (reinterpret_cast<size_t>(A) & 15) == 0 && (!ROOT || (reinterpret_cast<size_t>(X) & 15) == 0)) {
+    // wide levels of the reference's widths (fin = C = 64 / 128 / 256): FBW features per block - FBW (x 2) weight loads in
+    // flight per round trip instead of 16 (the pooled levels are a chain of global round trips: 8 -> 2 for C = 128 with
+    // one node per thread) - and the operand rows read four features per LDS instruction.  Same fma order per output.
+    constexpr int FBW = NACC == 1 ? 64 : (NACC <= 8 ? 32 : 16);
+    for (int f0 = 0; f0 < fin; f0 += FBW) {
+      float w1[FBW], w2[FBW];
+#pragma unroll
+      for (int q = 0; q < FBW; ++q) {
+        w1[q] = wl[(f0 + q) * C + c];
+        w2[q] = ROOT ? wr[(f0 + q) * C + c] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < FBW; q += 4) {
+#pragma unroll
+        for (int r = 0; r < NACC; ++r) {
+          const int i = min(g + r * G, n - 1);   // (rows past n re-read row n - 1, never stored)
+          const float4 a4 = *reinterpret_cast<const float4*>(A + i * fin + f0 + q);
+          float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ROOT) x4 = *reinterpret_cast<const float4*>(X + i * fin + f0 + q);
+          acc[r] = fmaf(w1[q], a4.x, acc[r]);
+          if (ROOT) acc[r] = fmaf(w2[q], x4.x, acc[r]);
+          acc[r] = fmaf(w1[q + 1], a4.y, acc[r]);
+          if (ROOT) acc[r] = fmaf(w2[q + 1], x4.y, acc[r]);
+          acc[r] = fmaf(w1[q + 2], a4.z, acc[r]);
+          if (ROOT) acc[r] = fmaf(w2[q + 2], x4.z, acc[r]);
+          acc[r] = fmaf(w1[q + 3], a4.w, acc[r]);
+          if (ROOT) acc[r] = fmaf(w2[q + 3], x4.w, acc[r]);
+        }
+      }
+    }
   } else {
     constexpr int FB = 16;
     // (issuing the next block's weight loads before the current block is used was measured slower: 18 -> 25 k cycles
@@ -227,6 +261,55 @@ __device__ __forceinline__ void conv_dense_small_n(const Lds& L, int n, int fin,
   for (int r = 0; r < NACC; ++r) {
     const int i = g + r * G;
     if (i < n) L.h[i * (C + 1) + c] = acc[r] + bc;
+  }
+}
+
+// Form (c), C = 128 (16 channels per wave of the 512-thread workgroup) and enough nodes to fill lanes: lane = NODE, the
+// wave's 16 channels in 16 accumulators per lane.  In forms (a) and (b) a wave's lanes are channels and every operand
+// A[i][f] is ONE LDS address read by all 64 lanes - the LDS spends a full-rate read on a broadcast, and that traffic, not
+// the FMAs, bounded the convolutions (level 0: 52 k cycles for 12 k cycles of FMA issue, level 1: 75 k).  Here a lane reads
+// its own row (one LDS read per feature, re-used for 16 channels) and the weights W[f][c0 .. c0 + 15] are the same for the
+// whole wave: read through the constant address space they arrive as ONE scalar load of 16 dwords per feature and feed
+// the FMAs as scalar operands.  (The weights are not written inside this kernel; global and constant addresses coincide.)
+// Same fma sequence per output as the other forms.
+typedef float floatx16w __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(4))) float* cfloatp;
+typedef const __attribute__((address_space(4))) floatx16w* cfloat16p;
+template <bool ROOT>
+__device__ __forceinline__ void conv_dense_nodes(const Lds& L, int n, int fin, int C, const float* __restrict__ wl,
+                                                 const float* __restrict__ b, const float* __restrict__ wr, const float* A,
+                                                 const float* X) {
+  const int lane = threadIdx.x & 63;
+  const int c0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 16;
+  const cfloatp wlc = (cfloatp)wl + c0, wrc = ROOT ? (cfloatp)wr + c0 : (cfloatp)wl + c0, bcp = (cfloatp)b + c0;
+  const floatx16w bias = *(cfloat16p)bcp;
+  for (int base = 0; base < n; base += 64) {
+    const int i = min(base + lane, n - 1);      // (lanes past n re-read row n - 1, never stored)
+    const float* ar = A + i * fin;
+    const float* xr = X + i * fin;
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+#pragma unroll 2
+    for (int f = 0; f < fin; ++f) {
+      const floatx16w w1 = *(cfloat16p)(wlc + f * C);
+      const float a = ar[f];
+      floatx16w w2 = w1;
+      float xv = 0.f;
+      if (ROOT) {
+        w2 = *(cfloat16p)(wrc + f * C);
+        xv = xr[f];
+      }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        acc[k] = fmaf(w1[k], a, acc[k]);
+        if (ROOT) acc[k] = fmaf(w2[k], xv, acc[k]);
+      }
+    }
+    if (base + lane < n) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) L.h[i * (C + 1) + c0 + k] = acc[k] + bias[k];
+    }
   }
 }
 
@@ -298,7 +381,12 @@ __device__ __forceinline__ void run_level(const Lds& L, const Level& lv, int C, 
   GT_STAMP(1)
   // ---- dense part
   const int G = WGT / C;
-  if (fin <= 32) {
+  if (C == 16 * (WGT / 64) && n >= 16 && fin <= MDQ_GCN_FORMC_MAXFIN) {        // lane = node, scalar weights (form (c))
+    if (lv.type == 0)
+      conv_dense_nodes<true>(L, n, fin, C, lv.wl, lv.b, lv.wr, L.agg, L.x);
+    else
+      conv_dense_nodes<false>(L, n, fin, C, lv.wl, lv.b, nullptr, L.agg, L.x);
+  } else if (fin <= 32) {
     if (lv.type == 0)
       conv_dense_small_fin_any<true>(L, n, fin, C, lv.wl, lv.b, lv.wr, L.agg, L.x);
     else
@@ -312,10 +400,12 @@ __device__ __forceinline__ void run_level(const Lds& L, const Level& lv, int C, 
     const int per = (n + G - 1) / G;   // nodes per thread (workgroup-uniform)
     if (lv.type == 0) {
       if (per <= 1) conv_dense_small_n<true, 1>(L, n, fin, C, lv.wl, lv.b, lv.wr, L.agg, L.x, wbuf);
+      else if (per <= 5) conv_dense_small_n<true, 5>(L, n, fin, C, lv.wl, lv.b, lv.wr, L.agg, L.x, wbuf);
       else if (per <= 8) conv_dense_small_n<true, 8>(L, n, fin, C, lv.wl, lv.b, lv.wr, L.agg, L.x, wbuf);
       else conv_dense_small_n<true, NACC>(L, n, fin, C, lv.wl, lv.b, lv.wr, L.agg, L.x, wbuf);
     } else {
       if (per <= 1) conv_dense_small_n<false, 1>(L, n, fin, C, lv.wl, lv.b, nullptr, L.agg, L.x, wbuf);
+      else if (per <= 5) conv_dense_small_n<false, 5>(L, n, fin, C, lv.wl, lv.b, nullptr, L.agg, L.x, wbuf);
       else if (per <= 8) conv_dense_small_n<false, 8>(L, n, fin, C, lv.wl, lv.b, nullptr, L.agg, L.x, wbuf);
       else conv_dense_small_n<false, NACC>(L, n, fin, C, lv.wl, lv.b, nullptr, L.agg, L.x, wbuf);
     }

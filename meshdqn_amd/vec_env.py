@@ -214,6 +214,13 @@ class VecEnv2DAirfoil:
                                    done=torch.cuda.Event()) for _ in range(2)]
             self._flow_n = 0          # flows launched
             self._flow_prev = None
+            # TWO sets of the flow engine's inputs (private meshes + start fields): the main stream fills set k % 2 for
+            # flow k while flow k - 1 still reads the other one.  With one set the hand-over was a serial chain - flow
+            # k - 1 ends -> main copies -> flow k starts, two event round trips + the copy per step on the flow's
+            # critical path - and the S3 step lasted (flow leg + ~70 us) instead of max(main chain, flow leg).
+            ft, t0 = self._ftopo, self.flow_ts[0]
+            self._flow_in = [dict(coords=ft.coords, cells=ft.cells, nv=ft.nv, nt=ft.nt, u_n=t0["u_n"], p_n=t0["p_n"])]
+            self._flow_in.append({k: torch.zeros_like(a) for k, a in self._flow_in[0].items()})
 
     def _flow(self, keep, out_u, out_p):
         """`flow_steps` IPCS steps on every (coarsened) mesh, warm-started from the interpolated last snapshot."""
@@ -252,12 +259,18 @@ class VecEnv2DAirfoil:
         ft, dt = self._ftopo, self.dtopo
         t, d = self.flow_ts[0], self.flow_descs[0]
         main = torch.cuda.current_stream(self.device)
-        if self._flow_prev is not None:
-            main.wait_event(self._flow_res[self._flow_prev]["done"])     # the previous flow still reads the private meshes
+        fin = self._flow_in[self._flow_n % 2]
+        # flow k - 2 read this input set (long finished).  Inside a graph capture only events recorded IN the capture may be
+        # waited for (HIP takes an older event of the - by then capturing - flow stream for a captured one and the capture
+        # ends "unjoined"); `rollout_graph` has waited for the older flows on the host, before the capture and before
+        # every replay.
+        base = getattr(self, "_flow_capture_base", None)
+        if self._flow_n >= 2 and self._flow_prev is not None and (base is None or self._flow_n - 2 >= base):
+            main.wait_event(self._flow_res[self._flow_n % 2]["done"])
         # meshes + the warm start (the in-place reset of a terminated environment rewrites its rows of out_u / out_p) in
         # ONE launch (six torch copies were ~50 us of the main chain)
         su, sp_ = out_u[:, self.S - 1], out_p[:, self.S - 1]
-        pairs = [(ft.coords, dt.coords), (ft.cells, dt.cells), (ft.nv, dt.nv), (ft.nt, dt.nt), (t["u_n"], su), (t["p_n"], sp_)]
+        pairs = [(fin["coords"], dt.coords), (fin["cells"], dt.cells), (fin["nv"], dt.nv), (fin["nt"], dt.nt), (fin["u_n"], su), (fin["p_n"], sp_)]
         n = len(pairs)
         vp, i64 = C.c_void_p * n, C.c_int64 * n
         rows, rb, ss, ds = [], [], [], []
@@ -274,10 +287,13 @@ class VecEnv2DAirfoil:
         _lib.check(self.lib.mdq_copy_strided(n, vp(*[d_.data_ptr() for d_, _ in pairs]), vp(*[s_.data_ptr() for _, s_ in pairs]),
                                              i64(*rows), i64(*rb), i64(*ss), i64(*ds), _lib.stream_ptr()), "mdq_copy_strided")
         self._flow_ready.record(main)
-        keep = dict(coords=ft.coords, cell_dofs=ft.t["cell_dofs"], af_facets=ft.t["af_facets"], nv=ft.nv, nt=ft.nt,
-                    ne=ft.t["ne"], naf=ft.t["naf"])
+        keep = dict(coords=fin["coords"], cell_dofs=ft.t["cell_dofs"], af_facets=ft.t["af_facets"], nv=fin["nv"], nt=fin["nt"],
+                    ne=ft.t["ne"], naf=ft.t["naf"], u_n=fin["u_n"], p_n=fin["p_n"])
         for kk, v in keep.items():
             setattr(d, kk, v.data_ptr())
+        for kk in ("coords", "cells", "nv", "nt"):            # the flow's topology engine reads the same set
+            setattr(ft.desc, kk, fin[kk].data_ptr())
+        t["u_n"], t["p_n"] = fin["u_n"], fin["p_n"]
         res = self._flow_res[self._flow_n % 2]
         with torch.cuda.stream(self._flow_stream):
             self._flow_stream.wait_event(self._flow_ready)
@@ -732,12 +748,16 @@ class VecEnv2DAirfoil:
             interp_i, flow_par = getattr(self, "_interp_i", 0), (self._flow_n % 2 if self.flow_overlap else 0)
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=cur):
-                ro["state"] = self._state_device()    # (the graph's first node: the state from the current device data)
-                for _ in range(K):
-                    self.rollout_step(ro, fused, pack=False)
-                if self.flow_overlap:
-                    cur.wait_stream(self._flow_stream)   # the flow leg joins before the capture ends
+            self._flow_capture_base = self._flow_n if self.flow_overlap else None
+            try:
+                with torch.cuda.graph(g, stream=cur):
+                    ro["state"] = self._state_device()    # (the graph's first node: the state from the current device data)
+                    for _ in range(K):
+                        self.rollout_step(ro, fused, pack=False)
+                    if self.flow_overlap:
+                        cur.wait_stream(self._flow_stream)   # the flow leg joins before the capture ends
+            finally:
+                self._flow_capture_base = None
             ent = graphs[key] = dict(g=g, ro=ro, interp_i=interp_i, flow_par=flow_par,
                                      post={k: getattr(self, k, None) for k in self._GRAPH_HOST_STATE})
         else:
