@@ -617,23 +617,27 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     if (tid == 0) status[b] = -5;
     return;
   }
+  // (one thread per ENTRY: as one thread per facet the 36 reads of the cell's dofs were a chain of L2 round trips)
+  int* ofe = reinterpret_cast<int*>(R + 61440);              // [nof] outflow edges in edge order (behind `fill`)
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     const int e = tid * PER + i;
     if (e < ne && flg[i]) {
       pf[ea[e]] = 1;
       pf[eb[e]] = 1;
-      const int c = eown[e] / 3, k = eown[e] % 3;
-      cof[c] = (int8_t)k;
-      const int rows[3] = {k == 0 ? 1 : 0, k == 2 ? 1 : 2, 3 + k};
-      const int base = 18 * scanb[e];
-      for (int q = 0; q < 3; ++q)
-        for (int j = 0; j < 6; ++j) {
-          const int row = cd[rows[q] * D.NT + c], col = cd[j * D.NT + c];
-          ekey[base + 6 * q + j] = ((uint32_t)row << 20) | ((uint32_t)col << 8);  // (src breaks ties below)
-          esrc[base + 6 * q + j] = c * 36 + rows[q] * 6 + j;
-        }
+      cof[eown[e] / 3] = (int8_t)(eown[e] % 3);
+      ofe[scanb[e]] = e;
     }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < nent; idx += TW) {
+    const int f = idx / 18, rem = idx - 18 * f, q = rem / 6, j = rem - 6 * q;
+    const int e = ofe[f];
+    const int c = eown[e] / 3, k = eown[e] % 3;
+    const int rowl = q == 0 ? (k == 0 ? 1 : 0) : (q == 1 ? (k == 2 ? 1 : 2) : 3 + k);
+    const int row = cd[rowl * D.NT + c], col = cd[j * D.NT + c];
+    ekey[idx] = ((uint32_t)row << 20) | ((uint32_t)col << 8);  // (src breaks ties below)
+    esrc[idx] = c * 36 + rowl * 6 + j;
   }
   __syncthreads();
   {
@@ -692,11 +696,16 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   // packed per-triangle metadata
   for (int i = 0; i < 6; ++i)
     for (int t = tid; t < nt; t += TW) scat[i * D.NT + t] = cd[i * D.NT + t] | (i == 0 ? ((int32_t)(cof[t] + 1) << 28) : 0);
-  // dof <- element-slot gathers, ascending slots: count, scan, unordered fill, per-dof sort of the (short) lists
+  // dof <- element-slot gathers, ascending slots: count, scan, unordered fill and per-dof sort of the (short) lists in an
+  // LDS staging array (slot ids fit 16 bits), then one coalesced copy out.  (Filling and insertion-sorting the lists
+  // in global memory was 78 k cycles of dependent L2 round trips for the two lists.)
+  uint16_t* stage = reinterpret_cast<uint16_t*>(R);          // [nl * nt] <= 6 TNT entries = 24 KB (blist .. cntd are dead)
+  static_assert(6 * TNT * 2 <= 20480 + (TNP + 8) * 4, "gather staging fits in front of `fill`");
   auto gather = [&](int nl, int ndof, int32_t* gptr, int32_t* gsrc) {
     for (int i = tid; i < TNS; i += TW) scanb[i] = 0;
     __syncthreads();
-    for (int s = tid; s < nl * nt; s += TW) atomicAdd(&scanb[cd[(s % nl) * D.NT + s / nl]], 1);
+    for (int i = 0; i < nl; ++i)
+      for (int t = tid; t < nt; t += TW) atomicAdd(&scanb[cd[i * D.NT + t]], 1);
     __syncthreads();
     const int tot = scan_excl(scanb, TNS, part);
     (void)tot;
@@ -705,23 +714,26 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
       if (i < ndof) fill[i] = 0;
     }
     __syncthreads();
-    for (int s = tid; s < nl * nt; s += TW) {
-      const int dof = cd[(s % nl) * D.NT + s / nl];
-      gsrc[scanb[dof] + atomicAdd(&fill[dof], 1)] = s;   // slot = t * nl + i with t = s / nl, i = s % nl
-    }
+    for (int i = 0; i < nl; ++i)
+      for (int t = tid; t < nt; t += TW) {
+        const int dof = cd[i * D.NT + t];
+        stage[scanb[dof] + atomicAdd(&fill[dof], 1)] = (uint16_t)(t * nl + i);   // slot = t * nl + i
+      }
     __syncthreads();
     for (int i = tid; i < ndof; i += TW) {
       const int q0 = scanb[i], q1 = q0 + fill[i];
       for (int a_ = q0 + 1; a_ < q1; ++a_) {
-        const int32_t w = gsrc[a_];
+        const uint16_t w = stage[a_];
         int j = a_ - 1;
-        while (j >= q0 && gsrc[j] > w) {
-          gsrc[j + 1] = gsrc[j];
+        while (j >= q0 && stage[j] > w) {
+          stage[j + 1] = stage[j];
           --j;
         }
-        gsrc[j + 1] = w;
+        stage[j + 1] = w;
       }
     }
+    __syncthreads();
+    for (int q = tid; q < nl * nt; q += TW) gsrc[q] = stage[q];
     __syncthreads();
   };
   TT_STAMP(9)
@@ -729,17 +741,35 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   TT_STAMP(10)
   gather(6, n2, O.g2_ptr + Bq * (D.NP + 1), O.g2_src + Bq * 6 * D.NT);
   TT_STAMP(11)
-  // SELL-64 pattern of the P1 Laplacian: row = {vertex} + neighbours, ascending; slice width = longest row
-  for (int i = tid; i < TNS; i += TW) scanb[i] = i < nv ? 1 : 0;   // the diagonal
+  // SELL-64 pattern of the P1 Laplacian: row = {vertex} + neighbours, ascending; slice width = longest row.
+  // The neighbour lists come from the edge arrays, all in LDS: degree by atomics, scan, unordered fill, then every row
+  // ranks its (distinct) entries by counting.  (The first version collected a row's columns from its incident cells
+  // through the g1 lists and the cell array in GLOBAL memory into a dynamically indexed local array: chains of dependent
+  // L2 round trips and scratch traffic, 95 k of the flow variant's 570 k cycles.)
+  uint16_t* adjl = reinterpret_cast<uint16_t*>(R);           // [2 ne] <= 2 TNE entries (blist .. poly are dead)
+  int* rptr = cntd;                                          // [nv + 1] row pointers of adjl (cntd is dead)
+  int* rcur = cntd + TNV + 8;                                // [nv] fill cursors
+  for (int i = tid; i < TNS; i += TW) scanb[i] = 0;
   __syncthreads();
   for (int e = tid; e < ne; e += TW) {
     atomicAdd(&scanb[ea[e]], 1);
     atomicAdd(&scanb[eb[e]], 1);
   }
   __syncthreads();
-  for (int i = tid; i < nv; i += TW) fill[i] = scanb[i];   // row lengths (1 + number of incident edges)
+  for (int i = tid; i < nv; i += TW) {
+    fill[i] = scanb[i] + 1;   // row lengths (the diagonal + the incident edges)
+    rcur[i] = 0;
+  }
   __syncthreads();
-  // every thread owns whole rows: it collects the columns of its row from the row's incident cells (g1 lists)
+  scan_excl(scanb, TNS, part);
+  for (int i = tid; i <= nv; i += TW) rptr[i] = i < nv ? scanb[i] : 2 * ne;
+  __syncthreads();
+  for (int e = tid; e < ne; e += TW) {
+    const int a_ = ea[e], b_ = eb[e];
+    adjl[rptr[a_] + atomicAdd(&rcur[a_], 1)] = (uint16_t)b_;
+    adjl[rptr[b_] + atomicAdd(&rcur[b_], 1)] = (uint16_t)a_;
+  }
+  __syncthreads();
   {
     int32_t* so = O.sl1_off + Bq * (D.NV / 64 + 2);
     int32_t* sc = O.sl1_col + Bq * O.NSE1;
@@ -758,36 +788,25 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
       return;
     }
     for (int s_ = tid; s_ <= ns; s_ += TW) so[s_] = s_ < ns ? scanb[s_] : total;
-    const int32_t* g1p = O.g1_ptr + Bq * (D.NV + 1);
-    const int32_t* g1s = O.g1_src + Bq * 3 * D.NT;
     for (int r = tid; r < 64 * ns; r += TW) {
       const int s_ = r >> 6, l = r & 63;
       const int base = scanb[s_], w = ((s_ + 1 < ns ? scanb[s_ + 1] : total) - base) >> 6;
-      int len = 0;
-      int cols[24];
-      if (r < nv) {
-        cols[len++] = r;
-        for (int q = g1p[r]; q < g1p[r + 1]; ++q) {
-          const int t = g1s[q] / 3;
-          for (int k = 0; k < 3; ++k) {
-            const int c = tri[3 * t + k];
-            bool seen = false;
-            for (int j = 0; j < len; ++j) seen = seen || cols[j] == c;
-            if (!seen && len < 24) cols[len++] = c;
-          }
-        }
-        for (int a_ = 1; a_ < len; ++a_) {
-          const int wv = cols[a_];
-          int j = a_ - 1;
-          while (j >= 0 && cols[j] > wv) {
-            cols[j + 1] = cols[j];
-            --j;
-          }
-          cols[j + 1] = wv;
-        }
-      }
       const int rr = min(r, nv - 1);
-      for (int j = 0; j < w; ++j) sc[base + 64 * j + l] = j < len ? cols[j] : rr;
+      int len = 0;
+      if (r < nv) {
+        const int q0 = rptr[r], q1 = rptr[r + 1];
+        len = q1 - q0 + 1;
+        int below = 0;                                       // neighbours below the diagonal
+        for (int q = q0; q < q1; ++q) {
+          const int v = adjl[q];
+          int rank = v > r ? 1 : 0;                          // (the diagonal entry)
+          for (int q2 = q0; q2 < q1; ++q2) rank += adjl[q2] < v ? 1 : 0;
+          below += v < r ? 1 : 0;
+          sc[base + 64 * rank + l] = v;
+        }
+        sc[base + 64 * below + l] = r;
+      }
+      for (int j = len; j < w; ++j) sc[base + 64 * j + l] = rr;
     }
   }
   TT_STAMP(6)
