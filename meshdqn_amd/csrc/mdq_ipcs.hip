@@ -422,10 +422,47 @@ extern "C" int mdq_st_trace_host(long long* out, int reset) {
 #define ST_STAMP(k)
 #endif
 
+// ST: the per-cell / per-dof data the row loops chase (geometry, cell dofs, Dirichlet flags and values, the P1 scaling) is
+// staged in LDS first.  The row loops are chains of dependent loads (slot -> geometry / dofs -> flags -> values, per
+// incident cell of every row): from global memory each level is an L2 round trip and the kernel was 270 k cycles of
+// latency (P2 rows 134 k, P1 values 71 k, P1 diagonal 33 k); from LDS a level costs a tenth of that.
+// 52 NT + 9 N2 + 9 NV bytes: 119 KB for ys930; a mesh that does not fit runs the unstaged instance.
+template <bool ST>
 __global__ __launch_bounds__(WG) void setup_matfree_kernel(mdq_ipcs_desc d) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const EnvView v = env_view(d, b);
   const double a = d.rho / d.dt, mu = d.mu;
+  extern __shared__ __align__(16) unsigned char setup_lds[];
+  double* sGeo = reinterpret_cast<double*>(setup_lds);             // [5][NT]
+  double* sGx = sGeo + 5 * (size_t)d.NT;                            // [N2]
+  double* sSd = sGx + d.N2;                                         // [NV]
+  uint16_t* sCd = reinterpret_cast<uint16_t*>(sSd + d.NV);          // [6][NT]
+  uint8_t* sFl = reinterpret_cast<uint8_t*>(sCd + 6 * (size_t)d.NT);  // [N2]
+  uint8_t* sPf = sFl + d.N2;                                        // [NV]
+  auto geo = [&](int e) -> Geo {
+    if (!ST) return load_geo(v, e);
+    Geo g;
+    g.j00 = sGeo[0 * v.NT + e];
+    g.j01 = sGeo[1 * v.NT + e];
+    g.j10 = sGeo[2 * v.NT + e];
+    g.j11 = sGeo[3 * v.NT + e];
+    g.det = sGeo[4 * v.NT + e];
+    return g;
+  };
+  auto cdof = [&](int j, int e) -> int { return ST ? (int)sCd[j * v.NT + e] : v.cell_dofs[j * v.NT + e]; };
+  auto uflag = [&](int i) -> bool { return ST ? sFl[i] != 0 : v.bcu_flag[i] != 0; };
+  auto ugx = [&](int i) -> double { return ST ? sGx[i] : v.bcu_gx[i]; };
+  auto pflag = [&](int i) -> bool { return ST ? sPf[i] != 0 : v.bcp_flag[i] != 0; };
+  auto sdk = [&](int i) -> double { return ST ? sSd[i] : v.sdiagK[i]; };
+  if (ST) {
+    for (int j = 0; j < 6; ++j)
+      for (int e = tid; e < v.nt; e += WG) sCd[j * v.NT + e] = (uint16_t)v.cell_dofs[j * v.NT + e];
+    for (int i = tid; i < v.n2; i += WG) {
+      sFl[i] = v.bcu_flag[i];
+      sGx[i] = v.bcu_gx[i];
+    }
+    for (int i = tid; i < v.nv; i += WG) sPf[i] = v.bcp_flag[i];
+  }
   // reference-element tables in LDS: the row loops index them with the (lane-dependent) local row of a slot; from
   // constant memory that is one more dependent round trip per local column inside the conditional column loop
   __shared__ double sMhat[6][6];
@@ -441,11 +478,19 @@ __global__ __launch_bounds__(WG) void setup_matfree_kernel(mdq_ipcs_desc d) {
     const double J00 = X[1][0] - X[0][0], J01 = X[2][0] - X[0][0];
     const double J10 = X[1][1] - X[0][1], J11 = X[2][1] - X[0][1];
     const double det = J00 * J11 - J01 * J10;
-    v.geom[0 * v.NT + e] = J11 / det;
-    v.geom[1 * v.NT + e] = -J01 / det;
-    v.geom[2 * v.NT + e] = -J10 / det;
-    v.geom[3 * v.NT + e] = J00 / det;
-    v.geom[4 * v.NT + e] = fabs(det);
+    const double q0 = J11 / det, q1 = -J01 / det, q2 = -J10 / det, q3 = J00 / det, q4 = fabs(det);
+    v.geom[0 * v.NT + e] = q0;
+    v.geom[1 * v.NT + e] = q1;
+    v.geom[2 * v.NT + e] = q2;
+    v.geom[3 * v.NT + e] = q3;
+    v.geom[4 * v.NT + e] = q4;
+    if (ST) {
+      sGeo[0 * v.NT + e] = q0;
+      sGeo[1 * v.NT + e] = q1;
+      sGeo[2 * v.NT + e] = q2;
+      sGeo[3 * v.NT + e] = q3;
+      sGeo[4 * v.NT + e] = q4;
+    }
   }
   __syncthreads();
   ST_STAMP(0)
@@ -482,18 +527,18 @@ __global__ __launch_bounds__(WG) void setup_matfree_kernel(mdq_ipcs_desc d) {
       double gj[2][6];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        gg[u] = load_geo(v, ee[u]);
+        gg[u] = geo(ee[u]);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) cj[u][j] = v.cell_dofs[j * v.NT + ee[u]];
+        for (int j = 0; j < 6; ++j) cj[u][j] = cdof(j, ee[u]);
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) fj[u][j] = v.bcu_flag[cj[u][j]] != 0;
+        for (int j = 0; j < 6; ++j) fj[u][j] = uflag(cj[u][j]);
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) gj[u][j] = v.bcu_gx[cj[u][j]];
+        for (int j = 0; j < 6; ++j) gj[u][j] = ugx(cj[u][j]);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         if (u == 1 && !two) break;
@@ -554,8 +599,8 @@ __global__ __launch_bounds__(WG) void setup_matfree_kernel(mdq_ipcs_desc d) {
         dg.x -= 0.5 * mu * bv.x;
         dg.y -= 0.5 * mu * bv.w;
       }
-      if (v.bcu_flag[c]) {
-        const double gx = v.bcu_gx[c];
+      if (uflag(c)) {
+        const double gx = ugx(c);
         l1.x -= 0.5 * mu * bv.x * gx;
         l1.y -= 0.5 * mu * bv.z * gx;
       }
@@ -565,7 +610,7 @@ __global__ __launch_bounds__(WG) void setup_matfree_kernel(mdq_ipcs_desc d) {
   }
   __syncthreads();
   for (int r = tid; r < v.n2; r += WG) {
-    const bool fr = v.bcu_flag[r] != 0;
+    const bool fr = uflag(r);
     const double2 dg = v.idiag1[r];
     v.idiag1[r] = fr ? make_double2(1.0, 1.0) : make_double2(1.0 / dg.x, 1.0 / dg.y);
     v.sdiagM[r] = fr ? 1.0 : sqrt(v.sdiagM[r]);
@@ -580,16 +625,20 @@ __global__ __launch_bounds__(WG) void setup_matfree_kernel(mdq_ipcs_desc d) {
       int j = -1;
 #pragma unroll
       for (int q = 0; q < 3; ++q)
-        if (v.cell_dofs[q * v.NT + e] == c) j = q;
+        if (cdof(q, e) == c) j = q;
       if (j < 0) continue;
-      const Geo g = load_geo(v, e);
+      const Geo g = geo(e);
       const double dix = sel3(i, -g.j00 - g.j10, g.j00, g.j10), diy = sel3(i, -g.j01 - g.j11, g.j01, g.j11);
       const double djx = sel3(j, -g.j00 - g.j10, g.j00, g.j10), djy = sel3(j, -g.j01 - g.j11, g.j01, g.j11);
       kk += 0.5 * g.det * (dix * djx + diy * djy);
     }
     return kk;
   };
-  for (int r = tid; r < v.nv; r += WG) v.sdiagK[r] = v.bcp_flag[r] ? 1.0 : sqrt(k1_entry(r, r));
+  for (int r = tid; r < v.nv; r += WG) {
+    const double sd = pflag(r) ? 1.0 : sqrt(k1_entry(r, r));
+    v.sdiagK[r] = sd;
+    if (ST) sSd[r] = sd;
+  }
   __syncthreads();
   ST_STAMP(4)
   const int rows1 = ((v.nv + 63) >> 6) << 6;
@@ -615,17 +664,17 @@ __global__ __launch_bounds__(WG) void setup_matfree_kernel(mdq_ipcs_desc d) {
         vals[j] = 0.0;
       }
       if (r < v.nv) {
-        if (v.bcp_flag[r]) {
+        if (pflag(r)) {
 #pragma unroll
           for (int j = 0; j < KW; ++j) vals[j] = cols[j] == r ? 1.0 : 0.0;
         } else {
           for (int s_ = v.g1_ptr[r]; s_ < v.g1_ptr[r + 1]; ++s_) {
             const int slot = v.g1_src[s_];
             const int e = slot / 3, i = slot - e * 3;
-            const Geo g = load_geo(v, e);
+            const Geo g = geo(e);
             int cq[3];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) cq[q] = v.cell_dofs[q * v.NT + e];
+            for (int q = 0; q < 3; ++q) cq[q] = cdof(q, e);
             const double dix = sel3(i, -g.j00 - g.j10, g.j00, g.j10), diy = sel3(i, -g.j01 - g.j11, g.j01, g.j11);
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
@@ -635,12 +684,12 @@ __global__ __launch_bounds__(WG) void setup_matfree_kernel(mdq_ipcs_desc d) {
               for (int j = 0; j < KW; ++j) vals[j] += cols[j] == cq[q] ? val : 0.0;
             }
           }
-          const double sr = v.sdiagK[r];
+          const double sr = sdk(r);
 #pragma unroll
           for (int j = 0; j < KW; ++j) {
             if (cols[j] >= 0) {
               const int c = cols[j];
-              vals[j] = v.bcp_flag[c] ? (c == r ? 1.0 : 0.0) : vals[j] / (sr * v.sdiagK[c]);
+              vals[j] = pflag(c) ? (c == r ? 1.0 : 0.0) : vals[j] / (sr * sdk(c));
             }
           }
         }
@@ -658,10 +707,10 @@ __global__ __launch_bounds__(WG) void setup_matfree_kernel(mdq_ipcs_desc d) {
         const int c = v.sl1_col[ps];
         if (c > prev) {  // real entry (columns ascend; the padding repeats the row index)
           prev = c;
-          if (v.bcp_flag[r] || v.bcp_flag[c])
+          if (pflag(r) || pflag(c))
             kk = (c == r) ? 1.0 : 0.0;
           else
-            kk = k1_entry(r, c) / (v.sdiagK[r] * v.sdiagK[c]);
+            kk = k1_entry(r, c) / (sdk(r) * sdk(c));
         }
       }
       v.K1s[ps] = kk;
@@ -4177,8 +4226,18 @@ int mdq_ipcs_setup_matfree(const mdq_ipcs_desc* d, void* stream) {
   if (d->nbo && (!d->bo_rows || !d->bo_ptr || !d->bo_col || !d->bo_src || !d->bo_val))
     return fail_msg("mdq_ipcs_setup_matfree: outflow row list incomplete");
   if (int rc = ensure_tables()) return rc;
-  hipLaunchKernelGGL(setup_matfree_kernel, dim3(d->B), dim3(WG), 0, (hipStream_t)stream, *d);
-  hipError_t e = hipGetLastError();
+  // staged instance when the mesh's per-cell / per-dof data fit the LDS beside the kernel's static tables
+  const size_t stage_bytes = 52 * (size_t)d->NT + 9 * (size_t)d->N2 + 9 * (size_t)d->NV + 64;
+  hipError_t e;
+  if (stage_bytes <= 156 * 1024) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&setup_matfree_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)stage_bytes);
+    if (e != hipSuccess) return fail("setup_matfree_kernel attribute", e);
+    hipLaunchKernelGGL(setup_matfree_kernel<true>, dim3(d->B), dim3(WG), stage_bytes, (hipStream_t)stream, *d);
+  } else {
+    hipLaunchKernelGGL(setup_matfree_kernel<false>, dim3(d->B), dim3(WG), 0, (hipStream_t)stream, *d);
+  }
+  e = hipGetLastError();
   if (e != hipSuccess) return fail("setup_matfree_kernel launch", e);
   return 0;
 }
