@@ -55,31 +55,22 @@ struct Lds {
   int* misc;     // [8]
 };
 
-// CSR by target (sources kept in edge order => deterministic sums).  T = 1..8 threads per target node, each scanning
-// a contiguous part of the edge list four entries per LDS read (esrc / edst / adj are 16-byte aligned; the padding of
-// the last quad never matches).  Counting the (node, part) pairs in lane order, a workgroup-wide inclusive scan
-// (wave shuffles + one exchange of the wave totals) gives every pair the position of its first entry directly.
+// CSR by target (sources kept in edge order => deterministic sums): in-degrees by LDS atomics, a workgroup-wide
+// exclusive scan (wave shuffles + one exchange of the wave totals), an unordered fill of EDGE IDS through per-node
+// cursors, then every node sorts its (short) list of edge ids and replaces them by the sources.  (The first version
+// let 2-8 threads per node scan the whole edge list: O(n E) comparisons, 34 k of the kernel's 320 k cycles at level 0.)
 __device__ __forceinline__ void build_csr(const Lds& L, int n, int E) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int E4 = (E + 3) >> 2;
-  const int4* d4 = reinterpret_cast<const int4*>(L.edst);
-  const int4* s4 = reinterpret_cast<const int4*>(L.esrc);
-  if (tid < 4 && E + tid < 4 * E4) L.edst[E + tid] = -1;   // the tail of the last quad matches no node
+  int* cnt = L.newid;       // [n] degree, then fill cursor (newid is dead until this level's pooling)
   int* wtot = L.misc + 8;   // [WGT / 64] wave totals
-  int sh = 0;               // log2(T)
-  while (sh < 3 && (n << (sh + 1)) <= WGT) ++sh;
-  const int T = 1 << sh, QP = (E4 + T - 1) >> sh;          // quads per part
+  for (int i = tid; i < n; i += WGT) cnt[i] = 0;
+  __syncthreads();
+  for (int e = tid; e < E; e += WGT) atomicAdd(&cnt[L.edst[e]], 1);
   __syncthreads();
   int carry = 0;
-  for (int base = 0; base < (n << sh); base += WGT) {       // (n * T <= WGT whenever n <= WGT: one pass)
-    const int el = base + tid, i = el >> sh, t = el & (T - 1);
-    const int qa = min(t * QP, E4), qb = min(qa + QP, E4);
-    int c = 0;
-    if (i < n)
-      for (int q = qa; q < qb; ++q) {
-        const int4 d = d4[q];
-        c += (d.x == i) + (d.y == i) + (d.z == i) + (d.w == i);
-      }
+  for (int base = 0; base < n; base += WGT) {
+    const int i = base + tid;
+    const int c = i < n ? cnt[i] : 0;
     int v = c;   // inclusive scan inside the wave
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -94,24 +85,33 @@ __device__ __forceinline__ void build_csr(const Lds& L, int n, int E) {
       if (w < wave) pre += wt;
       all += wt;
     }
-    int p = pre + v - c;   // first entry of this (node, part)
     if (i < n) {
-      if (t == 0) L.adj_ptr[i] = p;
-      for (int q = qa; q < qb; ++q) {
-        const int4 d = d4[q];
-        if ((d.x == i) | (d.y == i) | (d.z == i) | (d.w == i)) {
-          const int4 sv = s4[q];
-          if (d.x == i) L.adj[p++] = sv.x;
-          if (d.y == i) L.adj[p++] = sv.y;
-          if (d.z == i) L.adj[p++] = sv.z;
-          if (d.w == i) L.adj[p++] = sv.w;
-        }
-      }
+      L.adj_ptr[i] = pre + v - c;
+      cnt[i] = 0;
     }
     carry = all;
     __syncthreads();   // (wtot is rewritten by the next pass)
   }
   if (tid == 0) L.adj_ptr[n] = carry;
+  __syncthreads();
+  for (int e = tid; e < E; e += WGT) {
+    const int d = L.edst[e];
+    L.adj[L.adj_ptr[d] + atomicAdd(&cnt[d], 1)] = e;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += WGT) {
+    const int p0 = L.adj_ptr[i], p1 = L.adj_ptr[i + 1];
+    for (int a_ = p0 + 1; a_ < p1; ++a_) {
+      const int w = L.adj[a_];
+      int j = a_ - 1;
+      while (j >= p0 && L.adj[j] > w) {
+        L.adj[j + 1] = L.adj[j];
+        --j;
+      }
+      L.adj[j + 1] = w;
+    }
+    for (int q = p0; q < p1; ++q) L.adj[q] = L.esrc[L.adj[q]];
+  }
   __syncthreads();
 }
 
@@ -347,6 +347,11 @@ __device__ __forceinline__ void run_level(const Lds& L, const Level& lv, int C, 
 #ifdef MDQ_GCN_TRACE
   long long tq_ = __builtin_amdgcn_s_memtime();
 #endif
+  // the pooling weights of this level, requested now and used after the convolution (as a load in front of the score
+  // phase it was a global round trip - 3 k cycles - on the critical path of every level)
+  float pwv[(256 + WGT - 1) / WGT];
+#pragma unroll
+  for (int q = 0; q < (256 + WGT - 1) / WGT; ++q) pwv[q] = (tid + q * WGT < C) ? lv.pw[tid + q * WGT] : 0.f;
   if (TAPE && tape->esrc)
     for (int e = tid; e < E; e += WGT) {
       tape->esrc[e] = L.esrc[e];
@@ -415,39 +420,33 @@ __device__ __forceinline__ void run_level(const Lds& L, const Level& lv, int C, 
   GT_STAMP(2)
   // ---- relu + score = tanh(h . w / |w|)
   // pool weights once into LDS (L.deg is free here: the aggregation is done)
-  for (int c = tid; c < C; c += WGT) L.deg[c] = lv.pw[c];
+#pragma unroll
+  for (int q = 0; q < (256 + WGT - 1) / WGT; ++q)
+    if (tid + q * WGT < C) L.deg[tid + q * WGT] = pwv[q];
   __syncthreads();
   float wn = 0.f;
 #pragma unroll 16
   for (int c = 0; c < C; ++c) wn = fmaf(L.deg[c], L.deg[c], wn);
   wn = sqrtf(wn);
-  if (n > WGT / 16) {
-    // many nodes: one thread per node walks the channels (relu in place + dot product)
-    for (int i = tid; i < n; i += WGT) {
+  {
+    // 16 lanes per node, each lane a strided slice of the channels, butterfly sum (relu in place + dot product with the
+    // pooling weights); WGT / 16 nodes per pass.  (One thread per node walking all channels - the first version of the
+    // many-node case - kept 3 of 8 waves busy on a 128-step dependent chain: 22 k cycles at level 0.)
+    const int sub = tid % 16;
+    for (int base = 0; base < n; base += WGT / 16) {
+      const int i = base + tid / 16;
       float sp = 0.f;
-#pragma unroll 8
-      for (int c = 0; c < C; ++c) {
-        float hv = L.h[i * (C + 1) + c];
-        hv = hv > 0.f ? hv : 0.f;
-        L.h[i * (C + 1) + c] = hv;
-        sp = fmaf(hv, L.deg[c], sp);
-      }
-      L.score[i] = tanhf(sp / wn);
-    }
-  } else {
-    // few nodes (the pooled levels): 16 lanes per node, each lane a strided slice of the channels, butterfly sum
-    const int i = tid / 16, sub = tid % 16;
-    float sp = 0.f;
-    if (i < n)
-      for (int c = sub; c < C; c += 16) {
-        float hv = L.h[i * (C + 1) + c];
-        hv = hv > 0.f ? hv : 0.f;
-        L.h[i * (C + 1) + c] = hv;
-        sp = fmaf(hv, L.deg[c], sp);
-      }
+      if (i < n)
+        for (int c = sub; c < C; c += 16) {
+          float hv = L.h[i * (C + 1) + c];
+          hv = hv > 0.f ? hv : 0.f;
+          L.h[i * (C + 1) + c] = hv;
+          sp = fmaf(hv, L.deg[c], sp);
+        }
 #pragma unroll
-    for (int off = 8; off > 0; off >>= 1) sp += __shfl_xor(sp, off, 16);
-    if (i < n && sub == 0) L.score[i] = tanhf(sp / wn);
+      for (int off = 8; off > 0; off >>= 1) sp += __shfl_xor(sp, off, 16);
+      if (i < n && sub == 0) L.score[i] = tanhf(sp / wn);
+    }
   }
   __syncthreads();
   GT_STAMP(3)
@@ -491,20 +490,9 @@ __device__ __forceinline__ void run_level(const Lds& L, const Level& lv, int C, 
     __syncthreads();
   }
   // ---- pooled features x'[r][c] = h[perm r][c] * score[perm r]  -> L.x with stride C
-  if (n > WGT / 16) {
-    for (int i = tid; i < n; i += WGT) {
-      const int r = L.newid[i];
-      if (r >= 0) {
-        const float sc = L.score[i];
-#pragma unroll 8
-        for (int c = 0; c < C; ++c) L.x[r * C + c] = L.h[i * (C + 1) + c] * sc;
-      }
-    }
-  } else {
-    for (int idx = tid; idx < n * C; idx += WGT) {
-      const int i = idx / C, c = idx - i * C, r = L.newid[i];
-      if (r >= 0) L.x[r * C + c] = L.h[i * (C + 1) + c] * L.score[i];
-    }
+  for (int idx = tid; idx < n * C; idx += WGT) {
+    const int i = idx / C, c = idx - i * C, r = L.newid[i];
+    if (r >= 0) L.x[r * C + c] = L.h[i * (C + 1) + c] * L.score[i];
   }
   GT_STAMP(5)
   // ---- filter + relabel edges, preserving edge order (wave 0, ballot compaction)
