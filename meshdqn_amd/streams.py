@@ -84,6 +84,15 @@ _CALIBRATED = {}
 LOG = []
 
 
+def profiler_attached() -> bool:
+    """True when the process runs under rocprofv3 / rocprof (their launchers preload a tool library and pass their options
+    through ROCPROF_* / ROCP_* variables)."""
+    import os
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower():
+        return True
+    return any(k.startswith(("ROCPROF_", "ROCP_TOOL", "ROCPROFILER_")) for k in os.environ)
+
+
 def _cu_partition(dev):
     """Compute-unit ranges (lo, hi) of the three roles, or None (plain torch streams).  `MDQ_CU_PARTITION`:
       "full" (default)  every role gets a stream created with a CU mask that covers the WHOLE chip.  Such a stream owns a
@@ -91,13 +100,23 @@ def _cu_partition(dev):
                         queues, which is what removes the stream lottery: measured over repeated processes, plain
                         streams gave 123 k env-steps/s or - flow leg behind the main chain - 85 k depending on the
                         creation history, full-mask streams 123-125 k every time with every probe passing.
-      "0"               plain torch streams (the round-2 behaviour: probes + calibration have to sort the pairs out)
+      "0"               plain torch streams (the round-2 behaviour: probes + calibration have to sort the pairs out).  Chosen
+                        automatically under rocprofv3 (`profiler_attached`): the profiler of ROCm 7.2 dies at exit, before
+                        writing its output, in a process that owns CU-masked queues (a four-line script reproduces it;
+                        destroying the streams first cures the script but not a process with events / graphs on them)
       "1"               main on the first half of the driver's CU numbering, flow + optimiser chain on the second half
                         (the numbering goes round-robin over XCDs and shader engines: each half is half of every shader
                         engine).  Measured SLOWER (97-120 k): the chains do not suffer from sharing compute units.
       "lo:hi,lo:hi,lo:hi"  explicit ranges of main, flow, opt ("-" = a plain stream)."""
     import os
-    spec = os.environ.get("MDQ_CU_PARTITION", _CU_PARTITION_DEFAULT)
+    spec = os.environ.get("MDQ_CU_PARTITION")
+    if spec is None:
+        spec = _CU_PARTITION_DEFAULT
+        if profiler_attached():      # (an explicit MDQ_CU_PARTITION still wins)
+            if not any(e.get("event") == "profiler attached" for e in LOG):
+                LOG.append(dict(event="profiler attached", note="plain torch streams + calibration instead of CU-mask streams: "
+                                "rocprofv3 (ROCm 7.2) dies at exit - before it writes its output - in a process that owns CU-masked queues"))
+            spec = "0"
     if spec in ("", "0"):
         return None
     ncu = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -130,7 +149,7 @@ def _masked_stream(dev, lo, hi):
         mask[i // 32] |= 1 << (i % 32)
     out = C.c_void_p()
     _lib.check(_lib.load().mdq_stream_create_cu_mask(mask, words, C.byref(out)), "mdq_stream_create_cu_mask")
-    return torch.cuda.ExternalStream(out.value, device=dev)
+    return torch.cuda.ExternalStream(out.value, device=dev)      # (kept for the process's lifetime)
 
 
 _CU_PARTITION_DEFAULT = "full"
@@ -173,6 +192,18 @@ def role_streams(device) -> dict:
     LOG.append(dict(device=idx, event="roles created in fixed order", probes=how,
                     cu_partition=None if part is None else {k: (list(v) if v else None) for k, v in part.items()}))
     return r
+
+
+def roles_own_queues(device) -> bool:
+    """True when the roles of `device` are CU-mask streams (a hardware queue each) and every pair passed its probe: there
+    is nothing left for a calibration by timing to decide, and creating more such streams only uses up hardware queues
+    (a process that had created ~25 of them ran its last measurements at half speed: the queues were time-sliced)."""
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    for e in LOG:
+        if e.get("event") == "roles created in fixed order" and e.get("device") == idx:
+            return e.get("cu_partition") is not None and all(v == "probe ok" for v in e.get("probes", {}).values())
+    return False
 
 
 def calibrated_flow_stream(device, main):

@@ -619,6 +619,15 @@ class DQNTrainer:
         real env steps with the loop's own synchronisation; the fastest stays.  The environments are reset afterwards."""
         dev = self.ctx.device
         main = torch.cuda.current_stream(dev)
+        from . import streams as _st
+        if _st.roles_own_queues(dev):
+            roles = _st.role_streams(dev)
+            flow_now = getattr(venv, "_flow_stream", None)
+            if getattr(self, "_opt_stream", None) is roles["opt"] and (flow_now is None or flow_now is roles["flow"]):
+                # CU-mask role streams with every probe passed: a hardware queue each, nothing to choose between
+                self._opt_calibrated_for = (main, flow_now)
+                self.opt_calibration_ms = []
+                return []
         B, N = venv.B, venv.N
         st0 = venv._state_device()
         F_ = st0["x"].shape[2]

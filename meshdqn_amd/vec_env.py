@@ -808,6 +808,12 @@ class VecEnv2DAirfoil:
             self._calibrated_for = cur
             self.calibration_ms = []
             return []
+        if _st.roles_own_queues(dev) and self._flow_stream is _st.role_streams(dev)["flow"]:
+            # CU-mask role streams with every probe passed: a hardware queue each, nothing to choose between
+            self._calibrated_for = cur
+            self.calibration_ms = []
+            _st.remember_flow_stream(dev, cur, self._flow_stream, [], "role streams own their hardware queues: no calibration")
+            return []
         results = []
         how = "first two candidates agree"
         for t in range(max(1, int(tries))):
