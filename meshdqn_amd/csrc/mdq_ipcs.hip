@@ -23,6 +23,9 @@
 #include "mdq_device.h"
 #include "mdq_elem.h"
 
+#ifndef MDQ_PCG_WG_DEFAULT
+#define MDQ_PCG_WG_DEFAULT 512
+#endif
 namespace mdq {
 
 __constant__ RefTab c_tab;
@@ -4321,6 +4324,9 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
         e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&at_pressure_kernel<false, 1024>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e_ == hipSuccess)
+        e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&at_pressure_kernel<true, 1024>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e_ == hipSuccess)
         e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&at_correction_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       return e_;
@@ -4332,6 +4338,12 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
       const char* s_ = std::getenv("MDQ_AT_WG");
       const int w_ = s_ ? std::atoi(s_) : 768;
       return w_ == 512 ? 512 : 768;
+    }();
+    // Krylov pressure kernel: 16 waves x ONE row per thread (MDQ_PCG_WG=1024) or 8 waves x two rows (512)
+    static const int pcg_wg = [] {
+      const char* s_ = std::getenv("MDQ_PCG_WG");
+      const int w_ = s_ ? std::atoi(s_) : MDQ_PCG_WG_DEFAULT;
+      return w_ == 1024 ? 1024 : 512;
     }();
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     if (kernel_ms) {
@@ -4348,6 +4360,8 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
       if (kernel_ms) hipEventRecord(ev[1], st);
       if (d->pd_enabled)
         hipLaunchKernelGGL((at_pressure_kernel<false, 1024>), dim3(d->B), dim3(1024), lds_p, st, *d, iters);
+      else if (k1_lds && pcg_wg == 1024 && d->NV <= 1024)
+        hipLaunchKernelGGL((at_pressure_kernel<true, 1024>), dim3(d->B), dim3(1024), lds_p, st, *d, iters);
       else if (k1_lds)
         hipLaunchKernelGGL(at_pressure_kernel<true>, dim3(d->B), dim3(WG), lds_p, st, *d, iters);
       else

@@ -177,8 +177,12 @@ def role_streams(device) -> dict:
         fp = int(os.environ.get("MDQ_FLOW_PRIORITY", "0"))     # (experiment knob: -1 = high priority for the flow stream)
         part = _cu_partition(dev)
         if part is not None:
-            r = {k: (_masked_stream(dev, *part[k]) if part[k] is not None else torch.cuda.Stream(device=dev)) for k in ("main", "flow", "opt")}
-        else:
+            try:
+                r = {k: (_masked_stream(dev, *part[k]) if part[k] is not None else torch.cuda.Stream(device=dev)) for k in ("main", "flow", "opt")}
+            except Exception as e:       # (a runtime that refuses CU masks: plain streams, probes and calibration as before)
+                LOG.append(dict(device=idx, event="CU-mask streams unavailable", error=str(e)))
+                part = None
+        if part is None:
             r = dict(main=torch.cuda.Stream(device=dev), flow=torch.cuda.Stream(device=dev, priority=fp), opt=torch.cuda.Stream(device=dev))
         how = {}
         for a, b in (("flow", "main"), ("opt", "main"), ("opt", "flow")):

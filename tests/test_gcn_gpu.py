@@ -14,7 +14,8 @@ def _graph(rng, n, e, f):
 
 
 @pytest.mark.parametrize("cls,kw,feat", [("NodeRemovalNet", dict(output_dim=181, conv_width=128, topk=0.1), 17),
-                                          ("AirfoilGCNN", dict(conv_width=64), 17)])
+                                          ("AirfoilGCNN", dict(conv_width=64), 17),
+                                          ("AirfoilGCNN", dict(conv_width=128), 17)])   # (GCNConv at the width of the node-per-lane form)
 def test_fused_forward_matches_oracle(lib_built, cls, kw, feat):
     from meshdqn_amd import airfoilgcnn as prod
     from meshdqn_amd.data import Batch
@@ -30,6 +31,8 @@ def test_fused_forward_matches_oracle(lib_built, cls, kw, feat):
     net_o.load_state_dict(sd)
     net_p = net_p.cuda()
     sizes = [(180, 372), (180, 495), (37, 60), (180, 0), (64, 300), (180, 420)] + [(180, 400)] * 34
+    if cls == "AirfoilGCNN" and kw["conv_width"] == 128:      # (its pooling ratio keeps more rows: 180-node graphs exceed the LDS)
+        sizes = [(100, 250), (64, 150), (37, 60), (100, 0), (90, 300), (17, 30)] + [(100, 220)] * 10
     graphs = [_graph(rng, n, e, feat) for n, e in sizes]
     batch = Batch.from_data_list(graphs)
     with torch.no_grad():
