@@ -359,6 +359,19 @@ __device__ __forceinline__ void sequential_sweep(unsigned char* lds, int n_int, 
   }
 }
 
+#ifdef MDQ_LIN_TRACE
+// debug build only: s_memtime deltas of thread 0 of mesh 0 at the phase boundaries of the set-up
+__device__ long long mdq_lin_trace_buf[16];
+#define LT_STAMP(k) { __syncthreads(); const long long tn_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) mdq_lin_trace_buf[k] += tn_ - tq_; tq_ = tn_; }
+extern "C" int mdq_lin_trace_host(long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mdq_lin_trace_buf), sizeof(long long) * 16) != hipSuccess) return -1;
+  if (reset) { long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(mdq_lin_trace_buf), z, sizeof z) != hipSuccess) return -1; }
+  return 0;
+}
+#else
+#define LT_STAMP(k)
+#endif
+
 __global__ __launch_bounds__(LWG) void smooth_linear_kernel(int NV, int NT, double* coords, const int32_t* cells,
                                                             const int32_t* nv_, const int32_t* nt_, const int32_t* iters_,
                                                             const int32_t* rem, const int32_t* rstat, int iters_env,
@@ -387,6 +400,9 @@ __global__ __launch_bounds__(LWG) void smooth_linear_kernel(int NV, int NT, doub
   uint16_t* nbl = reinterpret_cast<uint16_t*>(lds + OFF_NB);
   int* cnt = reinterpret_cast<int*>(lds + OFF_SROW + 3 * LNT * 4);      // (scratch behind the arrival-order lists)
   static_assert(3 * LNT * 4 + LNV * 4 <= LNV * SROW, "cnt scratch");
+#ifdef MDQ_LIN_TRACE
+  long long tq_ = __builtin_amdgcn_s_memtime();
+#endif
   // ---- vertex -> cells
   for (int v = tid; v < LNV; v += LWG) cnt[v] = 0;
   if (tid < 3) misc[tid] = tid == 2 ? 1 : 0;
@@ -410,6 +426,7 @@ __global__ __launch_bounds__(LWG) void smooth_linear_kernel(int NV, int NT, doub
     }
   }
   __syncthreads();
+  LT_STAMP(0)
   // ---- per vertex: cells in ascending cell order (the fixed order of every later sum), distinct neighbours in order
   // of first appearance with their multiplicity, interior test (every neighbour seen exactly twice)
   for (int v = tid; v < LNV; v += LWG) {
@@ -446,6 +463,7 @@ __global__ __launch_bounds__(LWG) void smooth_linear_kernel(int NV, int NT, doub
     cnt[v] = interior ? 1 : 0;
   }
   __syncthreads();
+  LT_STAMP(1)
   scan_inclusive(cnt, part);
   const int n_int = cnt[LNV - 1];
   const int nb = (n_int + BS - 1) / BS;
@@ -460,6 +478,7 @@ __global__ __launch_bounds__(LWG) void smooth_linear_kernel(int NV, int NT, doub
     if (rk[v] == 0xFFFF)
       for (int q = ptr[v]; q < ptr[v + 1]; ++q) inc[q] = 0xFFFFFFFFu;
   // (tmp / cnt are dead from here on: the solver rows take their place)
+  LT_STAMP(2)
   // ---- per interior rank: gather slots (every neighbour that is not a lower-numbered member of the own block),
   // in-block lower neighbours (the strictly lower triangle of the block), validation flags of the cell entries
   for (int r = tid; r < nb * BS; r += LWG) {
@@ -504,6 +523,7 @@ __global__ __launch_bounds__(LWG) void smooth_linear_kernel(int NV, int NT, doub
     *reinterpret_cast<u4*>(lds + OFF_SROW + r * SROW + 16) = u4{wds[4], wds[5], wds[6], wds[7]};
   }
   __syncthreads();
+  LT_STAMP(3)
   const bool eligible = misc[2] != 0 && n_int > 0;
   if (!eligible) {                               // the careful walk takes all the sweeps
     if (tid == 0) {
@@ -520,13 +540,22 @@ __global__ __launch_bounds__(LWG) void smooth_linear_kernel(int NV, int NT, doub
     const double* r2ktab = reinterpret_cast<const double*>(lds + OFF_R2K);   // 2 x 1 / (2 k) = 1 / k, correctly rounded
     for (int blk = wave; blk < nb; blk += LWG / 64) {
       const int r0 = blk * BS, j = lane & 31;
+      // the 32 rows are a chain (row i needs the rows of its in-block lower neighbours), so what counts is the latency of ONE
+      // row step: its metadata - degree, lower count and the up to 8 lower neighbours, the same for every lane - is loaded
+      // once, one row per lane, and broadcast with v_readlane inside the loop (as LDS reads it was two dependent round
+      // trips in front of the reads of T: 64 k of the set-up's 140 k cycles went into this phase)
+      const uint32_t kdv = kdeg[r0 + j];
+      const uint2 lmv = *reinterpret_cast<const uint2*>(lmeta + (r0 + j) * MAXLOW);
       if (lane < 32) {
         for (int i = 0; i < BS; ++i) {
-          const uint32_t kd = kdeg[r0 + i];
+          const uint32_t kd = (uint32_t)__builtin_amdgcn_readlane((int)kdv, i);
+          const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)lmv.x, i), hi = (uint32_t)__builtin_amdgcn_readlane((int)lmv.y, i);
           const int nl = kd >> 8;
+          // (the reads of T stay in a loop of nl steps: fully unrolled to 8 unconditional reads the step was 2.5x slower -
+          // a lone wave issues ~170 instructions per row then, and issue, not the LDS round trips, bounds the chain)
           double val = 0.0;
           for (int t = 0; t < nl; ++t) {
-            const int w = lmeta[(r0 + i) * MAXLOW + t];
+            const int w = (int)(((t < 4 ? lo : hi) >> (8 * (t & 3))) & 0xFFu);
             if (j <= w) val += T[w * (w + 1) / 2 + j];
           }
           val = val * (2.0 * r2ktab[kd & 0xFF]) + (i == j ? 1.0 : 0.0);
@@ -549,6 +578,7 @@ __global__ __launch_bounds__(LWG) void smooth_linear_kernel(int NV, int NT, doub
   }
   __threadfence_block();
   __syncthreads();
+  LT_STAMP(4)
   // ---- positions (the setup scratch is dead): cur and the snapshot of sweep 0; zero records
   for (int v = tid; v <= LNV; v += LWG) {
     d2 p = {0.0, 0.0};
@@ -561,6 +591,7 @@ __global__ __launch_bounds__(LWG) void smooth_linear_kernel(int NV, int NT, doub
     *reinterpret_cast<d2*>(lds + OFF_SNAP + PBUF + v * 16) = p;
   }
   __syncthreads();   // (also orders the workspace stores of this workgroup before its loads: same CU, same L2)
+  LT_STAMP(5)
   // ---- sweeps.  Two modes:
   //  CHECKED (from sweep 0 until a sweep passes at the first try): solve, then ALL waves validate at once; vertices whose
   //    update was not clearly a full step are flagged and the sweep is redone from its snapshot by repair_sweep (exact
@@ -662,6 +693,7 @@ __global__ __launch_bounds__(LWG) void smooth_linear_kernel(int NV, int NT, doub
       ++s;
     }
   }
+  LT_STAMP(6)
   // ---- result
   __syncthreads();
   for (int v = tid; v < nv; v += LWG) {
