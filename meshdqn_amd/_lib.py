@@ -63,7 +63,7 @@ class InterpDesc(C.Structure):
         ("npts", C.c_void_p), ("np1", C.c_void_p), ("points", C.c_void_p),
         ("src_coords", C.c_void_p), ("src_cell_dofs", C.c_void_p), ("src_geom", C.c_void_p),
         ("bin_ptr", C.c_void_p), ("bin_cells", C.c_void_p), ("src_u", C.c_void_p), ("src_p", C.c_void_p),
-        ("out_u", C.c_void_p), ("out_p", C.c_void_p), ("out_cell", C.c_void_p),
+        ("out_u", C.c_void_p), ("out_p", C.c_void_p), ("out_cell", C.c_void_p), ("src_cellrec", C.c_void_p),
     ]
 
 

@@ -25,6 +25,44 @@ __global__ __launch_bounds__(256) void interpolate_kernel(mdq_interp_desc d) {
     const int bin = gy * d.gnx + gx;
     int best = -1;
     double bxi = 0.0, beta = 0.0, bviol = -1e300;
+    if (d.src_cellrec) {
+      // candidates in batches of CB: their ids in one round trip, their records (vertex 0 + Jinv, 48 bytes) in a second
+      // one, then the same tests in the same order.  (Cell by cell - id, then its dofs, then the vertex - a point paid
+      // three dependent L2 round trips per candidate: the whole kernel was the latency of its longest candidate list.)
+      constexpr int CB = 6;
+      const int s0 = d.bin_ptr[bin], s1 = d.bin_ptr[bin + 1];
+      bool found = false;
+      for (int sb = s0; sb < s1 && !found; sb += CB) {
+        int cid[CB];
+#pragma unroll
+        for (int q = 0; q < CB; ++q) cid[q] = d.bin_cells[min(sb + q, s1 - 1)];
+        double2 r0[CB], r1[CB], r2[CB];
+#pragma unroll
+        for (int q = 0; q < CB; ++q) {
+          const double2* rp = reinterpret_cast<const double2*>(d.src_cellrec + (int64_t)cid[q] * 6);
+          r0[q] = rp[0];
+          r1[q] = rp[1];
+          r2[q] = rp[2];
+        }
+#pragma unroll
+        for (int q = 0; q < CB; ++q) {
+          if (sb + q < s1 && !found) {
+            const double dx = px - r0[q].x, dy = py - r0[q].y;
+            const double xi = r1[q].x * dx + r1[q].y * dy, eta = r2[q].x * dx + r2[q].y * dy;
+            const double l0 = 1.0 - xi - eta;
+            double viol = fmin(fmin(l0, xi), eta);
+            viol = viol < 0.0 ? viol : 0.0;
+            if (viol > bviol) {  // strict: the first (lowest id) best candidate wins
+              bviol = viol;
+              best = cid[q];
+              bxi = xi;
+              beta = eta;
+              if (viol == 0.0) found = true;
+            }
+          }
+        }
+      }
+    } else
     for (int s = d.bin_ptr[bin]; s < d.bin_ptr[bin + 1]; ++s) {
       const int c = d.bin_cells[s];
       const int v0 = d.src_cell_dofs[0 * d.src_nt + c];

@@ -120,6 +120,9 @@ class SnapshotInterpolator:
                       src_cell_dofs=torch.from_numpy(np.ascontiguousarray(topo.cell_dofs.T, np.int32)).to(dev),
                       src_geom=torch.from_numpy(geom).to(dev), bin_ptr=torch.from_numpy(bin_ptr).to(dev),
                       bin_cells=torch.from_numpy(bin_cells).to(dev),
+                      # one record per source cell for the point location: vertex 0 + Jinv (same doubles as src_coords / src_geom)
+                      src_cellrec=torch.from_numpy(np.ascontiguousarray(np.stack(
+                          [X[:, 0, 0], X[:, 0, 1], geom[0], geom[1], geom[2], geom[3]], axis=1))).to(dev),
                       src_u=u_snap.to(dev, torch.float64).contiguous(), src_p=p_snap.to(dev, torch.float64).contiguous())
         self.grid = (gnx, gny, float(lo[0]), float(lo[1]), 1.0 / hx, 1.0 / hy)
 
