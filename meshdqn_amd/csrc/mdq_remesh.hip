@@ -18,7 +18,10 @@
 
 namespace mdq_rm {
 
-constexpr int RW = 256;
+#ifndef MDQ_REMESH_WG
+#define MDQ_REMESH_WG 1024
+#endif
+constexpr int RW = MDQ_REMESH_WG;   // threads per mesh (256 in rounds 1-3: the parallel phases are loops of LDS atomics / hash probes, i.e. latency chains)
 constexpr int RNV = 1024, RNT = 2048, RNS = 3 * RNT, RHS = 8192;
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 
@@ -45,8 +48,9 @@ __global__ __launch_bounds__(RW) void remesh_kernel(int NV, int NT, double* coor
   uint32_t* hkey = reinterpret_cast<uint32_t*>(nbr + RNS);           // [RHS]            32 KB | the flip stack re-uses
   uint32_t* hval = hkey + RHS;                                       // [RHS]            32 KB | this region
   int* stack = reinterpret_cast<int*>(hkey);                         // [2 * RHS]
-  int* misc = reinterpret_cast<int*>(hval + RHS);                    // [80]: counters, star list
+  int* misc = reinterpret_cast<int*>(hval + RHS);                    // [336]: counters, star list, lane 0's work arrays
   int* star = misc + 8;                                              // [64]
+  int* lane0 = misc + 80;                                            // [4][64] ring bookkeeping of the serial part
   const int b = blockIdx.x, tid = threadIdx.x;
   const int rv = remove_idx[b];
   if (tid == 0) status[b] = 0;
@@ -78,7 +82,8 @@ __global__ __launch_bounds__(RW) void remesh_kernel(int NV, int NT, double* coor
   // ---------------- lane 0: ring of the star, ear clipping, slot bookkeeping (host remove_vertex, slot for slot)
   if (tid == 0) {
     int rc = 0;
-    int ea[64], eb[64], ring[64], poly[64];
+    // (in LDS: as local arrays with run-time indices they lived in scratch memory, a global round trip per access)
+    int *ea = lane0, *eb = lane0 + 64, *ring = lane0 + 128, *poly = lane0 + 192;
     if (ns > 64) rc = -1;
     else if (ns < 3) rc = -2;
     if (rc == 0) {
@@ -324,7 +329,7 @@ extern "C" int mdq_remesh(int32_t B, int32_t NV, int32_t NT, double* coords, int
   if (B <= 0 || !coords || !cells || !nv || !nt || !remove_idx || !status) return mdq_set_error("mdq_remesh: bad arguments");
   if (NV > mdq_rm::RNV || NT > mdq_rm::RNT)
     return mdq_set_error("mdq_remesh: capacity above 1024 vertices / 2048 triangles (use mdq_remesh_host)");
-  const size_t lds = 16384 + 2 * sizeof(int) * mdq_rm::RNS + 2 * sizeof(uint32_t) * mdq_rm::RHS + sizeof(int) * 80;
+  const size_t lds = 16384 + 2 * sizeof(int) * mdq_rm::RNS + 2 * sizeof(uint32_t) * mdq_rm::RHS + sizeof(int) * 336;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mdq_rm::remesh_kernel),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (attr != hipSuccess) return mdq_set_error("hipFuncSetAttribute(remesh_kernel) failed");

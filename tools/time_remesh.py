@@ -1,19 +1,31 @@
-import sys, time, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
+"""Duration of mdq_remesh for 128 ys930 meshes (one random interior vertex removed each), HIP events; compare library
+variants through MDQ_LIB_PATH (tools/micro/build_variant.sh NAME -DMDQ_REMESH_WG=...)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from meshdqn_amd.mesh_ops import remesh_batch_gpu
 from meshdqn_amd.topology import MeshTopology
-from meshdqn_amd.ipcs_batch import smooth_coords
-from meshdqn_amd.mesh_ops import remesh_batch
-z=np.load('tests/golden/ys930.npz'); t=MeshTopology(z['coords'],z['cells']); x=smooth_coords(t,50)
-print('affinity', len(os.sched_getaffinity(0)), 'cpu_count', os.cpu_count())
-try: print('cpu.max', open('/sys/fs/cgroup/cpu.max').read().strip())
-except Exception as e: print('no cpu.max', e)
-B=128
-rng=np.random.default_rng(0)
-for T in (1,8,32,64,128):
-    best=1e9
-    for rep in range(3):
-        cb=np.tile(x[None],(B,1,1)).copy(); tb=np.tile(t.cells.astype(np.int32)[None],(B,1,1)).copy()
-        nv=np.full(B,t.nv,np.int32); nt=np.full(B,t.nt,np.int32)
-        rem=rng.integers(200,800,B).astype(np.int32)
-        t0=time.time(); st=remesh_batch(cb,tb,nv,nt,rem,50,T); best=min(best,time.time()-t0)
-    print('threads',T,'ms per call',best*1e3)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+z = np.load(os.path.join(ROOT, "tests", "golden", "ys930.npz"))
+B = 128
+topo = MeshTopology(z["coords"], z["cells"])
+interior = np.flatnonzero(~topo.on_boundary_vertices()) if hasattr(topo, "on_boundary_vertices") else np.arange(300, 800)
+rng = np.random.default_rng(0)
+c0 = torch.from_numpy(np.repeat(z["coords"][None], B, 0).copy()).cuda()
+t0 = torch.from_numpy(np.repeat(z["cells"][None].astype(np.int32), B, 0).copy()).cuda()
+ms = []
+for rep in range(12):
+    coords, cells = c0.clone(), t0.clone()
+    nv = torch.full((B,), z["coords"].shape[0], dtype=torch.int32, device="cuda")
+    nt = torch.full((B,), z["cells"].shape[0], dtype=torch.int32, device="cuda")
+    rem = torch.from_numpy(rng.choice(interior, B).astype(np.int32)).cuda()
+    st = torch.zeros(B, dtype=torch.int32, device="cuda")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    remesh_batch_gpu(coords, cells, nv, nt, rem, st)
+    e1.record()
+    torch.cuda.synchronize()
+    ms.append(e0.elapsed_time(e1))
+    ok = int((st == 0).sum())
+print(f"{os.environ.get('MDQ_LIB_PATH', 'default')}: remesh of {B} meshes {np.median(ms[2:]) * 1e3:.1f} us (min {min(ms[2:]) * 1e3:.1f}); {ok} of {B} removals succeeded in the last launch")
