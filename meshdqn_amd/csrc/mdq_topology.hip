@@ -14,7 +14,10 @@
 
 namespace mdq_topo {
 
-constexpr int TW = 512;
+#ifndef MDQ_TOPO_TW
+#define MDQ_TOPO_TW 1024
+#endif
+constexpr int TW = MDQ_TOPO_TW;
 constexpr int TNV = 1024, TNT = 2048, TNE = 3072, TNP = TNV + TNE, TNS = 3 * TNT;  // capacities (ids fit 10 / 12 bits)
 constexpr int HSZ = 8192;
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
@@ -645,11 +648,13 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     int32_t* bo_ptr = O.bo_ptr + Bq * (O.NBO + 1);
     int32_t* bo_col = O.bo_col + Bq * O.NBE;
     int32_t* bo_src = O.bo_src + Bq * O.NBE;
+    int* lrow = reinterpret_cast<int*>(R + 61440 + 1024);      // [nbo] rows of the outflow list (behind `ofe`)
     // rank by counting over (row, col, src); then rows = runs of equal row
     for (int t = tid; t < nent; t += TW) {
       const uint32_t kt = ekey[t];
       const int st = esrc[t];
       int rank = 0;
+#pragma unroll 8
       for (int q = 0; q < nent; ++q) rank += (ekey[q] < kt) || (ekey[q] == kt && esrc[q] < st);
       bo_col[rank] = (int32_t)((kt >> 8) & 0xFFF);
       bo_src[rank] = st;
@@ -671,6 +676,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
       const int t = tid * PER + i;
       if (t < nent && flg[i]) {
         bo_rows[scanb[t]] = cntd[t];
+        lrow[scanb[t]] = cntd[t];
         bo_ptr[scanb[t]] = t;
       }
     }
@@ -681,9 +687,11 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     }
     __syncthreads();
     // at most two outflow rows per row-owner thread of the 512-thread kernels
-    for (int t = tid; t < nbo; t += TW) {
-      int same = 0;
-      for (int q = 0; q < nbo; ++q) same += (bo_rows[q] % 512) == (bo_rows[t] % 512);
+    for (int t = tid; t < nbo; t += TW) {     // (from the LDS copy of the row list: as a loop of global loads of the list
+      int same = 0;                           //  just written it was ~nbo dependent L2 round trips, most of this phase)
+      const int mine = lrow[t] % 512;
+#pragma unroll 8
+      for (int q = 0; q < nbo; ++q) same += (lrow[q] % 512) == mine;
       if (same > 2) misc[0] = 1;
     }
     __syncthreads();
