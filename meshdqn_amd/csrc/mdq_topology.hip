@@ -643,6 +643,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     esrc[idx] = c * 36 + rowl * 6 + j;
   }
   __syncthreads();
+  TT_STAMP(14)
   {
     int32_t* bo_rows = O.bo_rows + Bq * O.NBO;
     int32_t* bo_ptr = O.bo_ptr + Bq * (O.NBO + 1);
@@ -650,17 +651,29 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     int32_t* bo_src = O.bo_src + Bq * O.NBE;
     int* lrow = reinterpret_cast<int*>(R + 61440 + 1024);      // [nbo] rows of the outflow list (behind `ofe`)
     // rank by counting over (row, col, src); then rows = runs of equal row
-    for (int t = tid; t < nent; t += TW) {
-      const uint32_t kt = ekey[t];
-      const int st = esrc[t];
-      int rank = 0;
+    // (four lanes per entry, a quarter of the list each: one lane per entry left most of the workgroup idle on a loop of
+    //  ~450 steps)
+    {
+      const int QE = (nent + 3) >> 2;
+      for (int it0 = 0; it0 < 4 * nent; it0 += TW) {
+        const int it = it0 + tid, t = min(it >> 2, nent - 1), part_ = it & 3;
+        const uint32_t kt = ekey[t];
+        const int st = esrc[t];
+        const int q0 = part_ * QE, q1 = min(nent, q0 + QE);
+        int rank = 0;
 #pragma unroll 8
-      for (int q = 0; q < nent; ++q) rank += (ekey[q] < kt) || (ekey[q] == kt && esrc[q] < st);
-      bo_col[rank] = (int32_t)((kt >> 8) & 0xFFF);
-      bo_src[rank] = st;
-      cntd[rank] = (int32_t)(kt >> 20);  // row of the sorted entry
+        for (int q = q0; q < q1; ++q) rank += (ekey[q] < kt) || (ekey[q] == kt && esrc[q] < st);
+        rank += __shfl_xor(rank, 1, 64);
+        rank += __shfl_xor(rank, 2, 64);
+        if (part_ == 0 && (it >> 2) < nent) {
+          bo_col[rank] = (int32_t)((kt >> 8) & 0xFFF);
+          bo_src[rank] = st;
+          cntd[rank] = (int32_t)(kt >> 20);  // row of the sorted entry
+        }
+      }
     }
     __syncthreads();
+    TT_STAMP(15)
     for (int t = tid; t < TNS; t += TW) scanb[t] = (t < nent && (t == 0 || cntd[t] != cntd[t - 1])) ? 1 : 0;
     __syncthreads();
 #pragma unroll

@@ -26,8 +26,8 @@ for _ in range(n):
 torch.cuda.synchronize(); lib.mdq_topo_trace_host(buf, 0)
 names = ["load + hash init", "edges (hash, first-appearance ids)", "P2 points, boundary, facet tags", "removable", "polygon distances + argsort + window",
          "state graph", "IPCS: SELL pattern of the P1 Laplacian (tail)", "IPCS: Dirichlet data", "IPCS: outflow entries", "IPCS: packed metadata",
-         "IPCS: gather lists P1", "IPCS: gather lists P2", "(of 4) polygon distances", "(of 4) argsort"]
-tot = sum(buf[:14])
+         "IPCS: gather lists P1", "IPCS: gather lists P2", "(of 4) polygon distances", "(of 4) argsort", "(of 8) facet scan + entries", "(of 8) entry sort"]
+tot = sum(buf[:16])
 print(f"topology_kernel, mesh 0: {tot / n:.0f} ticks per launch")
 for k, nm in enumerate(names):
     print(f"{k:2d} {nm:48s} {buf[k] / n:9.0f}  {100.0 * buf[k] / max(tot, 1):5.1f} %")
