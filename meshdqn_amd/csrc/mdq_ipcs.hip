@@ -26,6 +26,9 @@
 #ifndef MDQ_PCG_WG_DEFAULT
 #define MDQ_PCG_WG_DEFAULT 512
 #endif
+#ifndef MDQ_SETUP_WG
+#define MDQ_SETUP_WG 768
+#endif
 namespace mdq {
 
 __constant__ RefTab c_tab;
@@ -430,8 +433,9 @@ extern "C" int mdq_st_trace_host(long long* out, int reset) {
 // incident cell of every row): from global memory each level is an L2 round trip and the kernel was 270 k cycles of
 // latency (P2 rows 134 k, P1 values 71 k, P1 diagonal 33 k); from LDS a level costs a tenth of that.
 // 52 NT + 9 N2 + 9 NV bytes: 119 KB for ys930; a mesh that does not fit runs the unstaged instance.
+constexpr int SWG = MDQ_SETUP_WG;   // threads of the set-up kernel (its row loops are latency chains: more rows in flight)
 template <bool ST>
-__global__ __launch_bounds__(WG) void setup_matfree_kernel(mdq_ipcs_desc d) {
+__global__ __launch_bounds__(SWG) void setup_matfree_kernel(mdq_ipcs_desc d) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const EnvView v = env_view(d, b);
   const double a = d.rho / d.dt, mu = d.mu;
@@ -459,23 +463,23 @@ __global__ __launch_bounds__(WG) void setup_matfree_kernel(mdq_ipcs_desc d) {
   auto sdk = [&](int i) -> double { return ST ? sSd[i] : v.sdiagK[i]; };
   if (ST) {
     for (int j = 0; j < 6; ++j)
-      for (int e = tid; e < v.nt; e += WG) sCd[j * v.NT + e] = (uint16_t)v.cell_dofs[j * v.NT + e];
-    for (int i = tid; i < v.n2; i += WG) {
+      for (int e = tid; e < v.nt; e += SWG) sCd[j * v.NT + e] = (uint16_t)v.cell_dofs[j * v.NT + e];
+    for (int i = tid; i < v.n2; i += SWG) {
       sFl[i] = v.bcu_flag[i];
       sGx[i] = v.bcu_gx[i];
     }
-    for (int i = tid; i < v.nv; i += WG) sPf[i] = v.bcp_flag[i];
+    for (int i = tid; i < v.nv; i += SWG) sPf[i] = v.bcp_flag[i];
   }
   // reference-element tables in LDS: the row loops index them with the (lane-dependent) local row of a slot; from
   // constant memory that is one more dependent round trip per local column inside the conditional column loop
   __shared__ double sMhat[6][6];
   __shared__ double sGhat[2][2][6][6];
-  for (int q = tid; q < 36; q += WG) sMhat[q / 6][q % 6] = c_tab.Mhat[q / 6][q % 6];
-  for (int q = tid; q < 144; q += WG) sGhat[q / 72][(q / 36) % 2][(q / 6) % 6][q % 6] = c_tab.Ghat[q / 72][(q / 36) % 2][(q / 6) % 6][q % 6];
+  for (int q = tid; q < 36; q += SWG) sMhat[q / 6][q % 6] = c_tab.Mhat[q / 6][q % 6];
+  for (int q = tid; q < 144; q += SWG) sGhat[q / 72][(q / 36) % 2][(q / 6) % 6][q % 6] = c_tab.Ghat[q / 72][(q / 36) % 2][(q / 6) % 6][q % 6];
 #ifdef MDQ_SETUP_TRACE
   long long tq_ = __builtin_amdgcn_s_memtime();
 #endif
-  for (int e = tid; e < v.nt; e += WG) {
+  for (int e = tid; e < v.nt; e += SWG) {
     double X[3][2];
     load_cell_coords(v, e, X);
     const double J00 = X[1][0] - X[0][0], J01 = X[2][0] - X[0][0];
@@ -499,7 +503,7 @@ __global__ __launch_bounds__(WG) void setup_matfree_kernel(mdq_ipcs_desc d) {
   ST_STAMP(0)
   if (v.nbo > 0) {
     const int nbe = v.bo_ptr[v.nbo];
-    for (int t = tid; t < nbe; t += WG) {
+    for (int t = tid; t < nbe; t += SWG) {
       const int slot = v.bo_src[t];
       const int e = slot / 36, ij = slot - e * 36, i = ij / 6, j = ij - i * 6;
       const Geo g = load_geo(v, e);
@@ -510,7 +514,7 @@ __global__ __launch_bounds__(WG) void setup_matfree_kernel(mdq_ipcs_desc d) {
   }
   ST_STAMP(1)
   // ---- P2 rows: raw diagonals (kept in idiag1 / sdiagM until the outflow rows have been corrected) and lifts
-  for (int r = tid; r < v.n2; r += WG) {
+  for (int r = tid; r < v.n2; r += SWG) {
     double l1x = 0.0, l1y = 0.0, l3x = 0.0, dx = 0.0, dy = 0.0, dm = 0.0;
     // incident cells two at a time: the four dependent load levels of a cell (slot -> geometry / dofs -> Dirichlet
     // flags -> values) are paid once per pair; the second cell of an odd tail is the first one again, not added
@@ -592,7 +596,7 @@ __global__ __launch_bounds__(WG) void setup_matfree_kernel(mdq_ipcs_desc d) {
   __syncthreads();
   ST_STAMP(2)
   // outflow rows: - mu/2 B on the diagonal and in the lifts (one thread per row: no conflicts)
-  for (int t = tid; t < v.nbo; t += WG) {
+  for (int t = tid; t < v.nbo; t += SWG) {
     const int row = v.bo_rows[t];
     double2 dg = v.idiag1[row], l1 = v.lift1[row];
     for (int k = v.bo_ptr[t]; k < v.bo_ptr[t + 1]; ++k) {
@@ -612,7 +616,7 @@ __global__ __launch_bounds__(WG) void setup_matfree_kernel(mdq_ipcs_desc d) {
     v.lift1[row] = l1;
   }
   __syncthreads();
-  for (int r = tid; r < v.n2; r += WG) {
+  for (int r = tid; r < v.n2; r += SWG) {
     const bool fr = uflag(r);
     const double2 dg = v.idiag1[r];
     v.idiag1[r] = fr ? make_double2(1.0, 1.0) : make_double2(1.0 / dg.x, 1.0 / dg.y);
@@ -637,7 +641,7 @@ __global__ __launch_bounds__(WG) void setup_matfree_kernel(mdq_ipcs_desc d) {
     }
     return kk;
   };
-  for (int r = tid; r < v.nv; r += WG) {
+  for (int r = tid; r < v.nv; r += SWG) {
     const double sd = pflag(r) ? 1.0 : sqrt(k1_entry(r, r));
     v.sdiagK[r] = sd;
     if (ST) sSd[r] = sd;
@@ -646,7 +650,7 @@ __global__ __launch_bounds__(WG) void setup_matfree_kernel(mdq_ipcs_desc d) {
   ST_STAMP(4)
   const int rows1 = ((v.nv + 63) >> 6) << 6;
   constexpr int KW = 16;   // widest row handled by the one-pass path (vertex degree + 1; wider rows: generic path)
-  for (int r = tid; r < rows1; r += WG) {
+  for (int r = tid; r < rows1; r += SWG) {
     const int off = v.sl1_off[r >> 6];
     const int width = (v.sl1_off[(r >> 6) + 1] - off) >> 6;
     if (width <= KW) {
@@ -4236,9 +4240,9 @@ int mdq_ipcs_setup_matfree(const mdq_ipcs_desc* d, void* stream) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&setup_matfree_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)stage_bytes);
     if (e != hipSuccess) return fail("setup_matfree_kernel attribute", e);
-    hipLaunchKernelGGL(setup_matfree_kernel<true>, dim3(d->B), dim3(WG), stage_bytes, (hipStream_t)stream, *d);
+    hipLaunchKernelGGL(setup_matfree_kernel<true>, dim3(d->B), dim3(SWG), stage_bytes, (hipStream_t)stream, *d);
   } else {
-    hipLaunchKernelGGL(setup_matfree_kernel<false>, dim3(d->B), dim3(WG), 0, (hipStream_t)stream, *d);
+    hipLaunchKernelGGL(setup_matfree_kernel<false>, dim3(d->B), dim3(SWG), 0, (hipStream_t)stream, *d);
   }
   e = hipGetLastError();
   if (e != hipSuccess) return fail("setup_matfree_kernel launch", e);
