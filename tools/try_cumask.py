@@ -21,7 +21,8 @@ cfg = dict(flow_config=dict(flow_params=dict(mu=1e-3, rho=1.0, inflow="constant"
                              time_reward=0.005, save_steps=100, goal_vertices=0.95, plot_dir=""))
 base = Env2DAirfoil(cfg)
 net = NodeRemovalNet(181, conv_width=128, topk=0.1); net.set_num_nodes(17); net = net.cuda()
-variants = [("S1", dict(flow_steps=0)), ("S3", dict(flow_steps=1, flow_overlap=True))]
+_pcg = os.environ.get("TRY_PCG_DEGREE")
+variants = [("S1", dict(flow_steps=0)), ("S3", dict(flow_steps=1, flow_overlap=True, **(dict(flow_pcg_degree=int(_pcg)) if _pcg else {})))]
 rng = np.random.default_rng(1370)
 for name, kw in variants:
     grp = VecEnvGroups(cfg, B, 1, base_env=base, **kw)
