@@ -552,39 +552,36 @@ __global__ __launch_bounds__(SWG) void setup_matfree_kernel(mdq_ipcs_desc d) {
         const Geo g = gg[u];
         const int i = ii[u];
         const double Ja[2][2] = {{g.j00, g.j01}, {g.j10, g.j11}};
-        // row i of the reference tables, read in one batch in front of the (conditional) column loop
-        double mh[6], gh[4][6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          mh[j] = sMhat[i][j];
-          gh[0][j] = sGhat[0][0][i][j];
-          gh[1][j] = sGhat[0][1][i][j];
-          gh[2][j] = sGhat[1][0][i][j];
-          gh[3][j] = sGhat[1][1][i][j];
+        // The diagonal term with the tables indexed by the lane's own i: ONE block for the wave.  (As a column loop
+        // unrolled over j with `if (j != i && !fc) continue` the wave ran all six blocks - its lanes sit at different i -
+        // i.e. ~270 fp64 instructions per cell for one term per lane.)  The Dirichlet columns follow in ascending j as
+        // before; only waves that hold cells at the boundary enter those blocks.
+        {
+          const double m = g.det * sMhat[i][i];
+          const double g00 = sGhat[0][0][i][i], g01 = sGhat[0][1][i][i];
+          const double g10 = sGhat[1][0][i][i], g11 = sGhat[1][1][i][i];
+          const double kxx = g.det * (Ja[0][0] * (Ja[0][0] * g00 + Ja[1][0] * g01) + Ja[1][0] * (Ja[0][0] * g10 + Ja[1][0] * g11));
+          const double kyy = g.det * (Ja[0][1] * (Ja[0][1] * g00 + Ja[1][1] * g01) + Ja[1][1] * (Ja[0][1] * g10 + Ja[1][1] * g11));
+          const double L = kxx + kyy;
+          dx += a * m + 0.5 * mu * (L + kxx);
+          dy += a * m + 0.5 * mu * (L + kyy);
+          dm += m;
         }
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-          const bool fc = fj[u][j];
-          if (j != i && !fc) continue;
-          const double m = g.det * mh[j];
-          const double g00 = gh[0][j], g01 = gh[1][j];
-          const double g10 = gh[2][j], g11 = gh[3][j];
+          if (!fj[u][j]) continue;
+          const double m = g.det * sMhat[i][j];
+          const double g00 = sGhat[0][0][i][j], g01 = sGhat[0][1][i][j];
+          const double g10 = sGhat[1][0][i][j], g11 = sGhat[1][1][i][j];
           const double kxx = g.det * (Ja[0][0] * (Ja[0][0] * g00 + Ja[1][0] * g01) + Ja[1][0] * (Ja[0][0] * g10 + Ja[1][0] * g11));
           const double kxy = g.det * (Ja[0][0] * (Ja[0][1] * g00 + Ja[1][1] * g01) + Ja[1][0] * (Ja[0][1] * g10 + Ja[1][1] * g11));
           const double kyy = g.det * (Ja[0][1] * (Ja[0][1] * g00 + Ja[1][1] * g01) + Ja[1][1] * (Ja[0][1] * g10 + Ja[1][1] * g11));
           const double L = kxx + kyy;
-          const double bx = a * m + 0.5 * mu * (L + kxx), bz = 0.5 * mu * kxy, bw = a * m + 0.5 * mu * (L + kyy);
-          if (j == i) {
-            dx += bx;
-            dy += bw;
-            dm += m;
-          }
-          if (fc) {
-            const double gx = gj[u][j];
-            l1x += bx * gx;
-            l1y += bz * gx;
-            l3x += m * gx;
-          }
+          const double bx = a * m + 0.5 * mu * (L + kxx), bz = 0.5 * mu * kxy;
+          const double gx = gj[u][j];
+          l1x += bx * gx;
+          l1y += bz * gx;
+          l3x += m * gx;
         }
       }
     }
