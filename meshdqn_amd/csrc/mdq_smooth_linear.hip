@@ -41,7 +41,13 @@
 namespace mdq_smooth_lin {
 constexpr int LNV = 1024;          // vertex capacity
 constexpr int LNT = 2048;          // triangle capacity
-constexpr int LWG = 512;           // threads per workgroup: waves 0 / 1 solve x / y, waves 2, 3, 6, 7 validate
+#ifndef MDQ_SMOOTH_LWG
+#define MDQ_SMOOTH_LWG 768
+#endif
+constexpr int LWG = MDQ_SMOOTH_LWG;   // threads per workgroup (512 or 768): waves 0 / 1 solve x / y, the waves on the other two SIMDs validate
+constexpr int SCT = 512;           // threads that take part in the block scans (two entries each)
+constexpr int TRW = LWG / 64 < 11 ? LWG / 64 : 11;   // waves that build block inverses (their packed triangles share 3 position buffers)
+static_assert(LWG == 512 || LWG == 768, "workgroup shape");
 constexpr int BS = 32;             // rows per block
 constexpr int NSLOT = 14;          // gather slots per row (7 per lane half)
 constexpr int MAXNB = 16;          // neighbours / cells per vertex the setup handles (more: the mesh goes to the careful walk)
@@ -72,7 +78,7 @@ constexpr int LDS_BYTES = OFF_PART + LWG * 4;
 constexpr int OFF_NB = OFF_CUR;                              // [LNV][MAXNB] u16: id | count << 10
 constexpr int OFF_TRI = OFF_CUR;                             // 8 waves x 528 doubles (packed lower triangles)
 constexpr int OFF_TMP = OFF_SROW;                            // cell lists in arrival order (before the rows are built)
-static_assert(LNV * MAXNB * 2 <= 3 * PBUF && 8 * 528 * 8 <= 3 * PBUF && 3 * LNT * 4 <= LNV * SROW, "setup scratch");
+static_assert(LNV * MAXNB * 2 <= 3 * PBUF && TRW * 528 * 8 <= 3 * PBUF && 3 * LNT * 4 <= LNV * SROW, "setup scratch");
 static_assert(OFF_SROW % 16 == 0 && OFF_PTR % 16 == 0 && OFF_INC % 16 == 0 && OFF_G % 16 == 0 && OFF_R2K % 8 == 0, "LDS alignment");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
@@ -106,26 +112,31 @@ __device__ __forceinline__ double halves_sum(double v) {
   return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
 }
 
-__device__ __forceinline__ void scan_inclusive(int* data, int* part) {   // data[0..LNV), LWG threads, 2 entries each
+__device__ __forceinline__ void scan_inclusive(int* data, int* part) {   // data[0..LNV): the first SCT threads, 2 entries each
   const int tid = threadIdx.x;
-  constexpr int PER = LNV / LWG;
+  constexpr int PER = LNV / SCT;
+  const bool sc = tid < SCT;
   int loc[PER], run = 0;
+  if (sc) {
 #pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    run += data[tid * PER + i];
-    loc[i] = run;
+    for (int i = 0; i < PER; ++i) {
+      run += data[tid * PER + i];
+      loc[i] = run;
+    }
+    part[tid] = run;
   }
-  part[tid] = run;
   __syncthreads();
-  for (int off = 1; off < LWG; off <<= 1) {
-    const int add = tid >= off ? part[tid - off] : 0;
+  for (int off = 1; off < SCT; off <<= 1) {
+    const int add = (sc && tid >= off) ? part[tid - off] : 0;
     __syncthreads();
-    part[tid] += add;
+    if (sc) part[tid] += add;
     __syncthreads();
   }
-  const int base = part[tid] - run;
+  if (sc) {
+    const int base = part[tid] - run;
 #pragma unroll
-  for (int i = 0; i < PER; ++i) data[tid * PER + i] = base + loc[i];
+    for (int i = 0; i < PER; ++i) data[tid * PER + i] = base + loc[i];
+  }
   __syncthreads();
 }
 
@@ -538,7 +549,7 @@ __global__ __launch_bounds__(LWG) void smooth_linear_kernel(int NV, int NT, doub
   {
     double* T = reinterpret_cast<double*>(lds + OFF_TRI) + wave * 528;
     const double* r2ktab = reinterpret_cast<const double*>(lds + OFF_R2K);   // 2 x 1 / (2 k) = 1 / k, correctly rounded
-    for (int blk = wave; blk < nb; blk += LWG / 64) {
+    for (int blk = wave < TRW ? wave : nb; blk < nb; blk += TRW) {
       const int r0 = blk * BS, j = lane & 31;
       // the 32 rows are a chain (row i needs the rows of its in-block lower neighbours), so what counts is the latency of ONE
       // row step: its metadata - degree, lower count and the up to 8 lower neighbours, the same for every lane - is loaded
@@ -600,7 +611,10 @@ __global__ __launch_bounds__(LWG) void smooth_linear_kernel(int NV, int NT, doub
   //  PIPELINED: waves 0 / 1 solve sweep s WHILE waves 2, 3, 6, 7 validate sweep s - 1 from the two snapshots (waves 4 / 5
   //    stay off the solvers' SIMDs); a sweep that fails goes back to its snapshot and to the CHECKED mode.
   const d2* mgd = reinterpret_cast<const d2*>(mg);
-  const int vw = wave == 2 ? 0 : wave == 3 ? 1 : wave == 6 ? 2 : wave == 7 ? 3 : -1;
+  // validators of the pipelined mode: the waves of SIMDs 2 and 3 (waves 2, 3, 6, 7, 10, 11); the other waves of SIMDs 0 / 1
+  // stay off the solvers' issue slots
+  constexpr int NVAL = 2 * (LWG / 256);
+  const int vw = (wave & 3) >= 2 ? 2 * (wave >> 2) + (wave & 1) : -1;
   const int ne = 3 * nt, npass = (ne + 63) / 64;
   unsigned char* fixv = lds + OFF_FIXV;
   auto copy_pos = [&](int dst_off, int src_off) {
@@ -668,7 +682,7 @@ __global__ __launch_bounds__(LWG) void smooth_linear_kernel(int NV, int NT, doub
         const unsigned char* NEW = lds + OFF_SNAP + (s & 1) * PBUF;
         if (s < S) {
           if (vw >= 0)
-            for (int p = vw; p < npass; p += 4) bad |= validate_entry<false>(lds, 64 * p + lane, ne, OLD, NEW);
+            for (int p = vw; p < npass; p += NVAL) bad |= validate_entry<false>(lds, 64 * p + lane, ne, OLD, NEW);
         } else {                                // behind the last sweep: everybody
           for (int p = wave; p < npass; p += LWG / 64) bad |= validate_entry<false>(lds, 64 * p + lane, ne, OLD, NEW);
         }
