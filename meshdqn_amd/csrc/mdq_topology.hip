@@ -413,7 +413,6 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     // pass 1: segments that can hold the minimum, segments the ray straddles (bit k of word h: segment i0 + 32 h + k)
     uint32_t cm[2] = {0u, 0u}, sm[2] = {0u, 0u};
     bool sa = ye[i0] > py;
-#ifndef TOPO_NOPASS1
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int kn = min(32, QS - 32 * h);
@@ -432,10 +431,8 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
         sa = sb;
       }
     }
-#endif
     double d2 = 1e300;
     bool inside = false;
-#ifndef TOPO_NOEXACT
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       uint32_t m = cm[h];
@@ -458,9 +455,6 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
         }
       }
     }
-#else
-    d2 = (double)(cm[0] + sm[0] + cm[1] + sm[1]) + (double)vmin + (sa ? 1.0 : 0.0);   // (experiment: keeps the passes alive)
-#endif
     d2 = fmin(d2, __shfl_xor(d2, 1, 64));
     d2 = fmin(d2, __shfl_xor(d2, 2, 64));
     int par = inside ? 1 : 0;
