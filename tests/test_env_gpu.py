@@ -930,3 +930,56 @@ def test_stream_calibration_keeps_a_working_flow_stream_and_resets_the_envs(lib_
     assert r is streams.role_streams("cuda:0") and len({id(v) for v in r.values()}) == 3 and venv._flow_stream is not None
     assert any(e["event"].startswith("roles created") for e in streams.LOG)
     assert any(e["event"] == "flow stream calibrated" for e in streams.LOG)
+
+
+@pytest.mark.parametrize("kind", ["star", "far", "sliver", "dense"])
+def test_device_closest_ranking_equals_host_engine_for_other_polygons(lib_built, meshes, kind):
+    """The N-closest ranking of `mdq_env_topology` (fp32 estimates pick the polygon segments that can hold a vertex's
+    minimum distance and the segments its ray straddles; only those are evaluated exactly) against the host engine's full
+    fp64 loop, bit for bit, for polygons that stress the selection: a star that swallows part of the mesh (vertices inside:
+    distance 0 and ties broken by index), a small polygon far outside (every distance large, all segments nearly
+    equidistant), a sliver with near-degenerate segments, a dense polygon with the capacity's 256 points."""
+    from meshdqn_amd.ipcs_batch import smooth_coords
+    from meshdqn_amd.mesh_ops import DeviceTopologyBatch, HostTopologyBatch
+    from meshdqn_amd.topology import MeshTopology
+    coords, cells = meshes["ys930"]
+    t0 = MeshTopology(coords, cells)
+    x0 = smooth_coords(t0, 50)
+    tags = t0.facet_tags(x0)
+    rng = np.random.default_rng(5)
+    if kind == "star":
+        th = np.sort(rng.uniform(0, 2 * np.pi, 97))
+        r = 0.12 + 0.1 * rng.random(97)
+        polygon = np.stack([0.6 + r * np.cos(th), 0.2 + 0.7 * r * np.sin(th)], axis=1)
+    elif kind == "far":
+        th = np.linspace(0, 2 * np.pi, 41, endpoint=False)
+        polygon = np.stack([40.0 + 1e-3 * np.cos(th), -25.0 + 1e-3 * np.sin(th)], axis=1)
+    elif kind == "sliver":
+        xs = np.linspace(0.3, 1.9, 60)
+        polygon = np.concatenate([np.stack([xs, 0.2 + 1e-9 * np.sin(40 * xs)], axis=1),
+                                  np.stack([xs[::-1], 0.2 + 1e-7 + 1e-9 * np.cos(33 * xs[::-1])], axis=1),
+                                  [[0.3, 0.2 + 5e-8], [0.3, 0.2 + 5e-8]]])        # (a repeated point: a degenerate segment)
+    else:
+        th = np.linspace(0, 2 * np.pi, 256, endpoint=False)
+        polygon = np.stack([1.1 + 0.5 * np.cos(th) * (1 + 0.05 * np.sin(9 * th)), 0.2 + 0.1 * np.sin(th)], axis=1)
+    B = 2
+    args = (B, t0.nv, t0.nt, t0.ne, int((tags == 1).sum()), 180, 1536, np.ascontiguousarray(polygon))
+    hb = HostTopologyBatch(*args)
+    for b in range(B):
+        hb.coords[b], hb.cells[b], hb.nv[b], hb.nt[b] = x0, np.sort(cells, axis=1), t0.nv, t0.nt
+    hb.coords[1] += 1e-7 * rng.standard_normal(hb.coords[1].shape) * (~t0.on_boundary)[:, None]     # (a second, jittered mesh)
+    hb.offset[:] = [0, 5]
+    hb.run(2)
+    db = DeviceTopologyBatch(*args, device="cuda")
+    db.coords.copy_(torch.from_numpy(hb.coords)); db.cells.copy_(torch.from_numpy(hb.cells))
+    db.nv.copy_(torch.from_numpy(hb.nv)); db.nt.copy_(torch.from_numpy(hb.nt)); db.offset.copy_(torch.from_numpy(hb.offset))
+    db.run()
+    g = {k: v.cpu().numpy() for k, v in db.t.items()}
+    for b in range(B):
+        for k in ("nremovable", "nsel", "nedges"):
+            assert g[k][b] == hb.h[k][b], (kind, k, b)
+        assert np.array_equal(g["n_closest"][b], hb.h["n_closest"][b]), (kind, b)
+        assert np.array_equal(g["coord_map"][b], hb.h["coord_map"][b]), (kind, b)
+        nE = int(hb.h["nedges"][b])
+        for k in ("edge_src", "edge_dst", "edge_len"):
+            assert np.array_equal(g[k][b][:nE], hb.h[k][b][:nE]), (kind, k, b)
