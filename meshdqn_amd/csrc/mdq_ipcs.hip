@@ -434,7 +434,9 @@ extern "C" int mdq_st_trace_host(long long* out, int reset) {
 // latency (P2 rows 134 k, P1 values 71 k, P1 diagonal 33 k); from LDS a level costs a tenth of that.
 // 52 NT + 9 N2 + 9 NV bytes: 119 KB for ys930; a mesh that does not fit runs the unstaged instance.
 constexpr int SWG = MDQ_SETUP_WG;   // threads of the set-up kernel (its row loops are latency chains: more rows in flight)
-template <bool ST>
+// LS (with ST): the dof <- element-slot lists (g1 / g2 pointers and slots, 16-bit in LDS) are staged as well when they fit:
+// the row loops then have no dependent global load left.
+template <bool ST, bool LS = false>
 __global__ __launch_bounds__(SWG) void setup_matfree_kernel(mdq_ipcs_desc d) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const EnvView v = env_view(d, b);
@@ -446,6 +448,14 @@ __global__ __launch_bounds__(SWG) void setup_matfree_kernel(mdq_ipcs_desc d) {
   uint16_t* sCd = reinterpret_cast<uint16_t*>(sSd + d.NV);          // [6][NT]
   uint8_t* sFl = reinterpret_cast<uint8_t*>(sCd + 6 * (size_t)d.NT);  // [N2]
   uint8_t* sPf = sFl + d.N2;                                        // [NV]
+  uint16_t* sG2p = reinterpret_cast<uint16_t*>(sPf + d.NV + ((d.N2 + d.NV) & 1));   // [N2 + 1]  (LS)
+  uint16_t* sG2s = sG2p + d.N2 + 1;                                 // [6 NT]
+  uint16_t* sG1p = sG2s + 6 * (size_t)d.NT;                         // [NV + 1]
+  uint16_t* sG1s = sG1p + d.NV + 1;                                 // [3 NT]
+  auto g2p = [&](int i) -> int { return LS ? (int)sG2p[i] : v.g2_ptr[i]; };
+  auto g2s = [&](int i) -> int { return LS ? (int)sG2s[i] : v.g2_src[i]; };
+  auto g1p = [&](int i) -> int { return LS ? (int)sG1p[i] : v.g1_ptr[i]; };
+  auto g1s = [&](int i) -> int { return LS ? (int)sG1s[i] : v.g1_src[i]; };
   auto geo = [&](int e) -> Geo {
     if (!ST) return load_geo(v, e);
     Geo g;
@@ -469,6 +479,12 @@ __global__ __launch_bounds__(SWG) void setup_matfree_kernel(mdq_ipcs_desc d) {
       sGx[i] = v.bcu_gx[i];
     }
     for (int i = tid; i < v.nv; i += SWG) sPf[i] = v.bcp_flag[i];
+    if (LS) {
+      for (int i = tid; i <= v.n2; i += SWG) sG2p[i] = (uint16_t)v.g2_ptr[i];
+      for (int i = tid; i < 6 * v.nt; i += SWG) sG2s[i] = (uint16_t)v.g2_src[i];
+      for (int i = tid; i <= v.nv; i += SWG) sG1p[i] = (uint16_t)v.g1_ptr[i];
+      for (int i = tid; i < 3 * v.nt; i += SWG) sG1s[i] = (uint16_t)v.g1_src[i];
+    }
   }
   // reference-element tables in LDS: the row loops index them with the (lane-dependent) local row of a slot; from
   // constant memory that is one more dependent round trip per local column inside the conditional column loop
@@ -518,13 +534,13 @@ __global__ __launch_bounds__(SWG) void setup_matfree_kernel(mdq_ipcs_desc d) {
     double l1x = 0.0, l1y = 0.0, l3x = 0.0, dx = 0.0, dy = 0.0, dm = 0.0;
     // incident cells two at a time: the four dependent load levels of a cell (slot -> geometry / dofs -> Dirichlet
     // flags -> values) are paid once per pair; the second cell of an odd tail is the first one again, not added
-    const int s0 = v.g2_ptr[r], s1 = v.g2_ptr[r + 1];
+    const int s0 = g2p(r), s1 = g2p(r + 1);
     for (int s = s0; s < s1; s += 2) {
       const bool two = s + 1 < s1;
       int ee[2], ii[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        const int slot = v.g2_src[(u == 1 && two) ? s + 1 : s];
+        const int slot = g2s((u == 1 && two) ? s + 1 : s);
         ee[u] = slot / 6;
         ii[u] = slot - ee[u] * 6;
       }
@@ -623,8 +639,8 @@ __global__ __launch_bounds__(SWG) void setup_matfree_kernel(mdq_ipcs_desc d) {
   // ---- P1 Laplacian: entry (r, c) = sum over the cells of r that contain c of |T| grad(l_r).grad(l_c)
   auto k1_entry = [&](int r, int c) {
     double kk = 0.0;
-    for (int s = v.g1_ptr[r]; s < v.g1_ptr[r + 1]; ++s) {
-      const int slot = v.g1_src[s];
+    for (int s = g1p(r); s < g1p(r + 1); ++s) {
+      const int slot = g1s(s);
       const int e = slot / 3, i = slot - e * 3;
       int j = -1;
 #pragma unroll
@@ -672,8 +688,8 @@ __global__ __launch_bounds__(SWG) void setup_matfree_kernel(mdq_ipcs_desc d) {
 #pragma unroll
           for (int j = 0; j < KW; ++j) vals[j] = cols[j] == r ? 1.0 : 0.0;
         } else {
-          for (int s_ = v.g1_ptr[r]; s_ < v.g1_ptr[r + 1]; ++s_) {
-            const int slot = v.g1_src[s_];
+          for (int s_ = g1p(r); s_ < g1p(r + 1); ++s_) {
+            const int slot = g1s(s_);
             const int e = slot / 3, i = slot - e * 3;
             const Geo g = geo(e);
             int cq[3];
@@ -4233,7 +4249,15 @@ int mdq_ipcs_setup_matfree(const mdq_ipcs_desc* d, void* stream) {
   // staged instance when the mesh's per-cell / per-dof data fit the LDS beside the kernel's static tables
   const size_t stage_bytes = 52 * (size_t)d->NT + 9 * (size_t)d->N2 + 9 * (size_t)d->NV + 64;
   hipError_t e;
-  if (stage_bytes <= 156 * 1024) {
+  // + the slot lists (16-bit: slot ids < 6 NT <= 65535, pointers likewise) when they fit as well
+  const size_t list_bytes = 2 * ((size_t)d->N2 + 1 + 6 * (size_t)d->NT + (size_t)d->NV + 1 + 3 * (size_t)d->NT) + 2;
+  if (stage_bytes + list_bytes <= 156 * 1024 && 6 * (size_t)d->NT <= 65535) {
+    const size_t bytes = stage_bytes + list_bytes;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&setup_matfree_kernel<true, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return fail("setup_matfree_kernel attribute", e);
+    hipLaunchKernelGGL((setup_matfree_kernel<true, true>), dim3(d->B), dim3(SWG), bytes, (hipStream_t)stream, *d);
+  } else if (stage_bytes <= 156 * 1024) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&setup_matfree_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)stage_bytes);
     if (e != hipSuccess) return fail("setup_matfree_kernel attribute", e);
