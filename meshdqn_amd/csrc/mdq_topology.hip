@@ -789,12 +789,16 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     int32_t* so = O.sl1_off + Bq * (D.NV / 64 + 2);
     int32_t* sc = O.sl1_col + Bq * O.NSE1;
     const int ns = (nv + 63) / 64;
-    // slice widths -> offsets
-    for (int s_ = tid; s_ < TNS; s_ += TW) {
-      int w = 0;
-      if (s_ < ns)
-        for (int r = 64 * s_; r < min(nv, 64 * s_ + 64); ++r) w = max(w, fill[r]);
-      scanb[s_] = 64 * w;
+    // slice widths -> offsets (one wave per slice: the longest of its 64 rows by a shuffle reduction; as one THREAD per
+    // slice walking 64 rows the 14 slices of a mesh cost 64 dependent LDS reads each)
+    for (int s_ = tid; s_ < TNS; s_ += TW) scanb[s_] = 0;
+    __syncthreads();
+    for (int s_ = tid >> 6; s_ < ns; s_ += TW / 64) {
+      const int r = 64 * s_ + (tid & 63);
+      int w = r < nv ? fill[r] : 0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) w = max(w, __shfl_xor(w, o, 64));
+      if ((tid & 63) == 0) scanb[s_] = 64 * w;
     }
     __syncthreads();
     const int total = scan_excl(scanb, TNS, part);
