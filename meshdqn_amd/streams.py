@@ -88,8 +88,10 @@ def profiler_attached() -> bool:
     """True when the process runs under rocprofv3 / rocprof (their launchers preload a tool library and pass their options
     through ROCPROF_* / ROCP_* variables)."""
     import os
-    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower():
-        return True
+    for var in ("LD_PRELOAD", "HSA_TOOLS_LIB"):          # (HSA_TOOLS_LIB: the tool libraries of rocprof v1 / v2, roctracer)
+        val = os.environ.get(var, "").lower()
+        if "rocprof" in val or "roctracer" in val:
+            return True
     return any(k.startswith(("ROCPROF_", "ROCP_TOOL", "ROCPROFILER_")) for k in os.environ)
 
 

@@ -12,7 +12,11 @@ def test_profiler_detection_from_the_environment(monkeypatch):
     monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
     assert streams.profiler_attached()
     monkeypatch.setenv("LD_PRELOAD", "")
+    monkeypatch.delenv("HSA_TOOLS_LIB", raising=False)
     assert not streams.profiler_attached()
+    monkeypatch.setenv("HSA_TOOLS_LIB", "/opt/rocm/lib/librocprofiler64.so.1")
+    assert streams.profiler_attached()
+    monkeypatch.delenv("HSA_TOOLS_LIB")
     monkeypatch.setenv("ROCPROF_KERNEL_TRACE", "1")
     assert streams.profiler_attached()
     monkeypatch.delenv("ROCPROF_KERNEL_TRACE")
