@@ -386,7 +386,11 @@ __device__ __forceinline__ void run_level(const Lds& L, const Level& lv, int C, 
   GT_STAMP(1)
   // ---- dense part
   const int G = WGT / C;
-  if (C == 16 * (WGT / 64) && n >= 16 && fin <= MDQ_GCN_FORMC_MAXFIN) {        // lane = node, scalar weights (form (c))
+  // (form (c) reads 16 weights per scalar load: rows of 64-byte aligned segments - torch allocations are; other callers
+  //  of the C ABI fall through to the other forms)
+  const bool w64 = ((reinterpret_cast<size_t>(lv.wl) | reinterpret_cast<size_t>(lv.b) |
+                     (lv.type == 0 ? reinterpret_cast<size_t>(lv.wr) : (size_t)0)) & 63) == 0;
+  if (C == 16 * (WGT / 64) && n >= 16 && fin <= MDQ_GCN_FORMC_MAXFIN && w64) {        // lane = node, scalar weights (form (c))
     if (lv.type == 0)
       conv_dense_nodes<true>(L, n, fin, C, lv.wl, lv.b, lv.wr, L.agg, L.x);
     else
