@@ -439,7 +439,8 @@ typedef struct mdq_interp_desc {
   double* out_p;                /* [B][S][NP1]                                                 */
   int32_t* out_cell;            /* [B][NP] located source cell (may be NULL)                   */
   /* optional, device: [src_nt][6] = {x, y of the cell's vertex 0, the four Jinv entries of src_geom} - what the point
-   * location needs of a candidate cell in ONE record (NULL: gathered from src_cell_dofs / src_coords / src_geom) */
+   * location needs of a candidate cell in ONE record, 16-byte aligned (NULL: gathered from src_cell_dofs / src_coords /
+   * src_geom) */
   const double* src_cellrec;
 } mdq_interp_desc;
 
