@@ -616,6 +616,11 @@ typedef struct mdq_ipcs_topo_out {
   int32_t* g2_src;        /* [B][6*NT] */
   int32_t* sl1_off;       /* [B][NV/64+2] */
   int32_t* sl1_col;       /* [B][NSE1] */
+  /* optional inputs of a `flow_only` run of mdq_env_topology (both NULL: the edges are numbered here): the cell dofs
+   * [B][6][NT] and edge counts [B] that another engine's run derived from the SAME meshes - the edge numbering is taken
+   * from them instead of being found again through the hash table */
+  const int32_t* cell_dofs_in;
+  const int32_t* ne_in;
 } mdq_ipcs_topo_out;
 
 /* ---- batched topology + N-closest selection + state graph (host arrays) ---- */

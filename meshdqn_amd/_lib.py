@@ -79,7 +79,8 @@ class IpcsTopoOut(C.Structure):
     """Mirror of `mdq_ipcs_topo_out`."""
     _fields_ = [(n, C.c_int32) for n in ("NBO", "NBE", "NSE1", "flow_only")] + [
         (n, C.c_void_p) for n in ("mf_scat", "cell_outflow", "bcu_flag", "bcu_gx", "bcp_flag", "nbo", "bo_rows", "bo_ptr",
-                                  "bo_col", "bo_src", "g1_ptr", "g1_src", "g2_ptr", "g2_src", "sl1_off", "sl1_col")]
+                                  "bo_col", "bo_src", "g1_ptr", "g1_src", "g2_ptr", "g2_src", "sl1_off", "sl1_col",
+                                  "cell_dofs_in", "ne_in")]
 
 
 # every symbol include/meshdqn_hip.h declares: name -> (restype, argtypes)

@@ -151,71 +151,124 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     return h;
   };
   const int nslots = 3 * nt;
-  for (int s = tid; s < nslots; s += TW) {
-    int a, c;
-    const uint32_t key = slot_key(s, a, c);
-    uint32_t h = hslot(key);
-    for (;;) {
-      const uint32_t old = atomicCAS(&hkey[h], EMPTY, key);
-      if (old == EMPTY || old == key) break;
-      h = (h + 1) & (HSZ - 1);
+  const bool edges_given = has_ipcs && O.flow_only && O.cell_dofs_in && O.ne_in;
+  int ne_given = 0;
+  if (edges_given) {
+    // The edge numbering of another engine's run on the same mesh (its cell dofs 3..5 = nv + edge id): owner = lowest slot
+    // of an edge, boundary = a single owner, both by LDS atomics on the edge id - the hash insert + three probes per slot
+    // of the general path (33 k cycles) are not needed.  Same ea / eb / eown / eflag / eid_slot / cell dofs as that path.
+    const int32_t* cin = O.cell_dofs_in + Bq * 6 * D.NT;
+    ne_given = O.ne_in[b];
+    int* own = reinterpret_cast<int*>(hkey);               // [ne] lowest slot   (the hash arrays are not used on this path)
+    int* cnt_ = reinterpret_cast<int*>(hval);              // [ne] owners
+    if (ne_given < 0 || ne_given > TNE || nv + ne_given > D.NP) {
+      if (tid == 0) status[b] = -1;
+      return;
     }
-    atomicMin(&hval[h], (uint32_t)s);
-  }
-  __syncthreads();
-  for (int s = tid; s < TNS; s += TW) {
-    int first = 0;
-    if (s < nslots) {
-      int a, c;
-      const uint32_t h = probe(slot_key(s, a, c));
-      const uint32_t m = hval[h] & 0x7FFFFFFFu;
-      first = m == (uint32_t)s;
-      if (!first) atomicOr(&hval[h], 0x80000000u);  // a second owner: interior edge
+    for (int e = tid; e < ne_given; e += TW) {
+      own[e] = 0x7FFFFFFF;
+      cnt_[e] = 0;
     }
-    scanb[s] = first;
-  }
-  __syncthreads();
-  // (the flags must be read back before the scan overwrites them)
-  bool isfirst[PER];
-#pragma unroll
-  for (int i = 0; i < PER; ++i) isfirst[i] = scanb[tid * PER + i] != 0;
-  __syncthreads();
-  const int ne = scan_excl(scanb, TNS, part);
-  const int n2 = nv + ne;
-  if (ne > TNE || n2 > D.NP) {
-    if (tid == 0) status[b] = -1;
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int s = tid * PER + i;
-    if (s < nslots && isfirst[i]) {
+    __syncthreads();
+    for (int s = tid; s < nslots; s += TW) {
+      const int t = s / 3, k = s - 3 * t;
+      const int e = cin[(3 + k) * D.NT + t] - nv;
+      if (e < 0 || e >= ne_given) {
+        status[b] = -1;                                    // (not the dofs of this mesh)
+        continue;
+      }
+      eid_slot[s] = (uint16_t)e;
+      atomicMin(&own[e], s);
+      atomicAdd(&cnt_[e], 1);
+      cd[(3 + k) * D.NT + t] = nv + e;
+      cd[k * D.NT + t] = tri[3 * t + k];
+    }
+    __syncthreads();
+    for (int e = tid; e < ne_given; e += TW) {
       int a, c;
-      const uint32_t h = probe(slot_key(s, a, c));
-      const int e = scanb[s];
-      const bool shared = (hval[h] & 0x80000000u) != 0;
+      const int s = own[e];
+      slot_key(s < nslots ? s : 0, a, c);
       ea[e] = (uint16_t)a;
       eb[e] = (uint16_t)c;
       eown[e] = (uint16_t)s;
-      eflag[e] = shared ? 0 : 1;
+      eflag[e] = cnt_[e] >= 2 ? 0 : 1;
     }
+    if (tid == 0) D.ne[b] = ne_given;
+    for (int i = tid; i < nv; i += TW) {
+      pts[2 * i] = X[i].x;
+      pts[2 * i + 1] = X[i].y;
+    }
+    __syncthreads();
+    if (status[b] != 0) return;
   }
-  __syncthreads();
-  for (int s = tid; s < nslots; s += TW) {
-    int a, c;
-    const uint32_t h = probe(slot_key(s, a, c));
-    const int e = scanb[hval[h] & 0x7FFFFFFFu];
-    eid_slot[s] = (uint16_t)e;
-    const int t = s / 3, k = s - 3 * t;
-    cd[(3 + k) * D.NT + t] = nv + e;
-    cd[k * D.NT + t] = tri[3 * t + k];
+  int ne = ne_given;
+  if (!edges_given) {
+    for (int s = tid; s < nslots; s += TW) {
+      int a, c;
+      const uint32_t key = slot_key(s, a, c);
+      uint32_t h = hslot(key);
+      for (;;) {
+        const uint32_t old = atomicCAS(&hkey[h], EMPTY, key);
+        if (old == EMPTY || old == key) break;
+        h = (h + 1) & (HSZ - 1);
+      }
+      atomicMin(&hval[h], (uint32_t)s);
+    }
+    __syncthreads();
+    for (int s = tid; s < TNS; s += TW) {
+      int first = 0;
+      if (s < nslots) {
+        int a, c;
+        const uint32_t h = probe(slot_key(s, a, c));
+        const uint32_t m = hval[h] & 0x7FFFFFFFu;
+        first = m == (uint32_t)s;
+        if (!first) atomicOr(&hval[h], 0x80000000u);  // a second owner: interior edge
+      }
+      scanb[s] = first;
+    }
+    __syncthreads();
+    // (the flags must be read back before the scan overwrites them)
+    bool isfirst[PER];
+  #pragma unroll
+    for (int i = 0; i < PER; ++i) isfirst[i] = scanb[tid * PER + i] != 0;
+    __syncthreads();
+    ne = scan_excl(scanb, TNS, part);
+    if (ne > TNE || nv + ne > D.NP) {
+      if (tid == 0) status[b] = -1;
+      return;
+    }
+  #pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int s = tid * PER + i;
+      if (s < nslots && isfirst[i]) {
+        int a, c;
+        const uint32_t h = probe(slot_key(s, a, c));
+        const int e = scanb[s];
+        const bool shared = (hval[h] & 0x80000000u) != 0;
+        ea[e] = (uint16_t)a;
+        eb[e] = (uint16_t)c;
+        eown[e] = (uint16_t)s;
+        eflag[e] = shared ? 0 : 1;
+      }
+    }
+    __syncthreads();
+    for (int s = tid; s < nslots; s += TW) {
+      int a, c;
+      const uint32_t h = probe(slot_key(s, a, c));
+      const int e = scanb[hval[h] & 0x7FFFFFFFu];
+      eid_slot[s] = (uint16_t)e;
+      const int t = s / 3, k = s - 3 * t;
+      cd[(3 + k) * D.NT + t] = nv + e;
+      cd[k * D.NT + t] = tri[3 * t + k];
+    }
+    if (tid == 0) D.ne[b] = ne;
+    for (int i = tid; i < nv; i += TW) {
+      pts[2 * i] = X[i].x;
+      pts[2 * i + 1] = X[i].y;
+    }
+    __syncthreads();
   }
-  if (tid == 0) D.ne[b] = ne;
-  for (int i = tid; i < nv; i += TW) {
-    pts[2 * i] = X[i].x;
-    pts[2 * i + 1] = X[i].y;
-  }
-  __syncthreads();
+  const int n2 = nv + ne;
   TT_STAMP(1)
   // ================= P2 dof coordinates, boundary vertices, facet tags (later marks override earlier ones)
   const double E = 3.0e-16;

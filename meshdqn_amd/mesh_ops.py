@@ -411,6 +411,15 @@ class DeviceTopologyBatch:
             d.ipcs = C.cast(C.pointer(o), C.c_void_p)
         self.desc = d
 
+    def take_edges_from(self, cell_dofs=None, ne=None):
+        """A `flow_only` engine: take the edge numbering from the cell dofs (B,6,NT) / edge counts (B,) that another engine's
+        run derived from the SAME meshes instead of finding it again through the hash table (None: number the edges here)."""
+        if self.ti is None:
+            raise ValueError("take_edges_from needs an engine with the IPCS index data")
+        self._edges_in = (cell_dofs, ne)         # (kept alive)
+        self._ipcs_out.cell_dofs_in = None if cell_dofs is None else cell_dofs.data_ptr()
+        self._ipcs_out.ne_in = None if ne is None else ne.data_ptr()
+
     def run(self, stream=None, check=True):
         _lib.check(self.lib.mdq_env_topology(C.byref(self.desc), _lib.stream_ptr(stream), self.status.data_ptr()),
                    "mdq_env_topology")

@@ -219,7 +219,10 @@ class VecEnv2DAirfoil:
             # k - 1 ends -> main copies -> flow k starts, two event round trips + the copy per step on the flow's
             # critical path - and the S3 step lasted (flow leg + ~70 us) instead of max(main chain, flow leg).
             ft, t0 = self._ftopo, self.flow_ts[0]
-            self._flow_in = [dict(coords=ft.coords, cells=ft.cells, nv=ft.nv, nt=ft.nt, u_n=t0["u_n"], p_n=t0["p_n"])]
+            self._flow_in = [dict(coords=ft.coords, cells=ft.cells, nv=ft.nv, nt=ft.nt, u_n=t0["u_n"], p_n=t0["p_n"],
+                                  # the main engine's cell dofs / edge counts of the same meshes: the flow's topology run takes
+                                  # its edge numbering from them (no second hash pass)
+                                  cell_dofs=torch.zeros_like(self.dtopo.t["cell_dofs"]), ne=torch.zeros_like(self.dtopo.t["ne"]))]
             self._flow_in.append({k: torch.zeros_like(a) for k, a in self._flow_in[0].items()})
 
     def _flow(self, keep, out_u, out_p):
@@ -270,7 +273,8 @@ class VecEnv2DAirfoil:
         # meshes + the warm start (the in-place reset of a terminated environment rewrites its rows of out_u / out_p) in
         # ONE launch (six torch copies were ~50 us of the main chain)
         su, sp_ = out_u[:, self.S - 1], out_p[:, self.S - 1]
-        pairs = [(fin["coords"], dt.coords), (fin["cells"], dt.cells), (fin["nv"], dt.nv), (fin["nt"], dt.nt), (fin["u_n"], su), (fin["p_n"], sp_)]
+        pairs = [(fin["coords"], dt.coords), (fin["cells"], dt.cells), (fin["nv"], dt.nv), (fin["nt"], dt.nt), (fin["u_n"], su), (fin["p_n"], sp_),
+                 (fin["cell_dofs"], dt.t["cell_dofs"]), (fin["ne"], dt.t["ne"])]
         n = len(pairs)
         vp, i64 = C.c_void_p * n, C.c_int64 * n
         rows, rb, ss, ds = [], [], [], []
@@ -293,6 +297,7 @@ class VecEnv2DAirfoil:
             setattr(d, kk, v.data_ptr())
         for kk in ("coords", "cells", "nv", "nt"):            # the flow's topology engine reads the same set
             setattr(ft.desc, kk, fin[kk].data_ptr())
+        ft.take_edges_from(fin["cell_dofs"], fin["ne"])
         t["u_n"], t["p_n"] = fin["u_n"], fin["p_n"]
         res = self._flow_res[self._flow_n % 2]
         with torch.cuda.stream(self._flow_stream):

@@ -513,6 +513,22 @@ def test_device_topology_engine_is_bit_identical_to_host_engine(lib_built, meshe
         assert np.array_equal(gi["mf_scat"][b][:, :nt], hi["mf_scat"][b][:, :nt])
         nse = int(hi["sl1_off"][b][(nv + 63) // 64])
         assert np.array_equal(gi["sl1_col"][b][:nse], hi["sl1_col"][b][:nse])
+    # the flow stream's variant: no selection / state graph, edge numbering taken from the first engine's cell dofs instead
+    # of the hash table - the same index data, cell dofs, points and facets
+    fb = DeviceTopologyBatch(*args, device="cuda", ipcs=True, nse1_cap=hb.NSE1, flow_only=True)
+    fb.coords.copy_(db.coords); fb.cells.copy_(db.cells); fb.nv.copy_(db.nv); fb.nt.copy_(db.nt)
+    fb.take_edges_from(db.t["cell_dofs"].clone(), db.t["ne"].clone())
+    fb.run()
+    torch.cuda.synchronize()
+    for k in ("ne", "naf", "cell_dofs", "points", "af_facets"):
+        assert torch.equal(fb.t[k], db.t[k]), k
+    for k in db.ti:
+        assert torch.equal(fb.ti[k], db.ti[k]), k
+    bad = db.t["cell_dofs"].clone()
+    bad[1, 3:] += 5000                                     # (not the dofs of this mesh: refused, not trusted)
+    fb.take_edges_from(bad, db.t["ne"].clone())
+    with pytest.raises(Exception):
+        fb.run()
 
 
 @pytest.mark.parametrize("name", ["ys930", "ah93w145"])
