@@ -442,6 +442,9 @@ typedef struct mdq_interp_desc {
    * location needs of a candidate cell in ONE record, 16-byte aligned (NULL: gathered from src_cell_dofs / src_coords /
    * src_geom) */
   const double* src_cellrec;
+  /* optional, device [B]: added to npts[b] (a caller that holds vertex and edge counts separately passes np1 as npts and
+   * the edge counts here instead of launching an add) */
+  const int32_t* npts_extra;
 } mdq_interp_desc;
 
 /*

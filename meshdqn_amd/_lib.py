@@ -64,6 +64,7 @@ class InterpDesc(C.Structure):
         ("src_coords", C.c_void_p), ("src_cell_dofs", C.c_void_p), ("src_geom", C.c_void_p),
         ("bin_ptr", C.c_void_p), ("bin_cells", C.c_void_p), ("src_u", C.c_void_p), ("src_p", C.c_void_p),
         ("out_u", C.c_void_p), ("out_p", C.c_void_p), ("out_cell", C.c_void_p), ("src_cellrec", C.c_void_p),
+        ("npts_extra", C.c_void_p),
     ]
 
 

@@ -13,7 +13,7 @@ namespace mdq_mesh {
 // snapshots with the P2 / P1 bases of that cell.
 __global__ __launch_bounds__(256) void interpolate_kernel(mdq_interp_desc d) {
   const int b = blockIdx.y;
-  const int npts = d.npts[b];
+  const int npts = d.npts[b] + (d.npts_extra ? d.npts_extra[b] : 0);
   const int np1 = d.np1[b];
   const int64_t B = b;
   const double* pts = d.points + B * d.NP * 2;

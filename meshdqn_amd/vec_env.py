@@ -421,14 +421,14 @@ class VecEnv2DAirfoil:
             dt = self.dtopo
             dt.run(check=False)                     # status is read back with the other results below
             t_pts, np1 = dt.t["points"], dt.nv
-            npts = np1 + dt.t["ne"]
+            npts, npts_extra = np1, dt.t["ne"]          # (P2 points = vertices + edges: added inside the kernel)
         else:
             torch.cuda.current_stream(dev).synchronize()   # pending async uploads read the arrays the engine rewrites
             self.topo.run(self.nthreads)
             up = self.topo.upload
             t_pts = up("points", dev)
             np1 = up("nv", dev)
-            npts = np1 + up("ne", dev)
+            npts, npts_extra = np1 + up("ne", dev), None
         it = self.interp
         # two persistent (ping-pong) result sets, zero-filled once: the interpolation writes every valid dof of the current
         # meshes and nothing reads the padding behind them (INVARIANT: rows behind nv / np2 of a set hold stale values of
@@ -445,6 +445,7 @@ class VecEnv2DAirfoil:
         d.src_nv, d.src_nt, d.src_n2 = it.topo.nv, it.topo.nt, it.topo.np2
         d.gnx, d.gny, d.x0, d.y0, d.inv_hx, d.inv_hy = it.grid
         d.npts, d.np1, d.points = npts.data_ptr(), np1.data_ptr(), t_pts.data_ptr()
+        d.npts_extra = None if npts_extra is None else npts_extra.data_ptr()
         for k, v in it.t.items():
             setattr(d, k, v.data_ptr())
         d.out_u, d.out_p, d.out_cell = out_u.data_ptr(), out_p.data_ptr(), None
