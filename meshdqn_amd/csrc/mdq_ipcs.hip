@@ -23,6 +23,9 @@
 #include "mdq_device.h"
 #include "mdq_elem.h"
 
+#ifndef MDQ_PCG_REGM
+#define MDQ_PCG_REGM 1
+#endif
 #ifndef MDQ_PCG_WG_DEFAULT
 #define MDQ_PCG_WG_DEFAULT 512
 #endif
@@ -1266,6 +1269,122 @@ __device__ inline int cg_pressure_reg(int n, const int32_t* sl_off, const int32_
       for (int j = 0; j < wid[k]; ++j) y0 += a[j * 64] * vec[c[j * 64]];
       y[k] = y0;
     }
+  };
+  __syncthreads();
+  double y[2], xv[2], rv[2], pv[2];
+  spmv(x, y);
+  double acc[2] = {0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    xv[k] = rv[k] = pv[k] = 0.0;
+    if (row[k] < n) {
+      const double b = r[row[k]];
+      xv[k] = x[row[k]];
+      rv[k] = pv[k] = b - y[k];
+      p[row[k]] = pv[k];
+      acc[0] += b * b;
+      acc[1] += rv[k] * rv[k];
+    }
+  }
+  block_sum<2, NW>(acc, red);
+  const double bb = acc[0], tol2 = rtol * rtol * bb;
+  double rr = acc[1];
+  int it = 0;
+  if (rr > tol2 && bb != 0.0) {
+    while (it < maxit) {
+      ++it;
+      double q[2];
+      spmv(p, q);
+      double a1[1] = {pv[0] * q[0] + pv[1] * q[1]};
+      block_sum1<1, NW>(a1, red, rsel);
+      if (!(a1[0] > 0.0)) break;
+      const double alpha = rr / a1[0];
+      double a2[1] = {0.0};
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        xv[k] += alpha * pv[k];
+        rv[k] -= alpha * q[k];
+        a2[0] += rv[k] * rv[k];
+      }
+      block_sum1<1, NW>(a2, red, rsel);
+      const double rr_new = a2[0];
+      if (!(rr_new > tol2)) break;
+      const double beta = rr_new / rr;
+      rr = rr_new;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        pv[k] = rv[k] + beta * pv[k];
+        if (row[k] < n) p[row[k]] = pv[k];
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+    if (row[k] < n) x[row[k]] = xv[k];
+  __syncthreads();
+  return it;
+}
+
+// cg_pressure_reg with the matrix rows of a thread in REGISTERS and a BRANCH-FREE operator application.  Counters of the
+// LDS-resident version (profiles/r03_sq_summary.json): LDS utilisation 20 %, bank conflicts 0.3 %, VALU busy 18 % - the
+// iteration is a chain of LDS LATENCIES, not bandwidth: per row three batches of (index, value) reads followed by the
+// dependent gathers, two rows one after the other, ~2 100 of the iteration's ~3 400 cycles.  Here a thread loads the
+// up to RW entries of its two rows once (slots past a slice's width: value 0, column = own row, like the SELL padding),
+// and an application issues all 2 x RW gathers back to back - no branch, so nothing waits between them - and then runs
+// the two fma chains in the same column order as before (adding 0 * p[row] for the padded slots).  (The Chebyshev
+// variant below keeps its rows in registers too but guards every gather with a branch on the slice width, which
+// serialises the round trips: that is why it never beat the LDS version.)  Needs n <= 2 * NTH and slices of at most RW
+// entries per row: returns -1 otherwise (the caller takes cg_pressure_reg).
+template <int NTH, int RW = 16>
+__device__ inline int cg_pressure_regm(int n, const int32_t* sl_off, const int32_t* sl_col, const double* A, double rtol,
+                                       int maxit, double* x, double* r, double* p, double* red, int& rsel) {
+  constexpr int NW = NTH / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nsl = (n + 63) >> 6;
+  int row[2];
+  double av[2][RW];
+  int co[2][RW];                      // byte offsets into the gathered vector
+  bool fits = true;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int s_ = wave + NW * k;
+    row[k] = (s_ << 6) + lane;
+    const int base = s_ < nsl ? sl_off[s_] : 0;
+    const int wid = s_ < nsl ? (sl_off[s_ + 1] - base) >> 6 : 0;
+    fits = fits && wid <= RW;
+    const int self = min(row[k], n - 1);
+#pragma unroll
+    for (int j = 0; j < RW; ++j) {
+      const bool in = j < wid;
+      av[k][j] = in ? A[base + lane + j * 64] : 0.0;
+      co[k][j] = 8 * (in ? sl_col[base + lane + j * 64] : self);
+    }
+  }
+  // workgroup-wide OR of `!fits` through the (still unused) search-direction vector (no static LDS in this kernel)
+  if (threadIdx.x == 0) p[NW] = 0.0;
+  __syncthreads();
+  if (!fits) p[NW] = 1.0;
+  __syncthreads();
+  const bool toowide = p[NW] != 0.0;
+  __syncthreads();
+  if (toowide) return -1;
+  auto spmv = [&](const double* vec, double(&y)[2]) {
+    const char* vb = reinterpret_cast<const char*>(vec);
+    double g[2][RW];
+#pragma unroll
+    for (int j = 0; j < RW; ++j) {
+      g[0][j] = *reinterpret_cast<const double*>(vb + co[0][j]);
+      g[1][j] = *reinterpret_cast<const double*>(vb + co[1][j]);
+    }
+    double y0 = 0.0, y1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < RW; ++j) {
+      y0 += av[0][j] * g[0][j];
+      y1 += av[1][j] * g[1][j];
+    }
+    y[0] = y0;
+    y[1] = y1;
   };
   __syncthreads();
   double y[2], xv[2], rv[2], pv[2];
@@ -3816,6 +3935,8 @@ __global__ __launch_bounds__(NTH) void at_pressure_kernel(mdq_ipcs_desc d, int32
         itc = cg_pressure_2l<NTH>(nv, so1, ci1, K1, v.coords, d.rtol, d.maxit_p, px, pr, pp, P.NVp, red, rsel);
       else if (nv <= 2 * NTH && d.pcg_degree > 0)   // rows in registers, Chebyshev-preconditioned (degree 1: Jacobi only)
         itc = cg_pressure_cheb<NTH>(nv, so1, ci1, K1, d.rtol, d.maxit_p, d.pcg_degree, px, pr, pp, red, rsel);
+      if (itc < 0 && nv <= 2 * NTH && d.pcg_degree == 0 && MDQ_PCG_REGM)   // rows in registers, branch-free application
+        itc = cg_pressure_regm<NTH>(nv, so1, ci1, K1, d.rtol, d.maxit_p, px, pr, pp, red, rsel);
       if (itc >= 0)
         it_p += itc;
       else if (nv <= 2 * NTH)
