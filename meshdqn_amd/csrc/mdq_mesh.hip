@@ -400,25 +400,21 @@ __global__ void env_result_kernel(int B, int N, int S, const double* new_drags, 
   steps[b] = (dn && auto_reset) ? 0 : st;
 }
 
-// (1024 threads and 64 KB per workgroup: with 256 threads and 16 KB the grid of a 128-environment step was 26 k workgroups,
-// nearly all of which only read their mask byte - 12 us of workgroup dispatch per env step)
-constexpr int RESTORE_MCHUNK = 16384;   // words per workgroup of the masked kernel
-constexpr int RESTORE_MTH = 1024;
-__global__ __launch_bounds__(RESTORE_MTH) void restore_rows_masked_kernel(RestoreArgs a, const uint8_t* mask) {
+__global__ __launch_bounds__(256) void restore_rows_masked_kernel(RestoreArgs a, const uint8_t* mask) {
   if (!mask[blockIdx.x]) return;
   const int t = blockIdx.y;
   const int64_t n = a.words[t];
-  const int64_t w0 = (int64_t)blockIdx.z * RESTORE_MCHUNK;
+  const int64_t w0 = (int64_t)blockIdx.z * RESTORE_CHUNK;
   if (w0 >= n) return;
-  const int64_t w1 = w0 + RESTORE_MCHUNK < n ? w0 + RESTORE_MCHUNK : n;
+  const int64_t w1 = w0 + RESTORE_CHUNK < n ? w0 + RESTORE_CHUNK : n;
   uint32_t* d = a.dst[t] + (int64_t)blockIdx.x * n;
   const uint32_t* s = a.src[t];
   if ((n & 3) == 0 && ((reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(s)) & 15) == 0) {
     uint4* d4 = reinterpret_cast<uint4*>(d);
     const uint4* s4 = reinterpret_cast<const uint4*>(s);
-    for (int64_t i = (w0 >> 2) + threadIdx.x; i < (w1 >> 2); i += RESTORE_MTH) d4[i] = s4[i];
+    for (int64_t i = (w0 >> 2) + threadIdx.x; i < (w1 >> 2); i += 256) d4[i] = s4[i];
   } else {
-    for (int64_t i = w0 + threadIdx.x; i < w1; i += RESTORE_MTH) d[i] = s[i];
+    for (int64_t i = w0 + threadIdx.x; i < w1; i += 256) d[i] = s[i];
   }
 }
 
@@ -494,9 +490,8 @@ extern "C" int mdq_restore_rows_masked(int32_t n, void* const* dst, const void* 
   }
   int64_t wmax = 0;
   for (int t = 0; t < n; ++t) wmax = a.words[t] > wmax ? a.words[t] : wmax;
-  const int chunks = (int)((wmax + mdq_mesh::RESTORE_MCHUNK - 1) / mdq_mesh::RESTORE_MCHUNK);
-  hipLaunchKernelGGL(mdq_mesh::restore_rows_masked_kernel, dim3(B, n, chunks), dim3(mdq_mesh::RESTORE_MTH), 0, (hipStream_t)stream, a,
-                     mask);
+  const int chunks = (int)((wmax + mdq_mesh::RESTORE_CHUNK - 1) / mdq_mesh::RESTORE_CHUNK);
+  hipLaunchKernelGGL(mdq_mesh::restore_rows_masked_kernel, dim3(B, n, chunks), dim3(256), 0, (hipStream_t)stream, a, mask);
   if (hipGetLastError() != hipSuccess) return mdq_set_error("restore_rows_masked_kernel launch failed");
   return 0;
 }
