@@ -517,33 +517,40 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   }
   __syncthreads();
   TT_STAMP(12)
-  // stable argsort by counting, four lanes per entry (a quarter of the list each): rank = entries with a smaller distance
-  // + entries with the SAME distance and a smaller index; the second count only runs for entries that have a twin
+  // stable argsort: bitonic sort of (distance, index) pairs in LDS - unique keys, so the result is the order the counting
+  // sort produced (ascending distance, ties by index).  The compare-exchange stages at distance < 64 stay inside a wave's 64
+  // consecutive elements and need no workgroup barrier (a wave's LDS operations execute in order), so a sort of up to
+  // 1 024 entries pays 14 barriers for its 55 stages.  (Counting ranks - every entry against every other, four lanes per
+  // entry - was issue-bound at 45 k cycles.)
   {
-    const int QL = (nrem + 3) >> 2;
-    for (int it0 = 0; it0 < 4 * nrem; it0 += TW) {
-      const int it = it0 + tid, r = min(it >> 2, nrem - 1), part = it & 3;
-      const double dr = dist[r];
-      const int q0 = part * QL, q1 = min(nrem, q0 + QL);
-      int lt = 0, eq = 0;
-#pragma unroll 8
-      for (int q = q0; q < q1; ++q) {
-        const double dq = dist[q];
-        lt += dq < dr ? 1 : 0;
-        eq += dq == dr ? 1 : 0;
+    int P = 64;
+    while (P < nrem) P <<= 1;                       // <= TNV
+    for (int i = tid; i < P; i += TW) {
+      if (i >= nrem) dist[i] = __builtin_huge_val();
+      order[i] = (uint16_t)(i < nrem ? i : 0xFFFF);
+    }
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+      if (k > 64) __syncthreads();                  // (the wave-local stages of the previous k are done everywhere)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < P; i += TW) {
+          const int x = i ^ j;
+          if (x > i) {
+            const bool up = (i & k) == 0;
+            const double a_ = dist[i], c_ = dist[x];
+            const uint16_t ia = order[i], ic = order[x];
+            const bool after = a_ > c_ || (a_ == c_ && ia > ic);      // the pair (a, ia) sorts behind (c, ic)
+            if (after == up) {
+              dist[i] = c_;
+              dist[x] = a_;
+              order[i] = ic;
+              order[x] = ia;
+            }
+          }
+        }
+        if (j >= 64) __syncthreads();
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
-      lt += __shfl_xor(lt, 1, 64);
-      lt += __shfl_xor(lt, 2, 64);
-      eq += __shfl_xor(eq, 1, 64);
-      eq += __shfl_xor(eq, 2, 64);
-      int tie = 0;
-      if (eq > 1) {                                // (its own entry counts once)
-        const int qe = min(q1, r);
-        for (int q = q0; q < qe; ++q) tie += dist[q] == dr ? 1 : 0;
-      }
-      tie += __shfl_xor(tie, 1, 64);
-      tie += __shfl_xor(tie, 2, 64);
-      if (part == 0 && (it >> 2) < nrem) order[lt + tie] = (uint16_t)r;
     }
   }
   TT_STAMP(13)
