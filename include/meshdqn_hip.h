@@ -58,7 +58,9 @@ typedef struct mdq_ipcs_desc {
      these bound the error of the iterative replacement) */
   double rtol;          /* relative residual tolerance (preconditioned norm) */
   int32_t maxit_u, maxit_p, maxit_m;
-  int32_t mode;         /* operator application: -1 auto, 0 assembled SELL (global gather vectors),
+  int32_t mode;         /* operator application: -1 auto (fastest that fits), -2 auto among the BITWISE REPRODUCIBLE
+                           variants (everything but 3: what ground truths / re-simulations of thousands of steps run
+                           on, deploy_dqn.py:262-269, Env2DAirfoil.py:111-125), 0 assembled SELL (global gather vectors),
                            1 assembled SELL (LDS gather vectors), 2 matrix-free LDS element tiles (bitwise
                            reproducible), 3 matrix-free with LDS fp64 atomics (fastest; round-off reproducible),
                            4 assembled SELL with TWO workgroups per environment (any mesh size, rows / cells / slices

@@ -4421,7 +4421,8 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
     mode = 0;
     if (red_bytes + P.vel1_bytes <= LDS_MAX) mode = 1;
     if (red_bytes + P.vel2_bytes <= LDS_MAX && d->N2 <= MF_ROWS * WG) mode = 2;
-    if (red_bytes + P.vel3_bytes <= LDS_MAX && d->N2 <= MF_ROWS * WG) mode = 3;
+    // (mode -2 = auto among the BITWISE REPRODUCIBLE variants: everything but the LDS-atomic mode 3)
+    if (d->mode != -2 && red_bytes + P.vel3_bytes <= LDS_MAX && d->N2 <= MF_ROWS * WG) mode = 3;
     if (mode == 0) {
       // a mesh that only fits the assembled global-memory path: two workgroups per environment while the batch leaves
       // at least half of the chip idle even so (measured on ys930 red-refined, ms per step one / two workgroups: B = 1

@@ -18,7 +18,9 @@ re-meshes and restarts the flow from rest, flow_solver.py:233-359), so the polic
 all M coarsened meshes of the episode (+ the mesh of the final simulation) are re-simulated together as ONE `IpcsBatch`:
 M environments x `solver_steps` steps in `solver_steps` launches instead of M x `solver_steps` (one workgroup per mesh:
 44 meshes use 44 CUs instead of 1).  `batched=False` keeps the reference's order (DEPLOY mode: every step re-assembles and
-re-factorises, then `run_sim`); both give the same files (tested to 1e-9).
+re-factorises, then `run_sim`); both give the same files BIT FOR BIT at the stock 5000 steps (the flow solver's default is
+the reproducible operator mode 2: one workgroup per mesh, fixed summation order, so a mesh's trajectory does not depend
+on the batch it is simulated in; tests/test_deploy_gpu.py).
 """
 from __future__ import annotations
 
@@ -54,7 +56,8 @@ def resimulate_batch(env, meshes):
     fs = env.flow_solver
     topos = [MeshTopology(np.asarray(c, np.float64), np.asarray(t)) for c, t in meshes]
     batch = IpcsBatch(topos, [t.coords for t in topos], mu=fs.mu, rho=fs.rho, dt=fs.dt_value, rtol=fs.rtol,
-                      device=fs.device, pressure_direct=("device" if fs.solver_type == "lu" else False))
+                      device=fs.device, mode=getattr(fs, "mode", -1),
+                      pressure_direct=("device" if fs.solver_type == "lu" else False))
     batch.assemble()
     drags, lifts, done = [], [], 0
     while done < env.solver_steps:

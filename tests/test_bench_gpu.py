@@ -100,3 +100,33 @@ def test_bench_two_torchrun_ranks_share_one_gpu(lib_built):
                  "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2"] + small, env)
     assert res["n_gpus"] == 2 and res["collective_backend"]["ranks"] == 2 and res["config"]["collective_backend"]["ranks"] == 2
     assert abs(res["value"] - 2 * 16 * 6 / (res["ms_per_step"] * 6e-3)) < 1e-6 * res["value"]
+
+
+TINY = ["--steps", "3", "--warmup", "1", "--repeats", "2", "--spinup", "20", "--s2-steps", "10", "--envs", "4",
+        "--s1-steps", "0", "--train-steps", "0", "--s1-solver-steps", "100", "--no-cpu-baseline"]
+
+
+def test_bench_eight_ranks_share_one_gpu(lib_built):
+    """The launcher at the width the driver uses (N = 8), tiny envs, all ranks on cuda:0 over gloo: eight builds behind the
+    rank-0 barrier, eight ground truths, the 127.0.0.1 rendezvous with the short timeout, max-over-ranks timing."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MDQ_SHARE_GPU="1", MDQ_DIST_BACKEND="gloo")
+    res = _line([sys.executable, "bench.py", "--gpus", "8"] + TINY, env)
+    assert res["n_gpus"] == 8 and res["collective_backend"]["ranks"] == 8 and res["scaling"] == "weak"
+    assert abs(res["value"] - 8 * 4 * 3 / (res["ms_per_step"] * 3e-3)) < 1e-6 * res["value"]
+    assert res["value_min"] <= res["value"] <= res["value_max"]
+
+
+def test_bench_launcher_tears_down_when_a_rank_dies(lib_built):
+    """Rank 3 of 8 exits at the start (MDQ_BENCH_FAIL_RANK): the other seven sit in the rendezvous; the parent names the
+    rank, terminates its children and exits non-zero within seconds - not after a c10d timeout."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MDQ_SHARE_GPU="1", MDQ_DIST_BACKEND="gloo", MDQ_BENCH_FAIL_RANK="3")
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "8"] + TINY, cwd=ROOT, env=env, capture_output=True, text=True,
+                         timeout=600)
+    took = time.monotonic() - t0
+    assert out.returncode == 1 and took < 150, (out.returncode, took, out.stderr[-2000:])   # (8 x `import torch` on a cold box)
+    assert "rank 3 of 8 exited with code 3" in out.stderr and "MDQ_BENCH_FAIL_RANK" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

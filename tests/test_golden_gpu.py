@@ -47,15 +47,33 @@ def test_first_steps_match_golden(meshes, lib_built):
 
 
 @pytest.mark.slow
-def test_trajectory_checkpoints_match_golden(meshes, lib_built):
-    """Default solver tolerances, 5000 steps from rest: every 1000th step against the derived vectors (5e-6: the LDS
-    atomics make the run reproducible to round-off only, and over thousands of steps at rtol 1e-10 the run-to-run
-    spread of drag / lift is 1e-8 .. 1.6e-6, measured with tools/traj_spread.py) and the last one against the
-    reference CSV rows (north-star tolerance 1e-4, CSV print precision 5e-8)."""
+@pytest.mark.parametrize("mode", [-2, 3])
+def test_trajectory_checkpoints_match_golden(meshes, lib_built, mode):
+    """5000 steps from rest at the tolerance that stands in for the reference's LU (rtol 1e-13): every 1000th step within
+    1e-9 of the derived vectors (the oracle's exact-LU trajectory) - in the reproducible operator mode the flow solver
+    defaults to (-2 -> 2) AND in mode 3 (LDS atomics): measured 7e-10 / 4e-10 at worst (tools/traj_determinism.py).  The
+    5e-6 this test needed in rounds 1-3 was the Krylov stopping test at rtol 1e-10 (1e-8 .. 1.3e-6 in every mode), not the
+    atomics.  The last step against the reference CSV rows (north-star tolerance 1e-4, CSV print precision 5e-8)."""
+    batch, _, _ = _batch(meshes, mode=mode, rtol=1e-13, pressure_direct="device")
+    for k in range(1, 6):
+        drag, lift = batch.evolve(1000)
+        torch.cuda.synchronize()
+        for b, n in enumerate(NAMES):
+            g = FLOW[n]["steps"][str(1000 * k)]
+            assert abs(drag[b, -1].item() - g["drag"]) < 1e-9 * abs(g["drag"]), (n, k)
+            assert abs(lift[b, -1].item() - g["lift"]) < 1e-9 * abs(g["lift"]), (n, k)
+    for b, n in enumerate(NAMES):
+        assert abs(drag[b, -1].item() - KAT[n]["drag"]) < 1e-6 * abs(KAT[n]["drag"])
+        assert abs(lift[b, -1].item() - KAT[n]["lift"]) < 1e-6 * abs(KAT[n]["lift"])
+
+
+@pytest.mark.slow
+def test_trajectory_at_the_default_tolerance_stays_inside_the_contract(meshes, lib_built):
+    """The batched S2 / S3 legs run at rtol 1e-10 in mode 3: 5000 steps land within 5e-6 of the exact-LU checkpoints (measured
+    1e-8 .. 1.4e-6) and within the north star's 1e-4 of the FEniCS CSV rows."""
     batch, _, _ = _batch(meshes)
     for k in range(1, 6):
-        for _ in range(10):
-            drag, lift = batch.evolve(100)
+        drag, lift = batch.evolve(1000)
         torch.cuda.synchronize()
         for b, n in enumerate(NAMES):
             g = FLOW[n]["steps"][str(1000 * k)]

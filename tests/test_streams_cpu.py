@@ -39,3 +39,22 @@ def test_roles_own_queues_reads_the_log(monkeypatch):
                            cu_partition={"main": [0, 256], "flow": [0, 256], "opt": [0, 256]})]
     assert streams.roles_own_queues("cuda:0")
     assert not streams.roles_own_queues("cuda:1")
+
+
+def test_bench_profiler_test_agrees_with_the_package(monkeypatch):
+    """bench.py's CPU-baseline interpreters decide `skip the multi-process legs under a profiler` with the same environment
+    test as the package's stream roles (the two guards had drifted apart)."""
+    import importlib.util
+    import os
+    from meshdqn_amd import streams
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for k in list(os.environ):
+        if k.startswith(("ROCPROF_", "ROCP_TOOL", "ROCPROFILER_")):
+            monkeypatch.delenv(k, raising=False)
+    for var, val in (("LD_PRELOAD", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so"), ("LD_PRELOAD", "libfoo.so"),
+                     ("HSA_TOOLS_LIB", "librocprofiler64.so.1"), ("ROCPROF_KERNEL_TRACE", "1"), ("ROCP_TOOL_LIBRARIES", "x.so")):
+        monkeypatch.setenv(var, val)
+        assert bench._profiler_attached() == streams.profiler_attached(), (var, val)
+        monkeypatch.delenv(var)
