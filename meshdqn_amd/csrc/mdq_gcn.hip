@@ -123,7 +123,9 @@ template <bool ROOT, int FIN>
 __device__ __forceinline__ void conv_dense_small_fin(const Lds& L, int n, int fin_rt, int C, const float* __restrict__ wl,
                                             const float* __restrict__ b, const float* __restrict__ wr,
                                             const float* A, const float* X) {
-  const int tid = threadIdx.x, c = tid % C, g = tid / C, G = WGT / C;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));   // (keeps the per-row address arithmetic inside the level: see run_level)
+  const int c = tid % C, g = tid / C, G = WGT / C;
   constexpr int NF = FIN > 0 ? FIN : 32;
   const int fin = FIN > 0 ? FIN : fin_rt;
   float wlr[NF], wrr[NF];
@@ -168,7 +170,9 @@ __device__ __forceinline__ void conv_dense_small_n(const Lds& L, int n, int fin,
                                           const float* __restrict__ b, const float* __restrict__ wr, const float* A,
                                           const float* X, float* wbuf) {
   constexpr int NACC = NA;   // (shadows the namespace constant inside this instance)
-  const int tid = threadIdx.x, c = tid % C, g = tid / C, G = WGT / C;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int c = tid % C, g = tid / C, G = WGT / C;
   float acc[NACC];
 #pragma unroll
   for (int r = 0; r < NACC; ++r) acc[r] = 0.f;
@@ -214,6 +218,9 @@ __device__ __forceinline__ void conv_dense_small_n(const Lds& L, int n, int fin,
       for (int q = 0; q < FBW; q += 4) {
 #pragma unroll
         for (int r = 0; r < NACC; ++r) {
+          // (rows in groups of 8: the compiler otherwise puts the operand reads of all NACC rows of several q in flight and
+          //  spills - the 24-row instance carried 600 B of scratch per lane)
+          if (NACC > 8 && (r & 7) == 0) asm volatile("" ::: "memory");
           const int i = min(g + r * G, n - 1);   // (rows past n re-read row n - 1, never stored)
           const float4 a4 = *reinterpret_cast<const float4*>(A + i * fin + f0 + q);
           float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -248,6 +255,7 @@ __device__ __forceinline__ void conv_dense_small_n(const Lds& L, int n, int fin,
         for (int r = 0; r < NACC; ++r) {
           // rows past n re-read row n - 1 (never stored): unconditional reads, so that the LDS loads of a block
           // are in flight together instead of one conditional block - one LDS round trip - per (feature, row)
+          if (NACC > 8 && (r & 7) == 0) asm volatile("" ::: "memory");
           const int i = min(g + r * G, n - 1);
           acc[r] = fmaf(w1[q], A[i * fin + f], acc[r]);
           if (ROOT) acc[r] = fmaf(w2[q], X[i * fin + f], acc[r]);
@@ -343,7 +351,9 @@ struct TapeLevel {
 template <bool TAPE = false>
 __device__ __forceinline__ void run_level(const Lds& L, const Level& lv, int C, double ratio, int& n, int& E, int32_t* perm, float& rmax,
                                  float& rmean, int NMAX, const TapeLevel* tape = nullptr) {
-  const int tid = threadIdx.x, fin = lv.fin;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int fin = lv.fin;
 #ifdef MDQ_GCN_TRACE
   long long tq_ = __builtin_amdgcn_s_memtime();
 #endif
