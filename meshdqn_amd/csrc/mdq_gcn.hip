@@ -164,11 +164,13 @@ __device__ __forceinline__ void conv_dense_small_fin_any(const Lds& L, int n, in
 // one coalesced cooperative copy (all its loads in flight at once) - streaming the rows from global memory one
 // dependent round trip per feature was 60 % of the whole kernel.
 // NA = accumulators (nodes) per thread: the unrolled node loop costs its instructions whether a node exists or not,
-// so the pooled levels (18, 2, 1 nodes) run instances with 8 / 1 accumulators instead of the 24 of the widest case.
+// so the pooled levels (18, 2, 1 nodes) run instances with 5 / 1 accumulators; more than 8 rows per thread are served by
+// repeated passes of the 8-row instance over row blocks `r0` (the 24-accumulator instance of rounds 2-3 could not be
+// register-allocated without scratch; the weights of a level come from L2 either way).
 template <bool ROOT, int NA>
 __device__ __forceinline__ void conv_dense_small_n(const Lds& L, int n, int fin, int C, const float* __restrict__ wl,
                                           const float* __restrict__ b, const float* __restrict__ wr, const float* A,
-                                          const float* X, float* wbuf) {
+                                          const float* X, float* wbuf, int r0 = 0) {
   constexpr int NACC = NA;   // (shadows the namespace constant inside this instance)
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));
@@ -184,7 +186,7 @@ __device__ __forceinline__ void conv_dense_small_n(const Lds& L, int n, int fin,
       const float w = wbuf[f * C + c];
 #pragma unroll
       for (int r = 0; r < NACC; ++r) {
-        const int i = g + r * G;
+        const int i = g + (r0 + r) * G;
         if (i < n) acc[r] = fmaf(w, A[i * fin + f], acc[r]);
       }
     }
@@ -197,7 +199,7 @@ __device__ __forceinline__ void conv_dense_small_n(const Lds& L, int n, int fin,
         const float w = wbuf[f * C + c];
 #pragma unroll
         for (int r = 0; r < NACC; ++r) {
-          const int i = g + r * G;
+          const int i = g + (r0 + r) * G;
           if (i < n) acc[r] = fmaf(w, X[i * fin + f], acc[r]);
         }
       }
@@ -206,7 +208,7 @@ __device__ __forceinline__ void conv_dense_small_n(const Lds& L, int n, int fin,
     // wide levels of the reference's widths (fin = C = 64 / 128 / 256): FBW features per block - FBW (x 2) weight loads in
     // flight per round trip instead of 16 (the pooled levels are a chain of global round trips: 8 -> 2 for C = 128 with
     // one node per thread) - and the operand rows read four features per LDS instruction.  Same fma order per output.
-    constexpr int FBW = NACC == 1 ? 64 : (NACC <= 8 ? 32 : 16);
+    constexpr int FBW = NACC <= 5 ? 32 : 8;   // (64 for one row: spilled beside the other instances)
     for (int f0 = 0; f0 < fin; f0 += FBW) {
       float w1[FBW], w2[FBW];
 #pragma unroll
@@ -218,10 +220,7 @@ __device__ __forceinline__ void conv_dense_small_n(const Lds& L, int n, int fin,
       for (int q = 0; q < FBW; q += 4) {
 #pragma unroll
         for (int r = 0; r < NACC; ++r) {
-          // (rows in groups of 8: the compiler otherwise puts the operand reads of all NACC rows of several q in flight and
-          //  spills - the 24-row instance carried 600 B of scratch per lane)
-          if (NACC > 8 && (r & 7) == 0) asm volatile("" ::: "memory");
-          const int i = min(g + r * G, n - 1);   // (rows past n re-read row n - 1, never stored)
+          const int i = min(g + (r0 + r) * G, n - 1);   // (rows past n re-read row n - 1, never stored)
           const float4 a4 = *reinterpret_cast<const float4*>(A + i * fin + f0 + q);
           float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
           if (ROOT) x4 = *reinterpret_cast<const float4*>(X + i * fin + f0 + q);
@@ -237,7 +236,7 @@ __device__ __forceinline__ void conv_dense_small_n(const Lds& L, int n, int fin,
       }
     }
   } else {
-    constexpr int FB = 16;
+    constexpr int FB = NACC > 5 ? 8 : 16;
     // (issuing the next block's weight loads before the current block is used was measured slower: 18 -> 25 k cycles
     // on the one-node levels)
     for (int f0 = 0; f0 < fin; f0 += FB) {
@@ -255,8 +254,7 @@ __device__ __forceinline__ void conv_dense_small_n(const Lds& L, int n, int fin,
         for (int r = 0; r < NACC; ++r) {
           // rows past n re-read row n - 1 (never stored): unconditional reads, so that the LDS loads of a block
           // are in flight together instead of one conditional block - one LDS round trip - per (feature, row)
-          if (NACC > 8 && (r & 7) == 0) asm volatile("" ::: "memory");
-          const int i = min(g + r * G, n - 1);
+          const int i = min(g + (r0 + r) * G, n - 1);
           acc[r] = fmaf(w1[q], A[i * fin + f], acc[r]);
           if (ROOT) acc[r] = fmaf(w2[q], X[i * fin + f], acc[r]);
         }
@@ -267,7 +265,7 @@ __device__ __forceinline__ void conv_dense_small_n(const Lds& L, int n, int fin,
   __syncthreads();  // (the staging buffer lives behind the rows of L.h written below; keep phases apart)
 #pragma unroll
   for (int r = 0; r < NACC; ++r) {
-    const int i = g + r * G;
+    const int i = g + (r0 + r) * G;
     if (i < n) L.h[i * (C + 1) + c] = acc[r] + bc;
   }
 }
@@ -348,6 +346,9 @@ struct TapeLevel {
 
 // one conv + relu + TopK pool + readout level; features in L.x ([n][fin]) are replaced by the pooled ones
 // TAPE: the training kernel's instance (keeps the rows of the kept nodes); the inference instance carries none of it
+// (One register allocation has to cover every form inlined here: rounds 2-3 carried 1.4 KB of scratch per lane - the
+// address arithmetic of the 24-row form hoisted out of the level loop, spilled at kernel entry and re-read at every level
+// by graphs that never ran that form.  Now: thread id opaque per level, at most 8 rows per pass, 32 weights in flight.)
 template <bool TAPE = false>
 __device__ __forceinline__ void run_level(const Lds& L, const Level& lv, int C, double ratio, int& n, int& E, int32_t* perm, float& rmax,
                                  float& rmean, int NMAX, const TapeLevel* tape = nullptr) {
@@ -421,12 +422,16 @@ __device__ __forceinline__ void run_level(const Lds& L, const Level& lv, int C, 
       if (per <= 1) conv_dense_small_n<true, 1>(L, n, fin, C, lv.wl, lv.b, lv.wr, L.agg, L.x, wbuf);
       else if (per <= 5) conv_dense_small_n<true, 5>(L, n, fin, C, lv.wl, lv.b, lv.wr, L.agg, L.x, wbuf);
       else if (per <= 8) conv_dense_small_n<true, 8>(L, n, fin, C, lv.wl, lv.b, lv.wr, L.agg, L.x, wbuf);
-      else conv_dense_small_n<true, NACC>(L, n, fin, C, lv.wl, lv.b, lv.wr, L.agg, L.x, wbuf);
+      else
+        for (int r0 = 0; r0 < per; r0 += 8)
+          conv_dense_small_n<true, 8>(L, n, fin, C, lv.wl, lv.b, lv.wr, L.agg, L.x, wbuf, r0);
     } else {
       if (per <= 1) conv_dense_small_n<false, 1>(L, n, fin, C, lv.wl, lv.b, nullptr, L.agg, L.x, wbuf);
       else if (per <= 5) conv_dense_small_n<false, 5>(L, n, fin, C, lv.wl, lv.b, nullptr, L.agg, L.x, wbuf);
       else if (per <= 8) conv_dense_small_n<false, 8>(L, n, fin, C, lv.wl, lv.b, nullptr, L.agg, L.x, wbuf);
-      else conv_dense_small_n<false, NACC>(L, n, fin, C, lv.wl, lv.b, nullptr, L.agg, L.x, wbuf);
+      else
+        for (int r0 = 0; r0 < per; r0 += 8)
+          conv_dense_small_n<false, 8>(L, n, fin, C, lv.wl, lv.b, nullptr, L.agg, L.x, wbuf, r0);
     }
   }
   (void)G;

@@ -44,6 +44,19 @@ struct TapeOffsets {
   int hsel, ssel, aggsel, xsel, perm, amax, esrc, edst;   // in 4-byte units from the graph's workspace; esrc < 0: none
 };
 
+__device__ __forceinline__ TapeLevel tape_level(float* ws, const TapeOffsets& o) {
+  TapeLevel t;
+  t.hsel = ws + o.hsel;
+  t.ssel = ws + o.ssel;
+  t.aggsel = ws + o.aggsel;
+  t.xsel = ws + o.xsel;
+  t.perm = reinterpret_cast<int*>(ws + o.perm);
+  t.amax = reinterpret_cast<int*>(ws + o.amax);
+  t.esrc = o.esrc >= 0 ? reinterpret_cast<int*>(ws + o.esrc) : nullptr;
+  t.edst = o.edst >= 0 ? reinterpret_cast<int*>(ws + o.edst) : nullptr;
+  return t;
+}
+
 // workspace of one graph: [0] its loss term, then the tape of every level sized for NMAX nodes / EMAX edges
 __host__ __device__ inline int tape_layout(const mdq_gcn_net& net, int NMAX, int EMAX, TapeOffsets* off) {
   int pos = 4, n = NMAX;
@@ -154,10 +167,16 @@ __global__ __launch_bounds__(WGT) void gcn_train_kernel(mdq_gcn_net net, mdq_gcn
   __syncthreads();
   TP_STAMP(0)
   // ---------------------------------------------------------------- forward levels (tape: rows of the kept nodes)
-  TapeOffsets off[6];
-  tape_layout(net, NMAX, EMAX, off);
-  TapeLevel tp[6];
-  int nl[6], kl[6], El[6];
+  // per-level tables in LDS: indexed by the (run-time) level, as private arrays they lived in scratch memory (672 B per
+  // lane in round 3)
+  __shared__ TapeOffsets off[6];
+  __shared__ TapeLevel tps[6];
+  __shared__ int nl[6], kl[6], El[6];
+  if (tid == 0) {
+    tape_layout(net, NMAX, EMAX, off);
+    for (int l = 0; l < net.nlevels; ++l) tps[l] = tape_level(ws, off[l]);
+  }
+  __syncthreads();
   int n = nn, E = ne;
   float rmax = 0.f, rmean = 0.f;
   for (int l = 0; l < net.nlevels; ++l) {
@@ -168,18 +187,12 @@ __global__ __launch_bounds__(WGT) void gcn_train_kernel(mdq_gcn_net net, mdq_gcn
     lv.b = net.levels[l].b;
     lv.wr = net.levels[l].w_r;
     lv.pw = net.levels[l].pool_w;
-    tp[l].hsel = ws + off[l].hsel;
-    tp[l].ssel = ws + off[l].ssel;
-    tp[l].aggsel = ws + off[l].aggsel;
-    tp[l].xsel = ws + off[l].xsel;
-    tp[l].perm = reinterpret_cast<int*>(ws + off[l].perm);
-    tp[l].amax = reinterpret_cast<int*>(ws + off[l].amax);
-    tp[l].esrc = off[l].esrc >= 0 ? reinterpret_cast<int*>(ws + off[l].esrc) : nullptr;
-    tp[l].edst = off[l].edst >= 0 ? reinterpret_cast<int*>(ws + off[l].edst) : nullptr;
-    nl[l] = n;
-    El[l] = E;
-    run_level<true>(L, lv, C, net.ratio, n, E, nullptr, rmax, rmean, NMAX, &tp[l]);
-    kl[l] = n;
+    if (tid == 0) {
+      nl[l] = n;
+      El[l] = E;
+    }
+    run_level<true>(L, lv, C, net.ratio, n, E, nullptr, rmax, rmean, NMAX, &tps[l]);
+    if (tid == 0) kl[l] = n;
     TP_STAMP(1 + l)
   }
   // ---------------------------------------------------------------- head forward, loss term, head backward
@@ -301,7 +314,7 @@ __global__ __launch_bounds__(WGT) void gcn_train_kernel(mdq_gcn_net net, mdq_gcn
     const int nin = nl[l], k = kl[l], El_ = El[l], fin = net.levels[l].fin, type = net.levels[l].type;
     const float* wl = net.levels[l].w_l;
     const float* wr = net.levels[l].w_r;
-    const TapeLevel& T = tp[l];
+    const TapeLevel& T = tps[l];
     // ---- readout gradients onto what the next level passed down
     for (int idx = tid; idx < k * C; idx += WGT) {
       const int r = idx / C, c = idx - r * C;

@@ -23,11 +23,11 @@
 #include "mdq_device.h"
 #include "mdq_elem.h"
 
+#ifndef MDQ_CORR_MX0_INTERLEAVE
+#define MDQ_CORR_MX0_INTERLEAVE false
+#endif
 #ifndef MDQ_PCG_REGM
 #define MDQ_PCG_REGM 1
-#endif
-#ifndef MDQ_PCG_WG_DEFAULT
-#define MDQ_PCG_WG_DEFAULT 512
 #endif
 #ifndef MDQ_SETUP_WG
 #define MDQ_SETUP_WG 768
@@ -3505,6 +3505,15 @@ __device__ __forceinline__ double f2d(float f) {
   return (double)f;
 }
 
+// a workgroup-uniform double moved to scalar registers (two v_readfirstlane): loop invariants such as rho / dt, mu or the
+// squared tolerance otherwise occupy a VGPR pair each for the whole Krylov loop (the 768-thread velocity kernel, capped at
+// 168 VGPRs, spilled two of them and re-read them in every iteration)
+__device__ __forceinline__ double uniform_double(double x) {
+  const long long b = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 // ---- mode 3 as three kernels per time step (separate register allocation per phase: the BiCGStab
 // loop then runs without spill reloads; state is handed over through global memory as before) ----
 template <int TW, int TROWS, int TPAIR>
@@ -3514,7 +3523,7 @@ __global__ __launch_bounds__(TW) void at_velocity_kernel(mdq_ipcs_desc d, int32_
   const EnvView v = env_view(d, b);
   const int n2 = v.n2, nv = v.nv;
   const LdsPlan P = lds_plan(d.N2, d.NV, d.NSE1);
-  const double a = d.rho / d.dt, mu = d.mu;
+  const double a = uniform_double(d.rho / d.dt), mu = d.mu;
   (void)a; (void)mu; (void)nv; (void)n2;
   double* red = smem;  // 64 doubles
   double* U = smem + 64;
@@ -3709,7 +3718,7 @@ __global__ __launch_bounds__(TW) void at_velocity_kernel(mdq_ipcs_desc d, int32_
       if (row < n2) Pl[row] = make_double2(0.0, 0.0);
     }
     {
-      const double bb = acc[0], tol2 = d.rtol * d.rtol * bb;
+      const double bb = acc[0], tol2 = uniform_double(d.rtol * d.rtol * bb);
       double rr = acc[1];
       if (rr > tol2 && bb != 0.0) {
         double rho = rr, rho_old = 1.0, alpha = 1.0, omega = 1.0;
@@ -3931,12 +3940,17 @@ __global__ __launch_bounds__(NTH) void at_pressure_kernel(mdq_ipcs_desc d, int32
       pressure_direct<NTH>(pd, nv, pr, px, pp, pq, lK);
     } else {
       int itc = -1;
-      if (d.pcg_degree < 0)                    // two-level additive preconditioner (geometric aggregates)
-        itc = cg_pressure_2l<NTH>(nv, so1, ci1, K1, v.coords, d.rtol, d.maxit_p, px, pr, pp, P.NVp, red, rsel);
-      else if (nv <= 2 * NTH && d.pcg_degree > 0)   // rows in registers, Chebyshev-preconditioned (degree 1: Jacobi only)
-        itc = cg_pressure_cheb<NTH>(nv, so1, ci1, K1, d.rtol, d.maxit_p, d.pcg_degree, px, pr, pp, red, rsel);
-      if (itc < 0 && nv <= 2 * NTH && d.pcg_degree == 0 && MDQ_PCG_REGM)   // rows in registers, branch-free application
-        itc = cg_pressure_regm<NTH>(nv, so1, ci1, K1, d.rtol, d.maxit_p, px, pr, pp, red, rsel);
+      // (the 1024-thread instance is the direct solver's shape - 128 VGPRs per thread: the register-hungry Krylov variants
+      //  compiled into it cost 272 B of scratch per lane in round 3 without ever running there; an environment without
+      //  factors takes the plain register CG below)
+      if constexpr (NTH <= 512) {
+        if (d.pcg_degree < 0)                    // two-level additive preconditioner (geometric aggregates)
+          itc = cg_pressure_2l<NTH>(nv, so1, ci1, K1, v.coords, d.rtol, d.maxit_p, px, pr, pp, P.NVp, red, rsel);
+        else if (nv <= 2 * NTH && d.pcg_degree > 0)   // rows in registers, Chebyshev-preconditioned (degree 1: Jacobi only)
+          itc = cg_pressure_cheb<NTH>(nv, so1, ci1, K1, d.rtol, d.maxit_p, d.pcg_degree, px, pr, pp, red, rsel);
+        if (itc < 0 && nv <= 2 * NTH && d.pcg_degree == 0 && MDQ_PCG_REGM)   // rows in registers, branch-free application
+          itc = cg_pressure_regm<NTH>(nv, so1, ci1, K1, d.rtol, d.maxit_p, px, pr, pp, red, rsel);
+      }
       if (itc >= 0)
         it_p += itc;
       else if (nv <= 2 * NTH)
@@ -4120,12 +4134,16 @@ __global__ __launch_bounds__(WG) void at_correction_kernel(mdq_ipcs_desc d, int 
           const double2 bi = fl ? x[k] : make_double2((f3[k].x - l3[k].x) * ism[k], (f3[k].y - l3[k].y) * ism[k]);
           am[0] += bi.x * bi.x + bi.y * bi.y;
         } else {
-          x[k] = f3[k] = make_double2(0.0, 0.0);
+          f3[k] = make_double2(0.0, 0.0);
         }
       }
+      // (x0 is not carried in registers across the element loop below - 28 VGPRs the loop's two interleaved triangles need,
+      //  spilled to scratch in round 3: its own rows are read back from the staged copy, which the loop only reads)
       __syncthreads();
       CT_STAMP(2)
-      atomic_accumulate<true>(v, Yd, tm, [&](int, const Geo& g, const ElemIdx& E, int, double2(&ye)[6]) {
+      // (one triangle at a time: beside f3 / ism / the prefetched metadata the two interleaved triangles of the other
+      //  applications did not fit - 180 B of scratch per lane in round 3; this application runs once per launch)
+      atomic_accumulate<MDQ_CORR_MX0_INTERLEAVE>(v, Yd, tm, [&](int, const Geo& g, const ElemIdx& E, int, double2(&ye)[6]) {
         double2 xe[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) xe[i] = Pl[E.dof[i]];
@@ -4136,9 +4154,10 @@ __global__ __launch_bounds__(WG) void at_correction_kernel(mdq_ipcs_desc d, int 
 #pragma unroll
       for (int k = 0; k < MF_ROWS; ++k) {
         const int row = tid + k * WG;
-        r[k] = p[k] = make_double2(0.0, 0.0);
+        r[k] = p[k] = x[k] = make_double2(0.0, 0.0);
         if (row < n2) {
           const double2 ax = Yl[row];
+          x[k] = Pl[row];
           r[k] = make_double2((f3[k].x - ax.x) * ism[k], (f3[k].y - ax.y) * ism[k]);  // 0 on constrained rows
           p[k] = r[k];
           am[1] += r[k].x * r[k].x + r[k].y * r[k].y;
@@ -4471,9 +4490,6 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
         e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&at_pressure_kernel<false, 1024>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e_ == hipSuccess)
-        e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&at_pressure_kernel<true, 1024>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e_ == hipSuccess)
         e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&at_correction_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       return e_;
@@ -4485,12 +4501,6 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
       const char* s_ = std::getenv("MDQ_AT_WG");
       const int w_ = s_ ? std::atoi(s_) : 768;
       return w_ == 512 ? 512 : 768;
-    }();
-    // Krylov pressure kernel: 16 waves x ONE row per thread (MDQ_PCG_WG=1024) or 8 waves x two rows (512)
-    static const int pcg_wg = [] {
-      const char* s_ = std::getenv("MDQ_PCG_WG");
-      const int w_ = s_ ? std::atoi(s_) : MDQ_PCG_WG_DEFAULT;
-      return w_ == 1024 ? 1024 : 512;
     }();
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     if (kernel_ms) {
@@ -4507,8 +4517,6 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
       if (kernel_ms) hipEventRecord(ev[1], st);
       if (d->pd_enabled)
         hipLaunchKernelGGL((at_pressure_kernel<false, 1024>), dim3(d->B), dim3(1024), lds_p, st, *d, iters);
-      else if (k1_lds && pcg_wg == 1024 && d->NV <= 1024)
-        hipLaunchKernelGGL((at_pressure_kernel<true, 1024>), dim3(d->B), dim3(1024), lds_p, st, *d, iters);
       else if (k1_lds)
         hipLaunchKernelGGL(at_pressure_kernel<true>, dim3(d->B), dim3(WG), lds_p, st, *d, iters);
       else
