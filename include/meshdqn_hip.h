@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MDQ_ABI_VERSION 4
+#define MDQ_ABI_VERSION 5
 
 /* ---- error handling ----------------------------------------------------- */
 int mdq_abi_version(void);
@@ -534,6 +534,71 @@ int mdq_env_result(int32_t B, int32_t N, int32_t S, const double* new_drags, con
 /* mdq_restore_rows for the environments with mask[b] != 0 (device array): the in-place reset without a host-side list. */
 int mdq_restore_rows_masked(int32_t n, void* const* dst, const void* const* src, const int64_t* row_bytes, int32_t B,
                             const uint8_t* mask, void* stream);
+
+/*
+ * The END of a device-resident env step in ONE launch (round 4; before: mdq_copy_strided + mdq_env_result +
+ * mdq_restore_rows_masked + mdq_state_features, four launches of 5-9 us each on the latency chain of the step), one
+ * environment per workgroup row:
+ *   1. reward / terminal flag / codes / step counters exactly as mdq_env_result (Env2DAirfoil.py:380-428, :342-377); the step
+ *      counters and codes are read from *_in and written to *_out (several workgroups of an environment read them);
+ *   2. every row array t < n_rows (dst[t] laid out [B][row_bytes[t]]): the part [handover_off, + handover_bytes) of
+ *      environment b's row is first copied to handover_dst[t] ([B][handover_bytes[t]]; NULL: none) - the meshes and warm-start
+ *      fields the flow stream's IPCS leg of THIS step works on, taken before a reset rewrites them - and then, where the
+ *      environment terminated and auto_reset is set, the row is overwritten with the cached initial row src[t] (NULL: the
+ *      array is handed over only) - Env2DAirfoil.reset, Env2DAirfoil.py:102-129, in place;
+ *   3. the node features of the NEXT state (mdq_state_features, Env2DAirfoil.get_state :244-290): computed from the
+ *      environment's current arrays, or - for an environment that was just reset - the cached features x_init [N][2 + 3 S]
+ *      of the initial state.
+ * All pointers are device pointers; sizes / offsets are multiples of 4 bytes (16-byte aligned rows are copied 16 bytes
+ * per lane).
+ */
+#define MDQ_FINISH_MAX_ROWS 16
+typedef struct {
+  int32_t B, N, S, NV, NP, n_rows;
+  int32_t nv0, timesteps, auto_reset, _pad;
+  double threshold, time_reward, goal_vertices, negative_reward;
+  /* 1. result */
+  const double* new_drags;     /* [B][S] */
+  const double* gt_drag;       /* [S] */
+  const int32_t* nv;           /* [B] */
+  const int32_t* rstat;        /* [B] status of mdq_remesh */
+  const int32_t* topo_status;  /* [B] status of mdq_env_topology (or NULL) */
+  const int32_t* nsel;         /* [B] */
+  const int32_t* code_in;      /* [B] codes of the action decoding (mdq_env_act / mdq_remesh_act) */
+  int32_t* code_out;           /* [B] */
+  const int32_t* steps_in;     /* [B] */
+  int32_t* steps_out;          /* [B] (a different array) */
+  double* reward;              /* [B] */
+  uint8_t* done;               /* [B] */
+  int32_t* err_flag;           /* [1] */
+  int32_t* nv_out;             /* [B] or NULL */
+  /* 2. hand-over + in-place reset */
+  void* dst[MDQ_FINISH_MAX_ROWS];
+  const void* src[MDQ_FINISH_MAX_ROWS];
+  int64_t row_bytes[MDQ_FINISH_MAX_ROWS];
+  void* handover_dst[MDQ_FINISH_MAX_ROWS];
+  int64_t handover_off[MDQ_FINISH_MAX_ROWS];
+  int64_t handover_bytes[MDQ_FINISH_MAX_ROWS];
+  /* 3. features of the next state */
+  const double* coords;        /* [B][NV][2] (one of the row arrays above) */
+  const double* u;             /* [B][S][NP][2] */
+  const double* p;             /* [B][S][NV] */
+  const int32_t* n_closest;    /* [B][N] */
+  const float* x_init;         /* [N][2 + 3 S] or NULL (then auto_reset environments get their features computed too - from
+                                  the rows this launch has just restored: only valid with ONE workgroup per environment) */
+  float* x;                    /* [B][N][2 + 3 S] */
+} mdq_env_finish_desc;
+int mdq_env_finish(const mdq_env_finish_desc* d, void* stream);
+
+/*
+ * mdq_env_act + mdq_remesh in one launch (the action decoding is the head of the removal kernel; same outputs as the two
+ * entry points called one after the other): q / explore / rand_action / nsel / coord_map / offset / action / rem / code as
+ * for mdq_env_act, the mesh arguments and status as for mdq_remesh.
+ */
+int mdq_remesh_act(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv, int32_t* nt, int32_t N,
+                   const float* q, const uint8_t* explore, const int32_t* rand_action, const int32_t* nsel,
+                   const int32_t* coord_map, int32_t* offset, int32_t* action, int32_t* rem, int32_t* code, int32_t* status,
+                   void* stream);
 
 /* edge_ptr [B+1] = exclusive prefix sums of nedges [B] (offsets of mdq_compact_edges / mdq_gcn_forward). */
 int mdq_edge_ptr(int32_t B, const int32_t* nedges, int32_t* edge_ptr, void* stream);

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # (MDQ_LIB_PATH: a differently built copy of the library, e.g. an experiment of tools/: development knob)
 LIB_PATH = os.environ.get("MDQ_LIB_PATH") or os.path.join(HERE, "libmeshdqn_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class MeshDQNHipError(RuntimeError):
@@ -84,6 +84,21 @@ class IpcsTopoOut(C.Structure):
                                   "cell_dofs_in", "ne_in")]
 
 
+FINISH_MAX_ROWS = 16
+
+
+class EnvFinishDesc(C.Structure):
+    """Mirror of `mdq_env_finish_desc`."""
+    _fields_ = [(n, C.c_int32) for n in ("B", "N", "S", "NV", "NP", "n_rows", "nv0", "timesteps", "auto_reset", "_pad")] + [
+        (n, C.c_double) for n in ("threshold", "time_reward", "goal_vertices", "negative_reward")] + [
+        (n, C.c_void_p) for n in ("new_drags", "gt_drag", "nv", "rstat", "topo_status", "nsel", "code_in", "code_out",
+                                  "steps_in", "steps_out", "reward", "done", "err_flag", "nv_out")] + [
+        ("dst", C.c_void_p * FINISH_MAX_ROWS), ("src", C.c_void_p * FINISH_MAX_ROWS),
+        ("row_bytes", C.c_int64 * FINISH_MAX_ROWS), ("handover_dst", C.c_void_p * FINISH_MAX_ROWS),
+        ("handover_off", C.c_int64 * FINISH_MAX_ROWS), ("handover_bytes", C.c_int64 * FINISH_MAX_ROWS)] + [
+        (n, C.c_void_p) for n in ("coords", "u", "p", "n_closest", "x_init", "x")]
+
+
 # every symbol include/meshdqn_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "mdq_abi_version": (C.c_int, []),
@@ -120,6 +135,9 @@ SYMBOLS = {
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int32,
                                  C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdq_restore_rows_masked": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mdq_env_finish": (C.c_int, [C.POINTER(EnvFinishDesc), C.c_void_p]),
+    "mdq_remesh_act": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+                       + [C.c_void_p] * 11),
     "mdq_edge_ptr": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdq_smooth": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_void_p]),

@@ -496,6 +496,137 @@ extern "C" int mdq_restore_rows_masked(int32_t n, void* const* dst, const void* 
   return 0;
 }
 
+namespace mdq_mesh {
+// The end of a device-resident env step in one launch: blockIdx.x = environment, blockIdx.y = one of gridDim.y workgroups
+// that share its copy work (result logic: computed by every workgroup from the *_in arrays, written by y = 0).
+__global__ __launch_bounds__(256) void env_finish_kernel(mdq_env_finish_desc d) {
+  const int b = blockIdx.x, y = blockIdx.y, Y = gridDim.y, tid = threadIdx.x;
+  __shared__ int s_reset;
+  if (tid == 0) {
+#pragma clang fp contract(off)
+    // ---- 1. mdq_env_result for environment b (same operations in the same order)
+    int c = d.code_in[b];
+    if (d.rstat[b] != 0 || d.nsel[b] < d.N) c = 2;
+    if (d.topo_status && d.topo_status[b] != 0) {
+      c = 2;
+      if (y == 0) atomicOr(d.err_flag, 1);
+    }
+    const double drag_factor = -2.0 * log(0.5) / d.threshold;
+    double ss = 0.0;
+    bool acc = false;
+    for (int s = 0; s < d.S; ++s) {
+      const double g = d.gt_drag[s], dr = d.new_drags[(int64_t)b * d.S + s];
+      const double e = fabs(g - dr) / fabs(g);
+      ss += e * e;
+      acc = acc || fabs(fabs(g - dr) / g) > d.threshold;
+    }
+    const double drag_reward = 2.0 * exp(-drag_factor * sqrt(ss)) - 1.0;
+    const int nvb = d.nv[b];
+    const double tr = (double)(d.nv0 - nvb) * d.time_reward;
+    const bool vert = (double)nvb < d.goal_vertices * (double)d.nv0;
+    const bool ok = c == 0;
+    const double r = ok ? drag_reward + tr : d.negative_reward;
+    bool dn = ok ? (acc || vert) : (c != 1);
+    const int st = d.steps_in[b] + 1;
+    dn = dn || st >= d.timesteps;
+    if (y == 0) {
+      d.reward[b] = r;
+      if (d.nv_out) d.nv_out[b] = nvb;
+      d.done[b] = dn ? 1 : 0;
+      d.code_out[b] = c;
+      d.steps_out[b] = (dn && d.auto_reset) ? 0 : st;
+    }
+    s_reset = (dn && d.auto_reset) ? 1 : 0;
+  }
+  __syncthreads();
+  const bool reset = s_reset != 0;
+  // ---- 2. hand-over of the pre-reset rows, then the in-place reset: word i of a row is read once, copied out if it lies
+  // in the hand-over window, then overwritten (same thread: no ordering problem between the two)
+  const int lin = y * 256 + tid, nlin = Y * 256;
+  for (int t = 0; t < d.n_rows; ++t) {
+    uint32_t* ho = static_cast<uint32_t*>(d.handover_dst[t]);
+    const uint32_t* src = static_cast<const uint32_t*>(d.src[t]);
+    const bool restore = reset && src != nullptr;
+    if (!ho && !restore) continue;
+    const int64_t words = d.row_bytes[t] >> 2, h0 = d.handover_off[t] >> 2, hw = d.handover_bytes[t] >> 2;
+    uint32_t* row = static_cast<uint32_t*>(d.dst[t]) + (int64_t)b * words;
+    uint32_t* hob = ho ? ho + (int64_t)b * hw : nullptr;
+    const int64_t lo = restore ? 0 : h0, hi = restore ? words : h0 + hw;
+    const bool vec = ((words | h0 | hw) & 3) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(row) | reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(hob)) & 15) == 0;
+    if (vec) {
+      uint4* row4 = reinterpret_cast<uint4*>(row);
+      const uint4* src4 = reinterpret_cast<const uint4*>(src);
+      uint4* ho4 = reinterpret_cast<uint4*>(hob);
+      const int64_t h04 = h0 >> 2, h14 = (h0 + hw) >> 2;
+      for (int64_t i = (lo >> 2) + lin; i < (hi >> 2); i += nlin) {
+        if (ho && i >= h04 && i < h14) ho4[i - h04] = row4[i];
+        if (restore) row4[i] = src4[i];
+      }
+    } else {
+      for (int64_t i = lo + lin; i < hi; i += nlin) {
+        if (ho && i >= h0 && i < h0 + hw) hob[i - h0] = row[i];
+        if (restore) row[i] = src[i];
+      }
+    }
+  }
+  // ---- 3. node features of the next state (state_features_kernel's formulas); a reset environment: the cached ones
+  const int N = d.N, S = d.S, F = 2 + 3 * S;
+  float* xb = d.x + (int64_t)b * N * F;
+  if (reset && d.x_init) {
+    for (int i = lin; i < N * F; i += nlin) xb[i] = d.x_init[i];
+    return;
+  }
+  if (reset) {               // (no cached features: read the rows restored above - needs all of them: one workgroup only)
+    __threadfence_block();
+    __syncthreads();
+  }
+  const int32_t* nc = d.n_closest + (int64_t)b * N;
+  const int nselb = d.nsel[b];
+  for (int i = lin; i < N * F; i += nlin) {
+    const int n = i / F, f = i - n * F;
+    float val = 0.f;
+    if (n < nselb) {
+      if (f < 2) {
+        val = (float)d.coords[((int64_t)b * d.NV + nc[n]) * 2 + f];
+      } else if (f < 2 + 2 * S) {
+        const int q = n * 2 * S + (f - 2);
+        const int s = q / (2 * N), r = q - s * 2 * N, m = r >> 1, c = r & 1;
+        val = (float)d.u[(((int64_t)b * S + s) * d.NP + nc[m]) * 2 + c];
+      } else {
+        const int s = f - 2 - 2 * S;
+        val = (float)d.p[((int64_t)b * S + s) * d.NV + nc[n]];
+      }
+    }
+    xb[i] = val;
+  }
+}
+}  // namespace mdq_mesh
+
+extern "C" int mdq_env_finish(const mdq_env_finish_desc* d, void* stream) {
+  if (!d || d->B <= 0 || d->N <= 0 || d->S <= 0 || d->n_rows < 0 || d->n_rows > MDQ_FINISH_MAX_ROWS || !d->new_drags ||
+      !d->gt_drag || !d->nv || !d->rstat || !d->nsel || !d->code_in || !d->code_out || !d->steps_in || !d->steps_out ||
+      d->steps_in == d->steps_out || !d->reward || !d->done || !d->err_flag || !d->coords || !d->u || !d->p || !d->n_closest || !d->x)
+    return mdq_set_error("mdq_env_finish: bad arguments");
+  int64_t bytes = 0;
+  for (int t = 0; t < d->n_rows; ++t) {
+    if (!d->dst[t] || d->row_bytes[t] <= 0 || ((d->row_bytes[t] | d->handover_off[t] | d->handover_bytes[t]) & 3) ||
+        (((uintptr_t)d->dst[t] | (uintptr_t)d->src[t] | (uintptr_t)d->handover_dst[t]) & 3) ||
+        (d->handover_dst[t] && (d->handover_off[t] < 0 || d->handover_bytes[t] <= 0 ||
+                                d->handover_off[t] + d->handover_bytes[t] > d->row_bytes[t])))
+      return mdq_set_error("mdq_env_finish: rows must be non-empty 4-byte aligned multiples of 4 bytes with a hand-over window inside them");
+    bytes += d->handover_dst[t] ? d->handover_bytes[t] : 0;
+  }
+  // workgroups per environment: enough lanes for the hand-over copies (16 bytes per lane and pass, ~4 passes); without
+  // cached initial features the reset path needs the whole environment in one workgroup
+  int Y = (int)((bytes / 16 + 1023) / 1024);
+  Y = Y < 1 ? 1 : (Y > 8 ? 8 : Y);
+  if (d->auto_reset && !d->x_init) Y = 1;
+  hipLaunchKernelGGL(mdq_mesh::env_finish_kernel, dim3(d->B, Y), dim3(256), 0, (hipStream_t)stream, *d);
+  if (hipGetLastError() != hipSuccess) return mdq_set_error("env_finish_kernel launch failed");
+  return 0;
+}
+
 extern "C" int mdq_edge_ptr(int32_t B, const int32_t* nedges, int32_t* edge_ptr, void* stream) {
   if (B <= 0 || !nedges || !edge_ptr) return mdq_set_error("mdq_edge_ptr: bad arguments");
   hipLaunchKernelGGL(mdq_mesh::edge_ptr_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, nedges, edge_ptr);

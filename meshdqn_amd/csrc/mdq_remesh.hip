@@ -38,8 +38,23 @@ __device__ __forceinline__ double incircle(double2 a, double2 b, double2 c, doub
 }
 __device__ __forceinline__ uint32_t hslot(uint32_t key) { return (key * 2654435761u) >> 19; }
 
+// the action decoding of mdq_env_act (env_act_kernel, mdq_mesh.hip) as the head of the removal kernel
+struct ActArgs {
+  int N;
+  const float* q;
+  const uint8_t* explore;
+  const int32_t* rand_action;
+  const int32_t* nsel;
+  const int32_t* coord_map;
+  int32_t* offset;
+  int32_t* action;
+  int32_t* rem;
+  int32_t* code;
+};
+
+template <bool ACT>
 __global__ __launch_bounds__(RW) void remesh_kernel(int NV, int NT, double* coords, int32_t* cells, int32_t* nv_,
-                                                    int32_t* nt_, const int32_t* remove_idx, int32_t* status) {
+                                                    int32_t* nt_, const int32_t* remove_idx, int32_t* status, ActArgs A) {
 #pragma clang fp contract(off)
   extern __shared__ __align__(16) unsigned char smem[];
   double2* X = reinterpret_cast<double2*>(smem);                     // [RNV]            16 KB
@@ -52,7 +67,51 @@ __global__ __launch_bounds__(RW) void remesh_kernel(int NV, int NT, double* coor
   int* star = misc + 8;                                              // [64]
   int* lane0 = misc + 80;                                            // [4][64] ring bookkeeping of the serial part
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int rv = remove_idx[b];
+  int rv;
+  if (ACT) {
+    // wave 0: greedy action = first maximum of the Q-row (torch.argmax), epsilon-greedy choice, Env2DAirfoil.step's decoding
+    if (tid < 64) {
+      const int lane = tid, N = A.N, NA = N + 1;
+      int a;
+      if (A.q) {
+        float best = -__builtin_inff();
+        int bi = 0x7FFFFFFF;
+        for (int i = lane; i < NA; i += 64) {
+          const float v = A.q[(int64_t)b * NA + i];
+          if (v > best || (v == best && i < bi) || (bi == 0x7FFFFFFF && !(v < best))) {   // (NaN rows: first index)
+            best = v;
+            bi = i;
+          }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+          const float ov = __shfl_xor(best, off);
+          const int oi = __shfl_xor(bi, off);
+          if (ov > best || (ov == best && oi < bi)) {
+            best = ov;
+            bi = oi;
+          }
+        }
+        a = (A.explore && A.explore[b]) ? A.rand_action[b] : bi;
+      } else {
+        a = A.action[b];
+      }
+      if (lane == 0) {
+        const bool shift = a == N;
+        const bool pick = a >= 0 && a < A.nsel[b] && !shift;
+        if (shift) A.offset[b] += 1;
+        A.action[b] = a;
+        const int r = pick ? A.coord_map[(int64_t)b * N + min(max(a, 0), N - 1)] : -1;
+        A.rem[b] = r;
+        A.code[b] = (!shift && !pick) ? 2 : 0;
+        misc[2] = r;
+      }
+    }
+    __syncthreads();
+    rv = misc[2];
+    __syncthreads();
+  } else {
+    rv = remove_idx[b];
+  }
   if (tid == 0) status[b] = 0;
   if (rv < 0) return;  // "do nothing" / invalid action: the reference leaves the mesh untouched
   int nv = nv_[b], nt = nt_[b];
@@ -324,17 +383,44 @@ __global__ __launch_bounds__(RW) void remesh_kernel(int NV, int NT, double* coor
 
 }  // namespace mdq_rm
 
-extern "C" int mdq_remesh(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv, int32_t* nt,
-                          const int32_t* remove_idx, int32_t* status, void* stream) {
-  if (B <= 0 || !coords || !cells || !nv || !nt || !remove_idx || !status) return mdq_set_error("mdq_remesh: bad arguments");
+static int remesh_launch(const char* who, int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv,
+                         int32_t* nt, const int32_t* remove_idx, int32_t* status, const mdq_rm::ActArgs* act, void* stream) {
+  if (B <= 0 || !coords || !cells || !nv || !nt || (!remove_idx && !act) || !status) return mdq_set_error("mdq_remesh: bad arguments");
   if (NV > mdq_rm::RNV || NT > mdq_rm::RNT)
     return mdq_set_error("mdq_remesh: capacity above 1024 vertices / 2048 triangles (use mdq_remesh_host)");
+  (void)who;
   const size_t lds = 16384 + 2 * sizeof(int) * mdq_rm::RNS + 2 * sizeof(uint32_t) * mdq_rm::RHS + sizeof(int) * 336;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mdq_rm::remesh_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  static const hipError_t attr = [] {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mdq_rm::remesh_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mdq_rm::remesh_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return e;
+  }();
   if (attr != hipSuccess) return mdq_set_error("hipFuncSetAttribute(remesh_kernel) failed");
-  hipLaunchKernelGGL(mdq_rm::remesh_kernel, dim3(B), dim3(mdq_rm::RW), lds, (hipStream_t)stream, NV, NT, coords, cells, nv,
-                     nt, remove_idx, status);
+  if (act)
+    hipLaunchKernelGGL(mdq_rm::remesh_kernel<true>, dim3(B), dim3(mdq_rm::RW), lds, (hipStream_t)stream, NV, NT, coords, cells,
+                       nv, nt, remove_idx, status, *act);
+  else
+    hipLaunchKernelGGL(mdq_rm::remesh_kernel<false>, dim3(B), dim3(mdq_rm::RW), lds, (hipStream_t)stream, NV, NT, coords, cells,
+                       nv, nt, remove_idx, status, mdq_rm::ActArgs{});
   if (hipGetLastError() != hipSuccess) return mdq_set_error("remesh_kernel launch failed");
   return 0;
+}
+
+extern "C" int mdq_remesh(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv, int32_t* nt,
+                          const int32_t* remove_idx, int32_t* status, void* stream) {
+  if (!remove_idx) return mdq_set_error("mdq_remesh: bad arguments");
+  return remesh_launch("mdq_remesh", B, NV, NT, coords, cells, nv, nt, remove_idx, status, nullptr, stream);
+}
+
+extern "C" int mdq_remesh_act(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv, int32_t* nt,
+                              int32_t N, const float* q, const uint8_t* explore, const int32_t* rand_action,
+                              const int32_t* nsel, const int32_t* coord_map, int32_t* offset, int32_t* action, int32_t* rem,
+                              int32_t* code, int32_t* status, void* stream) {
+  if (N <= 0 || !nsel || !coord_map || !offset || !action || !rem || !code || (explore && !rand_action))
+    return mdq_set_error("mdq_remesh_act: bad arguments");
+  const mdq_rm::ActArgs a{N, q, explore, rand_action, nsel, coord_map, offset, action, rem, code};
+  return remesh_launch("mdq_remesh_act", B, NV, NT, coords, cells, nv, nt, nullptr, status, &a, stream);
 }

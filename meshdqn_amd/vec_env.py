@@ -256,40 +256,27 @@ class VecEnv2DAirfoil:
         self._flow_keep = keep       # device buffers the descriptor points at
         return drag, lift
 
-    def _flow_overlapped(self, out_u, out_p):
-        """The same on the flow stream: the meshes are copied to the flow's own engine (on the main stream, behind the
-        last flow), which derives topology + IPCS index data itself; results land in page-locked memory."""
-        ft, dt = self._ftopo, self.dtopo
-        t, d = self.flow_ts[0], self.flow_descs[0]
+    def _flow_handover(self, out_u, out_p):
+        """First half of the overlapped flow leg: the input set the flow stream will read (filled alternately: flow k - 1
+        may still be reading the other one) and the (destination, source) pairs of the hand-over - the meshes, the main
+        engine's edge numbering and the warm start (last interpolated snapshot), copied BEFORE an in-place reset of a
+        terminated environment rewrites them."""
+        dt = self.dtopo
         main = torch.cuda.current_stream(self.device)
         fin = self._flow_in[self._flow_n % 2]
-        # flow k - 2 read this input set (long finished).  Inside a graph capture only events recorded IN the capture may be
-        # waited for (HIP takes an older event of the - by then capturing - flow stream for a captured one and the capture
-        # ends "unjoined"); `rollout_graph` has waited for the older flows on the host, before the capture and before
-        # every replay.
-        base = getattr(self, "_flow_capture_base", None)
-        if self._flow_n >= 2 and self._flow_prev is not None and (base is None or self._flow_n - 2 >= base):
+        if self._flow_n >= 2 and self._flow_prev is not None:          # flow k - 2 read this input set (long finished)
             main.wait_event(self._flow_res[self._flow_n % 2]["done"])
-        # meshes + the warm start (the in-place reset of a terminated environment rewrites its rows of out_u / out_p) in
-        # ONE launch (six torch copies were ~50 us of the main chain)
         su, sp_ = out_u[:, self.S - 1], out_p[:, self.S - 1]
         pairs = [(fin["coords"], dt.coords), (fin["cells"], dt.cells), (fin["nv"], dt.nv), (fin["nt"], dt.nt), (fin["u_n"], su), (fin["p_n"], sp_),
                  (fin["cell_dofs"], dt.t["cell_dofs"]), (fin["ne"], dt.t["ne"])]
-        n = len(pairs)
-        vp, i64 = C.c_void_p * n, C.c_int64 * n
-        rows, rb, ss, ds = [], [], [], []
-        for dst, src in pairs:
-            if dst.shape != src.shape or dst.dtype != src.dtype or not dst.is_contiguous():
-                raise ValueError("flow hand-over: buffers of different shapes")
-            if src.is_contiguous():
-                rows.append(1); rb.append(src.numel() * src.element_size()); ss.append(rb[-1]); ds.append(rb[-1])
-            else:                                   # a snapshot slice: contiguous per environment
-                per = src[0].numel() * src.element_size()
-                if not src[0].is_contiguous():
-                    raise ValueError("flow hand-over: rows of the source must be contiguous")
-                rows.append(src.shape[0]); rb.append(per); ss.append(src.stride(0) * src.element_size()); ds.append(per)
-        _lib.check(self.lib.mdq_copy_strided(n, vp(*[d_.data_ptr() for d_, _ in pairs]), vp(*[s_.data_ptr() for _, s_ in pairs]),
-                                             i64(*rows), i64(*rb), i64(*ss), i64(*ds), _lib.stream_ptr()), "mdq_copy_strided")
+        return fin, pairs
+
+    def _flow_start(self, fin):
+        """Second half: the hand-over is enqueued on the main stream - topology (edges from the main engine), matrix-free
+        set-up and the IPCS step(s) follow on the flow stream; results land in page-locked memory."""
+        ft = self._ftopo
+        t, d = self.flow_ts[0], self.flow_descs[0]
+        main = torch.cuda.current_stream(self.device)
         self._flow_ready.record(main)
         keep = dict(coords=fin["coords"], cell_dofs=ft.t["cell_dofs"], af_facets=ft.t["af_facets"], nv=fin["nv"], nt=fin["nt"],
                     ne=ft.t["ne"], naf=ft.t["naf"], u_n=fin["u_n"], p_n=fin["p_n"])
@@ -316,6 +303,29 @@ class VecEnv2DAirfoil:
             res["done"].record(self._flow_stream)
         self._flow_prev = self._flow_n % 2
         self._flow_n += 1
+
+    def _flow_overlapped(self, out_u, out_p):
+        """The IPCS leg on the flow stream: the meshes are copied to the flow's own engine (on the main stream, behind the
+        last flow), which derives topology + IPCS index data itself (host-driven `step()`; the device-resident step hands
+        the rows over inside `mdq_env_finish`)."""
+        fin, pairs = self._flow_handover(out_u, out_p)
+        # meshes + the warm start in ONE launch (six torch copies were ~50 us of the main chain)
+        n = len(pairs)
+        vp, i64 = C.c_void_p * n, C.c_int64 * n
+        rows, rb, ss, ds = [], [], [], []
+        for dst, src in pairs:
+            if dst.shape != src.shape or dst.dtype != src.dtype or not dst.is_contiguous():
+                raise ValueError("flow hand-over: buffers of different shapes")
+            if src.is_contiguous():
+                rows.append(1); rb.append(src.numel() * src.element_size()); ss.append(rb[-1]); ds.append(rb[-1])
+            else:                                   # a snapshot slice: contiguous per environment
+                per = src[0].numel() * src.element_size()
+                if not src[0].is_contiguous():
+                    raise ValueError("flow hand-over: rows of the source must be contiguous")
+                rows.append(src.shape[0]); rb.append(per); ss.append(src.stride(0) * src.element_size()); ds.append(per)
+        _lib.check(self.lib.mdq_copy_strided(n, vp(*[d_.data_ptr() for d_, _ in pairs]), vp(*[s_.data_ptr() for _, s_ in pairs]),
+                                             i64(*rows), i64(*rb), i64(*ss), i64(*ds), _lib.stream_ptr()), "mdq_copy_strided")
+        self._flow_start(fin)
         return None, None
 
     def flow_wait(self):
@@ -412,7 +422,7 @@ class VecEnv2DAirfoil:
         self._refresh_launch()
         self._refresh_collect()
 
-    def _refresh_launch(self, readback=True):
+    def _refresh_launch(self, readback=True, defer_flow=False):
         """Everything of `_refresh` that is enqueued on the stream, up to the asynchronous read-back (`readback=False`:
         the device-resident rollout keeps the results on the device)."""
         dev, h = self.device, self.h
@@ -471,7 +481,7 @@ class VecEnv2DAirfoil:
         self.u, self.p, self._coords_dev = out_u, out_p, t_coords
         self._dev_drag, self._dev_lift = drag, lift
         fd = fl = None
-        if self.flow_steps > 0:
+        if self.flow_steps > 0 and not (defer_flow and self.flow_overlap):   # (deferred: handed over by mdq_env_finish)
             fd, fl = self._flow(keep, out_u, out_p)
             if not self.gpu_topology:
                 self.flow_drag, self.flow_lift = fd.cpu().numpy(), fl.cpu().numpy()
@@ -712,77 +722,6 @@ class VecEnv2DAirfoil:
             self.rollout_step(ro, fused)
         return self.rollout_end(ro)
 
-    # host-side fields `rollout_step` moves along; a graph replay has to leave them where the capture left them
-    _GRAPH_HOST_STATE = ("u", "p", "_coords_dev", "_dev_drag", "_dev_lift", "_interp_i", "_flow_n", "_flow_prev", "_flow_keep")
-
-    def rollout_graph(self, fused, steps: int, explore=None, rand_actions=None, actions=None):
-        """`rollout_device` with the whole rollout - `steps` env steps, main chain AND the flow leg on its stream - replayed
-        from ONE HIP graph: the first call with a given (steps, kind of input, network) runs eagerly (it creates every
-        lazily allocated buffer), the second captures the launches of `rollout_step` (the state of step 0 is recomputed by
-        the graph's first node; inputs and outputs live in static buffers) and replays them, later calls copy their inputs
-        in and replay.  Same results as `rollout_device` (tested); the host enqueues ~0.06 ms per env step instead of
-        ~0.26 ms.  `steps` must be even (the interpolation results ping-pong between two buffer sets); host-driven steps
-        or eager rollouts between two replays are fine as long as they leave that parity alone (else: a new capture)."""
-        K = int(steps)
-        if K <= 0 or K % 2:
-            raise ValueError("rollout_graph needs an even, positive number of steps")
-        cur = torch.cuda.current_stream(self.device)
-        if cur == torch.cuda.default_stream(self.device):
-            if getattr(self, "_main_stream", None) is None:
-                from .streams import role_streams
-                self._main_stream = role_streams(self.device)["main"]
-            self._main_stream.wait_stream(cur)
-            with torch.cuda.stream(self._main_stream):
-                out = self.rollout_graph(fused, K, explore, rand_actions, actions)
-            cur.wait_stream(self._main_stream)
-            return out
-        graphs = self.__dict__.setdefault("_graphs", {})
-        key = (K, actions is not None, id(fused), int(cur.cuda_stream))
-        ent = graphs.get(key)
-        if ent is None:                               # first call: eager (warms every lazily created buffer)
-            graphs[key] = "warm"
-            return self.rollout_device(fused, K, explore, rand_actions, actions)
-        if ent != "warm" and (ent["interp_i"] != getattr(self, "_interp_i", 0) or
-                              (self.flow_overlap and ent["flow_par"] != self._flow_n % 2)):
-            ent = "warm"                              # the ping-pong parity moved since the capture: capture again
-        if self.flow_overlap:
-            self.flow_wait()                          # the last flow leg (eager or replayed) still reads the private meshes
-        if fused is not None:
-            fused._pack()
-        if ent == "warm":
-            ro = self.rollout_begin(K, explore, rand_actions, actions)
-            interp_i, flow_par = getattr(self, "_interp_i", 0), (self._flow_n % 2 if self.flow_overlap else 0)
-            torch.cuda.synchronize(self.device)
-            g = torch.cuda.CUDAGraph()
-            self._flow_capture_base = self._flow_n if self.flow_overlap else None
-            try:
-                with torch.cuda.graph(g, stream=cur):
-                    ro["state"] = self._state_device()    # (the graph's first node: the state from the current device data)
-                    for _ in range(K):
-                        self.rollout_step(ro, fused, pack=False)
-                    if self.flow_overlap:
-                        cur.wait_stream(self._flow_stream)   # the flow leg joins before the capture ends
-            finally:
-                self._flow_capture_base = None
-            ent = graphs[key] = dict(g=g, ro=ro, interp_i=interp_i, flow_par=flow_par,
-                                     post={k: getattr(self, k, None) for k in self._GRAPH_HOST_STATE})
-        else:
-            ro = ent["ro"]
-            if self._pending is not None:
-                self._refresh_collect()
-            if actions is not None:
-                ro["act"].copy_(torch.from_numpy(np.ascontiguousarray(actions, dtype=np.int32).reshape(K, self.B)))
-            else:
-                ro["explore"].copy_(torch.from_numpy(np.ascontiguousarray(explore, dtype=np.uint8).reshape(K, self.B)))
-                ro["rand"].copy_(torch.from_numpy(np.ascontiguousarray(rand_actions, dtype=np.int32).reshape(K, self.B)))
-            ro["d_steps"].copy_(torch.from_numpy(self.steps.astype(np.int32)))
-            ro["err"].zero_()
-            self.dtopo.offset.copy_(torch.from_numpy(self.offset))
-        ent["g"].replay()
-        for k, v in ent["post"].items():              # the host-side view of the buffers, as the captured steps left it
-            setattr(self, k, v)
-        return self.rollout_end(ro)
-
     def calibrate_streams(self, fused, tries: int = 6, steps: int = 8):
         """Pick a flow stream that REALLY runs beside the current (main) stream, by measurement.  HIP maps streams
         round-robin onto hardware queues; besides the pairs that land on one queue (the flow leg then runs behind the
@@ -865,8 +804,10 @@ class VecEnv2DAirfoil:
         ro = dict(K=K, k=0, given=actions is not None, act=act_all, explore=expl_all, rand=rand_all,
                   rew=torch.empty((K, B), dtype=torch.float64, device=dev), done=torch.empty((K, B), dtype=torch.uint8, device=dev),
                   code=torch.empty((K, B), dtype=i32, device=dev), nv=torch.empty((K, B), dtype=i32, device=dev),
-                  rem=torch.empty(B, dtype=i32, device=dev), its=torch.empty(B, dtype=i32, device=dev),
-                  d_steps=torch.from_numpy(self.steps.astype(np.int32)).to(dev), err=torch.zeros(1, dtype=i32, device=dev))
+                  rem=torch.empty(B, dtype=i32, device=dev), code_act=torch.empty(B, dtype=i32, device=dev),
+                  # step counters: read by every workgroup of mdq_env_finish, written to the other array (si: the current one)
+                  d_steps=[torch.from_numpy(self.steps.astype(np.int32)).to(dev), torch.empty(B, dtype=i32, device=dev)], si=0,
+                  err=torch.zeros(1, dtype=i32, device=dev))
         if getattr(self, "_gt_drag_dev", None) is None:
             self._gt_drag_dev = torch.from_numpy(np.ascontiguousarray(self.gt_drag, dtype=np.float64)).to(dev)
         dt.offset.copy_(torch.from_numpy(self.offset))
@@ -877,22 +818,27 @@ class VecEnv2DAirfoil:
         """One batched env step of a `rollout_begin` context, enqueued on the current stream; afterwards `ro["state"]`
         is the new batched state and `ro["act"][k] / ro["rew"][k] / ro["done"][k]` (device) describe the step (k = ro["k"] - 1).
         `pack=False`: the Q-forward uses the packed parameter copy as it is (a learning loop whose optimiser runs on another
-        stream brings it up to date itself, at a point that is ordered against the parameter writes)."""
+        stream brings it up to date itself, at a point that is ordered against the parameter writes).
+        Launches of a step (round 4: 8 + the hand-back launch of the smoothing, 14 in round 3): Q-forward (embedding, MLP head),
+        `mdq_remesh_act` (action decoding + vertex removal), `mdq_smooth_fast_env`, `mdq_env_topology`,
+        `mdq_interpolate_snapshots`, `mdq_probe_forces`, `mdq_env_finish` (reward / terminal logic, hand-over of the meshes
+        to the flow stream, in-place resets, node features of the next state)."""
         dt, lib, B, N, S, k = self.dtopo, self.lib, self.B, self.N, self.S, ro["k"]
         if k >= ro["K"]:
             raise IndexError("rollout_step beyond the steps of rollout_begin")
         sp = _lib.stream_ptr
-        st, rem, its = ro["state"], ro["rem"], ro["its"]
+        st, rem = ro["state"], ro["rem"]
         q = None
         if not ro["given"]:
             q = fused.forward_arrays(st["x"], st["node_ptr"], st["edge_src_pad"], st["edge_dst_pad"], None, N, self.EMAX,
                                      pack=pack, edge_cnt=st["nedges_dev"])
-        _lib.check(lib.mdq_env_act(B, N, None if q is None else q.data_ptr(),
-                                   None if ro["explore"] is None else ro["explore"][k].data_ptr(),
-                                   None if ro["rand"] is None else ro["rand"][k].data_ptr(), dt.t["nsel"].data_ptr(),
-                                   dt.t["coord_map"].data_ptr(), dt.offset.data_ptr(), ro["act"][k].data_ptr(),
-                                   rem.data_ptr(), ro["code"][k].data_ptr(), sp()), "mdq_env_act")
-        remesh_batch_gpu(dt.coords, dt.cells, dt.nv, dt.nt, rem, self._rstat)
+        NVc, NTc = dt.coords.shape[1], dt.cells.shape[1]
+        _lib.check(lib.mdq_remesh_act(B, NVc, NTc, dt.coords.data_ptr(), dt.cells.data_ptr(), dt.nv.data_ptr(), dt.nt.data_ptr(),
+                                      N, None if q is None else q.data_ptr(),
+                                      None if ro["explore"] is None else ro["explore"][k].data_ptr(),
+                                      None if ro["rand"] is None else ro["rand"][k].data_ptr(), dt.t["nsel"].data_ptr(),
+                                      dt.t["coord_map"].data_ptr(), dt.offset.data_ptr(), ro["act"][k].data_ptr(),
+                                      rem.data_ptr(), ro["code_act"].data_ptr(), self._rstat.data_ptr(), sp()), "mdq_remesh_act")
         tm = getattr(self, "smooth_events", None)     # (bench: HIP events around the launch, on this stream)
         if tm is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -902,20 +848,88 @@ class VecEnv2DAirfoil:
         if tm is not None:
             e1.record()
             tm.append((e0, e1))
-        self._refresh_launch(readback=False)
-        _lib.check(lib.mdq_env_result(B, N, S, self._dev_drag.data_ptr(), self._gt_drag_dev.data_ptr(), dt.nv.data_ptr(),
-                                      int(self.initial_num_node), self._rstat.data_ptr(), dt.status.data_ptr(),
-                                      dt.t["nsel"].data_ptr(), ro["code"][k].data_ptr(), ro["d_steps"].data_ptr(),
-                                      self.threshold, self.TIME_REWARD, self.goal_vertices, int(self.timesteps),
-                                      self.NEGATIVE_REWARD, 1 if self.auto_reset else 0, ro["rew"][k].data_ptr(),
-                                      ro["done"][k].data_ptr(), ro["err"].data_ptr(), ro["nv"][k].data_ptr(), sp()),
-                   "mdq_env_result")
-        if self.auto_reset:
-            ra = self._restore_arg_arrays()
-            _lib.check(lib.mdq_restore_rows_masked(ra["n"], ra["dst"], ra["src"], ra["nbytes"], B,
-                                                   ro["done"][k].data_ptr(), sp()), "mdq_restore_rows_masked")
-        ro["state"] = self._state_device()
+        self._refresh_launch(readback=False, defer_flow=True)
+        # ---- the end of the step in one launch
+        x = torch.empty((B, N, 2 + 3 * S), dtype=torch.float32, device=self.device)
+        d = self._finish_desc(ro, k, x)
+        fin = None
+        if self.flow_steps > 0 and self.flow_overlap:
+            fin, pairs = self._flow_handover(self.u, self.p)
+            self._finish_handover(d, pairs)
+        _lib.check(lib.mdq_env_finish(C.byref(d), sp()), "mdq_env_finish")
+        if fin is not None:
+            self._flow_start(fin)
+        ro["si"] ^= 1
+        ro["state"] = dict(x=x, node_ptr=self._node_ptr, edge_src_pad=dt.t["edge_src"], edge_dst_pad=dt.t["edge_dst"],
+                           nedges_dev=dt.t["nedges"])
         ro["k"] = k + 1
+
+    def _finish_desc(self, ro, k, x):
+        """Descriptor of `mdq_env_finish` for step k of a rollout (built once per environment object; the per-step
+        pointers are patched in)."""
+        dt, B, N, S = self.dtopo, self.B, self.N, self.S
+        d = getattr(self, "_fin_desc", None)
+        if d is None:
+            d = self._fin_desc = _lib.EnvFinishDesc()
+            d.B, d.N, d.S, d.NV, d.NP = B, N, S, self.NV, self.NP
+            d.nv0, d.timesteps, d.auto_reset = int(self.initial_num_node), int(self.timesteps), 1 if self.auto_reset else 0
+            d.threshold, d.time_reward, d.goal_vertices, d.negative_reward = (float(self.threshold), float(self.TIME_REWARD),
+                                                                                float(self.goal_vertices), float(self.NEGATIVE_REWARD))
+            d.gt_drag, d.nv, d.rstat = self._gt_drag_dev.data_ptr(), dt.nv.data_ptr(), self._rstat.data_ptr()
+            d.topo_status, d.nsel, d.n_closest = dt.status.data_ptr(), dt.t["nsel"].data_ptr(), dt.t["n_closest"].data_ptr()
+        c = self._init_cache
+        if c.get("x") is None:      # node features of the initial state (what an environment shows right after its reset)
+            xi = torch.empty((1, N, 2 + 3 * S), dtype=torch.float32, device=self.device)
+            _lib.check(self.lib.mdq_state_features(1, N, S, self.NV, self.NP, self._x0_dev.data_ptr(), c["u"].data_ptr(),
+                                                   c["p"].data_ptr(), c["dev"]["n_closest"].data_ptr(),
+                                                   c["dev"]["nsel"].data_ptr(), xi.data_ptr(), _lib.stream_ptr()),
+                       "mdq_state_features")
+            c["x"] = xi
+        d.x_init = c["x"].data_ptr()
+        ra = self._restore_arg_arrays()                # (u / p / coords change their addresses from step to step)
+        n = ra["n"]
+        if n + 2 > _lib.FINISH_MAX_ROWS:
+            raise _lib.MeshDQNHipError("mdq_env_finish: too many row arrays")
+        d.n_rows = n
+        for t in range(n):
+            d.dst[t], d.src[t], d.row_bytes[t] = ra["dst"][t], ra["src"][t], ra["nbytes"][t]
+            d.handover_dst[t], d.handover_off[t], d.handover_bytes[t] = None, 0, 0
+        if not self.auto_reset:                        # nothing is restored: the rows stay as hand-over sources only
+            for t in range(n):
+                d.src[t] = None
+        d.new_drags = self._dev_drag.data_ptr()
+        d.code_in, d.code_out = ro["code_act"].data_ptr(), ro["code"][k].data_ptr()
+        d.steps_in, d.steps_out = ro["d_steps"][ro["si"]].data_ptr(), ro["d_steps"][ro["si"] ^ 1].data_ptr()
+        d.reward, d.done, d.err_flag, d.nv_out = (ro["rew"][k].data_ptr(), ro["done"][k].data_ptr(), ro["err"].data_ptr(),
+                                                  ro["nv"][k].data_ptr())
+        d.coords, d.u, d.p, d.x = self._coords_dev.data_ptr(), self.u.data_ptr(), self.p.data_ptr(), x.data_ptr()
+        return d
+
+    def _finish_handover(self, d, pairs):
+        """The hand-over windows of `mdq_env_finish`: every (destination, source) pair of `_flow_handover` is a window of
+        one of the row arrays (a whole row, or - the warm start - the last snapshot of the u / p rows) or, for arrays that
+        are not reset in place (the edge numbering), a row array of its own without a source."""
+        n = d.n_rows
+        index = {int(d.dst[t]): t for t in range(n)}
+        for dst, src in pairs:
+            if dst.dtype != src.dtype or not dst.is_contiguous() or dst.shape != src.shape or not src[0].is_contiguous():
+                raise ValueError("flow hand-over: buffers of different shapes")
+            base = src._base if src._base is not None else src
+            per = src[0].numel() * src.element_size()
+            t = index.get(int(base.data_ptr()))
+            if t is None:                              # not one of the restored arrays: hand-over only
+                if not src.is_contiguous():
+                    raise ValueError("flow hand-over: an array that is not reset must be contiguous")
+                t = n
+                n += 1
+                d.dst[t], d.src[t], d.row_bytes[t] = src.data_ptr(), None, per
+                off = 0
+            else:
+                off = src.data_ptr() - base.data_ptr()
+                if off < 0 or off + per > d.row_bytes[t] or (not src.is_contiguous() and src.stride(0) * src.element_size() != d.row_bytes[t]):
+                    raise ValueError("flow hand-over: the source is not a window of a row array")
+            d.handover_dst[t], d.handover_off[t], d.handover_bytes[t] = dst.data_ptr(), off, per
+        d.n_rows = n
 
     def rollout_end(self, ro):
         """The one read-back of a rollout; the host mirrors of the environments follow the device."""
@@ -924,7 +938,7 @@ class VecEnv2DAirfoil:
                    actions=ro["act"][:K].cpu().numpy(), codes=ro["code"][:K].cpu().numpy(), nv=ro["nv"][:K].cpu().numpy())
         if int(ro["err"].item()) != 0:
             raise _lib.MeshDQNHipError("topology kernel failed inside rollout_device")
-        self._sync_host_from_device(ro["d_steps"], out["dones"][-1] if K and self.auto_reset else None)
+        self._sync_host_from_device(ro["d_steps"][ro["si"]], out["dones"][-1] if K and self.auto_reset else None)
         return out
 
     def _sync_host_from_device(self, d_steps, last_done=None):

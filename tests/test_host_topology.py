@@ -110,7 +110,8 @@ def test_pressure_direct_factors_reproduce_dense_solve(meshes):
 
 
 @pytest.mark.parametrize("cname,pyname", [("mdq_ipcs_desc", "IpcsDesc"), ("mdq_interp_desc", "InterpDesc"),
-                                          ("mdq_env_topo_desc", "EnvTopoDesc"), ("mdq_ipcs_topo_out", "IpcsTopoOut")])
+                                          ("mdq_env_topo_desc", "EnvTopoDesc"), ("mdq_ipcs_topo_out", "IpcsTopoOut"),
+                                          ("mdq_env_finish_desc", "EnvFinishDesc")])
 def test_descriptor_layout_matches_c_header(tmp_path, cname, pyname):
     """every ctypes mirror has the same size / field offsets as its struct in the C header."""
     import ctypes as C, os, subprocess
