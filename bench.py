@@ -337,30 +337,6 @@ def measure_env_steps(args, dev, dist, world, flow_steps=0, steps=None, warmup=8
                 out["smooth_kernel_in_rollout_ms"]["last_launch_diagnostics"] = repr(exc)
         for e in groups.envs:
             e.smooth_events = None
-    if keep is not None and not args.host_step and len(groups.envs) == 1 and steps % 2 == 0:
-        # the same rollouts replayed from ONE HIP graph per `steps` env steps (VecEnv2DAirfoil.rollout_graph: main chain and
-        # flow leg captured together): same kernels, same results; what changes is the host side (one graph launch per
-        # rollout instead of ~13 launches per env step)
-        try:
-            env0 = groups.envs[0]
-            host_ms = []
-
-            def run_graph(k):
-                ex, ra = draw(k)
-                with torch.cuda.stream(groups.streams[0]):
-                    t0 = time.perf_counter()
-                    env0.rollout_graph(fused[0], k, ex[0], ra[0])
-                    host_ms.append((time.perf_counter() - t0) * 1e3)
-            run_graph(steps)                       # eager (warms), then capture + first replay
-            run_graph(steps)
-            gt = [_timed(dist, dev, lambda: run_graph(steps)) for _ in range(repeats)]
-            gel = float(np.median(gt))
-            out["graph_replay"] = dict(value=world * B * steps / gel, ms_per_batched_step=gel / steps * 1e3, repeats=repeats,
-                                       seconds_per_repeat=gt,
-                                       what="the same S3 rollouts replayed from one HIP graph per rollout (rollout_graph); "
-                                            "seconds include the input upload and the read-back of the results")
-        except Exception as exc:  # noqa: BLE001 - side measurement
-            out["graph_replay"] = dict(error=repr(exc))
     return out
 
 

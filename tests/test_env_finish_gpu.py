@@ -150,7 +150,8 @@ def test_remesh_act_equals_env_act_then_remesh(lib_built, meshes, given):
     explore = (rng.random(B) < 0.4).astype(np.uint8)
     rand = rng.integers(0, N + 1, B).astype(np.int32)
     rand[7], explore[7] = N, 1
-    acts = rng.integers(-2, N + 3, B).astype(np.int32)
+    acts = rng.integers(0, N, B).astype(np.int32)
+    acts[:6] = [-1, N, N + 1, 179, -5, N + 40]            # invalid, "do nothing", out of range, maybe beyond nsel, ...
     res = []
     for fused in (False, True):
         coords = torch.from_numpy(np.repeat(coords0[None], B, 0).copy()).cuda()
@@ -175,4 +176,4 @@ def test_remesh_act_equals_env_act_then_remesh(lib_built, meshes, given):
         res.append([t.cpu() for t in (coords, cells, nv, nt, off, action, rem, code, stat)])
     for a, b in zip(*res):
         assert torch.equal(a, b)
-    assert (res[1][6] >= 0).sum() > B // 2 and (res[1][2] == NV - 1).sum() > B // 2 and (res[1][7] == 2).any()
+    assert (res[1][6] >= 0).sum() > B // 2 and (res[1][2] == NV - 1).sum() > B // 2 and (res[1][7] == 2).any() and (res[1][6] < 0).any()

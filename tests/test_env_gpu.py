@@ -867,46 +867,6 @@ def test_device_resident_rollout_equals_host_logic_steps(lib_built, flow):
         assert np.abs(out["rewards"][k] - hist[k][1]).max() < 1e-12 and np.array_equal(out["dones"][k], hist[k][2])
 
 
-@pytest.mark.parametrize("flow", [0, 1])
-def test_rollout_graph_equals_rollout_device(lib_built, flow):
-    """`rollout_graph` (the launches of a whole rollout - with `flow` the IPCS leg on its own stream too - captured once
-    and replayed as ONE HIP graph) against `rollout_device` on a twin environment: the eager first call, the capturing
-    second call and two replays with new random inputs give the same actions, rewards, terminations, vertex counts and
-    final meshes; an eager rollout in between (even number of steps) does not disturb the graph."""
-    from meshdqn_amd.airfoilgcnn import NodeRemovalNet
-    from meshdqn_amd.env import Env2DAirfoil
-    from meshdqn_amd.gcn_fused import FusedGcn
-    from meshdqn_amd.vec_env import VecEnv2DAirfoil
-    cfg = _config("ys930")
-    base = Env2DAirfoil(cfg)
-    B, K = 5, 4
-    torch.manual_seed(0)
-    net = NodeRemovalNet(181, conv_width=128, topk=0.1)
-    net.set_num_nodes(17)
-    net.cuda()
-    kw = dict(flow_steps=1, flow_overlap=True) if flow else {}
-    eager = VecEnv2DAirfoil(cfg, B, base_env=base, nthreads=2, **kw)
-    graph = VecEnv2DAirfoil(cfg, B, base_env=base, nthreads=2, **kw)
-    fe, fg = FusedGcn(net), FusedGcn(net)
-    rng = np.random.default_rng(17)
-    for call in range(5):
-        ex, ra = rng.random((K, B)) < 0.5, rng.integers(0, 181, (K, B))
-        a = eager.rollout_device(fe, K, ex, ra)
-        b = graph.rollout_device(fg, K, ex, ra) if call == 3 else graph.rollout_graph(fg, K, ex, ra)
-        for k in ("actions", "dones", "nv", "codes"):
-            assert np.array_equal(a[k], b[k]), (call, k)
-        assert np.abs(a["rewards"] - b["rewards"]).max() < 1e-12, call
-        assert np.array_equal(eager.nv, graph.nv) and np.array_equal(eager.steps, graph.steps)
-        nvm = int(eager.nv.max())
-        assert np.abs(eager.coords[:, :nvm] - graph.coords[:, :nvm]).max() < 1e-15, call
-        if flow:
-            fa, fb = eager.flow_wait(), graph.flow_wait()
-            assert np.allclose(fa[0], fb[0], rtol=1e-9, atol=0) and np.allclose(fa[1], fb[1], rtol=1e-9, atol=0), call
-    assert any(isinstance(v, dict) for v in graph._graphs.values())
-    with pytest.raises(ValueError):
-        graph.rollout_graph(fg, 3, rng.random((3, B)) < 0.5, rng.integers(0, 181, (3, B)))
-
-
 def test_stream_calibration_keeps_a_working_flow_stream_and_resets_the_envs(lib_built):
     """`VecEnv2DAirfoil.calibrate_streams` (a few real steps per candidate flow stream, the fastest stays) leaves the
     environments in their initial state and the overlapped flow path working: the rollout that follows equals the one
