@@ -617,10 +617,14 @@ extern "C" int mdq_env_finish(const mdq_env_finish_desc* d, void* stream) {
       return mdq_set_error("mdq_env_finish: rows must be non-empty 4-byte aligned multiples of 4 bytes with a hand-over window inside them");
     bytes += d->handover_dst[t] ? d->handover_bytes[t] : 0;
   }
-  // workgroups per environment: enough lanes for the hand-over copies (16 bytes per lane and pass, ~4 passes); without
-  // cached initial features the reset path needs the whole environment in one workgroup
+  // workgroups per environment: enough lanes for the hand-over copies AND the in-place reset of a terminated environment
+  // (16 bytes per lane and pass, ~4 passes; the workgroups of the other environments find nothing to restore and leave);
+  // without cached initial features the reset path needs the whole environment in one workgroup
+  int64_t rbytes = 0;
+  for (int t = 0; t < d->n_rows; ++t) rbytes += (d->auto_reset && d->src[t]) ? d->row_bytes[t] : 0;
+  if (rbytes > bytes) bytes = rbytes;
   int Y = (int)((bytes / 16 + 1023) / 1024);
-  Y = Y < 1 ? 1 : (Y > 8 ? 8 : Y);
+  Y = Y < 1 ? 1 : (Y > 16 ? 16 : Y);
   if (d->auto_reset && !d->x_init) Y = 1;
   hipLaunchKernelGGL(mdq_mesh::env_finish_kernel, dim3(d->B, Y), dim3(256), 0, (hipStream_t)stream, *d);
   if (hipGetLastError() != hipSuccess) return mdq_set_error("env_finish_kernel launch failed");

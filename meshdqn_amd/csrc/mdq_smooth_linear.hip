@@ -52,6 +52,7 @@ constexpr int BS = 32;             // rows per block
 constexpr int NSLOT = 14;          // gather slots per row (7 per lane half)
 constexpr int MAXNB = 16;          // neighbours / cells per vertex the setup handles (more: the mesh goes to the careful walk)
 constexpr int MAXLOW = 8;          // lower-numbered neighbours inside the own block
+constexpr int MAXLATE = 4;         // neighbours of a row of an odd block inside the (even) block before it: the coupling of a block pair
 constexpr int SROW = 32;           // bytes per solver row: [7 x u16 gather offsets, u16 store offset] x 2 halves
 constexpr int ZOFF = LNV * 16;     // the zero record of a position buffer (byte offset)
 constexpr int PBUF = (LNV + 1) * 16;
@@ -67,8 +68,9 @@ constexpr int OFF_RK = OFF_INC + 3 * LNT * 4;                // interior rank (0
 constexpr int OFF_IVERT = OFF_RK + LNV * 2;                  // interior vertices in index order
 constexpr int OFF_LMETA = OFF_IVERT + LNV * 2;               // per rank: local indices of the lower neighbours inside the block
 constexpr int OFF_KDEG = OFF_LMETA + LNV * MAXLOW;           // per rank: number of neighbours | in-block lower count << 8
-constexpr int OFF_G = OFF_KDEG + LNV * 2;                    // g of the block in flight, per component
-constexpr int OFF_R2K = OFF_G + 2 * BS * 8;                  // 1 / (2 k)
+constexpr int OFF_LATE = OFF_KDEG + LNV * 2;                 // per rank of an ODD block: byte offsets of its (<= MAXLATE) neighbours in the block before
+constexpr int OFF_G = OFF_LATE + LNV * MAXLATE * 2;          // g of the two blocks in flight, per component
+constexpr int OFF_R2K = OFF_G + 2 * 2 * BS * 8;              // 1 / (2 k)
 constexpr int OFF_MISC = OFF_R2K + 32 * 8;                   // [0] n_int  [1] bad / newly flagged  [2] eligible
 constexpr int OFF_FIXV = OFF_MISC + 64;                      // per vertex: takes the exact update in the sweep at hand
 constexpr int OFF_PART = OFF_FIXV + LNV + 16;
@@ -79,7 +81,12 @@ constexpr int OFF_NB = OFF_CUR;                              // [LNV][MAXNB] u16
 constexpr int OFF_TRI = OFF_CUR;                             // 8 waves x 528 doubles (packed lower triangles)
 constexpr int OFF_TMP = OFF_SROW;                            // cell lists in arrival order (before the rows are built)
 static_assert(LNV * MAXNB * 2 <= 3 * PBUF && TRW * 528 * 8 <= 3 * PBUF && 3 * LNT * 4 <= LNV * SROW, "setup scratch");
-static_assert(OFF_SROW % 16 == 0 && OFF_PTR % 16 == 0 && OFF_INC % 16 == 0 && OFF_G % 16 == 0 && OFF_R2K % 8 == 0, "LDS alignment");
+static_assert(OFF_SROW % 16 == 0 && OFF_PTR % 16 == 0 && OFF_INC % 16 == 0 && OFF_G % 16 == 0 && OFF_R2K % 8 == 0 && OFF_LATE % 8 == 0, "LDS alignment");
+// workspace of one mesh: the block inverses M_b (MBLOCKS blocks incl. prefetch padding), then the pair couplings V_p
+__host__ __device__ constexpr int mblocks(int NV) { return (NV + BS - 1) / BS + 3; }
+__host__ __device__ constexpr int vblocks(int NV) { return (NV + 2 * BS - 1) / (2 * BS) + 2; }
+constexpr int WPAIR = 6;           // waves that build pair couplings at a time (a private 32 x 32 scratch each, in the position buffers)
+static_assert(WPAIR * BS * BS * 8 <= 3 * PBUF, "pair scratch");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -174,8 +181,25 @@ __device__ __forceinline__ bool validate_entry(unsigned char* lds, int e, int ne
 
 // the block step of a solver wave (component COMP): lane = row i | half h << 5.  M: the lane's 16 entries of row i
 // (columns 16 h .. 16 h + 15) as 8 pairs; meta: the lane's 8 u16 of the solver row (7 gather offsets + the store offset)
+#ifdef MDQ_LIN_TRACE2
+// debug build only: where the cycles of ONE block step go (wave 0 = the x component of mesh 0; s_memtime waits for the
+// wave's outstanding LDS operations, so every stamp is also a fence: the sum of the parts overstates the step a little)
+__device__ long long mdq_lin_bt_buf[8];
+#define BT_DECL long long bt_t_ = __builtin_amdgcn_s_memtime();
+#define BT(k) { const long long tn_ = __builtin_amdgcn_s_memtime(); if (COMP == 0 && blockIdx.x == 0 && (threadIdx.x & 63) == 0) mdq_lin_bt_buf[k] += tn_ - bt_t_; bt_t_ = __builtin_amdgcn_s_memtime(); }
+extern "C" int mdq_lin_bt_host(long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mdq_lin_bt_buf), sizeof(long long) * 8) != hipSuccess) return -1;
+  if (reset) { long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(mdq_lin_bt_buf), z, sizeof z) != hipSuccess) return -1; }
+  return 0;
+}
+#else
+#define BT_DECL
+#define BT(k)
+#endif
+
 template <int COMP>
 __device__ __forceinline__ void solve_block(unsigned char* lds, const u4 meta, const d2 (&M)[8], int i, int h) {
+  BT_DECL
   const unsigned char* cur = lds + OFF_CUR + COMP * 8;
   const double v0 = *reinterpret_cast<const double*>(cur + (meta.x & 0xFFFF));
   const double v1 = *reinterpret_cast<const double*>(cur + (meta.x >> 16));
@@ -184,20 +208,102 @@ __device__ __forceinline__ void solve_block(unsigned char* lds, const u4 meta, c
   const double v4 = *reinterpret_cast<const double*>(cur + (meta.z & 0xFFFF));
   const double v5 = *reinterpret_cast<const double*>(cur + (meta.z >> 16));
   const double v6 = *reinterpret_cast<const double*>(cur + (meta.w & 0xFFFF));
+#ifdef MDQ_LIN_TRACE2
+  double sv_ = ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + v6);
+  asm volatile("" : "+v"(sv_));
+  BT(0)                                 // gather: 7 LDS reads + 6 adds
+  const double g = halves_sum(sv_);
+#else
   const double g = halves_sum(((v0 + v1) + (v2 + v3)) + ((v4 + v5) + v6));
+#endif
   double* G = reinterpret_cast<double*>(lds + OFF_G) + COMP * BS;
   if (h == 0) G[i] = g;
   asm volatile("" ::: "memory");      // (the LDS serves a wave's operations in order: the reads below see the store)
+  BT(1)                                 // cross-half add (2 permlane swaps) + store of g
   const d2* gq = reinterpret_cast<const d2*>(G + 16 * h);
   double acc0 = 0.0, acc1 = 0.0;
+#ifdef MDQ_LIN_TRACE2
+  d2 gg_[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) gg_[t] = gq[t];
+  BT(2)                                 // the 8 reads of g (16 values) back from LDS
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    acc0 = __builtin_fma(M[t].x, gg_[t].x, acc0);
+    acc1 = __builtin_fma(M[t].y, gg_[t].y, acc1);
+  }
+  asm volatile("" : "+v"(acc0), "+v"(acc1));
+  BT(3)                                 // two chains of 8 FMAs (includes the wait for the prefetched M rows)
+#else
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     const d2 gg = gq[t];
     acc0 = __builtin_fma(M[t].x, gg.x, acc0);
     acc1 = __builtin_fma(M[t].y, gg.y, acc1);
   }
+#endif
   const double x = halves_sum(acc0 + acc1);
   if (h == 0) *reinterpret_cast<double*>(lds + OFF_CUR + COMP * 8 + (meta.w >> 16)) = x;
+  asm volatile("" ::: "memory");
+  BT(4)                                 // cross-half add + store of x
+}
+
+// The PAIRED block step (round 4).  For blocks (b, b + 1) the gather of block b + 1 is split, g_{b+1} = e_{b+1} + C x_b
+// (C: the 0 / 1 coupling of its rows to the rows of block b they have as neighbours - the "late" slots, kept out of the
+// solver rows of odd blocks), so that
+//      x_b     = M_b g_b,
+//      x_{b+1} = M_{b+1} e_{b+1} + V g_b,       V = M_{b+1} C M_b   (32 x 32, topology only: built once per launch),
+// and BOTH gathers are issued together: ONE dependent round (gather -> cross-half add -> broadcast through LDS -> FMA
+// chains -> cross-half add -> store) serves 64 rows instead of 32.  A block step is a chain of LDS round trips and of one
+// wave's issue slots (tools/trace_smooth_block.py: gather 131, add + store of g 110, read-back 117, FMAs 40, add + store
+// of x 121 cycles with a fence after each part); the pair pays the round trips once and 48 instead of 2 x 16 FMAs per lane.
+// tools/smooth_pair_proto.py: the paired form = the sequential sweep to 3e-15 after 44 sweeps, like the single step.
+// m0 / m1: the solver rows of the pair on entry, of the NEXT pair (read from nxt, behind the gather) on exit
+template <int COMP>
+__device__ __forceinline__ void solve_pair(unsigned char* lds, u4& m0, u4& m1, const unsigned char* nxt, const d2 (&M0)[8],
+                                           const d2 (&M1)[8], const d2 (&V)[8], int i, int h) {
+  const unsigned char* cur = lds + OFF_CUR + COMP * 8;
+  const double a0 = *reinterpret_cast<const double*>(cur + (m0.x & 0xFFFF)), a1 = *reinterpret_cast<const double*>(cur + (m0.x >> 16));
+  const double a2 = *reinterpret_cast<const double*>(cur + (m0.y & 0xFFFF)), a3 = *reinterpret_cast<const double*>(cur + (m0.y >> 16));
+  const double a4 = *reinterpret_cast<const double*>(cur + (m0.z & 0xFFFF)), a5 = *reinterpret_cast<const double*>(cur + (m0.z >> 16));
+  const double a6 = *reinterpret_cast<const double*>(cur + (m0.w & 0xFFFF));
+  const double b0 = *reinterpret_cast<const double*>(cur + (m1.x & 0xFFFF)), b1 = *reinterpret_cast<const double*>(cur + (m1.x >> 16));
+  const double b2 = *reinterpret_cast<const double*>(cur + (m1.y & 0xFFFF)), b3 = *reinterpret_cast<const double*>(cur + (m1.y >> 16));
+  const double b4 = *reinterpret_cast<const double*>(cur + (m1.z & 0xFFFF)), b5 = *reinterpret_cast<const double*>(cur + (m1.z >> 16));
+  const double b6 = *reinterpret_cast<const double*>(cur + (m1.w & 0xFFFF));
+  const int so0 = m0.w >> 16, so1 = m1.w >> 16;     // where the results go
+  // (the next pair's solver rows: requested here, their round trip rides behind the gather's; prefetched a whole step ahead
+  //  they cost 8 VGPRs through the FMA phase and the loop spilled)
+  m0 = *reinterpret_cast<const u4*>(nxt);
+  m1 = *reinterpret_cast<const u4*>(nxt + BS * SROW);
+  const double g0 = halves_sum(((a0 + a1) + (a2 + a3)) + ((a4 + a5) + a6));
+  const double g1 = halves_sum(((b0 + b1) + (b2 + b3)) + ((b4 + b5) + b6));
+  double* G = reinterpret_cast<double*>(lds + OFF_G) + COMP * 2 * BS;
+  if (h == 0) {
+    G[i] = g0;
+    G[BS + i] = g1;
+  }
+  asm volatile("" ::: "memory");      // (the LDS serves a wave's operations in order: the reads below see the stores)
+  const d2* gq0 = reinterpret_cast<const d2*>(G + 16 * h);
+  const d2* gq1 = reinterpret_cast<const d2*>(G + BS + 16 * h);
+  double p0 = 0.0, p1 = 0.0, q0 = 0.0, q1 = 0.0, r0 = 0.0, r1 = 0.0;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if (t == 4) asm volatile("" ::: "memory");   // (two batches of reads: all 16 in flight at once cost 64 VGPRs and spilled)
+    const d2 ga = gq0[t], gb = gq1[t];
+    p0 = __builtin_fma(M0[t].x, ga.x, p0);
+    p1 = __builtin_fma(M0[t].y, ga.y, p1);
+    q0 = __builtin_fma(M1[t].x, gb.x, q0);
+    q1 = __builtin_fma(M1[t].y, gb.y, q1);
+    r0 = __builtin_fma(V[t].x, ga.x, r0);
+    r1 = __builtin_fma(V[t].y, ga.y, r1);
+  }
+  const double x0 = halves_sum(p0 + p1);
+  const double x1 = halves_sum((q0 + q1) + (r0 + r1));
+  if (h == 0) {
+    *reinterpret_cast<double*>(lds + OFF_CUR + COMP * 8 + so0) = x0;
+    *reinterpret_cast<double*>(lds + OFF_CUR + COMP * 8 + so1) = x1;
+  }
   asm volatile("" ::: "memory");
 }
 
@@ -213,27 +319,26 @@ __device__ __forceinline__ void load_m(d2 (&M)[8], const d2* mg, int b, int i, i
 }
 
 template <int COMP>
-__device__ __forceinline__ void solve_sweep(unsigned char* lds, const d2* mg, int nb, int lane) {
+__device__ __forceinline__ void solve_sweep(unsigned char* lds, const d2* mg, const d2* mgv, int nb, int lane) {
   const int i = lane & 31, h = lane >> 5;
   const unsigned char* srow = lds + OFF_SROW + i * SROW + h * 16;
-  d2 MA[8], MB[8], MC[8];
-  load_m(MA, mg, 0, i, h);
-  load_m(MB, mg, 1, i, h);
-  u4 meta = *reinterpret_cast<const u4*>(srow);
-  for (int b = 0; b < nb; b += 3) {
-    u4 mnext = *reinterpret_cast<const u4*>(srow + (b + 1) * (BS * SROW));
-    load_m(MC, mg, b + 2, i, h);           // (the workspace holds two blocks of padding behind the last one)
-    solve_block<COMP>(lds, meta, MA, i, h);
-    if (b + 1 >= nb) break;
-    meta = *reinterpret_cast<const u4*>(srow + (b + 2) * (BS * SROW));
-    load_m(MA, mg, b + 3, i, h);
-    solve_block<COMP>(lds, mnext, MB, i, h);
-    if (b + 2 >= nb) break;
-    mnext = *reinterpret_cast<const u4*>(srow + (b + 3) * (BS * SROW));
-    load_m(MB, mg, b + 4, i, h);
-    solve_block<COMP>(lds, meta, MC, i, h);
-    meta = mnext;
+  const int np = nb >> 1;
+  // one pair's rows of M_b, M_{b+1}, V in registers; the rows of the NEXT pair are requested right behind the FMAs that
+  // consume the current ones (a full step - two LDS round trips and the next gather - before their first use) into the
+  // same registers: 96 VGPRs instead of the 192 of two pairs in flight (the kernel runs 3 waves per SIMD: 170 VGPRs)
+  d2 M0[8], M1[8], V[8];
+  load_m(M0, mg, 0, i, h);
+  load_m(M1, mg, 1, i, h);
+  load_m(V, mgv, 0, i, h);
+  u4 m0 = *reinterpret_cast<const u4*>(srow), m1 = *reinterpret_cast<const u4*>(srow + BS * SROW);
+#pragma unroll 1
+  for (int p = 0; p < np; ++p) {
+    solve_pair<COMP>(lds, m0, m1, srow + (2 * p + 2) * (BS * SROW), M0, M1, V, i, h);   // (rows behind the last block: never used)
+    load_m(M0, mg, 2 * p + 2, i, h);         // (the workspace holds padding behind the last block / pair)
+    load_m(M1, mg, 2 * p + 3, i, h);
+    load_m(V, mgv, p + 1, i, h);
   }
+  if (nb & 1) solve_block<COMP>(lds, m0, M0, i, h);      // an odd number of blocks: the last one on its own
 }
 
 __device__ __forceinline__ double grp8_mind(double v) {
@@ -313,8 +418,15 @@ __device__ __forceinline__ void repair_sweep(unsigned char* lds, const d2* mg, i
     const d2 v2 = *reinterpret_cast<const d2*>(cur + (meta.y & 0xFFFF)), v3 = *reinterpret_cast<const d2*>(cur + (meta.y >> 16));
     const d2 v4 = *reinterpret_cast<const d2*>(cur + (meta.z & 0xFFFF)), v5 = *reinterpret_cast<const d2*>(cur + (meta.z >> 16));
     const d2 v6 = *reinterpret_cast<const d2*>(cur + (meta.w & 0xFFFF));
-    const double gx = halves_sum(((v0.x + v1.x) + (v2.x + v3.x)) + ((v4.x + v5.x) + v6.x));
-    const double gy = halves_sum(((v0.y + v1.y) + (v2.y + v3.y)) + ((v4.y + v5.y) + v6.y));
+    d2 lsum = {0.0, 0.0};
+    if ((b & 1) && h == 0) {   // the neighbours in the block before (kept out of the solver rows of odd blocks: solve_pair)
+      const uint2 lw = *reinterpret_cast<const uint2*>(lds + OFF_LATE + (b * BS + i) * (MAXLATE * 2));
+      const d2 l0 = *reinterpret_cast<const d2*>(cur + (lw.x & 0xFFFF)), l1 = *reinterpret_cast<const d2*>(cur + (lw.x >> 16));
+      const d2 l2 = *reinterpret_cast<const d2*>(cur + (lw.y & 0xFFFF)), l3 = *reinterpret_cast<const d2*>(cur + (lw.y >> 16));
+      lsum = d2{(l0.x + l1.x) + (l2.x + l3.x), (l0.y + l1.y) + (l2.y + l3.y)};
+    }
+    const double gx = halves_sum((((v0.x + v1.x) + (v2.x + v3.x)) + ((v4.x + v5.x) + v6.x)) + lsum.x);
+    const double gy = halves_sum((((v0.y + v1.y) + (v2.y + v3.y)) + ((v4.y + v5.y) + v6.y)) + lsum.y);
     if (h == 0) {
       G[i] = gx;
       G[BS + i] = gy;
@@ -492,11 +604,15 @@ __global__ __launch_bounds__(LWG) void smooth_linear_kernel(int NV, int NT, doub
   LT_STAMP(2)
   // ---- per interior rank: gather slots (every neighbour that is not a lower-numbered member of the own block),
   // in-block lower neighbours (the strictly lower triangle of the block), validation flags of the cell entries
+  uint16_t* late = reinterpret_cast<uint16_t*>(lds + OFF_LATE);
   for (int r = tid; r < nb * BS; r += LWG) {
     uint16_t slots[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) slots[s] = (uint16_t)ZOFF;
-    int ns = 0, nl = 0, k = 1;
+    uint16_t lt[MAXLATE];
+#pragma unroll
+    for (int s = 0; s < MAXLATE; ++s) lt[s] = (uint16_t)ZOFF;
+    int ns = 0, nl = 0, nlate = 0, k = 1;
     if (r < n_int) {
       const int v = ivert[r], q0 = ptr[v];
       k = ptr[v + 1] - q0;
@@ -506,6 +622,13 @@ __global__ __launch_bounds__(LWG) void smooth_linear_kernel(int NV, int NT, doub
         if (rw != 0xFFFF && w < v && (rw >> 5) == (r >> 5)) {
           if (nl < MAXLOW) lmeta[r * MAXLOW + nl] = (unsigned char)(rw & 31);
           ++nl;
+        } else if (((r >> 5) & 1) && rw != 0xFFFF && (rw >> 5) == (r >> 5) - 1) {
+          // a row of an ODD block with a neighbour in the block before it (lower-numbered: interior ranks follow the vertex
+          // ids): the coupling of the block pair, not a gather slot (solve_pair)
+#pragma unroll
+          for (int s = 0; s < MAXLATE; ++s)
+            if (s == nlate) lt[s] = (uint16_t)(w * 16);
+          ++nlate;
         } else {
           // slot j of the row: lane half (j & 1), position (j >> 1)
           if (ns < NSLOT) {
@@ -517,7 +640,7 @@ __global__ __launch_bounds__(LWG) void smooth_linear_kernel(int NV, int NT, doub
           ++ns;
         }
       }
-      if (ns > NSLOT || nl > MAXLOW) misc[2] = 0;
+      if (ns > NSLOT || nl > MAXLOW || nlate > MAXLATE) misc[2] = 0;
       slots[7] = (uint16_t)(v * 16);                          // where the row's result goes
       for (int q = q0; q < q0 + k; ++q) {                      // validation entries: a | c << 10 | v << 20 | new(a) << 30 | new(c) << 31
         const uint32_t w = inc[q];
@@ -527,6 +650,7 @@ __global__ __launch_bounds__(LWG) void smooth_linear_kernel(int NV, int NT, doub
       }
     }
     kdeg[r] = (uint16_t)(k | (min(nl, MAXLOW) << 8));
+    *reinterpret_cast<uint2*>(late + r * MAXLATE) = uint2{(uint32_t)lt[0] | ((uint32_t)lt[1] << 16), (uint32_t)lt[2] | ((uint32_t)lt[3] << 16)};
     uint32_t wds[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) wds[s] = (uint32_t)slots[2 * s] | ((uint32_t)slots[2 * s + 1] << 16);
@@ -589,6 +713,60 @@ __global__ __launch_bounds__(LWG) void smooth_linear_kernel(int NV, int NT, doub
   }
   __threadfence_block();
   __syncthreads();
+  // ---- pair couplings V_p = M_{2p+1} C M_{2p} (solve_pair): one wave per pair, WPAIR pairs at a time.  Lane = row i | half
+  // h << 5.  W = M_{2p+1} C first (row i in the wave's LDS scratch: column j collects the entries M_{2p+1}[i][k] of the
+  // rows k that have row j of the block before as a neighbour), then V[i][16 h .. 16 h + 15] = sum_m W[i][m] M_{2p}[m][..]
+  // with the rows of M_{2p} read back from the workspace (the same 128 bytes for every lane of a half).
+  double* mgv = mg + (int64_t)mblocks(NV) * MBLK;
+  {
+    const int np = nb >> 1, i = lane & 31, h = lane >> 5;
+    double* Wl = reinterpret_cast<double*>(lds + OFF_CUR) + wave * (BS * BS);
+    const d2* mgd_ = reinterpret_cast<const d2*>(mg);
+    for (int pr = wave < WPAIR ? wave : np; pr < np; pr += WPAIR) {
+      const int b1 = 2 * pr + 1;
+      d2 A[16];
+      load_m(reinterpret_cast<d2(&)[8]>(A[0]), mgd_, b1, i, 0);
+      load_m(reinterpret_cast<d2(&)[8]>(A[8]), mgd_, b1, i, 1);
+#pragma unroll
+      for (int m = 0; m < 16; ++m) Wl[i * BS + 16 * h + m] = 0.0;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (h == 0) {
+#pragma unroll
+        for (int k = 0; k < BS; ++k) {
+          const double mik = (k & 1) ? A[k >> 1].y : A[k >> 1].x;
+          const uint2 lw = *reinterpret_cast<const uint2*>(lds + OFF_LATE + (b1 * BS + k) * (MAXLATE * 2));   // (uniform)
+#pragma unroll
+          for (int q = 0; q < MAXLATE; ++q) {
+            const uint32_t off = ((q & 2) ? lw.y : lw.x) >> (16 * (q & 1)) & 0xFFFFu;
+            if (off != (uint32_t)ZOFF) {
+              const int j = rk[off >> 4] & 31;
+              Wl[i * BS + j] += mik;
+            }
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      double acc[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) acc[c] = 0.0;
+      const d2* m0p = mgd_ + ((size_t)((b1 - 1) * 2 + h) * 8) * 32;
+      for (int m = 0; m < BS; ++m) {
+        const double w = Wl[i * BS + m];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const d2 mv = m0p[t * 32 + m];
+          acc[2 * t] = __builtin_fma(w, mv.x, acc[2 * t]);
+          acc[2 * t + 1] = __builtin_fma(w, mv.y, acc[2 * t + 1]);
+        }
+      }
+      d2* out = reinterpret_cast<d2*>(mgv) + ((size_t)(pr * 2 + h) * 8) * 32 + i;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) out[t * 32] = d2{acc[2 * t], acc[2 * t + 1]};
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
   LT_STAMP(4)
   // ---- positions (the setup scratch is dead): cur and the snapshot of sweep 0; zero records
   for (int v = tid; v <= LNV; v += LWG) {
@@ -611,6 +789,7 @@ __global__ __launch_bounds__(LWG) void smooth_linear_kernel(int NV, int NT, doub
   //  PIPELINED: waves 0 / 1 solve sweep s WHILE waves 2, 3, 6, 7 validate sweep s - 1 from the two snapshots (waves 4 / 5
   //    stay off the solvers' SIMDs); a sweep that fails goes back to its snapshot and to the CHECKED mode.
   const d2* mgd = reinterpret_cast<const d2*>(mg);
+  const d2* mgvd = reinterpret_cast<const d2*>(mgv);
   // validators of the pipelined mode: the waves of SIMDs 2 and 3 (waves 2, 3, 6, 7, 10, 11); the other waves of SIMDs 0 / 1
   // stay off the solvers' issue slots
   constexpr int NVAL = 2 * (LWG / 256);
@@ -624,11 +803,11 @@ __global__ __launch_bounds__(LWG) void smooth_linear_kernel(int NV, int NT, doub
   auto solve_fast = [&]() {
     if (wave == 0) {
       __builtin_amdgcn_s_setprio(3);
-      solve_sweep<0>(lds, mgd, nb, lane);
+      solve_sweep<0>(lds, mgd, mgvd, nb, lane);
       __builtin_amdgcn_s_setprio(0);
     } else if (wave == 1) {
       __builtin_amdgcn_s_setprio(3);
-      solve_sweep<1>(lds, mgd, nb, lane);
+      solve_sweep<1>(lds, mgd, mgvd, nb, lane);
       __builtin_amdgcn_s_setprio(0);
     }
   };
@@ -731,8 +910,8 @@ __global__ void count_redo_kernel(int B, const int32_t* redo, unsigned long long
 
 extern "C" int64_t mdq_smooth_fast_workspace_bytes(int32_t B, int32_t NV) {
   if (B <= 0 || NV <= 0) return 0;
-  const int64_t blocks = (NV + mdq_smooth_lin::BS - 1) / mdq_smooth_lin::BS + 2;     // two blocks of padding (prefetch)
-  return (int64_t)B * blocks * mdq_smooth_lin::MBLK * 8 + (int64_t)B * 16 + 256;   // block inverses, [B] redo, [B][3] diagnostics
+  const int64_t blocks = mdq_smooth_lin::mblocks(NV) + mdq_smooth_lin::vblocks(NV);   // (both with padding for the prefetch)
+  return (int64_t)B * blocks * mdq_smooth_lin::MBLK * 8 + (int64_t)B * 16 + 256;   // block inverses + pair couplings, [B] redo, [B][3] diagnostics
 }
 
 static int smooth_fast_impl(const char* who, int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t* cells,
@@ -745,7 +924,7 @@ static int smooth_fast_impl(const char* who, int32_t B, int32_t NV, int32_t NT, 
   if (workspace_bytes < mdq_smooth_fast_workspace_bytes(B, NV) || (reinterpret_cast<uintptr_t>(workspace) & 15))
     return mdq_set_error("mdq_smooth_fast: workspace too small or not 16-byte aligned (mdq_smooth_fast_workspace_bytes)");
   (void)who;
-  const int64_t blocks = (NV + mdq_smooth_lin::BS - 1) / mdq_smooth_lin::BS + 2;
+  const int64_t blocks = mdq_smooth_lin::mblocks(NV) + mdq_smooth_lin::vblocks(NV);
   const int64_t mstride = blocks * mdq_smooth_lin::MBLK;
   double* mws = reinterpret_cast<double*>(workspace);
   int32_t* redo = reinterpret_cast<int32_t*>(mws + (int64_t)B * mstride);

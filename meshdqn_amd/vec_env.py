@@ -897,6 +897,11 @@ class VecEnv2DAirfoil:
         if not self.auto_reset:                        # nothing is restored: the rows stay as hand-over sources only
             for t in range(n):
                 d.src[t] = None
+        else:
+            # the interpolated snapshots (rows 0 / 1: 0.3 MB per environment) are NOT restored here: every step of a rollout
+            # interpolates them again on the current meshes before anything reads them, and the state of a reset environment
+            # comes from the cached features (x_init); they stay hand-over sources (the warm start of the flow leg)
+            d.src[0] = d.src[1] = None
         d.new_drags = self._dev_drag.data_ptr()
         d.code_in, d.code_out = ro["code_act"].data_ptr(), ro["code"][k].data_ptr()
         d.steps_in, d.steps_out = ro["d_steps"][ro["si"]].data_ptr(), ro["d_steps"][ro["si"] ^ 1].data_ptr()
