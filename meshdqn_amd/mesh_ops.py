@@ -354,7 +354,8 @@ def smooth_fast_stats(device, B: int, NV: int, stream=None) -> np.ndarray:
                          int(_lib.stream_ptr(stream).value or 0), B, NV))
     if ws is None:
         raise KeyError("no mdq_smooth_fast workspace for these sizes on this stream")
-    off = B * ((NV + 31) // 32 + 2) * 1024 * 8            # behind the block inverses (mdq_smooth_fast_workspace_bytes)
+    # (the diagnostics are the tail of the workspace: block inverses + pair couplings, then [B] redo + [B][3] + 256 spare bytes)
+    off = int(_lib.load().mdq_smooth_fast_workspace_bytes(B, NV)) - 16 * B - 256
     raw = ws[off:off + 16 * B].view(torch.int32).cpu().numpy()
     out = np.concatenate([raw[:B, None], raw[B:4 * B].reshape(B, 3)], axis=1)
     return out          # (column 3: pipelined sweeps redone checked | sweeps taken in plain index order << 16)

@@ -34,13 +34,7 @@ for step in range(K):
     run(1)
     torch.cuda.synchronize()
     ms = [a.elapsed_time(b) for a, b in env.smooth_events]
-    st = None
-    for key in list(__import__("meshdqn_amd.mesh_ops", fromlist=["_SMOOTH_WS"])._SMOOTH_WS):
-        if key[2] == B:
-            ws = __import__("meshdqn_amd.mesh_ops", fromlist=["_SMOOTH_WS"])._SMOOTH_WS[key]
-            off = B * ((key[3] + 31) // 32 + 2) * 1024 * 8
-            raw = ws[off:off + 16 * B].view(torch.int32).cpu().numpy()
-            st = np.concatenate([raw[:B, None], raw[B:4 * B].reshape(B, 3)], axis=1)
+    st = smooth_fast_stats(env.device, B, env.NV, grp.streams[0])
     rows.append((ms[0] if ms else float("nan"), st))
 env.smooth_events = None
 print("launch ms | max/mean repaired sweeps | max/mean repair rounds | max/mean sent back | handed back")
