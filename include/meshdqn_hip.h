@@ -64,7 +64,9 @@ typedef struct mdq_ipcs_desc {
                            1 assembled SELL (LDS gather vectors), 2 matrix-free LDS element tiles (bitwise
                            reproducible), 3 matrix-free with LDS fp64 atomics (fastest; round-off reproducible),
                            4 assembled SELL with TWO workgroups per environment (any mesh size, rows / cells / slices
-                           dealt out over the team, agent-scope team barriers; auto picks it over 0 when 4 B <= CUs) */
+                           dealt out over the team, agent-scope team barriers; auto picks it over 0 when 4 B <= CUs),
+                           5 matrix-free element tiles with the vectors in GLOBAL memory (any mesh size: what auto takes for
+                           meshes beyond the LDS-resident vectors of 2 / 3 when mf_scat / mf_tptr are given; bitwise reproducible) */
   /* per-environment counts, device int32[B] */
   const int32_t* nv;
   const int32_t* nt;

@@ -42,14 +42,21 @@ constexpr int MF_CH = 1024;  // triangles per LDS tile: 2 per thread, interleave
 
 __host__ __device__ inline int64_t work_per_env(int NV, int NT, int NE) {
   const int64_t N2 = (int64_t)NV + NE;
-  // escr 12*NT | 6 velocity vectors (double2[N2]) | p_new[NV] | 24 spare | assembled modes: 5 history vectors + counter
-  const int64_t n = 12 * (int64_t)NT + 12 * N2 + NV + 26 + 10 * N2 + 2;
+  // escr 12*NT | 6 velocity vectors (double2[N2]) | p_new[NV] | 24 spare | assembled modes: 5 history vectors + counter |
+  // mode 5: the accumulation vector of the tile application (double2[N2])
+  const int64_t n = 12 * (int64_t)NT + 12 * N2 + NV + 26 + 10 * N2 + 2 + 2 * N2 + 2;
   return (n + 31) & ~(int64_t)31;  // keep every environment's slab 256-byte aligned
 }
 // offset (in doubles, even) of the tentative-velocity history of the assembled modes 0-2 inside an environment's slab
 __host__ __device__ inline int64_t work_hist_offset(int NV, int NT, int NE) {
   const int64_t N2 = (int64_t)NV + NE;
   return (12 * (int64_t)NT + 12 * N2 + NV + 24 + 1) & ~(int64_t)1;
+}
+
+// offset (in doubles, even) of mode 5's accumulation vector (behind the history vectors and their counter)
+__host__ __device__ inline int64_t work_ytmp_offset(int NV, int NT, int NE) {
+  const int64_t N2 = (int64_t)NV + NE;
+  return (work_hist_offset(NV, NT, NE) + 10 * N2 + 2 + 1) & ~(int64_t)1;
 }
 
 struct EnvView {
@@ -950,6 +957,60 @@ __device__ __forceinline__ void tile_accumulate(const EnvView& v, double2* es, T
   }
 }
 
+// MODE 5: the same element tiles for meshes whose vectors do not fit the LDS (ys930 red-refined: 12.9 k velocity dofs,
+// 207 KB per vector): the operator input is gathered from GLOBAL memory (L2), the element results of a chunk go through the
+// LDS tile, and the row owners (rows tid, tid + WG, ... as in every vector pass) add their tile entries - in fixed order -
+// to an accumulation vector in the environment's workspace slab; after the last chunk every row hands its sum to `epi`.
+// Per application and triangle: 6 dof ids + 6 tile positions + 5 geometry doubles + the outflow tag (89 B) instead of the
+// 36 B per SELL entry of the assembled operator (~2 KB per triangle), and no sparsity pattern: like mode 2 it needs only
+// what mdq_ipcs_setup_matfree derives on the device.  Bitwise reproducible.  mf_scat: packed words (N2 <= 4096) or plain
+// tile positions (larger meshes, MeshTopology.matfree_maps).
+template <class ElemOp, class Epi>
+__device__ __forceinline__ void tile_apply_global(const EnvView& v, bool packed, double2* es, double2* ytmp, ElemOp op, Epi epi) {
+  const int tid = threadIdx.x, n = v.n2;
+  const int nch = (v.nt + MF_CH - 1) / MF_CH;
+  for (int chunk = 0; chunk < nch; ++chunk) {
+#pragma unroll
+    for (int j = 0; j < MF_EPT; ++j) {
+      const int e = chunk * MF_CH + tid + j * WG;
+      if (e < v.nt) {
+        ElemIdx E;
+        int pos[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const int w = v.mf_scat[i * v.NT + e];
+          pos[i] = packed ? (w >> 12) & 0x1FFF : w;
+          E.dof[i] = v.cell_dofs[i * v.NT + e];
+        }
+        const Geo g = load_geo(v, e);
+        double2 ye[6];
+        op(e, g, E, (int)v.cell_outflow[e], ye);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) es[pos[i]] = ye[i];
+      }
+    }
+    __syncthreads();
+    const int32_t* tp = v.mf_tptr + chunk * v.mf_tstride;
+    for (int row = tid; row < n; row += WG) {
+      const int lo = tp[row], hi = tp[row + 1];
+      if (chunk == 0 || hi > lo) {
+        double2 a = chunk == 0 ? make_double2(0.0, 0.0) : ytmp[row];
+        for (int j = lo; j < hi; ++j) {
+          const double2 c = es[j];
+          a.x += c.x;
+          a.y += c.y;
+        }
+        ytmp[row] = a;
+      }
+    }
+    __syncthreads();
+  }
+  for (int row = tid; row < n; row += WG) {
+    const double2 a = ytmp[row];
+    epi(row, a.x, a.y);
+  }
+}
+
 // ================================================================== sparse kernels (workgroup-wide)
 //
 // SELL-64, one thread per row: wave w owns slices w, w+NWAVE, ... (rows tid, tid+WG, ...), the
@@ -1037,15 +1098,37 @@ struct VelCtx {
   double2* t;    // A s (own rows)
   double2* gp;   // where SpMV #1 gathers p from   (MODE 2: the LDS stage buffer)
   double2* gr;   // where SpMV #2 gathers s from   (MODE 2: the same LDS stage buffer)
-  double2* es;   // MODE 2: LDS element tile
+  double2* es;   // MODE 2 / 5: LDS element tile
+  double2* yt;   // MODE 5: accumulation vector (global, own rows)
+  bool packed;   // MODE 5: mf_scat holds packed words
   double a, mu;
 };
 
 // y = (D^-1 A1_bc) x on vectors that vanish on constrained dofs (see bicgstab_velocity)
+__device__ __forceinline__ void velocity_op(const EnvView& v, double a, double mu, int e, int ko, const Geo& g,
+                                            const double2 (&xe)[6], double2 (&ye)[6]);
+
 template <int MODE, class Epi>
 __device__ __forceinline__ void apply_velocity(const EnvView& v, const VelCtx& c, const double2* gx, Epi epi) {
-  static_assert(MODE != 2, "the matrix-free mode has its own kernel (evolve_mf_kernel)");
-  spmv_sell_b2(v.sl2_off, v.sl2_col, v.A1, gx, v.n2, epi);
+  static_assert(MODE != 2, "the LDS-resident matrix-free mode has its own kernel (evolve_mf_kernel)");
+  if constexpr (MODE == 5) {
+    // full element operator on the gathered vector, rows scaled by D^-1 (0 on constrained rows) on the way out
+    tile_apply_global(
+        v, c.packed, c.es, c.yt,
+        [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
+          double2 xe[6];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) xe[i] = gx[E.dof[i]];
+          velocity_op(v, c.a, c.mu, e, ko, g, xe, ye);
+        },
+        [&](int row, double y0, double y1) {
+          const bool fl = v.bcu_flag[row] != 0;
+          const double2 id = v.idiag1[row];
+          epi(row, fl ? 0.0 : y0 * id.x, fl ? 0.0 : y1 * id.y);
+        });
+  } else {
+    spmv_sell_b2(v.sl2_off, v.sl2_col, v.A1, gx, v.n2, epi);
+  }
 }
 
 // BiCGStab on the row-scaled velocity system  (D^-1 A1_bc) x = D^-1 b.
@@ -1069,7 +1152,7 @@ __device__ inline int bicgstab_velocity(const EnvView& v, const VelCtx& c, doubl
       const double2 ri = c.r[i], pi = c.p[i], vi = c.vv[i];
       const double2 pn = make_double2(ri.x + beta * (pi.x - omega * vi.x), ri.y + beta * (pi.y - omega * vi.y));
       c.p[i] = pn;
-      if (MODE == 2) c.gp[i] = pn;
+      if (MODE == 2) c.gp[i] = pn;     // (mode 5: gp IS p)
     }
     __syncthreads();
     double a1[1] = {0.0};
@@ -1133,14 +1216,32 @@ struct MassCtx {
   double2* p;   // search direction (own rows)
   double2* q;   // M p (own rows)
   double2* gp;  // where the SpMV gathers p from
-  double2* es;  // MODE 2: LDS element tile
+  double2* es;  // MODE 2 / 5: LDS element tile
+  double2* yt;  // MODE 5: accumulation vector (global, own rows)
+  bool packed;
 };
 
 // y = (S^-1 M_bc S^-1) x on vectors that vanish on constrained dofs
 template <int MODE, class Epi>
 __device__ __forceinline__ void apply_mass(const EnvView& v, const MassCtx& c, const double2* gx, Epi epi) {
-  static_assert(MODE != 2, "the matrix-free mode has its own kernel (evolve_mf_kernel)");
-  spmv_sell_2rhs(v.sl2_off, v.sl2_col, v.Ms, gx, v.n2, epi);
+  static_assert(MODE != 2, "the LDS-resident matrix-free mode has its own kernel (evolve_mf_kernel)");
+  if constexpr (MODE == 5) {
+    // gx holds S^-1 p (staged by the caller); rows scaled by S^-1 (0 on constrained rows) on the way out
+    tile_apply_global(
+        v, c.packed, c.es, c.yt,
+        [&](int, const Geo& g, const ElemIdx& E, int, double2(&ye)[6]) {
+          double2 xe[6];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) xe[i] = gx[E.dof[i]];
+          elem_mass(g, xe, ye);
+        },
+        [&](int row, double y0, double y1) {
+          const double is = v.bcu_flag[row] ? 0.0 : 1.0 / v.sdiagM[row];
+          epi(row, y0 * is, y1 * is);
+        });
+  } else {
+    spmv_sell_2rhs(v.sl2_off, v.sl2_col, v.Ms, gx, v.n2, epi);
+  }
 }
 
 // CG on the symmetrically scaled mass system, both velocity components at once.
@@ -1181,7 +1282,7 @@ __device__ inline int cg_mass(const EnvView& v, const MassCtx& c, double rtol, i
       const double2 ri = c.r[i], pi = c.p[i];
       const double2 pn = make_double2(ri.x + beta * pi.x, ri.y + beta * pi.y);
       c.p[i] = pn;
-      if (MODE == 2) {
+      if (MODE == 2 || MODE == 5) {
         const double is = 1.0 / v.sdiagM[i];
         c.gp[i] = make_double2(pn.x * is, pn.y * is);
       }
@@ -2149,7 +2250,13 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
   vc.t = vt;
   vc.a = d.rho / d.dt;
   vc.mu = d.mu;
-  vc.es = L1;
+  // MF: the element-tile operators (mode 5; the MODE == 2 branches of this kernel are the same formulas with an LDS stage)
+  constexpr bool MF = MODE == 2 || MODE == 5;
+  double2* ytmp = reinterpret_cast<double2*>(w + work_ytmp_offset(d.NV, d.NT, d.NE));   // mode 5: accumulation vector
+  double2* stage = MODE == 5 ? vh : L0;   // where the mass solve stages S^-1 p for the gathers (mode 5: vh is free there)
+  vc.es = MODE == 5 ? L0 : L1;
+  vc.yt = ytmp;
+  vc.packed = d.N2 <= 4096;
   if (MODE == 1) {
     vc.p = vc.gp = L0;
     vc.r = vc.gr = L1;
@@ -2157,7 +2264,7 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
     vc.p = vp;
     vc.r = vr;
     vc.gp = vc.gr = L0;
-  } else {
+  } else {                       // modes 0 / 5: the gathers read the Krylov vectors themselves (global memory)
     vc.p = vc.gp = vp;
     vc.r = vc.gr = vr;
   }
@@ -2165,10 +2272,12 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
   mc.x = xs;
   mc.r = vr;
   mc.q = vv;
-  mc.es = L1;
-  if (MODE == 2) {
+  mc.es = MODE == 5 ? L0 : L1;
+  mc.yt = ytmp;
+  mc.packed = d.N2 <= 4096;
+  if (MF) {
     mc.p = vp;
-    mc.gp = L0;
+    mc.gp = stage;
   } else {
     mc.p = mc.gp = (MODE == 1) ? L0 : vp;
   }
@@ -2227,8 +2336,8 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
       }
       if (fl) x0 = g;
       xs[i] = x0;
-      if (MODE == 2) {
-        L0[i] = x0;
+      if (MF) {
+        if (MODE == 2) L0[i] = x0;
         vc.r[i] = fl ? make_double2(0.0, 0.0) : make_double2(f.x * id.x, f.y * id.y);
       } else {
         vc.r[i] = bi;
@@ -2236,7 +2345,7 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
       acc[0] += bi.x * bi.x + bi.y * bi.y;
     }
     __syncthreads();
-    apply_velocity<MODE>(v, vc, MODE == 2 ? L0 : xs, [&](int row, double y0, double y1) {
+    apply_velocity<MODE>(v, vc, MODE == 2 ? L0 : xs, [&](int row, double y0, double y1) {   // (mode 5 gathers x0 from xs)
       const double2 bi = vc.r[row];
       const double2 r0 = make_double2(bi.x - y0, bi.y - y1);
       vc.r[row] = r0;
@@ -2306,8 +2415,8 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
       const double2 bi = fl ? g : make_double2((f.x - l.x) / sd, (f.y - l.y) / sd);
       const double2 x0 = fl ? g : xs[i];
       xs[i] = make_double2(x0.x * sd, x0.y * sd);  // scaled unknown S x
-      if (MODE == 2) {
-        L0[i] = x0;  // S^-1 (S x0)
+      if (MF) {
+        stage[i] = x0;  // S^-1 (S x0)
         mc.r[i] = fl ? make_double2(0.0, 0.0) : make_double2(f.x / sd, f.y / sd);
       } else {
         mc.r[i] = bi;
@@ -2315,7 +2424,7 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
       am[0] += bi.x * bi.x + bi.y * bi.y;
     }
     __syncthreads();
-    apply_mass<MODE>(v, mc, MODE == 2 ? L0 : xs, [&](int row, double y0, double y1) {
+    apply_mass<MODE>(v, mc, MF ? stage : xs, [&](int row, double y0, double y1) {
       const double2 bi = mc.r[row];
       const double2 r0 = make_double2(bi.x - y0, bi.y - y1);
       mc.r[row] = r0;
@@ -2323,12 +2432,12 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
       am[1] += r0.x * r0.x + r0.y * r0.y;
     });
     block_sum<2>(am, red);
-    if (MODE == 2) {
+    if (MF) {
       // stage S^-1 p0 (own rows; the apply above is complete: block_sum barriers passed)
       for (int i = tid; i < n2; i += WG) {
         const double is = 1.0 / v.sdiagM[i];
         const double2 p0 = mc.p[i];
-        L0[i] = make_double2(p0.x * is, p0.y * is);
+        stage[i] = make_double2(p0.x * is, p0.y * is);
       }
       __syncthreads();
     }
@@ -4436,12 +4545,16 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
   if (red_bytes + P.prs_vec_bytes > LDS_MAX) return fail_msg("mesh too large for the LDS-resident pressure vectors");
   const bool k1_lds = !d->pd_enabled && red_bytes + P.prs_vec_bytes + P.prs_mat_bytes <= LDS_MAX;
   int mode = d->mode;
-  if (mode < 0 || mode > 4) {  // auto: fastest variant that fits
+  const size_t tile_bytes = sizeof(double2) * 6 * MF_CH;      // mode 5: the element tile
+  if (mode < 0 || mode > 5) {  // auto: fastest variant that fits
     mode = 0;
     if (red_bytes + P.vel1_bytes <= LDS_MAX) mode = 1;
     if (red_bytes + P.vel2_bytes <= LDS_MAX && d->N2 <= MF_ROWS * WG) mode = 2;
     // (mode -2 = auto among the BITWISE REPRODUCIBLE variants: everything but the LDS-atomic mode 3)
     if (d->mode != -2 && red_bytes + P.vel3_bytes <= LDS_MAX && d->N2 <= MF_ROWS * WG) mode = 3;
+    // a mesh beyond the LDS-resident vectors: the element tiles with global vectors (mode 5: ~5x less memory traffic than
+    // the assembled operators and no sparsity pattern), when the tile maps were handed over
+    if (mode == 0 && d->mf_scat && d->mf_tptr && d->cell_outflow && std::getenv("MDQ_NO_MODE5") == nullptr) mode = 5;
     if (mode == 0) {
       // a mesh that only fits the assembled global-memory path: two workgroups per environment while the batch leaves
       // at least half of the chip idle even so (measured on ys930 red-refined, ms per step one / two workgroups: B = 1
@@ -4463,8 +4576,9 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
   if (mode == 2 && (red_bytes + P.vel2_bytes > LDS_MAX || d->N2 > MF_ROWS * WG))
     return fail_msg("matrix-free tile mode needs N2 <= 3584 and the x stage + element tile in LDS");
   if (mode == 1 && red_bytes + P.vel1_bytes > LDS_MAX) return fail_msg("LDS gather vectors do not fit");
+  if (mode == 5 && (!d->mf_scat || !d->mf_tptr || !d->cell_outflow)) return fail_msg("mode 5 needs the tile maps (mf_scat, mf_tptr) and cell_outflow");
   size_t u = P.prs_vec_bytes + (k1_lds ? P.prs_mat_bytes : 0);  // (K1 values alias the scratch vector: CG does not use it)
-  const size_t vel = mode == 3 ? P.vel3_bytes : (mode == 2 ? P.vel2_bytes : (mode == 1 ? P.vel1_bytes : 0));
+  const size_t vel = mode == 3 ? P.vel3_bytes : (mode == 2 ? P.vel2_bytes : (mode == 1 ? P.vel1_bytes : (mode == 5 ? tile_bytes : 0)));
   if (vel > u) u = vel;
   const size_t lds = red_bytes + u;
   hipError_t e;
@@ -4545,6 +4659,9 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
   else if (mode == 4)
     e = k1_lds ? launch_evolve_team<true>(d, lds, nsteps, drag, lift, iters, st)
                : launch_evolve_team<false>(d, lds, nsteps, drag, lift, iters, st);
+  else if (mode == 5)
+    e = k1_lds ? launch_evolve<5, true>(d, lds, nsteps, drag, lift, iters, st)
+               : launch_evolve<5, false>(d, lds, nsteps, drag, lift, iters, st);
   else
     e = k1_lds ? launch_evolve<0, true>(d, lds, nsteps, drag, lift, iters, st)
                : launch_evolve<0, false>(d, lds, nsteps, drag, lift, iters, st);

@@ -800,8 +800,10 @@ static int smooth_fast_impl(const char* who, int32_t B, int32_t NV, int32_t NT, 
   // 2. environments handed back (meshes beyond the kernel's limits: more than 16 cells at a vertex, 14 gather slots per
   //    row, 8 lower neighbours inside a block): the per-vertex walk, ONE workgroup over the - normally zero - environments
   //    with sweeps left (128 workgroups of 141 KB LDS each would wait for the other streams' kernels to leave the CUs)
-  hipLaunchKernelGGL(mdq_smoothing::smooth_kernel, dim3(1), dim3(mdq_smoothing::SWG), 0, st, B, NV, NT, coords, cells, nv, nt,
-                     redo, 0, trace);
+  //    (four workgroups since round 4: a mesh family that hits the limits often would otherwise be walked one mesh after
+  //    the other by a single workgroup; they return at once when nothing was handed back)
+  hipLaunchKernelGGL(mdq_smoothing::smooth_kernel, dim3(B < 4 ? B : 4), dim3(mdq_smoothing::SWG), 0, st, B, NV, NT, coords, cells,
+                     nv, nt, redo, 0, trace);
   if (hipGetLastError() != hipSuccess) return mdq_set_error("mdq_smooth_fast: launch failed");
   return 0;
 }

@@ -112,6 +112,12 @@ class IpcsBatch:
         h["sl1_off"] = stack("sl1_off", (NV // 64 + 2,), np.int32)
         h["sl1_col"] = stack("sl1_col", (NSE1,), np.int32)
         NCH = (NT + 1023) // 1024
+        if N2 > 4096:
+            # capacity beyond the packed words (dof ids of 12 bits): the kernels read plain tile positions for EVERY mesh of
+            # the batch (mode 5: element tiles with global vectors), also for the ones that would fit the packed form
+            for t_, p_ in zip(self.topos, per):
+                if t_.np2 <= 4096:
+                    p_["mf_scat"], p_["mf_tptr"] = t_.matfree_maps(1024)
         h["mf_scat"] = stack("mf_scat", (6, NT), np.int32)
         h["mf_tptr"] = stack("mf_tptr", (NCH, N2 + 1), np.int32)
         h["nbo"] = np.array([p["bo_rows"].size for p in per], np.int32)

@@ -352,6 +352,10 @@ def smooth_fast_stats(device, B: int, NV: int, stream=None) -> np.ndarray:
     rounds (vertices with limited steps), repair rounds in total, pipelined sweeps whose validation failed]."""
     ws = _SMOOTH_WS.get((torch.device(device) if not isinstance(device, torch.device) else device,
                          int(_lib.stream_ptr(stream).value or 0), B, NV))
+    if ws is None and stream is None:       # (no stream given: the workspace of these sizes on whatever stream used it last)
+        for key, val in _SMOOTH_WS.items():
+            if key[2] == B and key[3] == NV:
+                ws = val
     if ws is None:
         raise KeyError("no mdq_smooth_fast workspace for these sizes on this stream")
     # (the diagnostics are the tail of the workspace: block inverses + pair couplings, then [B] redo + [B][3] + 256 spare bytes)

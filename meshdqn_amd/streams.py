@@ -204,22 +204,28 @@ def roles_own_queues(device) -> bool:
     """True when the roles of `device` are CU-mask streams (a hardware queue each) and every pair passed its probe: there
     is nothing left for a calibration by timing to decide, and creating more such streams only uses up hardware queues
     (a process that had created ~25 of them ran its last measurements at half speed: the queues were time-sliced)."""
-    idx = torch.device(device).index
-    idx = torch.cuda.current_device() if idx is None else idx
+    idx = device_index(device)
     for e in LOG:
         if e.get("event") == "roles created in fixed order" and e.get("device") == idx:
             return e.get("cu_partition") is not None and all(v == "probe ok" for v in e.get("probes", {}).values())
     return False
 
 
+def device_index(device) -> int:
+    """The one normalisation of a device to its index for every per-device dictionary of this package ('cuda' without an
+    index = the current device; round 3 keyed some tables on `torch.device(device).index`, which is None there)."""
+    idx = torch.device(device).index
+    return torch.cuda.current_device() if idx is None else int(idx)
+
+
 def calibrated_flow_stream(device, main):
     """The flow stream `calibrate_streams` chose for rollouts on `main` in this process (None: not calibrated yet)."""
     for (idx, m), st in _CALIBRATED.items():
-        if idx == torch.device(device).index and m == main:
+        if idx == device_index(device) and m == main:
             return st
     return None
 
 
 def remember_flow_stream(device, main, flow, ms, how):
-    _CALIBRATED[(torch.device(device).index, main)] = flow
-    LOG.append(dict(device=torch.device(device).index, event="flow stream calibrated", how=how, ms_per_step=[round(v, 3) for v in ms]))
+    _CALIBRATED[(device_index(device), main)] = flow
+    LOG.append(dict(device=device_index(device), event="flow stream calibrated", how=how, ms_per_step=[round(v, 3) for v in ms]))

@@ -623,7 +623,8 @@ class DQNTrainer:
         if _st.roles_own_queues(dev):
             roles = _st.role_streams(dev)
             flow_now = getattr(venv, "_flow_stream", None)
-            if getattr(self, "_opt_stream", None) is roles["opt"] and (flow_now is None or flow_now is roles["flow"]):
+            if (getattr(self, "_opt_stream", None) is roles["opt"] and (flow_now is None or flow_now is roles["flow"]) and
+                    (main is roles["main"] or main == roles["main"] or _st._overlaps(roles["opt"], main, dev))):
                 # CU-mask role streams with every probe passed: a hardware queue each, nothing to choose between
                 self._opt_calibrated_for = (main, flow_now)
                 self.opt_calibration_ms = []
@@ -771,8 +772,10 @@ class DQNTrainer:
             # optimiser / scheduler state dicts + numpy arrays of the loops (`extra`): the safe unpickler with numpy's array
             # reconstruction allow-listed - a checkpoint directory is not a code-execution vector
             _ma = (getattr(np, "_core", None) or np.core).multiarray      # (numpy >= 2: numpy._core)
-            safe = [np.ndarray, np.dtype, type(np.dtype(np.int64)), type(np.dtype(np.float64)), type(np.dtype(np.float32)),
-                    type(np.dtype(np.int32)), type(np.dtype(np.bool_))]
+            # (every fixed-size numeric dtype class: `extra` is whatever the loop hands over - an RNG state is uint32 / uint64)
+            safe = [np.ndarray, np.dtype] + sorted({type(np.dtype(t)) for t in (
+                np.bool_, np.int8, np.int16, np.int32, np.int64, np.uint8, np.uint16, np.uint32, np.uint64, np.float16,
+                np.float32, np.float64, np.complex64, np.complex128)}, key=lambda c: c.__name__)
             for name in ("_reconstruct", "scalar"):
                 fn = getattr(_ma, name, None)
                 if fn is not None:

@@ -753,8 +753,11 @@ class VecEnv2DAirfoil:
             self._calibrated_for = cur
             self.calibration_ms = []
             return []
-        if _st.roles_own_queues(dev) and self._flow_stream is _st.role_streams(dev)["flow"]:
-            # CU-mask role streams with every probe passed: a hardware queue each, nothing to choose between
+        if (_st.roles_own_queues(dev) and self._flow_stream is _st.role_streams(dev)["flow"] and
+                (cur is _st.role_streams(dev)["main"] or cur == _st.role_streams(dev)["main"] or _st._overlaps(self._flow_stream, cur, dev))):
+            # CU-mask role streams with every probe passed: a hardware queue each, nothing to choose between.  (The probes of
+            # `role_streams` compare the roles with the MAIN role: a caller on another stream - the bench's env groups - is
+            # probed here, once, before the shortcut is taken)
             self._calibrated_for = cur
             self.calibration_ms = []
             _st.remember_flow_stream(dev, cur, self._flow_stream, [], "role streams own their hardware queues: no calibration")
@@ -961,6 +964,16 @@ class VecEnv2DAirfoil:
         if last_done is not None and last_done.any():      # (restarted environments: the cached initial forces, like step())
             self.new_drags[last_done] = self._init_cache["drags"]
             self.new_lifts[last_done] = self._init_cache["lifts"]
+            # ... and their interpolated snapshots: `mdq_env_finish` leaves them alone inside a rollout (every step
+            # interpolates again before anything reads them); whoever reads the state after the LAST step - get_state(), a
+            # host-driven step() - must find the initial fields in the rows of the environments that step reset
+            c = self._init_cache
+            ti = torch.from_numpy(np.flatnonzero(last_done).astype(np.int32)).to(self.device)
+            dst = (C.c_void_p * 2)(self.u.data_ptr(), self.p.data_ptr())
+            src = (C.c_void_p * 2)(c["u"].data_ptr(), c["p"].data_ptr())
+            nb = (C.c_int64 * 2)(self.u[0].numel() * 8, self.p[0].numel() * 8)
+            _lib.check(self.lib.mdq_restore_rows(2, dst, src, nb, int(ti.numel()), ti.data_ptr(), _lib.stream_ptr()),
+                       "mdq_restore_rows")
         self._deferred_mirror = None
 
 

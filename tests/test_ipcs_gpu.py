@@ -178,10 +178,12 @@ def test_flow_solver_surface_matches_oracle(lib_built, tmp_path):
 
 
 @pytest.mark.slow
-def test_refined_mesh_c5_assembled_path(meshes, lib_built):
+@pytest.mark.parametrize("mode", [-1, 0, 5, -2])
+def test_refined_mesh_c5_paths(meshes, lib_built, mode):
     """BASELINE config 5: ys930 red-refined once (3322 vertices / 6280 triangles, 25 848 velocity dofs).
-    Too large for the LDS-resident matrix-free modes -> assembled SELL operators (mode 0) + direct pressure
-    solve; parity against the oracle for the first steps."""
+    Too large for the LDS-resident matrix-free modes -> the element tiles with GLOBAL vectors (mode 5: what auto and the
+    reproducible auto take since round 4) or the assembled SELL operators (mode 0); parity against the oracle for the first
+    steps, and a mixed batch (a refined mesh beside the lab mesh: the small one rides along in the big one's layout)."""
     import torch
     from meshdqn_amd.ipcs_batch import IpcsBatch, smooth_coords
     from meshdqn_amd.mesh_ops import red_refine
@@ -189,21 +191,32 @@ def test_refined_mesh_c5_assembled_path(meshes, lib_built):
     from oracle.ipcs import OracleFlowSolver
     coords, cells = meshes["ys930"]
     t0 = MeshTopology(coords, cells)
-    rc, rcells = red_refine(smooth_coords(t0, 50), cells)
+    x0 = smooth_coords(t0, 50)
+    rc, rcells = red_refine(x0, cells)
     topo = MeshTopology(rc, rcells)
     assert (topo.nv, topo.nt, topo.ne) == (3322, 6280, 9602)
-    batch = IpcsBatch([topo, topo], [rc, rc], rtol=1e-12)   # auto mode
+    batch = IpcsBatch([topo, t0, topo], [rc, x0, rc], rtol=1e-12, mode=mode)
     ora = OracleFlowSolver(rc, rcells, smooth=False)
+    ora0 = OracleFlowSolver(coords, cells)
     for step in range(2):
         drag, lift = batch.evolve(1)
         uo, po, do, lo = ora.evolve()
+        uo0, po0, do0, lo0 = ora0.evolve()
     torch.cuda.synchronize()
     n2, nv = ora.th.np2, ora.th.nv
-    u = batch.u_n[1, :n2].cpu().numpy()
+    u = batch.u_n[2, :n2].cpu().numpy()
     ug = np.concatenate([u[:, 0], u[:, 1]])
     assert np.abs(ug - uo).max() / np.abs(uo).max() < 1e-8
-    assert np.abs(batch.p_n[1, :nv].cpu().numpy() - po).max() / np.abs(po).max() < 1e-8
-    assert abs(drag[0, 0].item() - do) / abs(do) < 1e-8 and abs(lift[1, 0].item() - lo) / abs(lo) < 1e-8
+    assert np.abs(batch.p_n[2, :nv].cpu().numpy() - po).max() / np.abs(po).max() < 1e-8
+    assert abs(drag[0, 0].item() - do) / abs(do) < 1e-8 and abs(lift[2, 0].item() - lo) / abs(lo) < 1e-8
+    u0 = batch.u_n[1, :ora0.th.np2].cpu().numpy()
+    assert np.abs(np.concatenate([u0[:, 0], u0[:, 1]]) - uo0).max() / np.abs(uo0).max() < 1e-8
+    assert abs(drag[1, 0].item() - do0) / abs(do0) < 1e-8
+    if mode in (5, -2):            # bitwise reproducible: a second batch gives the same bits
+        b2 = IpcsBatch([topo, t0, topo], [rc, x0, rc], rtol=1e-12, mode=mode)
+        for step in range(2):
+            d2, l2 = b2.evolve(1)
+        assert torch.equal(d2, drag) and torch.equal(l2, lift) and torch.equal(b2.u_n, batch.u_n)
 
 
 def test_setup_matfree_matches_assemble(meshes, lib_built):

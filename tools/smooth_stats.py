@@ -34,7 +34,7 @@ for step in range(K):
     run(1)
     torch.cuda.synchronize()
     ms = [a.elapsed_time(b) for a, b in env.smooth_events]
-    st = smooth_fast_stats(env.device, B, env.NV, grp.streams[0])
+    st = smooth_fast_stats(env.device, B, env.NV)
     rows.append((ms[0] if ms else float("nan"), st))
 env.smooth_events = None
 print("launch ms | max/mean repaired sweeps | max/mean repair rounds | max/mean sent back | handed back")
