@@ -151,6 +151,12 @@ typedef struct mdq_ipcs_desc {
   /* workspace, device: at least mdq_ipcs_workspace_doubles() doubles */
   double* work;
   int64_t work_doubles;
+  /* mode 5 (optional; NULL: the row owners walk mf_tptr): per chunk the rows its 1024 triangles touch, ascending - entry =
+     (row, first tile position | number of tile entries << 16) - so that a row phase visits ~2 500 touched rows instead of
+     all N2 (12 924 on the refined ys930) */
+  const int32_t* mf_rlist;     /* [B][NCH][NRL][2] */
+  const int32_t* mf_rcnt;      /* [B][NCH] touched rows of the chunk */
+  int32_t NRL, _pad_rl;
 } mdq_ipcs_desc;
 
 /* doubles of workspace needed for a descriptor with the given capacities */

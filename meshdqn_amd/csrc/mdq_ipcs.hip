@@ -70,6 +70,8 @@ struct EnvView {
   const int32_t *sl2_off, *sl2_col, *sl1_off, *sl1_col;
   const int32_t *mf_scat, *mf_tptr;
   int mf_tstride;  // N2+1
+  const int32_t *mf_rlist, *mf_rcnt;   // mode 5: touched rows per chunk (or null)
+  int NRL;
   const int32_t *g2_ptr, *g2_src, *g1_ptr, *g1_src;
   const uint8_t* bcu_flag;
   const double* bcu_gx;
@@ -122,6 +124,9 @@ __device__ __forceinline__ EnvView env_view(const mdq_ipcs_desc& d, int b) {
   v.mf_scat = d.mf_scat + B * 6 * d.NT;
   v.mf_tstride = d.N2 + 1;
   v.mf_tptr = d.mf_tptr + B * ((d.NT + MF_CH - 1) / MF_CH) * (d.N2 + 1);
+  v.NRL = d.NRL;
+  v.mf_rlist = (d.mf_rlist && d.mf_rcnt && d.NRL > 0) ? d.mf_rlist + B * ((d.NT + MF_CH - 1) / MF_CH) * d.NRL * 2 : nullptr;
+  v.mf_rcnt = v.mf_rlist ? d.mf_rcnt + B * ((d.NT + MF_CH - 1) / MF_CH) : nullptr;
   v.g2_ptr = d.g2_ptr + B * (d.N2 + 1);
   v.g2_src = d.g2_src + B * 6 * d.NT;
   v.g1_ptr = d.g1_ptr + B * (d.NV + 1);
@@ -965,10 +970,28 @@ __device__ __forceinline__ void tile_accumulate(const EnvView& v, double2* es, T
 // 36 B per SELL entry of the assembled operator (~2 KB per triangle), and no sparsity pattern: like mode 2 it needs only
 // what mdq_ipcs_setup_matfree derives on the device.  Bitwise reproducible.  mf_scat: packed words (N2 <= 4096) or plain
 // tile positions (larger meshes, MeshTopology.matfree_maps).
+#ifdef MDQ_T5_TRACE
+// debug build only: s_memtime cycles of the phases of a mode-5 operator application (thread 0 of environment 0)
+__device__ long long mdq_t5_trace_buf[8];
+#define T5_STAMP(k) { const long long tn_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) mdq_t5_trace_buf[k] += tn_ - t5q_; t5q_ = tn_; }
+extern "C" int mdq_t5_trace_host(long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mdq_t5_trace_buf), sizeof(long long) * 8) != hipSuccess) return -1;
+  if (reset) { long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(mdq_t5_trace_buf), z, sizeof z) != hipSuccess) return -1; }
+  return 0;
+}
+#else
+#define T5_STAMP(k)
+#endif
+
 template <class ElemOp, class Epi>
 __device__ __forceinline__ void tile_apply_global(const EnvView& v, bool packed, double2* es, double2* ytmp, ElemOp op, Epi epi) {
   const int tid = threadIdx.x, n = v.n2;
   const int nch = (v.nt + MF_CH - 1) / MF_CH;
+#ifdef MDQ_T5_TRACE
+  long long t5q_ = __builtin_amdgcn_s_memtime();
+  if (tid == 0 && blockIdx.x == 0) mdq_t5_trace_buf[7] += 1;
+#endif
+  for (int row = tid; row < n; row += WG) ytmp[row] = make_double2(0.0, 0.0);   // (own rows: visible to the row phases behind the barriers)
   for (int chunk = 0; chunk < nch; ++chunk) {
 #pragma unroll
     for (int j = 0; j < MF_EPT; ++j) {
@@ -989,26 +1012,80 @@ __device__ __forceinline__ void tile_apply_global(const EnvView& v, bool packed,
         for (int i = 0; i < 6; ++i) es[pos[i]] = ye[i];
       }
     }
+    T5_STAMP(0)
     __syncthreads();
-    const int32_t* tp = v.mf_tptr + chunk * v.mf_tstride;
-    for (int row = tid; row < n; row += WG) {
-      const int lo = tp[row], hi = tp[row + 1];
-      if (chunk == 0 || hi > lo) {
-        double2 a = chunk == 0 ? make_double2(0.0, 0.0) : ytmp[row];
-        for (int j = lo; j < hi; ++j) {
-          const double2 c = es[j];
-          a.x += c.x;
-          a.y += c.y;
+    T5_STAMP(1)
+    if (v.mf_rlist) {
+      // row phase over the rows this chunk TOUCHES (ascending list: one thread per entry, a row belongs to one entry per
+      // chunk): entry and running sum of a batch are requested together.  Walking every own row's tile range (the branch
+      // below) visited 12 924 rows per chunk on the refined mesh for ~2 500 touched ones: 57 % of an application.
+      const int2* rl = reinterpret_cast<const int2*>(v.mf_rlist) + (size_t)chunk * v.NRL;
+      const int nr = v.mf_rcnt[chunk];
+      constexpr int RB = 4;
+      for (int k0 = tid; k0 < nr; k0 += RB * WG) {
+        int2 en[RB];
+        double2 a[RB];
+#pragma unroll
+        for (int k = 0; k < RB; ++k) en[k] = rl[min(k0 + k * WG, nr - 1)];
+#pragma unroll
+        for (int k = 0; k < RB; ++k) a[k] = ytmp[en[k].x];
+#pragma unroll
+        for (int k = 0; k < RB; ++k) {
+          if (k0 + k * WG < nr) {
+            const int lo = en[k].y & 0xFFFF, cnt = en[k].y >> 16;
+            for (int j = lo; j < lo + cnt; ++j) {
+              const double2 c = es[j];
+              a[k].x += c.x;
+              a[k].y += c.y;
+            }
+            ytmp[en[k].x] = a[k];
+          }
         }
-        ytmp[row] = a;
+      }
+    } else {
+      // row phase in batches of RB own rows: the tile ranges and the running sums of a batch are requested together
+      const int32_t* tp = v.mf_tptr + chunk * v.mf_tstride;
+      constexpr int RB = 8;
+      for (int row0 = tid; row0 < n; row0 += RB * WG) {
+        int lo[RB], hi[RB];
+        double2 a[RB];
+#pragma unroll
+        for (int k = 0; k < RB; ++k) {
+          const int rc = min(row0 + k * WG, n - 1);
+          lo[k] = tp[rc];
+          hi[k] = tp[rc + 1];
+        }
+#pragma unroll
+        for (int k = 0; k < RB; ++k) a[k] = ytmp[min(row0 + k * WG, n - 1)];
+#pragma unroll
+        for (int k = 0; k < RB; ++k) {
+          const int row = row0 + k * WG;
+          if (row < n && hi[k] > lo[k]) {
+            for (int j = lo[k]; j < hi[k]; ++j) {
+              const double2 c = es[j];
+              a[k].x += c.x;
+              a[k].y += c.y;
+            }
+            ytmp[row] = a[k];
+          }
+        }
       }
     }
+    T5_STAMP(2)
     __syncthreads();
+    T5_STAMP(3)
   }
-  for (int row = tid; row < n; row += WG) {
-    const double2 a = ytmp[row];
-    epi(row, a.x, a.y);
+  // epilogue: the sums of a batch of own rows are requested together (the caller's own loads follow row by row)
+  constexpr int EB = 4;
+  for (int row0 = tid; row0 < n; row0 += EB * WG) {
+    double2 a[EB];
+#pragma unroll
+    for (int k = 0; k < EB; ++k) a[k] = ytmp[min(row0 + k * WG, n - 1)];
+#pragma unroll
+    for (int k = 0; k < EB; ++k)
+      if (row0 + k * WG < n) epi(row0 + k * WG, a[k].x, a[k].y);
   }
+  T5_STAMP(4)
 }
 
 // ================================================================== sparse kernels (workgroup-wide)

@@ -118,6 +118,24 @@ class IpcsBatch:
             for t_, p_ in zip(self.topos, per):
                 if t_.np2 <= 4096:
                     p_["mf_scat"], p_["mf_tptr"] = t_.matfree_maps(1024)
+            # per chunk the rows its triangles touch (mode 5's row phase: ~2 500 of the refined mesh's 12 924 rows per chunk)
+            for p_ in per:
+                tp = p_["mf_tptr"]
+                cnt = np.diff(tp, axis=1)
+                p_["mf_rcnt"] = (cnt > 0).sum(axis=1).astype(np.int32)
+            NRL = int(max(p_["mf_rcnt"].max() for p_ in per))
+            for p_ in per:
+                tp = p_["mf_tptr"]
+                cnt = np.diff(tp, axis=1)
+                rl = np.zeros((tp.shape[0], NRL, 2), np.int32)
+                for c in range(tp.shape[0]):
+                    rows = np.flatnonzero(cnt[c] > 0)
+                    rl[c, :rows.size, 0] = rows
+                    rl[c, :rows.size, 1] = tp[c, rows] | (cnt[c, rows] << 16)
+                p_["mf_rlist"] = rl
+            h["mf_rlist"] = stack("mf_rlist", (NCH, NRL, 2), np.int32)
+            h["mf_rcnt"] = stack("mf_rcnt", (NCH,), np.int32)
+            self._NRL = NRL
         h["mf_scat"] = stack("mf_scat", (6, NT), np.int32)
         h["mf_tptr"] = stack("mf_tptr", (NCH, N2 + 1), np.int32)
         h["nbo"] = np.array([p["bo_rows"].size for p in per], np.int32)
@@ -174,6 +192,7 @@ class IpcsBatch:
             if name in t:
                 setattr(d, name, t[name].data_ptr())
         d.work_doubles = nwork
+        d.NRL = getattr(self, "_NRL", 0)
         d.pd_enabled = 0
         # Krylov pressure solve of mode 3: degree of the Chebyshev polynomial preconditioner (0, default: the plain Jacobi-CG
         # kernel).  Measured on ys930 (tools/time_pcg.py): iterations 154 -> 95 / 67 / 52 / 37 / 30 for degree 2 / 3 / 4 / 6 / 8,

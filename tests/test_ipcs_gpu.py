@@ -308,10 +308,20 @@ def test_two_workgroups_per_environment_match_one(meshes, lib_built):
     assert np.abs(out[4][1] - out[0][1]).max() < 1e-11 * np.abs(out[0][1]).max()
     assert np.abs(out[4][2] - out[0][2]).max() < 1e-8 * np.abs(out[0][2]).max()
     assert np.array_equal(out[4][3], out[0][3])
-    # auto mode: a small batch of a mesh that only fits the assembled path takes the team kernel (same bits as mode 4)
-    ba = IpcsBatch([rt] * 5, [rc] * 5, rtol=1e-10)
-    d, _ = ba.evolve(6)
+    # auto mode WITHOUT the element tiles of mode 5 (what auto takes for a mesh this size since round 4: MDQ_NO_MODE5 is
+    # read per launch): a small batch of a mesh that only fits the assembled path takes the team kernel (same bits as mode 4)
+    os.environ["MDQ_NO_MODE5"] = "1"
+    try:
+        ba = IpcsBatch([rt] * 5, [rc] * 5, rtol=1e-10)
+        d, _ = ba.evolve(6)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["MDQ_NO_MODE5"]
     assert np.array_equal(d.cpu().numpy(), out[4][0])
+    # ... and with them: mode 5, the same forces to the solver tolerance
+    b5 = IpcsBatch([rt] * 5, [rc] * 5, rtol=1e-10)
+    d5, _ = b5.evolve(6)
+    assert np.abs(d5.cpu().numpy() - out[0][0]).max() < 1e-8 * np.abs(out[0][0]).max()
 
 
 def test_polynomial_preconditioned_pressure_cg_matches_oracle(meshes, lib_built):
