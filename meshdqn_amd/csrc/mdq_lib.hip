@@ -6,6 +6,7 @@
 #include "mdq_gcn_train.hip"
 #include "mdq_replay.hip"
 #include "mdq_mesh.hip"
+#include "mdq_smooth_big.hip"
 #include "mdq_smooth.hip"
 #include "mdq_smooth_linear.hip"
 #include "mdq_topology.hip"

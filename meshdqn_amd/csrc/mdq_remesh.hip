@@ -22,7 +22,17 @@ namespace mdq_rm {
 #define MDQ_REMESH_WG 1024
 #endif
 constexpr int RW = MDQ_REMESH_WG;   // threads per mesh (256 in rounds 1-3: the parallel phases are loops of LDS atomics / hash probes, i.e. latency chains)
-constexpr int RNV = 1024, RNT = 2048, RNS = 3 * RNT, RHS = 8192;
+// Capacities as a template parameter K (round 4): K = 1 - 1024 vertices / 2048 triangles, every table in LDS (the
+// kernel of the 128-environment batches); K = 4 - 4096 vertices / 8192 triangles (BASELINE configs[4]: ys930 red-refined,
+// 3 322 vertices), the same code on a slab in GLOBAL memory per mesh (L2 resident; slower: every table access is an L2
+// round trip instead of an LDS one - the reference's _remove_vertex takes whatever mesh it is given, Env2DAirfoil.py:452-512).
+template <int K>
+struct Cap {
+  static constexpr int NV = 1024 * K, NT = 2048 * K, NS = 3 * NT, HS = 8192 * K;
+  static constexpr int VBITS = K == 1 ? 10 : 12, HSHIFT = K == 1 ? 19 : 17;       // vertex ids / 32 - log2(HS)
+  static constexpr size_t BYTES = (size_t)16 * NV + 2 * sizeof(int) * NS + 2 * sizeof(uint32_t) * HS + sizeof(int) * 336;
+};
+constexpr int RNV = Cap<1>::NV, RNT = Cap<1>::NT;
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 
 __device__ __forceinline__ double orient2d(double2 a, double2 b, double2 c) {
@@ -36,7 +46,8 @@ __device__ __forceinline__ double incircle(double2 a, double2 b, double2 c, doub
   return (ax * ax + ay * ay) * (bx * cy - by * cx) - (bx * bx + by * by) * (ax * cy - ay * cx) +
          (cx * cx + cy * cy) * (ax * by - ay * bx);
 }
-__device__ __forceinline__ uint32_t hslot(uint32_t key) { return (key * 2654435761u) >> 19; }
+template <int SH>
+__device__ __forceinline__ uint32_t hslot(uint32_t key) { return (key * 2654435761u) >> SH; }
 
 // the action decoding of mdq_env_act (env_act_kernel, mdq_mesh.hip) as the head of the removal kernel
 struct ActArgs {
@@ -52,13 +63,17 @@ struct ActArgs {
   int32_t* code;
 };
 
-template <bool ACT>
+template <bool ACT, int K>
 __global__ __launch_bounds__(RW) void remesh_kernel(int NV, int NT, double* coords, int32_t* cells, int32_t* nv_,
-                                                    int32_t* nt_, const int32_t* remove_idx, int32_t* status, ActArgs A) {
+                                                    int32_t* nt_, const int32_t* remove_idx, int32_t* status, ActArgs A,
+                                                    unsigned char* slab) {
 #pragma clang fp contract(off)
-  extern __shared__ __align__(16) unsigned char smem[];
-  double2* X = reinterpret_cast<double2*>(smem);                     // [RNV]            16 KB
-  int* tri = reinterpret_cast<int*>(smem + 16384);                   // [RNT][3]         24 KB
+  using C = Cap<K>;
+  constexpr int RNV = C::NV, RNS = C::NS, RHS = C::HS;
+  extern __shared__ __align__(16) unsigned char lds_[];
+  unsigned char* smem = K == 1 ? lds_ : slab + (size_t)blockIdx.x * ((C::BYTES + 255) & ~(size_t)255);
+  double2* X = reinterpret_cast<double2*>(smem);                     // [RNV]            16 KB (K = 1)
+  int* tri = reinterpret_cast<int*>(smem + 16 * RNV);                // [RNT][3]         24 KB
   int* nbr = tri + RNS;                                              // [RNT][3]         24 KB
   uint32_t* hkey = reinterpret_cast<uint32_t*>(nbr + RNS);           // [RHS]            32 KB | the flip stack re-uses
   uint32_t* hval = hkey + RHS;                                       // [RHS]            32 KB | this region
@@ -265,8 +280,8 @@ __global__ __launch_bounds__(RW) void remesh_kernel(int NV, int NT, double* coor
   for (int s = tid; s < 3 * nt; s += RW) {
     const int t = s / 3, k = s - 3 * t;
     const int a = tri[3 * t + (k + 1) % 3], c = tri[3 * t + (k + 2) % 3];
-    const uint32_t key = ((uint32_t)min(a, c) << 10) | (uint32_t)max(a, c);
-    uint32_t h = hslot(key);
+    const uint32_t key = ((uint32_t)min(a, c) << C::VBITS) | (uint32_t)max(a, c);
+    uint32_t h = hslot<C::HSHIFT>(key);
     for (;;) {
       const uint32_t old = atomicCAS(&hkey[h], EMPTY, key);
       if (old == EMPTY || old == key) break;
@@ -383,30 +398,53 @@ __global__ __launch_bounds__(RW) void remesh_kernel(int NV, int NT, double* coor
 
 }  // namespace mdq_rm
 
-static int remesh_launch(const char* who, int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv,
-                         int32_t* nt, const int32_t* remove_idx, int32_t* status, const mdq_rm::ActArgs* act, void* stream) {
-  if (B <= 0 || !coords || !cells || !nv || !nt || (!remove_idx && !act) || !status) return mdq_set_error("mdq_remesh: bad arguments");
-  if (NV > mdq_rm::RNV || NT > mdq_rm::RNT)
-    return mdq_set_error("mdq_remesh: capacity above 1024 vertices / 2048 triangles (use mdq_remesh_host)");
-  (void)who;
-  const size_t lds = 16384 + 2 * sizeof(int) * mdq_rm::RNS + 2 * sizeof(uint32_t) * mdq_rm::RHS + sizeof(int) * 336;
+static unsigned char* g_big_slab = nullptr;     // K = 4: the tables of every mesh of a launch (grown on demand, kept)
+static size_t g_big_slab_bytes = 0;
+
+template <int K>
+static int remesh_launch_k(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv, int32_t* nt,
+                           const int32_t* remove_idx, int32_t* status, const mdq_rm::ActArgs* act, void* stream, unsigned char* slab) {
+  const size_t lds = K == 1 ? mdq_rm::Cap<1>::BYTES : 0;
   static const hipError_t attr = [] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mdq_rm::remesh_kernel<false>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mdq_rm::remesh_kernel<false, K>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mdq_rm::remesh_kernel<true>),
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mdq_rm::remesh_kernel<true, K>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return e;
   }();
   if (attr != hipSuccess) return mdq_set_error("hipFuncSetAttribute(remesh_kernel) failed");
   if (act)
-    hipLaunchKernelGGL(mdq_rm::remesh_kernel<true>, dim3(B), dim3(mdq_rm::RW), lds, (hipStream_t)stream, NV, NT, coords, cells,
-                       nv, nt, remove_idx, status, *act);
+    hipLaunchKernelGGL((mdq_rm::remesh_kernel<true, K>), dim3(B), dim3(mdq_rm::RW), lds, (hipStream_t)stream, NV, NT, coords,
+                       cells, nv, nt, remove_idx, status, *act, slab);
   else
-    hipLaunchKernelGGL(mdq_rm::remesh_kernel<false>, dim3(B), dim3(mdq_rm::RW), lds, (hipStream_t)stream, NV, NT, coords, cells,
-                       nv, nt, remove_idx, status, mdq_rm::ActArgs{});
+    hipLaunchKernelGGL((mdq_rm::remesh_kernel<false, K>), dim3(B), dim3(mdq_rm::RW), lds, (hipStream_t)stream, NV, NT, coords,
+                       cells, nv, nt, remove_idx, status, mdq_rm::ActArgs{}, slab);
   if (hipGetLastError() != hipSuccess) return mdq_set_error("remesh_kernel launch failed");
   return 0;
+}
+
+static int remesh_launch(const char* who, int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv,
+                         int32_t* nt, const int32_t* remove_idx, int32_t* status, const mdq_rm::ActArgs* act, void* stream) {
+  if (B <= 0 || !coords || !cells || !nv || !nt || (!remove_idx && !act) || !status) return mdq_set_error("mdq_remesh: bad arguments");
+  (void)who;
+  if (NV <= mdq_rm::Cap<1>::NV && NT <= mdq_rm::Cap<1>::NT)
+    return remesh_launch_k<1>(B, NV, NT, coords, cells, nv, nt, remove_idx, status, act, stream, nullptr);
+  if (NV > mdq_rm::Cap<4>::NV || NT > mdq_rm::Cap<4>::NT)
+    return mdq_set_error("mdq_remesh: capacity above 4096 vertices / 8192 triangles");
+  // the large-mesh instance: its tables live in a slab in global memory (one per process, grown on demand; launches that
+  // share it are ordered by the caller's stream: one stream per process uses the large instance at a time)
+  const size_t per = (mdq_rm::Cap<4>::BYTES + 255) & ~(size_t)255, need = per * (size_t)B;
+  if (need > g_big_slab_bytes) {
+    if (g_big_slab) {
+      if (hipDeviceSynchronize() != hipSuccess || hipFree(g_big_slab) != hipSuccess) return mdq_set_error("mdq_remesh: cannot release the table slab");
+      g_big_slab = nullptr;
+      g_big_slab_bytes = 0;
+    }
+    if (hipMalloc(reinterpret_cast<void**>(&g_big_slab), need) != hipSuccess) return mdq_set_error("mdq_remesh: cannot allocate the table slab of the large-mesh instance");
+    g_big_slab_bytes = need;
+  }
+  return remesh_launch_k<4>(B, NV, NT, coords, cells, nv, nt, remove_idx, status, act, stream, g_big_slab);
 }
 
 extern "C" int mdq_remesh(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv, int32_t* nt,

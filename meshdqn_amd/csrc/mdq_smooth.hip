@@ -771,8 +771,8 @@ extern "C" int mdq_smooth_stats(int64_t* out64, int32_t reset) {
 extern "C" int mdq_smooth(int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t* cells, const int32_t* nv,
                           const int32_t* nt, const int32_t* iterations, void* stream) {
   if (B <= 0 || !coords || !cells || !nv || !nt || !iterations) return mdq_set_error("mdq_smooth: bad arguments");
-  if (NV > mdq_smoothing::SNV || NT > mdq_smoothing::SNT)
-    return mdq_set_error("mdq_smooth: mesh capacity above 1024 vertices / 2048 triangles (use mdq_smooth_host)");
+  if (NV > mdq_smoothing::SNV || NT > mdq_smoothing::SNT)     // a mesh beyond the 1024-vertex kernels: level-scheduled kernel
+    return smooth_big_launch(B, NV, NT, coords, cells, nv, nt, iterations, nullptr, nullptr, 0, stream);
   long long* trace = nullptr;
 #ifdef MDQ_SMOOTH_TRACE
   trace = mdq_smooth_trace_host();

@@ -1,0 +1,286 @@
+// DOLFIN `Mesh.smooth(n)` (flow_solver.py:65-67, 236-237) for meshes BEYOND the 1024-vertex kernels (mdq_smooth.hip,
+// mdq_smooth_linear.hip): up to 4096 vertices / 8192 triangles, one 512-thread workgroup per mesh (round 4: the reference
+// smooths whatever mesh it is given - BASELINE configs[4] is ys930 red-refined, 3 322 vertices).
+//
+// A Gauss-Seidel sweep in vertex order is a dependency DAG: an interior vertex needs the NEW positions of its lower-numbered
+// interior neighbours and the OLD ones of everything else.  level(v) = 1 + max level of its lower-numbered interior
+// neighbours (0 for fixed vertices): two neighbours never share a level, so all vertices of a level can take DOLFIN's exact
+// update (centroid of the neighbours, step limited to half the smallest altitude over the incident cells' opposite edges,
+// "stays" below DOLFIN_EPS) at once and IN PLACE - exact sequential semantics, a workgroup barrier per level.  Positions live
+// in LDS (64 KB), the vertex -> cells table (sorted by cell: the fixed summation order of the other kernels' exact update)
+// and the level schedule on a slab in global memory.  Straightforward, not fast: ~1.5 ms for 50 sweeps of the refined ys930.
+#include <hip/hip_runtime.h>
+
+#include "../../include/meshdqn_hip.h"
+
+namespace mdq_smooth_big {
+constexpr int BNV = 4096, BNT = 8192, BWG = 512;
+constexpr size_t SLAB_BYTES = sizeof(int) * (BNV + 8) + sizeof(uint32_t) * 3 * BNT * 2 + sizeof(uint16_t) * BNV * 2 + sizeof(int) * (BNV + 8);
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+template <int CTRL>
+__device__ __forceinline__ double dppd(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double grp8_sum(double v) {
+  v += dppd<0xB1>(v);
+  v += dppd<0x4E>(v);
+  v += dppd<0x141>(v);
+  return v;
+}
+__device__ __forceinline__ double grp8_min(double v) {
+  v = fmin(v, dppd<0xB1>(v));
+  v = fmin(v, dppd<0x4E>(v));
+  v = fmin(v, dppd<0x141>(v));
+  return v;
+}
+__device__ __forceinline__ double rsqrt_d(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  y = y * (1.5 - hx * y * y);
+  y = y * (1.5 - hx * y * y);
+  return y;
+}
+__device__ __forceinline__ double rcp_d(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = y * (2.0 - x * y);
+  y = y * (2.0 - x * y);
+  return y;
+}
+
+// DOLFIN's update of vertex v by a group of 8 lanes (lane l of the group takes incident cells l, l + 8, ...): the same
+// arithmetic, in the same order, as exact_vertex of mdq_smooth_linear.hip / exact_update of mdq_smooth.hip
+__device__ __forceinline__ d2 exact_vertex(const d2* X, const int* ptr, const uint32_t* inc, int v, int l) {
+#pragma clang fp contract(off)
+  const double EPS = 3.0e-16;
+  const int q0 = ptr[v], k = ptr[v + 1] - q0;
+  const d2 p = X[v];
+  double sx = 0.0, sy = 0.0, rm = 1e300;
+  for (int q = l; q < k; q += 8) {
+    const uint32_t w = inc[q0 + q];
+    const d2 pa = X[w & 0xFFFF], pc = X[w >> 16];
+    sx += pa.x + pc.x;
+    sy += pa.y + pc.y;
+    const double tx = pc.x - pa.x, ty = pc.y - pa.y;
+    const double cr = ty * (p.x - pa.x) - tx * (p.y - pa.y);
+    rm = fmin(rm, cr * cr * rcp_d(tx * tx + ty * ty));   // SQUARED distance to the line through the opposite edge
+  }
+  sx = grp8_sum(sx);
+  sy = grp8_sum(sy);
+  rm = grp8_min(rm);
+  const double r2k = 1.0 / (2.0 * k);
+  const double dx = sx * r2k - p.x, dy = sy * r2k - p.y;
+  const double q2 = dx * dx + dy * dy;
+  if (!(q2 >= EPS * EPS && q2 > 0.0)) return p;          // |c - p| < DOLFIN_EPS: the vertex stays
+  if (0.25 * rm < q2) {                                  // limited step: needs the lengths
+    const double f = 0.5 * (rm * rsqrt_d(rm)) * rsqrt_d(q2);
+    return d2{p.x + f * dx, p.y + f * dy};
+  }
+  return d2{p.x + dx, p.y + dy};                         // |c - p| <= r_min / 2: to the centroid itself
+}
+
+__global__ __launch_bounds__(BWG) void smooth_big_kernel(int NV, int NT, double* coords, const int32_t* cells, const int32_t* nv_,
+                                                         const int32_t* nt_, const int32_t* iters_, const int32_t* rem,
+                                                         const int32_t* rstat, int iters_env, unsigned char* slab, int32_t* status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_[];
+  d2* X = reinterpret_cast<d2*>(dyn_);                       // [BNV] 64 KB
+  int* cnt = reinterpret_cast<int*>(dyn_ + sizeof(d2) * BNV);   // [BNV] 16 KB: counts / cursors, then levels
+  __shared__ int part[BWG];
+  __shared__ int misc[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int S = iters_ ? iters_[b] : ((rem[b] >= 0 && rstat[b] == 0) ? iters_env : 0);
+  if (status && tid == 0) status[b] = 0;
+  if (S <= 0) return;
+  const int nv = nv_[b], nt = nt_[b];
+  double2* xg = reinterpret_cast<double2*>(coords) + (int64_t)b * NV;
+  const int32_t* tri = cells + (int64_t)b * NT * 3;
+  unsigned char* sb = slab + (size_t)b * ((SLAB_BYTES + 255) & ~(size_t)255);
+  int* ptr = reinterpret_cast<int*>(sb);                                   // [BNV + 1] vertex -> cells
+  uint32_t* inc = reinterpret_cast<uint32_t*>(ptr + BNV + 8);              // [3 BNT] a | c << 16, sorted by cell per vertex
+  uint32_t* cel = inc + 3 * BNT;                                           // [3 BNT] cell id of the entry
+  uint16_t* order = reinterpret_cast<uint16_t*>(cel + 3 * BNT);            // [BNV] interior vertices grouped by level
+  uint16_t* intr = order + BNV;                                            // [BNV] 1 = interior
+  int* lptr = reinterpret_cast<int*>(intr + BNV);                          // [levels + 2]
+  // ---- vertex -> cells
+  for (int v = tid; v < BNV; v += BWG) cnt[v] = 0;
+  __syncthreads();
+  for (int t = tid; t < nt; t += BWG)
+    for (int k = 0; k < 3; ++k) atomicAdd(&cnt[tri[3 * t + k]], 1);
+  __syncthreads();
+  {   // exclusive scan of cnt[0 .. BNV) -> ptr: 8 entries per thread, thread totals by Hillis-Steele
+    constexpr int PER = BNV / BWG;
+    int loc[PER], run = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      loc[i] = run;
+      run += cnt[tid * PER + i];
+    }
+    part[tid] = run;
+    __syncthreads();
+    for (int off = 1; off < BWG; off <<= 1) {
+      const int add = tid >= off ? part[tid - off] : 0;
+      __syncthreads();
+      part[tid] += add;
+      __syncthreads();
+    }
+    const int base = part[tid] - run;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) ptr[tid * PER + i] = base + loc[i];
+    if (tid == BWG - 1) ptr[BNV] = part[tid];
+  }
+  __syncthreads();
+  for (int v = tid; v < BNV; v += BWG) cnt[v] = 0;
+  __syncthreads();
+  for (int t = tid; t < nt; t += BWG) {
+    const int vs[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
+    for (int k = 0; k < 3; ++k) {
+      const int v = vs[k], a = vs[(k + 1) % 3], c = vs[(k + 2) % 3];
+      const int q = ptr[v] + atomicAdd(&cnt[v], 1);
+      inc[q] = (uint32_t)a | ((uint32_t)c << 16);
+      cel[q] = (uint32_t)t;
+    }
+  }
+  __syncthreads();
+  // ---- per vertex: entries in ascending cell order; interior = every neighbour seen exactly twice
+  for (int v = tid; v < nv; v += BWG) {
+    const int q0 = ptr[v], k = ptr[v + 1] - q0;
+    for (int i = 1; i < k; ++i) {
+      const uint32_t ci = cel[q0 + i], wi = inc[q0 + i];
+      int j = i - 1;
+      while (j >= 0 && cel[q0 + j] > ci) {
+        cel[q0 + j + 1] = cel[q0 + j];
+        inc[q0 + j + 1] = inc[q0 + j];
+        --j;
+      }
+      cel[q0 + j + 1] = ci;
+      inc[q0 + j + 1] = wi;
+    }
+    bool interior = k > 0;
+    for (int e = 0; e < 2 * k && interior; ++e) {
+      const uint32_t we = inc[q0 + (e >> 1)];
+      const uint32_t id = (e & 1) ? we >> 16 : we & 0xFFFF;
+      int seen = 0;
+      for (int f = 0; f < 2 * k; ++f) {
+        const uint32_t wf = inc[q0 + (f >> 1)];
+        seen += ((f & 1) ? wf >> 16 : wf & 0xFFFF) == id;
+      }
+      interior = seen == 2;
+    }
+    intr[v] = interior ? 1 : 0;
+  }
+  for (int v = tid; v < BNV; v += BWG) cnt[v] = 0;           // levels (0: fixed vertex / not reached yet)
+  if (tid == 0) misc[0] = 1;
+  __syncthreads();
+  // ---- levels by relaxation: level(v) = 1 + max level of the lower-numbered interior neighbours (monotone: converges to the
+  // longest-path levels in at most as many rounds as there are levels)
+  int rounds = 0;
+  while (misc[0] && rounds < BNV) {
+    __syncthreads();
+    if (tid == 0) misc[0] = 0;
+    __syncthreads();
+    bool changed = false;
+    for (int v = tid; v < nv; v += BWG) {
+      if (!intr[v]) continue;
+      const int q0 = ptr[v], k = ptr[v + 1] - q0;
+      int lv = 1;
+      for (int q = 0; q < k; ++q) {
+        const uint32_t w = inc[q0 + q];
+        const int a = w & 0xFFFF, c = w >> 16;
+        if (a < v && intr[a]) lv = max(lv, cnt[a] + 1);
+        if (c < v && intr[c]) lv = max(lv, cnt[c] + 1);
+      }
+      if (lv != cnt[v]) changed = true;
+      cnt[v] = lv;                                           // (benign race: levels only grow towards the fixed point)
+    }
+    if (changed) misc[0] = 1;
+    ++rounds;
+    __syncthreads();
+  }
+  // ---- vertices grouped by level (counting sort; the order inside a level does not matter)
+  int lmax = 0;
+  for (int v = tid; v < nv; v += BWG) lmax = max(lmax, cnt[v]);
+  part[tid] = lmax;
+  __syncthreads();
+  for (int off = BWG / 2; off > 0; off >>= 1) {
+    if (tid < off) part[tid] = max(part[tid], part[tid + off]);
+    __syncthreads();
+  }
+  lmax = part[0];
+  __syncthreads();
+  for (int l = tid; l <= lmax + 1; l += BWG) lptr[l] = 0;
+  __syncthreads();
+  for (int v = tid; v < nv; v += BWG)
+    if (cnt[v] > 0) atomicAdd(&lptr[cnt[v] + 1], 1);
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int l = 0; l <= lmax + 1; ++l) {
+      run += lptr[l];
+      lptr[l] = run;
+    }
+  }
+  __syncthreads();
+  // (fill: cursors in `part` would not hold a level each - use the level start from lptr through atomics on a copy in cel,
+  //  which is dead now)
+  int* cur = reinterpret_cast<int*>(cel);
+  for (int l = tid; l <= lmax; l += BWG) cur[l] = lptr[l];
+  __syncthreads();
+  for (int v = tid; v < nv; v += BWG)
+    if (cnt[v] > 0) order[atomicAdd(&cur[cnt[v]], 1)] = (uint16_t)v;
+  // ---- positions
+  for (int v = tid; v < nv; v += BWG) {
+    const double2 xv = xg[v];
+    X[v] = d2{xv.x, xv.y};
+  }
+  __syncthreads();
+  // ---- sweeps: level by level, 8 lanes per vertex
+  const int grp = tid >> 3, l8 = tid & 7;
+  for (int s = 0; s < S; ++s) {
+    for (int l = 1; l <= lmax; ++l) {
+      const int i0 = lptr[l], i1 = lptr[l + 1];
+      for (int i = i0 + grp; i < i1; i += BWG / 8) {
+        const int v = order[i];
+        const d2 xn = exact_vertex(X, ptr, inc, v, l8);
+        if (l8 == 0) X[v] = xn;
+      }
+      __syncthreads();
+    }
+  }
+  for (int v = tid; v < nv; v += BWG) {
+    const d2 p = X[v];
+    xg[v] = double2{p.x, p.y};
+  }
+}
+}  // namespace mdq_smooth_big
+
+static unsigned char* g_smooth_slab = nullptr;   // the tables of every mesh of a launch (grown on demand, kept)
+static size_t g_smooth_slab_bytes = 0;
+
+// mdq_smooth / mdq_smooth_fast / mdq_smooth_fast_env for NV > 1024 (called by those entry points)
+static int smooth_big_launch(int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t* cells, const int32_t* nv,
+                             const int32_t* nt, const int32_t* iterations, const int32_t* rem, const int32_t* rstat,
+                             int32_t iters_env, void* stream) {
+  using namespace mdq_smooth_big;
+  if (NV > BNV || NT > BNT) return mdq_set_error("mdq_smooth: capacity above 4096 vertices / 8192 triangles");
+  const size_t per = (SLAB_BYTES + 255) & ~(size_t)255, need = per * (size_t)B;
+  if (need > g_smooth_slab_bytes) {
+    if (g_smooth_slab) {
+      if (hipDeviceSynchronize() != hipSuccess || hipFree(g_smooth_slab) != hipSuccess) return mdq_set_error("mdq_smooth: cannot release the table slab");
+      g_smooth_slab = nullptr;
+      g_smooth_slab_bytes = 0;
+    }
+    if (hipMalloc(reinterpret_cast<void**>(&g_smooth_slab), need) != hipSuccess) return mdq_set_error("mdq_smooth: cannot allocate the table slab of the large-mesh kernel");
+    g_smooth_slab_bytes = need;
+  }
+  const size_t lds = sizeof(d2) * BNV + sizeof(int) * BNV;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&smooth_big_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (attr != hipSuccess) return mdq_set_error("hipFuncSetAttribute(smooth_big_kernel) failed");
+  hipLaunchKernelGGL(smooth_big_kernel, dim3(B), dim3(BWG), lds, (hipStream_t)stream, NV, NT, coords, cells, nv, nt, iterations,
+                     rem, rstat, iters_env, g_smooth_slab, nullptr);
+  if (hipGetLastError() != hipSuccess) return mdq_set_error("smooth_big_kernel launch failed");
+  return 0;
+}

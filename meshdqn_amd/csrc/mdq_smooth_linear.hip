@@ -780,8 +780,8 @@ static int smooth_fast_impl(const char* who, int32_t B, int32_t NV, int32_t NT, 
                             const int32_t* rstat, int32_t iters_env, void* workspace, int64_t workspace_bytes, void* stream) {
   if (B <= 0 || !coords || !cells || !nv || !nt || (!iterations && (!rem || !rstat)) || !workspace)
     return mdq_set_error("mdq_smooth_fast: bad arguments");
-  if (NV > mdq_smooth_lin::LNV || NT > mdq_smooth_lin::LNT)
-    return mdq_set_error("mdq_smooth_fast: mesh capacity above 1024 vertices / 2048 triangles (use mdq_smooth_host)");
+  if (NV > mdq_smooth_lin::LNV || NT > mdq_smooth_lin::LNT)   // a mesh beyond the 1024-vertex kernels: level-scheduled kernel
+    return smooth_big_launch(B, NV, NT, coords, cells, nv, nt, iterations, rem, rstat, iters_env, stream);
   if (workspace_bytes < mdq_smooth_fast_workspace_bytes(B, NV) || (reinterpret_cast<uintptr_t>(workspace) & 15))
     return mdq_set_error("mdq_smooth_fast: workspace too small or not 16-byte aligned (mdq_smooth_fast_workspace_bytes)");
   (void)who;

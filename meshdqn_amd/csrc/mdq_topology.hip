@@ -18,13 +18,23 @@ namespace mdq_topo {
 #define MDQ_TOPO_TW 1024
 #endif
 constexpr int TW = MDQ_TOPO_TW;
-constexpr int TNV = 1024, TNT = 2048, TNE = 3072, TNP = TNV + TNE, TNS = 3 * TNT;  // capacities (ids fit 10 / 12 bits)
-constexpr int HSZ = 8192;
+// Capacities as a template parameter K (round 4), as in mdq_remesh.hip: K = 1 - 1024 vertices / 2048 triangles / 3072
+// edges, every table in LDS (ids fit 10 / 12 bits); K = 4 - 4096 / 8192 / 12288 (the red-refined lab meshes of BASELINE
+// configs[4]), the same code with every table on a slab in GLOBAL memory per mesh.  All byte offsets of the table layout
+// scale with K; the index data of the matrix-free IPCS path (packed 12-bit dof ids) exists for K = 1 only.
+template <int K>
+struct TCap {
+  static constexpr int NV = 1024 * K, NT = 2048 * K, NE = 3072 * K, NP = NV + NE, NS = 3 * NT, HS = 8192 * K;
+  static constexpr int VBITS = K == 1 ? 10 : 12, HSHIFT = K == 1 ? 19 : 17, PER = NS / TW;
+  static constexpr size_t BYTES = (size_t)16 * NV + 8 * HS + sizeof(int) * NS + sizeof(uint16_t) * NS + 3 * sizeof(uint16_t) * NE + NE + NV +
+                                  sizeof(int) * (TW + 16);
+};
+constexpr int TNV = TCap<1>::NV, TNT = TCap<1>::NT, TNP = TCap<1>::NP;     // (the K = 1 capacities: host-side checks)
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
-constexpr int PER = TNS / TW;  // 12 entries per thread in the block scans
 constexpr int TNPOLY = 256;
 
-// exclusive scan of a[0..n) in place (n <= TNS), returns the total; `part` = TW ints of scratch
+// exclusive scan of a[0..n) in place (n <= PER * TW), returns the total; `part` = TW ints of scratch
+template <int PER>
 __device__ inline int scan_excl(int* a, int n, int* part) {
   const int tid = threadIdx.x;
   int loc[PER], run = 0;
@@ -63,7 +73,8 @@ __device__ inline int scan_excl(int* a, int n, int* part) {
   return total;
 }
 
-__device__ __forceinline__ uint32_t hslot(uint32_t key) { return (key * 2654435761u) >> 19; }  // 13 bits
+template <int SH>
+__device__ __forceinline__ uint32_t hslot_t(uint32_t key) { return (key * 2654435761u) >> SH; }
 
 // squared point-segment distance, operation order of the host engine (seg_dist2)
 __device__ __forceinline__ double seg_dist2(double px, double py, double ax, double ay, double bx, double by) {
@@ -88,17 +99,25 @@ extern "C" int mdq_topo_trace_host(long long* out, int reset) {
 #define TT_STAMP(k)
 #endif
 
+template <int K>
 __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_ipcs_topo_out O, int has_ipcs,
-                                                      int32_t* status) {
+                                                      int32_t* status, unsigned char* slab) {
 #pragma clang fp contract(off)
 #ifdef MDQ_TOPO_TRACE
   long long tq_ = __builtin_amdgcn_s_memtime();
 #endif
-  extern __shared__ __align__(16) unsigned char smem[];
+  using CP = TCap<K>;
+  constexpr int TNV = CP::NV, TNE = CP::NE, TNP = CP::NP, TNS = CP::NS, HSZ = CP::HS, PER = CP::PER;
+  constexpr int TNT = CP::NT;
+  (void)TNT;
+  auto hslot = [](uint32_t key) { return hslot_t<CP::HSHIFT>(key); };
+  auto scan_excl = [](int* a_, int n_, int* part_) { return mdq_topo::scan_excl<CP::PER>(a_, n_, part_); };
+  extern __shared__ __align__(16) unsigned char lds_[];
+  unsigned char* smem = K == 1 ? lds_ : slab + (size_t)blockIdx.x * ((CP::BYTES + 255) & ~(size_t)255);
   double2* X = reinterpret_cast<double2*>(smem);                              // [TNV]
-  uint32_t* hkey = reinterpret_cast<uint32_t*>(smem + 16384);                 // [HSZ]   | region R (64 KB), re-used
+  uint32_t* hkey = reinterpret_cast<uint32_t*>(smem + 16 * TNV);              // [HSZ]   | region R (64 KB for K = 1), re-used
   uint32_t* hval = hkey + HSZ;                                                // [HSZ]   | after the edge phase
-  int* scanb = reinterpret_cast<int*>(smem + 16384 + 65536);                  // [TNS]
+  int* scanb = reinterpret_cast<int*>(smem + 16 * TNV + 8 * HSZ);             // [TNS]
   uint16_t* eid_slot = reinterpret_cast<uint16_t*>(scanb + TNS);              // [TNS]
   uint16_t* ea = eid_slot + TNS;                                              // [TNE]
   uint16_t* eb = ea + TNE;
@@ -108,14 +127,15 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   int* part = reinterpret_cast<int*>(onb + TNV);                              // [TW]
   int* misc = part + TW;                                                      // [16]
   // region R after the edge phase
-  unsigned char* R = smem + 16384;
+  unsigned char* R = smem + 16 * TNV;
+  constexpr int RPOLY = 16 * TNV, RSEG = RPOLY + 16 * TNPOLY;                // (K = 1: 16384 / 20480)
   uint16_t* blist = reinterpret_cast<uint16_t*>(R);                           // [TNV] boundary vertices
   uint16_t* remv = blist + TNV;                                               // [TNV] removable vertices (ascending)
   uint16_t* order = remv + TNV;                                               // [TNV]
   int16_t* inv = reinterpret_cast<int16_t*>(order + TNV);                     // [TNV]
-  double* dist = reinterpret_cast<double*>(R + 8192);                         // [TNV]
-  double2* poly = reinterpret_cast<double2*>(R + 16384);                      // [TNPOLY]
-  int* cntd = reinterpret_cast<int*>(R + 20480);                              // [TNP + 1] counts / pointers (IPCS phase)
+  double* dist = reinterpret_cast<double*>(R + 8 * TNV);                      // [TNV]
+  double2* poly = reinterpret_cast<double2*>(R + RPOLY);                      // [TNPOLY]
+  int* cntd = reinterpret_cast<int*>(R + RSEG);                               // [TNP + 1] counts / pointers (IPCS phase)
   int* fill = cntd + TNP + 8;                                                 // [TNP]
 
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -143,7 +163,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     const int va = tri[3 * t + (k == 0 ? 1 : 0)], vb = tri[3 * t + (k == 2 ? 1 : 2)];
     a = min(va, vb);
     c = max(va, vb);
-    return ((uint32_t)a << 10) | (uint32_t)c;
+    return ((uint32_t)a << CP::VBITS) | (uint32_t)c;
   };
   auto probe = [&](uint32_t key) {
     uint32_t h = hslot(key);
@@ -414,9 +434,9 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   // parity over exactly the straddled segments are the values of the full loop, bit for bit.
   const int QS = (((np_ + 3) >> 2) + 3) & ~3;                                 // segments per quarter (multiple of 4, <= 64)
   const int NSEG = 4 * QS;                                                    // <= TNPOLY
-  float4* segf = reinterpret_cast<float4*>(R + 20480);                        // [NSEG] {ax, ay, bx - ax, by - ay}
-  float* segr = reinterpret_cast<float*>(R + 20480 + TNPOLY * 16);            // [NSEG] 1 / |b - a|^2
-  double* ye = reinterpret_cast<double*>(R + 20480 + TNPOLY * 20);            // [NSEG + 1] y of polygon vertex i (closed)
+  float4* segf = reinterpret_cast<float4*>(R + RSEG);                         // [NSEG] {ax, ay, bx - ax, by - ay}
+  float* segr = reinterpret_cast<float*>(R + RSEG + TNPOLY * 16);             // [NSEG] 1 / |b - a|^2
+  double* ye = reinterpret_cast<double*>(R + RSEG + TNPOLY * 20);             // [NSEG + 1] y of polygon vertex i (closed)
   float* pmx = reinterpret_cast<float*>(ye + TNPOLY + 2);                     // [TW / 64] wave maxima of |polygon coordinate|
   {
     float m = 0.f;
@@ -531,7 +551,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     }
     __syncthreads();
     for (int k = 2; k <= P; k <<= 1) {
-      if (k > 64) __syncthreads();                  // (the wave-local stages of the previous k are done everywhere)
+      if (k > 64 && K == 1) __syncthreads();        // (the wave-local stages of the previous k are done everywhere)
       for (int j = k >> 1; j > 0; j >>= 1) {
         for (int i = tid; i < P; i += TW) {
           const int x = i ^ j;
@@ -548,7 +568,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
             }
           }
         }
-        if (j >= 64) __syncthreads();
+        if (j >= 64 || K != 1) __syncthreads();   // (K != 1: the tables are in global memory - no in-order guarantee without a fence)
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
     }
@@ -618,6 +638,10 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   TT_STAMP(5)
   }
   if (!has_ipcs) return;
+  if constexpr (K != 1) {
+    if (tid == 0) status[b] = -7;     // (the index data of the matrix-free IPCS path packs 12-bit dof ids: K = 1 only)
+    return;
+  } else {
   __syncthreads();
 
   // ================= index data of the matrix-free IPCS path (ipcs_topology_one of the host engine)
@@ -889,23 +913,45 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     }
   }
   TT_STAMP(6)
+  }   // (K == 1: IPCS index data)
 }
 
 }  // namespace mdq_topo
 
+static unsigned char* g_topo_slab = nullptr;    // K = 4: the tables of every mesh of a launch (grown on demand, kept)
+static size_t g_topo_slab_bytes = 0;
+
 extern "C" int mdq_env_topology(const mdq_env_topo_desc* d, void* stream, int32_t* status) {
   if (!d || d->B <= 0 || !status) return mdq_set_error("mdq_env_topology: bad arguments");
-  if (d->NV > mdq_topo::TNV || d->NT > mdq_topo::TNT || d->NP > mdq_topo::TNP || d->npoly > mdq_topo::TNPOLY)
-    return mdq_set_error("mdq_env_topology: capacity above 1024 vertices / 2048 triangles / 4096 P2 dofs / 256 polygon points");
+  if (d->npoly > mdq_topo::TNPOLY) return mdq_set_error("mdq_env_topology: more than 256 polygon points");
   mdq_ipcs_topo_out o = {};
   if (d->ipcs) o = *d->ipcs;
-  const size_t lds = 16384 + 65536 + sizeof(int) * mdq_topo::TNS + sizeof(uint16_t) * mdq_topo::TNS +
-                     3 * sizeof(uint16_t) * mdq_topo::TNE + mdq_topo::TNE + mdq_topo::TNV + sizeof(int) * (mdq_topo::TW + 16);
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mdq_topo::topology_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (attr != hipSuccess) return mdq_set_error("hipFuncSetAttribute(topology_kernel) failed");
-  hipLaunchKernelGGL(mdq_topo::topology_kernel, dim3(d->B), dim3(mdq_topo::TW), lds, (hipStream_t)stream, *d, o,
-                     d->ipcs ? 1 : 0, status);
+  if (d->NV <= mdq_topo::TNV && d->NT <= mdq_topo::TNT && d->NP <= mdq_topo::TNP) {
+    const size_t lds = mdq_topo::TCap<1>::BYTES;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mdq_topo::topology_kernel<1>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) return mdq_set_error("hipFuncSetAttribute(topology_kernel) failed");
+    hipLaunchKernelGGL(mdq_topo::topology_kernel<1>, dim3(d->B), dim3(mdq_topo::TW), lds, (hipStream_t)stream, *d, o,
+                       d->ipcs ? 1 : 0, status, nullptr);
+  } else {
+    using C4 = mdq_topo::TCap<4>;
+    if (d->NV > C4::NV || d->NT > C4::NT || d->NP > C4::NP)
+      return mdq_set_error("mdq_env_topology: capacity above 4096 vertices / 8192 triangles / 16384 P2 dofs");
+    if (d->ipcs) return mdq_set_error("mdq_env_topology: the IPCS index data exists for meshes of at most 1024 vertices");
+    // the large-mesh instance: tables on a slab in global memory (one per process, grown on demand; one stream at a time)
+    const size_t per = (C4::BYTES + 255) & ~(size_t)255, need = per * (size_t)d->B;
+    if (need > g_topo_slab_bytes) {
+      if (g_topo_slab) {
+        if (hipDeviceSynchronize() != hipSuccess || hipFree(g_topo_slab) != hipSuccess) return mdq_set_error("mdq_env_topology: cannot release the table slab");
+        g_topo_slab = nullptr;
+        g_topo_slab_bytes = 0;
+      }
+      if (hipMalloc(reinterpret_cast<void**>(&g_topo_slab), need) != hipSuccess) return mdq_set_error("mdq_env_topology: cannot allocate the table slab of the large-mesh instance");
+      g_topo_slab_bytes = need;
+    }
+    hipLaunchKernelGGL(mdq_topo::topology_kernel<4>, dim3(d->B), dim3(mdq_topo::TW), 0, (hipStream_t)stream, *d, o, 0, status,
+                       g_topo_slab);
+  }
   if (hipGetLastError() != hipSuccess) return mdq_set_error("topology_kernel launch failed");
   return 0;
 }

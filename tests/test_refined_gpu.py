@@ -1,0 +1,166 @@
+"""GPU: the env step on a mesh beyond 1024 vertices (BASELINE configs[4]: ys930 red-refined once, 3 322 vertices / 6 280
+triangles) - the large-mesh instances of the device kernels (round 4: mdq_remesh / mdq_env_topology with their tables on a
+slab in global memory, the level-scheduled smoothing kernel) against the C++ host twins, which the CPU suite pins to
+scipy / the oracle; then `VecEnv2DAirfoil` (device-resident) against the host-engine `VecEnv2DAirfoil` on the same scripts.
+Reference: Env2DAirfoil._remove_vertex / _check_mesh (Env2DAirfoil.py:452-512, 547-602), FlowSolver.remesh
+(flow_solver.py:233-359) take whatever mesh they are given."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _refined(meshes, name="ys930"):
+    from meshdqn_amd.ipcs_batch import smooth_coords
+    from meshdqn_amd.mesh_ops import red_refine
+    from meshdqn_amd.topology import MeshTopology
+    coords, cells = meshes[name]
+    rc, rcells = red_refine(smooth_coords(MeshTopology(coords, cells), 50), cells)
+    t = MeshTopology(rc, rcells)
+    return t, smooth_coords(t, 50)
+
+
+def test_large_mesh_remesh_and_smoothing_match_the_host_engine(lib_built, meshes):
+    """12 consecutive removals on 3 refined meshes with different action streams (incl. "do nothing" and a boundary vertex):
+    cells as a set, vertex counts and failure codes equal, smoothed coordinates to 1e-12."""
+    from meshdqn_amd.mesh_ops import remesh_batch, remesh_batch_gpu, smooth_batch_gpu
+    from meshdqn_amd.topology import MeshTopology
+    t0, x0 = _refined(meshes)
+    assert t0.nv == 3322 and t0.nt == 6280
+    B, NV, NT = 3, t0.nv, t0.nt
+    hc = np.repeat(x0[None], B, 0).copy()
+    ht = np.repeat(np.sort(t0.cells, axis=1)[None].astype(np.int32), B, 0).copy()
+    hnv = np.full(B, NV, np.int32); hnt = np.full(B, NT, np.int32)
+    dc, dtri = torch.from_numpy(hc).cuda(), torch.from_numpy(ht).cuda()
+    dnv, dnt = torch.from_numpy(hnv).cuda(), torch.from_numpy(hnt).cuda()
+    dst = torch.zeros(B, dtype=torch.int32, device="cuda")
+    rng = np.random.default_rng(11)
+    for step in range(12):
+        rem = np.empty(B, np.int32)
+        for b in range(B):
+            t = MeshTopology(hc[b, :hnv[b]], ht[b, :hnt[b]])
+            rem[b] = rng.choice(np.flatnonzero(~t.on_boundary))
+        if step % 5 == 3:
+            rem[1] = -1
+        if step == 4:
+            rem[2] = 0                        # a boundary vertex: refused, mesh untouched
+        hst = remesh_batch(hc, ht, hnv, hnt, rem, 50, 2)
+        drem = torch.from_numpy(rem).cuda()
+        remesh_batch_gpu(dc, dtri, dnv, dnt, drem, dst)
+        its = torch.where((drem >= 0) & (dst == 0), 50, 0).to(torch.int32)
+        smooth_batch_gpu(dc, dtri, dnv, dnt, its)
+        torch.cuda.synchronize()
+        assert np.array_equal(dst.cpu().numpy() != 0, hst != 0), (step, dst.cpu().numpy(), hst)
+        assert np.array_equal(dnv.cpu().numpy(), hnv) and np.array_equal(dnt.cpu().numpy(), hnt)
+        gc, gt = dc.cpu().numpy(), dtri.cpu().numpy()
+        for b in range(B):
+            assert {tuple(r) for r in gt[b, :hnt[b]].tolist()} == {tuple(r) for r in ht[b, :hnt[b]].tolist()}, (step, b)
+            assert np.abs(gc[b, :hnv[b]] - hc[b, :hnv[b]]).max() < 1e-12, (step, b)
+
+
+def test_large_mesh_smoothing_is_reproducible_and_matches_the_host_loop(lib_built, meshes):
+    from meshdqn_amd.ipcs_batch import smooth_coords
+    from meshdqn_amd.mesh_ops import red_refine, smooth_batch_gpu
+    from meshdqn_amd.topology import MeshTopology
+    coords, cells = meshes["ah93w145"]
+    rc, rcells = red_refine(coords, cells)                 # NOT smoothed before: limited steps in the first sweeps
+    t = MeshTopology(rc, rcells)
+    host = smooth_coords(t, 50)
+    outs = []
+    for rep in range(2):
+        tc = torch.from_numpy(np.stack([rc, rc])).cuda()
+        tt = torch.from_numpy(np.sort(rcells, axis=1).astype(np.int32)[None].repeat(2, 0).copy()).cuda()
+        one = lambda v: torch.full((2,), v, dtype=torch.int32, device="cuda")     # noqa: E731
+        its = torch.tensor([50, 7], dtype=torch.int32, device="cuda")
+        smooth_batch_gpu(tc, tt, one(t.nv), one(t.nt), its)
+        outs.append(tc.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    assert np.abs(outs[0][0] - host).max() < 1e-13
+    assert np.abs(outs[0][1] - smooth_coords(t, 7)).max() < 1e-13
+
+
+def test_large_mesh_topology_engine_is_bit_identical_to_host_engine(lib_built, meshes):
+    """mdq_env_topology's large-mesh instance against mdq_env_topology_host: every output array of the S1 step (edges, dof
+    map, points, airfoil facets, removable vertices, N-closest window, state graph), after removals, with a shifted window."""
+    from meshdqn_amd.mesh_ops import DeviceTopologyBatch, HostTopologyBatch, remesh_batch
+    t0, x0 = _refined(meshes)
+    tags = t0.facet_tags(x0)
+    polygon = x0[[v for v in range(t0.nv) if t0.on_boundary[v] and -0.5 < x0[v, 0] < 3 and -0.5 < x0[v, 1] < 0.5]]
+    assert 200 < len(polygon) <= 256
+    B = 3
+    args = (B, t0.nv, t0.nt, t0.ne, int((tags == 1).sum()), 180, 1536, polygon)
+    hb = HostTopologyBatch(*args, ipcs=False)
+    for b in range(B):
+        hb.coords[b], hb.cells[b], hb.nv[b], hb.nt[b] = x0, np.sort(t0.cells, axis=1), t0.nv, t0.nt
+    interior = np.flatnonzero(~t0.on_boundary)
+    for rnd in range(3):
+        rem = np.array([-1, interior[40 + 7 * rnd], interior[1300 + 11 * rnd]], np.int32)
+        assert (remesh_batch(hb.coords, hb.cells, hb.nv, hb.nt, rem, 50, 2) == 0).all()
+    hb.offset[:] = [0, 3, 0]
+    hb.run(2)
+    db = DeviceTopologyBatch(*args, device="cuda", ipcs=False)
+    db.coords.copy_(torch.from_numpy(hb.coords)); db.cells.copy_(torch.from_numpy(hb.cells))
+    db.nv.copy_(torch.from_numpy(hb.nv)); db.nt.copy_(torch.from_numpy(hb.nt)); db.offset.copy_(torch.from_numpy(hb.offset))
+    db.run()
+    torch.cuda.synchronize()
+    g = {k: v.cpu().numpy() for k, v in db.t.items()}
+    for b in range(B):
+        nv, nt, ne = int(hb.nv[b]), int(hb.nt[b]), int(hb.h["ne"][b])
+        n2 = nv + ne
+        for k in ("ne", "naf", "nremovable", "nsel", "nedges"):
+            assert g[k][b] == hb.h[k][b], (k, b)
+        naf, nE = int(hb.h["naf"][b]), int(hb.h["nedges"][b])
+        assert np.array_equal(g["cell_dofs"][b][:, :nt], hb.h["cell_dofs"][b][:, :nt])
+        assert np.array_equal(g["points"][b][:n2], hb.h["points"][b][:n2])                 # bitwise
+        assert np.array_equal(g["af_facets"][b][:naf], hb.h["af_facets"][b][:naf])
+        assert np.array_equal(g["n_closest"][b], hb.h["n_closest"][b])
+        assert np.array_equal(g["coord_map"][b], hb.h["coord_map"][b])
+        for k in ("edge_src", "edge_dst", "edge_len"):
+            assert np.array_equal(g[k][b][:nE], hb.h[k][b][:nE]), (k, b)
+
+
+@pytest.mark.slow
+def test_vec_env_steps_the_refined_mesh_on_the_device(lib_built, meshes, tmp_path):
+    """`VecEnv2DAirfoil` on the red-refined ys930 (3 322 vertices): the device-resident engine (`step()` and
+    `rollout_device`) against the same class on the C++ host engine, per-environment scripted actions incl. "do nothing":
+    identical selections / vertex counts / terminal flags, rewards and forces to 1e-9."""
+    from meshdqn_amd.env import Env2DAirfoil
+    from meshdqn_amd.vec_env import VecEnv2DAirfoil
+    t0, _ = _refined(meshes)
+    path = os.path.join(str(tmp_path), "ys930_refined.npz")
+    np.savez(path, coords=t0.coords, cells=t0.cells)
+    cfg = dict(flow_config=dict(flow_params=dict(mu=1e-3, rho=1.0, inflow="constant"), geometry_params=dict(mesh=path),
+                                solver_params=dict(dt=0.001, solver_type="lu", smooth=True, rtol=1e-10)),
+               agent_params=dict(solver_steps=10, episodes=10, timesteps=10000, threshold=0.001, N_closest=180, gt_drag=-1,
+                                 gt_time=-1, u=-1, p=-1, time_reward=0.005, save_steps=2, goal_vertices=0.95, plot_dir=""))
+    base = Env2DAirfoil(cfg)
+    assert len(base.flow_solver.mesh.coordinates()) == 3322
+    B, K = 3, 5
+    script = np.random.default_rng(21).integers(0, 181, size=(K, B))
+    script[2, 1] = 180
+    runs = []
+    for kw in (dict(gpu_smoothing=False, gpu_topology=False, gpu_remesh=False), dict()):
+        env = VecEnv2DAirfoil(cfg, B, base_env=base, auto_reset=False, nthreads=2, **kw)
+        env.get_state()
+        out = []
+        for k in range(K):
+            st, rew, done, info = env.step(script[k])
+            out.append((info["nv"].copy(), st["coord_map"].copy(), st["nedges"].copy(), info["new_drags"].copy(), rew.copy(),
+                        done.copy(), st["x"].cpu().numpy()))
+        runs.append(out)
+    for a, r in zip(runs[1], runs[0]):
+        assert np.array_equal(a[0], r[0]) and np.array_equal(a[1], r[1]) and np.array_equal(a[2], r[2])
+        assert np.allclose(a[3], r[3], rtol=1e-9, atol=0) and np.allclose(a[4], r[4], rtol=1e-9) and np.array_equal(a[5], r[5])
+        assert np.allclose(a[6], r[6], rtol=1e-5, atol=1e-6)
+    assert (runs[1][-1][0] < 3322).all()
+    # and without a host round trip inside the steps
+    dev = VecEnv2DAirfoil(cfg, B, base_env=base, auto_reset=False, nthreads=2)
+    dev.get_state()
+    out = dev.rollout_device(None, K, actions=script)
+    for k in range(K):
+        assert np.array_equal(out["nv"][k], runs[0][k][0]) and np.array_equal(out["dones"][k], runs[0][k][5])
+        assert np.abs(out["rewards"][k] - runs[0][k][4]).max() < 1e-9
