@@ -277,7 +277,7 @@ static int smooth_big_launch(int32_t B, int32_t NV, int32_t NT, double* coords, 
   }
   const size_t lds = sizeof(d2) * BNV + sizeof(int) * BNV;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&smooth_big_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(d2) * BNV + sizeof(int) * BNV));
   if (attr != hipSuccess) return mdq_set_error("hipFuncSetAttribute(smooth_big_kernel) failed");
   hipLaunchKernelGGL(smooth_big_kernel, dim3(B), dim3(BWG), lds, (hipStream_t)stream, NV, NT, coords, cells, nv, nt, iterations,
                      rem, rstat, iters_env, g_smooth_slab, nullptr);
