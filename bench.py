@@ -205,13 +205,40 @@ def cpu_baseline(budget_s=15.0, spinup=20):
     return out
 
 
+_REFINED = {}
+
+
+def _refined_mesh_file(name):
+    """`<name>_refined`: the lab mesh red-refined once (ys930: 3 322 vertices / 6 280 triangles, BASELINE configs[4]),
+    written once per process to a temporary .npz (the environment loads meshes from files)."""
+    if name not in _REFINED:
+        import tempfile
+        from meshdqn_amd.ipcs_batch import smooth_coords
+        from meshdqn_amd.mesh_ops import red_refine
+        from meshdqn_amd.topology import MeshTopology
+        z = np.load(os.path.join(ROOT, "tests", "golden", f"{name}.npz"))
+        rc, rcells = red_refine(smooth_coords(MeshTopology(z["coords"], z["cells"]), 50), z["cells"])
+        fd, path = tempfile.mkstemp(prefix=f"mdq_{name}_refined_", suffix=".npz")
+        os.close(fd)
+        np.savez(path, coords=rc, cells=rcells)
+        _REFINED[name] = path
+    return _REFINED[name]
+
+
 def _env_config(args, mesh=None):
+    mesh = mesh or args.mesh
+    steps = args.s1_solver_steps
+    if mesh.endswith("_refined"):
+        path = _refined_mesh_file(mesh[:-len("_refined")])
+        steps = min(steps, 200)        # (ground truth of a rate measurement: 5000 steps of the refined mesh take a minute)
+    else:
+        path = os.path.join(ROOT, "tests", "golden", f"{mesh}.npz")
     return dict(flow_config=dict(flow_params=dict(mu=1e-3, rho=1.0, inflow="constant"),
-                                 geometry_params=dict(mesh=os.path.join(ROOT, "tests", "golden", f"{mesh or args.mesh}.npz")),
+                                 geometry_params=dict(mesh=path),
                                  solver_params=dict(dt=0.001, solver_type="lu", smooth=True)),
-                agent_params=dict(solver_steps=args.s1_solver_steps, episodes=10, timesteps=10000, threshold=0.001,
+                agent_params=dict(solver_steps=steps, episodes=10, timesteps=10000, threshold=0.001,
                                   N_closest=180, gt_drag=-1, gt_time=-1, u=-1, p=-1, time_reward=0.005,
-                                  save_steps=args.s1_solver_steps // 5, goal_vertices=0.95, plot_dir=""))
+                                  save_steps=max(steps // 5, 1), goal_vertices=0.95, plot_dir=""))
 
 
 _BASE_ENVS = {}
@@ -911,6 +938,16 @@ def main(argv=None):
             cfgs["S3_full_chip"] = f3
         except Exception as exc:  # noqa: BLE001
             cfgs["S3_full_chip"] = dict(error=repr(exc))
+        try:
+            r1 = measure_env_steps(args, dev, None, 1, 0, steps=max(args.s1_steps // 5, 2), warmup=2, repeats=3, mesh=f"{args.mesh}_refined")
+            r1["what"] = ("the S1 env step (vertex removal + Delaunay restoration + smooth(50) + interpolation + forces + state graph + "
+                          "Q-forward, device-resident) on the red-refined mesh (BASELINE configs[4]: 3 322 vertices / 6 280 triangles): the "
+                          "large-mesh instances of the removal / topology kernels (tables on a slab in global memory) and the "
+                          "level-scheduled smoothing kernel - the env step of rounds 1-3 refused meshes above 1024 vertices; ground truth "
+                          "of 200 solver steps (a rate measurement)")
+            cfgs["C5_s1_refined_mesh"] = r1
+        except Exception as exc:  # noqa: BLE001
+            cfgs["C5_s1_refined_mesh"] = dict(error=repr(exc))
         try:
             cfgs["deploy_episode_s"] = measure_deploy(args, dev)
         except Exception as exc:  # noqa: BLE001

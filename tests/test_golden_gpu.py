@@ -51,17 +51,18 @@ def test_first_steps_match_golden(meshes, lib_built):
 def test_trajectory_checkpoints_match_golden(meshes, lib_built, mode):
     """5000 steps from rest at the tolerance that stands in for the reference's LU (rtol 1e-13): every 1000th step within
     1e-9 of the derived vectors (the oracle's exact-LU trajectory) - in the reproducible operator mode the flow solver
-    defaults to (-2 -> 2) AND in mode 3 (LDS atomics): measured 7e-10 / 4e-10 at worst (tools/traj_determinism.py).  The
+    defaults to (-2 -> 2) and within 3e-9 in mode 3 (LDS atomics: 1e-10 .. 1.6e-9 from run to run; tools/traj_determinism.py).  The
     5e-6 this test needed in rounds 1-3 was the Krylov stopping test at rtol 1e-10 (1e-8 .. 1.3e-6 in every mode), not the
     atomics.  The last step against the reference CSV rows (north-star tolerance 1e-4, CSV print precision 5e-8)."""
     batch, _, _ = _batch(meshes, mode=mode, rtol=1e-13, pressure_direct="device")
+    tol = 1e-9 if mode == -2 else 3e-9       # (mode 3 is reproducible to the solver tolerance only: 1e-10 .. 1.6e-9 from run to run)
     for k in range(1, 6):
         drag, lift = batch.evolve(1000)
         torch.cuda.synchronize()
         for b, n in enumerate(NAMES):
             g = FLOW[n]["steps"][str(1000 * k)]
-            assert abs(drag[b, -1].item() - g["drag"]) < 1e-9 * abs(g["drag"]), (n, k)
-            assert abs(lift[b, -1].item() - g["lift"]) < 1e-9 * abs(g["lift"]), (n, k)
+            assert abs(drag[b, -1].item() - g["drag"]) < tol * abs(g["drag"]), (n, k)
+            assert abs(lift[b, -1].item() - g["lift"]) < tol * abs(g["lift"]), (n, k)
     for b, n in enumerate(NAMES):
         assert abs(drag[b, -1].item() - KAT[n]["drag"]) < 1e-6 * abs(KAT[n]["drag"])
         assert abs(lift[b, -1].item() - KAT[n]["lift"]) < 1e-6 * abs(KAT[n]["lift"])
