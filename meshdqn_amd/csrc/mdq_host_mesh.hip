@@ -589,7 +589,7 @@ static int ipcs_topology_one(const mdq_env_topo_desc& D, const mdq_ipcs_topo_out
     if (t == 0 || ent[t].row != ent[t - 1].row) {
       if (nbo >= O.NBO) return -5;
       bo_rows[nbo++] = ent[t].row;
-      if (++own[ent[t].row % 512] > 2) return -4;
+      if (n2 <= 4096 && ++own[ent[t].row % 512] > 2) return -4;   // (a limit of mode 3's row owners: lab-sized meshes only)
     }
     bo_col[t] = ent[t].col;
     bo_src[t] = ent[t].src;
@@ -597,9 +597,10 @@ static int ipcs_topology_one(const mdq_env_topo_desc& D, const mdq_ipcs_topo_out
   }
   O.nbo[b] = nbo;
   // ---- packed per-triangle metadata of the matrix-free operators
-  if (n2 > 4096) return -1;
-  for (int i = 0; i < 6; ++i)
-    for (int t = 0; t < nt; ++t) scat[i * D.NT + t] = cd[i * D.NT + t] | (i == 0 ? ((int32_t)(cof[t] + 1) << 28) : 0);
+  // (12-bit dof ids: lab-sized meshes; a larger mesh feeds mode 5, which reads cell_dofs / cell_outflow themselves)
+  if (n2 <= 4096)
+    for (int i = 0; i < 6; ++i)
+      for (int t = 0; t < nt; ++t) scat[i * D.NT + t] = cd[i * D.NT + t] | (i == 0 ? ((int32_t)(cof[t] + 1) << 28) : 0);
   // ---- dof <- element-slot gathers (ascending slots)
   auto gather = [&](int nl, int ndof, int32_t* ptr, int32_t* src) {
     std::fill(ptr, ptr + ndof + 1, 0);

@@ -123,7 +123,7 @@ __device__ __forceinline__ EnvView env_view(const mdq_ipcs_desc& d, int b) {
   v.sl1_col = d.sl1_col + B * d.NSE1;
   v.mf_scat = d.mf_scat + B * 6 * d.NT;
   v.mf_tstride = d.N2 + 1;
-  v.mf_tptr = d.mf_tptr + B * ((d.NT + MF_CH - 1) / MF_CH) * (d.N2 + 1);
+  v.mf_tptr = d.mf_tptr ? d.mf_tptr + B * ((d.NT + MF_CH - 1) / MF_CH) * (d.N2 + 1) : nullptr;
   v.NRL = d.NRL;
   v.mf_rlist = (d.mf_rlist && d.mf_rcnt && d.NRL > 0) ? d.mf_rlist + B * ((d.NT + MF_CH - 1) / MF_CH) * d.NRL * 2 : nullptr;
   v.mf_rcnt = v.mf_rlist ? d.mf_rcnt + B * ((d.NT + MF_CH - 1) / MF_CH) : nullptr;
@@ -991,6 +991,34 @@ __device__ __forceinline__ void tile_apply_global(const EnvView& v, bool packed,
   long long t5q_ = __builtin_amdgcn_s_memtime();
   if (tid == 0 && blockIdx.x == 0) mdq_t5_trace_buf[7] += 1;
 #endif
+  if (!v.mf_tptr) {
+    // no tile maps (index data built ON THE DEVICE by mdq_env_topology's large-mesh instance, which emits the dof <-
+    // element-slot lists but no tile positions): the element results go to the slab's element scratch (6 double2 per
+    // triangle, free during the solves) and every row sums its slots in ascending order - the gather the right-hand sides use
+    double2* es2 = reinterpret_cast<double2*>(v.work);
+    for (int e = tid; e < v.nt; e += WG) {
+      ElemIdx E;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) E.dof[i] = v.cell_dofs[i * v.NT + e];
+      const Geo g = load_geo(v, e);
+      double2 ye[6];
+      op(e, g, E, (int)v.cell_outflow[e], ye);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) es2[e * 6 + i] = ye[i];
+    }
+    __syncthreads();
+    for (int row = tid; row < n; row += WG) {
+      double2 a = make_double2(0.0, 0.0);
+      for (int s = v.g2_ptr[row]; s < v.g2_ptr[row + 1]; ++s) {
+        const double2 c = es2[v.g2_src[s]];
+        a.x += c.x;
+        a.y += c.y;
+      }
+      epi(row, a.x, a.y);
+    }
+    __syncthreads();
+    return;
+  }
   for (int row = tid; row < n; row += WG) ytmp[row] = make_double2(0.0, 0.0);   // (own rows: visible to the row phases behind the barriers)
   for (int chunk = 0; chunk < nch; ++chunk) {
 #pragma unroll
@@ -4631,7 +4659,7 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
     if (d->mode != -2 && red_bytes + P.vel3_bytes <= LDS_MAX && d->N2 <= MF_ROWS * WG) mode = 3;
     // a mesh beyond the LDS-resident vectors: the element tiles with global vectors (mode 5: ~5x less memory traffic than
     // the assembled operators and no sparsity pattern), when the tile maps were handed over
-    if (mode == 0 && d->mf_scat && d->mf_tptr && d->cell_outflow && std::getenv("MDQ_NO_MODE5") == nullptr) mode = 5;
+    if (mode == 0 && d->cell_outflow && ((d->mf_scat && d->mf_tptr) || (d->g2_ptr && d->g2_src)) && std::getenv("MDQ_NO_MODE5") == nullptr) mode = 5;
     if (mode == 0) {
       // a mesh that only fits the assembled global-memory path: two workgroups per environment while the batch leaves
       // at least half of the chip idle even so (measured on ys930 red-refined, ms per step one / two workgroups: B = 1
@@ -4653,7 +4681,8 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
   if (mode == 2 && (red_bytes + P.vel2_bytes > LDS_MAX || d->N2 > MF_ROWS * WG))
     return fail_msg("matrix-free tile mode needs N2 <= 3584 and the x stage + element tile in LDS");
   if (mode == 1 && red_bytes + P.vel1_bytes > LDS_MAX) return fail_msg("LDS gather vectors do not fit");
-  if (mode == 5 && (!d->mf_scat || !d->mf_tptr || !d->cell_outflow)) return fail_msg("mode 5 needs the tile maps (mf_scat, mf_tptr) and cell_outflow");
+  if (mode == 5 && (!d->cell_outflow || !((d->mf_scat && d->mf_tptr) || (d->g2_ptr && d->g2_src))))
+    return fail_msg("mode 5 needs cell_outflow and the tile maps (mf_scat, mf_tptr) or the dof <- slot lists (g2_ptr, g2_src)");
   size_t u = P.prs_vec_bytes + (k1_lds ? P.prs_mat_bytes : 0);  // (K1 values alias the scratch vector: CG does not use it)
   const size_t vel = mode == 3 ? P.vel3_bytes : (mode == 2 ? P.vel2_bytes : (mode == 1 ? P.vel1_bytes : (mode == 5 ? tile_bytes : 0)));
   if (vel > u) u = vel;

@@ -10,6 +10,8 @@
 // sqrt / division), so every output array is bit-identical to mdq_env_topology_host's.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "../../include/meshdqn_hip.h"
 
 namespace mdq_topo {
@@ -638,10 +640,6 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   TT_STAMP(5)
   }
   if (!has_ipcs) return;
-  if constexpr (K != 1) {
-    if (tid == 0) status[b] = -7;     // (the index data of the matrix-free IPCS path packs 12-bit dof ids: K = 1 only)
-    return;
-  } else {
   __syncthreads();
 
   // ================= index data of the matrix-free IPCS path (ipcs_topology_one of the host engine)
@@ -691,15 +689,20 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     if (tid == 0) status[b] = -5;
     return;
   }
-  // entry keys in LDS (aliasing dist / poly: both dead): key = row << 24 | col << 12 | (i * 6 + j), src kept beside it
-  uint32_t* ekey = reinterpret_cast<uint32_t*>(dist);      // [nent] (<= 2048)
+  // entry keys (aliasing dist / poly: both dead): key = row << RSH | col << CSH, src kept beside it (12-bit dof ids and 32-bit
+  // keys for K = 1, 14-bit ids and 64-bit keys for the large-mesh instance)
+  using EKey = typename std::conditional<K == 1, uint32_t, uint64_t>::type;
+  constexpr int RSH = K == 1 ? 20 : 40, CSH = K == 1 ? 8 : 20;
+  constexpr EKey CMASK = K == 1 ? (EKey)0xFFF : (EKey)0xFFFFF;
+  EKey* ekey = reinterpret_cast<EKey*>(dist);              // [nent] (<= 1024 entries: 8 KB of the 8 TNV bytes of `dist`)
   int32_t* esrc = reinterpret_cast<int32_t*>(poly);        // [nent] -> spills into cntd for nent > 1024: keep it small
   if (nent > 1024) {
     if (tid == 0) status[b] = -5;
     return;
   }
   // (one thread per ENTRY: as one thread per facet the 36 reads of the cell's dofs were a chain of L2 round trips)
-  int* ofe = reinterpret_cast<int*>(R + 61440);              // [nof] outflow edges in edge order (behind `fill`)
+  constexpr int ROFE = RSEG + (2 * TNP + 16) * 4 + 8192;     // (behind cntd and `fill`; K = 1: 61 472)
+  int* ofe = reinterpret_cast<int*>(R + ROFE);               // [nof] outflow edges in edge order
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     const int e = tid * PER + i;
@@ -717,7 +720,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     const int c = eown[e] / 3, k = eown[e] % 3;
     const int rowl = q == 0 ? (k == 0 ? 1 : 0) : (q == 1 ? (k == 2 ? 1 : 2) : 3 + k);
     const int row = cd[rowl * D.NT + c], col = cd[j * D.NT + c];
-    ekey[idx] = ((uint32_t)row << 20) | ((uint32_t)col << 8);  // (src breaks ties below)
+    ekey[idx] = ((EKey)row << RSH) | ((EKey)col << CSH);  // (src breaks ties below)
     esrc[idx] = c * 36 + rowl * 6 + j;
   }
   __syncthreads();
@@ -727,7 +730,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     int32_t* bo_ptr = O.bo_ptr + Bq * (O.NBO + 1);
     int32_t* bo_col = O.bo_col + Bq * O.NBE;
     int32_t* bo_src = O.bo_src + Bq * O.NBE;
-    int* lrow = reinterpret_cast<int*>(R + 61440 + 1024);      // [nbo] rows of the outflow list (behind `ofe`)
+    int* lrow = reinterpret_cast<int*>(R + ROFE + 1024);       // [nbo] rows of the outflow list (behind `ofe`)
     // rank by counting over (row, col, src); then rows = runs of equal row
     // (four lanes per entry, a quarter of the list each: one lane per entry left most of the workgroup idle on a loop of
     //  ~450 steps)
@@ -735,7 +738,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
       const int QE = (nent + 3) >> 2;
       for (int it0 = 0; it0 < 4 * nent; it0 += TW) {
         const int it = it0 + tid, t = min(it >> 2, nent - 1), part_ = it & 3;
-        const uint32_t kt = ekey[t];
+        const EKey kt = ekey[t];
         const int st = esrc[t];
         const int q0 = part_ * QE, q1 = min(nent, q0 + QE);
         int rank = 0;
@@ -744,9 +747,9 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
         rank += __shfl_xor(rank, 1, 64);
         rank += __shfl_xor(rank, 2, 64);
         if (part_ == 0 && (it >> 2) < nent) {
-          bo_col[rank] = (int32_t)((kt >> 8) & 0xFFF);
+          bo_col[rank] = (int32_t)((kt >> CSH) & CMASK);
           bo_src[rank] = st;
-          cntd[rank] = (int32_t)(kt >> 20);  // row of the sorted entry
+          cntd[rank] = (int32_t)(kt >> RSH);  // row of the sorted entry
         }
       }
     }
@@ -777,8 +780,8 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
       misc[0] = 0;
     }
     __syncthreads();
-    // at most two outflow rows per row-owner thread of the 512-thread kernels
-    for (int t = tid; t < nbo; t += TW) {     // (from the LDS copy of the row list: as a loop of global loads of the list
+    // at most two outflow rows per row-owner thread of the 512-thread kernels (mode 3: meshes of the K = 1 instance only)
+    for (int t = tid; t < (K == 1 ? nbo : 0); t += TW) {     // (from the LDS copy of the row list: as a loop of global loads of the list
       int same = 0;                           //  just written it was ~nbo dependent L2 round trips, most of this phase)
       const int mine = lrow[t] % 512;
 #pragma unroll 8
@@ -792,14 +795,15 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     }
   }
   TT_STAMP(8)
-  // packed per-triangle metadata
-  for (int i = 0; i < 6; ++i)
-    for (int t = tid; t < nt; t += TW) scat[i * D.NT + t] = cd[i * D.NT + t] | (i == 0 ? ((int32_t)(cof[t] + 1) << 28) : 0);
+  // packed per-triangle metadata (mode 3; the large-mesh instance feeds mode 5, which reads cell_dofs / cell_outflow themselves)
+  if (K == 1)
+    for (int i = 0; i < 6; ++i)
+      for (int t = tid; t < nt; t += TW) scat[i * D.NT + t] = cd[i * D.NT + t] | (i == 0 ? ((int32_t)(cof[t] + 1) << 28) : 0);
   // dof <- element-slot gathers, ascending slots: count, scan, unordered fill and per-dof sort of the (short) lists in an
   // LDS staging array (slot ids fit 16 bits), then one coalesced copy out.  (Filling and insertion-sorting the lists
   // in global memory was 78 k cycles of dependent L2 round trips for the two lists.)
   uint16_t* stage = reinterpret_cast<uint16_t*>(R);          // [nl * nt] <= 6 TNT entries = 24 KB (blist .. cntd are dead)
-  static_assert(6 * TNT * 2 <= 20480 + (TNP + 8) * 4, "gather staging fits in front of `fill`");
+  static_assert(6 * TNT * 2 <= RSEG + (TNP + 8) * 4, "gather staging fits in front of `fill`");
   auto gather = [&](int nl, int ndof, int32_t* gptr, int32_t* gsrc) {
     for (int i = tid; i < TNS; i += TW) scanb[i] = 0;
     __syncthreads();
@@ -913,7 +917,6 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     }
   }
   TT_STAMP(6)
-  }   // (K == 1: IPCS index data)
 }
 
 }  // namespace mdq_topo
@@ -937,7 +940,6 @@ extern "C" int mdq_env_topology(const mdq_env_topo_desc* d, void* stream, int32_
     using C4 = mdq_topo::TCap<4>;
     if (d->NV > C4::NV || d->NT > C4::NT || d->NP > C4::NP)
       return mdq_set_error("mdq_env_topology: capacity above 4096 vertices / 8192 triangles / 16384 P2 dofs");
-    if (d->ipcs) return mdq_set_error("mdq_env_topology: the IPCS index data exists for meshes of at most 1024 vertices");
     // the large-mesh instance: tables on a slab in global memory (one per process, grown on demand; one stream at a time)
     const size_t per = (C4::BYTES + 255) & ~(size_t)255, need = per * (size_t)d->B;
     if (need > g_topo_slab_bytes) {
@@ -949,8 +951,8 @@ extern "C" int mdq_env_topology(const mdq_env_topo_desc* d, void* stream, int32_
       if (hipMalloc(reinterpret_cast<void**>(&g_topo_slab), need) != hipSuccess) return mdq_set_error("mdq_env_topology: cannot allocate the table slab of the large-mesh instance");
       g_topo_slab_bytes = need;
     }
-    hipLaunchKernelGGL(mdq_topo::topology_kernel<4>, dim3(d->B), dim3(mdq_topo::TW), 0, (hipStream_t)stream, *d, o, 0, status,
-                       g_topo_slab);
+    hipLaunchKernelGGL(mdq_topo::topology_kernel<4>, dim3(d->B), dim3(mdq_topo::TW), 0, (hipStream_t)stream, *d, o,
+                       d->ipcs ? 1 : 0, status, g_topo_slab);
   }
   if (hipGetLastError() != hipSuccess) return mdq_set_error("topology_kernel launch failed");
   return 0;

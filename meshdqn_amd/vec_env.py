@@ -111,16 +111,19 @@ class VecEnv2DAirfoil:
         nse1 = int(64 * deg.reshape(-1, 64).max(axis=1).sum())        # SELL-64 entries of the P1 Laplacian, initial mesh
         nse1_cap = (int(1.2 * nse1) + 63) // 64 * 64
         self.topo = HostTopologyBatch(B, NV, NT, self.NE, self.NAF, N, self.EMAX, self.polygon,
-                                      ipcs=self.flow_steps > 0 and not self.gpu_topology, nse1_cap=nse1_cap)
+                                      ipcs=self.flow_steps > 0 and not self.gpu_topology, nse1_cap=nse1_cap,
+                                      nbo_cap=max(64, 2 * (2 * int((topo0.facet_tags() == 3).sum()) + 1)))
         self.dtopo = None
+        # outflow rows of the facet term: two vertices + one edge dof per outflow facet, shared vertices counted once
+        nbo_cap = max(64, 2 * (2 * int((topo0.facet_tags() == 3).sum()) + 1))
         if self.gpu_topology:
             self.dtopo = DeviceTopologyBatch(B, NV, NT, self.NE, self.NAF, N, self.EMAX, self.polygon, self.device,
-                                             ipcs=self.flow_steps > 0 and not self.flow_overlap, nse1_cap=nse1_cap)
+                                             ipcs=self.flow_steps > 0 and not self.flow_overlap, nse1_cap=nse1_cap, nbo_cap=nbo_cap)
             if self.flow_overlap:
                 # the flow stream's own engine: a private copy of the meshes, the full topology (with the IPCS index data,
                 # which only the flow needs: 0.19 ms less on the critical path) and the IPCS step run there
                 self._ftopo = DeviceTopologyBatch(B, NV, NT, self.NE, self.NAF, N, self.EMAX, self.polygon, self.device,
-                                                  ipcs=True, nse1_cap=nse1_cap, flow_only=True)
+                                                  ipcs=True, nse1_cap=nse1_cap, flow_only=True, nbo_cap=nbo_cap)
         self._packed_host, self._packed_ev, self._pending, self._step_pending = None, torch.cuda.Event(), None, None
         self._restore_args = {}
         self._deferred_mirror = None
@@ -177,7 +180,9 @@ class VecEnv2DAirfoil:
             d.NSE1, d.NBO, d.NBE = tp.NSE1, tp.NBO, tp.NBE
             d.mu, d.rho, d.dt, d.rtol = fs.mu, fs.rho, fs.dt_value, self.flow_rtol
             d.maxit_u, d.maxit_p, d.maxit_m = 200, 4000, 200
-            d.mode, d.pd_enabled = 3, 0
+            # mode 3 (LDS-resident vectors) on the lab meshes; a mesh beyond its limits (the red-refined ones): auto, i.e. the
+            # element tiles with global vectors (mode 5, here without tile maps: the dof <- slot lists of the topology engine)
+            d.mode, d.pd_enabled = (3 if NP <= 3584 else -1), 0
             d.pcg_degree = int(getattr(self, "flow_pcg_degree", 0))
             for name, _typ in _lib.IpcsDesc._fields_:
                 if name in t:

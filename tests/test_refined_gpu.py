@@ -164,3 +164,89 @@ def test_vec_env_steps_the_refined_mesh_on_the_device(lib_built, meshes, tmp_pat
     for k in range(K):
         assert np.array_equal(out["nv"][k], runs[0][k][0]) and np.array_equal(out["dones"][k], runs[0][k][5])
         assert np.abs(out["rewards"][k] - runs[0][k][4]).max() < 1e-9
+
+
+def test_large_mesh_ipcs_index_data_is_bit_identical_to_host_engine(lib_built, meshes):
+    """The index data of the matrix-free IPCS path from the large-mesh topology instance (Dirichlet flags / values, outflow
+    cells and facet entries, dof <- element-slot lists, SELL pattern of the P1 Laplacian) against the host engine - what the
+    S3 step on the refined mesh feeds to mdq_ipcs_setup_matfree and to mode 5 of mdq_ipcs_evolve."""
+    from meshdqn_amd.mesh_ops import DeviceTopologyBatch, HostTopologyBatch, remesh_batch
+    t0, x0 = _refined(meshes)
+    tags = t0.facet_tags(x0)
+    polygon = x0[[v for v in range(t0.nv) if t0.on_boundary[v] and -0.5 < x0[v, 0] < 3 and -0.5 < x0[v, 1] < 0.5]]
+    B = 2
+    nbo_cap = 2 * (2 * int((tags == 3).sum()) + 1)
+    args = (B, t0.nv, t0.nt, t0.ne, int((tags == 1).sum()), 180, 1536, polygon)
+    hb = HostTopologyBatch(*args, ipcs=True, nbo_cap=nbo_cap)
+    for b in range(B):
+        hb.coords[b], hb.cells[b], hb.nv[b], hb.nt[b] = x0, np.sort(t0.cells, axis=1), t0.nv, t0.nt
+    interior = np.flatnonzero(~t0.on_boundary)
+    rem = np.array([-1, interior[700]], np.int32)
+    assert (remesh_batch(hb.coords, hb.cells, hb.nv, hb.nt, rem, 50, 2) == 0).all()
+    hb.run(2)
+    db = DeviceTopologyBatch(*args, device="cuda", ipcs=True, nse1_cap=hb.NSE1, nbo_cap=nbo_cap)
+    db.coords.copy_(torch.from_numpy(hb.coords)); db.cells.copy_(torch.from_numpy(hb.cells))
+    db.nv.copy_(torch.from_numpy(hb.nv)); db.nt.copy_(torch.from_numpy(hb.nt)); db.offset.copy_(torch.from_numpy(hb.offset))
+    db.run()
+    torch.cuda.synchronize()
+    gi = {k: v.cpu().numpy() for k, v in db.ti.items()}
+    hi = hb.hi
+    for b in range(B):
+        nv, nt, ne = int(hb.nv[b]), int(hb.nt[b]), int(hb.h["ne"][b])
+        n2 = nv + ne
+        assert gi["nbo"][b] == hi["nbo"][b] and hi["nbo"][b] > 64
+        nbo = int(hi["nbo"][b])
+        nbe = int(hi["bo_ptr"][b][nbo])
+        checks = dict(cell_outflow=nt, bcu_flag=n2, bcu_gx=n2, bcp_flag=nv, bo_rows=nbo, bo_ptr=nbo + 1, bo_col=nbe,
+                      bo_src=nbe, g1_ptr=nv + 1, g1_src=3 * nt, g2_ptr=n2 + 1, g2_src=6 * nt, sl1_off=(nv + 63) // 64 + 1)
+        for k, n in checks.items():
+            assert np.array_equal(gi[k][b][:n], hi[k][b][:n]), (k, b)
+        nse = int(hi["sl1_off"][b][(nv + 63) // 64])
+        assert np.array_equal(gi["sl1_col"][b][:nse], hi["sl1_col"][b][:nse])
+
+
+@pytest.mark.slow
+def test_vec_env_s3_step_on_the_refined_mesh(lib_built, meshes, tmp_path):
+    """The north-star step on the refined mesh: after every batched removal IPCS steps on every coarsened mesh (device
+    topology with index data -> mdq_ipcs_setup_matfree -> mode 5 of mdq_ipcs_evolve through the dof <- slot lists, warm start
+    = interpolated last snapshot) against the sparse-LU oracle solver on the very same mesh and start fields; and the same
+    step with the IPCS leg on the flow stream (results one step late) against the in-line one."""
+    from meshdqn_amd.env import Env2DAirfoil
+    from meshdqn_amd.vec_env import VecEnv2DAirfoil
+    from oracle.ipcs import OracleFlowSolver
+    t0, _ = _refined(meshes)
+    path = os.path.join(str(tmp_path), "ys930_refined.npz")
+    np.savez(path, coords=t0.coords, cells=t0.cells)
+    cfg = dict(flow_config=dict(flow_params=dict(mu=1e-3, rho=1.0, inflow="constant"), geometry_params=dict(mesh=path),
+                                solver_params=dict(dt=0.001, solver_type="lu", smooth=True, rtol=1e-10)),
+               agent_params=dict(solver_steps=10, episodes=10, timesteps=10000, threshold=0.001, N_closest=180, gt_drag=-1,
+                                 gt_time=-1, u=-1, p=-1, time_reward=0.005, save_steps=2, goal_vertices=0.95, plot_dir=""))
+    base = Env2DAirfoil(cfg)
+    B, K = 2, 2
+    acts = np.array([[5, 40], [180, 77]])
+    venv = VecEnv2DAirfoil(cfg, B, base_env=base, auto_reset=False, nthreads=2, flow_steps=K, flow_rtol=1e-12)
+    venv.get_state()
+    inline = []
+    for k in range(2):
+        st, rew, done, info = venv.step(acts[k])
+        inline.append((info["flow_drag"].copy(), info["flow_lift"].copy()))
+        assert (venv.flow_iters.cpu().numpy() > 0).all()
+        for b in range(B):
+            nv, nt = int(venv.nv[b]), int(venv.nt[b])
+            n2 = nv + int(venv.h["ne"][b])
+            o = OracleFlowSolver(venv.coords[b, :nv].copy(), venv.cells[b, :nt].copy(), smooth=False)
+            assert o.th.np2 == n2
+            u0 = venv.u[b, venv.S - 1, :n2].cpu().numpy()
+            o.u_n = np.concatenate([u0[:, 0], u0[:, 1]])
+            o.p_n = venv.p[b, venv.S - 1, :nv].cpu().numpy().copy()
+            for s_ in range(K):
+                uo, po, do, lo = o.evolve()
+                assert abs(info["flow_drag"][b, s_] - do) < 1e-8 * abs(do), (k, b, s_)
+                assert abs(info["flow_lift"][b, s_] - lo) < 1e-8 * abs(lo), (k, b, s_)
+    over = VecEnv2DAirfoil(cfg, B, base_env=base, auto_reset=False, nthreads=2, flow_steps=K, flow_rtol=1e-12, flow_overlap=True)
+    over.get_state()
+    over.step(acts[0])
+    _, _, _, info = over.step(acts[1])
+    assert info["flow_lag"] == 1 and np.allclose(info["flow_drag"], inline[0][0], rtol=1e-9)     # the flow of step 0, delivered late
+    last = over.flow_wait()
+    assert np.allclose(last[0], inline[1][0], rtol=1e-9) and np.allclose(last[1], inline[1][1], rtol=1e-9)
