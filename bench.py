@@ -949,6 +949,14 @@ def main(argv=None):
         except Exception as exc:  # noqa: BLE001
             cfgs["C5_s1_refined_mesh"] = dict(error=repr(exc))
         try:
+            r3 = measure_env_steps(args, dev, None, 1, 1, steps=max(args.s1_steps // 10, 2), warmup=2, repeats=3, mesh=f"{args.mesh}_refined")
+            r3["what"] = ("the S3 (north-star) env step on the red-refined mesh: the S1 step above + one IPCS step on every coarsened "
+                          "mesh on the flow stream - index data from the large-mesh topology instance, mdq_ipcs_setup_matfree, the "
+                          "element operators with global vectors (mode 5 through the dof <- slot lists), Jacobi-CG pressure solve")
+            cfgs["C5_s3_refined_mesh"] = r3
+        except Exception as exc:  # noqa: BLE001
+            cfgs["C5_s3_refined_mesh"] = dict(error=repr(exc))
+        try:
             cfgs["deploy_episode_s"] = measure_deploy(args, dev)
         except Exception as exc:  # noqa: BLE001
             cfgs["deploy_episode_s"] = dict(error=repr(exc))
