@@ -983,6 +983,26 @@ def main(argv=None):
                 return json.load(open(fp)).get(key)
             except Exception:  # noqa: BLE001
                 return None
+
+        def pmc_traffic(name, leg, kernel, source):
+            """HBM bytes per launch of `kernel` from the committed PMC summary - refused (None + the reason) when the summary is
+            missing or was collected from a different version of the kernel's source file (sha256 stamped at collection)."""
+            import hashlib
+            stamp = (prof(name, "kernel_sources_sha256") or {}).get(source)
+            try:
+                now = hashlib.sha256(open(os.path.join(ROOT, "meshdqn_amd", "csrc", source), "rb").read()).hexdigest()
+            except OSError:
+                now = None
+            val = (((prof(name, "hbm_bytes_per_launch") or {}).get(leg) or {}).get(kernel) or {}).get("corrected")
+            src = (f"profiles/{name} @ {prof(name, 'git_commit') or 'unstamped'} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                   "this command, gfx950 wide-read correction; counters cannot be read inside the run)")
+            if val is None:
+                return None, src + f" - NO figure for {kernel}"
+            if stamp is None or stamp != now:
+                return None, src + f" - REFUSED: {source} has changed since the counters were collected (sha256 differs)"
+            return val, src + f"; {source} sha256 {now[:12]} matches"
+        sm_traffic, sm_traffic_src = pmc_traffic("r04_pmc_summary.json", "s3", "mdq_smooth_lin::smooth_linear_kernel",
+                                                 "mdq_smooth_linear.hip")
         nt, nv = topo.nt, topo.nv
         insitu = s3.get("smooth_kernel_in_rollout_ms")
         sm_ms = insitu["mean"] if insitu else smk["launch_ms"]      # the launches of the timed region themselves
@@ -1039,16 +1059,14 @@ def main(argv=None):
                 "reference_published": "45.8 IPCS steps/s for 1 env (FEniCS, unknown hardware; BASELINE.md) - context only",
             },
             "roofline": {"bound": "hbm", "achieved": sm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sm_gbs / HBM_PEAK_GBS,
-                         "traffic": ((prof("r03_pmc_summary.json", "hbm_bytes_per_launch") or {}).get("s3") or {}).get(
-                             "mdq_smooth_lin::smooth_linear_kernel", {}).get("corrected"),
+                         "traffic": sm_traffic,
                          "kernel": "smooth_linear_kernel (DOLFIN smooth(50) as blocked triangular solves: 32-row block inverses built "
                                    "per launch, 22 dependent block steps per sweep, validation in parallel, limited steps repaired)",
                          "launch_ms": sm_ms, "launches_timed": insitu["launches"] if insitu else smk["launches"],
                          "launch_ms_min_max": [insitu["min"], insitu["max"]] if insitu else None,
                          "launch_ms_alone": smk["launch_ms"],
                          "last_launch_diagnostics": insitu.get("last_launch_diagnostics") if insitu else None,
-                         "traffic_source": "profiles/r03_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                           "command, gfx950 wide-read correction; counters cannot be read inside the run)",
+                         "traffic_source": sm_traffic_src,
                          "workspace_bytes_per_launch": smk.get("workspace_bytes_per_launch"),
                          "algorithmic_bytes_per_launch": smk["algorithmic_bytes_per_launch"],
                          "share_of_step": sm_ms / s3["ms_per_batched_step"],

@@ -51,6 +51,12 @@ for tag in res:
         f_ = res[tag]["FETCH_SIZE"][k]["mean"]
         w_ = res[tag].get("WRITE_SIZE", {}).get(k, dict(mean=0.0))["mean"]
         pmc.setdefault("hbm_bytes_per_launch", {}).setdefault(tag, {})[k] = dict(raw=(f_ + w_) * 1024, corrected=(2 * f_ + w_) * 1024)
+# stamp: the counters describe THESE kernel sources; bench.py refuses the traffic figure when a source has changed since
+import hashlib, os
+root = os.environ.get("GRAFT_REPO_ROOT", ".")
+pmc["kernel_sources_sha256"] = {f: hashlib.sha256(open(os.path.join(root, "meshdqn_amd/csrc", f), "rb").read()).hexdigest()
+                                for f in ("mdq_smooth_linear.hip", "mdq_ipcs.hip", "mdq_gcn.hip")}
+pmc["git_commit"] = os.environ.get("MDQ_GIT_COMMIT")   # passed in by the caller (the GPU box has no .git)
 json.dump(pmc, open(f"{out}/r04_pmc_summary.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in summ.items()}, indent=1)[:6000])
 print(json.dumps(pmc.get("hbm_bytes_per_launch", {}), indent=1)[:3000])
