@@ -2307,9 +2307,12 @@ __host__ __device__ inline LdsPlan lds_plan(int N2, int NV, int NSE1) {
   return P;
 }
 
-template <int MODE, bool K1_LDS>
+// PG: the four pressure CG vectors live in the workspace slab as well (they alias the velocity Krylov vectors, idle during
+// step 2) - a mesh whose pressure vectors exceed the LDS (NV > ~4000) still steps; modes 0 / 5 only, K1_LDS = false.
+template <int MODE, bool K1_LDS, bool PG = false>
 __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps, double* drag, double* lift,
                                                      int32_t* iters) {
+  static_assert(!PG || (!K1_LDS && (MODE == 0 || MODE == 5)), "global pressure vectors: modes 0 / 5 without the LDS matrix");
   extern __shared__ __align__(16) double smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const EnvView v = env_view(d, b);
@@ -2318,14 +2321,6 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
 
   double* red = smem;  // 64 doubles
   double* U = smem + 64;
-  // pressure view of the union
-  double* px = U;
-  double* pr = px + P.NVp;
-  double* pp = pr + P.NVp;
-  double* pq = pp + P.NVp;
-  double* lK = pq + P.NVp;                                            // [NSE1]
-  int32_t* lci = reinterpret_cast<int32_t*>(lK + d.NSE1);            // [NSE1]
-  int32_t* lso = lci + d.NSE1 + (d.NSE1 & 1);                         // [NV/64+2]
 
   // workspace carve-up (global; stays in this CU's L2 slice)
   double* w = v.work;
@@ -2337,6 +2332,14 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
   double2* vp = vh + d.N2;
   double2* vv = vp + d.N2;
   double2* vt = vv + d.N2;
+  // pressure view of the union (PG: of the idle velocity vectors; 2 N2 doubles each >= NV)
+  double* px = PG ? reinterpret_cast<double*>(vr) : U;
+  double* pr = PG ? reinterpret_cast<double*>(vh) : px + P.NVp;
+  double* pp = PG ? reinterpret_cast<double*>(vp) : pr + P.NVp;
+  double* pq = PG ? reinterpret_cast<double*>(vv) : pp + P.NVp;
+  double* lK = pq + P.NVp;                                            // [NSE1]   (K1_LDS only)
+  int32_t* lci = reinterpret_cast<int32_t*>(lK + d.NSE1);            // [NSE1]
+  int32_t* lso = lci + d.NSE1 + (d.NSE1 & 1);                         // [NV/64+2]
   double2* h1 = reinterpret_cast<double2*>(w + work_hist_offset(d.NV, d.NT, d.NE));  // u* history of the velocity solve
   double2* h2 = h1 + d.N2;
   double2* h3 = h2 + d.N2;
@@ -2492,7 +2495,7 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
       px[i] = v.p_n[i] * sd;
     }
     MDQ_STAMP(3)
-    if (d.pd_enabled && d.pd_hdr[4 * (int64_t)b + 2] > 0) {   // (nparts = 0: no factors for this environment -> Krylov)
+    if (!PG && d.pd_enabled && d.pd_hdr[4 * (int64_t)b + 2] > 0) {   // (nparts = 0: no factors for this environment -> Krylov)
       const PdView pd = pd_view(d, b);
       pressure_direct(pd, nv, pr, px, pp, pq, lK);
     } else {
@@ -2578,13 +2581,13 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
   }
 }
 
-template <int MODE, bool K1_LDS>
+template <int MODE, bool K1_LDS, bool PG = false>
 static hipError_t launch_evolve(const mdq_ipcs_desc* d, size_t lds, int nsteps, double* drag, double* lift,
                                 int32_t* iters, hipStream_t stream) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&evolve_kernel<MODE, K1_LDS>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&evolve_kernel<MODE, K1_LDS, PG>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((evolve_kernel<MODE, K1_LDS>), dim3(d->B), dim3(WG), lds, stream, *d, nsteps, drag, lift,
+  hipLaunchKernelGGL((evolve_kernel<MODE, K1_LDS, PG>), dim3(d->B), dim3(WG), lds, stream, *d, nsteps, drag, lift,
                      iters);
   return hipGetLastError();
 }
@@ -4647,8 +4650,12 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
   if (int rc = ensure_tables()) return rc;
   const LdsPlan P = lds_plan(d->N2, d->NV, d->NSE1);
   const size_t LDS_MAX = 160 * 1024, red_bytes = 64 * sizeof(double);
-  if (red_bytes + P.prs_vec_bytes > LDS_MAX) return fail_msg("mesh too large for the LDS-resident pressure vectors");
-  const bool k1_lds = !d->pd_enabled && red_bytes + P.prs_vec_bytes + P.prs_mat_bytes <= LDS_MAX;
+  // pressure CG vectors beyond the LDS: kept in the workspace slab (modes 0 / 5; Jacobi-CG only - the factorisation has
+  // its own, smaller limits and reports such a mesh through pd_status)
+  const bool pg = red_bytes + P.prs_vec_bytes > LDS_MAX;
+  // (pd_enabled with pg: the factors' own limits are far below this size - every such environment has nparts = 0 and
+  //  takes the Krylov branch anyway; a small mesh riding along in the big layout is solved by CG as well)
+  const bool k1_lds = !pg && !d->pd_enabled && red_bytes + P.prs_vec_bytes + P.prs_mat_bytes <= LDS_MAX;
   int mode = d->mode;
   const size_t tile_bytes = sizeof(double2) * 6 * MF_CH;      // mode 5: the element tile
   if (mode < 0 || mode > 5) {  // auto: fastest variant that fits
@@ -4672,7 +4679,7 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
           return 0;
         return n_;
       }();
-      if (2 * TEAM * d->B <= ncu) mode = 4;
+      if (!pg && 2 * TEAM * d->B <= ncu) mode = 4;
     }
   }
   if (kernel_ms && mode != 3) return fail_msg("per-kernel timing exists for the three-kernel mode 3 only");
@@ -4683,7 +4690,9 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
   if (mode == 1 && red_bytes + P.vel1_bytes > LDS_MAX) return fail_msg("LDS gather vectors do not fit");
   if (mode == 5 && (!d->cell_outflow || !((d->mf_scat && d->mf_tptr) || (d->g2_ptr && d->g2_src))))
     return fail_msg("mode 5 needs cell_outflow and the tile maps (mf_scat, mf_tptr) or the dof <- slot lists (g2_ptr, g2_src)");
-  size_t u = P.prs_vec_bytes + (k1_lds ? P.prs_mat_bytes : 0);  // (K1 values alias the scratch vector: CG does not use it)
+  if (pg && mode != 0 && mode != 5)
+    return fail_msg("mesh too large for the LDS-resident pressure vectors of this operator mode (use mode -1, 0 or 5)");
+  size_t u = pg ? 0 : P.prs_vec_bytes + (k1_lds ? P.prs_mat_bytes : 0);  // (K1 values alias the scratch vector: CG does not use it)
   const size_t vel = mode == 3 ? P.vel3_bytes : (mode == 2 ? P.vel2_bytes : (mode == 1 ? P.vel1_bytes : (mode == 5 ? tile_bytes : 0)));
   if (vel > u) u = vel;
   const size_t lds = red_bytes + u;
@@ -4766,11 +4775,13 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
     e = k1_lds ? launch_evolve_team<true>(d, lds, nsteps, drag, lift, iters, st)
                : launch_evolve_team<false>(d, lds, nsteps, drag, lift, iters, st);
   else if (mode == 5)
-    e = k1_lds ? launch_evolve<5, true>(d, lds, nsteps, drag, lift, iters, st)
-               : launch_evolve<5, false>(d, lds, nsteps, drag, lift, iters, st);
+    e = pg ? launch_evolve<5, false, true>(d, lds, nsteps, drag, lift, iters, st)
+           : (k1_lds ? launch_evolve<5, true>(d, lds, nsteps, drag, lift, iters, st)
+                     : launch_evolve<5, false>(d, lds, nsteps, drag, lift, iters, st));
   else
-    e = k1_lds ? launch_evolve<0, true>(d, lds, nsteps, drag, lift, iters, st)
-               : launch_evolve<0, false>(d, lds, nsteps, drag, lift, iters, st);
+    e = pg ? launch_evolve<0, false, true>(d, lds, nsteps, drag, lift, iters, st)
+           : (k1_lds ? launch_evolve<0, true>(d, lds, nsteps, drag, lift, iters, st)
+                     : launch_evolve<0, false>(d, lds, nsteps, drag, lift, iters, st));
   if (e != hipSuccess) return fail("evolve_kernel launch", e);
   return 0;
 }

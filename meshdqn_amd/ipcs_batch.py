@@ -184,7 +184,7 @@ class IpcsBatch:
         d.mu, d.rho, d.dt, d.rtol = self.mu, self.rho, self.dt, self.rtol
         d.maxit_u, d.maxit_p, d.maxit_m = self.maxit
         if int(mode) in (-1, 3) and max(p["bo_max_per_thread"] for p in per) > 2:
-            mode = 2 if int(mode) == -1 else mode
+            mode = -2 if int(mode) == -1 else mode      # (auto without the LDS-atomic mode 3)
             if int(mode) == 3:
                 raise ValueError("mode 3 supports at most 2 outflow rows per row-owner thread")
         d.mode = int(mode)

@@ -219,6 +219,37 @@ def test_refined_mesh_c5_paths(meshes, lib_built, mode):
         assert torch.equal(d2, drag) and torch.equal(l2, lift) and torch.equal(b2.u_n, batch.u_n)
 
 
+@pytest.mark.slow
+@pytest.mark.parametrize("mode", [-1, 0])
+def test_twice_refined_mesh_steps_with_global_pressure_vectors(meshes, lib_built, mode):
+    """flow_solver.py:147-159 solves a mesh of any size.  ys930 red-refined TWICE (12 924 vertices / 25 120 triangles,
+    50 968 velocity dofs per component): beyond the LDS-resident pressure vectors of every mode, so the four pressure
+    CG vectors live in the workspace slab too (evolve_kernel<*, false, PG = true>: element tiles with global vectors
+    by default, assembled SELL operators with mode 0).  Parity against the oracle for the first steps."""
+    import torch
+    from meshdqn_amd.ipcs_batch import IpcsBatch, smooth_coords
+    from meshdqn_amd.mesh_ops import red_refine
+    from meshdqn_amd.topology import MeshTopology
+    from oracle.ipcs import OracleFlowSolver
+    coords, cells = meshes["ys930"]
+    rc, rcells = red_refine(smooth_coords(MeshTopology(coords, cells), 50), cells)
+    rc, rcells = red_refine(rc, rcells)
+    topo = MeshTopology(rc, rcells)
+    assert (topo.nv, topo.nt) == (12924, 25120)
+    batch = IpcsBatch([topo], [rc], rtol=1e-12, mode=mode)
+    ora = OracleFlowSolver(rc, rcells, smooth=False)
+    for step in range(2):
+        drag, lift = batch.evolve(1)
+        uo, po, do, lo = ora.evolve()
+    torch.cuda.synchronize()
+    n2, nv = ora.th.np2, ora.th.nv
+    u = batch.u_n[0, :n2].cpu().numpy()
+    assert np.abs(np.concatenate([u[:, 0], u[:, 1]]) - uo).max() / np.abs(uo).max() < 1e-8
+    assert np.abs(batch.p_n[0, :nv].cpu().numpy() - po).max() / np.abs(po).max() < 1e-8
+    assert abs(drag[0, 0].item() - do) / abs(do) < 1e-8 and abs(lift[0, 0].item() - lo) / abs(lo) < 1e-8
+    print(f"twice refined, mode {mode}: iterations per step {batch.iters.cpu().numpy()[0] / 2.0}")
+
+
 def test_setup_matfree_matches_assemble(meshes, lib_built):
     """mdq_ipcs_setup_matfree (pattern-free operator setup of the matrix-free path) reproduces what
     mdq_ipcs_assemble writes: geometry, outflow blocks, Jacobi diagonals, lifting vectors, scaled P1 Laplacian."""
