@@ -204,6 +204,8 @@ __device__ __forceinline__ void conv_dense_small_n(const Lds& L, int n, int fin,
         }
       }
     }
+  } else if (g + r0 * G >= n) {
+    // a row group without a row (n < G on the last pooled levels: 2 or 1 rows for 4 groups) streams no weights
   } else if ((fin & 63) == 0 && (reinterpret_cast<size_t>(A) & 15) == 0 && (!ROOT || (reinterpret_cast<size_t>(X) & 15) == 0)) {
     // wide levels of the reference's widths (fin = C = 64 / 128 / 256): FBW features per block - FBW (x 2) weight loads in
     // flight per round trip instead of 16 (the pooled levels are a chain of global round trips: 8 -> 2 for C = 128 with
@@ -319,6 +321,97 @@ __device__ __forceinline__ void conv_dense_nodes(const Lds& L, int n, int fin, i
   }
 }
 
+// Form (d), the first POOLED level (8 < n <= 32 rows, fin = C): the convolution as 16 x 16 x 4 fp32 matrix-core products
+// (with one or two rows the 16-row tiles are 90 % padding and the matrix pipe itself takes longer than form (b): 9.9 k
+// against 7.6 k cycles measured).
+// In forms (a) / (b) every operand A[i][f] is one LDS address read by a whole wave, and that broadcast traffic - 2 560
+// wave-wide 16-byte reads for the 18 x 256 x 128 product of level 1 - bounded the level (37 k cycles for 10 k cycles of
+// FMA issue).  v_mfma_f32_16x16x4_f32 IS a sequential fp32 fma chain over k (tools/micro/mfma_exact.hip: 0 of 51 200
+// outputs differ from fmaf(a_k, b_k, acc) applied for k = 0, 1, 2, ... across instructions), so with chain position
+// p = 2 f + (0: lin_l on the aggregate, 1: lin_r on the node's own row) as the k index every output is bitwise what the
+// other forms compute.  The operand rows are staged once as T[i][p] behind the output rows of L.h with a row stride
+// = 4 (mod 64): lane (row m, k-slot s) reads bank 4 m + s - conflict free.  Wave w owns the 16-column block(s)
+// w, w + WGT / 64, ...: every weight is loaded exactly once per graph, KB k-steps of loads in flight.
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+// floats of the staged operands of form (d): per 16-row block 64 rows (k-slot s, row m) of NK values + 4 of padding
+__device__ __forceinline__ int mfma_stage_floats(int n, int KP) { return ((n + 15) >> 4) * 64 * ((KP >> 2) + 4); }
+template <bool ROOT>
+__device__ __forceinline__ void conv_dense_mfma(const Lds& L, int n, int fin, int C, const float* __restrict__ wl,
+                                                const float* __restrict__ b, const float* __restrict__ wr, const float* A,
+                                                const float* X) {
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int KP = ROOT ? 2 * fin : fin;          // chain positions per output
+  const int NK = KP >> 2;                       // k-steps (instructions) per output block
+  const int TS = NK + 4;                        // row stride of the staged operands: = 4 (mod 64) for NK = 64
+  float* T = L.h + ((n * (C + 1) + 3) & ~3);
+  const int lane = tid & 63, wave = tid >> 6, s = lane >> 4, m = lane & 15;
+  const int wstep = ROOT ? 2 * C : 4 * C;
+  constexpr int KB = 64;
+  // the weights of this wave's first column block: requested before the staging below (they do not depend on it)
+  float w[KB];
+  {
+    const int c0 = wave * 16;
+    const float* wp = ROOT ? ((s & 1) ? wr : wl) + (s >> 1) * C + c0 + m : wl + s * C + c0 + m;
+    if (wave < (C >> 4)) {
+#pragma unroll
+      for (int q = 0; q < KB; ++q) w[q] = (q < NK) ? wp[q * wstep] : 0.f;
+    }
+  }
+  // operands, slot-major: T[(rb * 64 + s * 16 + m) * TS + t] = chain position p = 4 t + s of row rb * 16 + m, so that lane
+  // (s, m) reads its k-steps t, t + 1, t + 2, t + 3 with ONE 16-byte LDS read (row index = lane id, stride = 4 mod 64:
+  // conflict free) instead of four 4-byte reads in front of four dependent matrix instructions
+  for (int idx = tid; idx < n * fin; idx += WGT) {
+    const int i = idx / fin, f = idx - i * fin;
+    float* tr = T + ((i >> 4) * 64 + (i & 15)) * TS;
+    if (ROOT) {
+      const int p = 2 * f;                                        // (p, p + 1: slots p & 3 and (p & 3) + 1, same t)
+      tr[(p & 3) * 16 * TS + (p >> 2)] = A[idx];
+      tr[((p & 3) + 1) * 16 * TS + (p >> 2)] = X[idx];
+    } else {
+      tr[(f & 3) * 16 * TS + (f >> 2)] = A[idx];
+    }
+  }
+  __syncthreads();
+  const bool two = n > 16;
+  const float* t0p = T + (s * 16 + min(m, n - 1)) * TS;                       // (rows past n re-read row n - 1, never stored)
+  const float* t1p = T + (64 + s * 16 + min(m, n - 17)) * TS;                 // (only read when n > 16)
+  for (int cb = wave; cb < (C >> 4); cb += WGT / 64) {
+    const int c0 = cb * 16;
+    const float* wp = ROOT ? ((s & 1) ? wr : wl) + (s >> 1) * C + c0 + m : wl + s * C + c0 + m;
+    v4f_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < NK; k0 += KB) {
+      if (cb != wave || k0 != 0) {
+#pragma unroll
+        for (int q = 0; q < KB; ++q) w[q] = (k0 + q < NK) ? wp[(k0 + q) * wstep] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < KB; q += 4)
+        if (k0 + q < NK) {                                   // (workgroup-uniform; NK is a multiple of 4 here)
+          const float4 a0 = *reinterpret_cast<const float4*>(t0p + k0 + q);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, w[q], acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, w[q + 1], acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, w[q + 2], acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, w[q + 3], acc0, 0, 0, 0);
+          if (two) {
+            const float4 a1 = *reinterpret_cast<const float4*>(t1p + k0 + q);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, w[q], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, w[q + 1], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, w[q + 2], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, w[q + 3], acc1, 0, 0, 0);
+          }
+        }
+    }
+    const float bc = b[c0 + m];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i0 = s * 4 + r, i1 = 16 + s * 4 + r;
+      if (i0 < n) L.h[i0 * (C + 1) + c0 + m] = acc0[r] + bc;
+      if (two && i1 < n) L.h[i1 * (C + 1) + c0 + m] = acc1[r] + bc;
+    }
+  }
+}
+
 // level input buffer: level 0 holds [NMAX][fin0], later levels [ceil(ratio*NMAX)][C]
 __host__ __device__ inline int mdq_gcn_xs(const mdq_gcn_net& net, int NMAX) {
   const int k1 = (int)ceil(net.ratio * (double)NMAX);
@@ -344,6 +437,28 @@ struct TapeLevel {
   int* edst;
 };
 
+// |pool_w| of every level, once per graph while the inputs are on their way: wave l walks level l's chain c = 0, 1, ...
+// (the same fmaf chain every thread used to walk at every level - 3.2 k cycles of dependent FMAs on each level's
+// critical path) and leaves the norm in L.misc[1 + l].  Needs nlevels <= 7 and the staging rows in L.h (free at kernel
+// start); returns false when they do not fit - the levels then compute their norm themselves.
+__device__ __forceinline__ bool pool_norms(const Lds& L, const mdq_gcn_net& net, int NMAX) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, C = net.C, CS = (C + 3) & ~3;
+  if (net.nlevels > 7 || (size_t)NMAX * (C + 1) < (size_t)net.nlevels * CS) return false;
+  for (int l = wave; l < net.nlevels; l += WGT / 64) {
+    float* st = L.h + l * CS;
+    const float* pw = net.levels[l].pool_w;
+    for (int c = lane; c < C; c += 64) st[c] = pw[c];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float wn = 0.f;
+#pragma unroll 16
+    for (int c = 0; c < C; ++c) wn = fmaf(st[c], st[c], wn);
+    if (lane == 0) reinterpret_cast<float*>(L.misc)[1 + l] = sqrtf(wn);
+  }
+  return true;
+}
+
 // one conv + relu + TopK pool + readout level; features in L.x ([n][fin]) are replaced by the pooled ones
 // TAPE: the training kernel's instance (keeps the rows of the kept nodes); the inference instance carries none of it
 // (One register allocation has to cover every form inlined here: rounds 2-3 carried 1.4 KB of scratch per lane - the
@@ -351,7 +466,7 @@ struct TapeLevel {
 // by graphs that never ran that form.  Now: thread id opaque per level, at most 8 rows per pass, 32 weights in flight.)
 template <bool TAPE = false>
 __device__ __forceinline__ void run_level(const Lds& L, const Level& lv, int C, double ratio, int& n, int& E, int32_t* perm, float& rmax,
-                                 float& rmean, int NMAX, const TapeLevel* tape = nullptr) {
+                                 float& rmean, int NMAX, const TapeLevel* tape = nullptr, float wn_pre = -1.f) {
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));
   const int fin = lv.fin;
@@ -411,6 +526,12 @@ __device__ __forceinline__ void run_level(const Lds& L, const Level& lv, int C, 
       conv_dense_small_fin_any<true>(L, n, fin, C, lv.wl, lv.b, lv.wr, L.agg, L.x);
     else
       conv_dense_small_fin_any<false>(L, n, fin, C, lv.wl, lv.b, nullptr, L.agg, L.x);
+  } else if (n > 8 && n <= 32 && (C & 15) == 0 && (fin & (lv.type == 0 ? 7 : 15)) == 0 && (reinterpret_cast<size_t>(L.h) & 15) == 0 &&
+             ((n * (C + 1) + 3) & ~3) + mfma_stage_floats(n, lv.type == 0 ? 2 * fin : fin) <= NMAX * (C + 1)) {   // matrix cores (form (d))
+    if (lv.type == 0)
+      conv_dense_mfma<true>(L, n, fin, C, lv.wl, lv.b, lv.wr, L.agg, L.x);
+    else
+      conv_dense_mfma<false>(L, n, fin, C, lv.wl, lv.b, nullptr, L.agg, L.x);
   } else {
     // (n <= NACC*G is guaranteed by the host-side check)
     // (staging each weight matrix in LDS behind the rows of L.h - conv_dense_small_n's `wbuf` path - was measured
@@ -443,10 +564,27 @@ __device__ __forceinline__ void run_level(const Lds& L, const Level& lv, int C, 
   for (int q = 0; q < (256 + WGT - 1) / WGT; ++q)
     if (tid + q * WGT < C) L.deg[tid + q * WGT] = pwv[q];
   __syncthreads();
-  float wn = 0.f;
+  // |w|: the same chain c = 0, 1, ... in every thread that needs it (one 16-byte LDS read per four channels; waves
+  // without a node skip it - on the pooled levels that is all but the first, and the LDS pipe is what this costs)
+  float wn = wn_pre;
+  if (wn_pre < 0.f && (tid & ~63) / 16 < n) {
+    wn = 0.f;
+    if ((C & 3) == 0 && (reinterpret_cast<size_t>(L.deg) & 15) == 0) {
+#pragma unroll 8
+      for (int c = 0; c < C; c += 4) {
+        const float4 d4 = *reinterpret_cast<const float4*>(L.deg + c);
+        wn = fmaf(d4.x, d4.x, wn);
+        wn = fmaf(d4.y, d4.y, wn);
+        wn = fmaf(d4.z, d4.z, wn);
+        wn = fmaf(d4.w, d4.w, wn);
+      }
+    } else {
 #pragma unroll 16
-  for (int c = 0; c < C; ++c) wn = fmaf(L.deg[c], L.deg[c], wn);
-  wn = sqrtf(wn);
+      for (int c = 0; c < C; ++c) wn = fmaf(L.deg[c], L.deg[c], wn);
+    }
+    wn = sqrtf(wn);
+  }
+  GT_STAMP(8)
   {
     // 16 lanes per node, each lane a strided slice of the channels, butterfly sum (relu in place + dot product with the
     // pooling weights); WGT / 16 nodes per pass.  (One thread per node walking all channels - the first version of the
@@ -470,19 +608,43 @@ __device__ __forceinline__ void run_level(const Lds& L, const Level& lv, int C, 
   __syncthreads();
   GT_STAMP(3)
   // ---- top-k by rank counting (descending score, ties by lower index = stable sort)
+  // two lanes per node, each counting over half of the scores (integer partial ranks: the sum is exact in any order),
+  // four scores per LDS read where the array is 16-byte aligned; kept[r] = the node of rank r < k (L.adj_ptr is free:
+  // the aggregation is done) for the pooled-feature loop below
   const int k = (int)ceil(ratio * (double)n);
-  for (int i = tid; i < n; i += WGT) {
-    const float si = L.score[i];
-    int rank = 0;
-#pragma unroll 8
-    for (int j = 0; j < n; ++j) {
-      const float sj = L.score[j];
-      rank += (sj > si) || (sj == si && j < i);
-    }
-    L.newid[i] = rank < k ? rank : -1;
-    if (perm) {               // TopKPooling's `perm` (kept node r of this level = node perm[r] of its input), on request
-      if (rank < k) perm[rank] = i;
-      if (i >= k) perm[i] = -1;
+  int* kept = L.adj_ptr;
+  {
+    const bool s4 = (reinterpret_cast<size_t>(L.score) & 15) == 0;
+    const int jm = min(((((n + 1) >> 1) + 3) & ~3), n), half = tid & 1;
+    for (int base = 0; base < n; base += WGT / 2) {
+      const int i = base + (tid >> 1);
+      int rank = 0;
+      if (i < n) {
+        const float si = L.score[i];
+        int j = half ? jm : 0;
+        const int j1 = half ? n : jm;
+        if (s4)
+          for (; j + 4 <= j1; j += 4) {
+            const float4 q = *reinterpret_cast<const float4*>(L.score + j);
+            rank += (q.x > si) || (q.x == si && j < i);
+            rank += (q.y > si) || (q.y == si && j + 1 < i);
+            rank += (q.z > si) || (q.z == si && j + 2 < i);
+            rank += (q.w > si) || (q.w == si && j + 3 < i);
+          }
+        for (; j < j1; ++j) {
+          const float sj = L.score[j];
+          rank += (sj > si) || (sj == si && j < i);
+        }
+      }
+      rank += __shfl_xor(rank, 1);
+      if (i < n && half == 0) {
+        L.newid[i] = rank < k ? rank : -1;
+        if (rank < k) kept[rank] = i;
+        if (perm) {             // TopKPooling's `perm` (kept node r of this level = node perm[r] of its input), on request
+          if (rank < k) perm[rank] = i;
+          if (i >= k) perm[i] = -1;
+        }
+      }
     }
   }
   __syncthreads();
@@ -509,9 +671,9 @@ __device__ __forceinline__ void run_level(const Lds& L, const Level& lv, int C, 
     __syncthreads();
   }
   // ---- pooled features x'[r][c] = h[perm r][c] * score[perm r]  -> L.x with stride C
-  for (int idx = tid; idx < n * C; idx += WGT) {
-    const int i = idx / C, c = idx - i * C, r = L.newid[i];
-    if (r >= 0) L.x[r * C + c] = L.h[i * (C + 1) + c] * L.score[i];
+  for (int idx = tid; idx < k * C; idx += WGT) {
+    const int r = idx / C, c = idx - r * C, i = kept[r];
+    L.x[idx] = L.h[i * (C + 1) + c] * L.score[i];
   }
   GT_STAMP(5)
   // ---- filter + relabel edges, preserving edge order (wave 0, ballot compaction)
@@ -597,6 +759,7 @@ __global__ __launch_bounds__(WGT) void gcn_embed_kernel(mdq_gcn_net net, int NMA
     L.esrc[e] = esrc[e0 + e];
     L.edst[e] = edst[e0 + e];
   }
+  const bool norms = pool_norms(L, net, NMAX);
   __syncthreads();
   int n = nn, E = ne;
   float rmax = 0.f, rmean = 0.f;
@@ -612,7 +775,8 @@ __global__ __launch_bounds__(WGT) void gcn_embed_kernel(mdq_gcn_net net, int NMA
     if (tid == 0 && b == 0) mdq_gcn_trace_level = l;
     __syncthreads();
 #endif
-    run_level(L, lv, C, net.ratio, n, E, perm ? perm + ((size_t)b * net.nlevels + l) * NMAX : nullptr, rmax, rmean, NMAX);
+    run_level(L, lv, C, net.ratio, n, E, perm ? perm + ((size_t)b * net.nlevels + l) * NMAX : nullptr, rmax, rmean, NMAX, nullptr,
+              norms ? reinterpret_cast<const float*>(L.misc)[1 + l] : -1.f);
   }
   if (tid < C) {
     emb[(size_t)b * 2 * C + tid] = rmax;

@@ -164,6 +164,7 @@ __global__ __launch_bounds__(WGT) void gcn_train_kernel(mdq_gcn_net net, mdq_gcn
     L.esrc[e] = D.esrc[e0 + e];
     L.edst[e] = D.edst[e0 + e];
   }
+  const bool norms = pool_norms(L, net, NMAX);
   __syncthreads();
   TP_STAMP(0)
   // ---------------------------------------------------------------- forward levels (tape: rows of the kept nodes)
@@ -191,7 +192,8 @@ __global__ __launch_bounds__(WGT) void gcn_train_kernel(mdq_gcn_net net, mdq_gcn
       nl[l] = n;
       El[l] = E;
     }
-    run_level<true>(L, lv, C, net.ratio, n, E, nullptr, rmax, rmean, NMAX, &tps[l]);
+    run_level<true>(L, lv, C, net.ratio, n, E, nullptr, rmax, rmean, NMAX, &tps[l],
+                    norms ? reinterpret_cast<const float*>(L.misc)[1 + l] : -1.f);
     if (tid == 0) kl[l] = n;
     TP_STAMP(1 + l)
   }

@@ -24,8 +24,8 @@ n = 20
 for _ in range(n):
     fused.forward_arrays(x, node_ptr, esrc, edst, eptr, N, EM)
 torch.cuda.synchronize(); lib.mdq_gcn_trace_host(buf, 0)
-names = ["build_csr", "aggregation", "dense (conv)", "relu + score", "top-k rank", "pooled features", "edge filter", "readout"]
+names = ["build_csr", "aggregation", "dense (conv)", "relu + score", "top-k rank", "pooled features", "edge filter", "readout", "(norm)"]
 tot = sum(buf[:80])
 print(f"total {tot / n:.0f} ticks per launch (graph 0)")
 for l in range(4):
-    print("level", l, " ".join(f"{names[k]}={buf[l * 10 + k] / n:.0f}" for k in range(8)))
+    print("level", l, " ".join(f"{names[k]}={buf[l * 10 + k] / n:.0f}" for k in range(9)))
