@@ -37,7 +37,7 @@ constexpr int TNPOLY = 256;
 
 // exclusive scan of a[0..n) in place (n <= PER * TW), returns the total; `part` = TW ints of scratch
 template <int PER>
-__device__ inline int scan_excl(int* a, int n, int* part) {
+__device__ __forceinline__ int scan_excl(int* a, int n, int* part) {
   const int tid = threadIdx.x;
   int loc[PER], run = 0;
 #pragma unroll
@@ -113,7 +113,9 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   constexpr int TNT = CP::NT;
   (void)TNT;
   auto hslot = [](uint32_t key) { return hslot_t<CP::HSHIFT>(key); };
-  auto scan_excl = [](int* a_, int n_, int* part_) { return mdq_topo::scan_excl<CP::PER>(a_, n_, part_); };
+  // (always inlined: with a seventh call site the compiler kept it as a FUNCTION - a call inside the kernel, 288 B of stack
+  //  per lane and every section slower)
+  auto scan_excl = [](int* a_, int n_, int* part_) __attribute__((always_inline)) { return mdq_topo::scan_excl<CP::PER>(a_, n_, part_); };
   extern __shared__ __align__(16) unsigned char lds_[];
   unsigned char* smem = K == 1 ? lds_ : slab + (size_t)blockIdx.x * ((CP::BYTES + 255) & ~(size_t)255);
   double2* X = reinterpret_cast<double2*>(smem);                              // [TNV]
@@ -380,11 +382,50 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     if (v < nv && flg[i]) blist[scanb[v]] = (uint16_t)v;
   }
   __syncthreads();
-  // boundary coordinates packed (the distance buffer is free until the next section): the comparison loop then reads
+  // Two hash SETS of the boundary vertices' x and y values (bit patterns; x + 0.0 folds -0 into +0, the one pair of
+  // different patterns that compares equal; a NaN equals nothing and is not inserted) at the end of region R, which is free
+  // here: a vertex then takes two look-ups instead of comparing with every boundary vertex (876 x ~190 x 2 comparisons,
+  // 25 k of the kernel's 175 k cycles).  The same predicate, exactly.  More boundary vertices than half a table: the loop.
+  constexpr int TSZ = 1024 * K;
+  unsigned long long* hx = reinterpret_cast<unsigned long long*>(R + 8 * HSZ - 16 * TSZ);
+  unsigned long long* hy = hx + TSZ;
+  const bool hashed = nb <= TSZ / 2;
+  auto hpos = [](unsigned long long bits) { return (int)((bits * 0x9E3779B97F4A7C15ull) >> (64 - 10 - (K == 1 ? 0 : 2))); };
+  if (hashed) {
+    for (int i = tid; i < 2 * TSZ; i += TW) hx[i] = ~0ull;
+    __syncthreads();
+    for (int j = tid; j < 2 * nb; j += TW) {
+      const double2 q = X[blist[j >> 1]];
+      const double val = (j & 1) ? q.y : q.x;
+      if (val == val) {
+        unsigned long long* tab = (j & 1) ? hy : hx;
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(val + 0.0);
+        int h = hpos(bits);
+        while (true) {
+          const unsigned long long old = atomicCAS(&tab[h], ~0ull, bits);
+          if (old == ~0ull || old == bits) break;
+          h = (h + 1) & (TSZ - 1);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  auto hfind = [&](const unsigned long long* tab, double val) {
+    if (!(val == val)) return 0;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(val + 0.0);
+    int h = hpos(bits);
+    while (true) {
+      const unsigned long long k_ = tab[h];
+      if (k_ == bits) return 1;
+      if (k_ == ~0ull) return 0;
+      h = (h + 1) & (TSZ - 1);
+    }
+  };
+  // (fallback) boundary coordinates packed (the distance buffer is free until the next section): the comparison loop reads
   // consecutive entries, independent of each other, instead of an index and a dependent gather per boundary vertex
   double2* bxy = reinterpret_cast<double2*>(dist);   // [nb] <= TNV / 2 entries fit the TNV doubles of `dist`
   const bool packed = nb <= TNV / 2;
-  if (packed)
+  if (packed && !hashed)
     for (int j = tid; j < nb; j += TW) bxy[j] = X[blist[j]];
   __syncthreads();
   for (int v = tid; v < TNS; v += TW) {
@@ -392,7 +433,9 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     if (v < nv) {
       const double px = X[v].x, py = X[v].y;
       int hit = 0;
-      if (packed) {
+      if (hashed) {
+        hit = hfind(hx, px) | hfind(hy, py);
+      } else if (packed) {
 #pragma unroll 8
         for (int j = 0; j < nb; ++j) {
           const double2 q = bxy[j];
@@ -424,24 +467,40 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   const int np_ = D.npoly;
   for (int i = tid; i < np_; i += TW) poly[i] = make_double2(D.polygon[2 * i], D.polygon[2 * i + 1]);
   __syncthreads();
-  // Four lanes per vertex, a quarter of the polygon each.  The old loop evaluated `seg_dist2` and the crossing abscissa in
-  // fp64 for EVERY (vertex, segment) pair, one LDS round trip per pair, although a vertex's distance is decided by the one
-  // or two segments next to it and its inside flag by the two segments its horizontal ray meets.  Now an fp32 estimate of
-  // every pair picks the segments that CAN hold the minimum - estimate (as a distance) no larger than the estimated
-  // distance to the nearest polygon VERTEX + 2 eta, eta = a bound on an estimate's absolute error: the true nearest
-  // segment is at most as far as the nearest vertex, so it always qualifies - and only those are evaluated with
-  // `seg_dist2`; the straddle test (exact comparisons) picks the segments whose crossing abscissa is evaluated.  Both sets
-  // are bit masks walked in wave-uniform loops (a branch inside the segment loop would run for every segment: the lanes
-  // of a wave are near different segments).  The minimum over a superset of the segments that can attain it and the
-  // parity over exactly the straddled segments are the values of the full loop, bit for bit.
-  const int QS = (((np_ + 3) >> 2) + 3) & ~3;                                 // segments per quarter (multiple of 4, <= 64)
-  const int NSEG = 4 * QS;                                                    // <= TNPOLY
+  // One lane per vertex, segments culled in GROUPS of four, waves made coherent by a counting sort.
+  // Exactness is kept the way rounds 2-3 kept it: `seg_dist2` is evaluated on a SUPERSET of the segments that can attain
+  // a vertex's minimum distance, the crossing abscissa on exactly the segments its horizontal ray straddles - so minimum
+  // and parity are the values of the full (vertex x segment) loop, bit for bit.  What changed is how the superset is found.
+  // Rounds 2-3: four lanes per vertex ran an fp32 estimate of EVERY pair (~2 000 instructions per lane, 47 waves: 88 k of the
+  // kernel's 175 k cycles, issue-bound).  Now:
+  //   (B) per vertex: the bounding circle of every group (<= 64 groups) gives the nearest group (home); fp32 estimates of
+  //       the 12 segments of home - 1 .. home + 1 give U = estimate + 2 eta, an upper bound of the true distance + eta
+  //       (eta bounds an estimate's absolute error, as before);
+  //   (C) the vertices are sorted by (ray can straddle, home): the 64 vertices of a wave sit next to the same few groups;
+  //   (D) per vertex, in that order: a group whose circle is farther than U (+ eta) cannot hold the minimum - the group
+  //       loop is wave-uniform and a group is skipped when NO lane of the wave needs it (6 - 10 of 30 remain); segments of
+  //       the others with an estimate <= U are candidates (bit masks, 32 segments at a time, walked in wave-uniform loops:
+  //       the lanes sit at different segments).  A segment attaining the minimum d* has estimate <= d* + eta <= U and lies
+  //       in a group whose circle is at most d* away: it is always a candidate.  Straddle bits only for waves that hold a
+  //       vertex inside the polygon's y range (no segment straddles the others' rays).
+  const int NG = (np_ + 3) >> 2;                                              // groups of 4 segments (<= 64)
+  const int NW = (np_ + 31) >> 5;                                             // 32-segment words (<= 8)
+  const int NSEG = 32 * NW;                                                   // <= TNPOLY
   float4* segf = reinterpret_cast<float4*>(R + RSEG);                         // [NSEG] {ax, ay, bx - ax, by - ay}
   float* segr = reinterpret_cast<float*>(R + RSEG + TNPOLY * 16);             // [NSEG] 1 / |b - a|^2
   double* ye = reinterpret_cast<double*>(R + RSEG + TNPOLY * 20);             // [NSEG + 1] y of polygon vertex i (closed)
   float* pmx = reinterpret_cast<float*>(ye + TNPOLY + 2);                     // [TW / 64] wave maxima of |polygon coordinate|
+  unsigned char* R2 = R + 8 * HSZ - 16 * 1024 * K;                            // (the look-up tables of the section above are dead)
+  uint16_t* sorder = reinterpret_cast<uint16_t*>(R2 + 4 * TNV);               // [TNV] removable vertices by (band, home)
+  uint8_t* keyv = reinterpret_cast<uint8_t*>(R2 + 6 * TNV);                   // [TNV] sort key
+  float4* grp = reinterpret_cast<float4*>(R2 + 8 * TNV);                      // [64] {cx, cy, radius, -}
+  double* yrange = reinterpret_cast<double*>(R2 + 8 * TNV + 1024);            // [4 * TW / 64] wave minima / maxima of the polygon's y, x
+  float4* chf = reinterpret_cast<float4*>(R2 + 8 * TNV + 1024 + 512);         // [64] group chord {ax, ay, bx - ax, by - ay}
+  float2* chr = reinterpret_cast<float2*>(R2 + 8 * TNV + 1024 + 512 + 1024);  // [64] {1 / |chord|^2, deviation of the group's polyline from it}
+  int* hist = scanb;                                                          // [128]
   {
     float m = 0.f;
+    double y0 = 1e300, y1 = -1e300, x0_ = 1e300, x1_ = -1e300;
     for (int i = tid; i <= NSEG; i += TW) {
       if (i < np_) {
         const double2 A = poly[i], Bp = poly[i + 1 == np_ ? 0 : i + 1];
@@ -449,6 +508,10 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
         segf[i] = make_float4((float)A.x, (float)A.y, (float)abx, (float)aby);
         segr[i] = l2 > 0.0 ? 1.0f / (float)l2 : 0.f;
         ye[i] = A.y;
+        y0 = fmin(y0, A.y);
+        y1 = fmax(y1, A.y);
+        x0_ = fmin(x0_, A.x);
+        x1_ = fmax(x1_, A.x);
         m = fmaxf(m, fmaxf(fabsf((float)A.x), fabsf((float)A.y)));
       } else {                                   // padding: far away, never straddled
         if (i < NSEG) {
@@ -459,92 +522,338 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
       }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((tid & 63) == 0) pmx[tid >> 6] = m;
+    for (int o = 32; o > 0; o >>= 1) {
+      m = fmaxf(m, __shfl_xor(m, o, 64));
+      y0 = fmin(y0, __shfl_xor(y0, o, 64));
+      y1 = fmax(y1, __shfl_xor(y1, o, 64));
+      x0_ = fmin(x0_, __shfl_xor(x0_, o, 64));
+      x1_ = fmax(x1_, __shfl_xor(x1_, o, 64));
+    }
+    if ((tid & 63) == 0) {
+      pmx[tid >> 6] = m;
+      yrange[tid >> 6] = y0;
+      yrange[TW / 64 + (tid >> 6)] = y1;
+      yrange[2 * (TW / 64) + (tid >> 6)] = x0_;
+      yrange[3 * (TW / 64) + (tid >> 6)] = x1_;
+    }
+    for (int i = tid; i < 128; i += TW) hist[i] = 0;
   }
   __syncthreads();
   float mpoly = 0.f;
+  double ylo = 1e300, yhi = -1e300, xlo = 1e300, xhi = -1e300;
 #pragma unroll
-  for (int w = 0; w < TW / 64; ++w) mpoly = fmaxf(mpoly, pmx[w]);
-  for (int it0 = 0; it0 < 4 * nrem; it0 += TW) {
-    const int it = it0 + tid, r = min(it >> 2, nrem - 1), part = it & 3;
+  for (int w = 0; w < TW / 64; ++w) {
+    mpoly = fmaxf(mpoly, pmx[w]);
+    ylo = fmin(ylo, yrange[w]);
+    yhi = fmax(yhi, yrange[TW / 64 + w]);
+    xlo = fmin(xlo, yrange[2 * (TW / 64) + w]);
+    xhi = fmax(xhi, yrange[3 * (TW / 64) + w]);
+  }
+  // (workgroup-uniform values: kept in scalar registers - as five doubles in vector registers they spilled)
+  auto uni = [](double v_) {
+    const unsigned long long u_ = (unsigned long long)__double_as_longlong(v_);
+    const unsigned lo_ = __builtin_amdgcn_readfirstlane((unsigned)u_), hi_ = __builtin_amdgcn_readfirstlane((unsigned)(u_ >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi_ << 32) | lo_));
+  };
+  ylo = uni(ylo);
+  yhi = uni(yhi);
+  xlo = uni(xlo);
+  xhi = uni(xhi);
+  mpoly = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(mpoly)));
+  const double xmg = 3.0e-14 * fmax(fabs(xlo), fabs(xhi)) + 1e-300;   // (>= the per-segment margins of the crossing test)
+  // group circles: centre of the bounding box of the group's <= 5 polygon vertices (fp32), radius = the largest distance
+  // of one of them from it, rounded up generously (the group tests below add eta on top)
+  for (int g = tid; g < NG; g += TW) {
+    float x0 = 3.0e38f, x1 = -3.0e38f, yy0 = 3.0e38f, yy1 = -3.0e38f;
+    const int i1 = min(4 * g + 4, np_);                  // last polygon vertex of the group (np_ = vertex 0 again)
+    for (int i = 4 * g; i <= i1; ++i) {
+      const double2 A = poly[i == np_ ? 0 : i];
+      x0 = fminf(x0, (float)A.x);
+      x1 = fmaxf(x1, (float)A.x);
+      yy0 = fminf(yy0, (float)A.y);
+      yy1 = fmaxf(yy1, (float)A.y);
+    }
+    const float cx = 0.5f * (x0 + x1), cy = 0.5f * (yy0 + yy1);
+    float rr = 0.f;
+    for (int i = 4 * g; i <= i1; ++i) {
+      const double2 A = poly[i == np_ ? 0 : i];
+      const float wx = (float)A.x - cx, wy = (float)A.y - cy;
+      rr = fmaxf(rr, wx * wx + wy * wy);
+    }
+    grp[g] = make_float4(cx, cy, sqrtf(rr) * 1.00001f + 1.0e-30f, 0.f);
+    // chord first - last vertex of the group and the largest distance of a vertex in between from it (the distance to a
+    // segment is convex along the polyline: attained at a vertex): dist(p, group) >= dist(p, chord) - deviation
+    const double2 P0 = poly[4 * g], P1 = poly[i1 == np_ ? 0 : i1];
+    const float cax = (float)P0.x, cay = (float)P0.y, cbx = (float)(P1.x - P0.x), cby = (float)(P1.y - P0.y);
+    const float l2 = cbx * cbx + cby * cby, rl = l2 > 0.f ? 1.0f / l2 : 0.f;
+    float dev = 0.f;
+    for (int i = 4 * g + 1; i < i1; ++i) {
+      const double2 A = poly[i];
+      const float wx = (float)A.x - cax, wy = (float)A.y - cay;
+      float t = (wx * cbx + wy * cby) * rl;
+      t = fminf(fmaxf(t, 0.f), 1.f);
+      const float ex = wx - t * cbx, ey = wy - t * cby;
+      dev = fmaxf(dev, ex * ex + ey * ey);
+    }
+    chf[g] = make_float4(cax, cay, cbx, cby);
+    chr[g] = make_float2(rl, sqrtf(dev) * 1.001f + 1.0e-30f);
+  }
+  __syncthreads();
+  auto estimate = [&](int i, float pxf, float pyf) {      // fp32 estimate of the squared distance to segment i
+    const float4 sg = segf[i];
+    const float wx = pxf - sg.x, wy = pyf - sg.y;
+    float t = (wx * sg.z + wy * sg.w) * segr[i];
+    t = fminf(fmaxf(t, 0.f), 1.f);
+    const float cx = wx - t * sg.z, cy = wy - t * sg.w;
+    return cx * cx + cy * cy;
+  };
+  TT_STAMP(6)
+  // (B) home group (nearest circle centre: a heuristic, nothing depends on it being the nearest group), sort key
+  for (int r = tid; r < nrem; r += TW) {
     const double px = X[remv[r]].x, py = X[remv[r]].y;
     const float pxf = (float)px, pyf = (float)py;
-    const int i0 = part * QS;
-    // absolute error bound of an fp32 distance estimate: <= ~30 ulp of the largest coordinate M (inputs 1 ulp each, the projection parameter 13 M / |ab| + 3.5, the closest point 17 M + 4.5 |ab| + ..., DESIGN section 4); 64 taken
-    const float eta = 64.0f * 5.9604645e-8f * fmaxf(mpoly, fmaxf(fabsf(pxf), fabsf(pyf)));
-    // pass 0: nearest polygon vertex (estimate)
-    float vmin = 3.0e38f;
-#pragma unroll 4
-    for (int k = 0; k < QS; ++k) {
-      const float4 sg = segf[i0 + k];
-      const float wx = pxf - sg.x, wy = pyf - sg.y;
-      vmin = fminf(vmin, wx * wx + wy * wy);
-    }
-    vmin = fminf(vmin, __shfl_xor(vmin, 1, 64));
-    vmin = fminf(vmin, __shfl_xor(vmin, 2, 64));
-    const float dm = sqrtf(vmin) + 2.0f * eta;
-    const float thr = dm * dm * 1.000001f;
-    // pass 1: segments that can hold the minimum, segments the ray straddles (bit k of word h: segment i0 + 32 h + k)
-    uint32_t cm[2] = {0u, 0u}, sm[2] = {0u, 0u};
-    bool sa = ye[i0] > py;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int kn = min(32, QS - 32 * h);
-#pragma unroll 4
-      for (int k = 0; k < kn; ++k) {
-        const int i = i0 + 32 * h + k;
-        const float4 sg = segf[i];
-        const float wx = pxf - sg.x, wy = pyf - sg.y;
-        float t = (wx * sg.z + wy * sg.w) * segr[i];
-        t = fminf(fmaxf(t, 0.f), 1.f);
-        const float cx = wx - t * sg.z, cy = wy - t * sg.w;
-        const float a = cx * cx + cy * cy;
-        cm[h] |= (a <= thr ? 1u : 0u) << k;
-        const bool sb = ye[i + 1] > py;
-        sm[h] |= (sa != sb ? 1u : 0u) << k;
-        sa = sb;
+    float best = 3.0e38f;
+    int home = 0;
+    for (int g = 0; g < NG; ++g) {
+      const float4 G = grp[g];
+      const float wx = pxf - G.x, wy = pyf - G.y;
+      const float dd = wx * wx + wy * wy;
+      if (dd < best) {
+        best = dd;
+        home = g;
       }
     }
+    const int key = ((py >= ylo && py < yhi && px >= xlo - xmg && px <= xhi + xmg) ? 64 : 0) + home;
+    keyv[r] = (uint8_t)key;
+    atomicAdd(&hist[key], 1);
+  }
+  __syncthreads();
+  TT_STAMP(7)
+  // (C) counting sort by key (any order inside a key: the vertices are independent of each other)
+  scan_excl(hist, 128, part);
+  __syncthreads();
+  for (int r = tid; r < nrem; r += TW) sorder[atomicAdd(&hist[keyv[r]], 1)] = (uint16_t)r;
+  __syncthreads();
+  TT_STAMP(8)
+  // (D)
+  for (int base = 0; base < nrem; base += TW) {
+    const int slot = base + tid;
+    const bool live = slot < nrem;
+    const int r = sorder[min(slot, nrem - 1)];
+    const double px = X[remv[r]].x, py = X[remv[r]].y;
+    const float pxf = (float)px, pyf = (float)py;
+    // absolute error bound of an fp32 distance estimate: <= ~30 ulp of the largest coordinate M (inputs 1 ulp each, the projection parameter 13 M / |ab| + 3.5, the closest point 17 M + 4.5 |ab| + ..., DESIGN section 4); 64 taken
+    const float eta = 64.0f * 5.9604645e-8f * fmaxf(mpoly, fmaxf(fabsf(pxf), fabsf(pyf)));
     double d2 = 1e300;
-    bool inside = false;
+    // candidate queue: up to four segment ids, a byte each (np_ <= 256); a vertex with a fifth candidate (never seen on the
+    // lab meshes) is evaluated against every segment instead.  The exact evaluations then take max-over-lanes(candidates)
+    // rounds per wave instead of a sum of per-word maxima
+    uint32_t cq = 0u;
+    int cn = 0;
+    bool ovf = false;
+    auto push = [&](int id, bool c) {
+      if (c) {
+        if (cn == 4) ovf = true;
+        else {
+          cq |= (uint32_t)id << (8 * cn);
+          ++cn;
+        }
+      }
+    };
+    // the 12 segments of the home neighbourhood, per lane (the lanes of a wave read the same few segments: sorted)
+    int gi[3];
+    float amin = 3.0e38f;
+    {
+      const int home = keyv[r] & 63;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      uint32_t m = cm[h];
-      while (__any(m != 0u)) {
-        if (m != 0u) {
-          const int i = i0 + 32 * h + __ffs((int)m) - 1;
-          m &= m - 1u;
+      for (int dg = 0; dg < 3; ++dg) {
+        int g = home + dg - 1;
+        g = g < 0 ? NG - 1 : (g >= NG ? 0 : g);
+        gi[dg] = g;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) amin = fminf(amin, estimate(4 * g + k, pxf, pyf));
+      }
+    }
+    const float U = sqrtf(amin) + 2.0f * eta;
+    // FOREIGN groups within reach of U (bit g): the home neighbourhood can miss the nearest segment - the circle centres
+    // are a heuristic, and near the trailing edge the other surface is as close.  Rare: the group loops below are
+    // wave-uniform and skip a group no lane of the wave needs.
+    unsigned long long fm = 0ull;
+    {
+      // (the chord test, not the bounding circle: at a distance comparable to a group's size the circle of nearly every
+      //  neighbour is within reach - 11 of 12 waves ran the foreign loops, 28 k cycles; 2 eta: the estimate's error twice,
+      //  once for the chord, once for the deviation)
+      const float Ue = U + 2.0f * eta;
+      for (int g = 0; g < NG; ++g) {
+        const float4 sg = chf[g];
+        const float2 cr = chr[g];
+        const float wx = pxf - sg.x, wy = pyf - sg.y;
+        float t = (wx * sg.z + wy * sg.w) * cr.x;
+        t = fminf(fmaxf(t, 0.f), 1.f);
+        const float ex = wx - t * sg.z, ey = wy - t * sg.w;
+        const float reach = Ue + cr.y;                                    // (dist(p, chord) - deviation <= U + 2 eta, squared)
+        const bool q = live && (ex * ex + ey * ey <= reach * reach * 1.000001f) && g != gi[0] && g != gi[1] && g != gi[2];
+        fm |= (unsigned long long)(q ? 1 : 0) << g;
+      }
+    }
+    const bool foreign = __any(fm != 0ull);
+    if (foreign) {
+      for (int g = 0; g < NG; ++g) {
+        const bool q = (fm >> g) & 1ull;
+        if (__any(q)) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float a = estimate(4 * g + k, pxf, pyf);
+            amin = q ? fminf(amin, a) : amin;
+          }
+        }
+      }
+    }
+    const float U2 = sqrtf(amin) + 2.0f * eta;              // (<= U: amin only went down)
+    const float thr = U2 * U2 * 1.000001f;
+    // (the 12 estimates again rather than 12 registers kept across the loops above: the kernel runs 16 waves per CU - 128
+    //  registers per lane - and spilled)
+#pragma unroll
+    for (int dg = 0; dg < 3; ++dg) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int id = 4 * gi[dg] + k;
+        push(id, live && estimate(id, pxf, pyf) <= thr);
+      }
+    }
+    if (foreign) {
+      const float Ue = U2 + 2.0f * eta;
+      for (int g = 0; g < NG; ++g) {
+        if (!__any((fm >> g) & 1ull)) continue;
+        const float4 sg = chf[g];
+        const float2 cr = chr[g];
+        const float wx = pxf - sg.x, wy = pyf - sg.y;
+        float t = (wx * sg.z + wy * sg.w) * cr.x;
+        t = fminf(fmaxf(t, 0.f), 1.f);
+        const float ex = wx - t * sg.z, ey = wy - t * sg.w;
+        const float reach = Ue + cr.y;
+        const bool q = ((fm >> g) & 1ull) && (ex * ex + ey * ey <= reach * reach * 1.000001f);
+        if (__any(q)) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float a = estimate(4 * g + k, pxf, pyf);
+            push(4 * g + k, q && a <= thr);
+          }
+        }
+      }
+    }
+    {
+      // (one copy of the exact evaluation: queue rounds first, then - wave-uniform, rare - every segment for overflowed lanes)
+      const bool anyovf = __any(ovf);
+      int it = 0;
+      while (true) {
+        const bool qrun = cn > 0, orun = ovf && it < np_;
+        if (!__any(qrun || (anyovf && orun))) break;
+        int i = it;
+        if (qrun) {
+          i = (int)(cq & 255u);
+          cq >>= 8;
+          --cn;
+        } else {
+          ++it;
+        }
+        if (qrun || orun) {
           const double2 A = poly[i], Bp = poly[i + 1 == np_ ? 0 : i + 1];
           d2 = fmin(d2, seg_dist2(px, py, A.x, A.y, Bp.x, Bp.y));
         }
       }
-      m = sm[h];
-      while (__any(m != 0u)) {
-        if (m != 0u) {
-          const int i = i0 + 32 * h + __ffs((int)m) - 1;
+    }
+    // inside test (crossing number of the horizontal ray to the right).  Only a vertex inside the polygon's bounding box
+    // can be inside: below / above it no segment straddles the ray; left of it EVERY straddled segment is crossed - an even
+    // number, the polygon is closed - and right of it none (margins as in the per-segment test below).  The sort put the
+    // vertices inside the box into waves of their own.
+    bool inside = false;
+    const bool inb = live && py >= ylo && py < yhi && px >= xlo - xmg && px <= xhi + xmg;
+    if (__any(inb)) {
+      bool sa = ye[0] > py;
+      for (int w = 0; w < NW; ++w) {
+        uint32_t sm = 0u;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+          const bool sb = ye[32 * w + k + 1] > py;
+          sm |= (sa != sb ? 1u : 0u) << k;
+          sa = sb;
+        }
+        if (!inb) sm = 0u;
+        // crossings: xin lies between the segment's end abscissae (the ray straddles it: the parameter is in [0, 1]) up to
+        // rounding - |xin_fp - xin| <= 4 eps (|A.x| + |B.x - A.x|) - so a vertex clearly left / right of BOTH ends is
+        // decided by comparisons; the division only for the lanes in between (margin 64 eps (|A.x| + |B.x|))
+        uint32_t m = sm;
+        while (__any(m != 0u)) {
+          const bool has = m != 0u;
+          const int i = min(32 * w + __ffs((int)m) - 1, np_ - 1);
           m &= m - 1u;
           const double2 A = poly[i], Bp = poly[i + 1 == np_ ? 0 : i + 1];
-          const double xin = A.x + (py - A.y) * (Bp.x - A.x) / (Bp.y - A.y);
-          if (px < xin) inside = !inside;
+          const double mg = 1.5e-14 * (fabs(A.x) + fabs(Bp.x)) + 1e-300;
+          const bool left = px < fmin(A.x, Bp.x) - mg, right = px > fmax(A.x, Bp.x) + mg;
+          if (has && left) inside = !inside;
+          const bool amb = has && !left && !right;
+          if (__any(amb)) {
+            if (amb) {
+              const double xin = A.x + (py - A.y) * (Bp.x - A.x) / (Bp.y - A.y);
+              if (px < xin) inside = !inside;
+            }
+          }
         }
       }
     }
-    d2 = fmin(d2, __shfl_xor(d2, 1, 64));
-    d2 = fmin(d2, __shfl_xor(d2, 2, 64));
-    int par = inside ? 1 : 0;
-    par ^= __shfl_xor(par, 1, 64);
-    par ^= __shfl_xor(par, 2, 64);
-    if (part == 0 && (it >> 2) < nrem) dist[r] = par ? 0.0 : sqrt(d2);
+    if (live) dist[r] = inside ? 0.0 : sqrt(d2);
   }
   __syncthreads();
   TT_STAMP(12)
-  // stable argsort: bitonic sort of (distance, index) pairs in LDS - unique keys, so the result is the order the counting
-  // sort produced (ascending distance, ties by index).  The compare-exchange stages at distance < 64 stay inside a wave's 64
-  // consecutive elements and need no workgroup barrier (a wave's LDS operations execute in order), so a sort of up to
-  // 1 024 entries pays 14 barriers for its 55 stages.  (Counting ranks - every entry against every other, four lanes per
-  // entry - was issue-bound at 45 k cycles.)
+  // Stable argsort as a BUCKET sort.  Key of an entry = the leading bits of its (non-negative) distance - 6 bits of
+  // clamped exponent (2^-40 .. 2^23; below / above: one bucket each), 5 of mantissa: 2 048 buckets, monotone in the
+  // distance.  Histogram by LDS atomics, exclusive scan, scatter by a second round of atomics (any order inside a
+  // bucket), then every entry counts the members of ITS bucket that sort before it (distance, then index: unique keys)
+  // and is stored at bucket start + count: the order of a stable argsort, exactly.  Buckets hold 1 - 5 entries on the
+  // lab meshes: ~4 k cycles against the 38 k of the 1 024-entry bitonic sort (55 LDS stages, 14 barriers) this replaces.
+  // A bucket of more than 48 entries (many equal distances, e.g. vertices inside the polygon): the bitonic sort, as before.
+  const int off = D.offset[b];
+  bool ranked = false;
   {
+    constexpr int E0 = 1023 - 40;                          // exponent of bucket group 0 (and everything below it)
+    auto bkey = [&](int i_) {
+      const uint32_t h = (uint32_t)((unsigned long long)__double_as_longlong(dist[i_]) >> 32);
+      const int e = (int)(h >> 20) - E0;
+      return e <= 0 ? 0 : (e >= 63 ? 2047 : (e << 5) | (int)((h >> 15) & 31u));
+    };
+    int* hist = scanb;                                     // [2048]
+    uint16_t* sidx = reinterpret_cast<uint16_t*>(inv);     // [nrem] entries grouped by bucket (inv is set up after this)
+    for (int i = tid; i < 2048; i += TW) hist[i] = 0;
+    if (tid == 0) misc[4] = 0;
+    __syncthreads();
+    for (int i = tid; i < nrem; i += TW) atomicAdd(&hist[bkey(i)], 1);
+    __syncthreads();
+    for (int i = tid; i < 2048; i += TW)
+      if (hist[i] > 48) misc[4] = 1;
+    __syncthreads();
+    if (misc[4] == 0) {
+      ranked = true;
+      scan_excl(hist, 2048, part);                         // bucket starts, in place
+      __syncthreads();
+      for (int i = tid; i < nrem; i += TW) sidx[atomicAdd(&hist[bkey(i)], 1)] = (uint16_t)i;   // hist[k] -> end of bucket k
+      __syncthreads();
+      for (int i = tid; i < nrem; i += TW) {
+        const int k_ = bkey(i);
+        const int q0 = k_ == 0 ? 0 : hist[k_ - 1], q1 = hist[k_];
+        const double di = dist[i];
+        int rank = q0;
+        for (int q = q0; q < q1; ++q) {
+          const int j_ = sidx[q];
+          const double dj = dist[j_];
+          rank += (dj < di) || (dj == di && j_ < i);
+        }
+        order[rank] = (uint16_t)i;
+      }
+      __syncthreads();
+    }
+  }
+  if (!ranked) {
     int P = 64;
     while (P < nrem) P <<= 1;                       // <= TNV
     for (int i = tid; i < P; i += TW) {
@@ -574,11 +883,11 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
     }
+    __syncthreads();
   }
   TT_STAMP(13)
   for (int v = tid; v < TNV; v += TW) inv[v] = -1;
   __syncthreads();
-  const int off = D.offset[b];
   int nsel = nrem - off;
   nsel = nsel > D.N ? D.N : (nsel < 0 ? 0 : nsel);
   {

@@ -21,6 +21,11 @@ if [ -z "$QUICK" ]; then
     timeout 600 rocprofv3 --pmc $C --output-format csv -d $OUT/C5_$C -- python3 $R/tools/time_c5.py pmc > $OUT/C5_$C.log 2>&1
   done
 fi
+# timelines of one batched env step (S3: both streams; S1), from the rollout timing tool
+for F in 1 0; do
+  timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/tl$F -- python3 $R/tools/time_rollout.py 128 $F 30 2 > $OUT/tl$F.log 2>&1
+  python3 $R/tools/timeline_step.py $OUT/tl$F smooth_linear_kernel -3 > $OUT/r04_timeline_s$((1 + 2 * F))_step.txt 2>&1
+done
 cd $R
 python3 - "$OUT" <<'PY'
 import csv, glob, json, shutil, sys
