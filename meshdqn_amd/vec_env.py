@@ -214,6 +214,7 @@ class VecEnv2DAirfoil:
             from .streams import role_streams
             self._flow_stream = role_streams(dev)["flow"]   # (the process's flow stream: fixed creation order, one probe)
             self._flow_ready = torch.cuda.Event()
+            self._late_handover = os.environ.get("MDQ_LATE_HANDOVER", "") == "1"      # (A / B switch of the early mesh hand-over)
             # page-locked result buffers (two: the results of step k are read while step k + 1 is in flight) + events
             self._flow_res = [dict(host=torch.zeros((2, B, self.flow_steps), dtype=torch.float64, pin_memory=True),
                                    done=torch.cuda.Event()) for _ in range(2)]
@@ -242,7 +243,7 @@ class VecEnv2DAirfoil:
             setattr(d, kk, keep[kk].data_ptr())
         return self._flow_launch(t, d, keep, out_u, out_p)
 
-    def _flow_launch(self, t, d, keep, out_u, out_p):
+    def _flow_launch(self, t, d, keep, out_u, out_p, before_evolve=None):
         if out_u is not None:
             t["u_n"].copy_(out_u[:, self.S - 1])
             t["p_n"].copy_(out_p[:, self.S - 1])
@@ -256,6 +257,8 @@ class VecEnv2DAirfoil:
                        "mdq_ipcs_factorize_pressure")
         drag = torch.empty((self.B, self.flow_steps), dtype=torch.float64, device=self.device)
         lift = torch.empty_like(drag)
+        if before_evolve is not None:       # (the set-up above reads the mesh only; the warm start is needed from here on)
+            before_evolve()
         _lib.check(self.lib.mdq_ipcs_evolve(C.byref(d), self.flow_steps, drag.data_ptr(), lift.data_ptr(),
                                             self.flow_iters.data_ptr(), _lib.stream_ptr()), "mdq_ipcs_evolve")
         self._flow_keep = keep       # device buffers the descriptor points at
@@ -276,9 +279,37 @@ class VecEnv2DAirfoil:
                  (fin["cell_dofs"], dt.t["cell_dofs"]), (fin["ne"], dt.t["ne"])]
         return fin, pairs
 
-    def _flow_start(self, fin):
+    def _flow_handover_mesh(self):
+        """Device-resident step, EARLY half of the hand-over: meshes + the main engine's edge numbering are copied (one
+        launch on the main stream) right after the main topology run, so that the flow stream can derive its own topology
+        and the operator set-up while the main stream still interpolates / evaluates the step - handing everything over
+        inside `mdq_env_finish` left the flow stream idle for ~60 us of every step (profiles/r04_timeline_s3_step.txt).
+        The warm start (u / p windows) follows in `mdq_env_finish` as before."""
+        dt = self.dtopo
+        main = torch.cuda.current_stream(self.device)
+        fin = self._flow_in[self._flow_n % 2]
+        if self._flow_n >= 2 and self._flow_prev is not None:          # flow k - 2 read this input set (long finished)
+            main.wait_event(self._flow_res[self._flow_n % 2]["done"])
+        pairs = [(fin["coords"], dt.coords), (fin["cells"], dt.cells), (fin["nv"], dt.nv), (fin["nt"], dt.nt),
+                 (fin["cell_dofs"], dt.t["cell_dofs"]), (fin["ne"], dt.t["ne"])]
+        n = len(pairs)
+        vp, i64 = C.c_void_p * n, C.c_int64 * n
+        nb = [src.numel() * src.element_size() for _, src in pairs]
+        for dst, src in pairs:
+            if dst.shape != src.shape or dst.dtype != src.dtype or not dst.is_contiguous() or not src.is_contiguous():
+                raise ValueError("flow hand-over: buffers of different shapes")
+        _lib.check(self.lib.mdq_copy_strided(n, vp(*[d_.data_ptr() for d_, _ in pairs]), vp(*[s_.data_ptr() for _, s_ in pairs]),
+                                             i64(*([1] * n)), i64(*nb), i64(*nb), i64(*nb), _lib.stream_ptr()), "mdq_copy_strided")
+        if getattr(self, "_flow_mesh_ready", None) is None:
+            self._flow_mesh_ready = torch.cuda.Event()
+        self._flow_mesh_ready.record(main)
+        self._flow_fin_early = fin
+
+    def _flow_start(self, fin, mesh_early=False):
         """Second half: the hand-over is enqueued on the main stream - topology (edges from the main engine), matrix-free
-        set-up and the IPCS step(s) follow on the flow stream; results land in page-locked memory."""
+        set-up and the IPCS step(s) follow on the flow stream; results land in page-locked memory.  `mesh_early`: the
+        meshes were handed over by `_flow_handover_mesh` - topology and set-up wait for THAT, only the IPCS step for the
+        rest."""
         ft = self._ftopo
         t, d = self.flow_ts[0], self.flow_descs[0]
         main = torch.cuda.current_stream(self.device)
@@ -293,13 +324,14 @@ class VecEnv2DAirfoil:
         t["u_n"], t["p_n"] = fin["u_n"], fin["p_n"]
         res = self._flow_res[self._flow_n % 2]
         with torch.cuda.stream(self._flow_stream):
-            self._flow_stream.wait_event(self._flow_ready)
+            self._flow_stream.wait_event(self._flow_mesh_ready if mesh_early else self._flow_ready)
             fe = getattr(self, "flow_events", None)     # (tools: HIP events around the leg, on the flow stream)
             if fe is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             ft.run(check=False)                  # (same meshes, same deterministic kernel as the main stream's run)
-            drag, lift = self._flow_launch(t, d, keep, None, None)
+            drag, lift = self._flow_launch(t, d, keep, None, None,
+                                           (lambda: self._flow_stream.wait_event(self._flow_ready)) if mesh_early else None)
             if fe is not None:
                 e1.record()
                 fe.append((e0, e1))
@@ -427,7 +459,7 @@ class VecEnv2DAirfoil:
         self._refresh_launch()
         self._refresh_collect()
 
-    def _refresh_launch(self, readback=True, defer_flow=False):
+    def _refresh_launch(self, readback=True, defer_flow=False, after_topology=None):
         """Everything of `_refresh` that is enqueued on the stream, up to the asynchronous read-back (`readback=False`:
         the device-resident rollout keeps the results on the device)."""
         dev, h = self.device, self.h
@@ -435,6 +467,8 @@ class VecEnv2DAirfoil:
         if self.gpu_topology:
             dt = self.dtopo
             dt.run(check=False)                     # status is read back with the other results below
+            if after_topology is not None:
+                after_topology()
             t_pts, np1 = dt.t["points"], dt.nv
             npts, npts_extra = np1, dt.t["ne"]          # (P2 points = vertices + edges: added inside the kernel)
         else:
@@ -856,17 +890,22 @@ class VecEnv2DAirfoil:
         if tm is not None:
             e1.record()
             tm.append((e0, e1))
-        self._refresh_launch(readback=False, defer_flow=True)
+        flow = self.flow_steps > 0 and self.flow_overlap
+        early = flow and self.gpu_topology and not self._late_handover
+        self._refresh_launch(readback=False, defer_flow=True, after_topology=self._flow_handover_mesh if early else None)
         # ---- the end of the step in one launch
         x = torch.empty((B, N, 2 + 3 * S), dtype=torch.float32, device=self.device)
         d = self._finish_desc(ro, k, x)
         fin = None
-        if self.flow_steps > 0 and self.flow_overlap:
+        if flow and early:
+            fin = self._flow_fin_early
+            self._finish_handover(d, [(fin["u_n"], self.u[:, self.S - 1]), (fin["p_n"], self.p[:, self.S - 1])])
+        elif flow:
             fin, pairs = self._flow_handover(self.u, self.p)
             self._finish_handover(d, pairs)
         _lib.check(lib.mdq_env_finish(C.byref(d), sp()), "mdq_env_finish")
         if fin is not None:
-            self._flow_start(fin)
+            self._flow_start(fin, mesh_early=early)
         ro["si"] ^= 1
         ro["state"] = dict(x=x, node_ptr=self._node_ptr, edge_src_pad=dt.t["edge_src"], edge_dst_pad=dt.t["edge_dst"],
                            nedges_dev=dt.t["nedges"])
