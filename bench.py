@@ -53,6 +53,14 @@ _WARMED = False
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def prof_early(name, key):
+    """A key of a committed summary under profiles/ (None when absent)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name))).get(key)
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def _profiler_attached():
     """The environment test of `meshdqn_amd.streams.profiler_attached` (kept in step with it by tests/test_streams_cpu.py;
     repeated here because the CPU-baseline interpreters do not import torch)."""
@@ -967,10 +975,17 @@ def main(argv=None):
             c5, b5 = measure_s2(args, dev, None, 1, [rt] * B, [rc_] * B, 20, 5, 100)
             it5 = np.tile(np.array([[c5["krylov_iters_per_step"][k] for k in ("velocity_bicgstab", "pressure", "correction_cg")]]), (B, 1))
             by5 = b5.algorithmic_bytes_per_step(it5)
-            c5.update(what="C5: S2 on ys930 red-refined once (assembled SELL path: the mesh does not fit the LDS-resident modes), "
-                           "100 spin-up steps from rest", vertices=int(rt.nv), triangles=int(rt.nt),
+            c5.update(what="C5: S2 on ys930 red-refined once (the mesh does not fit the LDS-resident modes: auto mode takes the element "
+                           "tiles with GLOBAL vectors, mode 5 - bitwise reproducible; round 3 ran the assembled SELL operators here, "
+                           "6.65 k env-steps/s), 100 spin-up steps from rest; Jacobi-CG pressure solve (the factorisation's limits are "
+                           "below this size)", vertices=int(rt.nv), triangles=int(rt.nt),
                       survey_csr_bytes_per_step=by5, survey_equivalent_GBs=by5 / (c5["ms_per_step"] * 1e-3) / 1e9,
-                      frac_of_hbm_peak=by5 / (c5["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                      survey_equivalent_over_hbm_peak=by5 / (c5["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      measured_hbm_bytes_per_launch=(((prof_early("r04_pmc_summary.json", "hbm_bytes_per_launch") or {}).get("c5") or {})
+                                                     .get("mdq::evolve_kernel<5, false, false>")),
+                      note="survey_* = the bytes an assembled-CSR implementation would stream (SURVEY 8(d) convention) over the step "
+                           "time - NOT a roofline fraction of this kernel; measured_hbm_bytes_per_launch = rocprofv3 FETCH_SIZE + "
+                           "WRITE_SIZE of the same kernel (profiles/r04_pmc_summary.json; one launch = one step of 128 environments)")
             del b5
             cfgs["C5_s2_refined_mesh"] = c5
         except Exception as exc:  # noqa: BLE001

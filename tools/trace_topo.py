@@ -25,8 +25,9 @@ for _ in range(n):
     venv.step(rng.integers(0, 181, 128))
 torch.cuda.synchronize(); lib.mdq_topo_trace_host(buf, 0)
 names = ["load + hash init", "edges (hash, first-appearance ids)", "P2 points, boundary, facet tags", "removable", "polygon distances + argsort + window",
-         "state graph", "IPCS: SELL pattern of the P1 Laplacian (tail)", "IPCS: Dirichlet data", "IPCS: outflow entries", "IPCS: packed metadata",
-         "IPCS: gather lists P1", "IPCS: gather lists P2", "(of 4) polygon distances", "(of 4) argsort", "(of 8) facet scan + entries", "(of 8) entry sort"]
+         "state graph", "IPCS: SELL pattern (tail) + [distances: segments, groups, chords]", "IPCS: Dirichlet data + [distances: home groups, keys]",
+         "IPCS: outflow entries + [distances: counting sort]", "IPCS: packed metadata",
+         "IPCS: gather lists P1", "IPCS: gather lists P2", "(of 4) polygon distances: candidates, exact evaluations, inside test (+ slots 6-8 in brackets)", "(of 4) argsort (bucket sort)", "(of 8) facet scan + entries", "(of 8) entry sort"]
 tot = sum(buf[:16])
 print(f"topology_kernel, mesh 0: {tot / n:.0f} ticks per launch")
 for k, nm in enumerate(names):
