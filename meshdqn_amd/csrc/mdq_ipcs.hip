@@ -2663,7 +2663,8 @@ __global__ void reset_history_kernel(mdq_ipcs_desc d, int32_t* iters) {
   double2* h1 = reinterpret_cast<double2*>(w + work_hist_offset(d.NV, d.NT, d.NE));
   double* ccnt = reinterpret_cast<double*>(h1 + 3 * (int64_t)d.N2);                  // mode 3: correction ring
   ccnt[0] = ccnt[1] = ccnt[2] = ccnt[3] = 0.0;
-  reinterpret_cast<double*>(h1 + 5 * (int64_t)d.N2)[0] = 0.0;                        // modes 0-2, 4: hcnt
+  reinterpret_cast<double*>(h1 + 5 * (int64_t)d.N2)[0] = 0.0;                        // modes 0-2, 4, 5: hcnt
+  reinterpret_cast<double*>(h1 + 5 * (int64_t)d.N2)[1] = 0.0;                        // mode 2: corrections stored
   if (iters) iters[3 * b] = iters[3 * b + 1] = iters[3 * b + 2] = 0;
 }
 
@@ -3127,6 +3128,19 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
   double* escr1 = w;
   double2* xs = reinterpret_cast<double2*>(w + 12 * (int64_t)d.NT);  // u* for the element loops of steps 2/3
   double* pnew = reinterpret_cast<double*>(xs + 6 * (int64_t)d.N2);
+  // initial guesses extrapolated in time (round 4; the three-kernel mode 3 has had them since round 1): the last five
+  // tentative velocities (same slots and counter as evolve_kernel: h1 = newest) and a ring of the last three velocity
+  // corrections u_{n+1} - u* in the Krylov-vector slots this kernel does not use (its vectors live in registers).  Every
+  // row is read and written by its owner only.  Same operations in the same order in every run: still bitwise reproducible.
+  double2* h1 = reinterpret_cast<double2*>(w + work_hist_offset(d.NV, d.NT, d.NE));
+  double2* h2 = h1 + d.N2;
+  double2* h3 = h2 + d.N2;
+  double2* h4 = h3 + d.N2;
+  double2* h5 = h4 + d.N2;
+  double* hcnt = reinterpret_cast<double*>(h5 + d.N2);   // [0]: tentative velocities stored, [1]: corrections stored
+  double2* c1 = xs + 2 * (int64_t)d.N2;                  // newest correction
+  double2* c2 = c1 + d.N2;
+  double2* c3 = c2 + d.N2;
 
   const int nsl1 = (nv + 63) >> 6;
   const int32_t* so1 = K1_LDS ? lso : v.sl1_off;
@@ -3158,6 +3172,7 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
     // rh (constant) live in global memory, touched by their row owner only (coalesced, L2 resident).
     double2* xg = xs;
     double2* rhg = reinterpret_cast<double2*>(w + 12 * (int64_t)d.NT) + d.N2;
+    const int nhist = (int)hcnt[0], ncorr = (int)hcnt[1];
     // Jacobi row scaling of the velocity system with the Dirichlet flag folded in (0 = constrained row)
     // (kept in fp32: any positive row scaling is a valid left preconditioner and the solution of
     // D^-1 A x = D^-1 b does not depend on it; fp32 halves its register footprint)
@@ -3194,6 +3209,33 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
           y);
     }
     MDQ_STAMP(0)
+    // initial guess: u_n, or the polynomial extrapolation in time of the stored tentative velocities (evolve_kernel's
+    // formulas); it satisfies the Dirichlet values.  (A rolled loop of its own: inside the unrolled row loop below its five
+    // history rows per unrolled row went to scratch.)
+#pragma unroll 1
+    for (int row = tid; row < n2; row += WG) {
+      double2 x0 = v.u_n[row];
+      if (nhist >= 2) {
+        const double2 us1 = h1[row], us2 = h2[row];
+        x0 = make_double2(2.0 * us1.x - us2.x, 2.0 * us1.y - us2.y);
+        if (nhist >= 3) {
+          const double2 us3 = h3[row];
+          x0 = make_double2(3.0 * (us1.x - us2.x) + us3.x, 3.0 * (us1.y - us2.y) + us3.y);
+          if (nhist >= 4) {
+            const double2 us4 = h4[row];
+            x0 = make_double2(4.0 * (us1.x + us3.x) - 6.0 * us2.x - us4.x, 4.0 * (us1.y + us3.y) - 6.0 * us2.y - us4.y);
+            if (nhist >= 5) {
+              const double2 us5 = h5[row];
+              x0 = make_double2(5.0 * (us1.x - us4.x) - 10.0 * (us2.x - us3.x) + us5.x,
+                                5.0 * (us1.y - us4.y) - 10.0 * (us2.y - us3.y) + us5.y);
+            }
+          }
+        }
+      }
+      if (v.bcu_flag[row] != 0) x0 = make_double2(v.bcu_gx[row], 0.0);
+      xg[row] = x0;
+      stage[row] = x0;
+    }
     double acc[2] = {0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < MF_ROWS; ++k) {
@@ -3201,9 +3243,6 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
       if (row < n2) {
         const bool fl = v.bcu_flag[row] != 0;
         const double2 g = make_double2(v.bcu_gx[row], 0.0);
-        const double2 x0 = fl ? g : v.u_n[row];  // initial guess satisfies the Dirichlet values
-        xg[row] = x0;
-        stage[row] = x0;
         // |D^-1 b|^2 with b = f - lift (free) / g (constrained): same norm as the assembled path
         const double2 l = v.lift1[row];
         const double2 bi = fl ? g : make_double2((y[k].x - l.x) * idg[k].x, (y[k].y - l.y) * idg[k].y);
@@ -3350,6 +3389,15 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
       }
     }
     __syncthreads();  // xg (= xs, u*) complete: the element loops of steps 2 and 3 gather it
+#pragma unroll 1
+    for (int row = tid; row < n2; row += WG) {   // shift the history, newest first: h1 = u* of this step (own rows)
+      if (nhist >= 4) h5[row] = h4[row];
+      if (nhist >= 3) h4[row] = h3[row];
+      if (nhist >= 2) h3[row] = h2[row];
+      if (nhist >= 1) h2[row] = h1[row];
+      h1[row] = xs[row];
+    }
+    if (tid == 0) hcnt[0] = (double)(nhist < 5 ? nhist + 1 : 5);
     MDQ_STAMP(2)
 
     // ================= step 2: pressure (assembled K1 in SELL form, LDS resident)
@@ -3382,6 +3430,23 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
     __syncthreads();
 
     // ================= step 3: velocity correction (mass solve, both components)
+#pragma unroll 1
+    for (int row = tid; row < n2; row += WG) {   // predicted correction of the own rows -> rhg (the shadow residual is dead here)
+      double2 dp_ = make_double2(0.0, 0.0);
+      if (ncorr >= 1) {
+        const double2 d1 = c1[row];
+        dp_ = d1;
+        if (ncorr >= 2) {
+          const double2 d2 = c2[row];
+          dp_ = make_double2(2.0 * d1.x - d2.x, 2.0 * d1.y - d2.y);
+          if (ncorr >= 3) {
+            const double2 d3 = c3[row];
+            dp_ = make_double2(3.0 * (d1.x - d2.x) + d3.x, 3.0 * (d1.y - d2.y) + d3.y);
+          }
+        }
+      }
+      rhg[row] = dp_;
+    }
     {
       const double* pold = v.p_n;
       tile_accumulate(
@@ -3402,7 +3467,13 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
 #pragma unroll
     for (int k = 0; k < MF_ROWS; ++k) {
       const int row = tid + k * WG;
-      x[k] = row < n2 ? xs[row] : make_double2(0.0, 0.0);  // u* (own rows)
+      // u* (own rows) + the correction extrapolated from the ring (written to rhg by the rolled loop in front of the
+      // right-hand side; 0 on constrained rows: the corrections vanish there)
+      x[k] = make_double2(0.0, 0.0);
+      if (row < n2) {
+        const double2 us = xs[row], dp_ = rhg[row];
+        x[k] = make_double2(us.x + dp_.x, us.y + dp_.y);
+      }
     }
     // symmetric Jacobi scaling S^-1 of the mass system, 0 on constrained rows
     double ism[MF_ROWS];
@@ -3502,6 +3573,14 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
       const int row = tid + k * WG;
       if (row < n2) v.u_n[row] = (ism[k] != 0.0) ? make_double2(x[k].x * ism[k], x[k].y * ism[k]) : x[k];
     }
+#pragma unroll 1
+    for (int row = tid; row < n2; row += WG) {   // ring of corrections, newest first (own rows: written just above)
+      const double2 un = v.u_n[row], us = xs[row];
+      if (ncorr >= 2) c3[row] = c2[row];
+      if (ncorr >= 1) c2[row] = c1[row];
+      c1[row] = make_double2(un.x - us.x, un.y - us.y);
+    }
+    if (tid == 0) hcnt[1] = (double)(ncorr < 3 ? ncorr + 1 : 3);
     for (int i = tid; i < nv; i += WG) v.p_n[i] = pnew[i];
     __syncthreads();
     double dr, li;
