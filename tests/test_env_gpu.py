@@ -908,13 +908,14 @@ def test_stream_calibration_keeps_a_working_flow_stream_and_resets_the_envs(lib_
     assert any(e["event"] == "flow stream calibrated" for e in streams.LOG)
 
 
-@pytest.mark.parametrize("kind", ["star", "far", "sliver", "dense"])
+@pytest.mark.parametrize("kind", ["star", "far", "sliver", "dense", "ring"])
 def test_device_closest_ranking_equals_host_engine_for_other_polygons(lib_built, meshes, kind):
     """The N-closest ranking of `mdq_env_topology` (fp32 estimates pick the polygon segments that can hold a vertex's
     minimum distance and the segments its ray straddles; only those are evaluated exactly) against the host engine's full
     fp64 loop, bit for bit, for polygons that stress the selection: a star that swallows part of the mesh (vertices inside:
     distance 0 and ties broken by index), a small polygon far outside (every distance large, all segments nearly
-    equidistant), a sliver with near-degenerate segments, a dense polygon with the capacity's 256 points."""
+    equidistant), a sliver with near-degenerate segments, a dense polygon with the capacity's 256 points, a regular polygon centred on a
+    vertex (all segments equidistant: the candidate queue overflows)."""
     from meshdqn_amd.ipcs_batch import smooth_coords
     from meshdqn_amd.mesh_ops import DeviceTopologyBatch, HostTopologyBatch
     from meshdqn_amd.topology import MeshTopology
@@ -935,6 +936,12 @@ def test_device_closest_ranking_equals_host_engine_for_other_polygons(lib_built,
         polygon = np.concatenate([np.stack([xs, 0.2 + 1e-9 * np.sin(40 * xs)], axis=1),
                                   np.stack([xs[::-1], 0.2 + 1e-7 + 1e-9 * np.cos(33 * xs[::-1])], axis=1),
                                   [[0.3, 0.2 + 5e-8], [0.3, 0.2 + 5e-8]]])        # (a repeated point: a degenerate segment)
+    elif kind == "ring":
+        # a regular 64-gon centred ON an interior vertex: for that vertex every segment is equally far (more candidates than
+        # the kernel's four-slot queue holds: its every-segment path), its neighbours sit near the centre too
+        c = x0[np.flatnonzero(~t0.on_boundary)[400]]
+        th = np.linspace(0, 2 * np.pi, 64, endpoint=False)
+        polygon = np.stack([c[0] + 0.11 * np.cos(th), c[1] + 0.11 * np.sin(th)], axis=1)
     else:
         th = np.linspace(0, 2 * np.pi, 256, endpoint=False)
         polygon = np.stack([1.1 + 0.5 * np.cos(th) * (1 + 0.05 * np.sin(9 * th)), 0.2 + 0.1 * np.sin(th)], axis=1)
