@@ -156,7 +156,8 @@ typedef struct mdq_ipcs_desc {
      all N2 (12 924 on the refined ys930) */
   const int32_t* mf_rlist;     /* [B][NCH][NRL][2] */
   const int32_t* mf_rcnt;      /* [B][NCH] touched rows of the chunk */
-  int32_t NRL, _pad_rl;
+  int32_t NRL, rl_flags;             /* rl_flags = 1: bit 31 / bit 30 of a list entry's row word mark the FIRST / LAST chunk that
+                                        touches the row, and every row < n2 is touched by some chunk (ABI 5, round 4) */
 } mdq_ipcs_desc;
 
 /* doubles of workspace needed for a descriptor with the given capacities */

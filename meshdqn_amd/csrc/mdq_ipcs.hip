@@ -71,7 +71,7 @@ struct EnvView {
   const int32_t *mf_scat, *mf_tptr;
   int mf_tstride;  // N2+1
   const int32_t *mf_rlist, *mf_rcnt;   // mode 5: touched rows per chunk (or null)
-  int NRL;
+  int NRL, rl_flags;
   const int32_t *g2_ptr, *g2_src, *g1_ptr, *g1_src;
   const uint8_t* bcu_flag;
   const double* bcu_gx;
@@ -125,6 +125,7 @@ __device__ __forceinline__ EnvView env_view(const mdq_ipcs_desc& d, int b) {
   v.mf_tstride = d.N2 + 1;
   v.mf_tptr = d.mf_tptr ? d.mf_tptr + B * ((d.NT + MF_CH - 1) / MF_CH) * (d.N2 + 1) : nullptr;
   v.NRL = d.NRL;
+  v.rl_flags = d.rl_flags;
   v.mf_rlist = (d.mf_rlist && d.mf_rcnt && d.NRL > 0) ? d.mf_rlist + B * ((d.NT + MF_CH - 1) / MF_CH) * d.NRL * 2 : nullptr;
   v.mf_rcnt = v.mf_rlist ? d.mf_rcnt + B * ((d.NT + MF_CH - 1) / MF_CH) : nullptr;
   v.g2_ptr = d.g2_ptr + B * (d.N2 + 1);
@@ -1019,7 +1020,13 @@ __device__ __forceinline__ void tile_apply_global(const EnvView& v, bool packed,
     __syncthreads();
     return;
   }
-  for (int row = tid; row < n; row += WG) ytmp[row] = make_double2(0.0, 0.0);   // (own rows: visible to the row phases behind the barriers)
+  // rl_flags: the touched-row lists mark the first / last chunk of every row - no zero fill and no read at the first touch
+  // (9.29 -> 9.07 ms per step of 128 refined meshes).  Running the caller's epilogue at the LAST touch and dropping the pass
+  // over the rows at the end (-DMDQ_T5_LAST_EPI: two more vector streams saved) was measured SLOWER, 10.52 ms: the epilogue's
+  // own loads then sit one row at a time inside the row loop instead of four rows in flight
+  const bool rlf = v.mf_rlist && v.rl_flags != 0;
+  if (!rlf)
+    for (int row = tid; row < n; row += WG) ytmp[row] = make_double2(0.0, 0.0);   // (own rows: visible to the row phases behind the barriers)
   for (int chunk = 0; chunk < nch; ++chunk) {
 #pragma unroll
     for (int j = 0; j < MF_EPT; ++j) {
@@ -1056,17 +1063,25 @@ __device__ __forceinline__ void tile_apply_global(const EnvView& v, bool packed,
 #pragma unroll
         for (int k = 0; k < RB; ++k) en[k] = rl[min(k0 + k * WG, nr - 1)];
 #pragma unroll
-        for (int k = 0; k < RB; ++k) a[k] = ytmp[en[k].x];
+        for (int k = 0; k < RB; ++k) {
+          a[k] = make_double2(0.0, 0.0);
+          if (!(rlf && en[k].x < 0)) a[k] = ytmp[en[k].x & 0x3FFFFFFF];
+        }
 #pragma unroll
         for (int k = 0; k < RB; ++k) {
           if (k0 + k * WG < nr) {
-            const int lo = en[k].y & 0xFFFF, cnt = en[k].y >> 16;
+            const int lo = en[k].y & 0xFFFF, cnt = en[k].y >> 16, row = en[k].x & 0x3FFFFFFF;
             for (int j = lo; j < lo + cnt; ++j) {
               const double2 c = es[j];
               a[k].x += c.x;
               a[k].y += c.y;
             }
-            ytmp[en[k].x] = a[k];
+#ifdef MDQ_T5_LAST_EPI
+            if (rlf && (en[k].x & 0x40000000)) epi(row, a[k].x, a[k].y);
+            else ytmp[row] = a[k];
+#else
+            ytmp[row] = a[k];
+#endif
           }
         }
       }
@@ -1105,6 +1120,9 @@ __device__ __forceinline__ void tile_apply_global(const EnvView& v, bool packed,
   }
   // epilogue: the sums of a batch of own rows are requested together (the caller's own loads follow row by row)
   constexpr int EB = 4;
+#ifdef MDQ_T5_LAST_EPI
+  if (!rlf)
+#endif
   for (int row0 = tid; row0 < n; row0 += EB * WG) {
     double2 a[EB];
 #pragma unroll

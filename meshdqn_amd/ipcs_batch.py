@@ -7,6 +7,7 @@ raw device pointers to the C ABI.  No CPU fallback.
 """
 from __future__ import annotations
 
+import os
 import ctypes as C
 from typing import Sequence
 
@@ -124,15 +125,29 @@ class IpcsBatch:
                 cnt = np.diff(tp, axis=1)
                 p_["mf_rcnt"] = (cnt > 0).sum(axis=1).astype(np.int32)
             NRL = int(max(p_["mf_rcnt"].max() for p_ in per))
+            # bit 31 / 30 of the row word: this chunk is the FIRST / LAST one that touches the row - the row phase starts the
+            # row's sum at 0 instead of reading a zero-filled accumulation vector (the last-touch bit is used by an experiment
+            # build only, see tile_apply_global); valid when every row of every mesh is touched by some chunk (every dof
+            # belongs to a cell)
+            flags_ok = os.environ.get("MDQ_NO_RL_FLAGS", "") != "1"      # (A / B switch: plain row words, rl_flags = 0)
+            for t_, p_ in zip(self.topos, per):
+                flags_ok = flags_ok and bool((np.diff(p_["mf_tptr"], axis=1) > 0)[:, :t_.np2].any(axis=0).all())
             for p_ in per:
                 tp = p_["mf_tptr"]
                 cnt = np.diff(tp, axis=1)
+                touched = cnt > 0
+                first = touched & (np.cumsum(touched, axis=0) == 1)
+                last = touched & (np.cumsum(touched[::-1], axis=0)[::-1] == 1)
                 rl = np.zeros((tp.shape[0], NRL, 2), np.int32)
                 for c in range(tp.shape[0]):
-                    rows = np.flatnonzero(cnt[c] > 0)
-                    rl[c, :rows.size, 0] = rows
+                    rows = np.flatnonzero(touched[c])
+                    word = rows.astype(np.uint32)
+                    if flags_ok:
+                        word = word | (first[c, rows].astype(np.uint32) << 31) | (last[c, rows].astype(np.uint32) << 30)
+                    rl[c, :rows.size, 0] = word.view(np.int32)
                     rl[c, :rows.size, 1] = tp[c, rows] | (cnt[c, rows] << 16)
                 p_["mf_rlist"] = rl
+            self._rl_flags = 1 if flags_ok else 0
             h["mf_rlist"] = stack("mf_rlist", (NCH, NRL, 2), np.int32)
             h["mf_rcnt"] = stack("mf_rcnt", (NCH,), np.int32)
             self._NRL = NRL
@@ -193,6 +208,7 @@ class IpcsBatch:
                 setattr(d, name, t[name].data_ptr())
         d.work_doubles = nwork
         d.NRL = getattr(self, "_NRL", 0)
+        d.rl_flags = getattr(self, "_rl_flags", 0)
         d.pd_enabled = 0
         # Krylov pressure solve of mode 3: degree of the Chebyshev polynomial preconditioner (0, default: the plain Jacobi-CG
         # kernel).  Measured on ys930 (tools/time_pcg.py): iterations 154 -> 95 / 67 / 52 / 37 / 30 for degree 2 / 3 / 4 / 6 / 8,
