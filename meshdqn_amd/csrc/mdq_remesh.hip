@@ -63,6 +63,19 @@ struct ActArgs {
   int32_t* code;
 };
 
+#ifdef MDQ_RM_TRACE
+// debug build only: s_memtime deltas of thread 0 of mesh 0 at the phase boundaries
+__device__ long long mdq_rm_trace_buf[16];
+#define RM_STAMP(k) { const long long tn_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) mdq_rm_trace_buf[k] += tn_ - tq_; tq_ = tn_; }
+extern "C" int mdq_rm_trace_host(long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mdq_rm_trace_buf), sizeof(long long) * 16) != hipSuccess) return -1;
+  if (reset) { long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(mdq_rm_trace_buf), z, sizeof z) != hipSuccess) return -1; }
+  return 0;
+}
+#else
+#define RM_STAMP(k)
+#endif
+
 template <bool ACT, int K>
 __global__ __launch_bounds__(RW) void remesh_kernel(int NV, int NT, double* coords, int32_t* cells, int32_t* nv_,
                                                     int32_t* nt_, const int32_t* remove_idx, int32_t* status, ActArgs A,
@@ -82,6 +95,9 @@ __global__ __launch_bounds__(RW) void remesh_kernel(int NV, int NT, double* coor
   int* star = misc + 8;                                              // [64]
   int* lane0 = misc + 80;                                            // [4][64] ring bookkeeping of the serial part
   const int b = blockIdx.x, tid = threadIdx.x;
+#ifdef MDQ_RM_TRACE
+  long long tq_ = __builtin_amdgcn_s_memtime();
+#endif
   int rv;
   if (ACT) {
     // wave 0: greedy action = first maximum of the Q-row (torch.argmax), epsilon-greedy choice, Env2DAirfoil.step's decoding
@@ -127,6 +143,7 @@ __global__ __launch_bounds__(RW) void remesh_kernel(int NV, int NT, double* coor
   } else {
     rv = remove_idx[b];
   }
+  RM_STAMP(0)
   if (tid == 0) status[b] = 0;
   if (rv < 0) return;  // "do nothing" / invalid action: the reference leaves the mesh untouched
   int nv = nv_[b], nt = nt_[b];
@@ -152,6 +169,7 @@ __global__ __launch_bounds__(RW) void remesh_kernel(int NV, int NT, double* coor
     }
   }
   __syncthreads();
+  RM_STAMP(1)
   const int ns = misc[0];
   // ---------------- lane 0: ring of the star, ear clipping, slot bookkeeping (host remove_vertex, slot for slot)
   if (tid == 0) {
@@ -249,6 +267,7 @@ __global__ __launch_bounds__(RW) void remesh_kernel(int NV, int NT, double* coor
     if (tid == 0) status[b] = misc[1];
     return;  // mesh untouched (nothing has been written back)
   }
+  RM_STAMP(2)
   nt = misc[2];
   // drop the vertex: ids above shift down, coordinates move up
   for (int i = tid; i < 3 * nt; i += RW)
@@ -266,6 +285,7 @@ __global__ __launch_bounds__(RW) void remesh_kernel(int NV, int NT, double* coor
     if (v >= rv && v + 1 < nv) X[v] = moved[i];
   }
   --nv;
+  RM_STAMP(3)
   // ---------------- neighbour table: nbr[3t+k] = cell across the edge opposite local vertex k
   for (int h = tid; h < RHS; h += RW) {
     hkey[h] = EMPTY;
@@ -294,6 +314,7 @@ __global__ __launch_bounds__(RW) void remesh_kernel(int NV, int NT, double* coor
     }
   }
   __syncthreads();
+  RM_STAMP(4)
   if (misc[3]) {
     if (tid == 0) status[b] = -11;  // non-manifold (-10 + make_delaunay's -1)
     return;
@@ -313,6 +334,7 @@ __global__ __launch_bounds__(RW) void remesh_kernel(int NV, int NT, double* coor
     }
   }
   __syncthreads();
+  RM_STAMP(5)
   // ---------------- lane 0: Lawson flips from the violating edges (host make_delaunay's loop)
   if (tid == 0) {
     int sp = misc[4];
@@ -375,6 +397,7 @@ __global__ __launch_bounds__(RW) void remesh_kernel(int NV, int NT, double* coor
     misc[1] = rc;
   }
   __syncthreads();
+  RM_STAMP(6)
   if (misc[1] != 0) {
     if (tid == 0) status[b] = misc[1];
     return;
@@ -394,6 +417,7 @@ __global__ __launch_bounds__(RW) void remesh_kernel(int NV, int NT, double* coor
     nv_[b] = nv;
     nt_[b] = nt;
   }
+  RM_STAMP(7)
 }
 
 }  // namespace mdq_rm
