@@ -1056,7 +1056,10 @@ __device__ __forceinline__ void tile_apply_global(const EnvView& v, bool packed,
       // below) visited 12 924 rows per chunk on the refined mesh for ~2 500 touched ones: 57 % of an application.
       const int2* rl = reinterpret_cast<const int2*>(v.mf_rlist) + (size_t)chunk * v.NRL;
       const int nr = v.mf_rcnt[chunk];
-      constexpr int RB = 4;
+#ifndef MDQ_T5_RB
+#define MDQ_T5_RB 8
+#endif
+      constexpr int RB = MDQ_T5_RB;
       for (int k0 = tid; k0 < nr; k0 += RB * WG) {
         int2 en[RB];
         double2 a[RB];
@@ -1119,7 +1122,10 @@ __device__ __forceinline__ void tile_apply_global(const EnvView& v, bool packed,
     T5_STAMP(3)
   }
   // epilogue: the sums of a batch of own rows are requested together (the caller's own loads follow row by row)
-  constexpr int EB = 4;
+#ifndef MDQ_T5_EB
+#define MDQ_T5_EB 8
+#endif
+  constexpr int EB = MDQ_T5_EB;
 #ifdef MDQ_T5_LAST_EPI
   if (!rlf)
 #endif
