@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/meshdqn_hip.h"
+#include "mdq_slab.h"
 
 namespace mdq_rm {
 
@@ -422,8 +423,7 @@ __global__ __launch_bounds__(RW) void remesh_kernel(int NV, int NT, double* coor
 
 }  // namespace mdq_rm
 
-static unsigned char* g_big_slab = nullptr;     // K = 4: the tables of every mesh of a launch (grown on demand, kept)
-static size_t g_big_slab_bytes = 0;
+static mdq_slab::Pool g_remesh_slabs;   // K = 4: the tables of every mesh of a launch, one slab per stream (mdq_slab.h)
 
 template <int K>
 static int remesh_launch_k(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv, int32_t* nt,
@@ -456,19 +456,11 @@ static int remesh_launch(const char* who, int32_t B, int32_t NV, int32_t NT, dou
     return remesh_launch_k<1>(B, NV, NT, coords, cells, nv, nt, remove_idx, status, act, stream, nullptr);
   if (NV > mdq_rm::Cap<4>::NV || NT > mdq_rm::Cap<4>::NT)
     return mdq_set_error("mdq_remesh: capacity above 4096 vertices / 8192 triangles");
-  // the large-mesh instance: its tables live in a slab in global memory (one per process, grown on demand; launches that
-  // share it are ordered by the caller's stream: one stream per process uses the large instance at a time)
+  // the large-mesh instance: its tables live in a slab in global memory (one per stream, grown on demand)
   const size_t per = (mdq_rm::Cap<4>::BYTES + 255) & ~(size_t)255, need = per * (size_t)B;
-  if (need > g_big_slab_bytes) {
-    if (g_big_slab) {
-      if (hipDeviceSynchronize() != hipSuccess || hipFree(g_big_slab) != hipSuccess) return mdq_set_error("mdq_remesh: cannot release the table slab");
-      g_big_slab = nullptr;
-      g_big_slab_bytes = 0;
-    }
-    if (hipMalloc(reinterpret_cast<void**>(&g_big_slab), need) != hipSuccess) return mdq_set_error("mdq_remesh: cannot allocate the table slab of the large-mesh instance");
-    g_big_slab_bytes = need;
-  }
-  return remesh_launch_k<4>(B, NV, NT, coords, cells, nv, nt, remove_idx, status, act, stream, g_big_slab);
+  unsigned char* slab = g_remesh_slabs.get(stream, need);
+  if (!slab) return mdq_set_error("mdq_remesh: cannot allocate the table slab of the large-mesh instance");
+  return remesh_launch_k<4>(B, NV, NT, coords, cells, nv, nt, remove_idx, status, act, stream, slab);
 }
 
 extern "C" int mdq_remesh(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv, int32_t* nt,

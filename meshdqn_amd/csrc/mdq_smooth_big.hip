@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/meshdqn_hip.h"
+#include "mdq_slab.h"
 
 namespace mdq_smooth_big {
 constexpr int BNV = 4096, BNT = 8192, BWG = 512;
@@ -256,8 +257,7 @@ __global__ __launch_bounds__(BWG) void smooth_big_kernel(int NV, int NT, double*
 }
 }  // namespace mdq_smooth_big
 
-static unsigned char* g_smooth_slab = nullptr;   // the tables of every mesh of a launch (grown on demand, kept)
-static size_t g_smooth_slab_bytes = 0;
+static mdq_slab::Pool g_smooth_slabs;   // the tables of every mesh of a launch, one slab per stream (mdq_slab.h)
 
 // mdq_smooth / mdq_smooth_fast / mdq_smooth_fast_env for NV > 1024 (called by those entry points)
 static int smooth_big_launch(int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t* cells, const int32_t* nv,
@@ -266,21 +266,14 @@ static int smooth_big_launch(int32_t B, int32_t NV, int32_t NT, double* coords, 
   using namespace mdq_smooth_big;
   if (NV > BNV || NT > BNT) return mdq_set_error("mdq_smooth: capacity above 4096 vertices / 8192 triangles");
   const size_t per = (SLAB_BYTES + 255) & ~(size_t)255, need = per * (size_t)B;
-  if (need > g_smooth_slab_bytes) {
-    if (g_smooth_slab) {
-      if (hipDeviceSynchronize() != hipSuccess || hipFree(g_smooth_slab) != hipSuccess) return mdq_set_error("mdq_smooth: cannot release the table slab");
-      g_smooth_slab = nullptr;
-      g_smooth_slab_bytes = 0;
-    }
-    if (hipMalloc(reinterpret_cast<void**>(&g_smooth_slab), need) != hipSuccess) return mdq_set_error("mdq_smooth: cannot allocate the table slab of the large-mesh kernel");
-    g_smooth_slab_bytes = need;
-  }
+  unsigned char* slab = g_smooth_slabs.get(stream, need);
+  if (!slab) return mdq_set_error("mdq_smooth: cannot allocate the table slab of the large-mesh kernel");
   const size_t lds = sizeof(d2) * BNV + sizeof(int) * BNV;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&smooth_big_kernel),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(d2) * BNV + sizeof(int) * BNV));
   if (attr != hipSuccess) return mdq_set_error("hipFuncSetAttribute(smooth_big_kernel) failed");
   hipLaunchKernelGGL(smooth_big_kernel, dim3(B), dim3(BWG), lds, (hipStream_t)stream, NV, NT, coords, cells, nv, nt, iterations,
-                     rem, rstat, iters_env, g_smooth_slab, nullptr);
+                     rem, rstat, iters_env, slab, nullptr);
   if (hipGetLastError() != hipSuccess) return mdq_set_error("smooth_big_kernel launch failed");
   return 0;
 }

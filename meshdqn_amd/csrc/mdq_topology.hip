@@ -13,6 +13,7 @@
 #include <type_traits>
 
 #include "../../include/meshdqn_hip.h"
+#include "mdq_slab.h"
 
 namespace mdq_topo {
 
@@ -1230,8 +1231,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
 
 }  // namespace mdq_topo
 
-static unsigned char* g_topo_slab = nullptr;    // K = 4: the tables of every mesh of a launch (grown on demand, kept)
-static size_t g_topo_slab_bytes = 0;
+static mdq_slab::Pool g_topo_slabs;     // K = 4: the tables of every mesh of a launch, one slab per stream (mdq_slab.h)
 
 extern "C" int mdq_env_topology(const mdq_env_topo_desc* d, void* stream, int32_t* status) {
   if (!d || d->B <= 0 || !status) return mdq_set_error("mdq_env_topology: bad arguments");
@@ -1249,19 +1249,12 @@ extern "C" int mdq_env_topology(const mdq_env_topo_desc* d, void* stream, int32_
     using C4 = mdq_topo::TCap<4>;
     if (d->NV > C4::NV || d->NT > C4::NT || d->NP > C4::NP)
       return mdq_set_error("mdq_env_topology: capacity above 4096 vertices / 8192 triangles / 16384 P2 dofs");
-    // the large-mesh instance: tables on a slab in global memory (one per process, grown on demand; one stream at a time)
+    // the large-mesh instance: tables on a slab in global memory (one per stream, grown on demand)
     const size_t per = (C4::BYTES + 255) & ~(size_t)255, need = per * (size_t)d->B;
-    if (need > g_topo_slab_bytes) {
-      if (g_topo_slab) {
-        if (hipDeviceSynchronize() != hipSuccess || hipFree(g_topo_slab) != hipSuccess) return mdq_set_error("mdq_env_topology: cannot release the table slab");
-        g_topo_slab = nullptr;
-        g_topo_slab_bytes = 0;
-      }
-      if (hipMalloc(reinterpret_cast<void**>(&g_topo_slab), need) != hipSuccess) return mdq_set_error("mdq_env_topology: cannot allocate the table slab of the large-mesh instance");
-      g_topo_slab_bytes = need;
-    }
+    unsigned char* slab = g_topo_slabs.get(stream, need);
+    if (!slab) return mdq_set_error("mdq_env_topology: cannot allocate the table slab of the large-mesh instance");
     hipLaunchKernelGGL(mdq_topo::topology_kernel<4>, dim3(d->B), dim3(mdq_topo::TW), 0, (hipStream_t)stream, *d, o,
-                       d->ipcs ? 1 : 0, status, g_topo_slab);
+                       d->ipcs ? 1 : 0, status, slab);
   }
   if (hipGetLastError() != hipSuccess) return mdq_set_error("topology_kernel launch failed");
   return 0;
