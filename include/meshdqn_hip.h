@@ -456,6 +456,17 @@ typedef struct mdq_interp_desc {
   /* optional, device [B]: added to npts[b] (a caller that holds vertex and edge counts separately passes np1 as npts and
    * the edge counts here instead of launching an add) */
   const int32_t* npts_extra;
+  /* optional (ABI 5, round 4), `sparse` != 0: only what the device-resident env step reads of the S x (P2 + P1) fields -
+   *   vertices: every snapshot (state features, pressures of the force integrals);
+   *   edge midpoints: the LAST snapshot only (the warm start of the flow leg; sparse = 2: not even that - a step without
+   *   a flow leg), and every snapshot for the three edges of the cells that carry an airfoil facet (the force integrals of
+   *   the reward, probes.py:23-50).  The other entries of out_u keep whatever they held.  Needs the topology engine's
+   *   airfoil-facet list and cell dofs of the TARGET meshes. */
+  const int32_t* af_facets;     /* device [B][NAF][2] (cell, local facet)                      */
+  const int32_t* naf;           /* device [B]                                                  */
+  const int32_t* cell_dofs;     /* device [B][6][NT] dof ids of the target meshes              */
+  int32_t NT, NAF;
+  int32_t sparse, _pad2;
 } mdq_interp_desc;
 
 /*

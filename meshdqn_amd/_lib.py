@@ -66,6 +66,8 @@ class InterpDesc(C.Structure):
         ("bin_ptr", C.c_void_p), ("bin_cells", C.c_void_p), ("src_u", C.c_void_p), ("src_p", C.c_void_p),
         ("out_u", C.c_void_p), ("out_p", C.c_void_p), ("out_cell", C.c_void_p), ("src_cellrec", C.c_void_p),
         ("npts_extra", C.c_void_p),
+        ("af_facets", C.c_void_p), ("naf", C.c_void_p), ("cell_dofs", C.c_void_p),
+        ("NT", C.c_int32), ("NAF", C.c_int32), ("sparse", C.c_int32), ("_pad2", C.c_int32),
     ]
 
 

@@ -17,7 +17,25 @@ __global__ __launch_bounds__(256) void interpolate_kernel(mdq_interp_desc d) {
   const int np1 = d.np1[b];
   const int64_t B = b;
   const double* pts = d.points + B * d.NP * 2;
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < npts; k += gridDim.x * blockDim.x) {
+  // sparse mode (see the header): blocks [0, nbA) walk the points - vertices every snapshot, edge midpoints the last one
+  // (or none) - blocks [nbA, gridDim.x) the three edges of the airfoil-facet cells, the remaining snapshots
+  const int nbA = d.sparse ? (d.NP + 255) / 256 : (int)gridDim.x;
+  const bool passB = (int)blockIdx.x >= nbA;
+  const int nB = passB ? 3 * d.naf[b] : 0;
+  const int kfirst = passB ? ((int)blockIdx.x - nbA) * (int)blockDim.x + (int)threadIdx.x : (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  const int kstride = passB ? ((int)gridDim.x - nbA) * (int)blockDim.x : nbA * (int)blockDim.x;
+  for (int kk = kfirst; kk < (passB ? nB : npts); kk += kstride) {
+    int k = kk, s_lo = 0, s_hi = d.S;
+    if (passB) {
+      const int f = kk / 3, j = kk - 3 * f;
+      const int cell = d.af_facets[(B * d.NAF + f) * 2];
+      k = d.cell_dofs[(B * 6 + 3 + j) * d.NT + cell];
+      if (d.sparse == 1) s_hi = d.S - 1;          // (the last snapshot of every edge midpoint is pass A's)
+      if (k < np1 || k >= npts || s_hi <= s_lo) continue;
+    } else if (d.sparse && k >= np1) {
+      if (d.sparse == 2) continue;
+      s_lo = d.S - 1;
+    }
     const double px = pts[2 * k], py = pts[2 * k + 1];
     int gx = (int)floor((px - d.x0) * d.inv_hx), gy = (int)floor((py - d.y0) * d.inv_hy);
     gx = gx < 0 ? 0 : (gx >= d.gnx ? d.gnx - 1 : gx);
@@ -93,7 +111,7 @@ __global__ __launch_bounds__(256) void interpolate_kernel(mdq_interp_desc d) {
     int dof[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) dof[i] = d.src_cell_dofs[i * d.src_nt + best];
-    for (int s = 0; s < d.S; ++s) {
+    for (int s = s_lo; s < s_hi; ++s) {
       const double* us = d.src_u + (int64_t)s * d.src_n2 * 2;
       double ux = 0.0, uy = 0.0;
 #pragma unroll
@@ -117,7 +135,12 @@ __global__ __launch_bounds__(256) void interpolate_kernel(mdq_interp_desc d) {
 
 extern "C" int mdq_interpolate_snapshots(const mdq_interp_desc* d, void* stream) {
   if (!d || d->B <= 0 || d->S <= 0 || d->NP <= 0) return mdq_set_error("mdq_interpolate_snapshots: bad arguments");
-  const int bx = (d->NP + 255) / 256;
+  int bx = (d->NP + 255) / 256;
+  if (d->sparse) {
+    if (d->sparse < 0 || d->sparse > 2 || !d->af_facets || !d->naf || !d->cell_dofs || d->NT <= 0 || d->NAF <= 0)
+      return mdq_set_error("mdq_interpolate_snapshots: sparse mode needs af_facets, naf, cell_dofs, NT, NAF");
+    bx += (3 * d->NAF + 255) / 256;
+  }
   hipLaunchKernelGGL(mdq_mesh::interpolate_kernel, dim3(bx, d->B), dim3(256), 0, (hipStream_t)stream, *d);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return mdq_set_error(hipGetErrorString(e));

@@ -459,7 +459,7 @@ class VecEnv2DAirfoil:
         self._refresh_launch()
         self._refresh_collect()
 
-    def _refresh_launch(self, readback=True, defer_flow=False, after_topology=None):
+    def _refresh_launch(self, readback=True, defer_flow=False, after_topology=None, sparse=0):
         """Everything of `_refresh` that is enqueued on the stream, up to the asynchronous read-back (`readback=False`:
         the device-resident rollout keeps the results on the device)."""
         dev, h = self.device, self.h
@@ -498,6 +498,12 @@ class VecEnv2DAirfoil:
         for k, v in it.t.items():
             setattr(d, k, v.data_ptr())
         d.out_u, d.out_p, d.out_cell = out_u.data_ptr(), out_p.data_ptr(), None
+        if sparse and self.gpu_topology:
+            # device-resident step: only the entries it reads (vertices, the last snapshot's edge values for the flow leg's warm
+            # start, the edges of the airfoil-facet cells for the force integrals) - the edge values of the other snapshots, 60 %
+            # of the kernel's work, are read by nothing; the host-driven step() keeps the full fields (self.u is public there)
+            d.sparse, d.NT, d.NAF = int(sparse), NT, self.NAF
+            d.af_facets, d.naf, d.cell_dofs = dt.t["af_facets"].data_ptr(), dt.t["naf"].data_ptr(), dt.t["cell_dofs"].data_ptr()
         _lib.check(self.lib.mdq_interpolate_snapshots(C.byref(d), _lib.stream_ptr()), "mdq_interpolate_snapshots")
         # forces: light mesh descriptor over the batch
         md = _lib.IpcsDesc()
@@ -892,7 +898,8 @@ class VecEnv2DAirfoil:
             tm.append((e0, e1))
         flow = self.flow_steps > 0 and self.flow_overlap
         early = flow and self.gpu_topology and not self._late_handover
-        self._refresh_launch(readback=False, defer_flow=True, after_topology=self._flow_handover_mesh if early else None)
+        sparse = 0 if os.environ.get("MDQ_FULL_INTERP", "") == "1" else (1 if self.flow_steps > 0 else 2)
+        self._refresh_launch(readback=False, defer_flow=True, after_topology=self._flow_handover_mesh if early else None, sparse=sparse)
         # ---- the end of the step in one launch
         x = torch.empty((B, N, 2 + 3 * S), dtype=torch.float32, device=self.device)
         d = self._finish_desc(ro, k, x)
