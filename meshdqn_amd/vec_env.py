@@ -215,6 +215,9 @@ class VecEnv2DAirfoil:
             self._flow_stream = role_streams(dev)["flow"]   # (the process's flow stream: fixed creation order, one probe)
             self._flow_ready = torch.cuda.Event()
             self._late_handover = os.environ.get("MDQ_LATE_HANDOVER", "") == "1"      # (A / B switch of the early mesh hand-over)
+            # the last IPCS kernel writes drag / lift of the leg straight into the page-locked result buffers (2 KB over the bus)
+            # instead of two device-to-host copies behind it (12 us of the flow chain); MDQ_FLOW_RESULT_COPY=1: the copies
+            self._flow_direct_results = os.environ.get("MDQ_FLOW_RESULT_COPY", "") != "1"
             # page-locked result buffers (two: the results of step k are read while step k + 1 is in flight) + events
             self._flow_res = [dict(host=torch.zeros((2, B, self.flow_steps), dtype=torch.float64, pin_memory=True),
                                    done=torch.cuda.Event()) for _ in range(2)]
@@ -243,20 +246,30 @@ class VecEnv2DAirfoil:
             setattr(d, kk, keep[kk].data_ptr())
         return self._flow_launch(t, d, keep, out_u, out_p)
 
-    def _flow_launch(self, t, d, keep, out_u, out_p, before_evolve=None):
-        if out_u is not None:
-            t["u_n"].copy_(out_u[:, self.S - 1])
-            t["p_n"].copy_(out_p[:, self.S - 1])
+    def _flow_reset(self, d):
         # no initial-guess history on a new mesh: the counters inside the workspace (not a fill of its 100 MB) + the
         # iteration counters, one small launch
         _lib.check(self.lib.mdq_ipcs_reset_history(C.byref(d), self.flow_iters.data_ptr(), _lib.stream_ptr()),
                    "mdq_ipcs_reset_history")
+
+    def _flow_launch(self, t, d, keep, out_u, out_p, before_evolve=None, reset=True, out=None):
+        """`reset=False`: the caller has already enqueued `_flow_reset` (ahead of a wait: off the leg's critical path).
+        `out` = (drag, lift) tensors the kernels write - page-locked host tensors are written over the bus directly, which
+        saves the two result copies at the end of the leg."""
+        if out_u is not None:
+            t["u_n"].copy_(out_u[:, self.S - 1])
+            t["p_n"].copy_(out_p[:, self.S - 1])
+        if reset:
+            self._flow_reset(d)
         _lib.check(self.lib.mdq_ipcs_setup_matfree(C.byref(d), _lib.stream_ptr()), "mdq_ipcs_setup_matfree")
         if self.flow_pressure == "direct":
             _lib.check(self.lib.mdq_ipcs_factorize_pressure(C.byref(d), self.flow_pd_status.data_ptr(), _lib.stream_ptr()),
                        "mdq_ipcs_factorize_pressure")
-        drag = torch.empty((self.B, self.flow_steps), dtype=torch.float64, device=self.device)
-        lift = torch.empty_like(drag)
+        if out is not None:
+            drag, lift = out
+        else:
+            drag = torch.empty((self.B, self.flow_steps), dtype=torch.float64, device=self.device)
+            lift = torch.empty_like(drag)
         if before_evolve is not None:       # (the set-up above reads the mesh only; the warm start is needed from here on)
             before_evolve()
         _lib.check(self.lib.mdq_ipcs_evolve(C.byref(d), self.flow_steps, drag.data_ptr(), lift.data_ptr(),
@@ -323,7 +336,9 @@ class VecEnv2DAirfoil:
         ft.take_edges_from(fin["cell_dofs"], fin["ne"])
         t["u_n"], t["p_n"] = fin["u_n"], fin["p_n"]
         res = self._flow_res[self._flow_n % 2]
+        direct = self._flow_direct_results and tuple(res["host"][0].shape) == (self.B, self.flow_steps)
         with torch.cuda.stream(self._flow_stream):
+            self._flow_reset(d)                  # (behind flow k - 1, in FRONT of the wait for this step's meshes)
             self._flow_stream.wait_event(self._flow_mesh_ready if mesh_early else self._flow_ready)
             fe = getattr(self, "flow_events", None)     # (tools: HIP events around the leg, on the flow stream)
             if fe is not None:
@@ -331,12 +346,14 @@ class VecEnv2DAirfoil:
                 e0.record()
             ft.run(check=False)                  # (same meshes, same deterministic kernel as the main stream's run)
             drag, lift = self._flow_launch(t, d, keep, None, None,
-                                           (lambda: self._flow_stream.wait_event(self._flow_ready)) if mesh_early else None)
+                                           (lambda: self._flow_stream.wait_event(self._flow_ready)) if mesh_early else None,
+                                           reset=False, out=(res["host"][0], res["host"][1]) if direct else None)
             if fe is not None:
                 e1.record()
                 fe.append((e0, e1))
-            res["host"][0].copy_(drag, non_blocking=True)
-            res["host"][1].copy_(lift, non_blocking=True)
+            if not direct:
+                res["host"][0].copy_(drag, non_blocking=True)
+                res["host"][1].copy_(lift, non_blocking=True)
             res["done"].record(self._flow_stream)
         self._flow_prev = self._flow_n % 2
         self._flow_n += 1
