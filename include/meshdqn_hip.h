@@ -714,6 +714,19 @@ typedef struct mdq_ipcs_topo_out {
 } mdq_ipcs_topo_out;
 
 /* ---- batched topology + N-closest selection + state graph (host arrays) ---- */
+/* Optional second set of outputs of mdq_env_topology (device engine only; ABI 5, round 4): copies of the mesh and of its
+ * edge numbering for ANOTHER engine that works on the same meshes on another stream - the flow leg of the S3 env step
+ * (VecEnv2DAirfoil, flow_overlap): written by the topology kernel itself, so that the other stream can start as soon as this
+ * launch has finished instead of waiting for a copy launch behind it.  A HOST struct holding device pointers. */
+typedef struct mdq_topo_handover {
+  double* coords;           /* [B][NV][2] rows < nv */
+  int32_t* cells;           /* [B][NT][3] rows < nt */
+  int32_t* nv;              /* [B] */
+  int32_t* nt;              /* [B] */
+  int32_t* cell_dofs;       /* [B][6][NT] */
+  int32_t* ne;              /* [B] */
+} mdq_topo_handover;
+
 typedef struct mdq_env_topo_desc {
   int32_t B, NV, NT, NP, NAF, N, EMAX, npoly;   /* capacities; N = N_closest; npoly = airfoil polygon points */
   /* inputs */
@@ -738,6 +751,7 @@ typedef struct mdq_env_topo_desc {
   int32_t* edge_dst;        /* [B][EMAX] */
   double* edge_len;         /* [B][EMAX] edge_attr */
   const mdq_ipcs_topo_out* ipcs;  /* optional (NULL: skip) */
+  const mdq_topo_handover* handover;  /* optional (NULL: none; ignored by the host engine) */
 } mdq_env_topo_desc;
 
 /*

@@ -76,7 +76,12 @@ class EnvTopoDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("B", "NV", "NT", "NP", "NAF", "N", "EMAX", "npoly")] + [
         (n, C.c_void_p) for n in ("coords", "cells", "nv", "nt", "offset", "polygon", "ne", "cell_dofs", "points", "naf",
                                   "af_facets", "nremovable", "nsel", "n_closest", "coord_map", "nedges", "edge_src",
-                                  "edge_dst", "edge_len", "ipcs")]
+                                  "edge_dst", "edge_len", "ipcs", "handover")]
+
+
+class TopoHandover(C.Structure):
+    """Mirror of `mdq_topo_handover`."""
+    _fields_ = [(n, C.c_void_p) for n in ("coords", "cells", "nv", "nt", "cell_dofs", "ne")]
 
 
 class IpcsTopoOut(C.Structure):

@@ -104,7 +104,7 @@ extern "C" int mdq_topo_trace_host(long long* out, int reset) {
 
 template <int K>
 __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_ipcs_topo_out O, int has_ipcs,
-                                                      int32_t* status, unsigned char* slab) {
+                                                      int32_t* status, unsigned char* slab, mdq_topo_handover HO) {
 #pragma clang fp contract(off)
 #ifdef MDQ_TOPO_TRACE
   long long tq_ = __builtin_amdgcn_s_memtime();
@@ -151,9 +151,20 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   int32_t* cd = D.cell_dofs + Bq * 6 * D.NT;
   double* pts = D.points + Bq * D.NP * 2;
   if (tid == 0) status[b] = 0;
+  // (HO: the mesh and - below - its edge numbering also go to another engine's input arrays, see mdq_topo_handover)
+  int32_t* hcd = HO.cell_dofs ? HO.cell_dofs + Bq * 6 * D.NT : nullptr;
   for (int v = tid; v < TNV; v += TW) {
-    if (v < nv) X[v] = make_double2(xg[2 * v], xg[2 * v + 1]);
+    if (v < nv) {
+      X[v] = make_double2(xg[2 * v], xg[2 * v + 1]);
+      if (HO.coords) reinterpret_cast<double2*>(HO.coords)[Bq * D.NV + v] = X[v];
+    }
     onb[v] = 0;
+  }
+  if (HO.cells)
+    for (int i = tid; i < 3 * nt; i += TW) HO.cells[Bq * D.NT * 3 + i] = tri[i];
+  if (tid == 0) {
+    if (HO.nv) HO.nv[b] = nv;
+    if (HO.nt) HO.nt[b] = nt;
   }
   for (int h = tid; h < HSZ; h += TW) {
     hkey[h] = EMPTY;
@@ -207,6 +218,10 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
       atomicAdd(&cnt_[e], 1);
       cd[(3 + k) * D.NT + t] = nv + e;
       cd[k * D.NT + t] = tri[3 * t + k];
+      if (hcd) {
+        hcd[(3 + k) * D.NT + t] = nv + e;
+        hcd[k * D.NT + t] = tri[3 * t + k];
+      }
     }
     __syncthreads();
     for (int e = tid; e < ne_given; e += TW) {
@@ -218,7 +233,10 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
       eown[e] = (uint16_t)s;
       eflag[e] = cnt_[e] >= 2 ? 0 : 1;
     }
-    if (tid == 0) D.ne[b] = ne_given;
+    if (tid == 0) {
+      D.ne[b] = ne_given;
+      if (HO.ne) HO.ne[b] = ne_given;
+    }
     for (int i = tid; i < nv; i += TW) {
       pts[2 * i] = X[i].x;
       pts[2 * i + 1] = X[i].y;
@@ -285,8 +303,15 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
       const int t = s / 3, k = s - 3 * t;
       cd[(3 + k) * D.NT + t] = nv + e;
       cd[k * D.NT + t] = tri[3 * t + k];
+      if (hcd) {
+        hcd[(3 + k) * D.NT + t] = nv + e;
+        hcd[k * D.NT + t] = tri[3 * t + k];
+      }
     }
-    if (tid == 0) D.ne[b] = ne;
+    if (tid == 0) {
+      D.ne[b] = ne;
+      if (HO.ne) HO.ne[b] = ne;
+    }
     for (int i = tid; i < nv; i += TW) {
       pts[2 * i] = X[i].x;
       pts[2 * i + 1] = X[i].y;
@@ -1238,13 +1263,15 @@ extern "C" int mdq_env_topology(const mdq_env_topo_desc* d, void* stream, int32_
   if (d->npoly > mdq_topo::TNPOLY) return mdq_set_error("mdq_env_topology: more than 256 polygon points");
   mdq_ipcs_topo_out o = {};
   if (d->ipcs) o = *d->ipcs;
+  mdq_topo_handover h = {};
+  if (d->handover) h = *d->handover;
   if (d->NV <= mdq_topo::TNV && d->NT <= mdq_topo::TNT && d->NP <= mdq_topo::TNP) {
     const size_t lds = mdq_topo::TCap<1>::BYTES;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mdq_topo::topology_kernel<1>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) return mdq_set_error("hipFuncSetAttribute(topology_kernel) failed");
     hipLaunchKernelGGL(mdq_topo::topology_kernel<1>, dim3(d->B), dim3(mdq_topo::TW), lds, (hipStream_t)stream, *d, o,
-                       d->ipcs ? 1 : 0, status, nullptr);
+                       d->ipcs ? 1 : 0, status, nullptr, h);
   } else {
     using C4 = mdq_topo::TCap<4>;
     if (d->NV > C4::NV || d->NT > C4::NT || d->NP > C4::NP)
@@ -1254,7 +1281,7 @@ extern "C" int mdq_env_topology(const mdq_env_topo_desc* d, void* stream, int32_
     unsigned char* slab = g_topo_slabs.get(stream, need);
     if (!slab) return mdq_set_error("mdq_env_topology: cannot allocate the table slab of the large-mesh instance");
     hipLaunchKernelGGL(mdq_topo::topology_kernel<4>, dim3(d->B), dim3(mdq_topo::TW), 0, (hipStream_t)stream, *d, o,
-                       d->ipcs ? 1 : 0, status, slab);
+                       d->ipcs ? 1 : 0, status, slab, h);
   }
   if (hipGetLastError() != hipSuccess) return mdq_set_error("topology_kernel launch failed");
   return 0;

@@ -425,6 +425,22 @@ class DeviceTopologyBatch:
         self._ipcs_out.cell_dofs_in = None if cell_dofs is None else cell_dofs.data_ptr()
         self._ipcs_out.ne_in = None if ne is None else ne.data_ptr()
 
+    def set_handover(self, coords=None, cells=None, nv=None, nt=None, cell_dofs=None, ne=None):
+        """Second set of outputs of the next `run()` calls (`mdq_topo_handover`): the kernel also writes the mesh and its
+        edge numbering to these tensors (another engine's inputs); no arguments: off."""
+        if coords is None:
+            self._handover = None
+            self.desc.handover = None
+            return
+        h = _lib.TopoHandover()
+        for k, v in dict(coords=coords, cells=cells, nv=nv, nt=nt, cell_dofs=cell_dofs, ne=ne).items():
+            want = getattr(self, k) if k in ("coords", "cells", "nv", "nt") else self.t[k]
+            if v.shape != want.shape or v.dtype != want.dtype or not v.is_contiguous():
+                raise ValueError(f"topology hand-over: `{k}` does not match the engine's array")
+            setattr(h, k, v.data_ptr())
+        self._handover = (h, coords, cells, nv, nt, cell_dofs, ne)     # (keeps the struct and the tensors alive)
+        self.desc.handover = C.cast(C.pointer(h), C.c_void_p)
+
     def run(self, stream=None, check=True):
         _lib.check(self.lib.mdq_env_topology(C.byref(self.desc), _lib.stream_ptr(stream), self.status.data_ptr()),
                    "mdq_env_topology")

@@ -218,6 +218,7 @@ class VecEnv2DAirfoil:
             # the last IPCS kernel writes drag / lift of the leg straight into the page-locked result buffers (2 KB over the bus)
             # instead of two device-to-host copies behind it (12 us of the flow chain); MDQ_FLOW_RESULT_COPY=1: the copies
             self._flow_direct_results = os.environ.get("MDQ_FLOW_RESULT_COPY", "") != "1"
+            self._handover_in_kernel = os.environ.get("MDQ_HANDOVER_COPY", "") != "1"    # (A / B: the copy launch of the first version)
             # page-locked result buffers (two: the results of step k are read while step k + 1 is in flight) + events
             self._flow_res = [dict(host=torch.zeros((2, B, self.flow_steps), dtype=torch.float64, pin_memory=True),
                                    done=torch.cuda.Event()) for _ in range(2)]
@@ -292,6 +293,16 @@ class VecEnv2DAirfoil:
                  (fin["cell_dofs"], dt.t["cell_dofs"]), (fin["ne"], dt.t["ne"])]
         return fin, pairs
 
+    def _flow_handover_target(self):
+        """Before the main topology run of a device-resident step: the flow input set this step fills becomes the second
+        output set of the topology kernel (meshes + edge numbering written by that launch itself: no copy launch on the main
+        chain, 6 us + two event gaps per step)."""
+        main = torch.cuda.current_stream(self.device)
+        fin = self._flow_in[self._flow_n % 2]
+        if self._flow_n >= 2 and self._flow_prev is not None:          # flow k - 2 read this input set (long finished)
+            main.wait_event(self._flow_res[self._flow_n % 2]["done"])
+        self.dtopo.set_handover(fin["coords"], fin["cells"], fin["nv"], fin["nt"], fin["cell_dofs"], fin["ne"])
+
     def _flow_handover_mesh(self):
         """Device-resident step, EARLY half of the hand-over: meshes + the main engine's edge numbering are copied (one
         launch on the main stream) right after the main topology run, so that the flow stream can derive its own topology
@@ -301,8 +312,16 @@ class VecEnv2DAirfoil:
         dt = self.dtopo
         main = torch.cuda.current_stream(self.device)
         fin = self._flow_in[self._flow_n % 2]
-        if self._flow_n >= 2 and self._flow_prev is not None:          # flow k - 2 read this input set (long finished)
+        if not self._handover_in_kernel and self._flow_n >= 2 and self._flow_prev is not None:   # flow k - 2 read this input set
             main.wait_event(self._flow_res[self._flow_n % 2]["done"])
+        if self._handover_in_kernel:
+            # the main topology kernel has written this input set itself (`_flow_handover_target`, mdq_topo_handover)
+            dt.set_handover()                    # (this launch only: a later host-driven step() must not write there)
+            if getattr(self, "_flow_mesh_ready", None) is None:
+                self._flow_mesh_ready = torch.cuda.Event()
+            self._flow_mesh_ready.record(main)
+            self._flow_fin_early = fin
+            return
         pairs = [(fin["coords"], dt.coords), (fin["cells"], dt.cells), (fin["nv"], dt.nv), (fin["nt"], dt.nt),
                  (fin["cell_dofs"], dt.t["cell_dofs"]), (fin["ne"], dt.t["ne"])]
         n = len(pairs)
@@ -476,13 +495,15 @@ class VecEnv2DAirfoil:
         self._refresh_launch()
         self._refresh_collect()
 
-    def _refresh_launch(self, readback=True, defer_flow=False, after_topology=None, sparse=0):
+    def _refresh_launch(self, readback=True, defer_flow=False, after_topology=None, sparse=0, before_topology=None):
         """Everything of `_refresh` that is enqueued on the stream, up to the asynchronous read-back (`readback=False`:
         the device-resident rollout keeps the results on the device)."""
         dev, h = self.device, self.h
         B, NV, NT, NP = self.B, self.NV, self.NT, self.NP
         if self.gpu_topology:
             dt = self.dtopo
+            if before_topology is not None:
+                before_topology()
             dt.run(check=False)                     # status is read back with the other results below
             if after_topology is not None:
                 after_topology()
@@ -916,7 +937,8 @@ class VecEnv2DAirfoil:
         flow = self.flow_steps > 0 and self.flow_overlap
         early = flow and self.gpu_topology and not self._late_handover
         sparse = 0 if os.environ.get("MDQ_FULL_INTERP", "") == "1" else (1 if self.flow_steps > 0 else 2)
-        self._refresh_launch(readback=False, defer_flow=True, after_topology=self._flow_handover_mesh if early else None, sparse=sparse)
+        self._refresh_launch(readback=False, defer_flow=True, after_topology=self._flow_handover_mesh if early else None, sparse=sparse,
+                             before_topology=self._flow_handover_target if early and self._handover_in_kernel else None)
         # ---- the end of the step in one launch
         x = torch.empty((B, N, 2 + 3 * S), dtype=torch.float32, device=self.device)
         d = self._finish_desc(ro, k, x)
