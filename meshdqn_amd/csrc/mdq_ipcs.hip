@@ -3112,6 +3112,14 @@ static hipError_t launch_evolve_team(const mdq_ipcs_desc* d, size_t lds, int nst
 // touched only for the element metadata (dofs, tile maps, geometry) and once per time step for
 // the state vectors.
 
+// float kept in a register -> double at the point of use: the asm stops the compiler from hoisting the conversion
+// out of the Krylov loop, which turns 4-byte loop invariants into 8-byte ones (measured: they were then spilled to
+// scratch and re-read one by one in every vector phase of every iteration)
+__device__ __forceinline__ double f2d(float f) {
+  asm volatile("" : "+v"(f));
+  return (double)f;
+}
+
 #define MDQ_FOR_ROWS(k, row)                       \
   _Pragma("unroll") for (int k = 0; k < MF_ROWS; ++k) \
     if (const int row = threadIdx.x + k * WG; row < n2)
@@ -3269,7 +3277,7 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
         const double2 g = make_double2(v.bcu_gx[row], 0.0);
         // |D^-1 b|^2 with b = f - lift (free) / g (constrained): same norm as the assembled path
         const double2 l = v.lift1[row];
-        const double2 bi = fl ? g : make_double2((y[k].x - l.x) * idg[k].x, (y[k].y - l.y) * idg[k].y);
+        const double2 bi = fl ? g : make_double2((y[k].x - l.x) * f2d(idg[k].x), (y[k].y - l.y) * f2d(idg[k].y));
         acc[0] += bi.x * bi.x + bi.y * bi.y;
       }
     }
@@ -3289,7 +3297,7 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
       for (int k = 0; k < MF_ROWS; ++k) {
         const int row = tid + k * WG;
         // r0 = D^-1 (f - A_full x0) on free rows, 0 on constrained rows (idg = 0 there)
-        r[k] = make_double2((y[k].x - ax[k].x) * idg[k].x, (y[k].y - ax[k].y) * idg[k].y);
+        r[k] = make_double2((y[k].x - ax[k].x) * f2d(idg[k].x), (y[k].y - ax[k].y) * f2d(idg[k].y));
         if (row < n2) rhg[row] = r[k];
         p[k] = make_double2(0.0, 0.0);
         vv[k] = make_double2(0.0, 0.0);
@@ -3336,7 +3344,7 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
 #pragma unroll
           for (int k = 0; k < MF_ROWS; ++k) {
             const int row = tid + k * WG;
-            vv[k] = make_double2(vv[k].x * idg[k].x, vv[k].y * idg[k].y);
+            vv[k] = make_double2(vv[k].x * f2d(idg[k].x), vv[k].y * f2d(idg[k].y));
             if (row < n2) {
               const double2 h = rhg[row];
               a1[0] += h.x * vv[k].x + h.y * vv[k].y;
@@ -3381,7 +3389,7 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
           double a3[2] = {0.0, 0.0};
 #pragma unroll
           for (int k = 0; k < MF_ROWS; ++k) {
-            t[k] = make_double2(t[k].x * idg[k].x, t[k].y * idg[k].y);
+            t[k] = make_double2(t[k].x * f2d(idg[k].x), t[k].y * f2d(idg[k].y));
             a3[0] += t[k].x * r[k].x + t[k].y * r[k].y;
             a3[1] += t[k].x * t[k].x + t[k].y * t[k].y;
           }
@@ -3817,13 +3825,6 @@ __device__ __forceinline__ void outflow_entries_add(const EnvView& v, const BoEn
   for (int t = threadIdx.x + TW; t < o.nbe; t += TW) outflow_entry_apply(v, t, outflow_entry_rc(v, t), coef, x, Yd);
 }
 
-// float kept in a register -> double at the point of use: the asm stops the compiler from hoisting the conversion
-// out of the Krylov loop, which turns 4-byte loop invariants into 8-byte ones (measured: they were then spilled to
-// scratch and re-read one by one in every vector phase of every iteration)
-__device__ __forceinline__ double f2d(float f) {
-  asm volatile("" : "+v"(f));
-  return (double)f;
-}
 
 // a workgroup-uniform double moved to scalar registers (two v_readfirstlane): loop invariants such as rho / dt, mu or the
 // squared tolerance otherwise occupy a VGPR pair each for the whole Krylov loop (the 768-thread velocity kernel, capped at
