@@ -177,3 +177,70 @@ def test_remesh_act_equals_env_act_then_remesh(lib_built, meshes, given):
     for a, b in zip(*res):
         assert torch.equal(a, b)
     assert (res[1][6] >= 0).sum() > B // 2 and (res[1][2] == NV - 1).sum() > B // 2 and (res[1][7] == 2).any() and (res[1][6] < 0).any()
+
+
+def _venv(meshes_dir, B, flow_steps):
+    from meshdqn_amd.vec_env import VecEnv2DAirfoil
+    cfg = dict(flow_config=dict(flow_params=dict(mu=1e-3, rho=1.0, inflow="constant"),
+                                geometry_params=dict(mesh=os.path.join(meshes_dir, "ys930.npz")),
+                                solver_params=dict(dt=0.001, solver_type="lu", smooth=True)),
+               agent_params=dict(solver_steps=40, episodes=10, timesteps=10000, threshold=0.001, N_closest=180, gt_drag=-1, gt_time=-1,
+                                 u=-1, p=-1, time_reward=0.005, save_steps=8, goal_vertices=0.95, plot_dir=""))
+    return VecEnv2DAirfoil(cfg, B, flow_steps=flow_steps, flow_overlap=bool(flow_steps))
+
+
+@pytest.mark.parametrize("sparse", [1, 2])
+def test_sparse_interpolation_equals_the_full_fields_where_a_rollout_reads_them(lib_built, sparse):
+    """`mdq_interp_desc.sparse` (round 4: the device-resident step interpolates only what it reads): vertices at every
+    snapshot, the edge midpoints of the airfoil-facet cells at every snapshot, every edge midpoint at the last snapshot
+    (sparse = 1; sparse = 2: no other edge values at all) - bit for bit the values of the full interpolation, on meshes
+    that have taken a few removals."""
+    venv = _venv(GOLDEN, 6, 0)
+    rng = np.random.default_rng(3)
+    for _ in range(4):
+        venv.step(rng.integers(0, 180, venv.B))
+    dt, S = venv.dtopo, venv.S
+    venv._refresh_launch(readback=False, sparse=0)
+    u0, p0 = venv.u.clone(), venv.p.clone()
+    venv._interp_bufs[venv._interp_i ^ 1][0].fill_(float("nan"))          # the set the next call writes
+    venv._interp_bufs[venv._interp_i ^ 1][1].fill_(float("nan"))
+    venv._refresh_launch(readback=False, sparse=sparse)
+    torch.cuda.synchronize()
+    u1, p1 = venv.u, venv.p
+    nv, ne, naf = dt.nv.cpu().numpy(), dt.t["ne"].cpu().numpy(), dt.t["naf"].cpu().numpy()
+    af, cd = dt.t["af_facets"].cpu().numpy(), dt.t["cell_dofs"].cpu().numpy()
+    for b in range(venv.B):
+        n1, n2 = int(nv[b]), int(nv[b] + ne[b])
+        assert torch.equal(p1[b, :, :n1], p0[b, :, :n1])
+        assert torch.equal(u1[b, :, :n1], u0[b, :, :n1])
+        edges = np.unique(cd[b, 3:, af[b, :naf[b], 0]].reshape(-1))
+        assert edges.size >= naf[b] and edges.min() >= n1 and edges.max() < n2
+        assert torch.equal(u1[b, :, edges], u0[b, :, edges])
+        if sparse == 1:
+            assert torch.equal(u1[b, S - 1, :n2], u0[b, S - 1, :n2])
+        other = np.setdiff1d(np.arange(n1, n2), edges)
+        untouched = torch.isnan(u1[b, :S - 1][:, other]).all() if sparse == 1 else torch.isnan(u1[b][:, other]).all()
+        assert bool(untouched)                                              # (nothing else was computed)
+
+
+def test_topology_handover_outputs_equal_the_mesh_and_its_edge_numbering(lib_built):
+    """`mdq_topo_handover` (round 4): the second output set of mdq_env_topology - what the flow stream's engine reads - holds
+    the rows of the mesh and the cell dofs / edge counts the launch wrote to its own outputs."""
+    venv = _venv(GOLDEN, 5, 0)
+    rng = np.random.default_rng(4)
+    for _ in range(3):
+        venv.step(rng.integers(0, 180, venv.B))
+    dt = venv.dtopo
+    ho = dict(coords=torch.full_like(dt.coords, -1.0), cells=torch.full_like(dt.cells, -1), nv=torch.full_like(dt.nv, -1),
+              nt=torch.full_like(dt.nt, -1), cell_dofs=torch.full_like(dt.t["cell_dofs"], -1), ne=torch.full_like(dt.t["ne"], -1))
+    dt.set_handover(**ho)
+    dt.run()
+    dt.set_handover()
+    torch.cuda.synchronize()
+    assert torch.equal(ho["nv"], dt.nv) and torch.equal(ho["nt"], dt.nt) and torch.equal(ho["ne"], dt.t["ne"])
+    for b in range(venv.B):
+        n, t = int(dt.nv[b]), int(dt.nt[b])
+        assert torch.equal(ho["coords"][b, :n], dt.coords[b, :n]) and torch.equal(ho["cells"][b, :t], dt.cells[b, :t])
+        assert torch.equal(ho["cell_dofs"][b, :, :t], dt.t["cell_dofs"][b, :, :t])
+    with pytest.raises(ValueError):
+        dt.set_handover(**{**ho, "cells": ho["cells"][:, :-1]})
