@@ -1172,10 +1172,22 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     }
     __syncthreads();
     for (int q = tid; q < nl * nt; q += TW) gsrc[q] = stage[q];
+    if (nl == 6) {
+      // The P1 lists (vertex <- (cell, local vertex) slots, slot = 3 t + i) ARE the vertex rows of the P2 lists (slot =
+      // 6 t + i, i < 3): the vertex dofs come first, a vertex has one slot per incident cell, and both lists ascend with
+      // the cell.  They are written from the sorted staging array here instead of by a count / scan / fill / sort pass of
+      // their own (16 k of the flow variant's 128 k cycles); the same arrays, bit for bit.
+      int32_t* g1p_ = O.g1_ptr + Bq * (D.NV + 1);
+      int32_t* g1s_ = O.g1_src + Bq * 3 * D.NT;
+      for (int i = tid; i <= nv; i += TW) g1p_[i] = i < nv ? scanb[i] : 3 * nt;
+      for (int q = tid; q < 3 * nt; q += TW) {
+        const int w = stage[q];
+        g1s_[q] = (w / 6) * 3 + (w - (w / 6) * 6);
+      }
+    }
     __syncthreads();
   };
   TT_STAMP(9)
-  gather(3, nv, O.g1_ptr + Bq * (D.NV + 1), O.g1_src + Bq * 3 * D.NT);
   TT_STAMP(10)
   gather(6, n2, O.g2_ptr + Bq * (D.NP + 1), O.g2_src + Bq * 6 * D.NT);
   TT_STAMP(11)
