@@ -39,9 +39,16 @@ extern "C" {
 
 #define MDQ_ABI_VERSION 5
 
+/* The library is built with -fvisibility=hidden: the entry points below are its ONLY exported symbols. */
+#if defined(__GNUC__)
+#define MDQ_API __attribute__((visibility("default")))
+#else
+#define MDQ_API
+#endif
+
 /* ---- error handling ----------------------------------------------------- */
-int mdq_abi_version(void);
-const char* mdq_last_error(void);
+MDQ_API int mdq_abi_version(void);
+MDQ_API const char* mdq_last_error(void);
 
 /* ---- IPCS batch descriptor ---------------------------------------------- */
 typedef struct mdq_ipcs_desc {
@@ -161,7 +168,7 @@ typedef struct mdq_ipcs_desc {
 } mdq_ipcs_desc;
 
 /* doubles of workspace needed for a descriptor with the given capacities */
-int64_t mdq_ipcs_workspace_doubles(int32_t B, int32_t NV, int32_t NT, int32_t NE);
+MDQ_API int64_t mdq_ipcs_workspace_doubles(int32_t B, int32_t NV, int32_t NT, int32_t NE);
 
 /*
  * Assemble the three IPCS operators for every environment of the batch.
@@ -170,7 +177,7 @@ int64_t mdq_ipcs_workspace_doubles(int32_t B, int32_t NV, int32_t NT, int32_t NE
  * per-triangle geometry + P2/P1 element matrices -> CSR values by a
  * deterministic gather, symmetric Dirichlet elimination, Jacobi scaling.
  */
-int mdq_ipcs_assemble(const mdq_ipcs_desc* d, void* stream);
+MDQ_API int mdq_ipcs_assemble(const mdq_ipcs_desc* d, void* stream);
 
 /*
  * A new mesh in the same descriptor (FlowSolver.remesh, flow_solver.py:233-359: the solvers restart without history): the
@@ -178,7 +185,7 @@ int mdq_ipcs_assemble(const mdq_ipcs_desc* d, void* stream);
  * while their counter is zero), and - when `iters` is not NULL - the [B][3] iteration counters too.  Replaces a fill of
  * the whole workspace in front of mdq_ipcs_setup_matfree.
  */
-int mdq_ipcs_reset_history(const mdq_ipcs_desc* d, int32_t* iters, void* stream);
+MDQ_API int mdq_ipcs_reset_history(const mdq_ipcs_desc* d, int32_t* iters, void* stream);
 
 /*
  * Operator setup of the MATRIX-FREE path only (mode 3, CG pressure solver) - what `FlowSolver.remesh` would have to
@@ -189,7 +196,7 @@ int mdq_ipcs_reset_history(const mdq_ipcs_desc* d, int32_t* iters, void* stream)
  * idiag1, sdiagM, sdiagK, K1s.  The pattern pointers (rowptr*, colidx*, asm*, sl2*) and A1/Ms may be NULL; such a
  * descriptor is valid for mdq_ipcs_evolve with mode = 3 and pd_enabled = 0 only.
  */
-int mdq_ipcs_setup_matfree(const mdq_ipcs_desc* d, void* stream);
+MDQ_API int mdq_ipcs_setup_matfree(const mdq_ipcs_desc* d, void* stream);
 
 /*
  * Advance every environment by `nsteps` IPCS time steps.
@@ -204,7 +211,7 @@ int mdq_ipcs_setup_matfree(const mdq_ipcs_desc* d, void* stream);
  * guess of the velocity solve is extrapolated.  Zero `work` whenever u_n / p_n are replaced from outside or the mesh
  * changes (stale history only costs iterations, never accuracy: every solve still runs to `rtol`).
  */
-int mdq_ipcs_evolve(const mdq_ipcs_desc* d, int32_t nsteps, double* drag, double* lift,
+MDQ_API int mdq_ipcs_evolve(const mdq_ipcs_desc* d, int32_t nsteps, double* drag, double* lift,
                     int32_t* iters, void* stream);
 
 /*
@@ -212,7 +219,7 @@ int mdq_ipcs_evolve(const mdq_ipcs_desc* d, int32_t nsteps, double* drag, double
  * kernel launch; the accumulated durations (milliseconds over all nsteps) of the velocity / pressure /
  * correction kernels are returned in host array kernel_ms[3].  Synchronises the stream (measurement aid).
  */
-int mdq_ipcs_evolve_timed(const mdq_ipcs_desc* d, int32_t nsteps, double* drag, double* lift,
+MDQ_API int mdq_ipcs_evolve_timed(const mdq_ipcs_desc* d, int32_t nsteps, double* drag, double* lift,
                           int32_t* iters, void* stream, double* kernel_ms);
 
 /*
@@ -222,7 +229,7 @@ int mdq_ipcs_evolve_timed(const mdq_ipcs_desc* d, int32_t nsteps, double* drag, 
  *   u : device double[B][nfields][N2][2], p : device double[B][nfields][NV]
  *   drag, lift : device double[B][nfields]
  */
-int mdq_probe_forces(const mdq_ipcs_desc* d, int32_t nfields, const double* u, const double* p,
+MDQ_API int mdq_probe_forces(const mdq_ipcs_desc* d, int32_t nfields, const double* u, const double* p,
                      double* drag, double* lift, void* stream);
 
 /*
@@ -236,7 +243,7 @@ int mdq_probe_forces(const mdq_ipcs_desc* d, int32_t nfields, const double* u, c
  * < 0: the mesh exceeds those limits - its header says nparts = 0 and mdq_ipcs_evolve (pd_enabled = 1) runs the
  * Krylov pressure solve for that environment.
  */
-int mdq_ipcs_factorize_pressure(const mdq_ipcs_desc* d, int32_t* status, void* stream);
+MDQ_API int mdq_ipcs_factorize_pressure(const mdq_ipcs_desc* d, int32_t* status, void* stream);
 
 /* ---- graph Q-network forward (airfoilgcnn.py:85-145 NodeRemovalNet, :170-209 AirfoilGCNN) ---- */
 typedef struct mdq_gcn_level {
@@ -274,7 +281,7 @@ typedef struct mdq_gcn_net {
  *   out      device float [B][out_dim] (out)    head outputs (softmax probabilities if net.softmax)
  *   NMAX / EMAX: upper bounds of nodes / edges per graph (sizes the LDS carve-up)
  */
-int mdq_gcn_forward(const mdq_gcn_net* net, int32_t B, int32_t NMAX, int32_t EMAX, const float* x,
+MDQ_API int mdq_gcn_forward(const mdq_gcn_net* net, int32_t B, int32_t NMAX, int32_t EMAX, const float* x,
                     const int32_t* node_ptr, const int32_t* esrc, const int32_t* edst,
                     const int32_t* edge_ptr, float* emb, float* out, void* stream);
 
@@ -286,14 +293,14 @@ int mdq_gcn_forward(const mdq_gcn_net* net, int32_t B, int32_t NMAX, int32_t EMA
  *   status int32 [B]                 0 ok, -1 / -2: graph b has more nodes / edges than NMAX / EMAX (its outputs are NaN;
  *                                    the LDS carve-up is sized from those bounds, a larger graph is never staged)
  */
-int mdq_gcn_forward_ex(const mdq_gcn_net* net, int32_t B, int32_t NMAX, int32_t EMAX, const float* x,
+MDQ_API int mdq_gcn_forward_ex(const mdq_gcn_net* net, int32_t B, int32_t NMAX, int32_t EMAX, const float* x,
                        const int32_t* node_ptr, const int32_t* esrc, const int32_t* edst,
                        const int32_t* edge_ptr, float* emb, float* out, int32_t* perm, int32_t* status, void* stream);
 
 /* The same forward on edge lists PADDED to EMAX slots per graph (graph b: esrc_pad / edst_pad [b * EMAX .. + edge_cnt[b])) -
  * the layout mdq_env_topology writes (edge_src / edge_dst / nedges): no offsets, no compaction in front of the Q-forward
  * of a device-resident env step. */
-int mdq_gcn_forward_padded(const mdq_gcn_net* net, int32_t B, int32_t NMAX, int32_t EMAX, const float* x,
+MDQ_API int mdq_gcn_forward_padded(const mdq_gcn_net* net, int32_t B, int32_t NMAX, int32_t EMAX, const float* x,
                            const int32_t* node_ptr, const int32_t* esrc_pad, const int32_t* edst_pad,
                            const int32_t* edge_cnt, float* emb, float* out, int32_t* perm, int32_t* status, void* stream);
 
@@ -332,7 +339,7 @@ typedef struct mdq_gcn_train_desc {
 } mdq_gcn_train_desc;
 
 /* floats of workspace per graph for mdq_gcn_train_step (-1: bad arguments) */
-int64_t mdq_gcn_train_workspace(const mdq_gcn_net* net, int32_t NMAX, int32_t EMAX);
+MDQ_API int64_t mdq_gcn_train_workspace(const mdq_gcn_net* net, int32_t NMAX, int32_t EMAX);
 
 /*
  * Forward + double-DQN Huber loss + full backward of `net` over a minibatch, without autograd: replaces
@@ -340,7 +347,7 @@ int64_t mdq_gcn_train_workspace(const mdq_gcn_net* net, int32_t NMAX, int32_t EM
  * GCNConv / TopKPooling / global max + mean pool behind it.  One workgroup per graph (forward out of LDS, backward over
  * the rows TopKPooling kept), then a reduction of the per-graph gradients in graph order: bitwise reproducible.
  */
-int mdq_gcn_train_step(const mdq_gcn_net* net, const mdq_gcn_train_desc* d, void* stream);
+MDQ_API int mdq_gcn_train_step(const mdq_gcn_net* net, const mdq_gcn_train_desc* d, void* stream);
 
 /* Parameters of the module (torch layout) into the layout the kernels read, all segments in ONE launch:
  * segment s is a [rows][cols] matrix written transposed ([cols][rows]); cols == 1: a plain copy of `rows` floats. */
@@ -351,7 +358,7 @@ typedef struct mdq_gcn_pack_table {
   float* dst[MDQ_GCN_PACK_MAX];
   int32_t rows[MDQ_GCN_PACK_MAX], cols[MDQ_GCN_PACK_MAX];
 } mdq_gcn_pack_table;
-int mdq_gcn_pack(const mdq_gcn_pack_table* table, void* stream);
+MDQ_API int mdq_gcn_pack(const mdq_gcn_pack_table* table, void* stream);
 
 /* ---- device-resident replay memory + optimiser update (airfoil_dqn.py:48-67 ReplayMemory, :184-200 apply_gradients) ---- */
 /*
@@ -365,7 +372,7 @@ int mdq_gcn_pack(const mdq_gcn_pack_table* table, void* stream);
  * the records (base_prev + b) % capacity, whose action / reward / done [B] (of the step that led to this state) are
  * filled in too.  base_cur or base_prev < 0: that half is skipped.  All pointers device.
  */
-int mdq_replay_step(float* ring, int32_t rec_len, int32_t capacity, int32_t B, int32_t nf, int32_t EM, const float* x,
+MDQ_API int mdq_replay_step(float* ring, int32_t rec_len, int32_t capacity, int32_t B, int32_t nf, int32_t EM, const float* x,
                     const int32_t* edge_src, const int32_t* edge_dst, const int32_t* nedges, int32_t base_cur,
                     int32_t base_prev, const int32_t* action, const double* reward, const uint8_t* done, void* stream);
 
@@ -390,7 +397,7 @@ typedef struct mdq_replay_sample_desc {
   float* reward;              /* [n] */
   float* nonfinal;            /* [n] */
 } mdq_replay_sample_desc;
-int mdq_replay_sample(const mdq_replay_sample_desc* d, void* stream);
+MDQ_API int mdq_replay_sample(const mdq_replay_sample_desc* d, void* stream);
 
 /*
  * torch.optim.Adam.step (amsgrad False; weight decay added to the gradient) for up to 32 parameter tensors in one
@@ -406,25 +413,25 @@ typedef struct mdq_adam_desc {
   float* exp_avg_sq;
   double lr, beta1, beta2, eps, weight_decay, bias_correction1, bias_correction2;
 } mdq_adam_desc;
-int mdq_adam_step(const mdq_adam_desc* d, void* stream);
+MDQ_API int mdq_adam_step(const mdq_adam_desc* d, void* stream);
 
 /* Up to 8 buffer copies in one launch (no reference counterpart; the env step hands its meshes and the warm-start fields
  * to the flow engine with it): buffer t = rows[t] rows of row_bytes[t] bytes, consecutive rows src_stride_bytes[t] /
  * dst_stride_bytes[t] apart (all multiples of 4, pointers 4-byte aligned; device pointers, host arrays of them). */
-int mdq_copy_strided(int32_t n, void* const* dst, const void* const* src, const int64_t* rows, const int64_t* row_bytes,
+MDQ_API int mdq_copy_strided(int32_t n, void* const* dst, const void* const* src, const int64_t* rows, const int64_t* row_bytes,
                      const int64_t* src_stride_bytes, const int64_t* dst_stride_bytes, void* stream);
 
 /* Probe kernel for meshdqn_amd/streams.py (no reference counterpart): `wgs` workgroups that each hold `lds_bytes` of LDS and
  * spin for `ticks_100mhz` ticks of the 100 MHz wall clock - with more workgroups than CUs it keeps the dispatcher of its
  * hardware queue busy, which is how two HIP streams are tested for really running beside each other. */
-int mdq_spin(int32_t wgs, int32_t lds_bytes, int64_t ticks_100mhz, void* stream);
+MDQ_API int mdq_spin(int32_t wgs, int32_t lds_bytes, int64_t ticks_100mhz, void* stream);
 
 /* A HIP stream restricted to the compute units of `mask` (nwords 32-bit words; bit i = compute unit i in the driver's
  * numbering, which goes round-robin over the XCDs and then over the shader engines of an XCD), and its release.  No
  * reference counterpart: meshdqn_amd/streams.py gives the env step's main chain and its flow leg disjoint halves of the
  * chip (both are chains of kernels with one workgroup per environment). */
-int mdq_stream_create_cu_mask(const uint32_t* mask, int32_t nwords, void** stream);
-int mdq_stream_destroy(void* stream);
+MDQ_API int mdq_stream_create_cu_mask(const uint32_t* mask, int32_t nwords, void** stream);
+MDQ_API int mdq_stream_destroy(void* stream);
 
 /* ---- snapshot interpolation onto coarsened meshes (Env2DAirfoil.py:556-593, :515-522) ---- */
 typedef struct mdq_interp_desc {
@@ -474,7 +481,7 @@ typedef struct mdq_interp_desc {
  * coarsened meshes: point location (containing cell, else nearest = extrapolation) + basis evaluation.
  * Replaces `v_func.interpolate(original_u)` / `p_func.interpolate(original_p)` (Env2DAirfoil.py:556-568).
  */
-int mdq_interpolate_snapshots(const mdq_interp_desc* d, void* stream);
+MDQ_API int mdq_interpolate_snapshots(const mdq_interp_desc* d, void* stream);
 
 /* ---- host-side mesh smoothing (DOLFIN Mesh.smooth, flow_solver.py:65-67,236-237) ---- */
 /*
@@ -483,7 +490,7 @@ int mdq_interpolate_snapshots(const mdq_interp_desc* d, void* stream);
  *   coords [nv][2] in/out; nbr_ptr[nv+1], nbr[]: vertex -> neighbour vertices;
  *   vc_ptr[nv+1], vc[]: vertex -> cell*3+local; cells[nt][3]; on_boundary[nv].
  */
-int mdq_smooth_host(double* coords, int32_t nv, const int32_t* cells, int32_t nt,
+MDQ_API int mdq_smooth_host(double* coords, int32_t nv, const int32_t* cells, int32_t nt,
                     const int64_t* nbr_ptr, const int64_t* nbr, const int64_t* vc_ptr,
                     const int64_t* vc, const uint8_t* on_boundary, int32_t iterations);
 
@@ -496,7 +503,7 @@ int mdq_smooth_host(double* coords, int32_t nv, const int32_t* cells, int32_t nt
  *   coords [B][NV][2], cells [B][NT][3] (any orientation in; ascending vertex ids per cell out),
  *   nv[B], nt[B] (updated), status[B] (0 ok, <0: star/ear-clipping/flip failure, mesh unusable).
  */
-int mdq_remesh_host(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv,
+MDQ_API int mdq_remesh_host(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv,
                     int32_t* nt, const int32_t* remove_idx, int32_t smooth_iters, int32_t nthreads,
                     int32_t* status);
 
@@ -506,7 +513,7 @@ int mdq_remesh_host(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* 
  * reshape of the (S,N,2) array).  coords [B][NV][2], u [B][S][NP][2], p [B][S][NV] (f64), n_closest [B][N], nsel [B]
  * (rows >= nsel are zero) -> x [B][N][2+3S] (f32).  All device pointers.
  */
-int mdq_state_features(int32_t B, int32_t N, int32_t S, int32_t NV, int32_t NP, const double* coords, const double* u,
+MDQ_API int mdq_state_features(int32_t B, int32_t N, int32_t S, int32_t NV, int32_t NP, const double* coords, const double* u,
                        const double* p, const int32_t* n_closest, const int32_t* nsel, float* x, void* stream);
 
 /*
@@ -514,7 +521,7 @@ int mdq_state_features(int32_t B, int32_t N, int32_t S, int32_t NV, int32_t NP, 
  * arrays of mdq_env_topology to the packed form mdq_gcn_forward reads: the first edge_ptr[b+1] - edge_ptr[b]
  * entries of src_pad / dst_pad [B][EMAX] go to esrc / edst [edge_ptr[b] ...).  All device pointers.
  */
-int mdq_compact_edges(int32_t B, int32_t EMAX, const int32_t* src_pad, const int32_t* dst_pad, const int32_t* edge_ptr,
+MDQ_API int mdq_compact_edges(int32_t B, int32_t EMAX, const int32_t* src_pad, const int32_t* dst_pad, const int32_t* edge_ptr,
                       int32_t* esrc, int32_t* edst, void* stream);
 
 /* ---- control logic of the batched env step on the device (Env2DAirfoil.step, Env2DAirfoil.py:318-377; calculate_reward
@@ -528,13 +535,13 @@ int mdq_compact_edges(int32_t B, int32_t EMAX, const int32_t* src_pad, const int
  * shifts the N-closest window (offset[b] += 1), an action without a vertex behind it (>= nsel[b]) gives code 2, otherwise
  * rem[b] = coord_map[b][action] (else -1).  Outputs: action, rem, code [B].
  */
-int mdq_env_act(int32_t B, int32_t N, const float* q, const uint8_t* explore, const int32_t* rand_action,
+MDQ_API int mdq_env_act(int32_t B, int32_t N, const float* q, const uint8_t* explore, const int32_t* rand_action,
                 const int32_t* nsel, const int32_t* coord_map, int32_t* offset, int32_t* action, int32_t* rem,
                 int32_t* code, void* stream);
 
 /* its[b] = iterations where a vertex was removed (rem >= 0) and the re-triangulation succeeded (rstat == 0), else 0:
  * the smoothing request of flow_solver.py:236-237 for mdq_smooth. */
-int mdq_env_smooth_iters(int32_t B, const int32_t* rem, const int32_t* rstat, int32_t iterations, int32_t* its,
+MDQ_API int mdq_env_smooth_iters(int32_t B, const int32_t* rem, const int32_t* rstat, int32_t iterations, int32_t* its,
                          void* stream);
 
 /*
@@ -545,14 +552,14 @@ int mdq_env_smooth_iters(int32_t B, const int32_t* rem, const int32_t* rstat, in
  * nsel < N, topology status != 0 - the latter also sets bit 0 of *err_flag); failed steps get negative_reward.
  * code / steps [B] in/out (steps restart at 0 for terminated environments when auto_reset); reward f64 [B], done u8 [B].
  */
-int mdq_env_result(int32_t B, int32_t N, int32_t S, const double* new_drags, const double* gt_drag, const int32_t* nv,
+MDQ_API int mdq_env_result(int32_t B, int32_t N, int32_t S, const double* new_drags, const double* gt_drag, const int32_t* nv,
                    int32_t nv0, const int32_t* rstat, const int32_t* topo_status, const int32_t* nsel, int32_t* code,
                    int32_t* steps, double threshold, double time_reward, double goal_vertices, int32_t timesteps,
                    double negative_reward, int32_t auto_reset, double* reward, uint8_t* done, int32_t* err_flag,
                    int32_t* nv_out /* optional [B]: copy of nv (the vertex counts of this step) */, void* stream);
 
 /* mdq_restore_rows for the environments with mask[b] != 0 (device array): the in-place reset without a host-side list. */
-int mdq_restore_rows_masked(int32_t n, void* const* dst, const void* const* src, const int64_t* row_bytes, int32_t B,
+MDQ_API int mdq_restore_rows_masked(int32_t n, void* const* dst, const void* const* src, const int64_t* row_bytes, int32_t B,
                             const uint8_t* mask, void* stream);
 
 /*
@@ -608,20 +615,20 @@ typedef struct {
                                   the rows this launch has just restored: only valid with ONE workgroup per environment) */
   float* x;                    /* [B][N][2 + 3 S] */
 } mdq_env_finish_desc;
-int mdq_env_finish(const mdq_env_finish_desc* d, void* stream);
+MDQ_API int mdq_env_finish(const mdq_env_finish_desc* d, void* stream);
 
 /*
  * mdq_env_act + mdq_remesh in one launch (the action decoding is the head of the removal kernel; same outputs as the two
  * entry points called one after the other): q / explore / rand_action / nsel / coord_map / offset / action / rem / code as
  * for mdq_env_act, the mesh arguments and status as for mdq_remesh.
  */
-int mdq_remesh_act(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv, int32_t* nt, int32_t N,
+MDQ_API int mdq_remesh_act(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv, int32_t* nt, int32_t N,
                    const float* q, const uint8_t* explore, const int32_t* rand_action, const int32_t* nsel,
                    const int32_t* coord_map, int32_t* offset, int32_t* action, int32_t* rem, int32_t* code, int32_t* status,
                    void* stream);
 
 /* edge_ptr [B+1] = exclusive prefix sums of nedges [B] (offsets of mdq_compact_edges / mdq_gcn_forward). */
-int mdq_edge_ptr(int32_t B, const int32_t* nedges, int32_t* edge_ptr, void* stream);
+MDQ_API int mdq_edge_ptr(int32_t B, const int32_t* nedges, int32_t* edge_ptr, void* stream);
 
 /*
  * Env2DAirfoil.reset (Env2DAirfoil.py:102-129: mesh, snapshots and selection back to the initial ones) for a SUBSET
@@ -629,7 +636,7 @@ int mdq_edge_ptr(int32_t B, const int32_t* nedges, int32_t* edge_ptr, void* stre
  * row idx[i] (i < n_idx) is overwritten with the cached initial row src[t].  dst / src / row_bytes are host arrays
  * of device pointers / sizes (4-byte aligned multiples of 4 bytes); idx is a device pointer.
  */
-int mdq_restore_rows(int32_t n, void* const* dst, const void* const* src, const int64_t* row_bytes, int32_t n_idx,
+MDQ_API int mdq_restore_rows(int32_t n, void* const* dst, const void* const* src, const int64_t* row_bytes, int32_t n_idx,
                      const int32_t* idx, void* stream);
 
 /*
@@ -640,7 +647,7 @@ int mdq_restore_rows(int32_t n, void* const* dst, const void* const* src, const 
  * cells [B][NT][3], nv / nt [B], iterations [B] (0 = leave that mesh alone); all device pointers.
  * Capacity: NV <= 1024, NT <= 2048 (larger meshes: mdq_smooth_host).
  */
-int mdq_smooth(int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t* cells, const int32_t* nv,
+MDQ_API int mdq_smooth(int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t* cells, const int32_t* nv,
                const int32_t* nt, const int32_t* iterations, void* stream);
 
 /*
@@ -653,13 +660,13 @@ int mdq_smooth(int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t*
  * device workspace of at least mdq_smooth_fast_workspace_bytes(B, NV) bytes, 16-byte aligned (block inverses,
  * per-environment diagnostics).
  */
-int64_t mdq_smooth_fast_workspace_bytes(int32_t B, int32_t NV);
-int mdq_smooth_fast(int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t* cells, const int32_t* nv,
+MDQ_API int64_t mdq_smooth_fast_workspace_bytes(int32_t B, int32_t NV);
+MDQ_API int mdq_smooth_fast(int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t* cells, const int32_t* nv,
                     const int32_t* nt, const int32_t* iterations, void* workspace, int64_t workspace_bytes, void* stream);
 /* Inside an env step (Env2DAirfoil._check_mesh -> flow_solver.remesh -> smooth(50), flow_solver.py:236-237): `iterations`
  * sweeps for the environments whose vertex removal succeeded (rem[b] >= 0 and rstat[b] == 0, the outputs of mdq_env_act /
  * mdq_remesh), none for the others - mdq_env_smooth_iters + mdq_smooth_fast in one launch. */
-int mdq_smooth_fast_env(int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t* cells, const int32_t* nv,
+MDQ_API int mdq_smooth_fast_env(int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t* cells, const int32_t* nv,
                         const int32_t* nt, const int32_t* rem, const int32_t* rstat, int32_t iterations, void* workspace,
                         int64_t workspace_bytes, void* stream);
 
@@ -668,7 +675,7 @@ int mdq_smooth_fast_env(int32_t B, int32_t NV, int32_t NT, double* coords, const
  * that met an update that was not clearly a full step and were redone by careful sweeps (see mdq_smooth.hip).
  * out64 is a HOST array of 64 int64 (may be NULL); reset != 0 zeroes the counters.  Synchronises the device.
  */
-int mdq_smooth_stats(int64_t* out64, int32_t reset);
+MDQ_API int mdq_smooth_stats(int64_t* out64, int32_t reset);
 
 /*
  * Env2DAirfoil._remove_vertex (Env2DAirfoil.py:452-512) for B meshes on the GPU, WITHOUT the smoothing (mdq_smooth):
@@ -678,7 +685,7 @@ int mdq_smooth_stats(int64_t* out64, int32_t reset);
  * -1..-4 star / boundary vertex / ear clipping failures, -11 non-manifold, -12 flip work list exhausted (mesh b is
  * untouched on failure).  All pointers are device pointers.  Capacity: NV <= 1024, NT <= 2048.
  */
-int mdq_remesh(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv, int32_t* nt,
+MDQ_API int mdq_remesh(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv, int32_t* nt,
                const int32_t* remove_idx, int32_t* status, void* stream);
 
 /* ---- optional outputs of mdq_env_topology_host: the index data of the matrix-free IPCS path (mode 3 with the CG
@@ -760,14 +767,14 @@ typedef struct mdq_env_topo_desc {
  * 293-315) and the state graph edges (:258-280).  status[b] = 0 ok, <0 capacity exceeded
  * (-1 NP, -2 NAF, -3 EMAX, -4 more than 2 outflow rows per row-owner thread, -5 NBO/NBE, -6 NSE1).
  */
-int mdq_env_topology_host(const mdq_env_topo_desc* d, int32_t nthreads, int32_t* status);
+MDQ_API int mdq_env_topology_host(const mdq_env_topo_desc* d, int32_t nthreads, int32_t* status);
 
 /*
  * The same engine as a HIP kernel (one workgroup per environment, everything in LDS): every pointer of the descriptor
  * (and of d->ipcs, a HOST struct holding device pointers) and `status` are DEVICE pointers.  All output arrays are
  * bit-identical to mdq_env_topology_host's.  Capacity: NV <= 1024, NT <= 2048, NP <= 4096, npoly <= 256.
  */
-int mdq_env_topology(const mdq_env_topo_desc* d, void* stream, int32_t* status);
+MDQ_API int mdq_env_topology(const mdq_env_topo_desc* d, void* stream, int32_t* status);
 
 #ifdef __cplusplus
 }

@@ -2,19 +2,45 @@
 
 hipcc cross-compiles for gfx950 without a GPU present; the built .so is
 git-ignored but travels with the working tree to the GPU box.
+
+The library is several translation units compiled in parallel (objects cached
+under `build/obj`, recompiled when their sources or any header change) and
+linked with `-fvisibility=hidden`: only the `MDQ_API` entry points of
+`include/meshdqn_hip.h` are exported.
 """
 from __future__ import annotations
 
+import concurrent.futures as cf
+import hashlib
 import os
 import shutil
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmeshdqn_hip.so")
-SOURCES = ["mdq_lib.hip"]
+OBJ = os.path.join(ROOT, "build", "obj")
 ARCH = "gfx950"
+
+# translation unit -> (source, extra flags, the .hip files it includes besides itself).  mdq_ipcs.hip is compiled in
+# parts (-DMDQ_IPCS_PART=k: each part instantiates the kernels of some operator modes and their launchers; part 0 also
+# holds the entry points) because it alone took a minute as one unit.
+UNITS = {
+    "ipcs0": ("mdq_ipcs.hip", ["-DMDQ_IPCS_PART=0"], []),
+    "ipcs1": ("mdq_ipcs.hip", ["-DMDQ_IPCS_PART=1"], []),
+    "ipcs2": ("mdq_ipcs.hip", ["-DMDQ_IPCS_PART=2"], []),
+    "ipcs3": ("mdq_ipcs.hip", ["-DMDQ_IPCS_PART=3"], []),
+    "pressure_factor": ("mdq_pressure_factor.hip", [], []),
+    "gcn": ("mdq_tu_gcn.hip", [], ["mdq_gcn.hip", "mdq_gcn_train.hip"]),
+    "replay": ("mdq_replay.hip", [], []),
+    "mesh": ("mdq_mesh.hip", [], []),
+    "smooth": ("mdq_tu_smooth.hip", [], ["mdq_smooth_big.hip", "mdq_smooth.hip", "mdq_smooth_linear.hip"]),
+    "topology": ("mdq_topology.hip", [], []),
+    "remesh": ("mdq_remesh.hip", [], []),
+    "host_mesh": ("mdq_host_mesh.hip", [], []),
+}
 
 
 def _hipcc() -> str:
@@ -24,6 +50,30 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm; set HIPCC=/path/to/hipcc)")
 
 
+def _headers() -> list:
+    hs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
+    hs.append(os.path.join(ROOT, "include", "meshdqn_hip.h"))
+    return hs
+
+
+def _flags(verbose: bool) -> list:
+    fl = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-fvisibility=hidden",
+          "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    if verbose:
+        fl.append("-Rpass-analysis=kernel-resource-usage")
+    return fl + os.environ.get("MDQ_CFLAGS", "").split()
+
+
+def _unit_key(name: str, flags: list) -> str:
+    src, extra, incs = UNITS[name]
+    h = hashlib.sha256()
+    h.update(" ".join(flags + extra).encode())
+    for p in [os.path.join(CSRC, src)] + [os.path.join(CSRC, i) for i in incs] + _headers():
+        with open(p, "rb") as f:
+            h.update(p.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
 def _stale() -> bool:
     if os.environ.get("MDQ_LIB_PATH"):      # an explicitly chosen library: nothing to build
         return False
@@ -31,26 +81,70 @@ def _stale() -> bool:
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
-    deps.append(os.path.join(HERE, "..", "include", "meshdqn_hip.h"))
+    deps.append(os.path.join(ROOT, "include", "meshdqn_hip.h"))
     return any(os.path.getmtime(p) > t for p in deps if os.path.isfile(p))
 
 
+def declared_symbols() -> list:
+    """The entry points `include/meshdqn_hip.h` declares (MDQ_API)."""
+    import re
+    with open(os.path.join(ROOT, "include", "meshdqn_hip.h")) as f:
+        return sorted(set(re.findall(r"^MDQ_API\s+[A-Za-z0-9_\* ]*?\b(mdq_[a-z0-9_]+)\s*\(", f.read(), flags=re.M)))
+
+
+def _version_script() -> str:
+    """Linker version script: the header's entry points (and the *_trace_host helpers of the -DMDQ_*_TRACE debug builds) are
+    the library's only dynamic symbols - kernel stubs, libstdc++ instantiations and __hip_cuid_* stay local."""
+    path = os.path.join(OBJ, "exports.map")
+    body = "{\n  global:\n" + "".join(f"    {n};\n" for n in declared_symbols()) + "    mdq_*_trace_host;\n  local:\n    *;\n};\n"
+    with open(path, "w") as f:
+        f.write(body)
+    return path
+
+
+def _compile(name: str, flags: list, force: bool) -> tuple:
+    src, extra, _ = UNITS[name]
+    obj = os.path.join(OBJ, name + ".o")
+    keyf = obj + ".key"
+    key = _unit_key(name, flags)
+    if not force and os.path.exists(obj) and os.path.exists(keyf) and open(keyf).read() == key:
+        return name, obj, ""
+    cmd = [_hipcc()] + flags + extra + ["-c", os.path.join(CSRC, src), "-o", obj + ".tmp"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc failed on {src} ({name}):\n{res.stdout}{res.stderr}")
+    os.replace(obj + ".tmp", obj)
+    with open(keyf, "w") as f:
+        f.write(key)
+    return name, obj, res.stderr
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
+    """`force` recompiles every unit; otherwise only units whose sources / headers / flags changed."""
+    if not force and not verbose and not _stale():
         return LIB
-    cmd = [_hipcc(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared",
-           "-I", os.path.join(HERE, "..", "include"), "-I", CSRC]
+    os.makedirs(OBJ, exist_ok=True)
+    flags = _flags(verbose)
+    jobs = int(os.environ.get("MDQ_BUILD_JOBS", "0")) or min(len(UNITS), os.cpu_count() or 4)
+    objs, logs = {}, {}
+    with cf.ThreadPoolExecutor(jobs) as ex:
+        futs = [ex.submit(_compile, n, flags, force or verbose) for n in UNITS]
+        for f in futs:
+            try:
+                n, o, log = f.result()
+            except RuntimeError as e:
+                sys.stderr.write(str(e))
+                raise RuntimeError("hipcc failed building libmeshdqn_hip.so") from None
+            objs[n], logs[n] = o, log
     if verbose:
-        cmd.append("-Rpass-analysis=kernel-resource-usage")
-    cmd += os.environ.get("MDQ_CFLAGS", "").split()
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", LIB + ".tmp"]
+        for n in UNITS:
+            sys.stderr.write(logs[n])
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fvisibility=hidden",
+           f"-Wl,--version-script={_version_script()}"] + [objs[n] for n in UNITS] + ["-o", LIB + ".tmp"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         sys.stderr.write(res.stdout + res.stderr)
-        raise RuntimeError("hipcc failed building libmeshdqn_hip.so")
-    if verbose:
-        sys.stderr.write(res.stderr)
+        raise RuntimeError("hipcc failed linking libmeshdqn_hip.so")
     os.replace(LIB + ".tmp", LIB)
     return LIB
 

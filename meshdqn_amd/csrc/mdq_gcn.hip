@@ -14,6 +14,7 @@
 #include <cmath>
 
 #include "../../include/meshdqn_hip.h"
+#include "mdq_internal.h"
 
 namespace mdq_gcn {
 

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/meshdqn_hip.h"
+#include "mdq_internal.h"
 
 #include <condition_variable>
 #include <functional>

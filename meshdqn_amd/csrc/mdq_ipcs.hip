@@ -20,8 +20,22 @@
 #include <string>
 
 #include "../../include/meshdqn_hip.h"
+#include "mdq_internal.h"
 #include "mdq_device.h"
 #include "mdq_elem.h"
+
+// This file is compiled as several translation units (meshdqn_amd/build.py: -DMDQ_IPCS_PART=k), each instantiating the
+// kernels of some operator modes together with their launchers - as ONE unit it took a minute of every rebuild:
+//   part 0  entry points, assembly, matrix-free set-up, probes, the three kernels of mode 3
+//   part 1  evolve_kernel<0 / 1> (assembled SELL operators)
+//   part 2  evolve_kernel<5> (element tiles, global vectors), evolve_team_kernel (mode 4)
+//   part 3  the kernels of mode 2 (element tiles, LDS / register vectors: the reproducible mode of the long runs)
+// Without the macro everything is one unit.  Kernels and device tables have internal linkage: every unit that uses the
+// reference-element tables owns a copy of them (ensure_tables).
+#ifndef MDQ_IPCS_PART
+#define MDQ_IPCS_PART -1
+#endif
+#define MDQ_IN_PART(k) (MDQ_IPCS_PART == (k) || MDQ_IPCS_PART == -1)
 
 #ifndef MDQ_CORR_MX0_INTERLEAVE
 #define MDQ_CORR_MX0_INTERLEAVE false
@@ -34,7 +48,7 @@
 #endif
 namespace mdq {
 
-__constant__ RefTab c_tab;
+static __constant__ RefTab c_tab;
 
 constexpr int MF_CH = 1024;  // triangles per LDS tile: 2 per thread, interleaved for FP64 ILP (host maps use the same chunking)
 
@@ -230,7 +244,7 @@ __device__ inline void outflow_entry(const EnvView& v, int e, int k, int i, int 
   }
 }
 
-__global__ __launch_bounds__(WG) void assemble_kernel(mdq_ipcs_desc d) {
+static __global__ __launch_bounds__(WG) void assemble_kernel(mdq_ipcs_desc d) {
   const int b = blockIdx.x;
   EnvView v = env_view(d, b);
   v.nnz2 = v.rowptr2[v.n2];
@@ -433,13 +447,15 @@ __global__ __launch_bounds__(WG) void assemble_kernel(mdq_ipcs_desc d) {
 // the element matrices (dof <- element-slot gathers g2/g1), the scaled + BC-eliminated P1 Laplacian in SELL-64.
 // Same numbers as assemble_kernel up to the summation order.  One workgroup per environment.
 #ifdef MDQ_SETUP_TRACE
-__device__ long long mdq_st_trace_buf[16];
+static __device__ long long mdq_st_trace_buf[16];
 #define ST_STAMP(k) { __syncthreads(); const long long tn_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) mdq_st_trace_buf[k] += tn_ - tq_; tq_ = tn_; }
-extern "C" int mdq_st_trace_host(long long* out, int reset) {
+#if MDQ_IN_PART(0)
+extern "C" MDQ_API int mdq_st_trace_host(long long* out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mdq_st_trace_buf), sizeof(long long) * 16) != hipSuccess) return -1;
   if (reset) { long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(mdq_st_trace_buf), z, sizeof z) != hipSuccess) return -1; }
   return 0;
 }
+#endif
 #else
 #define ST_STAMP(k)
 #endif
@@ -973,13 +989,15 @@ __device__ __forceinline__ void tile_accumulate(const EnvView& v, double2* es, T
 // tile positions (larger meshes, MeshTopology.matfree_maps).
 #ifdef MDQ_T5_TRACE
 // debug build only: s_memtime cycles of the phases of a mode-5 operator application (thread 0 of environment 0)
-__device__ long long mdq_t5_trace_buf[8];
+static __device__ long long mdq_t5_trace_buf[8];
 #define T5_STAMP(k) { const long long tn_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) mdq_t5_trace_buf[k] += tn_ - t5q_; t5q_ = tn_; }
-extern "C" int mdq_t5_trace_host(long long* out, int reset) {
+#if MDQ_IN_PART(2)
+extern "C" MDQ_API int mdq_t5_trace_host(long long* out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mdq_t5_trace_buf), sizeof(long long) * 8) != hipSuccess) return -1;
   if (reset) { long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(mdq_t5_trace_buf), z, sizeof z) != hipSuccess) return -1; }
   return 0;
 }
+#endif
 #else
 #define T5_STAMP(k)
 #endif
@@ -2076,27 +2094,33 @@ __device__ inline int cg_pressure_2l(int n, const int32_t* sl_off, const int32_t
 
 #ifdef MDQ_AT_TRACE
 // debug build only: s_memtime deltas of thread 0 of environment 0 at the phase boundaries of at_velocity_kernel
-__device__ long long mdq_at_trace_buf[16];
+static __device__ long long mdq_at_trace_buf[16];
 #define AT_STAMP(k) { const long long tn_ = __builtin_amdgcn_s_memtime(); if (tid == 0 && b == 0) mdq_at_trace_buf[k] += tn_ - tq_; tq_ = tn_; }
-extern "C" int mdq_at_trace_host(long long* out, int reset) {
+#if MDQ_IN_PART(0)
+extern "C" MDQ_API int mdq_at_trace_host(long long* out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mdq_at_trace_buf), sizeof(long long) * 16) != hipSuccess) return -1;
   if (reset) { long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(mdq_at_trace_buf), z, sizeof z) != hipSuccess) return -1; }
   return 0;
 }
-__device__ long long mdq_pt_trace_buf[16];
+#endif
+static __device__ long long mdq_pt_trace_buf[16];
 #define PT_STAMP(k) { const long long tn_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) mdq_pt_trace_buf[k] += tn_ - tqp_; tqp_ = tn_; }
-extern "C" int mdq_pt_trace_host(long long* out, int reset) {
+#if MDQ_IN_PART(0)
+extern "C" MDQ_API int mdq_pt_trace_host(long long* out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mdq_pt_trace_buf), sizeof(long long) * 16) != hipSuccess) return -1;
   if (reset) { long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(mdq_pt_trace_buf), z, sizeof z) != hipSuccess) return -1; }
   return 0;
 }
-__device__ long long mdq_ct_trace_buf[16];
+#endif
+static __device__ long long mdq_ct_trace_buf[16];
 #define CT_STAMP(k) { const long long tn_ = __builtin_amdgcn_s_memtime(); if (tid == 0 && b == 0) mdq_ct_trace_buf[k] += tn_ - tq_; tq_ = tn_; }
-extern "C" int mdq_ct_trace_host(long long* out, int reset) {
+#if MDQ_IN_PART(0)
+extern "C" MDQ_API int mdq_ct_trace_host(long long* out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mdq_ct_trace_buf), sizeof(long long) * 16) != hipSuccess) return -1;
   if (reset) { long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(mdq_ct_trace_buf), z, sizeof z) != hipSuccess) return -1; }
   return 0;
 }
+#endif
 #else
 #define AT_STAMP(k)
 #define CT_STAMP(k)
@@ -2285,7 +2309,7 @@ __device__ inline void forces(const EnvView& v, double mu, const double2* __rest
   lift = acc[1];
 }
 
-__global__ __launch_bounds__(WG) void probe_kernel(mdq_ipcs_desc d, int nfields, const double* u, const double* p,
+static __global__ __launch_bounds__(WG) void probe_kernel(mdq_ipcs_desc d, int nfields, const double* u, const double* p,
                                                     double* drag, double* lift) {
   __shared__ double red[NWAVE * 2];
   const int b = blockIdx.x;
@@ -2678,7 +2702,7 @@ __device__ __forceinline__ void team_sum(double (&v)[N], double* red, Team& t) {
 // the counters of the extrapolated initial guesses (tentative velocities stored, corrections stored / ring position / lagged
 // |b| / step parity of the fused correction start), of every operator mode, back to zero - instead of a fill of the whole
 // workspace (100 MB per 128 environments in every S3 env step) - and, optionally, the iteration counters.
-__global__ void reset_history_kernel(mdq_ipcs_desc d, int32_t* iters) {
+static __global__ void reset_history_kernel(mdq_ipcs_desc d, int32_t* iters) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= d.B) return;
   double* w = d.work + (int64_t)b * work_per_env(d.NV, d.NT, d.NE);
@@ -2692,7 +2716,7 @@ __global__ void reset_history_kernel(mdq_ipcs_desc d, int32_t* iters) {
   if (iters) iters[3 * b] = iters[3 * b + 1] = iters[3 * b + 2] = 0;
 }
 
-__global__ void team_reset_kernel(mdq_ipcs_desc d) {
+static __global__ void team_reset_kernel(mdq_ipcs_desc d) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= d.B) return;
   double* w = d.work + (int64_t)b * work_per_env(d.NV, d.NT, d.NE);
@@ -4286,7 +4310,7 @@ __global__ __launch_bounds__(NTH) void at_pressure_kernel(mdq_ipcs_desc d, int32
   if (tid == 0 && iters) iters[3 * b + 1] += it_p;
 }
 
-__global__ __launch_bounds__(WG) void at_correction_kernel(mdq_ipcs_desc d, int nsteps, int step, double* drag,
+static __global__ __launch_bounds__(WG) void at_correction_kernel(mdq_ipcs_desc d, int nsteps, int step, double* drag,
                                                             double* lift, int32_t* iters) {
   extern __shared__ __align__(16) double smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -4590,17 +4614,6 @@ __global__ __launch_bounds__(WG) void at_correction_kernel(mdq_ipcs_desc d, int 
 
 // ================================================================== host side
 
-static thread_local std::string g_err;
-
-static int fail(const char* what, hipError_t e) {
-  g_err = std::string(what) + ": " + hipGetErrorString(e);
-  return -1;
-}
-static int fail_msg(const std::string& m) {
-  g_err = m;
-  return -2;
-}
-
 static void build_tables(RefTab& T) {
   const double s15 = std::sqrt(15.0);
   const double a1 = (6.0 - s15) / 21.0, a2 = (6.0 + s15) / 21.0;
@@ -4639,7 +4652,8 @@ static void build_tables(RefTab& T) {
   T.gw[0] = T.gw[1] = 0.5;
 }
 
-static int ensure_tables() {
+// the reference-element tables of THIS translation unit's kernels (c_tab has internal linkage)
+static hipError_t upload_tables() {
   static std::once_flag once;
   static hipError_t err = hipSuccess;
   std::call_once(once, [] {
@@ -4647,6 +4661,66 @@ static int ensure_tables() {
     build_tables(T);
     err = hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &T, sizeof(T));
   });
+  return err;
+}
+
+// launchers of the operator modes whose kernels live in the other parts of this file (each uploads its own tables)
+struct EvolveArgs {
+  const mdq_ipcs_desc* d;
+  size_t lds;
+  int nsteps;
+  double *drag, *lift;
+  int32_t* iters;
+  hipStream_t st;
+};
+hipError_t part_launch_assembled(int mode, bool k1_lds, bool pg, const EvolveArgs& a);   // modes 0 / 1 (part 1)
+hipError_t part_launch_tiles(int mode, bool k1_lds, bool pg, const EvolveArgs& a);       // modes 5 / 4 (part 2)
+hipError_t part_launch_mf(bool k1_lds, const EvolveArgs& a);                              // mode 2     (part 3)
+
+#if MDQ_IN_PART(1)
+hipError_t part_launch_assembled(int mode, bool k1_lds, bool pg, const EvolveArgs& a) {
+  if (hipError_t e = upload_tables(); e != hipSuccess) return e;
+  if (mode == 1)
+    return k1_lds ? launch_evolve<1, true>(a.d, a.lds, a.nsteps, a.drag, a.lift, a.iters, a.st)
+                  : launch_evolve<1, false>(a.d, a.lds, a.nsteps, a.drag, a.lift, a.iters, a.st);
+  return pg ? launch_evolve<0, false, true>(a.d, a.lds, a.nsteps, a.drag, a.lift, a.iters, a.st)
+            : (k1_lds ? launch_evolve<0, true>(a.d, a.lds, a.nsteps, a.drag, a.lift, a.iters, a.st)
+                      : launch_evolve<0, false>(a.d, a.lds, a.nsteps, a.drag, a.lift, a.iters, a.st));
+}
+#endif
+#if MDQ_IN_PART(2)
+hipError_t part_launch_tiles(int mode, bool k1_lds, bool pg, const EvolveArgs& a) {
+  if (hipError_t e = upload_tables(); e != hipSuccess) return e;
+  if (mode == 4)
+    return k1_lds ? launch_evolve_team<true>(a.d, a.lds, a.nsteps, a.drag, a.lift, a.iters, a.st)
+                  : launch_evolve_team<false>(a.d, a.lds, a.nsteps, a.drag, a.lift, a.iters, a.st);
+  return pg ? launch_evolve<5, false, true>(a.d, a.lds, a.nsteps, a.drag, a.lift, a.iters, a.st)
+            : (k1_lds ? launch_evolve<5, true>(a.d, a.lds, a.nsteps, a.drag, a.lift, a.iters, a.st)
+                      : launch_evolve<5, false>(a.d, a.lds, a.nsteps, a.drag, a.lift, a.iters, a.st));
+}
+#endif
+#if MDQ_IN_PART(3)
+hipError_t part_launch_mf(bool k1_lds, const EvolveArgs& a) {
+  if (hipError_t e = upload_tables(); e != hipSuccess) return e;
+  return k1_lds ? launch_evolve_mf<true>(a.d, a.lds, a.nsteps, a.drag, a.lift, a.iters, a.st)
+                : launch_evolve_mf<false>(a.d, a.lds, a.nsteps, a.drag, a.lift, a.iters, a.st);
+}
+#endif
+
+#if MDQ_IN_PART(0)
+static thread_local std::string g_err;
+
+static int fail(const char* what, hipError_t e) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return -1;
+}
+static int fail_msg(const std::string& m) {
+  g_err = m;
+  return -2;
+}
+
+static int ensure_tables() {
+  const hipError_t err = upload_tables();
   if (err != hipSuccess) return fail("hipMemcpyToSymbol(c_tab)", err);
   return 0;
 }
@@ -4661,9 +4735,11 @@ static int check_desc(const mdq_ipcs_desc* d) {
   return 0;
 }
 
+#endif  // part 0
 }  // namespace mdq
 
-// shared by the other sources of this translation unit
+#if MDQ_IN_PART(0)
+// shared by the other translation units of the library (mdq_internal.h)
 int mdq_set_error(const char* msg) {
   mdq::g_err = msg;
   return -2;
@@ -4869,23 +4945,15 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
     if (kernel_ms)
       for (int i = 0; i < 4; ++i) hipEventDestroy(ev[i]);
     e = hipGetLastError();
-  } else if (mode == 2)
-    e = k1_lds ? launch_evolve_mf<true>(d, lds, nsteps, drag, lift, iters, st)
-               : launch_evolve_mf<false>(d, lds, nsteps, drag, lift, iters, st);
-  else if (mode == 1)
-    e = k1_lds ? launch_evolve<1, true>(d, lds, nsteps, drag, lift, iters, st)
-               : launch_evolve<1, false>(d, lds, nsteps, drag, lift, iters, st);
-  else if (mode == 4)
-    e = k1_lds ? launch_evolve_team<true>(d, lds, nsteps, drag, lift, iters, st)
-               : launch_evolve_team<false>(d, lds, nsteps, drag, lift, iters, st);
-  else if (mode == 5)
-    e = pg ? launch_evolve<5, false, true>(d, lds, nsteps, drag, lift, iters, st)
-           : (k1_lds ? launch_evolve<5, true>(d, lds, nsteps, drag, lift, iters, st)
-                     : launch_evolve<5, false>(d, lds, nsteps, drag, lift, iters, st));
-  else
-    e = pg ? launch_evolve<0, false, true>(d, lds, nsteps, drag, lift, iters, st)
-           : (k1_lds ? launch_evolve<0, true>(d, lds, nsteps, drag, lift, iters, st)
-                     : launch_evolve<0, false>(d, lds, nsteps, drag, lift, iters, st));
+  } else {
+    const EvolveArgs a{d, lds, nsteps, drag, lift, iters, st};
+    if (mode == 2)
+      e = part_launch_mf(k1_lds, a);
+    else if (mode == 4 || mode == 5)
+      e = part_launch_tiles(mode, k1_lds, pg, a);
+    else
+      e = part_launch_assembled(mode, k1_lds, pg, a);
+  }
   if (e != hipSuccess) return fail("evolve_kernel launch", e);
   return 0;
 }
@@ -4948,3 +5016,4 @@ int mdq_smooth_host(double* x, int32_t nv, const int32_t* cells, int32_t nt, con
 }
 
 }  // extern "C"
+#endif  // part 0

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/meshdqn_hip.h"
+#include "mdq_internal.h"
 
 namespace mdq_mesh {
 

@@ -34,6 +34,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/meshdqn_hip.h"
+#include "mdq_internal.h"
 
 namespace mdq_smoothing {
 // diagnostics (mdq_smooth_stats): [s] = speculative sweeps s that were abandoned for a careful redo

@@ -37,6 +37,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/meshdqn_hip.h"
+#include "mdq_internal.h"
 
 namespace mdq_smooth_lin {
 constexpr int LNV = 1024;          // vertex capacity

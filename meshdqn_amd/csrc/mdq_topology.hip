@@ -13,6 +13,7 @@
 #include <type_traits>
 
 #include "../../include/meshdqn_hip.h"
+#include "mdq_internal.h"
 #include "mdq_slab.h"
 
 namespace mdq_topo {

@@ -77,16 +77,22 @@ def test_host_smoothing_matches_oracle(meshes, lib_built):
     assert 0.02 < disp.max() < 0.05
 
 
-def test_library_exports_every_declared_symbol(lib_built):
-    import re, os
-    from meshdqn_amd import _lib
+def test_library_exports_exactly_the_declared_symbols(lib_built):
+    """the dynamic symbol table of the library == the MDQ_API declarations of the header == the ctypes binding: no kernel
+    stub, no C++ helper, no libstdc++ instantiation leaks out (-fvisibility=hidden + the linker version script)."""
+    import re, os, subprocess
+    from meshdqn_amd import _lib, build
     lib = _lib.load()
     hdr = open(os.path.join(os.path.dirname(_lib.HERE), "include", "meshdqn_hip.h")).read()
     declared = set(re.findall(r"\b(mdq_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(build.declared_symbols())          # every declaration carries MDQ_API
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name)
     assert lib.mdq_abi_version() == _lib.ABI_VERSION
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib_built]).decode()
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert exported == declared, sorted(exported ^ declared)
 
 
 def test_pressure_direct_factors_reproduce_dense_solve(meshes):
