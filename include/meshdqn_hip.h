@@ -17,6 +17,13 @@
  *     the caller (torch tensors); the library never frees them and performs no
  *     hidden allocation; work is enqueued on the given hipStream_t (passed as
  *     void*; NULL = default stream) and the call returns without a device sync.
+ *     Scratch memory is ALWAYS the caller's: every entry point that needs some
+ *     takes a `workspace` (+ its size in bytes) whose minimum size a
+ *     `*_workspace_bytes` / `*_workspace_doubles` query returns (0: none needed;
+ *     < 0: the sizes are beyond the kernels); launches that may overlap - other
+ *     streams - need workspaces of their own.  (ABI 5 kept the tables of the
+ *     large-mesh kernel instances in process-static slabs grown with hipMalloc
+ *     inside the calls: that broke this rule and is gone.)
  *   - "host" arguments are ordinary host pointers.
  *   - not re-entrant per batch descriptor; independent descriptors may be used
  *     from independent streams / processes.
@@ -37,7 +44,7 @@
 extern "C" {
 #endif
 
-#define MDQ_ABI_VERSION 5
+#define MDQ_ABI_VERSION 6
 
 /* The library is built with -fvisibility=hidden: the entry points below are its ONLY exported symbols. */
 #if defined(__GNUC__)
@@ -614,6 +621,10 @@ typedef struct {
   const float* x_init;         /* [N][2 + 3 S] or NULL (then auto_reset environments get their features computed too - from
                                   the rows this launch has just restored: only valid with ONE workgroup per environment) */
   float* x;                    /* [B][N][2 + 3 S] */
+  int32_t* arrive;             /* [B] arrival counters of the workgroups of an environment, ZERO before the first launch and
+                                  left at zero by every launch: the rows among dst[] that ARE nv / nsel - inputs of the
+                                  terminal decision every workgroup of the environment takes - are restored by the last
+                                  workgroup to have read them.  NULL: one workgroup per environment */
 } mdq_env_finish_desc;
 MDQ_API int mdq_env_finish(const mdq_env_finish_desc* d, void* stream);
 
@@ -625,7 +636,7 @@ MDQ_API int mdq_env_finish(const mdq_env_finish_desc* d, void* stream);
 MDQ_API int mdq_remesh_act(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv, int32_t* nt, int32_t N,
                    const float* q, const uint8_t* explore, const int32_t* rand_action, const int32_t* nsel,
                    const int32_t* coord_map, int32_t* offset, int32_t* action, int32_t* rem, int32_t* code, int32_t* status,
-                   void* stream);
+                   void* workspace, int64_t workspace_bytes, void* stream);
 
 /* edge_ptr [B+1] = exclusive prefix sums of nedges [B] (offsets of mdq_compact_edges / mdq_gcn_forward). */
 MDQ_API int mdq_edge_ptr(int32_t B, const int32_t* nedges, int32_t* edge_ptr, void* stream);
@@ -645,10 +656,12 @@ MDQ_API int mdq_restore_rows(int32_t n, void* const* dst, const void* const* src
  * minimum altitude of its cells; boundary vertices (an incident edge with one owner) are fixed.  One workgroup per
  * mesh: a list schedule of the sweep's dependency graph, walked by one wave out of LDS (exact sequential semantics).  coords [B][NV][2] (in/out),
  * cells [B][NT][3], nv / nt [B], iterations [B] (0 = leave that mesh alone); all device pointers.
- * Capacity: NV <= 1024, NT <= 2048 (larger meshes: mdq_smooth_host).
+ * Capacity: NV <= 1024, NT <= 2048 out of LDS (workspace NULL / 0); up to NV <= 4096, NT <= 8192 through the level-scheduled
+ * large-mesh kernel, whose tables live in `workspace` (device, 16-byte aligned, >= mdq_smooth_workspace_bytes(B, NV, NT)).
  */
+MDQ_API int64_t mdq_smooth_workspace_bytes(int32_t B, int32_t NV, int32_t NT);
 MDQ_API int mdq_smooth(int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t* cells, const int32_t* nv,
-               const int32_t* nt, const int32_t* iterations, void* stream);
+               const int32_t* nt, const int32_t* iterations, void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
  * The same smoothing, faster: a Gauss-Seidel sweep in which every vertex takes the full step is the linear system
@@ -683,10 +696,13 @@ MDQ_API int mdq_smooth_stats(int64_t* out64, int32_t reset);
  * reference's global scipy Delaunay + all-boundary filter as a set of cells; vertex ids above the removed one shift
  * down; cells are written with ascending vertex ids.  remove_idx[b] < 0 leaves mesh b untouched.  status[b]: 0 ok,
  * -1..-4 star / boundary vertex / ear clipping failures, -11 non-manifold, -12 flip work list exhausted (mesh b is
- * untouched on failure).  All pointers are device pointers.  Capacity: NV <= 1024, NT <= 2048.
+ * untouched on failure).  All pointers are device pointers.  Capacity: NV <= 1024, NT <= 2048 with every table in LDS
+ * (workspace NULL / 0); up to NV <= 4096, NT <= 8192 with the tables in `workspace` (device, 16-byte aligned, at least
+ * mdq_remesh_workspace_bytes(B, NV, NT) bytes: 0 for the LDS instance, -1 beyond the kernels).
  */
+MDQ_API int64_t mdq_remesh_workspace_bytes(int32_t B, int32_t NV, int32_t NT);
 MDQ_API int mdq_remesh(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv, int32_t* nt,
-               const int32_t* remove_idx, int32_t* status, void* stream);
+               const int32_t* remove_idx, int32_t* status, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- optional outputs of mdq_env_topology_host: the index data of the matrix-free IPCS path (mode 3 with the CG
  *      pressure solver) on every coarsened mesh, i.e. what FlowSolver.__init__/remesh derive from the mesh
@@ -759,6 +775,9 @@ typedef struct mdq_env_topo_desc {
   double* edge_len;         /* [B][EMAX] edge_attr */
   const mdq_ipcs_topo_out* ipcs;  /* optional (NULL: skip) */
   const mdq_topo_handover* handover;  /* optional (NULL: none; ignored by the host engine) */
+  void* workspace;          /* device, 16-byte aligned, >= mdq_env_topology_workspace_bytes(d) bytes: the tables of the
+                               large-mesh kernel instance (NULL / 0 for meshes of up to 1024 vertices and for the host engine) */
+  int64_t workspace_bytes;
 } mdq_env_topo_desc;
 
 /*
@@ -772,8 +791,11 @@ MDQ_API int mdq_env_topology_host(const mdq_env_topo_desc* d, int32_t nthreads, 
 /*
  * The same engine as a HIP kernel (one workgroup per environment, everything in LDS): every pointer of the descriptor
  * (and of d->ipcs, a HOST struct holding device pointers) and `status` are DEVICE pointers.  All output arrays are
- * bit-identical to mdq_env_topology_host's.  Capacity: NV <= 1024, NT <= 2048, NP <= 4096, npoly <= 256.
+ * bit-identical to mdq_env_topology_host's.  Capacity: NV <= 1024, NT <= 2048, NP <= 4096 with every table in LDS; up to
+ * NV <= 4096, NT <= 8192, NP <= 16384 with the tables in d->workspace (mdq_env_topology_workspace_bytes: 0 for the LDS
+ * instance, -1 beyond the kernels); npoly <= 256.
  */
+MDQ_API int64_t mdq_env_topology_workspace_bytes(const mdq_env_topo_desc* d);
 MDQ_API int mdq_env_topology(const mdq_env_topo_desc* d, void* stream, int32_t* status);
 
 #ifdef __cplusplus

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # (MDQ_LIB_PATH: a differently built copy of the library, e.g. an experiment of tools/: development knob)
 LIB_PATH = os.environ.get("MDQ_LIB_PATH") or os.path.join(HERE, "libmeshdqn_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class MeshDQNHipError(RuntimeError):
@@ -76,7 +76,7 @@ class EnvTopoDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("B", "NV", "NT", "NP", "NAF", "N", "EMAX", "npoly")] + [
         (n, C.c_void_p) for n in ("coords", "cells", "nv", "nt", "offset", "polygon", "ne", "cell_dofs", "points", "naf",
                                   "af_facets", "nremovable", "nsel", "n_closest", "coord_map", "nedges", "edge_src",
-                                  "edge_dst", "edge_len", "ipcs", "handover")]
+                                  "edge_dst", "edge_len", "ipcs", "handover", "workspace")] + [("workspace_bytes", C.c_int64)]
 
 
 class TopoHandover(C.Structure):
@@ -104,7 +104,7 @@ class EnvFinishDesc(C.Structure):
         ("dst", C.c_void_p * FINISH_MAX_ROWS), ("src", C.c_void_p * FINISH_MAX_ROWS),
         ("row_bytes", C.c_int64 * FINISH_MAX_ROWS), ("handover_dst", C.c_void_p * FINISH_MAX_ROWS),
         ("handover_off", C.c_int64 * FINISH_MAX_ROWS), ("handover_bytes", C.c_int64 * FINISH_MAX_ROWS)] + [
-        (n, C.c_void_p) for n in ("coords", "u", "p", "n_closest", "x_init", "x")]
+        (n, C.c_void_p) for n in ("coords", "u", "p", "n_closest", "x_init", "x", "arrive")]
 
 
 # every symbol include/meshdqn_hip.h declares: name -> (restype, argtypes)
@@ -126,11 +126,13 @@ SYMBOLS = {
     "mdq_gcn_forward_padded": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdq_interpolate_snapshots": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mdq_remesh_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "mdq_remesh": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                             C.c_void_p, C.c_void_p]),
+                             C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mdq_remesh_host": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "mdq_env_topology_host": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "mdq_env_topology_workspace_bytes": (C.c_int64, [C.c_void_p]),
     "mdq_env_topology": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdq_state_features": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -145,10 +147,11 @@ SYMBOLS = {
     "mdq_restore_rows_masked": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mdq_env_finish": (C.c_int, [C.POINTER(EnvFinishDesc), C.c_void_p]),
     "mdq_remesh_act": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
-                       + [C.c_void_p] * 11),
+                       + [C.c_void_p] * 11 + [C.c_int64, C.c_void_p]),
     "mdq_edge_ptr": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mdq_smooth_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "mdq_smooth": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                             C.c_void_p]),
+                             C.c_void_p, C.c_int64, C.c_void_p]),
     "mdq_smooth_stats": (C.c_int, [C.c_void_p, C.c_int32]),
     "mdq_smooth_fast_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
     "mdq_smooth_fast": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -3144,6 +3144,13 @@ __device__ __forceinline__ double f2d(float f) {
   return (double)f;
 }
 
+// a lane index the compiler cannot see through: the per-row addresses (7 rows x 6 slab vectors x 64 bits) are then
+// computed where they are used - hoisted out of the Krylov loop they were what the register allocator spilled
+__device__ __forceinline__ int opaque_lane(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
 #define MDQ_FOR_ROWS(k, row)                       \
   _Pragma("unroll") for (int k = 0; k < MF_ROWS; ++k) \
     if (const int row = threadIdx.x + k * WG; row < n2)
@@ -3158,36 +3165,37 @@ __device__ __forceinline__ void velocity_op(const EnvView& v, double a, double m
   }
 }
 
-template <bool K1_LDS>
-__global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nsteps, double* drag, double* lift,
+// Round 5: ONE STEP = THREE LAUNCHES (PHASE 1 tentative velocity, 2 pressure, 3 correction + probes), like mode 3.  The
+// persistent kernel of rounds 1-4 (all steps in one launch, r / p / v / t of the BiCGStab solve and x / r / p / q of the mass CG
+// in registers across the element phases) sat at 256 VGPRs + 836-932 B per lane of scratch: every operator application
+// spilled and re-read ~200 dwords per lane, 428 KB per workgroup, around a phase that needs ~100 registers of its own.  Now
+// every phase has its own register allocation, and across an operator application only what the application cannot get
+// elsewhere stays in registers: the residual r (+ the fp32 row scaling).  The search direction p is in LDS anyway while it is
+// applied (the gather copy `stage`: the owner reads its rows back from there) and, like v = A p and the iterate x, has a
+// row-owner-only copy in the environment's workspace slab (coalesced 16-byte accesses that stay in L2): 4 vector passes of
+// 53 KB per iteration instead of the scratch traffic.  Same operations on the same values in the same order as before
+// (x += alpha p and x += omega s are the two fma's the old single expression contracted to): bitwise reproducible, and the
+// element results still meet in the LDS tile in ascending triangle order.
+template <bool K1_LDS, int PHASE>
+__global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nsteps, int step, double* drag, double* lift,
                                                         int32_t* iters) {
   extern __shared__ __align__(16) double smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const EnvView v = env_view(d, b);
   const int n2 = v.n2, nv = v.nv;
   const LdsPlan P = lds_plan(d.N2, d.NV, d.NSE1);
-  const double a = d.rho / d.dt, mu = d.mu;
 
   double* red = smem;  // 64 doubles
   double* U = smem + 64;
-  double* px = U;
-  double* pr = px + P.NVp;
-  double* pp = pr + P.NVp;
-  double* pq = pp + P.NVp;
-  double* lK = pq + P.NVp;
-  int32_t* lci = reinterpret_cast<int32_t*>(lK + d.NSE1);
-  int32_t* lso = lci + d.NSE1 + (d.NSE1 & 1);
-  double2* stage = reinterpret_cast<double2*>(U);  // gather copy of the operator input
-  double2* tile = stage + P.N2p;                    // element results of one chunk
 
   double* w = v.work;
   double* escr1 = w;
-  double2* xs = reinterpret_cast<double2*>(w + 12 * (int64_t)d.NT);  // u* for the element loops of steps 2/3
+  double2* xs = reinterpret_cast<double2*>(w + 12 * (int64_t)d.NT);  // u* (the iterate of the velocity solve)
+  double2* rhg = xs + d.N2;                                            // shadow residual; phase 3: predicted correction, then x
   double* pnew = reinterpret_cast<double*>(xs + 6 * (int64_t)d.N2);
-  // initial guesses extrapolated in time (round 4; the three-kernel mode 3 has had them since round 1): the last five
-  // tentative velocities (same slots and counter as evolve_kernel: h1 = newest) and a ring of the last three velocity
-  // corrections u_{n+1} - u* in the Krylov-vector slots this kernel does not use (its vectors live in registers).  Every
-  // row is read and written by its owner only.  Same operations in the same order in every run: still bitwise reproducible.
+  // initial guesses extrapolated in time: the last five tentative velocities (same slots and counter as evolve_kernel:
+  // h1 = newest) and a ring of the last three velocity corrections u_{n+1} - u*.  Every row is read and written by its
+  // owner only.
   double2* h1 = reinterpret_cast<double2*>(w + work_hist_offset(d.NV, d.NT, d.NE));
   double2* h2 = h1 + d.N2;
   double2* h3 = h2 + d.N2;
@@ -3197,77 +3205,36 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
   double2* c1 = xs + 2 * (int64_t)d.N2;                  // newest correction
   double2* c2 = c1 + d.N2;
   double2* c3 = c2 + d.N2;
+  double2* pg = c3 + d.N2;                                                              // search direction (own rows)
+  double2* vg = reinterpret_cast<double2*>(w + work_ytmp_offset(d.NV, d.NT, d.NE));     // v = D^-1 A p (own rows)
 
-  const int nsl1 = (nv + 63) >> 6;
-  const int32_t* so1 = K1_LDS ? lso : v.sl1_off;
-  const int32_t* ci1 = K1_LDS ? lci : v.sl1_col;
-  const double* K1 = K1_LDS ? lK : v.K1s;
-
-#ifdef MDQ_PROFILE
-  __shared__ long long sprof_s[16];
-  if (tid < 16) sprof_s[tid] = 0;
-  const_cast<EnvView&>(v).sprof = sprof_s;
-  __syncthreads();
-#endif
-  TileMeta tm;
-  tile_prefetch(v, tm, 0);
-
-  int it_u = 0, it_p = 0, it_m = 0;
-#ifdef MDQ_PROFILE
-  long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  long long tprev = __builtin_amdgcn_s_memtime();
-#endif
-  __syncthreads();
-
-  for (int step = 0; step < nsteps; ++step) {
-    MDQ_STAMP(7)
+  if constexpr (PHASE == 1) {
     // ================= step 1: tentative velocity
-    double2 r[MF_ROWS], p[MF_ROWS], vv[MF_ROWS], y[MF_ROWS];
-    // Register budget: the element phase interleaves two triangles per thread for FP64 ILP, so only
-    // r, p, v stay in registers across it; x (updated once per iteration) and the shadow residual
-    // rh (constant) live in global memory, touched by their row owner only (coalesced, L2 resident).
-    double2* xg = xs;
-    double2* rhg = reinterpret_cast<double2*>(w + 12 * (int64_t)d.NT) + d.N2;
-    const int nhist = (int)hcnt[0], ncorr = (int)hcnt[1];
-    // Jacobi row scaling of the velocity system with the Dirichlet flag folded in (0 = constrained row)
-    // (kept in fp32: any positive row scaling is a valid left preconditioner and the solution of
-    // D^-1 A x = D^-1 b does not depend on it; fp32 halves its register footprint)
-    float2 idg[MF_ROWS];
-#pragma unroll
-    for (int k = 0; k < MF_ROWS; ++k) {
-      const int row = tid + k * WG;
-      idg[k] = make_float2(0.f, 0.f);
-      if (row < n2 && !v.bcu_flag[row]) {
+    const double a = d.rho / d.dt, mu = d.mu;
+    double2* stage = reinterpret_cast<double2*>(U);  // gather copy of the operator input
+    double2* tile = stage + P.N2p;                    // element results of one chunk
+    double2* rg = reinterpret_cast<double2*>(w);     // (the element scratch of phase 2, idle here: room for the row scaling)
+    TileMeta tm;
+    tile_prefetch(v, tm, 0);
+    int it_u = 0;
+    double2 r[MF_ROWS];
+    const int nhist = (int)hcnt[0];
+    // Jacobi row scaling of the velocity system with the Dirichlet flag folded in (0 = constrained row), rounded to fp32
+    // as in rounds 1-4 (any positive row scaling is a valid left preconditioner and the solution of D^-1 A x = D^-1 b does
+    // not depend on it; the same values keep the trajectories of the committed fixtures) - now an own-row vector in the
+    // slab like p and v: as a register array it was what the compiler spilled (36 dwords, re-read in every row loop)
+    double2* idgg = rg;
+#pragma unroll 1
+    for (int row = tid; row < n2; row += WG) {
+      double2 s_ = make_double2(0.0, 0.0);
+      if (!v.bcu_flag[row]) {
         const double2 t_ = v.idiag1[row];
-        idg[k] = make_float2((float)t_.x, (float)t_.y);
+        s_ = make_double2((double)(float)t_.x, (double)(float)t_.y);
       }
+      idgg[row] = s_;
     }
-    {
-      // f = rhs(F1) (volume + outflow facet term), element vectors through the tile
-      const double2* un = v.u_n;
-      const double* pn = v.p_n;
-      tile_accumulate(
-          v, tile, tm,
-          [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
-            double2 ue[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) ue[i] = un[E.dof[i]];
-            double pe[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) pe[i] = pn[E.dof[i]];
-            elem_rhs1_vol(g, a, mu, d.rho, ue, pe, ye);
-            if (ko >= 0) {
-              double X[3][2];
-              load_cell_coords(v, e, X);
-              elem_outflow_add(g, X, ko, 0.5 * mu, ue, ye);
-            }
-          },
-          y);
-    }
-    MDQ_STAMP(0)
     // initial guess: u_n, or the polynomial extrapolation in time of the stored tentative velocities (evolve_kernel's
-    // formulas); it satisfies the Dirichlet values.  (A rolled loop of its own: inside the unrolled row loop below its five
-    // history rows per unrolled row went to scratch.)
+    // formulas); it satisfies the Dirichlet values
 #pragma unroll 1
     for (int row = tid; row < n2; row += WG) {
       double2 x0 = v.u_n[row];
@@ -3289,24 +3256,48 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
         }
       }
       if (v.bcu_flag[row] != 0) x0 = make_double2(v.bcu_gx[row], 0.0);
-      xg[row] = x0;
+      xs[row] = x0;
       stage[row] = x0;
     }
     double acc[2] = {0.0, 0.0};
-#pragma unroll
-    for (int k = 0; k < MF_ROWS; ++k) {
-      const int row = tid + k * WG;
-      if (row < n2) {
-        const bool fl = v.bcu_flag[row] != 0;
-        const double2 g = make_double2(v.bcu_gx[row], 0.0);
-        // |D^-1 b|^2 with b = f - lift (free) / g (constrained): same norm as the assembled path
-        const double2 l = v.lift1[row];
-        const double2 bi = fl ? g : make_double2((y[k].x - l.x) * f2d(idg[k].x), (y[k].y - l.y) * f2d(idg[k].y));
-        acc[0] += bi.x * bi.x + bi.y * bi.y;
-      }
-    }
-    __syncthreads();
     {
+      double2 y[MF_ROWS];
+      {
+        // f = rhs(F1) (volume + outflow facet term), element vectors through the tile
+        const double2* un = v.u_n;
+        const double* pn = v.p_n;
+        tile_accumulate(
+            v, tile, tm,
+            [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
+              double2 ue[6];
+#pragma unroll
+              for (int i = 0; i < 6; ++i) ue[i] = un[E.dof[i]];
+              double pe[3];
+#pragma unroll
+              for (int i = 0; i < 3; ++i) pe[i] = pn[E.dof[i]];
+              elem_rhs1_vol(g, a, mu, d.rho, ue, pe, ye);
+              if (ko >= 0) {
+                double X[3][2];
+                load_cell_coords(v, e, X);
+                elem_outflow_add(g, X, ko, 0.5 * mu, ue, ye);
+              }
+            },
+            y);
+      }
+#pragma unroll
+      for (int k = 0; k < MF_ROWS; ++k) {
+        const int row = tid + k * WG;
+        if (row < n2) {
+          const bool fl = v.bcu_flag[row] != 0;
+          const double2 g = make_double2(v.bcu_gx[row], 0.0);
+          // |D^-1 b|^2 with b = f - lift (free) / g (constrained): same norm as the assembled path
+          const double2 l = v.lift1[row];
+          const double2 sc = idgg[row];
+          const double2 bi = fl ? g : make_double2((y[k].x - l.x) * sc.x, (y[k].y - l.y) * sc.y);
+          acc[0] += bi.x * bi.x + bi.y * bi.y;
+        }
+      }
+      // (the tile_accumulate above ended with a barrier: the staged x0 of every row is visible)
       double2 ax[MF_ROWS];
       tile_accumulate(
           v, tile, tm,
@@ -3320,85 +3311,82 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
 #pragma unroll
       for (int k = 0; k < MF_ROWS; ++k) {
         const int row = tid + k * WG;
-        // r0 = D^-1 (f - A_full x0) on free rows, 0 on constrained rows (idg = 0 there)
-        r[k] = make_double2((y[k].x - ax[k].x) * f2d(idg[k].x), (y[k].y - ax[k].y) * f2d(idg[k].y));
-        if (row < n2) rhg[row] = r[k];
-        p[k] = make_double2(0.0, 0.0);
-        vv[k] = make_double2(0.0, 0.0);
+        // r0 = D^-1 (f - A_full x0) on free rows, 0 on constrained rows (the scaling is 0 there)
+        r[k] = make_double2(0.0, 0.0);
+        if (row < n2) {
+          const double2 sc = idgg[row];
+          r[k] = make_double2((y[k].x - ax[k].x) * sc.x, (y[k].y - ax[k].y) * sc.y);
+          rhg[row] = r[k];
+          pg[row] = make_double2(0.0, 0.0);
+          vg[row] = make_double2(0.0, 0.0);
+        }
         acc[1] += r[k].x * r[k].x + r[k].y * r[k].y;
       }
     }
     block_sum<2>(acc, red);
-    MDQ_STAMP(1)
     {
       const double bb = acc[0], tol2 = d.rtol * d.rtol * bb;
       double rr = acc[1];
       if (rr > tol2 && bb != 0.0) {
         double rho = rr, rho_old = 1.0, alpha = 1.0, omega = 1.0;
         int it = 0;
-#ifdef MDQ_PROFILE
-        long long tb = __builtin_amdgcn_s_memtime();
-#define MDQ_BSTAMP(k) { long long tn = __builtin_amdgcn_s_memtime(); if (tid == 0) sprof_s[k] += tn - tb; tb = tn; }
-#else
-#define MDQ_BSTAMP(k)
-#endif
         while (it < d.maxit_u) {
           ++it;
-          MDQ_BSTAMP(15)
           const double beta = (rho / rho_old) * (alpha / omega);
 #pragma unroll
           for (int k = 0; k < MF_ROWS; ++k) {
-            const int row = tid + k * WG;
-            p[k] = make_double2(r[k].x + beta * (p[k].x - omega * vv[k].x), r[k].y + beta * (p[k].y - omega * vv[k].y));
-            if (row < n2) stage[row] = p[k];
+            const int row = opaque_lane(tid) + k * WG;
+            if (row < n2) {
+              const double2 po = pg[row], vo = vg[row];
+              const double2 pk = make_double2(r[k].x + beta * (po.x - omega * vo.x), r[k].y + beta * (po.y - omega * vo.y));
+              pg[row] = pk;
+              stage[row] = pk;
+            }
           }
           __syncthreads();
-          MDQ_BSTAMP(8)
-          tile_accumulate(
-              v, tile, tm,
-              [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
-                double2 xe[6];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) xe[i] = stage[E.dof[i]];
-                velocity_op(v, a, mu, e, ko, g, xe, ye);
-              },
-              vv);
-          MDQ_BSTAMP(9)
           double a1[1] = {0.0};
+          {
+            double2 vv[MF_ROWS];
+            tile_accumulate(
+                v, tile, tm,
+                [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
+                  double2 xe[6];
 #pragma unroll
-          for (int k = 0; k < MF_ROWS; ++k) {
-            const int row = tid + k * WG;
-            vv[k] = make_double2(vv[k].x * f2d(idg[k].x), vv[k].y * f2d(idg[k].y));
-            if (row < n2) {
-              const double2 h = rhg[row];
-              a1[0] += h.x * vv[k].x + h.y * vv[k].y;
+                  for (int i = 0; i < 6; ++i) xe[i] = stage[E.dof[i]];
+                  velocity_op(v, a, mu, e, ko, g, xe, ye);
+                },
+                vv);
+#pragma unroll
+            for (int k = 0; k < MF_ROWS; ++k) {
+              const int row = opaque_lane(tid) + k * WG;
+              if (row < n2) {
+                const double2 h = rhg[row], sc = idgg[row];
+                vv[k] = make_double2(vv[k].x * sc.x, vv[k].y * sc.y);
+                a1[0] += h.x * vv[k].x + h.y * vv[k].y;
+                vg[row] = vv[k];
+              }
             }
           }
           block_sum<1>(a1, red);
-          MDQ_BSTAMP(10)
           if (a1[0] == 0.0) break;
           alpha = rho / a1[0];
           double a2[1] = {0.0};
 #pragma unroll
           for (int k = 0; k < MF_ROWS; ++k) {
-            const int row = tid + k * WG;
-            r[k] = make_double2(r[k].x - alpha * vv[k].x, r[k].y - alpha * vv[k].y);  // s
-            if (row < n2) stage[row] = r[k];
+            const int row = opaque_lane(tid) + k * WG;
+            if (row < n2) {
+              const double2 vo = vg[row], pk = stage[row], xo = xs[row];    // (own rows: written by this thread above)
+              r[k] = make_double2(r[k].x - alpha * vo.x, r[k].y - alpha * vo.y);  // s
+              xs[row] = make_double2(xo.x + alpha * pk.x, xo.y + alpha * pk.y);
+              stage[row] = r[k];
+            }
+            else
+              r[k] = make_double2(0.0, 0.0);
             a2[0] += r[k].x * r[k].x + r[k].y * r[k].y;
           }
           block_sum<1>(a2, red);  // its barriers publish the staged s
-          MDQ_BSTAMP(11)
-          if (!(a2[0] > tol2)) {
-#pragma unroll
-            for (int k = 0; k < MF_ROWS; ++k) {
-              const int row = tid + k * WG;
-              if (row < n2) {
-                const double2 xo = xg[row];
-                xg[row] = make_double2(xo.x + alpha * p[k].x, xo.y + alpha * p[k].y);
-              }
-            }
-            break;
-          }
+          if (!(a2[0] > tol2)) break;            // (x = x + alpha p is already in place)
+          double a3[2] = {0.0, 0.0};
           double2 t[MF_ROWS];
           tile_accumulate(
               v, tile, tm,
@@ -3409,32 +3397,30 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
                 velocity_op(v, a, mu, e, ko, g, xe, ye);
               },
               t);
-          MDQ_BSTAMP(12)
-          double a3[2] = {0.0, 0.0};
 #pragma unroll
           for (int k = 0; k < MF_ROWS; ++k) {
-            t[k] = make_double2(t[k].x * f2d(idg[k].x), t[k].y * f2d(idg[k].y));
+            const int row = opaque_lane(tid) + k * WG;
+            const double2 sc = row < n2 ? idgg[row] : make_double2(0.0, 0.0);
+            t[k] = make_double2(t[k].x * sc.x, t[k].y * sc.y);
             a3[0] += t[k].x * r[k].x + t[k].y * r[k].y;
             a3[1] += t[k].x * t[k].x + t[k].y * t[k].y;
           }
           block_sum<2>(a3, red);
-          MDQ_BSTAMP(13)
           if (a3[1] == 0.0) break;
           omega = a3[0] / a3[1];
           double a4[2] = {0.0, 0.0};
 #pragma unroll
           for (int k = 0; k < MF_ROWS; ++k) {
-            const int row = tid + k * WG;
+            const int row = opaque_lane(tid) + k * WG;
             if (row < n2) {
-              const double2 xo = xg[row], h = rhg[row];
-              xg[row] = make_double2(xo.x + alpha * p[k].x + omega * r[k].x, xo.y + alpha * p[k].y + omega * r[k].y);
+              const double2 xo = xs[row], h = rhg[row];
+              xs[row] = make_double2(xo.x + omega * r[k].x, xo.y + omega * r[k].y);
               r[k] = make_double2(r[k].x - omega * t[k].x, r[k].y - omega * t[k].y);
               a4[0] += r[k].x * r[k].x + r[k].y * r[k].y;
               a4[1] += h.x * r[k].x + h.y * r[k].y;
             }
           }
           block_sum<2>(a4, red);
-          MDQ_BSTAMP(14)
           rr = a4[0];
           if (!(rr > tol2)) break;
           rho_old = rho;
@@ -3444,7 +3430,6 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
         it_u += it;
       }
     }
-    __syncthreads();  // xg (= xs, u*) complete: the element loops of steps 2 and 3 gather it
 #pragma unroll 1
     for (int row = tid; row < n2; row += WG) {   // shift the history, newest first: h1 = u* of this step (own rows)
       if (nhist >= 4) h5[row] = h4[row];
@@ -3454,9 +3439,21 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
       h1[row] = xs[row];
     }
     if (tid == 0) hcnt[0] = (double)(nhist < 5 ? nhist + 1 : 5);
-    MDQ_STAMP(2)
-
+    if (tid == 0 && iters) iters[3 * b + 0] += it_u;
+  } else if constexpr (PHASE == 2) {
     // ================= step 2: pressure (assembled K1 in SELL form, LDS resident)
+    double* px = U;
+    double* pr = px + P.NVp;
+    double* pp = pr + P.NVp;
+    double* pq = pp + P.NVp;
+    double* lK = pq + P.NVp;
+    int32_t* lci = reinterpret_cast<int32_t*>(lK + d.NSE1);
+    int32_t* lso = lci + d.NSE1 + (d.NSE1 & 1);
+    const int nsl1 = (nv + 63) >> 6;
+    const int32_t* so1 = K1_LDS ? lso : v.sl1_off;
+    const int32_t* ci1 = K1_LDS ? lci : v.sl1_col;
+    const double* K1 = K1_LDS ? lK : v.K1s;
+    int it_p = 0;
     if (K1_LDS && !d.pd_enabled) {
       const int ne1 = v.sl1_off[nsl1];
       for (int kk = tid; kk < ne1; kk += WG) {
@@ -3474,81 +3471,77 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
       pr[i] = v.bcp_flag[i] ? 0.0 : bsum / sd;
       px[i] = v.p_n[i] * sd;
     }
-    MDQ_STAMP(3)
     if (d.pd_enabled && d.pd_hdr[4 * (int64_t)b + 2] > 0) {   // (nparts = 0: no factors for this environment -> Krylov)
       const PdView pd = pd_view(d, b);
       pressure_direct(pd, nv, pr, px, pp, pq, lK);
     } else {
       it_p += cg_pressure(nv, so1, ci1, K1, d.rtol, d.maxit_p, px, pr, pp, pq, red);
     }
-    MDQ_STAMP(4)
     for (int i = tid; i < nv; i += WG) pnew[i] = px[i] / v.sdiagK[i];
-    __syncthreads();
-
+    if (tid == 0 && iters) iters[3 * b + 1] += it_p;
+  } else {
     // ================= step 3: velocity correction (mass solve, both components)
-#pragma unroll 1
-    for (int row = tid; row < n2; row += WG) {   // predicted correction of the own rows -> rhg (the shadow residual is dead here)
-      double2 dp_ = make_double2(0.0, 0.0);
-      if (ncorr >= 1) {
-        const double2 d1 = c1[row];
-        dp_ = d1;
-        if (ncorr >= 2) {
-          const double2 d2 = c2[row];
-          dp_ = make_double2(2.0 * d1.x - d2.x, 2.0 * d1.y - d2.y);
-          if (ncorr >= 3) {
-            const double2 d3 = c3[row];
-            dp_ = make_double2(3.0 * (d1.x - d2.x) + d3.x, 3.0 * (d1.y - d2.y) + d3.y);
-          }
-        }
-      }
-      rhg[row] = dp_;
-    }
-    {
-      const double* pold = v.p_n;
-      tile_accumulate(
-          v, tile, tm,
-          [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
-            double2 ue[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) ue[i] = xs[E.dof[i]];
-            double dp[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) dp[i] = pnew[E.dof[i]] - pold[E.dof[i]];
-            elem_rhs3(g, d.dt, ue, dp, ye);
-          },
-          y);
-    }
+    double2* stage = reinterpret_cast<double2*>(U);
+    double2* tile = stage + P.N2p;
+    double2* xg = rhg;              // the scaled unknown S x of the mass CG (own rows), once the predicted correction is consumed
+    TileMeta tm;
+    tile_prefetch(v, tm, 0);
+    int it_m = 0;
+    const int ncorr = (int)hcnt[1];
     double am[2] = {0.0, 0.0};
-    double2 x[MF_ROWS];
-#pragma unroll
-    for (int k = 0; k < MF_ROWS; ++k) {
-      const int row = tid + k * WG;
-      // u* (own rows) + the correction extrapolated from the ring (written to rhg by the rolled loop in front of the
-      // right-hand side; 0 on constrained rows: the corrections vanish there)
-      x[k] = make_double2(0.0, 0.0);
-      if (row < n2) {
-        const double2 us = xs[row], dp_ = rhg[row];
-        x[k] = make_double2(us.x + dp_.x, us.y + dp_.y);
-      }
-    }
+    double2 r[MF_ROWS], p[MF_ROWS];
     // symmetric Jacobi scaling S^-1 of the mass system, 0 on constrained rows
     double ism[MF_ROWS];
-    // x still holds u* (satisfies the Dirichlet values): scaled unknown S x, stage S^-1 (S x0) = x0
-#pragma unroll
-    for (int k = 0; k < MF_ROWS; ++k) {
-      const int row = tid + k * WG;
-      ism[k] = 0.0;
-      if (row < n2) {
-        const bool fl = v.bcu_flag[row] != 0;
-        if (!fl) ism[k] = 1.0 / v.sdiagM[row];
-        stage[row] = x[k];
-        const double2 l = v.lift3[row];
-        const double2 bi = fl ? x[k] : make_double2((y[k].x - l.x) * ism[k], (y[k].y - l.y) * ism[k]);
-        am[0] += bi.x * bi.x + bi.y * bi.y;
-      }
-    }
-    __syncthreads();
     {
+      double2 y[MF_ROWS];
+      {
+        const double* pold = v.p_n;
+        tile_accumulate(
+            v, tile, tm,
+            [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
+              double2 ue[6];
+#pragma unroll
+              for (int i = 0; i < 6; ++i) ue[i] = xs[E.dof[i]];
+              double dp[3];
+#pragma unroll
+              for (int i = 0; i < 3; ++i) dp[i] = pnew[E.dof[i]] - pold[E.dof[i]];
+              elem_rhs3(g, d.dt, ue, dp, ye);
+            },
+            y);
+      }
+      double2 x[MF_ROWS];
+#pragma unroll
+      for (int k = 0; k < MF_ROWS; ++k) {
+        const int row = tid + k * WG;
+        // u* (own rows) + the correction extrapolated from the ring (0 on constrained rows: the corrections vanish there)
+        x[k] = make_double2(0.0, 0.0);
+        ism[k] = 0.0;
+        if (row < n2) {
+          double2 dp_ = make_double2(0.0, 0.0);
+          if (ncorr >= 1) {
+            const double2 d1 = c1[row];
+            dp_ = d1;
+            if (ncorr >= 2) {
+              const double2 d2 = c2[row];
+              dp_ = make_double2(2.0 * d1.x - d2.x, 2.0 * d1.y - d2.y);
+              if (ncorr >= 3) {
+                const double2 d3 = c3[row];
+                dp_ = make_double2(3.0 * (d1.x - d2.x) + d3.x, 3.0 * (d1.y - d2.y) + d3.y);
+              }
+            }
+          }
+          const double2 us = xs[row];
+          x[k] = make_double2(us.x + dp_.x, us.y + dp_.y);
+          // x satisfies the Dirichlet values: scaled unknown S x, stage S^-1 (S x0) = x0
+          const bool fl = v.bcu_flag[row] != 0;
+          if (!fl) ism[k] = 1.0 / v.sdiagM[row];
+          stage[row] = x[k];
+          const double2 l = v.lift3[row];
+          const double2 bi = fl ? x[k] : make_double2((y[k].x - l.x) * ism[k], (y[k].y - l.y) * ism[k]);
+          am[0] += bi.x * bi.x + bi.y * bi.y;
+        }
+      }
+      __syncthreads();
       double2 ax[MF_ROWS];
       tile_accumulate(
           v, tile, tm,
@@ -3561,15 +3554,16 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
           ax);
 #pragma unroll
       for (int k = 0; k < MF_ROWS; ++k) {
+        const int row = tid + k * WG;
         r[k] = make_double2((y[k].x - ax[k].x) * ism[k], (y[k].y - ax[k].y) * ism[k]);  // 0 on constrained rows
         p[k] = r[k];
         am[1] += r[k].x * r[k].x + r[k].y * r[k].y;
         // scaled unknown: S x (S = 1/ism on free rows; constrained rows keep x = g with S = 1)
         if (ism[k] != 0.0) x[k] = make_double2(x[k].x / ism[k], x[k].y / ism[k]);
+        if (row < n2) xg[row] = x[k];
       }
     }
     block_sum<2>(am, red);
-    MDQ_STAMP(5)
     {
       const double bb = am[0], tol2 = d.rtol * d.rtol * bb;
       double rr = am[1];
@@ -3605,7 +3599,11 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
           double a2[1] = {0.0};
 #pragma unroll
           for (int k = 0; k < MF_ROWS; ++k) {
-            x[k] = make_double2(x[k].x + alpha * p[k].x, x[k].y + alpha * p[k].y);
+            const int row = tid + k * WG;
+            if (row < n2) {
+              const double2 xo = xg[row];
+              xg[row] = make_double2(xo.x + alpha * p[k].x, xo.y + alpha * p[k].y);
+            }
             r[k] = make_double2(r[k].x - alpha * q[k].x, r[k].y - alpha * q[k].y);
             a2[0] += r[k].x * r[k].x + r[k].y * r[k].y;
           }
@@ -3621,20 +3619,20 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
         it_m += it;
       }
     }
-    MDQ_STAMP(6)
 
     // ================= update state + probes
 #pragma unroll
     for (int k = 0; k < MF_ROWS; ++k) {
       const int row = tid + k * WG;
-      if (row < n2) v.u_n[row] = (ism[k] != 0.0) ? make_double2(x[k].x * ism[k], x[k].y * ism[k]) : x[k];
-    }
-#pragma unroll 1
-    for (int row = tid; row < n2; row += WG) {   // ring of corrections, newest first (own rows: written just above)
-      const double2 un = v.u_n[row], us = xs[row];
-      if (ncorr >= 2) c3[row] = c2[row];
-      if (ncorr >= 1) c2[row] = c1[row];
-      c1[row] = make_double2(un.x - us.x, un.y - us.y);
+      if (row < n2) {
+        const double2 xk = xg[row], us = xs[row];
+        const double2 un = (ism[k] != 0.0) ? make_double2(xk.x * ism[k], xk.y * ism[k]) : xk;
+        v.u_n[row] = un;
+        // ring of corrections, newest first (own rows)
+        if (ncorr >= 2) c3[row] = c2[row];
+        if (ncorr >= 1) c2[row] = c1[row];
+        c1[row] = make_double2(un.x - us.x, un.y - us.y);
+      }
     }
     if (tid == 0) hcnt[1] = (double)(ncorr < 3 ? ncorr + 1 : 3);
     for (int i = tid; i < nv; i += WG) v.p_n[i] = pnew[i];
@@ -3645,28 +3643,35 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
       drag[(int64_t)b * nsteps + step] = dr;
       lift[(int64_t)b * nsteps + step] = li;
     }
-  }
-#ifdef MDQ_PROFILE
-  if (tid == 0) {
-    double* pw = pnew + d.NV;
-    for (int k = 0; k < 8; ++k) pw[k] += (double)prof[k];
-    for (int k = 0; k < 16; ++k) pw[8 + k] += (double)sprof_s[k];
-  }
-#endif
-  if (tid == 0 && iters) {
-    iters[3 * b + 0] += it_u;
-    iters[3 * b + 1] += it_p;
-    iters[3 * b + 2] += it_m;
+    if (tid == 0 && iters) iters[3 * b + 2] += it_m;
   }
 }
 
 template <bool K1_LDS>
 static hipError_t launch_evolve_mf(const mdq_ipcs_desc* d, size_t lds, int nsteps, double* drag, double* lift,
                                    int32_t* iters, hipStream_t stream) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&evolve_mf_kernel<K1_LDS>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((evolve_mf_kernel<K1_LDS>), dim3(d->B), dim3(WG), lds, stream, *d, nsteps, drag, lift, iters);
+  static const hipError_t attr = [] {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&evolve_mf_kernel<K1_LDS, 1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&evolve_mf_kernel<K1_LDS, 2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&evolve_mf_kernel<K1_LDS, 3>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return e;
+  }();
+  if (attr != hipSuccess) return attr;
+  const LdsPlan P = lds_plan(d->N2, d->NV, d->NSE1);
+  const size_t red_bytes = 64 * sizeof(double);
+  const size_t lds_v = red_bytes + P.vel2_bytes;
+  const size_t lds_p = red_bytes + P.prs_vec_bytes + (K1_LDS ? P.prs_mat_bytes : 0);
+  (void)lds;
+  for (int step = 0; step < nsteps; ++step) {
+    hipLaunchKernelGGL((evolve_mf_kernel<K1_LDS, 1>), dim3(d->B), dim3(WG), lds_v, stream, *d, nsteps, step, drag, lift, iters);
+    hipLaunchKernelGGL((evolve_mf_kernel<K1_LDS, 2>), dim3(d->B), dim3(WG), lds_p, stream, *d, nsteps, step, drag, lift, iters);
+    hipLaunchKernelGGL((evolve_mf_kernel<K1_LDS, 3>), dim3(d->B), dim3(WG), lds_v, stream, *d, nsteps, step, drag, lift, iters);
+  }
   return hipGetLastError();
 }
 

@@ -523,6 +523,12 @@ extern "C" int mdq_restore_rows_masked(int32_t n, void* const* dst, const void* 
 namespace mdq_mesh {
 // The end of a device-resident env step in one launch: blockIdx.x = environment, blockIdx.y = one of gridDim.y workgroups
 // that share its copy work (result logic: computed by every workgroup from the *_in arrays, written by y = 0).
+// The terminal decision reads nv[b] and nsel[b], which are ALSO row arrays this launch resets in place: a workgroup (b, y)
+// that started after another one had restored them would decide "not terminal" and skip its share of the rows - a
+// half-reset environment (round 4's kernel: harmless only while all B Y workgroups were co-resident).  So the rows whose
+// destination is d.nv / d.nsel are kept out of the strided restore: every workgroup of a resetting environment arrives
+// at a counter when it has finished READING (decision + hand-over copies), and the LAST one to arrive restores them and
+// puts the counter back to zero - no workgroup waits for another.
 __global__ __launch_bounds__(256) void env_finish_kernel(mdq_env_finish_desc d) {
   const int b = blockIdx.x, y = blockIdx.y, Y = gridDim.y, tid = threadIdx.x;
   __shared__ int s_reset;
@@ -570,7 +576,8 @@ __global__ __launch_bounds__(256) void env_finish_kernel(mdq_env_finish_desc d) 
   for (int t = 0; t < d.n_rows; ++t) {
     uint32_t* ho = static_cast<uint32_t*>(d.handover_dst[t]);
     const uint32_t* src = static_cast<const uint32_t*>(d.src[t]);
-    const bool restore = reset && src != nullptr;
+    const bool late = d.dst[t] == static_cast<const void*>(d.nv) || d.dst[t] == static_cast<const void*>(d.nsel);
+    const bool restore = reset && src != nullptr && !late;
     if (!ho && !restore) continue;
     const int64_t words = d.row_bytes[t] >> 2, h0 = d.handover_off[t] >> 2, hw = d.handover_bytes[t] >> 2;
     uint32_t* row = static_cast<uint32_t*>(d.dst[t]) + (int64_t)b * words;
@@ -591,6 +598,27 @@ __global__ __launch_bounds__(256) void env_finish_kernel(mdq_env_finish_desc d) 
       for (int64_t i = lo + lin; i < hi; i += nlin) {
         if (ho && i >= h0 && i < h0 + hw) hob[i - h0] = row[i];
         if (restore) row[i] = src[i];
+      }
+    }
+  }
+  // ---- 2b. the decision's own inputs (nv, nsel): restored by the last workgroup of the environment to get here
+  if (reset) {
+    __syncthreads();                                   // this workgroup's hand-over reads are done
+    if (tid == 0) {
+      bool last = true;
+      if (Y > 1) {
+        __threadfence();
+        last = atomicAdd(d.arrive + b, 1) == Y - 1;
+      }
+      if (last) {
+        for (int t = 0; t < d.n_rows; ++t) {
+          const uint32_t* src = static_cast<const uint32_t*>(d.src[t]);
+          if (!src || (d.dst[t] != static_cast<const void*>(d.nv) && d.dst[t] != static_cast<const void*>(d.nsel))) continue;
+          const int64_t words = d.row_bytes[t] >> 2;
+          uint32_t* row = static_cast<uint32_t*>(d.dst[t]) + (int64_t)b * words;
+          for (int64_t i = 0; i < words; ++i) row[i] = src[i];
+        }
+        if (Y > 1) d.arrive[b] = 0;                     // the next launch finds the counter at zero again
       }
     }
   }
@@ -650,6 +678,10 @@ extern "C" int mdq_env_finish(const mdq_env_finish_desc* d, void* stream) {
   int Y = (int)((bytes / 16 + 1023) / 1024);
   Y = Y < 1 ? 1 : (Y > 16 ? 16 : Y);
   if (d->auto_reset && !d->x_init) Y = 1;
+  if (d->auto_reset && Y > 1 && !d->arrive) {
+    // (a caller without the counter array keeps one workgroup per environment: slower for large rows, never wrong)
+    Y = 1;
+  }
   hipLaunchKernelGGL(mdq_mesh::env_finish_kernel, dim3(d->B, Y), dim3(256), 0, (hipStream_t)stream, *d);
   if (hipGetLastError() != hipSuccess) return mdq_set_error("env_finish_kernel launch failed");
   return 0;

@@ -16,7 +16,6 @@
 
 #include "../../include/meshdqn_hip.h"
 #include "mdq_internal.h"
-#include "mdq_slab.h"
 
 namespace mdq_rm {
 
@@ -424,8 +423,6 @@ __global__ __launch_bounds__(RW) void remesh_kernel(int NV, int NT, double* coor
 
 }  // namespace mdq_rm
 
-static mdq_slab::Pool g_remesh_slabs;   // K = 4: the tables of every mesh of a launch, one slab per stream (mdq_slab.h)
-
 template <int K>
 static int remesh_launch_k(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv, int32_t* nt,
                            const int32_t* remove_idx, int32_t* status, const mdq_rm::ActArgs* act, void* stream, unsigned char* slab) {
@@ -449,33 +446,40 @@ static int remesh_launch_k(int32_t B, int32_t NV, int32_t NT, double* coords, in
   return 0;
 }
 
+extern "C" int64_t mdq_remesh_workspace_bytes(int32_t B, int32_t NV, int32_t NT) {
+  if (B <= 0 || NV <= 0 || NT <= 0) return 0;
+  if (NV <= mdq_rm::Cap<1>::NV && NT <= mdq_rm::Cap<1>::NT) return 0;         // every table in LDS
+  if (NV > mdq_rm::Cap<4>::NV || NT > mdq_rm::Cap<4>::NT) return -1;           // beyond the kernels
+  return (int64_t)((mdq_rm::Cap<4>::BYTES + 255) & ~(size_t)255) * B;
+}
+
 static int remesh_launch(const char* who, int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv,
-                         int32_t* nt, const int32_t* remove_idx, int32_t* status, const mdq_rm::ActArgs* act, void* stream) {
+                         int32_t* nt, const int32_t* remove_idx, int32_t* status, const mdq_rm::ActArgs* act, void* workspace,
+                         int64_t workspace_bytes, void* stream) {
   if (B <= 0 || !coords || !cells || !nv || !nt || (!remove_idx && !act) || !status) return mdq_set_error("mdq_remesh: bad arguments");
   (void)who;
   if (NV <= mdq_rm::Cap<1>::NV && NT <= mdq_rm::Cap<1>::NT)
-    return remesh_launch_k<1>(B, NV, NT, coords, cells, nv, nt, remove_idx, status, act, stream, nullptr);
+    return remesh_launch_k<1>(B, NV, NT, coords, cells, nv, nt, remove_idx, status, act, stream, nullptr);   // (no workspace needed)
   if (NV > mdq_rm::Cap<4>::NV || NT > mdq_rm::Cap<4>::NT)
     return mdq_set_error("mdq_remesh: capacity above 4096 vertices / 8192 triangles");
-  // the large-mesh instance: its tables live in a slab in global memory (one per stream, grown on demand)
-  const size_t per = (mdq_rm::Cap<4>::BYTES + 255) & ~(size_t)255, need = per * (size_t)B;
-  unsigned char* slab = g_remesh_slabs.get(stream, need);
-  if (!slab) return mdq_set_error("mdq_remesh: cannot allocate the table slab of the large-mesh instance");
-  return remesh_launch_k<4>(B, NV, NT, coords, cells, nv, nt, remove_idx, status, act, stream, slab);
+  // the large-mesh instance: its tables live in the CALLER's workspace (global memory, one slab per mesh)
+  if (!workspace || workspace_bytes < mdq_remesh_workspace_bytes(B, NV, NT) || (reinterpret_cast<uintptr_t>(workspace) & 15))
+    return mdq_set_error("mdq_remesh: workspace missing, too small or not 16-byte aligned (mdq_remesh_workspace_bytes)");
+  return remesh_launch_k<4>(B, NV, NT, coords, cells, nv, nt, remove_idx, status, act, stream, static_cast<unsigned char*>(workspace));
 }
 
 extern "C" int mdq_remesh(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv, int32_t* nt,
-                          const int32_t* remove_idx, int32_t* status, void* stream) {
+                          const int32_t* remove_idx, int32_t* status, void* workspace, int64_t workspace_bytes, void* stream) {
   if (!remove_idx) return mdq_set_error("mdq_remesh: bad arguments");
-  return remesh_launch("mdq_remesh", B, NV, NT, coords, cells, nv, nt, remove_idx, status, nullptr, stream);
+  return remesh_launch("mdq_remesh", B, NV, NT, coords, cells, nv, nt, remove_idx, status, nullptr, workspace, workspace_bytes, stream);
 }
 
 extern "C" int mdq_remesh_act(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv, int32_t* nt,
                               int32_t N, const float* q, const uint8_t* explore, const int32_t* rand_action,
                               const int32_t* nsel, const int32_t* coord_map, int32_t* offset, int32_t* action, int32_t* rem,
-                              int32_t* code, int32_t* status, void* stream) {
+                              int32_t* code, int32_t* status, void* workspace, int64_t workspace_bytes, void* stream) {
   if (N <= 0 || !nsel || !coord_map || !offset || !action || !rem || !code || (explore && !rand_action))
     return mdq_set_error("mdq_remesh_act: bad arguments");
   const mdq_rm::ActArgs a{N, q, explore, rand_action, nsel, coord_map, offset, action, rem, code};
-  return remesh_launch("mdq_remesh_act", B, NV, NT, coords, cells, nv, nt, nullptr, status, &a, stream);
+  return remesh_launch("mdq_remesh_act", B, NV, NT, coords, cells, nv, nt, nullptr, status, &a, workspace, workspace_bytes, stream);
 }

@@ -769,11 +769,17 @@ extern "C" int mdq_smooth_stats(int64_t* out64, int32_t reset) {
   return 0;
 }
 
+extern "C" int64_t mdq_smooth_workspace_bytes(int32_t B, int32_t NV, int32_t NT) {
+  if (B <= 0 || NV <= 0 || NT <= 0) return 0;
+  if (NV <= mdq_smoothing::SNV && NT <= mdq_smoothing::SNT) return 0;          // every table in LDS
+  return smooth_big_workspace_bytes(B, NV, NT);
+}
+
 extern "C" int mdq_smooth(int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t* cells, const int32_t* nv,
-                          const int32_t* nt, const int32_t* iterations, void* stream) {
+                          const int32_t* nt, const int32_t* iterations, void* workspace, int64_t workspace_bytes, void* stream) {
   if (B <= 0 || !coords || !cells || !nv || !nt || !iterations) return mdq_set_error("mdq_smooth: bad arguments");
   if (NV > mdq_smoothing::SNV || NT > mdq_smoothing::SNT)     // a mesh beyond the 1024-vertex kernels: level-scheduled kernel
-    return smooth_big_launch(B, NV, NT, coords, cells, nv, nt, iterations, nullptr, nullptr, 0, stream);
+    return smooth_big_launch(B, NV, NT, coords, cells, nv, nt, iterations, nullptr, nullptr, 0, workspace, workspace_bytes, stream);
   long long* trace = nullptr;
 #ifdef MDQ_SMOOTH_TRACE
   trace = mdq_smooth_trace_host();

@@ -13,7 +13,6 @@
 
 #include "../../include/meshdqn_hip.h"
 #include "mdq_internal.h"
-#include "mdq_slab.h"
 
 namespace mdq_smooth_big {
 constexpr int BNV = 4096, BNT = 8192, BWG = 512;
@@ -258,17 +257,22 @@ __global__ __launch_bounds__(BWG) void smooth_big_kernel(int NV, int NT, double*
 }
 }  // namespace mdq_smooth_big
 
-static mdq_slab::Pool g_smooth_slabs;   // the tables of every mesh of a launch, one slab per stream (mdq_slab.h)
+// bytes of caller workspace the large-mesh kernel needs (0: the mesh fits the 1024-vertex kernels; -1: beyond the kernels)
+static int64_t smooth_big_workspace_bytes(int32_t B, int32_t NV, int32_t NT) {
+  using namespace mdq_smooth_big;
+  if (NV > BNV || NT > BNT) return -1;
+  return (int64_t)((SLAB_BYTES + 255) & ~(size_t)255) * B;
+}
 
 // mdq_smooth / mdq_smooth_fast / mdq_smooth_fast_env for NV > 1024 (called by those entry points)
 static int smooth_big_launch(int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t* cells, const int32_t* nv,
                              const int32_t* nt, const int32_t* iterations, const int32_t* rem, const int32_t* rstat,
-                             int32_t iters_env, void* stream) {
+                             int32_t iters_env, void* workspace, int64_t workspace_bytes, void* stream) {
   using namespace mdq_smooth_big;
   if (NV > BNV || NT > BNT) return mdq_set_error("mdq_smooth: capacity above 4096 vertices / 8192 triangles");
-  const size_t per = (SLAB_BYTES + 255) & ~(size_t)255, need = per * (size_t)B;
-  unsigned char* slab = g_smooth_slabs.get(stream, need);
-  if (!slab) return mdq_set_error("mdq_smooth: cannot allocate the table slab of the large-mesh kernel");
+  if (!workspace || workspace_bytes < smooth_big_workspace_bytes(B, NV, NT) || (reinterpret_cast<uintptr_t>(workspace) & 15))
+    return mdq_set_error("mdq_smooth: workspace missing, too small or not 16-byte aligned (mdq_smooth_workspace_bytes / mdq_smooth_fast_workspace_bytes)");
+  unsigned char* slab = static_cast<unsigned char*>(workspace);
   const size_t lds = sizeof(d2) * BNV + sizeof(int) * BNV;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&smooth_big_kernel),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(d2) * BNV + sizeof(int) * BNV));

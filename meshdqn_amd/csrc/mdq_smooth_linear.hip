@@ -772,6 +772,8 @@ __global__ void count_redo_kernel(int B, const int32_t* redo, unsigned long long
 
 extern "C" int64_t mdq_smooth_fast_workspace_bytes(int32_t B, int32_t NV) {
   if (B <= 0 || NV <= 0) return 0;
+  if (NV > mdq_smooth_lin::LNV)       // a mesh beyond the 1024-vertex kernels: the tables of the level-scheduled kernel
+    return smooth_big_workspace_bytes(B, NV, 1);
   const int64_t blocks = (NV + mdq_smooth_lin::BS - 1) / mdq_smooth_lin::BS + 2;     // two blocks of padding (prefetch)
   return (int64_t)B * blocks * mdq_smooth_lin::MBLK * 8 + (int64_t)B * 16 + 256;   // block inverses, [B] redo, [B][3] diagnostics
 }
@@ -782,7 +784,7 @@ static int smooth_fast_impl(const char* who, int32_t B, int32_t NV, int32_t NT, 
   if (B <= 0 || !coords || !cells || !nv || !nt || (!iterations && (!rem || !rstat)) || !workspace)
     return mdq_set_error("mdq_smooth_fast: bad arguments");
   if (NV > mdq_smooth_lin::LNV || NT > mdq_smooth_lin::LNT)   // a mesh beyond the 1024-vertex kernels: level-scheduled kernel
-    return smooth_big_launch(B, NV, NT, coords, cells, nv, nt, iterations, rem, rstat, iters_env, stream);
+    return smooth_big_launch(B, NV, NT, coords, cells, nv, nt, iterations, rem, rstat, iters_env, workspace, workspace_bytes, stream);
   if (workspace_bytes < mdq_smooth_fast_workspace_bytes(B, NV) || (reinterpret_cast<uintptr_t>(workspace) & 15))
     return mdq_set_error("mdq_smooth_fast: workspace too small or not 16-byte aligned (mdq_smooth_fast_workspace_bytes)");
   (void)who;

@@ -14,7 +14,6 @@
 
 #include "../../include/meshdqn_hip.h"
 #include "mdq_internal.h"
-#include "mdq_slab.h"
 
 namespace mdq_topo {
 
@@ -1269,7 +1268,13 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
 
 }  // namespace mdq_topo
 
-static mdq_slab::Pool g_topo_slabs;     // K = 4: the tables of every mesh of a launch, one slab per stream (mdq_slab.h)
+extern "C" int64_t mdq_env_topology_workspace_bytes(const mdq_env_topo_desc* d) {
+  if (!d || d->B <= 0) return 0;
+  if (d->NV <= mdq_topo::TNV && d->NT <= mdq_topo::TNT && d->NP <= mdq_topo::TNP) return 0;     // every table in LDS
+  using C4 = mdq_topo::TCap<4>;
+  if (d->NV > C4::NV || d->NT > C4::NT || d->NP > C4::NP) return -1;                             // beyond the kernels
+  return (int64_t)((C4::BYTES + 255) & ~(size_t)255) * d->B;
+}
 
 extern "C" int mdq_env_topology(const mdq_env_topo_desc* d, void* stream, int32_t* status) {
   if (!d || d->B <= 0 || !status) return mdq_set_error("mdq_env_topology: bad arguments");
@@ -1289,10 +1294,10 @@ extern "C" int mdq_env_topology(const mdq_env_topo_desc* d, void* stream, int32_
     using C4 = mdq_topo::TCap<4>;
     if (d->NV > C4::NV || d->NT > C4::NT || d->NP > C4::NP)
       return mdq_set_error("mdq_env_topology: capacity above 4096 vertices / 8192 triangles / 16384 P2 dofs");
-    // the large-mesh instance: tables on a slab in global memory (one per stream, grown on demand)
-    const size_t per = (C4::BYTES + 255) & ~(size_t)255, need = per * (size_t)d->B;
-    unsigned char* slab = g_topo_slabs.get(stream, need);
-    if (!slab) return mdq_set_error("mdq_env_topology: cannot allocate the table slab of the large-mesh instance");
+    // the large-mesh instance: tables in the CALLER's workspace (global memory, one slab per mesh)
+    if (!d->workspace || d->workspace_bytes < mdq_env_topology_workspace_bytes(d) || (reinterpret_cast<uintptr_t>(d->workspace) & 15))
+      return mdq_set_error("mdq_env_topology: workspace missing, too small or not 16-byte aligned (mdq_env_topology_workspace_bytes)");
+    unsigned char* slab = static_cast<unsigned char*>(d->workspace);
     hipLaunchKernelGGL(mdq_topo::topology_kernel<4>, dim3(d->B), dim3(mdq_topo::TW), 0, (hipStream_t)stream, *d, o,
                        d->ipcs ? 1 : 0, status, slab, h);
   }

@@ -302,6 +302,22 @@ class HostTopologyBatch:
 
 
 _SMOOTH_WS = {}
+_WS = {}
+
+
+def _workspace(kind: str, device, sp, nbytes: int, tag=()):
+    """Caller-owned scratch of an entry point (`*_workspace_bytes`): one torch tensor per (kind, device, stream, sizes) -
+    launches on one stream are ordered and may share it, launches on different streams get their own.  (0, 0) when the
+    entry point needs none; raises when the sizes are beyond the kernels (< 0)."""
+    if nbytes < 0:
+        raise _lib.MeshDQNHipError(f"{kind}: mesh capacities beyond the kernels")
+    if nbytes == 0:
+        return None, 0
+    key = (kind, torch.device(device), int(sp.value or 0)) + tuple(tag)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return ws.data_ptr(), ws.numel()
 
 
 def smooth_batch_gpu(coords: torch.Tensor, cells: torch.Tensor, nv: torch.Tensor, nt: torch.Tensor,
@@ -316,8 +332,10 @@ def smooth_batch_gpu(coords: torch.Tensor, cells: torch.Tensor, nv: torch.Tensor
     assert coords.dtype == torch.float64 and cells.dtype == torch.int32 and coords.is_contiguous() and cells.is_contiguous()
     assert nv.dtype == torch.int32 and nt.dtype == torch.int32 and iterations.dtype == torch.int32
     if not fast:
+        sp = _lib.stream_ptr(stream)
+        wp, wn = _workspace("smooth", coords.device, sp, int(lib.mdq_smooth_workspace_bytes(B, NV, NT)), (B, NV, NT))
         _lib.check(lib.mdq_smooth(B, NV, NT, coords.data_ptr(), cells.data_ptr(), nv.data_ptr(), nt.data_ptr(),
-                                  iterations.data_ptr(), _lib.stream_ptr(stream)), "mdq_smooth")
+                                  iterations.data_ptr(), wp, wn, sp), "mdq_smooth")
         return
     # workspace (block inverses of every mesh): one per (device, stream, B, NV) - launches on one stream are ordered
     sp = _lib.stream_ptr(stream)
@@ -414,6 +432,12 @@ class DeviceTopologyBatch:
                 setattr(o, k, a.data_ptr())
             self._ipcs_out = o
             d.ipcs = C.cast(C.pointer(o), C.c_void_p)
+        # the tables of the large-mesh kernel instance: this engine's own workspace (engines on different streams never share)
+        nb = int(self.lib.mdq_env_topology_workspace_bytes(C.byref(d)))
+        if nb < 0:
+            raise _lib.MeshDQNHipError("mdq_env_topology: capacity above 4096 vertices / 8192 triangles / 16384 P2 dofs")
+        self.workspace = torch.empty(nb, dtype=torch.uint8, device=dev) if nb else None
+        d.workspace, d.workspace_bytes = (self.workspace.data_ptr() if nb else None), nb
         self.desc = d
 
     def take_edges_from(self, cell_dofs=None, ne=None):
@@ -459,5 +483,13 @@ def remesh_batch_gpu(coords: torch.Tensor, cells: torch.Tensor, nv: torch.Tensor
     assert coords.dtype == torch.float64 and cells.dtype == torch.int32 and coords.is_contiguous() and cells.is_contiguous()
     for a in (nv, nt, remove_idx, status):
         assert a.dtype == torch.int32 and a.is_cuda
+    sp = _lib.stream_ptr(stream)
+    wp, wn = remesh_workspace(coords.device, sp, B, NV, NT)
     _lib.check(lib.mdq_remesh(B, NV, NT, coords.data_ptr(), cells.data_ptr(), nv.data_ptr(), nt.data_ptr(),
-                              remove_idx.data_ptr(), status.data_ptr(), _lib.stream_ptr(stream)), "mdq_remesh")
+                              remove_idx.data_ptr(), status.data_ptr(), wp, wn, sp), "mdq_remesh")
+
+
+def remesh_workspace(device, sp, B: int, NV: int, NT: int):
+    """(pointer, bytes) of the workspace of `mdq_remesh` / `mdq_remesh_act` for these capacities on this stream (None, 0 for
+    meshes whose tables fit LDS)."""
+    return _workspace("remesh", device, sp, int(_lib.load().mdq_remesh_workspace_bytes(B, NV, NT)), (B, NV, NT))

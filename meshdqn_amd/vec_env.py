@@ -25,7 +25,8 @@ import torch
 
 from . import _lib
 from .env import Env2DAirfoil
-from .mesh_ops import DeviceTopologyBatch, HostTopologyBatch, remesh_batch, remesh_batch_gpu, smooth_batch_gpu, smooth_env_gpu
+from .mesh_ops import (DeviceTopologyBatch, HostTopologyBatch, remesh_batch, remesh_batch_gpu, remesh_workspace, smooth_batch_gpu,
+                       smooth_env_gpu)
 
 
 def _host_cores() -> int:
@@ -924,7 +925,8 @@ class VecEnv2DAirfoil:
                                       None if ro["explore"] is None else ro["explore"][k].data_ptr(),
                                       None if ro["rand"] is None else ro["rand"][k].data_ptr(), dt.t["nsel"].data_ptr(),
                                       dt.t["coord_map"].data_ptr(), dt.offset.data_ptr(), ro["act"][k].data_ptr(),
-                                      rem.data_ptr(), ro["code_act"].data_ptr(), self._rstat.data_ptr(), sp()), "mdq_remesh_act")
+                                      rem.data_ptr(), ro["code_act"].data_ptr(), self._rstat.data_ptr(),
+                                      *remesh_workspace(self.device, sp(), B, NVc, NTc), sp()), "mdq_remesh_act")
         tm = getattr(self, "smooth_events", None)     # (bench: HIP events around the launch, on this stream)
         if tm is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -970,6 +972,8 @@ class VecEnv2DAirfoil:
                                                                                 float(self.goal_vertices), float(self.NEGATIVE_REWARD))
             d.gt_drag, d.nv, d.rstat = self._gt_drag_dev.data_ptr(), dt.nv.data_ptr(), self._rstat.data_ptr()
             d.topo_status, d.nsel, d.n_closest = dt.status.data_ptr(), dt.t["nsel"].data_ptr(), dt.t["n_closest"].data_ptr()
+            self._fin_arrive = torch.zeros(B, dtype=torch.int32, device=self.device)   # (every launch leaves it at zero)
+            d.arrive = self._fin_arrive.data_ptr()
         c = self._init_cache
         if c.get("x") is None:      # node features of the initial state (what an environment shows right after its reset)
             xi = torch.empty((1, N, 2 + 3 * S), dtype=torch.float32, device=self.device)

@@ -236,6 +236,55 @@ def test_host_remesh_equals_scipy_delaunay_over_an_episode(meshes, lib_built, na
     # (the host smoother itself is pinned to the python oracle by test_host_smoothing_matches_oracle)
 
 
+@pytest.mark.parametrize("smoothed", [True, False])
+def test_host_remesh_equals_scipy_delaunay_on_the_red_refined_mesh(meshes, lib_built, smoothed):
+    """BASELINE configs[4] (ys930 red-refined once: 3 322 vertices): the C++ engine against the reference's pipeline
+    (`Env2DAirfoil._remove_vertex`, Env2DAirfoil.py:452-512: global Qhull Delaunay + all-boundary filter) over 48 consecutive
+    removals - refinement MIDPOINTS (ids >= 876: every one sits in the middle of a parent edge, between two pairs of
+    congruent sub-triangles) and original vertices alternately, every third pick among the 60 interior vertices nearest to the
+    airfoil, where the policy acts.  Set equality of the cells at every step, on the smoothed mesh (what the env steps, with
+    `smooth(50)` after every removal as FlowSolver.remesh does, flow_solver.py:236-237) and on the raw refinement, whose
+    parallelogram pairs are the nearest thing to co-circular quads this mesh family has (no disagreement found: the local
+    cavity re-triangulation + Lawson flips reproduce Qhull on it)."""
+    from meshdqn_amd.ipcs_batch import smooth_coords
+    from meshdqn_amd.mesh_ops import red_refine, remesh_batch
+    coords, cells = meshes["ys930"]
+    rc, rcells = red_refine(smooth_coords(MeshTopology(coords, cells), 50), cells)
+    t0 = MeshTopology(rc, rcells)
+    assert (t0.nv, t0.nt) == (3322, 6280)
+    x = smooth_coords(t0, 50) if smoothed else rc.copy()
+    c = np.sort(rcells, axis=1).astype(np.int32)
+    hc = np.zeros((1, t0.nv, 2)); hc[0] = x
+    ht = np.zeros((1, t0.nt, 3), np.int32); ht[0] = c
+    nv = np.array([t0.nv], np.int32); nt = np.array([t0.nt], np.int32)
+    rng = np.random.default_rng(5)
+    ref_x, ref_c = x.copy(), c.copy()
+    n_mid = 0
+    for step in range(48):
+        t = MeshTopology(ref_x, ref_c)
+        interior = np.flatnonzero(~t.on_boundary)
+        n_orig = 876 - (step - n_mid)                  # original vertices still present (ids below this)
+        if step % 3 == 2:                              # near the airfoil
+            af = np.flatnonzero(t.on_boundary & (np.abs(ref_x[:, 1]) < 0.45) & (ref_x[:, 0] > -0.45) & (ref_x[:, 0] < 2.9))
+            d = np.min(np.linalg.norm(ref_x[interior][:, None] - ref_x[af][None], axis=2), axis=1)
+            cand = interior[np.argsort(d)[:60]]
+        elif step % 2 == 0:
+            cand = interior[interior >= n_orig]
+        else:
+            cand = interior[interior < n_orig]
+        idx = int(rng.choice(cand))
+        n_mid += idx >= n_orig
+        st = remesh_batch(hc, ht, nv, nt, np.array([idx], np.int32), 50 if smoothed else 0, 1)
+        assert st[0] == 0
+        ref_x, ref_c = _scipy_remove(ref_x, ref_c, idx)
+        assert (nv[0], nt[0]) == (len(ref_x), len(ref_c))
+        assert {tuple(r) for r in ht[0, :nt[0]].tolist()} == {tuple(r) for r in ref_c.tolist()}, (step, idx)
+        if smoothed:
+            ref_x = smooth_coords(MeshTopology(ref_x, ref_c), 50)
+            assert np.abs(hc[0, :nv[0]] - ref_x).max() < 1e-13
+    assert n_mid >= 16
+
+
 def test_host_engine_is_thread_safe(meshes, lib_built):
     """Concurrent callers (the env groups of VecEnvGroups) share one worker pool: results equal the sequential ones."""
     import threading

@@ -103,6 +103,37 @@ def test_oracle_stock_episode_replays_from_its_snapshots(meshes):
         assert np.allclose(env.new_drags, g["new_drags"], rtol=1e-9, atol=0)
 
 
+def test_refined_mesh_fixture_is_what_the_oracle_produces():
+    """tests/golden/oracle_stock_ys930_refined.{json,npz} (make_refined_fixtures.py): the mesh is the red refinement of the
+    oracle-smoothed ys930, and the oracle - handed the stored ground truth - replays the first two steps of an episode
+    (global Qhull Delaunay of 3 321 points, smoothing, interpolation onto 12 9xx P2 dofs: ~25 s per step)."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from make_refined_fixtures import red_refine
+    from oracle.env import OracleEnv
+    from oracle.mesh import OracleMesh
+    ep = json.load(open(os.path.join(GOLDEN, "oracle_stock_ys930_refined.json")))
+    z = np.load(os.path.join(GOLDEN, "oracle_stock_ys930_refined.npz"))
+    m = np.load(os.path.join(GOLDEN, "ys930.npz"))
+    base = OracleMesh(m["coords"], m["cells"])
+    base.smooth(50)
+    coords, cells = red_refine(base.coords, m["cells"])
+    assert np.array_equal(coords, z["coords"]) and np.array_equal(cells, z["cells"]) and coords.shape == (3322, 2)
+    assert all(sum(s["action"] != 180 for s in e["steps"]) == 7 and e["steps"][-1]["done"] and e["steps"][-1]["nv"] == 3315
+               for e in ep["episodes"].values())                      # every episode ends on the vertex criterion
+    assert all(s["removed_vertex"] >= 876 for s in ep["episodes"]["midpoints"]["steps"] if s["action"] != 180)
+    env = OracleEnv(z["coords"], z["cells"], ep["agent_params"],
+                    snapshots=dict(gt_drag=z["gt_drag"], gt_lift=z["gt_lift"], u=z["u"], p=z["p"]))
+    env.get_state()
+    for g in ep["episodes"]["random_3370"]["steps"][:2]:
+        removed = int(env.coord_map.get(g["action"], -1))
+        st, r, done, _ = env.step(g["action"])
+        assert removed == g["removed_vertex"] and (env.flow.mesh.nv, env.flow.mesh.nt) == (g["nv"], g["nt"])
+        assert abs(r - g["reward"]) < 1e-9 and done == g["done"] and st["edge_index"].shape[1] == g["E"]
+        assert [int(env.coord_map[i]) for i in range(180)] == g["coord_map"]
+        assert np.allclose(env.new_drags, g["new_drags"], rtol=1e-9, atol=0)
+
+
 def test_gcn_oracle_and_module_match_fixture():
     import sys
     import torch

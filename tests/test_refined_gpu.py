@@ -250,3 +250,235 @@ def test_vec_env_s3_step_on_the_refined_mesh(lib_built, meshes, tmp_path):
     assert info["flow_lag"] == 1 and np.allclose(info["flow_drag"], inline[0][0], rtol=1e-9)     # the flow of step 0, delivered late
     last = over.flow_wait()
     assert np.allclose(last[0], inline[1][0], rtol=1e-9) and np.allclose(last[1], inline[1][1], rtol=1e-9)
+
+
+def test_large_mesh_entry_points_use_the_callers_workspace_only(lib_built, meshes):
+    """include/meshdqn_hip.h: "the library performs no hidden allocation ... returns without a device sync" - round 4's
+    large-mesh instances grew process-static slabs with hipMalloc (+ hipStreamSynchronize / hipFree) inside mdq_remesh,
+    mdq_env_topology and mdq_smooth*.  ABI 6: the tables live in a caller-owned workspace.  Here, through the C ABI: (1) every
+    entry point REFUSES a missing / short / misaligned workspace with a negative code and a text; (2) after a one-mesh warm-up
+    on the same stream (code objects loaded, the queue's private-segment backing allocated by the runtime - a NEW stream would
+    make the runtime allocate that for its queue while a kernel with scratch runs, which is not the library's doing) a call
+    with EIGHT meshes leaves hipMemGetInfo's free byte count where it was - the old slabs were grown on demand, i.e. exactly this
+    call allocated (and synchronised the stream to free the smaller slab); (3) the queries return 0 for the 1024-vertex kernels and -1 beyond the 4096-vertex ones."""
+    import ctypes as C
+    from meshdqn_amd import _lib
+    from meshdqn_amd.mesh_ops import DeviceTopologyBatch
+    lib = _lib.load()
+    t0, x0 = _refined(meshes)
+    NV, NT = t0.nv, t0.nt
+    assert lib.mdq_remesh_workspace_bytes(4, 876, 1570) == 0 and lib.mdq_smooth_workspace_bytes(4, 876, 1570) == 0
+    assert lib.mdq_remesh_workspace_bytes(4, 5000, 9000) == -1 and lib.mdq_smooth_workspace_bytes(4, 5000, 9000) == -1
+    tags = t0.facet_tags(x0)
+    polygon = x0[[v for v in range(t0.nv) if t0.on_boundary[v] and -0.5 < x0[v, 0] < 3 and -0.5 < x0[v, 1] < 0.5]]
+    interior = np.flatnonzero(~t0.on_boundary)
+    i32 = torch.int32
+
+    def state(B):
+        c = torch.from_numpy(np.repeat(x0[None], B, 0).copy()).cuda()
+        t = torch.from_numpy(np.repeat(np.sort(t0.cells, axis=1)[None].astype(np.int32), B, 0).copy()).cuda()
+        return dict(c=c, t=t, nv=torch.full((B,), NV, dtype=i32, device="cuda"), nt=torch.full((B,), NT, dtype=i32, device="cuda"),
+                    rem=torch.from_numpy(interior[100:100 + B].astype(np.int32)).cuda(), st=torch.zeros(B, dtype=i32, device="cuda"),
+                    its=torch.full((B,), 3, dtype=i32, device="cuda"))
+
+    def calls(B, s, ws):
+        """mdq_remesh, mdq_smooth, mdq_smooth_fast, mdq_env_topology on B refined meshes with the workspaces `ws`."""
+        sp = C.c_void_p(s.cuda_stream)
+        a = state(B)
+        args = (B, NV, NT, a["c"].data_ptr(), a["t"].data_ptr(), a["nv"].data_ptr(), a["nt"].data_ptr())
+        rcs = [lib.mdq_remesh(*args, a["rem"].data_ptr(), a["st"].data_ptr(), *ws["remesh"], sp),
+               lib.mdq_smooth(*args, a["its"].data_ptr(), *ws["smooth"], sp),
+               lib.mdq_smooth_fast(*args, a["its"].data_ptr(), *ws["fast"], sp)]
+        db = ws["topo_engine"]
+        db.coords.copy_(a["c"]); db.cells.copy_(a["t"]); db.nv.copy_(a["nv"]); db.nt.copy_(a["nt"])
+        if "topo" in ws:
+            db.desc.workspace, db.desc.workspace_bytes = ws["topo"]
+        rcs.append(lib.mdq_env_topology(C.byref(db.desc), sp, db.status.data_ptr()))
+        return rcs, a
+
+    def workspaces(B):
+        eng = DeviceTopologyBatch(B, NV, NT, t0.ne, int((tags == 1).sum()), 180, 1536, polygon, device="cuda", ipcs=False)
+        out = dict(topo_engine=eng)
+        for k, n in (("remesh", lib.mdq_remesh_workspace_bytes(B, NV, NT)), ("smooth", lib.mdq_smooth_workspace_bytes(B, NV, NT)),
+                     ("fast", lib.mdq_smooth_fast_workspace_bytes(B, NV))):
+            assert n > 0
+            w = torch.empty(int(n), dtype=torch.uint8, device="cuda")
+            out[k] = (w.data_ptr(), int(n))
+            out["keep_" + k] = w
+        return out
+
+    # (1) refused, loudly
+    w2 = workspaces(2)
+    s0 = torch.cuda.Stream()
+    eng = w2["topo_engine"]
+    good_topo = (eng.desc.workspace, eng.desc.workspace_bytes)
+    assert good_topo[1] == lib.mdq_env_topology_workspace_bytes(C.byref(eng.desc)) > 0
+    for bad in (lambda p, n: (None, 0), lambda p, n: (p, n - 1), lambda p, n: (p + 4, n)):
+        ws = dict(w2)
+        for k in ("remesh", "smooth", "fast"):
+            ws[k] = bad(*w2[k])
+        ws["topo"] = bad(*good_topo)
+        rcs, _ = calls(2, s0, ws)
+        assert all(rc < 0 for rc in rcs), rcs
+        assert b"workspace" in lib.mdq_last_error() or b"bad arguments" in lib.mdq_last_error()
+    # (2) warm-up with the right workspaces, then eight meshes on a new stream: no allocation inside the calls
+    w2["topo"] = good_topo
+    rcs, a = calls(2, s0, w2)
+    assert rcs == [0, 0, 0, 0]
+    torch.cuda.synchronize()
+    assert (a["st"] == 0).all() and (a["nv"] == NV - 1).all()
+    w8, s1 = workspaces(8), s0
+    probe = state(8)                                   # (torch's own allocations of calls(): in the cache before the measurement)
+    del probe
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    rcs, a = calls(8, s1, w8)
+    free1 = torch.cuda.mem_get_info()[0]               # NOT synchronised: the calls have returned, the kernels may still run
+    torch.cuda.synchronize()
+    free2 = torch.cuda.mem_get_info()[0]
+    assert rcs == [0, 0, 0, 0]
+    assert free1 == free0 and free2 == free0, (free0, free1, free2)
+    assert (a["st"] == 0).all() and (a["nv"] == NV - 1).all() and (w8["topo_engine"].status == 0).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 5: the refined-mesh env step against the ORACLE (global Qhull Delaunay + all-boundary filter = the reference's
+# Env2DAirfoil._remove_vertex, Env2DAirfoil.py:452-512; _check_mesh :547-602), not only against the C++ twin: committed
+# episodes of tests/golden/oracle_stock_ys930_refined.{json,npz} (make_refined_fixtures.py).  Nothing below runs the oracle.
+
+def _refined_fixture():
+    import json
+    ep = json.load(open(os.path.join(GOLDEN, "oracle_stock_ys930_refined.json")))
+    z = np.load(os.path.join(GOLDEN, "oracle_stock_ys930_refined.npz"))
+    return ep, z
+
+
+def _refined_cfg(ep, z, tmp):
+    """An env on the fixture's mesh that reloads the oracle's ground truth (Env2DAirfoil.py:126-153, as tests/test_stock_gpu.py)."""
+    tmp = str(tmp)
+    path = os.path.join(tmp, "ys930_refined.npz")
+    np.savez(path, coords=z["coords"], cells=z["cells"])
+    snap = os.path.join(tmp, "snapshots")
+    os.makedirs(snap, exist_ok=True)
+    u, p = z["u"], z["p"]
+    n2 = u.shape[1] // 2
+    np.save(os.path.join(snap, "save_velocities.npy"), np.stack([u[:, :n2], u[:, n2:]], axis=2).reshape(len(u), -1))
+    np.save(os.path.join(snap, "save_pressures.npy"), p)
+    ap = dict(ep["agent_params"])
+    ap.update(gt_drag=z["gt_drag"].copy(), gt_lift=z["gt_lift"].copy(), gt_time=np.array([0.05]), plot_dir=tmp)
+    return dict(flow_config=dict(flow_params=dict(mu=1e-3, rho=1.0, inflow="constant"), geometry_params=dict(mesh=path),
+                                 solver_params=dict(dt=0.001, solver_type="lu", smooth=True)), agent_params=ap)
+
+
+def _refined_script(ep, B=None, seed=0):
+    names = list(ep["episodes"])
+    B = B or len(names)
+    assign = np.arange(B) % len(names) if B == len(names) else np.random.default_rng(seed).permutation(np.arange(B) % len(names))
+    K = max(len(ep["episodes"][n]["steps"]) for n in names)
+    acts = np.full((K, B), 180, np.int64)
+    for b in range(B):
+        s = ep["episodes"][names[assign[b]]]["steps"]
+        acts[:len(s), b] = [g["action"] for g in s]
+    return names, assign, K, acts
+
+
+def _check_refined(g, where, nv=None, E=None, r=None, done=None, drags=None, lifts=None, cmap=None, removed=None, x_sum=None):
+    if done is not None:
+        assert bool(done) == g["done"], where
+    if r is not None:
+        assert abs(r - g["reward"]) < 1e-6, (where, r, g["reward"])
+    if nv is not None:
+        assert nv == g["nv"], where
+    if E is not None:
+        assert E == g["E"], where
+    if removed is not None:
+        assert removed == g["removed_vertex"], where
+    if drags is not None:
+        assert np.allclose(drags, g["new_drags"], rtol=1e-7, atol=0), where
+        assert np.allclose(lifts, g["new_lifts"], rtol=1e-7, atol=0), where
+    if cmap is not None:
+        assert list(cmap)[:len(g["coord_map"])] == g["coord_map"], where          # all 180 ids of the N-closest window
+    if x_sum is not None:
+        assert abs(x_sum - g["x_sum"]) < 2e-3, where
+
+
+@pytest.mark.slow
+def test_refined_mesh_episodes_match_the_oracle(lib_built, tmp_path):
+    """BASELINE configs[4]'s mesh: `VecEnv2DAirfoil.step` (device mesh engine, host reward logic) and
+    `rollout_device(actions=...)` (everything as kernels) against the oracle episodes: removed vertex ids, nv / E and the whole
+    coord_map exact at every step, rewards <= 1e-6, interpolated forces <= 1e-7, `done` equal - incl. the episode that removes
+    refinement midpoints and ends on the vertex criterion at its 7th removal."""
+    from meshdqn_amd.env import Env2DAirfoil
+    from meshdqn_amd.vec_env import VecEnv2DAirfoil
+    ep, z = _refined_fixture()
+    cfg = _refined_cfg(ep, z, tmp_path)
+    names, assign, K, acts = _refined_script(ep)
+    base = Env2DAirfoil(cfg)
+    assert len(base.flow_solver.mesh.coordinates()) == 3322 and np.array_equal(base.gt_drag, z["gt_drag"])
+    venv = VecEnv2DAirfoil(cfg, len(names), base_env=base, auto_reset=False, nthreads=2)
+    st = venv.get_state()
+    checked = 0
+    for k in range(K):
+        removed = [int(st["coord_map"][b][acts[k, b]]) if acts[k, b] != 180 else -1 for b in range(len(names))]
+        st, rew, done, info = venv.step(acts[k])
+        for b, n in enumerate(names):
+            s = ep["episodes"][n]["steps"]
+            if k < len(s):
+                _check_refined(s[k], (n, k), int(info["nv"][b]), int(st["edge_ptr"][b + 1] - st["edge_ptr"][b]), rew[b], done[b],
+                               info["new_drags"][b], info["new_lifts"][b], st["coord_map"][b].tolist(), removed[b],
+                               float(st["x"][b].double().sum()))
+                checked += 1
+    assert checked == sum(len(e["steps"]) for e in ep["episodes"].values()) >= 15
+    assert any(s["done"] and s["nv"] == 3315 for e in ep["episodes"].values() for s in e["steps"])      # the vertex terminal
+    dev = VecEnv2DAirfoil(cfg, len(names), base_env=base, auto_reset=False, nthreads=2)
+    dev.get_state()
+    for k in range(K):                                  # single steps: every state is read back and compared
+        out = dev.rollout_device(None, 1, actions=acts[k:k + 1])
+        for b, n in enumerate(names):
+            s = ep["episodes"][n]["steps"]
+            if k < len(s):
+                assert out["codes"][0, b] == 0
+                _check_refined(s[k], (n, k, "device"), int(out["nv"][0, b]), int(dev.h["nedges"][b]), out["rewards"][0, b],
+                               out["dones"][0, b], dev.new_drags[b], dev.new_lifts[b], dev.h["coord_map"][b].tolist())
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("flow_steps", [0, 1])
+def test_refined_mesh_episodes_at_the_baseline_batch(lib_built, flow_steps, tmp_path):
+    """The same episodes dealt out over B = 128 environments (BASELINE configs[4]: 128 refined meshes per GPU; round 4 only
+    `bench.py` ran this size, which checks nothing), through `rollout_device` in chunks - the S1 step and the S3 step with the
+    IPCS leg on the flow stream: every environment reproduces its episode step for step."""
+    from meshdqn_amd.env import Env2DAirfoil
+    from meshdqn_amd.vec_env import VecEnv2DAirfoil
+    B = 128
+    ep, z = _refined_fixture()
+    cfg = _refined_cfg(ep, z, tmp_path)
+    names, assign, K, acts = _refined_script(ep, B, seed=128)
+    venv = VecEnv2DAirfoil(cfg, B, base_env=Env2DAirfoil(cfg), auto_reset=False, nthreads=4, flow_steps=flow_steps,
+                           flow_overlap=bool(flow_steps))
+    venv.get_state()
+    k0, checked, chunks = 0, 0, [1, 2, 3]
+    while k0 < K:
+        n = min(chunks.pop(0) if chunks else 4, K - k0)
+        out = venv.rollout_device(None, n, actions=acts[k0:k0 + n])
+        assert np.isfinite(out["rewards"]).all() and (out["codes"] == 0).all()
+        for j in range(n):
+            last = j == n - 1
+            for b in range(B):
+                s = ep["episodes"][names[assign[b]]]["steps"]
+                if k0 + j < len(s):
+                    _check_refined(s[k0 + j], (names[assign[b]], b, k0 + j), int(out["nv"][j, b]),
+                                   int(venv.h["nedges"][b]) if last else None, out["rewards"][j, b], out["dones"][j, b],
+                                   venv.new_drags[b] if last else None, venv.new_lifts[b] if last else None,
+                                   venv.h["coord_map"][b].tolist() if last else None)
+                    checked += 1
+        k0 += n
+    assert checked == sum(len(ep["episodes"][names[a]]["steps"]) for a in assign)
+    if flow_steps:
+        fd, fl = venv.flow_wait()
+        it = venv.flow_iters.cpu().numpy()
+        assert (it[:, 0] > 0).all() and (it[:, 1] > 0).all() and np.isfinite(fd).all() and np.isfinite(fl).all()
+        # environments that replayed the same episode hold the same mesh and the same warm start: same re-solved forces
+        for a in range(len(names)):
+            idx = np.flatnonzero(assign == a)
+            assert np.allclose(fd[idx], fd[idx[0]], rtol=1e-9, atol=0) and np.allclose(fl[idx], fl[idx[0]], rtol=1e-9, atol=0)

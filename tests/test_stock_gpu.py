@@ -243,6 +243,23 @@ def test_stock_episodes_at_the_baseline_batch(lib_built, mesh, flow_steps, tmp_p
         k0 += n
     assert checked == sum(len(ep["episodes"][names[a]]["steps"]) for a in assign)
     if flow_steps:                   # the flow leg really ran on every coarsened mesh (its forces arrive one step late)
-        venv.flow_wait()
+        fd, fl = venv.flow_wait()
         it = venv.flow_iters.cpu().numpy()
         assert (it[:, 0] > 0).all() and (it[:, 1] > 0).all()       # velocity BiCGStab / pressure CG iterations of every env
+        # ... and its VALUES (round 4 looked at the iteration counts only): environments that replayed the same episode end on
+        # the same mesh with the same warm start, so their re-solved drag / lift agree (mode 3's LDS atomics: round-off), and
+        # four sampled environments against the sparse-LU oracle on the very same mesh and start fields
+        for a in range(len(names)):
+            idx = np.flatnonzero(assign == a)
+            assert np.allclose(fd[idx], fd[idx[0]], rtol=1e-9, atol=0) and np.allclose(fl[idx], fl[idx[0]], rtol=1e-9, atol=0), names[a]
+        from oracle.ipcs import OracleFlowSolver            # (checker)
+        for b in [int(np.flatnonzero(assign == a)[-1]) for a in range(min(4, len(names)))]:
+            nv, nt = int(venv.nv[b]), int(venv.nt[b])
+            n2 = nv + int(venv.h["ne"][b])
+            o = OracleFlowSolver(venv.coords[b, :nv].copy(), venv.cells[b, :nt].copy(), smooth=False)
+            assert o.th.np2 == n2
+            u0 = venv.u[b, venv.S - 1, :n2].cpu().numpy()
+            o.u_n = np.concatenate([u0[:, 0], u0[:, 1]])
+            o.p_n = venv.p[b, venv.S - 1, :nv].cpu().numpy().copy()
+            _, _, do, lo = o.evolve()
+            assert abs(fd[b, 0] - do) < 1e-7 * abs(do) and abs(fl[b, 0] - lo) < 1e-7 * abs(lo), (b, fd[b, 0], do, fl[b, 0], lo)
