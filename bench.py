@@ -587,86 +587,21 @@ def _stream_log():
 
 
 def _visible_gpus():
-    """GPUs the kernel driver exposes (kfd topology nodes with SIMDs), without touching the HIP runtime; None if the
-    topology cannot be read (the ranks then find out themselves)."""
-    import glob
-    n, seen = 0, False
-    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
-        try:
-            props = dict(l.split()[:2] for l in open(f).read().splitlines() if len(l.split()) >= 2)
-        except OSError:
-            continue
-        seen = True
-        if int(props.get("simd_count", "0")) > 0:
-            n += 1
-    return n if (seen and n > 0) else None       # (0 GPU nodes found: treat the topology as unreadable)
+    return _launcher().visible_gpus()
 
 
-def _relay(stream, prefix, sink, tail, keep=None):
-    """Reader thread of one child pipe: every line goes to `sink` with the rank prefix; the last lines are kept in `tail`
-    (what the parent prints when that rank fails) and - rank 0's stdout - all lines in `keep`."""
-    for line in iter(stream.readline, ""):
-        if keep is not None:
-            keep.append(line)
-        else:
-            sink.write(prefix + line)
-            sink.flush()
-        tail.append(line)
-        del tail[:-30]
-    stream.close()
-
-
-def _stop_children(procs, grace=5.0):
-    """Terminate exactly the processes this parent started (SIGTERM, then SIGKILL after `grace` seconds)."""
-    import subprocess
-    for p_ in procs:
-        if p_.poll() is None:
-            p_.terminate()
-    t_end = time.monotonic() + grace
-    for p_ in procs:
-        try:
-            p_.wait(timeout=max(0.05, t_end - time.monotonic()))
-        except subprocess.TimeoutExpired:
-            p_.kill()
-            p_.wait()
+# the rank launcher lives in the package (train.py --gpus N uses it too); imported lazily by file path so that this parent
+# process never runs the package's __init__ chain
+def _launcher():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mdq_launcher", os.path.join(ROOT, "meshdqn_amd", "launcher.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
 def run_watched(cmds, timeout_s, poll=0.2):
-    """Start one child per (argv, env) entry and watch ALL of them: returns (failed, why, out0, tails, exit codes) where
-    `failed` is None when every child exited 0, else the index of the first child that exited non-zero (or that was still
-    running at the timeout) - in which case the other children have been terminated.  stdout of child 0 is collected in
-    `out0`, everything else is relayed to stderr with a `[rank r]` prefix; `tails[r]` = the last lines of child r."""
-    import subprocess
-    import threading
-    procs, threads, tails, out0 = [], [], [], []
-    for r, (argv_r, env_r) in enumerate(cmds):
-        p_ = subprocess.Popen(argv_r, env=env_r, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, bufsize=1)
-        procs.append(p_)
-        tails.append([])
-        for stream, keep in ((p_.stdout, out0 if r == 0 else None), (p_.stderr, None)):
-            th = threading.Thread(target=_relay, args=(stream, f"[rank {r}] ", sys.stderr, tails[r], keep), daemon=True)
-            th.start()
-            threads.append(th)
-    deadline = time.monotonic() + timeout_s
-    failed, why = None, ""
-    while True:
-        rcs = [p_.poll() for p_ in procs]
-        bad = [r for r, rc in enumerate(rcs) if rc not in (None, 0)]
-        if bad:
-            failed, why = bad[0], f"exited with code {rcs[bad[0]]}"
-            break
-        if all(rc == 0 for rc in rcs):
-            break
-        if time.monotonic() > deadline:
-            failed = next(r for r, rc in enumerate(rcs) if rc is None)
-            why = "still running at the launch timeout (MDQ_LAUNCH_TIMEOUT)"
-            break
-        time.sleep(poll)
-    if failed is not None:
-        _stop_children(procs)
-    for th in threads:
-        th.join(timeout=5)
-    return failed, why, out0, tails, [p_.returncode for p_ in procs]
+    return _launcher().run_watched(cmds, timeout_s, poll)
 
 
 def launch_ranks(args, argv):
@@ -699,19 +634,11 @@ def launch_ranks(args, argv):
             env["MDQ_BENCH_CPU_JSON"] = cpu_file
         except Exception as exc:  # noqa: BLE001 - the baseline is informational
             sys.stderr.write(f"[bench] cpu baseline child failed ({exc!r})\n")
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=env.get("MASTER_PORT", str(port)))
-    cmds = [([sys.executable, os.path.abspath(__file__)] + argv, dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(n)]
-    failed, why, out0, tails, rcs = run_watched(cmds, float(os.environ.get("MDQ_LAUNCH_TIMEOUT", "1700")))
+    rc, out0 = _launcher().start_ranks(os.path.abspath(__file__), argv, n, env=env, tag="bench")
     if cpu_file:
         os.unlink(cpu_file)
-    if failed is not None:
-        sys.stderr.write(f"[bench] rank {failed} of {n} {why}; the other ranks were terminated "
-                         f"(exit codes {rcs}): no result line.  Last output of rank {failed}:\n")
-        sys.stderr.write("".join("    " + l for l in tails[failed][-15:]))
-        return 1
+    if rc != 0:
+        return rc
     lines = [l for l in out0 if l.startswith("{")]
     if not lines:
         sys.stderr.write("[bench] rank 0 printed no JSON line\n")
@@ -804,9 +731,6 @@ def main(argv=None):
                              f"{args.gpus} needs {args.gpus} GPUs on this node\n")
             return 2
         dev_index = local_rank % ndev if os.environ.get("MDQ_SHARE_GPU") else local_rank
-        if os.environ.get("MDQ_BENCH_FAIL_RANK") == str(rank):      # failure injection for the launcher tests
-            sys.stderr.write(f"[bench] rank {rank}: MDQ_BENCH_FAIL_RANK set, exiting with code 3 before the rendezvous\n")
-            return 3
         torch.cuda.set_device(dev_index)
         backend = os.environ.get("MDQ_DIST_BACKEND", "nccl")
         # rendezvous with a SHORT timeout (a rank that never shows up fails the job in MDQ_RENDEZVOUS_TIMEOUT seconds, not in

@@ -70,18 +70,36 @@ class DistContext:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if device is None:
-            device = torch.device("cuda", self.local_rank) if torch.cuda.is_available() else torch.device("cpu")
+            if torch.cuda.is_available():
+                # MDQ_SHARE_GPU=1 (+ MDQ_DIST_BACKEND=gloo: RCCL refuses two ranks on one device): a debugging aid that lets
+                # the multi-rank control flow run on a box with fewer GPUs than ranks; never set by a production launcher
+                ndev = torch.cuda.device_count()
+                if self.local_rank >= ndev and not os.environ.get("MDQ_SHARE_GPU"):
+                    raise RuntimeError(f"rank {self.rank}: local rank {self.local_rank} has no GPU of its own ({ndev} visible)")
+                device = torch.device("cuda", self.local_rank % ndev)
+            else:
+                device = torch.device("cpu")
         self.device = device
         self.owns_group = False
         if self.world > 1 and not dist.is_initialized():
+            import datetime
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            backend = backend or ("nccl" if device.type == "cuda" else "gloo")
+            backend = backend or os.environ.get("MDQ_DIST_BACKEND") or ("nccl" if device.type == "cuda" else "gloo")
+            kw = dict(timeout=datetime.timedelta(seconds=float(os.environ.get("MDQ_DIST_TIMEOUT", "1800"))))
+            if "TORCHELASTIC_RUN_ID" not in os.environ and os.environ.get("MASTER_PORT"):
+                # started by meshdqn_amd.launcher (not torchrun, whose agent owns the store): rendezvous with a SHORT timeout -
+                # a rank that never shows up fails the job in MDQ_RENDEZVOUS_TIMEOUT seconds, not in c10d's 10-30 minutes
+                store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), self.world, self.rank == 0,
+                                      timeout=datetime.timedelta(seconds=float(os.environ.get("MDQ_RENDEZVOUS_TIMEOUT", "180"))))
+                kw.update(store=store, rank=self.rank, world_size=self.world)
             if device.type == "cuda":
                 torch.cuda.set_device(device)
-                dist.init_process_group(backend, device_id=device)
+            if device.type == "cuda" and backend == "nccl":
+                dist.init_process_group(backend, device_id=device, **kw)
             else:
-                dist.init_process_group(backend)
+                dist.init_process_group(backend, **kw)
             self.owns_group = True
+        self.backend = dist.get_backend() if (self.world > 1 and dist.is_initialized()) else None
 
     def shard(self, n_total: int):
         """Contiguous block of environment ids owned by this rank (env id -> rank = id // (n/world))."""

@@ -117,16 +117,29 @@ def test_bench_eight_ranks_share_one_gpu(lib_built):
     assert res["value_min"] <= res["value"] <= res["value_max"]
 
 
-def test_bench_launcher_tears_down_when_a_rank_dies(lib_built):
-    """Rank 3 of 8 exits at the start (MDQ_BENCH_FAIL_RANK): the other seven sit in the rendezvous; the parent names the
-    rank, terminates its children and exits non-zero within seconds - not after a c10d timeout."""
-    import time
+def _dying_rank_env(tmp_path, rank, **extra):
+    """Failure injection that lives in the TESTS (round 4 had a hook inside bench.py's main): a `sitecustomize` on the
+    children's PYTHONPATH ends the interpreter whose RANK is `rank` with exit code 3 before its script starts."""
+    (tmp_path / "sitecustomize.py").write_text(
+        "import os, sys\n"
+        f"if os.environ.get('RANK') == '{rank}' and os.environ.get('WORLD_SIZE'):\n"
+        f"    sys.stderr.write('rank {rank}: failure injected by the test (sitecustomize), exiting with code 3 before the rendezvous\\n')\n"
+        "    sys.stderr.flush()\n"
+        "    os._exit(3)\n")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    env.update(MDQ_SHARE_GPU="1", MDQ_DIST_BACKEND="gloo", MDQ_BENCH_FAIL_RANK="3")
+    env.update(MDQ_SHARE_GPU="1", MDQ_DIST_BACKEND="gloo", PYTHONPATH=str(tmp_path) + os.pathsep + env.get("PYTHONPATH", ""), **extra)
+    return env
+
+
+def test_bench_launcher_tears_down_when_a_rank_dies(lib_built, tmp_path):
+    """Rank 3 of 8 exits at the start: the other seven sit in the rendezvous; the parent names the rank, terminates its
+    children and exits non-zero within seconds - not after a c10d timeout."""
+    import time
+    env = _dying_rank_env(tmp_path, 3)
     t0 = time.monotonic()
     out = subprocess.run([sys.executable, "bench.py", "--gpus", "8"] + TINY, cwd=ROOT, env=env, capture_output=True, text=True,
                          timeout=600)
     took = time.monotonic() - t0
     assert out.returncode == 1 and took < 150, (out.returncode, took, out.stderr[-2000:])   # (8 x `import torch` on a cold box)
-    assert "rank 3 of 8 exited with code 3" in out.stderr and "MDQ_BENCH_FAIL_RANK" in out.stderr
+    assert "rank 3 of 8 exited with code 3" in out.stderr and "failure injected by the test" in out.stderr
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
