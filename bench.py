@@ -361,6 +361,12 @@ def measure_env_steps(args, dev, dist, world, flow_steps=0, steps=None, warmup=8
             ms = np.array([a.elapsed_time(b_) for a, b_ in ev])
             out["smooth_kernel_in_rollout_ms"] = dict(mean=float(ms.mean()), min=float(ms.min()), max=float(ms.max()),
                                                       launches=int(ms.size))
+            # steady-state period of a batched step: HIP events in front of consecutive smoothing launches on the group's stream,
+            # inside the timed rollouts (the first steps of every rollout - pipeline fill - and the rollout boundaries left out)
+            ev0 = getattr(groups.envs[0], "smooth_events", None) or []
+            per = [ev0[k - 1][0].elapsed_time(ev0[k][0]) for k in range(1, len(ev0)) if (k % steps) >= 5]
+            if per:
+                out["steady_state_ms_per_step"] = float(np.median(per))
             try:        # the kernel's own diagnostics of the LAST launch of the timed rollouts (per environment)
                 from meshdqn_amd.mesh_ops import smooth_fast_stats
                 st = smooth_fast_stats(dev, groups.envs[0].B, groups.envs[0].NV, groups.streams[0])
@@ -576,6 +582,19 @@ def _diverged_meshes(args, n_envs, removals=20):
         rem = np.array([int(r.integers(nb, nv[b])) for b, r in enumerate(rngs)], np.int32)
         assert (remesh_batch(coords, cells, nv, nt, rem, 50) == 0).all()
     return [(MeshTopology(coords[b, :nv[b]], cells[b, :nt[b]]), coords[b, :nv[b]].copy()) for b in range(n_envs)]
+
+
+PMC_SUMMARY = "r05_pmc_summary.json"      # profiles/: ONE PMC pass per committed file (tools/refresh_profiles_r05.sh)
+
+
+def _kernel_sources(kernel):
+    """csrc files a kernel (demangled name) is compiled from: its own .hip by namespace + every shared header."""
+    ns = kernel.split("::")[0]
+    own = {"mdq": ["mdq_ipcs.hip", "mdq_elem.h"], "mdq_smooth_lin": ["mdq_smooth_linear.hip"], "mdq_smoothing": ["mdq_smooth.hip"],
+           "mdq_smooth_big": ["mdq_smooth_big.hip"], "mdq_topo": ["mdq_topology.hip"], "mdq_rm": ["mdq_remesh.hip"],
+           "mdq_mesh": ["mdq_mesh.hip"], "mdq_gcn": ["mdq_gcn.hip", "mdq_gcn_train.hip"], "mdq_pf": ["mdq_pressure_factor.hip"],
+           "mdq_replay": ["mdq_replay.hip"]}.get(ns, [])
+    return own + ["mdq_device.h", "mdq_internal.h"]
 
 
 def _stream_log():
@@ -905,11 +924,11 @@ def main(argv=None):
                            "below this size)", vertices=int(rt.nv), triangles=int(rt.nt),
                       survey_csr_bytes_per_step=by5, survey_equivalent_GBs=by5 / (c5["ms_per_step"] * 1e-3) / 1e9,
                       survey_equivalent_over_hbm_peak=by5 / (c5["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                      measured_hbm_bytes_per_launch=(((prof_early("r04_pmc_summary.json", "hbm_bytes_per_launch") or {}).get("c5") or {})
+                      measured_hbm_bytes_per_launch=(((prof_early(PMC_SUMMARY, "hbm_bytes_per_launch") or {}).get("c5") or {})
                                                      .get("mdq::evolve_kernel<5, false, false>")),
                       note="survey_* = the bytes an assembled-CSR implementation would stream (SURVEY 8(d) convention) over the step "
                            "time - NOT a roofline fraction of this kernel; measured_hbm_bytes_per_launch = rocprofv3 FETCH_SIZE + "
-                           "WRITE_SIZE of the same kernel (profiles/r04_pmc_summary.json; one launch = one step of 128 environments)")
+                           "WRITE_SIZE of the same kernel (profiles/" + PMC_SUMMARY + "; one launch = one step of 128 environments)")
             del b5
             cfgs["C5_s2_refined_mesh"] = c5
         except Exception as exc:  # noqa: BLE001
@@ -923,25 +942,26 @@ def main(argv=None):
             except Exception:  # noqa: BLE001
                 return None
 
-        def pmc_traffic(name, leg, kernel, source):
-            """HBM bytes per launch of `kernel` from the committed PMC summary - refused (None + the reason) when the summary is
-            missing or was collected from a different version of the kernel's source file (sha256 stamped at collection)."""
+        def pmc_traffic(name, leg, kernel):
+            """HBM bytes per launch of `kernel` from the committed PMC summary - refused PER KERNEL (None + the reason) when the
+            summary is missing or was collected from a different version of any source file that kernel is compiled from
+            (sha256 of every csrc file stamped at collection; kernel -> files: `_kernel_sources`)."""
             import hashlib
-            stamp = (prof(name, "kernel_sources_sha256") or {}).get(source)
-            try:
-                now = hashlib.sha256(open(os.path.join(ROOT, "meshdqn_amd", "csrc", source), "rb").read()).hexdigest()
-            except OSError:
-                now = None
+            stamps = prof(name, "kernel_sources_sha256") or {}
             val = (((prof(name, "hbm_bytes_per_launch") or {}).get(leg) or {}).get(kernel) or {}).get("corrected")
             src = (f"profiles/{name} @ {prof(name, 'git_commit') or 'unstamped'} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                    "this command, gfx950 wide-read correction; counters cannot be read inside the run)")
             if val is None:
                 return None, src + f" - NO figure for {kernel}"
-            if stamp is None or stamp != now:
-                return None, src + f" - REFUSED: {source} has changed since the counters were collected (sha256 differs)"
-            return val, src + f"; {source} sha256 {now[:12]} matches"
-        sm_traffic, sm_traffic_src = pmc_traffic("r04_pmc_summary.json", "s3", "mdq_smooth_lin::smooth_linear_kernel",
-                                                 "mdq_smooth_linear.hip")
+            for source in _kernel_sources(kernel):
+                try:
+                    now = hashlib.sha256(open(os.path.join(ROOT, "meshdqn_amd", "csrc", source), "rb").read()).hexdigest()
+                except OSError:
+                    now = None
+                if stamps.get(source) is None or stamps.get(source) != now:
+                    return None, src + f" - REFUSED for {kernel}: {source} has changed since the counters were collected (sha256 differs)"
+            return val, src + f"; sha256 of {', '.join(_kernel_sources(kernel))} match"
+        sm_traffic, sm_traffic_src = pmc_traffic(PMC_SUMMARY, "s3", "mdq_smooth_lin::smooth_linear_kernel")
         nt, nv = topo.nt, topo.nv
         insitu = s3.get("smooth_kernel_in_rollout_ms")
         sm_ms = insitu["mean"] if insitu else smk["launch_ms"]      # the launches of the timed region themselves
@@ -958,6 +978,9 @@ def main(argv=None):
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": s3["ms_per_batched_step"],
+            # period of a batched step inside the rollouts (HIP events; ms_per_step also pays the fill and the drain of the
+            # two-stream pipeline and the one read-back per rollout: K = --steps batched steps per rollout)
+            "steady_state_ms_per_step": s3.get("steady_state_ms_per_step"),
             "repeats": args.repeats,
             "value_min": s3["value_min"],
             "value_max": s3["value_max"],
@@ -1040,6 +1063,18 @@ def main(argv=None):
                 "note": "matrix-free: operators are re-derived per triangle from 64 B of metadata, Krylov vectors live in "
                         "LDS/registers; one workgroup (one CU) per environment: 128 of 256 CUs at the BASELINE configuration"},
         }
+        try:        # per-kernel resources of the library that ran (written by meshdqn_amd/build.py from the compiler's remarks)
+            kres = json.load(open(os.path.join(ROOT, "meshdqn_amd", "libmeshdqn_hip.resources.json")))
+            res["kernel_scratch"] = dict(
+                kernels=len(kres), with_scratch={k: v["scratch_bytes_per_lane"] for k, v in kres.items() if v["scratch_bytes_per_lane"] > 0},
+                hot_kernels={k: dict(vgprs=v["vgprs"], scratch=v["scratch_bytes_per_lane"], occupancy=v["occupancy"])
+                             for k, v in kres.items() if any(t in k for t in ("smooth_linear", "at_velocity", "at_pressure", "at_correction",
+                                                                               "topology_kernel", "gcn_embed", "mlp_head_c128", "remesh_kernel",
+                                                                               "evolve_mf", "evolve_kernel<5", "setup_matfree", "interpolate",
+                                                                               "env_finish", "probe"))},
+                unit="bytes per lane (-Rpass-analysis=kernel-resource-usage of this build)")
+        except Exception as exc:  # noqa: BLE001
+            res["kernel_scratch"] = dict(error=repr(exc))
         res["rates"] = {"S3_north_star_step": s3, "S1_reference_step": s1, "S2_ipcs_step": s2, "S2_full_chip": full,
                         "training_loop": tr, **cfgs}
         if cpu is not None:

@@ -21,6 +21,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmeshdqn_hip.so")
+RESOURCES = os.path.join(HERE, "libmeshdqn_hip.resources.json")   # per-kernel VGPRs / scratch / occupancy of THIS build (bench.py)
 OBJ = os.path.join(ROOT, "build", "obj")
 ARCH = "gfx950"
 
@@ -58,10 +59,36 @@ def _headers() -> list:
 
 def _flags(verbose: bool) -> list:
     fl = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-fvisibility=hidden",
-          "-I", os.path.join(ROOT, "include"), "-I", CSRC]
-    if verbose:
-        fl.append("-Rpass-analysis=kernel-resource-usage")
+          "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Rpass-analysis=kernel-resource-usage"]
     return fl + os.environ.get("MDQ_CFLAGS", "").split()
+
+
+def parse_resources(log: str) -> dict:
+    """kernel (demangled, without arguments) -> dict(vgprs, agprs, sgprs, scratch_bytes_per_lane, occupancy, lds_bytes) from the
+    `-Rpass-analysis=kernel-resource-usage` remarks of a compile."""
+    import re
+    rows, cur = [], None
+    for line in log.splitlines():
+        m = re.search(r"remark: (?:\S+ )?\s*(Function Name|Name|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|"
+                      r"LDS Size \[bytes/block\]|SGPRs): (\S+)", line)
+        if not m:
+            continue
+        k, v = m.group(1), m.group(2)
+        if k in ("Function Name", "Name"):
+            cur = {"name": v}
+            rows.append(cur)
+        elif cur is not None:
+            cur[k.split(" ")[0]] = v
+    if not rows:
+        return {}
+    names = subprocess.run(["c++filt"] + [r["name"] for r in rows], capture_output=True, text=True).stdout.splitlines()
+    out = {}
+    for r, n in zip(rows, names):
+        n = re.sub(r"\(.*", "", n).replace("void ", "")
+        out[n] = dict(vgprs=int(r.get("VGPRs", -1)), agprs=int(r.get("AGPRs", -1)), sgprs=int(r.get("SGPRs", -1)),
+                      scratch_bytes_per_lane=int(r.get("ScratchSize", -1)), occupancy=int(r.get("Occupancy", -1)),
+                      lds_bytes=int(r.get("LDS", -1)))
+    return out
 
 
 def _unit_key(name: str, flags: list) -> str:
@@ -107,13 +134,15 @@ def _compile(name: str, flags: list, force: bool) -> tuple:
     obj = os.path.join(OBJ, name + ".o")
     keyf = obj + ".key"
     key = _unit_key(name, flags)
-    if not force and os.path.exists(obj) and os.path.exists(keyf) and open(keyf).read() == key:
-        return name, obj, ""
+    if not force and os.path.exists(obj) and os.path.exists(keyf) and os.path.exists(obj + ".log") and open(keyf).read() == key:
+        return name, obj, open(obj + ".log").read()
     cmd = [_hipcc()] + flags + extra + ["-c", os.path.join(CSRC, src), "-o", obj + ".tmp"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src} ({name}):\n{res.stdout}{res.stderr}")
     os.replace(obj + ".tmp", obj)
+    with open(obj + ".log", "w") as f:
+        f.write(res.stderr)
     with open(keyf, "w") as f:
         f.write(key)
     return name, obj, res.stderr
@@ -128,7 +157,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     jobs = int(os.environ.get("MDQ_BUILD_JOBS", "0")) or min(len(UNITS), os.cpu_count() or 4)
     objs, logs = {}, {}
     with cf.ThreadPoolExecutor(jobs) as ex:
-        futs = [ex.submit(_compile, n, flags, force or verbose) for n in UNITS]
+        futs = [ex.submit(_compile, n, flags, force) for n in UNITS]
         for f in futs:
             try:
                 n, o, log = f.result()
@@ -146,6 +175,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
         sys.stderr.write(res.stdout + res.stderr)
         raise RuntimeError("hipcc failed linking libmeshdqn_hip.so")
     os.replace(LIB + ".tmp", LIB)
+    import json
+    table = {}
+    for n in UNITS:
+        table.update(parse_resources(logs[n]))
+    with open(RESOURCES, "w") as f:
+        json.dump(table, f, indent=0, sort_keys=True)
     return LIB
 
 

@@ -16,7 +16,8 @@ SMALL = ["--steps", "6", "--warmup", "2", "--repeats", "3", "--spinup", "60", "-
          "--s1-steps", "4", "--s1-warmup", "3", "--train-steps", "3", "--s1-solver-steps", "200"]
 KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
         "vs_baseline", "dtype", "data", "config", "roofline", "roofline_s2_velocity", "rates", "repeats", "value_min",
-        "value_max", "s1_env_steps_per_s", "s2_ipcs_env_steps_per_s", "s3_env_steps_per_s", "training_env_steps_per_s"}
+        "value_max", "s1_env_steps_per_s", "s2_ipcs_env_steps_per_s", "s3_env_steps_per_s", "training_env_steps_per_s",
+        "steady_state_ms_per_step", "kernel_scratch"}
 
 
 def _line(cmd, env):
@@ -35,6 +36,9 @@ def test_bench_single_rank_line(lib_built):
     assert res["value"] > 0 and abs(res["value"] - 16 * 6 / (res["ms_per_step"] * 6e-3)) < 1e-6 * res["value"]
     assert res["value"] == res["s3_env_steps_per_s"] == res["rates"]["S3_north_star_step"]["value"]
     assert res["value_min"] <= res["value"] <= res["value_max"]
+    assert 0 < res["steady_state_ms_per_step"] <= res["ms_per_step"] * 1.5          # the HIP-event period of a step inside the rollouts
+    ks = res["kernel_scratch"]
+    assert ks["kernels"] >= 55 and all(v["scratch"] == 0 for k, v in ks["hot_kernels"].items() if "evolve_kernel<5" not in k and "topology_kernel<4>" not in k), ks
     assert "S3" in res["config"]["workload"] and res["config"]["krylov_iters_per_ipcs_step"]["velocity_bicgstab"] > 0
     roof = res["roofline"]
     assert roof["bound"] == "hbm" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
