@@ -106,6 +106,11 @@ def _stale() -> bool:
         return False
     if not os.path.exists(LIB):
         return True
+    try:        # built with other flags (MDQ_CFLAGS experiments)?
+        if open(os.path.join(OBJ, "flags.txt")).read() != " ".join(_flags(False)):
+            return True
+    except OSError:
+        return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
     deps.append(os.path.join(ROOT, "include", "meshdqn_hip.h"))
@@ -175,6 +180,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         sys.stderr.write(res.stdout + res.stderr)
         raise RuntimeError("hipcc failed linking libmeshdqn_hip.so")
     os.replace(LIB + ".tmp", LIB)
+    with open(os.path.join(OBJ, "flags.txt"), "w") as f:
+        f.write(" ".join(flags))
     import json
     table = {}
     for n in UNITS:

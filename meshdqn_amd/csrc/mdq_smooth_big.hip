@@ -15,10 +15,21 @@
 #include "mdq_internal.h"
 
 namespace mdq_smooth_big {
-constexpr int BNV = 4096, BNT = 8192, BWG = 512;
-constexpr size_t SLAB_BYTES = sizeof(int) * (BNV + 8) + sizeof(uint32_t) * 3 * BNT * 2 + sizeof(uint16_t) * BNV * 2 + sizeof(int) * (BNV + 8);
+constexpr int BNV = 4096, BNT = 8192, BWG = 1024;
+constexpr int MAXK = 16;           // incident cells per vertex in the level-ordered work records (more: the general loop)
+constexpr int MAXLEV = 1024;       // levels whose starts are kept in LDS (more: the general loop)
+constexpr size_t SLAB_BYTES = sizeof(int) * (BNV + 8) + sizeof(uint32_t) * 3 * BNT * 2 + sizeof(uint16_t) * BNV * 2 + sizeof(int) * (BNV + 8) +
+                              sizeof(uint32_t) * BNV + sizeof(uint32_t) * BNV * MAXK;
 
 typedef double d2 __attribute__((ext_vector_type(2)));
+
+#ifdef MDQ_SB_TRACE
+// debug build only: s_memtime cycles of the sections of a level (wave 0 of mesh 0), summed over the launch
+static __device__ long long mdq_sb_trace_buf[8];
+#define SB_STAMP(k) { const long long tn_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) mdq_sb_trace_buf[k] += tn_ - tq_; tq_ = tn_; }
+#else
+#define SB_STAMP(k)
+#endif
 
 template <int CTRL>
 __device__ __forceinline__ double dppd(double v) {
@@ -50,6 +61,68 @@ __device__ __forceinline__ double rcp_d(double x) {
   y = y * (2.0 - x * y);
   y = y * (2.0 - x * y);
   return y;
+}
+
+// the same update by a group of FOUR lanes from a work record whose entries are already in registers: lane l plays the lanes
+// l and l + 4 of the 8-lane form (entries l, l + 8 and l + 4, l + 12 of the vertex's ascending-cell list), and the two partial
+// sums go through the 8-lane tree - (xor 1, xor 2) inside each virtual quad, then quad 0 + quad 1 - so that every sum is
+// associated exactly as in exact_vertex: identical bits, half the lanes (the level loop is bound by instruction issue: the
+// scalar tail - divisions, comparisons - ran in eight lanes per vertex)
+__device__ __forceinline__ d2 exact_vertex_rec(const d2* X, const double* r2k_tab, int v, int k, int l, const uint32_t (&w)[4]) {
+#pragma clang fp contract(off)
+  const double EPS = 3.0e-16;
+  // every LDS read of the update is issued up front (the addresses are in registers: one round trip, not a chain of them);
+  // entries beyond k read position 0 and contribute +0.0 / no minimum (x + 0.0 == x: the sums keep their bits)
+  const d2 p = X[v];
+  const double r2k = r2k_tab[k];                             // 1.0 / (2.0 * k), rounded once (the table is built with that division)
+  // (entries l + 8, l + 12 exist for vertices with more than 8 cells only: a wave none of whose vertices has them skips
+  //  that half of the arithmetic - the level loop is bound by the fp64 instructions it issues)
+  const bool wide = __builtin_amdgcn_ballot_w64(k > 8) != 0;
+  d2 pa[4], pc[4];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    pa[e] = X[w[e] & 0xFFFF];
+    pc[e] = X[w[e] >> 16];
+  }
+  if (wide) {
+#pragma unroll
+    for (int e = 2; e < 4; ++e) {
+      pa[e] = X[w[e] & 0xFFFF];
+      pc[e] = X[w[e] >> 16];
+    }
+  }
+  double sx[2] = {0.0, 0.0}, sy[2] = {0.0, 0.0}, rm = 1e300;
+  auto entry = [&](int h, int e, bool on) {
+    sx[h] += on ? pa[e].x + pc[e].x : 0.0;
+    sy[h] += on ? pa[e].y + pc[e].y : 0.0;
+    const double tx = pc[e].x - pa[e].x, ty = pc[e].y - pa[e].y;
+    const double cr = ty * (p.x - pa[e].x) - tx * (p.y - pa[e].y);
+    const double t2 = tx * tx + ty * ty;
+    const double r_ = cr * cr * rcp_d(on ? t2 : 1.0);
+    rm = on ? fmin(rm, r_) : rm;
+  };
+  entry(0, 0, l < k);                 // virtual lane l:     entry l
+  if (wide) entry(0, 2, l + 8 < k);   //                     entry l + 8
+  entry(1, 1, l + 4 < k);             // virtual lane l + 4: entry l + 4
+  if (wide) entry(1, 3, l + 12 < k);  //                     entry l + 12
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    sx[h] += dppd<0xB1>(sx[h]);
+    sx[h] += dppd<0x4E>(sx[h]);
+    sy[h] += dppd<0xB1>(sy[h]);
+    sy[h] += dppd<0x4E>(sy[h]);
+  }
+  rm = fmin(rm, dppd<0xB1>(rm));
+  rm = fmin(rm, dppd<0x4E>(rm));
+  const double sxt = sx[0] + sx[1], syt = sy[0] + sy[1];
+  const double dx = sxt * r2k - p.x, dy = syt * r2k - p.y;
+  const double q2 = dx * dx + dy * dy;
+  if (!(q2 >= EPS * EPS && q2 > 0.0)) return p;
+  if (0.25 * rm < q2) {
+    const double f = 0.5 * (rm * rsqrt_d(rm)) * rsqrt_d(q2);
+    return d2{p.x + f * dx, p.y + f * dy};
+  }
+  return d2{p.x + dx, p.y + dy};
 }
 
 // DOLFIN's update of vertex v by a group of 8 lanes (lane l of the group takes incident cells l, l + 8, ...): the same
@@ -91,6 +164,8 @@ __global__ __launch_bounds__(BWG) void smooth_big_kernel(int NV, int NT, double*
   int* cnt = reinterpret_cast<int*>(dyn_ + sizeof(d2) * BNV);   // [BNV] 16 KB: counts / cursors, then levels
   __shared__ int part[BWG];
   __shared__ int misc[4];
+  __shared__ double r2k_tab[MAXK + 1];
+  __shared__ int lstart[MAXLEV + 2];                          // level starts (a copy of lptr: the sweeps never leave the CU for them)
   const int b = blockIdx.x, tid = threadIdx.x;
   const int S = iters_ ? iters_[b] : ((rem[b] >= 0 && rstat[b] == 0) ? iters_env : 0);
   if (status && tid == 0) status[b] = 0;
@@ -105,6 +180,8 @@ __global__ __launch_bounds__(BWG) void smooth_big_kernel(int NV, int NT, double*
   uint16_t* order = reinterpret_cast<uint16_t*>(cel + 3 * BNT);            // [BNV] interior vertices grouped by level
   uint16_t* intr = order + BNV;                                            // [BNV] 1 = interior
   int* lptr = reinterpret_cast<int*>(intr + BNV);                          // [levels + 2]
+  uint32_t* meta = reinterpret_cast<uint32_t*>(lptr + BNV + 8);            // [BNV] per level-ordered position: v | k << 16
+  uint32_t* inc2 = meta + BNV;                                             // [BNV][MAXK] its entries, ascending cell
   // ---- vertex -> cells
   for (int v = tid; v < BNV; v += BWG) cnt[v] = 0;
   __syncthreads();
@@ -231,6 +308,22 @@ __global__ __launch_bounds__(BWG) void smooth_big_kernel(int NV, int NT, double*
   __syncthreads();
   for (int v = tid; v < nv; v += BWG)
     if (cnt[v] > 0) order[atomicAdd(&cur[cnt[v]], 1)] = (uint16_t)v;
+  if (tid == 0) misc[1] = lmax > MAXLEV ? 1 : 0;             // 1: the general loop below (records / level starts do not fit)
+  __syncthreads();
+  // ---- work records in level order: the sweeps read them with addresses that depend on the position only (the walk
+  // order[i] -> ptr[v] -> inc[q] was three dependent L2 round trips per update: 2 us per level, 4 ms per launch)
+  const int n_int = lptr[lmax + 1];
+  for (int i = tid; i < n_int; i += BWG) {
+    const int v = order[i], q0 = ptr[v], k = ptr[v + 1] - q0;
+    meta[i] = (uint32_t)v | ((uint32_t)k << 16);
+    if (k > MAXK) misc[1] = 1;
+    for (int q = 0; q < MAXK; ++q) inc2[i * MAXK + q] = q < k ? inc[q0 + q] : 0u;
+  }
+  for (int l = tid; l <= lmax + 1 && l < MAXLEV + 2; l += BWG) lstart[l] = lptr[l];
+  if (tid >= 1 && tid <= MAXK) {
+#pragma clang fp contract(off)
+    r2k_tab[tid] = 1.0 / (2.0 * tid);
+  }
   // ---- positions
   for (int v = tid; v < nv; v += BWG) {
     const double2 xv = xg[v];
@@ -239,6 +332,81 @@ __global__ __launch_bounds__(BWG) void smooth_big_kernel(int NV, int NT, double*
   __syncthreads();
   // ---- sweeps: level by level, 8 lanes per vertex
   const int grp = tid >> 3, l8 = tid & 7;
+#ifndef MDQ_SB_SWG
+#define MDQ_SB_SWG 1024
+#endif
+  constexpr int SWG = MDQ_SB_SWG;   // threads of the sweeps (the set-up phases want all BWG: loops of memory round trips)
+  if (lmax > 0 && !misc[1] && tid >= SWG) return;   // the other waves retire: a barrier counts the live waves only
+  const int nthr = (lmax > 0 && !misc[1]) ? SWG : BWG;
+  if (lmax == 0) {
+    // (no interior vertex: nothing moves)
+  } else if (!misc[1]) {
+    // records of the first pass of the NEXT level are requested before the current level is computed: their latency hides
+    // behind the update + the barrier (they do not depend on the positions)
+    constexpr int G = SWG / 4;
+    const int g4 = tid >> 2, l4 = tid & 3;
+    struct Rec { uint32_t m, w[4]; };
+    auto fetch = [&](int i, int i1, Rec& r) {
+      r.m = 0u;
+      r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0u;
+      if (i < i1) {
+        r.m = meta[i];
+        const uint32_t* e = inc2 + i * MAXK + l4;
+        r.w[0] = e[0];      // entry l
+        r.w[1] = e[4];      // entry l + 4
+        r.w[2] = e[8];      // entry l + 8
+        r.w[3] = e[12];     // entry l + 12
+      }
+    };
+    // two record sets used alternately (a register copy `cur = nxt` would wait for the loads it copies - in front of the
+    // barrier, i.e. the L2 round trip back on every level)
+    Rec ra, rb;
+    int i0 = lstart[1], i1 = lstart[2];                       // this level
+    int j0 = lmax > 1 ? lstart[2] : i0, j1 = lmax > 1 ? lstart[3] : i1;   // the next one (level 1 again behind the last)
+    fetch(i0 + g4, i1, ra);
+    auto level = [&](int l, Rec& mine, Rec& next) {
+      // the level starts two levels ahead are read now and used by the NEXT call's record request: no LDS round trip in
+      // front of the global one
+      const int l2 = (l % lmax + 1) % lmax + 1;              // the level after the next one (cyclic)
+#ifdef MDQ_SB_TRACE
+      long long tq_ = __builtin_amdgcn_s_memtime();
+#endif
+      const int k0 = lstart[l2], k1 = lstart[l2 + 1];
+#ifndef MDQ_SB_NOFETCH
+      fetch(j0 + g4, j1, next);
+#endif
+      SB_STAMP(0)
+      for (int i = i0 + g4; i < i1; i += G) {
+        if (i != i0 + g4) fetch(i, i1, mine);                 // (further passes of a wide level)
+        const int v = mine.m & 0xFFFF, k = mine.m >> 16;
+#ifdef MDQ_SB_NOCOMP
+        const d2 xn = X[v] + X[mine.w[0] & 0xFFFF] * 1e-300;
+        (void)k;
+#else
+        const d2 xn = exact_vertex_rec(X, r2k_tab, v, k, l4, mine.w);
+#endif
+        if (l4 == 0) X[v] = xn;
+      }
+      SB_STAMP(1)
+      i0 = j0; i1 = j1; j0 = k0; j1 = k1;
+      SB_STAMP(2)
+      // LDS-only barrier: the positions of this level are in LDS (lgkmcnt), the records requested for the next level are
+      // still on their way (vmcnt) and stay in flight - __syncthreads() drains the vector-memory counter as well
+#ifndef MDQ_SB_NOBAR
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+      SB_STAMP(3)
+    };
+    const int total = S * lmax;
+    int t = 0, l = 1;
+    for (; t + 1 < total; t += 2) {
+      level(l, ra, rb);
+      l = l < lmax ? l + 1 : 1;
+      level(l, rb, ra);
+      l = l < lmax ? l + 1 : 1;
+    }
+    if (t < total) level(l, ra, rb);
+  } else
   for (int s = 0; s < S; ++s) {
     for (int l = 1; l <= lmax; ++l) {
       const int i0 = lptr[l], i1 = lptr[l + 1];
@@ -250,12 +418,21 @@ __global__ __launch_bounds__(BWG) void smooth_big_kernel(int NV, int NT, double*
       __syncthreads();
     }
   }
-  for (int v = tid; v < nv; v += BWG) {
+  __syncthreads();
+  for (int v = tid; v < nv; v += nthr) {
     const d2 p = X[v];
     xg[v] = double2{p.x, p.y};
   }
 }
 }  // namespace mdq_smooth_big
+
+#ifdef MDQ_SB_TRACE
+extern "C" MDQ_API int mdq_sb_trace_host(long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mdq_smooth_big::mdq_sb_trace_buf), sizeof(long long) * 8) != hipSuccess) return -1;
+  if (reset) { long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(mdq_smooth_big::mdq_sb_trace_buf), z, sizeof z) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 
 // bytes of caller workspace the large-mesh kernel needs (0: the mesh fits the 1024-vertex kernels; -1: beyond the kernels)
 static int64_t smooth_big_workspace_bytes(int32_t B, int32_t NV, int32_t NT) {

@@ -20,8 +20,9 @@ MESH = sys.argv[5] if len(sys.argv) > 5 else "ys930"
 G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 cfg = dict(flow_config=dict(flow_params=dict(mu=1e-3, rho=1.0, inflow="constant"), geometry_params=dict(mesh=os.path.join(G, f"{MESH}.npz")),
                             solver_params=dict(dt=0.001, solver_type="lu", smooth=True, reproducible=False, rtol=1e-10)),   # (ground truth only)
-           agent_params=dict(solver_steps=5000, episodes=10, timesteps=10000, threshold=0.001, N_closest=180, gt_drag=-1, gt_time=-1, u=-1, p=-1,
-                             time_reward=0.005, save_steps=1000, goal_vertices=0.95, plot_dir=""))
+           agent_params=dict(solver_steps=int(os.environ.get("MDQ_TOOL_SOLVER_STEPS", "5000")), episodes=10, timesteps=10000, threshold=0.001,
+                             N_closest=180, gt_drag=-1, gt_time=-1, u=-1, p=-1, time_reward=0.005,
+                             save_steps=int(os.environ.get("MDQ_TOOL_SOLVER_STEPS", "5000")) // 5, goal_vertices=0.95, plot_dir=""))
 base = Env2DAirfoil(cfg)
 venv = VecEnv2DAirfoil(cfg, B, base_env=base, flow_steps=FLOW, flow_overlap=bool(FLOW))
 net = NodeRemovalNet(181, conv_width=128, topk=0.1); net.set_num_nodes(17); net = net.cuda(); fused = FusedGcn(net)
