@@ -170,6 +170,10 @@ typedef struct mdq_ipcs_desc {
      all N2 (12 924 on the refined ys930) */
   const int32_t* mf_rlist;     /* [B][NCH][NRL][2] */
   const int32_t* mf_rcnt;      /* [B][NCH] touched rows of the chunk */
+  const int32_t* mf_lpos;      /* [B][6][NT] optional (NULL: off), with mf_rlist: position of dof i of triangle e in its chunk's row
+                                  list (bits 0-15) | tile position (bits 16-31, = the plain mf_scat value): the chunk's input rows
+                                  are then staged in LDS through the row list instead of gathered per triangle from global memory
+                                  (needs NRL rows of 16 bytes behind the 96 KB tile: NRL <= ~3900) */
   int32_t NRL, rl_flags;             /* rl_flags = 1: bit 31 / bit 30 of a list entry's row word mark the FIRST / LAST chunk that
                                         touches the row, and every row < n2 is touched by some chunk (ABI 5, round 4) */
 } mdq_ipcs_desc;

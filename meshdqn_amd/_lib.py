@@ -50,7 +50,7 @@ class IpcsDesc(C.Structure):
         ("sdiagM", C.c_void_p), ("sdiagK", C.c_void_p),
         ("u_n", C.c_void_p), ("p_n", C.c_void_p),
         ("work", C.c_void_p), ("work_doubles", C.c_int64),
-        ("mf_rlist", C.c_void_p), ("mf_rcnt", C.c_void_p), ("NRL", C.c_int32), ("rl_flags", C.c_int32),
+        ("mf_rlist", C.c_void_p), ("mf_rcnt", C.c_void_p), ("mf_lpos", C.c_void_p), ("NRL", C.c_int32), ("rl_flags", C.c_int32),
     ]
 
 

@@ -73,6 +73,11 @@ __host__ __device__ inline int64_t work_ytmp_offset(int NV, int NT, int NE) {
   return (work_hist_offset(NV, NT, NE) + 10 * N2 + 2 + 1) & ~(int64_t)1;
 }
 
+// mode 5 with the chunk's input rows staged in LDS behind the element tile: does the stage (NRL rows) fit?
+__host__ __device__ inline bool mode5_stage_fits(int NRL) {
+  return NRL > 0 && 64 * sizeof(double) + sizeof(double2) * 6 * MF_CH + sizeof(double2) * (size_t)NRL <= 160 * 1024;
+}
+
 struct EnvView {
   int nv, nt, ne, n2, nnz2, nnz1, naf;
   int NT;  // capacity (SoA stride of cell_dofs / geom)
@@ -85,6 +90,7 @@ struct EnvView {
   const int32_t *mf_scat, *mf_tptr;
   int mf_tstride;  // N2+1
   const int32_t *mf_rlist, *mf_rcnt;   // mode 5: touched rows per chunk (or null)
+  const int32_t* mf_lpos;              // mode 5: [6][NT] position of the dof in its chunk's row list | tile position << 16 (or null)
   int NRL, rl_flags;
   const int32_t *g2_ptr, *g2_src, *g1_ptr, *g1_src;
   const uint8_t* bcu_flag;
@@ -142,6 +148,7 @@ __device__ __forceinline__ EnvView env_view(const mdq_ipcs_desc& d, int b) {
   v.rl_flags = d.rl_flags;
   v.mf_rlist = (d.mf_rlist && d.mf_rcnt && d.NRL > 0) ? d.mf_rlist + B * ((d.NT + MF_CH - 1) / MF_CH) * d.NRL * 2 : nullptr;
   v.mf_rcnt = v.mf_rlist ? d.mf_rcnt + B * ((d.NT + MF_CH - 1) / MF_CH) : nullptr;
+  v.mf_lpos = (v.mf_rlist && d.mf_lpos && mode5_stage_fits(d.NRL)) ? d.mf_lpos + B * 6 * d.NT : nullptr;
   v.g2_ptr = d.g2_ptr + B * (d.N2 + 1);
   v.g2_src = d.g2_src + B * 6 * d.NT;
   v.g1_ptr = d.g1_ptr + B * (d.NV + 1);
@@ -244,6 +251,7 @@ __device__ inline void outflow_entry(const EnvView& v, int e, int k, int i, int 
   }
 }
 
+#if MDQ_IN_PART(0)
 static __global__ __launch_bounds__(WG) void assemble_kernel(mdq_ipcs_desc d) {
   const int b = blockIdx.x;
   EnvView v = env_view(d, b);
@@ -439,6 +447,7 @@ static __global__ __launch_bounds__(WG) void assemble_kernel(mdq_ipcs_desc d) {
     for (int j = len; j < width; ++j) v.K1s[pos1(r, j)] = 0.0;
   }
 }
+#endif
 
 // ================================================================== matrix-free operator setup
 //
@@ -1002,8 +1011,15 @@ extern "C" MDQ_API int mdq_t5_trace_host(long long* out, int reset) {
 #define T5_STAMP(k)
 #endif
 
+// `gx`: the operator's input vector (global); op(e, geometry, outflow edge, xe[6], ye[6]) applies one triangle's operator to
+// its six gathered input values.  With mf_lpos (round 5) the rows a chunk touches are STAGED in LDS behind the tile first -
+// one pass over the chunk's ascending row list, coalesced where the rows are consecutive - and the triangles gather from
+// there through 16-bit local indices: six random 16-byte reads per triangle from global memory pulled a cache line each
+// (the PMC traffic of the kernel was 1.2-1.95x its algorithmic bytes), and the triangle's dof ids + tile positions are
+// one packed word per dof (24 B per triangle instead of 48).
 template <class ElemOp, class Epi>
-__device__ __forceinline__ void tile_apply_global(const EnvView& v, bool packed, double2* es, double2* ytmp, ElemOp op, Epi epi) {
+__device__ __forceinline__ void tile_apply_global(const EnvView& v, bool packed, double2* es, double2* ytmp, const double2* gx,
+                                                  ElemOp op, Epi epi) {
   const int tid = threadIdx.x, n = v.n2;
   const int nch = (v.nt + MF_CH - 1) / MF_CH;
 #ifdef MDQ_T5_TRACE
@@ -1016,12 +1032,12 @@ __device__ __forceinline__ void tile_apply_global(const EnvView& v, bool packed,
     // triangle, free during the solves) and every row sums its slots in ascending order - the gather the right-hand sides use
     double2* es2 = reinterpret_cast<double2*>(v.work);
     for (int e = tid; e < v.nt; e += WG) {
-      ElemIdx E;
+      double2 xe[6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) E.dof[i] = v.cell_dofs[i * v.NT + e];
+      for (int i = 0; i < 6; ++i) xe[i] = gx[v.cell_dofs[i * v.NT + e]];
       const Geo g = load_geo(v, e);
       double2 ye[6];
-      op(e, g, E, (int)v.cell_outflow[e], ye);
+      op(e, g, (int)v.cell_outflow[e], xe, ye);
 #pragma unroll
       for (int i = 0; i < 6; ++i) es2[e * 6 + i] = ye[i];
     }
@@ -1045,22 +1061,40 @@ __device__ __forceinline__ void tile_apply_global(const EnvView& v, bool packed,
   const bool rlf = v.mf_rlist && v.rl_flags != 0;
   if (!rlf)
     for (int row = tid; row < n; row += WG) ytmp[row] = make_double2(0.0, 0.0);   // (own rows: visible to the row phases behind the barriers)
+  double2* xst = es + 6 * MF_CH;                        // (staged input rows of the chunk: behind the tile, mf_lpos only)
   for (int chunk = 0; chunk < nch; ++chunk) {
+    if (v.mf_lpos) {
+      const int2* rl = reinterpret_cast<const int2*>(v.mf_rlist) + (size_t)chunk * v.NRL;
+      const int nr = v.mf_rcnt[chunk];
+      for (int k = tid; k < nr; k += WG) xst[k] = gx[rl[k].x & 0x3FFFFFFF];
+      __syncthreads();
+    }
 #pragma unroll
     for (int j = 0; j < MF_EPT; ++j) {
       const int e = chunk * MF_CH + tid + j * WG;
       if (e < v.nt) {
-        ElemIdx E;
         int pos[6];
+        double2 xe[6];
+        if (v.mf_lpos) {
+          int w[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          const int w = v.mf_scat[i * v.NT + e];
-          pos[i] = packed ? (w >> 12) & 0x1FFF : w;
-          E.dof[i] = v.cell_dofs[i * v.NT + e];
+          for (int i = 0; i < 6; ++i) w[i] = v.mf_lpos[i * v.NT + e];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            pos[i] = w[i] >> 16;
+            xe[i] = xst[w[i] & 0xFFFF];
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            const int w = v.mf_scat[i * v.NT + e];
+            pos[i] = packed ? (w >> 12) & 0x1FFF : w;
+            xe[i] = gx[v.cell_dofs[i * v.NT + e]];
+          }
         }
         const Geo g = load_geo(v, e);
         double2 ye[6];
-        op(e, g, E, (int)v.cell_outflow[e], ye);
+        op(e, g, (int)v.cell_outflow[e], xe, ye);
 #pragma unroll
         for (int i = 0; i < 6; ++i) es[pos[i]] = ye[i];
       }
@@ -1261,13 +1295,8 @@ __device__ __forceinline__ void apply_velocity(const EnvView& v, const VelCtx& c
   if constexpr (MODE == 5) {
     // full element operator on the gathered vector, rows scaled by D^-1 (0 on constrained rows) on the way out
     tile_apply_global(
-        v, c.packed, c.es, c.yt,
-        [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
-          double2 xe[6];
-#pragma unroll
-          for (int i = 0; i < 6; ++i) xe[i] = gx[E.dof[i]];
-          velocity_op(v, c.a, c.mu, e, ko, g, xe, ye);
-        },
+        v, c.packed, c.es, c.yt, gx,
+        [&](int e, const Geo& g, int ko, const double2(&xe)[6], double2(&ye)[6]) { velocity_op(v, c.a, c.mu, e, ko, g, xe, ye); },
         [&](int row, double y0, double y1) {
           const bool fl = v.bcu_flag[row] != 0;
           const double2 id = v.idiag1[row];
@@ -1375,13 +1404,8 @@ __device__ __forceinline__ void apply_mass(const EnvView& v, const MassCtx& c, c
   if constexpr (MODE == 5) {
     // gx holds S^-1 p (staged by the caller); rows scaled by S^-1 (0 on constrained rows) on the way out
     tile_apply_global(
-        v, c.packed, c.es, c.yt,
-        [&](int, const Geo& g, const ElemIdx& E, int, double2(&ye)[6]) {
-          double2 xe[6];
-#pragma unroll
-          for (int i = 0; i < 6; ++i) xe[i] = gx[E.dof[i]];
-          elem_mass(g, xe, ye);
-        },
+        v, c.packed, c.es, c.yt, gx,
+        [&](int, const Geo& g, int, const double2(&xe)[6], double2(&ye)[6]) { elem_mass(g, xe, ye); },
         [&](int row, double y0, double y1) {
           const double is = v.bcu_flag[row] ? 0.0 : 1.0 / v.sdiagM[row];
           epi(row, y0 * is, y1 * is);
@@ -2309,6 +2333,7 @@ __device__ inline void forces(const EnvView& v, double mu, const double2* __rest
   lift = acc[1];
 }
 
+#if MDQ_IN_PART(0)
 static __global__ __launch_bounds__(WG) void probe_kernel(mdq_ipcs_desc d, int nfields, const double* u, const double* p,
                                                     double* drag, double* lift) {
   __shared__ double red[NWAVE * 2];
@@ -2326,6 +2351,7 @@ static __global__ __launch_bounds__(WG) void probe_kernel(mdq_ipcs_desc d, int n
     __syncthreads();
   }
 }
+#endif
 
 // ================================================================== time stepping
 
@@ -2702,6 +2728,7 @@ __device__ __forceinline__ void team_sum(double (&v)[N], double* red, Team& t) {
 // the counters of the extrapolated initial guesses (tentative velocities stored, corrections stored / ring position / lagged
 // |b| / step parity of the fused correction start), of every operator mode, back to zero - instead of a fill of the whole
 // workspace (100 MB per 128 environments in every S3 env step) - and, optionally, the iteration counters.
+#if MDQ_IN_PART(0)
 static __global__ void reset_history_kernel(mdq_ipcs_desc d, int32_t* iters) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= d.B) return;
@@ -2715,7 +2742,10 @@ static __global__ void reset_history_kernel(mdq_ipcs_desc d, int32_t* iters) {
   reinterpret_cast<double*>(h1 + 5 * (int64_t)d.N2)[1] = 0.0;                        // mode 2: corrections stored
   if (iters) iters[3 * b] = iters[3 * b + 1] = iters[3 * b + 2] = 0;
 }
+#endif
 
+static __global__ void team_reset_kernel(mdq_ipcs_desc d);   // (defined in part 2 only; named by launch_evolve_team)
+#if MDQ_IN_PART(2)
 static __global__ void team_reset_kernel(mdq_ipcs_desc d) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= d.B) return;
@@ -2724,6 +2754,7 @@ static __global__ void team_reset_kernel(mdq_ipcs_desc d) {
   unsigned* ctr = reinterpret_cast<unsigned*>(spare + 8);
   ctr[0] = ctr[1] = 0u;
 }
+#endif
 
 template <bool K1_LDS>
 __global__ __launch_bounds__(WG) void evolve_team_kernel(mdq_ipcs_desc d, int nsteps, double* drag, double* lift,
@@ -4315,6 +4346,7 @@ __global__ __launch_bounds__(NTH) void at_pressure_kernel(mdq_ipcs_desc d, int32
   if (tid == 0 && iters) iters[3 * b + 1] += it_p;
 }
 
+#if MDQ_IN_PART(0)
 static __global__ __launch_bounds__(WG) void at_correction_kernel(mdq_ipcs_desc d, int nsteps, int step, double* drag,
                                                             double* lift, int32_t* iters) {
   extern __shared__ __align__(16) double smem[];
@@ -4615,6 +4647,7 @@ static __global__ __launch_bounds__(WG) void at_correction_kernel(mdq_ipcs_desc 
   }
   if (tid == 0 && iters) iters[3 * b + 2] += it_m;
 }
+#endif
 
 
 // ================================================================== host side
@@ -4842,7 +4875,9 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
   //  takes the Krylov branch anyway; a small mesh riding along in the big layout is solved by CG as well)
   const bool k1_lds = !pg && !d->pd_enabled && red_bytes + P.prs_vec_bytes + P.prs_mat_bytes <= LDS_MAX;
   int mode = d->mode;
-  const size_t tile_bytes = sizeof(double2) * 6 * MF_CH;      // mode 5: the element tile
+  // mode 5: the element tile (+ the stage of a chunk's input rows behind it when the packed local maps are given and fit)
+  const size_t tile_bytes = sizeof(double2) * 6 * MF_CH +
+                            ((d->mf_lpos && d->mf_rlist && d->mf_rcnt && mode5_stage_fits(d->NRL)) ? sizeof(double2) * (size_t)d->NRL : 0);
   if (mode < 0 || mode > 5) {  // auto: fastest variant that fits
     mode = 0;
     if (red_bytes + P.vel1_bytes <= LDS_MAX) mode = 1;

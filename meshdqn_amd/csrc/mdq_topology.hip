@@ -99,7 +99,9 @@ extern "C" int mdq_topo_trace_host(long long* out, int reset) {
   return 0;
 }
 #else
-#define TT_STAMP(k)
+// (K = 4: the lane index is made opaque at every section boundary - the per-lane 64-bit table addresses of the slab
+//  instance, hoisted across sections, were what the register allocator spilled)
+#define TT_STAMP(k) { if (K != 1) asm volatile("" : "+v"(tid)); }
 #endif
 
 template <int K>
@@ -143,7 +145,8 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   int* cntd = reinterpret_cast<int*>(R + RSEG);                               // [TNP + 1] counts / pointers (IPCS phase)
   int* fill = cntd + TNP + 8;                                                 // [TNP]
 
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x;
+  int tid = threadIdx.x;
   const int nv = D.nv[b], nt = D.nt[b];
   const int64_t Bq = b;
   const double* xg = D.coords + Bq * D.NV * 2;

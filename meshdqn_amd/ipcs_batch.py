@@ -147,9 +147,25 @@ class IpcsBatch:
                     rl[c, :rows.size, 0] = word.view(np.int32)
                     rl[c, :rows.size, 1] = tp[c, rows] | (cnt[c, rows] << 16)
                 p_["mf_rlist"] = rl
+                # packed local maps (round 5): position of every dof of a triangle in its chunk's row list | tile position << 16 -
+                # the kernel stages the chunk's input rows in LDS through the row list and gathers from there
+                # (MDQ_NO_LPOS=1: the per-triangle gathers from global memory of round 4, A / B switch)
+                if NRL <= 0xFFFF and os.environ.get("MDQ_NO_LPOS", "") != "1":
+                    cdofs = p_["cell_dofs_soa"]                       # (6, nt)
+                    scat = p_["mf_scat"]
+                    lpos = np.zeros_like(scat)
+                    for c in range(tp.shape[0]):
+                        lo_, hi_ = c * 1024, min((c + 1) * 1024, cdofs.shape[1])
+                        rows = np.flatnonzero(touched[c])
+                        loc = np.searchsorted(rows, cdofs[:, lo_:hi_])
+                        assert (rows[loc] == cdofs[:, lo_:hi_]).all() and scat[:, lo_:hi_].max(initial=0) < 0x8000
+                        lpos[:, lo_:hi_] = loc | (scat[:, lo_:hi_] << 16)
+                    p_["mf_lpos"] = lpos.astype(np.int32)
             self._rl_flags = 1 if flags_ok else 0
             h["mf_rlist"] = stack("mf_rlist", (NCH, NRL, 2), np.int32)
             h["mf_rcnt"] = stack("mf_rcnt", (NCH,), np.int32)
+            if all("mf_lpos" in p_ for p_ in per):
+                h["mf_lpos"] = stack("mf_lpos", (6, NT), np.int32)
             self._NRL = NRL
         h["mf_scat"] = stack("mf_scat", (6, NT), np.int32)
         h["mf_tptr"] = stack("mf_tptr", (NCH, N2 + 1), np.int32)
