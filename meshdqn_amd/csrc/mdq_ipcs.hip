@@ -3376,8 +3376,8 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
           }
           __syncthreads();
           double a1[1] = {0.0};
+          double2 vv[MF_ROWS];                   // (live until s = r - alpha v below; its slab copy is for the next p update)
           {
-            double2 vv[MF_ROWS];
             tile_accumulate(
                 v, tile, tm,
                 [&](int e, const Geo& g, const ElemIdx& E, int ko, double2(&ye)[6]) {
@@ -3406,7 +3406,7 @@ __global__ __launch_bounds__(WG) void evolve_mf_kernel(mdq_ipcs_desc d, int nste
           for (int k = 0; k < MF_ROWS; ++k) {
             const int row = opaque_lane(tid) + k * WG;
             if (row < n2) {
-              const double2 vo = vg[row], pk = stage[row], xo = xs[row];    // (own rows: written by this thread above)
+              const double2 vo = vv[k], pk = stage[row], xo = xs[row];    // (own rows)
               r[k] = make_double2(r[k].x - alpha * vo.x, r[k].y - alpha * vo.y);  // s
               xs[row] = make_double2(xo.x + alpha * pk.x, xo.y + alpha * pk.y);
               stage[row] = r[k];
