@@ -672,8 +672,11 @@ __device__ __forceinline__ void run_level(const Lds& L, const Level& lv, int C, 
     __syncthreads();
   }
   // ---- pooled features x'[r][c] = h[perm r][c] * score[perm r]  -> L.x with stride C
+  // (NaN scores - a diverged network - rank nothing consistently: ranks are then no permutation and some kept[r] still hold
+  //  adjacency pointers of the aggregation phase; the clamp keeps every read inside the level's arrays, the NaNs propagate)
   for (int idx = tid; idx < k * C; idx += WGT) {
-    const int r = idx / C, c = idx - r * C, i = kept[r];
+    const int r = idx / C, c = idx - r * C;
+    const int i = min(max(kept[r], 0), n - 1);
     L.x[idx] = L.h[i * (C + 1) + c] * L.score[i];
   }
   GT_STAMP(5)

@@ -505,7 +505,11 @@ class VecEnv2DAirfoil:
             dt = self.dtopo
             if before_topology is not None:
                 before_topology()
-            dt.run(check=False)                     # status is read back with the other results below
+            try:
+                dt.run(check=False)                 # status is read back with the other results below
+            except Exception:
+                dt.set_handover()                   # (a hand-over armed by `before_topology` must not outlive a failed launch:
+                raise                               #  a later host-driven step() would overwrite the flow leg's input set)
             if after_topology is not None:
                 after_topology()
             t_pts, np1 = dt.t["points"], dt.nv
@@ -544,6 +548,7 @@ class VecEnv2DAirfoil:
             d.sparse, d.NT, d.NAF = int(sparse), NT, self.NAF
             d.af_facets, d.naf, d.cell_dofs = dt.t["af_facets"].data_ptr(), dt.t["naf"].data_ptr(), dt.t["cell_dofs"].data_ptr()
         _lib.check(self.lib.mdq_interpolate_snapshots(C.byref(d), _lib.stream_ptr()), "mdq_interpolate_snapshots")
+        self._interp_last = (d, int(d.sparse), (out_u, out_p, t_pts, npts, np1, npts_extra))     # (rollout_end completes a sparse field)
         # forces: light mesh descriptor over the batch
         md = _lib.IpcsDesc()
         md.B, md.NV, md.NT, md.NE, md.N2, md.NAF = B, NV, NT, self.NE, NP, self.NAF
@@ -1036,6 +1041,15 @@ class VecEnv2DAirfoil:
     def rollout_end(self, ro):
         """The one read-back of a rollout; the host mirrors of the environments follow the device."""
         K = ro["k"]
+        last = getattr(self, "_interp_last", None)
+        if K and last is not None and last[1]:
+            # the steps of a rollout interpolate only what they read (sparse: most edge-midpoint entries of `self.u` are skipped);
+            # `self.u` / `self.p` are public - whoever reads them after the rollout (field dumps, deploy, tests, a host-driven
+            # step()) finds the COMPLETE fields of the last step's meshes: one full pass here, once per rollout (~45 us)
+            d = last[0]
+            d.sparse = 0
+            _lib.check(self.lib.mdq_interpolate_snapshots(C.byref(d), _lib.stream_ptr()), "mdq_interpolate_snapshots")
+            self._interp_last = (d, 0, last[2])
         out = dict(rewards=ro["rew"][:K].cpu().numpy(), dones=ro["done"][:K].cpu().numpy().astype(bool),
                    actions=ro["act"][:K].cpu().numpy(), codes=ro["code"][:K].cpu().numpy(), nv=ro["nv"][:K].cpu().numpy())
         if int(ro["err"].item()) != 0:
