@@ -11,6 +11,8 @@
 // and the level schedule on a slab in global memory.  Straightforward, not fast: ~1.5 ms for 50 sweeps of the refined ys930.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../../include/meshdqn_hip.h"
 #include "mdq_internal.h"
 
@@ -154,6 +156,79 @@ __device__ __forceinline__ d2 exact_vertex(const d2* X, const int* ptr, const ui
     return d2{p.x + f * dx, p.y + f * dy};
   }
   return d2{p.x + dx, p.y + dy};                         // |c - p| <= r_min / 2: to the centroid itself
+}
+
+// The sweeps of the level schedule (shared by the two kernels below): positions X and level starts `lstart` in LDS, the
+// level-ordered work records meta[i] = v | k << 16, inc2[i][MAXK] in the workspace.
+__device__ __forceinline__ void level_sweeps(d2* X, const double* r2k_tab, const int* lstart, const uint32_t* meta, const uint32_t* inc2,
+                                             int lmax, int S, int tid) {
+  {
+    // records of the first pass of the NEXT level are requested before the current level is computed: their latency hides
+    // behind the update + the barrier (they do not depend on the positions)
+    constexpr int G = BWG / 4;
+    const int g4 = tid >> 2, l4 = tid & 3;
+    struct Rec { uint32_t m, w[4]; };
+    auto fetch = [&](int i, int i1, Rec& r) {
+      r.m = 0u;
+      r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0u;
+      if (i < i1) {
+        r.m = meta[i];
+        const uint32_t* e = inc2 + i * MAXK + l4;
+        r.w[0] = e[0];      // entry l
+        r.w[1] = e[4];      // entry l + 4
+        r.w[2] = e[8];      // entry l + 8
+        r.w[3] = e[12];     // entry l + 12
+      }
+    };
+    // two record sets used alternately (a register copy `cur = nxt` would wait for the loads it copies - in front of the
+    // barrier, i.e. the L2 round trip back on every level)
+    Rec ra, rb;
+    int i0 = lstart[1], i1 = lstart[2];                       // this level
+    int j0 = lmax > 1 ? lstart[2] : i0, j1 = lmax > 1 ? lstart[3] : i1;   // the next one (level 1 again behind the last)
+    fetch(i0 + g4, i1, ra);
+    auto level = [&](int l, Rec& mine, Rec& next) {
+      // the level starts two levels ahead are read now and used by the NEXT call's record request: no LDS round trip in
+      // front of the global one
+      const int l2 = (l % lmax + 1) % lmax + 1;              // the level after the next one (cyclic)
+#ifdef MDQ_SB_TRACE
+      long long tq_ = __builtin_amdgcn_s_memtime();
+#endif
+      const int k0 = lstart[l2], k1 = lstart[l2 + 1];
+#ifndef MDQ_SB_NOFETCH
+      fetch(j0 + g4, j1, next);
+#endif
+      SB_STAMP(0)
+      for (int i = i0 + g4; i < i1; i += G) {
+        if (i != i0 + g4) fetch(i, i1, mine);                 // (further passes of a wide level)
+        const int v = mine.m & 0xFFFF, k = mine.m >> 16;
+#ifdef MDQ_SB_NOCOMP
+        const d2 xn = X[v] + X[mine.w[0] & 0xFFFF] * 1e-300;
+        (void)k;
+#else
+        const d2 xn = exact_vertex_rec(X, r2k_tab, v, k, l4, mine.w);
+#endif
+        if (l4 == 0) X[v] = xn;
+      }
+      SB_STAMP(1)
+      i0 = j0; i1 = j1; j0 = k0; j1 = k1;
+      SB_STAMP(2)
+      // LDS-only barrier: the positions of this level are in LDS (lgkmcnt), the records requested for the next level are
+      // still on their way (vmcnt) and stay in flight - __syncthreads() drains the vector-memory counter as well
+#ifndef MDQ_SB_NOBAR
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+      SB_STAMP(3)
+    };
+    const int total = S * lmax;
+    int t = 0, l = 1;
+    for (; t + 1 < total; t += 2) {
+      level(l, ra, rb);
+      l = l < lmax ? l + 1 : 1;
+      level(l, rb, ra);
+      l = l < lmax ? l + 1 : 1;
+    }
+    if (t < total) level(l, ra, rb);
+  }
 }
 
 __global__ __launch_bounds__(BWG) void smooth_big_kernel(int NV, int NT, double* coords, const int32_t* cells, const int32_t* nv_,
@@ -332,80 +407,11 @@ __global__ __launch_bounds__(BWG) void smooth_big_kernel(int NV, int NT, double*
   __syncthreads();
   // ---- sweeps: level by level, 8 lanes per vertex
   const int grp = tid >> 3, l8 = tid & 7;
-#ifndef MDQ_SB_SWG
-#define MDQ_SB_SWG 1024
-#endif
-  constexpr int SWG = MDQ_SB_SWG;   // threads of the sweeps (the set-up phases want all BWG: loops of memory round trips)
-  if (lmax > 0 && !misc[1] && tid >= SWG) return;   // the other waves retire: a barrier counts the live waves only
-  const int nthr = (lmax > 0 && !misc[1]) ? SWG : BWG;
+  const int nthr = BWG;
   if (lmax == 0) {
     // (no interior vertex: nothing moves)
   } else if (!misc[1]) {
-    // records of the first pass of the NEXT level are requested before the current level is computed: their latency hides
-    // behind the update + the barrier (they do not depend on the positions)
-    constexpr int G = SWG / 4;
-    const int g4 = tid >> 2, l4 = tid & 3;
-    struct Rec { uint32_t m, w[4]; };
-    auto fetch = [&](int i, int i1, Rec& r) {
-      r.m = 0u;
-      r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0u;
-      if (i < i1) {
-        r.m = meta[i];
-        const uint32_t* e = inc2 + i * MAXK + l4;
-        r.w[0] = e[0];      // entry l
-        r.w[1] = e[4];      // entry l + 4
-        r.w[2] = e[8];      // entry l + 8
-        r.w[3] = e[12];     // entry l + 12
-      }
-    };
-    // two record sets used alternately (a register copy `cur = nxt` would wait for the loads it copies - in front of the
-    // barrier, i.e. the L2 round trip back on every level)
-    Rec ra, rb;
-    int i0 = lstart[1], i1 = lstart[2];                       // this level
-    int j0 = lmax > 1 ? lstart[2] : i0, j1 = lmax > 1 ? lstart[3] : i1;   // the next one (level 1 again behind the last)
-    fetch(i0 + g4, i1, ra);
-    auto level = [&](int l, Rec& mine, Rec& next) {
-      // the level starts two levels ahead are read now and used by the NEXT call's record request: no LDS round trip in
-      // front of the global one
-      const int l2 = (l % lmax + 1) % lmax + 1;              // the level after the next one (cyclic)
-#ifdef MDQ_SB_TRACE
-      long long tq_ = __builtin_amdgcn_s_memtime();
-#endif
-      const int k0 = lstart[l2], k1 = lstart[l2 + 1];
-#ifndef MDQ_SB_NOFETCH
-      fetch(j0 + g4, j1, next);
-#endif
-      SB_STAMP(0)
-      for (int i = i0 + g4; i < i1; i += G) {
-        if (i != i0 + g4) fetch(i, i1, mine);                 // (further passes of a wide level)
-        const int v = mine.m & 0xFFFF, k = mine.m >> 16;
-#ifdef MDQ_SB_NOCOMP
-        const d2 xn = X[v] + X[mine.w[0] & 0xFFFF] * 1e-300;
-        (void)k;
-#else
-        const d2 xn = exact_vertex_rec(X, r2k_tab, v, k, l4, mine.w);
-#endif
-        if (l4 == 0) X[v] = xn;
-      }
-      SB_STAMP(1)
-      i0 = j0; i1 = j1; j0 = k0; j1 = k1;
-      SB_STAMP(2)
-      // LDS-only barrier: the positions of this level are in LDS (lgkmcnt), the records requested for the next level are
-      // still on their way (vmcnt) and stay in flight - __syncthreads() drains the vector-memory counter as well
-#ifndef MDQ_SB_NOBAR
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-      SB_STAMP(3)
-    };
-    const int total = S * lmax;
-    int t = 0, l = 1;
-    for (; t + 1 < total; t += 2) {
-      level(l, ra, rb);
-      l = l < lmax ? l + 1 : 1;
-      level(l, rb, ra);
-      l = l < lmax ? l + 1 : 1;
-    }
-    if (t < total) level(l, ra, rb);
+    level_sweeps(X, r2k_tab, lstart, meta, inc2, lmax, S, tid);
   } else
   for (int s = 0; s < S; ++s) {
     for (int l = 1; l <= lmax; ++l) {
@@ -424,6 +430,237 @@ __global__ __launch_bounds__(BWG) void smooth_big_kernel(int NV, int NT, double*
     xg[v] = double2{p.x, p.y};
   }
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The same level schedule with the SET-UP OUT OF LDS (round 5), for meshes whose tables fit the LDS next to the positions
+// (23 NV + 12 NT bytes <= ~151 KB: the red-refined ys930 of BASELINE configs[4] needs 148 KB): vertex -> cells CSR, per-vertex
+// cell order, interior test, levels by relaxation and the counting sort by level all run on LDS arrays (in the kernel above
+// they are loops of L2 round trips: 0.62 ms of its 2.2 ms; here 0.37 ms, of which the 41 relaxation rounds are 0.2 ms), the
+// level-ordered work records go to the workspace and the sweeps are the shared level_sweeps().  A mesh with more than MAXK
+// cells at a vertex, more than 1 000 levels or 255+ sweeps is handed back to the kernel above (`redo`).
+//
+// Measured and NOT kept (tools/sweep_dag.py: the dependency DAG of ALL 50 sweeps is 968 levels deep on this mesh against
+// 50 x 40 = 2 000 - sweep s + 1 may start long before sweep s has ended - so two forms without a level schedule were built on
+// this set-up; each group of four lanes owns the tasks (sweep, position in level order) g, g + G, ... in that order, a byte per
+// vertex in LDS counts its finished sweeps, a task runs when its neighbours' counters allow it; same bits as the level form):
+//   free-running waves, every wave polling (all neighbour bytes per round / one byte per round):   3.80 / 4.26 ms per launch
+//   rounds with a workgroup barrier, every group running at most one ready task per round:         5.37 ms
+// against 1.96 ms for the level schedule.  Free-running, the sixteen groups of a wave become ready a few hundred cycles apart
+// and each one costs the wave a whole pass through the update code; in rounds, a group's list is in (sweep, level) order and
+// its level-1 tasks of sweep s + 1 sit behind its last task of sweep s - the overlap of sweeps the DAG allows needs tasks
+// picked out of order (a work queue), which was not built.
+constexpr int FWG = 1024;
+__host__ __device__ inline size_t flow_lds_bytes(int NV, int NT) {
+  const size_t nvp = (size_t)((NV + 3) & ~3);
+  return 16 * nvp + 12 * (size_t)NT + 2 * (nvp + 4) + 4 * nvp + nvp + 64;      // X | inc | ptr | trec | done
+}
+
+__global__ __launch_bounds__(FWG) void smooth_flow_kernel(int NV, int NT, double* coords, const int32_t* cells, const int32_t* nv_,
+                                                          const int32_t* nt_, const int32_t* iters_, const int32_t* rem,
+                                                          const int32_t* rstat, int iters_env, unsigned char* slab, int32_t* redo) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_[];
+  const int nvp = (NV + 3) & ~3;
+  d2* X = reinterpret_cast<d2*>(dyn_);                                       // [nvp]   (set-up: cnt int[NV] | cel u16[3 NT])
+  uint32_t* inc = reinterpret_cast<uint32_t*>(dyn_ + 16 * (size_t)nvp);      // [3 NT]  a | c << 16, ascending cell per vertex
+  uint16_t* ptr = reinterpret_cast<uint16_t*>(inc + 3 * (size_t)NT);          // [nvp + 4]
+  uint32_t* trec = reinterpret_cast<uint32_t*>(ptr + nvp + 4);               // [nvp]   by interior rank: v | k << 12 | q0 << 17
+  unsigned char* done = reinterpret_cast<unsigned char*>(trec + nvp);        // [nvp]   finished sweeps (255: fixed vertex)
+  int* cnt = reinterpret_cast<int*>(dyn_);
+  uint16_t* cel = reinterpret_cast<uint16_t*>(dyn_ + 4 * (size_t)nvp);
+  __shared__ int part[FWG];
+  __shared__ int lvl[MAXLEV + 2];                            // level counts / starts / cursors
+  __shared__ double r2k_tab[MAXK + 1];
+  __shared__ int misc[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int S = iters_ ? iters_[b] : ((rem[b] >= 0 && rstat[b] == 0) ? iters_env : 0);
+  // redo[b]: sweeps handed back to the level kernel (launched behind this one; it returns at once for 0) - a mesh with more
+  // than MAXK cells at a vertex or a sweep count that does not fit the byte counters
+  if (tid == 0) redo[b] = (S >= 255) ? S : 0;
+  if (S <= 0 || S >= 255) return;
+  const int nv = nv_[b], nt = nt_[b];
+  double2* xg = reinterpret_cast<double2*>(coords) + (int64_t)b * NV;
+  const int32_t* tri = cells + (int64_t)b * NT * 3;
+  // block-wide exclusive scan of a[0 .. nvp) (ints in LDS), four consecutive entries per thread; returns the total
+  auto scan_excl = [&](int* a) {
+    const int per = (nvp + FWG - 1) / FWG;        // <= 4 for NV <= 4096
+    int loc[4], run = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid * per + i;
+      loc[i] = run;
+      run += (i < per && idx < nvp) ? a[idx] : 0;
+    }
+    part[tid] = run;
+    __syncthreads();
+    for (int off = 1; off < FWG; off <<= 1) {
+      const int add = tid >= off ? part[tid - off] : 0;
+      __syncthreads();
+      part[tid] += add;
+      __syncthreads();
+    }
+    const int base = part[tid] - run, total = part[FWG - 1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid * per + i;
+      if (i < per && idx < nvp) a[idx] = base + loc[i];
+    }
+    __syncthreads();
+    return total;
+  };
+  // ---- vertex -> cells
+  for (int v = tid; v < nvp; v += FWG) cnt[v] = 0;
+  if (tid == 0) misc[0] = 0;
+  if (tid >= 1 && tid <= MAXK) {
+#pragma clang fp contract(off)
+    r2k_tab[tid] = 1.0 / (2.0 * tid);
+  }
+  __syncthreads();
+  for (int t = tid; t < nt; t += FWG)
+    for (int k = 0; k < 3; ++k) atomicAdd(&cnt[tri[3 * t + k]], 1);
+  __syncthreads();
+  scan_excl(cnt);
+  for (int v = tid; v < nvp; v += FWG) ptr[v] = (uint16_t)cnt[v];
+  if (tid == 0) ptr[nvp] = (uint16_t)(3 * nt);
+  __syncthreads();
+  // (the cursors: cnt[v] itself runs from ptr[v] upwards)
+  for (int t = tid; t < nt; t += FWG) {
+    const int vs[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
+    for (int k = 0; k < 3; ++k) {
+      const int v = vs[k], a = vs[(k + 1) % 3], c = vs[(k + 2) % 3];
+      const int q = atomicAdd(&cnt[v], 1);
+      inc[q] = (uint32_t)a | ((uint32_t)c << 16);
+      cel[q] = (uint16_t)t;
+    }
+  }
+  __syncthreads();
+  // ---- per vertex: entries in ascending cell order; interior = every neighbour seen exactly twice
+  for (int v = tid; v < nvp; v += FWG) {
+    unsigned char dn = 255;
+    if (v < nv) {
+      const int q0 = ptr[v], k = (v + 1 < nvp ? (int)ptr[v + 1] : 3 * nt) - q0;
+      for (int i = 1; i < k; ++i) {
+        const uint16_t ci = cel[q0 + i];
+        const uint32_t wi = inc[q0 + i];
+        int j = i - 1;
+        while (j >= 0 && cel[q0 + j] > ci) {
+          cel[q0 + j + 1] = cel[q0 + j];
+          inc[q0 + j + 1] = inc[q0 + j];
+          --j;
+        }
+        cel[q0 + j + 1] = ci;
+        inc[q0 + j + 1] = wi;
+      }
+      bool interior = k > 0;
+      for (int e = 0; e < 2 * k && interior; ++e) {
+        const uint32_t we = inc[q0 + (e >> 1)];
+        const uint32_t id = (e & 1) ? we >> 16 : we & 0xFFFF;
+        int seen = 0;
+        for (int f = 0; f < 2 * k; ++f) {
+          const uint32_t wf = inc[q0 + (f >> 1)];
+          seen += ((f & 1) ? wf >> 16 : wf & 0xFFFF) == id;
+        }
+        interior = seen == 2;
+      }
+      if (interior) dn = 0;
+      if (interior && k > MAXK) misc[0] = 1;             // (more than 16 cells at a vertex: the level kernel's general loop)
+    }
+    done[v] = dn;
+  }
+  __syncthreads();
+  // ---- levels of one sweep's dependency DAG by relaxation (level(v) = 1 + max over the lower-numbered interior neighbours;
+  // monotone, converges in as many rounds as there are levels), then the task records in LEVEL order: (sweep, level, position)
+  // is a topological order of the DAG of all sweeps, and dealing the positions out round-robin puts the vertices of a level
+  // on different groups (in index order a group's next vertex was rarely the one the wavefront had reached: 4.0 ms)
+  int* lev = cnt;                                            // (cel is dead: the scratch may be rewritten)
+  for (int v = tid; v < nvp; v += FWG) lev[v] = 0;
+  if (tid == 0) misc[1] = 1;
+  __syncthreads();
+  for (int round = 0; round < nvp && misc[1]; ++round) {
+    __syncthreads();
+    if (tid == 0) misc[1] = 0;
+    __syncthreads();
+    bool changed = false;
+    for (int v = tid; v < nv; v += FWG) {
+      if (done[v] != 0) continue;
+      const int q0 = ptr[v], k = (v + 1 < nvp ? (int)ptr[v + 1] : 3 * nt) - q0;
+      int lv = 1;
+      for (int q = 0; q < k; ++q) {
+        const uint32_t w_ = inc[q0 + q];
+        const int a_ = w_ & 0xFFFF, c_ = w_ >> 16;
+        if (a_ < v && done[a_] == 0) lv = max(lv, lev[a_] + 1);
+        if (c_ < v && done[c_] == 0) lv = max(lv, lev[c_] + 1);
+      }
+      if (lv != lev[v]) changed = true;
+      lev[v] = lv;                                           // (benign race: levels only grow towards the fixed point)
+    }
+    if (changed) misc[1] = 1;
+    __syncthreads();
+  }
+  for (int l_ = tid; l_ < MAXLEV + 2; l_ += FWG) lvl[l_] = 0;
+  __syncthreads();
+  for (int v = tid; v < nv; v += FWG)
+    if (done[v] == 0) {
+      if (lev[v] > 1000) misc[0] = 1;                      // (level starts live in `part`: FWG ints)
+      else atomicAdd(&lvl[lev[v]], 1);
+    }
+  __syncthreads();
+  if (tid == 0) {                                            // exclusive scan over the (few dozen) levels
+    int run = 0;
+    for (int l_ = 0; l_ < MAXLEV + 2; ++l_) {
+      const int c_ = lvl[l_];
+      lvl[l_] = run;
+      run += c_;
+    }
+    misc[2] = run;
+  }
+  __syncthreads();
+  const int n_int = misc[2];
+  if (misc[0] == 0)
+    for (int v = tid; v < nv; v += FWG)
+      if (done[v] == 0) {
+        const int q0 = ptr[v], k = (v + 1 < nvp ? (int)ptr[v + 1] : 3 * nt) - q0;
+        trec[atomicAdd(&lvl[lev[v]], 1)] = (uint32_t)v | ((uint32_t)k << 12) | ((uint32_t)q0 << 17);
+      }
+  __syncthreads();
+  if (misc[0] != 0) {                   // (handed back: the coordinates are untouched)
+    if (tid == 0) redo[b] = S;
+    return;
+  }
+  // ---- the level-ordered work records of the sweeps, to the workspace (the sweeps read them one level ahead); level starts
+  uint32_t* meta = reinterpret_cast<uint32_t*>(slab + (size_t)b * ((SLAB_BYTES + 255) & ~(size_t)255));
+  uint32_t* inc2 = meta + BNV;
+  for (int i = tid; i < n_int; i += FWG) {
+    const uint32_t tr = trec[i];
+    const int v = tr & 0xFFF, k = (tr >> 12) & 31, q0 = tr >> 17;
+    meta[i] = (uint32_t)v | ((uint32_t)k << 16);
+    for (int q = 0; q < MAXK; ++q) inc2[i * MAXK + q] = q < k ? inc[q0 + q] : 0u;
+  }
+  // (after the fill lvl[l] is the END of level l = the start of level l + 1; level 0 is empty)
+  int lmax = 0;
+  for (int v = tid; v < nv; v += FWG) lmax = max(lmax, done[v] == 0 ? lev[v] : 0);
+  part[tid] = lmax;
+  __syncthreads();
+  for (int off = FWG / 2; off > 0; off >>= 1) {
+    if (tid < off) part[tid] = max(part[tid], part[tid + off]);
+    __syncthreads();
+  }
+  lmax = part[0];
+  __syncthreads();
+  for (int l_ = tid; l_ <= lmax + 1; l_ += FWG) part[l_] = l_ >= 1 ? lvl[l_ - 1] : 0;      // lstart (part: MAXLEV + 2 <= FWG ints)
+  __syncthreads();
+  // ---- positions (over the set-up scratch: the barriers above end its last readers)
+  for (int v = tid; v < nv; v += FWG) {
+    const double2 xv = xg[v];
+    X[v] = d2{xv.x, xv.y};
+  }
+  __syncthreads();
+  if (lmax > 0) level_sweeps(X, r2k_tab, part, meta, inc2, lmax, S, tid);
+  __syncthreads();
+  for (int v = tid; v < nv; v += FWG) {
+    const d2 p = X[v];
+    xg[v] = double2{p.x, p.y};
+  }
+}
 }  // namespace mdq_smooth_big
 
 #ifdef MDQ_SB_TRACE
@@ -438,7 +675,7 @@ extern "C" MDQ_API int mdq_sb_trace_host(long long* out, int reset) {
 static int64_t smooth_big_workspace_bytes(int32_t B, int32_t NV, int32_t NT) {
   using namespace mdq_smooth_big;
   if (NV > BNV || NT > BNT) return -1;
-  return (int64_t)((SLAB_BYTES + 255) & ~(size_t)255) * B;
+  return (int64_t)((SLAB_BYTES + 255) & ~(size_t)255) * B + (((int64_t)B * 4 + 255) & ~(int64_t)255);   // tables + the hand-back counts
 }
 
 // mdq_smooth / mdq_smooth_fast / mdq_smooth_fast_env for NV > 1024 (called by those entry points)
@@ -454,6 +691,22 @@ static int smooth_big_launch(int32_t B, int32_t NV, int32_t NT, double* coords, 
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&smooth_big_kernel),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(d2) * BNV + sizeof(int) * BNV));
   if (attr != hipSuccess) return mdq_set_error("hipFuncSetAttribute(smooth_big_kernel) failed");
+  // meshes whose tables fit the LDS beside the positions: the kernel with the LDS set-up, then this launch for what it hands back
+  // (normally nothing: every workgroup returns at once).  MDQ_NO_SMOOTH_FLOW=1: the level kernel alone (A / B switch)
+  const size_t flow_lds = flow_lds_bytes(NV, NT);
+  static const bool no_flow = std::getenv("MDQ_NO_SMOOTH_FLOW") != nullptr;
+  if (!no_flow && flow_lds + 8832 <= 160 * 1024 && NT <= 2 * ((NV + 3) & ~3)) {
+    static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&smooth_flow_kernel),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8832);
+    if (attr2 != hipSuccess) return mdq_set_error("hipFuncSetAttribute(smooth_flow_kernel) failed");
+    int32_t* redo = reinterpret_cast<int32_t*>(slab + ((SLAB_BYTES + 255) & ~(size_t)255) * (size_t)B);
+    hipLaunchKernelGGL(smooth_flow_kernel, dim3(B), dim3(FWG), flow_lds, (hipStream_t)stream, NV, NT, coords, cells, nv, nt,
+                       iterations, rem, rstat, iters_env, slab, redo);
+    hipLaunchKernelGGL(smooth_big_kernel, dim3(B), dim3(BWG), lds, (hipStream_t)stream, NV, NT, coords, cells, nv, nt, redo,
+                       nullptr, nullptr, 0, slab, nullptr);
+    if (hipGetLastError() != hipSuccess) return mdq_set_error("smooth_flow_kernel launch failed");
+    return 0;
+  }
   hipLaunchKernelGGL(smooth_big_kernel, dim3(B), dim3(BWG), lds, (hipStream_t)stream, NV, NT, coords, cells, nv, nt, iterations,
                      rem, rstat, iters_env, slab, nullptr);
   if (hipGetLastError() != hipSuccess) return mdq_set_error("smooth_big_kernel launch failed");
