@@ -572,30 +572,44 @@ __global__ __launch_bounds__(FWG) void smooth_flow_kernel(int NV, int NT, double
   // is a topological order of the DAG of all sweeps, and dealing the positions out round-robin puts the vertices of a level
   // on different groups (in index order a group's next vertex was rarely the one the wavefront had reached: 4.0 ms)
   int* lev = cnt;                                            // (cel is dead: the scratch may be rewritten)
-  for (int v = tid; v < nvp; v += FWG) lev[v] = 0;
-  if (tid == 0) misc[1] = 1;
-  __syncthreads();
-  for (int round = 0; round < nvp && misc[1]; ++round) {
-    __syncthreads();
-    if (tid == 0) misc[1] = 0;
-    __syncthreads();
-    bool changed = false;
-    for (int v = tid; v < nv; v += FWG) {
-      if (done[v] != 0) continue;
+  // (Kahn's algorithm instead of relaxation - every vertex is expanded ONCE, when its level is known: the 41 relaxation rounds,
+  //  each re-reading every vertex's entries through three dependent LDS reads, were 0.2 ms of the set-up)
+  int* indeg = reinterpret_cast<int*>(cel);                  // [nvp] lower interior neighbours still without a level (x 2: every
+  for (int v = tid; v < nvp; v += FWG) {                     //  neighbour appears in two cells)
+    int n_low = 0;
+    if (v < nv && done[v] == 0) {
       const int q0 = ptr[v], k = (v + 1 < nvp ? (int)ptr[v + 1] : 3 * nt) - q0;
-      int lv = 1;
       for (int q = 0; q < k; ++q) {
         const uint32_t w_ = inc[q0 + q];
         const int a_ = w_ & 0xFFFF, c_ = w_ >> 16;
-        if (a_ < v && done[a_] == 0) lv = max(lv, lev[a_] + 1);
-        if (c_ < v && done[c_] == 0) lv = max(lv, lev[c_] + 1);
+        n_low += (a_ < v && done[a_] == 0) + (c_ < v && done[c_] == 0);
       }
-      if (lv != lev[v]) changed = true;
-      lev[v] = lv;                                           // (benign race: levels only grow towards the fixed point)
     }
-    if (changed) misc[1] = 1;
+    lev[v] = 0;
+    indeg[v] = n_low;
+  }
+  __syncthreads();
+  for (int level = 1; level <= nvp; ++level) {
+    int found = 0;
+    for (int v = tid; v < nv; v += FWG)
+      if (done[v] == 0 && lev[v] == 0 && indeg[v] == 0) {
+        lev[v] = level;
+        found = 1;
+      }
+    if (!__syncthreads_or(found)) break;
+    for (int v = tid; v < nv; v += FWG)
+      if (lev[v] == level && done[v] == 0) {
+        const int q0 = ptr[v], k = (v + 1 < nvp ? (int)ptr[v + 1] : 3 * nt) - q0;
+        for (int q = 0; q < k; ++q) {
+          const uint32_t w_ = inc[q0 + q];
+          const int a_ = w_ & 0xFFFF, c_ = w_ >> 16;
+          if (a_ > v && done[a_] == 0) atomicSub(&indeg[a_], 1);
+          if (c_ > v && done[c_] == 0) atomicSub(&indeg[c_], 1);
+        }
+      }
     __syncthreads();
   }
+  __syncthreads();
   for (int l_ = tid; l_ < MAXLEV + 2; l_ += FWG) lvl[l_] = 0;
   __syncthreads();
   for (int v = tid; v < nv; v += FWG)

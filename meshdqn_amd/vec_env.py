@@ -1052,16 +1052,15 @@ class VecEnv2DAirfoil:
             self._interp_last = (d, 0, last[2])
         # ONE read-back: the per-step outputs + every small host mirror as one packed buffer (a dozen device-to-host copies, each
         # a synchronisation of its own, were 0.4-0.5 ms per rollout: round 4's `rollout_end` was 0.7-0.95 ms - 5 % of the
-        # driver's 20-step rollouts), the meshes (4 MB per 128 environments) into their page-locked mirrors on the mirror stream
+        # driver's 20-step rollouts), the meshes (4 MB per 128 environments) into their page-locked mirrors in front of it
         dev, dt, h = self.device, self.dtopo, self.h
         main = torch.cuda.current_stream(dev)
         pin = self.topo.pinned
-        self._mirror_ev.record(main)
-        with torch.cuda.stream(self._mirror_stream):
-            self._mirror_stream.wait_event(self._mirror_ev)
-            pin["coords"].copy_(dt.coords, non_blocking=True)
-            pin["cells"].copy_(dt.cells, non_blocking=True)
-            self._mirror_done.record(self._mirror_stream)
+        # (on the MAIN stream: the side stream of the host-driven step() - a plain pool stream - cost the S3 rollouts of a process
+        #  40 % once it had been used here, 0.73 -> 1.04-1.10 ms per step in bench.py: the stream -> hardware-queue lottery of
+        #  DESIGN 5 "Streams"; the copies run behind the last step's kernels either way)
+        pin["coords"].copy_(dt.coords, non_blocking=True)
+        pin["cells"].copy_(dt.cells, non_blocking=True)
         parts = [("rewards", ro["rew"][:K]), ("dones", ro["done"][:K]), ("actions", ro["act"][:K]), ("codes", ro["code"][:K]),
                  ("nv_steps", ro["nv"][:K]), ("err", ro["err"]), ("nv", dt.nv), ("nt", dt.nt), ("offset", dt.offset),
                  ("steps", ro["d_steps"][ro["si"]]), ("drag", self._dev_drag), ("lift", self._dev_lift)]
@@ -1102,7 +1101,6 @@ class VecEnv2DAirfoil:
             nb = (C.c_int64 * 2)(self.u[0].numel() * 8, self.p[0].numel() * 8)
             _lib.check(self.lib.mdq_restore_rows(2, dst, src, nb, int(ti.numel()), ti.data_ptr(), _lib.stream_ptr()),
                        "mdq_restore_rows")
-        self._mirror_done.synchronize()                         # the mesh mirrors (coords / cells) are complete
         self._deferred_mirror = None
         return out
 
