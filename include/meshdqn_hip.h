@@ -80,7 +80,10 @@ typedef struct mdq_ipcs_desc {
                            4 assembled SELL with TWO workgroups per environment (any mesh size, rows / cells / slices
                            dealt out over the team, agent-scope team barriers; auto picks it over 0 when 4 B <= CUs),
                            5 matrix-free element tiles with the vectors in GLOBAL memory (any mesh size: what auto takes for
-                           meshes beyond the LDS-resident vectors of 2 / 3 when mf_scat / mf_tptr are given; bitwise reproducible) */
+                           meshes beyond the LDS-resident vectors of 2 / 3 when mf_scat / mf_tptr are given; bitwise reproducible),
+                           7 the element tiles of 5 with TWO workgroups per environment (chunks dealt out alternately, one
+                           accumulation vector per workgroup; bitwise reproducible run to run, a row's sum associated
+                           differently from 5; what auto takes instead of 5 while 2 B <= CUs).  6 is not a mode. */
   /* per-environment counts, device int32[B] */
   const int32_t* nv;
   const int32_t* nt;

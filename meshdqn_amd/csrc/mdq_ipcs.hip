@@ -57,8 +57,8 @@ constexpr int MF_CH = 1024;  // triangles per LDS tile: 2 per thread, interleave
 __host__ __device__ inline int64_t work_per_env(int NV, int NT, int NE) {
   const int64_t N2 = (int64_t)NV + NE;
   // escr 12*NT | 6 velocity vectors (double2[N2]) | p_new[NV] | 24 spare | assembled modes: 5 history vectors + counter |
-  // mode 5: the accumulation vector of the tile application (double2[N2])
-  const int64_t n = 12 * (int64_t)NT + 12 * N2 + NV + 26 + 10 * N2 + 2 + 2 * N2 + 2;
+  // mode 5: the accumulation vector of the tile application (double2[N2]) | mode 7: the second workgroup's accumulation vector
+  const int64_t n = 12 * (int64_t)NT + 12 * N2 + NV + 26 + 10 * N2 + 2 + 2 * N2 + 2 + 2 * N2 + 2;
   return (n + 31) & ~(int64_t)31;  // keep every environment's slab 256-byte aligned
 }
 // offset (in doubles, even) of the tentative-velocity history of the assembled modes 0-2 inside an environment's slab
@@ -67,7 +67,8 @@ __host__ __device__ inline int64_t work_hist_offset(int NV, int NT, int NE) {
   return (12 * (int64_t)NT + 12 * N2 + NV + 24 + 1) & ~(int64_t)1;
 }
 
-// offset (in doubles, even) of mode 5's accumulation vector (behind the history vectors and their counter)
+// offset (in doubles, even) of mode 5's accumulation vector (behind the history vectors and their counter); mode 7's second
+// one follows it at + 2 N2 + 2
 __host__ __device__ inline int64_t work_ytmp_offset(int NV, int NT, int NE) {
   const int64_t N2 = (int64_t)NV + NE;
   return (work_hist_offset(NV, NT, NE) + 10 * N2 + 2 + 1) & ~(int64_t)1;
@@ -1011,58 +1012,28 @@ extern "C" MDQ_API int mdq_t5_trace_host(long long* out, int reset) {
 #define T5_STAMP(k)
 #endif
 
-// `gx`: the operator's input vector (global); op(e, geometry, outflow edge, xe[6], ye[6]) applies one triangle's operator to
-// its six gathered input values.  With mf_lpos (round 5) the rows a chunk touches are STAGED in LDS behind the tile first -
-// one pass over the chunk's ascending row list, coalesced where the rows are consecutive - and the triangles gather from
-// there through 16-bit local indices: six random 16-byte reads per triangle from global memory pulled a cache line each
-// (the PMC traffic of the kernel was 1.2-1.95x its algorithmic bytes), and the triangle's dof ids + tile positions are
-// one packed word per dof (24 B per triangle instead of 48).
-template <class ElemOp, class Epi>
-__device__ __forceinline__ void tile_apply_global(const EnvView& v, bool packed, double2* es, double2* ytmp, const double2* gx,
-                                                  ElemOp op, Epi epi) {
+// The chunk loop of a tile application: chunks c0, c0 + cs, ... of the environment's triangles, their row sums accumulated
+// into `ytmp` (c0 = 0, cs = 1: the whole operator; mode 7 deals the chunks out to the workgroups of a team, one accumulation
+// vector each).  `flags_ok`: the touched-row lists mark the first chunk of every row IN THE ORDER 0, 1, 2, ... - usable only
+// when this call walks all chunks in that order; otherwise the vector is zero-filled first.
+template <class ElemOp>
+__device__ __forceinline__ void tile_chunks_global(const EnvView& v, bool packed, double2* es, double2* ytmp, const double2* gx,
+                                                   ElemOp op, int c0, int cs, bool flags_ok) {
   const int tid = threadIdx.x, n = v.n2;
   const int nch = (v.nt + MF_CH - 1) / MF_CH;
 #ifdef MDQ_T5_TRACE
   long long t5q_ = __builtin_amdgcn_s_memtime();
   if (tid == 0 && blockIdx.x == 0) mdq_t5_trace_buf[7] += 1;
 #endif
-  if (!v.mf_tptr) {
-    // no tile maps (index data built ON THE DEVICE by mdq_env_topology's large-mesh instance, which emits the dof <-
-    // element-slot lists but no tile positions): the element results go to the slab's element scratch (6 double2 per
-    // triangle, free during the solves) and every row sums its slots in ascending order - the gather the right-hand sides use
-    double2* es2 = reinterpret_cast<double2*>(v.work);
-    for (int e = tid; e < v.nt; e += WG) {
-      double2 xe[6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) xe[i] = gx[v.cell_dofs[i * v.NT + e]];
-      const Geo g = load_geo(v, e);
-      double2 ye[6];
-      op(e, g, (int)v.cell_outflow[e], xe, ye);
-#pragma unroll
-      for (int i = 0; i < 6; ++i) es2[e * 6 + i] = ye[i];
-    }
-    __syncthreads();
-    for (int row = tid; row < n; row += WG) {
-      double2 a = make_double2(0.0, 0.0);
-      for (int s = v.g2_ptr[row]; s < v.g2_ptr[row + 1]; ++s) {
-        const double2 c = es2[v.g2_src[s]];
-        a.x += c.x;
-        a.y += c.y;
-      }
-      epi(row, a.x, a.y);
-    }
-    __syncthreads();
-    return;
-  }
   // rl_flags: the touched-row lists mark the first / last chunk of every row - no zero fill and no read at the first touch
   // (9.29 -> 9.07 ms per step of 128 refined meshes).  Running the caller's epilogue at the LAST touch and dropping the pass
-  // over the rows at the end (-DMDQ_T5_LAST_EPI: two more vector streams saved) was measured SLOWER, 10.52 ms: the epilogue's
-  // own loads then sit one row at a time inside the row loop instead of four rows in flight
-  const bool rlf = v.mf_rlist && v.rl_flags != 0;
+  // over the rows at the end (two more vector streams saved) was measured SLOWER, 10.52 ms: the epilogue's own loads then
+  // sit one row at a time inside the row loop instead of four rows in flight
+  const bool rlf = flags_ok && v.mf_rlist && v.rl_flags != 0;
   if (!rlf)
     for (int row = tid; row < n; row += WG) ytmp[row] = make_double2(0.0, 0.0);   // (own rows: visible to the row phases behind the barriers)
   double2* xst = es + 6 * MF_CH;                        // (staged input rows of the chunk: behind the tile, mf_lpos only)
-  for (int chunk = 0; chunk < nch; ++chunk) {
+  for (int chunk = c0; chunk < nch; chunk += cs) {
     if (v.mf_lpos) {
       const int2* rl = reinterpret_cast<const int2*>(v.mf_rlist) + (size_t)chunk * v.NRL;
       const int nr = v.mf_rcnt[chunk];
@@ -1131,12 +1102,7 @@ __device__ __forceinline__ void tile_apply_global(const EnvView& v, bool packed,
               a[k].x += c.x;
               a[k].y += c.y;
             }
-#ifdef MDQ_T5_LAST_EPI
-            if (rlf && (en[k].x & 0x40000000)) epi(row, a[k].x, a[k].y);
-            else ytmp[row] = a[k];
-#else
             ytmp[row] = a[k];
-#endif
           }
         }
       }
@@ -1173,14 +1139,54 @@ __device__ __forceinline__ void tile_apply_global(const EnvView& v, bool packed,
     __syncthreads();
     T5_STAMP(3)
   }
+}
+
+// `gx`: the operator's input vector (global); op(e, geometry, outflow edge, xe[6], ye[6]) applies one triangle's operator to
+// its six gathered input values.  With mf_lpos (round 5) the rows a chunk touches are STAGED in LDS behind the tile first -
+// one pass over the chunk's ascending row list, coalesced where the rows are consecutive - and the triangles gather from
+// there through 16-bit local indices (the triangle's dof ids + tile positions are one packed word per dof: 24 B per
+// triangle instead of 48).
+template <class ElemOp, class Epi>
+__device__ __forceinline__ void tile_apply_global(const EnvView& v, bool packed, double2* es, double2* ytmp, const double2* gx,
+                                                  ElemOp op, Epi epi) {
+  const int tid = threadIdx.x, n = v.n2;
+  if (!v.mf_tptr) {
+    // no tile maps (index data built ON THE DEVICE by mdq_env_topology's large-mesh instance, which emits the dof <-
+    // element-slot lists but no tile positions): the element results go to the slab's element scratch (6 double2 per
+    // triangle, free during the solves) and every row sums its slots in ascending order - the gather the right-hand sides use
+    double2* es2 = reinterpret_cast<double2*>(v.work);
+    for (int e = tid; e < v.nt; e += WG) {
+      double2 xe[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) xe[i] = gx[v.cell_dofs[i * v.NT + e]];
+      const Geo g = load_geo(v, e);
+      double2 ye[6];
+      op(e, g, (int)v.cell_outflow[e], xe, ye);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) es2[e * 6 + i] = ye[i];
+    }
+    __syncthreads();
+    for (int row = tid; row < n; row += WG) {
+      double2 a = make_double2(0.0, 0.0);
+      for (int s = v.g2_ptr[row]; s < v.g2_ptr[row + 1]; ++s) {
+        const double2 c = es2[v.g2_src[s]];
+        a.x += c.x;
+        a.y += c.y;
+      }
+      epi(row, a.x, a.y);
+    }
+    __syncthreads();
+    return;
+  }
+  tile_chunks_global(v, packed, es, ytmp, gx, op, 0, 1, true);
+#ifdef MDQ_T5_TRACE
+  long long t5q_ = __builtin_amdgcn_s_memtime();
+#endif
   // epilogue: the sums of a batch of own rows are requested together (the caller's own loads follow row by row)
 #ifndef MDQ_T5_EB
 #define MDQ_T5_EB 8
 #endif
   constexpr int EB = MDQ_T5_EB;
-#ifdef MDQ_T5_LAST_EPI
-  if (!rlf)
-#endif
   for (int row0 = tid; row0 < n; row0 += EB * WG) {
     double2 a[EB];
 #pragma unroll
@@ -2686,9 +2692,26 @@ struct Team {
   double* slot;      // [2 parities][TEAM][4] partial sums
   unsigned epoch;
   int par;
+  bool local;        // both workgroups run on the same XCD (team_place): the barrier need not go beyond that XCD's L2
 };
+// The agent-scope fences of the general barrier write the XCD's L2 back and invalidate it - what an environment re-reads in
+// every operator application (0.7 MB of element metadata on the refined mesh) is gone after every barrier: measured on the
+// element tiles, 215 barriers per step, 27.3 ms per step of 128 refined meshes against 11.5 ms for ONE workgroup per
+// environment.  Two workgroups on the SAME XCD share its L2, and the vector L1 of a CU is write-through: waiting for the
+// own stores (vmcnt) and invalidating the own L1 behind the barrier is all the coherence they need.  The launcher's block
+// numbering puts a team on block ids 8 apart - the same XCD under the dispatcher's round-robin - and every team CHECKS it
+// (hardware register XCC_ID, exchanged through the general barrier at kernel start): any other placement keeps the
+// general protocol.
+__device__ __forceinline__ unsigned xcc_id() {
+  unsigned x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  return x & 0xFu;
+}
 __device__ __forceinline__ void team_sync(Team& t) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // every wave: its stores are visible device-wide
+  if (t.local)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // every wave: its stores have reached the XCD's L2
+  else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");     // every wave: its stores are visible device-wide
   __syncthreads();
   ++t.epoch;
   if (threadIdx.x == 0) {
@@ -2706,7 +2729,22 @@ __device__ __forceinline__ void team_sync(Team& t) {
     }
   }
   __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // every wave: no stale lines of the partner's data in this CU's L1
+  if (t.local)
+    asm volatile("buffer_inv sc0" ::: "memory");            // every wave: no stale lines of the partner's data in this CU's L1
+  else
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+// the placement check at kernel start (through the general barrier); `ids`: two words of the environment's slab
+__device__ __forceinline__ void team_place(Team& t, unsigned* ids) {
+  t.local = false;
+  if (threadIdx.x == 0) __hip_atomic_store(ids + t.rank, xcc_id() + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  team_sync(t);
+  const unsigned i0 = __hip_atomic_load(ids, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned i1 = __hip_atomic_load(ids + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  static_assert(TEAM == 2, "two ids");
+#ifndef MDQ_TEAM_GENERAL_BARRIER
+  t.local = i0 == i1;
+#endif
 }
 template <int N>
 __device__ __forceinline__ void team_sum(double (&v)[N], double* red, Team& t) {
@@ -2848,7 +2886,7 @@ __global__ __launch_bounds__(WG) void evolve_team_kernel(mdq_ipcs_desc d, int ns
       if (row < n2) epi(row, y0, y1);
     }
   };
-  team_sync(T);
+  team_place(T, reinterpret_cast<unsigned*>(spare + 25));
   for (int step = 0; step < nsteps; ++step) {
     // ---------------- step 1: tentative velocity
     for (int e = gt; e < v.nt; e += GS) {
@@ -3156,6 +3194,460 @@ static hipError_t launch_evolve_team(const mdq_ipcs_desc* d, size_t lds, int nst
   const int teams8 = (d->B + 7) / 8;                       // blocks: groups of 8 environments x TEAM ranks
   hipLaunchKernelGGL((evolve_team_kernel<K1_LDS>), dim3(teams8 * 8 * TEAM), dim3(WG), lds, stream, *d, nsteps, drag, lift,
                      iters);
+  return hipGetLastError();
+}
+
+// ================================================================== element tiles, TWO workgroups per environment (mode 7)
+//
+// Mode 5 gives an environment ONE workgroup, and what bounds it on the refined mesh is that workgroup's memory-level
+// parallelism (22 GB/s per CU), not the chip: at the BASELINE batch of 128 environments half of the CUs idle,
+// and 256 environments take 14.2 ms where 128 take 11.3.  Here the two workgroups of a team (the protocol of mode 4: team
+// barriers, reductions through the team's slots) share an environment's tile operators: the chunks of a tile application
+// are dealt out alternately, every workgroup accumulates its chunks' row sums into ITS OWN vector of the slab (in fixed
+// order, as mode 5 does), and behind one team barrier the rows - dealt out over the 1 024 threads of the team like every
+// vector pass - add the two partial sums in rank order and run the caller's epilogue.  Bitwise reproducible run to run;
+// NOT bitwise mode 5: a row's sum is (chunks 0, 2, 4, ..) + (chunks 1, 3, 5, ..) instead of chunk after chunk.  Without
+// tile maps (index data built on the device) the element results go to the slab's element scratch, triangles and rows
+// dealt out over the team.  Right-hand sides, the pressure solve (rank 0) and the probes: as in mode 4.
+template <class ElemOp, class Epi>
+__device__ __forceinline__ void tile_apply_team(const EnvView& v, Team& T, bool packed, double2* es, double2* y0v, double2* y1v,
+                                                const double2* gx, ElemOp op, Epi epi) {
+  const int tid = threadIdx.x, n = v.n2, gt = T.rank * WG + tid;
+  constexpr int GS = TEAM * WG;
+  if (!v.mf_tptr) {
+    double2* es2 = reinterpret_cast<double2*>(v.work);
+    for (int e = gt; e < v.nt; e += GS) {
+      double2 xe[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) xe[i] = gx[v.cell_dofs[i * v.NT + e]];
+      const Geo g = load_geo(v, e);
+      double2 ye[6];
+      op(e, g, (int)v.cell_outflow[e], xe, ye);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) es2[e * 6 + i] = ye[i];
+    }
+    team_sync(T);
+    for (int row = gt; row < n; row += GS) {
+      double2 a = make_double2(0.0, 0.0);
+      for (int s = v.g2_ptr[row]; s < v.g2_ptr[row + 1]; ++s) {
+        const double2 c = es2[v.g2_src[s]];
+        a.x += c.x;
+        a.y += c.y;
+      }
+      epi(row, a.x, a.y);
+    }
+    return;       // (the caller's team reduction is the barrier in front of the next use of the element scratch)
+  }
+  tile_chunks_global(v, packed, es, T.rank ? y1v : y0v, gx, op, T.rank, TEAM, false);
+  team_sync(T);
+  constexpr int EB = 4;
+  for (int row0 = gt; row0 < n; row0 += EB * GS) {
+    double2 a[EB], c[EB];
+#pragma unroll
+    for (int k = 0; k < EB; ++k) {
+      a[k] = y0v[min(row0 + k * GS, n - 1)];
+      c[k] = y1v[min(row0 + k * GS, n - 1)];
+    }
+#pragma unroll
+    for (int k = 0; k < EB; ++k)
+      if (row0 + k * GS < n) epi(row0 + k * GS, a[k].x + c[k].x, a[k].y + c[k].y);
+  }
+}
+
+template <bool K1_LDS>
+__global__ __launch_bounds__(WG) void evolve_team_tiles_kernel(mdq_ipcs_desc d, int nsteps, double* drag, double* lift,
+                                                                int32_t* iters) {
+  extern __shared__ __align__(16) double smem[];
+  const int q = blockIdx.x / (8 * TEAM), r8 = blockIdx.x % (8 * TEAM);
+  const int b = q * 8 + (r8 & 7), rank = r8 >> 3;
+  if (b >= d.B) return;
+  const int tid = threadIdx.x, gt = rank * WG + tid;
+  constexpr int GS = TEAM * WG;
+  const EnvView v = env_view(d, b);
+  const int n2 = v.n2, nv = v.nv;
+  const LdsPlan P = lds_plan(d.N2, d.NV, d.NSE1);
+  double* red = smem;
+  double* U = smem + 64;
+  // pressure view of the union (rank 0 only) | velocity view: the element tile (+ the staged rows of a chunk)
+  double* px = U;
+  double* pr = px + P.NVp;
+  double* pp = pr + P.NVp;
+  double* pq = pp + P.NVp;
+  double* lK = pq + P.NVp;
+  int32_t* lci = reinterpret_cast<int32_t*>(lK + d.NSE1);
+  int32_t* lso = lci + d.NSE1 + (d.NSE1 & 1);
+  double2* es = reinterpret_cast<double2*>(U);
+  double* w = v.work;
+  double2* escr2 = reinterpret_cast<double2*>(w);
+  double* escr1 = w;
+  double2* xs = reinterpret_cast<double2*>(w + 12 * (int64_t)d.NT);
+  double2* vr = xs + d.N2;
+  double2* vh = vr + d.N2;
+  double2* vp = vh + d.N2;
+  double2* vv = vp + d.N2;
+  double2* vt = vv + d.N2;
+  double2* h1 = reinterpret_cast<double2*>(w + work_hist_offset(d.NV, d.NT, d.NE));
+  double2* h2 = h1 + d.N2;
+  double2* h3 = h2 + d.N2;
+  double2* h4 = h3 + d.N2;
+  double2* h5 = h4 + d.N2;
+  double* hcnt = reinterpret_cast<double*>(h5 + d.N2);
+  double2* y0v = reinterpret_cast<double2*>(w + work_ytmp_offset(d.NV, d.NT, d.NE));   // the workgroups' accumulation vectors
+  double2* y1v = y0v + d.N2 + 1;
+  double2* stage = vh;                                   // the mass solve's S^-1 p (vh is free there)
+  double* pnew = reinterpret_cast<double*>(vt + d.N2);
+  double* spare = pnew + d.NV;
+  Team T;
+  T.rank = rank;
+  T.ctr = reinterpret_cast<unsigned*>(spare + 8);
+  T.slot = spare + 9;
+  T.epoch = 0;
+  T.par = 0;
+  const int nsl1 = (nv + 63) >> 6;
+  const int32_t* so1 = K1_LDS ? lso : v.sl1_off;
+  const int32_t* ci1 = K1_LDS ? lci : v.sl1_col;
+  const double* K1 = K1_LDS ? lK : v.K1s;
+  const double a = d.rho / d.dt, mu = d.mu;
+  const bool packed = d.N2 <= 4096;
+  int it_u = 0, it_p = 0, it_m = 0;
+  // y = D^-1 A x (0 on constrained rows) / y = S^-1 M x' on the team's rows
+  auto apply_vel = [&](const double2* gx, auto epi) {
+    tile_apply_team(
+        v, T, packed, es, y0v, y1v, gx,
+        [&](int e, const Geo& g, int ko, const double2(&xe)[6], double2(&ye)[6]) { velocity_op(v, a, mu, e, ko, g, xe, ye); },
+        [&](int row, double y0, double y1) {
+          const bool fl = v.bcu_flag[row] != 0;
+          const double2 id = v.idiag1[row];
+          epi(row, fl ? 0.0 : y0 * id.x, fl ? 0.0 : y1 * id.y);
+        });
+  };
+  auto apply_mass = [&](const double2* gx, auto epi) {
+    tile_apply_team(
+        v, T, packed, es, y0v, y1v, gx,
+        [&](int, const Geo& g, int, const double2(&xe)[6], double2(&ye)[6]) { elem_mass(g, xe, ye); },
+        [&](int row, double y0, double y1) {
+          const double is = v.bcu_flag[row] ? 0.0 : 1.0 / v.sdiagM[row];
+          epi(row, y0 * is, y1 * is);
+        });
+  };
+  team_place(T, reinterpret_cast<unsigned*>(spare + 25));
+  for (int step = 0; step < nsteps; ++step) {
+    // ---------------- step 1: tentative velocity
+    for (int e = gt; e < v.nt; e += GS) {
+      const ElemIdx E = load_dofs(v, e);
+      const Geo g = load_geo(v, e);
+      double2 ue[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) ue[i] = v.u_n[E.dof[i]];
+      double pe[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) pe[i] = v.p_n[E.dof[i]];
+      double2 rr_[6];
+      elem_rhs1_vol(g, a, mu, d.rho, ue, pe, rr_);
+      const int ko = v.cell_outflow[e];
+      if (ko >= 0) {
+        double X[3][2];
+        load_cell_coords(v, e, X);
+        elem_outflow_add(g, X, ko, 0.5 * mu, ue, rr_);
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) escr2[e * 6 + i] = rr_[i];
+    }
+    team_sync(T);
+    double acc[2] = {0.0, 0.0};
+    const int nhist = (int)hcnt[0];
+    for (int i = gt; i < n2; i += GS) {
+      double2 f = make_double2(0.0, 0.0);
+      for (int s_ = v.g2_ptr[i]; s_ < v.g2_ptr[i + 1]; ++s_) {
+        const double2 c = escr2[v.g2_src[s_]];
+        f.x += c.x;
+        f.y += c.y;
+      }
+      const double2 l = v.lift1[i], id = v.idiag1[i];
+      const bool fl = v.bcu_flag[i] != 0;
+      const double2 g = make_double2(v.bcu_gx[i], 0.0);
+      const double2 bi = fl ? g : make_double2((f.x - l.x) * id.x, (f.y - l.y) * id.y);
+      double2 x0 = v.u_n[i];
+      if (nhist >= 2) {
+        const double2 us1 = h1[i], us2 = h2[i];
+        x0 = make_double2(2.0 * us1.x - us2.x, 2.0 * us1.y - us2.y);
+        if (nhist >= 3) {
+          const double2 us3 = h3[i];
+          x0 = make_double2(3.0 * (us1.x - us2.x) + us3.x, 3.0 * (us1.y - us2.y) + us3.y);
+          if (nhist >= 4) {
+            const double2 us4 = h4[i];
+            x0 = make_double2(4.0 * (us1.x + us3.x) - 6.0 * us2.x - us4.x, 4.0 * (us1.y + us3.y) - 6.0 * us2.y - us4.y);
+            if (nhist >= 5) {
+              const double2 us5 = h5[i];
+              x0 = make_double2(5.0 * (us1.x - us4.x) - 10.0 * (us2.x - us3.x) + us5.x,
+                                5.0 * (us1.y - us4.y) - 10.0 * (us2.y - us3.y) + us5.y);
+            }
+          }
+        }
+      }
+      if (fl) x0 = g;
+      xs[i] = x0;
+      vr[i] = fl ? make_double2(0.0, 0.0) : make_double2(f.x * id.x, f.y * id.y);   // (full operator on x0: no lifting vector)
+      acc[0] += bi.x * bi.x + bi.y * bi.y;
+    }
+    team_sync(T);
+    apply_vel(xs, [&](int row, double y0, double y1) {
+      const double2 bi = vr[row];
+      const double2 r0 = make_double2(bi.x - y0, bi.y - y1);
+      vr[row] = r0;
+      vh[row] = r0;
+      vp[row] = make_double2(0.0, 0.0);
+      vv[row] = make_double2(0.0, 0.0);
+      acc[1] += r0.x * r0.x + r0.y * r0.y;
+    });
+    team_sum<2>(acc, red, T);
+    {  // BiCGStab (bicgstab_velocity<5>, rows and chunks over the team)
+      const double bb = acc[0], tol2 = d.rtol * d.rtol * bb;
+      double rr = acc[1];
+      if (rr > tol2 && bb != 0.0) {
+        double rho = rr, rho_old = 1.0, alpha = 1.0, omega = 1.0;
+        int it = 0;
+        while (it < d.maxit_u) {
+          ++it;
+          const double beta = (rho / rho_old) * (alpha / omega);
+          for (int i = gt; i < n2; i += GS) {
+            const double2 ri = vr[i], pi = vp[i], vi = vv[i];
+            vp[i] = make_double2(ri.x + beta * (pi.x - omega * vi.x), ri.y + beta * (pi.y - omega * vi.y));
+          }
+          team_sync(T);
+          double a1[1] = {0.0};
+          apply_vel(vp, [&](int row, double y0, double y1) {
+            vv[row] = make_double2(y0, y1);
+            const double2 h = vh[row];
+            a1[0] += h.x * y0 + h.y * y1;
+          });
+          team_sum<1>(a1, red, T);
+          if (a1[0] == 0.0) break;
+          alpha = rho / a1[0];
+          double a2[1] = {0.0};
+          for (int i = gt; i < n2; i += GS) {
+            const double2 ri = vr[i], vi = vv[i];
+            const double2 sv = make_double2(ri.x - alpha * vi.x, ri.y - alpha * vi.y);
+            vr[i] = sv;
+            a2[0] += sv.x * sv.x + sv.y * sv.y;
+          }
+          team_sum<1>(a2, red, T);       // (its team barrier also publishes s)
+          if (!(a2[0] > tol2)) {
+            for (int i = gt; i < n2; i += GS) {
+              const double2 xi = xs[i], pi = vp[i];
+              xs[i] = make_double2(xi.x + alpha * pi.x, xi.y + alpha * pi.y);
+            }
+            break;
+          }
+          double a3[2] = {0.0, 0.0};
+          apply_vel(vr, [&](int row, double y0, double y1) {
+            vt[row] = make_double2(y0, y1);
+            const double2 sv = vr[row];
+            a3[0] += y0 * sv.x + y1 * sv.y;
+            a3[1] += y0 * y0 + y1 * y1;
+          });
+          team_sum<2>(a3, red, T);
+          if (a3[1] == 0.0) break;
+          omega = a3[0] / a3[1];
+          double a4[2] = {0.0, 0.0};
+          for (int i = gt; i < n2; i += GS) {
+            const double2 ti = vt[i], xi = xs[i], pi = vp[i], si = vr[i], hi = vh[i];
+            xs[i] = make_double2(xi.x + alpha * pi.x + omega * si.x, xi.y + alpha * pi.y + omega * si.y);
+            const double2 rn = make_double2(si.x - omega * ti.x, si.y - omega * ti.y);
+            vr[i] = rn;
+            a4[0] += rn.x * rn.x + rn.y * rn.y;
+            a4[1] += hi.x * rn.x + hi.y * rn.y;
+          }
+          team_sum<2>(a4, red, T);
+          rr = a4[0];
+          if (!(rr > tol2)) break;
+          rho_old = rho;
+          rho = a4[1];
+          if (rho == 0.0 || omega == 0.0) break;
+        }
+        it_u += it;
+      }
+    }
+    team_sync(T);
+    for (int i = gt; i < n2; i += GS) {  // history, newest first
+      if (nhist >= 4) h5[i] = h4[i];
+      if (nhist >= 3) h4[i] = h3[i];
+      if (nhist >= 2) h3[i] = h2[i];
+      if (nhist >= 1) h2[i] = h1[i];
+      h1[i] = xs[i];
+    }
+    // ---------------- step 2: pressure (element loop by the team, the solve by rank 0)
+    {
+      const double idt = 1.0 / d.dt;
+      for (int e = gt; e < v.nt; e += GS) {
+        const ElemIdx E = load_dofs(v, e);
+        const Geo g = load_geo(v, e);
+        double2 ue[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) ue[i] = xs[E.dof[i]];
+        double pe[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pe[i] = v.p_n[E.dof[i]];
+        double r3[3];
+        elem_rhs2(g, idt, ue, pe, r3);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) escr1[e * 3 + j] = r3[j];
+      }
+    }
+    team_sync(T);
+    if (rank == 0) {
+      if (tid == 0) hcnt[0] = (double)(nhist < 5 ? nhist + 1 : 5);
+      if (K1_LDS && !d.pd_enabled) {
+        const int ne1 = v.sl1_off[nsl1];
+        for (int k = tid; k < ne1; k += WG) {
+          lK[k] = v.K1s[k];
+          lci[k] = v.sl1_col[k];
+        }
+        for (int k = tid; k <= nsl1; k += WG) lso[k] = v.sl1_off[k];
+      }
+      for (int i = tid; i < nv; i += WG) {
+        double bsum = 0.0;
+        for (int s_ = v.g1_ptr[i]; s_ < v.g1_ptr[i + 1]; ++s_) bsum += escr1[v.g1_src[s_]];
+        const double sd = v.sdiagK[i];
+        pr[i] = v.bcp_flag[i] ? 0.0 : bsum / sd;
+        px[i] = v.p_n[i] * sd;
+      }
+      if (d.pd_enabled && d.pd_hdr[4 * (int64_t)b + 2] > 0) {
+        const PdView pd = pd_view(d, b);
+        pressure_direct(pd, nv, pr, px, pp, pq, lK);
+      } else {
+        it_p += cg_pressure(nv, so1, ci1, K1, d.rtol, d.maxit_p, px, pr, pp, pq, red);
+      }
+      for (int i = tid; i < nv; i += WG) pnew[i] = px[i] / v.sdiagK[i];
+    }
+    team_sync(T);
+    // ---------------- step 3: velocity correction
+    for (int e = gt; e < v.nt; e += GS) {
+      const ElemIdx E = load_dofs(v, e);
+      const Geo g = load_geo(v, e);
+      double2 ue[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) ue[i] = xs[E.dof[i]];
+      double dp[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) dp[i] = pnew[E.dof[i]] - v.p_n[E.dof[i]];
+      double2 rr_[6];
+      elem_rhs3(g, d.dt, ue, dp, rr_);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) escr2[e * 6 + i] = rr_[i];
+    }
+    team_sync(T);
+    double am[2] = {0.0, 0.0};
+    for (int i = gt; i < n2; i += GS) {
+      double2 f = make_double2(0.0, 0.0);
+      for (int s_ = v.g2_ptr[i]; s_ < v.g2_ptr[i + 1]; ++s_) {
+        const double2 c = escr2[v.g2_src[s_]];
+        f.x += c.x;
+        f.y += c.y;
+      }
+      const double2 l = v.lift3[i];
+      const double sd = v.sdiagM[i];
+      const bool fl = v.bcu_flag[i] != 0;
+      const double2 g = make_double2(v.bcu_gx[i], 0.0);
+      const double2 bi = fl ? g : make_double2((f.x - l.x) / sd, (f.y - l.y) / sd);
+      const double2 x0 = fl ? g : xs[i];
+      xs[i] = make_double2(x0.x * sd, x0.y * sd);   // scaled unknown S x
+      stage[i] = x0;                                 // S^-1 (S x0)
+      vr[i] = fl ? make_double2(0.0, 0.0) : make_double2(f.x / sd, f.y / sd);
+      am[0] += bi.x * bi.x + bi.y * bi.y;
+    }
+    team_sync(T);
+    apply_mass(stage, [&](int row, double y0, double y1) {
+      const double2 bi = vr[row];
+      const double2 r0 = make_double2(bi.x - y0, bi.y - y1);
+      vr[row] = r0;
+      vp[row] = r0;
+      am[1] += r0.x * r0.x + r0.y * r0.y;
+    });
+    team_sum<2>(am, red, T);          // (every gather of x0 from `stage` is behind its team barrier)
+    for (int i = gt; i < n2; i += GS) {
+      const double is = 1.0 / v.sdiagM[i];
+      const double2 p0 = vp[i];
+      stage[i] = make_double2(p0.x * is, p0.y * is);
+    }
+    team_sync(T);
+    {  // CG on the mass system (cg_mass<5>)
+      const double bb = am[0], tol2 = d.rtol * d.rtol * bb;
+      double rr = am[1];
+      if (rr > tol2 && bb != 0.0) {
+        int it = 0;
+        while (it < d.maxit_m) {
+          ++it;
+          double a1[1] = {0.0};
+          apply_mass(stage, [&](int row, double y0, double y1) {
+            vv[row] = make_double2(y0, y1);
+            const double2 pi = vp[row];
+            a1[0] += pi.x * y0 + pi.y * y1;
+          });
+          team_sum<1>(a1, red, T);
+          if (!(a1[0] > 0.0)) break;
+          const double alpha = rr / a1[0];
+          double a2[1] = {0.0};
+          for (int i = gt; i < n2; i += GS) {
+            const double2 xi = xs[i], pi = vp[i], ri = vr[i], qi = vv[i];
+            xs[i] = make_double2(xi.x + alpha * pi.x, xi.y + alpha * pi.y);
+            const double2 rn = make_double2(ri.x - alpha * qi.x, ri.y - alpha * qi.y);
+            vr[i] = rn;
+            a2[0] += rn.x * rn.x + rn.y * rn.y;
+          }
+          team_sum<1>(a2, red, T);
+          const double rr_new = a2[0];
+          if (!(rr_new > tol2)) break;
+          const double beta = rr_new / rr;
+          rr = rr_new;
+          for (int i = gt; i < n2; i += GS) {
+            const double2 ri = vr[i], pi = vp[i];
+            const double2 pn = make_double2(ri.x + beta * pi.x, ri.y + beta * pi.y);
+            vp[i] = pn;
+            const double is = 1.0 / v.sdiagM[i];
+            stage[i] = make_double2(pn.x * is, pn.y * is);
+          }
+          team_sync(T);
+        }
+        it_m += it;
+      }
+    }
+    team_sync(T);
+    // ---------------- update state + probes
+    for (int i = gt; i < n2; i += GS) {
+      const double sd = v.sdiagM[i];
+      const double2 x = xs[i];
+      v.u_n[i] = make_double2(x.x / sd, x.y / sd);
+    }
+    for (int i = gt; i < nv; i += GS) v.p_n[i] = pnew[i];
+    team_sync(T);
+    if (rank == 0) {
+      double dr, li;
+      forces(v, d.mu, v.u_n, v.p_n, red, dr, li);
+      if (tid == 0) {
+        const bool failed = __hip_atomic_load(T.ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        drag[(int64_t)b * nsteps + step] = failed ? __builtin_nan("") : dr;
+        lift[(int64_t)b * nsteps + step] = failed ? __builtin_nan("") : li;
+      }
+    }
+  }
+  if (rank == 0 && tid == 0 && iters) {
+    iters[3 * b + 0] += it_u;
+    iters[3 * b + 1] += it_p;
+    iters[3 * b + 2] += it_m;
+  }
+}
+
+template <bool K1_LDS>
+static hipError_t launch_evolve_team_tiles(const mdq_ipcs_desc* d, size_t lds, int nsteps, double* drag, double* lift,
+                                           int32_t* iters, hipStream_t stream) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&evolve_team_tiles_kernel<K1_LDS>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(team_reset_kernel, dim3((d->B + 63) / 64), dim3(64), 0, stream, *d);
+  const int teams8 = (d->B + 7) / 8;                       // blocks: groups of 8 environments x TEAM ranks
+  hipLaunchKernelGGL((evolve_team_tiles_kernel<K1_LDS>), dim3(teams8 * 8 * TEAM), dim3(WG), lds, stream, *d, nsteps, drag,
+                     lift, iters);
   return hipGetLastError();
 }
 
@@ -4732,6 +5224,9 @@ hipError_t part_launch_tiles(int mode, bool k1_lds, bool pg, const EvolveArgs& a
   if (mode == 4)
     return k1_lds ? launch_evolve_team<true>(a.d, a.lds, a.nsteps, a.drag, a.lift, a.iters, a.st)
                   : launch_evolve_team<false>(a.d, a.lds, a.nsteps, a.drag, a.lift, a.iters, a.st);
+  if (mode == 7)
+    return k1_lds ? launch_evolve_team_tiles<true>(a.d, a.lds, a.nsteps, a.drag, a.lift, a.iters, a.st)
+                  : launch_evolve_team_tiles<false>(a.d, a.lds, a.nsteps, a.drag, a.lift, a.iters, a.st);
   return pg ? launch_evolve<5, false, true>(a.d, a.lds, a.nsteps, a.drag, a.lift, a.iters, a.st)
             : (k1_lds ? launch_evolve<5, true>(a.d, a.lds, a.nsteps, a.drag, a.lift, a.iters, a.st)
                       : launch_evolve<5, false>(a.d, a.lds, a.nsteps, a.drag, a.lift, a.iters, a.st));
@@ -4878,7 +5373,8 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
   // mode 5: the element tile (+ the stage of a chunk's input rows behind it when the packed local maps are given and fit)
   const size_t tile_bytes = sizeof(double2) * 6 * MF_CH +
                             ((d->mf_lpos && d->mf_rlist && d->mf_rcnt && mode5_stage_fits(d->NRL)) ? sizeof(double2) * (size_t)d->NRL : 0);
-  if (mode < 0 || mode > 5) {  // auto: fastest variant that fits
+  if (mode == 6) return fail_msg("unknown operator mode 6");
+  if (mode < 0 || mode > 7) {  // auto: fastest variant that fits
     mode = 0;
     if (red_bytes + P.vel1_bytes <= LDS_MAX) mode = 1;
     if (red_bytes + P.vel2_bytes <= LDS_MAX && d->N2 <= MF_ROWS * WG) mode = 2;
@@ -4901,6 +5397,18 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
       }();
       if (!pg && 2 * TEAM * d->B <= ncu) mode = 4;
     }
+    // the element tiles with TWO workgroups per environment while the batch leaves half of the chip idle (BASELINE batch of
+    // 128 refined meshes: 11.3 -> ms per step; MDQ_NO_TEAM_TILES=1 is the A / B switch)
+    if (mode == 5 && !pg && std::getenv("MDQ_NO_TEAM_TILES") == nullptr) {
+      static const int ncu5 = [] {
+        int dev_ = 0, n_ = 0;
+        if (hipGetDevice(&dev_) != hipSuccess ||
+            hipDeviceGetAttribute(&n_, hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess)
+          return 0;
+        return n_;
+      }();
+      if (TEAM * d->B <= ncu5) mode = 7;
+    }
   }
   if (kernel_ms && mode != 3) return fail_msg("per-kernel timing exists for the three-kernel mode 3 only");
   if (mode == 3 && (red_bytes + P.vel3_bytes > LDS_MAX || d->N2 > MF_ROWS * WG))
@@ -4908,12 +5416,12 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
   if (mode == 2 && (red_bytes + P.vel2_bytes > LDS_MAX || d->N2 > MF_ROWS * WG))
     return fail_msg("matrix-free tile mode needs N2 <= 3584 and the x stage + element tile in LDS");
   if (mode == 1 && red_bytes + P.vel1_bytes > LDS_MAX) return fail_msg("LDS gather vectors do not fit");
-  if (mode == 5 && (!d->cell_outflow || !((d->mf_scat && d->mf_tptr) || (d->g2_ptr && d->g2_src))))
-    return fail_msg("mode 5 needs cell_outflow and the tile maps (mf_scat, mf_tptr) or the dof <- slot lists (g2_ptr, g2_src)");
+  if ((mode == 5 || mode == 7) && (!d->cell_outflow || !((d->mf_scat && d->mf_tptr) || (d->g2_ptr && d->g2_src))))
+    return fail_msg("modes 5 / 7 need cell_outflow and the tile maps (mf_scat, mf_tptr) or the dof <- slot lists (g2_ptr, g2_src)");
   if (pg && mode != 0 && mode != 5)
     return fail_msg("mesh too large for the LDS-resident pressure vectors of this operator mode (use mode -1, 0 or 5)");
   size_t u = pg ? 0 : P.prs_vec_bytes + (k1_lds ? P.prs_mat_bytes : 0);  // (K1 values alias the scratch vector: CG does not use it)
-  const size_t vel = mode == 3 ? P.vel3_bytes : (mode == 2 ? P.vel2_bytes : (mode == 1 ? P.vel1_bytes : (mode == 5 ? tile_bytes : 0)));
+  const size_t vel = mode == 3 ? P.vel3_bytes : (mode == 2 ? P.vel2_bytes : (mode == 1 ? P.vel1_bytes : ((mode == 5 || mode == 7) ? tile_bytes : 0)));
   if (vel > u) u = vel;
   const size_t lds = red_bytes + u;
   hipError_t e;
@@ -4989,7 +5497,7 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
     const EvolveArgs a{d, lds, nsteps, drag, lift, iters, st};
     if (mode == 2)
       e = part_launch_mf(k1_lds, a);
-    else if (mode == 4 || mode == 5)
+    else if (mode == 4 || mode == 5 || mode == 7)
       e = part_launch_tiles(mode, k1_lds, pg, a);
     else
       e = part_launch_assembled(mode, k1_lds, pg, a);

@@ -355,6 +355,52 @@ def test_two_workgroups_per_environment_match_one(meshes, lib_built):
     assert np.abs(d5.cpu().numpy() - out[0][0]).max() < 1e-8 * np.abs(out[0][0]).max()
 
 
+def test_two_workgroups_per_environment_on_the_element_tiles(meshes, lib_built):
+    """mode 7 (evolve_team_tiles_kernel: the element tiles of mode 5 with TWO workgroups per environment - the chunks of a
+    tile application dealt out alternately, one accumulation vector per workgroup, the rows add the two in rank order
+    behind a team barrier that stays inside the XCD when both workgroups run there) against mode 5 on ys930 red-refined:
+    same iteration counts (+-1 where a stopping test is crossed closely), forces and fields to round-off (a row's sum is
+    associated differently), every environment of
+    the batch bitwise equal, a second run bitwise equal; what auto takes while two workgroups per environment fit the
+    chip (MDQ_NO_TEAM_TILES=1: mode 5); with the direct pressure solve and with the Krylov one; and a small mesh riding
+    along in the big layout (fewer chunks than workgroups for some operators)."""
+    import torch
+    from meshdqn_amd.ipcs_batch import IpcsBatch, smooth_coords
+    from meshdqn_amd.mesh_ops import red_refine
+    from meshdqn_amd.topology import MeshTopology
+    coords, cells = meshes["ys930"]
+    t0 = MeshTopology(coords, cells)
+    x0 = smooth_coords(t0, 50)
+    rc, rcells = red_refine(x0, cells)
+    rt = MeshTopology(rc, rcells)
+    for direct in (True, False):
+        out = {}
+        for key, mode in (("5", 5), ("7", 7), ("7b", 7), ("auto", -2)):
+            bb = IpcsBatch([rt] * 4 + [t0], [rc] * 4 + [x0], rtol=1e-10, mode=mode, pressure_direct=direct)
+            d, l = bb.evolve(6)
+            torch.cuda.synchronize()
+            out[key] = (d.cpu().numpy(), l.cpu().numpy(), bb.u_n.cpu().numpy(), bb.p_n.cpu().numpy(), bb.iters.cpu().numpy())
+        assert np.isfinite(out["7"][0]).all() and (out["7"][0][:4] == out["7"][0][0]).all()
+        for k in range(5):
+            assert np.array_equal(out["7"][k], out["7b"][k]), k          # run to run
+            assert np.array_equal(out["7"][k], out["auto"][k]), k        # auto = the team while it fits the chip
+        # iteration counts over the 6 steps (a stopping test sits on round-off: one more or less where it is crossed closely)
+        assert np.abs(out["7"][4].astype(int) - out["5"][4].astype(int)).max() <= 2
+        assert np.abs(out["7"][0] - out["5"][0]).max() < 1e-11 * np.abs(out["5"][0]).max()
+        assert np.abs(out["7"][1] - out["5"][1]).max() < 1e-9 * np.abs(out["5"][1]).max()
+        # (fields: two solves stopped at rtol 1e-10 - the bound of the mode-4 test above)
+        assert np.abs(out["7"][2] - out["5"][2]).max() < 1e-8 * np.abs(out["5"][2]).max()
+        assert np.abs(out["7"][3] - out["5"][3]).max() < 1e-8 * np.abs(out["5"][3]).max()
+    os.environ["MDQ_NO_TEAM_TILES"] = "1"
+    try:
+        b5 = IpcsBatch([rt] * 4 + [t0], [rc] * 4 + [x0], rtol=1e-10, mode=-2, pressure_direct=False)
+        d5, _ = b5.evolve(6)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["MDQ_NO_TEAM_TILES"]
+    assert np.array_equal(d5.cpu().numpy(), out["5"][0])
+
+
 def test_polynomial_preconditioned_pressure_cg_matches_oracle(meshes, lib_built):
     """The Krylov pressure solve of the three-kernel mode with the Chebyshev polynomial preconditioner (degree 4 and 8 on
     top of the Jacobi scaling) and with the two-level additive preconditioner (geometric aggregates, coarse matrix inverted
