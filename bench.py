@@ -903,7 +903,8 @@ def main(argv=None):
             r3 = measure_env_steps(args, dev, None, 1, 1, steps=max(args.s1_steps // 10, 2), warmup=2, repeats=3, mesh=f"{args.mesh}_refined")
             r3["what"] = ("the S3 (north-star) env step on the red-refined mesh: the S1 step above + one IPCS step on every coarsened "
                           "mesh on the flow stream - index data from the large-mesh topology instance, mdq_ipcs_setup_matfree, the "
-                          "element operators with global vectors (mode 5 through the dof <- slot lists), Jacobi-CG pressure solve")
+                          "element operators with global vectors and two workgroups per environment (mode 7 through the dof <- slot lists), "
+                          "Jacobi-CG pressure solve")
             cfgs["C5_s3_refined_mesh"] = r3
         except Exception as exc:  # noqa: BLE001
             cfgs["C5_s3_refined_mesh"] = dict(error=repr(exc))
@@ -919,13 +920,14 @@ def main(argv=None):
             it5 = np.tile(np.array([[c5["krylov_iters_per_step"][k] for k in ("velocity_bicgstab", "pressure", "correction_cg")]]), (B, 1))
             by5 = b5.algorithmic_bytes_per_step(it5)
             c5.update(what="C5: S2 on ys930 red-refined once (the mesh does not fit the LDS-resident modes: auto mode takes the element "
-                           "tiles with GLOBAL vectors, mode 5 - bitwise reproducible; round 3 ran the assembled SELL operators here, "
-                           "6.65 k env-steps/s), 100 spin-up steps from rest; Jacobi-CG pressure solve (the factorisation's limits are "
-                           "below this size)", vertices=int(rt.nv), triangles=int(rt.nt),
+                           "tiles with GLOBAL vectors and - while two workgroups per environment fit the chip - TWO workgroups per "
+                           "environment, mode 7: bitwise reproducible run to run; mode 5, one workgroup, ran here until round 5: "
+                           "11.7 k env-steps/s; round 3 ran the assembled SELL operators, 6.65 k), 100 spin-up steps from rest; "
+                           "direct pressure solve from host-built factors", vertices=int(rt.nv), triangles=int(rt.nt),
                       survey_csr_bytes_per_step=by5, survey_equivalent_GBs=by5 / (c5["ms_per_step"] * 1e-3) / 1e9,
                       survey_equivalent_over_hbm_peak=by5 / (c5["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                       measured_hbm_bytes_per_launch=(((prof_early(PMC_SUMMARY, "hbm_bytes_per_launch") or {}).get("c5") or {})
-                                                     .get("mdq::evolve_kernel<5, false, false>")),
+                                                     .get("mdq::evolve_team_tiles_kernel<false>")),
                       note="survey_* = the bytes an assembled-CSR implementation would stream (SURVEY 8(d) convention) over the step "
                            "time - NOT a roofline fraction of this kernel; measured_hbm_bytes_per_launch = rocprofv3 FETCH_SIZE + "
                            "WRITE_SIZE of the same kernel (profiles/" + PMC_SUMMARY + "; one launch = one step of 128 environments)")
@@ -1070,7 +1072,7 @@ def main(argv=None):
                 hot_kernels={k: dict(vgprs=v["vgprs"], scratch=v["scratch_bytes_per_lane"], occupancy=v["occupancy"])
                              for k, v in kres.items() if any(t in k for t in ("smooth_linear", "at_velocity", "at_pressure", "at_correction",
                                                                                "topology_kernel", "gcn_embed", "mlp_head_c128", "remesh_kernel",
-                                                                               "evolve_mf", "evolve_kernel<5", "setup_matfree", "interpolate",
+                                                                               "evolve_mf", "evolve_kernel<5", "evolve_team_tiles", "setup_matfree", "interpolate",
                                                                                "env_finish", "probe"))},
                 unit="bytes per lane (-Rpass-analysis=kernel-resource-usage of this build)")
         except Exception as exc:  # noqa: BLE001

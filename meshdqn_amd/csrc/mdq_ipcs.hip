@@ -2122,6 +2122,268 @@ __device__ inline int cg_pressure_2l(int n, const int32_t* sl_off, const int32_t
   return it;
 }
 
+// The two-level preconditioner for the meshes BEYOND the register-resident solvers (cg_pressure: four LDS vectors, 512
+// threads, any n up to the LDS): where Jacobi-CG needs hundreds of iterations (refined ys930, 3 322 vertices: 320-343).
+// Same operator z = r + P A_c^-1 P^T r over NAGX x NAGY geometric aggregates as cg_pressure_2l, with what that one's header
+// lists as missing: the aggregation in O(n) - a 1 024-bin histogram of x, its prefix sums cut into NAGX strips of (about)
+// equal population, per strip a 256-bin histogram of y cut into NAGY cells; vertices of one fine bin share a strip / cell,
+// an empty aggregate gets a unit diagonal - and one-barrier reductions.  Scratch: the histograms and then the fp64 coarse
+// matrix in the p | q vectors (free until the first search direction), the fp32 inverse, the per-wave partial
+// restrictions and the aggregate of every vertex in `extra` (the fifth LDS vector, the direct solver's scratch).
+// Returns -1 where it does not apply (too few vertices, LDS scratch too small): the caller runs cg_pressure.
+constexpr int TL_XB = 1024, TL_YB = 256;
+__host__ __device__ inline size_t tl_extra_bytes(int n) {
+  return sizeof(float) * NAG * NAG + sizeof(double) * ((WG / 64) * NAG + NAG) + (size_t)((n + 7) & ~7);
+}
+__device__ __attribute__((noinline)) int cg_pressure_2l_lds(int n, const int32_t* sl_off, const int32_t* sl_col, const double* A, const double* coords,
+                                         double rtol, int maxit, double* x, double* r, double* p, double* q, int NVp,
+                                         double* extra, double* red) {
+  constexpr int NW = WG / 64;
+  static_assert(NW == NAGX, "one wave per strip in the y pass");
+  static_assert(sizeof(float) * NAG * NAG % 8 == 0, "alignment of the partial restrictions");
+  if (n < 4 * NAG || tl_extra_bytes(n) > sizeof(double) * (size_t)NVp || 2 * (size_t)NVp < (size_t)NAG * NAG ||
+      2 * sizeof(double) * (size_t)NVp < sizeof(int) * (TL_XB + NAGX * TL_YB + 2 * NAGX) + (size_t)n)
+    return -1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* AI = reinterpret_cast<float*>(extra);                             // [NAG][NAG] inverse of the coarse matrix
+  double* WP = extra + NAG * NAG / 2;                                      // [NW][NAG] per-wave partial restrictions
+  double* YV = WP + NW * NAG;                                              // [NAG] coarse result
+  unsigned char* AG = reinterpret_cast<unsigned char*>(YV + NAG);          // [n] aggregate of a vertex
+  double acc[2] = {0.0, 0.0};
+  __syncthreads();
+  spmv_sell(sl_off, sl_col, A, x, n, [&](int row, double y0) {
+    const double b = r[row];
+    const double r0 = b - y0;
+    r[row] = r0;
+    acc[0] += b * b;
+    acc[1] += r0 * r0;
+  });
+  block_sum<2>(acc, red);
+  const double bb = acc[0], tol2 = rtol * rtol * bb;
+  double rr = acc[1];
+  if (!(rr > tol2) || bb == 0.0) return 0;
+  // ---- aggregates
+  {
+    int* HX = reinterpret_cast<int*>(p);          // [TL_XB] counts, then exclusive prefix sums
+    int* HY = HX + TL_XB;                         // [NAGX][TL_YB]
+    int* SC = HY + NAGX * TL_YB;                  // [NAGX] population of a strip ([NW] wave totals of the scan behind it)
+    unsigned char* ST = reinterpret_cast<unsigned char*>(SC + 2 * NAGX);   // [n] strip of a vertex
+    double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
+    for (int i = tid; i < n; i += WG) {
+      const double cx = coords[2 * i], cy = coords[2 * i + 1];
+      lo[0] = fmin(lo[0], cx);
+      hi[0] = fmax(hi[0], cx);
+      lo[1] = fmin(lo[1], cy);
+      hi[1] = fmax(hi[1], cy);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      for (int off = 32; off > 0; off >>= 1) {
+        lo[c] = fmin(lo[c], __shfl_xor(lo[c], off));
+        hi[c] = fmax(hi[c], __shfl_xor(hi[c], off));
+      }
+    if (lane == 0) {
+      red[32 + wave] = lo[0];
+      red[40 + wave] = hi[0];
+      red[48 + wave] = lo[1];
+      red[56 + wave] = hi[1];
+    }
+    for (int k = tid; k < TL_XB + NAGX * TL_YB + NAGX; k += WG) HX[k] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int w_ = 0; w_ < NW; ++w_) {
+      lo[0] = fmin(lo[0], red[32 + w_]);
+      hi[0] = fmax(hi[0], red[40 + w_]);
+      lo[1] = fmin(lo[1], red[48 + w_]);
+      hi[1] = fmax(hi[1], red[56 + w_]);
+    }
+    const double sx = hi[0] > lo[0] ? TL_XB / (hi[0] - lo[0]) : 0.0, sy = hi[1] > lo[1] ? TL_YB / (hi[1] - lo[1]) : 0.0;
+    auto xbin = [&](int i) { return min(TL_XB - 1, (int)((coords[2 * i] - lo[0]) * sx)); };
+    auto ybin = [&](int i) { return min(TL_YB - 1, (int)((coords[2 * i + 1] - lo[1]) * sy)); };
+    for (int i = tid; i < n; i += WG) atomicAdd(&HX[xbin(i)], 1);
+    __syncthreads();
+    {  // exclusive prefix sums of the 1 024 counts: two bins per thread, scan over the workgroup
+      const int c0 = HX[2 * tid], c1 = HX[2 * tid + 1];
+      int s_ = c0 + c1;
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t_ = __shfl_up(s_, off);
+        if (lane >= off) s_ += t_;
+      }
+      int* WT = SC + NAGX;                        // [NW] wave totals
+      if (lane == 63) WT[wave] = s_;
+      __syncthreads();
+      int before = 0;
+      for (int w_ = 0; w_ < wave; ++w_) before += WT[w_];
+      const int ex = before + s_ - c0 - c1;
+      HX[2 * tid] = ex;
+      HX[2 * tid + 1] = ex + c0;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += WG) {
+      const int st = min(NAGX - 1, (int)((long long)HX[xbin(i)] * NAGX / n));
+      ST[i] = (unsigned char)st;
+      atomicAdd(&SC[st], 1);
+      atomicAdd(&HY[st * TL_YB + ybin(i)], 1);
+    }
+    __syncthreads();
+    {  // per strip (= wave): exclusive prefix sums of its 256 counts, four bins per lane
+      int* h = HY + wave * TL_YB + 4 * lane;
+      const int c0 = h[0], c1 = h[1], c2 = h[2], c3 = h[3];
+      int s_ = c0 + c1 + c2 + c3;
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t_ = __shfl_up(s_, off);
+        if (lane >= off) s_ += t_;
+      }
+      const int ex = s_ - (c0 + c1 + c2 + c3);
+      h[0] = ex;
+      h[1] = ex + c0;
+      h[2] = ex + c0 + c1;
+      h[3] = ex + c0 + c1 + c2;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += WG) {
+      const int st = ST[i];
+      const int cell = min(NAGY - 1, (int)((long long)HY[st * TL_YB + ybin(i)] * NAGY / max(SC[st], 1)));
+      AG[i] = (unsigned char)(st * NAGY + cell);
+    }
+  }
+  // ---- coarse matrix (fp64, in p | q), its inverse, the fp32 copy
+  double* AC = p;
+  __syncthreads();
+  for (int e = tid; e < NAG * NAG; e += WG) AC[e] = 0.0;
+  __syncthreads();
+  {
+    const int nsl = (n + 63) >> 6;
+    for (int s_ = wave; s_ < nsl; s_ += NW) {
+      const int base = sl_off[s_], wd = (sl_off[s_ + 1] - base) >> 6;
+      const int row = (s_ << 6) + lane;
+      if (row < n) {
+        const int ar = AG[row] * NAG;
+        for (int j = 0; j < wd; ++j) {
+          const double av = A[base + lane + j * 64];
+          if (av != 0.0) atomicAdd(&AC[ar + AG[sl_col[base + lane + j * 64]]], av);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < NAG && AC[tid * NAG + tid] == 0.0) AC[tid * NAG + tid] = 1.0;   // (an empty aggregate)
+  __syncthreads();
+  {
+    constexpr int EPT = (NAG * NAG + WG - 1) / WG;
+    int ei_[EPT], ej_[EPT];
+#pragma unroll
+    for (int m = 0; m < EPT; ++m) {
+      const int e = tid + m * WG;
+      ei_[m] = e / NAG;
+      ej_[m] = e - ei_[m] * NAG;
+    }
+    for (int kk = 0; kk < NAG; ++kk) {
+      const double ip = 1.0 / AC[kk * NAG + kk];
+      double nv_[EPT];
+#pragma unroll
+      for (int m = 0; m < EPT; ++m) {
+        const int e = tid + m * WG;
+        nv_[m] = 0.0;
+        if (e < NAG * NAG) {
+          const int i = ei_[m], j = ej_[m];
+          const double aij = AC[e], aik = AC[i * NAG + kk], akj = AC[kk * NAG + j];
+          nv_[m] = i == kk ? (j == kk ? ip : akj * ip) : (j == kk ? -aik * ip : aij - aik * akj * ip);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < EPT; ++m) {
+        const int e = tid + m * WG;
+        if (e < NAG * NAG) AC[e] = nv_[m];
+      }
+      __syncthreads();
+    }
+    // fp32 copy, exactly symmetric: the entry of the upper triangle for both (i, j) and (j, i)
+#pragma unroll
+    for (int m = 0; m < EPT; ++m) {
+      const int e = tid + m * WG;
+      if (e < NAG * NAG) AI[e] = (float)AC[min(ei_[m], ej_[m]) * NAG + max(ei_[m], ej_[m])];
+    }
+  }
+  __syncthreads();
+  int rsel = 0;
+  double rz_old = 1.0;
+  int it = 0;
+  while (it < maxit) {
+    // ---- z = r + P A_c^-1 P^T r
+    if (lane < NAG) WP[wave * NAG + lane] = 0.0;
+    for (int i = tid; i < n; i += WG) atomicAdd(&WP[wave * NAG + AG[i]], r[i]);
+    __syncthreads();
+    if (tid < NAG * 8) {
+      const int I = tid >> 3, part = tid & 7;
+      double s_ = 0.0;
+      for (int J = part; J < NAG; J += 8) {
+        double w_ = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < NW; ++w2) w_ += WP[w2 * NAG + J];
+        s_ += (double)AI[I * NAG + J] * w_;
+      }
+      s_ += dpp_get<0xB1, 0xF>(s_);      // quad_perm [1,0,3,2]
+      s_ += dpp_get<0x4E, 0xF>(s_);      // quad_perm [2,3,0,1]
+      s_ += dpp_get<0x141, 0xF>(s_);     // row_half_mirror: the other quad of the group of 8
+      if (part == 0) YV[I] = s_;
+    }
+    __syncthreads();
+    double a0[1] = {0.0};
+    for (int i = tid; i < n; i += WG) {
+      const double ri = r[i], z = ri + YV[AG[i]];
+      q[i] = z;
+      a0[0] += ri * z;
+    }
+    block_sum1<1>(a0, red, rsel);
+    const double rz = a0[0];
+    const double beta = rz / rz_old;
+    rz_old = rz;
+    if (it == 0)
+      for (int i = tid; i < n; i += WG) p[i] = q[i];
+    else
+      for (int i = tid; i < n; i += WG) p[i] = q[i] + beta * p[i];
+    ++it;
+    __syncthreads();
+    double a1[1] = {0.0};
+    spmv_sell(sl_off, sl_col, A, p, n, [&](int row, double y0) {
+      q[row] = y0;
+      a1[0] += p[row] * y0;
+    });
+    block_sum1<1>(a1, red, rsel);
+    if (!(a1[0] > 0.0)) break;
+    const double alpha = rz / a1[0];
+    double a2[1] = {0.0};
+    for (int i = tid; i < n; i += WG) {
+      x[i] += alpha * p[i];
+      const double rn = r[i] - alpha * q[i];
+      r[i] = rn;
+      a2[0] += rn * rn;
+    }
+    block_sum1<1>(a2, red, rsel);
+    rr = a2[0];
+    if (!(rr > tol2)) break;
+  }
+  __syncthreads();
+  return it;
+}
+
+// the Krylov pressure solve of the kernels whose pressure vectors live in LDS (modes 0 / 4 / 5 / 7): two-level from
+// TL_AUTO_NV vertices on (pcg_degree 0 = auto) or on request (pcg_degree < 0), Jacobi-CG otherwise (pcg_degree > 0: always)
+#ifndef MDQ_TL_AUTO_NV
+#define MDQ_TL_AUTO_NV 2048
+#endif
+__device__ inline int pressure_krylov_lds(const mdq_ipcs_desc& d, bool k1_lds, int n, const int32_t* sl_off, const int32_t* sl_col,
+                                          const double* A, const double* coords, double* x, double* r, double* p, double* q,
+                                          int NVp, double* extra, double* red) {
+  int it = -1;
+  if (!k1_lds && (d.pcg_degree < 0 || (d.pcg_degree == 0 && n >= MDQ_TL_AUTO_NV)))
+    it = cg_pressure_2l_lds(n, sl_off, sl_col, A, coords, d.rtol, d.maxit_p, x, r, p, q, NVp, extra, red);
+  if (it < 0) it = cg_pressure(n, sl_off, sl_col, A, d.rtol, d.maxit_p, x, r, p, q, red);
+  return it;
+}
+
 #ifdef MDQ_AT_TRACE
 // debug build only: s_memtime deltas of thread 0 of environment 0 at the phase boundaries of at_velocity_kernel
 static __device__ long long mdq_at_trace_buf[16];
@@ -2579,7 +2841,10 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
       const PdView pd = pd_view(d, b);
       pressure_direct(pd, nv, pr, px, pp, pq, lK);
     } else {
-      it_p += cg_pressure(nv, so1, ci1, K1, d.rtol, d.maxit_p, px, pr, pp, pq, red);
+      if constexpr (PG)
+        it_p += cg_pressure(nv, so1, ci1, K1, d.rtol, d.maxit_p, px, pr, pp, pq, red);
+      else
+        it_p += pressure_krylov_lds(d, K1_LDS, nv, so1, ci1, K1, v.coords, px, pr, pp, pq, P.NVp, lK, red);
     }
     MDQ_STAMP(4)
     for (int i = tid; i < nv; i += WG) pnew[i] = px[i] / v.sdiagK[i];
@@ -3072,7 +3337,7 @@ __global__ __launch_bounds__(WG) void evolve_team_kernel(mdq_ipcs_desc d, int ns
         const PdView pd = pd_view(d, b);
         pressure_direct(pd, nv, pr, px, pp, pq, lK);
       } else {
-        it_p += cg_pressure(nv, so1, ci1, K1, d.rtol, d.maxit_p, px, pr, pp, pq, red);
+        it_p += pressure_krylov_lds(d, K1_LDS, nv, so1, ci1, K1, v.coords, px, pr, pp, pq, P.NVp, lK, red);
       }
       for (int i = tid; i < nv; i += WG) pnew[i] = px[i] / v.sdiagK[i];
     }
@@ -3516,7 +3781,7 @@ __global__ __launch_bounds__(WG) void evolve_team_tiles_kernel(mdq_ipcs_desc d, 
         const PdView pd = pd_view(d, b);
         pressure_direct(pd, nv, pr, px, pp, pq, lK);
       } else {
-        it_p += cg_pressure(nv, so1, ci1, K1, d.rtol, d.maxit_p, px, pr, pp, pq, red);
+        it_p += pressure_krylov_lds(d, K1_LDS, nv, so1, ci1, K1, v.coords, px, pr, pp, pq, P.NVp, lK, red);
       }
       for (int i = tid; i < nv; i += WG) pnew[i] = px[i] / v.sdiagK[i];
     }
