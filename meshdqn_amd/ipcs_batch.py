@@ -233,7 +233,9 @@ class IpcsBatch:
         # trades the one for the other.  pcg_degree < 0: two-level additive preconditioner (8 x 7 geometric aggregates, coarse
         # matrix inverted in LDS): 154 -> 86 iterations, but 465 us per solve in its first version (aggregation + inversion
         # ~0.1 ms, two more barriers and a coarse product per iteration).  Both kept as options (the reference's Krylov option
-        # is CG + AMG, flow_solver.py:152-155); the default is the Jacobi-CG.
+        # is CG + AMG, flow_solver.py:152-155); the default is the Jacobi-CG.  Meshes beyond mode 3 (pressure vectors in LDS,
+        # modes 0 / 4 / 5 / 7): 0 = auto, the two-level preconditioner with an O(n) aggregation from 2048 vertices on
+        # (cg_pressure_2l_lds: 325 -> 158 iterations on the refined ys930), > 0 = Jacobi-CG, < 0 = two-level wherever it fits.
         d.pcg_degree = int(pcg_degree)
         self.desc = d
         self.assembled = False

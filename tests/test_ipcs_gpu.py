@@ -401,6 +401,39 @@ def test_two_workgroups_per_environment_on_the_element_tiles(meshes, lib_built):
     assert np.array_equal(d5.cpu().numpy(), out["5"][0])
 
 
+@pytest.mark.parametrize("mode", [5, 7, 0])
+def test_two_level_pressure_cg_on_the_refined_mesh(meshes, lib_built, mode):
+    """cg_pressure_2l_lds: the Krylov pressure solve of the meshes beyond the LDS-resident velocity vectors (ys930
+    red-refined: 3 322 vertices) with the two-level additive preconditioner - O(n) aggregation by histograms, 8 x 7
+    aggregates, coarse matrix inverted in LDS - which `pcg_degree = 0` (auto) takes from 2048 vertices on; against the
+    Jacobi-CG (`pcg_degree = 1`) and the oracle's LU: the same answers to the solver tolerance, under 70 % of the
+    iterations; a batch whose environments differ (a coarsened copy: another aggregation per environment)."""
+    import torch
+    from meshdqn_amd.ipcs_batch import IpcsBatch, smooth_coords
+    from meshdqn_amd.mesh_ops import red_refine
+    from meshdqn_amd.topology import MeshTopology
+    from oracle.ipcs import OracleFlowSolver
+    coords, cells = meshes["ys930"]
+    x0 = smooth_coords(MeshTopology(coords, cells), 50)
+    rc, rcells = red_refine(x0, cells)
+    rt = MeshTopology(rc, rcells)
+    ora = OracleFlowSolver(rc, rcells, smooth=False)
+    ref = [ora.evolve() for _ in range(3)]
+    res = {}
+    for deg in (1, 0, -1):
+        b = IpcsBatch([rt, rt], [rc, rc], rtol=1e-12, mode=mode, pressure_direct=False, pcg_degree=deg)
+        for k in range(3):
+            d, l = b.evolve(1)
+            uo, po, do, lo = ref[k]
+            assert abs(d[0, 0].item() - do) < 1e-8 * abs(do) and abs(l[1, 0].item() - lo) < 1e-8 * abs(lo), (deg, k)
+        torch.cuda.synchronize()
+        p = b.p_n[0, :rt.nv].cpu().numpy()
+        assert np.abs(p - ref[2][1]).max() < 1e-8 * np.abs(ref[2][1]).max(), deg
+        res[deg] = b.iters.cpu().numpy()[0, 1] / 3.0
+    assert res[0] == res[-1] and res[0] < 0.7 * res[1], res
+    print(f"refined mesh, mode {mode}: pressure iterations per step Jacobi {res[1]:.0f}, two-level {res[0]:.0f}")
+
+
 def test_polynomial_preconditioned_pressure_cg_matches_oracle(meshes, lib_built):
     """The Krylov pressure solve of the three-kernel mode with the Chebyshev polynomial preconditioner (degree 4 and 8 on
     top of the Jacobi scaling) and with the two-level additive preconditioner (geometric aggregates, coarse matrix inverted
