@@ -2958,6 +2958,7 @@ struct Team {
   unsigned epoch;
   int par;
   bool local;        // both workgroups run on the same XCD (team_place): the barrier need not go beyond that XCD's L2
+  int rbeg, rend;    // mode 7: the rows of this workgroup in the vector passes and the epilogues
 };
 // The agent-scope fences of the general barrier write the XCD's L2 back and invalidate it - what an environment re-reads in
 // every operator application (0.7 MB of element metadata on the refined mesh) is gone after every barrier: measured on the
@@ -3492,7 +3493,7 @@ __device__ __forceinline__ void tile_apply_team(const EnvView& v, Team& T, bool 
       for (int i = 0; i < 6; ++i) es2[e * 6 + i] = ye[i];
     }
     team_sync(T);
-    for (int row = gt; row < n; row += GS) {
+    for (int row = T.rbeg + tid; row < T.rend; row += WG) {
       double2 a = make_double2(0.0, 0.0);
       for (int s = v.g2_ptr[row]; s < v.g2_ptr[row + 1]; ++s) {
         const double2 c = es2[v.g2_src[s]];
@@ -3506,16 +3507,16 @@ __device__ __forceinline__ void tile_apply_team(const EnvView& v, Team& T, bool 
   tile_chunks_global(v, packed, es, T.rank ? y1v : y0v, gx, op, T.rank, TEAM, false);
   team_sync(T);
   constexpr int EB = 4;
-  for (int row0 = gt; row0 < n; row0 += EB * GS) {
+  for (int row0 = T.rbeg + tid; row0 < T.rend; row0 += EB * WG) {
     double2 a[EB], c[EB];
 #pragma unroll
     for (int k = 0; k < EB; ++k) {
-      a[k] = y0v[min(row0 + k * GS, n - 1)];
-      c[k] = y1v[min(row0 + k * GS, n - 1)];
+      a[k] = y0v[min(row0 + k * WG, n - 1)];
+      c[k] = y1v[min(row0 + k * WG, n - 1)];
     }
 #pragma unroll
     for (int k = 0; k < EB; ++k)
-      if (row0 + k * GS < n) epi(row0 + k * GS, a[k].x + c[k].x, a[k].y + c[k].y);
+      if (row0 + k * WG < T.rend) epi(row0 + k * WG, a[k].x + c[k].x, a[k].y + c[k].y);
   }
 }
 
@@ -3568,6 +3569,16 @@ __global__ __launch_bounds__(WG) void evolve_team_tiles_kernel(mdq_ipcs_desc d, 
   T.slot = spare + 9;
   T.epoch = 0;
   T.par = 0;
+  {
+    // the rows of the vector passes and the epilogues: CONTIGUOUS halves (8.45 -> 8.2 ms per step of 128 refined meshes
+    // against rows dealt out alternately over the 1 024 threads: the two CUs no longer write into the same lines).  With
+    // an odd number of chunks workgroup 0 applies one more, but moving rows to the other workgroup to make up for it was
+    // measured slower both ways (0.32 / 0.61 of the rows to workgroup 0: 9.1 / 8.8 ms)
+    int split = n2 / 2;
+    split &= ~63;
+    T.rbeg = rank ? split : 0;
+    T.rend = rank ? n2 : split;
+  }
   const int nsl1 = (nv + 63) >> 6;
   const int32_t* so1 = K1_LDS ? lso : v.sl1_off;
   const int32_t* ci1 = K1_LDS ? lci : v.sl1_col;
@@ -3621,7 +3632,7 @@ __global__ __launch_bounds__(WG) void evolve_team_tiles_kernel(mdq_ipcs_desc d, 
     team_sync(T);
     double acc[2] = {0.0, 0.0};
     const int nhist = (int)hcnt[0];
-    for (int i = gt; i < n2; i += GS) {
+    for (int i = T.rbeg + tid; i < T.rend; i += WG) {
       double2 f = make_double2(0.0, 0.0);
       for (int s_ = v.g2_ptr[i]; s_ < v.g2_ptr[i + 1]; ++s_) {
         const double2 c = escr2[v.g2_src[s_]];
@@ -3675,7 +3686,7 @@ __global__ __launch_bounds__(WG) void evolve_team_tiles_kernel(mdq_ipcs_desc d, 
         while (it < d.maxit_u) {
           ++it;
           const double beta = (rho / rho_old) * (alpha / omega);
-          for (int i = gt; i < n2; i += GS) {
+          for (int i = T.rbeg + tid; i < T.rend; i += WG) {
             const double2 ri = vr[i], pi = vp[i], vi = vv[i];
             vp[i] = make_double2(ri.x + beta * (pi.x - omega * vi.x), ri.y + beta * (pi.y - omega * vi.y));
           }
@@ -3690,7 +3701,7 @@ __global__ __launch_bounds__(WG) void evolve_team_tiles_kernel(mdq_ipcs_desc d, 
           if (a1[0] == 0.0) break;
           alpha = rho / a1[0];
           double a2[1] = {0.0};
-          for (int i = gt; i < n2; i += GS) {
+          for (int i = T.rbeg + tid; i < T.rend; i += WG) {
             const double2 ri = vr[i], vi = vv[i];
             const double2 sv = make_double2(ri.x - alpha * vi.x, ri.y - alpha * vi.y);
             vr[i] = sv;
@@ -3698,7 +3709,7 @@ __global__ __launch_bounds__(WG) void evolve_team_tiles_kernel(mdq_ipcs_desc d, 
           }
           team_sum<1>(a2, red, T);       // (its team barrier also publishes s)
           if (!(a2[0] > tol2)) {
-            for (int i = gt; i < n2; i += GS) {
+            for (int i = T.rbeg + tid; i < T.rend; i += WG) {
               const double2 xi = xs[i], pi = vp[i];
               xs[i] = make_double2(xi.x + alpha * pi.x, xi.y + alpha * pi.y);
             }
@@ -3715,7 +3726,7 @@ __global__ __launch_bounds__(WG) void evolve_team_tiles_kernel(mdq_ipcs_desc d, 
           if (a3[1] == 0.0) break;
           omega = a3[0] / a3[1];
           double a4[2] = {0.0, 0.0};
-          for (int i = gt; i < n2; i += GS) {
+          for (int i = T.rbeg + tid; i < T.rend; i += WG) {
             const double2 ti = vt[i], xi = xs[i], pi = vp[i], si = vr[i], hi = vh[i];
             xs[i] = make_double2(xi.x + alpha * pi.x + omega * si.x, xi.y + alpha * pi.y + omega * si.y);
             const double2 rn = make_double2(si.x - omega * ti.x, si.y - omega * ti.y);
@@ -3734,7 +3745,7 @@ __global__ __launch_bounds__(WG) void evolve_team_tiles_kernel(mdq_ipcs_desc d, 
       }
     }
     team_sync(T);
-    for (int i = gt; i < n2; i += GS) {  // history, newest first
+    for (int i = T.rbeg + tid; i < T.rend; i += WG) {  // history, newest first
       if (nhist >= 4) h5[i] = h4[i];
       if (nhist >= 3) h4[i] = h3[i];
       if (nhist >= 2) h3[i] = h2[i];
@@ -3803,7 +3814,7 @@ __global__ __launch_bounds__(WG) void evolve_team_tiles_kernel(mdq_ipcs_desc d, 
     }
     team_sync(T);
     double am[2] = {0.0, 0.0};
-    for (int i = gt; i < n2; i += GS) {
+    for (int i = T.rbeg + tid; i < T.rend; i += WG) {
       double2 f = make_double2(0.0, 0.0);
       for (int s_ = v.g2_ptr[i]; s_ < v.g2_ptr[i + 1]; ++s_) {
         const double2 c = escr2[v.g2_src[s_]];
@@ -3830,7 +3841,7 @@ __global__ __launch_bounds__(WG) void evolve_team_tiles_kernel(mdq_ipcs_desc d, 
       am[1] += r0.x * r0.x + r0.y * r0.y;
     });
     team_sum<2>(am, red, T);          // (every gather of x0 from `stage` is behind its team barrier)
-    for (int i = gt; i < n2; i += GS) {
+    for (int i = T.rbeg + tid; i < T.rend; i += WG) {
       const double is = 1.0 / v.sdiagM[i];
       const double2 p0 = vp[i];
       stage[i] = make_double2(p0.x * is, p0.y * is);
@@ -3853,7 +3864,7 @@ __global__ __launch_bounds__(WG) void evolve_team_tiles_kernel(mdq_ipcs_desc d, 
           if (!(a1[0] > 0.0)) break;
           const double alpha = rr / a1[0];
           double a2[1] = {0.0};
-          for (int i = gt; i < n2; i += GS) {
+          for (int i = T.rbeg + tid; i < T.rend; i += WG) {
             const double2 xi = xs[i], pi = vp[i], ri = vr[i], qi = vv[i];
             xs[i] = make_double2(xi.x + alpha * pi.x, xi.y + alpha * pi.y);
             const double2 rn = make_double2(ri.x - alpha * qi.x, ri.y - alpha * qi.y);
@@ -3865,7 +3876,7 @@ __global__ __launch_bounds__(WG) void evolve_team_tiles_kernel(mdq_ipcs_desc d, 
           if (!(rr_new > tol2)) break;
           const double beta = rr_new / rr;
           rr = rr_new;
-          for (int i = gt; i < n2; i += GS) {
+          for (int i = T.rbeg + tid; i < T.rend; i += WG) {
             const double2 ri = vr[i], pi = vp[i];
             const double2 pn = make_double2(ri.x + beta * pi.x, ri.y + beta * pi.y);
             vp[i] = pn;
@@ -3879,7 +3890,7 @@ __global__ __launch_bounds__(WG) void evolve_team_tiles_kernel(mdq_ipcs_desc d, 
     }
     team_sync(T);
     // ---------------- update state + probes
-    for (int i = gt; i < n2; i += GS) {
+    for (int i = T.rbeg + tid; i < T.rend; i += WG) {
       const double sd = v.sdiagM[i];
       const double2 x = xs[i];
       v.u_n[i] = make_double2(x.x / sd, x.y / sd);
