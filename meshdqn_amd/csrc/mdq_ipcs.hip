@@ -3001,16 +3001,14 @@ __device__ __forceinline__ void team_sync(Team& t) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 // the placement check at kernel start (through the general barrier); `ids`: two words of the environment's slab
-__device__ __forceinline__ void team_place(Team& t, unsigned* ids) {
+__device__ __forceinline__ void team_place(Team& t, unsigned* ids, int general) {
   t.local = false;
   if (threadIdx.x == 0) __hip_atomic_store(ids + t.rank, xcc_id() + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   team_sync(t);
   const unsigned i0 = __hip_atomic_load(ids, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned i1 = __hip_atomic_load(ids + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   static_assert(TEAM == 2, "two ids");
-#ifndef MDQ_TEAM_GENERAL_BARRIER
-  t.local = i0 == i1;
-#endif
+  t.local = i0 == i1 && !general;     // (`general`: MDQ_TEAM_GENERAL_BARRIER=1 keeps the placement-independent protocol - tests)
 }
 template <int N>
 __device__ __forceinline__ void team_sum(double (&v)[N], double* red, Team& t) {
@@ -3062,7 +3060,7 @@ static __global__ void team_reset_kernel(mdq_ipcs_desc d) {
 
 template <bool K1_LDS>
 __global__ __launch_bounds__(WG) void evolve_team_kernel(mdq_ipcs_desc d, int nsteps, double* drag, double* lift,
-                                                          int32_t* iters) {
+                                                          int32_t* iters, int general) {
   extern __shared__ __align__(16) double smem[];
   // teams on neighbouring-by-8 block ids: with the dispatcher's round-robin both workgroups tend to share an XCD's L2
   // (a speed choice only: the protocol is placement-independent)
@@ -3152,7 +3150,7 @@ __global__ __launch_bounds__(WG) void evolve_team_kernel(mdq_ipcs_desc d, int ns
       if (row < n2) epi(row, y0, y1);
     }
   };
-  team_place(T, reinterpret_cast<unsigned*>(spare + 25));
+  team_place(T, reinterpret_cast<unsigned*>(spare + 25), general);
   for (int step = 0; step < nsteps; ++step) {
     // ---------------- step 1: tentative velocity
     for (int e = gt; e < v.nt; e += GS) {
@@ -3450,6 +3448,10 @@ __global__ __launch_bounds__(WG) void evolve_team_kernel(mdq_ipcs_desc d, int ns
   }
 }
 
+// MDQ_TEAM_GENERAL_BARRIER=1 (read per launch): the teams keep the placement-independent agent-scope barrier even when both
+// workgroups share an XCD - the same arithmetic, so the same bits (tests/test_ipcs_gpu.py), at 2-3x the step time
+static int team_general_barrier() { return std::getenv("MDQ_TEAM_GENERAL_BARRIER") != nullptr ? 1 : 0; }
+
 template <bool K1_LDS>
 static hipError_t launch_evolve_team(const mdq_ipcs_desc* d, size_t lds, int nsteps, double* drag, double* lift,
                                      int32_t* iters, hipStream_t stream) {
@@ -3459,7 +3461,7 @@ static hipError_t launch_evolve_team(const mdq_ipcs_desc* d, size_t lds, int nst
   hipLaunchKernelGGL(team_reset_kernel, dim3((d->B + 63) / 64), dim3(64), 0, stream, *d);
   const int teams8 = (d->B + 7) / 8;                       // blocks: groups of 8 environments x TEAM ranks
   hipLaunchKernelGGL((evolve_team_kernel<K1_LDS>), dim3(teams8 * 8 * TEAM), dim3(WG), lds, stream, *d, nsteps, drag, lift,
-                     iters);
+                     iters, team_general_barrier());
   return hipGetLastError();
 }
 
@@ -3522,7 +3524,7 @@ __device__ __forceinline__ void tile_apply_team(const EnvView& v, Team& T, bool 
 
 template <bool K1_LDS>
 __global__ __launch_bounds__(WG) void evolve_team_tiles_kernel(mdq_ipcs_desc d, int nsteps, double* drag, double* lift,
-                                                                int32_t* iters) {
+                                                                int32_t* iters, int general) {
   extern __shared__ __align__(16) double smem[];
   const int q = blockIdx.x / (8 * TEAM), r8 = blockIdx.x % (8 * TEAM);
   const int b = q * 8 + (r8 & 7), rank = r8 >> 3;
@@ -3606,7 +3608,7 @@ __global__ __launch_bounds__(WG) void evolve_team_tiles_kernel(mdq_ipcs_desc d, 
           epi(row, y0 * is, y1 * is);
         });
   };
-  team_place(T, reinterpret_cast<unsigned*>(spare + 25));
+  team_place(T, reinterpret_cast<unsigned*>(spare + 25), general);
   for (int step = 0; step < nsteps; ++step) {
     // ---------------- step 1: tentative velocity
     for (int e = gt; e < v.nt; e += GS) {
@@ -3923,7 +3925,7 @@ static hipError_t launch_evolve_team_tiles(const mdq_ipcs_desc* d, size_t lds, i
   hipLaunchKernelGGL(team_reset_kernel, dim3((d->B + 63) / 64), dim3(64), 0, stream, *d);
   const int teams8 = (d->B + 7) / 8;                       // blocks: groups of 8 environments x TEAM ranks
   hipLaunchKernelGGL((evolve_team_tiles_kernel<K1_LDS>), dim3(teams8 * 8 * TEAM), dim3(WG), lds, stream, *d, nsteps, drag,
-                     lift, iters);
+                     lift, iters, team_general_barrier());
   return hipGetLastError();
 }
 

@@ -399,6 +399,24 @@ def test_two_workgroups_per_environment_on_the_element_tiles(meshes, lib_built):
     finally:
         del os.environ["MDQ_NO_TEAM_TILES"]
     assert np.array_equal(d5.cpu().numpy(), out["5"][0])
+    # the team barrier that stays inside the XCD (what ran above, when both workgroups of a team were placed on one XCD)
+    # and the placement-independent agent-scope barrier (MDQ_TEAM_GENERAL_BARRIER=1, read per launch) order the same
+    # arithmetic: the same bits, for the tiles (mode 7) and for the assembled operators (mode 4)
+    for mode in (7, 4):
+        res = []
+        for general in (False, True):
+            if general:
+                os.environ["MDQ_TEAM_GENERAL_BARRIER"] = "1"
+            try:
+                bb = IpcsBatch([rt] * 4 + [t0], [rc] * 4 + [x0], rtol=1e-10, mode=mode, pressure_direct=False)
+                d, l = bb.evolve(4)
+                torch.cuda.synchronize()
+            finally:
+                os.environ.pop("MDQ_TEAM_GENERAL_BARRIER", None)
+            res.append((d.cpu().numpy(), l.cpu().numpy(), bb.u_n.cpu().numpy(), bb.p_n.cpu().numpy()))
+        assert np.isfinite(res[0][0]).all()
+        for a_, b_ in zip(*res):
+            assert np.array_equal(a_, b_), mode
 
 
 @pytest.mark.parametrize("mode", [5, 7, 0])
