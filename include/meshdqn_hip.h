@@ -139,10 +139,11 @@ typedef struct mdq_ipcs_desc {
                                   operator applications per iteration, no extra reductions); 0 / 1 = Jacobi only;
                                   < 0 = two-level additive preconditioner (8 x 7 geometric aggregates, coarse matrix
                                   inverted in LDS): fewer operator applications (167 -> ~100 iterations on ys930).
-                                  The modes whose pressure vectors live in LDS (0 / 4 / 5 / 7: the meshes beyond mode 3):
-                                  0 = auto - Jacobi-CG below 2048 vertices, the two-level preconditioner with an O(n)
-                                  aggregation from there (refined ys930, 3 322 vertices: 325 -> 158 iterations) -,
-                                  < 0 = two-level wherever its LDS scratch fits, > 0 = Jacobi-CG */
+                                  Modes 0 / 4 / 5 / 7 (the meshes beyond mode 3; pressure vectors in LDS or, beyond
+                                  ~4 000 vertices, in the workspace): 0 = auto - Jacobi-CG below 2048 vertices, the two-level
+                                  preconditioner with an O(n) aggregation from there (refined ys930, 3 322 vertices: 325 ->
+                                  158 iterations; refined twice, 12 924 vertices: 833 -> 470) -, < 0 = two-level wherever its
+                                  scratch fits, > 0 = Jacobi-CG */
   const int32_t* pd_hdr;       /* [B][4]  nI, nG, nparts, 0                       */
   const int32_t* pd_node;      /* [B][NV] node id of permuted position (interiors by subdomain, then separator) */
   const int32_t* pd_meta;      /* [B][NPART][6] q0, m, W offset, F offset, g, gidx offset */

@@ -2129,20 +2129,23 @@ __device__ inline int cg_pressure_2l(int n, const int32_t* sl_off, const int32_t
 // equal population, per strip a 256-bin histogram of y cut into NAGY cells; vertices of one fine bin share a strip / cell,
 // an empty aggregate gets a unit diagonal - and one-barrier reductions.  Scratch: the histograms and then the fp64 coarse
 // matrix in the p | q vectors (free until the first search direction), the fp32 inverse, the per-wave partial
-// restrictions and the aggregate of every vertex in `extra` (the fifth LDS vector, the direct solver's scratch).
-// Returns -1 where it does not apply (too few vertices, LDS scratch too small): the caller runs cg_pressure.
+// restrictions and the aggregate of every vertex in `extra` (LDS: the fifth pressure vector, the direct solver's scratch).
+// The four CG vectors may as well live in GLOBAL memory (meshes beyond ~4 000 vertices, the PG instances of the kernels:
+// `scratch` is then the search direction's slab vector, `extra` the LDS the pressure vectors do not occupy).
+// Returns -1 where it does not apply (too few vertices, a scratch too small): the caller runs cg_pressure.
 constexpr int TL_XB = 1024, TL_YB = 256;
 __host__ __device__ inline size_t tl_extra_bytes(int n) {
   return sizeof(float) * NAG * NAG + sizeof(double) * ((WG / 64) * NAG + NAG) + (size_t)((n + 7) & ~7);
 }
 __device__ __attribute__((noinline)) int cg_pressure_2l_lds(int n, const int32_t* sl_off, const int32_t* sl_col, const double* A, const double* coords,
-                                         double rtol, int maxit, double* x, double* r, double* p, double* q, int NVp,
-                                         double* extra, double* red) {
+                                         double rtol, int maxit, double* x, double* r, double* p, double* q,
+                                         size_t scratch_bytes, double* extra, size_t extra_bytes, double* red) {
   constexpr int NW = WG / 64;
   static_assert(NW == NAGX, "one wave per strip in the y pass");
   static_assert(sizeof(float) * NAG * NAG % 8 == 0, "alignment of the partial restrictions");
-  if (n < 4 * NAG || tl_extra_bytes(n) > sizeof(double) * (size_t)NVp || 2 * (size_t)NVp < (size_t)NAG * NAG ||
-      2 * sizeof(double) * (size_t)NVp < sizeof(int) * (TL_XB + NAGX * TL_YB + 2 * NAGX) + (size_t)n)
+  // (`scratch_bytes`: what is contiguous behind p - p | q in LDS, the slab vector of p in global memory)
+  if (n < 4 * NAG || tl_extra_bytes(n) > extra_bytes || scratch_bytes < sizeof(double) * NAG * NAG ||
+      scratch_bytes < sizeof(int) * (TL_XB + NAGX * TL_YB + 2 * NAGX) + (size_t)n)
     return -1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* AI = reinterpret_cast<float*>(extra);                             // [NAG][NAG] inverse of the coarse matrix
@@ -2248,7 +2251,9 @@ __device__ __attribute__((noinline)) int cg_pressure_2l_lds(int n, const int32_t
     }
   }
   // ---- coarse matrix (fp64, in p | q), its inverse, the fp32 copy
-  double* AC = p;
+  // (in LDS behind the tables when `extra` has the room - the instances with global vectors -, else in the scratch)
+  double* AC = extra_bytes >= tl_extra_bytes(n) + sizeof(double) * NAG * NAG
+                   ? reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(extra) + tl_extra_bytes(n)) : p;
   __syncthreads();
   for (int e = tid; e < NAG * NAG; e += WG) AC[e] = 0.0;
   __syncthreads();
@@ -2376,10 +2381,10 @@ __device__ __attribute__((noinline)) int cg_pressure_2l_lds(int n, const int32_t
 #endif
 __device__ inline int pressure_krylov_lds(const mdq_ipcs_desc& d, bool k1_lds, int n, const int32_t* sl_off, const int32_t* sl_col,
                                           const double* A, const double* coords, double* x, double* r, double* p, double* q,
-                                          int NVp, double* extra, double* red) {
+                                          size_t scratch_bytes, double* extra, size_t extra_bytes, double* red) {
   int it = -1;
   if (!k1_lds && (d.pcg_degree < 0 || (d.pcg_degree == 0 && n >= MDQ_TL_AUTO_NV)))
-    it = cg_pressure_2l_lds(n, sl_off, sl_col, A, coords, d.rtol, d.maxit_p, x, r, p, q, NVp, extra, red);
+    it = cg_pressure_2l_lds(n, sl_off, sl_col, A, coords, d.rtol, d.maxit_p, x, r, p, q, scratch_bytes, extra, extra_bytes, red);
   if (it < 0) it = cg_pressure(n, sl_off, sl_col, A, d.rtol, d.maxit_p, x, r, p, q, red);
   return it;
 }
@@ -2841,10 +2846,12 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
       const PdView pd = pd_view(d, b);
       pressure_direct(pd, nv, pr, px, pp, pq, lK);
     } else {
-      if constexpr (PG)
-        it_p += cg_pressure(nv, so1, ci1, K1, d.rtol, d.maxit_p, px, pr, pp, pq, red);
+      if constexpr (PG)      // (vectors in the slab - pp is a 2 N2-double vector there -, the preconditioner's tables in the LDS they leave free)
+        it_p += pressure_krylov_lds(d, false, nv, so1, ci1, K1, v.coords, px, pr, pp, pq, 2 * sizeof(double) * (size_t)d.N2, U,
+                                    MODE == 5 ? sizeof(double2) * 6 * MF_CH : tl_extra_bytes(d.NV) + sizeof(double) * NAG * NAG, red);
       else
-        it_p += pressure_krylov_lds(d, K1_LDS, nv, so1, ci1, K1, v.coords, px, pr, pp, pq, P.NVp, lK, red);
+        it_p += pressure_krylov_lds(d, K1_LDS, nv, so1, ci1, K1, v.coords, px, pr, pp, pq, 2 * sizeof(double) * (size_t)P.NVp, lK,
+                                    sizeof(double) * (size_t)P.NVp, red);
     }
     MDQ_STAMP(4)
     for (int i = tid; i < nv; i += WG) pnew[i] = px[i] / v.sdiagK[i];
@@ -3336,7 +3343,8 @@ __global__ __launch_bounds__(WG) void evolve_team_kernel(mdq_ipcs_desc d, int ns
         const PdView pd = pd_view(d, b);
         pressure_direct(pd, nv, pr, px, pp, pq, lK);
       } else {
-        it_p += pressure_krylov_lds(d, K1_LDS, nv, so1, ci1, K1, v.coords, px, pr, pp, pq, P.NVp, lK, red);
+        it_p += pressure_krylov_lds(d, K1_LDS, nv, so1, ci1, K1, v.coords, px, pr, pp, pq, 2 * sizeof(double) * (size_t)P.NVp, lK,
+                                    sizeof(double) * (size_t)P.NVp, red);
       }
       for (int i = tid; i < nv; i += WG) pnew[i] = px[i] / v.sdiagK[i];
     }
@@ -3794,7 +3802,8 @@ __global__ __launch_bounds__(WG) void evolve_team_tiles_kernel(mdq_ipcs_desc d, 
         const PdView pd = pd_view(d, b);
         pressure_direct(pd, nv, pr, px, pp, pq, lK);
       } else {
-        it_p += pressure_krylov_lds(d, K1_LDS, nv, so1, ci1, K1, v.coords, px, pr, pp, pq, P.NVp, lK, red);
+        it_p += pressure_krylov_lds(d, K1_LDS, nv, so1, ci1, K1, v.coords, px, pr, pp, pq, 2 * sizeof(double) * (size_t)P.NVp, lK,
+                                    sizeof(double) * (size_t)P.NVp, red);
       }
       for (int i = tid; i < nv; i += WG) pnew[i] = px[i] / v.sdiagK[i];
     }
@@ -5698,7 +5707,8 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
     return fail_msg("modes 5 / 7 need cell_outflow and the tile maps (mf_scat, mf_tptr) or the dof <- slot lists (g2_ptr, g2_src)");
   if (pg && mode != 0 && mode != 5)
     return fail_msg("mesh too large for the LDS-resident pressure vectors of this operator mode (use mode -1, 0 or 5)");
-  size_t u = pg ? 0 : P.prs_vec_bytes + (k1_lds ? P.prs_mat_bytes : 0);  // (K1 values alias the scratch vector: CG does not use it)
+  // (K1 values alias the scratch vector: CG does not use it; pg: the tables of the two-level preconditioner)
+  size_t u = pg ? tl_extra_bytes(d->NV) + sizeof(double) * NAG * NAG : P.prs_vec_bytes + (k1_lds ? P.prs_mat_bytes : 0);
   const size_t vel = mode == 3 ? P.vel3_bytes : (mode == 2 ? P.vel2_bytes : (mode == 1 ? P.vel1_bytes : ((mode == 5 || mode == 7) ? tile_bytes : 0)));
   if (vel > u) u = vel;
   const size_t lds = red_bytes + u;
