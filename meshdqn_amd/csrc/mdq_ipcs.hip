@@ -54,11 +54,22 @@ constexpr int MF_CH = 1024;  // triangles per LDS tile: 2 per thread, interleave
 
 // ------------------------------------------------------------------ per-environment views
 
+// mode 7: bytes that say which rows a workgroup's chunks touch, and which entries of the chunks' row lists are the FIRST
+// touch of their row by that workgroup (a chunk's list holds at most min(N2, 6 MF_CH) rows), in doubles
+__host__ __device__ inline int64_t work_touch_row_cap(int NV, int NE) {
+  const int64_t N2 = (int64_t)NV + NE;
+  return N2 < 6 * 1024 ? N2 : 6 * 1024;
+}
+__host__ __device__ inline int64_t work_touch_doubles(int NV, int NT, int NE) {
+  const int64_t N2 = (int64_t)NV + NE, nch = ((int64_t)NT + 1023) / 1024;
+  return (2 * N2 + nch * work_touch_row_cap(NV, NE) + 7) / 8 + 2;
+}
 __host__ __device__ inline int64_t work_per_env(int NV, int NT, int NE) {
   const int64_t N2 = (int64_t)NV + NE;
   // escr 12*NT | 6 velocity vectors (double2[N2]) | p_new[NV] | 24 spare | assembled modes: 5 history vectors + counter |
   // mode 5: the accumulation vector of the tile application (double2[N2]) | mode 7: the second workgroup's accumulation vector
-  const int64_t n = 12 * (int64_t)NT + 12 * N2 + NV + 26 + 10 * N2 + 2 + 2 * N2 + 2 + 2 * N2 + 2;
+  // | mode 7: touched-row bytes of the two workgroups (2 N2) + first-touch bytes of every chunk's row list
+  const int64_t n = 12 * (int64_t)NT + 12 * N2 + NV + 26 + 10 * N2 + 2 + 2 * N2 + 2 + 2 * N2 + 2 + work_touch_doubles(NV, NT, NE);
   return (n + 31) & ~(int64_t)31;  // keep every environment's slab 256-byte aligned
 }
 // offset (in doubles, even) of the tentative-velocity history of the assembled modes 0-2 inside an environment's slab
@@ -72,6 +83,12 @@ __host__ __device__ inline int64_t work_hist_offset(int NV, int NT, int NE) {
 __host__ __device__ inline int64_t work_ytmp_offset(int NV, int NT, int NE) {
   const int64_t N2 = (int64_t)NV + NE;
   return (work_hist_offset(NV, NT, NE) + 10 * N2 + 2 + 1) & ~(int64_t)1;
+}
+
+// offset (in doubles) of mode 7's touch bytes: behind the second accumulation vector
+__host__ __device__ inline int64_t work_touch_offset(int NV, int NT, int NE) {
+  const int64_t N2 = (int64_t)NV + NE;
+  return work_ytmp_offset(NV, NT, NE) + 4 * N2 + 4;
 }
 
 // mode 5 with the chunk's input rows staged in LDS behind the element tile: does the stage (NRL rows) fit?
@@ -1018,7 +1035,8 @@ extern "C" MDQ_API int mdq_t5_trace_host(long long* out, int reset) {
 // when this call walks all chunks in that order; otherwise the vector is zero-filled first.
 template <class ElemOp>
 __device__ __forceinline__ void tile_chunks_global(const EnvView& v, bool packed, double2* es, double2* ytmp, const double2* gx,
-                                                   ElemOp op, int c0, int cs, bool flags_ok) {
+                                                   ElemOp op, int c0, int cs, bool flags_ok,
+                                                   const unsigned char* firstb = nullptr, int first_stride = 0) {
   const int tid = threadIdx.x, n = v.n2;
   const int nch = (v.nt + MF_CH - 1) / MF_CH;
 #ifdef MDQ_T5_TRACE
@@ -1030,7 +1048,9 @@ __device__ __forceinline__ void tile_chunks_global(const EnvView& v, bool packed
   // over the rows at the end (two more vector streams saved) was measured SLOWER, 10.52 ms: the epilogue's own loads then
   // sit one row at a time inside the row loop instead of four rows in flight
   const bool rlf = flags_ok && v.mf_rlist && v.rl_flags != 0;
-  if (!rlf)
+  // (firstb, mode 7: first-touch bytes of THIS walk's chunks - one per entry of a chunk's row list, see team_touch_setup)
+  const bool fb = firstb != nullptr && v.mf_rlist;
+  if (!rlf && !fb)
     for (int row = tid; row < n; row += WG) ytmp[row] = make_double2(0.0, 0.0);   // (own rows: visible to the row phases behind the barriers)
   double2* xst = es + 6 * MF_CH;                        // (staged input rows of the chunk: behind the tile, mf_lpos only)
   for (int chunk = c0; chunk < nch; chunk += cs) {
@@ -1086,12 +1106,18 @@ __device__ __forceinline__ void tile_chunks_global(const EnvView& v, bool packed
       for (int k0 = tid; k0 < nr; k0 += RB * WG) {
         int2 en[RB];
         double2 a[RB];
+        unsigned fmask = 0;
 #pragma unroll
         for (int k = 0; k < RB; ++k) en[k] = rl[min(k0 + k * WG, nr - 1)];
+        if (fb) {
+          const unsigned char* fbc = firstb + (size_t)chunk * first_stride;
+#pragma unroll
+          for (int k = 0; k < RB; ++k) fmask |= fbc[min(k0 + k * WG, nr - 1)] ? 1u << k : 0u;
+        }
 #pragma unroll
         for (int k = 0; k < RB; ++k) {
           a[k] = make_double2(0.0, 0.0);
-          if (!(rlf && en[k].x < 0)) a[k] = ytmp[en[k].x & 0x3FFFFFFF];
+          if (!((rlf && en[k].x < 0) || ((fmask >> k) & 1u))) a[k] = ytmp[en[k].x & 0x3FFFFFFF];
         }
 #pragma unroll
         for (int k = 0; k < RB; ++k) {
@@ -3485,9 +3511,40 @@ static hipError_t launch_evolve_team(const mdq_ipcs_desc* d, size_t lds, int nst
 // NOT bitwise mode 5: a row's sum is (chunks 0, 2, 4, ..) + (chunks 1, 3, 5, ..) instead of chunk after chunk.  Without
 // tile maps (index data built on the device) the element results go to the slab's element scratch, triangles and rows
 // dealt out over the team.  Right-hand sides, the pressure solve (rank 0) and the probes: as in mode 4.
+// Which rows a workgroup's chunks touch (t0 / t1: one byte per row) and which entries of its chunks' row lists are the first
+// touch of their row in the workgroup's walk (first: one byte per entry) - built once per launch from the row lists: a
+// tile application then neither zero-fills the two accumulation vectors nor reads a partial sum that does not exist
+// (per application of the refined mesh 1.32 -> 0.57 MB of the ~2.9 MB the workgroups move; the zero fill + full reads were
+// what the first version of mode 7 moved more than mode 5, 38.4 against 32.1 GB per step of 128 environments).
+struct TeamTouch {
+  unsigned char *t0, *t1, *first;   // (first == nullptr: no row lists - zero fill and full reads)
+  int stride;                       // entries of `first` per chunk
+};
+__device__ inline void team_touch_setup(const EnvView& v, const Team& T, TeamTouch& tt) {
+  if (!v.mf_rlist || !v.mf_tptr) {
+    tt.first = nullptr;
+    return;
+  }
+  const int tid = threadIdx.x, n = v.n2, nch = (v.nt + MF_CH - 1) / MF_CH;
+  unsigned char* tm = T.rank ? tt.t1 : tt.t0;
+  for (int row = tid; row < n; row += WG) tm[row] = 0;
+  __syncthreads();
+  for (int chunk = T.rank; chunk < nch; chunk += TEAM) {
+    const int2* rl = reinterpret_cast<const int2*>(v.mf_rlist) + (size_t)chunk * v.NRL;
+    const int nr = v.mf_rcnt[chunk];
+    unsigned char* fbc = tt.first + (size_t)chunk * tt.stride;
+    for (int k = tid; k < nr; k += WG) {      // (a row appears once per chunk: its byte is read and set by one thread)
+      const int row = rl[k].x & 0x3FFFFFFF;
+      fbc[k] = tm[row] == 0;
+      tm[row] = 1;
+    }
+    __syncthreads();
+  }
+}
+
 template <class ElemOp, class Epi>
 __device__ __forceinline__ void tile_apply_team(const EnvView& v, Team& T, bool packed, double2* es, double2* y0v, double2* y1v,
-                                                const double2* gx, ElemOp op, Epi epi) {
+                                                const TeamTouch& tt, const double2* gx, ElemOp op, Epi epi) {
   const int tid = threadIdx.x, n = v.n2, gt = T.rank * WG + tid;
   constexpr int GS = TEAM * WG;
   if (!v.mf_tptr) {
@@ -3514,15 +3571,29 @@ __device__ __forceinline__ void tile_apply_team(const EnvView& v, Team& T, bool 
     }
     return;       // (the caller's team reduction is the barrier in front of the next use of the element scratch)
   }
-  tile_chunks_global(v, packed, es, T.rank ? y1v : y0v, gx, op, T.rank, TEAM, false);
+  tile_chunks_global(v, packed, es, T.rank ? y1v : y0v, gx, op, T.rank, TEAM, false, tt.first, tt.stride);
   team_sync(T);
   constexpr int EB = 4;
+  const bool masks = tt.first != nullptr && v.mf_rlist;
   for (int row0 = T.rbeg + tid; row0 < T.rend; row0 += EB * WG) {
     double2 a[EB], c[EB];
+    unsigned m0 = 0xFu, m1 = 0xFu;
+    if (masks) {
+      // a partial sum exists only where the workgroup's chunks touch the row (mostly ONE of the two: a row meets 1.2 chunks
+      // on average) - the other vector's entry is stale and not read
+      m0 = m1 = 0u;
+#pragma unroll
+      for (int k = 0; k < EB; ++k) {
+        const int rc = min(row0 + k * WG, n - 1);
+        m0 |= tt.t0[rc] ? 1u << k : 0u;
+        m1 |= tt.t1[rc] ? 1u << k : 0u;
+      }
+    }
 #pragma unroll
     for (int k = 0; k < EB; ++k) {
-      a[k] = y0v[min(row0 + k * WG, n - 1)];
-      c[k] = y1v[min(row0 + k * WG, n - 1)];
+      a[k] = c[k] = make_double2(0.0, 0.0);
+      if ((m0 >> k) & 1u) a[k] = y0v[min(row0 + k * WG, n - 1)];
+      if ((m1 >> k) & 1u) c[k] = y1v[min(row0 + k * WG, n - 1)];
     }
 #pragma unroll
     for (int k = 0; k < EB; ++k)
@@ -3570,6 +3641,11 @@ __global__ __launch_bounds__(WG) void evolve_team_tiles_kernel(mdq_ipcs_desc d, 
   double* hcnt = reinterpret_cast<double*>(h5 + d.N2);
   double2* y0v = reinterpret_cast<double2*>(w + work_ytmp_offset(d.NV, d.NT, d.NE));   // the workgroups' accumulation vectors
   double2* y1v = y0v + d.N2 + 1;
+  TeamTouch tt;
+  tt.t0 = reinterpret_cast<unsigned char*>(w + work_touch_offset(d.NV, d.NT, d.NE));
+  tt.t1 = tt.t0 + d.N2;
+  tt.first = tt.t1 + d.N2;
+  tt.stride = (int)work_touch_row_cap(d.NV, d.NE);
   double2* stage = vh;                                   // the mass solve's S^-1 p (vh is free there)
   double* pnew = reinterpret_cast<double*>(vt + d.N2);
   double* spare = pnew + d.NV;
@@ -3599,7 +3675,7 @@ __global__ __launch_bounds__(WG) void evolve_team_tiles_kernel(mdq_ipcs_desc d, 
   // y = D^-1 A x (0 on constrained rows) / y = S^-1 M x' on the team's rows
   auto apply_vel = [&](const double2* gx, auto epi) {
     tile_apply_team(
-        v, T, packed, es, y0v, y1v, gx,
+        v, T, packed, es, y0v, y1v, tt, gx,
         [&](int e, const Geo& g, int ko, const double2(&xe)[6], double2(&ye)[6]) { velocity_op(v, a, mu, e, ko, g, xe, ye); },
         [&](int row, double y0, double y1) {
           const bool fl = v.bcu_flag[row] != 0;
@@ -3609,7 +3685,7 @@ __global__ __launch_bounds__(WG) void evolve_team_tiles_kernel(mdq_ipcs_desc d, 
   };
   auto apply_mass = [&](const double2* gx, auto epi) {
     tile_apply_team(
-        v, T, packed, es, y0v, y1v, gx,
+        v, T, packed, es, y0v, y1v, tt, gx,
         [&](int, const Geo& g, int, const double2(&xe)[6], double2(&ye)[6]) { elem_mass(g, xe, ye); },
         [&](int row, double y0, double y1) {
           const double is = v.bcu_flag[row] ? 0.0 : 1.0 / v.sdiagM[row];
@@ -3617,6 +3693,8 @@ __global__ __launch_bounds__(WG) void evolve_team_tiles_kernel(mdq_ipcs_desc d, 
         });
   };
   team_place(T, reinterpret_cast<unsigned*>(spare + 25), general);
+  if (d.NRL > tt.stride) tt.first = nullptr;       // (cannot happen: a list holds at most min(N2, 6 MF_CH) rows)
+  else team_touch_setup(v, T, tt);                  // (published by the team barriers of step 1's right-hand side)
   for (int step = 0; step < nsteps; ++step) {
     // ---------------- step 1: tentative velocity
     for (int e = gt; e < v.nt; e += GS) {
