@@ -597,6 +597,32 @@ def _kernel_sources(kernel):
     return own + ["mdq_device.h", "mdq_internal.h"]
 
 
+def pmc_entry(name, leg, kernel):
+    """(raw / corrected HBM bytes per launch of `kernel`, source note) from the committed PMC summary - refused PER KERNEL (None +
+    the reason) when the summary is missing or was collected from a different version of any source file that kernel is
+    compiled from (sha256 of every csrc file stamped at collection; kernel -> files: `_kernel_sources`)."""
+    import hashlib
+    stamps = prof_early(name, "kernel_sources_sha256") or {}
+    ent = ((prof_early(name, "hbm_bytes_per_launch") or {}).get(leg) or {}).get(kernel)
+    src = (f"profiles/{name} @ {prof_early(name, 'git_commit') or 'unstamped'} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+           "this command, gfx950 wide-read correction; counters cannot be read inside the run)")
+    if not ent or ent.get("corrected") is None:
+        return None, src + f" - NO figure for {kernel}"
+    for source in _kernel_sources(kernel):
+        try:
+            now = hashlib.sha256(open(os.path.join(ROOT, "meshdqn_amd", "csrc", source), "rb").read()).hexdigest()
+        except OSError:
+            now = None
+        if stamps.get(source) is None or stamps.get(source) != now:
+            return None, src + f" - REFUSED for {kernel}: {source} has changed since the counters were collected (sha256 differs)"
+    return ent, src + f"; sha256 of {', '.join(_kernel_sources(kernel))} match"
+
+
+def pmc_traffic(name, leg, kernel):
+    ent, src = pmc_entry(name, leg, kernel)
+    return (ent["corrected"] if ent else None), src
+
+
 def _stream_log():
     try:
         from meshdqn_amd import streams
@@ -919,6 +945,7 @@ def main(argv=None):
             c5, b5 = measure_s2(args, dev, None, 1, [rt] * B, [rc_] * B, 20, 5, 100)
             it5 = np.tile(np.array([[c5["krylov_iters_per_step"][k] for k in ("velocity_bicgstab", "pressure", "correction_cg")]]), (B, 1))
             by5 = b5.algorithmic_bytes_per_step(it5)
+            c5_pmc, c5_pmc_src = pmc_entry(PMC_SUMMARY, "c5", "mdq::evolve_team_tiles_kernel<false>")
             c5.update(what="C5: S2 on ys930 red-refined once (the mesh does not fit the LDS-resident modes: auto mode takes the element "
                            "tiles with GLOBAL vectors and - while two workgroups per environment fit the chip - TWO workgroups per "
                            "environment, mode 7: bitwise reproducible run to run; mode 5, one workgroup, ran here until round 5: "
@@ -926,8 +953,7 @@ def main(argv=None):
                            "direct pressure solve from host-built factors", vertices=int(rt.nv), triangles=int(rt.nt),
                       survey_csr_bytes_per_step=by5, survey_equivalent_GBs=by5 / (c5["ms_per_step"] * 1e-3) / 1e9,
                       survey_equivalent_over_hbm_peak=by5 / (c5["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                      measured_hbm_bytes_per_launch=(((prof_early(PMC_SUMMARY, "hbm_bytes_per_launch") or {}).get("c5") or {})
-                                                     .get("mdq::evolve_team_tiles_kernel<false>")),
+                      measured_hbm_bytes_per_launch=c5_pmc, measured_hbm_source=c5_pmc_src,
                       note="survey_* = the bytes an assembled-CSR implementation would stream (SURVEY 8(d) convention) over the step "
                            "time - NOT a roofline fraction of this kernel; measured_hbm_bytes_per_launch = rocprofv3 FETCH_SIZE + "
                            "WRITE_SIZE of the same kernel (profiles/" + PMC_SUMMARY + "; one launch = one step of 128 environments)")
@@ -944,25 +970,6 @@ def main(argv=None):
             except Exception:  # noqa: BLE001
                 return None
 
-        def pmc_traffic(name, leg, kernel):
-            """HBM bytes per launch of `kernel` from the committed PMC summary - refused PER KERNEL (None + the reason) when the
-            summary is missing or was collected from a different version of any source file that kernel is compiled from
-            (sha256 of every csrc file stamped at collection; kernel -> files: `_kernel_sources`)."""
-            import hashlib
-            stamps = prof(name, "kernel_sources_sha256") or {}
-            val = (((prof(name, "hbm_bytes_per_launch") or {}).get(leg) or {}).get(kernel) or {}).get("corrected")
-            src = (f"profiles/{name} @ {prof(name, 'git_commit') or 'unstamped'} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                   "this command, gfx950 wide-read correction; counters cannot be read inside the run)")
-            if val is None:
-                return None, src + f" - NO figure for {kernel}"
-            for source in _kernel_sources(kernel):
-                try:
-                    now = hashlib.sha256(open(os.path.join(ROOT, "meshdqn_amd", "csrc", source), "rb").read()).hexdigest()
-                except OSError:
-                    now = None
-                if stamps.get(source) is None or stamps.get(source) != now:
-                    return None, src + f" - REFUSED for {kernel}: {source} has changed since the counters were collected (sha256 differs)"
-            return val, src + f"; sha256 of {', '.join(_kernel_sources(kernel))} match"
         sm_traffic, sm_traffic_src = pmc_traffic(PMC_SUMMARY, "s3", "mdq_smooth_lin::smooth_linear_kernel")
         nt, nv = topo.nt, topo.nv
         insitu = s3.get("smooth_kernel_in_rollout_ms")
