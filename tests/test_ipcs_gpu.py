@@ -401,6 +401,12 @@ def test_two_workgroups_per_environment_on_the_element_tiles(meshes, lib_built):
         # (fields: two solves stopped at rtol 1e-10 - the bound of the mode-4 test above)
         assert np.abs(out["7"][2] - out["5"][2]).max() < 1e-8 * np.abs(out["5"][2]).max()
         assert np.abs(out["7"][3] - out["5"][3]).max() < 1e-8 * np.abs(out["5"][3]).max()
+    # one launch of six steps (above) == six launches of one step: the per-launch set-up (placement check, touch bytes) and
+    # the history counters carry over exactly
+    b1 = IpcsBatch([rt] * 4 + [t0], [rc] * 4 + [x0], rtol=1e-10, mode=7, pressure_direct=False)
+    d1 = torch.cat([b1.evolve(1)[0].clone() for _ in range(6)], dim=1)
+    torch.cuda.synchronize()
+    assert np.array_equal(d1.cpu().numpy(), out["7"][0]) and np.array_equal(b1.u_n.cpu().numpy(), out["7"][2])
     os.environ["MDQ_NO_TEAM_TILES"] = "1"
     try:
         b5 = IpcsBatch([rt] * 4 + [t0], [rc] * 4 + [x0], rtol=1e-10, mode=-2, pressure_direct=False)
