@@ -12,7 +12,7 @@ z = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file_
 t0 = MeshTopology(z["coords"], z["cells"])
 rc, rcells = red_refine(smooth_coords(t0, 50), z["cells"])
 topo = MeshTopology(rc, rcells)
-batch = IpcsBatch([topo] * B, [rc] * B, rtol=1e-10, mode=5)
+batch = IpcsBatch([topo] * B, [rc] * B, rtol=1e-10, mode=int(os.environ.get("MDQ_MODE", "5")))
 batch.assemble()
 for _ in range(30):
     batch.evolve(1)
