@@ -222,6 +222,8 @@ class IpcsBatch:
         for name, _typ in _lib.IpcsDesc._fields_:
             if name in t:
                 setattr(d, name, t[name].data_ptr())
+        if os.environ.get("MDQ_NO_TILE_MAPS", "") == "1":     # (A / B: modes 5 / 7 through the dof <- slot lists, as on device-built index data)
+            d.mf_tptr = d.mf_scat = d.mf_rlist = d.mf_rcnt = d.mf_lpos = None
         d.work_doubles = nwork
         d.NRL = getattr(self, "_NRL", 0)
         d.rl_flags = getattr(self, "_rl_flags", 0)
