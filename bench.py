@@ -765,9 +765,18 @@ def main(argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rccl = None
-    if world > 1:
+    # MDQ_FORCE_COLLECTIVES=1: a job of ONE rank creates its process group too and runs its barriers, timing reductions and
+    # the learning loop's collectives through the backend (RCCL) - what a single-GPU box can exercise of the N > 1 path
+    forced = world == 1 and os.environ.get("MDQ_FORCE_COLLECTIVES", "") == "1"
+    if world > 1 or forced:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if forced and not os.environ.get("MASTER_PORT"):
+            import socket
+            s_ = socket.socket()
+            s_.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+            s_.close()
         # MDQ_SHARE_GPU=1 + MDQ_DIST_BACKEND=gloo: debugging aid that lets the multi-rank control flow be exercised on
         # a box with fewer GPUs than ranks (RCCL refuses two ranks on one device); never set by the driver
         ndev = torch.cuda.device_count()

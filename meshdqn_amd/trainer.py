@@ -81,7 +81,11 @@ class DistContext:
                 device = torch.device("cpu")
         self.device = device
         self.owns_group = False
-        if self.world > 1 and not dist.is_initialized():
+        # `multi`: the collectives run.  MDQ_FORCE_COLLECTIVES=1 turns them on for ONE rank as well - the gradient all-reduce
+        # and the record all-gathers then go through the backend (RCCL) with a group of one: what a single-GPU box can
+        # exercise of the multi-GPU path (same numbers as without a group; tests/test_trainer_gpu.py)
+        self.multi = self.world > 1 or os.environ.get("MDQ_FORCE_COLLECTIVES", "") == "1"
+        if self.multi and not dist.is_initialized():
             import datetime
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             backend = backend or os.environ.get("MDQ_DIST_BACKEND") or ("nccl" if device.type == "cuda" else "gloo")
@@ -99,7 +103,7 @@ class DistContext:
             else:
                 dist.init_process_group(backend, **kw)
             self.owns_group = True
-        self.backend = dist.get_backend() if (self.world > 1 and dist.is_initialized()) else None
+        self.backend = dist.get_backend() if (self.multi and dist.is_initialized()) else None
 
     def shard(self, n_total: int):
         """Contiguous block of environment ids owned by this rank (env id -> rank = id // (n/world))."""
@@ -109,20 +113,20 @@ class DistContext:
         return range(lo, lo + per + (1 if self.rank < extra else 0))
 
     def allreduce_mean_(self, flat: torch.Tensor) -> torch.Tensor:
-        if self.world > 1:
+        if self.multi:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
             flat /= self.world
         return flat
 
     def max_over_ranks(self, value: float) -> float:
-        if self.world == 1:
+        if not self.multi:
             return value
         t = torch.tensor([value], dtype=torch.float64, device=self.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     def barrier(self):
-        if self.world > 1:
+        if self.multi:
             dist.barrier()
 
     def close(self):
@@ -265,7 +269,7 @@ class SharedDeviceReplay:
 
 def allgather_records(ctx: DistContext, rec: torch.Tensor) -> torch.Tensor:
     """One all-gather of the (B, record) tensors of all ranks -> (world * B, record), rank order (RCCL: one call)."""
-    if ctx.world == 1:
+    if not ctx.multi:
         return rec
     out = torch.empty((ctx.world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
     try:
@@ -294,7 +298,7 @@ def allgather_records_into(ctx: DistContext, R: torch.Tensor, base: int, B: int,
 def allgather_transitions(ctx: DistContext, trs: List[Transition], n_nodes: int, n_feat: int, e_max: int):
     """All ranks contribute the same number of transitions per call (one per environment step)."""
     rec = pack_transitions(trs, n_nodes, n_feat, e_max).to(ctx.device)
-    if ctx.world == 1:
+    if not ctx.multi:
         return unpack_transitions(rec, n_nodes, n_feat, e_max)
     bufs = [torch.empty_like(rec) for _ in range(ctx.world)]
     dist.all_gather(bufs, rec)
@@ -476,7 +480,7 @@ class DQNTrainer:
                     g[k_].copy_(v_)
             g["graph"].replay()
             flat = None
-            if self.ctx.world > 1:
+            if self.ctx.multi:
                 flat = torch.cat([(gr if gr is not None else torch.zeros_like(p)).reshape(-1)
                                   for gr, p in zip(g["grads"], net.parameters())])
         except RuntimeError as exc:   # capture not supported for some op on this build: stay on the eager path
@@ -754,7 +758,7 @@ class DQNTrainer:
         loss, flat = self._fused_of(net, "train").train_step(gd["x"], b["node_ptr"], gd["esrc"], gd["edst"], gd["edge_ptr"], N, EM,
                                                     0 if sel else 1, qo, b["action"], b["reward"], b["nonfinal"], self.gamma,
                                                     loss_out=loss_out)
-        if self.ctx.world > 1:
+        if self.ctx.multi:
             self.ctx.allreduce_mean_(flat)
         self._adam_step_device(k, flat)
         self.num_grads += 1
@@ -853,7 +857,7 @@ def train_loop_per_worker(trainer: DQNTrainer, env_factory, num_episodes: int, m
             ep_actions.append(action)
             tr = Transition(state, torch.tensor([[action]], dtype=torch.long), None if done else next_state,
                             torch.tensor([reward], dtype=torch.float32))
-            if share_replay and ctx.world > 1:
+            if share_replay and ctx.multi:
                 for t in allgather_transitions(ctx, [tr], state.x.shape[0], state.x.shape[1], e_max):
                     trainer.memory.push(*t)
             else:
@@ -1131,7 +1135,7 @@ def train_loop_vec(trainer: DQNTrainer, venv, num_steps: int, optim_per_step: in
     # ranks exchange transitions)
     rep_dev = rep_sh = None
     dev_ok = device_replay and trainer.graphs and trainer.dense and DeviceReplay.eligible(st, trainer.e_max)
-    if dev_ok and share_replay and ctx.world > 1:
+    if dev_ok and share_replay and ctx.multi:
         # shared replay: every rank keeps ALL transitions as fixed-size records on its device; per batched step ONE
         # all-gather of the (B, record) tensor packed on the device
         rep_sh = trainer.device_memory
@@ -1201,7 +1205,7 @@ def train_loop_vec(trainer: DQNTrainer, venv, num_steps: int, optim_per_step: in
             a_t = torch.from_numpy(np.asarray(actions, np.int64)).reshape(B, 1, 1).unbind(0)
             r_t = torch.from_numpy(np.asarray(rew, np.float32)).reshape(B, 1).unbind(0)
             trs = [Transition(prev[b], a_t[b], None if done[b] else nxt[b], r_t[b]) for b in range(B)]
-            if share_replay and ctx.world > 1:
+            if share_replay and ctx.multi:
                 trs = allgather_transitions(ctx, trs, N, st["x"].shape[2], e_max)
             for t in trs:
                 trainer.memory.push(*t)
@@ -1243,7 +1247,7 @@ def train_loop_device(trainer: DQNTrainer, venv, num_steps: int, optim_per_step:
         raise _lib.MeshDQNHipError("train_loop_device needs a GPU and a vector env with the device mesh engine and auto_reset")
     lib = _lib.load()
     B, N = venv.B, venv.N
-    W = B * ctx.world if (share_replay and ctx.world > 1) else B     # records per batched step in this rank's ring
+    W = B * ctx.world if (share_replay and ctx.multi) else B     # records per batched step in this rank's ring
     steps_done = np.zeros(B, np.int64) if steps_done0 is None else np.asarray(steps_done0, np.int64).copy()
     fused1 = trainer._fused_of(trainer.policy_net_1)
     main = torch.cuda.current_stream(dev)

@@ -106,6 +106,18 @@ def test_bench_two_torchrun_ranks_share_one_gpu(lib_built):
     assert abs(res["value"] - 2 * 16 * 6 / (res["ms_per_step"] * 6e-3)) < 1e-6 * res["value"]
 
 
+def test_bench_one_rank_through_rccl(lib_built):
+    """The N > 1 control flow of bench.py over RCCL itself, as far as one GPU allows: MDQ_FORCE_COLLECTIVES=1 makes the single
+    rank create an "nccl" process group (communicator on the device) and run its barriers, the max-over-ranks timing
+    reductions and the learning loop's gradient all-reduce / record all-gather through it - the calls the driver's
+    N = 2, 4, 8 runs make.  (The side measurements are skipped; the learning loop runs.)"""
+    small = list(SMALL)
+    small[small.index("--s1-steps") + 1] = "0"
+    res = _line([sys.executable, "bench.py", "--no-cpu-baseline"] + small, dict(os.environ, MDQ_FORCE_COLLECTIVES="1"))
+    assert res["n_gpus"] == 1 and res["collective_backend"]["backend"].startswith("nccl") and res["collective_backend"]["ranks"] == 1
+    assert res["value"] > 0 and abs(res["value"] - 16 * 6 / (res["ms_per_step"] * 6e-3)) < 1e-6 * res["value"]
+
+
 TINY = ["--steps", "3", "--warmup", "1", "--repeats", "2", "--spinup", "20", "--s2-steps", "10", "--envs", "4",
         "--s1-steps", "0", "--train-steps", "0", "--s1-solver-steps", "100", "--no-cpu-baseline"]
 

@@ -81,3 +81,38 @@ def test_train_py_refuses_more_ranks_than_gpus(lib_built, tmp_path):
     out = subprocess.run([sys.executable, "train.py", "--gpus", "2", "--config", os.path.join(ROOT, "configs", "ray_ys930.yaml")],
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "needs 2 GPUs" in out.stderr
+
+
+def test_train_py_one_rank_through_rccl_equals_no_process_group(lib_built, tmp_path):
+    """The device-resident learning loop of `train.py` with its collectives going through RCCL - ONE rank, a process group of
+    one (`MDQ_FORCE_COLLECTIVES=1`, backend "nccl"): the flat gradient all-reduce inside every optimiser step and the in-place
+    record all-gather on the optimiser stream really run on the device's communicator; networks, Adam moments and the record
+    ring after every batched step are bit-identical to the same job without a process group.  (More than one rank over RCCL
+    needs more than one GPU; the eight-rank job above runs over gloo.)"""
+    import socket
+    B = 8
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "ray_ys930.yaml")))
+    cfg["flow_config"]["geometry_params"]["mesh"] = os.path.join(ROOT, "tests", "golden", "ys930.npz")
+    cfg["agent_params"].update(solver_steps=100, save_steps=20)
+    cpath = os.path.join(str(tmp_path), "cfg.yaml")
+    yaml.safe_dump(cfg, open(cpath, "w"))
+    digs = []
+    for forced in (False, True):
+        save = os.path.join(str(tmp_path), "rccl" if forced else "plain")
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MDQ_SHARE_GPU", "MDQ_DIST_BACKEND")}
+        if forced:
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+            s.close()
+            env.update(MDQ_FORCE_COLLECTIVES="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        out = subprocess.run([sys.executable, "train.py", "--config", cpath, "--envs", str(B), "--share-replay", "--save-dir", save,
+                              "--steps", "10", "--digest"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-4000:]
+        if forced:
+            assert "nccl" in out.stdout + out.stderr, (out.stdout[-2000:], out.stderr[-2000:])
+        digs.append(_digests(save, "", 1)[0])
+    assert len(digs[0]) == len(digs[1]) == 10 and digs[0][-1]["optimiser_steps"] >= 4
+    for a, b in zip(*digs):
+        for key in ("net1", "net2", "optimiser", "ring", "optimiser_steps", "steps_done"):
+            assert a[key] == b[key], (a["step"], key)

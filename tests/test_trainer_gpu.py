@@ -302,3 +302,80 @@ def test_two_gpu_rccl_gradient_allreduce_and_record_allgather(lib_built):
     assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
     assert res[0][3] != res[1][3]
     assert np.array_equal(res[0][4], res[1][4]) and res[0][4][:4].max() == 0.0 and res[0][4][4:].min() == 1.0
+
+
+def _rccl_single_worker(port, q):
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      MDQ_FORCE_COLLECTIVES="1")
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from meshdqn_amd.data import Data
+    from meshdqn_amd.trainer import (DistContext, DQNTrainer, Transition, allgather_records, allgather_records_into)
+    ctx = DistContext(backend="nccl", device=torch.device("cuda", 0))
+    info = dict(multi=ctx.multi, backend=ctx.backend, initialized=dist.is_initialized(), world=dist.get_world_size())
+    tr = DQNTrainer(180, 17, ctx=ctx, lr=1e-3, target_update=2, batch_size=8)
+    rng = np.random.default_rng(50)
+
+    def graph():
+        e = int(rng.integers(200, 500))
+        return Data(x=torch.from_numpy(rng.standard_normal((180, 17))).float(),
+                    edge_index=torch.from_numpy(rng.integers(0, 180, size=(2, e))).long())
+    losses = []
+    for step in range(3):
+        trs = [Transition(graph(), torch.tensor([[int(rng.integers(0, 181))]]), None if i % 4 == 3 else graph(),
+                          torch.tensor([float(rng.standard_normal())])) for i in range(8)]
+        losses.append(tr.optimize(trs))
+    info["graph_path"] = sorted(tr._graphs) if hasattr(tr, "_graphs") else None
+    rec = torch.arange(28, dtype=torch.float32, device=ctx.device).reshape(4, 7)
+    allrec = allgather_records(ctx, rec).cpu().numpy()
+    ring = torch.zeros((8, 7), dtype=torch.float32, device=ctx.device)
+    ring[4:8] = rec
+    allgather_records_into(ctx, ring, 4, 4, 4)              # the in-place form of the device loop (group of W = world * B rows)
+    torch.cuda.synchronize()
+    info["max_over_ranks"] = ctx.max_over_ranks(1.25)
+    q.put((info, losses, allrec, ring.cpu().numpy()))
+    ctx.barrier()
+    ctx.close()
+
+
+def test_single_rank_rccl_process_group(lib_built):
+    """What a one-GPU box can say about the RCCL path: `MDQ_FORCE_COLLECTIVES=1` makes a job of ONE rank create its process
+    group (backend "nccl" = RCCL, communicator on the device) and run every collective of the multi-GPU job through it -
+    the flat gradient all-reduce inside the optimiser step (three steps, the captured-graph path where it is taken), both
+    forms of the record all-gather, the timing reduction and the barrier - with the numbers of a job without a group.
+    (Two ranks need two GPUs: the test above.)"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    p = ctxm.Process(target=_rccl_single_worker, args=(port, q))
+    p.start()
+    info, losses, allrec, ring = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert info["multi"] and info["backend"] == "nccl" and info["initialized"] and info["world"] == 1, info
+    assert info["max_over_ranks"] == 1.25
+    want = np.arange(28, dtype=np.float32).reshape(4, 7)
+    assert np.array_equal(allrec, want) and np.array_equal(ring[4:8], want) and (ring[:4] == 0).all()
+    # the same three steps without a process group
+    from meshdqn_amd.data import Data
+    from meshdqn_amd.trainer import DistContext, DQNTrainer, Transition
+    tr = DQNTrainer(180, 17, ctx=DistContext(), lr=1e-3, target_update=2, batch_size=8)
+    assert not tr.ctx.multi
+    rng = np.random.default_rng(50)
+
+    def graph():
+        e = int(rng.integers(200, 500))
+        return Data(x=torch.from_numpy(rng.standard_normal((180, 17))).float(),
+                    edge_index=torch.from_numpy(rng.integers(0, 180, size=(2, e))).long())
+    ref = []
+    for step in range(3):
+        trs = [Transition(graph(), torch.tensor([[int(rng.integers(0, 181))]]), None if i % 4 == 3 else graph(),
+                          torch.tensor([float(rng.standard_normal())])) for i in range(8)]
+        ref.append(tr.optimize(trs))
+    assert np.allclose(ref, losses, rtol=1e-5, atol=1e-7), (ref, losses, info)

@@ -117,7 +117,7 @@ def main():
         def ring_rows(step):
             # FINISHED records of this job (the rows every rank must agree on): a step's records get their next state - and,
             # with the shared replay, travel to the other ranks - one step later (at once for the last step of the job)
-            wrec = args.envs * (ctx.world if (args.share_replay and ctx.world > 1) else 1)
+            wrec = args.envs * (ctx.world if (args.share_replay and ctx.multi) else 1)
             return min((step if step >= args.steps else step - 1) * wrec, trainer.device_memory.capacity)
 
         def on_every(step, steps_done):          # noqa: F811 - every batched step: digests, then the periodic checkpoint
@@ -143,6 +143,8 @@ def main():
         np.save(os.path.join(args.save_dir, prefix + "step_rewards.npy"), out["rewards"])
         yaml.safe_dump(cfg, open(os.path.join(args.save_dir, "config.yaml"), "w"))
         print(f"ranks {ctx.world}: {args.steps} batched steps x {args.envs} envs/rank, mean reward {out['rewards'].mean():.4f}")
+        if ctx.backend:
+            print(f"process group: backend {ctx.backend}, {ctx.world} rank(s)")
     ctx.close()
 
 
