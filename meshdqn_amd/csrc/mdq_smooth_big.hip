@@ -231,6 +231,74 @@ __device__ __forceinline__ void level_sweeps(d2* X, const double* r2k_tab, const
   }
 }
 
+// The sweeps of a SKEWED schedule (smooth_flow_kernel): every interior vertex has a time tau(v) >= 1 with
+//      1 <= tau(w) - tau(v) <= P - 1      for every pair of interior neighbours v < w,
+// and the update of v in sweep s runs at time step s P + tau(v) - 1.  The left inequality is the order of one Gauss-Seidel
+// sweep (w needs the new position of its lower-numbered neighbour v); the right one lets sweep s + 1 START while sweep s is
+// still running: v may take its sweep-(s + 1) update only after w has read v's sweep-s position, P + tau(v) > tau(w).  Two
+// vertices that share a time step are never neighbours (their taus are equal or differ by a multiple of P), so a step updates
+// in place like a level does - same values, same bits as the sequential sweeps.  tau = the level of the one-sweep DAG and
+// P = the number of levels is the plain level schedule (50 x 40 = 2 000 steps on the red-refined ys930); with P = 20
+// (smooth_flow_kernel finds the taus by relaxation) the same 50 sweeps are 1 020 steps twice as wide - the 968 levels of the
+// DAG of all sweeps that tools/sweep_dag.py counted, without a work queue.  Records are ordered by (residue (tau - 1) mod P,
+// then (tau - 1) / P): what a time step t updates - residue t mod P, the classes j whose sweep t / P - j is in [0, S) - is ONE
+// contiguous range; `lstart[l]`, l = residue * J + j + 1, are the class starts.
+__device__ __forceinline__ void skew_sweeps(d2* X, const double* r2k_tab, const int* lstart, const uint32_t* meta, const uint32_t* inc2,
+                                            int P, int J, int S, int tid) {
+  constexpr int G = BWG / 4;
+  const int g4 = tid >> 2, l4 = tid & 3;
+  struct Rec { uint32_t m, w[4]; };
+  auto fetch = [&](int i, int i1, Rec& r) {
+    r.m = 0u;
+    r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0u;
+    if (i < i1) {
+      r.m = meta[i];
+      const uint32_t* e = inc2 + i * MAXK + l4;
+      r.w[0] = e[0];
+      r.w[1] = e[4];
+      r.w[2] = e[8];
+      r.w[3] = e[12];
+    }
+  };
+  const int T = (S - 1 + J) * P;                             // time steps
+  // the record range of time step (q P + r)
+  auto range = [&](int r, int q, int& a, int& b) {
+    const int jlo = max(0, q - S + 1), jhi = min(J - 1, q);
+    a = b = 0;
+    if (jlo <= jhi && q < S - 1 + J) {
+      a = lstart[r * J + jlo + 1];
+      b = lstart[r * J + jhi + 2];
+    }
+  };
+  Rec ra, rb;
+  int i0, i1, j0, j1;
+  range(0, 0, i0, i1);
+  int r2 = P > 1 ? 1 : 0, q2 = P > 1 ? 0 : 1;                // (residue, sweep block) of the step after the current one ...
+  range(r2, q2, j0, j1);
+  fetch(i0 + g4, i1, ra);
+  auto step = [&](Rec& mine, Rec& next) {
+    // ... and of the one after that: its range is read now and used by the NEXT call's record request
+    if (++r2 == P) { r2 = 0; ++q2; }
+    int k0, k1;
+    range(r2, q2, k0, k1);
+    fetch(j0 + g4, j1, next);
+    for (int i = i0 + g4; i < i1; i += G) {
+      if (i != i0 + g4) fetch(i, i1, mine);                 // (further passes of a wide step)
+      const int v = mine.m & 0xFFFF, k = mine.m >> 16;
+      const d2 xn = exact_vertex_rec(X, r2k_tab, v, k, l4, mine.w);
+      if (l4 == 0) X[v] = xn;
+    }
+    i0 = j0; i1 = j1; j0 = k0; j1 = k1;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // (LDS-only barrier: see level_sweeps)
+  };
+  int t = 0;
+  for (; t + 1 < T; t += 2) {
+    step(ra, rb);
+    step(rb, ra);
+  }
+  if (t < T) step(ra, rb);
+}
+
 __global__ __launch_bounds__(BWG) void smooth_big_kernel(int NV, int NT, double* coords, const int32_t* cells, const int32_t* nv_,
                                                          const int32_t* nt_, const int32_t* iters_, const int32_t* rem,
                                                          const int32_t* rstat, int iters_env, unsigned char* slab, int32_t* status) {
@@ -610,6 +678,80 @@ __global__ __launch_bounds__(FWG) void smooth_flow_kernel(int NV, int NT, double
     __syncthreads();
   }
   __syncthreads();
+  // ---- number of levels; then the SKEW (skew_sweeps): times tau(v) with 1 <= tau(w) - tau(v) <= P - 1 over the interior edges
+  // v < w for a period P below the number of levels, by raise-only relaxation from the levels (the levels are the least
+  // solution of the left inequalities; raising tau(v) to tau(w) - (P - 1) where the right one fails and re-establishing the
+  // left ones converges to the least solution above them when one exists - in place: a monotone iteration from below reaches
+  // the same fixed point in any order).  P = half the levels (rounded up), then 5/8 and 3/4 of them; no P: tau = level, P =
+  // levels (the plain level schedule).  MDQ_NO_SMOOTH_SKEW (compile time): never.
+  int lmax = 0;
+  for (int v = tid; v < nv; v += FWG) lmax = max(lmax, done[v] == 0 ? lev[v] : 0);
+  part[tid] = lmax;
+  __syncthreads();
+  for (int off = FWG / 2; off > 0; off >>= 1) {
+    if (tid < off) part[tid] = max(part[tid], part[tid + off]);
+    __syncthreads();
+  }
+  lmax = part[0];
+  __syncthreads();
+  int P = lmax > 0 ? lmax : 1, J = 1;
+#ifndef MDQ_NO_SMOOTH_SKEW
+  if (lmax >= 8 && lmax <= 1000) {
+    int* tau = indeg;                                        // (the in-degrees are all zero now)
+    const int cand[3] = {(lmax + 1) / 2, (5 * lmax + 7) / 8, (3 * lmax + 3) / 4};
+    for (int c = 0; c < 3 && J == 1 && P == lmax; ++c) {
+      const int Pt = cand[c], lim = 3 * lmax;                // (a tau beyond three times the levels: no solution for this P)
+      for (int v = tid; v < nvp; v += FWG) tau[v] = lev[v];
+      __syncthreads();
+      bool ok = false;
+      for (int round = 0; round < 6 * lmax; ++round) {
+        int changed = 0;
+        for (int v = tid; v < nv; v += FWG)
+          if (done[v] == 0) {
+            const int q0 = ptr[v], k = (v + 1 < nvp ? (int)ptr[v + 1] : 3 * nt) - q0;
+            int t0 = tau[v], t_ = t0;
+            for (int q = 0; q < k; ++q) {
+              const uint32_t w_ = inc[q0 + q];
+              const int a_ = w_ & 0xFFFF, c_ = w_ >> 16;
+              if (done[a_] == 0) t_ = max(t_, a_ < v ? tau[a_] + 1 : tau[a_] - (Pt - 1));
+              if (done[c_] == 0) t_ = max(t_, c_ < v ? tau[c_] + 1 : tau[c_] - (Pt - 1));
+            }
+            if (t_ != t0) {
+              tau[v] = min(t_, lim + 1);
+              changed = max(changed, t_ > lim ? 2 : 1);
+            }
+          }
+        const int any = __syncthreads_or(changed);
+        if (!any) {
+          ok = true;
+          break;
+        }
+        if (__syncthreads_or(changed == 2)) break;           // diverging
+      }
+      if (ok) {
+        int tmax = 0;
+        for (int v = tid; v < nv; v += FWG) tmax = max(tmax, done[v] == 0 ? tau[v] : 0);
+        part[tid] = tmax;
+        __syncthreads();
+        for (int off = FWG / 2; off > 0; off >>= 1) {
+          if (tid < off) part[tid] = max(part[tid], part[tid + off]);
+          __syncthreads();
+        }
+        tmax = part[0];
+        __syncthreads();
+        const int Jt = (tmax + Pt - 1) / Pt;
+        if (Pt * Jt <= 1000) {
+          P = Pt;
+          J = Jt;
+          // the class of a vertex takes the place of its level: residue-major, 1-based
+          for (int v = tid; v < nv; v += FWG)
+            if (done[v] == 0) lev[v] = ((tau[v] - 1) % P) * J + (tau[v] - 1) / P + 1;
+        }
+      }
+      __syncthreads();
+    }
+  }
+#endif
   for (int l_ = tid; l_ < MAXLEV + 2; l_ += FWG) lvl[l_] = 0;
   __syncthreads();
   for (int v = tid; v < nv; v += FWG)
@@ -649,18 +791,10 @@ __global__ __launch_bounds__(FWG) void smooth_flow_kernel(int NV, int NT, double
     meta[i] = (uint32_t)v | ((uint32_t)k << 16);
     for (int q = 0; q < MAXK; ++q) inc2[i * MAXK + q] = q < k ? inc[q0 + q] : 0u;
   }
-  // (after the fill lvl[l] is the END of level l = the start of level l + 1; level 0 is empty)
-  int lmax = 0;
-  for (int v = tid; v < nv; v += FWG) lmax = max(lmax, done[v] == 0 ? lev[v] : 0);
-  part[tid] = lmax;
+  // (after the fill lvl[l] is the END of class / level l = the start of l + 1; 0 is empty)
+  const int ncls = P * J;                                    // classes (= levels when P is their number)
   __syncthreads();
-  for (int off = FWG / 2; off > 0; off >>= 1) {
-    if (tid < off) part[tid] = max(part[tid], part[tid + off]);
-    __syncthreads();
-  }
-  lmax = part[0];
-  __syncthreads();
-  for (int l_ = tid; l_ <= lmax + 1; l_ += FWG) part[l_] = l_ >= 1 ? lvl[l_ - 1] : 0;      // lstart (part: MAXLEV + 2 <= FWG ints)
+  for (int l_ = tid; l_ <= ncls + 1; l_ += FWG) part[l_] = l_ >= 1 ? lvl[l_ - 1] : 0;      // lstart (part: MAXLEV + 2 <= FWG ints)
   __syncthreads();
   // ---- positions (over the set-up scratch: the barriers above end its last readers)
   for (int v = tid; v < nv; v += FWG) {
@@ -668,7 +802,7 @@ __global__ __launch_bounds__(FWG) void smooth_flow_kernel(int NV, int NT, double
     X[v] = d2{xv.x, xv.y};
   }
   __syncthreads();
-  if (lmax > 0) level_sweeps(X, r2k_tab, part, meta, inc2, lmax, S, tid);
+  if (lmax > 0) skew_sweeps(X, r2k_tab, part, meta, inc2, P, J, S, tid);
   __syncthreads();
   for (int v = tid; v < nv; v += FWG) {
     const d2 p = X[v];

@@ -482,3 +482,63 @@ def test_refined_mesh_episodes_at_the_baseline_batch(lib_built, flow_steps, tmp_
         for a in range(len(names)):
             idx = np.flatnonzero(assign == a)
             assert np.allclose(fd[idx], fd[idx[0]], rtol=1e-9, atol=0) and np.allclose(fl[idx], fl[idx[0]], rtol=1e-9, atol=0)
+
+
+def test_skewed_sweep_schedule_gives_the_bits_of_the_level_schedule(lib_built, tmp_path):
+    """The large-mesh smoothing overlaps consecutive sweeps (skew_sweeps: vertex times tau with 1 <= tau(w) - tau(v) <= P - 1
+    over the interior edges, found by relaxation per launch): the same updates on the same values as the level-by-level
+    kernel (`MDQ_NO_SMOOTH_FLOW=1`, read once per process - hence two child processes) - bit for bit, for 1, 2, 3, 7 and 50
+    sweeps (fewer sweeps than overlapping classes included), on the red-refined ys930 and on a coarsened copy of it
+    (30 removals: another numbering, another tau)."""
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(str(tmp_path), "run.py")
+    with open(script, "w") as f:
+        f.write('''
+import hashlib, os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+from meshdqn_amd.ipcs_batch import smooth_coords
+from meshdqn_amd.mesh_ops import red_refine, remesh_batch, smooth_batch_gpu
+from meshdqn_amd.topology import MeshTopology
+m = np.load(os.path.join(%r, "tests", "golden", "ys930.npz"))
+rc, rcells = red_refine(smooth_coords(MeshTopology(m["coords"], m["cells"]), 50), m["cells"])
+t = MeshTopology(rc, rcells)
+meshes = [(rc.copy(), np.sort(rcells, axis=1).astype(np.int32))]
+# a coarsened copy: 30 interior vertices removed through the host engine
+c = np.zeros((1, t.nv, 2)); c[0] = rc
+tr = np.zeros((1, t.nt, 3), np.int32); tr[0] = meshes[0][1]
+nv, nt = np.array([t.nv], np.int32), np.array([t.nt], np.int32)
+rng = np.random.default_rng(5)
+done = 0
+while done < 30:
+    bnd = MeshTopology(c[0, :nv[0]], tr[0, :nt[0]]).on_boundary
+    v = int(rng.choice(np.flatnonzero(~bnd)))
+    st = remesh_batch(c, tr, nv, nt, np.array([v], np.int32))
+    done += int(st[0] == 0)
+meshes.append((c[0, :nv[0]].copy(), tr[0, :nt[0]].copy()))
+h = hashlib.sha256()
+for x, cells in meshes:
+    for s in (1, 2, 3, 7, 50):
+        tc = torch.from_numpy(x[None].copy()).cuda()
+        tt = torch.from_numpy(cells[None].copy()).cuda()
+        one = lambda v_: torch.full((1,), v_, dtype=torch.int32, device="cuda")
+        smooth_batch_gpu(tc, tt, one(len(x)), one(len(cells)), one(s))
+        out = tc.cpu().numpy()
+        assert np.isfinite(out).all()
+        h.update(out.tobytes())
+print("DIGEST", h.hexdigest(), len(meshes[1][0]))
+''' % (ROOT, ROOT))
+    dig = []
+    for flow in (True, False):
+        env = dict(os.environ)
+        env.pop("MDQ_NO_SMOOTH_FLOW", None)
+        if not flow:
+            env["MDQ_NO_SMOOTH_FLOW"] = "1"
+        out = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-3000:]
+        line = [l for l in out.stdout.splitlines() if l.startswith("DIGEST")][0].split()
+        dig.append(line[1])
+        assert int(line[2]) == 3322 - 30
+    assert dig[0] == dig[1]
