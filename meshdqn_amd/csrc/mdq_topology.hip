@@ -115,15 +115,21 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   constexpr int TNV = CP::NV, TNE = CP::NE, TNP = CP::NP, TNS = CP::NS, HSZ = CP::HS, PER = CP::PER;
   constexpr int TNT = CP::NT;
   (void)TNT;
-  auto hslot = [](uint32_t key) { return hslot_t<CP::HSHIFT>(key); };
+  // K = 4 (round 5): the EDGE HASH lives in LDS - 16 384 slots x (key, value) = 128 KB, load <= 0.75 at the capacity of 12 288
+  // edges - and, once the edge phase is over, the same LDS holds the vertex COORDINATES (64 KB): the hash inserts / probes
+  // (atomics and dependent reads on the slab: an L2 round trip each) were 47 % of the large-mesh instance and the coordinate
+  // reads most of the polygon-distance section's 27 % (tools/trace_topo.py on the refined ys930).  Every other table stays on
+  // the slab; the numbering of the edges does not depend on the table (first appearance by slot index).
+  constexpr int HT = K == 1 ? HSZ : 16384;                   // hash slots
+  auto hslot = [](uint32_t key) { return hslot_t<(K == 1 ? CP::HSHIFT : 18)>(key); };
   // (always inlined: with a seventh call site the compiler kept it as a FUNCTION - a call inside the kernel, 288 B of stack
   //  per lane and every section slower)
   auto scan_excl = [](int* a_, int n_, int* part_) __attribute__((always_inline)) { return mdq_topo::scan_excl<CP::PER>(a_, n_, part_); };
   extern __shared__ __align__(16) unsigned char lds_[];
   unsigned char* smem = K == 1 ? lds_ : slab + (size_t)blockIdx.x * ((CP::BYTES + 255) & ~(size_t)255);
   double2* X = reinterpret_cast<double2*>(smem);                              // [TNV]
-  uint32_t* hkey = reinterpret_cast<uint32_t*>(smem + 16 * TNV);              // [HSZ]   | region R (64 KB for K = 1), re-used
-  uint32_t* hval = hkey + HSZ;                                                // [HSZ]   | after the edge phase
+  uint32_t* hkey = K == 1 ? reinterpret_cast<uint32_t*>(smem + 16 * TNV) : reinterpret_cast<uint32_t*>(lds_);   // [HT] | region R (64 KB
+  uint32_t* hval = hkey + HT;                                                 // [HT]   | for K = 1), re-used after the edge phase
   int* scanb = reinterpret_cast<int*>(smem + 16 * TNV + 8 * HSZ);             // [TNS]
   uint16_t* eid_slot = reinterpret_cast<uint16_t*>(scanb + TNS);              // [TNS]
   uint16_t* ea = eid_slot + TNS;                                              // [TNE]
@@ -141,7 +147,11 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   uint16_t* order = remv + TNV;                                               // [TNV]
   int16_t* inv = reinterpret_cast<int16_t*>(order + TNV);                     // [TNV]
   double* dist = reinterpret_cast<double*>(R + 8 * TNV);                      // [TNV]
-  double2* poly = reinterpret_cast<double2*>(R + RPOLY);                      // [TNPOLY]
+  // (K = 4: the polygon and the small tables of the distance section - 16 KB that every vertex gathers from - sit in the upper
+  //  half of the LDS, free once the edge hash is dead; the coordinates take the lower half)
+  unsigned char* PB = K == 1 ? R + RPOLY : lds_ + 65536;                      // poly | segf | segr | ye | pmx
+  unsigned char* GB = K == 1 ? nullptr : lds_ + 65536 + 16384;                // grp | yrange | chf | chr   (K = 1: in R2, below)
+  double2* poly = reinterpret_cast<double2*>(PB);                             // [TNPOLY]
   int* cntd = reinterpret_cast<int*>(R + RSEG);                               // [TNP + 1] counts / pointers (IPCS phase)
   int* fill = cntd + TNP + 8;                                                 // [TNP]
 
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     if (HO.nv) HO.nv[b] = nv;
     if (HO.nt) HO.nt[b] = nt;
   }
-  for (int h = tid; h < HSZ; h += TW) {
+  for (int h = tid; h < HT; h += TW) {
     hkey[h] = EMPTY;
     hval[h] = 0x7FFFFFFFu;
   }
@@ -186,7 +196,8 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   };
   auto probe = [&](uint32_t key) {
     uint32_t h = hslot(key);
-    while (hkey[h] != key) h = (h + 1) & (HSZ - 1);
+    // (bounded: a key that was refused by a full table - below - must not spin here)
+    for (int n_ = 0; hkey[h] != key && n_ < HT; ++n_) h = (h + 1) & (HT - 1);
     return h;
   };
   const int nslots = 3 * nt;
@@ -253,14 +264,20 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
       int a, c;
       const uint32_t key = slot_key(s, a, c);
       uint32_t h = hslot(key);
-      for (;;) {
+      int n_ = 0;
+      for (;; ++n_) {
         const uint32_t old = atomicCAS(&hkey[h], EMPTY, key);
-        if (old == EMPTY || old == key) break;
-        h = (h + 1) & (HSZ - 1);
+        if (old == EMPTY || old == key || n_ >= HT) break;
+        h = (h + 1) & (HT - 1);
+      }
+      if (n_ >= HT) {
+        status[b] = -1;                                    // more distinct edges than hash slots: not a mesh within the capacities
+        continue;
       }
       atomicMin(&hval[h], (uint32_t)s);
     }
     __syncthreads();
+    if (K != 1 && status[b] != 0) return;                  // (workgroup-uniform: written before the barrier)
     for (int s = tid; s < TNS; s += TW) {
       int first = 0;
       if (s < nslots) {
@@ -320,6 +337,13 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
       pts[2 * i + 1] = X[i].y;
     }
     __syncthreads();
+  }
+  if (K != 1) {
+    // the hash is dead: the coordinates move from the slab into its LDS (every later section gathers them)
+    double2* Xl = reinterpret_cast<double2*>(lds_);
+    for (int v = tid; v < nv; v += TW) Xl[v] = X[v];
+    __syncthreads();
+    X = Xl;
   }
   const int n2 = nv + ne;
   TT_STAMP(1)
@@ -515,17 +539,18 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   const int NG = (np_ + 3) >> 2;                                              // groups of 4 segments (<= 64)
   const int NW = (np_ + 31) >> 5;                                             // 32-segment words (<= 8)
   const int NSEG = 32 * NW;                                                   // <= TNPOLY
-  float4* segf = reinterpret_cast<float4*>(R + RSEG);                         // [NSEG] {ax, ay, bx - ax, by - ay}
-  float* segr = reinterpret_cast<float*>(R + RSEG + TNPOLY * 16);             // [NSEG] 1 / |b - a|^2
-  double* ye = reinterpret_cast<double*>(R + RSEG + TNPOLY * 20);             // [NSEG + 1] y of polygon vertex i (closed)
+  float4* segf = reinterpret_cast<float4*>(PB + 16 * TNPOLY);                 // [NSEG] {ax, ay, bx - ax, by - ay}   (K = 1: R + RSEG)
+  float* segr = reinterpret_cast<float*>(PB + 16 * TNPOLY + TNPOLY * 16);     // [NSEG] 1 / |b - a|^2
+  double* ye = reinterpret_cast<double*>(PB + 16 * TNPOLY + TNPOLY * 20);     // [NSEG + 1] y of polygon vertex i (closed)
   float* pmx = reinterpret_cast<float*>(ye + TNPOLY + 2);                     // [TW / 64] wave maxima of |polygon coordinate|
   unsigned char* R2 = R + 8 * HSZ - 16 * 1024 * K;                            // (the look-up tables of the section above are dead)
   uint16_t* sorder = reinterpret_cast<uint16_t*>(R2 + 4 * TNV);               // [TNV] removable vertices by (band, home)
   uint8_t* keyv = reinterpret_cast<uint8_t*>(R2 + 6 * TNV);                   // [TNV] sort key
-  float4* grp = reinterpret_cast<float4*>(R2 + 8 * TNV);                      // [64] {cx, cy, radius, -}
-  double* yrange = reinterpret_cast<double*>(R2 + 8 * TNV + 1024);            // [4 * TW / 64] wave minima / maxima of the polygon's y, x
-  float4* chf = reinterpret_cast<float4*>(R2 + 8 * TNV + 1024 + 512);         // [64] group chord {ax, ay, bx - ax, by - ay}
-  float2* chr = reinterpret_cast<float2*>(R2 + 8 * TNV + 1024 + 512 + 1024);  // [64] {1 / |chord|^2, deviation of the group's polyline from it}
+  unsigned char* G2 = K == 1 ? R2 + 8 * TNV : GB;
+  float4* grp = reinterpret_cast<float4*>(G2);                                // [64] {cx, cy, radius, -}
+  double* yrange = reinterpret_cast<double*>(G2 + 1024);                      // [4 * TW / 64] wave minima / maxima of the polygon's y, x
+  float4* chf = reinterpret_cast<float4*>(G2 + 1024 + 512);                   // [64] group chord {ax, ay, bx - ax, by - ay}
+  float2* chr = reinterpret_cast<float2*>(G2 + 1024 + 512 + 1024);            // [64] {1 / |chord|^2, deviation of the group's polyline from it}
   int* hist = scanb;                                                          // [128]
   {
     float m = 0.f;
@@ -1301,7 +1326,11 @@ extern "C" int mdq_env_topology(const mdq_env_topo_desc* d, void* stream, int32_
     if (!d->workspace || d->workspace_bytes < mdq_env_topology_workspace_bytes(d) || (reinterpret_cast<uintptr_t>(d->workspace) & 15))
       return mdq_set_error("mdq_env_topology: workspace missing, too small or not 16-byte aligned (mdq_env_topology_workspace_bytes)");
     unsigned char* slab = static_cast<unsigned char*>(d->workspace);
-    hipLaunchKernelGGL(mdq_topo::topology_kernel<4>, dim3(d->B), dim3(mdq_topo::TW), 0, (hipStream_t)stream, *d, o,
+    const size_t lds4 = 2 * sizeof(uint32_t) * 16384;      // the edge hash, then the coordinates (see the kernel)
+    static const hipError_t attr4 = hipFuncSetAttribute(reinterpret_cast<const void*>(&mdq_topo::topology_kernel<4>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+    if (attr4 != hipSuccess) return mdq_set_error("hipFuncSetAttribute(topology_kernel<4>) failed");
+    hipLaunchKernelGGL(mdq_topo::topology_kernel<4>, dim3(d->B), dim3(mdq_topo::TW), lds4, (hipStream_t)stream, *d, o,
                        d->ipcs ? 1 : 0, status, slab, h);
   }
   if (hipGetLastError() != hipSuccess) return mdq_set_error("topology_kernel launch failed");

@@ -2,7 +2,7 @@
 # Build a variant of the library (extra -D flags) into tools/micro/bin/libmdq_NAME.so (git-ignored; travels with gpurun);
 # use it with MDQ_LIB_PATH=tools/micro/bin/libmdq_NAME.so.   tools/micro/build_variant.sh NAME -DMDQ_TOPO_TRACE ...
 # Same translation units as meshdqn_amd/build.py, objects under build/obj_NAME; linked WITHOUT the version script: the
-# trace builds export their read-back entry points (mdq_*_trace_host) beside the header's symbols.
+# trace builds export their read-back entry points (mdq_*_trace_host; default visibility: some carry no MDQ_API) beside the header's symbols.
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 ROOT="$(cd "$HERE/../.." && pwd)"
@@ -16,7 +16,7 @@ name, flags = sys.argv[1], sys.argv[2:]
 out = os.path.join("tools", "micro", "bin", f"libmdq_{name}.so")
 objd = os.path.join("build", f"obj_{name}")
 os.makedirs(objd, exist_ok=True)
-base = ["-O3", "-std=c++17", f"--offload-arch={b.ARCH}", "-fPIC", "-fvisibility=hidden", "-I", "include", "-I", b.CSRC] + flags
+base = ["-O3", "-std=c++17", f"--offload-arch={b.ARCH}", "-fPIC", "-I", "include", "-I", b.CSRC] + flags
 def comp(unit):
     src, extra, _ = b.UNITS[unit]
     obj = os.path.join(objd, unit + ".o")
