@@ -89,10 +89,15 @@ __global__ __launch_bounds__(RW) void remesh_kernel(int NV, int NT, double* coor
   double2* X = reinterpret_cast<double2*>(smem);                     // [RNV]            16 KB (K = 1)
   int* tri = reinterpret_cast<int*>(smem + 16 * RNV);                // [RNT][3]         24 KB
   int* nbr = tri + RNS;                                              // [RNT][3]         24 KB
-  uint32_t* hkey = reinterpret_cast<uint32_t*>(nbr + RNS);           // [RHS]            32 KB | the flip stack re-uses
-  uint32_t* hval = hkey + RHS;                                       // [RHS]            32 KB | this region
-  int* stack = reinterpret_cast<int*>(hkey);                         // [2 * RHS]
-  int* misc = reinterpret_cast<int*>(hval + RHS);                    // [336]: counters, star list, lane 0's work arrays
+  // K = 4 (round 5): the hash of the neighbour table - and the flip stack that re-uses it - in LDS, 16 384 slots (load <= 0.75
+  // at 12 288 edges; probes bounded): its inserts were atomics + dependent reads on the slab, an L2 round trip each, 75 % of the
+  // large-mesh instance (tools/trace_remesh.py on the refined ys930: 557 k of 743 k cycles).  Everything else stays on the slab.
+  constexpr int HT = K == 1 ? RHS : 16384;
+  constexpr int HSH = K == 1 ? C::HSHIFT : 18;
+  uint32_t* hkey = K == 1 ? reinterpret_cast<uint32_t*>(nbr + RNS) : reinterpret_cast<uint32_t*>(lds_);   // [HT] | the flip stack
+  uint32_t* hval = hkey + HT;                                        // [HT]             | re-uses this region
+  int* stack = reinterpret_cast<int*>(hkey);                         // [2 * HT]
+  int* misc = reinterpret_cast<int*>(reinterpret_cast<uint32_t*>(nbr + RNS) + 2 * RHS);   // [336]: counters, star list, lane 0's work arrays
   int* star = misc + 8;                                              // [64]
   int* lane0 = misc + 80;                                            // [4][64] ring bookkeeping of the serial part
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(RW) void remesh_kernel(int NV, int NT, double* coor
   --nv;
   RM_STAMP(3)
   // ---------------- neighbour table: nbr[3t+k] = cell across the edge opposite local vertex k
-  for (int h = tid; h < RHS; h += RW) {
+  for (int h = tid; h < HT; h += RW) {
     hkey[h] = EMPTY;
     hval[h] = EMPTY;
   }
@@ -302,11 +307,16 @@ __global__ __launch_bounds__(RW) void remesh_kernel(int NV, int NT, double* coor
     const int t = s / 3, k = s - 3 * t;
     const int a = tri[3 * t + (k + 1) % 3], c = tri[3 * t + (k + 2) % 3];
     const uint32_t key = ((uint32_t)min(a, c) << C::VBITS) | (uint32_t)max(a, c);
-    uint32_t h = hslot<C::HSHIFT>(key);
-    for (;;) {
+    uint32_t h = hslot<HSH>(key);
+    int n_ = 0;
+    for (;; ++n_) {
       const uint32_t old = atomicCAS(&hkey[h], EMPTY, key);
-      if (old == EMPTY || old == key) break;
-      h = (h + 1) & (RHS - 1);
+      if (old == EMPTY || old == key || n_ >= HT) break;
+      h = (h + 1) & (HT - 1);
+    }
+    if (n_ >= HT) {                 // more distinct edges than slots: not a triangulation within the capacities
+      misc[3] = 1;
+      continue;
     }
     const uint32_t o = atomicCAS(&hval[h], EMPTY, (uint32_t)s);
     if (o != EMPTY) {  // the second owner links both half-edges
@@ -350,7 +360,7 @@ __global__ __launch_bounds__(RW) void remesh_kernel(int NV, int NT, double* coor
     }
     int rc = 0, guard = 0;
     while (sp > 0) {
-      if (++guard > 200000 || sp + 4 > 2 * RHS) {
+      if (++guard > 200000 || sp + 4 > 2 * HT) {
         rc = -12;
         break;
       }
@@ -426,7 +436,7 @@ __global__ __launch_bounds__(RW) void remesh_kernel(int NV, int NT, double* coor
 template <int K>
 static int remesh_launch_k(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv, int32_t* nt,
                            const int32_t* remove_idx, int32_t* status, const mdq_rm::ActArgs* act, void* stream, unsigned char* slab) {
-  const size_t lds = K == 1 ? mdq_rm::Cap<1>::BYTES : 0;
+  const size_t lds = K == 1 ? mdq_rm::Cap<1>::BYTES : 2 * sizeof(uint32_t) * 16384;   // (K = 4: the edge hash / flip stack)
   static const hipError_t attr = [] {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mdq_rm::remesh_kernel<false, K>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -9,10 +9,10 @@ from meshdqn_amd.vec_env import VecEnv2DAirfoil
 from meshdqn_amd.airfoilgcnn import NodeRemovalNet
 from meshdqn_amd.gcn_fused import FusedGcn
 G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
-cfg = dict(flow_config=dict(flow_params=dict(mu=1e-3, rho=1.0, inflow="constant"), geometry_params=dict(mesh=os.path.join(G, "ys930.npz")),
+cfg = dict(flow_config=dict(flow_params=dict(mu=1e-3, rho=1.0, inflow="constant"), geometry_params=dict(mesh=os.path.join(G, os.environ.get("MDQ_TOOL_MESH", "ys930") + ".npz")),
                             solver_params=dict(dt=0.001, solver_type="lu", smooth=True, reproducible=False, rtol=1e-10)),
-           agent_params=dict(solver_steps=200, episodes=10, timesteps=10000, threshold=0.001, N_closest=180, gt_drag=-1, gt_time=-1, u=-1, p=-1,
-                             time_reward=0.005, save_steps=40, goal_vertices=0.95, plot_dir=""))
+           agent_params=dict(solver_steps=int(os.environ.get("MDQ_TOOL_SOLVER_STEPS", "200")), episodes=10, timesteps=10000, threshold=0.001, N_closest=180, gt_drag=-1, gt_time=-1, u=-1, p=-1,
+                             time_reward=0.005, save_steps=max(1, int(os.environ.get("MDQ_TOOL_SOLVER_STEPS", "200")) // 5), goal_vertices=0.95, plot_dir=""))
 B = 128
 venv = VecEnv2DAirfoil(cfg, B, flow_steps=0)
 net = NodeRemovalNet(181, conv_width=128, topk=0.1); net.set_num_nodes(17); net = net.cuda(); fused = FusedGcn(net)
