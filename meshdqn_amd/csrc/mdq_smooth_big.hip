@@ -726,7 +726,7 @@ __global__ __launch_bounds__(FWG) void smooth_flow_kernel(int NV, int NT, double
           ok = true;
           break;
         }
-        if (__syncthreads_or(changed == 2)) break;           // diverging
+        if ((round & 7) == 7 && __syncthreads_or(changed == 2)) break;   // diverging (looked at every eighth round: tau is capped)
       }
       if (ok) {
         int tmax = 0;
@@ -760,9 +760,10 @@ __global__ __launch_bounds__(FWG) void smooth_flow_kernel(int NV, int NT, double
       else atomicAdd(&lvl[lev[v]], 1);
     }
   __syncthreads();
-  if (tid == 0) {                                            // exclusive scan over the (few dozen) levels
+  if (tid == 0) {                                            // exclusive scan over the classes / levels in use (a few dozen)
     int run = 0;
-    for (int l_ = 0; l_ < MAXLEV + 2; ++l_) {
+    const int nl_ = min(MAXLEV + 2, P * J + 2);
+    for (int l_ = 0; l_ < nl_; ++l_) {
       const int c_ = lvl[l_];
       lvl[l_] = run;
       run += c_;

@@ -146,7 +146,9 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   uint16_t* remv = blist + TNV;                                               // [TNV] removable vertices (ascending)
   uint16_t* order = remv + TNV;                                               // [TNV]
   int16_t* inv = reinterpret_cast<int16_t*>(order + TNV);                     // [TNV]
-  double* dist = reinterpret_cast<double*>(R + 8 * TNV);                      // [TNV]
+  // (K = 4: the distances and the histograms of the two counting sorts in the upper half of the LDS too, behind the polygon tables:
+  //  lds_ + 64 KB: polygon tables 20 KB | histograms 8 KB | distances 32 KB)
+  double* dist = K == 1 ? reinterpret_cast<double*>(R + 8 * TNV) : reinterpret_cast<double*>(lds_ + 65536 + 28672);   // [TNV]
   // (K = 4: the polygon and the small tables of the distance section - 16 KB that every vertex gathers from - sit in the upper
   //  half of the LDS, free once the edge hash is dead; the coordinates take the lower half)
   unsigned char* PB = K == 1 ? R + RPOLY : lds_ + 65536;                      // poly | segf | segr | ye | pmx
@@ -440,7 +442,9 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   // here: a vertex then takes two look-ups instead of comparing with every boundary vertex (876 x ~190 x 2 comparisons,
   // 25 k of the kernel's 175 k cycles).  The same predicate, exactly.  More boundary vertices than half a table: the loop.
   constexpr int TSZ = 1024 * K;
-  unsigned long long* hx = reinterpret_cast<unsigned long long*>(R + 8 * HSZ - 16 * TSZ);
+  // (K = 4: in the upper half of the LDS - free between the edge hash and the polygon tables -: the inserts are atomics)
+  unsigned long long* hx = K == 1 ? reinterpret_cast<unsigned long long*>(R + 8 * HSZ - 16 * TSZ)
+                                  : reinterpret_cast<unsigned long long*>(lds_ + 65536);
   unsigned long long* hy = hx + TSZ;
   const bool hashed = nb <= TSZ / 2;
   auto hpos = [](unsigned long long bits) { return (int)((bits * 0x9E3779B97F4A7C15ull) >> (64 - 10 - (K == 1 ? 0 : 2))); };
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   double* yrange = reinterpret_cast<double*>(G2 + 1024);                      // [4 * TW / 64] wave minima / maxima of the polygon's y, x
   float4* chf = reinterpret_cast<float4*>(G2 + 1024 + 512);                   // [64] group chord {ax, ay, bx - ax, by - ay}
   float2* chr = reinterpret_cast<float2*>(G2 + 1024 + 512 + 1024);            // [64] {1 / |chord|^2, deviation of the group's polyline from it}
-  int* hist = scanb;                                                          // [128]
+  int* hist = K == 1 ? scanb : reinterpret_cast<int*>(lds_ + 65536 + 20480);  // [128]
   {
     float m = 0.f;
     double y0 = 1e300, y1 = -1e300, x0_ = 1e300, x1_ = -1e300;
@@ -876,7 +880,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
       const int e = (int)(h >> 20) - E0;
       return e <= 0 ? 0 : (e >= 63 ? 2047 : (e << 5) | (int)((h >> 15) & 31u));
     };
-    int* hist = scanb;                                     // [2048]
+    int* hist = K == 1 ? scanb : reinterpret_cast<int*>(lds_ + 65536 + 20480);   // [2048]
     uint16_t* sidx = reinterpret_cast<uint16_t*>(inv);     // [nrem] entries grouped by bucket (inv is set up after this)
     for (int i = tid; i < 2048; i += TW) hist[i] = 0;
     if (tid == 0) misc[4] = 0;
