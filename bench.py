@@ -623,6 +623,13 @@ def pmc_traffic(name, leg, kernel):
     return (ent["corrected"] if ent else None), src
 
 
+def _err(exc):
+    """A failed side measurement in the line: the exception and where it was raised (last frames)."""
+    import traceback
+    tb = traceback.extract_tb(exc.__traceback__)
+    return dict(error=repr(exc), where=[f"{os.path.basename(f.filename)}:{f.lineno} {f.name}" for f in tb[-4:]])
+
+
 def _stream_log():
     try:
         from meshdqn_amd import streams
@@ -899,13 +906,13 @@ def main(argv=None):
                                            krylov_iters_per_step=cg["krylov_iters_per_step"])
             cfgs["C2_s2_diverged_meshes"] = c2
         except Exception as exc:  # noqa: BLE001 - side measurement
-            cfgs["C2_s2_diverged_meshes"] = dict(error=repr(exc))
+            cfgs["C2_s2_diverged_meshes"] = _err(exc)
         try:
             c3 = measure_env_steps(args, dev, None, 1, 1, steps=args.s1_steps, repeats=3, mesh="ah93w145")
             c3["what"] = "C3: the S3 step on the second airfoil geometry (ah93w145, 797 vertices), 128 envs"
             cfgs["C3_s3_ah93w145"] = c3
         except Exception as exc:  # noqa: BLE001
-            cfgs["C3_s3_ah93w145"] = dict(error=repr(exc))
+            cfgs["C3_s3_ah93w145"] = _err(exc)
         try:
             sd = measure_env_steps(args, dev, None, 1, 1, steps=args.s1_steps, repeats=3, flow_pressure="direct")
             sd["what"] = ("the S3 step with the pressure matrix of every coarsened mesh re-factorised on the device in every step "
@@ -915,7 +922,7 @@ def main(argv=None):
                           "the Jacobi-CG: one solve per mesh does not pay for a factorisation")
             cfgs["S3_refactorised_pressure"] = sd
         except Exception as exc:  # noqa: BLE001
-            cfgs["S3_refactorised_pressure"] = dict(error=repr(exc))
+            cfgs["S3_refactorised_pressure"] = _err(exc)
         try:
             f3 = measure_env_steps(args, dev, None, 1, 1, steps=args.s1_steps, repeats=3, envs=2 * B)
             f3["what"] = (f"the S3 step with {2 * B} envs on the GPU (one workgroup per env on every CU): at the BASELINE batch of "
@@ -923,7 +930,7 @@ def main(argv=None):
                           "less than twice the time (the IPCS leg no longer hides beside a smoothing kernel that owns every CU)")
             cfgs["S3_full_chip"] = f3
         except Exception as exc:  # noqa: BLE001
-            cfgs["S3_full_chip"] = dict(error=repr(exc))
+            cfgs["S3_full_chip"] = _err(exc)
         try:
             r1 = measure_env_steps(args, dev, None, 1, 0, steps=max(args.s1_steps // 5, 2), warmup=2, repeats=3, mesh=f"{args.mesh}_refined")
             r1["what"] = ("the S1 env step (vertex removal + Delaunay restoration + smooth(50) + interpolation + forces + state graph + "
@@ -933,7 +940,7 @@ def main(argv=None):
                           "of 200 solver steps (a rate measurement)")
             cfgs["C5_s1_refined_mesh"] = r1
         except Exception as exc:  # noqa: BLE001
-            cfgs["C5_s1_refined_mesh"] = dict(error=repr(exc))
+            cfgs["C5_s1_refined_mesh"] = _err(exc)
         try:
             r3 = measure_env_steps(args, dev, None, 1, 1, steps=max(args.s1_steps // 10, 2), warmup=2, repeats=3, mesh=f"{args.mesh}_refined")
             r3["what"] = ("the S3 (north-star) env step on the red-refined mesh: the S1 step above + one IPCS step on every coarsened "
@@ -942,11 +949,11 @@ def main(argv=None):
                           "Jacobi-CG pressure solve")
             cfgs["C5_s3_refined_mesh"] = r3
         except Exception as exc:  # noqa: BLE001
-            cfgs["C5_s3_refined_mesh"] = dict(error=repr(exc))
+            cfgs["C5_s3_refined_mesh"] = _err(exc)
         try:
             cfgs["deploy_episode_s"] = measure_deploy(args, dev)
         except Exception as exc:  # noqa: BLE001
-            cfgs["deploy_episode_s"] = dict(error=repr(exc))
+            cfgs["deploy_episode_s"] = _err(exc)
         try:
             from meshdqn_amd.mesh_ops import red_refine
             rc_, rcells = red_refine(x, z["cells"])
@@ -969,7 +976,7 @@ def main(argv=None):
             del b5
             cfgs["C5_s2_refined_mesh"] = c5
         except Exception as exc:  # noqa: BLE001
-            cfgs["C5_s2_refined_mesh"] = dict(error=repr(exc))
+            cfgs["C5_s2_refined_mesh"] = _err(exc)
 
     if rank == 0:
         def prof(name, key):
@@ -1092,7 +1099,7 @@ def main(argv=None):
                                                                                "env_finish", "probe"))},
                 unit="bytes per lane (-Rpass-analysis=kernel-resource-usage of this build)")
         except Exception as exc:  # noqa: BLE001
-            res["kernel_scratch"] = dict(error=repr(exc))
+            res["kernel_scratch"] = _err(exc)
         res["rates"] = {"S3_north_star_step": s3, "S1_reference_step": s1, "S2_ipcs_step": s2, "S2_full_chip": full,
                         "training_loop": tr, **cfgs}
         if cpu is not None:

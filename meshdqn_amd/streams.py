@@ -47,7 +47,8 @@ def _overlaps(cand: torch.cuda.Stream, other: torch.cuda.Stream, device) -> bool
             _lib.check(lib.mdq_spin(half, 150 * 1024, 4_000, _lib.stream_ptr()), "mdq_spin")       # 40 us each
         c1.record(cand)
     c1.synchronize()
-    ok = c0.elapsed_time(c1) < 0.6
+    c0.synchronize()                          # (another process on the GPU can hold `other` back past the end of `cand`'s chain:
+    ok = c0.elapsed_time(c1) < 0.6            #  elapsed_time of an event that has not completed raises)
     torch.cuda.synchronize(device)
     return ok
 

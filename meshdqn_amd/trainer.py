@@ -686,6 +686,7 @@ class DQNTrainer:
             main.wait_stream(cand)
             e1.record(main)
             venv.rollout_end(ro)
+            e1.synchronize()
             return e0.elapsed_time(e1) / k
         results = []
         for t in range(max(1, int(tries))):

@@ -833,6 +833,7 @@ class VecEnv2DAirfoil:
                 self.rollout_step(ro, fused)
             e1.record(cur)
             self.rollout_end(ro)
+            e1.synchronize()
             return e0.elapsed_time(e1) / k
         from . import streams as _st
         known = _st.calibrated_flow_stream(dev, cur)

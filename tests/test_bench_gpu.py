@@ -52,7 +52,7 @@ def test_bench_single_rank_line(lib_built):
     assert isinstance(res["stream_setup"], list) and res["stream_setup"]
     for k in ("S1_reference_step", "S2_ipcs_step", "training_loop", "C2_s2_diverged_meshes", "C3_s3_ah93w145", "S3_full_chip",
               "S3_refactorised_pressure", "C5_s2_refined_mesh"):
-        assert res["rates"][k]["value"] > 0, (k, res["rates"][k])
+        assert res["rates"][k].get("value", 0) > 0, (k, res["rates"][k])
     c2 = res["rates"]["C2_s2_diverged_meshes"]     # factors built on the device for every coarsened mesh: no pressure iterations
     assert c2["krylov_iters_per_step"]["pressure"] == 0 and c2["factorisation_status_ok"] and c2["factorisation_ms_per_batch"] > 0
     assert c2["jacobi_cg_variant"]["krylov_iters_per_step"]["pressure"] > 15 and c2["value"] > c2["jacobi_cg_variant"]["value"]
@@ -74,7 +74,7 @@ def test_bench_gpus_flag_starts_the_ranks_itself(lib_built):
     assert abs(res["value"] - 2 * 16 * 6 / (res["ms_per_step"] * 6e-3)) < 1e-6 * res["value"]
     assert res["cpu_baseline"]["s2_ipcs"]["value"] > 0
     for k in ("C2_s2_diverged_meshes", "C3_s3_ah93w145", "C5_s2_refined_mesh"):
-        assert res["rates"][k]["value"] > 0, (k, res["rates"][k])
+        assert res["rates"][k].get("value", 0) > 0, (k, res["rates"][k])
     for k in ("device_loop_s3", "device_loop_s1", "host_loop_s1"):   # every loop ran (no fallback), with the record all-gather
         r = res["rates"]["training_loop"][k]
         assert "error" not in r and r["optimiser_steps"] > 0 and r["shared_replay"], (k, r)
