@@ -306,3 +306,44 @@ def test_trainer_save_load_roundtrip(tmp_path):
     os.remove(os.path.join(str(tmp_path), "restart_trainer_state.pt"))
     tr3 = DQNTrainer(180, 17, ctx=DistContext(device=torch.device("cpu")))
     assert tr3.load(str(tmp_path), "restart_", scheduler_steps=10) == {} and tr3.scheds[0].last_epoch == 10
+
+
+def _forced_worker(port, q):
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      MDQ_FORCE_COLLECTIVES="1")
+    torch.set_num_threads(1)
+    import torch.distributed as dist
+    ctx = DistContext(backend="gloo", device=torch.device("cpu"))
+    tr = DQNTrainer(180, 17, ctx=ctx, lr=1e-3, target_update=2)
+    losses = [tr.optimize(_transitions(100 * step)) for step in range(3)]
+    got = allgather_transitions(ctx, _transitions(7, 1), 180, 17, 512)
+    w1 = torch.cat([p.detach().reshape(-1) for p in tr.policy_net_1.parameters()])
+    q.put((ctx.multi, ctx.backend, dist.is_initialized() and dist.get_world_size(), losses, len(got), w1.numpy(), ctx.max_over_ranks(2.5)))
+    ctx.barrier()
+    ctx.close()
+
+
+def test_one_rank_with_forced_collectives_equals_no_process_group():
+    """`MDQ_FORCE_COLLECTIVES=1`: ONE rank creates its process group and sends the gradient all-reduce, the transition
+    all-gather, the timing reduction and the barrier through the backend (gloo here; "nccl" = RCCL on a GPU box:
+    tests/test_trainer_gpu.py) - with the numbers of a trainer that has no group at all."""
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    p = ctxm.Process(target=_forced_worker, args=(_free_port(), q))
+    p.start()
+    multi, backend, world, losses, ngot, w1, tmax = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert multi and backend == "gloo" and world == 1 and ngot == 1 and tmax == 2.5
+    os.environ.pop("MDQ_FORCE_COLLECTIVES", None)
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(1)                  # (as the worker: Adam turns the round-off of a threaded reduction into O(lr) steps)
+    try:
+        tr = DQNTrainer(180, 17, ctx=DistContext(device=torch.device("cpu")), lr=1e-3, target_update=2)
+        assert not tr.ctx.multi
+        ref = [tr.optimize(_transitions(100 * step)) for step in range(3)]
+        w_ref = torch.cat([p_.detach().reshape(-1) for p_ in tr.policy_net_1.parameters()]).numpy()
+    finally:
+        torch.set_num_threads(nthr)
+    assert np.allclose(ref, losses, rtol=1e-6, atol=1e-8)
+    assert np.allclose(w_ref, w1, rtol=1e-5, atol=1e-7)
