@@ -51,6 +51,7 @@ sys.path.insert(0, ROOT)
 
 _WARMED = False
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MAX_CLOCK_HZ = 2.4e9   # MI355X_MICROARCH.md: max clock 2400 MHz
 
 
 def prof_early(name, key):
@@ -186,7 +187,7 @@ def cpu_baseline(budget_s=15.0, spinup=20):
     out = dict(value=None, unit="env steps/s", cores=1, kind="port", sample="S3 leg skipped (MDQ_BENCH_CPU_LEGS)", s2_ipcs=s2)
     if "s3" in legs:
         n3, dt3 = cpu_baseline_s3(max(budget_s, 10.0))
-        out.update(value=n3 / dt3,
+        out.update(value=n3 / dt3, sample_short=f"{n3} S3 env steps of 1 ys930 env in {dt3:.1f} s on 1 core (numpy/scipy oracle, kind=port)",
                    sample=f"{n3} S3 env steps of 1 ys930 env in {dt3:.1f} s on 1 core: OracleEnv.step (scipy Delaunay, "
                           "python-loop smoothing / interpolation / probes / state) + Taylor-Hood assembly and sparse LU of "
                           "the coarsened mesh + one evolve() from the interpolated last snapshot (numpy/scipy oracle); no "
@@ -404,6 +405,7 @@ def measure_smooth_kernel(dev, groups, reps=20):
     nbytes = float((nv.astype(np.float64) * 32 + nt.astype(np.float64) * 12).sum())
     nblk = (np.maximum(nv - 182, 1) + 31) // 32          # (interior vertices of a ys930-family mesh: all but 182 boundary ones)
     return dict(launch_ms=float(np.mean(ms)), launch_ms_min=float(np.min(ms)), launches=reps, meshes=int(len(nv)),
+                block_steps_per_sweep=float(nblk.mean()),          # dependent block steps of one sweep (32-row blocks)
                 algorithmic_bytes_per_launch=nbytes,
                 workspace_bytes_per_launch=float((nblk * 8192.0 * (1 + 50)).sum()))   # block inverses: written once, read per sweep
 
@@ -630,6 +632,100 @@ def _err(exc):
     return dict(error=repr(exc), where=[f"{os.path.basename(f.filename)}:{f.lineno} {f.name}" for f in tb[-4:]])
 
 
+LINE_LIMIT = 8192        # bytes of the ONE stdout line (the driver reads the tail of stdout; round 5's 22.9 KB line was not parsed)
+DETAIL_FILE = "bench_detail.json"
+
+
+def _kernel_scratch():
+    """Per-kernel resources of the library that RAN (the table is stamped with the sha256 of the .so it was built with;
+    refused for any other library)."""
+    try:
+        from meshdqn_amd import build as _b
+        from meshdqn_amd._lib import LIB_PATH
+        kres = _b.library_resources(LIB_PATH)
+        hot = ("smooth_linear", "at_velocity", "at_pressure", "at_correction", "topology_kernel", "gcn_embed", "mlp_head_c128",
+               "remesh_kernel", "evolve_mf", "evolve_kernel<5", "evolve_team_tiles", "setup_matfree", "interpolate", "env_finish",
+               "probe")
+        return dict(kernels=len(kres), with_scratch={k: v["scratch_bytes_per_lane"] for k, v in kres.items() if v["scratch_bytes_per_lane"] > 0},
+                    hot_kernels={k: dict(vgprs=v["vgprs"], scratch=v["scratch_bytes_per_lane"], occupancy=v["occupancy"])
+                                 for k, v in kres.items() if any(t in k for t in hot)},
+                    unit="bytes per lane (-Rpass-analysis=kernel-resource-usage of this build)")
+    except Exception as exc:  # noqa: BLE001
+        return _err(exc)
+
+
+def _write_detail(res):
+    """Everything measured (prose, per-repeat times, side tables) goes to a FILE: MDQ_BENCH_DETAIL, default bench_detail.json
+    beside this script (a temporary file when that directory is read-only).  Returns the path written."""
+    import tempfile
+    path = os.environ.get("MDQ_BENCH_DETAIL") or os.path.join(ROOT, DETAIL_FILE)
+    try:
+        with open(path, "w") as f:
+            json.dump(res, f, indent=1)
+    except OSError:
+        fd, path = tempfile.mkstemp(prefix="mdq_bench_detail_", suffix=".json")
+        with os.fdopen(fd, "w") as f:
+            json.dump(res, f, indent=1)
+    return path
+
+
+def _num(v, digits=6):
+    """A float with `digits` significant digits (the line carries numbers, the detail file carries them in full)."""
+    if isinstance(v, bool) or not isinstance(v, float):
+        return v
+    return float(f"{v:.{digits}g}")
+
+
+def _short(v, n=120):
+    return v if not isinstance(v, str) or len(v) <= n else v[:n - 3] + "..."
+
+
+def compact_line(res, detail_path):
+    """The contract line from the full result: contract keys only, one NUMBER per side rate, no prose (strings <= 120
+    characters), <= LINE_LIMIT bytes.  Everything else is in the detail file."""
+    cfg, roof, cpu = res["config"], res["roofline"], res.get("cpu_baseline")
+    line = {k: _num(res[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "steady_state_ms_per_step",
+                                       "repeats", "value_min", "value_max", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {"workload": cfg["workload_short"], "mesh": cfg["mesh"], "envs_per_gpu": cfg["envs_per_gpu"],
+                      "rtol": cfg["rtol"], "dt": cfg["dt"], "mu": cfg["mu"], "rho": cfg["rho"],
+                      "krylov_iters_per_ipcs_step": {k: _num(v, 4) for k, v in cfg["krylov_iters_per_ipcs_step"].items()},
+                      "parallelism": cfg["parallelism"], "collective_backend": cfg["collective_backend"]}
+    line["roofline"] = {k: _num(roof.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+    line["roofline"].update(kernel="smooth_linear_kernel", traffic_source=_short(roof.get("traffic_source_short")),
+                            **{k: _num(roof.get(k)) for k in ("launch_ms", "launches_timed", "launch_ms_alone", "algorithmic_bytes_per_launch",
+                                                               "share_of_step", "floor_ms", "launch_over_floor", "device_copy_GBs_same_run")})
+    if cpu is not None:
+        s2 = cpu.get("s2_ipcs") or {}
+        line["cpu_baseline"] = {"value": _num(cpu.get("value")), "unit": cpu.get("unit"), "cores": cpu.get("cores"), "kind": cpu.get("kind"),
+                                "sample": _short(cpu.get("sample_short") or cpu.get("sample")),
+                                "parallel_value": _num(cpu.get("parallel_value")), "parallel_cores": cpu.get("parallel_cores"),
+                                "s2_ipcs": {"value": _num(s2.get("value")), "cores": s2.get("cores"),
+                                            "parallel_value": _num(s2.get("parallel_value")), "parallel_cores": 12 if s2.get("parallel_value") else None}}
+    rates = {}
+    for name, r in (res.get("rates") or {}).items():
+        if isinstance(r, dict):
+            rates[name] = _num(r["value"]) if isinstance(r.get("value"), (int, float)) else ("error" if "error" in r else None)
+        else:
+            rates[name] = None
+    line["rates"] = rates
+    line["rates_unit"] = "env steps/s (deploy_episode_s: seconds per deployed episode)"
+    c5 = (res.get("rates") or {}).get("C5_s3_refined_mesh") or {}
+    if isinstance(c5.get("krylov_iters_per_ipcs_step"), dict):
+        line["c5_s3_krylov_iters"] = {k: _num(v, 4) for k, v in c5["krylov_iters_per_ipcs_step"].items()}
+    line["detail"] = os.path.basename(detail_path)
+    return line
+
+
+def _detail_digest(res):
+    """A few human-readable lines for stderr."""
+    out = [f"[bench] {res['value']:.0f} {res['unit']} ({res['ms_per_step']:.4f} ms per batched step, steady state "
+           f"{res.get('steady_state_ms_per_step')}), {res['n_gpus']} GPU(s)"]
+    for name, r in (res.get("rates") or {}).items():
+        if isinstance(r, dict):
+            out.append(f"[bench]   {name}: {r.get('value')} {r.get('unit', '')}" + (f"  ERROR {r['error']}" if "error" in r else ""))
+    return "\n".join(out)
+
+
 def _stream_log():
     try:
         from meshdqn_amd import streams
@@ -762,7 +858,11 @@ def main(argv=None):
 
     # the contract is ONE JSON line on stdout: whatever the measured code prints (the environment keeps the reference's
     # progress messages, e.g. "MAXIMUM REMOVALS REACHED") goes to stderr
-    real_stdout = sys.stdout
+    # ... at the level of the file descriptor: RCCL prints its version banner to the C stdout when a communicator is created
+    # (lazily: at the first collective - which may be the LAST barrier of this program), and the driver reads the tail of stdout
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     sys.stdout = sys.stderr
     import torch
     # the GPU boxes expose 256 logical CPUs under a 16-core quota: a 256-thread intra-op pool that keeps spinning after
@@ -1021,6 +1121,9 @@ def main(argv=None):
             "collective_backend": rccl,          # backend, RCCL version, ranks (None for a single rank)
             "stream_setup": _stream_log(),       # rank 0: how the main / flow / optimiser streams were chosen
             "config": {
+                "workload_short": f"{args.mesh} ({nv} vertices / {nt} triangles), {B} envs per GPU, S3 env step (remesh+smooth+interp+"
+                                  f"forces+state+1 IPCS step+Q-fwd)",
+                "mesh": args.mesh,
                 "workload": f"{args.mesh} ({nv} vertices / {nt} triangles), {B} batched envs per GPU, step = S3 (north-star env "
                             f"step): remove vertex + Delaunay restoration + smooth(50) + 5-snapshot interpolation + 10 force "
                             f"integrals + state graph + ONE IPCS step on every coarsened mesh (matrix-free, Jacobi-BiCGStab / "
@@ -1054,6 +1157,8 @@ def main(argv=None):
                          "launch_ms_alone": smk["launch_ms"],
                          "last_launch_diagnostics": insitu.get("last_launch_diagnostics") if insitu else None,
                          "traffic_source": sm_traffic_src,
+                         "traffic_source_short": f"profiles/{PMC_SUMMARY} (rocprofv3 --pmc, gfx950-corrected)" if sm_traffic is not None
+                                                 else "refused: sources changed since profiles/" + PMC_SUMMARY,
                          "workspace_bytes_per_launch": smk.get("workspace_bytes_per_launch"),
                          "algorithmic_bytes_per_launch": smk["algorithmic_bytes_per_launch"],
                          "share_of_step": sm_ms / s3["ms_per_batched_step"],
@@ -1088,27 +1193,25 @@ def main(argv=None):
                 "note": "matrix-free: operators are re-derived per triangle from 64 B of metadata, Krylov vectors live in "
                         "LDS/registers; one workgroup (one CU) per environment: 128 of 256 CUs at the BASELINE configuration"},
         }
-        try:        # per-kernel resources of the library that ran (written by meshdqn_amd/build.py from the compiler's remarks)
-            kres = json.load(open(os.path.join(ROOT, "meshdqn_amd", "libmeshdqn_hip.resources.json")))
-            res["kernel_scratch"] = dict(
-                kernels=len(kres), with_scratch={k: v["scratch_bytes_per_lane"] for k, v in kres.items() if v["scratch_bytes_per_lane"] > 0},
-                hot_kernels={k: dict(vgprs=v["vgprs"], scratch=v["scratch_bytes_per_lane"], occupancy=v["occupancy"])
-                             for k, v in kres.items() if any(t in k for t in ("smooth_linear", "at_velocity", "at_pressure", "at_correction",
-                                                                               "topology_kernel", "gcn_embed", "mlp_head_c128", "remesh_kernel",
-                                                                               "evolve_mf", "evolve_kernel<5", "evolve_team_tiles", "setup_matfree", "interpolate",
-                                                                               "env_finish", "probe"))},
-                unit="bytes per lane (-Rpass-analysis=kernel-resource-usage of this build)")
-        except Exception as exc:  # noqa: BLE001
-            res["kernel_scratch"] = _err(exc)
+        res["kernel_scratch"] = _kernel_scratch()
         res["rates"] = {"S3_north_star_step": s3, "S1_reference_step": s1, "S2_ipcs_step": s2, "S2_full_chip": full,
                         "training_loop": tr, **cfgs}
         if cpu is not None:
             res["cpu_baseline"] = cpu
-        print(json.dumps(res), file=real_stdout, flush=True)
-    sys.stdout = real_stdout
+        # the smoothing kernel against ITS bound (a dependency chain, not HBM): block steps x sweeps x 4 LDS round trips of
+        # ~110 cycles each at the device clock
+        clock_hz = MAX_CLOCK_HZ
+        res["roofline"]["floor_ms"] = smk["block_steps_per_sweep"] * 50 * 4 * 110 / clock_hz * 1e3
+        res["roofline"]["launch_over_floor"] = sm_ms / res["roofline"]["floor_ms"]
+        detail_path = _write_detail(res)
+        sys.stderr.write(_detail_digest(res) + "\n")
+        line = json.dumps(compact_line(res, detail_path))
+        assert len(line) <= LINE_LIMIT, len(line)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:               # the LAST thing this process writes to stdout
+        print(line, file=real_stdout, flush=True)
 
 
 if __name__ == "__main__":

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define MDQ_ABI_VERSION 6
+#define MDQ_ABI_VERSION 7
 
 /* The library is built with -fvisibility=hidden: the entry points below are its ONLY exported symbols. */
 #if defined(__GNUC__)
@@ -184,7 +184,13 @@ typedef struct mdq_ipcs_desc {
                                   (needs NRL rows of 16 bytes behind the 96 KB tile: NRL <= ~3900) */
   int32_t NRL, rl_flags;             /* rl_flags = 1: bit 31 / bit 30 of a list entry's row word mark the FIRST / LAST chunk that
                                         touches the row, and every row < n2 is touched by some chunk (ABI 5, round 4) */
+  /* ABI 7 (round 6), optional (NULL: off): [B] STICKY status words of the environments, OR-ed into by mdq_ipcs_evolve and never
+     cleared by the library (the caller zeroes them).  MDQ_IPCS_TEAM_TIMEOUT: an IPCS step of the two-workgroup operator modes
+     (4 / 7) was abandoned because a team barrier timed out - the partner workgroup was not resident (another process or stream
+     held its CU).  That step and the later steps of the launch report NaN drag / lift; u_n / p_n keep the last completed step. */
+  int32_t* status;
 } mdq_ipcs_desc;
+#define MDQ_IPCS_TEAM_TIMEOUT 1
 
 /* doubles of workspace needed for a descriptor with the given capacities */
 MDQ_API int64_t mdq_ipcs_workspace_doubles(int32_t B, int32_t NV, int32_t NT, int32_t NE);

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # (MDQ_LIB_PATH: a differently built copy of the library, e.g. an experiment of tools/: development knob)
 LIB_PATH = os.environ.get("MDQ_LIB_PATH") or os.path.join(HERE, "libmeshdqn_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class MeshDQNHipError(RuntimeError):
@@ -51,6 +51,7 @@ class IpcsDesc(C.Structure):
         ("u_n", C.c_void_p), ("p_n", C.c_void_p),
         ("work", C.c_void_p), ("work_doubles", C.c_int64),
         ("mf_rlist", C.c_void_p), ("mf_rcnt", C.c_void_p), ("mf_lpos", C.c_void_p), ("NRL", C.c_int32), ("rl_flags", C.c_int32),
+        ("status", C.c_void_p),
     ]
 
 

@@ -109,8 +109,9 @@ def _stale() -> bool:
     try:        # built with other flags (MDQ_CFLAGS experiments)?
         if open(os.path.join(OBJ, "flags.txt")).read() != " ".join(_flags(False)):
             return True
-    except OSError:
-        return True
+    except OSError:     # no record of the flags (a tree copied without build/): stale only if flags were asked for
+        if os.environ.get("MDQ_CFLAGS"):
+            return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
     deps.append(os.path.join(ROOT, "include", "meshdqn_hip.h"))
@@ -186,9 +187,33 @@ def build(force: bool = False, verbose: bool = False) -> str:
     table = {}
     for n in UNITS:
         table.update(parse_resources(logs[n]))
+    # stamped with the sha256 of the library it describes: `library_resources` refuses the table for any other .so
+    table["_library_sha256"] = file_sha256(LIB)
     with open(RESOURCES, "w") as f:
         json.dump(table, f, indent=0, sort_keys=True)
     return LIB
+
+
+def file_sha256(path: str) -> str:
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
+def library_resources(lib_path: str) -> dict:
+    """The per-kernel resource table of `lib_path` - only if the table beside the in-tree library was written by the build
+    that linked exactly that file (sha256 stamp); raises otherwise (a prebuilt, variant or MDQ_LIB_PATH library has no
+    table of its own)."""
+    import json
+    with open(RESOURCES) as f:
+        table = json.load(f)
+    stamp = table.pop("_library_sha256", None)
+    if stamp is None or stamp != file_sha256(lib_path):
+        raise RuntimeError(f"{os.path.basename(RESOURCES)} does not describe {lib_path} (sha256 stamp "
+                           f"{'missing' if stamp is None else 'differs'}): rebuild with `python -m meshdqn_amd.build --force`")
+    return table
 
 
 if __name__ == "__main__":

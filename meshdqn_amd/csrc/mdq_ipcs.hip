@@ -3041,7 +3041,7 @@ __device__ __forceinline__ void team_place(Team& t, unsigned* ids, int general) 
   const unsigned i0 = __hip_atomic_load(ids, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned i1 = __hip_atomic_load(ids + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   static_assert(TEAM == 2, "two ids");
-  t.local = i0 == i1 && !general;     // (`general`: MDQ_TEAM_GENERAL_BARRIER=1 keeps the placement-independent protocol - tests)
+  t.local = i0 == i1 && !(general & 1);     // (`general` bit 0: MDQ_TEAM_GENERAL_BARRIER=1 keeps the placement-independent protocol - tests)
 }
 template <int N>
 __device__ __forceinline__ void team_sum(double (&v)[N], double* red, Team& t) {
@@ -3058,6 +3058,17 @@ __device__ __forceinline__ void team_sum(double (&v)[N], double* red, Team& t) {
   for (int n = 0; n < N; ++n) v[n] = s0[n] + s0[4 + n];
   t.par ^= 1;
 }
+
+// A bounded spin of this team ran out in this launch (the partner workgroup was not resident for ~2^22 polls: another process
+// or another stream held its CU).  Read by every thread behind a team barrier.  The step that sees it does NOT advance u_n / p_n,
+// drops the initial-guess history (the vectors computed past the broken barrier are finite garbage), reports NaN forces for
+// this and every later step of the launch, and the host raises (ipcs_batch.py / vec_env.py: `MeshDQNHipError`).
+__device__ __forceinline__ bool team_failed(const Team& t) {
+  return __hip_atomic_load(t.ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+// bit 1 of the kernels' `general` argument (MDQ_TEAM_TEST_ABSENT_PARTNER=1, tests only): the second workgroup of
+// environment 0 leaves at once - the time-out path of the barrier, forced
+__device__ __forceinline__ bool team_test_absent(int general, int b, int rank) { return (general & 2) && b == 0 && rank == 1; }
 
 // "No initial-guess history on a new mesh" (FlowSolver.remesh restarts u_n / p_n and the solvers, flow_solver.py:233-359):
 // the counters of the extrapolated initial guesses (tentative velocities stored, corrections stored / ring position / lagged
@@ -3099,7 +3110,7 @@ __global__ __launch_bounds__(WG) void evolve_team_kernel(mdq_ipcs_desc d, int ns
   // (a speed choice only: the protocol is placement-independent)
   const int q = blockIdx.x / (8 * TEAM), r8 = blockIdx.x % (8 * TEAM);
   const int b = q * 8 + (r8 & 7), rank = r8 >> 3;
-  if (b >= d.B) return;
+  if (b >= d.B || team_test_absent(general, b, rank)) return;
   const int tid = threadIdx.x, gt = rank * WG + tid;
   constexpr int GS = TEAM * WG;
   const EnvView v = env_view(d, b);
@@ -3458,6 +3469,14 @@ __global__ __launch_bounds__(WG) void evolve_team_kernel(mdq_ipcs_desc d, int ns
     }
     team_sync(T);
     // ---------------- update state + probes
+    if (team_failed(T)) {       // (see team_failed: the state stays the last good one, NaN forces from here on)
+      if (rank == 0 && tid == 0) {
+        hcnt[0] = 0.0;
+        if (d.status) atomicOr(d.status + b, MDQ_IPCS_TEAM_TIMEOUT);
+        for (int s_ = step; s_ < nsteps; ++s_) drag[(int64_t)b * nsteps + s_] = lift[(int64_t)b * nsteps + s_] = __builtin_nan("");
+      }
+      break;
+    }
     for (int i = gt; i < n2; i += GS) {
       const double sd = v.sdiagM[i];
       const double2 x = xs[i];
@@ -3469,7 +3488,7 @@ __global__ __launch_bounds__(WG) void evolve_team_kernel(mdq_ipcs_desc d, int ns
       double dr, li;
       forces(v, d.mu, v.u_n, v.p_n, red, dr, li);
       if (tid == 0) {
-        const bool failed = __hip_atomic_load(T.ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        const bool failed = team_failed(T);
         drag[(int64_t)b * nsteps + step] = failed ? __builtin_nan("") : dr;
         lift[(int64_t)b * nsteps + step] = failed ? __builtin_nan("") : li;
       }
@@ -3484,7 +3503,32 @@ __global__ __launch_bounds__(WG) void evolve_team_kernel(mdq_ipcs_desc d, int ns
 
 // MDQ_TEAM_GENERAL_BARRIER=1 (read per launch): the teams keep the placement-independent agent-scope barrier even when both
 // workgroups share an XCD - the same arithmetic, so the same bits (tests/test_ipcs_gpu.py), at 2-3x the step time
-static int team_general_barrier() { return std::getenv("MDQ_TEAM_GENERAL_BARRIER") != nullptr ? 1 : 0; }
+static int team_general_barrier() {
+  return (std::getenv("MDQ_TEAM_GENERAL_BARRIER") != nullptr ? 1 : 0) | (std::getenv("MDQ_TEAM_TEST_ABSENT_PARTNER") != nullptr ? 2 : 0);
+}
+
+// CUs the team modes may count on when they are chosen AUTOMATICALLY: every workgroup of a team must be resident at the same
+// time (the barrier spins), so the launch stream has to own that many CUs - the CUs of the stream's mask when it carries one
+// (hipExtStreamCreateWithCUMask: meshdqn_amd/streams.py, MDQ_CU_PARTITION), and none at all when the process has been told
+// that it shares the GPU with other processes (MDQ_SHARE_GPU: several ranks on one device).  An explicit mode 4 / 7 is the
+// caller's decision; a time-out is reported either way (team_failed).
+static int team_cus(hipStream_t st) {
+  static const int ncu = [] {
+    int dev_ = 0, n_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess || hipDeviceGetAttribute(&n_, hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess)
+      return 0;
+    return n_;
+  }();
+  if (std::getenv("MDQ_SHARE_GPU") != nullptr) return 0;
+  uint32_t mask[16] = {0};
+  if (hipExtStreamGetCUMask(st, 16, mask) != hipSuccess) {
+    (void)hipGetLastError();
+    return ncu;
+  }
+  int n = 0;
+  for (int i = 0; i < 16; ++i) n += __builtin_popcount(mask[i]);
+  return n > 0 && n < ncu ? n : ncu;
+}
 
 template <bool K1_LDS>
 static hipError_t launch_evolve_team(const mdq_ipcs_desc* d, size_t lds, int nsteps, double* drag, double* lift,
@@ -3607,7 +3651,7 @@ __global__ __launch_bounds__(WG) void evolve_team_tiles_kernel(mdq_ipcs_desc d, 
   extern __shared__ __align__(16) double smem[];
   const int q = blockIdx.x / (8 * TEAM), r8 = blockIdx.x % (8 * TEAM);
   const int b = q * 8 + (r8 & 7), rank = r8 >> 3;
-  if (b >= d.B) return;
+  if (b >= d.B || team_test_absent(general, b, rank)) return;
   const int tid = threadIdx.x, gt = rank * WG + tid;
   constexpr int GS = TEAM * WG;
   const EnvView v = env_view(d, b);
@@ -3979,6 +4023,14 @@ __global__ __launch_bounds__(WG) void evolve_team_tiles_kernel(mdq_ipcs_desc d, 
     }
     team_sync(T);
     // ---------------- update state + probes
+    if (team_failed(T)) {       // (see team_failed: the state stays the last good one, NaN forces from here on)
+      if (rank == 0 && tid == 0) {
+        hcnt[0] = 0.0;
+        if (d.status) atomicOr(d.status + b, MDQ_IPCS_TEAM_TIMEOUT);
+        for (int s_ = step; s_ < nsteps; ++s_) drag[(int64_t)b * nsteps + s_] = lift[(int64_t)b * nsteps + s_] = __builtin_nan("");
+      }
+      break;
+    }
     for (int i = T.rbeg + tid; i < T.rend; i += WG) {
       const double sd = v.sdiagM[i];
       const double2 x = xs[i];
@@ -3990,7 +4042,7 @@ __global__ __launch_bounds__(WG) void evolve_team_tiles_kernel(mdq_ipcs_desc d, 
       double dr, li;
       forces(v, d.mu, v.u_n, v.p_n, red, dr, li);
       if (tid == 0) {
-        const bool failed = __hip_atomic_load(T.ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        const bool failed = team_failed(T);
         drag[(int64_t)b * nsteps + step] = failed ? __builtin_nan("") : dr;
         lift[(int64_t)b * nsteps + step] = failed ? __builtin_nan("") : li;
       }
@@ -5753,26 +5805,13 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
       // at least half of the chip idle even so (measured on ys930 red-refined, ms per step one / two workgroups: B = 1
       // 13.7 / 8.0, 32: 16.7 / 11.9, 64: 24.5 / 22.0, 96: 26.0 / 29.3, 128: 20.0 / 26.1 - from ~64 environments on the
       // step is bound by the memory system as a whole, and the team barriers' cache write-backs / invalidations only add)
-      static const int ncu = [] {
-        int dev_ = 0, n_ = 0;
-        if (hipGetDevice(&dev_) != hipSuccess ||
-            hipDeviceGetAttribute(&n_, hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess)
-          return 0;
-        return n_;
-      }();
+      const int ncu = team_cus((hipStream_t)stream);
       if (!pg && 2 * TEAM * d->B <= ncu) mode = 4;
     }
     // the element tiles with TWO workgroups per environment while the batch leaves half of the chip idle (BASELINE batch of
     // 128 refined meshes: 11.3 -> ms per step; MDQ_NO_TEAM_TILES=1 is the A / B switch)
     if (mode == 5 && !pg && std::getenv("MDQ_NO_TEAM_TILES") == nullptr) {
-      static const int ncu5 = [] {
-        int dev_ = 0, n_ = 0;
-        if (hipGetDevice(&dev_) != hipSuccess ||
-            hipDeviceGetAttribute(&n_, hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess)
-          return 0;
-        return n_;
-      }();
-      if (TEAM * d->B <= ncu5) mode = 7;
+      if (TEAM * d->B <= team_cus((hipStream_t)stream)) mode = 7;
     }
   }
   if (kernel_ms && mode != 3) return fail_msg("per-kernel timing exists for the three-kernel mode 3 only");

@@ -67,7 +67,9 @@ def resimulate_batch(env, meshes):
         if done % env.save_steps == 0:
             drags.append(d[:, -1].clone())
             lifts.append(l[:, -1].clone())
-    return torch.stack(drags, 1).cpu().numpy(), torch.stack(lifts, 1).cpu().numpy()
+    out = torch.stack(drags, 1).cpu().numpy(), torch.stack(lifts, 1).cpu().numpy()
+    batch.check()               # (an abandoned step - team barrier time-out - is an error, not a NaN row in the evaluation)
+    return out
 
 
 @torch.no_grad()

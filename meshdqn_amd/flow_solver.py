@@ -18,6 +18,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+from . import _lib
 from .io_xdmf import load_mesh
 from .ipcs_batch import IpcsBatch, smooth_coords
 from .probes import DragProbe, LiftProbe
@@ -227,6 +228,9 @@ class FlowSolver(object):
                 dr, li = self.batch.evolve(1)
                 d.append(dr[0, 0].item())
                 l.append(li[0, 0].item())
+        if d[-1] != d[-1] or l[-1] != l[-1]:       # NaN: the kernels' report of a step they could not take (already synchronised)
+            self.batch.check()
+            raise _lib.MeshDQNHipError("IPCS step returned non-finite drag / lift (diverged solve)")
         self.accumulated_drag.extend(d)
         self.accumulated_lift.extend(l)
         return self.u_, self.p_, d[-1], l[-1]

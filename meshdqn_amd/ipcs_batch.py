@@ -206,6 +206,7 @@ class IpcsBatch:
         nwork = int(self.lib.mdq_ipcs_workspace_doubles(B, NV, NT, NE))
         t["work"] = z(nwork)
         self.iters = torch.zeros((B, 3), dtype=torch.int32, device=dev)
+        self.status = torch.zeros(B, dtype=torch.int32, device=dev)       # sticky (mdq_ipcs_desc.status, ABI 7): see `check`
         self.steps_done = 0
 
         d = _lib.IpcsDesc()
@@ -225,6 +226,7 @@ class IpcsBatch:
         if os.environ.get("MDQ_NO_TILE_MAPS", "") == "1":     # (A / B: modes 5 / 7 through the dof <- slot lists, as on device-built index data)
             d.mf_tptr = d.mf_scat = d.mf_rlist = d.mf_rcnt = d.mf_lpos = None
         d.work_doubles = nwork
+        d.status = self.status.data_ptr()
         d.NRL = getattr(self, "_NRL", 0)
         d.rl_flags = getattr(self, "_rl_flags", 0)
         d.pd_enabled = 0
@@ -426,6 +428,16 @@ class IpcsBatch:
         _lib.check(rc, "mdq_ipcs_evolve")
         self.steps_done += nsteps
         return drag, lift
+
+    def check(self):
+        """Synchronises and raises if any `evolve` since the last call abandoned a step (status words of the descriptor: the
+        two-workgroup operator modes 4 / 7 give a step up when a team barrier times out - csrc/mdq_ipcs.hip `team_failed`; the
+        forces of that step are NaN and u_n / p_n keep the last completed step).  `evolve` itself never synchronises."""
+        st = self.status.cpu().numpy()
+        if (st != 0).any():
+            self.status.zero_()
+            raise _lib.MeshDQNHipError(f"IPCS step abandoned in environment(s) {np.flatnonzero(st)[:8].tolist()}: team barrier "
+                                       "time-out (another process or stream held CUs of a two-workgroup operator mode)")
 
     def evolve_timed(self, nsteps: int = 1, stream=None, out=None):
         """`evolve` with HIP events around every kernel (mode 3): returns (drag, lift, ms) where ms[3] are the

@@ -209,6 +209,11 @@ class VecEnv2DAirfoil:
                 d.pd_enabled = 1
             self.flow_pd_status = torch.zeros(B, dtype=i32, device=dev)
         self.flow_iters = torch.zeros((B, 3), dtype=torch.int32, device=dev)
+        # sticky status words of the flow legs (mdq_ipcs_desc.status, ABI 7): a leg that gave up - team barrier time-out of the
+        # two-workgroup operator modes - is an ERROR at the next read-back (rollout_end / flow_wait), not a silent NaN
+        self.flow_status = torch.zeros(B, dtype=torch.int32, device=dev)
+        for d in self.flow_descs:
+            d.status = self.flow_status.data_ptr()
         self.flow_drag = np.zeros((B, self.flow_steps))
         self.flow_lift = np.zeros((B, self.flow_steps))
         if self.flow_overlap:
@@ -408,7 +413,9 @@ class VecEnv2DAirfoil:
             return None
         res = self._flow_res[self._flow_prev]
         res["done"].synchronize()
-        return res["host"][0].numpy().copy(), res["host"][1].numpy().copy()
+        fd, fl = res["host"][0].numpy().copy(), res["host"][1].numpy().copy()
+        _check_flow_forces(fd, fl, "flow_wait", self.flow_status.cpu().numpy())
+        return fd, fl
 
     # ------------------------------------------------------------------
     def _reset_env(self, b):
@@ -1066,6 +1073,8 @@ class VecEnv2DAirfoil:
                  ("nv_steps", ro["nv"][:K]), ("err", ro["err"]), ("nv", dt.nv), ("nt", dt.nt), ("offset", dt.offset),
                  ("steps", ro["d_steps"][ro["si"]]), ("drag", self._dev_drag), ("lift", self._dev_lift)]
         parts += [(k, dt.t[k]) for k in ("nsel", "nedges", "ne", "coord_map", "n_closest")]
+        if self.flow_steps > 0:
+            parts.append(("flow_status", self.flow_status))        # (legs up to the previous step: the last one may still run)
         flat = [t.contiguous().view(torch.uint8).reshape(-1) for _, t in parts]
         pad = [(-f.numel()) % 8 for f in flat]                  # (every part starts 8-byte aligned in the packed buffer)
         packed = torch.cat([x for f, p_ in zip(flat, pad) for x in ((f, f.new_zeros(p_)) if p_ else (f,))])
@@ -1084,6 +1093,8 @@ class VecEnv2DAirfoil:
                    nv=got["nv_steps"])
         if int(got["err"][0]) != 0:
             raise _lib.MeshDQNHipError("topology kernel failed inside rollout_device")
+        if K:               # a failed flow leg is an ERROR here, not a NaN in what the caller reads later
+            _check_flow_forces(got["drag"], got["lift"], "rollout_device", got.get("flow_status"))
         self.nv[...], self.nt[...], self.offset[...], self.steps[...] = got["nv"], got["nt"], got["offset"], got["steps"]
         for k in ("nsel", "nedges", "ne", "coord_map", "n_closest"):
             h[k][...] = got[k]
@@ -1104,6 +1115,22 @@ class VecEnv2DAirfoil:
                        "mdq_restore_rows")
         self._deferred_mirror = None
         return out
+
+
+def _check_flow_forces(drag, lift, where, status=None):
+    """Raises when a flow leg reported a step it could not take: a set status word (mdq_ipcs_desc.status: the two-workgroup
+    operator modes 4 / 7 abandon a step when a team barrier times out - the partner workgroup was not resident because another
+    process or stream held its CU; csrc/mdq_ipcs.hip `team_failed`; u_n / p_n of that environment were not advanced) or
+    non-finite drag / lift (the same event seen through the forces, or a solve that diverged)."""
+    bad = ~(np.isfinite(drag) & np.isfinite(lift))
+    bad = bad.reshape(bad.shape[0], -1).any(1)
+    timed_out = np.zeros_like(bad) if status is None else (np.asarray(status) != 0)
+    if bad.any() or timed_out.any():
+        which = np.flatnonzero(bad | timed_out)
+        raise _lib.MeshDQNHipError(
+            f"{where}: the flow leg failed in environment(s) {which[:8].tolist()}{' ...' if which.size > 8 else ''}: "
+            + ("team barrier time-out of the two-workgroup IPCS modes (is another process or a CU-masked stream holding CUs? "
+               "MDQ_NO_TEAM_TILES=1 keeps one workgroup per environment)" if timed_out.any() else "non-finite drag / lift"))
 
 
 class VecEnvGroups:

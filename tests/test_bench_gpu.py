@@ -14,18 +14,40 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--steps", "6", "--warmup", "2", "--repeats", "3", "--spinup", "60", "--s2-steps", "20", "--envs", "16",
          "--s1-steps", "4", "--s1-warmup", "3", "--train-steps", "3", "--s1-solver-steps", "200"]
-KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-        "vs_baseline", "dtype", "data", "config", "roofline", "roofline_s2_velocity", "rates", "repeats", "value_min",
-        "value_max", "s1_env_steps_per_s", "s2_ipcs_env_steps_per_s", "s3_env_steps_per_s", "training_env_steps_per_s",
-        "steady_state_ms_per_step", "kernel_scratch"}
+LINE_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+             "vs_baseline", "dtype", "data", "config", "roofline", "rates", "repeats", "value_min", "value_max",
+             "steady_state_ms_per_step", "detail"}
+KEYS = LINE_KEYS - {"detail"} | {"roofline_s2_velocity", "s1_env_steps_per_s", "s2_ipcs_env_steps_per_s", "s3_env_steps_per_s",
+                                 "training_env_steps_per_s", "kernel_scratch"}       # of the detail file
 
 
-def _line(cmd, env):
-    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-3000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    return json.loads(lines[0])
+def _line(cmd, env, tmp_path=None):
+    """Runs bench.py; returns the DETAIL (the full result, written to a file) after checking the stdout line against it:
+    the line is the last thing on stdout, <= 8 KB (the driver reads the tail of stdout), parses on its own, and carries
+    numbers only for the side rates."""
+    import tempfile
+    fd, detail_path = tempfile.mkstemp(prefix="mdq_bench_detail_test_", suffix=".json")
+    os.close(fd)
+    try:
+        out = subprocess.run(cmd, cwd=ROOT, env=dict(env, MDQ_BENCH_DETAIL=detail_path), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1 and out.stdout.rstrip("\n").endswith(lines[0]), out.stdout[-2000:]
+        assert len(lines[0]) <= 8192, len(lines[0])
+        line = json.loads(out.stdout[-8192:][out.stdout[-8192:].index("{"):])     # what a reader of the last 8 KB of stdout sees
+        detail = json.load(open(detail_path))
+    finally:
+        os.unlink(detail_path)
+    assert LINE_KEYS <= set(line) and line["detail"] == os.path.basename(detail_path)
+    for k in ("value", "ms_per_step", "value_min", "value_max"):
+        assert abs(line[k] - detail[k]) <= 1e-5 * abs(detail[k])
+    assert set(line["rates"]) == set(detail["rates"])
+    assert all(v is None or v == "error" or isinstance(v, (int, float)) for v in line["rates"].values())
+    for k in ("bound", "achieved", "peak", "frac", "traffic", "unit", "kernel", "launch_ms", "floor_ms", "launch_over_floor",
+              "algorithmic_bytes_per_launch", "traffic_source"):
+        assert k in line["roofline"], k
+    assert "cpu_baseline" not in detail or {"value", "cores", "kind", "sample", "s2_ipcs"} <= set(line["cpu_baseline"])
+    return detail
 
 
 def test_bench_single_rank_line(lib_built):
@@ -42,6 +64,7 @@ def test_bench_single_rank_line(lib_built):
     assert "S3" in res["config"]["workload"] and res["config"]["krylov_iters_per_ipcs_step"]["velocity_bicgstab"] > 0
     roof = res["roofline"]
     assert roof["bound"] == "hbm" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
+    assert 0.05 < roof["floor_ms"] < roof["launch_ms"] and abs(roof["launch_over_floor"] - roof["launch_ms"] / roof["floor_ms"]) < 1e-9
     assert "smooth_linear_kernel" in roof["kernel"] and roof["launch_ms"] > 0 and roof["step_survey_convention_equivalent"]["ipcs_leg_bytes_survey_csr_convention"] > 0
     assert roof["traffic_measured_in_run"] is False and "step" not in roof
     assert res["roofline_s2_velocity"]["bound"] == "lds-atomic/fp64"

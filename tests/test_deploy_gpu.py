@@ -64,7 +64,7 @@ def test_deploy_5000_steps_batched_equals_sequential_bitwise_and_two_runs_agree(
 
 @pytest.mark.parametrize("mesh", ["ys930", "ah93w145"])
 def test_ground_truth_5000_steps_is_bitwise_reproducible_and_1e9_from_the_oracle(lib_built, mesh):
-    """reset()'s ground truth twice: equal bits (drag / lift of all five snapshots, the snapshot fields); and within 3e-9
+    """reset()'s ground truth twice: equal bits (drag / lift of all five snapshots, the snapshot fields); and within 1e-9 (one value: 3e-9)
     of the oracle's sparse-LU trajectory (tests/golden/oracle_flow.json), which mode 3 at rtol 1e-10 missed by 1e-6.
     (3e-9, not round 4's 1e-9: two correctly rounded evaluation orders of the same 5000 steps end 1e-9 apart - the
     three-launch form of the reproducible mode, round 5, sits 8e-13 .. 2.3e-10 from the oracle at 19 of the 20 checkpoint
@@ -81,5 +81,7 @@ def test_ground_truth_5000_steps_is_bitwise_reproducible_and_1e9_from_the_oracle
         assert torch.equal(ua.data, ub.data) and torch.equal(pa.data, pb.data)
     for k in range(5):
         g = flow[str(1000 * (k + 1))]
-        assert abs(a.gt_drag[k] - g["drag"]) < 3e-9 * abs(g["drag"]), (k, a.gt_drag[k], g["drag"])
-        assert abs(a.gt_lift[k] - g["lift"]) < 3e-9 * abs(g["lift"]), (k, a.gt_lift[k], g["lift"])
+        # per-checkpoint bounds: 1e-9 for 19 of the 20 values, 3e-9 for the ys930 lift of step 5000 alone (1.29e-9, see above)
+        lift_tol = 3e-9 if (mesh, k) == ("ys930", 4) else 1e-9
+        assert abs(a.gt_drag[k] - g["drag"]) < 1e-9 * abs(g["drag"]), (k, a.gt_drag[k], g["drag"])
+        assert abs(a.gt_lift[k] - g["lift"]) < lift_tol * abs(g["lift"]), (k, a.gt_lift[k], g["lift"])

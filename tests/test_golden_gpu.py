@@ -50,24 +50,27 @@ def test_first_steps_match_golden(meshes, lib_built):
 @pytest.mark.parametrize("mode", [-2, 3])
 def test_trajectory_checkpoints_match_golden(meshes, lib_built, mode):
     """5000 steps from rest at the tolerance that stands in for the reference's LU (rtol 1e-13): every 1000th step within
-    3e-9 of the derived vectors (the oracle's sparse-LU trajectory) - in the reproducible operator mode the flow solver
+    1e-9 (one value: 3e-9, see `bound`) of the derived vectors (the oracle's sparse-LU trajectory) - in the reproducible operator mode the flow solver
     defaults to (-2 -> 2) and in mode 3 (LDS atomics: 1e-10 .. 1.6e-9 from run to run; tools/traj_determinism.py).  The
     5e-6 this test needed in rounds 1-3 was the Krylov stopping test at rtol 1e-10 (1e-8 .. 1.3e-6 in every mode), not the
     atomics.  The last step against the reference CSV rows (north-star tolerance 1e-4, CSV print precision 5e-8)."""
     batch, _, _ = _batch(meshes, mode=mode, rtol=1e-13, pressure_direct="device")
-    # 3e-9 in both modes.  Mode 3 is reproducible to the solver tolerance only (1e-10 .. 1.6e-9 from run to run); the
-    # reproducible mode repeats its own bits, but its distance from the oracle's sparse-LU trajectory is a matter of rounding
-    # just the same: round 5's three-launch form (tools/gt_distance.py) sits 8e-13 .. 2.3e-10 from the oracle at 19 of the 20
-    # checkpoint values and 1.29e-9 at the ys930 lift of step 5000 (a Krylov stopping test that fell the other way somewhere
-    # between steps 4000 and 5000: 3.2e-11 at step 4000), where round 4's persistent kernel had stayed below 1e-9.
-    tol = 3e-9
+    # PER-CHECKPOINT bounds.  The reproducible mode repeats its own bits; its distance from the oracle's sparse-LU trajectory
+    # is 8e-13 .. 2.3e-10 at 19 of the 20 checkpoint values (tools/gt_distance.py) - those keep 1e-9 - and 1.29e-9 at ONE value,
+    # the ys930 lift of step 5000 (3.2e-11 at step 4000: a Krylov stopping test fell the other way in between; round 4's
+    # persistent kernel stayed below 1e-9 there): that value alone gets 3e-9.  Mode 3 (LDS atomics) is reproducible to the
+    # solver tolerance only, 1e-10 .. 1.6e-9 from run to run: 3e-9 for all of its values.
+    def bound(mesh, k, what):
+        if mode == 3 or (mesh, k, what) == ("ys930", 5, "lift"):
+            return 3e-9
+        return 1e-9
     for k in range(1, 6):
         drag, lift = batch.evolve(1000)
         torch.cuda.synchronize()
         for b, n in enumerate(NAMES):
             g = FLOW[n]["steps"][str(1000 * k)]
-            assert abs(drag[b, -1].item() - g["drag"]) < tol * abs(g["drag"]), (n, k)
-            assert abs(lift[b, -1].item() - g["lift"]) < tol * abs(g["lift"]), (n, k)
+            assert abs(drag[b, -1].item() - g["drag"]) < bound(n, k, "drag") * abs(g["drag"]), (n, k)
+            assert abs(lift[b, -1].item() - g["lift"]) < bound(n, k, "lift") * abs(g["lift"]), (n, k)
     for b, n in enumerate(NAMES):
         assert abs(drag[b, -1].item() - KAT[n]["drag"]) < 1e-6 * abs(KAT[n]["drag"])
         assert abs(lift[b, -1].item() - KAT[n]["lift"]) < 1e-6 * abs(KAT[n]["lift"])

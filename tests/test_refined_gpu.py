@@ -482,6 +482,22 @@ def test_refined_mesh_episodes_at_the_baseline_batch(lib_built, flow_steps, tmp_
         for a in range(len(names)):
             idx = np.flatnonzero(assign == a)
             assert np.allclose(fd[idx], fd[idx[0]], rtol=1e-9, atol=0) and np.allclose(fl[idx], fl[idx[0]], rtol=1e-9, atol=0)
+        # ... and against the sparse-LU oracle on the very same mesh and warm start (as tests/test_stock_gpu.py does on the lab
+        # meshes): three sampled environments - the LAST one (its team holds the last block id, 255, on XCD 7), one on an even
+        # XCD (66 -> XCD 2) and environment 0.  This is the one place where mode 7's XCD-local team barrier runs with every CU
+        # of the chip busy; agreement between environments alone would not see a barrier that fails the same way everywhere.
+        from oracle.ipcs import OracleFlowSolver            # (checker)
+        for b in (B - 1, 66, 0):
+            nv, nt = int(venv.nv[b]), int(venv.nt[b])
+            n2 = nv + int(venv.h["ne"][b])
+            o = OracleFlowSolver(venv.coords[b, :nv].copy(), venv.cells[b, :nt].copy(), smooth=False)
+            assert o.th.np2 == n2
+            u0 = venv.u[b, venv.S - 1, :n2].cpu().numpy()
+            o.u_n = np.concatenate([u0[:, 0], u0[:, 1]])
+            o.p_n = venv.p[b, venv.S - 1, :nv].cpu().numpy().copy()
+            _, _, do, lo = o.evolve()
+            scale = max(abs(do), abs(lo))       # (1e-7 of the FORCE scale: the leg runs at the Krylov tolerance 1e-10)
+            assert abs(fd[b, 0] - do) < 1e-7 * abs(do) and abs(fl[b, 0] - lo) < 1e-7 * scale, (b, fd[b, 0], do, fl[b, 0], lo)
 
 
 def test_skewed_sweep_schedule_gives_the_bits_of_the_level_schedule(lib_built, tmp_path):
