@@ -435,6 +435,59 @@ def test_two_workgroups_per_environment_on_the_element_tiles(meshes, lib_built):
             assert np.array_equal(a_, b_), mode
 
 
+@pytest.mark.parametrize("mode", [7, 4])
+def test_team_barrier_time_out_is_an_error_not_a_nan(meshes, lib_built, mode):
+    """The time-out path of the team barrier, forced (MDQ_TEAM_TEST_ABSENT_PARTNER=1, read per launch: the second workgroup of
+    environment 0 leaves at once, as if it had never become resident): environment 0 reports NaN forces for the abandoned step
+    AND the later steps of the launch, sets its sticky status word (mdq_ipcs_desc.status, ABI 7), keeps the u_n / p_n of the last
+    completed step (they were garbage-but-finite before round 6 and became the next warm start); the other environments are
+    untouched bit for bit; `IpcsBatch.check()` raises; and the next launch - partner present again - continues from the kept
+    state exactly like a batch that never failed."""
+    import torch
+    from meshdqn_amd import _lib
+    from meshdqn_amd.ipcs_batch import IpcsBatch, smooth_coords
+    from meshdqn_amd.mesh_ops import red_refine
+    from meshdqn_amd.topology import MeshTopology
+    coords, cells = meshes["ys930"]
+    t0 = MeshTopology(coords, cells)
+    x0 = smooth_coords(t0, 50)
+    rc, rcells = red_refine(x0, cells)
+    rt = MeshTopology(rc, rcells)
+
+    def batch():
+        return IpcsBatch([rt] * 3, [rc] * 3, rtol=1e-10, mode=mode, pressure_direct=False)
+    good, bad = batch(), batch()
+    for b in (good, bad):
+        b.evolve(2)
+    torch.cuda.synchronize()
+    u2, p2 = good.u_n.cpu().numpy().copy(), good.p_n.cpu().numpy().copy()
+    assert np.array_equal(bad.u_n.cpu().numpy(), u2)
+    os.environ["MDQ_TEAM_TEST_ABSENT_PARTNER"] = "1"
+    try:
+        d, l = bad.evolve(2)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["MDQ_TEAM_TEST_ABSENT_PARTNER"]
+    gd, gl = good.evolve(2)
+    torch.cuda.synchronize()
+    d, l = d.cpu().numpy(), l.cpu().numpy()
+    assert np.isnan(d[0]).all() and np.isnan(l[0]).all()                          # both steps of the launch
+    assert np.array_equal(d[1:], gd.cpu().numpy()[1:]) and np.array_equal(l[1:], gl.cpu().numpy()[1:])
+    assert bad.status.cpu().numpy().tolist() == [1, 0, 0]
+    assert np.array_equal(bad.u_n.cpu().numpy()[0], u2[0]) and np.array_equal(bad.p_n.cpu().numpy()[0], p2[0])     # not advanced
+    assert np.array_equal(bad.u_n.cpu().numpy()[1:], good.u_n.cpu().numpy()[1:])
+    with pytest.raises(_lib.MeshDQNHipError, match="time-out"):
+        bad.check()
+    bad.check()                                                                   # (cleared by the raise)
+    # the partner is back: environment 0 continues from step 2's state with an empty initial-guess history - finite, and close to
+    # what the undisturbed batch produced for its step 3 (same state, other initial guess: the Krylov tolerance apart)
+    d3, _ = bad.evolve(1)
+    torch.cuda.synchronize()
+    d3 = d3.cpu().numpy()
+    assert np.isfinite(d3).all() and abs(d3[0, 0] - gd.cpu().numpy()[0, 0]) < 1e-7 * abs(d3[0, 0])
+    assert bad.status.cpu().numpy().tolist() == [0, 0, 0]
+
+
 @pytest.mark.parametrize("mode", [5, 7, 0])
 def test_two_level_pressure_cg_on_the_refined_mesh(meshes, lib_built, mode):
     """cg_pressure_2l_lds: the Krylov pressure solve of the meshes beyond the LDS-resident velocity vectors (ys930
