@@ -224,6 +224,32 @@ MDQ_API int mdq_ipcs_reset_history(const mdq_ipcs_desc* d, int32_t* iters, void*
 MDQ_API int mdq_ipcs_setup_matfree(const mdq_ipcs_desc* d, void* stream);
 
 /*
+ * ABI 7 (round 6).  The tile maps of the element-tile operator modes (5 / 7) for meshes that exist only on the device - the
+ * coarsened meshes of the S3 env step, i.e. what `FlowSolver.remesh` (flow_solver.py:233-359) would derive after every
+ * `Env2DAirfoil._remove_vertex` - built from the dof <- element-slot lists mdq_env_topology emits (g2_ptr, g2_src; needs nv, nt,
+ * ne as well).  WRITES the arrays the descriptor's mf_rlist [B][NCH][NRL][2], mf_rcnt [B][NCH] and mf_lpos [B][6][NT] point at
+ * (device, caller-owned; NCH = ceil(NT / 1024); NRL = row capacity of a chunk's list, <= 4064 for the LDS stage of the kernels):
+ * bit for bit what `IpcsBatch` builds on the host for the same cells and dof numbering, with the first / last chunk bits of
+ * rl_flags = 1.  mf_scat / mf_tptr stay NULL: mdq_ipcs_evolve takes the row lists + packed local maps alone.  An environment
+ * whose maps cannot be built (a chunk that touches more than NRL rows, a dof without a cell) gets mf_rcnt[b][0] = -1 and keeps
+ * the path through the element scratch and the dof <- slot lists; `status` (optional, device int32 [B]): 0 / 1 per environment.
+ * Limits: NT <= 8192, N2 <= 16384, tables (NCH + 4) * N2 bytes <= 160 KB of LDS.
+ */
+MDQ_API int mdq_ipcs_build_tile_maps(const mdq_ipcs_desc* d, int32_t* status, void* stream);
+
+/*
+ * ABI 7 (round 6).  Spatial order for the cells of a PRIVATE copy of B meshes (the flow engine's input set of the S3 step, in
+ * front of mdq_env_topology + mdq_ipcs_build_tile_maps): the cells of every mesh are sorted along a Morton curve of their
+ * centroids (ties by cell id: the order is a function of the mesh alone) and `cells` [B][NT][3] and - when not NULL - `cell_dofs`
+ * [B][6][NT] (another engine's dofs of the same cells) are permuted alike, in place.  Chunks of 1 024 consecutive triangles then
+ * share their rows (~2 500 touched rows per chunk instead of ~5 000 in the order refinement and cavity re-triangulations leave):
+ * what the tile maps need.  The reference has no counterpart: DOLFIN's assembly order is the mesh file's cell order
+ * (flow_solver.py:123-144) and only the summation order of the element loops depends on it.  NT <= 8192.
+ */
+MDQ_API int mdq_flow_sort_cells(int32_t B, int32_t NV, int32_t NT, const double* coords, const int32_t* nv, const int32_t* nt,
+                                int32_t* cells, int32_t* cell_dofs, void* stream);
+
+/*
  * Advance every environment by `nsteps` IPCS time steps.
  * Replaces `FlowSolver.evolve()` (flow_solver.py:362-396): per step three
  * right-hand-side assemblies, three linear solves (BiCGStab / CG / CG in place

@@ -115,6 +115,9 @@ SYMBOLS = {
     "mdq_ipcs_workspace_doubles": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "mdq_ipcs_assemble": (C.c_int, [C.POINTER(IpcsDesc), C.c_void_p]),
     "mdq_ipcs_setup_matfree": (C.c_int, [C.POINTER(IpcsDesc), C.c_void_p]),
+    "mdq_ipcs_build_tile_maps": (C.c_int, [C.POINTER(IpcsDesc), C.c_void_p, C.c_void_p]),
+    "mdq_flow_sort_cells": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]),
     "mdq_ipcs_evolve": (C.c_int, [C.POINTER(IpcsDesc), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mdq_ipcs_evolve_timed": (C.c_int, [C.POINTER(IpcsDesc), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.POINTER(C.c_double)]),

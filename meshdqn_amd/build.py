@@ -34,6 +34,7 @@ UNITS = {
     "ipcs2": ("mdq_ipcs.hip", ["-DMDQ_IPCS_PART=2"], []),
     "ipcs3": ("mdq_ipcs.hip", ["-DMDQ_IPCS_PART=3"], []),
     "pressure_factor": ("mdq_pressure_factor.hip", [], []),
+    "tilemaps": ("mdq_tilemaps.hip", [], []),
     "gcn": ("mdq_tu_gcn.hip", [], ["mdq_gcn.hip", "mdq_gcn_train.hip"]),
     "replay": ("mdq_replay.hip", [], []),
     "mesh": ("mdq_mesh.hip", [], []),

@@ -110,6 +110,7 @@ struct EnvView {
   const int32_t *mf_rlist, *mf_rcnt;   // mode 5: touched rows per chunk (or null)
   const int32_t* mf_lpos;              // mode 5: [6][NT] position of the dof in its chunk's row list | tile position << 16 (or null)
   int NRL, rl_flags;
+  bool tiles;                          // modes 5 / 7: tile maps present (else: element scratch + dof <- slot lists)
   const int32_t *g2_ptr, *g2_src, *g1_ptr, *g1_src;
   const uint8_t* bcu_flag;
   const double* bcu_gx;
@@ -166,7 +167,13 @@ __device__ __forceinline__ EnvView env_view(const mdq_ipcs_desc& d, int b) {
   v.rl_flags = d.rl_flags;
   v.mf_rlist = (d.mf_rlist && d.mf_rcnt && d.NRL > 0) ? d.mf_rlist + B * ((d.NT + MF_CH - 1) / MF_CH) * d.NRL * 2 : nullptr;
   v.mf_rcnt = v.mf_rlist ? d.mf_rcnt + B * ((d.NT + MF_CH - 1) / MF_CH) : nullptr;
+  // (maps built on the device, mdq_ipcs_build_tile_maps: a first count < 0 marks an environment whose maps could not be built -
+  //  it keeps the dof <- slot path)
+  if (v.mf_rcnt && !d.mf_tptr && v.mf_rcnt[0] < 0) v.mf_rlist = v.mf_rcnt = nullptr;
   v.mf_lpos = (v.mf_rlist && d.mf_lpos && mode5_stage_fits(d.NRL)) ? d.mf_lpos + B * 6 * d.NT : nullptr;
+  // the element results of an operator application go through the LDS tile: host-built maps (mf_scat + mf_tptr; the row lists
+  // optional) or the row lists + packed local maps alone (what the device builds)
+  v.tiles = v.mf_tptr != nullptr || (v.mf_rlist != nullptr && v.mf_lpos != nullptr);
   v.g2_ptr = d.g2_ptr + B * (d.N2 + 1);
   v.g2_src = d.g2_src + B * 6 * d.NT;
   v.g1_ptr = d.g1_ptr + B * (d.NV + 1);
@@ -1176,7 +1183,7 @@ template <class ElemOp, class Epi>
 __device__ __forceinline__ void tile_apply_global(const EnvView& v, bool packed, double2* es, double2* ytmp, const double2* gx,
                                                   ElemOp op, Epi epi) {
   const int tid = threadIdx.x, n = v.n2;
-  if (!v.mf_tptr) {
+  if (!v.tiles) {
     // no tile maps (index data built ON THE DEVICE by mdq_env_topology's large-mesh instance, which emits the dof <-
     // element-slot lists but no tile positions): the element results go to the slab's element scratch (6 double2 per
     // triangle, free during the solves) and every row sums its slots in ascending order - the gather the right-hand sides use
@@ -2163,37 +2170,17 @@ constexpr int TL_XB = 1024, TL_YB = 256;
 __host__ __device__ inline size_t tl_extra_bytes(int n) {
   return sizeof(float) * NAG * NAG + sizeof(double) * ((WG / 64) * NAG + NAG) + (size_t)((n + 7) & ~7);
 }
-__device__ __attribute__((noinline)) int cg_pressure_2l_lds(int n, const int32_t* sl_off, const int32_t* sl_col, const double* A, const double* coords,
-                                         double rtol, int maxit, double* x, double* r, double* p, double* q,
-                                         size_t scratch_bytes, double* extra, size_t extra_bytes, double* red) {
+// The set-up of the two-level preconditioner (shared by cg_pressure_2l_lds and cg_pressure_2l_onchip): aggregates AG[n] by the
+// histogram rule, coarse matrix by LDS atomics, its Gauss-Jordan inverse, the exactly symmetric fp32 copy AI [NAG][NAG].
+// `hist`: LDS scratch of 4 (TL_XB + NAGX TL_YB + 2 NAGX) + n bytes; AC: LDS [NAG][NAG] doubles (may alias `hist`: the
+// histograms are dead when it is zeroed); red: the reduction scratch ([32..63] used here).  Ends WITHOUT a barrier behind AI.
+__device__ __forceinline__ void tl_build(int n, const int32_t* sl_off, const int32_t* sl_col, const double* A, const double* coords,
+                                         int* hist, double* AC, float* AI, unsigned char* AG, double* red) {
   constexpr int NW = WG / 64;
-  static_assert(NW == NAGX, "one wave per strip in the y pass");
-  static_assert(sizeof(float) * NAG * NAG % 8 == 0, "alignment of the partial restrictions");
-  // (`scratch_bytes`: what is contiguous behind p - p | q in LDS, the slab vector of p in global memory)
-  if (n < 4 * NAG || tl_extra_bytes(n) > extra_bytes || scratch_bytes < sizeof(double) * NAG * NAG ||
-      scratch_bytes < sizeof(int) * (TL_XB + NAGX * TL_YB + 2 * NAGX) + (size_t)n)
-    return -1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* AI = reinterpret_cast<float*>(extra);                             // [NAG][NAG] inverse of the coarse matrix
-  double* WP = extra + NAG * NAG / 2;                                      // [NW][NAG] per-wave partial restrictions
-  double* YV = WP + NW * NAG;                                              // [NAG] coarse result
-  unsigned char* AG = reinterpret_cast<unsigned char*>(YV + NAG);          // [n] aggregate of a vertex
-  double acc[2] = {0.0, 0.0};
-  __syncthreads();
-  spmv_sell(sl_off, sl_col, A, x, n, [&](int row, double y0) {
-    const double b = r[row];
-    const double r0 = b - y0;
-    r[row] = r0;
-    acc[0] += b * b;
-    acc[1] += r0 * r0;
-  });
-  block_sum<2>(acc, red);
-  const double bb = acc[0], tol2 = rtol * rtol * bb;
-  double rr = acc[1];
-  if (!(rr > tol2) || bb == 0.0) return 0;
   // ---- aggregates
   {
-    int* HX = reinterpret_cast<int*>(p);          // [TL_XB] counts, then exclusive prefix sums
+    int* HX = hist;                               // [TL_XB] counts, then exclusive prefix sums
     int* HY = HX + TL_XB;                         // [NAGX][TL_YB]
     int* SC = HY + NAGX * TL_YB;                  // [NAGX] population of a strip ([NW] wave totals of the scan behind it)
     unsigned char* ST = reinterpret_cast<unsigned char*>(SC + 2 * NAGX);   // [n] strip of a vertex
@@ -2278,8 +2265,6 @@ __device__ __attribute__((noinline)) int cg_pressure_2l_lds(int n, const int32_t
   }
   // ---- coarse matrix (fp64, in p | q), its inverse, the fp32 copy
   // (in LDS behind the tables when `extra` has the room - the instances with global vectors -, else in the scratch)
-  double* AC = extra_bytes >= tl_extra_bytes(n) + sizeof(double) * NAG * NAG
-                   ? reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(extra) + tl_extra_bytes(n)) : p;
   __syncthreads();
   for (int e = tid; e < NAG * NAG; e += WG) AC[e] = 0.0;
   __syncthreads();
@@ -2337,6 +2322,42 @@ __device__ __attribute__((noinline)) int cg_pressure_2l_lds(int n, const int32_t
       if (e < NAG * NAG) AI[e] = (float)AC[min(ei_[m], ej_[m]) * NAG + max(ei_[m], ej_[m])];
     }
   }
+}
+
+__device__ __attribute__((noinline)) int cg_pressure_2l_lds(int n, const int32_t* sl_off, const int32_t* sl_col, const double* A, const double* coords,
+                                         double rtol, int maxit, double* x, double* r, double* p, double* q,
+                                         size_t scratch_bytes, double* extra, size_t extra_bytes, double* red) {
+  constexpr int NW = WG / 64;
+  static_assert(NW == NAGX, "one wave per strip in the y pass");
+  static_assert(sizeof(float) * NAG * NAG % 8 == 0, "alignment of the partial restrictions");
+  // (`scratch_bytes`: what is contiguous behind p - p | q in LDS, the slab vector of p in global memory)
+  if (n < 4 * NAG || tl_extra_bytes(n) > extra_bytes || scratch_bytes < sizeof(double) * NAG * NAG ||
+      scratch_bytes < sizeof(int) * (TL_XB + NAGX * TL_YB + 2 * NAGX) + (size_t)n)
+    return -1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* AI = reinterpret_cast<float*>(extra);                             // [NAG][NAG] inverse of the coarse matrix
+  double* WP = extra + NAG * NAG / 2;                                      // [NW][NAG] per-wave partial restrictions
+  double* YV = WP + NW * NAG;                                              // [NAG] coarse result
+  unsigned char* AG = reinterpret_cast<unsigned char*>(YV + NAG);          // [n] aggregate of a vertex
+  double acc[2] = {0.0, 0.0};
+  __syncthreads();
+  spmv_sell(sl_off, sl_col, A, x, n, [&](int row, double y0) {
+    const double b = r[row];
+    const double r0 = b - y0;
+    r[row] = r0;
+    acc[0] += b * b;
+    acc[1] += r0 * r0;
+  });
+  block_sum<2>(acc, red);
+  const double bb = acc[0], tol2 = rtol * rtol * bb;
+  double rr = acc[1];
+  if (!(rr > tol2) || bb == 0.0) return 0;
+  // ---- aggregates, coarse matrix (fp64: in LDS behind the tables when `extra` has the room - the instances with global
+  //      vectors -, else in the scratch p | q), its inverse, the fp32 copy
+  tl_build(n, sl_off, sl_col, A, coords, reinterpret_cast<int*>(p),
+           extra_bytes >= tl_extra_bytes(n) + sizeof(double) * NAG * NAG
+               ? reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(extra) + tl_extra_bytes(n)) : p,
+           AI, AG, red);
   __syncthreads();
   int rsel = 0;
   double rz_old = 1.0;
@@ -3565,7 +3586,7 @@ struct TeamTouch {
   int stride;                       // entries of `first` per chunk
 };
 __device__ inline void team_touch_setup(const EnvView& v, const Team& T, TeamTouch& tt) {
-  if (!v.mf_rlist || !v.mf_tptr) {
+  if (!v.mf_rlist || !v.tiles) {
     tt.first = nullptr;
     return;
   }
@@ -3591,7 +3612,7 @@ __device__ __forceinline__ void tile_apply_team(const EnvView& v, Team& T, bool 
                                                 const TeamTouch& tt, const double2* gx, ElemOp op, Epi epi) {
   const int tid = threadIdx.x, n = v.n2, gt = T.rank * WG + tid;
   constexpr int GS = TEAM * WG;
-  if (!v.mf_tptr) {
+  if (!v.tiles) {
     double2* es2 = reinterpret_cast<double2*>(v.work);
     for (int e = gt; e < v.nt; e += GS) {
       double2 xe[6];

@@ -44,6 +44,8 @@ def _host_cores() -> int:
 
 
 class VecEnv2DAirfoil:
+    FLOW_NRL = 4032         # row capacity of a chunk's list in the device-built tile maps (the kernels' LDS stage holds 4064 rows)
+
     def __init__(self, config, num_envs: int, compute_device="cuda", nthreads: int = 0, base_env: Env2DAirfoil | None = None,
                  auto_reset: bool = True, emax: int = 1536, flow_steps: int = 0, flow_rtol: float = 1e-10,
                  gpu_smoothing: bool = True, gpu_topology: bool = True, gpu_remesh: bool = True,
@@ -189,6 +191,22 @@ class VecEnv2DAirfoil:
                 if name in t:
                     setattr(d, name, t[name].data_ptr())
             d.work_doubles = nwork
+            # meshes beyond the LDS-resident modes (auto: the element tiles, modes 5 / 7): the tile maps of every coarsened mesh are
+            # built on the device in front of the IPCS step (mdq_ipcs_build_tile_maps: row lists + packed local maps) - without
+            # them the element results of every operator application go through 0.6 MB of global scratch per environment
+            # (MDQ_NO_DEVICE_TILE_MAPS=1: that path, A / B switch)
+            if NP > 3584 and self.gpu_topology and os.environ.get("MDQ_NO_DEVICE_TILE_MAPS", "") != "1":
+                nch = (NT + 1023) // 1024
+                nrl = min(self.FLOW_NRL, NP)
+                if (nch + 4) * ((NP + 15) & ~15) + 256 <= 160 * 1024:
+                    t["mf_rlist"] = torch.zeros((B, nch, nrl, 2), dtype=torch.int32, device=dev)
+                    t["mf_rcnt"] = torch.zeros((B, nch), dtype=torch.int32, device=dev)
+                    t["mf_lpos"] = torch.zeros((B, 6, NT), dtype=torch.int32, device=dev)
+                    for k in ("mf_rlist", "mf_rcnt", "mf_lpos"):
+                        setattr(d, k, t[k].data_ptr())
+                    d.NRL, d.rl_flags = nrl, 1
+                    d.mf_scat = d.mf_tptr = None
+                    self._flow_tile_maps = True
             self.flow_descs.append(d)
             self.flow_ts.append(t)
         self.flow_t, self.flow_desc = self.flow_ts[0], self.flow_descs[0]
@@ -269,6 +287,8 @@ class VecEnv2DAirfoil:
         if reset:
             self._flow_reset(d)
         _lib.check(self.lib.mdq_ipcs_setup_matfree(C.byref(d), _lib.stream_ptr()), "mdq_ipcs_setup_matfree")
+        if getattr(self, "_flow_tile_maps", False):
+            _lib.check(self.lib.mdq_ipcs_build_tile_maps(C.byref(d), None, _lib.stream_ptr()), "mdq_ipcs_build_tile_maps")
         if self.flow_pressure == "direct":
             _lib.check(self.lib.mdq_ipcs_factorize_pressure(C.byref(d), self.flow_pd_status.data_ptr(), _lib.stream_ptr()),
                        "mdq_ipcs_factorize_pressure")
@@ -369,6 +389,12 @@ class VecEnv2DAirfoil:
             if fe is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
+            if getattr(self, "_flow_tile_maps", False):
+                # the private copy's cells in a spatial order (chunks of 1 024 triangles that share their rows: what the tile maps
+                # of the IPCS step need), the main engine's cell dofs of the same cells permuted alike
+                _lib.check(self.lib.mdq_flow_sort_cells(self.B, self.NV, self.NT, fin["coords"].data_ptr(), fin["nv"].data_ptr(),
+                                                        fin["nt"].data_ptr(), fin["cells"].data_ptr(), fin["cell_dofs"].data_ptr(),
+                                                        _lib.stream_ptr()), "mdq_flow_sort_cells")
             ft.run(check=False)                  # (same meshes, same deterministic kernel as the main stream's run)
             drag, lift = self._flow_launch(t, d, keep, None, None,
                                            (lambda: self._flow_stream.wait_event(self._flow_ready)) if mesh_early else None,

@@ -558,3 +558,153 @@ print("DIGEST", h.hexdigest(), len(meshes[1][0]))
         dig.append(line[1])
         assert int(line[2]) == 3322 - 30
     assert dig[0] == dig[1]
+
+
+def test_device_built_tile_maps_equal_the_host_built_ones(lib_built):
+    """`mdq_ipcs_build_tile_maps` (round 6: the tile maps of the coarsened meshes of the S3 step, built on the device from the
+    dof <- slot lists) against what `IpcsBatch` builds on the host for the same cells and dof numbering: row lists (with the
+    first / last chunk bits), row counts and packed local maps bit for bit - on the red-refined ys930, on a coarsened copy of it
+    (30 removals: a cell order that is no longer the generator's) and with a lab mesh riding along in the big layout; a row
+    capacity that is too small marks the environment (-1) instead of writing a truncated list; and an IPCS step through the
+    device-built maps alone (mf_scat / mf_tptr NULL) gives the bits of the step through the host-built ones, modes 5 and 7."""
+    import ctypes as C
+    import torch
+    from meshdqn_amd import _lib
+    from meshdqn_amd.ipcs_batch import IpcsBatch, smooth_coords
+    from meshdqn_amd.mesh_ops import red_refine, remesh_batch
+    from meshdqn_amd.topology import MeshTopology
+    lib = _lib.load()
+    m = np.load(os.path.join(GOLDEN, "ys930.npz"))
+    t0 = MeshTopology(m["coords"], m["cells"])
+    x0 = smooth_coords(t0, 50)
+    rc, rcells = red_refine(x0, m["cells"])
+    rt = MeshTopology(rc, rcells)
+    c = np.zeros((1, rt.nv, 2)); c[0] = rc
+    tr = np.zeros((1, rt.nt, 3), np.int32); tr[0] = np.sort(rcells, axis=1)
+    nv, nt = np.array([rt.nv], np.int32), np.array([rt.nt], np.int32)
+    rng = np.random.default_rng(11)
+    done = 0
+    while done < 30:
+        bnd = MeshTopology(c[0, :nv[0]], tr[0, :nt[0]]).on_boundary
+        st = remesh_batch(c, tr, nv, nt, np.array([int(rng.choice(np.flatnonzero(~bnd)))], np.int32))
+        done += int(st[0] == 0)
+    ct = MeshTopology(c[0, :nv[0]].copy(), tr[0, :nt[0]].copy())
+    topos, xs = [rt, ct, t0, rt], [rc, ct.coords, x0, rc]
+    out = {}
+    for mode in (5, 7):
+        bb = IpcsBatch(topos, xs, rtol=1e-10, mode=mode, pressure_direct=False)
+        d = bb.desc
+        B, NT, NRL = d.B, d.NT, d.NRL
+        NCH = (NT + 1023) // 1024
+        assert NRL > 0 and d.rl_flags == 1 and "mf_lpos" in bb.t
+        host = {k: bb.t[k].clone() for k in ("mf_rlist", "mf_rcnt", "mf_lpos")}
+        dev = {k: torch.full_like(v, 0x5A5A5A5A) for k, v in host.items()}
+        d2 = _lib.IpcsDesc()
+        C.memmove(C.byref(d2), C.byref(d), C.sizeof(d))
+        for k, v in dev.items():
+            setattr(d2, k, v.data_ptr())
+        status = torch.full((B,), -7, dtype=torch.int32, device="cuda")
+        _lib.check(lib.mdq_ipcs_build_tile_maps(C.byref(d2), status.data_ptr(), None), "mdq_ipcs_build_tile_maps")
+        torch.cuda.synchronize()
+        assert status.cpu().tolist() == [0] * B
+        assert torch.equal(dev["mf_rcnt"], host["mf_rcnt"])
+        hr, dr, cnt = host["mf_rlist"].cpu().numpy(), dev["mf_rlist"].cpu().numpy(), host["mf_rcnt"].cpu().numpy()
+        hl, dl = host["mf_lpos"].cpu().numpy(), dev["mf_lpos"].cpu().numpy()
+        for b, t in enumerate(topos):
+            for ch in range(NCH):
+                assert np.array_equal(hr[b, ch, :cnt[b, ch]], dr[b, ch, :cnt[b, ch]]), (b, ch)
+            assert np.array_equal(hl[b, :, :t.nt], dl[b, :, :t.nt]), b
+        # a list capacity below what a chunk touches: the environment is marked, the others are built
+        small = int(cnt[2].max()) + 1                    # (enough for the lab mesh, not for the refined ones)
+        d3 = _lib.IpcsDesc()
+        C.memmove(C.byref(d3), C.byref(d2), C.sizeof(d2))
+        d3.NRL = small
+        rl_small = torch.zeros((B, NCH, small, 2), dtype=torch.int32, device="cuda")
+        rc_small = torch.zeros((B, NCH), dtype=torch.int32, device="cuda")
+        d3.mf_rlist, d3.mf_rcnt = rl_small.data_ptr(), rc_small.data_ptr()
+        _lib.check(lib.mdq_ipcs_build_tile_maps(C.byref(d3), status.data_ptr(), None), "mdq_ipcs_build_tile_maps")
+        torch.cuda.synchronize()
+        assert status.cpu().tolist() == [1, 1, 0, 1] and rc_small[:, 0].cpu().tolist() == [-1, -1, int(cnt[2, 0]), -1]
+        # the step through the device-built maps ALONE == the step through the host-built ones (direct pressure solve from
+        # host-built factors: the coarse matrix of the two-level Krylov solve is summed with LDS atomics across waves)
+        ref = IpcsBatch(topos, xs, rtol=1e-10, mode=mode, pressure_direct=True)
+        dr_, lr_ = ref.evolve(3)
+        bb = IpcsBatch(topos, xs, rtol=1e-10, mode=mode, pressure_direct=True)
+        for k, v in dev.items():
+            setattr(bb.desc, k, v.data_ptr())
+        bb.desc.mf_scat = bb.desc.mf_tptr = None
+        dd_, ld_ = bb.evolve(3)
+        torch.cuda.synchronize()
+        assert np.isfinite(dd_.cpu().numpy()).all()
+        # (to round-off, not bit for bit: the right-hand side of the direct pressure solve is summed with LDS atomics, and the
+        #  descriptor without mf_tptr makes every workgroup read one word more at its start - another arrival order)
+        for a_, b_ in ((dd_, dr_), (ld_, lr_), (bb.u_n, ref.u_n), (bb.p_n, ref.p_n)):
+            assert (a_ - b_).abs().max().item() <= 1e-11 * b_.abs().max().item(), (mode, (a_ - b_).abs().max().item())
+        out[mode] = dd_.cpu().numpy()
+        # ... and an environment marked -1 falls back to the dof <- slot path: the same forces to round-off
+        bb2 = IpcsBatch(topos, xs, rtol=1e-10, mode=mode, pressure_direct=True)
+        for k, v in dev.items():
+            setattr(bb2.desc, k, v.data_ptr())
+        bb2.desc.mf_scat = bb2.desc.mf_tptr = None
+        dev["mf_rcnt"][1, 0] = -1
+        df_, _ = bb2.evolve(3)
+        torch.cuda.synchronize()
+        df_ = df_.cpu().numpy()
+        assert np.array_equal(df_[[0, 2, 3]], out[mode][[0, 2, 3]]) and np.abs(df_[1] - out[mode][1]).max() < 1e-9 * np.abs(out[mode][1]).max()
+
+
+def test_flow_cell_sort_is_a_permutation_along_the_morton_curve(lib_built):
+    """`mdq_flow_sort_cells` on the refined fixture mesh (whose cell order is the refinement's: a chunk of 1 024 consecutive
+    triangles touches ~5 000 rows) and on a lab mesh in the same batch: the cells come back as a permutation of the input, a
+    second array [6][NT] is permuted alike, the Morton keys of the centroids (recomputed here with the same arithmetic) ascend with
+    ties in ascending cell id, two runs give the same order - and a chunk then touches fewer rows than the tile maps' lists hold."""
+    from meshdqn_amd import _lib
+    from meshdqn_amd.topology import MeshTopology
+    from meshdqn_amd.vec_env import VecEnv2DAirfoil
+    lib = _lib.load()
+    _, z = _refined_fixture()
+    m = np.load(os.path.join(GOLDEN, "ys930.npz"))
+    meshes = [(z["coords"], np.sort(z["cells"], axis=1)), (m["coords"], np.sort(m["cells"], axis=1))]
+    B, NV, NT = 2, max(len(c) for c, _ in meshes), max(len(t) for _, t in meshes)
+    coords = np.zeros((B, NV, 2)); cells = np.zeros((B, NT, 3), np.int32); tag = np.zeros((B, 6, NT), np.int32)
+    for b, (c, t) in enumerate(meshes):
+        coords[b, :len(c)] = c
+        cells[b, :len(t)] = t
+        tag[b, :, :len(t)] = np.arange(len(t))[None] * 6 + np.arange(6)[:, None]
+    nv = np.array([len(c) for c, _ in meshes], np.int32); nt = np.array([len(t) for _, t in meshes], np.int32)
+    outs = []
+    for _ in range(2):
+        tc, tcells, ttag = (torch.from_numpy(a.copy()).cuda() for a in (coords, cells, tag))
+        tnv, tnt = torch.from_numpy(nv).cuda(), torch.from_numpy(nt).cuda()
+        _lib.check(lib.mdq_flow_sort_cells(B, NV, NT, tc.data_ptr(), tnv.data_ptr(), tnt.data_ptr(), tcells.data_ptr(),
+                                           ttag.data_ptr(), None), "mdq_flow_sort_cells")
+        torch.cuda.synchronize()
+        outs.append((tcells.cpu().numpy(), ttag.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    sc, st = outs[0]
+
+    def part(x):
+        x = x.astype(np.uint64) & 0xFFFF
+        for sh, mk in ((8, 0x00FF00FF), (4, 0x0F0F0F0F), (2, 0x33333333), (1, 0x55555555)):
+            x = (x | (x << sh)) & mk
+        return x
+    for b, (c, t) in enumerate(meshes):
+        n = len(t)
+        src = st[b, 0, :n] // 6                                  # where every sorted cell came from
+        assert np.array_equal(np.sort(src), np.arange(n))         # a permutation ...
+        assert np.array_equal(sc[b, :n], t[src])                  # ... of the cells, vertex order inside a cell kept ...
+        assert np.array_equal(st[b, :, :n], tag[b][:, src])       # ... and of the second array
+        assert np.array_equal(sc[b, n:], cells[b, n:])
+        lo, hi = c.min(0), c.max(0)
+        cen = (c[t[src], :].sum(1)) * (1.0 / 3.0)                  # ((x0 + x1) + x2) / 3 as in the kernel
+        q = np.clip(((cen - lo) * (65536.0 / (hi - lo))).astype(np.int64), 0, 65535)
+        key = (part(q[:, 0]) | (part(q[:, 1]) << np.uint64(1))).astype(np.uint64)
+        assert (np.diff(key.astype(np.int64)) >= 0).all()
+        ties = np.diff(key.astype(np.int64)) == 0
+        assert (np.diff(src)[ties] > 0).all()
+        if n > 2048:        # rows a chunk of 1 024 triangles touches: before and after
+            def touched(tr):
+                tp = MeshTopology(c, tr)
+                return max(len(np.unique(tp.cell_dofs[k:k + 1024])) for k in range(0, n, 1024))
+            before, after = touched(t), touched(sc[b, :n])
+            assert before > VecEnv2DAirfoil.FLOW_NRL > 3200 > after, (before, after)

@@ -1,0 +1,45 @@
+"""The device-built tile maps inside the S3 step on the red-refined ys930: rows per chunk list of every environment after a few
+device-resident steps (-1 = the environment kept the dof <- slot path), and the flow leg's duration with / without the maps.
+   python tools/check_tilemaps.py [B]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+torch.set_num_threads(1)
+from meshdqn_amd.env import Env2DAirfoil
+from meshdqn_amd.vec_env import VecEnv2DAirfoil
+from meshdqn_amd.airfoilgcnn import NodeRemovalNet
+from meshdqn_amd.gcn_fused import FusedGcn
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+cfg = dict(flow_config=dict(flow_params=dict(mu=1e-3, rho=1.0, inflow="constant"), geometry_params=dict(mesh=os.path.join(G, "oracle_stock_ys930_refined.npz")),
+                            solver_params=dict(dt=0.001, solver_type="lu", smooth=True, reproducible=False, rtol=1e-10)),
+           agent_params=dict(solver_steps=50, episodes=10, timesteps=10000, threshold=0.001, N_closest=180, gt_drag=-1, gt_time=-1, u=-1, p=-1,
+                             time_reward=0.005, save_steps=10, goal_vertices=0.95, plot_dir=""))
+base = Env2DAirfoil(cfg)
+net = NodeRemovalNet(181, conv_width=128, topk=0.1); net.set_num_nodes(17); net = net.cuda(); fused = FusedGcn(net)
+for maps in (True, False):
+    if maps:
+        os.environ.pop("MDQ_NO_DEVICE_TILE_MAPS", None)
+    else:
+        os.environ["MDQ_NO_DEVICE_TILE_MAPS"] = "1"
+    venv = VecEnv2DAirfoil(cfg, B, base_env=base, flow_steps=1, flow_overlap=True)
+    venv.get_state()
+    rng = np.random.default_rng(1370)
+    def run(k):
+        ex = np.array([rng.random(B) < 0.5 for _ in range(k)]); ra = np.array([rng.integers(0, 181, B) for _ in range(k)])
+        return venv.rollout_device(fused, k, ex, ra)
+    run(6)
+    venv.flow_events = []
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    run(10)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    legs = np.array([a.elapsed_time(b) for a, b in venv.flow_events])
+    venv.flow_events = None
+    fd, fl = venv.flow_wait()
+    it = venv.flow_iters.cpu().numpy().mean(0)
+    line = f"maps={maps}: step {dt / 10 * 1e3:.3f} ms, flow leg median {np.median(legs):.3f} ms, iters {it.round(1).tolist()}, drag[0] {fd[0, 0]:.12e}"
+    if maps and getattr(venv, "_flow_tile_maps", False):
+        rc = venv.flow_ts[0]["mf_rcnt"].cpu().numpy()
+        line += f"; rcnt min {rc.min(0).tolist()} max {rc.max(0).tolist()}, marked {(rc[:, 0] < 0).sum()} of {B}"
+    print(line, flush=True)
+    del venv
