@@ -899,6 +899,7 @@ def main(argv=None):
         # rank-local side measurements
         import datetime
         pg_kw = dict(timeout=datetime.timedelta(seconds=float(os.environ.get("MDQ_DIST_TIMEOUT", "1800"))))
+        store = None
         if "TORCHELASTIC_RUN_ID" not in os.environ:      # (under torchrun the agent owns the store and watches its workers)
             store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world, rank == 0,
                                   timeout=datetime.timedelta(seconds=float(os.environ.get("MDQ_RENDEZVOUS_TIMEOUT", "180"))))
@@ -912,6 +913,8 @@ def main(argv=None):
         else:
             dist.init_process_group(backend, **pg_kw)
             rccl = dict(backend=backend, ranks=world)
+        if store is not None:       # (the short timeout was for the rendezvous: c10d does not re-time a store it is handed)
+            store.set_timeout(pg_kw["timeout"])
     else:
         dist = None
         dev_index = 0

@@ -95,6 +95,12 @@ __host__ __device__ inline int64_t work_touch_offset(int NV, int NT, int NE) {
 __host__ __device__ inline bool mode5_stage_fits(int NRL) {
   return NRL > 0 && 64 * sizeof(double) + sizeof(double2) * 6 * MF_CH + sizeof(double2) * (size_t)NRL <= 160 * 1024;
 }
+// LDS of the tile modes 5 / 7 behind the reduction scratch: the element tile (+ the stage of a chunk's input rows behind it when
+// the packed local maps are given and fit) - what the launcher allocates and what the kernels may re-use in the pressure phase
+__host__ __device__ inline size_t tile_lds_bytes(const mdq_ipcs_desc& d) {
+  return sizeof(double2) * 6 * MF_CH +
+         ((d.mf_lpos && d.mf_rlist && d.mf_rcnt && mode5_stage_fits(d.NRL)) ? sizeof(double2) * (size_t)d.NRL : 0);
+}
 
 struct EnvView {
   int nv, nt, ne, n2, nnz2, nnz1, naf;
@@ -2421,6 +2427,221 @@ __device__ __attribute__((noinline)) int cg_pressure_2l_lds(int n, const int32_t
   return it;
 }
 
+// ------------------------------------------------------------------ two-level PCG with the MATRIX ON THE CHIP (round 6)
+//
+// cg_pressure_2l_lds keeps the four CG vectors in LDS and streams the matrix from L2 in every iteration: on the red-refined
+// ys930 (3 322 rows, 25.5 k SELL entries = 300 KB) an iteration lasts 16.4 us, i.e. 18 GB/s - what ONE workgroup pulls out
+// of L2 (HISTORY 8.5) - and the 171 iterations of a fresh mesh are 2.8 ms of the S3 step's flow leg.  Here the matrix does
+// not move after the set-up: thread t owns rows t + k WG (k < K <= 7) = lane t % 64 of SELL slice 8 k + t / 64, so the slices
+// of the first OC_KR row groups are held in REGISTERS by their owner (OC_WR entries per row: fp64 value + 16-bit column,
+// padded with zero values) and the remaining slices are copied to LDS (fp64 values + 16-bit columns, the SELL layout as it
+// is); x, r, q, z of the own rows live in registers, only the search direction p - the one vector that is gathered - in LDS,
+// and the fp32 inverse of the coarse matrix in registers of the 448 threads of the coarse product.  An iteration is then
+// LDS gathers + five workgroup barriers.  Same preconditioner (tl_build), same recurrences, same stopping test as
+// cg_pressure_2l_lds; the row sums run over the SELL columns in the same order.  U: the kernel's LDS union; in: U[0..n) = x0,
+// U[NVp..NVp+n) = b; out: U[0..n) = x.  Returns the iterations, or -1 WITHOUT having touched anything when the mesh does
+// not fit (more than 7 row groups, a register slice wider than OC_WR, the LDS slices beyond U).
+constexpr int OC_KR = 4, OC_WR = 10, OC_KMAX = 7;
+__device__ __attribute__((noinline)) int cg_pressure_2l_onchip(int n, const int32_t* sl_off, const int32_t* sl_col, const double* A,
+                                                                const double* coords, double rtol, int maxit, double* U, size_t U_bytes,
+                                                                int NVp, double* red) {
+  constexpr int NW = WG / 64;
+  static_assert(NW == NAGX && NAG * 8 <= WG && OC_WR % 2 == 0, "one wave per strip; 8 threads per coarse row");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nsl = (n + 63) >> 6, K = (nsl + NW - 1) / NW;
+  if (n < 4 * NAG || K > OC_KMAX || n > 0xFFFF) return -1;
+  // ---- LDS plan: p [NP] | WP [NW][NAG] | YV [NAG] | AG [n] | LDS slices: values, then columns
+  const int NP = (n + 7) & ~7;
+  const int s_l0 = min(OC_KR * NW, nsl);                       // first slice that lives in LDS
+  const int e_l0 = sl_off[s_l0], ent_l = sl_off[nsl] - e_l0;   // its first entry; entries in LDS
+  double* P = U;
+  double* WP = P + NP;
+  double* YV = WP + NW * NAG;
+  unsigned char* AG = reinterpret_cast<unsigned char*>(YV + NAG);
+  double* LV = reinterpret_cast<double*>(AG + NP);
+  unsigned short* LC = reinterpret_cast<unsigned short*>(LV + ent_l);
+  const size_t need = sizeof(double) * (size_t)(NP + NW * NAG + NAG + ent_l) + (size_t)NP + sizeof(unsigned short) * (size_t)(ent_l + 8);
+  // (the set-up's scratch - histograms, the fp64 coarse matrix, its fp32 inverse - lies where the LDS slices go afterwards)
+  const size_t setup = sizeof(double) * (size_t)(NP + NW * NAG + NAG) + (size_t)NP + sizeof(double) * NAG * NAG + sizeof(float) * NAG * NAG +
+                       sizeof(int) * (TL_XB + NAGX * TL_YB + 2 * NAGX) + (size_t)NP;
+  bool bad = need > U_bytes || setup > U_bytes;
+#pragma unroll
+  for (int k = 0; k < OC_KR; ++k) {
+    const int s_ = k * NW + wave;
+    if (s_ < nsl && ((sl_off[s_ + 1] - sl_off[s_]) >> 6) > OC_WR) bad = true;
+  }
+  if (__syncthreads_or(bad)) return -1;
+  // ---- own rows of x0 and b
+  double x[OC_KMAX], r[OC_KMAX], q[OC_KMAX];
+#pragma unroll
+  for (int k = 0; k < OC_KMAX; ++k) {
+    const int row = tid + k * WG;
+    x[k] = row < n ? U[row] : 0.0;
+    r[k] = row < n ? U[NVp + row] : 0.0;
+  }
+  int lb[OC_KMAX - OC_KR], lw[OC_KMAX - OC_KR];                 // LDS slices of this wave: first entry (relative), width
+#pragma unroll
+  for (int k = OC_KR; k < OC_KMAX; ++k) {
+    const int s_ = k * NW + wave;
+    lb[k - OC_KR] = __builtin_amdgcn_readfirstlane(s_ < nsl ? sl_off[s_] - e_l0 : 0);
+    lw[k - OC_KR] = __builtin_amdgcn_readfirstlane(s_ < nsl ? (sl_off[s_ + 1] - sl_off[s_]) >> 6 : 0);
+  }
+  __syncthreads();                                              // (b is in registers: its LDS is free from here on)
+  // ---- the preconditioner (scratch where the LDS slices go), its fp32 inverse into registers
+  float ai[(NAG + 7) / 8];
+  {
+    double* AC = LV;
+    float* AI = reinterpret_cast<float*>(AC + NAG * NAG);
+    int* hist = reinterpret_cast<int*>(AI + NAG * NAG);
+    tl_build(n, sl_off, sl_col, A, coords, hist, AC, AI, AG, red);
+    __syncthreads();
+    const int I = tid >> 3, part = tid & 7;
+#pragma unroll
+    for (int m = 0; m < (NAG + 7) / 8; ++m) ai[m] = (tid < NAG * 8 && part + 8 * m < NAG) ? AI[I * NAG + part + 8 * m] : 0.0f;
+  }
+  unsigned agp[2] = {0u, 0u};                                   // aggregates of the own rows, one byte each
+#pragma unroll
+  for (int k = 0; k < OC_KMAX; ++k) agp[k >> 2] |= (tid + k * WG < n ? (unsigned)AG[tid + k * WG] : 0u) << (8 * (k & 3));
+  auto ag = [&](int k) { return (int)((agp[k >> 2] >> (8 * (k & 3))) & 0xFFu); };
+  __syncthreads();
+  // ---- the LDS slices
+  for (int e = tid; e < ent_l; e += WG) {
+    LV[e] = A[e_l0 + e];
+    LC[e] = (unsigned short)sl_col[e_l0 + e];
+  }
+  __syncthreads();
+  // (the register slices are loaded LAST: across the set-up above they were the allocator's first spill candidates)
+  double av[OC_KR][OC_WR];
+  unsigned ac[OC_KR][OC_WR / 2];
+#pragma unroll
+  for (int k = 0; k < OC_KR; ++k) {
+    const int s_ = k * NW + wave, own = min(tid + k * WG, n - 1);
+    const int base = s_ < nsl ? sl_off[s_] : 0, wd = s_ < nsl ? (sl_off[s_ + 1] - base) >> 6 : 0;
+#pragma unroll
+    for (int j = 0; j < OC_WR; j += 2) {
+      const bool h0 = j < wd, h1 = j + 1 < wd;
+      av[k][j] = h0 ? A[base + lane + j * 64] : 0.0;
+      av[k][j + 1] = h1 ? A[base + lane + (j + 1) * 64] : 0.0;
+      const unsigned c0 = h0 ? (unsigned)sl_col[base + lane + j * 64] : (unsigned)own;
+      const unsigned c1 = h1 ? (unsigned)sl_col[base + lane + (j + 1) * 64] : (unsigned)own;
+      ac[k][j / 2] = c0 | (c1 << 16);
+    }
+  }
+  auto spmv = [&](double (&y)[OC_KMAX]) {
+#pragma unroll
+    for (int k = 0; k < OC_KR; ++k) {
+      double s_ = 0.0;
+#pragma unroll
+      for (int j = 0; j < OC_WR; j += 2) {
+        // (opaque: the 40 gather addresses are loop invariants the compiler would otherwise keep in 40 registers - and spill)
+        asm volatile("" : "+v"(ac[k][j / 2]));
+        const unsigned c = ac[k][j / 2];
+        s_ += av[k][j] * P[c & 0xFFFFu];
+        s_ += av[k][j + 1] * P[c >> 16];
+      }
+      y[k] = s_;
+      __builtin_amdgcn_sched_barrier(0);       // (row by row: all 40 gathers in flight at once cost 80 registers and spilled)
+    }
+#pragma unroll
+    for (int k = OC_KR; k < OC_KMAX; ++k) {
+      double s_ = 0.0;
+      const double* a = LV + lb[k - OC_KR] + lane;
+      const unsigned short* c = LC + lb[k - OC_KR] + lane;
+      for (int j = 0; j < lw[k - OC_KR]; ++j) s_ += a[j * 64] * P[c[j * 64]];
+      y[k] = s_;
+    }
+  };
+  // ---- r = b - A x0
+  double acc[2] = {0.0, 0.0};
+  spmv(q);
+#pragma unroll
+  for (int k = 0; k < OC_KMAX; ++k)
+    if (tid + k * WG < n) {
+      const double b = r[k], r0 = b - q[k];
+      r[k] = r0;
+      acc[0] += b * b;
+      acc[1] += r0 * r0;
+    }
+  block_sum<2>(acc, red);
+  const double bb = acc[0], tol2 = rtol * rtol * bb;
+  double rr = acc[1];
+  int it = 0;
+  if (rr > tol2 && bb != 0.0) {
+    int rsel = 0;
+    double rz_old = 1.0;
+    while (it < maxit) {
+      // z = r + P A_c^-1 P^T r
+      if (lane < NAG) WP[wave * NAG + lane] = 0.0;
+#pragma unroll
+      for (int k = 0; k < OC_KMAX; ++k)
+        if (tid + k * WG < n) atomicAdd(&WP[wave * NAG + ag(k)], r[k]);
+      __syncthreads();
+      if (tid < NAG * 8) {
+        const int I = tid >> 3, part = tid & 7;
+        int part_o = part;
+        asm volatile("" : "+v"(part_o));            // (one base address + immediate offsets instead of 56 hoisted addresses)
+        const double* wq = WP + part_o;
+        double s_ = 0.0;
+        static_assert(NAG % 8 == 0, "every thread of a coarse row has NAG / 8 columns");
+#pragma unroll
+        for (int m = 0; m < NAG / 8; ++m) {
+          double w_ = 0.0;
+#pragma unroll
+          for (int w2 = 0; w2 < NW; ++w2) w_ += wq[w2 * NAG + 8 * m];
+          s_ += (double)ai[m] * w_;
+        }
+        s_ += dpp_get<0xB1, 0xF>(s_);      // quad_perm [1,0,3,2]
+        s_ += dpp_get<0x4E, 0xF>(s_);      // quad_perm [2,3,0,1]
+        s_ += dpp_get<0x141, 0xF>(s_);     // row_half_mirror: the other quad of the group of 8
+        if (part == 0) YV[I] = s_;
+      }
+      __syncthreads();
+      double a0[1] = {0.0};
+#pragma unroll
+      for (int k = 0; k < OC_KMAX; ++k)
+        if (tid + k * WG < n) a0[0] += r[k] * (r[k] + YV[ag(k)]);
+      block_sum1<1>(a0, red, rsel);
+      const double rz = a0[0];
+      const double beta = rz / rz_old;
+      rz_old = rz;
+#pragma unroll
+      for (int k = 0; k < OC_KMAX; ++k)
+        if (tid + k * WG < n) {
+          const double z = r[k] + YV[ag(k)];          // (read again instead of kept across the reduction: 14 registers)
+          P[tid + k * WG] = it == 0 ? z : z + beta * P[tid + k * WG];
+        }
+      ++it;
+      __syncthreads();
+      double a1[1] = {0.0};
+      spmv(q);
+#pragma unroll
+      for (int k = 0; k < OC_KMAX; ++k)
+        if (tid + k * WG < n) a1[0] += P[tid + k * WG] * q[k];
+      block_sum1<1>(a1, red, rsel);
+      if (!(a1[0] > 0.0)) break;
+      const double alpha = rz / a1[0];
+      double a2[1] = {0.0};
+#pragma unroll
+      for (int k = 0; k < OC_KMAX; ++k)
+        if (tid + k * WG < n) {
+          x[k] += alpha * P[tid + k * WG];
+          const double rn = r[k] - alpha * q[k];
+          r[k] = rn;
+          a2[0] += rn * rn;
+        }
+      block_sum1<1>(a2, red, rsel);
+      rr = a2[0];
+      if (!(rr > tol2)) break;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < OC_KMAX; ++k)
+    if (tid + k * WG < n) U[tid + k * WG] = x[k];
+  __syncthreads();
+  return it;
+}
+
 // the Krylov pressure solve of the kernels whose pressure vectors live in LDS (modes 0 / 4 / 5 / 7): two-level from
 // TL_AUTO_NV vertices on (pcg_degree 0 = auto) or on request (pcg_degree < 0), Jacobi-CG otherwise (pcg_degree > 0: always)
 #ifndef MDQ_TL_AUTO_NV
@@ -2428,9 +2649,14 @@ __device__ __attribute__((noinline)) int cg_pressure_2l_lds(int n, const int32_t
 #endif
 __device__ inline int pressure_krylov_lds(const mdq_ipcs_desc& d, bool k1_lds, int n, const int32_t* sl_off, const int32_t* sl_col,
                                           const double* A, const double* coords, double* x, double* r, double* p, double* q,
-                                          size_t scratch_bytes, double* extra, size_t extra_bytes, double* red) {
+                                          size_t scratch_bytes, double* extra, size_t extra_bytes, double* red,
+                                          double* U = nullptr, size_t U_bytes = 0, int NVp = 0) {
   int it = -1;
-  if (!k1_lds && (d.pcg_degree < 0 || (d.pcg_degree == 0 && n >= MDQ_TL_AUTO_NV)))
+  // (U: the LDS union of the kernel with x = U, r = U + NVp: the matrix-on-chip solver where the mesh fits it; pcg_degree -2
+  //  keeps round 5's solver with the matrix streamed from L2 - A / B switch)
+  if (!k1_lds && U != nullptr && d.pcg_degree != -2 && (d.pcg_degree < 0 || (d.pcg_degree == 0 && n >= MDQ_TL_AUTO_NV)))
+    it = cg_pressure_2l_onchip(n, sl_off, sl_col, A, coords, d.rtol, d.maxit_p, U, U_bytes, NVp, red);
+  if (it < 0 && !k1_lds && (d.pcg_degree < 0 || (d.pcg_degree == 0 && n >= MDQ_TL_AUTO_NV)))
     it = cg_pressure_2l_lds(n, sl_off, sl_col, A, coords, d.rtol, d.maxit_p, x, r, p, q, scratch_bytes, extra, extra_bytes, red);
   if (it < 0) it = cg_pressure(n, sl_off, sl_col, A, d.rtol, d.maxit_p, x, r, p, q, red);
   return it;
@@ -2898,7 +3124,8 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
                                     MODE == 5 ? sizeof(double2) * 6 * MF_CH : tl_extra_bytes(d.NV) + sizeof(double) * NAG * NAG, red);
       else
         it_p += pressure_krylov_lds(d, K1_LDS, nv, so1, ci1, K1, v.coords, px, pr, pp, pq, 2 * sizeof(double) * (size_t)P.NVp, lK,
-                                    sizeof(double) * (size_t)P.NVp, red);
+                                    sizeof(double) * (size_t)P.NVp, red, U,
+                                    max(P.prs_vec_bytes + (K1_LDS ? P.prs_mat_bytes : 0), MODE == 5 ? tile_lds_bytes(d) : (size_t)0), P.NVp);
     }
     MDQ_STAMP(4)
     for (int i = tid; i < nv; i += WG) pnew[i] = px[i] / v.sdiagK[i];
@@ -3402,7 +3629,7 @@ __global__ __launch_bounds__(WG) void evolve_team_kernel(mdq_ipcs_desc d, int ns
         pressure_direct(pd, nv, pr, px, pp, pq, lK);
       } else {
         it_p += pressure_krylov_lds(d, K1_LDS, nv, so1, ci1, K1, v.coords, px, pr, pp, pq, 2 * sizeof(double) * (size_t)P.NVp, lK,
-                                    sizeof(double) * (size_t)P.NVp, red);
+                                    sizeof(double) * (size_t)P.NVp, red, U, P.prs_vec_bytes + (K1_LDS ? P.prs_mat_bytes : 0), P.NVp);
       }
       for (int i = tid; i < nv; i += WG) pnew[i] = px[i] / v.sdiagK[i];
     }
@@ -3946,7 +4173,8 @@ __global__ __launch_bounds__(WG) void evolve_team_tiles_kernel(mdq_ipcs_desc d, 
         pressure_direct(pd, nv, pr, px, pp, pq, lK);
       } else {
         it_p += pressure_krylov_lds(d, K1_LDS, nv, so1, ci1, K1, v.coords, px, pr, pp, pq, 2 * sizeof(double) * (size_t)P.NVp, lK,
-                                    sizeof(double) * (size_t)P.NVp, red);
+                                    sizeof(double) * (size_t)P.NVp, red, U,
+                                    max(P.prs_vec_bytes + (K1_LDS ? P.prs_mat_bytes : 0), tile_lds_bytes(d)), P.NVp);
       }
       for (int i = tid; i < nv; i += WG) pnew[i] = px[i] / v.sdiagK[i];
     }
@@ -5809,8 +6037,7 @@ static int ipcs_evolve_impl(const mdq_ipcs_desc* d, int32_t nsteps, double* drag
   const bool k1_lds = !pg && !d->pd_enabled && red_bytes + P.prs_vec_bytes + P.prs_mat_bytes <= LDS_MAX;
   int mode = d->mode;
   // mode 5: the element tile (+ the stage of a chunk's input rows behind it when the packed local maps are given and fit)
-  const size_t tile_bytes = sizeof(double2) * 6 * MF_CH +
-                            ((d->mf_lpos && d->mf_rlist && d->mf_rcnt && mode5_stage_fits(d->NRL)) ? sizeof(double2) * (size_t)d->NRL : 0);
+  const size_t tile_bytes = tile_lds_bytes(*d);
   if (mode == 6) return fail_msg("unknown operator mode 6");
   if (mode < 0 || mode > 7) {  // auto: fastest variant that fits
     mode = 0;

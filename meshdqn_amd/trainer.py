@@ -89,7 +89,19 @@ class DistContext:
             import datetime
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             backend = backend or os.environ.get("MDQ_DIST_BACKEND") or ("nccl" if device.type == "cuda" else "gloo")
-            kw = dict(timeout=datetime.timedelta(seconds=float(os.environ.get("MDQ_DIST_TIMEOUT", "1800"))))
+            long_timeout = datetime.timedelta(seconds=float(os.environ.get("MDQ_DIST_TIMEOUT", "1800")))
+            kw = dict(timeout=long_timeout)
+            store = None
+            if self.world == 1 and "TORCHELASTIC_RUN_ID" not in os.environ:
+                # a forced group of one rank started by hand (MDQ_FORCE_COLLECTIVES=1 without a launcher): rank 0 of 1 on a free port
+                os.environ.setdefault("RANK", "0")
+                os.environ.setdefault("WORLD_SIZE", "1")
+                if not os.environ.get("MASTER_PORT"):
+                    import socket
+                    s_ = socket.socket()
+                    s_.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+                    s_.close()
             if "TORCHELASTIC_RUN_ID" not in os.environ and os.environ.get("MASTER_PORT"):
                 # started by meshdqn_amd.launcher (not torchrun, whose agent owns the store): rendezvous with a SHORT timeout -
                 # a rank that never shows up fails the job in MDQ_RENDEZVOUS_TIMEOUT seconds, not in c10d's 10-30 minutes
@@ -102,6 +114,11 @@ class DistContext:
                 dist.init_process_group(backend, device_id=device, **kw)
             else:
                 dist.init_process_group(backend, **kw)
+            if store is not None:
+                # the SHORT timeout was for the rendezvous only: c10d calls set_timeout on stores it creates itself, not on one it
+                # is handed - every later store wait (lazy communicator creation, new_group, gloo's full-mesh connect) would keep
+                # the 180 s and fail a job whose ranks drift apart by more than three minutes
+                store.set_timeout(long_timeout)
             self.owns_group = True
         self.backend = dist.get_backend() if (self.multi and dist.is_initialized()) else None
 

@@ -490,7 +490,7 @@ def test_team_barrier_time_out_is_an_error_not_a_nan(meshes, lib_built, mode):
 
 @pytest.mark.parametrize("mode", [5, 7, 0])
 def test_two_level_pressure_cg_on_the_refined_mesh(meshes, lib_built, mode):
-    """cg_pressure_2l_lds: the Krylov pressure solve of the meshes beyond the LDS-resident velocity vectors (ys930
+    """cg_pressure_2l_onchip / cg_pressure_2l_lds: the Krylov pressure solve of the meshes beyond the LDS-resident velocity vectors (ys930
     red-refined: 3 322 vertices) with the two-level additive preconditioner - O(n) aggregation by histograms, 8 x 7
     aggregates, coarse matrix inverted in LDS - which `pcg_degree = 0` (auto) takes from 2048 vertices on; against the
     Jacobi-CG (`pcg_degree = 1`) and the oracle's LU: the same answers to the solver tolerance, under 70 % of the
@@ -507,7 +507,7 @@ def test_two_level_pressure_cg_on_the_refined_mesh(meshes, lib_built, mode):
     ora = OracleFlowSolver(rc, rcells, smooth=False)
     ref = [ora.evolve() for _ in range(3)]
     res = {}
-    for deg in (1, 0, -1):
+    for deg in (1, 0, -1, -2):      # (-2: round 5's solver - vectors in LDS, the matrix streamed from L2; 0 / -1: the matrix on the chip)
         b = IpcsBatch([rt, rt], [rc, rc], rtol=1e-12, mode=mode, pressure_direct=False, pcg_degree=deg)
         for k in range(3):
             d, l = b.evolve(1)
@@ -518,6 +518,9 @@ def test_two_level_pressure_cg_on_the_refined_mesh(meshes, lib_built, mode):
         assert np.abs(p - ref[2][1]).max() < 1e-8 * np.abs(ref[2][1]).max(), deg
         res[deg] = b.iters.cpu().numpy()[0, 1] / 3.0
     assert res[0] == res[-1] and res[0] < 0.7 * res[1], res
+    # cg_pressure_2l_onchip (round 6) runs the recurrences of cg_pressure_2l_lds on the same preconditioner: the same iterations
+    # (a stopping test crossed closely may fall the other way once in three steps)
+    assert abs(res[-2] - res[0]) <= 1.0, res
     print(f"refined mesh, mode {mode}: pressure iterations per step Jacobi {res[1]:.0f}, two-level {res[0]:.0f}")
 
 

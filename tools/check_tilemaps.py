@@ -17,12 +17,12 @@ cfg = dict(flow_config=dict(flow_params=dict(mu=1e-3, rho=1.0, inflow="constant"
                              time_reward=0.005, save_steps=10, goal_vertices=0.95, plot_dir=""))
 base = Env2DAirfoil(cfg)
 net = NodeRemovalNet(181, conv_width=128, topk=0.1); net.set_num_nodes(17); net = net.cuda(); fused = FusedGcn(net)
-for maps in (True, False):
+for maps, deg in ((True, 0), (True, -2), (False, 0)):
     if maps:
         os.environ.pop("MDQ_NO_DEVICE_TILE_MAPS", None)
     else:
         os.environ["MDQ_NO_DEVICE_TILE_MAPS"] = "1"
-    venv = VecEnv2DAirfoil(cfg, B, base_env=base, flow_steps=1, flow_overlap=True)
+    venv = VecEnv2DAirfoil(cfg, B, base_env=base, flow_steps=1, flow_overlap=True, flow_pcg_degree=deg)
     venv.get_state()
     rng = np.random.default_rng(1370)
     def run(k):
@@ -37,7 +37,7 @@ for maps in (True, False):
     venv.flow_events = None
     fd, fl = venv.flow_wait()
     it = venv.flow_iters.cpu().numpy().mean(0)
-    line = f"maps={maps}: step {dt / 10 * 1e3:.3f} ms, flow leg median {np.median(legs):.3f} ms, iters {it.round(1).tolist()}, drag[0] {fd[0, 0]:.12e}"
+    line = f"maps={maps} pcg_degree={deg}: step {dt / 10 * 1e3:.3f} ms, flow leg median {np.median(legs):.3f} ms, iters {it.round(1).tolist()}, drag[0] {fd[0, 0]:.12e}"
     if maps and getattr(venv, "_flow_tile_maps", False):
         rc = venv.flow_ts[0]["mf_rcnt"].cpu().numpy()
         line += f"; rcnt min {rc.min(0).tolist()} max {rc.max(0).tolist()}, marked {(rc[:, 0] < 0).sum()} of {B}"
