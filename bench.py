@@ -586,7 +586,7 @@ def _diverged_meshes(args, n_envs, removals=20):
     return [(MeshTopology(coords[b, :nv[b]], cells[b, :nt[b]]), coords[b, :nv[b]].copy()) for b in range(n_envs)]
 
 
-PMC_SUMMARY = "r05_pmc_summary.json"      # profiles/: ONE PMC pass per committed file (tools/refresh_profiles_r05.sh)
+PMC_SUMMARY = "r06_pmc_summary.json"      # profiles/: ONE PMC pass per committed file (tools/refresh_profiles_r06.sh)
 
 
 def _kernel_sources(kernel):
@@ -620,8 +620,15 @@ def pmc_entry(name, leg, kernel):
     return ent, src + f"; sha256 of {', '.join(_kernel_sources(kernel))} match"
 
 
+PMC_OLDER = ("r05_pmc_summary.json",)       # earlier collections: used for a kernel whose sources have not changed since
+
+
 def pmc_traffic(name, leg, kernel):
+    """The newest committed collection that still describes `kernel` (sha256 of its sources): `name`, then PMC_OLDER."""
     ent, src = pmc_entry(name, leg, kernel)
+    for older in PMC_OLDER:
+        if ent is None:
+            ent, src = pmc_entry(older, leg, kernel)
     return (ent["corrected"] if ent else None), src
 
 
@@ -811,7 +818,7 @@ def main(argv=None):
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--s1-steps", type=int, default=50, help="batched steps of the S1 / C3 side measurements (0 = skip all side measurements)")
-    ap.add_argument("--cell-order", default="conflictfree", choices=["mesh", "conflictfree"])
+    ap.add_argument("--cell-order", default="auto", choices=["auto", "mesh", "conflictfree", "morton"])
     ap.add_argument("--train-steps", type=int, default=20, help="batched learning-loop steps (0 = skip)")
     ap.add_argument("--share-replay", action="store_true",
                     help="learning loops with the shared replay: every rank all-gathers the transition records of all ranks")
@@ -1160,7 +1167,7 @@ def main(argv=None):
                          "launch_ms_alone": smk["launch_ms"],
                          "last_launch_diagnostics": insitu.get("last_launch_diagnostics") if insitu else None,
                          "traffic_source": sm_traffic_src,
-                         "traffic_source_short": f"profiles/{PMC_SUMMARY} (rocprofv3 --pmc, gfx950-corrected)" if sm_traffic is not None
+                         "traffic_source_short": (sm_traffic_src.split(" @ ")[0] + " (rocprofv3 --pmc, gfx950-corrected)") if sm_traffic is not None
                                                  else "refused: sources changed since profiles/" + PMC_SUMMARY,
                          "workspace_bytes_per_launch": smk.get("workspace_bytes_per_launch"),
                          "algorithmic_bytes_per_launch": smk["algorithmic_bytes_per_launch"],

@@ -3124,7 +3124,7 @@ __global__ __launch_bounds__(WG) void evolve_kernel(mdq_ipcs_desc d, int nsteps,
                                     MODE == 5 ? sizeof(double2) * 6 * MF_CH : tl_extra_bytes(d.NV) + sizeof(double) * NAG * NAG, red);
       else
         it_p += pressure_krylov_lds(d, K1_LDS, nv, so1, ci1, K1, v.coords, px, pr, pp, pq, 2 * sizeof(double) * (size_t)P.NVp, lK,
-                                    sizeof(double) * (size_t)P.NVp, red, U,
+                                    sizeof(double) * (size_t)P.NVp, red, MODE == 5 ? U : nullptr,     // (matrix on the chip: the tile modes only)
                                     max(P.prs_vec_bytes + (K1_LDS ? P.prs_mat_bytes : 0), MODE == 5 ? tile_lds_bytes(d) : (size_t)0), P.NVp);
     }
     MDQ_STAMP(4)
@@ -3629,7 +3629,7 @@ __global__ __launch_bounds__(WG) void evolve_team_kernel(mdq_ipcs_desc d, int ns
         pressure_direct(pd, nv, pr, px, pp, pq, lK);
       } else {
         it_p += pressure_krylov_lds(d, K1_LDS, nv, so1, ci1, K1, v.coords, px, pr, pp, pq, 2 * sizeof(double) * (size_t)P.NVp, lK,
-                                    sizeof(double) * (size_t)P.NVp, red, U, P.prs_vec_bytes + (K1_LDS ? P.prs_mat_bytes : 0), P.NVp);
+                                    sizeof(double) * (size_t)P.NVp, red);
       }
       for (int i = tid; i < nv; i += WG) pnew[i] = px[i] / v.sdiagK[i];
     }

@@ -14,7 +14,9 @@ topo = MeshTopology(rc, rcells)
 print("refined mesh", topo.nv, topo.nt, topo.ne, flush=True)
 for direct in ((True,) if PMC else (True, False)):
     t = time.time()
-    batch = IpcsBatch([topo] * B, [rc] * B, rtol=1e-10, pressure_direct=direct, mode=int(os.environ.get("MDQ_MODE", "-1")))
+    batch = IpcsBatch([topo] * B, [rc] * B, rtol=1e-10, pressure_direct=direct, mode=int(os.environ.get("MDQ_MODE", "-1")),
+                      cell_order=os.environ.get("MDQ_CELL_ORDER", "auto"), pcg_degree=int(os.environ.get("MDQ_PCG", "0")))
+    print("cell order", os.environ.get("MDQ_CELL_ORDER", "auto"), "NRL", batch.desc.NRL, "lpos", bool(batch.desc.mf_lpos), flush=True)
     batch.assemble(); torch.cuda.synchronize()
     print("setup s", round(time.time() - t, 1), "mode", batch.desc.mode, flush=True)
     out = (torch.empty((B, 1), dtype=torch.float64, device="cuda"), torch.empty((B, 1), dtype=torch.float64, device="cuda"))
