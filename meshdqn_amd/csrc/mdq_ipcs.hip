@@ -1925,7 +1925,7 @@ __device__ inline int cg_pressure_cheb(int n, const int32_t* sl_off, const int32
 //      z = r + P A_c^-1 P^T r,     A_c = P^T A P,
 // P = piecewise constants over NAGX x NAGY geometric aggregates: vertices ranked by x into NAGX strips of equal
 // population, every strip ranked by y into NAGY cells (compact patches of ~16 vertices; aggregates of consecutive INDICES
-// do nothing for this matrix: tools + DESIGN 8.1).  A_c (56 x 56) is accumulated with LDS atomics, inverted in LDS by
+// do nothing for this matrix: tools + HISTORY 8.1).  A_c (56 x 56) is accumulated with LDS atomics, inverted in LDS by
 // Gauss-Jordan (SPD: no pivoting) once per solve and kept in fp32 (a preconditioner may be approximate; it is stored
 // exactly symmetric).  Per iteration: per-wave partial restrictions by LDS atomics (rows of one aggregate are scattered
 // over the waves), one 56^2 product spread over 448 threads, prolongation by one LDS read per row: two extra barriers.
@@ -3794,7 +3794,7 @@ static hipError_t launch_evolve_team(const mdq_ipcs_desc* d, size_t lds, int nst
 // ================================================================== element tiles, TWO workgroups per environment (mode 7)
 //
 // Mode 5 gives an environment ONE workgroup, and what bounds it on the refined mesh is that workgroup's memory-level
-// parallelism (22 GB/s per CU), not the chip: at the BASELINE batch of 128 environments half of the CUs idle,
+// parallelism (22 GB/s per CU, HISTORY 8.5), not the chip: at the BASELINE batch of 128 environments half of the CUs idle,
 // and 256 environments take 14.2 ms where 128 take 11.3.  Here the two workgroups of a team (the protocol of mode 4: team
 // barriers, reductions through the team's slots) share an environment's tile operators: the chunks of a tile application
 // are dealt out alternately, every workgroup accumulates its chunks' row sums into ITS OWN vector of the slab (in fixed

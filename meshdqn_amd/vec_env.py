@@ -1092,7 +1092,7 @@ class VecEnv2DAirfoil:
         pin = self.topo.pinned
         # (on the MAIN stream: the side stream of the host-driven step() - a plain pool stream - cost the S3 rollouts of a process
         #  40 % once it had been used here, 0.73 -> 1.04-1.10 ms per step in bench.py: the stream -> hardware-queue lottery of
-        #  DESIGN 5 "Streams"; the copies run behind the last step's kernels either way)
+        #  HISTORY 5 "Streams"; the copies run behind the last step's kernels either way)
         pin["coords"].copy_(dt.coords, non_blocking=True)
         pin["cells"].copy_(dt.cells, non_blocking=True)
         parts = [("rewards", ro["rew"][:K]), ("dones", ro["done"][:K]), ("actions", ro["act"][:K]), ("codes", ro["code"][:K]),
