@@ -40,11 +40,13 @@ constexpr int TNPOLY = 256;
 template <int PER>
 __device__ __forceinline__ int scan_excl(int* a, int n, int* part) {
   const int tid = threadIdx.x;
-  int loc[PER], run = 0;
+  // (the running sums of the thread's PER entries are NOT kept across the barriers below - PER registers, spilled by the 1 024-thread
+  //  large-mesh instance at its 128-VGPR cap - but formed again from the entries in the write-back pass)
+  int run = 0, tid1 = tid;
+  asm volatile("" : "+v"(tid1));       // (per call: shared between the ten calls of a launch, the addresses were spilled at kernel start)
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
-    const int idx = tid * PER + i;
-    loc[i] = run;
+    const int idx = tid1 * PER + i;
     run += idx < n ? a[idx] : 0;
   }
   // thread totals: inclusive scan inside the wave by shuffles, then the TW / 64 wave totals through LDS
@@ -66,11 +68,17 @@ __device__ __forceinline__ int scan_excl(int* a, int n, int* part) {
     if (w < wave) pre += wt;
     total += wt;
   }
-  const int base = pre + v - run;
+  int at = pre + v - run;
+  int tid2 = tid;
+  asm volatile("" : "+v"(tid2));       // (the entries' addresses - 64-bit on the slab - are formed again, not kept across the barriers)
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
-    const int idx = tid * PER + i;
-    if (idx < n) a[idx] = base + loc[i];
+    const int idx = tid2 * PER + i;
+    if (idx < n) {
+      const int val = a[idx];
+      a[idx] = at;
+      at += val;
+    }
   }
   __syncthreads();
   return total;

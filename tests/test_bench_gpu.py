@@ -60,10 +60,10 @@ def test_bench_single_rank_line(lib_built):
     assert res["value_min"] <= res["value"] <= res["value_max"]
     assert 0 < res["steady_state_ms_per_step"] <= res["ms_per_step"] * 1.5          # the HIP-event period of a step inside the rollouts
     ks = res["kernel_scratch"]
-    # (with a private segment: the large-mesh instances - `topology_kernel<4>` at the 128-VGPR cap of 1 024 threads; the tile kernels
-    #  that call the matrix-on-chip pressure solver, round 6: a `noinline` function of 256 VGPRs - its callee saves, the caller's saves
-    #  around the call, and one 7-row vector it keeps there; nothing inside the velocity loops: checked by source line in the ISA)
-    big = ("evolve_kernel<5", "topology_kernel<4>", "evolve_team_tiles_kernel<false>")
+    # (with a private segment: the tile kernels that call the matrix-on-chip pressure solver, round 6: a `noinline` function of 256
+    #  VGPRs - its callee saves, the caller's saves around the call, and one 7-row vector it keeps there; nothing inside the velocity
+    #  loops: checked by source line in the ISA.  `topology_kernel<4>`: 0 B since round 6 - 344 B in round 4, 124 B in round 5)
+    big = ("evolve_kernel<5", "evolve_team_tiles_kernel<false>")
     assert ks["kernels"] >= 55 and all(v["scratch"] == 0 for k, v in ks["hot_kernels"].items() if not any(b in k for b in big)), ks
     assert "S3" in res["config"]["workload"] and res["config"]["krylov_iters_per_ipcs_step"]["velocity_bicgstab"] > 0
     roof = res["roofline"]
