@@ -508,15 +508,21 @@ extern "C" MDQ_API int mdq_st_trace_host(long long* out, int reset) {
 constexpr int SWG = MDQ_SETUP_WG;   // threads of the set-up kernel (its row loops are latency chains: more rows in flight)
 // LS (with ST): the dof <- element-slot lists (g1 / g2 pointers and slots, 16-bit in LDS) are staged as well when they fit:
 // the row loops then have no dependent global load left.
-template <bool ST, bool LS = false>
+// GEO = false with ST (round 6, the meshes whose 40 B of geometry per cell do not fit: the red-refined lab meshes): only the
+// INDEX data is staged - cell dofs (16-bit), Dirichlet flags, the P1 scaling - 12 NT + N2 + 9 NV bytes (118 KB for the refined
+// ys930); geometry and Dirichlet values come from global memory.  Of a slot's chain slot -> cell dofs -> flags (-> values at
+// boundary cells only) the two inner levels are LDS round trips then; the unstaged instance paid an L2 round trip for each.
+template <bool ST, bool LS = false, bool GEO = ST>
 __global__ __launch_bounds__(SWG) void setup_matfree_kernel(mdq_ipcs_desc d) {
+  static_assert(ST || !GEO, "geometry is staged together with the index data only");
+  static_assert(GEO || !LS, "the slot lists are staged in the full instance only");
   const int b = blockIdx.x, tid = threadIdx.x;
   const EnvView v = env_view(d, b);
   const double a = d.rho / d.dt, mu = d.mu;
   extern __shared__ __align__(16) unsigned char setup_lds[];
-  double* sGeo = reinterpret_cast<double*>(setup_lds);             // [5][NT]
-  double* sGx = sGeo + 5 * (size_t)d.NT;                            // [N2]
-  double* sSd = sGx + d.N2;                                         // [NV]
+  double* sGeo = reinterpret_cast<double*>(setup_lds);             // [5][NT]   (GEO)
+  double* sGx = sGeo + (GEO ? 5 * (size_t)d.NT : 0);                // [N2]      (GEO)
+  double* sSd = sGx + (GEO ? d.N2 : 0);                             // [NV]
   uint16_t* sCd = reinterpret_cast<uint16_t*>(sSd + d.NV);          // [6][NT]
   uint8_t* sFl = reinterpret_cast<uint8_t*>(sCd + 6 * (size_t)d.NT);  // [N2]
   uint8_t* sPf = sFl + d.N2;                                        // [NV]
@@ -529,7 +535,7 @@ __global__ __launch_bounds__(SWG) void setup_matfree_kernel(mdq_ipcs_desc d) {
   auto g1p = [&](int i) -> int { return LS ? (int)sG1p[i] : v.g1_ptr[i]; };
   auto g1s = [&](int i) -> int { return LS ? (int)sG1s[i] : v.g1_src[i]; };
   auto geo = [&](int e) -> Geo {
-    if (!ST) return load_geo(v, e);
+    if (!GEO) return load_geo(v, e);
     Geo g;
     g.j00 = sGeo[0 * v.NT + e];
     g.j01 = sGeo[1 * v.NT + e];
@@ -540,7 +546,7 @@ __global__ __launch_bounds__(SWG) void setup_matfree_kernel(mdq_ipcs_desc d) {
   };
   auto cdof = [&](int j, int e) -> int { return ST ? (int)sCd[j * v.NT + e] : v.cell_dofs[j * v.NT + e]; };
   auto uflag = [&](int i) -> bool { return ST ? sFl[i] != 0 : v.bcu_flag[i] != 0; };
-  auto ugx = [&](int i) -> double { return ST ? sGx[i] : v.bcu_gx[i]; };
+  auto ugx = [&](int i) -> double { return GEO ? sGx[i] : v.bcu_gx[i]; };
   auto pflag = [&](int i) -> bool { return ST ? sPf[i] != 0 : v.bcp_flag[i] != 0; };
   auto sdk = [&](int i) -> double { return ST ? sSd[i] : v.sdiagK[i]; };
   if (ST) {
@@ -548,7 +554,7 @@ __global__ __launch_bounds__(SWG) void setup_matfree_kernel(mdq_ipcs_desc d) {
       for (int e = tid; e < v.nt; e += SWG) sCd[j * v.NT + e] = (uint16_t)v.cell_dofs[j * v.NT + e];
     for (int i = tid; i < v.n2; i += SWG) {
       sFl[i] = v.bcu_flag[i];
-      sGx[i] = v.bcu_gx[i];
+      if (GEO) sGx[i] = v.bcu_gx[i];
     }
     for (int i = tid; i < v.nv; i += SWG) sPf[i] = v.bcp_flag[i];
     if (LS) {
@@ -579,7 +585,7 @@ __global__ __launch_bounds__(SWG) void setup_matfree_kernel(mdq_ipcs_desc d) {
     v.geom[2 * v.NT + e] = q2;
     v.geom[3 * v.NT + e] = q3;
     v.geom[4 * v.NT + e] = q4;
-    if (ST) {
+    if (GEO) {
       sGeo[0 * v.NT + e] = q0;
       sGeo[1 * v.NT + e] = q1;
       sGeo[2 * v.NT + e] = q2;
@@ -5998,6 +6004,13 @@ int mdq_ipcs_setup_matfree(const mdq_ipcs_desc* d, void* stream) {
                             (int)stage_bytes);
     if (e != hipSuccess) return fail("setup_matfree_kernel attribute", e);
     hipLaunchKernelGGL(setup_matfree_kernel<true>, dim3(d->B), dim3(SWG), stage_bytes, (hipStream_t)stream, *d);
+  } else if (const size_t idx_bytes = 12 * (size_t)d->NT + (size_t)d->N2 + 9 * (size_t)d->NV + 64;
+             idx_bytes <= 156 * 1024 && d->N2 <= 65535 && std::getenv("MDQ_SETUP_UNSTAGED") == nullptr) {
+    // (the index data alone: cell dofs, flags, the P1 scaling; MDQ_SETUP_UNSTAGED=1: the unstaged instance, A / B switch)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&setup_matfree_kernel<true, false, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)idx_bytes);
+    if (e != hipSuccess) return fail("setup_matfree_kernel attribute", e);
+    hipLaunchKernelGGL((setup_matfree_kernel<true, false, false>), dim3(d->B), dim3(SWG), idx_bytes, (hipStream_t)stream, *d);
   } else {
     hipLaunchKernelGGL(setup_matfree_kernel<false>, dim3(d->B), dim3(SWG), 0, (hipStream_t)stream, *d);
   }

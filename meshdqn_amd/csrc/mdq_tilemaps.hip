@@ -28,6 +28,7 @@ namespace mdq_tm {
 constexpr int WG = 1024, CH = 1024, NW = WG / 64;
 constexpr int MAX_CH = 8;            // chunks of an environment (NT <= 8192)
 constexpr int MAX_N2 = 16384;        // rows (NV <= 4096 vertices + NE <= 12288 edges)
+constexpr int LMAX = 16;             // slots of a dof <- slot list (cells at a vertex)
 
 __global__ __launch_bounds__(WG) void tile_maps_kernel(mdq_ipcs_desc d, int32_t* rlist, int32_t* rcnt, int32_t* lpos, int32_t* status) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -47,23 +48,28 @@ __global__ __launch_bounds__(WG) void tile_maps_kernel(mdq_ipcs_desc d, int32_t*
   if (tid == 0) flag[0] = 0;
   for (int k = tid; k < nch * N2p / 4; k += WG) reinterpret_cast<uint32_t*>(cnt8)[k] = 0u;
   __syncthreads();
-  // ---- (1) run lengths per (chunk, row)
+  // ---- (1) run lengths per (chunk, row).  A list holds at most LMAX slots (a vertex of more than 16 cells is refused by the mesh
+  //      kernels as well); all of them are requested at once: walked slot by slot, a row was a chain of dependent L2 round trips
   for (int r = tid; r < n2; r += WG) {
     const int lo = g2_ptr[r], hi = g2_ptr[r + 1];
-    if (hi <= lo) flag[0] = 1;                   // a dof that belongs to no cell: the first-touch flags would miss its row
+    if (hi <= lo || hi - lo > LMAX) flag[0] = 1;  // a dof that belongs to no cell (the first-touch flags would miss its row) / too many
+    int ent[LMAX];
+#pragma unroll
+    for (int k = 0; k < LMAX; ++k) ent[k] = lo + k < hi ? g2_src[lo + k] : -1;
     int c_prev = -1, run = 0;
-    for (int k = lo; k < hi; ++k) {
-      const int c = (g2_src[k] / 6) / CH;
-      if (c != c_prev) {
-        if (c_prev >= 0) cnt8[c_prev * N2p + r] = (unsigned char)run;
-        if (c < c_prev || c >= nch) flag[0] = 1;   // (not ascending / beyond the mesh: not a list this kernel understands)
-        c_prev = c;
-        run = 0;
+#pragma unroll
+    for (int k = 0; k < LMAX; ++k)
+      if (ent[k] >= 0) {
+        const int c = (ent[k] / 6) / CH;
+        if (c != c_prev) {
+          if (c_prev >= 0) cnt8[c_prev * N2p + r] = (unsigned char)run;
+          if (c < c_prev || c >= nch) flag[0] = 1;   // (not ascending / beyond the mesh: not a list this kernel understands)
+          c_prev = c;
+          run = 0;
+        }
+        ++run;
       }
-      ++run;
-    }
-    if (c_prev >= 0) cnt8[c_prev * N2p + r] = (unsigned char)min(run, 255);
-    if (run > 255) flag[0] = 1;
+    if (c_prev >= 0) cnt8[c_prev * N2p + r] = (unsigned char)run;
   }
   __syncthreads();
   // ---- (2) per chunk: scans over the rows, list entries, packed words
@@ -124,10 +130,14 @@ __global__ __launch_bounds__(WG) void tile_maps_kernel(mdq_ipcs_desc d, int32_t*
         if (k > 0) {
           const int lo = g2_ptr[r], hi = g2_ptr[r + 1];
           const uint32_t w0 = pk[r];
+          int ent[LMAX];
+#pragma unroll
+          for (int q = 0; q < LMAX; ++q) ent[q] = lo + q < hi ? g2_src[lo + q] : -1;
           int j = 0;
-          for (int q = lo; q < hi; ++q) {
-            const int s = g2_src[q], e = s / 6;
-            if (e / CH == c) {
+#pragma unroll
+          for (int q = 0; q < LMAX; ++q) {
+            const int s = ent[q], e = s / 6;
+            if (s >= 0 && e / CH == c) {
               lp[(s - e * 6) * d.NT + e] = (int)((w0 & 0xFFFFu) | (((w0 >> 16) + (uint32_t)j) << 16));
               ++j;
             }

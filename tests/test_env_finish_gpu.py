@@ -258,3 +258,32 @@ def test_topology_handover_outputs_equal_the_mesh_and_its_edge_numbering(lib_bui
         assert torch.equal(ho["cell_dofs"][b, :, :t], dt.t["cell_dofs"][b, :, :t])
     with pytest.raises(ValueError):
         dt.set_handover(**{**ho, "cells": ho["cells"][:, :-1]})
+
+
+def test_fields_after_a_rollout_whose_last_step_resets_environments(lib_built):
+    """`venv.u / venv.p` are public: after `rollout_device` the rows of the environments the LAST step reset in place hold the
+    initial snapshot fields (what the reference's reset() exposes: the cached ground-truth snapshots), bit for bit - not an
+    interpolation of pre-reset fields onto the restored mesh (the full interpolation pass of `rollout_end` runs with the restored
+    vertex counts) -, and the rows of every other environment are the COMPLETE fields of their current meshes (equal to a
+    full interpolation launched afterwards); a host-driven step() that follows continues from there."""
+    venv = _venv(GOLDEN, 12, 0)
+    venv.get_state()
+    rng = np.random.default_rng(7)
+    acts = rng.integers(0, 180, (3, venv.B)).astype(np.int32)
+    out = venv.rollout_device(None, 3, actions=acts)
+    torch.cuda.synchronize()
+    last = out["dones"][-1]
+    assert last.any() and not last.all(), last          # (threshold 1e-3: some episodes end at their third removal, not all)
+    c = venv._init_cache
+    u, p = venv.u.clone(), venv.p.clone()
+    for b in np.flatnonzero(last):
+        assert torch.equal(u[b], c["u"]) and torch.equal(p[b], c["p"]), b      # (the rows cached from environment 0 at reset_all)
+        assert int(venv.nv[b]) == venv.NV and int(venv.steps[b]) == 0
+    venv._refresh_launch(readback=False, sparse=0)       # a full interpolation of the current meshes
+    torch.cuda.synchronize()
+    nv, ne = venv.dtopo.nv.cpu().numpy(), venv.dtopo.t["ne"].cpu().numpy()
+    for b in np.flatnonzero(~last):
+        n1, n2 = int(nv[b]), int(nv[b] + ne[b])
+        assert torch.equal(venv.u[b, :, :n2], u[b, :, :n2]) and torch.equal(venv.p[b, :, :n1], p[b, :, :n1]), b
+    st, rew, done, info = venv.step(rng.integers(0, 180, venv.B))
+    assert np.isfinite(rew).all() and (info["code"] == 0).all()
