@@ -26,11 +26,13 @@ constexpr int RW = MDQ_REMESH_WG;   // threads per mesh (256 in rounds 1-3: the 
 // Capacities as a template parameter K (round 4): K = 1 - 1024 vertices / 2048 triangles, every table in LDS (the
 // kernel of the 128-environment batches); K = 4 - 4096 vertices / 8192 triangles (BASELINE configs[4]: ys930 red-refined,
 // 3 322 vertices), the same code on a slab in GLOBAL memory per mesh (L2 resident; slower: every table access is an L2
-// round trip instead of an LDS one - the reference's _remove_vertex takes whatever mesh it is given, Env2DAirfoil.py:452-512).
+// round trip instead of an LDS one - the reference's _remove_vertex takes whatever mesh it is given, Env2DAirfoil.py:452-512);
+// K = 16 (round 6) - 16 384 vertices / 32 768 triangles (ys930 red-refined twice: 12 924 / 25 120): the slab form throughout, the
+// edge hash of 131 072 slots on the slab as well (it does not fit the LDS) - coverage, not speed.
 template <int K>
 struct Cap {
   static constexpr int NV = 1024 * K, NT = 2048 * K, NS = 3 * NT, HS = 8192 * K;
-  static constexpr int VBITS = K == 1 ? 10 : 12, HSHIFT = K == 1 ? 19 : 17;       // vertex ids / 32 - log2(HS)
+  static constexpr int VBITS = K == 1 ? 10 : (K == 4 ? 12 : 14), HSHIFT = K == 1 ? 19 : (K == 4 ? 17 : 15);   // vertex ids / 32 - log2(HS)
   static constexpr size_t BYTES = (size_t)16 * NV + 2 * sizeof(int) * NS + 2 * sizeof(uint32_t) * HS + sizeof(int) * 336;
 };
 constexpr int RNV = Cap<1>::NV, RNT = Cap<1>::NT;
@@ -92,9 +94,10 @@ __global__ __launch_bounds__(RW) void remesh_kernel(int NV, int NT, double* coor
   // K = 4 (round 5): the hash of the neighbour table - and the flip stack that re-uses it - in LDS, 16 384 slots (load <= 0.75
   // at 12 288 edges; probes bounded): its inserts were atomics + dependent reads on the slab, an L2 round trip each, 75 % of the
   // large-mesh instance (tools/trace_remesh.py on the refined ys930: 557 k of 743 k cycles).  Everything else stays on the slab.
-  constexpr int HT = K == 1 ? RHS : 16384;
-  constexpr int HSH = K == 1 ? C::HSHIFT : 18;
-  uint32_t* hkey = K == 1 ? reinterpret_cast<uint32_t*>(nbr + RNS) : reinterpret_cast<uint32_t*>(lds_);   // [HT] | the flip stack
+  constexpr int HT = K == 4 ? 16384 : RHS;
+  constexpr int HSH = K == 4 ? 18 : C::HSHIFT;
+  // (K = 1: behind the neighbour table in LDS; K = 4: the LDS; K = 16: behind the neighbour table on the slab)
+  uint32_t* hkey = K == 4 ? reinterpret_cast<uint32_t*>(lds_) : reinterpret_cast<uint32_t*>(nbr + RNS);   // [HT] | the flip stack
   uint32_t* hval = hkey + HT;                                        // [HT]             | re-uses this region
   int* stack = reinterpret_cast<int*>(hkey);                         // [2 * HT]
   int* misc = reinterpret_cast<int*>(reinterpret_cast<uint32_t*>(nbr + RNS) + 2 * RHS);   // [336]: counters, star list, lane 0's work arrays
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(RW) void remesh_kernel(int NV, int NT, double* coor
 template <int K>
 static int remesh_launch_k(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv, int32_t* nt,
                            const int32_t* remove_idx, int32_t* status, const mdq_rm::ActArgs* act, void* stream, unsigned char* slab) {
-  const size_t lds = K == 1 ? mdq_rm::Cap<1>::BYTES : 2 * sizeof(uint32_t) * 16384;   // (K = 4: the edge hash / flip stack)
+  const size_t lds = K == 1 ? mdq_rm::Cap<1>::BYTES : (K == 4 ? 2 * sizeof(uint32_t) * 16384 : 0);   // (K = 4: the edge hash / flip stack)
   static const hipError_t attr = [] {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mdq_rm::remesh_kernel<false, K>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -459,7 +462,8 @@ static int remesh_launch_k(int32_t B, int32_t NV, int32_t NT, double* coords, in
 extern "C" int64_t mdq_remesh_workspace_bytes(int32_t B, int32_t NV, int32_t NT) {
   if (B <= 0 || NV <= 0 || NT <= 0) return 0;
   if (NV <= mdq_rm::Cap<1>::NV && NT <= mdq_rm::Cap<1>::NT) return 0;         // every table in LDS
-  if (NV > mdq_rm::Cap<4>::NV || NT > mdq_rm::Cap<4>::NT) return -1;           // beyond the kernels
+  if (NV > mdq_rm::Cap<16>::NV || NT > mdq_rm::Cap<16>::NT) return -1;         // beyond the kernels
+  if (NV > mdq_rm::Cap<4>::NV || NT > mdq_rm::Cap<4>::NT) return (int64_t)((mdq_rm::Cap<16>::BYTES + 255) & ~(size_t)255) * B;
   return (int64_t)((mdq_rm::Cap<4>::BYTES + 255) & ~(size_t)255) * B;
 }
 
@@ -470,11 +474,13 @@ static int remesh_launch(const char* who, int32_t B, int32_t NV, int32_t NT, dou
   (void)who;
   if (NV <= mdq_rm::Cap<1>::NV && NT <= mdq_rm::Cap<1>::NT)
     return remesh_launch_k<1>(B, NV, NT, coords, cells, nv, nt, remove_idx, status, act, stream, nullptr);   // (no workspace needed)
-  if (NV > mdq_rm::Cap<4>::NV || NT > mdq_rm::Cap<4>::NT)
-    return mdq_set_error("mdq_remesh: capacity above 4096 vertices / 8192 triangles");
+  if (NV > mdq_rm::Cap<16>::NV || NT > mdq_rm::Cap<16>::NT)
+    return mdq_set_error("mdq_remesh: capacity above 16384 vertices / 32768 triangles");
   // the large-mesh instance: its tables live in the CALLER's workspace (global memory, one slab per mesh)
   if (!workspace || workspace_bytes < mdq_remesh_workspace_bytes(B, NV, NT) || (reinterpret_cast<uintptr_t>(workspace) & 15))
     return mdq_set_error("mdq_remesh: workspace missing, too small or not 16-byte aligned (mdq_remesh_workspace_bytes)");
+  if (NV > mdq_rm::Cap<4>::NV || NT > mdq_rm::Cap<4>::NT)
+    return remesh_launch_k<16>(B, NV, NT, coords, cells, nv, nt, remove_idx, status, act, stream, static_cast<unsigned char*>(workspace));
   return remesh_launch_k<4>(B, NV, NT, coords, cells, nv, nt, remove_idx, status, act, stream, static_cast<unsigned char*>(workspace));
 }
 

@@ -22,6 +22,17 @@ constexpr int MAXK = 16;           // incident cells per vertex in the level-ord
 constexpr int MAXLEV = 1024;       // levels whose starts are kept in LDS (more: the general loop)
 constexpr size_t SLAB_BYTES = sizeof(int) * (BNV + 8) + sizeof(uint32_t) * 3 * BNT * 2 + sizeof(uint16_t) * BNV * 2 + sizeof(int) * (BNV + 8) +
                               sizeof(uint32_t) * BNV + sizeof(uint32_t) * BNV * MAXK;
+// KV = 4 (round 6): 16 384 vertices / 32 768 triangles (ys930 red-refined twice: 12 924 / 25 120) - the level kernel with the
+// positions and the level array on the slab too (they do not fit the LDS): every update gathers from L2 and every level ends in a
+// full barrier.  Coverage, not speed: the reference's Mesh.smooth takes whatever mesh it is given (flow_solver.py:236-237).
+template <int KV>
+struct BCap {
+  static constexpr int NV = 4096 * KV, NT = 8192 * KV;
+  static constexpr size_t TABLES = sizeof(int) * (NV + 8) + sizeof(uint32_t) * 3 * NT * 2 + sizeof(uint16_t) * NV * 2 + sizeof(int) * (NV + 8) +
+                                   sizeof(uint32_t) * NV + sizeof(uint32_t) * NV * MAXK;
+  static constexpr size_t SLAB = TABLES + (KV > 1 ? 16 * (size_t)NV + sizeof(int) * NV + 64 : 0);     // + positions + levels
+};
+static_assert(BCap<1>::SLAB == SLAB_BYTES, "the 4096-vertex instance keeps its slab layout");
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
@@ -160,6 +171,7 @@ __device__ __forceinline__ d2 exact_vertex(const d2* X, const int* ptr, const ui
 
 // The sweeps of the level schedule (shared by the two kernels below): positions X and level starts `lstart` in LDS, the
 // level-ordered work records meta[i] = v | k << 16, inc2[i][MAXK] in the workspace.
+template <bool GX = false>       // GX: the positions are in GLOBAL memory (the 16 384-vertex instance): a full barrier per level
 __device__ __forceinline__ void level_sweeps(d2* X, const double* r2k_tab, const int* lstart, const uint32_t* meta, const uint32_t* inc2,
                                              int lmax, int S, int tid) {
   {
@@ -215,7 +227,8 @@ __device__ __forceinline__ void level_sweeps(d2* X, const double* r2k_tab, const
       // LDS-only barrier: the positions of this level are in LDS (lgkmcnt), the records requested for the next level are
       // still on their way (vmcnt) and stay in flight - __syncthreads() drains the vector-memory counter as well
 #ifndef MDQ_SB_NOBAR
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (GX) __syncthreads();
+      else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
       SB_STAMP(3)
     };
@@ -299,12 +312,16 @@ __device__ __forceinline__ void skew_sweeps(d2* X, const double* r2k_tab, const 
   if (t < T) step(ra, rb);
 }
 
+template <int KV>
 __global__ __launch_bounds__(BWG) void smooth_big_kernel(int NV, int NT, double* coords, const int32_t* cells, const int32_t* nv_,
                                                          const int32_t* nt_, const int32_t* iters_, const int32_t* rem,
                                                          const int32_t* rstat, int iters_env, unsigned char* slab, int32_t* status) {
+  constexpr int BNV = BCap<KV>::NV, BNT = BCap<KV>::NT;       // (shadow the 4096-vertex constants of the namespace)
+  constexpr size_t SLAB_BYTES = BCap<KV>::SLAB;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_[];
-  d2* X = reinterpret_cast<d2*>(dyn_);                       // [BNV] 64 KB
-  int* cnt = reinterpret_cast<int*>(dyn_ + sizeof(d2) * BNV);   // [BNV] 16 KB: counts / cursors, then levels
+  unsigned char* xbase = KV == 1 ? dyn_ : slab + (size_t)blockIdx.x * ((SLAB_BYTES + 255) & ~(size_t)255) + ((BCap<KV>::TABLES + 15) & ~(size_t)15);
+  d2* X = reinterpret_cast<d2*>(xbase);                      // [BNV] 64 KB of LDS (KV = 1) / on the slab behind the tables
+  int* cnt = reinterpret_cast<int*>(xbase + sizeof(d2) * BNV);  // [BNV] 16 KB: counts / cursors, then levels
   __shared__ int part[BWG];
   __shared__ int misc[4];
   __shared__ double r2k_tab[MAXK + 1];
@@ -479,7 +496,7 @@ __global__ __launch_bounds__(BWG) void smooth_big_kernel(int NV, int NT, double*
   if (lmax == 0) {
     // (no interior vertex: nothing moves)
   } else if (!misc[1]) {
-    level_sweeps(X, r2k_tab, lstart, meta, inc2, lmax, S, tid);
+    level_sweeps<(KV > 1)>(X, r2k_tab, lstart, meta, inc2, lmax, S, tid);
   } else
   for (int s = 0; s < S; ++s) {
     for (int l = 1; l <= lmax; ++l) {
@@ -823,7 +840,8 @@ extern "C" MDQ_API int mdq_sb_trace_host(long long* out, int reset) {
 // bytes of caller workspace the large-mesh kernel needs (0: the mesh fits the 1024-vertex kernels; -1: beyond the kernels)
 static int64_t smooth_big_workspace_bytes(int32_t B, int32_t NV, int32_t NT) {
   using namespace mdq_smooth_big;
-  if (NV > BNV || NT > BNT) return -1;
+  if (NV > BCap<4>::NV || NT > BCap<4>::NT) return -1;
+  if (NV > BNV || NT > BNT) return (int64_t)((BCap<4>::SLAB + 255) & ~(size_t)255) * B;                // (no hand-back launch there)
   return (int64_t)((SLAB_BYTES + 255) & ~(size_t)255) * B + (((int64_t)B * 4 + 255) & ~(int64_t)255);   // tables + the hand-back counts
 }
 
@@ -832,12 +850,18 @@ static int smooth_big_launch(int32_t B, int32_t NV, int32_t NT, double* coords, 
                              const int32_t* nt, const int32_t* iterations, const int32_t* rem, const int32_t* rstat,
                              int32_t iters_env, void* workspace, int64_t workspace_bytes, void* stream) {
   using namespace mdq_smooth_big;
-  if (NV > BNV || NT > BNT) return mdq_set_error("mdq_smooth: capacity above 4096 vertices / 8192 triangles");
+  if (NV > BCap<4>::NV || NT > BCap<4>::NT) return mdq_set_error("mdq_smooth: capacity above 16384 vertices / 32768 triangles");
   if (!workspace || workspace_bytes < smooth_big_workspace_bytes(B, NV, NT) || (reinterpret_cast<uintptr_t>(workspace) & 15))
     return mdq_set_error("mdq_smooth: workspace missing, too small or not 16-byte aligned (mdq_smooth_workspace_bytes / mdq_smooth_fast_workspace_bytes)");
   unsigned char* slab = static_cast<unsigned char*>(workspace);
+  if (NV > BNV || NT > BNT) {      // the 16 384-vertex instance: positions on the slab, no LDS beyond the static tables
+    hipLaunchKernelGGL(smooth_big_kernel<4>, dim3(B), dim3(BWG), 0, (hipStream_t)stream, NV, NT, coords, cells, nv, nt, iterations, rem,
+                       rstat, iters_env, slab, nullptr);
+    if (hipGetLastError() != hipSuccess) return mdq_set_error("smooth_big_kernel<4> launch failed");
+    return 0;
+  }
   const size_t lds = sizeof(d2) * BNV + sizeof(int) * BNV;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&smooth_big_kernel),
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&smooth_big_kernel<1>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(d2) * BNV + sizeof(int) * BNV));
   if (attr != hipSuccess) return mdq_set_error("hipFuncSetAttribute(smooth_big_kernel) failed");
   // meshes whose tables fit the LDS beside the positions: the kernel with the LDS set-up, then this launch for what it hands back
@@ -851,12 +875,12 @@ static int smooth_big_launch(int32_t B, int32_t NV, int32_t NT, double* coords, 
     int32_t* redo = reinterpret_cast<int32_t*>(slab + ((SLAB_BYTES + 255) & ~(size_t)255) * (size_t)B);
     hipLaunchKernelGGL(smooth_flow_kernel, dim3(B), dim3(FWG), flow_lds, (hipStream_t)stream, NV, NT, coords, cells, nv, nt,
                        iterations, rem, rstat, iters_env, slab, redo);
-    hipLaunchKernelGGL(smooth_big_kernel, dim3(B), dim3(BWG), lds, (hipStream_t)stream, NV, NT, coords, cells, nv, nt, redo,
+    hipLaunchKernelGGL(smooth_big_kernel<1>, dim3(B), dim3(BWG), lds, (hipStream_t)stream, NV, NT, coords, cells, nv, nt, redo,
                        nullptr, nullptr, 0, slab, nullptr);
     if (hipGetLastError() != hipSuccess) return mdq_set_error("smooth_flow_kernel launch failed");
     return 0;
   }
-  hipLaunchKernelGGL(smooth_big_kernel, dim3(B), dim3(BWG), lds, (hipStream_t)stream, NV, NT, coords, cells, nv, nt, iterations,
+  hipLaunchKernelGGL(smooth_big_kernel<1>, dim3(B), dim3(BWG), lds, (hipStream_t)stream, NV, NT, coords, cells, nv, nt, iterations,
                      rem, rstat, iters_env, slab, nullptr);
   if (hipGetLastError() != hipSuccess) return mdq_set_error("smooth_big_kernel launch failed");
   return 0;

@@ -28,9 +28,25 @@ constexpr int TW = MDQ_TOPO_TW;
 template <int K>
 struct TCap {
   static constexpr int NV = 1024 * K, NT = 2048 * K, NE = 3072 * K, NP = NV + NE, NS = 3 * NT, HS = 8192 * K;
-  static constexpr int VBITS = K == 1 ? 10 : 12, HSHIFT = K == 1 ? 19 : 17, PER = NS / TW;
-  static constexpr size_t BYTES = (size_t)16 * NV + 8 * HS + sizeof(int) * NS + sizeof(uint16_t) * NS + 3 * sizeof(uint16_t) * NE + NE + NV +
-                                  sizeof(int) * (TW + 16);
+  static constexpr int VBITS = K == 1 ? 10 : (K == 4 ? 12 : 14), HSHIFT = K == 1 ? 19 : (K == 4 ? 17 : 15), PER = NS / TW;
+  // (the owner SLOT of an edge - 3 * cell + local edge - is beyond 16 bits from 21 846 triangles on: K = 16)
+  using own_t = typename std::conditional<(K > 4), uint32_t, uint16_t>::type;
+  static constexpr size_t BASE = ((size_t)16 * NV + 8 * HS + sizeof(int) * NS + sizeof(uint16_t) * NS + 2 * sizeof(uint16_t) * NE + sizeof(own_t) * NE +
+                                  NE + NV + sizeof(int) * (TW + 16) + 15) & ~(size_t)15;
+  // (K = 16: + the staging array of the dof <- slot lists - slot ids 6 t + i are beyond 16 bits there, and 32-bit entries do not
+  //  fit in front of `fill` in region R)
+  using stage_t = typename std::conditional<(K > 4), uint32_t, uint16_t>::type;
+  static constexpr size_t BYTES = BASE + (K > 4 ? sizeof(uint32_t) * 6 * NT : 0);
+};
+// PER flags of a thread as bits (a `bool[PER]` is PER registers: 96 of them in the 16 384-vertex instance)
+template <int PER>
+struct Flags {
+  uint32_t w[(PER + 31) / 32];
+  __device__ __forceinline__ void set(int i, bool v) {
+    if ((i & 31) == 0) w[i >> 5] = 0u;
+    w[i >> 5] |= v ? 1u << (i & 31) : 0u;
+  }
+  __device__ __forceinline__ bool get(int i) const { return (w[i >> 5] >> (i & 31)) & 1u; }
 };
 constexpr int TNV = TCap<1>::NV, TNT = TCap<1>::NT, TNP = TCap<1>::NP;     // (the K = 1 capacities: host-side checks)
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
@@ -128,21 +144,22 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   // (atomics and dependent reads on the slab: an L2 round trip each) were 47 % of the large-mesh instance and the coordinate
   // reads most of the polygon-distance section's 27 % (tools/trace_topo.py on the refined ys930).  Every other table stays on
   // the slab; the numbering of the edges does not depend on the table (first appearance by slot index).
-  constexpr int HT = K == 1 ? HSZ : 16384;                   // hash slots
-  auto hslot = [](uint32_t key) { return hslot_t<(K == 1 ? CP::HSHIFT : 18)>(key); };
+  constexpr int HT = K == 4 ? 16384 : HSZ;                   // hash slots (K = 16: 131 072, on the slab like every other table)
+  auto hslot = [](uint32_t key) { return hslot_t<(K == 4 ? 18 : CP::HSHIFT)>(key); };
   // (always inlined: with a seventh call site the compiler kept it as a FUNCTION - a call inside the kernel, 288 B of stack
   //  per lane and every section slower)
   auto scan_excl = [](int* a_, int n_, int* part_) __attribute__((always_inline)) { return mdq_topo::scan_excl<CP::PER>(a_, n_, part_); };
   extern __shared__ __align__(16) unsigned char lds_[];
   unsigned char* smem = K == 1 ? lds_ : slab + (size_t)blockIdx.x * ((CP::BYTES + 255) & ~(size_t)255);
   double2* X = reinterpret_cast<double2*>(smem);                              // [TNV]
-  uint32_t* hkey = K == 1 ? reinterpret_cast<uint32_t*>(smem + 16 * TNV) : reinterpret_cast<uint32_t*>(lds_);   // [HT] | region R (64 KB
+  uint32_t* hkey = K == 4 ? reinterpret_cast<uint32_t*>(lds_) : reinterpret_cast<uint32_t*>(smem + 16 * TNV);   // [HT] | region R (64 KB
   uint32_t* hval = hkey + HT;                                                 // [HT]   | for K = 1), re-used after the edge phase
   int* scanb = reinterpret_cast<int*>(smem + 16 * TNV + 8 * HSZ);             // [TNS]
   uint16_t* eid_slot = reinterpret_cast<uint16_t*>(scanb + TNS);              // [TNS]
   uint16_t* ea = eid_slot + TNS;                                              // [TNE]
   uint16_t* eb = ea + TNE;
-  uint16_t* eown = eb + TNE;
+  using own_t = typename CP::own_t;
+  own_t* eown = reinterpret_cast<own_t*>(eb + TNE);                           // [TNE] owner slot of the edge
   uint8_t* eflag = reinterpret_cast<uint8_t*>(eown + TNE);                    // [TNE] bit0 boundary, bits 4-6 tag + 1
   uint8_t* onb = eflag + TNE;                                                 // [TNV]
   int* part = reinterpret_cast<int*>(onb + TNV);                              // [TW]
@@ -156,7 +173,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   int16_t* inv = reinterpret_cast<int16_t*>(order + TNV);                     // [TNV]
   // (K = 4: the distances and the histograms of the two counting sorts in the upper half of the LDS too, behind the polygon tables:
   //  lds_ + 64 KB: polygon tables 20 KB | histograms 8 KB | distances 32 KB)
-  double* dist = K == 1 ? reinterpret_cast<double*>(R + 8 * TNV) : reinterpret_cast<double*>(lds_ + 65536 + 28672);   // [TNV]
+  double* dist = K == 4 ? reinterpret_cast<double*>(lds_ + 65536 + 28672) : reinterpret_cast<double*>(R + 8 * TNV);   // [TNV]  (K = 16: on the slab)
   // (K = 4: the polygon and the small tables of the distance section - 16 KB that every vertex gathers from - sit in the upper
   //  half of the LDS, free once the edge hash is dead; the coordinates take the lower half)
   unsigned char* PB = K == 1 ? R + RPOLY : lds_ + 65536;                      // poly | segf | segr | ye | pmx
@@ -254,7 +271,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
       slot_key(s < nslots ? s : 0, a, c);
       ea[e] = (uint16_t)a;
       eb[e] = (uint16_t)c;
-      eown[e] = (uint16_t)s;
+      eown[e] = (own_t)s;
       eflag[e] = cnt_[e] >= 2 ? 0 : 1;
     }
     if (tid == 0) {
@@ -301,9 +318,9 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     }
     __syncthreads();
     // (the flags must be read back before the scan overwrites them)
-    bool isfirst[PER];
+    Flags<PER> isfirst;
   #pragma unroll
-    for (int i = 0; i < PER; ++i) isfirst[i] = scanb[tid * PER + i] != 0;
+    for (int i = 0; i < PER; ++i) isfirst.set(i, scanb[tid * PER + i] != 0);
     __syncthreads();
     ne = scan_excl(scanb, TNS, part);
     if (ne > TNE || nv + ne > D.NP) {
@@ -313,14 +330,14 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int s = tid * PER + i;
-      if (s < nslots && isfirst[i]) {
+      if (s < nslots && isfirst.get(i)) {
         int a, c;
         const uint32_t h = probe(slot_key(s, a, c));
         const int e = scanb[s];
         const bool shared = (hval[h] & 0x80000000u) != 0;
         ea[e] = (uint16_t)a;
         eb[e] = (uint16_t)c;
-        eown[e] = (uint16_t)s;
+        eown[e] = (own_t)s;
         eflag[e] = shared ? 0 : 1;
       }
     }
@@ -348,8 +365,9 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     }
     __syncthreads();
   }
-  if (K != 1) {
-    // the hash is dead: the coordinates move from the slab into its LDS (every later section gathers them)
+  if (K == 4) {
+    // the hash is dead: the coordinates move from the slab into its LDS (every later section gathers them; K = 16: they stay
+    // on the slab - 207 KB for the twice-refined ys930)
     double2* Xl = reinterpret_cast<double2*>(lds_);
     for (int v = tid; v < nv; v += TW) Xl[v] = X[v];
     __syncthreads();
@@ -407,9 +425,9 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   // airfoil facets in edge order
   for (int e = tid; e < TNS; e += TW) scanb[e] = (e < ne && (eflag[e] >> 4) == 2) ? 1 : 0;
   __syncthreads();
-  bool flg[PER];
+  Flags<PER> flg;
 #pragma unroll
-  for (int i = 0; i < PER; ++i) flg[i] = scanb[tid * PER + i] != 0;
+  for (int i = 0; i < PER; ++i) flg.set(i, scanb[tid * PER + i] != 0);
   __syncthreads();
   const int naf = scan_excl(scanb, TNS, part);
   if (naf > D.NAF) {
@@ -421,7 +439,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int e = tid * PER + i;
-      if (e < ne && flg[i]) {
+      if (e < ne && flg.get(i)) {
         const int q = scanb[e];
         af[2 * q] = eown[e] / 3;
         af[2 * q + 1] = eown[e] % 3;
@@ -436,20 +454,20 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   for (int v = tid; v < TNS; v += TW) scanb[v] = (v < nv && onb[v]) ? 1 : 0;
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < PER; ++i) flg[i] = scanb[tid * PER + i] != 0;
+  for (int i = 0; i < PER; ++i) flg.set(i, scanb[tid * PER + i] != 0);
   __syncthreads();
   const int nb = scan_excl(scanb, TNS, part);
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     const int v = tid * PER + i;
-    if (v < nv && flg[i]) blist[scanb[v]] = (uint16_t)v;
+    if (v < nv && flg.get(i)) blist[scanb[v]] = (uint16_t)v;
   }
   __syncthreads();
   // Two hash SETS of the boundary vertices' x and y values (bit patterns; x + 0.0 folds -0 into +0, the one pair of
   // different patterns that compares equal; a NaN equals nothing and is not inserted) at the end of region R, which is free
   // here: a vertex then takes two look-ups instead of comparing with every boundary vertex (876 x ~190 x 2 comparisons,
   // 25 k of the kernel's 175 k cycles).  The same predicate, exactly.  More boundary vertices than half a table: the loop.
-  constexpr int TSZ = 1024 * K;
+  constexpr int TSZ = 1024 * (K > 4 ? 4 : K);     // (K = 16: the LDS tables of K = 4; more boundary vertices than half a table: the loop)
   // (K = 4: in the upper half of the LDS - free between the edge hash and the polygon tables -: the inserts are atomics)
   unsigned long long* hx = K == 1 ? reinterpret_cast<unsigned long long*>(R + 8 * HSZ - 16 * TSZ)
                                   : reinterpret_cast<unsigned long long*>(lds_ + 65536);
@@ -518,13 +536,13 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   }
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < PER; ++i) flg[i] = scanb[tid * PER + i] != 0;
+  for (int i = 0; i < PER; ++i) flg.set(i, scanb[tid * PER + i] != 0);
   __syncthreads();
   const int nrem = scan_excl(scanb, TNS, part);
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     const int v = tid * PER + i;
-    if (v < nv && flg[i]) remv[scanb[v]] = (uint16_t)v;
+    if (v < nv && flg.get(i)) remv[scanb[v]] = (uint16_t)v;
   }
   if (tid == 0) D.nremovable[b] = nrem;
   TT_STAMP(3)
@@ -982,7 +1000,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   }
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < PER; ++i) flg[i] = scanb[tid * PER + i] != 0;
+  for (int i = 0; i < PER; ++i) flg.set(i, scanb[tid * PER + i] != 0);
   __syncthreads();
   const int ngood = scan_excl(scanb, TNS, part);
   if (3 * ngood > D.EMAX) {
@@ -996,7 +1014,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int t = tid * PER + i;
-      if (t < nt && flg[i]) {
+      if (t < nt && flg.get(i)) {
         const int v0 = tri[3 * t], v1 = tri[3 * t + 1], v2 = tri[3 * t + 2];
         const int vs[3] = {v0, v1, v2}, id[3] = {inv[v0], inv[v1], inv[v2]};
         const int pa[3] = {0, 0, 1}, pb[3] = {1, 2, 2};
@@ -1056,7 +1074,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   for (int e = tid; e < TNS; e += TW) scanb[e] = (e < ne && (eflag[e] >> 4) == 4) ? 1 : 0;
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < PER; ++i) flg[i] = scanb[tid * PER + i] != 0;
+  for (int i = 0; i < PER; ++i) flg.set(i, scanb[tid * PER + i] != 0);
   __syncthreads();
   const int nof = scan_excl(scanb, TNS, part);
   const int nent = 18 * nof;
@@ -1081,7 +1099,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     const int e = tid * PER + i;
-    if (e < ne && flg[i]) {
+    if (e < ne && flg.get(i)) {
       pf[ea[e]] = 1;
       pf[eb[e]] = 1;
       cof[eown[e] / 3] = (int8_t)(eown[e] % 3);
@@ -1133,7 +1151,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     for (int t = tid; t < TNS; t += TW) scanb[t] = (t < nent && (t == 0 || cntd[t] != cntd[t - 1])) ? 1 : 0;
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < PER; ++i) flg[i] = scanb[tid * PER + i] != 0;
+    for (int i = 0; i < PER; ++i) flg.set(i, scanb[tid * PER + i] != 0);
     __syncthreads();
     const int nbo = scan_excl(scanb, TNS, part);
     if (nbo > O.NBO) {
@@ -1143,7 +1161,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int t = tid * PER + i;
-      if (t < nent && flg[i]) {
+      if (t < nent && flg.get(i)) {
         bo_rows[scanb[t]] = cntd[t];
         lrow[scanb[t]] = cntd[t];
         bo_ptr[scanb[t]] = t;
@@ -1177,8 +1195,9 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   // dof <- element-slot gathers, ascending slots: count, scan, unordered fill and per-dof sort of the (short) lists in an
   // LDS staging array (slot ids fit 16 bits), then one coalesced copy out.  (Filling and insertion-sorting the lists
   // in global memory was 78 k cycles of dependent L2 round trips for the two lists.)
-  uint16_t* stage = reinterpret_cast<uint16_t*>(R);          // [nl * nt] <= 6 TNT entries = 24 KB (blist .. cntd are dead)
-  static_assert(6 * TNT * 2 <= RSEG + (TNP + 8) * 4, "gather staging fits in front of `fill`");
+  using stage_t = typename CP::stage_t;
+  stage_t* stage = K > 4 ? reinterpret_cast<stage_t*>(smem + CP::BASE) : reinterpret_cast<stage_t*>(R);   // [nl * nt] <= 6 TNT entries = 24 KB (blist .. cntd are dead)
+  static_assert(K > 4 || 6 * TNT * 2 <= RSEG + (TNP + 8) * 4, "gather staging fits in front of `fill`");
   auto gather = [&](int nl, int ndof, int32_t* gptr, int32_t* gsrc) {
     for (int i = tid; i < TNS; i += TW) scanb[i] = 0;
     __syncthreads();
@@ -1195,13 +1214,13 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     for (int i = 0; i < nl; ++i)
       for (int t = tid; t < nt; t += TW) {
         const int dof = cd[i * D.NT + t];
-        stage[scanb[dof] + atomicAdd(&fill[dof], 1)] = (uint16_t)(t * nl + i);   // slot = t * nl + i
+        stage[scanb[dof] + atomicAdd(&fill[dof], 1)] = (stage_t)(t * nl + i);   // slot = t * nl + i
       }
     __syncthreads();
     for (int i = tid; i < ndof; i += TW) {
       const int q0 = scanb[i], q1 = q0 + fill[i];
       for (int a_ = q0 + 1; a_ < q1; ++a_) {
-        const uint16_t w = stage[a_];
+        const stage_t w = stage[a_];
         int j = a_ - 1;
         while (j >= q0 && stage[j] > w) {
           stage[j + 1] = stage[j];
@@ -1312,7 +1331,9 @@ extern "C" int64_t mdq_env_topology_workspace_bytes(const mdq_env_topo_desc* d) 
   if (!d || d->B <= 0) return 0;
   if (d->NV <= mdq_topo::TNV && d->NT <= mdq_topo::TNT && d->NP <= mdq_topo::TNP) return 0;     // every table in LDS
   using C4 = mdq_topo::TCap<4>;
-  if (d->NV > C4::NV || d->NT > C4::NT || d->NP > C4::NP) return -1;                             // beyond the kernels
+  using C16 = mdq_topo::TCap<16>;
+  if (d->NV > C16::NV || d->NT > C16::NT || d->NP > C16::NP) return -1;                          // beyond the kernels
+  if (d->NV > C4::NV || d->NT > C4::NT || d->NP > C4::NP) return (int64_t)((C16::BYTES + 255) & ~(size_t)255) * d->B;
   return (int64_t)((C4::BYTES + 255) & ~(size_t)255) * d->B;
 }
 
@@ -1332,8 +1353,10 @@ extern "C" int mdq_env_topology(const mdq_env_topo_desc* d, void* stream, int32_
                        d->ipcs ? 1 : 0, status, nullptr, h);
   } else {
     using C4 = mdq_topo::TCap<4>;
-    if (d->NV > C4::NV || d->NT > C4::NT || d->NP > C4::NP)
-      return mdq_set_error("mdq_env_topology: capacity above 4096 vertices / 8192 triangles / 16384 P2 dofs");
+    using C16 = mdq_topo::TCap<16>;
+    if (d->NV > C16::NV || d->NT > C16::NT || d->NP > C16::NP)
+      return mdq_set_error("mdq_env_topology: capacity above 16384 vertices / 32768 triangles / 65536 P2 dofs");
+    const bool huge = d->NV > C4::NV || d->NT > C4::NT || d->NP > C4::NP;
     // the large-mesh instance: tables in the CALLER's workspace (global memory, one slab per mesh)
     if (!d->workspace || d->workspace_bytes < mdq_env_topology_workspace_bytes(d) || (reinterpret_cast<uintptr_t>(d->workspace) & 15))
       return mdq_set_error("mdq_env_topology: workspace missing, too small or not 16-byte aligned (mdq_env_topology_workspace_bytes)");
@@ -1342,6 +1365,15 @@ extern "C" int mdq_env_topology(const mdq_env_topo_desc* d, void* stream, int32_
     static const hipError_t attr4 = hipFuncSetAttribute(reinterpret_cast<const void*>(&mdq_topo::topology_kernel<4>),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
     if (attr4 != hipSuccess) return mdq_set_error("hipFuncSetAttribute(topology_kernel<4>) failed");
+    if (huge) {
+      // the 16 384-vertex instance (round 6): every table incl. the edge hash and the coordinates on the slab; the LDS keeps the
+      // small tables of the K = 4 layout (upper 64 KB .. 128 KB: polygon tables, hash sets of the boundary values, histograms)
+      static const hipError_t attr16 = hipFuncSetAttribute(reinterpret_cast<const void*>(&mdq_topo::topology_kernel<16>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+      if (attr16 != hipSuccess) return mdq_set_error("hipFuncSetAttribute(topology_kernel<16>) failed");
+      hipLaunchKernelGGL(mdq_topo::topology_kernel<16>, dim3(d->B), dim3(mdq_topo::TW), lds4, (hipStream_t)stream, *d, o,
+                         d->ipcs ? 1 : 0, status, slab, h);
+    } else
     hipLaunchKernelGGL(mdq_topo::topology_kernel<4>, dim3(d->B), dim3(mdq_topo::TW), lds4, (hipStream_t)stream, *d, o,
                        d->ipcs ? 1 : 0, status, slab, h);
   }

@@ -435,7 +435,7 @@ class DeviceTopologyBatch:
         # the tables of the large-mesh kernel instance: this engine's own workspace (engines on different streams never share)
         nb = int(self.lib.mdq_env_topology_workspace_bytes(C.byref(d)))
         if nb < 0:
-            raise _lib.MeshDQNHipError("mdq_env_topology: capacity above 4096 vertices / 8192 triangles / 16384 P2 dofs")
+            raise _lib.MeshDQNHipError("mdq_env_topology: capacity above 16384 vertices / 32768 triangles / 65536 P2 dofs")
         self.workspace = torch.empty(nb, dtype=torch.uint8, device=dev) if nb else None
         d.workspace, d.workspace_bytes = (self.workspace.data_ptr() if nb else None), nb
         self.desc = d

@@ -285,6 +285,47 @@ def test_host_remesh_equals_scipy_delaunay_on_the_red_refined_mesh(meshes, lib_b
     assert n_mid >= 16
 
 
+def test_host_remesh_equals_scipy_delaunay_on_the_twice_refined_mesh(meshes, lib_built):
+    """ys930 red-refined TWICE (12 924 vertices / 25 120 triangles: the only member of the family beyond BASELINE configs[4]'s
+    "~8k-tri"): the C++ engine - the twin `mdq_remesh`'s 16 384-vertex instance is tested against on the GPU - equals the
+    reference's global Qhull Delaunay + all-boundary filter (Env2DAirfoil.py:452-512) over 24 consecutive removals: vertices of
+    all three generations (original, first and second refinement), every third pick near the airfoil; set equality of the cells."""
+    from meshdqn_amd.ipcs_batch import smooth_coords
+    from meshdqn_amd.mesh_ops import red_refine, remesh_batch
+    coords, cells = meshes["ys930"]
+    rc, rcells = red_refine(smooth_coords(MeshTopology(coords, cells), 50), cells)
+    rc, rcells = red_refine(rc, rcells)
+    t0 = MeshTopology(rc, rcells)
+    assert (t0.nv, t0.nt) == (12924, 25120)
+    x = smooth_coords(t0, 50)
+    c = np.sort(rcells, axis=1).astype(np.int32)
+    hc = np.zeros((1, t0.nv, 2)); hc[0] = x
+    ht = np.zeros((1, t0.nt, 3), np.int32); ht[0] = c
+    nv = np.array([t0.nv], np.int32); nt = np.array([t0.nt], np.int32)
+    rng = np.random.default_rng(9)
+    ref_x, ref_c = x.copy(), c.copy()
+    picked = []
+    for step in range(24):
+        t = MeshTopology(ref_x, ref_c)
+        interior = np.flatnonzero(~t.on_boundary)
+        if step % 3 == 2:                              # near the airfoil
+            af = np.flatnonzero(t.on_boundary & (np.abs(ref_x[:, 1]) < 0.45) & (ref_x[:, 0] > -0.45) & (ref_x[:, 0] < 2.9))
+            d = np.min(np.linalg.norm(ref_x[interior][:, None] - ref_x[af][None], axis=2), axis=1)
+            cand = interior[np.argsort(d)[:120]]
+        else:                                          # one of the three generations in turn (ids shift down as vertices go)
+            lo, hi = [(0, 800), (900, 3200), (3400, len(ref_x))][step % 3 if step % 3 < 2 else 0] if step % 2 else (3400, len(ref_x))
+            cand = interior[(interior >= lo) & (interior < hi)]
+        idx = int(rng.choice(cand))
+        picked.append(idx)
+        st = remesh_batch(hc, ht, nv, nt, np.array([idx], np.int32), 0, 1)
+        assert st[0] == 0
+        ref_x, ref_c = _scipy_remove(ref_x, ref_c, idx)
+        assert (nv[0], nt[0]) == (len(ref_x), len(ref_c))
+        assert {tuple(r) for r in ht[0, :nt[0]].tolist()} == {tuple(r) for r in ref_c.tolist()}, (step, idx)
+        assert np.array_equal(hc[0, :nv[0]], ref_x)
+    assert min(picked) < 900 and max(picked) > 3400
+
+
 def test_host_engine_is_thread_safe(meshes, lib_built):
     """Concurrent callers (the env groups of VecEnvGroups) share one worker pool: results equal the sequential ones."""
     import threading

@@ -268,7 +268,10 @@ def test_large_mesh_entry_points_use_the_callers_workspace_only(lib_built, meshe
     t0, x0 = _refined(meshes)
     NV, NT = t0.nv, t0.nt
     assert lib.mdq_remesh_workspace_bytes(4, 876, 1570) == 0 and lib.mdq_smooth_workspace_bytes(4, 876, 1570) == 0
-    assert lib.mdq_remesh_workspace_bytes(4, 5000, 9000) == -1 and lib.mdq_smooth_workspace_bytes(4, 5000, 9000) == -1
+    # (mdq_remesh: 16 384 vertices since round 6 - the hash on the slab too; topology and smoothing: 4 096)
+    assert lib.mdq_remesh_workspace_bytes(4, 5000, 9000) > 4 * 2_000_000 and lib.mdq_remesh_workspace_bytes(4, 17000, 9000) == -1
+    assert lib.mdq_remesh_workspace_bytes(4, 5000, 33000) == -1 and lib.mdq_smooth_workspace_bytes(4, 5000, 9000) > 4 * 2_000_000
+    assert lib.mdq_smooth_workspace_bytes(4, 17000, 9000) == -1 and lib.mdq_smooth_fast_workspace_bytes(4, 17000) == -1
     tags = t0.facet_tags(x0)
     polygon = x0[[v for v in range(t0.nv) if t0.on_boundary[v] and -0.5 < x0[v, 0] < 3 and -0.5 < x0[v, 1] < 0.5]]
     interior = np.flatnonzero(~t0.on_boundary)
@@ -708,3 +711,134 @@ def test_flow_cell_sort_is_a_permutation_along_the_morton_curve(lib_built):
                 return max(len(np.unique(tp.cell_dofs[k:k + 1024])) for k in range(0, n, 1024))
             before, after = touched(t), touched(sc[b, :n])
             assert before > VecEnv2DAirfoil.FLOW_NRL > 3200 > after, (before, after)
+
+
+def test_twice_refined_mesh_removal_matches_the_host_engine(lib_built, meshes):
+    """`mdq_remesh` and `mdq_smooth_fast` beyond 4 096 vertices (round 6: the 16 384-vertex instances - every table incl. the
+    131 072-slot edge hash, the positions and the level array of the smoothing on the caller's slab) on ys930 red-refined twice
+    (12 924 vertices / 25 120 triangles): 10 consecutive removals on 2 meshes with different action streams (one "do nothing", one
+    boundary vertex), smooth(50) after every third one, against the C++ twins, which the CPU suite holds to scipy / Qhull on this
+    very mesh: cells as a set, counts, failure codes, coordinates to 1e-12."""
+    from meshdqn_amd.ipcs_batch import smooth_coords
+    from meshdqn_amd.mesh_ops import red_refine, remesh_batch, remesh_batch_gpu, smooth_batch_gpu
+    from meshdqn_amd.topology import MeshTopology
+    coords, cells = meshes["ys930"]
+    rc, rcells = red_refine(smooth_coords(MeshTopology(coords, cells), 50), cells)
+    rc, rcells = red_refine(rc, rcells)
+    t0 = MeshTopology(rc, rcells)
+    assert (t0.nv, t0.nt) == (12924, 25120)
+    x0 = smooth_coords(t0, 50)
+    B, NV, NT = 2, t0.nv, t0.nt
+    hc = np.repeat(x0[None], B, 0).copy()
+    ht = np.repeat(np.sort(t0.cells, axis=1)[None].astype(np.int32), B, 0).copy()
+    hnv = np.full(B, NV, np.int32); hnt = np.full(B, NT, np.int32)
+    dc, dtri = torch.from_numpy(hc).cuda(), torch.from_numpy(ht).cuda()
+    dnv, dnt = torch.from_numpy(hnv).cuda(), torch.from_numpy(hnt).cuda()
+    dst = torch.zeros(B, dtype=torch.int32, device="cuda")
+    rng = np.random.default_rng(13)
+    interior0 = np.flatnonzero(~t0.on_boundary)
+    for step in range(10):
+        rem = np.empty(B, np.int32)
+        for b in range(B):
+            # (an interior vertex of the ORIGINAL numbering that is still interior: the ids shift down by at most `step`)
+            t = MeshTopology(hc[b, :hnv[b]], ht[b, :hnt[b]])
+            rem[b] = rng.choice(np.flatnonzero(~t.on_boundary))
+        if step == 3:
+            rem[1] = -1
+        if step == 5:
+            rem[0] = 0                        # a boundary vertex: refused, mesh untouched
+        sweeps = 50 if step % 3 == 0 else 0        # (every third removal is followed by smooth(50), as the env step does)
+        hst = remesh_batch(hc, ht, hnv, hnt, rem, sweeps, 2)
+        drem = torch.from_numpy(rem).cuda()
+        remesh_batch_gpu(dc, dtri, dnv, dnt, drem, dst)
+        if sweeps:
+            smooth_batch_gpu(dc, dtri, dnv, dnt, torch.where((drem >= 0) & (dst == 0), sweeps, 0).to(torch.int32))
+        torch.cuda.synchronize()
+        assert np.array_equal(dst.cpu().numpy() != 0, hst != 0), (step, dst.cpu().numpy(), hst)
+        assert np.array_equal(dnv.cpu().numpy(), hnv) and np.array_equal(dnt.cpu().numpy(), hnt)
+        gc, gt = dc.cpu().numpy(), dtri.cpu().numpy()
+        for b in range(B):
+            assert {tuple(r) for r in gt[b, :hnt[b]].tolist()} == {tuple(r) for r in ht[b, :hnt[b]].tolist()}, (step, b)
+            assert np.abs(gc[b, :hnv[b]] - hc[b, :hnv[b]]).max() < 1e-12, (step, b)
+    assert hnv.tolist() == [NV - 9, NV - 9] and interior0.size > 12000
+
+
+def _twice_refined(meshes):
+    from meshdqn_amd.ipcs_batch import smooth_coords
+    from meshdqn_amd.mesh_ops import red_refine
+    from meshdqn_amd.topology import MeshTopology
+    coords, cells = meshes["ys930"]
+    rc, rcells = red_refine(smooth_coords(MeshTopology(coords, cells), 50), cells)
+    rc, rcells = red_refine(rc, rcells)
+    t = MeshTopology(rc, rcells)
+    assert (t.nv, t.nt) == (12924, 25120)
+    return t, smooth_coords(t, 50)
+
+
+@pytest.mark.parametrize("ipcs", [False, True])
+def test_twice_refined_mesh_topology_engine_is_bit_identical_to_host_engine(lib_built, meshes, ipcs):
+    """`mdq_env_topology` beyond 4 096 vertices (round 6: the 16 384-vertex instance - every table incl. the edge hash and the
+    coordinates on the caller's slab, 32-bit owner slots and slot lists) on ys930 red-refined twice (12 924 vertices, 38 043
+    edges), after removals, with a shifted window: every output array of the S1 step (edges, dof map, points, airfoil facets,
+    removable vertices, N-closest window, state graph) and, with `ipcs`, the index data of the matrix-free IPCS path (flags,
+    outflow entries, dof <- slot lists, SELL pattern) against `mdq_env_topology_host`, bit for bit."""
+    from meshdqn_amd.mesh_ops import DeviceTopologyBatch, HostTopologyBatch, remesh_batch
+    t0, x0 = _twice_refined(meshes)
+    tags = t0.facet_tags(x0)
+    # (the state polygon: the ORIGINAL airfoil vertices - 182 boundary vertices of ys930 minus the box - as the env passes it)
+    coords0, cells0 = meshes["ys930"]
+    from meshdqn_amd.topology import MeshTopology
+    tb = MeshTopology(coords0, cells0)
+    polygon = x0[[v for v in range(tb.nv) if tb.on_boundary[v] and -0.5 < x0[v, 0] < 3 and -0.5 < x0[v, 1] < 0.5]]
+    assert 50 < len(polygon) <= 256
+    B = 2
+    nbo_cap = 2 * (2 * int((tags == 3).sum()) + 1)
+    args = (B, t0.nv, t0.nt, t0.ne, int((tags == 1).sum()), 180, 1536, polygon)
+    kw = dict(ipcs=True, nbo_cap=nbo_cap) if ipcs else dict(ipcs=False)
+    hb = HostTopologyBatch(*args, **kw)
+    for b in range(B):
+        hb.coords[b], hb.cells[b], hb.nv[b], hb.nt[b] = x0, np.sort(t0.cells, axis=1), t0.nv, t0.nt
+    interior = np.flatnonzero(~t0.on_boundary)
+    for rnd in range(2):
+        rem = np.array([-1 if rnd == 0 else interior[5000], interior[40 + 7 * rnd]], np.int32)
+        assert (remesh_batch(hb.coords, hb.cells, hb.nv, hb.nt, rem, 0, 2) == 0).all()
+    hb.offset[:] = [0, 3]
+    hb.run(2)
+    if ipcs:
+        kw["nse1_cap"] = hb.NSE1
+    db = DeviceTopologyBatch(*args, device="cuda", **kw)
+    assert db.workspace is not None and db.workspace.numel() > 2 * 3_000_000
+    db.coords.copy_(torch.from_numpy(hb.coords)); db.cells.copy_(torch.from_numpy(hb.cells))
+    db.nv.copy_(torch.from_numpy(hb.nv)); db.nt.copy_(torch.from_numpy(hb.nt)); db.offset.copy_(torch.from_numpy(hb.offset))
+    db.run()
+    torch.cuda.synchronize()
+    g = {k: v.cpu().numpy() for k, v in db.t.items()}
+    for b in range(B):
+        nv, nt, ne = int(hb.nv[b]), int(hb.nt[b]), int(hb.h["ne"][b])
+        n2 = nv + ne
+        assert ne > 38000
+        for k in ("ne", "naf", "nremovable", "nsel", "nedges"):
+            assert g[k][b] == hb.h[k][b], (k, b)
+        naf, nE = int(hb.h["naf"][b]), int(hb.h["nedges"][b])
+        assert np.array_equal(g["cell_dofs"][b][:, :nt], hb.h["cell_dofs"][b][:, :nt])
+        assert np.array_equal(g["points"][b][:n2], hb.h["points"][b][:n2])                 # bitwise
+        assert np.array_equal(g["af_facets"][b][:naf], hb.h["af_facets"][b][:naf])
+        assert np.array_equal(g["n_closest"][b], hb.h["n_closest"][b])
+        assert np.array_equal(g["coord_map"][b], hb.h["coord_map"][b])
+        for k in ("edge_src", "edge_dst", "edge_len"):
+            assert np.array_equal(g[k][b][:nE], hb.h[k][b][:nE]), (k, b)
+    if ipcs:
+        gi = {k: v.cpu().numpy() for k, v in db.ti.items()}
+        hi = hb.hi
+        for b in range(B):
+            nv, nt, ne = int(hb.nv[b]), int(hb.nt[b]), int(hb.h["ne"][b])
+            n2 = nv + ne
+            assert gi["nbo"][b] == hi["nbo"][b] and hi["nbo"][b] > 20
+            nbo = int(hi["nbo"][b])
+            nbe = int(hi["bo_ptr"][b][nbo])
+            checks = dict(cell_outflow=nt, bcu_flag=n2, bcu_gx=n2, bcp_flag=nv, bo_rows=nbo, bo_ptr=nbo + 1, bo_col=nbe,
+                          bo_src=nbe, g1_ptr=nv + 1, g1_src=3 * nt, g2_ptr=n2 + 1, g2_src=6 * nt, sl1_off=(nv + 63) // 64 + 1)
+            for k, n in checks.items():
+                assert np.array_equal(gi[k][b][:n], hi[k][b][:n]), (k, b)
+            nse = int(hi["sl1_off"][b][(nv + 63) // 64])
+            assert np.array_equal(gi["sl1_col"][b][:nse], hi["sl1_col"][b][:nse])
