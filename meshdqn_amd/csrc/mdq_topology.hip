@@ -50,7 +50,7 @@ struct Flags {
 };
 constexpr int TNV = TCap<1>::NV, TNT = TCap<1>::NT, TNP = TCap<1>::NP;     // (the K = 1 capacities: host-side checks)
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
-constexpr int TNPOLY = 256;
+constexpr int TNPOLY = 256;            // polygon points of the K = 1 / 4 instances (K = 16: 512, `TPOLY` in the kernel)
 
 // exclusive scan of a[0..n) in place (n <= PER * TW), returns the total; `part` = TW ints of scratch
 template <int PER>
@@ -139,6 +139,12 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   constexpr int TNV = CP::NV, TNE = CP::NE, TNP = CP::NP, TNS = CP::NS, HSZ = CP::HS, PER = CP::PER;
   constexpr int TNT = CP::NT;
   (void)TNT;
+  // polygon points: 256 (the airfoil of the lab meshes and of their first refinement); the 16 384-vertex instance 512 (the
+  // twice-refined ys930 carries ~480): segment ids of the candidate queue in 16 bits, group masks of 128 bits, 128 groups
+  constexpr int TPOLY = K > 4 ? 512 : TNPOLY, NGMAX = TPOLY / 4;
+  using cq_t = typename std::conditional<(K > 4), unsigned long long, uint32_t>::type;
+  using fm_t = typename std::conditional<(K > 4), unsigned __int128, unsigned long long>::type;
+  constexpr int CQB = K > 4 ? 16 : 8;
   // K = 4 (round 5): the EDGE HASH lives in LDS - 16 384 slots x (key, value) = 128 KB, load <= 0.75 at the capacity of 12 288
   // edges - and, once the edge phase is over, the same LDS holds the vertex COORDINATES (64 KB): the hash inserts / probes
   // (atomics and dependent reads on the slab: an L2 round trip each) were 47 % of the large-mesh instance and the coordinate
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   int* misc = part + TW;                                                      // [16]
   // region R after the edge phase
   unsigned char* R = smem + 16 * TNV;
-  constexpr int RPOLY = 16 * TNV, RSEG = RPOLY + 16 * TNPOLY;                // (K = 1: 16384 / 20480)
+  constexpr int RPOLY = 16 * TNV, RSEG = RPOLY + 16 * TPOLY;                 // (K = 1: 16384 / 20480)
   uint16_t* blist = reinterpret_cast<uint16_t*>(R);                           // [TNV] boundary vertices
   uint16_t* remv = blist + TNV;                                               // [TNV] removable vertices (ascending)
   uint16_t* order = remv + TNV;                                               // [TNV]
@@ -176,9 +182,10 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   double* dist = K == 4 ? reinterpret_cast<double*>(lds_ + 65536 + 28672) : reinterpret_cast<double*>(R + 8 * TNV);   // [TNV]  (K = 16: on the slab)
   // (K = 4: the polygon and the small tables of the distance section - 16 KB that every vertex gathers from - sit in the upper
   //  half of the LDS, free once the edge hash is dead; the coordinates take the lower half)
-  unsigned char* PB = K == 1 ? R + RPOLY : lds_ + 65536;                      // poly | segf | segr | ye | pmx
-  unsigned char* GB = K == 1 ? nullptr : lds_ + 65536 + 16384;                // grp | yrange | chf | chr   (K = 1: in R2, below)
-  double2* poly = reinterpret_cast<double2*>(PB);                             // [TNPOLY]
+  // (K = 16: the lower half of the LDS is free - hash and coordinates are on the slab -: the polygon tables, twice as large, there)
+  unsigned char* PB = K == 1 ? R + RPOLY : (K == 4 ? lds_ + 65536 : lds_);    // poly | segf | segr | ye | pmx
+  unsigned char* GB = K == 1 ? nullptr : (K == 4 ? lds_ + 65536 + 16384 : lds_ + 32768);   // grp | yrange | chf | chr   (K = 1: in R2, below)
+  double2* poly = reinterpret_cast<double2*>(PB);                             // [TPOLY]
   int* cntd = reinterpret_cast<int*>(R + RSEG);                               // [TNP + 1] counts / pointers (IPCS phase)
   int* fill = cntd + TNP + 8;                                                 // [TNP]
 
@@ -569,18 +576,18 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
   const int NG = (np_ + 3) >> 2;                                              // groups of 4 segments (<= 64)
   const int NW = (np_ + 31) >> 5;                                             // 32-segment words (<= 8)
   const int NSEG = 32 * NW;                                                   // <= TNPOLY
-  float4* segf = reinterpret_cast<float4*>(PB + 16 * TNPOLY);                 // [NSEG] {ax, ay, bx - ax, by - ay}   (K = 1: R + RSEG)
-  float* segr = reinterpret_cast<float*>(PB + 16 * TNPOLY + TNPOLY * 16);     // [NSEG] 1 / |b - a|^2
-  double* ye = reinterpret_cast<double*>(PB + 16 * TNPOLY + TNPOLY * 20);     // [NSEG + 1] y of polygon vertex i (closed)
-  float* pmx = reinterpret_cast<float*>(ye + TNPOLY + 2);                     // [TW / 64] wave maxima of |polygon coordinate|
+  float4* segf = reinterpret_cast<float4*>(PB + 16 * TPOLY);                  // [NSEG] {ax, ay, bx - ax, by - ay}   (K = 1: R + RSEG)
+  float* segr = reinterpret_cast<float*>(PB + 16 * TPOLY + TPOLY * 16);       // [NSEG] 1 / |b - a|^2
+  double* ye = reinterpret_cast<double*>(PB + 16 * TPOLY + TPOLY * 20);       // [NSEG + 1] y of polygon vertex i (closed)
+  float* pmx = reinterpret_cast<float*>(ye + TPOLY + 2);                      // [TW / 64] wave maxima of |polygon coordinate|
   unsigned char* R2 = R + 8 * HSZ - 16 * 1024 * K;                            // (the look-up tables of the section above are dead)
   uint16_t* sorder = reinterpret_cast<uint16_t*>(R2 + 4 * TNV);               // [TNV] removable vertices by (band, home)
   uint8_t* keyv = reinterpret_cast<uint8_t*>(R2 + 6 * TNV);                   // [TNV] sort key
   unsigned char* G2 = K == 1 ? R2 + 8 * TNV : GB;
-  float4* grp = reinterpret_cast<float4*>(G2);                                // [64] {cx, cy, radius, -}
-  double* yrange = reinterpret_cast<double*>(G2 + 1024);                      // [4 * TW / 64] wave minima / maxima of the polygon's y, x
-  float4* chf = reinterpret_cast<float4*>(G2 + 1024 + 512);                   // [64] group chord {ax, ay, bx - ax, by - ay}
-  float2* chr = reinterpret_cast<float2*>(G2 + 1024 + 512 + 1024);            // [64] {1 / |chord|^2, deviation of the group's polyline from it}
+  float4* grp = reinterpret_cast<float4*>(G2);                                // [NGMAX] {cx, cy, radius, -}
+  double* yrange = reinterpret_cast<double*>(G2 + 16 * NGMAX);                // [4 * TW / 64] wave minima / maxima of the polygon's y, x
+  float4* chf = reinterpret_cast<float4*>(G2 + 16 * NGMAX + 512);             // [NGMAX] group chord {ax, ay, bx - ax, by - ay}
+  float2* chr = reinterpret_cast<float2*>(G2 + 16 * NGMAX + 512 + 16 * NGMAX);   // [NGMAX] {1 / |chord|^2, deviation of the group's polyline from it}
   int* hist = K == 1 ? scanb : reinterpret_cast<int*>(lds_ + 65536 + 20480);  // [128]
   {
     float m = 0.f;
@@ -620,7 +627,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
       yrange[2 * (TW / 64) + (tid >> 6)] = x0_;
       yrange[3 * (TW / 64) + (tid >> 6)] = x1_;
     }
-    for (int i = tid; i < 128; i += TW) hist[i] = 0;
+    for (int i = tid; i < 2 * NGMAX; i += TW) hist[i] = 0;
   }
   __syncthreads();
   float mpoly = 0.f;
@@ -707,14 +714,14 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
         home = g;
       }
     }
-    const int key = ((py >= ylo && py < yhi && px >= xlo - xmg && px <= xhi + xmg) ? 64 : 0) + home;
+    const int key = ((py >= ylo && py < yhi && px >= xlo - xmg && px <= xhi + xmg) ? NGMAX : 0) + home;
     keyv[r] = (uint8_t)key;
     atomicAdd(&hist[key], 1);
   }
   __syncthreads();
   TT_STAMP(7)
   // (C) counting sort by key (any order inside a key: the vertices are independent of each other)
-  scan_excl(hist, 128, part);
+  scan_excl(hist, 2 * NGMAX, part);
   __syncthreads();
   for (int r = tid; r < nrem; r += TW) sorder[atomicAdd(&hist[keyv[r]], 1)] = (uint16_t)r;
   __syncthreads();
@@ -732,14 +739,14 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     // candidate queue: up to four segment ids, a byte each (np_ <= 256); a vertex with a fifth candidate (never seen on the
     // lab meshes) is evaluated against every segment instead.  The exact evaluations then take max-over-lanes(candidates)
     // rounds per wave instead of a sum of per-word maxima
-    uint32_t cq = 0u;
+    cq_t cq = 0u;
     int cn = 0;
     bool ovf = false;
     auto push = [&](int id, bool c) {
       if (c) {
         if (cn == 4) ovf = true;
         else {
-          cq |= (uint32_t)id << (8 * cn);
+          cq |= (cq_t)id << (CQB * cn);
           ++cn;
         }
       }
@@ -748,7 +755,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     int gi[3];
     float amin = 3.0e38f;
     {
-      const int home = keyv[r] & 63;
+      const int home = keyv[r] & (NGMAX - 1);
 #pragma unroll
       for (int dg = 0; dg < 3; ++dg) {
         int g = home + dg - 1;
@@ -762,7 +769,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     // FOREIGN groups within reach of U (bit g): the home neighbourhood can miss the nearest segment - the circle centres
     // are a heuristic, and near the trailing edge the other surface is as close.  Rare: the group loops below are
     // wave-uniform and skip a group no lane of the wave needs.
-    unsigned long long fm = 0ull;
+    fm_t fm = 0;
     {
       // (the chord test, not the bounding circle: at a distance comparable to a group's size the circle of nearly every
       //  neighbour is within reach - 11 of 12 waves ran the foreign loops, 28 k cycles; 2 eta: the estimate's error twice,
@@ -777,13 +784,13 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
         const float ex = wx - t * sg.z, ey = wy - t * sg.w;
         const float reach = Ue + cr.y;                                    // (dist(p, chord) - deviation <= U + 2 eta, squared)
         const bool q = live && (ex * ex + ey * ey <= reach * reach * 1.000001f) && g != gi[0] && g != gi[1] && g != gi[2];
-        fm |= (unsigned long long)(q ? 1 : 0) << g;
+        fm |= (fm_t)(q ? 1 : 0) << g;
       }
     }
-    const bool foreign = __any(fm != 0ull);
+    const bool foreign = __any(fm != 0);
     if (foreign) {
       for (int g = 0; g < NG; ++g) {
-        const bool q = (fm >> g) & 1ull;
+        const bool q = (bool)((fm >> g) & 1);
         if (__any(q)) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
@@ -808,7 +815,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
     if (foreign) {
       const float Ue = U2 + 2.0f * eta;
       for (int g = 0; g < NG; ++g) {
-        if (!__any((fm >> g) & 1ull)) continue;
+        if (!__any((bool)((fm >> g) & 1))) continue;
         const float4 sg = chf[g];
         const float2 cr = chr[g];
         const float wx = pxf - sg.x, wy = pyf - sg.y;
@@ -816,7 +823,7 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
         t = fminf(fmaxf(t, 0.f), 1.f);
         const float ex = wx - t * sg.z, ey = wy - t * sg.w;
         const float reach = Ue + cr.y;
-        const bool q = ((fm >> g) & 1ull) && (ex * ex + ey * ey <= reach * reach * 1.000001f);
+        const bool q = (bool)((fm >> g) & 1) && (ex * ex + ey * ey <= reach * reach * 1.000001f);
         if (__any(q)) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
@@ -835,8 +842,8 @@ __global__ __launch_bounds__(TW) void topology_kernel(mdq_env_topo_desc D, mdq_i
         if (!__any(qrun || (anyovf && orun))) break;
         int i = it;
         if (qrun) {
-          i = (int)(cq & 255u);
-          cq >>= 8;
+          i = (int)(cq & (cq_t)((1u << CQB) - 1u));
+          cq >>= CQB;
           --cn;
         } else {
           ++it;
@@ -1339,7 +1346,12 @@ extern "C" int64_t mdq_env_topology_workspace_bytes(const mdq_env_topo_desc* d) 
 
 extern "C" int mdq_env_topology(const mdq_env_topo_desc* d, void* stream, int32_t* status) {
   if (!d || d->B <= 0 || !status) return mdq_set_error("mdq_env_topology: bad arguments");
-  if (d->npoly > mdq_topo::TNPOLY) return mdq_set_error("mdq_env_topology: more than 256 polygon points");
+  {
+    using C4_ = mdq_topo::TCap<4>;
+    const bool huge_ = d->NV > C4_::NV || d->NT > C4_::NT || d->NP > C4_::NP;
+    if (d->npoly > (huge_ ? 2 : 1) * mdq_topo::TNPOLY)
+      return mdq_set_error("mdq_env_topology: more than 256 polygon points (512 for the 16384-vertex instance)");
+  }
   mdq_ipcs_topo_out o = {};
   if (d->ipcs) o = *d->ipcs;
   mdq_topo_handover h = {};

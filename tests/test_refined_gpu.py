@@ -842,3 +842,65 @@ def test_twice_refined_mesh_topology_engine_is_bit_identical_to_host_engine(lib_
                 assert np.array_equal(gi[k][b][:n], hi[k][b][:n]), (k, b)
             nse = int(hi["sl1_off"][b][(nv + 63) // 64])
             assert np.array_equal(gi["sl1_col"][b][:nse], hi["sl1_col"][b][:nse])
+
+
+@pytest.mark.slow
+def test_vec_env_steps_the_twice_refined_mesh(lib_built, meshes, tmp_path):
+    """The env step past 4 096 vertices (round 6): `VecEnv2DAirfoil` on ys930 red-refined twice (12 924 vertices / 25 120
+    triangles - the only member of the family beyond BASELINE configs[4]'s "~8k-tri"): S1 through `step()` and `rollout_device`
+    on the device engine (removal, smoothing and topology instances of 16 384 vertices) against the same class on the C++ host
+    engine - identical selections / vertex counts / edge counts / terminal flags, rewards and interpolated forces to 1e-9 -, and
+    the S3 step: one IPCS step on every coarsened mesh (index data from the large topology instance, `mdq_ipcs_setup_matfree`,
+    the element operators with global vectors and global pressure vectors) against the sparse-LU oracle on the very same mesh
+    and warm start, 1e-8."""
+    from meshdqn_amd.env import Env2DAirfoil
+    from meshdqn_amd.vec_env import VecEnv2DAirfoil
+    from oracle.ipcs import OracleFlowSolver
+    t0, _ = _twice_refined(meshes)
+    path = os.path.join(str(tmp_path), "ys930_refined2.npz")
+    np.savez(path, coords=t0.coords, cells=t0.cells)
+    cfg = dict(flow_config=dict(flow_params=dict(mu=1e-3, rho=1.0, inflow="constant"), geometry_params=dict(mesh=path),
+                                solver_params=dict(dt=0.001, solver_type="lu", smooth=True, rtol=1e-10)),
+               agent_params=dict(solver_steps=5, episodes=10, timesteps=10000, threshold=0.001, N_closest=180, gt_drag=-1,
+                                 gt_time=-1, u=-1, p=-1, time_reward=0.005, save_steps=1, goal_vertices=0.95, plot_dir=""))
+    base = Env2DAirfoil(cfg)
+    assert len(base.flow_solver.mesh.coordinates()) == 12924
+    B, K = 2, 3
+    script = np.random.default_rng(23).integers(0, 181, size=(K, B))
+    script[1, 1] = 180
+    runs = []
+    for kw in (dict(gpu_smoothing=False, gpu_topology=False, gpu_remesh=False), dict()):
+        env = VecEnv2DAirfoil(cfg, B, base_env=base, auto_reset=False, nthreads=2, **kw)
+        env.get_state()
+        out = []
+        for k in range(K):
+            st, rew, done, info = env.step(script[k])
+            out.append((info["nv"].copy(), st["coord_map"].copy(), st["nedges"].copy(), info["new_drags"].copy(), rew.copy(),
+                        done.copy(), st["x"].cpu().numpy()))
+        runs.append(out)
+    for a, r in zip(runs[1], runs[0]):
+        assert np.array_equal(a[0], r[0]) and np.array_equal(a[1], r[1]) and np.array_equal(a[2], r[2])
+        assert np.allclose(a[3], r[3], rtol=1e-9, atol=0) and np.allclose(a[4], r[4], rtol=1e-9) and np.array_equal(a[5], r[5])
+        assert np.allclose(a[6], r[6], rtol=1e-5, atol=1e-6)
+    assert (runs[1][-1][0] < 12924).all()
+    dev = VecEnv2DAirfoil(cfg, B, base_env=base, auto_reset=False, nthreads=2)
+    dev.get_state()
+    out = dev.rollout_device(None, K, actions=script)
+    for k in range(K):
+        assert np.array_equal(out["nv"][k], runs[0][k][0]) and np.array_equal(out["dones"][k], runs[0][k][5])
+        assert np.abs(out["rewards"][k] - runs[0][k][4]).max() < 1e-9
+    # S3: the flow leg on the coarsened meshes
+    venv = VecEnv2DAirfoil(cfg, B, base_env=base, auto_reset=False, nthreads=2, flow_steps=1, flow_rtol=1e-12)
+    venv.get_state()
+    st, rew, done, info = venv.step(script[0])
+    assert (venv.flow_iters.cpu().numpy() > 0).all()
+    for b in range(B):
+        nv, nt = int(venv.nv[b]), int(venv.nt[b])
+        n2 = nv + int(venv.h["ne"][b])
+        o = OracleFlowSolver(venv.coords[b, :nv].copy(), venv.cells[b, :nt].copy(), smooth=False)
+        assert o.th.np2 == n2
+        u0 = venv.u[b, venv.S - 1, :n2].cpu().numpy()
+        o.u_n = np.concatenate([u0[:, 0], u0[:, 1]])
+        o.p_n = venv.p[b, venv.S - 1, :nv].cpu().numpy().copy()
+        uo, po, do, lo = o.evolve()
+        assert abs(info["flow_drag"][b, 0] - do) < 1e-8 * abs(do) and abs(info["flow_lift"][b, 0] - lo) < 1e-8 * abs(lo), b
