@@ -217,27 +217,33 @@ def cpu_baseline(budget_s=15.0, spinup=20):
 _REFINED = {}
 
 
-def _refined_mesh_file(name):
-    """`<name>_refined`: the lab mesh red-refined once (ys930: 3 322 vertices / 6 280 triangles, BASELINE configs[4]),
-    written once per process to a temporary .npz (the environment loads meshes from files)."""
-    if name not in _REFINED:
+def _refined_mesh_file(name, levels=1):
+    """`<name>_refined`: the lab mesh red-refined once (ys930: 3 322 vertices / 6 280 triangles, BASELINE configs[4]);
+    `<name>_refined2`: twice (12 924 / 25 120: the env-step instances of 16 384 vertices) - written once per process to a
+    temporary .npz (the environment loads meshes from files)."""
+    if (name, levels) not in _REFINED:
         import tempfile
         from meshdqn_amd.ipcs_batch import smooth_coords
         from meshdqn_amd.mesh_ops import red_refine
         from meshdqn_amd.topology import MeshTopology
         z = np.load(os.path.join(ROOT, "tests", "golden", f"{name}.npz"))
         rc, rcells = red_refine(smooth_coords(MeshTopology(z["coords"], z["cells"]), 50), z["cells"])
-        fd, path = tempfile.mkstemp(prefix=f"mdq_{name}_refined_", suffix=".npz")
+        for _ in range(levels - 1):
+            rc, rcells = red_refine(rc, rcells)
+        fd, path = tempfile.mkstemp(prefix=f"mdq_{name}_refined{levels}_", suffix=".npz")
         os.close(fd)
         np.savez(path, coords=rc, cells=rcells)
-        _REFINED[name] = path
-    return _REFINED[name]
+        _REFINED[(name, levels)] = path
+    return _REFINED[(name, levels)]
 
 
 def _env_config(args, mesh=None):
     mesh = mesh or args.mesh
     steps = args.s1_solver_steps
-    if mesh.endswith("_refined"):
+    if mesh.endswith("_refined2"):
+        path = _refined_mesh_file(mesh[:-len("_refined2")], 2)
+        steps = min(steps, 20)
+    elif mesh.endswith("_refined"):
         path = _refined_mesh_file(mesh[:-len("_refined")])
         steps = min(steps, 200)        # (ground truth of a rate measurement: 5000 steps of the refined mesh take a minute)
     else:
@@ -1060,6 +1066,14 @@ def main(argv=None):
             cfgs["C5_s3_refined_mesh"] = r3
         except Exception as exc:  # noqa: BLE001
             cfgs["C5_s3_refined_mesh"] = _err(exc)
+        try:
+            rb = measure_env_steps(args, dev, None, 1, 0, steps=2, warmup=1, repeats=3, mesh=f"{args.mesh}_refined2", envs=min(B, 32))
+            rb["what"] = ("the S1 env step on the TWICE red-refined mesh (12 924 vertices / 25 120 triangles: the 16 384-vertex instances "
+                          "of the removal / smoothing / topology kernels, every table on the caller's slab - coverage, not speed), "
+                          f"{min(B, 32)} environments")
+            cfgs["C5b_s1_twice_refined"] = rb
+        except Exception as exc:  # noqa: BLE001
+            cfgs["C5b_s1_twice_refined"] = _err(exc)
         try:
             cfgs["deploy_episode_s"] = measure_deploy(args, dev)
         except Exception as exc:  # noqa: BLE001

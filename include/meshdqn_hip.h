@@ -701,7 +701,8 @@ MDQ_API int mdq_restore_rows(int32_t n, void* const* dst, const void* const* src
  * mesh: a list schedule of the sweep's dependency graph, walked by one wave out of LDS (exact sequential semantics).  coords [B][NV][2] (in/out),
  * cells [B][NT][3], nv / nt [B], iterations [B] (0 = leave that mesh alone); all device pointers.
  * Capacity: NV <= 1024, NT <= 2048 out of LDS (workspace NULL / 0); up to NV <= 4096, NT <= 8192 through the level-scheduled
- * large-mesh kernel, whose tables live in `workspace` (device, 16-byte aligned, >= mdq_smooth_workspace_bytes(B, NV, NT)).
+ * large-mesh kernel, whose tables live in `workspace` (device, 16-byte aligned, >= mdq_smooth_workspace_bytes(B, NV, NT));
+ * up to NV <= 16384, NT <= 32768 (round 6) with the positions in `workspace` as well (-1 beyond that).
  */
 MDQ_API int64_t mdq_smooth_workspace_bytes(int32_t B, int32_t NV, int32_t NT);
 MDQ_API int mdq_smooth(int32_t B, int32_t NV, int32_t NT, double* coords, const int32_t* cells, const int32_t* nv,
@@ -742,7 +743,8 @@ MDQ_API int mdq_smooth_stats(int64_t* out64, int32_t reset);
  * -1..-4 star / boundary vertex / ear clipping failures, -11 non-manifold, -12 flip work list exhausted (mesh b is
  * untouched on failure).  All pointers are device pointers.  Capacity: NV <= 1024, NT <= 2048 with every table in LDS
  * (workspace NULL / 0); up to NV <= 4096, NT <= 8192 with the tables in `workspace` (device, 16-byte aligned, at least
- * mdq_remesh_workspace_bytes(B, NV, NT) bytes: 0 for the LDS instance, -1 beyond the kernels).
+ * mdq_remesh_workspace_bytes(B, NV, NT) bytes: 0 for the LDS instance, -1 beyond the kernels) and the edge hash in LDS; up to
+ * NV <= 16384, NT <= 32768 (round 6) with the edge hash in `workspace` as well.
  */
 MDQ_API int64_t mdq_remesh_workspace_bytes(int32_t B, int32_t NV, int32_t NT);
 MDQ_API int mdq_remesh(int32_t B, int32_t NV, int32_t NT, double* coords, int32_t* cells, int32_t* nv, int32_t* nt,
@@ -837,7 +839,8 @@ MDQ_API int mdq_env_topology_host(const mdq_env_topo_desc* d, int32_t nthreads, 
  * (and of d->ipcs, a HOST struct holding device pointers) and `status` are DEVICE pointers.  All output arrays are
  * bit-identical to mdq_env_topology_host's.  Capacity: NV <= 1024, NT <= 2048, NP <= 4096 with every table in LDS; up to
  * NV <= 4096, NT <= 8192, NP <= 16384 with the tables in d->workspace (mdq_env_topology_workspace_bytes: 0 for the LDS
- * instance, -1 beyond the kernels); npoly <= 256.
+ * instance, -1 beyond the kernels), npoly <= 256; up to NV <= 16384, NT <= 32768, NP <= 65536 (round 6: every table incl.
+ * the edge hash and the coordinates in d->workspace), npoly <= 512.
  */
 MDQ_API int64_t mdq_env_topology_workspace_bytes(const mdq_env_topo_desc* d);
 MDQ_API int mdq_env_topology(const mdq_env_topo_desc* d, void* stream, int32_t* status);

@@ -62,8 +62,9 @@ def test_bench_single_rank_line(lib_built):
     ks = res["kernel_scratch"]
     # (with a private segment: the tile kernels that call the matrix-on-chip pressure solver, round 6: a `noinline` function of 256
     #  VGPRs - its callee saves, the caller's saves around the call, and one 7-row vector it keeps there; nothing inside the velocity
-    #  loops: checked by source line in the ISA.  `topology_kernel<4>`: 0 B since round 6 - 344 B in round 4, 124 B in round 5)
-    big = ("evolve_kernel<5", "evolve_team_tiles_kernel<false>")
+    #  loops: checked by source line in the ISA.  `topology_kernel<4>`: 0 B since round 6 - 344 B in round 4, 124 B in round 5;
+    #  `topology_kernel<16>`: the 16 384-vertex coverage instance, 1 024 threads at 128 VGPRs - 1 256 B, not on any timed path)
+    big = ("evolve_kernel<5", "evolve_team_tiles_kernel<false>", "topology_kernel<16>")
     assert ks["kernels"] >= 55 and all(v["scratch"] == 0 for k, v in ks["hot_kernels"].items() if not any(b in k for b in big)), ks
     assert "S3" in res["config"]["workload"] and res["config"]["krylov_iters_per_ipcs_step"]["velocity_bicgstab"] > 0
     roof = res["roofline"]
@@ -78,7 +79,7 @@ def test_bench_single_rank_line(lib_built):
     assert dep["value"] > 0 and dep["resimulated_meshes"] == 45 and dep["same_first_rows"] and dep["sequential_3_removals_s"] > 0
     assert isinstance(res["stream_setup"], list) and res["stream_setup"]
     for k in ("S1_reference_step", "S2_ipcs_step", "training_loop", "C2_s2_diverged_meshes", "C3_s3_ah93w145", "S3_full_chip",
-              "S3_refactorised_pressure", "C5_s2_refined_mesh"):
+              "S3_refactorised_pressure", "C5_s2_refined_mesh", "C5_s1_refined_mesh", "C5_s3_refined_mesh", "C5b_s1_twice_refined"):
         assert res["rates"][k].get("value", 0) > 0, (k, res["rates"][k])
     c2 = res["rates"]["C2_s2_diverged_meshes"]     # factors built on the device for every coarsened mesh: no pressure iterations
     assert c2["krylov_iters_per_step"]["pressure"] == 0 and c2["factorisation_status_ok"] and c2["factorisation_ms_per_batch"] > 0

@@ -904,3 +904,40 @@ def test_vec_env_steps_the_twice_refined_mesh(lib_built, meshes, tmp_path):
         o.p_n = venv.p[b, venv.S - 1, :nv].cpu().numpy().copy()
         uo, po, do, lo = o.evolve()
         assert abs(info["flow_drag"][b, 0] - do) < 1e-8 * abs(do) and abs(info["flow_lift"][b, 0] - lo) < 1e-8 * abs(lo), b
+
+
+@pytest.mark.slow
+def test_twice_refined_mesh_episode_matches_the_oracle(lib_built, tmp_path):
+    """ys930 red-refined twice (12 924 vertices) against an ORACLE episode (tests/golden/make_refined2_fixtures.py ->
+    oracle_stock_ys930_refined2.{json,npz}: global scipy / Qhull Delaunay + the all-boundary filter, numpy smoothing and
+    interpolation, a short oracle ground truth handed over through the snapshot-reload branch): `VecEnv2DAirfoil.step` and
+    `rollout_device` - removed vertex ids, nv / E and the whole 180-entry coord_map exact at every step, rewards <= 1e-6,
+    interpolated forces <= 1e-7, `done` equal (the episode ends on the vertex criterion at its third removal)."""
+    import json
+    from meshdqn_amd.env import Env2DAirfoil
+    from meshdqn_amd.vec_env import VecEnv2DAirfoil
+    ep = json.load(open(os.path.join(GOLDEN, "oracle_stock_ys930_refined2.json")))
+    z = np.load(os.path.join(GOLDEN, "oracle_stock_ys930_refined2.npz"))
+    cfg = _refined_cfg(ep, z, tmp_path)
+    names, assign, K, acts = _refined_script(ep, 2)            # the one episode, in two environments
+    base = Env2DAirfoil(cfg)
+    assert len(base.flow_solver.mesh.coordinates()) == 12924 and np.array_equal(base.gt_drag, z["gt_drag"])
+    steps = ep["episodes"][names[0]]["steps"]
+    assert len(steps) >= 3 and steps[-1]["done"] and steps[-1]["nv"] == 12921
+    venv = VecEnv2DAirfoil(cfg, 2, base_env=base, auto_reset=False, nthreads=2)
+    st = venv.get_state()
+    for k in range(K):
+        removed = [int(st["coord_map"][b][acts[k, b]]) for b in range(2)]
+        st, rew, done, info = venv.step(acts[k])
+        for b in range(2):
+            _check_refined(steps[k], (k, b), int(info["nv"][b]), int(st["edge_ptr"][b + 1] - st["edge_ptr"][b]), rew[b], done[b],
+                           info["new_drags"][b], info["new_lifts"][b], st["coord_map"][b].tolist(), removed[b],
+                           float(st["x"][b].double().sum()))
+    dev = VecEnv2DAirfoil(cfg, 2, base_env=base, auto_reset=False, nthreads=2)
+    dev.get_state()
+    for k in range(K):
+        out = dev.rollout_device(None, 1, actions=acts[k:k + 1])
+        for b in range(2):
+            assert out["codes"][0, b] == 0
+            _check_refined(steps[k], (k, b, "device"), int(out["nv"][0, b]), int(dev.h["nedges"][b]), out["rewards"][0, b],
+                           out["dones"][0, b], dev.new_drags[b], dev.new_lifts[b], dev.h["coord_map"][b].tolist())
