@@ -941,3 +941,41 @@ def test_twice_refined_mesh_episode_matches_the_oracle(lib_built, tmp_path):
             assert out["codes"][0, b] == 0
             _check_refined(steps[k], (k, b, "device"), int(out["nv"][0, b]), int(dev.h["nedges"][b]), out["rewards"][0, b],
                            out["dones"][0, b], dev.new_drags[b], dev.new_lifts[b], dev.h["coord_map"][b].tolist())
+
+
+@pytest.mark.slow
+def test_refined_s3_rollouts_run_whole_episodes(lib_built, tmp_path):
+    """180 device-resident S3 steps of 64 refined meshes with auto-reset (threshold 10: episodes run to the vertex criterion at
+    the 167th removal and restart in place): every flow leg builds its tile maps on the Morton-sorted private cells (no
+    environment marked, under 2 400 touched rows per chunk), the two-workgroup kernel and the on-chip pressure solve never
+    report a failed step (`rollout_end` / `flow_wait` raise on a status word or a non-finite force), iteration counts stay in
+    their band, and the episodes really end and restart."""
+    from meshdqn_amd.airfoilgcnn import NodeRemovalNet
+    from meshdqn_amd.env import Env2DAirfoil
+    from meshdqn_amd.gcn_fused import FusedGcn
+    from meshdqn_amd.vec_env import VecEnv2DAirfoil
+    ep, z = _refined_fixture()
+    cfg = _refined_cfg(ep, z, tmp_path)
+    cfg["agent_params"].update(threshold=10.0, goal_vertices=0.95)
+    B = 64
+    venv = VecEnv2DAirfoil(cfg, B, base_env=Env2DAirfoil(cfg), flow_steps=1, flow_overlap=True)
+    assert venv._flow_tile_maps
+    torch.manual_seed(0)
+    net = NodeRemovalNet(181, conv_width=128, topk=0.1)
+    net.set_num_nodes(17)
+    fused = FusedGcn(net.cuda())
+    venv.get_state()
+    rng = np.random.default_rng(1370)
+    ended = 0
+    for r0 in range(0, 180, 10):
+        ex = np.array([rng.random(B) < 0.5 for _ in range(10)])
+        ra = np.array([rng.integers(0, 181, B) for _ in range(10)])
+        out = venv.rollout_device(fused, 10, ex, ra)
+        fd, fl = venv.flow_wait()
+        it = venv.flow_iters.cpu().numpy()
+        rc = venv.flow_ts[0]["mf_rcnt"].cpu().numpy()
+        assert np.isfinite(out["rewards"]).all() and (out["codes"] == 0).all() and np.isfinite(fd).all() and np.isfinite(fl).all()
+        assert (rc[:, 0] > 0).all() and rc.max() < 2400, (r0, rc.min(), rc.max())
+        assert (it[:, 0] > 5).all() and (it[:, 0] < 40).all() and (it[:, 1] > 100).all() and (it[:, 1] < 260).all(), (r0, it.max(0))
+        ended += int(out["dones"].sum())
+    assert ended >= B and int(venv.nv.max()) > 3322 - 20           # every episode ended once and restarted
