@@ -725,6 +725,10 @@ def compact_line(res, detail_path):
     c5 = (res.get("rates") or {}).get("C5_s3_refined_mesh") or {}
     if isinstance(c5.get("krylov_iters_per_ipcs_step"), dict):
         line["c5_s3_krylov_iters"] = {k: _num(v, 4) for k, v in c5["krylov_iters_per_ipcs_step"].items()}
+    r5 = ((res.get("rates") or {}).get("C5_s2_refined_mesh") or {}).get("roofline")
+    if isinstance(r5, dict):        # the genuinely HBM-bound kernel of the path (BASELINE configs[4]): its own roofline numbers
+        line["roofline_c5_s2"] = {k: _num(r5.get(k)) for k in ("bound", "kernel", "launch_ms", "algorithmic_bytes_per_launch", "achieved",
+                                                              "peak", "unit", "frac", "traffic", "traffic_raw")}
     line["detail"] = os.path.basename(detail_path)
     return line
 
@@ -1086,6 +1090,7 @@ def main(argv=None):
             it5 = np.tile(np.array([[c5["krylov_iters_per_step"][k] for k in ("velocity_bicgstab", "pressure", "correction_cg")]]), (B, 1))
             by5 = b5.algorithmic_bytes_per_step(it5)
             c5_pmc, c5_pmc_src = pmc_entry(PMC_SUMMARY, "c5", "mdq::evolve_team_tiles_kernel<false>")
+            alg5 = b5.tile_mode_bytes_per_step(it5)       # algorithmic bytes of the element-tile kernel (one launch = one step)
             c5.update(what="C5: S2 on ys930 red-refined once (the mesh does not fit the LDS-resident modes: auto mode takes the element "
                            "tiles with GLOBAL vectors and - while two workgroups per environment fit the chip - TWO workgroups per "
                            "environment, mode 7: bitwise reproducible run to run; mode 5, one workgroup, ran here until round 5: "
@@ -1094,6 +1099,14 @@ def main(argv=None):
                       survey_csr_bytes_per_step=by5, survey_equivalent_GBs=by5 / (c5["ms_per_step"] * 1e-3) / 1e9,
                       survey_equivalent_over_hbm_peak=by5 / (c5["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                       measured_hbm_bytes_per_launch=c5_pmc, measured_hbm_source=c5_pmc_src,
+                      # the HBM-BOUND kernel of the path (evolve_team_tiles_kernel: one launch = one IPCS step of the batch)
+                      roofline=dict(bound="hbm", kernel="evolve_team_tiles_kernel<false>", launch_ms=c5["ms_per_step"],
+                                    algorithmic_bytes_per_launch=alg5, achieved=alg5 / (c5["ms_per_step"] * 1e-3) / 1e9,
+                                    peak=HBM_PEAK_GBS, unit="GB/s", frac=alg5 / (c5["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    traffic=None if not c5_pmc else c5_pmc["corrected"],
+                                    traffic_raw=None if not c5_pmc else c5_pmc["raw"],
+                                    note="launch_ms = the step time (three small launches beside it: < 1 %); algorithmic bytes: "
+                                         "IpcsBatch.tile_mode_bytes_per_step (no cache credit)"),
                       note="survey_* = the bytes an assembled-CSR implementation would stream (SURVEY 8(d) convention) over the step "
                            "time - NOT a roofline fraction of this kernel; measured_hbm_bytes_per_launch = rocprofv3 FETCH_SIZE + "
                            "WRITE_SIZE of the same kernel (profiles/" + PMC_SUMMARY + "; one launch = one step of 128 environments)")

@@ -531,6 +531,37 @@ class IpcsBatch:
             tot += napply * apply_b + per_it_vec + state + prs
         return tot
 
+    def tile_mode_bytes_per_step(self, iters_per_step) -> float:
+        """Global-memory bytes the element-tile modes (5 / 7) have to move per batch step, no cache credit - the ALGORITHMIC
+        bytes of `evolve_team_tiles_kernel` / `evolve_kernel<5>` for the roofline of BASELINE configs[4]:
+          per operator application and triangle: 6 packed local-map words + 5 geometry doubles + the outflow byte (65 B);
+          per application and touched row of a chunk (T = sum of the chunks' row lists): the list entry (8 B) + the staged input row (16 B);
+          per application and row: the accumulated result written and read once (32 B);
+          per BiCGStab iteration (two applications): 15 vector streams of 16 B per row (p, s, x, r updates and the two
+          epilogues' operands); per mass-CG iteration (one application): 8 streams;
+          per step: right-hand-side element loops (3 x 65 B per triangle + u_n / p_n gathers 112 B per triangle), state vectors
+          (u_n, p_n, u*, the history slots: 10 x 16 B per row), the pressure solve's factors (direct) or its matrix once (Krylov
+          with the matrix on the chip)."""
+        tot = 0.0
+        for b, p in enumerate(self.per):
+            nv, nt, ne = p["nv"], p["nt"], p["ne"]
+            n2 = nv + ne
+            iu, ip, im = iters_per_step[b]
+            touched = float(np.asarray(p["mf_rcnt"]).sum()) if "mf_rcnt" in p else float(6 * nt)
+            napply = 1 + 2 * iu + 1 + im                     # A x0, 2 per BiCGStab iteration, M x0, 1 per CG iteration
+            apply_b = 65.0 * nt + 24.0 * touched + 32.0 * n2
+            vec = (15.0 * iu + 8.0 * im) * 16.0 * n2
+            rhs = 3 * (65.0 + 112.0) * nt
+            state = 10 * 16.0 * n2 + 4 * 8.0 * nv
+            if getattr(self, "pds", None) is not None and self.desc.pd_enabled:
+                q = self.pds[b]
+                prs = 8.0 * (q["W"].size + q["F"].size + q["Sinv"].size + q["gk_val"].size) + 4.0 * (
+                    q["gk_col"].size + 2 * nv + q["gidx"].size)
+            else:
+                prs = 12.0 * p["colidx1"].size
+            tot += napply * apply_b + vec + rhs + state + prs
+        return tot
+
     def velocity_kernel_bytes(self, iters_per_step) -> float:
         """Global-memory bytes of ONE launch of the dominant kernel (at_velocity_kernel, mode 3) for the whole
         batch, no cache credit: per operator application 64 B of triangle metadata (6 packed words + 5 geometry

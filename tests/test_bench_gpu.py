@@ -81,6 +81,9 @@ def test_bench_single_rank_line(lib_built):
     for k in ("S1_reference_step", "S2_ipcs_step", "training_loop", "C2_s2_diverged_meshes", "C3_s3_ah93w145", "S3_full_chip",
               "S3_refactorised_pressure", "C5_s2_refined_mesh", "C5_s1_refined_mesh", "C5_s3_refined_mesh", "C5b_s1_twice_refined"):
         assert res["rates"][k].get("value", 0) > 0, (k, res["rates"][k])
+    r5 = res["rates"]["C5_s2_refined_mesh"]["roofline"]        # the HBM-bound kernel of the path: its own roofline numbers
+    assert r5["bound"] == "hbm" and "evolve_team_tiles" in r5["kernel"] and 0.05 < r5["frac"] < 1.0
+    assert abs(r5["frac"] - r5["achieved"] / r5["peak"]) < 1e-12 and r5["algorithmic_bytes_per_launch"] > 1e8
     c2 = res["rates"]["C2_s2_diverged_meshes"]     # factors built on the device for every coarsened mesh: no pressure iterations
     assert c2["krylov_iters_per_step"]["pressure"] == 0 and c2["factorisation_status_ok"] and c2["factorisation_ms_per_batch"] > 0
     assert c2["jacobi_cg_variant"]["krylov_iters_per_step"]["pressure"] > 15 and c2["value"] > c2["jacobi_cg_variant"]["value"]
